@@ -1,0 +1,41 @@
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def load_manifest():
+    with open(os.path.join(GOLDEN, "manifest.json")) as f:
+        return json.load(f)
+
+
+def load_case(name, manifest=None):
+    """Golden vectors captured from the reference's own JavaScript (oracle/gen_golden.js)."""
+    m = manifest or load_manifest()
+    d = m[name]
+    out = {"meta": d["meta"]}
+    if d["arrays"]:
+        raw = open(os.path.join(GOLDEN, name + ".bin"), "rb").read()
+        for k, a in d["arrays"].items():
+            out[k] = np.frombuffer(raw, dtype="<" + a["dtype"], count=a["count"], offset=a["offset"]).copy()
+    return out
+
+
+def cases_of(kind):
+    return sorted(k for k, v in load_manifest().items() if v["kind"] == kind)
+
+
+@pytest.fixture(scope="session")
+def manifest():
+    return load_manifest()

@@ -1,0 +1,87 @@
+"""Pins the CPU oracle (oracle/gs_oracle.c) against golden vectors produced by
+the reference's own JavaScript (oracle/gen_golden.js ran /root/reference/index.js
+under node).  Bit-exact for sort / pack / ply; camera matrices exact in f64."""
+import numpy as np
+import pytest
+
+from conftest import cases_of, load_case
+from oracle import oracle
+
+
+@pytest.mark.parametrize("name", cases_of("sort"))
+def test_sort_matches_reference_worker(name):
+    c = load_case(name)
+    rows = c["rows4"].reshape(-1, 4)
+    got = oracle.sort(rows, c["view"], c.get("cutout"))
+    assert got.dtype == np.uint32
+    assert got.size == c["sorted"].size
+    assert np.array_equal(got, c["sorted"])
+
+
+def test_sort_full_matrix_stride():
+    c = load_case("sort_n4096")
+    rows = c["rows4"].reshape(-1, 4)
+    m = np.zeros((rows.shape[0], 16), np.float32)
+    m[:, 12:16] = rows
+    m[:, :12] = 7.0  # garbage that must be ignored (index.js:520-548 read only 12..15)
+    assert np.array_equal(oracle.sort(m, c["view"]), c["sorted"])
+
+
+@pytest.mark.parametrize("name", cases_of("pack"))
+def test_pack_matches_reference_pushDataBuffer(name):
+    c = load_case(name)
+    cs, cc, mats = oracle.pack(c["rows"])
+    assert np.array_equal(cs.reshape(-1).view(np.uint32), c["center_scale"].view(np.uint32))
+    assert np.array_equal(cc.reshape(-1), c["cov_color"])
+    assert np.array_equal(mats.reshape(-1).view(np.uint32), c["matrices"].view(np.uint32))
+
+
+def test_pack_parseint_quirk_present():
+    """Row 0 of pack_n300 is a needle with identity rotation: the reference's
+    parseInt(Number) returns the leading digit of the exponent-form string."""
+    c = load_case("pack_n300")
+    q = c["cov_color"].reshape(-1, 4)[0]
+    m22 = int(q[1] >> 16)
+    m33 = int(q[2] >> 16)
+    assert (m22, m33) != (0, 0)
+
+
+@pytest.mark.parametrize("name", cases_of("ply"))
+def test_ply_matches_reference_processPlyBuffer(name):
+    c = load_case(name)
+    got = oracle.ply_to_splat(c["ply"])
+    assert np.array_equal(got, c["rows"])
+
+
+def _ply(props, nbytes, end=True):
+    return (b"ply\nformat binary_little_endian 1.0\nelement vertex 1\n" +
+            b"".join(b"property float %s\n" % n for n in props) + (b"end_header\n" if end else b"") + b"\0" * nbytes)
+
+
+def test_ply_errors(manifest):
+    e = manifest["ply_errors"]["meta"]
+    assert e["no_end_header"] == "Unable to read .ply file header"
+    with pytest.raises(oracle.PlyError) as ei:
+        oracle.ply_to_splat(_ply([b"x"], 8, end=False))
+    assert str(ei.value) == e["no_end_header"]
+    with pytest.raises(oracle.PlyError) as ei:
+        oracle.ply_to_splat(_ply([b"x", b"y", b"z", b"scale_0", b"scale_1", b"scale_2", b"opacity", b"rot_0", b"rot_1",
+                                  b"rot_2"], 40))
+    assert str(ei.value) == e["missing_rot_3"]
+    with pytest.raises(oracle.PlyError) as ei:
+        oracle.ply_to_splat(_ply([b"x", b"y", b"z"], 12))
+    assert str(ei.value) == e["missing_red"]
+
+
+@pytest.mark.parametrize("name", cases_of("camera"))
+def test_camera_matches_reference(name):
+    c = load_case(name)
+    mv = oracle.model_view(c["cam_world"], c["obj_world"])
+    assert np.array_equal(mv, c["gs_mv"])
+    pr = oracle.projection(c["proj"])
+    assert np.array_equal(pr, c["gs_proj"])
+    view, cut = oracle.tick(c["cam_world"], c["obj_world"], c.get("cutout_world"))
+    assert np.array_equal(view.view(np.uint32), c["view"].view(np.uint32))
+    if "cutout" in c:
+        assert np.array_equal(cut.view(np.uint32), c["cutout"].view(np.uint32))
+    assert oracle.focal(pr, c["viewport"][1]) == c["focal"][0]
