@@ -1,0 +1,256 @@
+"""ctypes binding of the C ABI (include/gs_splat.h -> csrc/libgs_splat_hip.so).
+
+Plumbing only: every call goes straight into the HIP library.  There is no Python or CPU fallback -- if the
+library is missing, or no GPU is usable, this raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import build as _build
+
+GS_OK = 0
+E_BADARG, E_PLY_HEADER, E_PLY_PROP, E_HIP, E_OOM, E_NODEVICE, E_STATE, E_PLY_DATA = -1, -2, -3, -4, -5, -6, -7, -8
+RENDER_FLIP_Y, RENDER_COUNT_FRAGS, RENDER_NO_EARLY_OUT = 1, 2, 4
+OPT_PROFILE, OPT_TERMINATION = 1, 2
+BUF_CENTER_SCALE, BUF_COV_COLOR, BUF_SORT_ROWS, BUF_SORTED, BUF_PROJECTED, BUF_TILE_COUNT = 0, 1, 2, 3, 4, 5
+
+EXPORTS = [
+    "gs_create", "gs_destroy", "gs_last_error", "gs_version", "gs_clear", "gs_push_splat", "gs_push_matrices", "gs_load_ply",
+    "gs_ply_to_splat", "gs_count", "gs_sort", "gs_render", "gs_render_device", "gs_render_stereo", "gs_sync", "gs_set_stream",
+    "gs_model_view_matrix", "gs_projection_matrix", "gs_tick_uniforms", "gs_focal", "gs_scaled_size", "gs_set_option",
+    "gs_get_stats", "gs_download",
+]
+
+
+class RenderParams(C.Structure):
+    _fields_ = [("model_view", C.c_float * 16), ("projection", C.c_float * 16), ("fb_width", C.c_int32), ("fb_height", C.c_int32),
+                ("x0", C.c_int32), ("x1", C.c_int32), ("focal", C.c_float), ("background", C.c_float * 4), ("flags", C.c_uint32)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("n_splats", C.c_uint64), ("n_sorted", C.c_uint64), ("n_visible", C.c_uint64), ("n_pairs", C.c_uint64),
+                ("n_frags", C.c_uint64), ("n_tiles", C.c_uint64), ("ms_sort", C.c_float), ("ms_project", C.c_float),
+                ("ms_bin", C.c_float), ("ms_blend", C.c_float), ("ms_render", C.c_float), ("blend_launches", C.c_uint32)]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+class GsError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("gs_splat error %d: %s" % (code, msg))
+        self.code = code
+        self.message = msg
+
+
+_lib = None
+
+
+def library_path():
+    return _build.LIB
+
+
+def load(build_if_missing=True):
+    """dlopen the HIP library (building it first if absent and a compiler is present)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_build.LIB):
+        if not build_if_missing:
+            raise FileNotFoundError(_build.LIB + " not built; run __graft_entry__.build()")
+        _build.build_lib()
+    L = C.CDLL(_build.LIB)
+    vp, sz, i32, u32p, f32 = C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_uint32), C.c_float
+    L.gs_create.argtypes = [i32, C.POINTER(vp)]
+    L.gs_destroy.argtypes = [vp]
+    L.gs_last_error.argtypes = [vp]; L.gs_last_error.restype = C.c_char_p
+    L.gs_version.restype = C.c_uint32
+    L.gs_clear.argtypes = [vp]
+    L.gs_push_splat.argtypes = [vp, vp, sz]
+    L.gs_push_matrices.argtypes = [vp, vp, sz]
+    L.gs_load_ply.argtypes = [vp, vp, sz]
+    L.gs_ply_to_splat.argtypes = [vp, sz, vp, C.POINTER(sz), C.c_char_p, sz]
+    L.gs_count.argtypes = [vp]; L.gs_count.restype = sz
+    L.gs_sort.argtypes = [vp, vp, vp, vp, u32p]
+    L.gs_render.argtypes = [vp, C.POINTER(RenderParams), vp, sz]
+    L.gs_render_device.argtypes = [vp, C.POINTER(RenderParams), vp]
+    L.gs_render_stereo.argtypes = [vp, C.POINTER(RenderParams), C.POINTER(vp), sz]
+    L.gs_sync.argtypes = [vp]
+    L.gs_set_stream.argtypes = [vp, vp]
+    L.gs_model_view_matrix.argtypes = [vp, vp, vp]; L.gs_model_view_matrix.restype = None
+    L.gs_projection_matrix.argtypes = [vp, vp]; L.gs_projection_matrix.restype = None
+    L.gs_tick_uniforms.argtypes = [vp, vp, vp, vp, vp]; L.gs_tick_uniforms.restype = None
+    L.gs_focal.argtypes = [vp, C.c_double]; L.gs_focal.restype = C.c_double
+    L.gs_scaled_size.argtypes = [i32, i32, C.c_double, C.POINTER(i32), C.POINTER(i32)]; L.gs_scaled_size.restype = None
+    L.gs_set_option.argtypes = [vp, i32, C.c_int64]
+    L.gs_get_stats.argtypes = [vp, C.POINTER(Stats)]
+    L.gs_download.argtypes = [vp, i32, vp, sz]
+    _lib = L
+    return L
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+# ---- host helpers (no context needed) ------------------------------------------------------------------
+
+def model_view_matrix(cam_world, obj_world):
+    a = np.ascontiguousarray(cam_world, np.float64); b = np.ascontiguousarray(obj_world, np.float64); o = np.zeros(16, np.float64)
+    load().gs_model_view_matrix(_p(a), _p(b), _p(o))
+    return o
+
+
+def projection_matrix(proj):
+    a = np.ascontiguousarray(proj, np.float64); o = np.zeros(16, np.float64)
+    load().gs_projection_matrix(_p(a), _p(o))
+    return o
+
+
+def tick_uniforms(cam_world, obj_world, cutout_world=None):
+    a = np.ascontiguousarray(cam_world, np.float64); b = np.ascontiguousarray(obj_world, np.float64)
+    c = None if cutout_world is None else np.ascontiguousarray(cutout_world, np.float64)
+    view = np.zeros(4, np.float32); cut = np.zeros(16, np.float32)
+    load().gs_tick_uniforms(_p(a), _p(b), _p(c), _p(view), _p(cut))
+    return view, (cut if c is not None else None)
+
+
+def focal(gs_proj, viewport_h):
+    a = np.ascontiguousarray(gs_proj, np.float64)
+    return load().gs_focal(_p(a), float(viewport_h))
+
+
+def scaled_size(css_w, css_h, ratio):
+    w, h = C.c_int(0), C.c_int(0)
+    load().gs_scaled_size(int(css_w), int(css_h), float(ratio), C.byref(w), C.byref(h))
+    return w.value, h.value
+
+
+def ply_to_splat(ply_bytes):
+    """processPlyBuffer (index.js:600-745): PLY bytes -> uint8 array of 32-byte .splat rows."""
+    buf = np.frombuffer(bytes(ply_bytes), np.uint8)
+    n = C.c_size_t(0); err = C.create_string_buffer(256)
+    rc = load().gs_ply_to_splat(_p(buf), buf.size, None, C.byref(n), err, 256)
+    if rc != GS_OK:
+        raise GsError(rc, err.value.decode())
+    out = np.zeros(n.value * 32, np.uint8)
+    rc = load().gs_ply_to_splat(_p(buf), buf.size, _p(out), C.byref(n), err, 256)
+    if rc != GS_OK:
+        raise GsError(rc, err.value.decode())
+    return out
+
+
+def make_params(mv, proj, width, height, x0=0, x1=None, focal_=0.0, background=(0.0, 0.0, 0.0, 1.0), flags=0):
+    p = RenderParams()
+    p.model_view[:] = [float(v) for v in np.asarray(mv, np.float32)]
+    p.projection[:] = [float(v) for v in np.asarray(proj, np.float32)]
+    p.fb_width, p.fb_height = int(width), int(height)
+    p.x0, p.x1 = int(x0), int(width if x1 is None else x1)
+    p.focal = float(np.float32(focal_))
+    p.background[:] = [float(v) for v in background]
+    p.flags = int(flags)
+    return p
+
+
+class Context:
+    """One gs_ctx: one component instance on one GPU."""
+
+    def __init__(self, device=0):
+        self._L = load()
+        h = C.c_void_p()
+        rc = self._L.gs_create(int(device), C.byref(h))
+        if rc != GS_OK:
+            raise GsError(rc, self._L.gs_last_error(None).decode())
+        self._h = h
+        self.device = device
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.gs_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _ck(self, rc):
+        if rc != GS_OK:
+            raise GsError(rc, self._L.gs_last_error(self._h).decode())
+
+    # ingest
+    def clear(self):
+        self._ck(self._L.gs_clear(self._h))
+
+    def push_splat(self, rows):
+        rows = np.ascontiguousarray(np.asarray(rows).view(np.uint8).reshape(-1))
+        if rows.size % 32:
+            raise ValueError("rows must be a multiple of 32 bytes")
+        self._ck(self._L.gs_push_splat(self._h, _p(rows), rows.size // 32))
+
+    def push_matrices(self, matrices):
+        m = np.ascontiguousarray(matrices, np.float32).reshape(-1)
+        if m.size % 16:
+            raise ValueError("matrices must be a multiple of 16 floats")
+        self._ck(self._L.gs_push_matrices(self._h, _p(m), m.size // 16))
+
+    def load_ply(self, ply_bytes):
+        buf = np.frombuffer(bytes(ply_bytes), np.uint8)
+        self._ck(self._L.gs_load_ply(self._h, _p(buf), buf.size))
+
+    def count(self):
+        return self._L.gs_count(self._h)
+
+    # sort
+    def sort(self, view, cutout=None, want_indices=True):
+        view = np.ascontiguousarray(view, np.float32)
+        cut = None if cutout is None else np.ascontiguousarray(cutout, np.float32)
+        if not want_indices:
+            self._ck(self._L.gs_sort(self._h, _p(view), _p(cut), None, None))
+            return None
+        out = np.zeros(max(self.count(), 1), np.uint32)
+        n = C.c_uint32(0)
+        self._ck(self._L.gs_sort(self._h, _p(view), _p(cut), _p(out), C.byref(n)))
+        return out[:n.value].copy()
+
+    # render
+    def render(self, params, flip=False):
+        sw = params.x1 - params.x0
+        out = np.zeros((params.fb_height, sw, 4), np.uint8)
+        self._ck(self._L.gs_render(self._h, C.byref(params), _p(out), 0))
+        return out
+
+    def render_device(self, params, device_ptr=None):
+        self._ck(self._L.gs_render_device(self._h, C.byref(params), C.c_void_p(device_ptr) if device_ptr else None))
+
+    def render_stereo(self, left, right):
+        arr = (RenderParams * 2)(left, right)
+        o0 = np.zeros((left.fb_height, left.x1 - left.x0, 4), np.uint8)
+        o1 = np.zeros((right.fb_height, right.x1 - right.x0, 4), np.uint8)
+        outs = (C.c_void_p * 2)(o0.ctypes.data, o1.ctypes.data)
+        self._ck(self._L.gs_render_stereo(self._h, arr, outs, 0))
+        return o0, o1
+
+    def sync(self):
+        self._ck(self._L.gs_sync(self._h))
+
+    def set_stream(self, stream_ptr):
+        self._ck(self._L.gs_set_stream(self._h, C.c_void_p(stream_ptr) if stream_ptr else None))
+
+    def set_option(self, opt, value):
+        self._ck(self._L.gs_set_option(self._h, int(opt), int(value)))
+
+    def stats(self):
+        s = Stats()
+        self._ck(self._L.gs_get_stats(self._h, C.byref(s)))
+        return s.as_dict()
+
+    def download(self, which, count, dtype, width):
+        out = np.zeros((count, width), dtype)
+        self._ck(self._L.gs_download(self._h, int(which), _p(out), out.nbytes))
+        return out

@@ -1,0 +1,385 @@
+// gs_api.hip -- the C ABI (include/gs_splat.h): context lifetime, HBM residency, ingest, sort / render
+// entry points, stats.  No compute happens on the host here; every hot-path stage is a HIP kernel and the
+// library refuses to exist without a device (no CPU fallback).
+#include <new>
+#include <vector>
+#include "gs_internal.h"
+#include "gs_host_tables.h"
+
+static thread_local char g_create_err[512] = "";
+
+#define CHECK_CTX(ctx) do { if (!(ctx)) return GS_E_BADARG; } while (0)
+#define FAIL(code, ...) do { snprintf(ctx->err, sizeof ctx->err, __VA_ARGS__); return (code); } while (0)
+
+template <typename T> static int dev_alloc(gs_ctx *ctx, T **p, size_t count)
+{
+    *p = nullptr;
+    if (!count) count = 1;
+    hipError_t e = hipMalloc((void **)p, count * sizeof(T));
+    if (e != hipSuccess) {
+        snprintf(ctx->err, sizeof ctx->err, "hipMalloc(%zu bytes) failed: %s", count * sizeof(T), hipGetErrorString(e));
+        return e == hipErrorOutOfMemory ? GS_E_OOM : GS_E_HIP;
+    }
+    return GS_OK;
+}
+template <typename T> static void dev_free(T *&p) { if (p) { (void)hipFree(p); p = nullptr; } }
+#define TRY(x) do { int _rc = (x); if (_rc != GS_OK) return _rc; } while (0)
+
+static int ensure_scan_scratch(gs_ctx *ctx)
+{
+    // histogram table: bins x chunks for the larger of the two sorts; spine: one word per 2048 scanned words
+    size_t need_hist = (size_t)GS_RADIX_MAX_BINS * (gs_div_up(ctx->cap, GS_CHUNK) + 1);
+    const size_t ph = (size_t)GS_RADIX_MAX_BINS * (gs_div_up(ctx->pair_cap, GS_CHUNK) + 1);
+    if (ph > need_hist) need_hist = ph;
+    if (need_hist > ctx->hist_cap) { dev_free(ctx->hist); TRY(dev_alloc(ctx, &ctx->hist, need_hist)); ctx->hist_cap = need_hist; }
+    size_t need_spine = gs_div_up(need_hist, GS_CHUNK) + gs_div_up(ctx->cap, GS_CHUNK) + 16;
+    if (need_spine > ctx->spine_cap) { dev_free(ctx->spine); TRY(dev_alloc(ctx, &ctx->spine, need_spine)); ctx->spine_cap = need_spine; }
+    return GS_OK;
+}
+
+int gs_ensure_pair_capacity(gs_ctx *ctx, size_t pairs)
+{
+    if (pairs <= ctx->pair_cap) return GS_OK;
+    size_t cap = ctx->pair_cap ? ctx->pair_cap : (size_t)1 << 22;
+    while (cap < pairs) cap += cap / 2 + 1;
+    cap = (cap + GS_CHUNK - 1) / GS_CHUNK * GS_CHUNK;
+    if (cap > 0xFFFF0000ull) FAIL(GS_E_OOM, "pair list of %zu entries exceeds the 32-bit index space", pairs);
+    dev_free(ctx->pkey_a); dev_free(ctx->pkey_b); dev_free(ctx->pval_a); dev_free(ctx->pval_b);
+    ctx->pair_cap = 0;
+    TRY(dev_alloc(ctx, &ctx->pkey_a, cap)); TRY(dev_alloc(ctx, &ctx->pkey_b, cap));
+    TRY(dev_alloc(ctx, &ctx->pval_a, cap)); TRY(dev_alloc(ctx, &ctx->pval_b, cap));
+    ctx->pair_cap = cap;
+    return ensure_scan_scratch(ctx);
+}
+
+// grow the per-splat arrays to hold at least `want` splats, preserving the resident data
+static int ensure_capacity(gs_ctx *ctx, size_t want)
+{
+    if (want <= ctx->cap) return GS_OK;
+    if (want > 0x7FFFFFF0ull) FAIL(GS_E_BADARG, "more than 2^31 splats");
+    size_t cap = ctx->cap ? ctx->cap : (size_t)1 << 16;
+    while (cap < want) cap *= 2;
+    float4 *cs = nullptr, *sr = nullptr; uint4 *cc = nullptr;
+    TRY(dev_alloc(ctx, &cs, cap)); TRY(dev_alloc(ctx, &cc, cap)); TRY(dev_alloc(ctx, &sr, cap));
+    if (ctx->n) {
+        GS_HIP(hipMemcpyAsync(cs, ctx->center_scale, ctx->n * sizeof(float4), hipMemcpyDeviceToDevice, ctx->stream));
+        GS_HIP(hipMemcpyAsync(cc, ctx->cov_color, ctx->n * sizeof(uint4), hipMemcpyDeviceToDevice, ctx->stream));
+        GS_HIP(hipMemcpyAsync(sr, ctx->sort_rows, ctx->n * sizeof(float4), hipMemcpyDeviceToDevice, ctx->stream));
+        GS_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    dev_free(ctx->center_scale); dev_free(ctx->cov_color); dev_free(ctx->sort_rows);
+    ctx->center_scale = cs; ctx->cov_color = cc; ctx->sort_rows = sr;
+    dev_free(ctx->depth); dev_free(ctx->key_a); dev_free(ctx->key_b); dev_free(ctx->val_a); dev_free(ctx->val_b);
+    dev_free(ctx->proj); dev_free(ctx->rect); dev_free(ctx->tile_count); dev_free(ctx->pair_off);
+    TRY(dev_alloc(ctx, &ctx->depth, cap));
+    TRY(dev_alloc(ctx, &ctx->key_a, cap)); TRY(dev_alloc(ctx, &ctx->key_b, cap));
+    TRY(dev_alloc(ctx, &ctx->val_a, cap)); TRY(dev_alloc(ctx, &ctx->val_b, cap));
+    TRY(dev_alloc(ctx, &ctx->proj, cap)); TRY(dev_alloc(ctx, &ctx->rect, cap));
+    TRY(dev_alloc(ctx, &ctx->tile_count, cap)); TRY(dev_alloc(ctx, &ctx->pair_off, cap));
+    ctx->cap = cap;
+    ctx->have_sort = false; ctx->sorted = nullptr;
+    TRY(gs_ensure_pair_capacity(ctx, cap * 8 > ((size_t)1 << 22) ? cap * 8 : (size_t)1 << 22));
+    return ensure_scan_scratch(ctx);
+}
+
+extern "C" {
+
+GS_API uint32_t gs_version(void) { return 0x000100; }
+
+GS_API const char *gs_last_error(const gs_ctx *ctx) { return ctx ? ctx->err : g_create_err; }
+
+GS_API int gs_create(int device, gs_ctx **out)
+{
+    if (!out) return GS_E_BADARG;
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) {
+        snprintf(g_create_err, sizeof g_create_err, "no HIP device available (%s); this library has no CPU fallback",
+                 e != hipSuccess ? hipGetErrorString(e) : "device count 0");
+        return GS_E_NODEVICE;
+    }
+    if (device < 0 || device >= ndev) {
+        snprintf(g_create_err, sizeof g_create_err, "device %d out of range (have %d)", device, ndev);
+        return GS_E_BADARG;
+    }
+    gs_ctx *ctx = new (std::nothrow) gs_ctx();
+    if (!ctx) { snprintf(g_create_err, sizeof g_create_err, "out of host memory"); return GS_E_OOM; }
+    memset(ctx, 0, sizeof *ctx);
+    ctx->device = device; ctx->renderable = true; ctx->t_eps = 1.0f / 4096.0f;
+#define CREATE_HIP(call) do { hipError_t _e = (call); if (_e != hipSuccess) {                                              \
+        snprintf(g_create_err, sizeof g_create_err, "%s failed: %s", #call, hipGetErrorString(_e)); gs_destroy(ctx);      \
+        return GS_E_HIP; } } while (0)
+    CREATE_HIP(hipSetDevice(device));
+    CREATE_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    ctx->own_stream = true;
+    for (int i = 0; i < 8; i++) CREATE_HIP(hipEventCreate(&ctx->ev[i]));
+    CREATE_HIP(hipMalloc((void **)&ctx->ctl, sizeof(GsControl)));
+    CREATE_HIP(hipMemset(ctx->ctl, 0, sizeof(GsControl)));
+    CREATE_HIP(hipHostMalloc((void **)&ctx->ctl_host, sizeof(GsControl), hipHostMallocDefault));
+    memset(ctx->ctl_host, 0, sizeof(GsControl));
+    {
+        std::vector<double> tab(GS_POW10_ENTRIES);
+        gs_build_pow10_table(tab.data());
+        CREATE_HIP(hipMalloc((void **)&ctx->pow10tab, tab.size() * sizeof(double)));
+        CREATE_HIP(hipMemcpy(ctx->pow10tab, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
+#undef CREATE_HIP
+    *out = ctx;
+    return GS_OK;
+}
+
+GS_API int gs_destroy(gs_ctx *ctx)
+{
+    if (!ctx) return GS_OK;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    dev_free(ctx->center_scale); dev_free(ctx->cov_color); dev_free(ctx->sort_rows); dev_free(ctx->pow10tab);
+    dev_free(ctx->depth); dev_free(ctx->key_a); dev_free(ctx->key_b); dev_free(ctx->val_a); dev_free(ctx->val_b);
+    dev_free(ctx->hist); dev_free(ctx->spine);
+    dev_free(ctx->proj); dev_free(ctx->rect); dev_free(ctx->tile_count); dev_free(ctx->pair_off);
+    dev_free(ctx->pkey_a); dev_free(ctx->pkey_b); dev_free(ctx->pval_a); dev_free(ctx->pval_b);
+    dev_free(ctx->tile_range); dev_free(ctx->fb); dev_free(ctx->ctl);
+    if (ctx->ctl_host) (void)hipHostFree(ctx->ctl_host);
+    for (int i = 0; i < 8; i++) if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
+    if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return GS_OK;
+}
+
+GS_API int gs_clear(gs_ctx *ctx)
+{
+    CHECK_CTX(ctx);
+    GS_HIP(hipSetDevice(ctx->device));
+    GS_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->n = 0; ctx->renderable = true; ctx->have_sort = false; ctx->sorted = nullptr;
+    memset(&ctx->stats, 0, sizeof ctx->stats);
+    return GS_OK;
+}
+
+GS_API size_t gs_count(const gs_ctx *ctx) { return ctx ? ctx->n : 0; }
+
+GS_API int gs_push_splat(gs_ctx *ctx, const void *rows, size_t nrows)
+{
+    CHECK_CTX(ctx);
+    if (nrows == 0) return GS_OK;                               // pushDataBuffer: vertexCount <= 0 -> return (index.js:333-335)
+    if (!rows) FAIL(GS_E_BADARG, "gs_push_splat: rows is NULL");
+    if (!ctx->renderable && ctx->n) FAIL(GS_E_STATE, "gs_push_splat after gs_push_matrices: mixed ingest is not supported");
+    GS_HIP(hipSetDevice(ctx->device));
+    TRY(ensure_capacity(ctx, ctx->n + nrows));
+    uint4 *stage = nullptr;
+    TRY(dev_alloc(ctx, &stage, nrows * 2));
+    hipError_t e = hipMemcpyAsync(stage, rows, nrows * 32, hipMemcpyHostToDevice, ctx->stream);
+    int rc = GS_OK;
+    if (e != hipSuccess) { snprintf(ctx->err, sizeof ctx->err, "upload failed: %s", hipGetErrorString(e)); rc = GS_E_HIP; }
+    if (rc == GS_OK) rc = gs_launch_pack(ctx, stage, ctx->n, nrows);
+    e = hipStreamSynchronize(ctx->stream);
+    if (rc == GS_OK && e != hipSuccess) { snprintf(ctx->err, sizeof ctx->err, "pack failed: %s", hipGetErrorString(e)); rc = GS_E_HIP; }
+    dev_free(stage);
+    if (rc != GS_OK) return rc;
+    ctx->n += nrows; ctx->renderable = true; ctx->have_sort = false;
+    ctx->stats.n_splats = ctx->n;
+    return GS_OK;
+}
+
+GS_API int gs_push_matrices(gs_ctx *ctx, const float *matrices, size_t nrows)
+{
+    CHECK_CTX(ctx);
+    if (nrows == 0) return GS_OK;
+    if (!matrices) FAIL(GS_E_BADARG, "gs_push_matrices: matrices is NULL");
+    if (ctx->renderable && ctx->n) FAIL(GS_E_STATE, "gs_push_matrices after gs_push_splat: mixed ingest is not supported");
+    GS_HIP(hipSetDevice(ctx->device));
+    TRY(ensure_capacity(ctx, ctx->n + nrows));
+    // strided H2D copy: only elements 12..15 of every 16-float row are ever read (index.js:520-548)
+    GS_HIP(hipMemcpy2DAsync(ctx->sort_rows + ctx->n, 16, matrices + 12, 64, 16, nrows, hipMemcpyHostToDevice, ctx->stream));
+    GS_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->n += nrows; ctx->renderable = false; ctx->have_sort = false;
+    ctx->stats.n_splats = ctx->n;
+    return GS_OK;
+}
+
+GS_API int gs_load_ply(gs_ctx *ctx, const void *bytes, size_t nbytes)
+{
+    CHECK_CTX(ctx);
+    if (!bytes) FAIL(GS_E_BADARG, "gs_load_ply: bytes is NULL");
+    size_t n = 0;
+    int rc = gs_ply_to_splat(bytes, nbytes, nullptr, &n, ctx->err, sizeof ctx->err);
+    if (rc != GS_OK) return rc;
+    std::vector<uint8_t> rows;
+    try { rows.resize(n * 32); } catch (...) { FAIL(GS_E_OOM, "out of host memory for %zu rows", n); }
+    rc = gs_ply_to_splat(bytes, nbytes, rows.data(), &n, ctx->err, sizeof ctx->err);
+    if (rc != GS_OK) return rc;
+    return gs_push_splat(ctx, rows.data(), n);
+}
+
+GS_API int gs_sort(gs_ctx *ctx, const float view[4], const float *cutout16, uint32_t *out_idx, uint32_t *out_n)
+{
+    CHECK_CTX(ctx);
+    if (!view) FAIL(GS_E_BADARG, "gs_sort: view is NULL");
+    if (ctx->n == 0) {                                          // sort before any push (index.js:588-590)
+        if (out_idx) out_idx[0] = 0;
+        if (out_n) *out_n = 1;
+        ctx->have_sort = false; ctx->stats.n_sorted = 0;
+        return GS_OK;
+    }
+    GS_HIP(hipSetDevice(ctx->device));
+    TRY(gs_run_sort(ctx, view, cutout16));
+    if (out_idx || out_n) {
+        GS_HIP(hipMemcpyAsync(ctx->ctl_host, ctx->ctl, sizeof(GsControl), hipMemcpyDeviceToHost, ctx->stream));
+        GS_HIP(hipStreamSynchronize(ctx->stream));
+        const uint32_t V = ctx->ctl_host->n_kept;
+        ctx->stats.n_sorted = V; ctx->sorted_n_host = V;
+        if (out_n) *out_n = V;
+        if (out_idx && V) GS_HIP(hipMemcpy(out_idx, ctx->sorted, (size_t)V * 4, hipMemcpyDeviceToHost));
+    }
+    ctx->sort_timed = ctx->profile;
+    return GS_OK;
+}
+
+static int fill_uniforms(gs_ctx *ctx, const gs_render_params *p, GsFrameUniforms &u)
+{
+    if (!p) FAIL(GS_E_BADARG, "render params NULL");
+    if (p->fb_width <= 0 || p->fb_height <= 0 || p->fb_width > 65535 * GS_TILE || p->fb_height > 65535 * GS_TILE)
+        FAIL(GS_E_BADARG, "bad framebuffer size %dx%d", p->fb_width, p->fb_height);
+    if (p->x0 < 0 || p->x1 > p->fb_width || p->x0 >= p->x1) FAIL(GS_E_BADARG, "bad strip [%d,%d) for width %d", p->x0, p->x1, p->fb_width);
+    memcpy(u.mv, p->model_view, sizeof u.mv); memcpy(u.proj, p->projection, sizeof u.proj);
+    u.W = p->fb_width; u.H = p->fb_height; u.x0 = p->x0; u.x1 = p->x1;
+    u.vw = (float)p->fb_width; u.vh = (float)p->fb_height;
+    // focal = (viewport.w / 2) * |P[5]| in JS f64, uploaded as a float uniform (index.js:191-194)
+    u.focal = p->focal > 0 ? p->focal : (float)(((double)p->fb_height / 2.0) * fabs((double)p->projection[5]));
+    u.tiles_x = (p->x1 - p->x0 + GS_TILE - 1) / GS_TILE; u.tiles_y = (p->fb_height + GS_TILE - 1) / GS_TILE;
+    memcpy(u.bg, p->background, sizeof u.bg);
+    u.t_eps = ctx->t_eps; u.flags = p->flags;
+    return GS_OK;
+}
+
+static int render_common(gs_ctx *ctx, const gs_render_params *p, void *device_rgba, uint8_t *host_rgba, size_t stride)
+{
+    if (!ctx->renderable && ctx->n) FAIL(GS_E_STATE, "context was fed worker matrices only (gs_push_matrices): it can sort but not render");
+    GsFrameUniforms u;
+    TRY(fill_uniforms(ctx, p, u));
+    GS_HIP(hipSetDevice(ctx->device));
+    const size_t sw = (size_t)(u.x1 - u.x0), fb_bytes = sw * (size_t)u.H * 4;
+    const size_t ntiles = (size_t)u.tiles_x * u.tiles_y;
+    if (ntiles > ctx->tile_cap) { dev_free(ctx->tile_range); TRY(dev_alloc(ctx, &ctx->tile_range, ntiles)); ctx->tile_cap = ntiles; }
+    if (!device_rgba && fb_bytes > ctx->fb_cap) { dev_free(ctx->fb); TRY(dev_alloc(ctx, &ctx->fb, fb_bytes)); ctx->fb_cap = fb_bytes; }
+    if (!ctx->pair_cap) TRY(gs_ensure_pair_capacity(ctx, (size_t)1 << 22));
+    for (int attempt = 0;; attempt++) {
+        TRY(gs_run_render(ctx, u, (uint8_t *)device_rgba));
+        GS_HIP(hipMemcpyAsync(ctx->ctl_host, ctx->ctl, sizeof(GsControl), hipMemcpyDeviceToHost, ctx->stream));
+        GS_HIP(hipStreamSynchronize(ctx->stream));
+        if (!ctx->ctl_host->pair_overflow) break;
+        if (attempt >= 2) FAIL(GS_E_OOM, "pair list keeps overflowing (%u pairs)", ctx->ctl_host->scan_total);
+        TRY(gs_ensure_pair_capacity(ctx, (size_t)ctx->ctl_host->scan_total + ctx->ctl_host->scan_total / 4 + 1));
+    }
+    const GsControl *c = ctx->ctl_host;
+    ctx->stats.n_sorted = c->n_kept; ctx->stats.n_visible = c->n_visible; ctx->stats.n_pairs = c->n_pairs;
+    ctx->stats.n_tiles = ntiles; ctx->stats.blend_launches = 1;
+    if (u.flags & GS_RENDER_COUNT_FRAGS) ctx->stats.n_frags = c->n_frags;
+    if (ctx->profile && ctx->sort_timed && ctx->have_sort) {       // the sort's events completed before this frame did
+        float ms = 0;
+        GS_HIP(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
+        ctx->stats.ms_sort = ms;
+    }
+    if (ctx->profile) {
+        float a = 0, b = 0, d = 0;
+        GS_HIP(hipEventElapsedTime(&a, ctx->ev[2], ctx->ev[3]));
+        GS_HIP(hipEventElapsedTime(&b, ctx->ev[3], ctx->ev[4]));
+        GS_HIP(hipEventElapsedTime(&d, ctx->ev[4], ctx->ev[5]));
+        ctx->stats.ms_project = a; ctx->stats.ms_bin = b; ctx->stats.ms_blend = d; ctx->stats.ms_render = a + b + d;
+    }
+    if (host_rgba) {
+        const uint8_t *src = device_rgba ? (const uint8_t *)device_rgba : ctx->fb;
+        if (!stride) stride = sw * 4;
+        if (stride < sw * 4) FAIL(GS_E_BADARG, "stride %zu smaller than a row (%zu bytes)", stride, sw * 4);
+        GS_HIP(hipMemcpy2D(host_rgba, stride, src, sw * 4, sw * 4, (size_t)u.H, hipMemcpyDeviceToHost));
+    }
+    return GS_OK;
+}
+
+GS_API int gs_render(gs_ctx *ctx, const gs_render_params *p, uint8_t *rgba_out, size_t stride)
+{
+    CHECK_CTX(ctx);
+    if (!rgba_out) FAIL(GS_E_BADARG, "gs_render: rgba_out is NULL");
+    return render_common(ctx, p, nullptr, rgba_out, stride);
+}
+
+GS_API int gs_render_device(gs_ctx *ctx, const gs_render_params *p, void *device_rgba)
+{
+    CHECK_CTX(ctx);
+    return render_common(ctx, p, device_rgba, nullptr, 0);
+}
+
+GS_API int gs_render_stereo(gs_ctx *ctx, const gs_render_params eyes[2], uint8_t *rgba_out[2], size_t stride)
+{
+    CHECK_CTX(ctx);
+    if (!eyes || !rgba_out || !rgba_out[0] || !rgba_out[1]) FAIL(GS_E_BADARG, "gs_render_stereo: NULL argument");
+    TRY(render_common(ctx, &eyes[0], nullptr, rgba_out[0], stride));
+    return render_common(ctx, &eyes[1], nullptr, rgba_out[1], stride);
+}
+
+GS_API int gs_sync(gs_ctx *ctx)
+{
+    CHECK_CTX(ctx);
+    GS_HIP(hipSetDevice(ctx->device));
+    GS_HIP(hipStreamSynchronize(ctx->stream));
+    return GS_OK;
+}
+
+GS_API int gs_set_stream(gs_ctx *ctx, void *hip_stream)
+{
+    CHECK_CTX(ctx);
+    GS_HIP(hipSetDevice(ctx->device));
+    GS_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->own_stream) { (void)hipStreamDestroy(ctx->stream); ctx->own_stream = false; }
+    if (hip_stream) ctx->stream = (hipStream_t)hip_stream;
+    else { GS_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)); ctx->own_stream = true; }
+    return GS_OK;
+}
+
+GS_API int gs_set_option(gs_ctx *ctx, int option, int64_t value)
+{
+    CHECK_CTX(ctx);
+    switch (option) {
+    case GS_OPT_PROFILE: ctx->profile = value != 0; return GS_OK;
+    case GS_OPT_TERMINATION:
+        if (value < 2) FAIL(GS_E_BADARG, "termination 1/eps must be >= 2");
+        ctx->t_eps = 1.0f / (float)value; return GS_OK;
+    default: FAIL(GS_E_BADARG, "unknown option %d", option);
+    }
+}
+
+GS_API int gs_get_stats(gs_ctx *ctx, gs_stats *out)
+{
+    CHECK_CTX(ctx);
+    if (!out) FAIL(GS_E_BADARG, "gs_get_stats: out is NULL");
+    ctx->stats.n_splats = ctx->n;
+    *out = ctx->stats;
+    return GS_OK;
+}
+
+GS_API int gs_download(gs_ctx *ctx, int which, void *out, size_t nbytes)
+{
+    CHECK_CTX(ctx);
+    if (!out) FAIL(GS_E_BADARG, "gs_download: out is NULL");
+    GS_HIP(hipSetDevice(ctx->device));
+    GS_HIP(hipStreamSynchronize(ctx->stream));
+    const void *src = nullptr; size_t have = 0;
+    const size_t V = ctx->stats.n_sorted;
+    switch (which) {
+    case GS_BUF_CENTER_SCALE: src = ctx->center_scale; have = ctx->n * 16; break;
+    case GS_BUF_COV_COLOR: src = ctx->cov_color; have = ctx->n * 16; break;
+    case GS_BUF_SORT_ROWS: src = ctx->sort_rows; have = ctx->n * 16; break;
+    case GS_BUF_SORTED: src = ctx->sorted; have = ctx->have_sort ? V * 4 : 0; break;
+    case GS_BUF_PROJECTED: src = ctx->proj; have = ctx->have_sort ? V * 32 : 0; break;
+    case GS_BUF_TILE_COUNT: src = ctx->tile_count; have = ctx->have_sort ? V * 4 : 0; break;
+    default: FAIL(GS_E_BADARG, "unknown buffer %d", which);
+    }
+    if (nbytes > have) FAIL(GS_E_BADARG, "buffer %d holds %zu bytes, %zu requested", which, have, nbytes);
+    if (nbytes && (!ctx->renderable && (which == GS_BUF_CENTER_SCALE || which == GS_BUF_COV_COLOR)))
+        FAIL(GS_E_STATE, "context holds worker rows only");
+    if (nbytes) GS_HIP(hipMemcpy(out, src, nbytes, hipMemcpyDeviceToHost));
+    return GS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,117 @@
+// gs_internal.h -- context layout and kernel-launcher declarations shared by the .hip files.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include "../../include/gs_splat.h"
+#include "gs_device_math.h"
+
+// ---------------------------------------------------------------- geometry of the work decomposition
+#define GS_TILE 16                 // screen tile edge (pixels): 16x16 = one 256-thread workgroup
+#define GS_BLOCK 256               // threads per workgroup everywhere (4 wavefronts of 64)
+#define GS_CHUNK 2048              // items per workgroup pass in streaming kernels (8 per thread)
+#define GS_RADIX_MAX_BINS 512      // up to 9-bit digits (depth key = 17 bits = 8 + 9)
+#define GS_CULLED_KEY 65536u       // depth-sort key of culled / dropped splats (sorts behind every bucket)
+
+// Device-resident control block: every data-dependent count lives here so that no stage needs a
+// host round trip; kernels read their problem size from it (grid-stride over chunks).
+struct GsControl {
+    unsigned long long min_enc;    // ordered-u64 encoding of min kept depth (f64)
+    unsigned long long max_enc;    // ... max
+    unsigned long long n_frags;    // fragment counter (GS_RENDER_COUNT_FRAGS)
+    uint32_t n_total;              // N at the time of the sort
+    uint32_t n_kept;               // V : survivors of the sort culls  (= reference validCount)
+    uint32_t n_valid;              // V': survivors whose bucket is in [0,65535]
+    uint32_t n_visible;            // Vp: splats that pass the vertex-shader culls
+    uint32_t n_pairs;              // I : (tile, splat) pairs
+    uint32_t pair_overflow;        // set when I exceeded the pair capacity (pairs clamped to 0)
+    uint32_t scan_total;           // scratch: total of the last scan
+    uint32_t pad;
+};
+
+struct GsFrameUniforms {           // per-render constants, passed by value to kernels
+    float mv[16];
+    float proj[16];
+    float focal, vw, vh;
+    int32_t W, H;                  // full viewport
+    int32_t x0, x1;                // strip
+    int32_t tiles_x, tiles_y;      // tile grid of the strip (origin at pixel x0, row 0 = top)
+    float bg[4];
+    float t_eps;                   // early-out threshold on transmittance
+    uint32_t flags;
+};
+
+struct gs_ctx {
+    int device;
+    hipStream_t stream;
+    bool own_stream;
+    char err[512];
+
+    // resident splat data (append-only; capacity doubles)
+    size_t n, cap;
+    bool renderable;               // false once matrices-only rows were pushed
+    float4 *center_scale;          // N x (cx, cy, -z, max|Sigma|/32767)           index.js:378-382
+    uint4 *cov_color;              // N x (6 x int16 Sigma, RGBA8)                   index.js:384-394
+    float4 *sort_rows;             // N x worker-row elements 12..15                 index.js:396-401
+    double *pow10tab;              // parseInt table (gs_host_tables.h)
+
+    // sort scratch (sized by cap)
+    float *depth;                  // stored f32 depth or +inf for culled
+    uint32_t *key_a, *key_b, *val_a, *val_b;
+    uint32_t *sorted;              // alias of the buffer holding the final order
+    uint32_t sorted_n_host;        // V as last read back (only when the caller asked for it)
+    bool have_sort;
+
+    // radix / scan scratch
+    uint32_t *hist;  size_t hist_cap;       // [bins][chunks]
+    uint32_t *spine; size_t spine_cap;      // per-scan-chunk sums
+
+    // render scratch
+    gsm::Projected *proj;          // V records, sorted order
+    uint2 *rect;                   // V x (tx0 | ty0<<16, tx1 | ty1<<16), strip-local tile coords
+    uint32_t *tile_count;          // V
+    uint32_t *pair_off;            // V exclusive offsets
+    uint32_t *pkey_a, *pkey_b, *pval_a, *pval_b; size_t pair_cap;
+    uint2 *tile_range; size_t tile_cap;     // per tile [start,end) into the sorted pair list
+    uint8_t *fb; size_t fb_cap;             // RGBA8 strip
+    GsControl *ctl;                // device
+    GsControl *ctl_host;           // pinned host mirror
+
+    // options / stats
+    bool profile;
+    bool sort_timed;               // ev[0..1] bracket the last sort
+    float t_eps;
+    hipEvent_t ev[8];
+    gs_stats stats;
+};
+
+#define GS_HIP(call)                                                                                     \
+    do {                                                                                                 \
+        hipError_t _e = (call);                                                                          \
+        if (_e != hipSuccess) {                                                                          \
+            snprintf(ctx->err, sizeof ctx->err, "%s failed: %s (%s:%d)", #call, hipGetErrorString(_e),   \
+                     __FILE__, __LINE__);                                                                \
+            return (_e == hipErrorOutOfMemory) ? GS_E_OOM : GS_E_HIP;                                    \
+        }                                                                                                \
+    } while (0)
+
+static inline uint32_t gs_div_up(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
+
+// ---- gs_prims.hip
+// Exclusive scan of n u32 (n read on the device: *n_ptr, or 2^bits * ceil(*n_ptr/GS_CHUNK) when bits>0).
+// `total_out` (device, optional) receives the grand total.
+int gs_launch_scan(gs_ctx *ctx, const uint32_t *in, uint32_t *out, const uint32_t *n_ptr, int hist_bits,
+                   uint32_t max_n, uint32_t *total_out);
+// One stable LSD radix pass over n = *n_ptr (key,val) pairs on digit (key >> shift) & (2^bits-1).
+// vals_in == NULL: the value is the element index.  keys_out may be NULL.
+int gs_launch_radix_pass(gs_ctx *ctx, const uint32_t *keys_in, const uint32_t *vals_in, uint32_t *keys_out,
+                         uint32_t *vals_out, const uint32_t *n_ptr, uint32_t max_n, int shift, int bits);
+// ---- gs_pack.hip
+int gs_launch_pack(gs_ctx *ctx, const uint4 *rows_dev, size_t first, size_t nrows);
+// ---- gs_sort.hip
+int gs_run_sort(gs_ctx *ctx, const float view[4], const float *cutout16);
+// ---- gs_render.hip
+int gs_run_render(gs_ctx *ctx, const GsFrameUniforms &u, uint8_t *device_out);
+// ---- gs_api.hip
+int gs_ensure_pair_capacity(gs_ctx *ctx, size_t pairs);

@@ -1,0 +1,238 @@
+// gs_prims.hip -- device-wide exclusive scan and stable LSD radix pass for gfx950 (wave64).
+//
+// Both primitives read their problem size from device memory (GsControl), so no stage of the frame
+// needs a host round trip.  They are HBM/L2-streaming kernels: 256-thread workgroups, 2048 items per
+// workgroup pass, 16-byte vector loads where the access pattern allows, LDS digit histograms, and
+// wavefront ballots for the stable in-wave rank (no MFMA: there is no contraction here).
+#include "gs_internal.h"
+
+namespace {
+
+__device__ __forceinline__ uint32_t problem_len(const uint32_t *n_ptr, int hist_bits)
+{
+    const uint32_t n = *n_ptr;
+    if (hist_bits <= 0) return n;
+    return ((n + GS_CHUNK - 1) / GS_CHUNK) << hist_bits;       // digit-major histogram table
+}
+
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane)
+{
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t t = __shfl_up(v, d, 64);
+        if (lane >= d) v += t;
+    }
+    return v;
+}
+
+// exclusive scan of one value per thread across the 256-thread workgroup; *total = workgroup sum
+__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *s_wave /*[4]*/, uint32_t *total)
+{
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const uint32_t inc = wave_incl_scan(v, lane);
+    if (lane == 63) s_wave[w] = inc;
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) { const uint32_t s = s_wave[k]; if (k < w) base += s; tot += s; }
+    __syncthreads();
+    *total = tot;
+    return base + inc - v;
+}
+
+// ---------------------------------------------------------------- scan
+
+__global__ __launch_bounds__(GS_BLOCK) void k_scan_reduce(const uint32_t *__restrict__ in, uint32_t *__restrict__ spine,
+                                                          const uint32_t *n_ptr, int hist_bits)
+{
+    __shared__ uint32_t s_wave[4];
+    const uint32_t n = problem_len(n_ptr, hist_bits);
+    const uint32_t nchunks = (n + GS_CHUNK - 1) / GS_CHUNK;
+    for (uint32_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
+        const uint32_t base = c * GS_CHUNK + threadIdx.x * 8;
+        uint32_t s = 0;
+        if (base + 8 <= n) {
+            const uint4 a = *reinterpret_cast<const uint4 *>(in + base), b = *reinterpret_cast<const uint4 *>(in + base + 4);
+            s = a.x + a.y + a.z + a.w + b.x + b.y + b.z + b.w;
+        } else {
+            for (uint32_t k = 0; k < 8; k++) if (base + k < n) s += in[base + k];
+        }
+        uint32_t tot;
+        block_excl_scan(s, s_wave, &tot);
+        if (threadIdx.x == 0) spine[c] = tot;
+    }
+}
+
+__global__ __launch_bounds__(GS_BLOCK) void k_scan_spine(uint32_t *__restrict__ spine, const uint32_t *n_ptr, int hist_bits,
+                                                         uint32_t *total_out, uint32_t *total_out2)
+{
+    __shared__ uint32_t s_wave[4];
+    const uint32_t n = problem_len(n_ptr, hist_bits);
+    const uint32_t nsp = (n + GS_CHUNK - 1) / GS_CHUNK;
+    const uint32_t per = (nsp + GS_BLOCK - 1) / GS_BLOCK;
+    const uint32_t lo = min(threadIdx.x * per, nsp), hi = min(lo + per, nsp);
+    uint32_t s = 0;
+    for (uint32_t i = lo; i < hi; i++) s += spine[i];
+    uint32_t tot;
+    uint32_t run = block_excl_scan(s, s_wave, &tot);
+    for (uint32_t i = lo; i < hi; i++) { const uint32_t v = spine[i]; spine[i] = run; run += v; }
+    if (threadIdx.x == 0) {
+        if (total_out) *total_out = tot;
+        if (total_out2) *total_out2 = tot;
+    }
+}
+
+__global__ __launch_bounds__(GS_BLOCK) void k_scan_down(const uint32_t *in, uint32_t *out, const uint32_t *__restrict__ spine,
+                                                        const uint32_t *n_ptr, int hist_bits)
+{
+    __shared__ uint32_t s_wave[4];
+    const uint32_t n = problem_len(n_ptr, hist_bits);
+    const uint32_t nchunks = (n + GS_CHUNK - 1) / GS_CHUNK;
+    for (uint32_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
+        const uint32_t base = c * GS_CHUNK + threadIdx.x * 8;
+        uint32_t v[8];
+        if (base + 8 <= n) {
+            const uint4 a = *reinterpret_cast<const uint4 *>(in + base), b = *reinterpret_cast<const uint4 *>(in + base + 4);
+            v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+        } else {
+#pragma unroll
+            for (uint32_t k = 0; k < 8; k++) v[k] = (base + k < n) ? in[base + k] : 0u;
+        }
+        uint32_t s = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) s += v[k];
+        uint32_t tot;
+        uint32_t run = block_excl_scan(s, s_wave, &tot) + spine[c];
+        uint32_t o[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) { o[k] = run; run += v[k]; }
+        if (base + 8 <= n) {
+            *reinterpret_cast<uint4 *>(out + base) = make_uint4(o[0], o[1], o[2], o[3]);
+            *reinterpret_cast<uint4 *>(out + base + 4) = make_uint4(o[4], o[5], o[6], o[7]);
+        } else {
+#pragma unroll
+            for (uint32_t k = 0; k < 8; k++) if (base + k < n) out[base + k] = o[k];
+        }
+    }
+}
+
+// ---------------------------------------------------------------- radix pass
+
+// Per-chunk digit histogram -> hist[digit * nchunks + chunk] (digit-major, so ONE flat exclusive scan of
+// the table yields every (digit, chunk) base offset of the stable scatter).
+__global__ __launch_bounds__(GS_BLOCK) void k_radix_hist(const uint32_t *__restrict__ keys, const uint32_t *n_ptr, int shift,
+                                                         int bits, uint32_t *__restrict__ hist)
+{
+    __shared__ uint32_t s_hist[GS_RADIX_MAX_BINS];
+    const uint32_t n = *n_ptr;
+    const uint32_t nchunks = (n + GS_CHUNK - 1) / GS_CHUNK;
+    const uint32_t nbins = 1u << bits, mask = nbins - 1;
+    for (uint32_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
+        for (uint32_t d = threadIdx.x; d < nbins; d += GS_BLOCK) s_hist[d] = 0;
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const uint32_t i = c * GS_CHUNK + r * GS_BLOCK + threadIdx.x;
+            if (i < n) atomicAdd(&s_hist[(keys[i] >> shift) & mask], 1u);
+        }
+        __syncthreads();
+        for (uint32_t d = threadIdx.x; d < nbins; d += GS_BLOCK) hist[d * nchunks + c] = s_hist[d];
+        __syncthreads();
+    }
+}
+
+// Stable scatter.  Item order inside a chunk: wave w owns items [w*512, w*512+512), processed in 8 rounds
+// of 64 consecutive items (lane = item % 64), so "earlier" == (wave, round, lane) lexicographic.
+// Rank among equal digits: in-round via ballot match (one ballot per digit bit), across rounds via a
+// wave-private LDS counter row, across waves via a 4-way prefix added to the scanned global base.
+__global__ __launch_bounds__(GS_BLOCK) void k_radix_scatter(const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
+                                                            uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out,
+                                                            const uint32_t *n_ptr, int shift, int bits,
+                                                            const uint32_t *__restrict__ hist_scanned)
+{
+    __shared__ uint32_t s_cnt[4][GS_RADIX_MAX_BINS];            // 8 KiB
+    const uint32_t n = *n_ptr;
+    const uint32_t nchunks = (n + GS_CHUNK - 1) / GS_CHUNK;
+    const uint32_t nbins = 1u << bits, mask = nbins - 1;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    for (uint32_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
+        for (uint32_t i = threadIdx.x; i < 4 * GS_RADIX_MAX_BINS; i += GS_BLOCK) (&s_cnt[0][0])[i] = 0;
+        __syncthreads();
+        uint32_t key[8], val[8], rank[8];
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const uint32_t i = c * GS_CHUNK + w * 512 + r * 64 + lane;
+            const bool ok = i < n;
+            key[r] = ok ? keys_in[i] : 0xFFFFFFFFu;
+            val[r] = ok ? (vals_in ? vals_in[i] : i) : 0u;
+            const uint32_t d = (key[r] >> shift) & mask;
+            unsigned long long peers = __ballot(ok);
+            for (int b = 0; b < bits; b++) {
+                const bool bit = (d >> b) & 1u;
+                const unsigned long long vb = __ballot(ok && bit);
+                peers &= bit ? vb : ~vb;
+            }
+            const uint32_t before = __popcll(peers & lt), cnt = __popcll(peers);
+            const uint32_t prev = ok ? s_cnt[w][d] : 0u;
+            __builtin_amdgcn_wave_barrier();                     // every peer has read before the leader bumps
+            if (ok && before == 0) s_cnt[w][d] = prev + cnt;
+            __builtin_amdgcn_wave_barrier();
+            rank[r] = prev + before;
+        }
+        __syncthreads();
+        for (uint32_t d = threadIdx.x; d < nbins; d += GS_BLOCK) {
+            const uint32_t c0 = s_cnt[0][d], c1 = s_cnt[1][d], c2 = s_cnt[2][d];
+            const uint32_t base = hist_scanned[d * nchunks + c];
+            s_cnt[0][d] = base; s_cnt[1][d] = base + c0; s_cnt[2][d] = base + c0 + c1; s_cnt[3][d] = base + c0 + c1 + c2;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const uint32_t i = c * GS_CHUNK + w * 512 + r * 64 + lane;
+            if (i < n) {
+                const uint32_t d = (key[r] >> shift) & mask;
+                const uint32_t pos = s_cnt[w][d] + rank[r];
+                if (keys_out) keys_out[pos] = key[r];
+                vals_out[pos] = val[r];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+uint32_t grid_for(uint32_t max_items)
+{
+    uint32_t g = gs_div_up(max_items, GS_CHUNK);
+    if (g < 1) g = 1;
+    if (g > 2048) g = 2048;
+    return g;
+}
+
+}  // namespace
+
+int gs_launch_scan(gs_ctx *ctx, const uint32_t *in, uint32_t *out, const uint32_t *n_ptr, int hist_bits, uint32_t max_n,
+                   uint32_t *total_out)
+{
+    const uint32_t g = grid_for(max_n);
+    hipLaunchKernelGGL(k_scan_reduce, dim3(g), dim3(GS_BLOCK), 0, ctx->stream, in, ctx->spine, n_ptr, hist_bits);
+    hipLaunchKernelGGL(k_scan_spine, dim3(1), dim3(GS_BLOCK), 0, ctx->stream, ctx->spine, n_ptr, hist_bits, total_out,
+                       &ctx->ctl->scan_total);
+    hipLaunchKernelGGL(k_scan_down, dim3(g), dim3(GS_BLOCK), 0, ctx->stream, in, out, ctx->spine, n_ptr, hist_bits);
+    GS_HIP(hipGetLastError());
+    return GS_OK;
+}
+
+int gs_launch_radix_pass(gs_ctx *ctx, const uint32_t *keys_in, const uint32_t *vals_in, uint32_t *keys_out, uint32_t *vals_out,
+                         const uint32_t *n_ptr, uint32_t max_n, int shift, int bits)
+{
+    const uint32_t g = grid_for(max_n);
+    hipLaunchKernelGGL(k_radix_hist, dim3(g), dim3(GS_BLOCK), 0, ctx->stream, keys_in, n_ptr, shift, bits, ctx->hist);
+    const uint32_t max_hist = gs_div_up(max_n, GS_CHUNK) << bits;
+    int rc = gs_launch_scan(ctx, ctx->hist, ctx->hist, n_ptr, bits, max_hist, nullptr);
+    if (rc != GS_OK) return rc;
+    hipLaunchKernelGGL(k_radix_scatter, dim3(g), dim3(GS_BLOCK), 0, ctx->stream, keys_in, vals_in, keys_out, vals_out, n_ptr,
+                       shift, bits, ctx->hist);
+    GS_HIP(hipGetLastError());
+    return GS_OK;
+}

@@ -1,0 +1,239 @@
+// gs_render.hip -- the GPU half of the reference (vertex shader index.js:77-165, rasteriser, fragment shader
+// index.js:166-176, blend state index.js:177-181) as a tile-binned HIP pipeline:
+//
+//   k_project      one thread per SORTED splat (not 6 like the instanced quad): gather the two 16 B records,
+//                  Sigma' = (J W) Sigma (J W)^T, eigen axes, conservative tile rectangle         [HBM gather]
+//   scan           exclusive prefix sum of tiles-touched -> pair offsets, total I               [gs_prims]
+//   k_emit         (tile id, sorted position) pairs in splat order
+//   radix x2       stable sort of the pairs by tile id only: the input is already in depth order, so each
+//                  tile's list inherits the reference's draw order with no depth key            [gs_prims]
+//   k_tile_ranges  [start,end) of every tile in the sorted pair list
+//   k_blend        one 256-thread workgroup per 16x16 tile, LDS-staged batches of projected records,
+//                  FRONT-to-back traversal (reverse of the back-to-front list) with a transmittance
+//                  accumulator and workgroup-wide early termination; one rounding to RGBA8 at the end.
+//
+// The fixed-function rasteriser + ROP of the reference have no structural counterpart; parity is defined at
+// the pixel level against oracle/gs_oracle.c (DESIGN.md "Pixel parity").
+#include "gs_internal.h"
+
+namespace {
+
+__global__ void k_render_init(GsControl *ctl)
+{
+    ctl->n_visible = 0; ctl->n_pairs = 0; ctl->pair_overflow = 0; ctl->n_frags = 0;
+}
+
+__global__ __launch_bounds__(GS_BLOCK) void k_project(const uint32_t *__restrict__ sorted, const float4 *__restrict__ center_scale,
+                                                      const uint4 *__restrict__ cov_color, GsFrameUniforms u,
+                                                      gsm::Projected *__restrict__ proj, uint2 *__restrict__ rect,
+                                                      uint32_t *__restrict__ tile_count, GsControl *ctl)
+{
+    __shared__ uint32_t s_vis;
+    const uint32_t V = ctl->n_kept;
+    const uint32_t nchunks = (V + GS_BLOCK - 1) / GS_BLOCK;
+    for (uint32_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
+        if (threadIdx.x == 0) s_vis = 0;
+        __syncthreads();
+        const uint32_t j = c * GS_BLOCK + threadIdx.x;
+        uint32_t count = 0;
+        if (j < V) {
+            const uint32_t idx = sorted[j];
+            const float4 cs4 = center_scale[idx];
+            const uint4 cc4 = cov_color[idx];
+            const float cs[4] = { cs4.x, cs4.y, cs4.z, cs4.w };
+            const uint32_t cc[4] = { cc4.x, cc4.y, cc4.z, cc4.w };
+            gsm::Projected p; gsm::ProjExtra x;
+            if (gsm::project_splat(cs, cc, u.mv, u.proj, u.focal, u.vw, u.vh, p, x)) {
+                float xmin, xmax, ymin, ymax;
+                gsm::splat_pixel_bounds(p, x, xmin, xmax, ymin, ymax);
+                // clamp in float (bounds can be far outside the int range), then to the strip / screen
+                const float fx0 = fmaxf(xmin, (float)u.x0), fx1 = fminf(xmax, (float)(u.x1 - 1));
+                const float fy0 = fmaxf(ymin, 0.0f), fy1 = fminf(ymax, (float)(u.H - 1));
+                if (fx0 <= fx1 && fy0 <= fy1) {
+                    const int ix0 = (int)fx0, ix1 = (int)fx1, jy0 = (int)fy0, jy1 = (int)fy1;
+                    const int r0 = u.H - 1 - jy1, r1 = u.H - 1 - jy0;           // GL rows (y up) -> image rows (top-down)
+                    const uint32_t tx0 = (uint32_t)(ix0 - u.x0) / GS_TILE, tx1 = (uint32_t)(ix1 - u.x0) / GS_TILE;
+                    const uint32_t ty0 = (uint32_t)r0 / GS_TILE, ty1 = (uint32_t)r1 / GS_TILE;
+                    count = (tx1 - tx0 + 1) * (ty1 - ty0 + 1);
+                    rect[j] = make_uint2(tx0 | (ty0 << 16), tx1 | (ty1 << 16));
+                    float4 *dst = reinterpret_cast<float4 *>(proj + j);
+                    dst[0] = make_float4(p.cx, p.cy, p.ax, p.ay);
+                    dst[1] = make_float4(p.bx, p.by, __uint_as_float(p.rgba), p.alpha);
+                }
+            }
+            tile_count[j] = count;
+        }
+        if (count) atomicAdd(&s_vis, 1u);
+        __syncthreads();
+        if (threadIdx.x == 0 && s_vis) atomicAdd(&ctl->n_visible, s_vis);
+        __syncthreads();
+    }
+}
+
+// after the scan: I = scan_total; refuse (and flag) if it does not fit the pair buffers
+__global__ void k_pairs_check(GsControl *ctl, uint32_t pair_cap)
+{
+    const uint32_t total = ctl->scan_total;
+    if (total > pair_cap) { ctl->pair_overflow = 1; ctl->n_pairs = 0; }
+    else ctl->n_pairs = total;
+}
+
+__global__ __launch_bounds__(GS_BLOCK) void k_emit(const uint2 *__restrict__ rect, const uint32_t *__restrict__ tile_count,
+                                                   const uint32_t *__restrict__ pair_off, uint32_t tiles_x,
+                                                   uint32_t *__restrict__ pkey, uint32_t *__restrict__ pval, const GsControl *ctl)
+{
+    if (ctl->pair_overflow) return;
+    const uint32_t V = ctl->n_kept;
+    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < V; j += gridDim.x * blockDim.x) {
+        if (!tile_count[j]) continue;
+        const uint2 r = rect[j];
+        const uint32_t tx0 = r.x & 0xFFFF, ty0 = r.x >> 16, tx1 = r.y & 0xFFFF, ty1 = r.y >> 16;
+        uint32_t o = pair_off[j];
+        for (uint32_t ty = ty0; ty <= ty1; ty++)
+            for (uint32_t tx = tx0; tx <= tx1; tx++) { pkey[o] = ty * tiles_x + tx; pval[o] = j; o++; }
+    }
+}
+
+__global__ __launch_bounds__(GS_BLOCK) void k_tile_ranges(const uint32_t *__restrict__ pkey, uint2 *__restrict__ range,
+                                                          const GsControl *ctl)
+{
+    const uint32_t I = ctl->n_pairs;
+    for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < I; p += gridDim.x * blockDim.x) {
+        const uint32_t k = pkey[p];
+        if (p == 0 || pkey[p - 1] != k) range[k].x = p;
+        if (p == I - 1 || pkey[p + 1] != k) range[k].y = p + 1;
+    }
+}
+
+// Fragment shader + blend for one 16x16 tile.  Thread t shades pixel (t%16, t/16) of the tile.
+template <bool COUNT>
+__global__ __launch_bounds__(GS_BLOCK) void k_blend(const uint2 *__restrict__ tile_range, const uint32_t *__restrict__ pval,
+                                                    const gsm::Projected *__restrict__ proj, GsFrameUniforms u,
+                                                    uint8_t *__restrict__ out, GsControl *ctl)
+{
+    __shared__ float4 s_rec[2 * GS_BLOCK];                       // 8 KiB: one batch of projected records
+    __shared__ uint32_t s_frags;
+    const uint32_t tile = blockIdx.x;
+    const uint32_t tx = tile % (uint32_t)u.tiles_x, ty = tile / (uint32_t)u.tiles_x;
+    const int x = u.x0 + (int)tx * GS_TILE + (int)(threadIdx.x & 15);
+    const int r = (int)ty * GS_TILE + (int)(threadIdx.x >> 4);     // image row, 0 = top
+    const bool inside = x < u.x1 && r < u.H;
+    const float fx = (float)x + 0.5f;                              // pixel centre, GL window coordinates
+    const float fy = (float)(u.H - 1 - r) + 0.5f;
+    const uint2 range = tile_range[tile];
+    const bool no_early = COUNT || (u.flags & GS_RENDER_NO_EARLY_OUT);
+    if (COUNT) { if (threadIdx.x == 0) s_frags = 0; }
+
+    float T = 1.0f, cr = 0.0f, cg = 0.0f, cb = 0.0f, ca = 0.0f;
+    uint32_t nfr = 0;
+    bool done = !inside;
+    for (uint32_t end = range.y; end > range.x;) {
+        const uint32_t nb = min((uint32_t)GS_BLOCK, end - range.x);
+        if (threadIdx.x < nb) {                                    // nearest first: reverse the back-to-front list
+            const uint32_t j = pval[end - 1 - threadIdx.x];
+            const float4 *src = reinterpret_cast<const float4 *>(proj + j);
+            s_rec[2 * threadIdx.x] = src[0];
+            s_rec[2 * threadIdx.x + 1] = src[1];
+        }
+        __syncthreads();
+        if (!done) {
+            for (uint32_t k = 0; k < nb; k++) {
+                const float4 a = s_rec[2 * k], b = s_rec[2 * k + 1];
+                const float q = gsm::frag_power(fx - a.x, fy - a.y, a.z, a.w, b.x, b.y);   // -A, index.js:171
+                if (q <= 4.0f) {                                                           // discard, index.js:172
+                    const float B = __expf(-q) * b.w;                                      // index.js:173
+                    const float w = B * T;
+                    const uint32_t rgba = __float_as_uint(b.z);
+                    const float w255 = w * (1.0f / 255.0f);
+                    cr = fmaf((float)(rgba & 0xFF), w255, cr);
+                    cg = fmaf((float)((rgba >> 8) & 0xFF), w255, cg);
+                    cb = fmaf((float)((rgba >> 16) & 0xFF), w255, cb);
+                    ca += w;
+                    T *= (1.0f - B);
+                    if (COUNT) nfr++;
+                    if (!no_early && T < u.t_eps) { done = true; break; }
+                }
+            }
+        }
+        end -= nb;
+        if (__syncthreads_and(done)) break;                        // also fences s_rec before the next batch
+    }
+    if (inside) {
+        // dst <- src.rgb*a + dst.rgb*(1-a), dst.a <- a + dst.a*(1-a), composed over the background
+        const float o0 = fmaf(T, u.bg[0], cr), o1 = fmaf(T, u.bg[1], cg), o2 = fmaf(T, u.bg[2], cb), o3 = fmaf(T, u.bg[3], ca);
+        const int sw = u.x1 - u.x0;
+        const int orow = (u.flags & GS_RENDER_FLIP_Y) ? (u.H - 1 - r) : r;
+        uchar4 px;
+        px.x = (uint8_t)(fminf(fmaxf(o0, 0.0f), 1.0f) * 255.0f + 0.5f);
+        px.y = (uint8_t)(fminf(fmaxf(o1, 0.0f), 1.0f) * 255.0f + 0.5f);
+        px.z = (uint8_t)(fminf(fmaxf(o2, 0.0f), 1.0f) * 255.0f + 0.5f);
+        px.w = (uint8_t)(fminf(fmaxf(o3, 0.0f), 1.0f) * 255.0f + 0.5f);
+        reinterpret_cast<uchar4 *>(out)[(size_t)orow * sw + (x - u.x0)] = px;
+    }
+    if (COUNT) {
+        if (nfr) atomicAdd(&s_frags, nfr);
+        __syncthreads();
+        if (threadIdx.x == 0 && s_frags) atomicAdd(&ctl->n_frags, (unsigned long long)s_frags);
+    }
+}
+
+int bits_for(uint32_t n) { int b = 1; while ((1u << b) < n) b++; return b; }
+
+}  // namespace
+
+int gs_run_render(gs_ctx *ctx, const GsFrameUniforms &u, uint8_t *device_out)
+{
+    const uint32_t ntiles = (uint32_t)u.tiles_x * (uint32_t)u.tiles_y;
+    const uint32_t Vmax = (uint32_t)ctx->n;
+    uint8_t *out = device_out ? device_out : ctx->fb;
+    hipStream_t st = ctx->stream;
+
+    if (ctx->profile) GS_HIP(hipEventRecord(ctx->ev[2], st));
+    hipLaunchKernelGGL(k_render_init, dim3(1), dim3(1), 0, st, ctx->ctl);
+    if (Vmax && ctx->have_sort) {
+        uint32_t g = gs_div_up(Vmax, GS_BLOCK); if (g > 8192) g = 8192;
+        hipLaunchKernelGGL(k_project, dim3(g), dim3(GS_BLOCK), 0, st, ctx->sorted, ctx->center_scale, ctx->cov_color, u, ctx->proj,
+                           ctx->rect, ctx->tile_count, ctx->ctl);
+        GS_HIP(hipGetLastError());
+        if (ctx->profile) GS_HIP(hipEventRecord(ctx->ev[3], st));
+        int rc = gs_launch_scan(ctx, ctx->tile_count, ctx->pair_off, &ctx->ctl->n_kept, 0, Vmax, nullptr);
+        if (rc != GS_OK) return rc;
+        hipLaunchKernelGGL(k_pairs_check, dim3(1), dim3(1), 0, st, ctx->ctl, (uint32_t)ctx->pair_cap);
+        uint32_t ge = gs_div_up(Vmax, GS_BLOCK); if (ge > 4096) ge = 4096;
+        hipLaunchKernelGGL(k_emit, dim3(ge), dim3(GS_BLOCK), 0, st, ctx->rect, ctx->tile_count, ctx->pair_off, (uint32_t)u.tiles_x,
+                           ctx->pkey_a, ctx->pval_a, ctx->ctl);
+        GS_HIP(hipGetLastError());
+        const int tb = bits_for(ntiles);
+        const uint32_t *fkey, *fval;
+        const uint32_t pc = (uint32_t)ctx->pair_cap;
+        if (tb <= 9) {
+            rc = gs_launch_radix_pass(ctx, ctx->pkey_a, ctx->pval_a, ctx->pkey_b, ctx->pval_b, &ctx->ctl->n_pairs, pc, 0, tb);
+            if (rc != GS_OK) return rc;
+            fkey = ctx->pkey_b; fval = ctx->pval_b;
+        } else {
+            const int b1 = (tb + 1) / 2, b2 = tb - b1;
+            rc = gs_launch_radix_pass(ctx, ctx->pkey_a, ctx->pval_a, ctx->pkey_b, ctx->pval_b, &ctx->ctl->n_pairs, pc, 0, b1);
+            if (rc != GS_OK) return rc;
+            rc = gs_launch_radix_pass(ctx, ctx->pkey_b, ctx->pval_b, ctx->pkey_a, ctx->pval_a, &ctx->ctl->n_pairs, pc, b1, b2);
+            if (rc != GS_OK) return rc;
+            fkey = ctx->pkey_a; fval = ctx->pval_a;
+        }
+        GS_HIP(hipMemsetAsync(ctx->tile_range, 0, sizeof(uint2) * ntiles, st));
+        hipLaunchKernelGGL(k_tile_ranges, dim3(2048), dim3(GS_BLOCK), 0, st, fkey, ctx->tile_range, ctx->ctl);
+        GS_HIP(hipGetLastError());
+        if (ctx->profile) GS_HIP(hipEventRecord(ctx->ev[4], st));
+        if (u.flags & GS_RENDER_COUNT_FRAGS)
+            hipLaunchKernelGGL(k_blend<true>, dim3(ntiles), dim3(GS_BLOCK), 0, st, ctx->tile_range, fval, ctx->proj, u, out, ctx->ctl);
+        else
+            hipLaunchKernelGGL(k_blend<false>, dim3(ntiles), dim3(GS_BLOCK), 0, st, ctx->tile_range, fval, ctx->proj, u, out, ctx->ctl);
+        GS_HIP(hipGetLastError());
+    } else {
+        // nothing resident / never sorted: the frame is the background
+        GS_HIP(hipMemsetAsync(ctx->tile_range, 0, sizeof(uint2) * ntiles, st));
+        if (ctx->profile) { GS_HIP(hipEventRecord(ctx->ev[3], st)); GS_HIP(hipEventRecord(ctx->ev[4], st)); }
+        hipLaunchKernelGGL(k_blend<false>, dim3(ntiles), dim3(GS_BLOCK), 0, st, ctx->tile_range, ctx->pval_a, ctx->proj, u, out, ctx->ctl);
+        GS_HIP(hipGetLastError());
+    }
+    if (ctx->profile) GS_HIP(hipEventRecord(ctx->ev[5], st));
+    return GS_OK;
+}

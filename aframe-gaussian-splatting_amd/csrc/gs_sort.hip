@@ -1,0 +1,123 @@
+// gs_sort.hip -- the worker's sortSplats (index.js:507-570) as HIP kernels.
+//
+// Bit-exact contract: view depth, min/max and the bucket scale are IEEE f64 evaluated
+// left to right without FMA (library is built -ffp-contract=off); only the stored depth is rounded to
+// f32; the result is ordered by (bucket, original index).  Culled splats are carried through the two
+// stable radix passes with key 65536 (17-bit key = 8 + 9 bit digits) instead of being compacted first:
+// they sort behind every bucket and are simply not part of the first V' outputs.  Splats whose bucket
+// falls outside [0,65535] (f32 rounding of the stored depth >> depth range) are dropped exactly like
+// the reference's out-of-bounds typed-array writes drop them: the tail [V',V) of the result is 0.
+#include "gs_internal.h"
+
+namespace {
+
+struct SortUniforms { float view[4]; float cutout[16]; int has_cutout; };
+
+__global__ void k_sort_init(GsControl *ctl, uint32_t n)
+{
+    ctl->min_enc = ~0ull; ctl->max_enc = 0ull;
+    ctl->n_total = n; ctl->n_kept = 0; ctl->n_valid = 0;
+}
+
+// pass 1 (index.js:517-555): depth, culls, f64 min/max of survivors.  16 B/splat in, 4 B/splat out.
+__global__ __launch_bounds__(GS_BLOCK) void k_sort_depth(const float4 *__restrict__ rows, uint32_t n, SortUniforms u,
+                                                         float *__restrict__ depth_out, GsControl *ctl)
+{
+    __shared__ unsigned long long s_min, s_max;
+    __shared__ uint32_t s_cnt;
+    const uint32_t nchunks = (n + GS_CHUNK - 1) / GS_CHUNK;
+    for (uint32_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
+        if (threadIdx.x == 0) { s_min = ~0ull; s_max = 0ull; s_cnt = 0; }
+        __syncthreads();
+        unsigned long long mn = ~0ull, mx = 0ull;
+        uint32_t cnt = 0;
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const uint32_t i = c * GS_CHUNK + r * GS_BLOCK + threadIdx.x;
+            if (i < n) {
+                const float4 m = rows[i];
+                const double d = gsm::view_depth(u.view, m.x, m.y, m.z);
+                const bool inside = u.has_cutout ? gsm::in_cutout(u.cutout, m.x, m.y, m.z) : true;
+                const bool keep = gsm::sort_keep(d, m.w, inside);
+                depth_out[i] = keep ? (float)d : INFINITY;
+                if (keep) {
+                    const unsigned long long e = gsm::f64_to_ordered(d);
+                    mn = e < mn ? e : mn; mx = e > mx ? e : mx; cnt++;
+                }
+            }
+        }
+        if (cnt) { atomicMin(&s_min, mn); atomicMax(&s_max, mx); atomicAdd(&s_cnt, cnt); }
+        __syncthreads();
+        if (threadIdx.x == 0 && s_cnt) {
+            atomicMin(&ctl->min_enc, s_min); atomicMax(&ctl->max_enc, s_max); atomicAdd(&ctl->n_kept, s_cnt);
+        }
+        __syncthreads();
+    }
+}
+
+// pass 2 (index.js:558-561): 16-bit bucket of the stored depth; culled/dropped -> GS_CULLED_KEY
+__global__ __launch_bounds__(GS_BLOCK) void k_sort_bucket(const float *__restrict__ depth, uint32_t n, uint32_t *__restrict__ keys,
+                                                          GsControl *ctl)
+{
+    __shared__ uint32_t s_cnt;
+    const double mn = gsm::ordered_to_f64(ctl->min_enc), mx = gsm::ordered_to_f64(ctl->max_enc);
+    const double inv = 65535.0 / (mx - mn);                       // (256*256-1)/(maxDepth-minDepth)
+    const uint32_t nchunks = (n + GS_CHUNK - 1) / GS_CHUNK;
+    for (uint32_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
+        if (threadIdx.x == 0) s_cnt = 0;
+        __syncthreads();
+        uint32_t cnt = 0;
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const uint32_t i = c * GS_CHUNK + r * GS_BLOCK + threadIdx.x;
+            if (i < n) {
+                const float d = depth[i];
+                uint32_t k = GS_CULLED_KEY;
+                if (d != INFINITY) {
+                    const int32_t b = gsm::sort_bucket(d, mn, inv);
+                    if (b >= 0) { k = (uint32_t)b; cnt++; }
+                }
+                keys[i] = k;
+            }
+        }
+        if (cnt) atomicAdd(&s_cnt, cnt);
+        __syncthreads();
+        if (threadIdx.x == 0 && s_cnt) atomicAdd(&ctl->n_valid, s_cnt);
+        __syncthreads();
+    }
+}
+
+// the reference's unfilled tail: Uint32Array(V) slots never written stay 0
+__global__ void k_sort_tail(uint32_t *sorted, const GsControl *ctl)
+{
+    const uint32_t lo = ctl->n_valid, hi = ctl->n_kept;
+    for (uint32_t p = lo + blockIdx.x * blockDim.x + threadIdx.x; p < hi; p += gridDim.x * blockDim.x) sorted[p] = 0;
+}
+
+}  // namespace
+
+int gs_run_sort(gs_ctx *ctx, const float view[4], const float *cutout16)
+{
+    const uint32_t n = (uint32_t)ctx->n;
+    SortUniforms u;
+    memcpy(u.view, view, sizeof u.view);
+    u.has_cutout = cutout16 != nullptr;
+    if (cutout16) memcpy(u.cutout, cutout16, sizeof u.cutout); else memset(u.cutout, 0, sizeof u.cutout);
+
+    uint32_t g = gs_div_up(n, GS_CHUNK); if (g > 2048) g = 2048; if (g < 1) g = 1;
+    if (ctx->profile) GS_HIP(hipEventRecord(ctx->ev[0], ctx->stream));
+    hipLaunchKernelGGL(k_sort_init, dim3(1), dim3(1), 0, ctx->stream, ctx->ctl, n);
+    hipLaunchKernelGGL(k_sort_depth, dim3(g), dim3(GS_BLOCK), 0, ctx->stream, ctx->sort_rows, n, u, ctx->depth, ctx->ctl);
+    hipLaunchKernelGGL(k_sort_bucket, dim3(g), dim3(GS_BLOCK), 0, ctx->stream, ctx->depth, n, ctx->key_a, ctx->ctl);
+    GS_HIP(hipGetLastError());
+    int rc = gs_launch_radix_pass(ctx, ctx->key_a, nullptr, ctx->key_b, ctx->val_b, &ctx->ctl->n_total, n, 0, 8);
+    if (rc != GS_OK) return rc;
+    rc = gs_launch_radix_pass(ctx, ctx->key_b, ctx->val_b, nullptr, ctx->val_a, &ctx->ctl->n_total, n, 8, 9);
+    if (rc != GS_OK) return rc;
+    hipLaunchKernelGGL(k_sort_tail, dim3(64), dim3(GS_BLOCK), 0, ctx->stream, ctx->val_a, ctx->ctl);
+    GS_HIP(hipGetLastError());
+    if (ctx->profile) GS_HIP(hipEventRecord(ctx->ev[1], ctx->stream));
+    ctx->sorted = ctx->val_a;
+    ctx->have_sort = true;
+    return GS_OK;
+}

@@ -1,0 +1,198 @@
+#!/usr/bin/env python3
+"""bench.py -- frames/s of the hot path (sort -> project -> bin -> blend [-> strip gather]) on MI355X.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A "step" is one frame of the 120-frame benchmark orbit (entity yaw 0..360 deg, index.html:13 pose) over the
+synthetic train.splat-shaped scene (N = 1,048,576 splats, 1920x1080; BASELINE.json configs[1]): a bit-exact
+gs_sort for the frame's view vector followed by a full render, splat data already resident in HBM.  With N > 1 GPUs
+the viewport is split into tile-aligned column strips (splat buffer replicated, sort + project replicated on every
+GPU), each rank renders its strip into a device tensor and the strips are gathered to rank 0 over RCCL.
+
+Rank 0 prints ONE JSON line.  `value` = frames/s of the whole job; extra keys give Msplat-frags/s (reference-
+equivalent fragments, counted untimed by the GS_RENDER_COUNT_FRAGS variant), the per-stage GPU times from HIP
+events on the library's stream, the roofline of the dominant kernel and the CPU baseline.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+PKG = "aframe-gaussian-splatting_amd"
+HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6290 GB/s measured copy peak
+ORBIT_FRAMES = 120
+W, H = 1920, 1080
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=120)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--splats", type=int, default=None, help="override N (default: train.splat-shaped 1,048,576)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = torch = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    capi = importlib.import_module(PKG + ".capi")
+    synth = importlib.import_module(PKG + ".synth")
+
+    n_splats = args.splats or synth.N_TRAIN
+    rows = synth.make_splat_rows(n_splats)
+    ctx = capi.Context(local_rank)
+    ctx.push_splat(rows)
+
+    # tile-aligned column strips
+    tiles_x = (W + 15) // 16
+    t0, t1 = tiles_x * rank // world, tiles_x * (rank + 1) // world
+    x0, x1 = t0 * 16, min(t1 * 16, W)
+    sw_max = max(min(tiles_x * (r + 1) // world * 16, W) - tiles_x * r // world * 16 for r in range(world))
+
+    cams = [synth.index_html_camera(W, H, 360.0 * i / ORBIT_FRAMES, capi=capi) for i in range(ORBIT_FRAMES)]
+    params = [capi.make_params(c["gs_mv"], c["gs_proj"], W, H, x0=x0, x1=x1, focal_=c["focal"]) for c in cams]
+    strip = gathered = None
+    if world > 1:
+        strip = torch.zeros(H * sw_max * 4, dtype=torch.uint8, device="cuda")      # tight H x sw x 4 rows at the front
+        gathered = [torch.zeros_like(strip) for _ in range(world)] if rank == 0 else None
+    widths = [min(tiles_x * (r + 1) // world * 16, W) - tiles_x * r // world * 16 for r in range(world)]
+
+    def frame(i, flags=0):
+        k = i % ORBIT_FRAMES
+        ctx.sort(cams[k]["view"], want_indices=False)
+        p = params[k]
+        p.flags = flags
+        if world > 1:
+            ctx.render_device(p, strip.data_ptr())          # returns with the strip complete in HBM
+            dist.gather(strip, gathered, dst=0)
+            if rank == 0:
+                return torch.cat([g[: H * widths[r] * 4].view(H, widths[r], 4) for r, g in enumerate(gathered)], dim=1)
+        else:
+            ctx.render_device(p, None)
+        return None
+
+    def sync():
+        ctx.sync()
+        if world > 1:
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    # reference-equivalent fragments per orbit frame (untimed; no early termination)
+    frames_used = sorted(set((args.warmup + i) % ORBIT_FRAMES for i in range(args.steps)))
+    frags = {}
+    for k in frames_used:
+        ctx.sort(cams[k]["view"], want_indices=False)
+        p = params[k]
+        p.flags = capi.RENDER_COUNT_FRAGS
+        ctx.render_device(p, strip.data_ptr() if world > 1 else None)
+        frags[k] = ctx.stats()["n_frags"]
+        p.flags = 0
+    if world > 1:
+        t = torch.tensor([frags[k] for k in frames_used], dtype=torch.int64, device="cuda")
+        dist.all_reduce(t)
+        frags = dict(zip(frames_used, t.tolist()))
+
+    for i in range(args.warmup):
+        frame(i)
+    # ---- timed region: exactly K steps, barrier + synchronize on both sides
+    ctx.set_option(capi.OPT_PROFILE, 1)
+    stage = {"ms_sort": 0.0, "ms_project": 0.0, "ms_bin": 0.0, "ms_blend": 0.0}
+    pairs = visible = sorted_n = 0
+    sync()
+    t_start = time.perf_counter()
+    for i in range(args.steps):
+        frame(args.warmup + i)
+        s = ctx.stats()                                     # host-side struct copy, no GPU work
+        for key in stage:
+            stage[key] += s[key]
+        pairs += s["n_pairs"]; visible += s["n_visible"]; sorted_n += s["n_sorted"]
+    sync()
+    elapsed = time.perf_counter() - t_start
+    ctx.set_option(capi.OPT_PROFILE, 0)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    total_frags = sum(frags[(args.warmup + i) % ORBIT_FRAMES] for i in range(args.steps))
+    if rank == 0:
+        K = args.steps
+        fps = K / elapsed
+        sw = x1 - x0
+        # dominant kernel = the per-tile blend.  Algorithmic bytes per launch:
+        #   B_blend = I*(4 + 32) (pair list entry + projected record, read once per tile) + 4*fb (RGBA8 write)
+        blend_bytes = (pairs / K) * 36.0 + 4.0 * sw * H
+        blend_s = stage["ms_blend"] / K * 1e-3
+        achieved = blend_bytes / blend_s / 1e9 if blend_s > 0 else 0.0
+        # whole-frame algorithmic bytes (SURVEY.md 8d formula)
+        V, Vp, I = sorted_n / K, visible / K, pairs / K
+        frame_bytes = (16 * n_splats + 4 * V) + (Vp * 36 + V * 4 + Vp * 32) + (I * 20) + (I * 36 + 4 * sw * H)
+        out = {
+            "metric": "frames/sec @1920x1080 (sort+project+bin+blend per frame, 1M-splat train.splat-shaped scene)",
+            "value": round(fps, 3), "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / K * 1e3, 4), "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "train.splat-shaped synthetic, N=%d splats, %dx%d, 120-frame orbit (index.html:13 pose)" % (n_splats, W, H),
+                       "parallelism": "column strips x%d, splat buffer replicated, RCCL gather" % world if world > 1 else "single GPU",
+                       "strip_px": sw},
+            "msplat_frags_per_s": round(total_frags / 1e6 / elapsed, 1),
+            "frags_per_frame": round(total_frags / K),
+            "per_frame": {"V_sorted": round(V), "Vp_visible": round(Vp), "I_pairs": round(I),
+                          "ms_sort": round(stage["ms_sort"] / K, 4), "ms_project": round(stage["ms_project"] / K, 4),
+                          "ms_bin": round(stage["ms_bin"] / K, 4), "ms_blend": round(stage["ms_blend"] / K, 4)},
+            "frame_hbm": {"algorithmic_bytes": round(frame_bytes), "achieved_GBps": round(frame_bytes * fps / 1e9, 1),
+                          "frac_of_peak": round(frame_bytes * fps / 1e9 / HBM_PEAK_GBS, 5)},
+            "roofline": {"kernel": "k_blend", "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "bytes_per_launch": round(blend_bytes), "avg_launch_ms": round(blend_s * 1e3, 4)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(rows, cams[args.warmup % ORBIT_FRAMES], synth)
+        print(json.dumps(out), flush=True)
+    ctx.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(rows, cam, synth):
+    """The oracle (C restatement of the reference's CPU sort + WebGL path, single thread like the reference's one
+    Worker) timed on this host: 5 sorts of the full scene + one 1/8-width centre strip of frame `warmup` rendered
+    back-to-front.  frames/s = 1 / (t_sort + 8 * t_strip)."""
+    from oracle import oracle
+    cs, cc, mats = oracle.pack(rows)
+    rows4 = np.ascontiguousarray(mats[:, 12:16])
+    ts = []
+    for _ in range(5):
+        t = time.perf_counter(); idx = oracle.sort(rows4, cam["view"]); ts.append(time.perf_counter() - t)
+    t_sort = float(np.median(ts))
+    t = time.perf_counter()
+    _, _, fr = oracle.render(cs, cc, idx, cam["gs_mv"].astype(np.float32), cam["gs_proj"].astype(np.float32), cam["focal"], W, H,
+                             x0=840, x1=1080, want_f32=False)
+    t_strip = time.perf_counter() - t
+    return {"value": round(1.0 / (t_sort + 8 * t_strip), 5), "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": "oracle/gs_oracle.c, 1 thread: median of 5 sorts of all %d splats (%.1f ms, %.1f Msplat/s) + one 240-px "
+                      "centre strip of one 1080p frame (%.2f s, %d frags) scaled x8" % (rows4.shape[0], t_sort * 1e3,
+                                                                                      rows4.shape[0] / t_sort / 1e6, t_strip, fr),
+            "sort_msplat_per_s": round(rows4.shape[0] / t_sort / 1e6, 2), "host_cpus": os.cpu_count()}
+
+
+if __name__ == "__main__":
+    main()

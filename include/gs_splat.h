@@ -1,0 +1,172 @@
+/*
+ * gs_splat.h -- C ABI of the MI355X-native Gaussian-splat hot path.
+ *
+ * Drop-in boundary for the hot path of the A-Frame `gaussian_splatting`
+ * component (reference: quadjr/aframe-gaussian-splatting, file index.js).
+ * Every entry point names the reference interface it replaces (file:line).
+ * Plain pointers and sizes only; no C++ / torch types.  All functions return
+ * GS_OK (0) or a negative gs_status; the message for the last failure on a
+ * context is available from gs_last_error().
+ *
+ * Threading: a gs_ctx is single-caller (the reference is single-flight too:
+ * `sortReady`, index.js:206/220/439-440).  Several contexts may coexist (the
+ * reference allows several component instances per page, cutout-demo.html:24-25).
+ *
+ * There is NO CPU fallback: if no HIP device is usable gs_create() fails with
+ * GS_E_NODEVICE / GS_E_HIP and nothing else can be called.
+ */
+#ifndef GS_SPLAT_H
+#define GS_SPLAT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GS_API __attribute__((visibility("default")))
+
+typedef struct gs_ctx gs_ctx;
+
+typedef enum gs_status {
+    GS_OK = 0,
+    GS_E_BADARG = -1,      /* null / out-of-range argument                                              */
+    GS_E_PLY_HEADER = -2,  /* "Unable to read .ply file header"           (index.js:606-607)            */
+    GS_E_PLY_PROP = -3,    /* "<prop> not found"                          (index.js:643)                */
+    GS_E_HIP = -4,         /* a HIP runtime call failed                                                 */
+    GS_E_OOM = -5,         /* host or device allocation failed                                          */
+    GS_E_NODEVICE = -6,    /* no usable gfx950 device                                                   */
+    GS_E_STATE = -7,       /* call not valid in this state (e.g. render after matrices-only push)       */
+    GS_E_PLY_DATA = -8     /* vertex data shorter than the header promises (DataView RangeError in JS)  */
+} gs_status;
+
+/* ---- lifetime ----------------------------------------------------------------------------------- */
+
+/* One context = one component instance on one GPU (replaces the Worker spawn + GL resource creation,
+ * index.js:229-236 and initGL index.js:25-66).  `device` is the HIP device ordinal. */
+GS_API int gs_create(int device, gs_ctx **out);
+GS_API int gs_destroy(gs_ctx *ctx);
+/* Last error text for ctx; ctx == NULL returns the last gs_create() failure of the calling thread. */
+GS_API const char *gs_last_error(const gs_ctx *ctx);
+/* Library/ABI version, e.g. 0x000100 = 0.1.0 */
+GS_API uint32_t gs_version(void);
+
+/* ---- data ingest (reference: worker `clear`/`push`, pushDataBuffer, processPlyBuffer) --------------- */
+
+/* worker {method:"clear"} (index.js:573-575) + loadedVertexCount = 0 (index.js:226). */
+GS_API int gs_clear(gs_ctx *ctx);
+
+/* pushDataBuffer(buffer, vertexCount) (index.js:328-437): append `nrows` 32-byte .splat rows
+ * (f32 pos[3], f32 scale[3], u8 rgba[4], u8 quat_wxyz[4]).  Packs on the GPU, bit-exactly as the
+ * reference does, into the 16 B centre/scale record, the 16 B covariance/colour record and the
+ * worker's sort row.  Rows are borrowed for the duration of the call. */
+GS_API int gs_push_splat(gs_ctx *ctx, const void *rows, size_t nrows);
+
+/* worker {method:"push", matrices} (index.js:576-586): append `nrows` 16-float worker rows; only
+ * elements 12..15 are read, as in sortSplats (index.js:520-548).  A context fed this way can sort
+ * but not render. */
+GS_API int gs_push_matrices(gs_ctx *ctx, const float *matrices, size_t nrows);
+
+/* processPlyBuffer(inputBuffer) (index.js:600-745) followed by pushDataBuffer: parse a binary
+ * little-endian PLY, order rows by importance, convert to .splat rows, append. */
+GS_API int gs_load_ply(gs_ctx *ctx, const void *bytes, size_t nbytes);
+
+/* processPlyBuffer alone (host side): PLY bytes -> .splat rows.  Call with out_rows == NULL to get
+ * *out_nrows, then again with a buffer of 32 * *out_nrows bytes.  err (optional) receives the message
+ * the reference would throw. */
+GS_API int gs_ply_to_splat(const void *bytes, size_t nbytes, void *out_rows, size_t *out_nrows, char *err,
+                           size_t errlen);
+
+/* Number of splats resident (reference: loadedVertexCount / matrices.length/16). */
+GS_API size_t gs_count(const gs_ctx *ctx);
+
+/* ---- sort (reference: worker {method:"sort"} -> sortSplats, index.js:507-570, 587-596) --------------- */
+
+/* view = row 2 of gsModelViewMatrix (index.js:441-442); cutout16 = column-major object->unit-box
+ * matrix or NULL (index.js:443-452).  The order is kept on the device for gs_render().
+ * out_idx (optional, capacity >= max(gs_count(),1)) receives the reference's Uint32Array bit-exactly,
+ * *out_n its length.  Before any push the reference answers Uint32Array(1) = [0] (index.js:588-590):
+ * so does this (out_n = 1, out_idx[0] = 0). */
+GS_API int gs_sort(gs_ctx *ctx, const float view[4], const float *cutout16, uint32_t *out_idx, uint32_t *out_n);
+
+/* ---- render (reference: vertex shader + rasteriser + fragment shader + blend, index.js:77-195) ------- */
+
+#define GS_RENDER_FLIP_Y 1u      /* rows bottom-up (WebGL readPixels order) instead of top-down              */
+#define GS_RENDER_COUNT_FRAGS 2u /* no early termination; count reference-equivalent splat-fragments         */
+#define GS_RENDER_NO_EARLY_OUT 4u/* blend every fragment (parity debugging)                                   */
+
+typedef struct gs_render_params {
+    float model_view[16]; /* gsModelViewMatrix, column-major (getModelViewMatrix, index.js:467-487)      */
+    float projection[16]; /* gsProjectionMatrix, column-major (getProjectionMatrix, index.js:456-466)    */
+    int32_t fb_width;     /* `viewport` uniform, device pixels (index.js:189-193)                        */
+    int32_t fb_height;
+    int32_t x0, x1;       /* column strip [x0,x1) to produce; x0 = 0, x1 = fb_width for the whole frame  */
+    float focal;          /* `focal` uniform; <= 0: computed as fb_height/2*|projection[5]| (index.js:191) */
+    float background[4];  /* destination before blending; demos: opaque black sky (index.html:14)        */
+    uint32_t flags;       /* GS_RENDER_*                                                                  */
+} gs_render_params;
+
+/* Draw the last gs_sort() order into a tightly described RGBA8 image in caller-owned host memory.
+ * rgba_out: (x1-x0) x fb_height pixels, `stride` bytes per row (0 = tight), row 0 = top. */
+GS_API int gs_render(gs_ctx *ctx, const gs_render_params *p, uint8_t *rgba_out, size_t stride);
+/* Same, but the strip stays on the GPU: device_rgba is a device pointer (e.g. a torch tensor's
+ * data_ptr, tight rows) or NULL to render into the context's own framebuffer only. */
+GS_API int gs_render_device(gs_ctx *ctx, const gs_render_params *p, void *device_rgba);
+/* XR: two eyes share one sort order from the head camera (index.js:441) -- two params, two images. */
+GS_API int gs_render_stereo(gs_ctx *ctx, const gs_render_params eyes[2], uint8_t *rgba_out[2], size_t stride);
+
+/* Block until all work queued on the context's stream is done. */
+GS_API int gs_sync(gs_ctx *ctx);
+/* Run the context's kernels on a caller-owned hipStream_t (e.g. torch's current stream). NULL = own stream. */
+GS_API int gs_set_stream(gs_ctx *ctx, void *hip_stream);
+
+/* ---- uniforms / camera helpers (host side; reference: tick + camera matrices, index.js:438-487) ------ */
+
+/* getModelViewMatrix: camera.matrixWorld, object.matrixWorld (column-major f64) -> gsModelViewMatrix */
+GS_API void gs_model_view_matrix(const double cam_world[16], const double obj_world[16], double out[16]);
+/* getProjectionMatrix: camera.projectionMatrix -> gsProjectionMatrix */
+GS_API void gs_projection_matrix(const double proj[16], double out[16]);
+/* tick: the two messages posted to the worker: view[4] and (if cutout_world != NULL) cutout[16] */
+GS_API void gs_tick_uniforms(const double cam_world[16], const double obj_world[16], const double *cutout_world,
+                             float view[4], float cutout[16]);
+/* onBeforeRender focal (index.js:191) */
+GS_API double gs_focal(const double gs_proj[16], double viewport_h);
+/* init: pixelRatio / xrPixelRatio (index.js:10-15): drawing-buffer size = floor(css * ratio) when ratio > 0 */
+GS_API void gs_scaled_size(int css_w, int css_h, double ratio, int *out_w, int *out_h);
+
+/* ---- stats / introspection ---------------------------------------------------------------------- */
+
+typedef struct gs_stats {
+    uint64_t n_splats;    /* N resident                                                               */
+    uint64_t n_sorted;    /* V  = length of the last sort result                                      */
+    uint64_t n_visible;   /* Vp = splats surviving the vertex-shader culls in the last render          */
+    uint64_t n_pairs;     /* I  = (tile,splat) pairs binned in the last render                         */
+    uint64_t n_frags;     /* reference-equivalent fragments (last GS_RENDER_COUNT_FRAGS render)        */
+    uint64_t n_tiles;     /* tiles in the last rendered strip                                         */
+    float ms_sort;        /* GPU time of the last gs_sort (HIP events; 0 unless profiling is on)       */
+    float ms_project;
+    float ms_bin;
+    float ms_blend;
+    float ms_render;      /* project + bin + blend                                                    */
+    uint32_t blend_launches;
+} gs_stats;
+
+#define GS_OPT_PROFILE 1        /* value != 0: bracket stages with HIP events on the context stream        */
+#define GS_OPT_TERMINATION 2    /* value = 1/eps for the transmittance early-out (default 4096)          */
+GS_API int gs_set_option(gs_ctx *ctx, int option, int64_t value);
+GS_API int gs_get_stats(gs_ctx *ctx, gs_stats *out);
+
+/* Copy a device-resident array back to the host (parity tests / debugging). */
+#define GS_BUF_CENTER_SCALE 0 /* N x 4 f32   centerAndScaleData                                         */
+#define GS_BUF_COV_COLOR 1    /* N x 4 u32   covAndColorData                                            */
+#define GS_BUF_SORT_ROWS 2    /* N x 4 f32   worker row elements 12..15                                 */
+#define GS_BUF_SORTED 3       /* V u32       last sort result                                           */
+#define GS_BUF_PROJECTED 4    /* V x 8 f32   projected records of the last render (sorted order)         */
+#define GS_BUF_TILE_COUNT 5   /* V u32       tiles touched per sorted splat in the last render            */
+GS_API int gs_download(gs_ctx *ctx, int which, void *out, size_t nbytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GS_SPLAT_H */

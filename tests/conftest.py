@@ -9,6 +9,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 GOLDEN = os.path.join(ROOT, "tests", "golden")
+PKG_NAME = "aframe-gaussian-splatting_amd"
+
+
+def pkg(sub=None):
+    """The product package (hyphenated directory name -> importlib)."""
+    import importlib
+    return importlib.import_module(PKG_NAME + ("." + sub if sub else ""))
 
 
 def pytest_configure(config):

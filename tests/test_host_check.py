@@ -1,0 +1,93 @@
+"""CPU tier: the product's per-splat arithmetic header (csrc/gs_device_math.h) compiled for the host
+by tests/host_check/ and compared with golden vectors / the oracle.  This validates the formulas the HIP
+kernels execute before any GPU time is spent; it is not a product path (the library has no CPU fallback)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, cases_of, load_case, pkg
+from oracle import oracle
+
+HC_DIR = os.path.join(ROOT, "tests", "host_check")
+CSRC = os.path.join(ROOT, "aframe-gaussian-splatting_amd", "csrc")
+
+
+@pytest.fixture(scope="module")
+def hc():
+    so = os.path.join(HC_DIR, "libhost_check.so")
+    srcs = [os.path.join(HC_DIR, "host_check.cpp"), os.path.join(CSRC, "gs_device_math.h"), os.path.join(CSRC, "gs_host_tables.h")]
+    if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fvisibility=hidden",
+                               "-I", CSRC, "-o", so, srcs[0]])
+    L = C.CDLL(so)
+    L.hc_sort.restype = C.c_size_t
+    L.hc_sort.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.hc_pack.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.hc_project.restype = C.c_int
+    L.hc_project.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_void_p]
+    L.hc_frag_power.restype = C.c_float
+    L.hc_frag_power.argtypes = [C.c_float] * 6
+    L.hc_toint32.restype = C.c_int32
+    L.hc_toint32.argtypes = [C.c_double]
+    return L
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+@pytest.mark.parametrize("name", cases_of("sort"))
+def test_sort_keys_match_reference(hc, name):
+    c = load_case(name)
+    rows = np.ascontiguousarray(c["rows4"], np.float32)
+    n = rows.size // 4
+    out = np.zeros(max(n, 1), np.uint32)
+    cut = c.get("cutout")
+    v = hc.hc_sort(_p(rows), n, _p(c["view"]), _p(cut), _p(out))
+    assert v == c["sorted"].size
+    assert np.array_equal(out[:v], c["sorted"])
+
+
+@pytest.mark.parametrize("name", cases_of("pack"))
+def test_pack_matches_reference(hc, name):
+    c = load_case(name)
+    rows = np.ascontiguousarray(c["rows"])
+    n = rows.size // 32
+    cs = np.zeros(n * 4, np.float32); cc = np.zeros(n * 4, np.uint32); sr = np.zeros(n * 4, np.float32)
+    hc.hc_pack(_p(rows), n, _p(cs), _p(cc), _p(sr))
+    assert np.array_equal(cs.view(np.uint32), c["center_scale"].view(np.uint32))
+    assert np.array_equal(cc, c["cov_color"])
+    ref_rows = c["matrices"].reshape(-1, 16)[:, 12:16].reshape(-1)
+    assert np.array_equal(sr.view(np.uint32), np.ascontiguousarray(ref_rows).view(np.uint32))
+
+
+def test_toint32(hc):
+    for d, want in [(0.0, 0), (-0.9, 0), (65535.99, 65535), (-1.0, -1), (-393.7, -393), (2.0**31, -2**31), (2.0**32 + 5, 5),
+                    (-(2.0**32) - 7, -7), (float("inf"), 0), (float("nan"), 0), (1e300, 0), (2.0**53 + 2, 2), (4294967295.0, -1)]:
+        assert hc.hc_toint32(d) == want, d
+
+
+def test_project_matches_oracle_bit_exact(hc):
+    synth = pkg("synth")
+    rows = synth.make_splat_rows(3000, seed=5)
+    cs, cc, _ = oracle.pack(rows)
+    cam = synth.index_html_camera(1920, 1080, yaw_deg=23.0)
+    mv = cam["gs_mv"].astype(np.float32); P = cam["gs_proj"].astype(np.float32)
+    focal = np.float32(cam["focal"])
+    out = np.zeros(17, np.float32)
+    nvis = 0
+    for i in range(cs.shape[0]):
+        o = oracle.project(cs, cc, i, mv, P, focal, 1920, 1080)
+        vis = hc.hc_project(_p(cs), _p(cc), i, _p(mv), _p(P), focal, 1920.0, 1080.0, _p(out))
+        assert vis == o.visible, i
+        if vis:
+            nvis += 1
+            want = np.array([o.cx, o.cy, o.ax, o.ay, o.bx, o.by, o.v1x, o.v1y, o.v2x, o.v2y, o.zndc, o.alpha], np.float32)
+            assert np.array_equal(out[:12].view(np.uint32), want.view(np.uint32)), i
+            # conservative bounds really contain the ellipse extent
+            hw = 2 * np.sqrt(np.float64(o.v1x) ** 2 + np.float64(o.v2x) ** 2)
+            assert out[13] <= np.ceil(o.cx - hw - 0.5) and out[14] >= np.floor(o.cx + hw - 0.5)
+    assert nvis > 500
