@@ -220,9 +220,10 @@ class Context:
 
     # render
     def render(self, params, flip=False):
-        sw = params.x1 - params.x0
-        out = np.zeros((params.fb_height, sw, 4), np.uint8)
-        self._ck(self._L.gs_render(self._h, C.byref(params), _p(out), 0))
+        sw = max(params.x1 - params.x0, 0)
+        out = np.zeros((max(params.fb_height, 0), sw, 4), np.uint8)
+        scratch = out if out.size else np.zeros(4, np.uint8)          # let the library reject bad sizes itself
+        self._ck(self._L.gs_render(self._h, C.byref(params), _p(scratch), 0))
         return out
 
     def render_device(self, params, device_ptr=None):

@@ -203,6 +203,7 @@ def test_empty_and_degenerate(ctx):
     with pytest.raises(capi.GsError) as ei:
         ctx.render(_params(cam))
     assert ei.value.code == capi.E_STATE
+    ctx.clear()
     with pytest.raises(capi.GsError) as ei:
         ctx.render(capi.make_params(cam["gs_mv"], cam["gs_proj"], 64, 48, x0=10, x1=5))
     assert ei.value.code == capi.E_BADARG
