@@ -1,0 +1,175 @@
+// gaussian_splatting.js -- host side of the drop-in, in the reference's own language.
+//
+// A headless mirror of the A-Frame `gaussian_splatting` component surface (reference index.js:1-23 schema/init,
+// 222 loadData, 328 pushDataBuffer, 438 tick, 456/467 camera matrices, 488 createWorker, 600 processPlyBuffer):
+// same property names and defaults, same method names, same worker message protocol -- but the Worker sort and
+// the WebGL draw are replaced by the MI355X HIP path behind the N-API addon (gs_splat_napi.node -> libgs_splat_hip.so),
+// and `render()` returns the RGBA framebuffer that three.js would have drawn.
+//
+// camera / object arguments are duck-typed like three.js objects: {matrixWorld: {elements[16]},
+// projectionMatrix: {elements[16]}} (column-major).  There is no JS fallback for the hot path.
+'use strict';
+const fs = require('fs');
+const native = require('./gs_splat_napi.node');
+
+const schema = {                                   // index.js:2-7
+  src: { type: 'string', default: 'train.splat' },
+  cutoutEntity: { type: 'selector' },
+  pixelRatio: { type: 'number', default: 1 },
+  xrPixelRatio: { type: 'number', default: 0.5 },
+};
+const ROW_LENGTH = 3 * 4 + 3 * 4 + 4 + 4;          // index.js:227
+
+function elementsOf(m) { return m && m.elements ? m.elements : m; }
+
+class GaussianSplatting {
+  constructor(data, options) {
+    this.data = Object.assign({ src: schema.src.default, cutoutEntity: null, pixelRatio: schema.pixelRatio.default,
+      xrPixelRatio: schema.xrPixelRatio.default }, data || {});
+    this.device = (options && options.device) || 0;
+    this.handle = native.create(this.device);       // replaces `new Worker(...)` + GL resource creation
+    this.loadedVertexCount = 0;
+    this.rowLength = ROW_LENGTH;
+    this.sortReady = true;
+    this.instanceCount = 0;
+    this.sortedIndexes = null;
+    this.cutout = null;
+  }
+
+  // init (index.js:8-23): resolution properties are only applied when > 0; the cutout entity is resolved to its object3D.
+  init(sceneEl) {
+    const r = sceneEl && sceneEl.renderer;
+    if (r && this.data.pixelRatio > 0 && r.setPixelRatio) r.setPixelRatio(this.data.pixelRatio);
+    if (r && this.data.xrPixelRatio > 0 && r.xr && r.xr.setFramebufferScaleFactor) r.xr.setFramebufferScaleFactor(this.data.xrPixelRatio);
+    if (this.data.cutoutEntity) this.cutout = this.data.cutoutEntity.object3D || this.data.cutoutEntity;
+    return this;
+  }
+
+  // drawing-buffer size the reference would get from renderer.setPixelRatio / xr.setFramebufferScaleFactor
+  framebufferSize(cssWidth, cssHeight, xr) {
+    const [w, h] = native.scaledSize(cssWidth, cssHeight, xr ? this.data.xrPixelRatio : this.data.pixelRatio);
+    return { width: w, height: h };
+  }
+
+  // loadData (index.js:222-327).  No network on the target: `src` is a path or file:// URL.  `.splat` files are
+  // ingested progressively chunk by chunk exactly like the streaming branch (index.js:279-298); `.ply` is read whole,
+  // converted by processPlyBuffer, then pushed (index.js:305-325).
+  async loadData(camera, object, renderer, src, chunkBytes) {
+    this.camera = camera; this.object = object; this.renderer = renderer;
+    this.loadedVertexCount = 0;
+    native.clear(this.handle);                       // worker.postMessage({method: "clear"})
+    const file = String(src || this.data.src).replace(/^file:\/\//, '');
+    const isPly = file.endsWith('.ply');
+    const total = fs.statSync(file).size;
+    const fd = fs.openSync(file, 'r');
+    try {
+      if (isPly) {
+        const all = Buffer.alloc(total); fs.readSync(fd, all, 0, total, 0);
+        const rows = this.processPlyBuffer(all.buffer.slice(all.byteOffset, all.byteOffset + total));
+        this.pushDataBuffer(rows, Math.floor(rows.byteLength / this.rowLength));
+      } else {
+        const step = chunkBytes || (1 << 22);
+        let pending = Buffer.alloc(0), pos = 0;
+        while (pos < total) {
+          const buf = Buffer.alloc(Math.min(step, total - pos));
+          fs.readSync(fd, buf, 0, buf.length, pos); pos += buf.length;
+          pending = pending.length ? Buffer.concat([pending, buf]) : buf;
+          if (pending.length > this.rowLength) {     // bytesRemains > rowLength (index.js:280)
+            const vertexCount = Math.floor(pending.length / this.rowLength), used = vertexCount * this.rowLength;
+            const ab = pending.buffer.slice(pending.byteOffset, pending.byteOffset + used);
+            this.pushDataBuffer(ab, vertexCount);
+            pending = pending.slice(used);
+          }
+        }
+        if (pending.length >= this.rowLength) {
+          const n = Math.floor(pending.length / this.rowLength);
+          this.pushDataBuffer(pending.buffer.slice(pending.byteOffset, pending.byteOffset + n * this.rowLength), n);
+        }
+      }
+    } finally { fs.closeSync(fd); }
+    this.sortReady = true;
+    return this.loadedVertexCount;
+  }
+
+  // pushDataBuffer (index.js:328-437): pack + upload + worker push, all on the GPU side now.
+  pushDataBuffer(buffer, vertexCount) {
+    if (vertexCount <= 0) return;
+    native.pushSplat(this.handle, buffer, vertexCount);
+    this.loadedVertexCount += vertexCount;
+  }
+
+  // tick (index.js:438-455) + the worker reply handler (index.js:201-207), single flight.
+  tick() {
+    if (!this.sortReady) return;
+    this.sortReady = false;
+    try {
+      const u = this._tickUniforms();
+      const indexes = native.sort(this.handle, u.view, u.cutout);
+      this.sortedIndexes = indexes;
+      this.instanceCount = indexes.length;
+    } finally { this.sortReady = true; }
+  }
+
+  _tickUniforms() {
+    return native.tickUniforms(elementsOf(this.camera.matrixWorld), elementsOf(this.object.matrixWorld),
+      this.cutout ? elementsOf(this.cutout.matrixWorld) : undefined);
+  }
+
+  getProjectionMatrix(camera) {                      // index.js:456-466
+    if (!camera) camera = this.camera;
+    return { elements: native.projectionMatrix(elementsOf(camera.projectionMatrix)) };
+  }
+
+  getModelViewMatrix(camera) {                       // index.js:467-487
+    if (!camera) camera = this.camera;
+    return { elements: native.modelViewMatrix(elementsOf(camera.matrixWorld), elementsOf(this.object.matrixWorld)) };
+  }
+
+  // The draw: onBeforeRender uniforms (index.js:184-195) + vertex/fragment/blend (index.js:77-181) -> RGBA8 pixels.
+  // viewport = {width, height[, x0, x1]} in device pixels; returns Uint8Array, row 0 = top.
+  render(camera, viewport, options) {
+    const proj = this.getProjectionMatrix(camera).elements;
+    const p = Object.assign({
+      modelView: this.getModelViewMatrix(camera).elements, projection: proj,
+      width: viewport.width, height: viewport.height,
+      focal: (viewport.height / 2.0) * Math.abs(proj[5]),
+    }, options || {});
+    if (viewport.x0 !== undefined) p.x0 = viewport.x0;
+    if (viewport.x1 !== undefined) p.x1 = viewport.x1;
+    return native.render(this.handle, p);
+  }
+
+  // createWorker (index.js:488-599): same message protocol, GPU-backed.  `self` needs postMessage; onmessage is installed.
+  createWorker(self) {
+    const h = native.create(this.device);
+    let havePush = false;
+    self.onmessage = (e) => {
+      const d = e.data;
+      if (d.method === 'clear') { native.clear(h); havePush = false; }
+      if (d.method === 'push') { native.pushMatrices(h, d.matrices); havePush = true; }
+      if (d.method === 'sort') {
+        const sortedIndexes = havePush ? native.sort(h, d.view, d.cutout) : new Uint32Array(1);   // index.js:588-590
+        self.postMessage({ sortedIndexes }, [sortedIndexes.buffer]);
+      }
+    };
+    return self;
+  }
+
+  processPlyBuffer(inputBuffer) { return native.plyToSplat(inputBuffer); }   // index.js:600-745
+
+  stats() { return native.stats(this.handle); }
+
+  remove() { native.destroy(this.handle); }          // the reference leaks its worker/textures; this does not
+}
+
+// Optional: expose the same component name to an A-Frame-like registry.
+function register(AFRAME) {
+  AFRAME.registerComponent('gaussian_splatting', {
+    schema,
+    init() { this.impl = new GaussianSplatting(this.data).init(this.el && this.el.sceneEl); },
+    tick() { if (this.impl.camera) this.impl.tick(); },
+    remove() { this.impl.remove(); },
+  });
+}
+
+module.exports = { schema, GaussianSplatting, register, native };

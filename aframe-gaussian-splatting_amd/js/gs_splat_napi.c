@@ -1,0 +1,390 @@
+/*
+ * gs_splat_napi.c -- raw-C N-API addon over the C ABI (include/gs_splat.h).
+ *
+ * This is the binding a maintainer of the reference would add so that the component's hot path
+ * (Worker sort + WebGL draw, index.js:77-207, 438-598) runs on an MI355X and hands an RGBA framebuffer
+ * back to JavaScript.  It is deliberately thin: every function converts arguments, calls one gs_* entry
+ * point and converts the result; failures become thrown JS Errors carrying gs_last_error() (for the two
+ * PLY cases that is the reference's own message, index.js:606-607, 643).
+ *
+ * Build (no node-gyp): see aframe-gaussian-splatting_amd/build.py:build_addon().
+ */
+#include <node_api.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "gs_splat.h"
+
+#define NAPI_OK(call)                                                                   \
+    do { if ((call) != napi_ok) { napi_throw_error(env, NULL, "N-API call failed: " #call); return NULL; } } while (0)
+
+static napi_value throw_gs(napi_env env, gs_ctx *ctx, int rc)
+{
+    char code[16];
+    const char *msg = gs_last_error(ctx);
+    snprintf(code, sizeof code, "GS%d", rc);
+    napi_throw_error(env, code, (msg && *msg) ? msg : "gs_splat call failed");
+    return NULL;
+}
+
+static void ctx_finalize(napi_env env, void *data, void *hint) { (void)env; (void)hint; if (data) gs_destroy((gs_ctx *)data); }
+
+/* argument helpers ------------------------------------------------------------------------------- */
+
+static int get_args(napi_env env, napi_callback_info info, size_t want, napi_value *argv, size_t *got)
+{
+    size_t argc = want;
+    if (napi_get_cb_info(env, info, &argc, argv, NULL, NULL) != napi_ok) return 0;
+    for (size_t i = argc; i < want; i++) napi_get_undefined(env, &argv[i]);
+    if (got) *got = argc;
+    return 1;
+}
+
+static gs_ctx *get_ctx(napi_env env, napi_value v)
+{
+    void *p = NULL;
+    napi_valuetype t;
+    if (napi_typeof(env, v, &t) != napi_ok || t != napi_external || napi_get_value_external(env, v, &p) != napi_ok || !p) {
+        napi_throw_type_error(env, NULL, "expected a context handle returned by create()");
+        return NULL;
+    }
+    return (gs_ctx *)p;
+}
+
+/* bytes of an ArrayBuffer / TypedArray / DataView / Buffer; returns 0 if v is none of those */
+static int get_bytes(napi_env env, napi_value v, void **data, size_t *len)
+{
+    bool is = false;
+    if (napi_is_arraybuffer(env, v, &is) == napi_ok && is) return napi_get_arraybuffer_info(env, v, data, len) == napi_ok;
+    if (napi_is_typedarray(env, v, &is) == napi_ok && is) {
+        napi_typedarray_type ty; size_t n; napi_value ab; size_t off;
+        if (napi_get_typedarray_info(env, v, &ty, &n, data, &ab, &off) != napi_ok) return 0;
+        static const size_t esz[] = { 1, 1, 1, 2, 2, 4, 4, 4, 8, 8, 8 };
+        *len = n * esz[ty];
+        return 1;
+    }
+    if (napi_is_buffer(env, v, &is) == napi_ok && is) return napi_get_buffer_info(env, v, data, len) == napi_ok;
+    if (napi_is_dataview(env, v, &is) == napi_ok && is) {
+        napi_value ab; size_t off;
+        return napi_get_dataview_info(env, v, len, data, &ab, &off) == napi_ok;
+    }
+    return 0;
+}
+
+static int is_nullish(napi_env env, napi_value v)
+{
+    napi_valuetype t;
+    return napi_typeof(env, v, &t) != napi_ok || t == napi_undefined || t == napi_null;
+}
+
+/* array-like of numbers -> doubles (accepts Array, Float32Array, Float64Array, THREE.Matrix4.elements) */
+static int get_doubles(napi_env env, napi_value v, double *out, uint32_t n)
+{
+    bool is = false;
+    if (napi_is_typedarray(env, v, &is) == napi_ok && is) {
+        napi_typedarray_type ty; size_t len; void *data; napi_value ab; size_t off;
+        if (napi_get_typedarray_info(env, v, &ty, &len, &data, &ab, &off) != napi_ok || len < n) return 0;
+        if (ty == napi_float32_array) { for (uint32_t i = 0; i < n; i++) out[i] = ((float *)data)[i]; return 1; }
+        if (ty == napi_float64_array) { for (uint32_t i = 0; i < n; i++) out[i] = ((double *)data)[i]; return 1; }
+        return 0;
+    }
+    for (uint32_t i = 0; i < n; i++) {
+        napi_value e;
+        if (napi_get_element(env, v, i, &e) != napi_ok || napi_get_value_double(env, e, &out[i]) != napi_ok) return 0;
+    }
+    return 1;
+}
+
+static int get_floats(napi_env env, napi_value v, float *out, uint32_t n)
+{
+    double d[16];
+    if (n > 16 || !get_doubles(env, v, d, n)) return 0;
+    for (uint32_t i = 0; i < n; i++) out[i] = (float)d[i];
+    return 1;
+}
+
+static napi_value make_f64_array(napi_env env, const double *v, size_t n)
+{
+    napi_value ab, ta; void *data;
+    NAPI_OK(napi_create_arraybuffer(env, n * 8, &data, &ab));
+    memcpy(data, v, n * 8);
+    NAPI_OK(napi_create_typedarray(env, napi_float64_array, n, ab, 0, &ta));
+    return ta;
+}
+
+static int get_named_double(napi_env env, napi_value obj, const char *name, double *out, int required)
+{
+    napi_value v; bool has = false;
+    if (napi_has_named_property(env, obj, name, &has) != napi_ok || !has) return !required;
+    if (napi_get_named_property(env, obj, name, &v) != napi_ok) return 0;
+    if (is_nullish(env, v)) return !required;
+    return napi_get_value_double(env, v, out) == napi_ok;
+}
+
+/* functions ---------------------------------------------------------------------------------------- */
+
+static napi_value fn_create(napi_env env, napi_callback_info info)      /* create(device = 0) -> handle */
+{
+    napi_value argv[1]; int32_t dev = 0;
+    if (!get_args(env, info, 1, argv, NULL)) return NULL;
+    if (!is_nullish(env, argv[0])) NAPI_OK(napi_get_value_int32(env, argv[0], &dev));
+    gs_ctx *ctx = NULL;
+    int rc = gs_create(dev, &ctx);
+    if (rc != GS_OK) return throw_gs(env, NULL, rc);
+    napi_value h;
+    NAPI_OK(napi_create_external(env, ctx, ctx_finalize, NULL, &h));
+    return h;
+}
+
+static napi_value fn_clear(napi_env env, napi_callback_info info)       /* worker {method:"clear"} */
+{
+    napi_value argv[1];
+    if (!get_args(env, info, 1, argv, NULL)) return NULL;
+    gs_ctx *ctx = get_ctx(env, argv[0]); if (!ctx) return NULL;
+    int rc = gs_clear(ctx);
+    if (rc != GS_OK) return throw_gs(env, ctx, rc);
+    return NULL;
+}
+
+static napi_value push_common(napi_env env, napi_callback_info info, int which)
+{
+    napi_value argv[3];
+    if (!get_args(env, info, 3, argv, NULL)) return NULL;
+    gs_ctx *ctx = get_ctx(env, argv[0]); if (!ctx) return NULL;
+    void *data; size_t len;
+    if (!get_bytes(env, argv[1], &data, &len)) { napi_throw_type_error(env, NULL, "expected an ArrayBuffer or TypedArray"); return NULL; }
+    const size_t row = which == 0 ? 32 : 64;
+    size_t n = len / row;
+    if (!is_nullish(env, argv[2])) {                       /* pushDataBuffer(buffer, vertexCount) */
+        int64_t want = 0;
+        NAPI_OK(napi_get_value_int64(env, argv[2], &want));
+        if (want < 0) want = 0;
+        if ((size_t)want < n) n = (size_t)want;
+    }
+    int rc = which == 0 ? gs_push_splat(ctx, data, n) : (which == 1 ? gs_push_matrices(ctx, (const float *)data, n) : gs_load_ply(ctx, data, len));
+    if (rc != GS_OK) return throw_gs(env, ctx, rc);
+    napi_value r;
+    NAPI_OK(napi_create_double(env, (double)gs_count(ctx), &r));
+    return r;
+}
+static napi_value fn_push_splat(napi_env env, napi_callback_info info) { return push_common(env, info, 0); }
+static napi_value fn_push_matrices(napi_env env, napi_callback_info info) { return push_common(env, info, 1); }
+static napi_value fn_load_ply(napi_env env, napi_callback_info info) { return push_common(env, info, 2); }
+
+static napi_value fn_ply_to_splat(napi_env env, napi_callback_info info)  /* processPlyBuffer(inputBuffer) -> ArrayBuffer */
+{
+    napi_value argv[1];
+    if (!get_args(env, info, 1, argv, NULL)) return NULL;
+    void *data; size_t len;
+    if (!get_bytes(env, argv[0], &data, &len)) { napi_throw_type_error(env, NULL, "expected an ArrayBuffer or TypedArray"); return NULL; }
+    size_t n = 0; char err[256] = "";
+    int rc = gs_ply_to_splat(data, len, NULL, &n, err, sizeof err);
+    if (rc != GS_OK) { napi_throw_error(env, NULL, err); return NULL; }
+    napi_value ab; void *out;
+    NAPI_OK(napi_create_arraybuffer(env, n * 32, &out, &ab));
+    rc = gs_ply_to_splat(data, len, out, &n, err, sizeof err);
+    if (rc != GS_OK) { napi_throw_error(env, NULL, err); return NULL; }
+    return ab;
+}
+
+static napi_value fn_count(napi_env env, napi_callback_info info)
+{
+    napi_value argv[1], r;
+    if (!get_args(env, info, 1, argv, NULL)) return NULL;
+    gs_ctx *ctx = get_ctx(env, argv[0]); if (!ctx) return NULL;
+    NAPI_OK(napi_create_double(env, (double)gs_count(ctx), &r));
+    return r;
+}
+
+/* sort(h, view[4], cutout[16] | undefined, wantIndexes = true) -> Uint32Array (worker reply `sortedIndexes`) */
+static napi_value fn_sort(napi_env env, napi_callback_info info)
+{
+    napi_value argv[4];
+    if (!get_args(env, info, 4, argv, NULL)) return NULL;
+    gs_ctx *ctx = get_ctx(env, argv[0]); if (!ctx) return NULL;
+    float view[4], cut[16];
+    void *vb; size_t vlen;
+    if (get_bytes(env, argv[1], &vb, &vlen) && vlen >= 16) memcpy(view, vb, 16);   /* view.buffer as posted by tick */
+    else if (!get_floats(env, argv[1], view, 4)) { napi_throw_type_error(env, NULL, "view: expected 4 floats"); return NULL; }
+    const float *cutp = NULL;
+    if (!is_nullish(env, argv[2])) {
+        if (!get_floats(env, argv[2], cut, 16)) { napi_throw_type_error(env, NULL, "cutout: expected 16 floats"); return NULL; }
+        cutp = cut;
+    }
+    bool want = true;
+    if (!is_nullish(env, argv[3])) NAPI_OK(napi_get_value_bool(env, argv[3], &want));
+    if (!want) {
+        int rc = gs_sort(ctx, view, cutp, NULL, NULL);
+        if (rc != GS_OK) return throw_gs(env, ctx, rc);
+        return NULL;
+    }
+    size_t cap = gs_count(ctx); if (cap < 1) cap = 1;
+    uint32_t *tmp = (uint32_t *)malloc(cap * 4), n = 0;
+    if (!tmp) { napi_throw_error(env, NULL, "out of memory"); return NULL; }
+    int rc = gs_sort(ctx, view, cutp, tmp, &n);
+    if (rc != GS_OK) { free(tmp); return throw_gs(env, ctx, rc); }
+    napi_value ab, ta; void *out;
+    if (napi_create_arraybuffer(env, (size_t)n * 4, &out, &ab) != napi_ok) { free(tmp); napi_throw_error(env, NULL, "arraybuffer"); return NULL; }
+    memcpy(out, tmp, (size_t)n * 4);
+    free(tmp);
+    NAPI_OK(napi_create_typedarray(env, napi_uint32_array, n, ab, 0, &ta));
+    return ta;
+}
+
+static int fill_params(napi_env env, napi_value o, gs_render_params *p)
+{
+    napi_value v; double d;
+    memset(p, 0, sizeof *p);
+    if (napi_get_named_property(env, o, "modelView", &v) != napi_ok || !get_floats(env, v, p->model_view, 16)) return 0;
+    if (napi_get_named_property(env, o, "projection", &v) != napi_ok || !get_floats(env, v, p->projection, 16)) return 0;
+    if (!get_named_double(env, o, "width", &d, 1)) return 0; p->fb_width = (int32_t)d;
+    if (!get_named_double(env, o, "height", &d, 1)) return 0; p->fb_height = (int32_t)d;
+    p->x0 = 0; p->x1 = p->fb_width;
+    d = 0; if (!get_named_double(env, o, "x0", &d, 0)) return 0; p->x0 = (int32_t)d;
+    d = p->fb_width; if (!get_named_double(env, o, "x1", &d, 0)) return 0; p->x1 = (int32_t)d;
+    d = 0; if (!get_named_double(env, o, "focal", &d, 0)) return 0; p->focal = (float)d;
+    d = 0; if (!get_named_double(env, o, "flags", &d, 0)) return 0; p->flags = (uint32_t)d;
+    p->background[0] = p->background[1] = p->background[2] = 0.0f; p->background[3] = 1.0f;
+    bool has = false;
+    if (napi_has_named_property(env, o, "background", &has) == napi_ok && has) {
+        if (napi_get_named_property(env, o, "background", &v) != napi_ok) return 0;
+        if (!is_nullish(env, v) && !get_floats(env, v, p->background, 4)) return 0;
+    }
+    return 1;
+}
+
+/* render(h, {modelView, projection, width, height, x0?, x1?, focal?, background?, flags?}) -> Uint8Array RGBA, row 0 = top */
+static napi_value fn_render(napi_env env, napi_callback_info info)
+{
+    napi_value argv[2];
+    if (!get_args(env, info, 2, argv, NULL)) return NULL;
+    gs_ctx *ctx = get_ctx(env, argv[0]); if (!ctx) return NULL;
+    gs_render_params p;
+    if (!fill_params(env, argv[1], &p)) { napi_throw_type_error(env, NULL, "render: bad parameter object"); return NULL; }
+    if (p.x1 <= p.x0 || p.fb_height <= 0) { napi_throw_range_error(env, NULL, "render: empty strip"); return NULL; }
+    const size_t bytes = (size_t)(p.x1 - p.x0) * (size_t)p.fb_height * 4;
+    napi_value ab, ta; void *out;
+    NAPI_OK(napi_create_arraybuffer(env, bytes, &out, &ab));
+    int rc = gs_render(ctx, &p, (uint8_t *)out, 0);
+    if (rc != GS_OK) return throw_gs(env, ctx, rc);
+    NAPI_OK(napi_create_typedarray(env, napi_uint8_array, bytes, ab, 0, &ta));
+    return ta;
+}
+
+static napi_value fn_stats(napi_env env, napi_callback_info info)
+{
+    napi_value argv[1], o, v;
+    if (!get_args(env, info, 1, argv, NULL)) return NULL;
+    gs_ctx *ctx = get_ctx(env, argv[0]); if (!ctx) return NULL;
+    gs_stats s;
+    int rc = gs_get_stats(ctx, &s);
+    if (rc != GS_OK) return throw_gs(env, ctx, rc);
+    NAPI_OK(napi_create_object(env, &o));
+#define PUT(name, val) do { NAPI_OK(napi_create_double(env, (double)(val), &v)); NAPI_OK(napi_set_named_property(env, o, name, v)); } while (0)
+    PUT("nSplats", s.n_splats); PUT("nSorted", s.n_sorted); PUT("nVisible", s.n_visible); PUT("nPairs", s.n_pairs);
+    PUT("nFrags", s.n_frags); PUT("nTiles", s.n_tiles); PUT("msSort", s.ms_sort); PUT("msProject", s.ms_project);
+    PUT("msBin", s.ms_bin); PUT("msBlend", s.ms_blend); PUT("msRender", s.ms_render);
+#undef PUT
+    return o;
+}
+
+static napi_value fn_set_option(napi_env env, napi_callback_info info)
+{
+    napi_value argv[3]; int32_t opt; int64_t val;
+    if (!get_args(env, info, 3, argv, NULL)) return NULL;
+    gs_ctx *ctx = get_ctx(env, argv[0]); if (!ctx) return NULL;
+    NAPI_OK(napi_get_value_int32(env, argv[1], &opt));
+    NAPI_OK(napi_get_value_int64(env, argv[2], &val));
+    int rc = gs_set_option(ctx, opt, val);
+    if (rc != GS_OK) return throw_gs(env, ctx, rc);
+    return NULL;
+}
+
+/* uniform producers (host helpers) */
+static napi_value fn_model_view(napi_env env, napi_callback_info info)   /* getModelViewMatrix */
+{
+    napi_value argv[2]; double a[16], b[16], o[16];
+    if (!get_args(env, info, 2, argv, NULL)) return NULL;
+    if (!get_doubles(env, argv[0], a, 16) || !get_doubles(env, argv[1], b, 16)) { napi_throw_type_error(env, NULL, "expected two 16-element matrices"); return NULL; }
+    gs_model_view_matrix(a, b, o);
+    return make_f64_array(env, o, 16);
+}
+
+static napi_value fn_projection(napi_env env, napi_callback_info info)   /* getProjectionMatrix */
+{
+    napi_value argv[1]; double a[16], o[16];
+    if (!get_args(env, info, 1, argv, NULL)) return NULL;
+    if (!get_doubles(env, argv[0], a, 16)) { napi_throw_type_error(env, NULL, "expected a 16-element matrix"); return NULL; }
+    gs_projection_matrix(a, o);
+    return make_f64_array(env, o, 16);
+}
+
+static napi_value fn_tick(napi_env env, napi_callback_info info)         /* tick -> {view: Float32Array(4), cutout: Float32Array(16)|undefined} */
+{
+    napi_value argv[3]; double a[16], b[16], c[16];
+    if (!get_args(env, info, 3, argv, NULL)) return NULL;
+    if (!get_doubles(env, argv[0], a, 16) || !get_doubles(env, argv[1], b, 16)) { napi_throw_type_error(env, NULL, "expected two 16-element matrices"); return NULL; }
+    const int has_cut = !is_nullish(env, argv[2]);
+    if (has_cut && !get_doubles(env, argv[2], c, 16)) { napi_throw_type_error(env, NULL, "cutout: expected a 16-element matrix"); return NULL; }
+    float view[4], cut[16];
+    gs_tick_uniforms(a, b, has_cut ? c : NULL, view, cut);
+    napi_value o, ab, ta; void *data;
+    NAPI_OK(napi_create_object(env, &o));
+    NAPI_OK(napi_create_arraybuffer(env, 16, &data, &ab)); memcpy(data, view, 16);
+    NAPI_OK(napi_create_typedarray(env, napi_float32_array, 4, ab, 0, &ta));
+    NAPI_OK(napi_set_named_property(env, o, "view", ta));
+    if (has_cut) {
+        NAPI_OK(napi_create_arraybuffer(env, 64, &data, &ab)); memcpy(data, cut, 64);
+        NAPI_OK(napi_create_typedarray(env, napi_float32_array, 16, ab, 0, &ta));
+        NAPI_OK(napi_set_named_property(env, o, "cutout", ta));
+    }
+    return o;
+}
+
+static napi_value fn_scaled_size(napi_env env, napi_callback_info info)
+{
+    napi_value argv[3], arr, v; int32_t w, h, ow, oh; double r;
+    if (!get_args(env, info, 3, argv, NULL)) return NULL;
+    NAPI_OK(napi_get_value_int32(env, argv[0], &w)); NAPI_OK(napi_get_value_int32(env, argv[1], &h));
+    NAPI_OK(napi_get_value_double(env, argv[2], &r));
+    gs_scaled_size(w, h, r, &ow, &oh);
+    NAPI_OK(napi_create_array_with_length(env, 2, &arr));
+    NAPI_OK(napi_create_int32(env, ow, &v)); NAPI_OK(napi_set_element(env, arr, 0, v));
+    NAPI_OK(napi_create_int32(env, oh, &v)); NAPI_OK(napi_set_element(env, arr, 1, v));
+    return arr;
+}
+
+static napi_value fn_destroy(napi_env env, napi_callback_info info)      /* explicit teardown; GC finalizer is the fallback */
+{
+    napi_value argv[1];
+    if (!get_args(env, info, 1, argv, NULL)) return NULL;
+    void *p = NULL; napi_valuetype t;
+    if (napi_typeof(env, argv[0], &t) == napi_ok && t == napi_external && napi_get_value_external(env, argv[0], &p) == napi_ok && p)
+        gs_clear((gs_ctx *)p);        /* drop the data now; the handle's finalizer frees the context */
+    return NULL;
+}
+
+static napi_value init(napi_env env, napi_value exports)
+{
+    static const struct { const char *name; napi_callback fn; } fns[] = {
+        { "create", fn_create }, { "destroy", fn_destroy }, { "clear", fn_clear }, { "pushSplat", fn_push_splat },
+        { "pushMatrices", fn_push_matrices }, { "loadPly", fn_load_ply }, { "plyToSplat", fn_ply_to_splat }, { "count", fn_count },
+        { "sort", fn_sort }, { "render", fn_render }, { "stats", fn_stats }, { "setOption", fn_set_option },
+        { "modelViewMatrix", fn_model_view }, { "projectionMatrix", fn_projection }, { "tickUniforms", fn_tick },
+        { "scaledSize", fn_scaled_size },
+    };
+    for (size_t i = 0; i < sizeof fns / sizeof fns[0]; i++) {
+        napi_value f;
+        if (napi_create_function(env, fns[i].name, NAPI_AUTO_LENGTH, fns[i].fn, NULL, &f) != napi_ok ||
+            napi_set_named_property(env, exports, fns[i].name, f) != napi_ok) {
+            napi_throw_error(env, NULL, "gs_splat_napi: init failed");
+            return NULL;
+        }
+    }
+    napi_value v;
+    if (napi_create_uint32(env, gs_version(), &v) == napi_ok) napi_set_named_property(env, exports, "version", v);
+    return exports;
+}
+
+NAPI_MODULE(gs_splat_napi, init)

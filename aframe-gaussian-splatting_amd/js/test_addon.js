@@ -1,0 +1,114 @@
+// node test_addon.js cpu <goldenDir>
+// node test_addon.js gpu <goldenDir> <scene.splat> <out.rgba> <width> <height> <yawDeg>
+// Exercises the N-API addon + component shim.  Exit code 0 = all checks passed.
+'use strict';
+const fs = require('fs');
+const path = require('path');
+const { GaussianSplatting, schema, native } = require('./gaussian_splatting.js');
+
+const [mode, goldenDir] = process.argv.slice(2);
+const manifest = JSON.parse(fs.readFileSync(path.join(goldenDir, 'manifest.json'), 'utf8'));
+const TA = { f4: Float32Array, f8: Float64Array, u4: Uint32Array, i4: Int32Array, u1: Uint8Array, i2: Int16Array, u2: Uint16Array };
+function loadCase(name) {
+  const d = manifest[name]; const out = { meta: d.meta };
+  if (Object.keys(d.arrays).length) {
+    const raw = fs.readFileSync(path.join(goldenDir, name + '.bin'));
+    for (const k of Object.keys(d.arrays)) {
+      const a = d.arrays[k]; const T = TA[a.dtype];
+      const ab = raw.buffer.slice(raw.byteOffset + a.offset, raw.byteOffset + a.offset + a.count * T.BYTES_PER_ELEMENT);
+      out[k] = new T(ab);
+    }
+  }
+  return out;
+}
+function same(a, b) {
+  if (a.length !== b.length) return false;
+  for (let i = 0; i < a.length; i++) if (a[i] !== b[i] && !(a[i] !== a[i] && b[i] !== b[i])) return false;
+  return true;
+}
+let checks = 0;
+function ok(cond, what) { checks++; if (!cond) { console.error('FAIL:', what); process.exit(1); } }
+
+// ---- surface
+ok(schema.src.default === 'train.splat' && schema.pixelRatio.default === 1 && schema.xrPixelRatio.default === 0.5 &&
+   schema.cutoutEntity.type === 'selector', 'schema defaults (index.js:2-7)');
+for (const m of ['init', 'loadData', 'pushDataBuffer', 'tick', 'getProjectionMatrix', 'getModelViewMatrix', 'createWorker', 'processPlyBuffer'])
+  ok(typeof GaussianSplatting.prototype[m] === 'function', 'method ' + m);
+ok(same(native.scaledSize(2064, 2208, 0.5), [1032, 1104]) && same(native.scaledSize(800, 600, 0), [800, 600]), 'scaledSize');
+
+// ---- host helpers vs golden vectors captured from the reference
+for (const name of Object.keys(manifest).filter((k) => manifest[k].kind === 'camera')) {
+  const c = loadCase(name);
+  ok(same(native.modelViewMatrix(c.cam_world, c.obj_world), c.gs_mv), name + ' gsModelViewMatrix');
+  ok(same(native.projectionMatrix(c.proj), c.gs_proj), name + ' gsProjectionMatrix');
+  const t = native.tickUniforms(c.cam_world, c.obj_world, c.cutout_world);
+  ok(same(t.view, c.view), name + ' view');
+  if (c.cutout) ok(same(t.cutout, c.cutout), name + ' cutout');
+}
+for (const name of Object.keys(manifest).filter((k) => manifest[k].kind === 'ply')) {
+  const c = loadCase(name);
+  const rows = new Uint8Array(native.plyToSplat(c.ply.buffer.slice(c.ply.byteOffset, c.ply.byteOffset + c.ply.byteLength)));
+  ok(same(rows, c.rows), name + ' processPlyBuffer');
+}
+try { native.plyToSplat(Buffer.from('ply\nnope')); ok(false, 'bad header must throw'); } catch (e) {
+  ok(e.message === manifest.ply_errors.meta.no_end_header, 'PLY header message: ' + e.message);
+}
+
+if (mode === 'cpu') {
+  let threw = false;
+  try { native.create(0); } catch (e) { threw = true; ok(/no CPU fallback|HIP/.test(e.message), 'create error text: ' + e.message); }
+  if (!fs.existsSync('/dev/kfd')) ok(threw, 'create() must fail without a GPU (no CPU fallback)');
+  console.log('addon cpu checks ok:', checks);
+  process.exit(0);
+}
+
+// ---- GPU: worker protocol against the reference worker's golden outputs
+const [scenePath, outPath, W, H, yaw] = process.argv.slice(4);
+const comp = new GaussianSplatting({ src: scenePath, pixelRatio: 1 }).init(null);
+for (const name of Object.keys(manifest).filter((k) => manifest[k].kind === 'sort')) {
+  const c = loadCase(name);
+  let reply = null;
+  const self = { postMessage: (m) => { reply = m; } };
+  comp.createWorker(self);
+  self.onmessage({ data: { method: 'clear' } });
+  let o = 0;
+  for (const n of c.meta.pushes) {
+    const m = new Float32Array(n * 16);
+    for (let i = 0; i < n; i++) for (let k = 0; k < 4; k++) m[i * 16 + 12 + k] = c.rows4[(o + i) * 4 + k];
+    self.onmessage({ data: { method: 'push', matrices: m.buffer } });
+    o += n;
+  }
+  self.onmessage({ data: { method: 'sort', view: c.view.buffer.slice(c.view.byteOffset, c.view.byteOffset + 16), cutout: c.cutout } });
+  ok(same(reply.sortedIndexes, c.sorted), name + ' worker protocol');
+}
+{
+  let reply = null;
+  const self = { postMessage: (m) => { reply = m; } };
+  comp.createWorker(self);
+  self.onmessage({ data: { method: 'clear' } });
+  self.onmessage({ data: { method: 'sort', view: new Float32Array([0, 0, 1, -6]).buffer } });
+  ok(reply.sortedIndexes.length === 1 && reply.sortedIndexes[0] === 0, 'sort before push -> [0]');
+}
+
+// ---- GPU: loadData (progressive chunks) -> tick -> render, written out for the Python side to compare
+const THREE = require(path.join(__dirname, '..', '..', 'oracle', 'three_standin.js'));
+function compose(p, yawDeg) {
+  const h = yawDeg * Math.PI / 360;
+  return new THREE.Matrix4().compose(new THREE.Vector3(p[0], p[1], p[2]), new THREE.Quaternion(0, Math.sin(h), 0, Math.cos(h)),
+    new THREE.Vector3(1, 1, 1));
+}
+const camera = { matrixWorld: compose([0, 1.6, 0], 0), projectionMatrix: new THREE.Matrix4().makePerspectiveFov(80, W / H, 0.005, 10000) };
+const object = { matrixWorld: compose([0, 1.5, -2], Number(yaw)) };
+comp.loadData(camera, object, null, scenePath, 100003).then((n) => {
+  ok(n === Math.floor(fs.statSync(scenePath).size / 32), 'loadedVertexCount ' + n);
+  comp.tick();
+  ok(comp.instanceCount === comp.sortedIndexes.length && comp.instanceCount > 0, 'instanceCount');
+  const img = comp.render(camera, { width: Number(W), height: Number(H) });
+  ok(img.length === W * H * 4, 'framebuffer size');
+  fs.writeFileSync(outPath, Buffer.from(img.buffer, img.byteOffset, img.byteLength));
+  fs.writeFileSync(outPath + '.idx', Buffer.from(comp.sortedIndexes.buffer, comp.sortedIndexes.byteOffset, comp.sortedIndexes.byteLength));
+  const strip = comp.render(camera, { width: Number(W), height: Number(H), x0: 16, x1: 48 });
+  ok(strip.length === 32 * H * 4, 'strip size');
+  comp.remove();
+  console.log('addon gpu checks ok:', checks);
+}).catch((e) => { console.error('FAIL:', e); process.exit(1); });

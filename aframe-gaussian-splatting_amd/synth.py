@@ -68,7 +68,7 @@ def rows_to_inria_ply(rows_u8):
 
 def compose(pos, yaw_deg=0.0, scale=(1.0, 1.0, 1.0)):
     """Object world matrix: T * R_y(yaw) * S, as 16 column-major f64 (three.js Matrix4.compose)."""
-    h = math.radians(yaw_deg) / 2.0
+    h = yaw_deg * math.pi / 360.0
     x, y, z, w = 0.0, math.sin(h), 0.0, math.cos(h)
     x2, y2, z2 = x + x, y + y, z + z
     xx, xy, xz, yy, yz, zz, wx, wy, wz = x * x2, x * y2, x * z2, y * y2, y * z2, z * z2, w * x2, w * y2, w * z2

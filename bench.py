@@ -53,6 +53,7 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     capi = importlib.import_module(PKG + ".capi")
     synth = importlib.import_module(PKG + ".synth")
+    mg = importlib.import_module(PKG + ".multigpu")
 
     n_splats = args.splats or synth.N_TRAIN
     rows = synth.make_splat_rows(n_splats)
@@ -60,18 +61,14 @@ def main():
     ctx.push_splat(rows)
 
     # tile-aligned column strips
-    tiles_x = (W + 15) // 16
-    t0, t1 = tiles_x * rank // world, tiles_x * (rank + 1) // world
-    x0, x1 = t0 * 16, min(t1 * 16, W)
-    sw_max = max(min(tiles_x * (r + 1) // world * 16, W) - tiles_x * r // world * 16 for r in range(world))
+    x0, x1 = mg.strip_bounds(W, world, rank)
 
     cams = [synth.index_html_camera(W, H, 360.0 * i / ORBIT_FRAMES, capi=capi) for i in range(ORBIT_FRAMES)]
     params = [capi.make_params(c["gs_mv"], c["gs_proj"], W, H, x0=x0, x1=x1, focal_=c["focal"]) for c in cams]
     strip = gathered = None
     if world > 1:
-        strip = torch.zeros(H * sw_max * 4, dtype=torch.uint8, device="cuda")      # tight H x sw x 4 rows at the front
+        strip = torch.zeros(mg.strip_buffer_bytes(W, H, world), dtype=torch.uint8, device="cuda")   # tight H x sw x 4 rows at the front
         gathered = [torch.zeros_like(strip) for _ in range(world)] if rank == 0 else None
-    widths = [min(tiles_x * (r + 1) // world * 16, W) - tiles_x * r // world * 16 for r in range(world)]
 
     def frame(i, flags=0):
         k = i % ORBIT_FRAMES
@@ -80,9 +77,7 @@ def main():
         p.flags = flags
         if world > 1:
             ctx.render_device(p, strip.data_ptr())          # returns with the strip complete in HBM
-            dist.gather(strip, gathered, dst=0)
-            if rank == 0:
-                return torch.cat([g[: H * widths[r] * 4].view(H, widths[r], 4) for r, g in enumerate(gathered)], dim=1)
+            return mg.gather_strips(strip, W, H, dist, gathered)   # RCCL gather + row-major assembly on rank 0
         else:
             ctx.render_device(p, None)
         return None
