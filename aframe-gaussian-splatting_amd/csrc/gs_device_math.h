@@ -260,4 +260,50 @@ GS_HD void splat_pixel_bounds(const Projected &p, const ProjExtra &x, float &xmi
     ymin = ceilf(p.cy - hh - pady - 0.5f); ymax = floorf(p.cy + hh + pady - 0.5f);
 }
 
+
+// ---------------------------------------------------------------- exact tile coverage of the |p|<=2 ellipse
+// The ellipse is the conic  q(dx,dy) = A dx^2 + 2B dx dy + C dy^2 <= 4  with  A = |(ax,bx)|^2, B = ax*ay + bx*by,
+// C = |(ay,by)|^2 and discriminant D = AC - B^2 = (ax*by - ay*bx)^2 (Lagrange identity: no cancellation).
+// For a horizontal band dy in [ya,yb] the covered x-interval is [xl(clamp(dy_l)), xr(clamp(dy_r))] where
+// xr/xl are the right/left roots of q = 4 and dy_r = -B*hw/C (= -dy_l) is the height of the rightmost point
+// (xr is concave, xl convex).  A convex shape meets each tile row in one contiguous run of tiles, so per-row
+// ranges give EXACTLY the set of tiles the ellipse touches instead of its bounding rectangle.
+struct EllipseRows { float A, B, D, dy_r, pad; };
+
+GS_HD void ellipse_rows_setup(const Projected &p, EllipseRows &e)
+{
+    e.A = p.ax * p.ax + p.bx * p.bx;
+    e.B = p.ax * p.ay + p.bx * p.by;
+    const float C = p.ay * p.ay + p.by * p.by;
+    const float cr = p.ax * p.by - p.ay * p.bx;
+    e.D = cr * cr;
+    const float hw = 2.0f * sqrtf(C / e.D);
+    e.dy_r = -(e.B * hw) / C;
+    e.pad = 0.01f + 1.0e-4f * hw;
+}
+
+// x-interval (relative to the splat centre) covered inside the band dy in [ya, yb]
+GS_HD void ellipse_band_xrange(const EllipseRows &e, float ya, float yb, float &xmin, float &xmax)
+{
+    const float dr = fminf(fmaxf(e.dy_r, ya), yb), dl = fminf(fmaxf(-e.dy_r, ya), yb);
+    xmax = (-e.B * dr + sqrtf(fmaxf(4.0f * e.A - e.D * dr * dr, 0.0f))) / e.A;
+    xmin = (-e.B * dl - sqrtf(fmaxf(4.0f * e.A - e.D * dl * dl, 0.0f))) / e.A;
+}
+
+// Tiles of image tile-row `ty` (rows 16*ty .. 16*ty+15, top-down) that the splat can touch inside the strip
+// [x0,x1): first tile column (strip-local) and count (0 = none).  H = viewport height.
+GS_HD void splat_tile_row(const Projected &p, const EllipseRows &e, int ty, int H, int x0, int x1, uint32_t &tx0, uint32_t &n)
+{
+    const int r_lo = ty * 16, r_hi = (ty * 16 + 15 < H - 1) ? ty * 16 + 15 : H - 1;
+    // GL pixel-centre y of image row r is (H-1-r) + 0.5
+    const float ya = ((float)(H - 1 - r_hi) + 0.5f) - p.cy - e.pad, yb = ((float)(H - 1 - r_lo) + 0.5f) - p.cy + e.pad;
+    float xmin, xmax;
+    ellipse_band_xrange(e, ya, yb, xmin, xmax);
+    const float fi0 = fmaxf(ceilf(p.cx + xmin - e.pad - 0.5f), (float)x0);
+    const float fi1 = fminf(floorf(p.cx + xmax + e.pad - 0.5f), (float)(x1 - 1));
+    if (!(fi0 <= fi1)) { tx0 = 0; n = 0; return; }
+    const uint32_t a = (uint32_t)((int)fi0 - x0) >> 4, b = (uint32_t)((int)fi1 - x0) >> 4;
+    tx0 = a; n = b - a + 1;
+}
+
 }  // namespace gsm

@@ -54,7 +54,14 @@ __global__ __launch_bounds__(GS_BLOCK) void k_project(const uint32_t *__restrict
                     const int r0 = u.H - 1 - jy1, r1 = u.H - 1 - jy0;           // GL rows (y up) -> image rows (top-down)
                     const uint32_t tx0 = (uint32_t)(ix0 - u.x0) / GS_TILE, tx1 = (uint32_t)(ix1 - u.x0) / GS_TILE;
                     const uint32_t ty0 = (uint32_t)r0 / GS_TILE, ty1 = (uint32_t)r1 / GS_TILE;
-                    count = (tx1 - tx0 + 1) * (ty1 - ty0 + 1);
+                    // exact coverage: per tile row, the contiguous run of tiles the ellipse touches
+                    gsm::EllipseRows e;
+                    gsm::ellipse_rows_setup(p, e);
+                    for (uint32_t ty = ty0; ty <= ty1; ty++) {
+                        uint32_t a, n;
+                        gsm::splat_tile_row(p, e, (int)ty, u.H, u.x0, u.x1, a, n);
+                        count += n;
+                    }
                     rect[j] = make_uint2(tx0 | (ty0 << 16), tx1 | (ty1 << 16));
                     float4 *dst = reinterpret_cast<float4 *>(proj + j);
                     dst[0] = make_float4(p.cx, p.cy, p.ax, p.ay);
@@ -78,19 +85,68 @@ __global__ void k_pairs_check(GsControl *ctl, uint32_t pair_cap)
     else ctl->n_pairs = total;
 }
 
-__global__ __launch_bounds__(GS_BLOCK) void k_emit(const uint2 *__restrict__ rect, const uint32_t *__restrict__ tile_count,
-                                                   const uint32_t *__restrict__ pair_off, uint32_t tiles_x,
-                                                   uint32_t *__restrict__ pkey, uint32_t *__restrict__ pval, const GsControl *ctl)
+// (tile id, sorted position) pairs in splat order.  Splats touching few tiles are written by their own lane;
+// the few screen-filling ones (thousands of tiles each) are queued in LDS and expanded by a whole wavefront,
+// one lane per tile row, so that no single lane serialises thousands of stores.
+#define GS_EMIT_BIG 32u
+__global__ __launch_bounds__(GS_BLOCK) void k_emit(const gsm::Projected *__restrict__ proj, const uint2 *__restrict__ rect,
+                                                   const uint32_t *__restrict__ tile_count, const uint32_t *__restrict__ pair_off,
+                                                   GsFrameUniforms u, uint32_t *__restrict__ pkey, uint32_t *__restrict__ pval,
+                                                   const GsControl *ctl)
 {
+    __shared__ uint32_t s_big[GS_BLOCK];
+    __shared__ uint32_t s_nbig;
     if (ctl->pair_overflow) return;
     const uint32_t V = ctl->n_kept;
-    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < V; j += gridDim.x * blockDim.x) {
-        if (!tile_count[j]) continue;
-        const uint2 r = rect[j];
-        const uint32_t tx0 = r.x & 0xFFFF, ty0 = r.x >> 16, tx1 = r.y & 0xFFFF, ty1 = r.y >> 16;
-        uint32_t o = pair_off[j];
-        for (uint32_t ty = ty0; ty <= ty1; ty++)
-            for (uint32_t tx = tx0; tx <= tx1; tx++) { pkey[o] = ty * tiles_x + tx; pval[o] = j; o++; }
+    const uint32_t nchunks = (V + GS_BLOCK - 1) / GS_BLOCK;
+    const uint32_t tiles_x = (uint32_t)u.tiles_x;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (uint32_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
+        if (threadIdx.x == 0) s_nbig = 0;
+        __syncthreads();
+        const uint32_t j = c * GS_BLOCK + threadIdx.x;
+        const uint32_t cnt = j < V ? tile_count[j] : 0u;
+        if (cnt >= GS_EMIT_BIG) {
+            s_big[atomicAdd(&s_nbig, 1u)] = j;
+        } else if (cnt) {
+            const float4 *src = reinterpret_cast<const float4 *>(proj + j);
+            const float4 a = src[0], b = src[1];
+            gsm::Projected p; p.cx = a.x; p.cy = a.y; p.ax = a.z; p.ay = a.w; p.bx = b.x; p.by = b.y;
+            gsm::EllipseRows e;
+            gsm::ellipse_rows_setup(p, e);
+            const uint2 r = rect[j];
+            uint32_t o = pair_off[j];
+            for (uint32_t ty = r.x >> 16; ty <= (r.y >> 16); ty++) {
+                uint32_t t0, n;
+                gsm::splat_tile_row(p, e, (int)ty, u.H, u.x0, u.x1, t0, n);
+                for (uint32_t k = 0; k < n; k++) { pkey[o] = ty * tiles_x + t0 + k; pval[o] = j; o++; }
+            }
+        }
+        __syncthreads();
+        const uint32_t nbig = s_nbig;
+        for (uint32_t bi = w; bi < nbig; bi += 4) {                  // one wavefront per big splat
+            const uint32_t jb = s_big[bi];
+            const float4 *src = reinterpret_cast<const float4 *>(proj + jb);
+            const float4 a = src[0], b = src[1];
+            gsm::Projected p; p.cx = a.x; p.cy = a.y; p.ax = a.z; p.ay = a.w; p.bx = b.x; p.by = b.y;
+            gsm::EllipseRows e;
+            gsm::ellipse_rows_setup(p, e);
+            const uint2 r = rect[jb];
+            const uint32_t ty0 = r.x >> 16, ty1 = r.y >> 16;
+            uint32_t base = pair_off[jb];
+            for (uint32_t tyb = ty0; tyb <= ty1; tyb += 64) {        // 64 tile rows per sweep
+                const uint32_t ty = tyb + lane;
+                uint32_t t0 = 0, n = 0;
+                if (ty <= ty1) gsm::splat_tile_row(p, e, (int)ty, u.H, u.x0, u.x1, t0, n);
+                uint32_t inc = n;                                    // wave inclusive scan of the row lengths
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(inc, d, 64); if (lane >= d) inc += t; }
+                uint32_t o = base + inc - n;
+                for (uint32_t k = 0; k < n; k++) { pkey[o] = ty * tiles_x + t0 + k; pval[o] = jb; o++; }
+                base += __shfl(inc, 63, 64);
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -200,7 +256,7 @@ int gs_run_render(gs_ctx *ctx, const GsFrameUniforms &u, uint8_t *device_out)
         if (rc != GS_OK) return rc;
         hipLaunchKernelGGL(k_pairs_check, dim3(1), dim3(1), 0, st, ctx->ctl, (uint32_t)ctx->pair_cap);
         uint32_t ge = gs_div_up(Vmax, GS_BLOCK); if (ge > 4096) ge = 4096;
-        hipLaunchKernelGGL(k_emit, dim3(ge), dim3(GS_BLOCK), 0, st, ctx->rect, ctx->tile_count, ctx->pair_off, (uint32_t)u.tiles_x,
+        hipLaunchKernelGGL(k_emit, dim3(ge), dim3(GS_BLOCK), 0, st, ctx->proj, ctx->rect, ctx->tile_count, ctx->pair_off, u,
                            ctx->pkey_a, ctx->pval_a, ctx->ctl);
         GS_HIP(hipGetLastError());
         const int tb = bits_for(ntiles);

@@ -13,6 +13,13 @@ namespace {
 
 struct SortUniforms { float view[4]; float cutout[16]; int has_cutout; };
 
+__device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v, int m)
+{
+    uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+    lo = __shfl_xor(lo, m, 64); hi = __shfl_xor(hi, m, 64);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
 __global__ void k_sort_init(GsControl *ctl, uint32_t n)
 {
     ctl->min_enc = ~0ull; ctl->max_enc = 0ull;
@@ -46,7 +53,13 @@ __global__ __launch_bounds__(GS_BLOCK) void k_sort_depth(const float4 *__restric
                 }
             }
         }
-        if (cnt) { atomicMin(&s_min, mn); atomicMax(&s_max, mx); atomicAdd(&s_cnt, cnt); }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {                       // wavefront butterfly: one LDS atomic per wave, not per lane
+            const unsigned long long omn = shfl_xor_u64(mn, m), omx = shfl_xor_u64(mx, m);
+            mn = omn < mn ? omn : mn; mx = omx > mx ? omx : mx;
+            cnt += __shfl_xor(cnt, m, 64);
+        }
+        if ((threadIdx.x & 63) == 0 && cnt) { atomicMin(&s_min, mn); atomicMax(&s_max, mx); atomicAdd(&s_cnt, cnt); }
         __syncthreads();
         if (threadIdx.x == 0 && s_cnt) {
             atomicMin(&ctl->min_enc, s_min); atomicMax(&ctl->max_enc, s_max); atomicAdd(&ctl->n_kept, s_cnt);
@@ -80,7 +93,9 @@ __global__ __launch_bounds__(GS_BLOCK) void k_sort_bucket(const float *__restric
                 keys[i] = k;
             }
         }
-        if (cnt) atomicAdd(&s_cnt, cnt);
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) cnt += __shfl_xor(cnt, m, 64);
+        if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(&s_cnt, cnt);
         __syncthreads();
         if (threadIdx.x == 0 && s_cnt) atomicAdd(&ctl->n_valid, s_cnt);
         __syncthreads();

@@ -238,13 +238,23 @@ static int fill_params(napi_env env, napi_value o, gs_render_params *p)
     memset(p, 0, sizeof *p);
     if (napi_get_named_property(env, o, "modelView", &v) != napi_ok || !get_floats(env, v, p->model_view, 16)) return 0;
     if (napi_get_named_property(env, o, "projection", &v) != napi_ok || !get_floats(env, v, p->projection, 16)) return 0;
-    if (!get_named_double(env, o, "width", &d, 1)) return 0; p->fb_width = (int32_t)d;
-    if (!get_named_double(env, o, "height", &d, 1)) return 0; p->fb_height = (int32_t)d;
+    if (!get_named_double(env, o, "width", &d, 1)) return 0;
+    p->fb_width = (int32_t)d;
+    if (!get_named_double(env, o, "height", &d, 1)) return 0;
+    p->fb_height = (int32_t)d;
     p->x0 = 0; p->x1 = p->fb_width;
-    d = 0; if (!get_named_double(env, o, "x0", &d, 0)) return 0; p->x0 = (int32_t)d;
-    d = p->fb_width; if (!get_named_double(env, o, "x1", &d, 0)) return 0; p->x1 = (int32_t)d;
-    d = 0; if (!get_named_double(env, o, "focal", &d, 0)) return 0; p->focal = (float)d;
-    d = 0; if (!get_named_double(env, o, "flags", &d, 0)) return 0; p->flags = (uint32_t)d;
+    d = 0;
+    if (!get_named_double(env, o, "x0", &d, 0)) return 0;
+    p->x0 = (int32_t)d;
+    d = p->fb_width;
+    if (!get_named_double(env, o, "x1", &d, 0)) return 0;
+    p->x1 = (int32_t)d;
+    d = 0;
+    if (!get_named_double(env, o, "focal", &d, 0)) return 0;
+    p->focal = (float)d;
+    d = 0;
+    if (!get_named_double(env, o, "flags", &d, 0)) return 0;
+    p->flags = (uint32_t)d;
     p->background[0] = p->background[1] = p->background[2] = 0.0f; p->background[3] = 1.0f;
     bool has = false;
     if (napi_has_named_property(env, o, "background", &has) == napi_ok && has) {

@@ -61,6 +61,29 @@ int hc_project(const float *cs, const uint32_t *cc, uint32_t idx, const float *m
     return 1;
 }
 
+
+// exact per-tile-row coverage: returns rows written; out[3*k] = ty, tx0, n.  Also the AABB rect in rect[4].
+__attribute__((visibility("default")))
+int hc_tile_rows(const float *rec8, int W, int H, int x0, int x1, int *out, int max_rows, int *rect)
+{
+    gsm::Projected p; memcpy(&p, rec8, 32);
+    gsm::ProjExtra x; memcpy(&x, rec8 + 8, 5 * sizeof(float));
+    float xmin, xmax, ymin, ymax;
+    gsm::splat_pixel_bounds(p, x, xmin, xmax, ymin, ymax);
+    const float fy0 = fmaxf(ymin, 0.0f), fy1 = fminf(ymax, (float)(H - 1));
+    const float fx0 = fmaxf(xmin, (float)x0), fx1 = fminf(xmax, (float)(x1 - 1));
+    if (!(fx0 <= fx1 && fy0 <= fy1)) return 0;
+    const int r0 = H - 1 - (int)fy1, r1 = H - 1 - (int)fy0;
+    rect[0] = ((int)fx0 - x0) / 16; rect[1] = r0 / 16; rect[2] = ((int)fx1 - x0) / 16; rect[3] = r1 / 16;
+    gsm::EllipseRows e; gsm::ellipse_rows_setup(p, e);
+    int k = 0;
+    for (int ty = r0 / 16; ty <= r1 / 16 && k < max_rows; ty++) {
+        uint32_t tx0, n; gsm::splat_tile_row(p, e, ty, H, x0, x1, tx0, n);
+        out[3 * k] = ty; out[3 * k + 1] = (int)tx0; out[3 * k + 2] = (int)n; k++;
+    }
+    return k;
+}
+
 __attribute__((visibility("default")))
 float hc_frag_power(float dx, float dy, float ax, float ay, float bx, float by) { return gsm::frag_power(dx, dy, ax, ay, bx, by); }
 

@@ -91,3 +91,52 @@ def test_project_matches_oracle_bit_exact(hc):
             hw = 2 * np.sqrt(np.float64(o.v1x) ** 2 + np.float64(o.v2x) ** 2)
             assert out[13] <= np.ceil(o.cx - hw - 0.5) and out[14] >= np.floor(o.cx + hw - 0.5)
     assert nvis > 500
+
+
+def test_exact_tile_rows_are_a_superset_of_pixel_coverage_and_tighter_than_the_rect(hc):
+    """Per-row ellipse/tile coverage (gsm::splat_tile_row): never misses a tile that holds a covered pixel centre
+    (|p|^2 <= 4 by the exact fragment formula), and prunes the bounding rectangle."""
+    hc.hc_tile_rows.restype = C.c_int
+    hc.hc_tile_rows.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+    synth = pkg("synth")
+    W, H = 640, 360
+    rows = synth.make_splat_rows(6000, seed=8)
+    cs, cc, _ = oracle.pack(rows)
+    tot_rect = tot_exact = checked = 0
+    for yaw, (x0, x1) in [(0.0, (0, W)), (140.0, (0, W)), (250.0, (160, 331))]:
+        cam = synth.index_html_camera(W, H, yaw_deg=yaw)
+        mv = cam["gs_mv"].astype(np.float32); P = cam["gs_proj"].astype(np.float32); focal = np.float32(cam["focal"])
+        out = np.zeros(17, np.float32); tr = np.zeros(3 * 64, np.int32); rect = np.zeros(4, np.int32)
+        for i in range(cs.shape[0]):
+            if not hc.hc_project(_p(cs), _p(cc), i, _p(mv), _p(P), focal, float(W), float(H), _p(out)):
+                continue
+            rec = np.concatenate([out[0:6], out[12:13], out[11:12], out[6:11]]).astype(np.float32)
+            k = hc.hc_tile_rows(_p(rec), W, H, x0, x1, _p(tr), 64, _p(rect))
+            if k == 0:
+                continue
+            t = tr[:3 * k].reshape(k, 3)
+            tot_rect += (rect[2] - rect[0] + 1) * (rect[3] - rect[1] + 1)
+            tot_exact += int(t[:, 2].sum())
+            nz = t[t[:, 2] > 0]
+            assert np.all(nz[:, 1] >= rect[0]) and np.all(nz[:, 1] + nz[:, 2] - 1 <= rect[2])
+            # exact pixel coverage inside the (clamped) bounding box
+            bx0, bx1 = int(max(out[13], x0)), int(min(out[14], x1 - 1))
+            by0, by1 = int(max(out[15], 0)), int(min(out[16], H - 1))
+            if (bx1 - bx0 + 1) * (by1 - by0 + 1) > 40000:
+                continue
+            xs = (np.arange(bx0, bx1 + 1, dtype=np.float32) + np.float32(0.5)) - out[0]
+            ys = (np.arange(by0, by1 + 1, dtype=np.float32) + np.float32(0.5)) - out[1]
+            dx, dy = np.meshgrid(xs, ys)
+            ppx = dx * out[2] + dy * out[3]; ppy = dx * out[4] + dy * out[5]
+            cov = (ppx * ppx + ppy * ppy) <= np.float32(4.0000005)
+            jj, ii = np.nonzero(cov)
+            if jj.size == 0:
+                continue
+            checked += 1
+            trow = (H - 1 - (jj + by0)) // 16; tcol = (ii + bx0 - x0) // 16
+            lut = {int(r[0]): (int(r[1]), int(r[1] + r[2] - 1)) for r in t}
+            for ty_, tx_ in set(zip(trow.tolist(), tcol.tolist())):
+                lo, hi = lut[ty_]
+                assert lo <= tx_ <= hi, (i, ty_, tx_, lo, hi)
+    assert checked > 1500
+    assert tot_exact < 0.9 * tot_rect, (tot_exact, tot_rect)
