@@ -44,10 +44,9 @@ int gs_ensure_pair_capacity(gs_ctx *ctx, size_t pairs)
     while (cap < pairs) cap += cap / 2 + 1;
     cap = (cap + GS_CHUNK - 1) / GS_CHUNK * GS_CHUNK;
     if (cap > 0xFFFF0000ull) FAIL(GS_E_OOM, "pair list of %zu entries exceeds the 32-bit index space", pairs);
-    dev_free(ctx->pkey_a); dev_free(ctx->pkey_b); dev_free(ctx->pval_a); dev_free(ctx->pval_b);
+    dev_free(ctx->pair_a); dev_free(ctx->pair_b);
     ctx->pair_cap = 0;
-    TRY(dev_alloc(ctx, &ctx->pkey_a, cap)); TRY(dev_alloc(ctx, &ctx->pkey_b, cap));
-    TRY(dev_alloc(ctx, &ctx->pval_a, cap)); TRY(dev_alloc(ctx, &ctx->pval_b, cap));
+    TRY(dev_alloc(ctx, &ctx->pair_a, cap)); TRY(dev_alloc(ctx, &ctx->pair_b, cap));
     ctx->pair_cap = cap;
     return ensure_scan_scratch(ctx);
 }
@@ -69,11 +68,10 @@ static int ensure_capacity(gs_ctx *ctx, size_t want)
     }
     dev_free(ctx->center_scale); dev_free(ctx->cov_color); dev_free(ctx->sort_rows);
     ctx->center_scale = cs; ctx->cov_color = cc; ctx->sort_rows = sr;
-    dev_free(ctx->depth); dev_free(ctx->key_a); dev_free(ctx->key_b); dev_free(ctx->val_a); dev_free(ctx->val_b);
+    dev_free(ctx->depth); dev_free(ctx->key_a); dev_free(ctx->kv_b); dev_free(ctx->val_a);
     dev_free(ctx->proj); dev_free(ctx->rect); dev_free(ctx->tile_count); dev_free(ctx->pair_off);
     TRY(dev_alloc(ctx, &ctx->depth, cap));
-    TRY(dev_alloc(ctx, &ctx->key_a, cap)); TRY(dev_alloc(ctx, &ctx->key_b, cap));
-    TRY(dev_alloc(ctx, &ctx->val_a, cap)); TRY(dev_alloc(ctx, &ctx->val_b, cap));
+    TRY(dev_alloc(ctx, &ctx->key_a, cap)); TRY(dev_alloc(ctx, &ctx->kv_b, cap)); TRY(dev_alloc(ctx, &ctx->val_a, cap));
     TRY(dev_alloc(ctx, &ctx->proj, cap)); TRY(dev_alloc(ctx, &ctx->rect, cap));
     TRY(dev_alloc(ctx, &ctx->tile_count, cap)); TRY(dev_alloc(ctx, &ctx->pair_off, cap));
     ctx->cap = cap;
@@ -116,6 +114,11 @@ GS_API int gs_create(int device, gs_ctx **out)
     for (int i = 0; i < 8; i++) CREATE_HIP(hipEventCreate(&ctx->ev[i]));
     CREATE_HIP(hipMalloc((void **)&ctx->ctl, sizeof(GsControl)));
     CREATE_HIP(hipMemset(ctx->ctl, 0, sizeof(GsControl)));
+    CREATE_HIP(hipMalloc((void **)&ctx->part_min, GS_MAX_PART * sizeof(unsigned long long)));
+    CREATE_HIP(hipMalloc((void **)&ctx->part_max, GS_MAX_PART * sizeof(unsigned long long)));
+    CREATE_HIP(hipMalloc((void **)&ctx->part_cnt, GS_MAX_PART * sizeof(uint32_t)));
+    CREATE_HIP(hipMalloc((void **)&ctx->part_valid, GS_MAX_PART * sizeof(uint32_t)));
+    CREATE_HIP(hipMalloc((void **)&ctx->part_vis, GS_MAX_PART * sizeof(uint32_t)));
     CREATE_HIP(hipHostMalloc((void **)&ctx->ctl_host, sizeof(GsControl), hipHostMallocDefault));
     memset(ctx->ctl_host, 0, sizeof(GsControl));
     {
@@ -135,11 +138,12 @@ GS_API int gs_destroy(gs_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     dev_free(ctx->center_scale); dev_free(ctx->cov_color); dev_free(ctx->sort_rows); dev_free(ctx->pow10tab);
-    dev_free(ctx->depth); dev_free(ctx->key_a); dev_free(ctx->key_b); dev_free(ctx->val_a); dev_free(ctx->val_b);
+    dev_free(ctx->depth); dev_free(ctx->key_a); dev_free(ctx->kv_b); dev_free(ctx->val_a);
     dev_free(ctx->hist); dev_free(ctx->spine);
     dev_free(ctx->proj); dev_free(ctx->rect); dev_free(ctx->tile_count); dev_free(ctx->pair_off);
-    dev_free(ctx->pkey_a); dev_free(ctx->pkey_b); dev_free(ctx->pval_a); dev_free(ctx->pval_b);
+    dev_free(ctx->pair_a); dev_free(ctx->pair_b);
     dev_free(ctx->tile_range); dev_free(ctx->fb); dev_free(ctx->ctl);
+    dev_free(ctx->part_min); dev_free(ctx->part_max); dev_free(ctx->part_cnt); dev_free(ctx->part_valid); dev_free(ctx->part_vis);
     if (ctx->ctl_host) (void)hipHostFree(ctx->ctl_host);
     for (int i = 0; i < 8; i++) if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);

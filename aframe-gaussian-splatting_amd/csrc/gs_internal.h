@@ -12,6 +12,7 @@
 #define GS_BLOCK 256               // threads per workgroup everywhere (4 wavefronts of 64)
 #define GS_CHUNK 2048              // items per workgroup pass in streaming kernels (8 per thread)
 #define GS_RADIX_MAX_BINS 512      // up to 9-bit digits (depth key = 17 bits = 8 + 9)
+#define GS_MAX_PART 8192           // upper bound on the grid of any kernel that writes per-workgroup partials
 #define GS_CULLED_KEY 65536u       // depth-sort key of culled / dropped splats (sorts behind every bucket)
 
 // Device-resident control block: every data-dependent count lives here so that no stage needs a
@@ -58,7 +59,8 @@ struct gs_ctx {
 
     // sort scratch (sized by cap)
     float *depth;                  // stored f32 depth or +inf for culled
-    uint32_t *key_a, *key_b, *val_a, *val_b;
+    uint32_t *key_a, *val_a;       // bucket keys in, sorted indices out
+    uint2 *kv_b;                   // (key,val) records between the two passes
     uint32_t *sorted;              // alias of the buffer holding the final order
     uint32_t sorted_n_host;        // V as last read back (only when the caller asked for it)
     bool have_sort;
@@ -72,9 +74,12 @@ struct gs_ctx {
     uint2 *rect;                   // V x (tx0 | ty0<<16, tx1 | ty1<<16), strip-local tile coords
     uint32_t *tile_count;          // V
     uint32_t *pair_off;            // V exclusive offsets
-    uint32_t *pkey_a, *pkey_b, *pval_a, *pval_b; size_t pair_cap;
+    uint2 *pair_a, *pair_b; size_t pair_cap;   // (tile id, sorted position) records, ping-pong
     uint2 *tile_range; size_t tile_cap;     // per tile [start,end) into the sorted pair list
     uint8_t *fb; size_t fb_cap;             // RGBA8 strip
+    // per-workgroup partial reductions (instead of same-address global atomics, which serialise at ~11 ns each)
+    unsigned long long *part_min, *part_max;   // [GS_MAX_PART]
+    uint32_t *part_cnt, *part_valid, *part_vis; // [GS_MAX_PART]
     GsControl *ctl;                // device
     GsControl *ctl_host;           // pinned host mirror
 
@@ -103,10 +108,11 @@ static inline uint32_t gs_div_up(uint64_t a, uint64_t b) { return (uint32_t)((a 
 // `total_out` (device, optional) receives the grand total.
 int gs_launch_scan(gs_ctx *ctx, const uint32_t *in, uint32_t *out, const uint32_t *n_ptr, int hist_bits,
                    uint32_t max_n, uint32_t *total_out);
-// One stable LSD radix pass over n = *n_ptr (key,val) pairs on digit (key >> shift) & (2^bits-1).
-// vals_in == NULL: the value is the element index.  keys_out may be NULL.
-int gs_launch_radix_pass(gs_ctx *ctx, const uint32_t *keys_in, const uint32_t *vals_in, uint32_t *keys_out,
-                         uint32_t *vals_out, const uint32_t *n_ptr, uint32_t max_n, int shift, int bits);
+// One stable LSD radix pass over n = *n_ptr items on digit (key >> shift) & (2^bits-1).
+// in:  packed (key,val) uint2 records, or a plain key array whose value is the element index.
+// out: packed (key,val) uint2 records, or the values alone (final pass).
+int gs_launch_radix_pass(gs_ctx *ctx, const void *in, bool in_packed, void *out, bool out_packed, const uint32_t *n_ptr,
+                         uint32_t max_n, int shift, int bits);
 // ---- gs_pack.hip
 int gs_launch_pack(gs_ctx *ctx, const uint4 *rows_dev, size_t first, size_t nrows);
 // ---- gs_sort.hip

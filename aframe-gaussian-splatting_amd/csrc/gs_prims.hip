@@ -118,8 +118,9 @@ __global__ __launch_bounds__(GS_BLOCK) void k_scan_down(const uint32_t *in, uint
 
 // ---------------------------------------------------------------- radix pass
 
-// Per-chunk digit histogram -> hist[digit * nchunks + chunk] (digit-major, so ONE flat exclusive scan of
-// the table yields every (digit, chunk) base offset of the stable scatter).
+// Per-chunk digit histogram -> hist[digit * nchunks + chunk] (digit-major: each digit's row is contiguous for
+// k_radix_rowscan).  PACKED: keys are the .x of (key,val) uint2 records.
+template <bool PACKED>
 __global__ __launch_bounds__(GS_BLOCK) void k_radix_hist(const uint32_t *__restrict__ keys, const uint32_t *n_ptr, int shift,
                                                          int bits, uint32_t *__restrict__ hist)
 {
@@ -133,7 +134,7 @@ __global__ __launch_bounds__(GS_BLOCK) void k_radix_hist(const uint32_t *__restr
 #pragma unroll
         for (int r = 0; r < 8; r++) {
             const uint32_t i = c * GS_CHUNK + r * GS_BLOCK + threadIdx.x;
-            if (i < n) atomicAdd(&s_hist[(keys[i] >> shift) & mask], 1u);
+            if (i < n) atomicAdd(&s_hist[(keys[PACKED ? 2 * (size_t)i : i] >> shift) & mask], 1u);
         }
         __syncthreads();
         for (uint32_t d = threadIdx.x; d < nbins; d += GS_BLOCK) hist[d * nchunks + c] = s_hist[d];
@@ -141,21 +142,56 @@ __global__ __launch_bounds__(GS_BLOCK) void k_radix_hist(const uint32_t *__restr
     }
 }
 
+// One workgroup per digit: exclusive scan of that digit's row hist[d][0..nchunks) in place (running offset of
+// every chunk inside the digit's output run) and the row total -> totals[d].  Replaces a 3-kernel flat scan.
+__global__ __launch_bounds__(GS_BLOCK) void k_radix_rowscan(uint32_t *__restrict__ hist, const uint32_t *n_ptr, uint32_t *__restrict__ totals)
+{
+    __shared__ uint32_t s_wave[4];
+    const uint32_t n = *n_ptr;
+    const uint32_t nchunks = (n + GS_CHUNK - 1) / GS_CHUNK;
+    uint32_t *row = hist + (size_t)blockIdx.x * nchunks;
+    uint32_t carry = 0;
+    for (uint32_t base = 0; base < nchunks; base += GS_CHUNK) {
+        const uint32_t i0 = base + threadIdx.x * 8;
+        uint32_t v[8], sum = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < 8; k++) { v[k] = (i0 + k < nchunks) ? row[i0 + k] : 0u; sum += v[k]; }
+        uint32_t tot;
+        uint32_t run = carry + block_excl_scan(sum, s_wave, &tot);
+#pragma unroll
+        for (uint32_t k = 0; k < 8; k++) { if (i0 + k < nchunks) row[i0 + k] = run; run += v[k]; }
+        carry += tot;
+    }
+    if (threadIdx.x == 0) totals[blockIdx.x] = carry;
+}
+
 // Stable scatter.  Item order inside a chunk: wave w owns items [w*512, w*512+512), processed in 8 rounds
 // of 64 consecutive items (lane = item % 64), so "earlier" == (wave, round, lane) lexicographic.
 // Rank among equal digits: in-round via ballot match (one ballot per digit bit), across rounds via a
-// wave-private LDS counter row, across waves via a 4-way prefix added to the scanned global base.
-__global__ __launch_bounds__(GS_BLOCK) void k_radix_scatter(const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
-                                                            uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out,
+// wave-private LDS counter row, across waves via a 4-way prefix added to the chunk's offset in the digit run.
+// IN_PACKED: input is (key,val) uint2 records, else a key array whose value is the element index.
+// OUT_PACKED: output is (key,val) uint2 records (one 8-byte store per item), else the value alone (last pass).
+template <bool IN_PACKED, bool OUT_PACKED>
+__global__ __launch_bounds__(GS_BLOCK) void k_radix_scatter(const void *__restrict__ in, void *__restrict__ out,
                                                             const uint32_t *n_ptr, int shift, int bits,
-                                                            const uint32_t *__restrict__ hist_scanned)
+                                                            const uint32_t *__restrict__ hist_scanned, const uint32_t *__restrict__ totals)
 {
     __shared__ uint32_t s_cnt[4][GS_RADIX_MAX_BINS];            // 8 KiB
+    __shared__ uint32_t s_dbase[GS_RADIX_MAX_BINS];             // start of every digit's output run
+    __shared__ uint32_t s_wave[4];
     const uint32_t n = *n_ptr;
     const uint32_t nchunks = (n + GS_CHUNK - 1) / GS_CHUNK;
     const uint32_t nbins = 1u << bits, mask = nbins - 1;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const unsigned long long lt = (1ull << lane) - 1ull;
+    if (blockIdx.x >= nchunks) return;
+    {   // exclusive scan of the <= 512 digit totals (2 per thread)
+        const uint32_t d0 = threadIdx.x * 2;
+        const uint32_t v0 = d0 < nbins ? totals[d0] : 0u, v1 = d0 + 1 < nbins ? totals[d0 + 1] : 0u;
+        uint32_t tot;
+        const uint32_t ex = block_excl_scan(v0 + v1, s_wave, &tot);
+        s_dbase[d0] = ex; s_dbase[d0 + 1] = ex + v0;
+    }
     for (uint32_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
         for (uint32_t i = threadIdx.x; i < 4 * GS_RADIX_MAX_BINS; i += GS_BLOCK) (&s_cnt[0][0])[i] = 0;
         __syncthreads();
@@ -164,8 +200,13 @@ __global__ __launch_bounds__(GS_BLOCK) void k_radix_scatter(const uint32_t *__re
         for (int r = 0; r < 8; r++) {
             const uint32_t i = c * GS_CHUNK + w * 512 + r * 64 + lane;
             const bool ok = i < n;
-            key[r] = ok ? keys_in[i] : 0xFFFFFFFFu;
-            val[r] = ok ? (vals_in ? vals_in[i] : i) : 0u;
+            if (IN_PACKED) {
+                const uint2 kv = ok ? reinterpret_cast<const uint2 *>(in)[i] : make_uint2(0xFFFFFFFFu, 0u);
+                key[r] = kv.x; val[r] = kv.y;
+            } else {
+                key[r] = ok ? reinterpret_cast<const uint32_t *>(in)[i] : 0xFFFFFFFFu;
+                val[r] = i;
+            }
             const uint32_t d = (key[r] >> shift) & mask;
             unsigned long long peers = __ballot(ok);
             for (int b = 0; b < bits; b++) {
@@ -183,7 +224,7 @@ __global__ __launch_bounds__(GS_BLOCK) void k_radix_scatter(const uint32_t *__re
         __syncthreads();
         for (uint32_t d = threadIdx.x; d < nbins; d += GS_BLOCK) {
             const uint32_t c0 = s_cnt[0][d], c1 = s_cnt[1][d], c2 = s_cnt[2][d];
-            const uint32_t base = hist_scanned[d * nchunks + c];
+            const uint32_t base = s_dbase[d] + hist_scanned[d * nchunks + c];
             s_cnt[0][d] = base; s_cnt[1][d] = base + c0; s_cnt[2][d] = base + c0 + c1; s_cnt[3][d] = base + c0 + c1 + c2;
         }
         __syncthreads();
@@ -193,8 +234,8 @@ __global__ __launch_bounds__(GS_BLOCK) void k_radix_scatter(const uint32_t *__re
             if (i < n) {
                 const uint32_t d = (key[r] >> shift) & mask;
                 const uint32_t pos = s_cnt[w][d] + rank[r];
-                if (keys_out) keys_out[pos] = key[r];
-                vals_out[pos] = val[r];
+                if (OUT_PACKED) reinterpret_cast<uint2 *>(out)[pos] = make_uint2(key[r], val[r]);
+                else reinterpret_cast<uint32_t *>(out)[pos] = val[r];
             }
         }
         __syncthreads();
@@ -223,16 +264,20 @@ int gs_launch_scan(gs_ctx *ctx, const uint32_t *in, uint32_t *out, const uint32_
     return GS_OK;
 }
 
-int gs_launch_radix_pass(gs_ctx *ctx, const uint32_t *keys_in, const uint32_t *vals_in, uint32_t *keys_out, uint32_t *vals_out,
-                         const uint32_t *n_ptr, uint32_t max_n, int shift, int bits)
+int gs_launch_radix_pass(gs_ctx *ctx, const void *in, bool in_packed, void *out, bool out_packed, const uint32_t *n_ptr,
+                         uint32_t max_n, int shift, int bits)
 {
     const uint32_t g = grid_for(max_n);
-    hipLaunchKernelGGL(k_radix_hist, dim3(g), dim3(GS_BLOCK), 0, ctx->stream, keys_in, n_ptr, shift, bits, ctx->hist);
-    const uint32_t max_hist = gs_div_up(max_n, GS_CHUNK) << bits;
-    int rc = gs_launch_scan(ctx, ctx->hist, ctx->hist, n_ptr, bits, max_hist, nullptr);
-    if (rc != GS_OK) return rc;
-    hipLaunchKernelGGL(k_radix_scatter, dim3(g), dim3(GS_BLOCK), 0, ctx->stream, keys_in, vals_in, keys_out, vals_out, n_ptr,
-                       shift, bits, ctx->hist);
+    uint32_t *totals = ctx->spine;                               // 2^bits words; no generic scan is in flight here
+    const dim3 G(g), B(GS_BLOCK);
+    hipStream_t st = ctx->stream;
+    if (in_packed) hipLaunchKernelGGL(k_radix_hist<true>, G, B, 0, st, (const uint32_t *)in, n_ptr, shift, bits, ctx->hist);
+    else hipLaunchKernelGGL(k_radix_hist<false>, G, B, 0, st, (const uint32_t *)in, n_ptr, shift, bits, ctx->hist);
+    hipLaunchKernelGGL(k_radix_rowscan, dim3(1u << bits), B, 0, st, ctx->hist, n_ptr, totals);
+    if (in_packed && out_packed) hipLaunchKernelGGL((k_radix_scatter<true, true>), G, B, 0, st, in, out, n_ptr, shift, bits, ctx->hist, totals);
+    else if (in_packed) hipLaunchKernelGGL((k_radix_scatter<true, false>), G, B, 0, st, in, out, n_ptr, shift, bits, ctx->hist, totals);
+    else if (out_packed) hipLaunchKernelGGL((k_radix_scatter<false, true>), G, B, 0, st, in, out, n_ptr, shift, bits, ctx->hist, totals);
+    else hipLaunchKernelGGL((k_radix_scatter<false, false>), G, B, 0, st, in, out, n_ptr, shift, bits, ctx->hist, totals);
     GS_HIP(hipGetLastError());
     return GS_OK;
 }

@@ -18,24 +18,28 @@
 
 namespace {
 
-__global__ void k_render_init(GsControl *ctl)
-{
-    ctl->n_visible = 0; ctl->n_pairs = 0; ctl->pair_overflow = 0; ctl->n_frags = 0;
-}
-
+// Vertex-shader stage.  One thread per sorted splat; splats whose bounding box spans more than 16 tile rows
+// (a small minority, but up to 68 rows each) are queued in LDS and their exact per-row tile counts are summed by
+// a whole wavefront (one lane per tile row) so a single lane never walks 68 rows while 63 idle.
 __global__ __launch_bounds__(GS_BLOCK) void k_project(const uint32_t *__restrict__ sorted, const float4 *__restrict__ center_scale,
                                                       const uint4 *__restrict__ cov_color, GsFrameUniforms u,
                                                       gsm::Projected *__restrict__ proj, uint2 *__restrict__ rect,
-                                                      uint32_t *__restrict__ tile_count, GsControl *ctl)
+                                                      uint32_t *__restrict__ tile_count, uint32_t *__restrict__ part_vis,
+                                                      const GsControl *ctl)
 {
-    __shared__ uint32_t s_vis;
+    __shared__ float s_rec[GS_BLOCK][6];
+    __shared__ uint32_t s_rows[GS_BLOCK], s_j[GS_BLOCK];
+    __shared__ uint32_t s_nbig, s_vis;
     const uint32_t V = ctl->n_kept;
     const uint32_t nchunks = (V + GS_BLOCK - 1) / GS_BLOCK;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (threadIdx.x == 0) s_vis = 0;
     for (uint32_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
-        if (threadIdx.x == 0) s_vis = 0;
+        if (threadIdx.x == 0) s_nbig = 0;
         __syncthreads();
         const uint32_t j = c * GS_BLOCK + threadIdx.x;
         uint32_t count = 0;
+        bool queued = false;
         if (j < V) {
             const uint32_t idx = sorted[j];
             const float4 cs4 = center_scale[idx];
@@ -54,35 +58,76 @@ __global__ __launch_bounds__(GS_BLOCK) void k_project(const uint32_t *__restrict
                     const int r0 = u.H - 1 - jy1, r1 = u.H - 1 - jy0;           // GL rows (y up) -> image rows (top-down)
                     const uint32_t tx0 = (uint32_t)(ix0 - u.x0) / GS_TILE, tx1 = (uint32_t)(ix1 - u.x0) / GS_TILE;
                     const uint32_t ty0 = (uint32_t)r0 / GS_TILE, ty1 = (uint32_t)r1 / GS_TILE;
-                    // exact coverage: per tile row, the contiguous run of tiles the ellipse touches
-                    gsm::EllipseRows e;
-                    gsm::ellipse_rows_setup(p, e);
-                    for (uint32_t ty = ty0; ty <= ty1; ty++) {
-                        uint32_t a, n;
-                        gsm::splat_tile_row(p, e, (int)ty, u.H, u.x0, u.x1, a, n);
-                        count += n;
-                    }
                     rect[j] = make_uint2(tx0 | (ty0 << 16), tx1 | (ty1 << 16));
                     float4 *dst = reinterpret_cast<float4 *>(proj + j);
                     dst[0] = make_float4(p.cx, p.cy, p.ax, p.ay);
                     dst[1] = make_float4(p.bx, p.by, __uint_as_float(p.rgba), p.alpha);
+                    if (ty1 - ty0 >= 16) {                                      // > 16 tile rows: count cooperatively
+                        const uint32_t q = atomicAdd(&s_nbig, 1u);
+                        s_rec[q][0] = p.cx; s_rec[q][1] = p.cy; s_rec[q][2] = p.ax; s_rec[q][3] = p.ay; s_rec[q][4] = p.bx; s_rec[q][5] = p.by;
+                        s_rows[q] = ty0 | (ty1 << 16); s_j[q] = j;
+                        queued = true;
+                    } else {
+                        // exact coverage: per tile row, the contiguous run of tiles the ellipse touches
+                        gsm::EllipseRows e;
+                        gsm::ellipse_rows_setup(p, e);
+                        for (uint32_t ty = ty0; ty <= ty1; ty++) {
+                            uint32_t a, n;
+                            gsm::splat_tile_row(p, e, (int)ty, u.H, u.x0, u.x1, a, n);
+                            count += n;
+                        }
+                    }
                 }
             }
-            tile_count[j] = count;
+            if (!queued) tile_count[j] = count;
         }
-        if (count) atomicAdd(&s_vis, 1u);
+        uint32_t vis = count ? 1u : 0u;
         __syncthreads();
-        if (threadIdx.x == 0 && s_vis) atomicAdd(&ctl->n_visible, s_vis);
+        const uint32_t nbig = s_nbig;
+        for (uint32_t bi = w; bi < nbig; bi += 4) {                   // one wavefront per queued splat
+            gsm::Projected p;
+            p.cx = s_rec[bi][0]; p.cy = s_rec[bi][1]; p.ax = s_rec[bi][2]; p.ay = s_rec[bi][3]; p.bx = s_rec[bi][4]; p.by = s_rec[bi][5];
+            gsm::EllipseRows e;
+            gsm::ellipse_rows_setup(p, e);
+            const uint32_t ty0 = s_rows[bi] & 0xFFFF, ty1 = s_rows[bi] >> 16;
+            uint32_t sum = 0;
+            for (uint32_t ty = ty0 + lane; ty <= ty1; ty += 64) {
+                uint32_t a, n;
+                gsm::splat_tile_row(p, e, (int)ty, u.H, u.x0, u.x1, a, n);
+                sum += n;
+            }
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) sum += __shfl_xor(sum, m, 64);
+            if (lane == 0) { tile_count[s_j[bi]] = sum; if (sum) vis++; }
+        }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) vis += __shfl_xor(vis, m, 64);
+        if (lane == 0 && vis) atomicAdd(&s_vis, vis);
         __syncthreads();
     }
+    __syncthreads();
+    if (threadIdx.x == 0) part_vis[blockIdx.x] = s_vis;
 }
 
-// after the scan: I = scan_total; refuse (and flag) if it does not fit the pair buffers
-__global__ void k_pairs_check(GsControl *ctl, uint32_t pair_cap)
+// after the scan: I = scan_total, refused (and flagged) if it does not fit the pair buffers; Vp from the partials
+__global__ __launch_bounds__(GS_BLOCK) void k_pairs_check(GsControl *ctl, uint32_t pair_cap, const uint32_t *__restrict__ part_vis,
+                                                          uint32_t nparts)
 {
-    const uint32_t total = ctl->scan_total;
-    if (total > pair_cap) { ctl->pair_overflow = 1; ctl->n_pairs = 0; }
-    else ctl->n_pairs = total;
+    __shared__ uint32_t s_vis;
+    if (threadIdx.x == 0) s_vis = 0;
+    __syncthreads();
+    uint32_t v = 0;
+    for (uint32_t i = threadIdx.x; i < nparts; i += GS_BLOCK) v += part_vis[i];
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    if ((threadIdx.x & 63) == 0 && v) atomicAdd(&s_vis, v);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t total = ctl->scan_total;
+        ctl->n_visible = s_vis;
+        if (total > pair_cap) { ctl->pair_overflow = 1; ctl->n_pairs = 0; }
+        else { ctl->pair_overflow = 0; ctl->n_pairs = total; }
+    }
 }
 
 // (tile id, sorted position) pairs in splat order.  Splats touching few tiles are written by their own lane;
@@ -91,8 +136,7 @@ __global__ void k_pairs_check(GsControl *ctl, uint32_t pair_cap)
 #define GS_EMIT_BIG 32u
 __global__ __launch_bounds__(GS_BLOCK) void k_emit(const gsm::Projected *__restrict__ proj, const uint2 *__restrict__ rect,
                                                    const uint32_t *__restrict__ tile_count, const uint32_t *__restrict__ pair_off,
-                                                   GsFrameUniforms u, uint32_t *__restrict__ pkey, uint32_t *__restrict__ pval,
-                                                   const GsControl *ctl)
+                                                   GsFrameUniforms u, uint2 *__restrict__ pairs, const GsControl *ctl)
 {
     __shared__ uint32_t s_big[GS_BLOCK];
     __shared__ uint32_t s_nbig;
@@ -119,7 +163,7 @@ __global__ __launch_bounds__(GS_BLOCK) void k_emit(const gsm::Projected *__restr
             for (uint32_t ty = r.x >> 16; ty <= (r.y >> 16); ty++) {
                 uint32_t t0, n;
                 gsm::splat_tile_row(p, e, (int)ty, u.H, u.x0, u.x1, t0, n);
-                for (uint32_t k = 0; k < n; k++) { pkey[o] = ty * tiles_x + t0 + k; pval[o] = j; o++; }
+                for (uint32_t k = 0; k < n; k++) pairs[o++] = make_uint2(ty * tiles_x + t0 + k, j);
             }
         }
         __syncthreads();
@@ -142,7 +186,7 @@ __global__ __launch_bounds__(GS_BLOCK) void k_emit(const gsm::Projected *__restr
 #pragma unroll
                 for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(inc, d, 64); if (lane >= d) inc += t; }
                 uint32_t o = base + inc - n;
-                for (uint32_t k = 0; k < n; k++) { pkey[o] = ty * tiles_x + t0 + k; pval[o] = jb; o++; }
+                for (uint32_t k = 0; k < n; k++) pairs[o++] = make_uint2(ty * tiles_x + t0 + k, jb);
                 base += __shfl(inc, 63, 64);
             }
         }
@@ -150,20 +194,20 @@ __global__ __launch_bounds__(GS_BLOCK) void k_emit(const gsm::Projected *__restr
     }
 }
 
-__global__ __launch_bounds__(GS_BLOCK) void k_tile_ranges(const uint32_t *__restrict__ pkey, uint2 *__restrict__ range,
+__global__ __launch_bounds__(GS_BLOCK) void k_tile_ranges(const uint2 *__restrict__ pairs, uint2 *__restrict__ range,
                                                           const GsControl *ctl)
 {
     const uint32_t I = ctl->n_pairs;
     for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < I; p += gridDim.x * blockDim.x) {
-        const uint32_t k = pkey[p];
-        if (p == 0 || pkey[p - 1] != k) range[k].x = p;
-        if (p == I - 1 || pkey[p + 1] != k) range[k].y = p + 1;
+        const uint32_t k = pairs[p].x;
+        if (p == 0 || pairs[p - 1].x != k) range[k].x = p;
+        if (p == I - 1 || pairs[p + 1].x != k) range[k].y = p + 1;
     }
 }
 
 // Fragment shader + blend for one 16x16 tile.  Thread t shades pixel (t%16, t/16) of the tile.
 template <bool COUNT>
-__global__ __launch_bounds__(GS_BLOCK) void k_blend(const uint2 *__restrict__ tile_range, const uint32_t *__restrict__ pval,
+__global__ __launch_bounds__(GS_BLOCK) void k_blend(const uint2 *__restrict__ tile_range, const uint2 *__restrict__ pairs,
                                                     const gsm::Projected *__restrict__ proj, GsFrameUniforms u,
                                                     uint8_t *__restrict__ out, GsControl *ctl)
 {
@@ -186,7 +230,7 @@ __global__ __launch_bounds__(GS_BLOCK) void k_blend(const uint2 *__restrict__ ti
     for (uint32_t end = range.y; end > range.x;) {
         const uint32_t nb = min((uint32_t)GS_BLOCK, end - range.x);
         if (threadIdx.x < nb) {                                    // nearest first: reverse the back-to-front list
-            const uint32_t j = pval[end - 1 - threadIdx.x];
+            const uint32_t j = pairs[end - 1 - threadIdx.x].y;
             const float4 *src = reinterpret_cast<const float4 *>(proj + j);
             s_rec[2 * threadIdx.x] = src[0];
             s_rec[2 * threadIdx.x + 1] = src[1];
@@ -245,49 +289,50 @@ int gs_run_render(gs_ctx *ctx, const GsFrameUniforms &u, uint8_t *device_out)
     hipStream_t st = ctx->stream;
 
     if (ctx->profile) GS_HIP(hipEventRecord(ctx->ev[2], st));
-    hipLaunchKernelGGL(k_render_init, dim3(1), dim3(1), 0, st, ctx->ctl);
+    if (u.flags & GS_RENDER_COUNT_FRAGS) GS_HIP(hipMemsetAsync(&ctx->ctl->n_frags, 0, sizeof(unsigned long long), st));
     if (Vmax && ctx->have_sort) {
-        uint32_t g = gs_div_up(Vmax, GS_BLOCK); if (g > 8192) g = 8192;
+        uint32_t g = gs_div_up(Vmax, GS_BLOCK); if (g > GS_MAX_PART) g = GS_MAX_PART;
         hipLaunchKernelGGL(k_project, dim3(g), dim3(GS_BLOCK), 0, st, ctx->sorted, ctx->center_scale, ctx->cov_color, u, ctx->proj,
-                           ctx->rect, ctx->tile_count, ctx->ctl);
+                           ctx->rect, ctx->tile_count, ctx->part_vis, ctx->ctl);
         GS_HIP(hipGetLastError());
         if (ctx->profile) GS_HIP(hipEventRecord(ctx->ev[3], st));
         int rc = gs_launch_scan(ctx, ctx->tile_count, ctx->pair_off, &ctx->ctl->n_kept, 0, Vmax, nullptr);
         if (rc != GS_OK) return rc;
-        hipLaunchKernelGGL(k_pairs_check, dim3(1), dim3(1), 0, st, ctx->ctl, (uint32_t)ctx->pair_cap);
+        hipLaunchKernelGGL(k_pairs_check, dim3(1), dim3(GS_BLOCK), 0, st, ctx->ctl, (uint32_t)ctx->pair_cap, ctx->part_vis, g);
         uint32_t ge = gs_div_up(Vmax, GS_BLOCK); if (ge > 4096) ge = 4096;
         hipLaunchKernelGGL(k_emit, dim3(ge), dim3(GS_BLOCK), 0, st, ctx->proj, ctx->rect, ctx->tile_count, ctx->pair_off, u,
-                           ctx->pkey_a, ctx->pval_a, ctx->ctl);
+                           ctx->pair_a, ctx->ctl);
         GS_HIP(hipGetLastError());
         const int tb = bits_for(ntiles);
-        const uint32_t *fkey, *fval;
+        const uint2 *fpairs;
         const uint32_t pc = (uint32_t)ctx->pair_cap;
         if (tb <= 9) {
-            rc = gs_launch_radix_pass(ctx, ctx->pkey_a, ctx->pval_a, ctx->pkey_b, ctx->pval_b, &ctx->ctl->n_pairs, pc, 0, tb);
+            rc = gs_launch_radix_pass(ctx, ctx->pair_a, true, ctx->pair_b, true, &ctx->ctl->n_pairs, pc, 0, tb);
             if (rc != GS_OK) return rc;
-            fkey = ctx->pkey_b; fval = ctx->pval_b;
+            fpairs = ctx->pair_b;
         } else {
             const int b1 = (tb + 1) / 2, b2 = tb - b1;
-            rc = gs_launch_radix_pass(ctx, ctx->pkey_a, ctx->pval_a, ctx->pkey_b, ctx->pval_b, &ctx->ctl->n_pairs, pc, 0, b1);
+            rc = gs_launch_radix_pass(ctx, ctx->pair_a, true, ctx->pair_b, true, &ctx->ctl->n_pairs, pc, 0, b1);
             if (rc != GS_OK) return rc;
-            rc = gs_launch_radix_pass(ctx, ctx->pkey_b, ctx->pval_b, ctx->pkey_a, ctx->pval_a, &ctx->ctl->n_pairs, pc, b1, b2);
+            rc = gs_launch_radix_pass(ctx, ctx->pair_b, true, ctx->pair_a, true, &ctx->ctl->n_pairs, pc, b1, b2);
             if (rc != GS_OK) return rc;
-            fkey = ctx->pkey_a; fval = ctx->pval_a;
+            fpairs = ctx->pair_a;
         }
         GS_HIP(hipMemsetAsync(ctx->tile_range, 0, sizeof(uint2) * ntiles, st));
-        hipLaunchKernelGGL(k_tile_ranges, dim3(2048), dim3(GS_BLOCK), 0, st, fkey, ctx->tile_range, ctx->ctl);
+        hipLaunchKernelGGL(k_tile_ranges, dim3(2048), dim3(GS_BLOCK), 0, st, fpairs, ctx->tile_range, ctx->ctl);
         GS_HIP(hipGetLastError());
         if (ctx->profile) GS_HIP(hipEventRecord(ctx->ev[4], st));
         if (u.flags & GS_RENDER_COUNT_FRAGS)
-            hipLaunchKernelGGL(k_blend<true>, dim3(ntiles), dim3(GS_BLOCK), 0, st, ctx->tile_range, fval, ctx->proj, u, out, ctx->ctl);
+            hipLaunchKernelGGL(k_blend<true>, dim3(ntiles), dim3(GS_BLOCK), 0, st, ctx->tile_range, fpairs, ctx->proj, u, out, ctx->ctl);
         else
-            hipLaunchKernelGGL(k_blend<false>, dim3(ntiles), dim3(GS_BLOCK), 0, st, ctx->tile_range, fval, ctx->proj, u, out, ctx->ctl);
+            hipLaunchKernelGGL(k_blend<false>, dim3(ntiles), dim3(GS_BLOCK), 0, st, ctx->tile_range, fpairs, ctx->proj, u, out, ctx->ctl);
         GS_HIP(hipGetLastError());
     } else {
         // nothing resident / never sorted: the frame is the background
+        GS_HIP(hipMemsetAsync(ctx->ctl, 0, sizeof(GsControl), st));
         GS_HIP(hipMemsetAsync(ctx->tile_range, 0, sizeof(uint2) * ntiles, st));
         if (ctx->profile) { GS_HIP(hipEventRecord(ctx->ev[3], st)); GS_HIP(hipEventRecord(ctx->ev[4], st)); }
-        hipLaunchKernelGGL(k_blend<false>, dim3(ntiles), dim3(GS_BLOCK), 0, st, ctx->tile_range, ctx->pval_a, ctx->proj, u, out, ctx->ctl);
+        hipLaunchKernelGGL(k_blend<false>, dim3(ntiles), dim3(GS_BLOCK), 0, st, ctx->tile_range, ctx->pair_a, ctx->proj, u, out, ctx->ctl);
         GS_HIP(hipGetLastError());
     }
     if (ctx->profile) GS_HIP(hipEventRecord(ctx->ev[5], st));

@@ -20,24 +20,20 @@ __device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v,
     return ((unsigned long long)hi << 32) | lo;
 }
 
-__global__ void k_sort_init(GsControl *ctl, uint32_t n)
-{
-    ctl->min_enc = ~0ull; ctl->max_enc = 0ull;
-    ctl->n_total = n; ctl->n_kept = 0; ctl->n_valid = 0;
-}
-
 // pass 1 (index.js:517-555): depth, culls, f64 min/max of survivors.  16 B/splat in, 4 B/splat out.
+// Each workgroup leaves its (min, max, count) in a partial slot; no global atomics.
 __global__ __launch_bounds__(GS_BLOCK) void k_sort_depth(const float4 *__restrict__ rows, uint32_t n, SortUniforms u,
-                                                         float *__restrict__ depth_out, GsControl *ctl)
+                                                         float *__restrict__ depth_out, unsigned long long *__restrict__ part_min,
+                                                         unsigned long long *__restrict__ part_max, uint32_t *__restrict__ part_cnt)
 {
     __shared__ unsigned long long s_min, s_max;
     __shared__ uint32_t s_cnt;
+    if (threadIdx.x == 0) { s_min = ~0ull; s_max = 0ull; s_cnt = 0; }
+    __syncthreads();
     const uint32_t nchunks = (n + GS_CHUNK - 1) / GS_CHUNK;
+    unsigned long long mn = ~0ull, mx = 0ull;
+    uint32_t cnt = 0;
     for (uint32_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
-        if (threadIdx.x == 0) { s_min = ~0ull; s_max = 0ull; s_cnt = 0; }
-        __syncthreads();
-        unsigned long long mn = ~0ull, mx = 0ull;
-        uint32_t cnt = 0;
 #pragma unroll
         for (int r = 0; r < 8; r++) {
             const uint32_t i = c * GS_CHUNK + r * GS_BLOCK + threadIdx.x;
@@ -53,33 +49,51 @@ __global__ __launch_bounds__(GS_BLOCK) void k_sort_depth(const float4 *__restric
                 }
             }
         }
+    }
 #pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) {                       // wavefront butterfly: one LDS atomic per wave, not per lane
+    for (int m = 32; m >= 1; m >>= 1) {                           // wavefront butterfly, then one LDS atomic per wave
+        const unsigned long long omn = shfl_xor_u64(mn, m), omx = shfl_xor_u64(mx, m);
+        mn = omn < mn ? omn : mn; mx = omx > mx ? omx : mx;
+        cnt += __shfl_xor(cnt, m, 64);
+    }
+    if ((threadIdx.x & 63) == 0 && cnt) { atomicMin(&s_min, mn); atomicMax(&s_max, mx); atomicAdd(&s_cnt, cnt); }
+    __syncthreads();
+    if (threadIdx.x == 0) { part_min[blockIdx.x] = s_min; part_max[blockIdx.x] = s_max; part_cnt[blockIdx.x] = s_cnt; }
+}
+
+// pass 2 (index.js:558-561): 16-bit bucket of the stored depth; culled/dropped -> GS_CULLED_KEY.
+// Every workgroup first folds pass 1's partials (<= 2048 slots, L2-resident) into the global min/max.
+__global__ __launch_bounds__(GS_BLOCK) void k_sort_bucket(const float *__restrict__ depth, uint32_t n, uint32_t *__restrict__ keys,
+                                                          const unsigned long long *__restrict__ part_min,
+                                                          const unsigned long long *__restrict__ part_max,
+                                                          const uint32_t *__restrict__ part_cnt, uint32_t nparts,
+                                                          uint32_t *__restrict__ part_valid, GsControl *ctl)
+{
+    __shared__ unsigned long long s_min, s_max;
+    __shared__ uint32_t s_cnt, s_valid;
+    if (threadIdx.x == 0) { s_min = ~0ull; s_max = 0ull; s_cnt = 0; s_valid = 0; }
+    __syncthreads();
+    {
+        unsigned long long mn = ~0ull, mx = 0ull; uint32_t cnt = 0;
+        for (uint32_t i = threadIdx.x; i < nparts; i += GS_BLOCK) {
+            const unsigned long long a = part_min[i], b = part_max[i];
+            mn = a < mn ? a : mn; mx = b > mx ? b : mx; cnt += part_cnt[i];
+        }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
             const unsigned long long omn = shfl_xor_u64(mn, m), omx = shfl_xor_u64(mx, m);
             mn = omn < mn ? omn : mn; mx = omx > mx ? omx : mx;
             cnt += __shfl_xor(cnt, m, 64);
         }
-        if ((threadIdx.x & 63) == 0 && cnt) { atomicMin(&s_min, mn); atomicMax(&s_max, mx); atomicAdd(&s_cnt, cnt); }
-        __syncthreads();
-        if (threadIdx.x == 0 && s_cnt) {
-            atomicMin(&ctl->min_enc, s_min); atomicMax(&ctl->max_enc, s_max); atomicAdd(&ctl->n_kept, s_cnt);
-        }
-        __syncthreads();
+        if ((threadIdx.x & 63) == 0) { atomicMin(&s_min, mn); atomicMax(&s_max, mx); atomicAdd(&s_cnt, cnt); }
     }
-}
-
-// pass 2 (index.js:558-561): 16-bit bucket of the stored depth; culled/dropped -> GS_CULLED_KEY
-__global__ __launch_bounds__(GS_BLOCK) void k_sort_bucket(const float *__restrict__ depth, uint32_t n, uint32_t *__restrict__ keys,
-                                                          GsControl *ctl)
-{
-    __shared__ uint32_t s_cnt;
-    const double mn = gsm::ordered_to_f64(ctl->min_enc), mx = gsm::ordered_to_f64(ctl->max_enc);
+    __syncthreads();
+    if (blockIdx.x == 0 && threadIdx.x == 0) { ctl->min_enc = s_min; ctl->max_enc = s_max; ctl->n_kept = s_cnt; ctl->n_total = n; }
+    const double mn = gsm::ordered_to_f64(s_min), mx = gsm::ordered_to_f64(s_max);
     const double inv = 65535.0 / (mx - mn);                       // (256*256-1)/(maxDepth-minDepth)
     const uint32_t nchunks = (n + GS_CHUNK - 1) / GS_CHUNK;
+    uint32_t cnt = 0;
     for (uint32_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
-        if (threadIdx.x == 0) s_cnt = 0;
-        __syncthreads();
-        uint32_t cnt = 0;
 #pragma unroll
         for (int r = 0; r < 8; r++) {
             const uint32_t i = c * GS_CHUNK + r * GS_BLOCK + threadIdx.x;
@@ -93,20 +107,31 @@ __global__ __launch_bounds__(GS_BLOCK) void k_sort_bucket(const float *__restric
                 keys[i] = k;
             }
         }
-#pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) cnt += __shfl_xor(cnt, m, 64);
-        if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(&s_cnt, cnt);
-        __syncthreads();
-        if (threadIdx.x == 0 && s_cnt) atomicAdd(&ctl->n_valid, s_cnt);
-        __syncthreads();
     }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) cnt += __shfl_xor(cnt, m, 64);
+    if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(&s_valid, cnt);
+    __syncthreads();
+    if (threadIdx.x == 0) part_valid[blockIdx.x] = s_valid;
 }
 
-// the reference's unfilled tail: Uint32Array(V) slots never written stay 0
-__global__ void k_sort_tail(uint32_t *sorted, const GsControl *ctl)
+// V' = number of survivors with an in-range bucket; the reference's unfilled tail: Uint32Array(V) slots never
+// written stay 0.  One workgroup.
+__global__ __launch_bounds__(GS_BLOCK) void k_sort_tail(uint32_t *sorted, const uint32_t *__restrict__ part_valid, uint32_t nparts,
+                                                        GsControl *ctl)
 {
-    const uint32_t lo = ctl->n_valid, hi = ctl->n_kept;
-    for (uint32_t p = lo + blockIdx.x * blockDim.x + threadIdx.x; p < hi; p += gridDim.x * blockDim.x) sorted[p] = 0;
+    __shared__ uint32_t s_valid;
+    if (threadIdx.x == 0) s_valid = 0;
+    __syncthreads();
+    uint32_t v = 0;
+    for (uint32_t i = threadIdx.x; i < nparts; i += GS_BLOCK) v += part_valid[i];
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    if ((threadIdx.x & 63) == 0 && v) atomicAdd(&s_valid, v);
+    __syncthreads();
+    const uint32_t lo = s_valid, hi = ctl->n_kept;
+    if (threadIdx.x == 0) ctl->n_valid = lo;
+    for (uint32_t p = lo + threadIdx.x; p < hi; p += GS_BLOCK) sorted[p] = 0;
 }
 
 }  // namespace
@@ -119,17 +144,18 @@ int gs_run_sort(gs_ctx *ctx, const float view[4], const float *cutout16)
     u.has_cutout = cutout16 != nullptr;
     if (cutout16) memcpy(u.cutout, cutout16, sizeof u.cutout); else memset(u.cutout, 0, sizeof u.cutout);
 
-    uint32_t g = gs_div_up(n, GS_CHUNK); if (g > 2048) g = 2048; if (g < 1) g = 1;
+    uint32_t g = gs_div_up(n, GS_CHUNK); if (g > 1024) g = 1024; if (g < 1) g = 1;
     if (ctx->profile) GS_HIP(hipEventRecord(ctx->ev[0], ctx->stream));
-    hipLaunchKernelGGL(k_sort_init, dim3(1), dim3(1), 0, ctx->stream, ctx->ctl, n);
-    hipLaunchKernelGGL(k_sort_depth, dim3(g), dim3(GS_BLOCK), 0, ctx->stream, ctx->sort_rows, n, u, ctx->depth, ctx->ctl);
-    hipLaunchKernelGGL(k_sort_bucket, dim3(g), dim3(GS_BLOCK), 0, ctx->stream, ctx->depth, n, ctx->key_a, ctx->ctl);
+    hipLaunchKernelGGL(k_sort_depth, dim3(g), dim3(GS_BLOCK), 0, ctx->stream, ctx->sort_rows, n, u, ctx->depth, ctx->part_min,
+                       ctx->part_max, ctx->part_cnt);
+    hipLaunchKernelGGL(k_sort_bucket, dim3(g), dim3(GS_BLOCK), 0, ctx->stream, ctx->depth, n, ctx->key_a, ctx->part_min,
+                       ctx->part_max, ctx->part_cnt, g, ctx->part_valid, ctx->ctl);
     GS_HIP(hipGetLastError());
-    int rc = gs_launch_radix_pass(ctx, ctx->key_a, nullptr, ctx->key_b, ctx->val_b, &ctx->ctl->n_total, n, 0, 8);
+    int rc = gs_launch_radix_pass(ctx, ctx->key_a, false, ctx->kv_b, true, &ctx->ctl->n_total, n, 0, 8);
     if (rc != GS_OK) return rc;
-    rc = gs_launch_radix_pass(ctx, ctx->key_b, ctx->val_b, nullptr, ctx->val_a, &ctx->ctl->n_total, n, 8, 9);
+    rc = gs_launch_radix_pass(ctx, ctx->kv_b, true, ctx->val_a, false, &ctx->ctl->n_total, n, 8, 9);
     if (rc != GS_OK) return rc;
-    hipLaunchKernelGGL(k_sort_tail, dim3(64), dim3(GS_BLOCK), 0, ctx->stream, ctx->val_a, ctx->ctl);
+    hipLaunchKernelGGL(k_sort_tail, dim3(1), dim3(GS_BLOCK), 0, ctx->stream, ctx->val_a, ctx->part_valid, g, ctx->ctl);
     GS_HIP(hipGetLastError());
     if (ctx->profile) GS_HIP(hipEventRecord(ctx->ev[1], ctx->stream));
     ctx->sorted = ctx->val_a;
