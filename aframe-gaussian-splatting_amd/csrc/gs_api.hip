@@ -32,7 +32,7 @@ static int ensure_scan_scratch(gs_ctx *ctx)
     const size_t ph = (size_t)GS_RADIX_MAX_BINS * (gs_div_up(ctx->pair_cap, GS_CHUNK) + 1);
     if (ph > need_hist) need_hist = ph;
     if (need_hist > ctx->hist_cap) { dev_free(ctx->hist); TRY(dev_alloc(ctx, &ctx->hist, need_hist)); ctx->hist_cap = need_hist; }
-    size_t need_spine = gs_div_up(need_hist, GS_CHUNK) + gs_div_up(ctx->cap, GS_CHUNK) + 16;
+    size_t need_spine = gs_div_up(need_hist, GS_CHUNK) + gs_div_up(ctx->cap, GS_BLOCK) + GS_RADIX_MAX_BINS + 16;   // project/emit chunks of 256
     if (need_spine > ctx->spine_cap) { dev_free(ctx->spine); TRY(dev_alloc(ctx, &ctx->spine, need_spine)); ctx->spine_cap = need_spine; }
     return GS_OK;
 }
@@ -69,11 +69,11 @@ static int ensure_capacity(gs_ctx *ctx, size_t want)
     dev_free(ctx->center_scale); dev_free(ctx->cov_color); dev_free(ctx->sort_rows);
     ctx->center_scale = cs; ctx->cov_color = cc; ctx->sort_rows = sr;
     dev_free(ctx->depth); dev_free(ctx->key_a); dev_free(ctx->kv_b); dev_free(ctx->val_a);
-    dev_free(ctx->proj); dev_free(ctx->rect); dev_free(ctx->tile_count); dev_free(ctx->pair_off);
+    dev_free(ctx->proj); dev_free(ctx->rect); dev_free(ctx->tile_count);
     TRY(dev_alloc(ctx, &ctx->depth, cap));
     TRY(dev_alloc(ctx, &ctx->key_a, cap)); TRY(dev_alloc(ctx, &ctx->kv_b, cap)); TRY(dev_alloc(ctx, &ctx->val_a, cap));
     TRY(dev_alloc(ctx, &ctx->proj, cap)); TRY(dev_alloc(ctx, &ctx->rect, cap));
-    TRY(dev_alloc(ctx, &ctx->tile_count, cap)); TRY(dev_alloc(ctx, &ctx->pair_off, cap));
+    TRY(dev_alloc(ctx, &ctx->tile_count, cap));
     ctx->cap = cap;
     ctx->have_sort = false; ctx->sorted = nullptr;
     TRY(gs_ensure_pair_capacity(ctx, cap * 8 > ((size_t)1 << 22) ? cap * 8 : (size_t)1 << 22));
@@ -140,7 +140,7 @@ GS_API int gs_destroy(gs_ctx *ctx)
     dev_free(ctx->center_scale); dev_free(ctx->cov_color); dev_free(ctx->sort_rows); dev_free(ctx->pow10tab);
     dev_free(ctx->depth); dev_free(ctx->key_a); dev_free(ctx->kv_b); dev_free(ctx->val_a);
     dev_free(ctx->hist); dev_free(ctx->spine);
-    dev_free(ctx->proj); dev_free(ctx->rect); dev_free(ctx->tile_count); dev_free(ctx->pair_off);
+    dev_free(ctx->proj); dev_free(ctx->rect); dev_free(ctx->tile_count);
     dev_free(ctx->pair_a); dev_free(ctx->pair_b);
     dev_free(ctx->tile_range); dev_free(ctx->fb); dev_free(ctx->ctl);
     dev_free(ctx->part_min); dev_free(ctx->part_max); dev_free(ctx->part_cnt); dev_free(ctx->part_valid); dev_free(ctx->part_vis);

@@ -73,7 +73,6 @@ struct gs_ctx {
     gsm::Projected *proj;          // V records, sorted order
     uint2 *rect;                   // V x (tx0 | ty0<<16, tx1 | ty1<<16), strip-local tile coords
     uint32_t *tile_count;          // V
-    uint32_t *pair_off;            // V exclusive offsets
     uint2 *pair_a, *pair_b; size_t pair_cap;   // (tile id, sorted position) records, ping-pong
     uint2 *tile_range; size_t tile_cap;     // per tile [start,end) into the sorted pair list
     uint8_t *fb; size_t fb_cap;             // RGBA8 strip
@@ -111,8 +110,12 @@ int gs_launch_scan(gs_ctx *ctx, const uint32_t *in, uint32_t *out, const uint32_
 // One stable LSD radix pass over n = *n_ptr items on digit (key >> shift) & (2^bits-1).
 // in:  packed (key,val) uint2 records, or a plain key array whose value is the element index.
 // out: packed (key,val) uint2 records, or the values alone (final pass).
+// have_hist: the caller's producer kernel already filled ctx->hist for this digit (skips the histogram launch).
+// zero_key:  value-only output stores 0 for items with this key (0xFFFFFFFF = never).
 int gs_launch_radix_pass(gs_ctx *ctx, const void *in, bool in_packed, void *out, bool out_packed, const uint32_t *n_ptr,
-                         uint32_t max_n, int shift, int bits);
+                         uint32_t max_n, int shift, int bits, bool have_hist = false, uint32_t zero_key = 0xFFFFFFFFu);
+// grid used by the radix kernels for max_n items (a producer that pre-fills the histogram must use the same chunking)
+uint32_t gs_radix_grid(uint32_t max_n);
 // ---- gs_pack.hip
 int gs_launch_pack(gs_ctx *ctx, const uint4 *rows_dev, size_t first, size_t nrows);
 // ---- gs_sort.hip

@@ -171,9 +171,11 @@ __global__ __launch_bounds__(GS_BLOCK) void k_radix_rowscan(uint32_t *__restrict
 // wave-private LDS counter row, across waves via a 4-way prefix added to the chunk's offset in the digit run.
 // IN_PACKED: input is (key,val) uint2 records, else a key array whose value is the element index.
 // OUT_PACKED: output is (key,val) uint2 records (one 8-byte store per item), else the value alone (last pass).
+// zero_key: items whose key equals it store 0 as their value (value-only output): the depth sort uses this so that
+// culled splats (key 65536, which sort behind every bucket) leave zeros in the tail of the index list.
 template <bool IN_PACKED, bool OUT_PACKED>
 __global__ __launch_bounds__(GS_BLOCK) void k_radix_scatter(const void *__restrict__ in, void *__restrict__ out,
-                                                            const uint32_t *n_ptr, int shift, int bits,
+                                                            const uint32_t *n_ptr, int shift, int bits, uint32_t zero_key,
                                                             const uint32_t *__restrict__ hist_scanned, const uint32_t *__restrict__ totals)
 {
     __shared__ uint32_t s_cnt[4][GS_RADIX_MAX_BINS];            // 8 KiB
@@ -235,7 +237,7 @@ __global__ __launch_bounds__(GS_BLOCK) void k_radix_scatter(const void *__restri
                 const uint32_t d = (key[r] >> shift) & mask;
                 const uint32_t pos = s_cnt[w][d] + rank[r];
                 if (OUT_PACKED) reinterpret_cast<uint2 *>(out)[pos] = make_uint2(key[r], val[r]);
-                else reinterpret_cast<uint32_t *>(out)[pos] = val[r];
+                else reinterpret_cast<uint32_t *>(out)[pos] = key[r] == zero_key ? 0u : val[r];
             }
         }
         __syncthreads();
@@ -252,6 +254,8 @@ uint32_t grid_for(uint32_t max_items)
 
 }  // namespace
 
+uint32_t gs_radix_grid(uint32_t max_n) { return grid_for(max_n); }
+
 int gs_launch_scan(gs_ctx *ctx, const uint32_t *in, uint32_t *out, const uint32_t *n_ptr, int hist_bits, uint32_t max_n,
                    uint32_t *total_out)
 {
@@ -265,19 +269,20 @@ int gs_launch_scan(gs_ctx *ctx, const uint32_t *in, uint32_t *out, const uint32_
 }
 
 int gs_launch_radix_pass(gs_ctx *ctx, const void *in, bool in_packed, void *out, bool out_packed, const uint32_t *n_ptr,
-                         uint32_t max_n, int shift, int bits)
+                         uint32_t max_n, int shift, int bits, bool have_hist, uint32_t zero_key)
 {
     const uint32_t g = grid_for(max_n);
     uint32_t *totals = ctx->spine;                               // 2^bits words; no generic scan is in flight here
     const dim3 G(g), B(GS_BLOCK);
     hipStream_t st = ctx->stream;
-    if (in_packed) hipLaunchKernelGGL(k_radix_hist<true>, G, B, 0, st, (const uint32_t *)in, n_ptr, shift, bits, ctx->hist);
+    if (have_hist) { /* the producer of `in` already wrote hist[digit][chunk] */ }
+    else if (in_packed) hipLaunchKernelGGL(k_radix_hist<true>, G, B, 0, st, (const uint32_t *)in, n_ptr, shift, bits, ctx->hist);
     else hipLaunchKernelGGL(k_radix_hist<false>, G, B, 0, st, (const uint32_t *)in, n_ptr, shift, bits, ctx->hist);
     hipLaunchKernelGGL(k_radix_rowscan, dim3(1u << bits), B, 0, st, ctx->hist, n_ptr, totals);
-    if (in_packed && out_packed) hipLaunchKernelGGL((k_radix_scatter<true, true>), G, B, 0, st, in, out, n_ptr, shift, bits, ctx->hist, totals);
-    else if (in_packed) hipLaunchKernelGGL((k_radix_scatter<true, false>), G, B, 0, st, in, out, n_ptr, shift, bits, ctx->hist, totals);
-    else if (out_packed) hipLaunchKernelGGL((k_radix_scatter<false, true>), G, B, 0, st, in, out, n_ptr, shift, bits, ctx->hist, totals);
-    else hipLaunchKernelGGL((k_radix_scatter<false, false>), G, B, 0, st, in, out, n_ptr, shift, bits, ctx->hist, totals);
+    if (in_packed && out_packed) hipLaunchKernelGGL((k_radix_scatter<true, true>), G, B, 0, st, in, out, n_ptr, shift, bits, zero_key, ctx->hist, totals);
+    else if (in_packed) hipLaunchKernelGGL((k_radix_scatter<true, false>), G, B, 0, st, in, out, n_ptr, shift, bits, zero_key, ctx->hist, totals);
+    else if (out_packed) hipLaunchKernelGGL((k_radix_scatter<false, true>), G, B, 0, st, in, out, n_ptr, shift, bits, zero_key, ctx->hist, totals);
+    else hipLaunchKernelGGL((k_radix_scatter<false, false>), G, B, 0, st, in, out, n_ptr, shift, bits, zero_key, ctx->hist, totals);
     GS_HIP(hipGetLastError());
     return GS_OK;
 }

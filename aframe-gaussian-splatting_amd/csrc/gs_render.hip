@@ -18,190 +18,245 @@
 
 namespace {
 
-// Vertex-shader stage.  One thread per sorted splat; splats whose bounding box spans more than 16 tile rows
-// (a small minority, but up to 68 rows each) are queued in LDS and their exact per-row tile counts are summed by
-// a whole wavefront (one lane per tile row) so a single lane never walks 68 rows while 63 idle.
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v, int lane)
+{
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(v, d, 64); if (lane >= d) v += t; }
+    return v;
+}
+
+// Vertex-shader stage.  One thread per sorted splat, 256 splats per workgroup pass; the pass also leaves the chunk's
+// total tiles-touched in spine[chunk] (first level of the pair-offset scan).
+// Splats whose bounding box spans more than 16 tile rows (few, but up to 68 rows each) are queued in LDS and their
+// exact per-row tile counts are summed by a whole wavefront (one lane per tile row).
 __global__ __launch_bounds__(GS_BLOCK) void k_project(const uint32_t *__restrict__ sorted, const float4 *__restrict__ center_scale,
                                                       const uint4 *__restrict__ cov_color, GsFrameUniforms u,
                                                       gsm::Projected *__restrict__ proj, uint2 *__restrict__ rect,
-                                                      uint32_t *__restrict__ tile_count, uint32_t *__restrict__ part_vis,
-                                                      const GsControl *ctl)
+                                                      uint32_t *__restrict__ tile_count, uint32_t *__restrict__ spine,
+                                                      uint32_t *__restrict__ part_vis, const GsControl *ctl)
 {
     __shared__ float s_rec[GS_BLOCK][6];
     __shared__ uint32_t s_rows[GS_BLOCK], s_j[GS_BLOCK];
-    __shared__ uint32_t s_nbig, s_vis;
+    __shared__ uint32_t s_nbig, s_vis, s_sum;
     const uint32_t V = ctl->n_kept;
     const uint32_t nchunks = (V + GS_BLOCK - 1) / GS_BLOCK;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     if (threadIdx.x == 0) s_vis = 0;
     for (uint32_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
-        if (threadIdx.x == 0) s_nbig = 0;
-        __syncthreads();
-        const uint32_t j = c * GS_BLOCK + threadIdx.x;
-        uint32_t count = 0;
-        bool queued = false;
-        if (j < V) {
-            const uint32_t idx = sorted[j];
-            const float4 cs4 = center_scale[idx];
-            const uint4 cc4 = cov_color[idx];
-            const float cs[4] = { cs4.x, cs4.y, cs4.z, cs4.w };
-            const uint32_t cc[4] = { cc4.x, cc4.y, cc4.z, cc4.w };
-            gsm::Projected p; gsm::ProjExtra x;
-            if (gsm::project_splat(cs, cc, u.mv, u.proj, u.focal, u.vw, u.vh, p, x)) {
-                float xmin, xmax, ymin, ymax;
-                gsm::splat_pixel_bounds(p, x, xmin, xmax, ymin, ymax);
-                // clamp in float (bounds can be far outside the int range), then to the strip / screen
-                const float fx0 = fmaxf(xmin, (float)u.x0), fx1 = fminf(xmax, (float)(u.x1 - 1));
-                const float fy0 = fmaxf(ymin, 0.0f), fy1 = fminf(ymax, (float)(u.H - 1));
-                if (fx0 <= fx1 && fy0 <= fy1) {
-                    const int ix0 = (int)fx0, ix1 = (int)fx1, jy0 = (int)fy0, jy1 = (int)fy1;
-                    const int r0 = u.H - 1 - jy1, r1 = u.H - 1 - jy0;           // GL rows (y up) -> image rows (top-down)
-                    const uint32_t tx0 = (uint32_t)(ix0 - u.x0) / GS_TILE, tx1 = (uint32_t)(ix1 - u.x0) / GS_TILE;
-                    const uint32_t ty0 = (uint32_t)r0 / GS_TILE, ty1 = (uint32_t)r1 / GS_TILE;
-                    rect[j] = make_uint2(tx0 | (ty0 << 16), tx1 | (ty1 << 16));
-                    float4 *dst = reinterpret_cast<float4 *>(proj + j);
-                    dst[0] = make_float4(p.cx, p.cy, p.ax, p.ay);
-                    dst[1] = make_float4(p.bx, p.by, __uint_as_float(p.rgba), p.alpha);
-                    if (ty1 - ty0 >= 16) {                                      // > 16 tile rows: count cooperatively
-                        const uint32_t q = atomicAdd(&s_nbig, 1u);
-                        s_rec[q][0] = p.cx; s_rec[q][1] = p.cy; s_rec[q][2] = p.ax; s_rec[q][3] = p.ay; s_rec[q][4] = p.bx; s_rec[q][5] = p.by;
-                        s_rows[q] = ty0 | (ty1 << 16); s_j[q] = j;
-                        queued = true;
-                    } else {
-                        // exact coverage: per tile row, the contiguous run of tiles the ellipse touches
-                        gsm::EllipseRows e;
-                        gsm::ellipse_rows_setup(p, e);
-                        for (uint32_t ty = ty0; ty <= ty1; ty++) {
-                            uint32_t a, n;
-                            gsm::splat_tile_row(p, e, (int)ty, u.H, u.x0, u.x1, a, n);
-                            count += n;
+        if (threadIdx.x == 0) s_sum = 0;
+        {
+            if (threadIdx.x == 0) s_nbig = 0;
+            __syncthreads();
+            const uint32_t j = c * GS_BLOCK + threadIdx.x;
+            uint32_t count = 0;
+            bool queued = false;
+            if (j < V) {
+                const uint32_t idx = sorted[j];
+                const float4 cs4 = center_scale[idx];
+                const uint4 cc4 = cov_color[idx];
+                const float cs[4] = { cs4.x, cs4.y, cs4.z, cs4.w };
+                const uint32_t cc[4] = { cc4.x, cc4.y, cc4.z, cc4.w };
+                gsm::Projected p; gsm::ProjExtra x;
+                if (gsm::project_splat(cs, cc, u.mv, u.proj, u.focal, u.vw, u.vh, p, x)) {
+                    float xmin, xmax, ymin, ymax;
+                    gsm::splat_pixel_bounds(p, x, xmin, xmax, ymin, ymax);
+                    // clamp in float (bounds can be far outside the int range), then to the strip / screen
+                    const float fx0 = fmaxf(xmin, (float)u.x0), fx1 = fminf(xmax, (float)(u.x1 - 1));
+                    const float fy0 = fmaxf(ymin, 0.0f), fy1 = fminf(ymax, (float)(u.H - 1));
+                    if (fx0 <= fx1 && fy0 <= fy1) {
+                        const int ix0 = (int)fx0, ix1 = (int)fx1, jy0 = (int)fy0, jy1 = (int)fy1;
+                        const int r0 = u.H - 1 - jy1, r1 = u.H - 1 - jy0;       // GL rows (y up) -> image rows (top-down)
+                        const uint32_t tx0 = (uint32_t)(ix0 - u.x0) / GS_TILE, tx1 = (uint32_t)(ix1 - u.x0) / GS_TILE;
+                        const uint32_t ty0 = (uint32_t)r0 / GS_TILE, ty1 = (uint32_t)r1 / GS_TILE;
+                        rect[j] = make_uint2(tx0 | (ty0 << 16), tx1 | (ty1 << 16));
+                        float4 *dst = reinterpret_cast<float4 *>(proj + j);
+                        dst[0] = make_float4(p.cx, p.cy, p.ax, p.ay);
+                        dst[1] = make_float4(p.bx, p.by, __uint_as_float(p.rgba), p.alpha);
+                        if (ty1 - ty0 >= 16) {                                  // > 16 tile rows: count cooperatively
+                            const uint32_t q = atomicAdd(&s_nbig, 1u);
+                            s_rec[q][0] = p.cx; s_rec[q][1] = p.cy; s_rec[q][2] = p.ax; s_rec[q][3] = p.ay; s_rec[q][4] = p.bx; s_rec[q][5] = p.by;
+                            s_rows[q] = ty0 | (ty1 << 16); s_j[q] = j;
+                            queued = true;
+                        } else {
+                            // exact coverage: per tile row, the contiguous run of tiles the ellipse touches
+                            gsm::EllipseRows e;
+                            gsm::ellipse_rows_setup(p, e);
+                            for (uint32_t ty = ty0; ty <= ty1; ty++) {
+                                uint32_t a, n;
+                                gsm::splat_tile_row(p, e, (int)ty, u.H, u.x0, u.x1, a, n);
+                                count += n;
+                            }
                         }
                     }
                 }
+                if (!queued) tile_count[j] = count;
             }
-            if (!queued) tile_count[j] = count;
-        }
-        uint32_t vis = count ? 1u : 0u;
-        __syncthreads();
-        const uint32_t nbig = s_nbig;
-        for (uint32_t bi = w; bi < nbig; bi += 4) {                   // one wavefront per queued splat
-            gsm::Projected p;
-            p.cx = s_rec[bi][0]; p.cy = s_rec[bi][1]; p.ax = s_rec[bi][2]; p.ay = s_rec[bi][3]; p.bx = s_rec[bi][4]; p.by = s_rec[bi][5];
-            gsm::EllipseRows e;
-            gsm::ellipse_rows_setup(p, e);
-            const uint32_t ty0 = s_rows[bi] & 0xFFFF, ty1 = s_rows[bi] >> 16;
-            uint32_t sum = 0;
-            for (uint32_t ty = ty0 + lane; ty <= ty1; ty += 64) {
-                uint32_t a, n;
-                gsm::splat_tile_row(p, e, (int)ty, u.H, u.x0, u.x1, a, n);
-                sum += n;
+            uint32_t vis = count ? 1u : 0u, sum = count;
+            __syncthreads();
+            const uint32_t nbig = s_nbig;
+            for (uint32_t bi = w; bi < nbig; bi += 4) {               // one wavefront per queued splat
+                gsm::Projected p;
+                p.cx = s_rec[bi][0]; p.cy = s_rec[bi][1]; p.ax = s_rec[bi][2]; p.ay = s_rec[bi][3]; p.bx = s_rec[bi][4]; p.by = s_rec[bi][5];
+                gsm::EllipseRows e;
+                gsm::ellipse_rows_setup(p, e);
+                const uint32_t ty0 = s_rows[bi] & 0xFFFF, ty1 = s_rows[bi] >> 16;
+                uint32_t rsum = 0;
+                for (uint32_t ty = ty0 + lane; ty <= ty1; ty += 64) {
+                    uint32_t a, n;
+                    gsm::splat_tile_row(p, e, (int)ty, u.H, u.x0, u.x1, a, n);
+                    rsum += n;
+                }
+#pragma unroll
+                for (int m = 32; m >= 1; m >>= 1) rsum += __shfl_xor(rsum, m, 64);
+                if (lane == 0) { tile_count[s_j[bi]] = rsum; sum += rsum; if (rsum) vis++; }
             }
 #pragma unroll
-            for (int m = 32; m >= 1; m >>= 1) sum += __shfl_xor(sum, m, 64);
-            if (lane == 0) { tile_count[s_j[bi]] = sum; if (sum) vis++; }
+            for (int m = 32; m >= 1; m >>= 1) { vis += __shfl_xor(vis, m, 64); sum += __shfl_xor(sum, m, 64); }
+            if (lane == 0) { if (vis) atomicAdd(&s_vis, vis); if (sum) atomicAdd(&s_sum, sum); }
+            __syncthreads();
         }
-#pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) vis += __shfl_xor(vis, m, 64);
-        if (lane == 0 && vis) atomicAdd(&s_vis, vis);
-        __syncthreads();
+        if (threadIdx.x == 0) spine[c] = s_sum;
     }
     __syncthreads();
     if (threadIdx.x == 0) part_vis[blockIdx.x] = s_vis;
 }
 
-// after the scan: I = scan_total, refused (and flagged) if it does not fit the pair buffers; Vp from the partials
-__global__ __launch_bounds__(GS_BLOCK) void k_pairs_check(GsControl *ctl, uint32_t pair_cap, const uint32_t *__restrict__ part_vis,
-                                                          uint32_t nparts)
+// One workgroup: exclusive scan of the per-chunk totals (spine) -> chunk base offsets, I = grand total (refused and
+// flagged if it does not fit the pair buffers), Vp from the partials.
+__global__ __launch_bounds__(GS_BLOCK) void k_pairs_check(GsControl *ctl, uint32_t pair_cap, uint32_t *__restrict__ spine,
+                                                          const uint32_t *__restrict__ part_vis, uint32_t nparts)
 {
-    __shared__ uint32_t s_vis;
+    __shared__ uint32_t s_vis, s_wave[4];
     if (threadIdx.x == 0) s_vis = 0;
     __syncthreads();
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     uint32_t v = 0;
     for (uint32_t i = threadIdx.x; i < nparts; i += GS_BLOCK) v += part_vis[i];
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
-    if ((threadIdx.x & 63) == 0 && v) atomicAdd(&s_vis, v);
+    if (lane == 0 && v) atomicAdd(&s_vis, v);
+    // spine scan: each thread owns a contiguous slice
+    const uint32_t nsp = (ctl->n_kept + GS_BLOCK - 1) / GS_BLOCK;
+    const uint32_t per = (nsp + GS_BLOCK - 1) / GS_BLOCK;
+    const uint32_t lo = min(threadIdx.x * per, nsp), hi = min(lo + per, nsp);
+    uint32_t s = 0;
+    for (uint32_t i = lo; i < hi; i++) s += spine[i];
+    const uint32_t inc = wave_incl_scan_u32(s, lane);
+    if (lane == 63) s_wave[w] = inc;
     __syncthreads();
+    uint32_t base = 0, total = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) { const uint32_t t = s_wave[k]; if (k < w) base += t; total += t; }
+    uint32_t run = base + inc - s;
+    for (uint32_t i = lo; i < hi; i++) { const uint32_t t = spine[i]; spine[i] = run; run += t; }
     if (threadIdx.x == 0) {
-        const uint32_t total = ctl->scan_total;
         ctl->n_visible = s_vis;
+        ctl->scan_total = total;
         if (total > pair_cap) { ctl->pair_overflow = 1; ctl->n_pairs = 0; }
         else { ctl->pair_overflow = 0; ctl->n_pairs = total; }
     }
 }
 
-// (tile id, sorted position) pairs in splat order.  Splats touching few tiles are written by their own lane;
-// the few screen-filling ones (thousands of tiles each) are queued in LDS and expanded by a whole wavefront,
-// one lane per tile row, so that no single lane serialises thousands of stores.
+// (tile id, sorted position) records in splat order.  Each workgroup pass covers the same 256-splat chunk as
+// k_project; the pair offset of every splat is spine[chunk] + an in-workgroup exclusive scan of tile_count, so no
+// offset array ever goes to memory.  Splats touching few tiles are written by their own lane; the few screen-filling
+// ones (thousands of tiles each) are queued in LDS and expanded by a whole wavefront, one lane per tile row.
 #define GS_EMIT_BIG 32u
 __global__ __launch_bounds__(GS_BLOCK) void k_emit(const gsm::Projected *__restrict__ proj, const uint2 *__restrict__ rect,
-                                                   const uint32_t *__restrict__ tile_count, const uint32_t *__restrict__ pair_off,
+                                                   const uint32_t *__restrict__ tile_count, const uint32_t *__restrict__ spine,
                                                    GsFrameUniforms u, uint2 *__restrict__ pairs, const GsControl *ctl)
 {
-    __shared__ uint32_t s_big[GS_BLOCK];
-    __shared__ uint32_t s_nbig;
+    __shared__ uint32_t s_big[GS_BLOCK], s_bigoff[GS_BLOCK];
+    __shared__ uint32_t s_nbig, s_wave[4];
     if (ctl->pair_overflow) return;
     const uint32_t V = ctl->n_kept;
     const uint32_t nchunks = (V + GS_BLOCK - 1) / GS_BLOCK;
     const uint32_t tiles_x = (uint32_t)u.tiles_x;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     for (uint32_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
-        if (threadIdx.x == 0) s_nbig = 0;
-        __syncthreads();
-        const uint32_t j = c * GS_BLOCK + threadIdx.x;
-        const uint32_t cnt = j < V ? tile_count[j] : 0u;
-        if (cnt >= GS_EMIT_BIG) {
-            s_big[atomicAdd(&s_nbig, 1u)] = j;
-        } else if (cnt) {
-            const float4 *src = reinterpret_cast<const float4 *>(proj + j);
-            const float4 a = src[0], b = src[1];
-            gsm::Projected p; p.cx = a.x; p.cy = a.y; p.ax = a.z; p.ay = a.w; p.bx = b.x; p.by = b.y;
-            gsm::EllipseRows e;
-            gsm::ellipse_rows_setup(p, e);
-            const uint2 r = rect[j];
-            uint32_t o = pair_off[j];
-            for (uint32_t ty = r.x >> 16; ty <= (r.y >> 16); ty++) {
-                uint32_t t0, n;
-                gsm::splat_tile_row(p, e, (int)ty, u.H, u.x0, u.x1, t0, n);
-                for (uint32_t k = 0; k < n; k++) pairs[o++] = make_uint2(ty * tiles_x + t0 + k, j);
-            }
-        }
-        __syncthreads();
-        const uint32_t nbig = s_nbig;
-        for (uint32_t bi = w; bi < nbig; bi += 4) {                  // one wavefront per big splat
-            const uint32_t jb = s_big[bi];
-            const float4 *src = reinterpret_cast<const float4 *>(proj + jb);
-            const float4 a = src[0], b = src[1];
-            gsm::Projected p; p.cx = a.x; p.cy = a.y; p.ax = a.z; p.ay = a.w; p.bx = b.x; p.by = b.y;
-            gsm::EllipseRows e;
-            gsm::ellipse_rows_setup(p, e);
-            const uint2 r = rect[jb];
-            const uint32_t ty0 = r.x >> 16, ty1 = r.y >> 16;
-            uint32_t base = pair_off[jb];
-            for (uint32_t tyb = ty0; tyb <= ty1; tyb += 64) {        // 64 tile rows per sweep
-                const uint32_t ty = tyb + lane;
-                uint32_t t0 = 0, n = 0;
-                if (ty <= ty1) gsm::splat_tile_row(p, e, (int)ty, u.H, u.x0, u.x1, t0, n);
-                uint32_t inc = n;                                    // wave inclusive scan of the row lengths
+        uint32_t carry = spine[c];
+        {
+            if (threadIdx.x == 0) s_nbig = 0;
+            const uint32_t j = c * GS_BLOCK + threadIdx.x;
+            const uint32_t cnt = j < V ? tile_count[j] : 0u;
+            const uint32_t inc = wave_incl_scan_u32(cnt, lane);
+            if (lane == 63) s_wave[w] = inc;
+            __syncthreads();
+            uint32_t wbase = 0, total = 0;
 #pragma unroll
-                for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(inc, d, 64); if (lane >= d) inc += t; }
-                uint32_t o = base + inc - n;
-                for (uint32_t k = 0; k < n; k++) pairs[o++] = make_uint2(ty * tiles_x + t0 + k, jb);
-                base += __shfl(inc, 63, 64);
+            for (int k = 0; k < 4; k++) { const uint32_t t = s_wave[k]; if (k < w) wbase += t; total += t; }
+            uint32_t o = carry + wbase + inc - cnt;                  // this splat's first pair slot
+            carry += total;
+            if (cnt >= GS_EMIT_BIG) {
+                const uint32_t q = atomicAdd(&s_nbig, 1u);
+                s_big[q] = j; s_bigoff[q] = o;
+            } else if (cnt) {
+                const float4 *src = reinterpret_cast<const float4 *>(proj + j);
+                const float4 a = src[0], b = src[1];
+                gsm::Projected p; p.cx = a.x; p.cy = a.y; p.ax = a.z; p.ay = a.w; p.bx = b.x; p.by = b.y;
+                gsm::EllipseRows e;
+                gsm::ellipse_rows_setup(p, e);
+                const uint2 rc = rect[j];
+                for (uint32_t ty = rc.x >> 16; ty <= (rc.y >> 16); ty++) {
+                    uint32_t t0, n;
+                    gsm::splat_tile_row(p, e, (int)ty, u.H, u.x0, u.x1, t0, n);
+                    for (uint32_t k = 0; k < n; k++) pairs[o++] = make_uint2(ty * tiles_x + t0 + k, j);
+                }
             }
+            __syncthreads();
+            const uint32_t nbig = s_nbig;
+            for (uint32_t bi = w; bi < nbig; bi += 4) {              // one wavefront per big splat
+                const uint32_t jb = s_big[bi];
+                const float4 *src = reinterpret_cast<const float4 *>(proj + jb);
+                const float4 a = src[0], b = src[1];
+                gsm::Projected p; p.cx = a.x; p.cy = a.y; p.ax = a.z; p.ay = a.w; p.bx = b.x; p.by = b.y;
+                gsm::EllipseRows e;
+                gsm::ellipse_rows_setup(p, e);
+                const uint2 rc = rect[jb];
+                const uint32_t ty0 = rc.x >> 16, ty1 = rc.y >> 16;
+                uint32_t base = s_bigoff[bi];
+                for (uint32_t tyb = ty0; tyb <= ty1; tyb += 64) {    // 64 tile rows per sweep
+                    const uint32_t ty = tyb + lane;
+                    uint32_t t0 = 0, n = 0;
+                    if (ty <= ty1) gsm::splat_tile_row(p, e, (int)ty, u.H, u.x0, u.x1, t0, n);
+                    const uint32_t rinc = wave_incl_scan_u32(n, lane);
+                    uint32_t ob = base + rinc - n;
+                    for (uint32_t k = 0; k < n; k++) pairs[ob++] = make_uint2(ty * tiles_x + t0 + k, jb);
+                    base += __shfl(rinc, 63, 64);
+                }
+            }
+            __syncthreads();
         }
-        __syncthreads();
     }
 }
 
-__global__ __launch_bounds__(GS_BLOCK) void k_tile_ranges(const uint2 *__restrict__ pairs, uint2 *__restrict__ range,
+// [start,end) of every tile in the sorted pair list, written for ALL tiles (empty ones get an empty range at the
+// position where they would be), so no clearing pass is needed.
+__global__ __launch_bounds__(GS_BLOCK) void k_tile_ranges(const uint2 *__restrict__ pairs, uint2 *__restrict__ range, uint32_t ntiles,
                                                           const GsControl *ctl)
 {
     const uint32_t I = ctl->n_pairs;
+    if (I == 0) {
+        for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < ntiles; t += gridDim.x * blockDim.x) range[t] = make_uint2(0u, 0u);
+        return;
+    }
     for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < I; p += gridDim.x * blockDim.x) {
         const uint32_t k = pairs[p].x;
-        if (p == 0 || pairs[p - 1].x != k) range[k].x = p;
-        if (p == I - 1 || pairs[p + 1].x != k) range[k].y = p + 1;
+        if (p == 0) {
+            for (uint32_t t = 0; t < k; t++) range[t] = make_uint2(0u, 0u);
+            range[k].x = 0;
+        } else {
+            const uint32_t kp = pairs[p - 1].x;
+            if (kp != k) {
+                range[kp].y = p;
+                for (uint32_t t = kp + 1; t < k; t++) range[t] = make_uint2(p, p);
+                range[k].x = p;
+            }
+        }
+        if (p == I - 1) {
+            range[k].y = I;
+            for (uint32_t t = k + 1; t < ntiles; t++) range[t] = make_uint2(I, I);
+        }
     }
 }
 
@@ -293,16 +348,14 @@ int gs_run_render(gs_ctx *ctx, const GsFrameUniforms &u, uint8_t *device_out)
     if (Vmax && ctx->have_sort) {
         uint32_t g = gs_div_up(Vmax, GS_BLOCK); if (g > GS_MAX_PART) g = GS_MAX_PART;
         hipLaunchKernelGGL(k_project, dim3(g), dim3(GS_BLOCK), 0, st, ctx->sorted, ctx->center_scale, ctx->cov_color, u, ctx->proj,
-                           ctx->rect, ctx->tile_count, ctx->part_vis, ctx->ctl);
+                           ctx->rect, ctx->tile_count, ctx->spine, ctx->part_vis, ctx->ctl);
         GS_HIP(hipGetLastError());
         if (ctx->profile) GS_HIP(hipEventRecord(ctx->ev[3], st));
-        int rc = gs_launch_scan(ctx, ctx->tile_count, ctx->pair_off, &ctx->ctl->n_kept, 0, Vmax, nullptr);
-        if (rc != GS_OK) return rc;
-        hipLaunchKernelGGL(k_pairs_check, dim3(1), dim3(GS_BLOCK), 0, st, ctx->ctl, (uint32_t)ctx->pair_cap, ctx->part_vis, g);
-        uint32_t ge = gs_div_up(Vmax, GS_BLOCK); if (ge > 4096) ge = 4096;
-        hipLaunchKernelGGL(k_emit, dim3(ge), dim3(GS_BLOCK), 0, st, ctx->proj, ctx->rect, ctx->tile_count, ctx->pair_off, u,
+        hipLaunchKernelGGL(k_pairs_check, dim3(1), dim3(GS_BLOCK), 0, st, ctx->ctl, (uint32_t)ctx->pair_cap, ctx->spine, ctx->part_vis, g);
+        hipLaunchKernelGGL(k_emit, dim3(g), dim3(GS_BLOCK), 0, st, ctx->proj, ctx->rect, ctx->tile_count, ctx->spine, u,
                            ctx->pair_a, ctx->ctl);
         GS_HIP(hipGetLastError());
+        int rc;
         const int tb = bits_for(ntiles);
         const uint2 *fpairs;
         const uint32_t pc = (uint32_t)ctx->pair_cap;
@@ -318,8 +371,7 @@ int gs_run_render(gs_ctx *ctx, const GsFrameUniforms &u, uint8_t *device_out)
             if (rc != GS_OK) return rc;
             fpairs = ctx->pair_a;
         }
-        GS_HIP(hipMemsetAsync(ctx->tile_range, 0, sizeof(uint2) * ntiles, st));
-        hipLaunchKernelGGL(k_tile_ranges, dim3(2048), dim3(GS_BLOCK), 0, st, fpairs, ctx->tile_range, ctx->ctl);
+        hipLaunchKernelGGL(k_tile_ranges, dim3(2048), dim3(GS_BLOCK), 0, st, fpairs, ctx->tile_range, ntiles, ctx->ctl);
         GS_HIP(hipGetLastError());
         if (ctx->profile) GS_HIP(hipEventRecord(ctx->ev[4], st));
         if (u.flags & GS_RENDER_COUNT_FRAGS)

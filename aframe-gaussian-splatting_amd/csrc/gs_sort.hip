@@ -4,7 +4,7 @@
 // left to right without FMA (library is built -ffp-contract=off); only the stored depth is rounded to
 // f32; the result is ordered by (bucket, original index).  Culled splats are carried through the two
 // stable radix passes with key 65536 (17-bit key = 8 + 9 bit digits) instead of being compacted first:
-// they sort behind every bucket and are simply not part of the first V' outputs.  Splats whose bucket
+// they sort behind every bucket, are not part of the first V' outputs, and store 0 as their value.  Splats whose bucket
 // falls outside [0,65535] (f32 rounding of the stored depth >> depth range) are dropped exactly like
 // the reference's out-of-bounds typed-array writes drop them: the tail [V',V) of the result is 0.
 #include "gs_internal.h"
@@ -67,11 +67,12 @@ __global__ __launch_bounds__(GS_BLOCK) void k_sort_bucket(const float *__restric
                                                           const unsigned long long *__restrict__ part_min,
                                                           const unsigned long long *__restrict__ part_max,
                                                           const uint32_t *__restrict__ part_cnt, uint32_t nparts,
-                                                          uint32_t *__restrict__ part_valid, GsControl *ctl)
+                                                          uint32_t *__restrict__ hist, GsControl *ctl)
 {
     __shared__ unsigned long long s_min, s_max;
-    __shared__ uint32_t s_cnt, s_valid;
-    if (threadIdx.x == 0) { s_min = ~0ull; s_max = 0ull; s_cnt = 0; s_valid = 0; }
+    __shared__ uint32_t s_cnt;
+    __shared__ uint32_t s_hist[256];                              // low-digit histogram of this chunk = radix pass A's input
+    if (threadIdx.x == 0) { s_min = ~0ull; s_max = 0ull; s_cnt = 0; }
     __syncthreads();
     {
         unsigned long long mn = ~0ull, mx = 0ull; uint32_t cnt = 0;
@@ -92,8 +93,9 @@ __global__ __launch_bounds__(GS_BLOCK) void k_sort_bucket(const float *__restric
     const double mn = gsm::ordered_to_f64(s_min), mx = gsm::ordered_to_f64(s_max);
     const double inv = 65535.0 / (mx - mn);                       // (256*256-1)/(maxDepth-minDepth)
     const uint32_t nchunks = (n + GS_CHUNK - 1) / GS_CHUNK;
-    uint32_t cnt = 0;
     for (uint32_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
+        s_hist[threadIdx.x] = 0;
+        __syncthreads();
 #pragma unroll
         for (int r = 0; r < 8; r++) {
             const uint32_t i = c * GS_CHUNK + r * GS_BLOCK + threadIdx.x;
@@ -102,36 +104,16 @@ __global__ __launch_bounds__(GS_BLOCK) void k_sort_bucket(const float *__restric
                 uint32_t k = GS_CULLED_KEY;
                 if (d != INFINITY) {
                     const int32_t b = gsm::sort_bucket(d, mn, inv);
-                    if (b >= 0) { k = (uint32_t)b; cnt++; }
+                    if (b >= 0) k = (uint32_t)b;
                 }
                 keys[i] = k;
+                atomicAdd(&s_hist[k & 255u], 1u);
             }
         }
+        __syncthreads();
+        hist[threadIdx.x * nchunks + c] = s_hist[threadIdx.x];
+        __syncthreads();
     }
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) cnt += __shfl_xor(cnt, m, 64);
-    if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(&s_valid, cnt);
-    __syncthreads();
-    if (threadIdx.x == 0) part_valid[blockIdx.x] = s_valid;
-}
-
-// V' = number of survivors with an in-range bucket; the reference's unfilled tail: Uint32Array(V) slots never
-// written stay 0.  One workgroup.
-__global__ __launch_bounds__(GS_BLOCK) void k_sort_tail(uint32_t *sorted, const uint32_t *__restrict__ part_valid, uint32_t nparts,
-                                                        GsControl *ctl)
-{
-    __shared__ uint32_t s_valid;
-    if (threadIdx.x == 0) s_valid = 0;
-    __syncthreads();
-    uint32_t v = 0;
-    for (uint32_t i = threadIdx.x; i < nparts; i += GS_BLOCK) v += part_valid[i];
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
-    if ((threadIdx.x & 63) == 0 && v) atomicAdd(&s_valid, v);
-    __syncthreads();
-    const uint32_t lo = s_valid, hi = ctl->n_kept;
-    if (threadIdx.x == 0) ctl->n_valid = lo;
-    for (uint32_t p = lo + threadIdx.x; p < hi; p += GS_BLOCK) sorted[p] = 0;
 }
 
 }  // namespace
@@ -144,19 +126,19 @@ int gs_run_sort(gs_ctx *ctx, const float view[4], const float *cutout16)
     u.has_cutout = cutout16 != nullptr;
     if (cutout16) memcpy(u.cutout, cutout16, sizeof u.cutout); else memset(u.cutout, 0, sizeof u.cutout);
 
-    uint32_t g = gs_div_up(n, GS_CHUNK); if (g > 1024) g = 1024; if (g < 1) g = 1;
+    const uint32_t g = gs_radix_grid(n);                         // same chunking as the radix kernels (pre-filled histogram)
     if (ctx->profile) GS_HIP(hipEventRecord(ctx->ev[0], ctx->stream));
     hipLaunchKernelGGL(k_sort_depth, dim3(g), dim3(GS_BLOCK), 0, ctx->stream, ctx->sort_rows, n, u, ctx->depth, ctx->part_min,
                        ctx->part_max, ctx->part_cnt);
     hipLaunchKernelGGL(k_sort_bucket, dim3(g), dim3(GS_BLOCK), 0, ctx->stream, ctx->depth, n, ctx->key_a, ctx->part_min,
-                       ctx->part_max, ctx->part_cnt, g, ctx->part_valid, ctx->ctl);
+                       ctx->part_max, ctx->part_cnt, g, ctx->hist, ctx->ctl);
     GS_HIP(hipGetLastError());
-    int rc = gs_launch_radix_pass(ctx, ctx->key_a, false, ctx->kv_b, true, &ctx->ctl->n_total, n, 0, 8);
+    int rc = gs_launch_radix_pass(ctx, ctx->key_a, false, ctx->kv_b, true, &ctx->ctl->n_total, n, 0, 8, /*have_hist=*/true);
     if (rc != GS_OK) return rc;
-    rc = gs_launch_radix_pass(ctx, ctx->kv_b, true, ctx->val_a, false, &ctx->ctl->n_total, n, 8, 9);
+    // culled / dropped splats (key 65536) sort behind every bucket and store 0: the tail [V',V) of the result is 0 like
+    // the reference's never-written Uint32Array slots
+    rc = gs_launch_radix_pass(ctx, ctx->kv_b, true, ctx->val_a, false, &ctx->ctl->n_total, n, 8, 9, false, GS_CULLED_KEY);
     if (rc != GS_OK) return rc;
-    hipLaunchKernelGGL(k_sort_tail, dim3(1), dim3(GS_BLOCK), 0, ctx->stream, ctx->val_a, ctx->part_valid, g, ctx->ctl);
-    GS_HIP(hipGetLastError());
     if (ctx->profile) GS_HIP(hipEventRecord(ctx->ev[1], ctx->stream));
     ctx->sorted = ctx->val_a;
     ctx->have_sort = true;
