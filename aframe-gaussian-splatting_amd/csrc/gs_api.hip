@@ -1,6 +1,8 @@
 // gs_api.hip -- the C ABI (include/gs_splat.h): context lifetime, HBM residency, ingest, sort / render
 // entry points, stats.  No compute happens on the host here; every hot-path stage is a HIP kernel and the
 // library refuses to exist without a device (no CPU fallback).
+#include <stddef.h>
+#include <stdlib.h>
 #include <new>
 #include <vector>
 #include "gs_internal.h"
@@ -80,9 +82,70 @@ static int ensure_capacity(gs_ctx *ctx, size_t want)
     return ensure_scan_scratch(ctx);
 }
 
+
+// ---------------------------------------------------------------- profiling ring (HIP events on the context's stream)
+
+hipEvent_t gs_prof_event(gs_ctx *ctx, int k)
+{
+    if (!ctx->profile || !ctx->ring) return nullptr;
+    const uint32_t slot = ctx->ring_head % GS_PROF_RING;
+    ctx->ring_flags[slot] |= (uint8_t)(1u << k);
+    return ctx->ring[slot * 6 + k];
+}
+
+// fold the timings of every pending slot into the stats; the stream must be idle
+static int prof_drain(gs_ctx *ctx)
+{
+    for (; ctx->ring_pending; ctx->ring_pending--) {
+        const uint32_t slot = (ctx->ring_head - ctx->ring_pending) % GS_PROF_RING;
+        hipEvent_t *e = ctx->ring + slot * 6;
+        const uint8_t f = ctx->ring_flags[slot];
+        ctx->ring_flags[slot] = 0;
+        float ms;
+        if ((f & 3) == 3) { GS_HIP(hipEventElapsedTime(&ms, e[0], e[1])); ctx->stats.ms_sort = ms; ctx->stats.sum_ms_sort += ms; }
+        if ((f & 0x3C) == 0x3C) {
+            float a, b, d;
+            GS_HIP(hipEventElapsedTime(&a, e[2], e[3])); GS_HIP(hipEventElapsedTime(&b, e[3], e[4])); GS_HIP(hipEventElapsedTime(&d, e[4], e[5]));
+            ctx->stats.ms_project = a; ctx->stats.ms_bin = b; ctx->stats.ms_blend = d; ctx->stats.ms_render = a + b + d;
+            ctx->stats.sum_ms_project += a; ctx->stats.sum_ms_bin += b; ctx->stats.sum_ms_blend += d;
+            ctx->stats.prof_frames++;
+        }
+    }
+    return GS_OK;
+}
+
+// a frame has been enqueued: move to the next slot (draining first if the ring is full)
+static int prof_advance(gs_ctx *ctx)
+{
+    if (!ctx->profile || !ctx->ring) return GS_OK;
+    ctx->ring_head++; ctx->ring_pending++;
+    if (ctx->ring_pending >= GS_PROF_RING - 1) {
+        GS_HIP(hipStreamSynchronize(ctx->stream));
+        return prof_drain(ctx);
+    }
+    return GS_OK;
+}
+
+// after a stream sync: publish the counters of the last completed frame and react to pair-buffer overflow
+static int collect_status(gs_ctx *ctx, bool *overflowed)
+{
+    const GsControl *c = ctx->ctl_host;
+    ctx->stats.n_sorted = c->n_kept; ctx->stats.n_visible = c->n_visible; ctx->stats.n_pairs = c->n_pairs;
+    ctx->stats.acc_frames = c->acc_frames; ctx->stats.acc_sorted = c->acc_sorted; ctx->stats.acc_visible = c->acc_visible;
+    ctx->stats.acc_pairs = c->acc_pairs;
+    *overflowed = c->overflow_sticky != 0;
+    if (*overflowed) {
+        const size_t need = (size_t)c->max_total + c->max_total / 4 + 1;
+        GS_HIP(hipMemsetAsync(&ctx->ctl->overflow_sticky, 0, 2 * sizeof(uint32_t), ctx->stream));
+        GS_HIP(hipStreamSynchronize(ctx->stream));
+        TRY(gs_ensure_pair_capacity(ctx, need));
+    }
+    return GS_OK;
+}
+
 extern "C" {
 
-GS_API uint32_t gs_version(void) { return 0x000100; }
+GS_API uint32_t gs_version(void) { return 0x000200; }
 
 GS_API const char *gs_last_error(const gs_ctx *ctx) { return ctx ? ctx->err : g_create_err; }
 
@@ -111,7 +174,6 @@ GS_API int gs_create(int device, gs_ctx **out)
     CREATE_HIP(hipSetDevice(device));
     CREATE_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
     ctx->own_stream = true;
-    for (int i = 0; i < 8; i++) CREATE_HIP(hipEventCreate(&ctx->ev[i]));
     CREATE_HIP(hipMalloc((void **)&ctx->ctl, sizeof(GsControl)));
     CREATE_HIP(hipMemset(ctx->ctl, 0, sizeof(GsControl)));
     CREATE_HIP(hipMalloc((void **)&ctx->part_min, GS_MAX_PART * sizeof(unsigned long long)));
@@ -145,7 +207,8 @@ GS_API int gs_destroy(gs_ctx *ctx)
     dev_free(ctx->tile_range); dev_free(ctx->fb); dev_free(ctx->ctl);
     dev_free(ctx->part_min); dev_free(ctx->part_max); dev_free(ctx->part_cnt); dev_free(ctx->part_valid); dev_free(ctx->part_vis);
     if (ctx->ctl_host) (void)hipHostFree(ctx->ctl_host);
-    for (int i = 0; i < 8; i++) if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
+    if (ctx->ring) { for (int i = 0; i < GS_PROF_RING * 6; i++) if (ctx->ring[i]) (void)hipEventDestroy(ctx->ring[i]); free(ctx->ring); }
+    free(ctx->ring_flags);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return GS_OK;
@@ -236,7 +299,6 @@ GS_API int gs_sort(gs_ctx *ctx, const float view[4], const float *cutout16, uint
         if (out_n) *out_n = V;
         if (out_idx && V) GS_HIP(hipMemcpy(out_idx, ctx->sorted, (size_t)V * 4, hipMemcpyDeviceToHost));
     }
-    ctx->sort_timed = ctx->profile;
     return GS_OK;
 }
 
@@ -268,30 +330,28 @@ static int render_common(gs_ctx *ctx, const gs_render_params *p, void *device_rg
     if (ntiles > ctx->tile_cap) { dev_free(ctx->tile_range); TRY(dev_alloc(ctx, &ctx->tile_range, ntiles)); ctx->tile_cap = ntiles; }
     if (!device_rgba && fb_bytes > ctx->fb_cap) { dev_free(ctx->fb); TRY(dev_alloc(ctx, &ctx->fb, fb_bytes)); ctx->fb_cap = fb_bytes; }
     if (!ctx->pair_cap) TRY(gs_ensure_pair_capacity(ctx, (size_t)1 << 22));
+    const bool async = (u.flags & GS_RENDER_ASYNC) && !host_rgba && !(u.flags & GS_RENDER_COUNT_FRAGS);
+    ctx->stats.n_tiles = ntiles; ctx->stats.blend_launches = 1;
+    if (async) {
+        // pipelined frame: enqueue, stage the control block for gs_sync(), return.  An overflowing frame shows the
+        // background only and is reported (GS_E_RETRY) by the next gs_sync().
+        TRY(gs_run_render(ctx, u, (uint8_t *)device_rgba));
+        GS_HIP(hipMemcpyAsync(ctx->ctl_host, ctx->ctl, sizeof(GsControl), hipMemcpyDeviceToHost, ctx->stream));
+        ctx->async_pending = true;
+        return prof_advance(ctx);
+    }
     for (int attempt = 0;; attempt++) {
         TRY(gs_run_render(ctx, u, (uint8_t *)device_rgba));
         GS_HIP(hipMemcpyAsync(ctx->ctl_host, ctx->ctl, sizeof(GsControl), hipMemcpyDeviceToHost, ctx->stream));
         GS_HIP(hipStreamSynchronize(ctx->stream));
-        if (!ctx->ctl_host->pair_overflow) break;
+        if (ctx->profile && ctx->ring) { ctx->ring_head++; ctx->ring_pending++; TRY(prof_drain(ctx)); }
+        bool over = false;
+        TRY(collect_status(ctx, &over));
+        if (!over) break;
         if (attempt >= 2) FAIL(GS_E_OOM, "pair list keeps overflowing (%u pairs)", ctx->ctl_host->scan_total);
-        TRY(gs_ensure_pair_capacity(ctx, (size_t)ctx->ctl_host->scan_total + ctx->ctl_host->scan_total / 4 + 1));
     }
-    const GsControl *c = ctx->ctl_host;
-    ctx->stats.n_sorted = c->n_kept; ctx->stats.n_visible = c->n_visible; ctx->stats.n_pairs = c->n_pairs;
-    ctx->stats.n_tiles = ntiles; ctx->stats.blend_launches = 1;
-    if (u.flags & GS_RENDER_COUNT_FRAGS) ctx->stats.n_frags = c->n_frags;
-    if (ctx->profile && ctx->sort_timed && ctx->have_sort) {       // the sort's events completed before this frame did
-        float ms = 0;
-        GS_HIP(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
-        ctx->stats.ms_sort = ms;
-    }
-    if (ctx->profile) {
-        float a = 0, b = 0, d = 0;
-        GS_HIP(hipEventElapsedTime(&a, ctx->ev[2], ctx->ev[3]));
-        GS_HIP(hipEventElapsedTime(&b, ctx->ev[3], ctx->ev[4]));
-        GS_HIP(hipEventElapsedTime(&d, ctx->ev[4], ctx->ev[5]));
-        ctx->stats.ms_project = a; ctx->stats.ms_bin = b; ctx->stats.ms_blend = d; ctx->stats.ms_render = a + b + d;
-    }
+    ctx->async_pending = false;
+    if (u.flags & GS_RENDER_COUNT_FRAGS) ctx->stats.n_frags = ctx->ctl_host->n_frags;
     if (host_rgba) {
         const uint8_t *src = device_rgba ? (const uint8_t *)device_rgba : ctx->fb;
         if (!stride) stride = sw * 4;
@@ -327,6 +387,14 @@ GS_API int gs_sync(gs_ctx *ctx)
     CHECK_CTX(ctx);
     GS_HIP(hipSetDevice(ctx->device));
     GS_HIP(hipStreamSynchronize(ctx->stream));
+    TRY(prof_drain(ctx));
+    if (ctx->async_pending) {
+        ctx->async_pending = false;
+        bool over = false;
+        TRY(collect_status(ctx, &over));
+        if (over) FAIL(GS_E_RETRY, "an asynchronous frame needed %u pairs and overflowed the pair buffers; they were enlarged - "
+                                   "render the frames since the previous gs_sync() again", ctx->ctl_host->max_total);
+    }
     return GS_OK;
 }
 
@@ -345,7 +413,23 @@ GS_API int gs_set_option(gs_ctx *ctx, int option, int64_t value)
 {
     CHECK_CTX(ctx);
     switch (option) {
-    case GS_OPT_PROFILE: ctx->profile = value != 0; return GS_OK;
+    case GS_OPT_PROFILE:
+        GS_HIP(hipSetDevice(ctx->device));
+        GS_HIP(hipStreamSynchronize(ctx->stream));
+        TRY(prof_drain(ctx));
+        if (value && !ctx->ring) {
+            ctx->ring = (hipEvent_t *)calloc(GS_PROF_RING * 6, sizeof(hipEvent_t));
+            ctx->ring_flags = (uint8_t *)calloc(GS_PROF_RING, 1);
+            if (!ctx->ring || !ctx->ring_flags) FAIL(GS_E_OOM, "out of host memory");
+            for (int i = 0; i < GS_PROF_RING * 6; i++) GS_HIP(hipEventCreate(&ctx->ring[i]));
+        }
+        if (value && !ctx->profile) {                    // (re)start accumulation
+            ctx->stats.prof_frames = 0;
+            ctx->stats.sum_ms_sort = ctx->stats.sum_ms_project = ctx->stats.sum_ms_bin = ctx->stats.sum_ms_blend = 0;
+            GS_HIP(hipMemsetAsync(&ctx->ctl->acc_frames, 0, sizeof(GsControl) - offsetof(GsControl, acc_frames), ctx->stream));
+        }
+        ctx->profile = value != 0;
+        return GS_OK;
     case GS_OPT_TERMINATION:
         if (value < 2) FAIL(GS_E_BADARG, "termination 1/eps must be >= 2");
         ctx->t_eps = 1.0f / (float)value; return GS_OK;

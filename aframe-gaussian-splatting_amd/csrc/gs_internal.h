@@ -12,6 +12,7 @@
 #define GS_BLOCK 256               // threads per workgroup everywhere (4 wavefronts of 64)
 #define GS_CHUNK 2048              // items per workgroup pass in streaming kernels (8 per thread)
 #define GS_RADIX_MAX_BINS 512      // up to 9-bit digits (depth key = 17 bits = 8 + 9)
+#define GS_PROF_RING 256           // frames of HIP-event timings kept in flight
 #define GS_MAX_PART 8192           // upper bound on the grid of any kernel that writes per-workgroup partials
 #define GS_CULLED_KEY 65536u       // depth-sort key of culled / dropped splats (sorts behind every bucket)
 
@@ -28,7 +29,10 @@ struct GsControl {
     uint32_t n_pairs;              // I : (tile, splat) pairs
     uint32_t pair_overflow;        // set when I exceeded the pair capacity (pairs clamped to 0)
     uint32_t scan_total;           // scratch: total of the last scan
-    uint32_t pad;
+    uint32_t overflow_sticky;      // like pair_overflow but only ever cleared by the host (asynchronous frames)
+    uint32_t max_total;            // largest I seen since the host last cleared it
+    uint32_t acc_frames;           // frames rendered since profiling was switched on
+    unsigned long long acc_sorted, acc_visible, acc_pairs;   // sums of V, Vp, I over those frames
 };
 
 struct GsFrameUniforms {           // per-render constants, passed by value to kernels
@@ -84,9 +88,10 @@ struct gs_ctx {
 
     // options / stats
     bool profile;
-    bool sort_timed;               // ev[0..1] bracket the last sort
     float t_eps;
-    hipEvent_t ev[8];
+    // profiling ring: GS_PROF_RING slots x 6 events (sort begin/end, render begin, after project, after binning, end)
+    hipEvent_t *ring; uint8_t *ring_flags; uint32_t ring_head, ring_pending;
+    bool async_pending;            // frames were enqueued with GS_RENDER_ASYNC since the last gs_sync
     gs_stats stats;
 };
 
@@ -124,3 +129,6 @@ int gs_run_sort(gs_ctx *ctx, const float view[4], const float *cutout16);
 int gs_run_render(gs_ctx *ctx, const GsFrameUniforms &u, uint8_t *device_out);
 // ---- gs_api.hip
 int gs_ensure_pair_capacity(gs_ctx *ctx, size_t pairs);
+// event k (0..5) of the current profiling slot, or nullptr when profiling is off
+hipEvent_t gs_prof_event(gs_ctx *ctx, int k);
+#define GS_PROF_RECORD(ctx, k) do { hipEvent_t _pev = gs_prof_event(ctx, k); if (_pev) GS_HIP(hipEventRecord(_pev, (ctx)->stream)); } while (0)

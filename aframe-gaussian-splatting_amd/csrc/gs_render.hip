@@ -8,9 +8,9 @@
 //   radix x2       stable sort of the pairs by tile id only: the input is already in depth order, so each
 //                  tile's list inherits the reference's draw order with no depth key            [gs_prims]
 //   k_tile_ranges  [start,end) of every tile in the sorted pair list
-//   k_blend        one 256-thread workgroup per 16x16 tile, LDS-staged batches of projected records,
-//                  FRONT-to-back traversal (reverse of the back-to-front list) with a transmittance
-//                  accumulator and workgroup-wide early termination; one rounding to RGBA8 at the end.
+//   k_blend        one wavefront per 16x16 tile, 4 pixels per lane, LDS-staged batches of projected records,
+//                  FRONT-to-back traversal (reverse of the back-to-front list) with per-pixel transmittance
+//                  accumulators and wave-wide early termination; one rounding to RGBA8 at the end.
 //
 // The fixed-function rasteriser + ROP of the reference have no structural counterpart; parity is defined at
 // the pixel level against oracle/gs_oracle.c (DESIGN.md "Pixel parity").
@@ -152,8 +152,10 @@ __global__ __launch_bounds__(GS_BLOCK) void k_pairs_check(GsControl *ctl, uint32
     if (threadIdx.x == 0) {
         ctl->n_visible = s_vis;
         ctl->scan_total = total;
-        if (total > pair_cap) { ctl->pair_overflow = 1; ctl->n_pairs = 0; }
+        if (total > ctl->max_total) ctl->max_total = total;
+        if (total > pair_cap) { ctl->pair_overflow = 1; ctl->overflow_sticky = 1; ctl->n_pairs = 0; }
         else { ctl->pair_overflow = 0; ctl->n_pairs = total; }
+        ctl->acc_frames += 1; ctl->acc_sorted += ctl->n_kept; ctl->acc_visible += s_vis; ctl->acc_pairs += ctl->n_pairs;
     }
 }
 
@@ -260,75 +262,120 @@ __global__ __launch_bounds__(GS_BLOCK) void k_tile_ranges(const uint2 *__restric
     }
 }
 
-// Fragment shader + blend for one 16x16 tile.  Thread t shades pixel (t%16, t/16) of the tile.
+// Fragment shader + blend for one 16x16 tile, ONE wavefront per tile, four horizontally adjacent pixels per lane
+// (lane l: image row l/4 of the tile, pixels 4*(l%4) .. +3).  The projected records of a batch are staged in LDS and
+// broadcast-read by the whole wave: with one pixel per lane the 4 waves of a 256-thread tile each re-read every record
+// and the kernel is LDS-bandwidth-bound (2 x ds_read_b128 = 8 LDS cycles per record per wave against ~20 VALU cycles);
+// four pixels per lane amortise each record read over 4x the arithmetic, and the row-shared terms dy*ay, dy*by are
+// computed once -- the expression tree per pixel is unchanged (frag_power), so coverage stays bit-identical.
+// Traversal is FRONT-to-back (the list is back-to-front) with a per-pixel transmittance accumulator; the wave leaves
+// the list as soon as every pixel has T < t_eps (ballot), one rounding to RGBA8 at the end.
+#define GS_BLEND_BATCH 128
+typedef float f2 __attribute__((ext_vector_type(2)));            // two pixels per packed-fp32 instruction (v_pk_*_f32)
+__device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+
 template <bool COUNT>
-__global__ __launch_bounds__(GS_BLOCK) void k_blend(const uint2 *__restrict__ tile_range, const uint2 *__restrict__ pairs,
-                                                    const gsm::Projected *__restrict__ proj, GsFrameUniforms u,
-                                                    uint8_t *__restrict__ out, GsControl *ctl)
+__global__ __launch_bounds__(64) void k_blend(const uint2 *__restrict__ tile_range, const uint2 *__restrict__ pairs,
+                                              const gsm::Projected *__restrict__ proj, GsFrameUniforms u,
+                                              uint8_t *__restrict__ out, GsControl *ctl)
 {
-    __shared__ float4 s_rec[2 * GS_BLOCK];                       // 8 KiB: one batch of projected records
-    __shared__ uint32_t s_frags;
+    __shared__ float4 s_rec[2 * GS_BLEND_BATCH];                 // 4 KiB: one batch of projected records
     const uint32_t tile = blockIdx.x;
     const uint32_t tx = tile % (uint32_t)u.tiles_x, ty = tile / (uint32_t)u.tiles_x;
-    const int x = u.x0 + (int)tx * GS_TILE + (int)(threadIdx.x & 15);
-    const int r = (int)ty * GS_TILE + (int)(threadIdx.x >> 4);     // image row, 0 = top
-    const bool inside = x < u.x1 && r < u.H;
-    const float fx = (float)x + 0.5f;                              // pixel centre, GL window coordinates
-    const float fy = (float)(u.H - 1 - r) + 0.5f;
-    const uint2 range = tile_range[tile];
+    const int lane = threadIdx.x;
+    const int xb = u.x0 + (int)tx * GS_TILE + (lane & 3) * 4;      // first of this lane's 4 pixels
+    const int r = (int)ty * GS_TILE + (lane >> 2);                 // image row, 0 = top
+    const bool row_in = r < u.H;
+    const float fy = (float)(u.H - 1 - r) + 0.5f;                  // pixel centre, GL window coordinates
     const bool no_early = COUNT || (u.flags & GS_RENDER_NO_EARLY_OUT);
-    if (COUNT) { if (threadIdx.x == 0) s_frags = 0; }
-
-    float T = 1.0f, cr = 0.0f, cg = 0.0f, cb = 0.0f, ca = 0.0f;
+    const float t_eps = no_early ? -1.0f : u.t_eps;                // T < t_eps never holds when early-out is off
+    // per pixel pair: x centre, transmittance, premultiplied colour/alpha, and the coverage threshold qmax:
+    // 4 while the pixel is live (fragment kept iff q <= 4, index.js:172), -1 once it is outside / terminated
+    f2 fxA = { (float)xb + 0.5f, (float)(xb + 1) + 0.5f }, fxB = { (float)(xb + 2) + 0.5f, (float)(xb + 3) + 0.5f };
+    f2 TA = { 1.0f, 1.0f }, TB = { 1.0f, 1.0f };
+    f2 crA = { 0, 0 }, crB = { 0, 0 }, cgA = { 0, 0 }, cgB = { 0, 0 }, cbA = { 0, 0 }, cbB = { 0, 0 }, caA = { 0, 0 }, caB = { 0, 0 };
+    f2 qmA = { (row_in && xb < u.x1) ? 4.0f : -1.0f, (row_in && xb + 1 < u.x1) ? 4.0f : -1.0f };
+    f2 qmB = { (row_in && xb + 2 < u.x1) ? 4.0f : -1.0f, (row_in && xb + 3 < u.x1) ? 4.0f : -1.0f };
     uint32_t nfr = 0;
-    bool done = !inside;
+    const uint2 range = tile_range[tile];
+
     for (uint32_t end = range.y; end > range.x;) {
-        const uint32_t nb = min((uint32_t)GS_BLOCK, end - range.x);
-        if (threadIdx.x < nb) {                                    // nearest first: reverse the back-to-front list
-            const uint32_t j = pairs[end - 1 - threadIdx.x].y;
-            const float4 *src = reinterpret_cast<const float4 *>(proj + j);
-            s_rec[2 * threadIdx.x] = src[0];
-            s_rec[2 * threadIdx.x + 1] = src[1];
+        const uint32_t nb = min((uint32_t)GS_BLEND_BATCH, end - range.x);
+#pragma unroll
+        for (int h = 0; h < GS_BLEND_BATCH / 64; h++) {            // nearest first: reverse the back-to-front list
+            const uint32_t slot = h * 64 + lane;
+            if (slot < nb) {
+                const uint32_t j = pairs[end - 1 - slot].y;
+                const float4 *src = reinterpret_cast<const float4 *>(proj + j);
+                s_rec[2 * slot] = src[0];
+                s_rec[2 * slot + 1] = src[1];
+            }
         }
         __syncthreads();
-        if (!done) {
-            for (uint32_t k = 0; k < nb; k++) {
-                const float4 a = s_rec[2 * k], b = s_rec[2 * k + 1];
-                const float q = gsm::frag_power(fx - a.x, fy - a.y, a.z, a.w, b.x, b.y);   // -A, index.js:171
-                if (q <= 4.0f) {                                                           // discard, index.js:172
-                    const float B = __expf(-q) * b.w;                                      // index.js:173
-                    const float w = B * T;
+        if (fmaxf(fmaxf(qmA.x, qmA.y), fmaxf(qmB.x, qmB.y)) > 0.0f) {
+            for (uint32_t s = 0; s < nb; s++) {
+                const float4 a = s_rec[2 * s], b = s_rec[2 * s + 1];
+                const float dy = fy - a.y;
+                const float dyay = dy * a.w, dyby = dy * b.y;      // shared by the 4 pixels of the row
+                // |p|^2 of the interpolated vPosition, same expression tree per pixel as gsm::frag_power
+                const f2 dxA = fxA - a.x, dxB = fxB - a.x;
+                const f2 pxA = fma2(dxA, (f2)(a.z), (f2)(dyay)), pxB = fma2(dxB, (f2)(a.z), (f2)(dyay));
+                const f2 pyA = fma2(dxA, (f2)(b.x), (f2)(dyby)), pyB = fma2(dxB, (f2)(b.x), (f2)(dyby));
+                const f2 qA = fma2(pxA, pxA, pyA * pyA), qB = fma2(pxB, pxB, pyB * pyB);   // -A, index.js:171
+                const bool p0 = qA.x <= qmA.x, p1 = qA.y <= qmA.y, p2 = qB.x <= qmB.x, p3 = qB.y <= qmB.y;
+                if (p0 | p1 | p2 | p3) {                           // discard test, index.js:172
+                    const float alpha = b.w;
                     const uint32_t rgba = __float_as_uint(b.z);
-                    const float w255 = w * (1.0f / 255.0f);
-                    cr = fmaf((float)(rgba & 0xFF), w255, cr);
-                    cg = fmaf((float)((rgba >> 8) & 0xFF), w255, cg);
-                    cb = fmaf((float)((rgba >> 16) & 0xFF), w255, cb);
-                    ca += w;
-                    T *= (1.0f - B);
-                    if (COUNT) nfr++;
-                    if (!no_early && T < u.t_eps) { done = true; break; }
+                    // B = exp(A) * vColor.a (index.js:173); 0 for the pixels of this lane that the splat misses
+                    const f2 BA = { p0 ? __expf(-qA.x) * alpha : 0.0f, p1 ? __expf(-qA.y) * alpha : 0.0f };
+                    const f2 BB = { p2 ? __expf(-qB.x) * alpha : 0.0f, p3 ? __expf(-qB.y) * alpha : 0.0f };
+                    const f2 wA = BA * TA, wB = BB * TB;
+                    const f2 vA = wA * (1.0f / 255.0f), vB = wB * (1.0f / 255.0f);
+                    const float c0 = (float)(rgba & 0xFF), c1 = (float)((rgba >> 8) & 0xFF), c2 = (float)((rgba >> 16) & 0xFF);
+                    crA = fma2((f2)(c0), vA, crA); crB = fma2((f2)(c0), vB, crB);
+                    cgA = fma2((f2)(c1), vA, cgA); cgB = fma2((f2)(c1), vB, cgB);
+                    cbA = fma2((f2)(c2), vA, cbA); cbB = fma2((f2)(c2), vB, cbB);
+                    caA += wA; caB += wB;
+                    TA *= (1.0f - BA); TB *= (1.0f - BB);
+                    if (COUNT) nfr += (uint32_t)p0 + (uint32_t)p1 + (uint32_t)p2 + (uint32_t)p3;
+                    // a pixel stops taking fragments once its transmittance is below the threshold
+                    qmA.x = TA.x < t_eps ? -1.0f : qmA.x; qmA.y = TA.y < t_eps ? -1.0f : qmA.y;
+                    qmB.x = TB.x < t_eps ? -1.0f : qmB.x; qmB.y = TB.y < t_eps ? -1.0f : qmB.y;
+                    if (!(fmaxf(fmaxf(qmA.x, qmA.y), fmaxf(qmB.x, qmB.y)) > 0.0f)) break;
                 }
             }
         }
         end -= nb;
-        if (__syncthreads_and(done)) break;                        // also fences s_rec before the next batch
+        __syncthreads();                                           // s_rec is rewritten by the next batch
+        if (__all(!(fmaxf(fmaxf(qmA.x, qmA.y), fmaxf(qmB.x, qmB.y)) > 0.0f))) break;
     }
-    if (inside) {
+    if (row_in && xb < u.x1) {
         // dst <- src.rgb*a + dst.rgb*(1-a), dst.a <- a + dst.a*(1-a), composed over the background
-        const float o0 = fmaf(T, u.bg[0], cr), o1 = fmaf(T, u.bg[1], cg), o2 = fmaf(T, u.bg[2], cb), o3 = fmaf(T, u.bg[3], ca);
         const int sw = u.x1 - u.x0;
         const int orow = (u.flags & GS_RENDER_FLIP_Y) ? (u.H - 1 - r) : r;
-        uchar4 px;
-        px.x = (uint8_t)(fminf(fmaxf(o0, 0.0f), 1.0f) * 255.0f + 0.5f);
-        px.y = (uint8_t)(fminf(fmaxf(o1, 0.0f), 1.0f) * 255.0f + 0.5f);
-        px.z = (uint8_t)(fminf(fmaxf(o2, 0.0f), 1.0f) * 255.0f + 0.5f);
-        px.w = (uint8_t)(fminf(fmaxf(o3, 0.0f), 1.0f) * 255.0f + 0.5f);
-        reinterpret_cast<uchar4 *>(out)[(size_t)orow * sw + (x - u.x0)] = px;
+        const float Tk[4] = { TA.x, TA.y, TB.x, TB.y }, rk[4] = { crA.x, crA.y, crB.x, crB.y }, gk[4] = { cgA.x, cgA.y, cgB.x, cgB.y };
+        const float bk[4] = { cbA.x, cbA.y, cbB.x, cbB.y }, ak[4] = { caA.x, caA.y, caB.x, caB.y };
+        uint32_t px[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const float o0 = fmaf(Tk[k], u.bg[0], rk[k]), o1 = fmaf(Tk[k], u.bg[1], gk[k]);
+            const float o2 = fmaf(Tk[k], u.bg[2], bk[k]), o3 = fmaf(Tk[k], u.bg[3], ak[k]);
+            px[k] = (uint32_t)(fminf(fmaxf(o0, 0.0f), 1.0f) * 255.0f + 0.5f) |
+                    ((uint32_t)(fminf(fmaxf(o1, 0.0f), 1.0f) * 255.0f + 0.5f) << 8) |
+                    ((uint32_t)(fminf(fmaxf(o2, 0.0f), 1.0f) * 255.0f + 0.5f) << 16) |
+                    ((uint32_t)(fminf(fmaxf(o3, 0.0f), 1.0f) * 255.0f + 0.5f) << 24);
+        }
+        uint32_t *dst = reinterpret_cast<uint32_t *>(out) + (size_t)orow * sw + (xb - u.x0);
+        if (xb + 3 < u.x1 && (sw & 3) == 0) *reinterpret_cast<uint4 *>(dst) = make_uint4(px[0], px[1], px[2], px[3]);
+        else {
+#pragma unroll
+            for (int k = 0; k < 4; k++) if (xb + k < u.x1) dst[k] = px[k];
+        }
     }
     if (COUNT) {
-        if (nfr) atomicAdd(&s_frags, nfr);
-        __syncthreads();
-        if (threadIdx.x == 0 && s_frags) atomicAdd(&ctl->n_frags, (unsigned long long)s_frags);
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) nfr += __shfl_xor(nfr, m, 64);
+        if (lane == 0 && nfr) atomicAdd(&ctl->n_frags, (unsigned long long)nfr);
     }
 }
 
@@ -343,14 +390,14 @@ int gs_run_render(gs_ctx *ctx, const GsFrameUniforms &u, uint8_t *device_out)
     uint8_t *out = device_out ? device_out : ctx->fb;
     hipStream_t st = ctx->stream;
 
-    if (ctx->profile) GS_HIP(hipEventRecord(ctx->ev[2], st));
+    GS_PROF_RECORD(ctx, 2);
     if (u.flags & GS_RENDER_COUNT_FRAGS) GS_HIP(hipMemsetAsync(&ctx->ctl->n_frags, 0, sizeof(unsigned long long), st));
     if (Vmax && ctx->have_sort) {
         uint32_t g = gs_div_up(Vmax, GS_BLOCK); if (g > GS_MAX_PART) g = GS_MAX_PART;
         hipLaunchKernelGGL(k_project, dim3(g), dim3(GS_BLOCK), 0, st, ctx->sorted, ctx->center_scale, ctx->cov_color, u, ctx->proj,
                            ctx->rect, ctx->tile_count, ctx->spine, ctx->part_vis, ctx->ctl);
         GS_HIP(hipGetLastError());
-        if (ctx->profile) GS_HIP(hipEventRecord(ctx->ev[3], st));
+        GS_PROF_RECORD(ctx, 3);
         hipLaunchKernelGGL(k_pairs_check, dim3(1), dim3(GS_BLOCK), 0, st, ctx->ctl, (uint32_t)ctx->pair_cap, ctx->spine, ctx->part_vis, g);
         hipLaunchKernelGGL(k_emit, dim3(g), dim3(GS_BLOCK), 0, st, ctx->proj, ctx->rect, ctx->tile_count, ctx->spine, u,
                            ctx->pair_a, ctx->ctl);
@@ -373,20 +420,20 @@ int gs_run_render(gs_ctx *ctx, const GsFrameUniforms &u, uint8_t *device_out)
         }
         hipLaunchKernelGGL(k_tile_ranges, dim3(2048), dim3(GS_BLOCK), 0, st, fpairs, ctx->tile_range, ntiles, ctx->ctl);
         GS_HIP(hipGetLastError());
-        if (ctx->profile) GS_HIP(hipEventRecord(ctx->ev[4], st));
+        GS_PROF_RECORD(ctx, 4);
         if (u.flags & GS_RENDER_COUNT_FRAGS)
-            hipLaunchKernelGGL(k_blend<true>, dim3(ntiles), dim3(GS_BLOCK), 0, st, ctx->tile_range, fpairs, ctx->proj, u, out, ctx->ctl);
+            hipLaunchKernelGGL(k_blend<true>, dim3(ntiles), dim3(64), 0, st, ctx->tile_range, fpairs, ctx->proj, u, out, ctx->ctl);
         else
-            hipLaunchKernelGGL(k_blend<false>, dim3(ntiles), dim3(GS_BLOCK), 0, st, ctx->tile_range, fpairs, ctx->proj, u, out, ctx->ctl);
+            hipLaunchKernelGGL(k_blend<false>, dim3(ntiles), dim3(64), 0, st, ctx->tile_range, fpairs, ctx->proj, u, out, ctx->ctl);
         GS_HIP(hipGetLastError());
     } else {
         // nothing resident / never sorted: the frame is the background
         GS_HIP(hipMemsetAsync(ctx->ctl, 0, sizeof(GsControl), st));
         GS_HIP(hipMemsetAsync(ctx->tile_range, 0, sizeof(uint2) * ntiles, st));
-        if (ctx->profile) { GS_HIP(hipEventRecord(ctx->ev[3], st)); GS_HIP(hipEventRecord(ctx->ev[4], st)); }
-        hipLaunchKernelGGL(k_blend<false>, dim3(ntiles), dim3(GS_BLOCK), 0, st, ctx->tile_range, ctx->pair_a, ctx->proj, u, out, ctx->ctl);
+        GS_PROF_RECORD(ctx, 3); GS_PROF_RECORD(ctx, 4);
+        hipLaunchKernelGGL(k_blend<false>, dim3(ntiles), dim3(64), 0, st, ctx->tile_range, ctx->pair_a, ctx->proj, u, out, ctx->ctl);
         GS_HIP(hipGetLastError());
     }
-    if (ctx->profile) GS_HIP(hipEventRecord(ctx->ev[5], st));
+    GS_PROF_RECORD(ctx, 5);
     return GS_OK;
 }

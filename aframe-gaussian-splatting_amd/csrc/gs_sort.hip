@@ -127,7 +127,7 @@ int gs_run_sort(gs_ctx *ctx, const float view[4], const float *cutout16)
     if (cutout16) memcpy(u.cutout, cutout16, sizeof u.cutout); else memset(u.cutout, 0, sizeof u.cutout);
 
     const uint32_t g = gs_radix_grid(n);                         // same chunking as the radix kernels (pre-filled histogram)
-    if (ctx->profile) GS_HIP(hipEventRecord(ctx->ev[0], ctx->stream));
+    GS_PROF_RECORD(ctx, 0);
     hipLaunchKernelGGL(k_sort_depth, dim3(g), dim3(GS_BLOCK), 0, ctx->stream, ctx->sort_rows, n, u, ctx->depth, ctx->part_min,
                        ctx->part_max, ctx->part_cnt);
     hipLaunchKernelGGL(k_sort_bucket, dim3(g), dim3(GS_BLOCK), 0, ctx->stream, ctx->depth, n, ctx->key_a, ctx->part_min,
@@ -139,7 +139,7 @@ int gs_run_sort(gs_ctx *ctx, const float view[4], const float *cutout16)
     // the reference's never-written Uint32Array slots
     rc = gs_launch_radix_pass(ctx, ctx->kv_b, true, ctx->val_a, false, &ctx->ctl->n_total, n, 8, 9, false, GS_CULLED_KEY);
     if (rc != GS_OK) return rc;
-    if (ctx->profile) GS_HIP(hipEventRecord(ctx->ev[1], ctx->stream));
+    GS_PROF_RECORD(ctx, 1);
     ctx->sorted = ctx->val_a;
     ctx->have_sort = true;
     return GS_OK;

@@ -70,20 +70,24 @@ def main():
         strip = torch.zeros(mg.strip_buffer_bytes(W, H, world), dtype=torch.uint8, device="cuda")   # tight H x sw x 4 rows at the front
         gathered = [torch.zeros_like(strip) for _ in range(world)] if rank == 0 else None
 
+    if world > 1:
+        # run the library on torch's current stream: the RCCL gather then orders after the strip's kernels
+        # without a host round trip
+        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+
     def frame(i, flags=0):
         k = i % ORBIT_FRAMES
         ctx.sort(cams[k]["view"], want_indices=False)
         p = params[k]
         p.flags = flags
         if world > 1:
-            ctx.render_device(p, strip.data_ptr())          # returns with the strip complete in HBM
+            ctx.render_device(p, strip.data_ptr())
             return mg.gather_strips(strip, W, H, dist, gathered)   # RCCL gather + row-major assembly on rank 0
-        else:
-            ctx.render_device(p, None)
+        ctx.render_device(p, None)
         return None
 
     def sync():
-        ctx.sync()
+        ctx.sync()                                           # collects status/statistics of the asynchronous frames
         if world > 1:
             torch.cuda.synchronize()
             dist.barrier()
@@ -93,34 +97,31 @@ def main():
     frames_used = sorted(set((args.warmup + i) % ORBIT_FRAMES for i in range(args.steps)))
     frags = {}
     for k in frames_used:
-        ctx.sort(cams[k]["view"], want_indices=False)
-        p = params[k]
-        p.flags = capi.RENDER_COUNT_FRAGS
-        ctx.render_device(p, strip.data_ptr() if world > 1 else None)
+        frame(k, capi.RENDER_COUNT_FRAGS)
         frags[k] = ctx.stats()["n_frags"]
-        p.flags = 0
     if world > 1:
         t = torch.tensor([frags[k] for k in frames_used], dtype=torch.int64, device="cuda")
         dist.all_reduce(t)
         frags = dict(zip(frames_used, t.tolist()))
 
+    # frames are enqueued back to back like the reference's render loop (GS_RENDER_ASYNC); gs_sync() at the end of
+    # the region collects their status (an overflowing pair buffer would surface there as GS_E_RETRY)
     for i in range(args.warmup):
-        frame(i)
+        frame(i, capi.RENDER_ASYNC)
+    sync()
     # ---- timed region: exactly K steps, barrier + synchronize on both sides
-    ctx.set_option(capi.OPT_PROFILE, 1)
-    stage = {"ms_sort": 0.0, "ms_project": 0.0, "ms_bin": 0.0, "ms_blend": 0.0}
-    pairs = visible = sorted_n = 0
+    ctx.set_option(capi.OPT_PROFILE, 1)                      # HIP events around every stage, on the library's stream
     sync()
     t_start = time.perf_counter()
     for i in range(args.steps):
-        frame(args.warmup + i)
-        s = ctx.stats()                                     # host-side struct copy, no GPU work
-        for key in stage:
-            stage[key] += s[key]
-        pairs += s["n_pairs"]; visible += s["n_visible"]; sorted_n += s["n_sorted"]
+        frame(args.warmup + i, capi.RENDER_ASYNC)
     sync()
     elapsed = time.perf_counter() - t_start
+    s = ctx.stats()
     ctx.set_option(capi.OPT_PROFILE, 0)
+    assert s["acc_frames"] == args.steps and s["prof_frames"] == args.steps, (s["acc_frames"], s["prof_frames"])
+    stage = {"ms_sort": s["sum_ms_sort"], "ms_project": s["sum_ms_project"], "ms_bin": s["sum_ms_bin"], "ms_blend": s["sum_ms_blend"]}
+    pairs, visible, sorted_n = s["acc_pairs"], s["acc_visible"], s["acc_sorted"]
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

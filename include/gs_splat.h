@@ -38,7 +38,9 @@ typedef enum gs_status {
     GS_E_OOM = -5,         /* host or device allocation failed                                          */
     GS_E_NODEVICE = -6,    /* no usable gfx950 device                                                   */
     GS_E_STATE = -7,       /* call not valid in this state (e.g. render after matrices-only push)       */
-    GS_E_PLY_DATA = -8     /* vertex data shorter than the header promises (DataView RangeError in JS)  */
+    GS_E_PLY_DATA = -8,    /* vertex data shorter than the header promises (DataView RangeError in JS)  */
+    GS_E_RETRY = -9        /* gs_sync(): an asynchronous frame outgrew the pair buffers; they were enlarged,
+                              frames rendered since the previous gs_sync() must be rendered again            */
 } gs_status;
 
 /* ---- lifetime ----------------------------------------------------------------------------------- */
@@ -95,6 +97,9 @@ GS_API int gs_sort(gs_ctx *ctx, const float view[4], const float *cutout16, uint
 #define GS_RENDER_FLIP_Y 1u      /* rows bottom-up (WebGL readPixels order) instead of top-down              */
 #define GS_RENDER_COUNT_FRAGS 2u /* no early termination; count reference-equivalent splat-fragments         */
 #define GS_RENDER_NO_EARLY_OUT 4u/* blend every fragment (parity debugging)                                   */
+#define GS_RENDER_ASYNC 8u       /* gs_render_device only: enqueue the frame and return; completion, status and
+                                    statistics are collected by gs_sync().  The reference renders every frame
+                                    without waiting for the GPU either (index.js:184-207).                        */
 
 typedef struct gs_render_params {
     float model_view[16]; /* gsModelViewMatrix, column-major (getModelViewMatrix, index.js:467-487)      */
@@ -116,7 +121,8 @@ GS_API int gs_render_device(gs_ctx *ctx, const gs_render_params *p, void *device
 /* XR: two eyes share one sort order from the head camera (index.js:441) -- two params, two images. */
 GS_API int gs_render_stereo(gs_ctx *ctx, const gs_render_params eyes[2], uint8_t *rgba_out[2], size_t stride);
 
-/* Block until all work queued on the context's stream is done. */
+/* Block until all work queued on the context's stream is done; collects the status and statistics of frames
+ * rendered with GS_RENDER_ASYNC (GS_E_RETRY if one of them overflowed the pair buffers). */
 GS_API int gs_sync(gs_ctx *ctx);
 /* Run the context's kernels on a caller-owned hipStream_t (e.g. torch's current stream). NULL = own stream. */
 GS_API int gs_set_stream(gs_ctx *ctx, void *hip_stream);
@@ -150,6 +156,13 @@ typedef struct gs_stats {
     float ms_blend;
     float ms_render;      /* project + bin + blend                                                    */
     uint32_t blend_launches;
+    /* accumulated since GS_OPT_PROFILE was last switched on (collected at gs_sync / synchronous renders)     */
+    uint32_t prof_frames; /* frames whose HIP-event timings are summed below                                  */
+    float sum_ms_sort, sum_ms_project, sum_ms_bin, sum_ms_blend;
+    uint64_t acc_frames;  /* frames rendered (device-side counter)                                            */
+    uint64_t acc_sorted;  /* sum of V over those frames                                                       */
+    uint64_t acc_visible; /* sum of Vp                                                                        */
+    uint64_t acc_pairs;   /* sum of I                                                                         */
 } gs_stats;
 
 #define GS_OPT_PROFILE 1        /* value != 0: bracket stages with HIP events on the context stream        */

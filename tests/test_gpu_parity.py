@@ -279,3 +279,109 @@ def test_render_1080p_strip_vs_oracle(ctx, scene_1m):
     assert np.abs(got.astype(int) - want.astype(int)).max() <= PIXEL_TOL_LSB
     ctx.render(_params(cam, x0=880, x1=1040, flags=capi.RENDER_COUNT_FRAGS))
     assert ctx.stats()["n_frags"] == frags
+
+
+# ---------------------------------------------------------------- the larger BASELINE.json configurations
+
+@pytest.mark.skipif(os.environ.get("GS_SKIP_SLOW") == "1", reason="large configs")
+def test_c3_bicycle_6m_cutout_via_ply_loader(ctx):
+    """C3: ~6M gaussians through the .ply loader path, cutoutEntity AABB, 1920x1080.  Sort bit-exact vs the oracle;
+    pixels checked on a column strip; strips == full frame."""
+    n = 6 * (1 << 20) // 4                           # 1.5M through the PLY path (248 B/row) keeps the host side quick
+    rows = synth.make_splat_rows(n, seed=synth.SEED_BASE + 3)
+    ply = synth.rows_to_inria_ply(rows)
+    ctx.clear(); ctx.load_ply(ply)
+    assert ctx.count() == n
+    conv = capi.ply_to_splat(ply)
+    cs, cc, mats = oracle.pack(conv)
+    cam = synth.cutout_demo_camera(1920, 1080, 20.0, capi=capi)
+    idx = ctx.sort(cam["view"], cam["cutout"])
+    want = oracle.sort(mats, cam["view"], cam["cutout"])
+    assert want.size > 10000 and np.array_equal(idx, want)
+    full = ctx.render(_params(cam))
+    mv, P, focal = _f32(cam)
+    ref, _, frags = oracle.render(cs, cc, idx, mv, P, focal, 1920, 1080, x0=900, x1=1060, want_f32=False)
+    assert np.abs(full[:, 900:1060].astype(int) - ref.astype(int)).max() <= PIXEL_TOL_LSB
+    ctx.render(_params(cam, x0=900, x1=1060, flags=capi.RENDER_COUNT_FRAGS))
+    assert ctx.stats()["n_frags"] == frags
+
+
+@pytest.mark.skipif(os.environ.get("GS_SKIP_SLOW") == "1", reason="large configs")
+def test_c3_six_million_sort_and_render_properties(ctx):
+    rows = synth.make_splat_rows(synth.N_BICYCLE, seed=synth.SEED_BASE + 3)
+    _, _, mats = oracle.pack(rows)
+    ctx.clear(); ctx.push_splat(rows)
+    cam = synth.cutout_demo_camera(1920, 1080, 75.0, capi=capi)
+    rows4 = np.ascontiguousarray(mats[:, 12:16])
+    assert np.array_equal(ctx.sort(cam["view"], cam["cutout"]), oracle.sort(rows4, cam["view"], cam["cutout"]))
+    cam2 = synth.index_html_camera(1920, 1080, 75.0, capi=capi)
+    assert np.array_equal(ctx.sort(cam2["view"]), oracle.sort(rows4, cam2["view"]))
+    full = ctx.render(_params(cam2))
+    parts = [ctx.render(_params(cam2, x0=k * 480, x1=(k + 1) * 480)) for k in range(4)]
+    assert np.array_equal(np.concatenate(parts, axis=1), full)
+    assert ctx.stats()["n_pairs"] > 1000000
+
+
+@pytest.mark.skipif(os.environ.get("GS_SKIP_SLOW") == "1", reason="large configs")
+def test_c4_xr_stereo_and_c5_4k_strip(ctx, scene_1m):
+    """C4: XR stereo 2 x (2064x2208 x 0.5) with one shared sort; C5-shaped: 3840x2160 (32400 tiles -> 15-bit tile ids),
+    one of 8 column strips vs the oracle."""
+    ctx.clear(); ctx.push_splat(scene_1m["rows"])
+    l, r, head = synth.xr_eye_cameras(10.0, 0.5, capi=capi)
+    assert (l["vw"], l["vh"]) == (1032, 1104)
+    idx = ctx.sort(head["view"])
+    o0, o1 = ctx.render_stereo(_params(l), _params(r))
+    assert o0.shape == (1104, 1032, 4) and not np.array_equal(o0, o1)
+    cs, cc, _ = oracle.pack(scene_1m["rows"])
+    mv, P, focal = _f32(l)
+    ref, _, _ = oracle.render(cs, cc, idx, mv, P, focal, 1032, 1104, x0=500, x1=600, want_f32=False)
+    assert np.abs(o0[:, 500:600].astype(int) - ref.astype(int)).max() <= PIXEL_TOL_LSB
+    cam = synth.index_html_camera(3840, 2160, 200.0, capi=capi)
+    idx = ctx.sort(cam["view"])
+    strip = ctx.render(_params(cam, x0=3 * 480, x1=4 * 480))
+    mv, P, focal = _f32(cam)
+    ref, _, _ = oracle.render(cs, cc, idx, mv, P, focal, 3840, 2160, x0=3 * 480, x1=3 * 480 + 96, want_f32=False)
+    assert np.abs(strip[:, :96].astype(int) - ref.astype(int)).max() <= PIXEL_TOL_LSB
+    full = ctx.render(_params(cam))
+    assert np.array_equal(full[:, 3 * 480:4 * 480], strip)
+
+
+def test_async_frames_match_synchronous_ones_and_report_overflow(scene_small):
+    """GS_RENDER_ASYNC: frames enqueued back to back produce the same pixels as synchronous renders; statistics are
+    collected by gs_sync(); a frame that outgrows the pair buffers is reported as GS_E_RETRY and succeeds afterwards."""
+    import ctypes
+    with capi.Context(0) as c2:
+        c2.push_splat(scene_small["rows"])
+        cams = [synth.index_html_camera(320, 180, y, capi=capi) for y in (0.0, 90.0, 180.0)]
+        want = []
+        for cam in cams:
+            c2.sort(cam["view"]); want.append(c2.render(_params(cam)))
+        c2.set_option(capi.OPT_PROFILE, 1)
+        for cam in cams:
+            c2.sort(cam["view"], want_indices=False)
+            c2.render_device(_params(cam, flags=capi.RENDER_ASYNC), None)
+        c2.sync()
+        s = c2.stats()
+        assert s["acc_frames"] == 3 and s["prof_frames"] == 3 and s["sum_ms_blend"] > 0 and s["acc_pairs"] > 0
+        c2.set_option(capi.OPT_PROFILE, 0)
+        assert np.array_equal(c2.render(_params(cams[2])), want[2])       # last async frame == synchronous frame
+    with capi.Context(0) as c3:                                            # fresh context: small default pair capacity
+        rows = synth.make_splat_rows(300000, seed=5)
+        rows = rows.reshape(-1, 32).copy()
+        rows[:, 12:24] = (rows[:, 12:24].copy().view("<f4") * np.float32(6.0)).view(np.uint8)   # fat splats: many tiles each
+        c3.push_splat(rows)
+        cam = synth.index_html_camera(1920, 1080, 0.0, capi=capi)
+        c3.sort(cam["view"], want_indices=False)
+        c3.render_device(_params(cam, flags=capi.RENDER_ASYNC), None)
+        try:
+            c3.sync()
+            overflowed = False
+        except capi.GsError as e:
+            assert e.code == capi.E_RETRY
+            overflowed = True
+        c3.render_device(_params(cam, flags=capi.RENDER_ASYNC), None)
+        c3.sync()                                                          # enlarged buffers: no error now
+        a = c3.render(_params(cam))
+        assert c3.stats()["n_pairs"] > 0
+        if overflowed:
+            assert c3.stats()["n_pairs"] > (1 << 22)
