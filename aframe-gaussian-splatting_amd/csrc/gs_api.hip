@@ -60,16 +60,15 @@ static int ensure_capacity(gs_ctx *ctx, size_t want)
     if (want > 0x7FFFFFF0ull) FAIL(GS_E_BADARG, "more than 2^31 splats");
     size_t cap = ctx->cap ? ctx->cap : (size_t)1 << 16;
     while (cap < want) cap *= 2;
-    float4 *cs = nullptr, *sr = nullptr; uint4 *cc = nullptr;
-    TRY(dev_alloc(ctx, &cs, cap)); TRY(dev_alloc(ctx, &cc, cap)); TRY(dev_alloc(ctx, &sr, cap));
+    float4 *sr = nullptr; uint4 *sp = nullptr;
+    TRY(dev_alloc(ctx, &sp, cap * 2)); TRY(dev_alloc(ctx, &sr, cap));
     if (ctx->n) {
-        GS_HIP(hipMemcpyAsync(cs, ctx->center_scale, ctx->n * sizeof(float4), hipMemcpyDeviceToDevice, ctx->stream));
-        GS_HIP(hipMemcpyAsync(cc, ctx->cov_color, ctx->n * sizeof(uint4), hipMemcpyDeviceToDevice, ctx->stream));
+        GS_HIP(hipMemcpyAsync(sp, ctx->splat, ctx->n * 2 * sizeof(uint4), hipMemcpyDeviceToDevice, ctx->stream));
         GS_HIP(hipMemcpyAsync(sr, ctx->sort_rows, ctx->n * sizeof(float4), hipMemcpyDeviceToDevice, ctx->stream));
         GS_HIP(hipStreamSynchronize(ctx->stream));
     }
-    dev_free(ctx->center_scale); dev_free(ctx->cov_color); dev_free(ctx->sort_rows);
-    ctx->center_scale = cs; ctx->cov_color = cc; ctx->sort_rows = sr;
+    dev_free(ctx->splat); dev_free(ctx->sort_rows);
+    ctx->splat = sp; ctx->sort_rows = sr;
     dev_free(ctx->depth); dev_free(ctx->key_a); dev_free(ctx->kv_b); dev_free(ctx->val_a);
     dev_free(ctx->proj); dev_free(ctx->rect); dev_free(ctx->tile_count);
     TRY(dev_alloc(ctx, &ctx->depth, cap));
@@ -199,7 +198,7 @@ GS_API int gs_destroy(gs_ctx *ctx)
     if (!ctx) return GS_OK;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-    dev_free(ctx->center_scale); dev_free(ctx->cov_color); dev_free(ctx->sort_rows); dev_free(ctx->pow10tab);
+    dev_free(ctx->splat); dev_free(ctx->sort_rows); dev_free(ctx->pow10tab);
     dev_free(ctx->depth); dev_free(ctx->key_a); dev_free(ctx->kv_b); dev_free(ctx->val_a);
     dev_free(ctx->hist); dev_free(ctx->spine);
     dev_free(ctx->proj); dev_free(ctx->rect); dev_free(ctx->tile_count);
@@ -454,9 +453,14 @@ GS_API int gs_download(gs_ctx *ctx, int which, void *out, size_t nbytes)
     GS_HIP(hipStreamSynchronize(ctx->stream));
     const void *src = nullptr; size_t have = 0;
     const size_t V = ctx->stats.n_sorted;
+    if (which == GS_BUF_CENTER_SCALE || which == GS_BUF_COV_COLOR) {     // de-interleave the 32-byte splat records
+        if (!ctx->renderable && ctx->n) FAIL(GS_E_STATE, "context holds worker rows only");
+        if (nbytes > ctx->n * 16 || nbytes % 16) FAIL(GS_E_BADARG, "buffer %d holds %zu bytes, %zu requested", which, ctx->n * 16, nbytes);
+        if (nbytes) GS_HIP(hipMemcpy2D(out, 16, (const char *)ctx->splat + (which == GS_BUF_COV_COLOR ? 16 : 0), 32, 16, nbytes / 16,
+                                        hipMemcpyDeviceToHost));
+        return GS_OK;
+    }
     switch (which) {
-    case GS_BUF_CENTER_SCALE: src = ctx->center_scale; have = ctx->n * 16; break;
-    case GS_BUF_COV_COLOR: src = ctx->cov_color; have = ctx->n * 16; break;
     case GS_BUF_SORT_ROWS: src = ctx->sort_rows; have = ctx->n * 16; break;
     case GS_BUF_SORTED: src = ctx->sorted; have = ctx->have_sort ? V * 4 : 0; break;
     case GS_BUF_PROJECTED: src = ctx->proj; have = ctx->have_sort ? V * 32 : 0; break;

@@ -56,8 +56,11 @@ struct gs_ctx {
     // resident splat data (append-only; capacity doubles)
     size_t n, cap;
     bool renderable;               // false once matrices-only rows were pushed
-    float4 *center_scale;          // N x (cx, cy, -z, max|Sigma|/32767)           index.js:378-382
-    uint4 *cov_color;              // N x (6 x int16 Sigma, RGBA8)                   index.js:384-394
+    // the reference's two data textures, interleaved into ONE 32-byte record per splat so that the projection's
+    // gather by sorted index touches one cache line per splat instead of two:
+    //   [0] float4 (cx, cy, -z, max|Sigma|/32767)   centerAndScaleData  index.js:378-382
+    //   [1] uint4  (6 x int16 Sigma, RGBA8)         covAndColorData     index.js:384-394
+    uint4 *splat;                  // N x 2 x 16 B
     float4 *sort_rows;             // N x worker-row elements 12..15                 index.js:396-401
     double *pow10tab;              // parseInt table (gs_host_tables.h)
 

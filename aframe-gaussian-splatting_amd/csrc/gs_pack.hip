@@ -1,5 +1,5 @@
 // gs_pack.hip -- pushDataBuffer's pack loop (index.js:343-402) as one HIP kernel: 32 B .splat row in,
-// 16 B centre/scale + 16 B covariance/colour + 16 B sort row out, one thread per splat, all 16-byte
+// one interleaved 32 B record (16 B centre/scale + 16 B covariance/colour) + 16 B sort row out, one thread per splat, all 16-byte
 // coalesced accesses.  The covariance is built in f64 in three.js' operation order (gs_device_math.h) so the
 // int16 quantisation, including the parseInt exponent-form quirk, is bit-identical to the reference.
 #include "gs_internal.h"
@@ -7,16 +7,15 @@
 namespace {
 
 __global__ __launch_bounds__(GS_BLOCK) void k_pack(const uint4 *__restrict__ rows, uint32_t nrows, const double *__restrict__ pow10tab,
-                                                   float4 *__restrict__ center_scale, uint4 *__restrict__ cov_color,
-                                                   float4 *__restrict__ sort_rows)
+                                                   uint4 *__restrict__ splat, float4 *__restrict__ sort_rows)
 {
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nrows; i += gridDim.x * blockDim.x) {
         const uint4 a = rows[2 * i], b = rows[2 * i + 1];
         const uint32_t w[8] = { a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w };
         gsm::PackOut o;
         gsm::pack_row(w, pow10tab, o);
-        center_scale[i] = make_float4(o.cs[0], o.cs[1], o.cs[2], o.cs[3]);
-        cov_color[i] = make_uint4(o.cc[0], o.cc[1], o.cc[2], o.cc[3]);
+        splat[2 * i] = make_uint4(__float_as_uint(o.cs[0]), __float_as_uint(o.cs[1]), __float_as_uint(o.cs[2]), __float_as_uint(o.cs[3]));
+        splat[2 * i + 1] = make_uint4(o.cc[0], o.cc[1], o.cc[2], o.cc[3]);
         sort_rows[i] = make_float4(o.sort_row[0], o.sort_row[1], o.sort_row[2], o.sort_row[3]);
     }
 }
@@ -28,7 +27,7 @@ int gs_launch_pack(gs_ctx *ctx, const uint4 *rows_dev, size_t first, size_t nrow
     if (!nrows) return GS_OK;
     uint32_t g = gs_div_up(nrows, GS_BLOCK); if (g > 4096) g = 4096;
     hipLaunchKernelGGL(k_pack, dim3(g), dim3(GS_BLOCK), 0, ctx->stream, rows_dev, (uint32_t)nrows, ctx->pow10tab,
-                       ctx->center_scale + first, ctx->cov_color + first, ctx->sort_rows + first);
+                       ctx->splat + 2 * first, ctx->sort_rows + first);
     GS_HIP(hipGetLastError());
     return GS_OK;
 }

@@ -29,8 +29,8 @@ __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v, int lane)
 // total tiles-touched in spine[chunk] (first level of the pair-offset scan).
 // Splats whose bounding box spans more than 16 tile rows (few, but up to 68 rows each) are queued in LDS and their
 // exact per-row tile counts are summed by a whole wavefront (one lane per tile row).
-__global__ __launch_bounds__(GS_BLOCK) void k_project(const uint32_t *__restrict__ sorted, const float4 *__restrict__ center_scale,
-                                                      const uint4 *__restrict__ cov_color, GsFrameUniforms u,
+__global__ __launch_bounds__(GS_BLOCK) void k_project(const uint32_t *__restrict__ sorted, const uint4 *__restrict__ splat,
+                                                      GsFrameUniforms u,
                                                       gsm::Projected *__restrict__ proj, uint2 *__restrict__ rect,
                                                       uint32_t *__restrict__ tile_count, uint32_t *__restrict__ spine,
                                                       uint32_t *__restrict__ part_vis, const GsControl *ctl)
@@ -52,9 +52,8 @@ __global__ __launch_bounds__(GS_BLOCK) void k_project(const uint32_t *__restrict
             bool queued = false;
             if (j < V) {
                 const uint32_t idx = sorted[j];
-                const float4 cs4 = center_scale[idx];
-                const uint4 cc4 = cov_color[idx];
-                const float cs[4] = { cs4.x, cs4.y, cs4.z, cs4.w };
+                const uint4 cs4 = splat[2 * (size_t)idx], cc4 = splat[2 * (size_t)idx + 1];   // one 32-byte record, one line
+                const float cs[4] = { __uint_as_float(cs4.x), __uint_as_float(cs4.y), __uint_as_float(cs4.z), __uint_as_float(cs4.w) };
                 const uint32_t cc[4] = { cc4.x, cc4.y, cc4.z, cc4.w };
                 gsm::Projected p; gsm::ProjExtra x;
                 if (gsm::project_splat(cs, cc, u.mv, u.proj, u.focal, u.vw, u.vh, p, x)) {
@@ -394,7 +393,7 @@ int gs_run_render(gs_ctx *ctx, const GsFrameUniforms &u, uint8_t *device_out)
     if (u.flags & GS_RENDER_COUNT_FRAGS) GS_HIP(hipMemsetAsync(&ctx->ctl->n_frags, 0, sizeof(unsigned long long), st));
     if (Vmax && ctx->have_sort) {
         uint32_t g = gs_div_up(Vmax, GS_BLOCK); if (g > GS_MAX_PART) g = GS_MAX_PART;
-        hipLaunchKernelGGL(k_project, dim3(g), dim3(GS_BLOCK), 0, st, ctx->sorted, ctx->center_scale, ctx->cov_color, u, ctx->proj,
+        hipLaunchKernelGGL(k_project, dim3(g), dim3(GS_BLOCK), 0, st, ctx->sorted, ctx->splat, u, ctx->proj,
                            ctx->rect, ctx->tile_count, ctx->spine, ctx->part_vis, ctx->ctl);
         GS_HIP(hipGetLastError());
         GS_PROF_RECORD(ctx, 3);

@@ -45,12 +45,22 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = torch = None
-    if world > 1:
+    # N > 1: one process per GPU over RCCL.  GS_BENCH_TORCH=1 forces the same code path (torch stream, device strip
+    # tensor, RCCL gather) in a single process so it can be exercised on a 1-GPU box.
+    multi = world > 1 or os.environ.get("GS_BENCH_TORCH") == "1"
+    if multi:
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("NCCL_DEBUG", "WARN")        # keep RCCL's version banner off stdout (ONE JSON line)
+        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # a real (non-null) stream shared by torch, RCCL and the HIP library: the gather orders after the strip's
+        # kernels without any host round trip
+        stream = torch.cuda.Stream()
+        torch.cuda.set_stream(stream)
     capi = importlib.import_module(PKG + ".capi")
     synth = importlib.import_module(PKG + ".synth")
     mg = importlib.import_module(PKG + ".multigpu")
@@ -66,21 +76,20 @@ def main():
     cams = [synth.index_html_camera(W, H, 360.0 * i / ORBIT_FRAMES, capi=capi) for i in range(ORBIT_FRAMES)]
     params = [capi.make_params(c["gs_mv"], c["gs_proj"], W, H, x0=x0, x1=x1, focal_=c["focal"]) for c in cams]
     strip = gathered = None
-    if world > 1:
+    if multi:
         strip = torch.zeros(mg.strip_buffer_bytes(W, H, world), dtype=torch.uint8, device="cuda")   # tight H x sw x 4 rows at the front
         gathered = [torch.zeros_like(strip) for _ in range(world)] if rank == 0 else None
 
-    if world > 1:
-        # run the library on torch's current stream: the RCCL gather then orders after the strip's kernels
-        # without a host round trip
-        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    if multi:
+        assert stream.cuda_stream != 0
+        ctx.set_stream(stream.cuda_stream)
 
     def frame(i, flags=0):
         k = i % ORBIT_FRAMES
         ctx.sort(cams[k]["view"], want_indices=False)
         p = params[k]
         p.flags = flags
-        if world > 1:
+        if multi:
             ctx.render_device(p, strip.data_ptr())
             return mg.gather_strips(strip, W, H, dist, gathered)   # RCCL gather + row-major assembly on rank 0
         ctx.render_device(p, None)
@@ -88,7 +97,7 @@ def main():
 
     def sync():
         ctx.sync()                                           # collects status/statistics of the asynchronous frames
-        if world > 1:
+        if multi:
             torch.cuda.synchronize()
             dist.barrier()
             torch.cuda.synchronize()
@@ -99,7 +108,7 @@ def main():
     for k in frames_used:
         frame(k, capi.RENDER_COUNT_FRAGS)
         frags[k] = ctx.stats()["n_frags"]
-    if world > 1:
+    if multi:
         t = torch.tensor([frags[k] for k in frames_used], dtype=torch.int64, device="cuda")
         dist.all_reduce(t)
         frags = dict(zip(frames_used, t.tolist()))
@@ -122,7 +131,7 @@ def main():
     assert s["acc_frames"] == args.steps and s["prof_frames"] == args.steps, (s["acc_frames"], s["prof_frames"])
     stage = {"ms_sort": s["sum_ms_sort"], "ms_project": s["sum_ms_project"], "ms_bin": s["sum_ms_bin"], "ms_blend": s["sum_ms_blend"]}
     pairs, visible, sorted_n = s["acc_pairs"], s["acc_visible"], s["acc_sorted"]
-    if world > 1:
+    if multi:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -140,6 +149,13 @@ def main():
         # whole-frame algorithmic bytes (SURVEY.md 8d formula)
         V, Vp, I = sorted_n / K, visible / K, pairs / K
         frame_bytes = (16 * n_splats + 4 * V) + (Vp * 36 + V * 4 + Vp * 32) + (I * 20) + (I * 36 + 4 * sw * H)
+        traffic = None
+        try:                                                 # HBM bytes/launch of k_blend from the committed PMC passes
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_hbm_traffic.json")))
+            if world == 1 and n_splats == synth.N_TRAIN:
+                traffic = pmc["k_blend<false>"]["hbm_bytes"]
+        except Exception:
+            traffic = None
         out = {
             "metric": "frames/sec @1920x1080 (sort+project+bin+blend per frame, 1M-splat train.splat-shaped scene)",
             "value": round(fps, 3), "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
@@ -156,14 +172,16 @@ def main():
             "frame_hbm": {"algorithmic_bytes": round(frame_bytes), "achieved_GBps": round(frame_bytes * fps / 1e9, 1),
                           "frac_of_peak": round(frame_bytes * fps / 1e9 / HBM_PEAK_GBS, 5)},
             "roofline": {"kernel": "k_blend", "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                         "traffic_note": "HBM bytes/launch = 2*FETCH_SIZE + WRITE_SIZE from separate rocprofv3 --pmc passes "
+                                         "(profiles/r01_pmc_hbm_traffic.md); early termination reads far less than the algorithmic 36*I",
                          "bytes_per_launch": round(blend_bytes), "avg_launch_ms": round(blend_s * 1e3, 4)},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(rows, cams[args.warmup % ORBIT_FRAMES], synth)
         print(json.dumps(out), flush=True)
     ctx.close()
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
 
