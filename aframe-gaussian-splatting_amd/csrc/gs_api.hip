@@ -167,6 +167,7 @@ GS_API int gs_create(int device, gs_ctx **out)
     if (!ctx) { snprintf(g_create_err, sizeof g_create_err, "out of host memory"); return GS_E_OOM; }
     memset(ctx, 0, sizeof *ctx);
     ctx->device = device; ctx->renderable = true; ctx->t_eps = 1.0f / 4096.0f;
+    for (int i = 0; i < 4; i++) { char nm[16]; snprintf(nm, sizeof nm, "GS_DBG%d", i); const char *e = getenv(nm); ctx->dbg[i] = e ? atoi(e) : 0; }
 #define CREATE_HIP(call) do { hipError_t _e = (call); if (_e != hipSuccess) {                                              \
         snprintf(g_create_err, sizeof g_create_err, "%s failed: %s", #call, hipGetErrorString(_e)); gs_destroy(ctx);      \
         return GS_E_HIP; } } while (0)
@@ -314,7 +315,7 @@ static int fill_uniforms(gs_ctx *ctx, const gs_render_params *p, GsFrameUniforms
     u.focal = p->focal > 0 ? p->focal : (float)(((double)p->fb_height / 2.0) * fabs((double)p->projection[5]));
     u.tiles_x = (p->x1 - p->x0 + GS_TILE - 1) / GS_TILE; u.tiles_y = (p->fb_height + GS_TILE - 1) / GS_TILE;
     memcpy(u.bg, p->background, sizeof u.bg);
-    u.t_eps = ctx->t_eps; u.flags = p->flags;
+    u.t_eps = ctx->t_eps; u.flags = p->flags; u.dbg0 = ctx->dbg[0]; u.dbg1 = ctx->dbg[1];
     return GS_OK;
 }
 

@@ -268,26 +268,40 @@ GS_HD void splat_pixel_bounds(const Projected &p, const ProjExtra &x, float &xmi
 // xr/xl are the right/left roots of q = 4 and dy_r = -B*hw/C (= -dy_l) is the height of the rightmost point
 // (xr is concave, xl convex).  A convex shape meets each tile row in one contiguous run of tiles, so per-row
 // ranges give EXACTLY the set of tiles the ellipse touches instead of its bounding rectangle.
-struct EllipseRows { float A, B, D, dy_r, pad; };
+struct EllipseRows { float invA, B, D4A, D, dy_r, pad; };   // D4A = 4*A
+
+// The tile ranges only have to be (a) a superset of the true coverage -- guaranteed by `pad` -- and (b) the SAME
+// in the counting pass (k_project) and the writing pass (k_emit), which run this very code on the same stored
+// record.  They are not part of the pixel parity contract, so the 1-ulp hardware reciprocal / square root
+// (v_rcp_f32 / v_sqrt_f32, one instruction each) replace the ~15-instruction IEEE sequences here.
+#if defined(__HIP_DEVICE_COMPILE__)
+GS_HD float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+GS_HD float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+#else
+GS_HD float fast_rcp(float x) { return 1.0f / x; }
+GS_HD float fast_sqrt(float x) { return sqrtf(x); }
+#endif
 
 GS_HD void ellipse_rows_setup(const Projected &p, EllipseRows &e)
 {
-    e.A = p.ax * p.ax + p.bx * p.bx;
+    const float A = p.ax * p.ax + p.bx * p.bx;
     e.B = p.ax * p.ay + p.bx * p.by;
     const float C = p.ay * p.ay + p.by * p.by;
     const float cr = p.ax * p.by - p.ay * p.bx;
     e.D = cr * cr;
-    const float hw = 2.0f * sqrtf(C / e.D);
-    e.dy_r = -(e.B * hw) / C;
-    e.pad = 0.01f + 1.0e-4f * hw;
+    e.invA = fast_rcp(A);
+    e.D4A = 4.0f * A;
+    const float hw = 2.0f * fast_sqrt(C * fast_rcp(e.D));
+    e.dy_r = -(e.B * hw) * fast_rcp(C);
+    e.pad = 0.02f + 2.0e-4f * hw;
 }
 
 // x-interval (relative to the splat centre) covered inside the band dy in [ya, yb]
 GS_HD void ellipse_band_xrange(const EllipseRows &e, float ya, float yb, float &xmin, float &xmax)
 {
     const float dr = fminf(fmaxf(e.dy_r, ya), yb), dl = fminf(fmaxf(-e.dy_r, ya), yb);
-    xmax = (-e.B * dr + sqrtf(fmaxf(4.0f * e.A - e.D * dr * dr, 0.0f))) / e.A;
-    xmin = (-e.B * dl - sqrtf(fmaxf(4.0f * e.A - e.D * dl * dl, 0.0f))) / e.A;
+    xmax = (-e.B * dr + fast_sqrt(fmaxf(e.D4A - e.D * dr * dr, 0.0f))) * e.invA;
+    xmin = (-e.B * dl - fast_sqrt(fmaxf(e.D4A - e.D * dl * dl, 0.0f))) * e.invA;
 }
 
 // Tiles of image tile-row `ty` (rows 16*ty .. 16*ty+15, top-down) that the splat can touch inside the strip

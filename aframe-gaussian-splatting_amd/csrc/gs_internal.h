@@ -45,6 +45,7 @@ struct GsFrameUniforms {           // per-render constants, passed by value to k
     float bg[4];
     float t_eps;                   // early-out threshold on transmittance
     uint32_t flags;
+    int32_t dbg0, dbg1;            // experiment knobs (0 = default)
 };
 
 struct gs_ctx {
@@ -91,6 +92,7 @@ struct gs_ctx {
 
     // options / stats
     bool profile;
+    int dbg[4];                    // experiment knobs from env GS_DBG0..3 (0 = default behaviour)
     float t_eps;
     // profiling ring: GS_PROF_RING slots x 6 events (sort begin/end, render begin, after project, after binning, end)
     hipEvent_t *ring; uint8_t *ring_flags; uint32_t ring_head, ring_pending;

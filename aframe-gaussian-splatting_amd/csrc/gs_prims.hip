@@ -168,7 +168,9 @@ __global__ __launch_bounds__(GS_BLOCK) void k_radix_rowscan(uint32_t *__restrict
 // Stable scatter.  Item order inside a chunk: wave w owns items [w*512, w*512+512), processed in 8 rounds
 // of 64 consecutive items (lane = item % 64), so "earlier" == (wave, round, lane) lexicographic.
 // Rank among equal digits: in-round via ballot match (one ballot per digit bit), across rounds via a
-// wave-private LDS counter row, across waves via a 4-way prefix added to the chunk's offset in the digit run.
+// wave-private LDS counter row, across waves via a 4-way prefix.  The chunk is then REORDERED IN LDS into digit
+// order and written out slot by slot, so consecutive lanes store consecutive addresses inside each digit run
+// (runs of ~2048/bins items) instead of 64 unrelated 8-byte stores per instruction.
 // IN_PACKED: input is (key,val) uint2 records, else a key array whose value is the element index.
 // OUT_PACKED: output is (key,val) uint2 records (one 8-byte store per item), else the value alone (last pass).
 // zero_key: items whose key equals it store 0 as their value (value-only output): the depth sort uses this so that
@@ -178,8 +180,10 @@ __global__ __launch_bounds__(GS_BLOCK) void k_radix_scatter(const void *__restri
                                                             const uint32_t *n_ptr, int shift, int bits, uint32_t zero_key,
                                                             const uint32_t *__restrict__ hist_scanned, const uint32_t *__restrict__ totals)
 {
-    __shared__ uint32_t s_cnt[4][GS_RADIX_MAX_BINS];            // 8 KiB
-    __shared__ uint32_t s_dbase[GS_RADIX_MAX_BINS];             // start of every digit's output run
+    __shared__ uint32_t s_cnt[4][GS_RADIX_MAX_BINS];            // 8 KiB  per-wave digit counts -> local slot bases
+    __shared__ uint32_t s_dbase[GS_RADIX_MAX_BINS];             // start of every digit's output run (whole array)
+    __shared__ uint32_t s_gb[GS_RADIX_MAX_BINS];                // global position of local slot 0 of each digit (minus slot)
+    __shared__ uint2 s_kv[GS_CHUNK];                            // 16 KiB chunk in digit order
     __shared__ uint32_t s_wave[4];
     const uint32_t n = *n_ptr;
     const uint32_t nchunks = (n + GS_CHUNK - 1) / GS_CHUNK;
@@ -224,10 +228,23 @@ __global__ __launch_bounds__(GS_BLOCK) void k_radix_scatter(const void *__restri
             rank[r] = prev + before;
         }
         __syncthreads();
-        for (uint32_t d = threadIdx.x; d < nbins; d += GS_BLOCK) {
-            const uint32_t c0 = s_cnt[0][d], c1 = s_cnt[1][d], c2 = s_cnt[2][d];
-            const uint32_t base = s_dbase[d] + hist_scanned[d * nchunks + c];
-            s_cnt[0][d] = base; s_cnt[1][d] = base + c0; s_cnt[2][d] = base + c0 + c1; s_cnt[3][d] = base + c0 + c1 + c2;
+        {   // digit totals of the chunk -> local digit starts (exclusive scan over digits, 2 per thread)
+            const uint32_t d0 = threadIdx.x * 2;
+            uint32_t t0 = 0, t1 = 0;
+            if (d0 < nbins) t0 = s_cnt[0][d0] + s_cnt[1][d0] + s_cnt[2][d0] + s_cnt[3][d0];
+            if (d0 + 1 < nbins) t1 = s_cnt[0][d0 + 1] + s_cnt[1][d0 + 1] + s_cnt[2][d0 + 1] + s_cnt[3][d0 + 1];
+            uint32_t tot;
+            const uint32_t ex = block_excl_scan(t0 + t1, s_wave, &tot);      // (two barriers inside)
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                const uint32_t d = d0 + k;
+                if (d < nbins) {
+                    const uint32_t ls = k ? ex + t0 : ex;                    // local slot of the digit's first item
+                    const uint32_t c0 = s_cnt[0][d], c1 = s_cnt[1][d], c2 = s_cnt[2][d];
+                    s_cnt[0][d] = ls; s_cnt[1][d] = ls + c0; s_cnt[2][d] = ls + c0 + c1; s_cnt[3][d] = ls + c0 + c1 + c2;
+                    s_gb[d] = s_dbase[d] + hist_scanned[d * nchunks + c] - ls;
+                }
+            }
         }
         __syncthreads();
 #pragma unroll
@@ -235,9 +252,19 @@ __global__ __launch_bounds__(GS_BLOCK) void k_radix_scatter(const void *__restri
             const uint32_t i = c * GS_CHUNK + w * 512 + r * 64 + lane;
             if (i < n) {
                 const uint32_t d = (key[r] >> shift) & mask;
-                const uint32_t pos = s_cnt[w][d] + rank[r];
-                if (OUT_PACKED) reinterpret_cast<uint2 *>(out)[pos] = make_uint2(key[r], val[r]);
-                else reinterpret_cast<uint32_t *>(out)[pos] = key[r] == zero_key ? 0u : val[r];
+                s_kv[s_cnt[w][d] + rank[r]] = make_uint2(key[r], val[r]);
+            }
+        }
+        __syncthreads();
+        const uint32_t items = min((uint32_t)GS_CHUNK, n - c * GS_CHUNK);
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const uint32_t slot = r * GS_BLOCK + threadIdx.x;
+            if (slot < items) {
+                const uint2 kv = s_kv[slot];
+                const uint32_t pos = s_gb[(kv.x >> shift) & mask] + slot;
+                if (OUT_PACKED) reinterpret_cast<uint2 *>(out)[pos] = kv;
+                else reinterpret_cast<uint32_t *>(out)[pos] = kv.x == zero_key ? 0u : kv.y;
             }
         }
         __syncthreads();

@@ -188,7 +188,7 @@ __global__ __launch_bounds__(GS_BLOCK) void k_emit(const gsm::Projected *__restr
             for (int k = 0; k < 4; k++) { const uint32_t t = s_wave[k]; if (k < w) wbase += t; total += t; }
             uint32_t o = carry + wbase + inc - cnt;                  // this splat's first pair slot
             carry += total;
-            if (cnt >= GS_EMIT_BIG) {
+            if (cnt >= (u.dbg0 > 0 ? (uint32_t)u.dbg0 : GS_EMIT_BIG)) {
                 const uint32_t q = atomicAdd(&s_nbig, 1u);
                 s_big[q] = j; s_bigoff[q] = o;
             } else if (cnt) {
@@ -201,7 +201,7 @@ __global__ __launch_bounds__(GS_BLOCK) void k_emit(const gsm::Projected *__restr
                 for (uint32_t ty = rc.x >> 16; ty <= (rc.y >> 16); ty++) {
                     uint32_t t0, n;
                     gsm::splat_tile_row(p, e, (int)ty, u.H, u.x0, u.x1, t0, n);
-                    for (uint32_t k = 0; k < n; k++) pairs[o++] = make_uint2(ty * tiles_x + t0 + k, j);
+                    if (u.dbg1 != 1) for (uint32_t k = 0; k < n; k++) pairs[o++] = make_uint2(ty * tiles_x + t0 + k, j);
                 }
             }
             __syncthreads();
@@ -222,7 +222,7 @@ __global__ __launch_bounds__(GS_BLOCK) void k_emit(const gsm::Projected *__restr
                     if (ty <= ty1) gsm::splat_tile_row(p, e, (int)ty, u.H, u.x0, u.x1, t0, n);
                     const uint32_t rinc = wave_incl_scan_u32(n, lane);
                     uint32_t ob = base + rinc - n;
-                    for (uint32_t k = 0; k < n; k++) pairs[ob++] = make_uint2(ty * tiles_x + t0 + k, jb);
+                    if (u.dbg1 != 2) for (uint32_t k = 0; k < n; k++) pairs[ob++] = make_uint2(ty * tiles_x + t0 + k, jb);
                     base += __shfl(rinc, 63, 64);
                 }
             }
