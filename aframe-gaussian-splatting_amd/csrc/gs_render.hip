@@ -278,7 +278,7 @@ __global__ __launch_bounds__(64) void k_blend(const uint2 *__restrict__ tile_ran
                                               const gsm::Projected *__restrict__ proj, GsFrameUniforms u,
                                               uint8_t *__restrict__ out, GsControl *ctl)
 {
-    __shared__ float4 s_rec[2 * GS_BLEND_BATCH];                 // 4 KiB: one batch of projected records
+    __shared__ float4 s_rec[2 * GS_BLEND_BATCH + 2];             // 4 KiB: one batch of projected records (+1 inert slot)
     const uint32_t tile = blockIdx.x;
     const uint32_t tx = tile % (uint32_t)u.tiles_x, ty = tile / (uint32_t)u.tiles_x;
     const int lane = threadIdx.x;
@@ -310,38 +310,55 @@ __global__ __launch_bounds__(64) void k_blend(const uint2 *__restrict__ tile_ran
                 s_rec[2 * slot + 1] = src[1];
             }
         }
+        if (lane == 0 && (nb & 1)) {                               // pad an odd batch with a record no pixel can pass
+            s_rec[2 * nb] = make_float4(-1.0e9f, -1.0e9f, 1.0f, 1.0f);   // centre far away, a = (1,1): q ~ 1e18 > 4
+            s_rec[2 * nb + 1] = make_float4(1.0f, 1.0f, 0.0f, 0.0f);
+        }
         __syncthreads();
         if (fmaxf(fmaxf(qmA.x, qmA.y), fmaxf(qmB.x, qmB.y)) > 0.0f) {
-            for (uint32_t s = 0; s < nb; s++) {
-                const float4 a = s_rec[2 * s], b = s_rec[2 * s + 1];
-                const float dy = fy - a.y;
-                const float dyay = dy * a.w, dyby = dy * b.y;      // shared by the 4 pixels of the row
+            // Two splats per step: their coverage tests are independent, so the second one's LDS read + ~13-instruction
+            // dependent chain overlaps the first one's (the per-step latency, not issue bandwidth, bounds a tile that
+            // runs alone in the kernel's tail).  Blending is still applied strictly in list order.
+            for (uint32_t s = 0; s < nb; s += 2) {
+                const float4 a0 = s_rec[2 * s], b0 = s_rec[2 * s + 1];
+                const float4 a1 = s_rec[2 * s + 2], b1 = s_rec[2 * s + 3];     // slot nb holds an inert record when nb is odd
+                const float dy0 = fy - a0.y, dy1 = fy - a1.y;
+                const float dyay0 = dy0 * a0.w, dyby0 = dy0 * b0.y, dyay1 = dy1 * a1.w, dyby1 = dy1 * b1.y;
                 // |p|^2 of the interpolated vPosition, same expression tree per pixel as gsm::frag_power
-                const f2 dxA = fxA - a.x, dxB = fxB - a.x;
-                const f2 pxA = fma2(dxA, (f2)(a.z), (f2)(dyay)), pxB = fma2(dxB, (f2)(a.z), (f2)(dyay));
-                const f2 pyA = fma2(dxA, (f2)(b.x), (f2)(dyby)), pyB = fma2(dxB, (f2)(b.x), (f2)(dyby));
-                const f2 qA = fma2(pxA, pxA, pyA * pyA), qB = fma2(pxB, pxB, pyB * pyB);   // -A, index.js:171
-                const bool p0 = qA.x <= qmA.x, p1 = qA.y <= qmA.y, p2 = qB.x <= qmB.x, p3 = qB.y <= qmB.y;
-                if (p0 | p1 | p2 | p3) {                           // discard test, index.js:172
-                    const float alpha = b.w;
-                    const uint32_t rgba = __float_as_uint(b.z);
-                    // B = exp(A) * vColor.a (index.js:173); 0 for the pixels of this lane that the splat misses
-                    const f2 BA = { p0 ? __expf(-qA.x) * alpha : 0.0f, p1 ? __expf(-qA.y) * alpha : 0.0f };
-                    const f2 BB = { p2 ? __expf(-qB.x) * alpha : 0.0f, p3 ? __expf(-qB.y) * alpha : 0.0f };
-                    const f2 wA = BA * TA, wB = BB * TB;
-                    const f2 vA = wA * (1.0f / 255.0f), vB = wB * (1.0f / 255.0f);
-                    const float c0 = (float)(rgba & 0xFF), c1 = (float)((rgba >> 8) & 0xFF), c2 = (float)((rgba >> 16) & 0xFF);
-                    crA = fma2((f2)(c0), vA, crA); crB = fma2((f2)(c0), vB, crB);
-                    cgA = fma2((f2)(c1), vA, cgA); cgB = fma2((f2)(c1), vB, cgB);
-                    cbA = fma2((f2)(c2), vA, cbA); cbB = fma2((f2)(c2), vB, cbB);
-                    caA += wA; caB += wB;
-                    TA *= (1.0f - BA); TB *= (1.0f - BB);
-                    if (COUNT) nfr += (uint32_t)p0 + (uint32_t)p1 + (uint32_t)p2 + (uint32_t)p3;
-                    // a pixel stops taking fragments once its transmittance is below the threshold
-                    qmA.x = TA.x < t_eps ? -1.0f : qmA.x; qmA.y = TA.y < t_eps ? -1.0f : qmA.y;
-                    qmB.x = TB.x < t_eps ? -1.0f : qmB.x; qmB.y = TB.y < t_eps ? -1.0f : qmB.y;
-                    if (!(fmaxf(fmaxf(qmA.x, qmA.y), fmaxf(qmB.x, qmB.y)) > 0.0f)) break;
+                const f2 dxA0 = fxA - a0.x, dxB0 = fxB - a0.x, dxA1 = fxA - a1.x, dxB1 = fxB - a1.x;
+                const f2 pxA0 = fma2(dxA0, (f2)(a0.z), (f2)(dyay0)), pxB0 = fma2(dxB0, (f2)(a0.z), (f2)(dyay0));
+                const f2 pyA0 = fma2(dxA0, (f2)(b0.x), (f2)(dyby0)), pyB0 = fma2(dxB0, (f2)(b0.x), (f2)(dyby0));
+                const f2 pxA1 = fma2(dxA1, (f2)(a1.z), (f2)(dyay1)), pxB1 = fma2(dxB1, (f2)(a1.z), (f2)(dyay1));
+                const f2 pyA1 = fma2(dxA1, (f2)(b1.x), (f2)(dyby1)), pyB1 = fma2(dxB1, (f2)(b1.x), (f2)(dyby1));
+                const f2 qA0 = fma2(pxA0, pxA0, pyA0 * pyA0), qB0 = fma2(pxB0, pxB0, pyB0 * pyB0);   // -A, index.js:171
+                const f2 qA1 = fma2(pxA1, pxA1, pyA1 * pyA1), qB1 = fma2(pxB1, pxB1, pyB1 * pyB1);
+#define GS_BLEND_APPLY(qA, qB, bb)                                                                                     \
+                {                                                                                                      \
+                    const bool p0 = qA.x <= qmA.x, p1 = qA.y <= qmA.y, p2 = qB.x <= qmB.x, p3 = qB.y <= qmB.y;         \
+                    if (p0 | p1 | p2 | p3) {                           /* discard test, index.js:172 */                \
+                        const float alpha = bb.w;                                                                      \
+                        const uint32_t rgba = __float_as_uint(bb.z);                                                   \
+                        /* B = exp(A) * vColor.a (index.js:173); 0 for the pixels of this lane that the splat misses */ \
+                        const f2 BA = { p0 ? __expf(-qA.x) * alpha : 0.0f, p1 ? __expf(-qA.y) * alpha : 0.0f };        \
+                        const f2 BB = { p2 ? __expf(-qB.x) * alpha : 0.0f, p3 ? __expf(-qB.y) * alpha : 0.0f };        \
+                        const f2 wA = BA * TA, wB = BB * TB;                                                           \
+                        const f2 vA = wA * (1.0f / 255.0f), vB = wB * (1.0f / 255.0f);                                 \
+                        const float c0 = (float)(rgba & 0xFF), c1 = (float)((rgba >> 8) & 0xFF), c2 = (float)((rgba >> 16) & 0xFF); \
+                        crA = fma2((f2)(c0), vA, crA); crB = fma2((f2)(c0), vB, crB);                                  \
+                        cgA = fma2((f2)(c1), vA, cgA); cgB = fma2((f2)(c1), vB, cgB);                                  \
+                        cbA = fma2((f2)(c2), vA, cbA); cbB = fma2((f2)(c2), vB, cbB);                                  \
+                        caA += wA; caB += wB;                                                                          \
+                        TA *= (1.0f - BA); TB *= (1.0f - BB);                                                          \
+                        if (COUNT) nfr += (uint32_t)p0 + (uint32_t)p1 + (uint32_t)p2 + (uint32_t)p3;                   \
+                        /* a pixel stops taking fragments once its transmittance is below the threshold */           \
+                        qmA.x = TA.x < t_eps ? -1.0f : qmA.x; qmA.y = TA.y < t_eps ? -1.0f : qmA.y;                    \
+                        qmB.x = TB.x < t_eps ? -1.0f : qmB.x; qmB.y = TB.y < t_eps ? -1.0f : qmB.y;                    \
+                    }                                                                                                  \
                 }
+                GS_BLEND_APPLY(qA0, qB0, b0)
+                GS_BLEND_APPLY(qA1, qB1, b1)
+#undef GS_BLEND_APPLY
+                if (!(fmaxf(fmaxf(qmA.x, qmA.y), fmaxf(qmB.x, qmB.y)) > 0.0f)) break;
             }
         }
         end -= nb;
