@@ -466,6 +466,7 @@ GS_API int gs_download(gs_ctx *ctx, int which, void *out, size_t nbytes)
     case GS_BUF_SORTED: src = ctx->sorted; have = ctx->have_sort ? V * 4 : 0; break;
     case GS_BUF_PROJECTED: src = ctx->proj; have = ctx->have_sort ? V * 32 : 0; break;
     case GS_BUF_TILE_COUNT: src = ctx->tile_count; have = ctx->have_sort ? V * 4 : 0; break;
+    case 6: src = ctx->tile_range; have = ctx->tile_cap * 8; break;        // tile ranges (debugging)
     default: FAIL(GS_E_BADARG, "unknown buffer %d", which);
     }
     if (nbytes > have) FAIL(GS_E_BADARG, "buffer %d holds %zu bytes, %zu requested", which, have, nbytes);

@@ -113,10 +113,6 @@ struct gs_ctx {
 static inline uint32_t gs_div_up(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
 
 // ---- gs_prims.hip
-// Exclusive scan of n u32 (n read on the device: *n_ptr, or 2^bits * ceil(*n_ptr/GS_CHUNK) when bits>0).
-// `total_out` (device, optional) receives the grand total.
-int gs_launch_scan(gs_ctx *ctx, const uint32_t *in, uint32_t *out, const uint32_t *n_ptr, int hist_bits,
-                   uint32_t max_n, uint32_t *total_out);
 // One stable LSD radix pass over n = *n_ptr items on digit (key >> shift) & (2^bits-1).
 // in:  packed (key,val) uint2 records, or a plain key array whose value is the element index.
 // out: packed (key,val) uint2 records, or the values alone (final pass).

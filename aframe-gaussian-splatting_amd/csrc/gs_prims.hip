@@ -1,19 +1,12 @@
-// gs_prims.hip -- device-wide exclusive scan and stable LSD radix pass for gfx950 (wave64).
+// gs_prims.hip -- stable LSD radix pass for gfx950 (wave64): histogram, per-digit row scan, LDS-reordered scatter.
 //
-// Both primitives read their problem size from device memory (GsControl), so no stage of the frame
+// The kernels read their problem size from device memory (GsControl), so no stage of the frame
 // needs a host round trip.  They are HBM/L2-streaming kernels: 256-thread workgroups, 2048 items per
 // workgroup pass, 16-byte vector loads where the access pattern allows, LDS digit histograms, and
 // wavefront ballots for the stable in-wave rank (no MFMA: there is no contraction here).
 #include "gs_internal.h"
 
 namespace {
-
-__device__ __forceinline__ uint32_t problem_len(const uint32_t *n_ptr, int hist_bits)
-{
-    const uint32_t n = *n_ptr;
-    if (hist_bits <= 0) return n;
-    return ((n + GS_CHUNK - 1) / GS_CHUNK) << hist_bits;       // digit-major histogram table
-}
 
 __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane)
 {
@@ -38,82 +31,6 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *s_wave
     __syncthreads();
     *total = tot;
     return base + inc - v;
-}
-
-// ---------------------------------------------------------------- scan
-
-__global__ __launch_bounds__(GS_BLOCK) void k_scan_reduce(const uint32_t *__restrict__ in, uint32_t *__restrict__ spine,
-                                                          const uint32_t *n_ptr, int hist_bits)
-{
-    __shared__ uint32_t s_wave[4];
-    const uint32_t n = problem_len(n_ptr, hist_bits);
-    const uint32_t nchunks = (n + GS_CHUNK - 1) / GS_CHUNK;
-    for (uint32_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
-        const uint32_t base = c * GS_CHUNK + threadIdx.x * 8;
-        uint32_t s = 0;
-        if (base + 8 <= n) {
-            const uint4 a = *reinterpret_cast<const uint4 *>(in + base), b = *reinterpret_cast<const uint4 *>(in + base + 4);
-            s = a.x + a.y + a.z + a.w + b.x + b.y + b.z + b.w;
-        } else {
-            for (uint32_t k = 0; k < 8; k++) if (base + k < n) s += in[base + k];
-        }
-        uint32_t tot;
-        block_excl_scan(s, s_wave, &tot);
-        if (threadIdx.x == 0) spine[c] = tot;
-    }
-}
-
-__global__ __launch_bounds__(GS_BLOCK) void k_scan_spine(uint32_t *__restrict__ spine, const uint32_t *n_ptr, int hist_bits,
-                                                         uint32_t *total_out, uint32_t *total_out2)
-{
-    __shared__ uint32_t s_wave[4];
-    const uint32_t n = problem_len(n_ptr, hist_bits);
-    const uint32_t nsp = (n + GS_CHUNK - 1) / GS_CHUNK;
-    const uint32_t per = (nsp + GS_BLOCK - 1) / GS_BLOCK;
-    const uint32_t lo = min(threadIdx.x * per, nsp), hi = min(lo + per, nsp);
-    uint32_t s = 0;
-    for (uint32_t i = lo; i < hi; i++) s += spine[i];
-    uint32_t tot;
-    uint32_t run = block_excl_scan(s, s_wave, &tot);
-    for (uint32_t i = lo; i < hi; i++) { const uint32_t v = spine[i]; spine[i] = run; run += v; }
-    if (threadIdx.x == 0) {
-        if (total_out) *total_out = tot;
-        if (total_out2) *total_out2 = tot;
-    }
-}
-
-__global__ __launch_bounds__(GS_BLOCK) void k_scan_down(const uint32_t *in, uint32_t *out, const uint32_t *__restrict__ spine,
-                                                        const uint32_t *n_ptr, int hist_bits)
-{
-    __shared__ uint32_t s_wave[4];
-    const uint32_t n = problem_len(n_ptr, hist_bits);
-    const uint32_t nchunks = (n + GS_CHUNK - 1) / GS_CHUNK;
-    for (uint32_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
-        const uint32_t base = c * GS_CHUNK + threadIdx.x * 8;
-        uint32_t v[8];
-        if (base + 8 <= n) {
-            const uint4 a = *reinterpret_cast<const uint4 *>(in + base), b = *reinterpret_cast<const uint4 *>(in + base + 4);
-            v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
-        } else {
-#pragma unroll
-            for (uint32_t k = 0; k < 8; k++) v[k] = (base + k < n) ? in[base + k] : 0u;
-        }
-        uint32_t s = 0;
-#pragma unroll
-        for (int k = 0; k < 8; k++) s += v[k];
-        uint32_t tot;
-        uint32_t run = block_excl_scan(s, s_wave, &tot) + spine[c];
-        uint32_t o[8];
-#pragma unroll
-        for (int k = 0; k < 8; k++) { o[k] = run; run += v[k]; }
-        if (base + 8 <= n) {
-            *reinterpret_cast<uint4 *>(out + base) = make_uint4(o[0], o[1], o[2], o[3]);
-            *reinterpret_cast<uint4 *>(out + base + 4) = make_uint4(o[4], o[5], o[6], o[7]);
-        } else {
-#pragma unroll
-            for (uint32_t k = 0; k < 8; k++) if (base + k < n) out[base + k] = o[k];
-        }
-    }
 }
 
 // ---------------------------------------------------------------- radix pass
@@ -282,18 +199,6 @@ uint32_t grid_for(uint32_t max_items)
 }  // namespace
 
 uint32_t gs_radix_grid(uint32_t max_n) { return grid_for(max_n); }
-
-int gs_launch_scan(gs_ctx *ctx, const uint32_t *in, uint32_t *out, const uint32_t *n_ptr, int hist_bits, uint32_t max_n,
-                   uint32_t *total_out)
-{
-    const uint32_t g = grid_for(max_n);
-    hipLaunchKernelGGL(k_scan_reduce, dim3(g), dim3(GS_BLOCK), 0, ctx->stream, in, ctx->spine, n_ptr, hist_bits);
-    hipLaunchKernelGGL(k_scan_spine, dim3(1), dim3(GS_BLOCK), 0, ctx->stream, ctx->spine, n_ptr, hist_bits, total_out,
-                       &ctx->ctl->scan_total);
-    hipLaunchKernelGGL(k_scan_down, dim3(g), dim3(GS_BLOCK), 0, ctx->stream, in, out, ctx->spine, n_ptr, hist_bits);
-    GS_HIP(hipGetLastError());
-    return GS_OK;
-}
 
 int gs_launch_radix_pass(gs_ctx *ctx, const void *in, bool in_packed, void *out, bool out_packed, const uint32_t *n_ptr,
                          uint32_t max_n, int shift, int bits, bool have_hist, uint32_t zero_key)

@@ -295,11 +295,12 @@ __global__ __launch_bounds__(64) void k_blend(const uint2 *__restrict__ tile_ran
     f2 crA = { 0, 0 }, crB = { 0, 0 }, cgA = { 0, 0 }, cgB = { 0, 0 }, cbA = { 0, 0 }, cbB = { 0, 0 }, caA = { 0, 0 }, caB = { 0, 0 };
     f2 qmA = { (row_in && xb < u.x1) ? 4.0f : -1.0f, (row_in && xb + 1 < u.x1) ? 4.0f : -1.0f };
     f2 qmB = { (row_in && xb + 2 < u.x1) ? 4.0f : -1.0f, (row_in && xb + 3 < u.x1) ? 4.0f : -1.0f };
-    uint32_t nfr = 0;
+    uint32_t nfr = 0, dbg_steps = 0;
     const uint2 range = tile_range[tile];
 
     for (uint32_t end = range.y; end > range.x;) {
         const uint32_t nb = min((uint32_t)GS_BLEND_BATCH, end - range.x);
+        dbg_steps += nb;
 #pragma unroll
         for (int h = 0; h < GS_BLEND_BATCH / 64; h++) {            // nearest first: reverse the back-to-front list
             const uint32_t slot = h * 64 + lane;
@@ -393,6 +394,7 @@ __global__ __launch_bounds__(64) void k_blend(const uint2 *__restrict__ tile_ran
         for (int m = 32; m >= 1; m >>= 1) nfr += __shfl_xor(nfr, m, 64);
         if (lane == 0 && nfr) atomicAdd(&ctl->n_frags, (unsigned long long)nfr);
     }
+    if (u.dbg1 == 3 && lane == 0) const_cast<uint2 *>(tile_range)[tile] = make_uint2(dbg_steps, range.y - range.x);   // experiment: list entries staged vs list length
 }
 
 int bits_for(uint32_t n) { int b = 1; while ((1u << b) < n) b++; return b; }
