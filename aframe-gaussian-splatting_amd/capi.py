@@ -13,7 +13,7 @@ from . import build as _build
 GS_OK = 0
 E_BADARG, E_PLY_HEADER, E_PLY_PROP, E_HIP, E_OOM, E_NODEVICE, E_STATE, E_PLY_DATA, E_RETRY = -1, -2, -3, -4, -5, -6, -7, -8, -9
 RENDER_FLIP_Y, RENDER_COUNT_FRAGS, RENDER_NO_EARLY_OUT, RENDER_ASYNC = 1, 2, 4, 8
-OPT_PROFILE, OPT_TERMINATION = 1, 2
+OPT_PROFILE, OPT_TERMINATION, OPT_NEAR_PERMILLE = 1, 2, 3
 BUF_CENTER_SCALE, BUF_COV_COLOR, BUF_SORT_ROWS, BUF_SORTED, BUF_PROJECTED, BUF_TILE_COUNT = 0, 1, 2, 3, 4, 5
 
 EXPORTS = [
@@ -35,7 +35,7 @@ class Stats(C.Structure):
                 ("ms_bin", C.c_float), ("ms_blend", C.c_float), ("ms_render", C.c_float), ("blend_launches", C.c_uint32),
                 ("prof_frames", C.c_uint32), ("sum_ms_sort", C.c_float), ("sum_ms_project", C.c_float), ("sum_ms_bin", C.c_float),
                 ("sum_ms_blend", C.c_float), ("acc_frames", C.c_uint64), ("acc_sorted", C.c_uint64), ("acc_visible", C.c_uint64),
-                ("acc_pairs", C.c_uint64)]
+                ("acc_pairs", C.c_uint64), ("unsat_tiles", C.c_uint32), ("near_permille", C.c_uint32)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

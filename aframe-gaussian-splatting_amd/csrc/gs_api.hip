@@ -89,7 +89,7 @@ hipEvent_t gs_prof_event(gs_ctx *ctx, int k)
     if (!ctx->profile || !ctx->ring) return nullptr;
     const uint32_t slot = ctx->ring_head % GS_PROF_RING;
     ctx->ring_flags[slot] |= (uint8_t)(1u << k);
-    return ctx->ring[slot * 6 + k];
+    return ctx->ring[slot * GS_PROF_EVENTS + k];
 }
 
 // fold the timings of every pending slot into the stats; the stream must be idle
@@ -97,14 +97,16 @@ static int prof_drain(gs_ctx *ctx)
 {
     for (; ctx->ring_pending; ctx->ring_pending--) {
         const uint32_t slot = (ctx->ring_head - ctx->ring_pending) % GS_PROF_RING;
-        hipEvent_t *e = ctx->ring + slot * 6;
+        hipEvent_t *e = ctx->ring + slot * GS_PROF_EVENTS;
         const uint8_t f = ctx->ring_flags[slot];
         ctx->ring_flags[slot] = 0;
         float ms;
         if ((f & 3) == 3) { GS_HIP(hipEventElapsedTime(&ms, e[0], e[1])); ctx->stats.ms_sort = ms; ctx->stats.sum_ms_sort += ms; }
-        if ((f & 0x3C) == 0x3C) {
-            float a, b, d;
+        if ((f & 0x7C) == 0x7C) {
+            float a, b, d, r1;
             GS_HIP(hipEventElapsedTime(&a, e[2], e[3])); GS_HIP(hipEventElapsedTime(&b, e[3], e[4])); GS_HIP(hipEventElapsedTime(&d, e[4], e[5]));
+            GS_HIP(hipEventElapsedTime(&r1, e[5], e[6]));
+            b += r1;                                       // round 1 (binning against the unsaturated tiles + their blend)
             ctx->stats.ms_project = a; ctx->stats.ms_bin = b; ctx->stats.ms_blend = d; ctx->stats.ms_render = a + b + d;
             ctx->stats.sum_ms_project += a; ctx->stats.sum_ms_bin += b; ctx->stats.sum_ms_blend += d;
             ctx->stats.prof_frames++;
@@ -129,9 +131,36 @@ static int prof_advance(gs_ctx *ctx)
 static int collect_status(gs_ctx *ctx, bool *overflowed)
 {
     const GsControl *c = ctx->ctl_host;
-    ctx->stats.n_sorted = c->n_kept; ctx->stats.n_visible = c->n_visible; ctx->stats.n_pairs = c->n_pairs;
+    ctx->stats.n_sorted = c->n_kept; ctx->stats.n_visible = c->n_visible; ctx->stats.n_pairs = c->n_pairs_frame;
     ctx->stats.acc_frames = c->acc_frames; ctx->stats.acc_sorted = c->acc_sorted; ctx->stats.acc_visible = c->acc_visible;
     ctx->stats.acc_pairs = c->acc_pairs;
+    // Adapt the share of splats binned in round 0.  An "event" = a frame whose round 0 left tiles unsaturated (round 1
+    // re-binned for them): the share grows x1.5 and will never again shrink below 1.3 x the share that failed; without
+    // events it shrinks 2 % per collected frame.  After 16 clean frames round 1 is not even launched (11 empty kernels
+    // cost ~50 us): blend<0> raises round1_missed if that was wrong, and the frame is completed / re-rendered.
+    if (ctx->near_fixed_permille <= 0 && ctx->stats.n_tiles) {
+        const uint32_t events = c->unsat_events - ctx->seen_unsat_events;
+        const uint64_t frames = c->acc_frames >= ctx->seen_acc_frames ? c->acc_frames - ctx->seen_acc_frames : 1;
+        ctx->seen_unsat_events = c->unsat_events; ctx->seen_acc_frames = c->acc_frames;
+        if (ctx->last_two_rounds) {
+            if (events || c->round1_missed) {
+                const float fl = ctx->near_frac * 1.3f > 1.0f ? 1.0f : ctx->near_frac * 1.3f;
+                if (fl > ctx->near_floor) ctx->near_floor = fl;
+                float nf = ctx->near_frac * 1.5f; if (nf < ctx->near_floor) nf = ctx->near_floor; if (nf > 1.0f) nf = 1.0f;
+                ctx->near_frac = nf; ctx->clean_frames = 0; ctx->skip_hold = 32;
+            } else {
+                ctx->clean_frames += (uint32_t)(frames ? frames : 1);
+                float nf = ctx->near_frac * 0.98f; if (nf < ctx->near_floor) nf = ctx->near_floor; if (nf < 0.05f) nf = 0.05f;
+                if (nf < ctx->near_frac) ctx->near_frac = nf;
+                if (ctx->skip_hold) ctx->skip_hold--;
+            }
+            ctx->single_round_frames = 0;
+        } else if (ctx->near_frac >= 1.0f && ++ctx->single_round_frames >= 64) {
+            ctx->near_frac = 0.5f; ctx->near_floor = 0.0f; ctx->single_round_frames = 0; ctx->clean_frames = 0;
+        }
+    }
+    ctx->stats.unsat_tiles = ctx->last_two_rounds ? c->unsat_round0 : 0;
+    ctx->stats.near_permille = (uint32_t)(ctx->near_frac * 1000.0f + 0.5f);
     *overflowed = c->overflow_sticky != 0;
     if (*overflowed) {
         const size_t need = (size_t)c->max_total + c->max_total / 4 + 1;
@@ -166,7 +195,7 @@ GS_API int gs_create(int device, gs_ctx **out)
     gs_ctx *ctx = new (std::nothrow) gs_ctx();
     if (!ctx) { snprintf(g_create_err, sizeof g_create_err, "out of host memory"); return GS_E_OOM; }
     memset(ctx, 0, sizeof *ctx);
-    ctx->device = device; ctx->renderable = true; ctx->t_eps = 1.0f / 4096.0f;
+    ctx->device = device; ctx->renderable = true; ctx->t_eps = 1.0f / 4096.0f; ctx->near_frac = 0.25f;
     for (int i = 0; i < 4; i++) { char nm[16]; snprintf(nm, sizeof nm, "GS_DBG%d", i); const char *e = getenv(nm); ctx->dbg[i] = e ? atoi(e) : 0; }
 #define CREATE_HIP(call) do { hipError_t _e = (call); if (_e != hipSuccess) {                                              \
         snprintf(g_create_err, sizeof g_create_err, "%s failed: %s", #call, hipGetErrorString(_e)); gs_destroy(ctx);      \
@@ -204,10 +233,10 @@ GS_API int gs_destroy(gs_ctx *ctx)
     dev_free(ctx->hist); dev_free(ctx->spine);
     dev_free(ctx->proj); dev_free(ctx->rect); dev_free(ctx->tile_count);
     dev_free(ctx->pair_a); dev_free(ctx->pair_b);
-    dev_free(ctx->tile_range); dev_free(ctx->fb); dev_free(ctx->ctl);
+    dev_free(ctx->tile_range); dev_free(ctx->fb); dev_free(ctx->ctl); dev_free(ctx->state); dev_free(ctx->unsat_mask);
     dev_free(ctx->part_min); dev_free(ctx->part_max); dev_free(ctx->part_cnt); dev_free(ctx->part_valid); dev_free(ctx->part_vis);
     if (ctx->ctl_host) (void)hipHostFree(ctx->ctl_host);
-    if (ctx->ring) { for (int i = 0; i < GS_PROF_RING * 6; i++) if (ctx->ring[i]) (void)hipEventDestroy(ctx->ring[i]); free(ctx->ring); }
+    if (ctx->ring) { for (int i = 0; i < GS_PROF_RING * GS_PROF_EVENTS; i++) if (ctx->ring[i]) (void)hipEventDestroy(ctx->ring[i]); free(ctx->ring); }
     free(ctx->ring_flags);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -316,6 +345,12 @@ static int fill_uniforms(gs_ctx *ctx, const gs_render_params *p, GsFrameUniforms
     u.tiles_x = (p->x1 - p->x0 + GS_TILE - 1) / GS_TILE; u.tiles_y = (p->fb_height + GS_TILE - 1) / GS_TILE;
     memcpy(u.bg, p->background, sizeof u.bg);
     u.t_eps = ctx->t_eps; u.flags = p->flags; u.dbg0 = ctx->dbg[0]; u.dbg1 = ctx->dbg[1];
+    u.mask_words = (uint32_t)(u.tiles_x + 31) / 32;
+    // round 0 covers the nearest near_frac * N splats; counting / no-early-out renders need every fragment -> one round
+    const float frac = ctx->near_fixed_permille > 0 ? ctx->near_fixed_permille / 1000.0f : ctx->near_frac;
+    if ((p->flags & (GS_RENDER_COUNT_FRAGS | GS_RENDER_NO_EARLY_OUT)) || frac >= 1.0f) u.near_count = 0xFFFFFFFFu;
+    else { const double nc = ceil((double)frac * (double)ctx->n); u.near_count = nc < 1 ? 1u : (uint32_t)nc; }
+    u.skip_round1 = (u.near_count != 0xFFFFFFFFu && ctx->near_fixed_permille <= 0 && ctx->clean_frames >= 16 && !ctx->skip_hold) ? 1u : 0u;
     return GS_OK;
 }
 
@@ -330,7 +365,11 @@ static int render_common(gs_ctx *ctx, const gs_render_params *p, void *device_rg
     if (ntiles > ctx->tile_cap) { dev_free(ctx->tile_range); TRY(dev_alloc(ctx, &ctx->tile_range, ntiles)); ctx->tile_cap = ntiles; }
     if (!device_rgba && fb_bytes > ctx->fb_cap) { dev_free(ctx->fb); TRY(dev_alloc(ctx, &ctx->fb, fb_bytes)); ctx->fb_cap = fb_bytes; }
     if (!ctx->pair_cap) TRY(gs_ensure_pair_capacity(ctx, (size_t)1 << 22));
+    const size_t mask_total = (size_t)u.tiles_y * u.mask_words;
+    if (mask_total > ctx->mask_cap) { dev_free(ctx->unsat_mask); TRY(dev_alloc(ctx, &ctx->unsat_mask, mask_total)); ctx->mask_cap = mask_total; }
+    if (ntiles * 320 > ctx->state_cap) { dev_free(ctx->state); TRY(dev_alloc(ctx, &ctx->state, ntiles * 320)); ctx->state_cap = ntiles * 320; }
     const bool async = (u.flags & GS_RENDER_ASYNC) && !host_rgba && !(u.flags & GS_RENDER_COUNT_FRAGS);
+    ctx->last_two_rounds = u.near_count != 0xFFFFFFFFu && ctx->n && ctx->have_sort;
     ctx->stats.n_tiles = ntiles; ctx->stats.blend_launches = 1;
     if (async) {
         // pipelined frame: enqueue, stage the control block for gs_sync(), return.  An overflowing frame shows the
@@ -345,6 +384,14 @@ static int render_common(gs_ctx *ctx, const gs_render_params *p, void *device_rg
         GS_HIP(hipMemcpyAsync(ctx->ctl_host, ctx->ctl, sizeof(GsControl), hipMemcpyDeviceToHost, ctx->stream));
         GS_HIP(hipStreamSynchronize(ctx->stream));
         if (ctx->profile && ctx->ring) { ctx->ring_head++; ctx->ring_pending++; TRY(prof_drain(ctx)); }
+        if (ctx->ctl_host->round1_missed) {
+            // round 1 was skipped but a tile did not saturate: its mask bit and per-pixel state are intact -- finish it now
+            GS_HIP(hipMemsetAsync(&ctx->ctl->round1_missed, 0, sizeof(uint32_t), ctx->stream));
+            TRY(gs_run_round1(ctx, u, (uint8_t *)device_rgba));
+            GS_HIP(hipMemcpyAsync(ctx->ctl_host, ctx->ctl, sizeof(GsControl), hipMemcpyDeviceToHost, ctx->stream));
+            GS_HIP(hipStreamSynchronize(ctx->stream));
+            ctx->ctl_host->round1_missed = 1;                      // seen by the adaptation below
+        }
         bool over = false;
         TRY(collect_status(ctx, &over));
         if (!over) break;
@@ -390,8 +437,12 @@ GS_API int gs_sync(gs_ctx *ctx)
     TRY(prof_drain(ctx));
     if (ctx->async_pending) {
         ctx->async_pending = false;
+        const bool missed = ctx->ctl_host->round1_missed != 0;
+        if (missed) GS_HIP(hipMemsetAsync(&ctx->ctl->round1_missed, 0, sizeof(uint32_t), ctx->stream));
         bool over = false;
         TRY(collect_status(ctx, &over));
+        if (missed) FAIL(GS_E_RETRY, "an asynchronous frame skipped its second binning round but a tile had not saturated; "
+                                     "the share of splats binned first was raised - render the frames since the previous gs_sync() again");
         if (over) FAIL(GS_E_RETRY, "an asynchronous frame needed %u pairs and overflowed the pair buffers; they were enlarged - "
                                    "render the frames since the previous gs_sync() again", ctx->ctl_host->max_total);
     }
@@ -418,10 +469,10 @@ GS_API int gs_set_option(gs_ctx *ctx, int option, int64_t value)
         GS_HIP(hipStreamSynchronize(ctx->stream));
         TRY(prof_drain(ctx));
         if (value && !ctx->ring) {
-            ctx->ring = (hipEvent_t *)calloc(GS_PROF_RING * 6, sizeof(hipEvent_t));
+            ctx->ring = (hipEvent_t *)calloc(GS_PROF_RING * GS_PROF_EVENTS, sizeof(hipEvent_t));
             ctx->ring_flags = (uint8_t *)calloc(GS_PROF_RING, 1);
             if (!ctx->ring || !ctx->ring_flags) FAIL(GS_E_OOM, "out of host memory");
-            for (int i = 0; i < GS_PROF_RING * 6; i++) GS_HIP(hipEventCreate(&ctx->ring[i]));
+            for (int i = 0; i < GS_PROF_RING * GS_PROF_EVENTS; i++) GS_HIP(hipEventCreate(&ctx->ring[i]));
         }
         if (value && !ctx->profile) {                    // (re)start accumulation
             ctx->stats.prof_frames = 0;
@@ -429,6 +480,11 @@ GS_API int gs_set_option(gs_ctx *ctx, int option, int64_t value)
             GS_HIP(hipMemsetAsync(&ctx->ctl->acc_frames, 0, sizeof(GsControl) - offsetof(GsControl, acc_frames), ctx->stream));
         }
         ctx->profile = value != 0;
+        return GS_OK;
+    case GS_OPT_NEAR_PERMILLE:
+        if (value < 0 || value > 1000) FAIL(GS_E_BADARG, "near permille must be 0 (adaptive) .. 1000 (single round)");
+        ctx->near_fixed_permille = (int)value;
+        if (value == 0) ctx->near_frac = 0.25f;
         return GS_OK;
     case GS_OPT_TERMINATION:
         if (value < 2) FAIL(GS_E_BADARG, "termination 1/eps must be >= 2");

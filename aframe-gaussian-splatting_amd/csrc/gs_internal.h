@@ -13,6 +13,7 @@
 #define GS_CHUNK 2048              // items per workgroup pass in streaming kernels (8 per thread)
 #define GS_RADIX_MAX_BINS 512      // up to 9-bit digits (depth key = 17 bits = 8 + 9)
 #define GS_PROF_RING 256           // frames of HIP-event timings kept in flight
+#define GS_PROF_EVENTS 7
 #define GS_MAX_PART 8192           // upper bound on the grid of any kernel that writes per-workgroup partials
 #define GS_CULLED_KEY 65536u       // depth-sort key of culled / dropped splats (sorts behind every bucket)
 
@@ -30,7 +31,14 @@ struct GsControl {
     uint32_t pair_overflow;        // set when I exceeded the pair capacity (pairs clamped to 0)
     uint32_t scan_total;           // scratch: total of the last scan
     uint32_t overflow_sticky;      // like pair_overflow but only ever cleared by the host (asynchronous frames)
-    uint32_t max_total;            // largest I seen since the host last cleared it
+    uint32_t max_total;            // largest per-FRAME pair demand (sum over rounds) seen since the host last cleared it
+    uint32_t j_lo, j_hi;           // sorted-position range of the current binning round
+    uint32_t unsat_count;          // tiles left unsaturated by round 0 (counted by its blend)
+    uint32_t unsat_round0;         // copy taken when round 1 begins (what the host adapts near_count on)
+    uint32_t n_pairs_frame;        // I summed over the rounds of the frame
+    uint32_t want_frame;           // pair demand of the frame so far (counts rounds that overflowed, too)
+    uint32_t unsat_events;         // frames whose round 0 left tiles unsaturated (monotonic)
+    uint32_t round1_missed;        // sticky: round 1 was skipped optimistically but a tile needed it (host clears)
     uint32_t acc_frames;           // frames rendered since profiling was switched on
     unsigned long long acc_sorted, acc_visible, acc_pairs;   // sums of V, Vp, I over those frames
 };
@@ -46,6 +54,9 @@ struct GsFrameUniforms {           // per-render constants, passed by value to k
     float t_eps;                   // early-out threshold on transmittance
     uint32_t flags;
     int32_t dbg0, dbg1;            // experiment knobs (0 = default)
+    uint32_t near_count;           // round 0 bins the nearest near_count splats; 0xFFFFFFFF = single round (everything)
+    uint32_t mask_words;           // 32-bit words per tile row of the unsaturated-tile mask
+    uint32_t skip_round1;          // round 1 is not launched for this frame (optimistic; blend<0> raises round1_missed)
 };
 
 struct gs_ctx {
@@ -84,6 +95,16 @@ struct gs_ctx {
     uint2 *pair_a, *pair_b; size_t pair_cap;   // (tile id, sorted position) records, ping-pong
     uint2 *tile_range; size_t tile_cap;     // per tile [start,end) into the sorted pair list
     uint8_t *fb; size_t fb_cap;             // RGBA8 strip
+    float4 *state; size_t state_cap;        // per tile 64 lanes x 5 float4: (T, r, g, b, a) of each lane's 4 pixels, round 0 -> 1
+    uint32_t *unsat_mask; size_t mask_cap;  // one bit per tile (rows of mask_words words): left unsaturated by round 0
+    float near_frac;                        // round 0 covers the nearest near_frac * N splats (adapted from unsat_round0)
+    int near_fixed_permille;                // > 0: fixed by GS_OPT_NEAR_PERMILLE instead of adapted
+    bool last_two_rounds;                   // the last enqueued frame ran the two-round path (its unsat count is meaningful)
+    float near_floor;                       // never shrink the share below this (1.3 x the share that last proved too small)
+    uint32_t clean_frames, skip_hold;       // collected frames since the last unsaturated one / frames to keep round 1 on
+    uint32_t seen_unsat_events; uint64_t seen_acc_frames;
+    GsFrameUniforms *last_u;                // uniforms of the last enqueued frame (to run a skipped round 1 after the fact)
+    uint32_t single_round_frames;           // consecutive collected frames at near_frac == 1 (re-probe occlusion now and then)
     // per-workgroup partial reductions (instead of same-address global atomics, which serialise at ~11 ns each)
     unsigned long long *part_min, *part_max;   // [GS_MAX_PART]
     uint32_t *part_cnt, *part_valid, *part_vis; // [GS_MAX_PART]
@@ -94,7 +115,8 @@ struct gs_ctx {
     bool profile;
     int dbg[4];                    // experiment knobs from env GS_DBG0..3 (0 = default behaviour)
     float t_eps;
-    // profiling ring: GS_PROF_RING slots x 6 events (sort begin/end, render begin, after project, after binning, end)
+    // profiling ring: GS_PROF_RING slots x GS_PROF_EVENTS events (sort begin/end, render begin, after project, after
+    // binning, after blend of round 0, end of round 1)
     hipEvent_t *ring; uint8_t *ring_flags; uint32_t ring_head, ring_pending;
     bool async_pending;            // frames were enqueued with GS_RENDER_ASYNC since the last gs_sync
     gs_stats stats;
@@ -128,8 +150,9 @@ int gs_launch_pack(gs_ctx *ctx, const uint4 *rows_dev, size_t first, size_t nrow
 int gs_run_sort(gs_ctx *ctx, const float view[4], const float *cutout16);
 // ---- gs_render.hip
 int gs_run_render(gs_ctx *ctx, const GsFrameUniforms &u, uint8_t *device_out);
+int gs_run_round1(gs_ctx *ctx, const GsFrameUniforms &u, uint8_t *device_out);
 // ---- gs_api.hip
 int gs_ensure_pair_capacity(gs_ctx *ctx, size_t pairs);
-// event k (0..5) of the current profiling slot, or nullptr when profiling is off
+// event k (0..GS_PROF_EVENTS-1) of the current profiling slot, or nullptr when profiling is off
 hipEvent_t gs_prof_event(gs_ctx *ctx, int k);
 #define GS_PROF_RECORD(ctx, k) do { hipEvent_t _pev = gs_prof_event(ctx, k); if (_pev) GS_HIP(hipEventRecord(_pev, (ctx)->stream)); } while (0)

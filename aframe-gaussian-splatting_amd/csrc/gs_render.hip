@@ -1,16 +1,25 @@
 // gs_render.hip -- the GPU half of the reference (vertex shader index.js:77-165, rasteriser, fragment shader
 // index.js:166-176, blend state index.js:177-181) as a tile-binned HIP pipeline:
 //
-//   k_project      one thread per SORTED splat (not 6 like the instanced quad): gather the two 16 B records,
-//                  Sigma' = (J W) Sigma (J W)^T, eigen axes, conservative tile rectangle         [HBM gather]
-//   scan           exclusive prefix sum of tiles-touched -> pair offsets, total I               [gs_prims]
-//   k_emit         (tile id, sorted position) pairs in splat order
-//   radix x2       stable sort of the pairs by tile id only: the input is already in depth order, so each
+//   k_project      one thread per SORTED splat (not 6 like the instanced quad): gather one 32 B record,
+//                  Sigma' = (J W) Sigma (J W)^T, eigen axes, EXACT per-tile-row coverage count   [HBM gather]
+//   k_pairs_check  spine scan of tiles-touched -> chunk offsets, total I
+//   k_emit         (tile id, sorted position) records in splat order
+//   radix x2       stable sort of the records by tile id only: the input is already in depth order, so each
 //                  tile's list inherits the reference's draw order with no depth key            [gs_prims]
-//   k_tile_ranges  [start,end) of every tile in the sorted pair list
+//   k_tile_ranges  [start,end) of every tile in the sorted list
 //   k_blend        one wavefront per 16x16 tile, 4 pixels per lane, LDS-staged batches of projected records,
 //                  FRONT-to-back traversal (reverse of the back-to-front list) with per-pixel transmittance
 //                  accumulators and wave-wide early termination; one rounding to RGBA8 at the end.
+//
+// Occlusion-aware binning in two rounds.  Front-to-back blending stops a pixel at T < eps, so whatever lies behind a
+// saturated tile is never read -- in the benchmark scene 81 % of the (tile, splat) records.  Round 0 therefore bins
+// and blends only the NEAREST `near_count` splats of the sorted order; tiles in which every pixel terminated are
+// final.  Tiles that did not saturate keep their exact fp32 per-pixel state (T, premultiplied RGBA) and set a bit in
+// a tile mask; round 1 bins the remaining (farther) splats against the masked tiles only and continues those tiles
+// from the saved state.  The arithmetic per pixel is the same sequence of operations as a single pass, so the
+// result is bit-identical; only work that could not contribute is skipped.  When no tile is left unsaturated the
+// kernels of round 1 find an empty range and return at once.
 //
 // The fixed-function rasteriser + ROP of the reference have no structural counterpart; parity is defined at
 // the pixel level against oracle/gs_oracle.c (DESIGN.md "Pixel parity").
@@ -25,95 +34,127 @@ __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v, int lane)
     return v;
 }
 
+// bits [t0, t0+n) of one row of the unsaturated-tile mask
+__device__ __forceinline__ uint32_t mask_bits(const uint32_t *__restrict__ row, uint32_t word, uint32_t t0, uint32_t n)
+{
+    const uint32_t lo = word * 32u, hi = lo + 32u;
+    const uint32_t a = max(t0, lo), b = min(t0 + n, hi);
+    if (a >= b) return 0u;
+    const uint32_t span = b - a;
+    const uint32_t m = (span == 32u ? 0xFFFFFFFFu : ((1u << span) - 1u)) << (a - lo);
+    return row[word] & m;
+}
+__device__ __forceinline__ uint32_t mask_count(const uint32_t *__restrict__ row, uint32_t t0, uint32_t n)
+{
+    uint32_t c = 0;
+    for (uint32_t w = t0 >> 5; w <= ((t0 + n - 1) >> 5); w++) c += __popc(mask_bits(row, w, t0, n));
+    return c;
+}
+
+// Sorted-position range [lo, hi) of a round.  Round 0: the nearest `near_count` splats (the sorted order is
+// far -> near, so they are its tail).  Round 1: everything farther, or nothing if every tile saturated in round 0
+// (ctl->unsat_count is final once round 0's blend has completed).
+template <int ROUND>
+__device__ __forceinline__ void round_range(const GsControl *ctl, uint32_t near_count, uint32_t &lo, uint32_t &hi)
+{
+    const uint32_t V = ctl->n_kept;
+    const uint32_t nn = min(V, near_count);
+    if (ROUND == 0) { lo = V - nn; hi = V; }
+    else if (ctl->unsat_count == 0 || nn == V) { lo = 0; hi = 0; }
+    else { lo = 0; hi = V - nn; }
+}
+
 // Vertex-shader stage.  One thread per sorted splat, 256 splats per workgroup pass; the pass also leaves the chunk's
 // total tiles-touched in spine[chunk] (first level of the pair-offset scan).
 // Splats whose bounding box spans more than 16 tile rows (few, but up to 68 rows each) are queued in LDS and their
-// exact per-row tile counts are summed by a whole wavefront (one lane per tile row).
+// exact per-row tile counts are summed by a whole wavefront (one lane per tile row).  ROUND 1 counts only tiles whose
+// bit is set in the unsaturated-tile mask.
+template <int ROUND>
 __global__ __launch_bounds__(GS_BLOCK) void k_project(const uint32_t *__restrict__ sorted, const uint4 *__restrict__ splat,
-                                                      GsFrameUniforms u,
-                                                      gsm::Projected *__restrict__ proj, uint2 *__restrict__ rect,
+                                                      GsFrameUniforms u, gsm::Projected *__restrict__ proj, uint2 *__restrict__ rect,
                                                       uint32_t *__restrict__ tile_count, uint32_t *__restrict__ spine,
-                                                      uint32_t *__restrict__ part_vis, const GsControl *ctl)
+                                                      uint32_t *__restrict__ part_vis, const uint32_t *__restrict__ mask,
+                                                      const GsControl *ctl)
 {
     __shared__ float s_rec[GS_BLOCK][6];
     __shared__ uint32_t s_rows[GS_BLOCK], s_j[GS_BLOCK];
     __shared__ uint32_t s_nbig, s_vis, s_sum;
-    const uint32_t V = ctl->n_kept;
-    const uint32_t nchunks = (V + GS_BLOCK - 1) / GS_BLOCK;
+    uint32_t j_lo, j_hi;
+    round_range<ROUND>(ctl, u.near_count, j_lo, j_hi);
+    const uint32_t nchunks = (j_hi - j_lo + GS_BLOCK - 1) / GS_BLOCK;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     if (threadIdx.x == 0) s_vis = 0;
     for (uint32_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
-        if (threadIdx.x == 0) s_sum = 0;
-        {
-            if (threadIdx.x == 0) s_nbig = 0;
-            __syncthreads();
-            const uint32_t j = c * GS_BLOCK + threadIdx.x;
-            uint32_t count = 0;
-            bool queued = false;
-            if (j < V) {
-                const uint32_t idx = sorted[j];
-                const uint4 cs4 = splat[2 * (size_t)idx], cc4 = splat[2 * (size_t)idx + 1];   // one 32-byte record, one line
-                const float cs[4] = { __uint_as_float(cs4.x), __uint_as_float(cs4.y), __uint_as_float(cs4.z), __uint_as_float(cs4.w) };
-                const uint32_t cc[4] = { cc4.x, cc4.y, cc4.z, cc4.w };
-                gsm::Projected p; gsm::ProjExtra x;
-                if (gsm::project_splat(cs, cc, u.mv, u.proj, u.focal, u.vw, u.vh, p, x)) {
-                    float xmin, xmax, ymin, ymax;
-                    gsm::splat_pixel_bounds(p, x, xmin, xmax, ymin, ymax);
-                    // clamp in float (bounds can be far outside the int range), then to the strip / screen
-                    const float fx0 = fmaxf(xmin, (float)u.x0), fx1 = fminf(xmax, (float)(u.x1 - 1));
-                    const float fy0 = fmaxf(ymin, 0.0f), fy1 = fminf(ymax, (float)(u.H - 1));
-                    if (fx0 <= fx1 && fy0 <= fy1) {
-                        const int ix0 = (int)fx0, ix1 = (int)fx1, jy0 = (int)fy0, jy1 = (int)fy1;
-                        const int r0 = u.H - 1 - jy1, r1 = u.H - 1 - jy0;       // GL rows (y up) -> image rows (top-down)
-                        const uint32_t tx0 = (uint32_t)(ix0 - u.x0) / GS_TILE, tx1 = (uint32_t)(ix1 - u.x0) / GS_TILE;
-                        const uint32_t ty0 = (uint32_t)r0 / GS_TILE, ty1 = (uint32_t)r1 / GS_TILE;
-                        rect[j] = make_uint2(tx0 | (ty0 << 16), tx1 | (ty1 << 16));
-                        float4 *dst = reinterpret_cast<float4 *>(proj + j);
-                        dst[0] = make_float4(p.cx, p.cy, p.ax, p.ay);
-                        dst[1] = make_float4(p.bx, p.by, __uint_as_float(p.rgba), p.alpha);
-                        if (ty1 - ty0 >= 16) {                                  // > 16 tile rows: count cooperatively
-                            const uint32_t q = atomicAdd(&s_nbig, 1u);
-                            s_rec[q][0] = p.cx; s_rec[q][1] = p.cy; s_rec[q][2] = p.ax; s_rec[q][3] = p.ay; s_rec[q][4] = p.bx; s_rec[q][5] = p.by;
-                            s_rows[q] = ty0 | (ty1 << 16); s_j[q] = j;
-                            queued = true;
-                        } else {
-                            // exact coverage: per tile row, the contiguous run of tiles the ellipse touches
-                            gsm::EllipseRows e;
-                            gsm::ellipse_rows_setup(p, e);
-                            for (uint32_t ty = ty0; ty <= ty1; ty++) {
-                                uint32_t a, n;
-                                gsm::splat_tile_row(p, e, (int)ty, u.H, u.x0, u.x1, a, n);
-                                count += n;
-                            }
+        if (threadIdx.x == 0) { s_sum = 0; s_nbig = 0; }
+        __syncthreads();
+        const uint32_t j = j_lo + c * GS_BLOCK + threadIdx.x;
+        uint32_t count = 0;
+        bool queued = false;
+        if (j < j_hi) {
+            const uint32_t idx = sorted[j];
+            const uint4 cs4 = splat[2 * (size_t)idx], cc4 = splat[2 * (size_t)idx + 1];   // one 32-byte record, one line
+            const float cs[4] = { __uint_as_float(cs4.x), __uint_as_float(cs4.y), __uint_as_float(cs4.z), __uint_as_float(cs4.w) };
+            const uint32_t cc[4] = { cc4.x, cc4.y, cc4.z, cc4.w };
+            gsm::Projected p; gsm::ProjExtra x;
+            if (gsm::project_splat(cs, cc, u.mv, u.proj, u.focal, u.vw, u.vh, p, x)) {
+                float xmin, xmax, ymin, ymax;
+                gsm::splat_pixel_bounds(p, x, xmin, xmax, ymin, ymax);
+                // clamp in float (bounds can be far outside the int range), then to the strip / screen
+                const float fx0 = fmaxf(xmin, (float)u.x0), fx1 = fminf(xmax, (float)(u.x1 - 1));
+                const float fy0 = fmaxf(ymin, 0.0f), fy1 = fminf(ymax, (float)(u.H - 1));
+                if (fx0 <= fx1 && fy0 <= fy1) {
+                    const int ix0 = (int)fx0, ix1 = (int)fx1, jy0 = (int)fy0, jy1 = (int)fy1;
+                    const int r0 = u.H - 1 - jy1, r1 = u.H - 1 - jy0;       // GL rows (y up) -> image rows (top-down)
+                    const uint32_t tx0 = (uint32_t)(ix0 - u.x0) / GS_TILE, tx1 = (uint32_t)(ix1 - u.x0) / GS_TILE;
+                    const uint32_t ty0 = (uint32_t)r0 / GS_TILE, ty1 = (uint32_t)r1 / GS_TILE;
+                    rect[j] = make_uint2(tx0 | (ty0 << 16), tx1 | (ty1 << 16));
+                    float4 *dst = reinterpret_cast<float4 *>(proj + j);
+                    dst[0] = make_float4(p.cx, p.cy, p.ax, p.ay);
+                    dst[1] = make_float4(p.bx, p.by, __uint_as_float(p.rgba), p.alpha);
+                    if (ty1 - ty0 >= 16) {                                  // > 16 tile rows: count cooperatively
+                        const uint32_t q = atomicAdd(&s_nbig, 1u);
+                        s_rec[q][0] = p.cx; s_rec[q][1] = p.cy; s_rec[q][2] = p.ax; s_rec[q][3] = p.ay; s_rec[q][4] = p.bx; s_rec[q][5] = p.by;
+                        s_rows[q] = ty0 | (ty1 << 16); s_j[q] = j;
+                        queued = true;
+                    } else {
+                        // exact coverage: per tile row, the contiguous run of tiles the ellipse touches
+                        gsm::EllipseRows e;
+                        gsm::ellipse_rows_setup(p, e);
+                        for (uint32_t ty = ty0; ty <= ty1; ty++) {
+                            uint32_t a, n;
+                            gsm::splat_tile_row(p, e, (int)ty, u.H, u.x0, u.x1, a, n);
+                            if (ROUND == 1 && n) n = mask_count(mask + ty * u.mask_words, a, n);
+                            count += n;
                         }
                     }
                 }
-                if (!queued) tile_count[j] = count;
             }
-            uint32_t vis = count ? 1u : 0u, sum = count;
-            __syncthreads();
-            const uint32_t nbig = s_nbig;
-            for (uint32_t bi = w; bi < nbig; bi += 4) {               // one wavefront per queued splat
-                gsm::Projected p;
-                p.cx = s_rec[bi][0]; p.cy = s_rec[bi][1]; p.ax = s_rec[bi][2]; p.ay = s_rec[bi][3]; p.bx = s_rec[bi][4]; p.by = s_rec[bi][5];
-                gsm::EllipseRows e;
-                gsm::ellipse_rows_setup(p, e);
-                const uint32_t ty0 = s_rows[bi] & 0xFFFF, ty1 = s_rows[bi] >> 16;
-                uint32_t rsum = 0;
-                for (uint32_t ty = ty0 + lane; ty <= ty1; ty += 64) {
-                    uint32_t a, n;
-                    gsm::splat_tile_row(p, e, (int)ty, u.H, u.x0, u.x1, a, n);
-                    rsum += n;
-                }
-#pragma unroll
-                for (int m = 32; m >= 1; m >>= 1) rsum += __shfl_xor(rsum, m, 64);
-                if (lane == 0) { tile_count[s_j[bi]] = rsum; sum += rsum; if (rsum) vis++; }
-            }
-#pragma unroll
-            for (int m = 32; m >= 1; m >>= 1) { vis += __shfl_xor(vis, m, 64); sum += __shfl_xor(sum, m, 64); }
-            if (lane == 0) { if (vis) atomicAdd(&s_vis, vis); if (sum) atomicAdd(&s_sum, sum); }
-            __syncthreads();
+            if (!queued) tile_count[j] = count;
         }
+        uint32_t vis = count ? 1u : 0u, sum = count;
+        __syncthreads();
+        const uint32_t nbig = s_nbig;
+        for (uint32_t bi = w; bi < nbig; bi += 4) {                   // one wavefront per queued splat
+            gsm::Projected p;
+            p.cx = s_rec[bi][0]; p.cy = s_rec[bi][1]; p.ax = s_rec[bi][2]; p.ay = s_rec[bi][3]; p.bx = s_rec[bi][4]; p.by = s_rec[bi][5];
+            gsm::EllipseRows e;
+            gsm::ellipse_rows_setup(p, e);
+            const uint32_t ty0 = s_rows[bi] & 0xFFFF, ty1 = s_rows[bi] >> 16;
+            uint32_t rsum = 0;
+            for (uint32_t ty = ty0 + lane; ty <= ty1; ty += 64) {
+                uint32_t a, n;
+                gsm::splat_tile_row(p, e, (int)ty, u.H, u.x0, u.x1, a, n);
+                if (ROUND == 1 && n) n = mask_count(mask + ty * u.mask_words, a, n);
+                rsum += n;
+            }
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) rsum += __shfl_xor(rsum, m, 64);
+            if (lane == 0) { tile_count[s_j[bi]] = rsum; sum += rsum; if (rsum) vis++; }
+        }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) { vis += __shfl_xor(vis, m, 64); sum += __shfl_xor(sum, m, 64); }
+        if (lane == 0) { if (vis) atomicAdd(&s_vis, vis); if (sum) atomicAdd(&s_sum, sum); }
+        __syncthreads();
         if (threadIdx.x == 0) spine[c] = s_sum;
     }
     __syncthreads();
@@ -121,21 +162,27 @@ __global__ __launch_bounds__(GS_BLOCK) void k_project(const uint32_t *__restrict
 }
 
 // One workgroup: exclusive scan of the per-chunk totals (spine) -> chunk base offsets, I = grand total (refused and
-// flagged if it does not fit the pair buffers), Vp from the partials.
+// flagged if it does not fit the pair buffers), Vp from the partials, frame accumulators.
+template <int ROUND>
 __global__ __launch_bounds__(GS_BLOCK) void k_pairs_check(GsControl *ctl, uint32_t pair_cap, uint32_t *__restrict__ spine,
-                                                          const uint32_t *__restrict__ part_vis, uint32_t nparts)
+                                                          const uint32_t *__restrict__ part_vis, uint32_t nparts, uint32_t near_count,
+                                                          int last_round, uint32_t *__restrict__ mask, uint32_t mask_total_words)
 {
     __shared__ uint32_t s_vis, s_wave[4];
     if (threadIdx.x == 0) s_vis = 0;
     __syncthreads();
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int round = ROUND;
+    uint32_t j_lo, j_hi;
+    round_range<ROUND>(ctl, near_count, j_lo, j_hi);
+    if (ROUND == 0) for (uint32_t i = threadIdx.x; i < mask_total_words; i += GS_BLOCK) mask[i] = 0u;   // read by blend<0> onwards
+    const uint32_t nsp = (j_hi - j_lo + GS_BLOCK - 1) / GS_BLOCK;
     uint32_t v = 0;
-    for (uint32_t i = threadIdx.x; i < nparts; i += GS_BLOCK) v += part_vis[i];
+    if (nsp) for (uint32_t i = threadIdx.x; i < nparts; i += GS_BLOCK) v += part_vis[i];
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
     if (lane == 0 && v) atomicAdd(&s_vis, v);
     // spine scan: each thread owns a contiguous slice
-    const uint32_t nsp = (ctl->n_kept + GS_BLOCK - 1) / GS_BLOCK;
     const uint32_t per = (nsp + GS_BLOCK - 1) / GS_BLOCK;
     const uint32_t lo = min(threadIdx.x * per, nsp), hi = min(lo + per, nsp);
     uint32_t s = 0;
@@ -149,12 +196,19 @@ __global__ __launch_bounds__(GS_BLOCK) void k_pairs_check(GsControl *ctl, uint32
     uint32_t run = base + inc - s;
     for (uint32_t i = lo; i < hi; i++) { const uint32_t t = spine[i]; spine[i] = run; run += t; }
     if (threadIdx.x == 0) {
-        ctl->n_visible = s_vis;
+        if (ROUND == 0) { ctl->n_visible = 0; ctl->n_pairs_frame = 0; ctl->want_frame = 0; }
+        else { ctl->unsat_round0 = ctl->unsat_count; if (ctl->unsat_count) ctl->unsat_events += 1; }
+        ctl->j_lo = j_lo; ctl->j_hi = j_hi;                          // for k_tile_ranges / k_blend of this round
         ctl->scan_total = total;
-        if (total > ctl->max_total) ctl->max_total = total;
+        ctl->want_frame += total;
+        if (ctl->want_frame > ctl->max_total) ctl->max_total = ctl->want_frame;
         if (total > pair_cap) { ctl->pair_overflow = 1; ctl->overflow_sticky = 1; ctl->n_pairs = 0; }
-        else { ctl->pair_overflow = 0; ctl->n_pairs = total; }
-        ctl->acc_frames += 1; ctl->acc_sorted += ctl->n_kept; ctl->acc_visible += s_vis; ctl->acc_pairs += ctl->n_pairs;
+        else { if (round == 0) ctl->pair_overflow = 0; ctl->n_pairs = total; }
+        ctl->n_visible += s_vis; ctl->n_pairs_frame += ctl->n_pairs;
+        if (ROUND == 0 && near_count != 0xFFFFFFFFu) ctl->unsat_count = 0;   // counted by blend<0>, read by round 1
+        if (last_round) {
+            ctl->acc_frames += 1; ctl->acc_sorted += ctl->n_kept; ctl->acc_visible += ctl->n_visible; ctl->acc_pairs += ctl->n_pairs_frame;
+        }
     }
 }
 
@@ -162,24 +216,42 @@ __global__ __launch_bounds__(GS_BLOCK) void k_pairs_check(GsControl *ctl, uint32
 // k_project; the pair offset of every splat is spine[chunk] + an in-workgroup exclusive scan of tile_count, so no
 // offset array ever goes to memory.  Splats touching few tiles are written by their own lane; the few screen-filling
 // ones (thousands of tiles each) are queued in LDS and expanded by a whole wavefront, one lane per tile row.
+// ROUND 1 writes only the tiles whose bit is set in the unsaturated-tile mask.
 #define GS_EMIT_BIG 32u
+template <int ROUND>
+__device__ __forceinline__ uint32_t emit_run(uint2 *__restrict__ pairs, uint32_t o, uint32_t ty, uint32_t tiles_x, uint32_t t0, uint32_t n,
+                                             uint32_t j, const uint32_t *__restrict__ mask_row)
+{
+    if (ROUND == 0) {
+        for (uint32_t k = 0; k < n; k++) pairs[o++] = make_uint2(ty * tiles_x + t0 + k, j);
+    } else if (n) {
+        for (uint32_t w = t0 >> 5; w <= ((t0 + n - 1) >> 5); w++) {
+            uint32_t bits = mask_bits(mask_row, w, t0, n);
+            while (bits) { const uint32_t b = __ffs(bits) - 1; bits &= bits - 1; pairs[o++] = make_uint2(ty * tiles_x + w * 32 + b, j); }
+        }
+    }
+    return o;
+}
+
+template <int ROUND>
 __global__ __launch_bounds__(GS_BLOCK) void k_emit(const gsm::Projected *__restrict__ proj, const uint2 *__restrict__ rect,
                                                    const uint32_t *__restrict__ tile_count, const uint32_t *__restrict__ spine,
-                                                   GsFrameUniforms u, uint2 *__restrict__ pairs, const GsControl *ctl)
+                                                   GsFrameUniforms u, uint2 *__restrict__ pairs, const uint32_t *__restrict__ mask,
+                                                   const GsControl *ctl)
 {
     __shared__ uint32_t s_big[GS_BLOCK], s_bigoff[GS_BLOCK];
     __shared__ uint32_t s_nbig, s_wave[4];
     if (ctl->pair_overflow) return;
-    const uint32_t V = ctl->n_kept;
-    const uint32_t nchunks = (V + GS_BLOCK - 1) / GS_BLOCK;
+    const uint32_t j_lo = ctl->j_lo, j_hi = ctl->j_hi;               // set by k_pairs_check of this round
+    const uint32_t nchunks = (j_hi - j_lo + GS_BLOCK - 1) / GS_BLOCK;
     const uint32_t tiles_x = (uint32_t)u.tiles_x;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     for (uint32_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
         uint32_t carry = spine[c];
         {
             if (threadIdx.x == 0) s_nbig = 0;
-            const uint32_t j = c * GS_BLOCK + threadIdx.x;
-            const uint32_t cnt = j < V ? tile_count[j] : 0u;
+            const uint32_t j = j_lo + c * GS_BLOCK + threadIdx.x;
+            const uint32_t cnt = j < j_hi ? tile_count[j] : 0u;
             const uint32_t inc = wave_incl_scan_u32(cnt, lane);
             if (lane == 63) s_wave[w] = inc;
             __syncthreads();
@@ -188,7 +260,7 @@ __global__ __launch_bounds__(GS_BLOCK) void k_emit(const gsm::Projected *__restr
             for (int k = 0; k < 4; k++) { const uint32_t t = s_wave[k]; if (k < w) wbase += t; total += t; }
             uint32_t o = carry + wbase + inc - cnt;                  // this splat's first pair slot
             carry += total;
-            if (cnt >= (u.dbg0 > 0 ? (uint32_t)u.dbg0 : GS_EMIT_BIG)) {
+            if (cnt >= GS_EMIT_BIG) {
                 const uint32_t q = atomicAdd(&s_nbig, 1u);
                 s_big[q] = j; s_bigoff[q] = o;
             } else if (cnt) {
@@ -201,7 +273,7 @@ __global__ __launch_bounds__(GS_BLOCK) void k_emit(const gsm::Projected *__restr
                 for (uint32_t ty = rc.x >> 16; ty <= (rc.y >> 16); ty++) {
                     uint32_t t0, n;
                     gsm::splat_tile_row(p, e, (int)ty, u.H, u.x0, u.x1, t0, n);
-                    if (u.dbg1 != 1) for (uint32_t k = 0; k < n; k++) pairs[o++] = make_uint2(ty * tiles_x + t0 + k, j);
+                    o = emit_run<ROUND>(pairs, o, ty, tiles_x, t0, n, j, mask + ty * u.mask_words);
                 }
             }
             __syncthreads();
@@ -218,11 +290,13 @@ __global__ __launch_bounds__(GS_BLOCK) void k_emit(const gsm::Projected *__restr
                 uint32_t base = s_bigoff[bi];
                 for (uint32_t tyb = ty0; tyb <= ty1; tyb += 64) {    // 64 tile rows per sweep
                     const uint32_t ty = tyb + lane;
-                    uint32_t t0 = 0, n = 0;
-                    if (ty <= ty1) gsm::splat_tile_row(p, e, (int)ty, u.H, u.x0, u.x1, t0, n);
-                    const uint32_t rinc = wave_incl_scan_u32(n, lane);
-                    uint32_t ob = base + rinc - n;
-                    if (u.dbg1 != 2) for (uint32_t k = 0; k < n; k++) pairs[ob++] = make_uint2(ty * tiles_x + t0 + k, jb);
+                    uint32_t t0 = 0, n = 0, nm = 0;
+                    if (ty <= ty1) {
+                        gsm::splat_tile_row(p, e, (int)ty, u.H, u.x0, u.x1, t0, n);
+                        nm = (ROUND == 1 && n) ? mask_count(mask + ty * u.mask_words, t0, n) : n;
+                    }
+                    const uint32_t rinc = wave_incl_scan_u32(nm, lane);
+                    if (ty <= ty1) emit_run<ROUND>(pairs, base + rinc - nm, ty, tiles_x, t0, n, jb, mask + ty * u.mask_words);
                     base += __shfl(rinc, 63, 64);
                 }
             }
@@ -234,8 +308,9 @@ __global__ __launch_bounds__(GS_BLOCK) void k_emit(const gsm::Projected *__restr
 // [start,end) of every tile in the sorted pair list, written for ALL tiles (empty ones get an empty range at the
 // position where they would be), so no clearing pass is needed.
 __global__ __launch_bounds__(GS_BLOCK) void k_tile_ranges(const uint2 *__restrict__ pairs, uint2 *__restrict__ range, uint32_t ntiles,
-                                                          const GsControl *ctl)
+                                                          int round, const GsControl *ctl)
 {
+    if (round == 1 && ctl->j_hi == 0) return;                      // nothing left for round 1: its blend returns too
     const uint32_t I = ctl->n_pairs;
     if (I == 0) {
         for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < ntiles; t += gridDim.x * blockDim.x) range[t] = make_uint2(0u, 0u);
@@ -269,19 +344,25 @@ __global__ __launch_bounds__(GS_BLOCK) void k_tile_ranges(const uint2 *__restric
 // computed once -- the expression tree per pixel is unchanged (frag_power), so coverage stays bit-identical.
 // Traversal is FRONT-to-back (the list is back-to-front) with a per-pixel transmittance accumulator; the wave leaves
 // the list as soon as every pixel has T < t_eps (ballot), one rounding to RGBA8 at the end.
+// ROUND 0 starts from (T = 1, C = 0); a tile that is not saturated when its list ends saves its per-pixel state and
+// sets its bit in the tile mask (if a round 1 follows).  ROUND 1 runs only for masked tiles and resumes from the state.
 #define GS_BLEND_BATCH 128
 typedef float f2 __attribute__((ext_vector_type(2)));            // two pixels per packed-fp32 instruction (v_pk_*_f32)
 __device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
 
-template <bool COUNT>
+template <bool COUNT, int ROUND>
 __global__ __launch_bounds__(64) void k_blend(const uint2 *__restrict__ tile_range, const uint2 *__restrict__ pairs,
                                               const gsm::Projected *__restrict__ proj, GsFrameUniforms u,
-                                              uint8_t *__restrict__ out, GsControl *ctl)
+                                              uint8_t *__restrict__ out, float4 *__restrict__ state, uint32_t *__restrict__ mask,
+                                              GsControl *ctl)
 {
     __shared__ float4 s_rec[2 * GS_BLEND_BATCH + 2];             // 4 KiB: one batch of projected records (+1 inert slot)
-    const uint32_t tile = blockIdx.x;
-    const uint32_t tx = tile % (uint32_t)u.tiles_x, ty = tile / (uint32_t)u.tiles_x;
     const int lane = threadIdx.x;
+    if (ROUND == 1 && ctl->j_hi == 0) return;                      // every tile saturated in round 0
+    const uint32_t ntiles = (uint32_t)u.tiles_x * (uint32_t)u.tiles_y;
+    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {   // round 0: one tile per wave; round 1: small grid
+    const uint32_t tx = tile % (uint32_t)u.tiles_x, ty = tile / (uint32_t)u.tiles_x;
+    if (ROUND == 1 && !((mask[ty * u.mask_words + (tx >> 5)] >> (tx & 31)) & 1u)) continue;   // this tile is final already
     const int xb = u.x0 + (int)tx * GS_TILE + (lane & 3) * 4;      // first of this lane's 4 pixels
     const int r = (int)ty * GS_TILE + (lane >> 2);                 // image row, 0 = top
     const bool row_in = r < u.H;
@@ -295,6 +376,15 @@ __global__ __launch_bounds__(64) void k_blend(const uint2 *__restrict__ tile_ran
     f2 crA = { 0, 0 }, crB = { 0, 0 }, cgA = { 0, 0 }, cgB = { 0, 0 }, cbA = { 0, 0 }, cbB = { 0, 0 }, caA = { 0, 0 }, caB = { 0, 0 };
     f2 qmA = { (row_in && xb < u.x1) ? 4.0f : -1.0f, (row_in && xb + 1 < u.x1) ? 4.0f : -1.0f };
     f2 qmB = { (row_in && xb + 2 < u.x1) ? 4.0f : -1.0f, (row_in && xb + 3 < u.x1) ? 4.0f : -1.0f };
+    float4 *st = state + ((size_t)tile * 64 + lane) * 5;           // 5 x float4 per lane: T, r, g, b, a of its 4 pixels
+    if (ROUND == 1) {
+        const float4 t = st[0], c0 = st[1], c1 = st[2], c2 = st[3], c3 = st[4];
+        TA = (f2){ t.x, t.y }; TB = (f2){ t.z, t.w };
+        crA = (f2){ c0.x, c0.y }; crB = (f2){ c0.z, c0.w }; cgA = (f2){ c1.x, c1.y }; cgB = (f2){ c1.z, c1.w };
+        cbA = (f2){ c2.x, c2.y }; cbB = (f2){ c2.z, c2.w }; caA = (f2){ c3.x, c3.y }; caB = (f2){ c3.z, c3.w };
+        qmA.x = TA.x < t_eps ? -1.0f : qmA.x; qmA.y = TA.y < t_eps ? -1.0f : qmA.y;     // pixels that terminated in round 0
+        qmB.x = TB.x < t_eps ? -1.0f : qmB.x; qmB.y = TB.y < t_eps ? -1.0f : qmB.y;
+    }
     uint32_t nfr = 0, dbg_steps = 0;
     const uint2 range = tile_range[tile];
 
@@ -366,6 +456,18 @@ __global__ __launch_bounds__(64) void k_blend(const uint2 *__restrict__ tile_ran
         __syncthreads();                                           // s_rec is rewritten by the next batch
         if (__all(!(fmaxf(fmaxf(qmA.x, qmA.y), fmaxf(qmB.x, qmB.y)) > 0.0f))) break;
     }
+    if (ROUND == 0 && u.near_count != 0xFFFFFFFFu) {
+        // the nearer splats did not saturate this tile: keep the exact per-pixel state for round 1 and flag the tile
+        if (__any(fmaxf(fmaxf(qmA.x, qmA.y), fmaxf(qmB.x, qmB.y)) > 0.0f)) {
+            st[0] = make_float4(TA.x, TA.y, TB.x, TB.y);
+            st[1] = make_float4(crA.x, crA.y, crB.x, crB.y); st[2] = make_float4(cgA.x, cgA.y, cgB.x, cgB.y);
+            st[3] = make_float4(cbA.x, cbA.y, cbB.x, cbB.y); st[4] = make_float4(caA.x, caA.y, caB.x, caB.y);
+            if (lane == 0) {
+                atomicOr(&mask[ty * u.mask_words + (tx >> 5)], 1u << (tx & 31)); atomicAdd(&ctl->unsat_count, 1u);
+                if (u.skip_round1) ctl->round1_missed = 1;           // nobody will come for this tile unless the host notices
+            }
+        }
+    }
     if (row_in && xb < u.x1) {
         // dst <- src.rgb*a + dst.rgb*(1-a), dst.a <- a + dst.a*(1-a), composed over the background
         const int sw = u.x1 - u.x0;
@@ -395,11 +497,70 @@ __global__ __launch_bounds__(64) void k_blend(const uint2 *__restrict__ tile_ran
         if (lane == 0 && nfr) atomicAdd(&ctl->n_frags, (unsigned long long)nfr);
     }
     if (u.dbg1 == 3 && lane == 0) const_cast<uint2 *>(tile_range)[tile] = make_uint2(dbg_steps, range.y - range.x);   // experiment: list entries staged vs list length
+    __syncthreads();                                               // s_rec is reused by the next tile of this wave
+    }
 }
 
 int bits_for(uint32_t n) { int b = 1; while ((1u << b) < n) b++; return b; }
 
+// one round: project -> offsets -> emit -> stable sort by tile -> ranges -> blend.  Round 1 usually finds nothing to
+// do (every tile saturated), so it is launched on small grids: its kernels grid-stride when there is work.
+template <int ROUND>
+int run_round(gs_ctx *ctx, const GsFrameUniforms &u, uint8_t *out, bool last_round)
+{
+    const uint32_t ntiles = (uint32_t)u.tiles_x * (uint32_t)u.tiles_y;
+    const uint32_t Vmax = (uint32_t)ctx->n;
+    hipStream_t st = ctx->stream;
+    uint32_t g = gs_div_up(Vmax, GS_BLOCK); if (g > GS_MAX_PART) g = GS_MAX_PART;
+    const uint32_t small = 512;
+    if (ROUND == 1 && g > small) g = small;
+    const uint32_t pc = ROUND == 1 ? (uint32_t)(small * GS_CHUNK) : (uint32_t)ctx->pair_cap;      // grid hint for the radix kernels
+    hipLaunchKernelGGL(k_project<ROUND>, dim3(g), dim3(GS_BLOCK), 0, st, ctx->sorted, ctx->splat, u, ctx->proj, ctx->rect,
+                       ctx->tile_count, ctx->spine, ctx->part_vis, ctx->unsat_mask, ctx->ctl);
+    GS_HIP(hipGetLastError());
+    if (ROUND == 0) GS_PROF_RECORD(ctx, 3);
+    hipLaunchKernelGGL(k_pairs_check<ROUND>, dim3(1), dim3(GS_BLOCK), 0, st, ctx->ctl, (uint32_t)ctx->pair_cap, ctx->spine, ctx->part_vis, g,
+                       u.near_count, last_round ? 1 : 0, ctx->unsat_mask, (uint32_t)u.tiles_y * u.mask_words);
+    hipLaunchKernelGGL(k_emit<ROUND>, dim3(g), dim3(GS_BLOCK), 0, st, ctx->proj, ctx->rect, ctx->tile_count, ctx->spine, u, ctx->pair_a,
+                       ctx->unsat_mask, ctx->ctl);
+    GS_HIP(hipGetLastError());
+    int rc;
+    const int tb = bits_for(ntiles);
+    const uint2 *fpairs;
+    if (tb <= 9) {
+        rc = gs_launch_radix_pass(ctx, ctx->pair_a, true, ctx->pair_b, true, &ctx->ctl->n_pairs, pc, 0, tb);
+        if (rc != GS_OK) return rc;
+        fpairs = ctx->pair_b;
+    } else {
+        const int b1 = (tb + 1) / 2, b2 = tb - b1;
+        rc = gs_launch_radix_pass(ctx, ctx->pair_a, true, ctx->pair_b, true, &ctx->ctl->n_pairs, pc, 0, b1);
+        if (rc != GS_OK) return rc;
+        rc = gs_launch_radix_pass(ctx, ctx->pair_b, true, ctx->pair_a, true, &ctx->ctl->n_pairs, pc, b1, b2);
+        if (rc != GS_OK) return rc;
+        fpairs = ctx->pair_a;
+    }
+    hipLaunchKernelGGL(k_tile_ranges, dim3(ROUND == 1 ? small : 2048), dim3(GS_BLOCK), 0, st, fpairs, ctx->tile_range, ntiles, ROUND, ctx->ctl);
+    GS_HIP(hipGetLastError());
+    if (ROUND == 0) GS_PROF_RECORD(ctx, 4);
+    const uint32_t gb = ROUND == 1 ? (ntiles < 1024 ? ntiles : 1024) : ntiles;
+    if (u.flags & GS_RENDER_COUNT_FRAGS)
+        hipLaunchKernelGGL((k_blend<true, ROUND>), dim3(gb), dim3(64), 0, st, ctx->tile_range, fpairs, ctx->proj, u, out,
+                           ctx->state, ctx->unsat_mask, ctx->ctl);
+    else
+        hipLaunchKernelGGL((k_blend<false, ROUND>), dim3(gb), dim3(64), 0, st, ctx->tile_range, fpairs, ctx->proj, u, out,
+                           ctx->state, ctx->unsat_mask, ctx->ctl);
+    GS_HIP(hipGetLastError());
+    return GS_OK;
+}
+
 }  // namespace
+
+// a skipped round 1 turned out to be needed: run it now (mask + state of the frame are still intact)
+int gs_run_round1(gs_ctx *ctx, const GsFrameUniforms &u, uint8_t *device_out)
+{
+    GsFrameUniforms v = u; v.skip_round1 = 0;
+    return run_round<1>(ctx, v, device_out ? device_out : ctx->fb, false);
+}
 
 int gs_run_render(gs_ctx *ctx, const GsFrameUniforms &u, uint8_t *device_out)
 {
@@ -411,47 +572,25 @@ int gs_run_render(gs_ctx *ctx, const GsFrameUniforms &u, uint8_t *device_out)
     GS_PROF_RECORD(ctx, 2);
     if (u.flags & GS_RENDER_COUNT_FRAGS) GS_HIP(hipMemsetAsync(&ctx->ctl->n_frags, 0, sizeof(unsigned long long), st));
     if (Vmax && ctx->have_sort) {
-        uint32_t g = gs_div_up(Vmax, GS_BLOCK); if (g > GS_MAX_PART) g = GS_MAX_PART;
-        hipLaunchKernelGGL(k_project, dim3(g), dim3(GS_BLOCK), 0, st, ctx->sorted, ctx->splat, u, ctx->proj,
-                           ctx->rect, ctx->tile_count, ctx->spine, ctx->part_vis, ctx->ctl);
-        GS_HIP(hipGetLastError());
-        GS_PROF_RECORD(ctx, 3);
-        hipLaunchKernelGGL(k_pairs_check, dim3(1), dim3(GS_BLOCK), 0, st, ctx->ctl, (uint32_t)ctx->pair_cap, ctx->spine, ctx->part_vis, g);
-        hipLaunchKernelGGL(k_emit, dim3(g), dim3(GS_BLOCK), 0, st, ctx->proj, ctx->rect, ctx->tile_count, ctx->spine, u,
-                           ctx->pair_a, ctx->ctl);
-        GS_HIP(hipGetLastError());
-        int rc;
-        const int tb = bits_for(ntiles);
-        const uint2 *fpairs;
-        const uint32_t pc = (uint32_t)ctx->pair_cap;
-        if (tb <= 9) {
-            rc = gs_launch_radix_pass(ctx, ctx->pair_a, true, ctx->pair_b, true, &ctx->ctl->n_pairs, pc, 0, tb);
+        const bool two_rounds = u.near_count != 0xFFFFFFFFu;
+        int rc = run_round<0>(ctx, u, out, !two_rounds || u.skip_round1);
+        if (rc != GS_OK) return rc;
+        GS_PROF_RECORD(ctx, 5);
+        if (two_rounds && !u.skip_round1) {
+            rc = run_round<1>(ctx, u, out, true);
             if (rc != GS_OK) return rc;
-            fpairs = ctx->pair_b;
-        } else {
-            const int b1 = (tb + 1) / 2, b2 = tb - b1;
-            rc = gs_launch_radix_pass(ctx, ctx->pair_a, true, ctx->pair_b, true, &ctx->ctl->n_pairs, pc, 0, b1);
-            if (rc != GS_OK) return rc;
-            rc = gs_launch_radix_pass(ctx, ctx->pair_b, true, ctx->pair_a, true, &ctx->ctl->n_pairs, pc, b1, b2);
-            if (rc != GS_OK) return rc;
-            fpairs = ctx->pair_a;
         }
-        hipLaunchKernelGGL(k_tile_ranges, dim3(2048), dim3(GS_BLOCK), 0, st, fpairs, ctx->tile_range, ntiles, ctx->ctl);
-        GS_HIP(hipGetLastError());
-        GS_PROF_RECORD(ctx, 4);
-        if (u.flags & GS_RENDER_COUNT_FRAGS)
-            hipLaunchKernelGGL(k_blend<true>, dim3(ntiles), dim3(64), 0, st, ctx->tile_range, fpairs, ctx->proj, u, out, ctx->ctl);
-        else
-            hipLaunchKernelGGL(k_blend<false>, dim3(ntiles), dim3(64), 0, st, ctx->tile_range, fpairs, ctx->proj, u, out, ctx->ctl);
-        GS_HIP(hipGetLastError());
     } else {
         // nothing resident / never sorted: the frame is the background
         GS_HIP(hipMemsetAsync(ctx->ctl, 0, sizeof(GsControl), st));
         GS_HIP(hipMemsetAsync(ctx->tile_range, 0, sizeof(uint2) * ntiles, st));
+        GsFrameUniforms ub = u; ub.near_count = 0xFFFFFFFFu;
         GS_PROF_RECORD(ctx, 3); GS_PROF_RECORD(ctx, 4);
-        hipLaunchKernelGGL(k_blend<false>, dim3(ntiles), dim3(64), 0, st, ctx->tile_range, ctx->pair_a, ctx->proj, u, out, ctx->ctl);
+        hipLaunchKernelGGL((k_blend<false, 0>), dim3(ntiles), dim3(64), 0, st, ctx->tile_range, ctx->pair_a, ctx->proj, ub, out,
+                           ctx->state, ctx->unsat_mask, ctx->ctl);
         GS_HIP(hipGetLastError());
+        GS_PROF_RECORD(ctx, 5);
     }
-    GS_PROF_RECORD(ctx, 5);
+    GS_PROF_RECORD(ctx, 6);
     return GS_OK;
 }

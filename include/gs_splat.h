@@ -163,10 +163,14 @@ typedef struct gs_stats {
     uint64_t acc_sorted;  /* sum of V over those frames                                                       */
     uint64_t acc_visible; /* sum of Vp                                                                        */
     uint64_t acc_pairs;   /* sum of I                                                                         */
+    uint32_t unsat_tiles; /* tiles the nearest-splats round left unsaturated in the last collected frame             */
+    uint32_t near_permille;/* share of the splats binned in that first round (adapted, or GS_OPT_NEAR_PERMILLE)        */
 } gs_stats;
 
 #define GS_OPT_PROFILE 1        /* value != 0: bracket stages with HIP events on the context stream        */
 #define GS_OPT_TERMINATION 2    /* value = 1/eps for the transmittance early-out (default 4096)          */
+#define GS_OPT_NEAR_PERMILLE 3  /* occlusion-aware binning: 0 = adapt (default), 1..999 = bin that share of the nearest
+                                   splats first and the rest only against unsaturated tiles, 1000 = single round      */
 GS_API int gs_set_option(gs_ctx *ctx, int option, int64_t value);
 GS_API int gs_get_stats(gs_ctx *ctx, gs_stats *out);
 

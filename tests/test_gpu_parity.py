@@ -380,8 +380,37 @@ def test_async_frames_match_synchronous_ones_and_report_overflow(scene_small):
             assert e.code == capi.E_RETRY
             overflowed = True
         c3.render_device(_params(cam, flags=capi.RENDER_ASYNC), None)
-        c3.sync()                                                          # enlarged buffers: no error now
+        c3.sync()                                                          # enlarged to the frame's whole demand: no error now
         a = c3.render(_params(cam))
         assert c3.stats()["n_pairs"] > 0
         if overflowed:
             assert c3.stats()["n_pairs"] > (1 << 22)
+
+
+@pytest.mark.parametrize("w,h,n,seed", [(640, 360, 30000, 77), (1920, 1080, 400000, 12)])
+def test_two_round_occlusion_aware_binning_is_bit_identical(w, h, n, seed):
+    """GS_OPT_NEAR_PERMILLE: binning the nearest share of the splats first and the rest only against the tiles that did
+    not saturate must give exactly the single-round image, whatever the share (incl. shares that leave most tiles
+    unsaturated and shares that saturate everything)."""
+    rows = synth.make_splat_rows(n, seed=seed)
+    cam = synth.index_html_camera(w, h, 33.0, capi=capi)
+    with capi.Context(0) as c2:
+        c2.push_splat(rows)
+        c2.sort(cam["view"])
+        c2.set_option(capi.OPT_NEAR_PERMILLE, 1000)
+        ref = c2.render(_params(cam))
+        pairs_all = c2.stats()["n_pairs"]
+        seen_unsat = set()
+        for pm in (900, 500, 250, 100, 30, 5, 1):
+            c2.set_option(capi.OPT_NEAR_PERMILLE, pm)
+            img = c2.render(_params(cam))
+            st = c2.stats()
+            assert np.array_equal(img, ref), pm
+            assert st["near_permille"] in (pm, 250) and st["n_pairs"] <= pairs_all
+            seen_unsat.add(st["unsat_tiles"] > 0)
+            strips = [c2.render(_params(cam, x0=a, x1=b)) for a, b in ((0, w // 2 - 8), (w // 2 - 8, w))]
+            assert np.array_equal(np.concatenate(strips, axis=1), ref), pm
+        assert True in seen_unsat                       # some share really exercised round 1
+        c2.set_option(capi.OPT_NEAR_PERMILLE, 0)        # adaptive: still identical while the share moves
+        for _ in range(6):
+            assert np.array_equal(c2.render(_params(cam)), ref)
