@@ -249,6 +249,7 @@ GS_API int gs_clear(gs_ctx *ctx)
     GS_HIP(hipSetDevice(ctx->device));
     GS_HIP(hipStreamSynchronize(ctx->stream));
     ctx->n = 0; ctx->renderable = true; ctx->have_sort = false; ctx->sorted = nullptr;
+    ctx->near_frac = 0.25f; ctx->near_floor = 0.0f; ctx->clean_frames = 0; ctx->skip_hold = 0; ctx->single_round_frames = 0;
     memset(&ctx->stats, 0, sizeof ctx->stats);
     return GS_OK;
 }

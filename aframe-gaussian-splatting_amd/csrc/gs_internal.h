@@ -103,7 +103,6 @@ struct gs_ctx {
     float near_floor;                       // never shrink the share below this (1.3 x the share that last proved too small)
     uint32_t clean_frames, skip_hold;       // collected frames since the last unsaturated one / frames to keep round 1 on
     uint32_t seen_unsat_events; uint64_t seen_acc_frames;
-    GsFrameUniforms *last_u;                // uniforms of the last enqueued frame (to run a skipped round 1 after the fact)
     uint32_t single_round_frames;           // consecutive collected frames at near_frac == 1 (re-probe occlusion now and then)
     // per-workgroup partial reductions (instead of same-address global atomics, which serialise at ~11 ns each)
     unsigned long long *part_min, *part_max;   // [GS_MAX_PART]

@@ -456,7 +456,7 @@ __global__ __launch_bounds__(64) void k_blend(const uint2 *__restrict__ tile_ran
         __syncthreads();                                           // s_rec is rewritten by the next batch
         if (__all(!(fmaxf(fmaxf(qmA.x, qmA.y), fmaxf(qmB.x, qmB.y)) > 0.0f))) break;
     }
-    if (ROUND == 0 && u.near_count != 0xFFFFFFFFu) {
+    if (ROUND == 0 && u.near_count < ctl->n_kept) {               // farther splats exist beyond this round
         // the nearer splats did not saturate this tile: keep the exact per-pixel state for round 1 and flag the tile
         if (__any(fmaxf(fmaxf(qmA.x, qmA.y), fmaxf(qmB.x, qmB.y)) > 0.0f)) {
             st[0] = make_float4(TA.x, TA.y, TB.x, TB.y);
