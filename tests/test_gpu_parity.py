@@ -253,7 +253,7 @@ def test_render_1080p_properties(ctx, scene_1m):
     ctx.sort(cam["view"])
     full = ctx.render(_params(cam))
     st = ctx.stats()
-    assert st["n_sorted"] > 500000 and st["n_visible"] > 100000 and st["n_pairs"] >= st["n_visible"]
+    assert st["n_sorted"] > 500000 and st["n_visible"] > 10000 and st["n_pairs"] >= st["n_visible"]   # (visible = splats binned; fewer with occlusion-aware rounds)
     assert np.all(full[:, :, 3] == 255)                                     # opaque background keeps alpha 1
     # early termination at T < 1/4096 moves no channel by more than 1 LSB
     allf = ctx.render(_params(cam, flags=capi.RENDER_NO_EARLY_OUT))
