@@ -181,7 +181,7 @@ def main():
         try:                                                 # HBM bytes/launch of k_blend from the committed PMC passes
             pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_hbm_traffic.json")))
             if world == 1 and n_splats == synth.N_TRAIN:
-                traffic = pmc["k_blend<false>"]["hbm_bytes"]
+                traffic = pmc["k_blend<false, 0>"]["hbm_bytes"]
         except Exception:
             traffic = None
         out = {
