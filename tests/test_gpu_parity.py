@@ -414,3 +414,28 @@ def test_two_round_occlusion_aware_binning_is_bit_identical(w, h, n, seed):
         c2.set_option(capi.OPT_NEAR_PERMILLE, 0)        # adaptive: still identical while the share moves
         for _ in range(6):
             assert np.array_equal(c2.render(_params(cam)), ref)
+
+
+@pytest.mark.skipif(os.environ.get("GS_RUN_20M") != "1", reason="C5-size smoke (20M splats, 3840x2160): set GS_RUN_20M=1")
+def test_c5_twenty_million_splats_4k():
+    """C5: synthetic 20M gaussians at 3840x2160: bit-exact sort vs the oracle, 8 column strips == full frame,
+    a 64-px strip vs the oracle."""
+    n = synth.N_20M
+    rows = synth.make_splat_rows(n, seed=synth.SEED_BASE + 5, order_by_importance=False)
+    cs, cc, mats = oracle.pack(rows)
+    rows4 = np.ascontiguousarray(mats[:, 12:16]); del mats
+    cam = synth.index_html_camera(3840, 2160, 15.0, capi=capi)
+    with capi.Context(0) as c5:
+        r = rows.reshape(-1, 32)
+        for a in range(0, n, 1 << 22):                     # progressive ingest, 4M rows per push
+            c5.push_splat(r[a:a + (1 << 22)])
+        idx = c5.sort(cam["view"])
+        assert np.array_equal(idx, oracle.sort(rows4, cam["view"]))
+        full = c5.render(_params(cam))
+        st = c5.stats()
+        parts = [c5.render(_params(cam, x0=k * 480, x1=(k + 1) * 480)) for k in range(8)]
+        assert np.array_equal(np.concatenate(parts, axis=1), full)
+        mv, P, focal = _f32(cam)
+        ref, _, _ = oracle.render(cs, cc, idx, mv, P, focal, 3840, 2160, x0=1900, x1=1964, want_f32=False)
+        assert np.abs(full[:, 1900:1964].astype(int) - ref.astype(int)).max() <= PIXEL_TOL_LSB
+        print("C5 stats:", st)
