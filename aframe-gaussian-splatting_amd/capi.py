@@ -18,7 +18,8 @@ BUF_CENTER_SCALE, BUF_COV_COLOR, BUF_SORT_ROWS, BUF_SORTED, BUF_PROJECTED, BUF_T
 
 EXPORTS = [
     "gs_create", "gs_destroy", "gs_last_error", "gs_version", "gs_clear", "gs_push_splat", "gs_push_matrices", "gs_load_ply",
-    "gs_ply_to_splat", "gs_count", "gs_sort", "gs_render", "gs_render_device", "gs_render_stereo", "gs_sync", "gs_set_stream",
+    "gs_ply_to_splat", "gs_count", "gs_sort", "gs_render", "gs_render_device", "gs_render_stereo", "gs_set_scene", "gs_sync",
+    "gs_set_stream",
     "gs_model_view_matrix", "gs_projection_matrix", "gs_tick_uniforms", "gs_focal", "gs_scaled_size", "gs_set_option",
     "gs_get_stats", "gs_download",
 ]
@@ -80,6 +81,7 @@ def load(build_if_missing=True):
     L.gs_render.argtypes = [vp, C.POINTER(RenderParams), vp, sz]
     L.gs_render_device.argtypes = [vp, C.POINTER(RenderParams), vp]
     L.gs_render_stereo.argtypes = [vp, C.POINTER(RenderParams), C.POINTER(vp), sz]
+    L.gs_set_scene.argtypes = [vp, vp, vp, i32, i32]
     L.gs_sync.argtypes = [vp]
     L.gs_set_stream.argtypes = [vp, vp]
     L.gs_model_view_matrix.argtypes = [vp, vp, vp]; L.gs_model_view_matrix.restype = None
@@ -239,6 +241,16 @@ class Context:
         outs = (C.c_void_p * 2)(o0.ctypes.data, o1.ctypes.data)
         self._ck(self._L.gs_render_stereo(self._h, arr, outs, 0))
         return o0, o1
+
+    def set_scene(self, depth=None, rgba=None):
+        """Opaque-scene inputs (depthTest LEQUAL against `depth` [H,W] f32 window depth; blend over `rgba` [H,W,4] u8)."""
+        if depth is None and rgba is None:
+            self._ck(self._L.gs_set_scene(self._h, None, None, 0, 0))
+            return
+        d = None if depth is None else np.ascontiguousarray(depth, np.float32)
+        c = None if rgba is None else np.ascontiguousarray(rgba, np.uint8)
+        h, w = (d.shape if d is not None else c.shape[:2])
+        self._ck(self._L.gs_set_scene(self._h, _p(d), _p(c), int(w), int(h)))
 
     def sync(self):
         self._ck(self._L.gs_sync(self._h))

@@ -70,11 +70,11 @@ static int ensure_capacity(gs_ctx *ctx, size_t want)
     dev_free(ctx->splat); dev_free(ctx->sort_rows);
     ctx->splat = sp; ctx->sort_rows = sr;
     dev_free(ctx->depth); dev_free(ctx->key_a); dev_free(ctx->kv_b); dev_free(ctx->val_a);
-    dev_free(ctx->proj); dev_free(ctx->rect); dev_free(ctx->tile_count);
+    dev_free(ctx->proj); dev_free(ctx->rect); dev_free(ctx->tile_count); dev_free(ctx->zwin);
     TRY(dev_alloc(ctx, &ctx->depth, cap));
     TRY(dev_alloc(ctx, &ctx->key_a, cap)); TRY(dev_alloc(ctx, &ctx->kv_b, cap)); TRY(dev_alloc(ctx, &ctx->val_a, cap));
     TRY(dev_alloc(ctx, &ctx->proj, cap)); TRY(dev_alloc(ctx, &ctx->rect, cap));
-    TRY(dev_alloc(ctx, &ctx->tile_count, cap));
+    TRY(dev_alloc(ctx, &ctx->tile_count, cap)); TRY(dev_alloc(ctx, &ctx->zwin, cap));
     ctx->cap = cap;
     ctx->have_sort = false; ctx->sorted = nullptr;
     TRY(gs_ensure_pair_capacity(ctx, cap * 8 > ((size_t)1 << 22) ? cap * 8 : (size_t)1 << 22));
@@ -231,7 +231,8 @@ GS_API int gs_destroy(gs_ctx *ctx)
     dev_free(ctx->splat); dev_free(ctx->sort_rows); dev_free(ctx->pow10tab);
     dev_free(ctx->depth); dev_free(ctx->key_a); dev_free(ctx->kv_b); dev_free(ctx->val_a);
     dev_free(ctx->hist); dev_free(ctx->spine);
-    dev_free(ctx->proj); dev_free(ctx->rect); dev_free(ctx->tile_count);
+    dev_free(ctx->proj); dev_free(ctx->rect); dev_free(ctx->tile_count); dev_free(ctx->zwin);
+    dev_free(ctx->scene_depth); dev_free(ctx->scene_rgba);
     dev_free(ctx->pair_a); dev_free(ctx->pair_b);
     dev_free(ctx->tile_range); dev_free(ctx->fb); dev_free(ctx->ctl); dev_free(ctx->state); dev_free(ctx->unsat_mask);
     dev_free(ctx->part_min); dev_free(ctx->part_max); dev_free(ctx->part_cnt); dev_free(ctx->part_valid); dev_free(ctx->part_vis);
@@ -351,6 +352,9 @@ static int fill_uniforms(gs_ctx *ctx, const gs_render_params *p, GsFrameUniforms
     const float frac = ctx->near_fixed_permille > 0 ? ctx->near_fixed_permille / 1000.0f : ctx->near_frac;
     if ((p->flags & (GS_RENDER_COUNT_FRAGS | GS_RENDER_NO_EARLY_OUT)) || frac >= 1.0f) u.near_count = 0xFFFFFFFFu;
     else { const double nc = ceil((double)frac * (double)ctx->n); u.near_count = nc < 1 ? 1u : (uint32_t)nc; }
+    u.has_depth = ctx->scene_depth != nullptr; u.has_scene_rgba = ctx->scene_rgba != nullptr;
+    if ((u.has_depth || u.has_scene_rgba) && (ctx->scene_w != p->fb_width || ctx->scene_h != p->fb_height))
+        FAIL(GS_E_BADARG, "scene inputs are %dx%d but the frame is %dx%d", ctx->scene_w, ctx->scene_h, p->fb_width, p->fb_height);
     u.skip_round1 = (u.near_count != 0xFFFFFFFFu && ctx->near_fixed_permille <= 0 && ctx->clean_frames >= 16 && !ctx->skip_hold) ? 1u : 0u;
     return GS_OK;
 }
@@ -428,6 +432,22 @@ GS_API int gs_render_stereo(gs_ctx *ctx, const gs_render_params eyes[2], uint8_t
     if (!eyes || !rgba_out || !rgba_out[0] || !rgba_out[1]) FAIL(GS_E_BADARG, "gs_render_stereo: NULL argument");
     TRY(render_common(ctx, &eyes[0], nullptr, rgba_out[0], stride));
     return render_common(ctx, &eyes[1], nullptr, rgba_out[1], stride);
+}
+
+GS_API int gs_set_scene(gs_ctx *ctx, const float *depth, const uint8_t *rgba, int fb_width, int fb_height)
+{
+    CHECK_CTX(ctx);
+    GS_HIP(hipSetDevice(ctx->device));
+    GS_HIP(hipStreamSynchronize(ctx->stream));
+    dev_free(ctx->scene_depth); dev_free(ctx->scene_rgba);
+    ctx->scene_w = ctx->scene_h = 0;
+    if (!depth && !rgba) return GS_OK;
+    if (fb_width <= 0 || fb_height <= 0) FAIL(GS_E_BADARG, "gs_set_scene: bad size %dx%d", fb_width, fb_height);
+    const size_t px = (size_t)fb_width * fb_height;
+    if (depth) { TRY(dev_alloc(ctx, &ctx->scene_depth, px)); GS_HIP(hipMemcpy(ctx->scene_depth, depth, px * 4, hipMemcpyHostToDevice)); }
+    if (rgba) { TRY(dev_alloc(ctx, &ctx->scene_rgba, px)); GS_HIP(hipMemcpy(ctx->scene_rgba, rgba, px * 4, hipMemcpyHostToDevice)); }
+    ctx->scene_w = fb_width; ctx->scene_h = fb_height;
+    return GS_OK;
 }
 
 GS_API int gs_sync(gs_ctx *ctx)

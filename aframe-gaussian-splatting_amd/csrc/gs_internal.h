@@ -57,6 +57,7 @@ struct GsFrameUniforms {           // per-render constants, passed by value to k
     uint32_t near_count;           // round 0 bins the nearest near_count splats; 0xFFFFFFFF = single round (everything)
     uint32_t mask_words;           // 32-bit words per tile row of the unsaturated-tile mask
     uint32_t skip_round1;          // round 1 is not launched for this frame (optimistic; blend<0> raises round1_missed)
+    uint32_t has_depth, has_scene_rgba;   // scene compositing inputs present (gs_set_scene)
 };
 
 struct gs_ctx {
@@ -92,6 +93,8 @@ struct gs_ctx {
     gsm::Projected *proj;          // V records, sorted order
     uint2 *rect;                   // V x (tx0 | ty0<<16, tx1 | ty1<<16), strip-local tile coords
     uint32_t *tile_count;          // V
+    float *zwin;                   // V window depth of each sorted splat (written only while a scene depth buffer is set)
+    float *scene_depth; uint32_t *scene_rgba; int scene_w, scene_h;   // gs_set_scene
     uint2 *pair_a, *pair_b; size_t pair_cap;   // (tile id, sorted position) records, ping-pong
     uint2 *tile_range; size_t tile_cap;     // per tile [start,end) into the sorted pair list
     uint8_t *fb; size_t fb_cap;             // RGBA8 strip

@@ -74,7 +74,7 @@ __global__ __launch_bounds__(GS_BLOCK) void k_project(const uint32_t *__restrict
                                                       GsFrameUniforms u, gsm::Projected *__restrict__ proj, uint2 *__restrict__ rect,
                                                       uint32_t *__restrict__ tile_count, uint32_t *__restrict__ spine,
                                                       uint32_t *__restrict__ part_vis, const uint32_t *__restrict__ mask,
-                                                      const GsControl *ctl)
+                                                      float *__restrict__ zwin, const GsControl *ctl)
 {
     __shared__ float s_rec[GS_BLOCK][6];
     __shared__ uint32_t s_rows[GS_BLOCK], s_j[GS_BLOCK];
@@ -111,6 +111,7 @@ __global__ __launch_bounds__(GS_BLOCK) void k_project(const uint32_t *__restrict
                     float4 *dst = reinterpret_cast<float4 *>(proj + j);
                     dst[0] = make_float4(p.cx, p.cy, p.ax, p.ay);
                     dst[1] = make_float4(p.bx, p.by, __uint_as_float(p.rgba), p.alpha);
+                    if (u.has_depth) zwin[j] = x.zndc * 0.5f + 0.5f;           // gl_FragCoord.z of every fragment of the quad
                     if (ty1 - ty0 >= 16) {                                  // > 16 tile rows: count cooperatively
                         const uint32_t q = atomicAdd(&s_nbig, 1u);
                         s_rec[q][0] = p.cx; s_rec[q][1] = p.cy; s_rec[q][2] = p.ax; s_rec[q][3] = p.ay; s_rec[q][4] = p.bx; s_rec[q][5] = p.by;
@@ -350,13 +351,17 @@ __global__ __launch_bounds__(GS_BLOCK) void k_tile_ranges(const uint2 *__restric
 typedef float f2 __attribute__((ext_vector_type(2)));            // two pixels per packed-fp32 instruction (v_pk_*_f32)
 __device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
 
-template <bool COUNT, int ROUND>
+// SCENE: the opaque scene's depth buffer (fragment kept iff its window depth <= the buffer: depthTest LEQUAL,
+// depthWrite off, index.js:179-180) and/or colour image (the destination the splats are blended over).
+template <bool COUNT, int ROUND, bool SCENE>
 __global__ __launch_bounds__(64) void k_blend(const uint2 *__restrict__ tile_range, const uint2 *__restrict__ pairs,
                                               const gsm::Projected *__restrict__ proj, GsFrameUniforms u,
                                               uint8_t *__restrict__ out, float4 *__restrict__ state, uint32_t *__restrict__ mask,
-                                              GsControl *ctl)
+                                              const float *__restrict__ zwin, const float *__restrict__ scene_depth,
+                                              const uint32_t *__restrict__ scene_rgba, GsControl *ctl)
 {
     __shared__ float4 s_rec[2 * GS_BLEND_BATCH + 2];             // 4 KiB: one batch of projected records (+1 inert slot)
+    __shared__ float s_z[GS_BLEND_BATCH + 2];                    // their window depths (SCENE only)
     const int lane = threadIdx.x;
     if (ROUND == 1 && ctl->j_hi == 0) return;                      // every tile saturated in round 0
     const uint32_t ntiles = (uint32_t)u.tiles_x * (uint32_t)u.tiles_y;
@@ -376,6 +381,15 @@ __global__ __launch_bounds__(64) void k_blend(const uint2 *__restrict__ tile_ran
     f2 crA = { 0, 0 }, crB = { 0, 0 }, cgA = { 0, 0 }, cgB = { 0, 0 }, cbA = { 0, 0 }, cbB = { 0, 0 }, caA = { 0, 0 }, caB = { 0, 0 };
     f2 qmA = { (row_in && xb < u.x1) ? 4.0f : -1.0f, (row_in && xb + 1 < u.x1) ? 4.0f : -1.0f };
     f2 qmB = { (row_in && xb + 2 < u.x1) ? 4.0f : -1.0f, (row_in && xb + 3 < u.x1) ? 4.0f : -1.0f };
+    // opaque scene depth under each of the lane's 4 pixels (+inf = nothing in front of the far plane)
+    float zb0 = 3.0e38f, zb1 = 3.0e38f, zb2 = 3.0e38f, zb3 = 3.0e38f;
+    if (SCENE && u.has_depth && row_in) {
+        const float *zr = scene_depth + (size_t)r * u.W + xb;
+        if (xb < u.x1) zb0 = zr[0];
+        if (xb + 1 < u.x1) zb1 = zr[1];
+        if (xb + 2 < u.x1) zb2 = zr[2];
+        if (xb + 3 < u.x1) zb3 = zr[3];
+    }
     float4 *st = state + ((size_t)tile * 64 + lane) * 5;           // 5 x float4 per lane: T, r, g, b, a of its 4 pixels
     if (ROUND == 1) {
         const float4 t = st[0], c0 = st[1], c1 = st[2], c2 = st[3], c3 = st[4];
@@ -399,9 +413,11 @@ __global__ __launch_bounds__(64) void k_blend(const uint2 *__restrict__ tile_ran
                 const float4 *src = reinterpret_cast<const float4 *>(proj + j);
                 s_rec[2 * slot] = src[0];
                 s_rec[2 * slot + 1] = src[1];
+                if (SCENE) s_z[slot] = u.has_depth ? zwin[j] : 0.0f;
             }
         }
-        if (lane == 0 && (nb & 1)) {                               // pad an odd batch with a record no pixel can pass
+        if (lane == 0 && (nb & 1)) {
+            if (SCENE) s_z[nb] = 0.0f;                               // pad an odd batch with a record no pixel can pass
             s_rec[2 * nb] = make_float4(-1.0e9f, -1.0e9f, 1.0f, 1.0f);   // centre far away, a = (1,1): q ~ 1e18 > 4
             s_rec[2 * nb + 1] = make_float4(1.0f, 1.0f, 0.0f, 0.0f);
         }
@@ -423,9 +439,10 @@ __global__ __launch_bounds__(64) void k_blend(const uint2 *__restrict__ tile_ran
                 const f2 pyA1 = fma2(dxA1, (f2)(b1.x), (f2)(dyby1)), pyB1 = fma2(dxB1, (f2)(b1.x), (f2)(dyby1));
                 const f2 qA0 = fma2(pxA0, pxA0, pyA0 * pyA0), qB0 = fma2(pxB0, pxB0, pyB0 * pyB0);   // -A, index.js:171
                 const f2 qA1 = fma2(pxA1, pxA1, pyA1 * pyA1), qB1 = fma2(pxB1, pxB1, pyB1 * pyB1);
-#define GS_BLEND_APPLY(qA, qB, bb)                                                                                     \
+#define GS_BLEND_APPLY(qA, qB, bb, zz)                                                                                 \
                 {                                                                                                      \
-                    const bool p0 = qA.x <= qmA.x, p1 = qA.y <= qmA.y, p2 = qB.x <= qmB.x, p3 = qB.y <= qmB.y;         \
+                    bool p0 = qA.x <= qmA.x, p1 = qA.y <= qmA.y, p2 = qB.x <= qmB.x, p3 = qB.y <= qmB.y;               \
+                    if (SCENE) { p0 = p0 && zz <= zb0; p1 = p1 && zz <= zb1; p2 = p2 && zz <= zb2; p3 = p3 && zz <= zb3; } \
                     if (p0 | p1 | p2 | p3) {                           /* discard test, index.js:172 */                \
                         const float alpha = bb.w;                                                                      \
                         const uint32_t rgba = __float_as_uint(bb.z);                                                   \
@@ -446,8 +463,9 @@ __global__ __launch_bounds__(64) void k_blend(const uint2 *__restrict__ tile_ran
                         qmB.x = TB.x < t_eps ? -1.0f : qmB.x; qmB.y = TB.y < t_eps ? -1.0f : qmB.y;                    \
                     }                                                                                                  \
                 }
-                GS_BLEND_APPLY(qA0, qB0, b0)
-                GS_BLEND_APPLY(qA1, qB1, b1)
+                const float z0 = SCENE ? s_z[s] : 0.0f, z1 = SCENE ? s_z[s + 1] : 0.0f;
+                GS_BLEND_APPLY(qA0, qB0, b0, z0)
+                GS_BLEND_APPLY(qA1, qB1, b1, z1)
 #undef GS_BLEND_APPLY
                 if (!(fmaxf(fmaxf(qmA.x, qmA.y), fmaxf(qmB.x, qmB.y)) > 0.0f)) break;
             }
@@ -477,8 +495,14 @@ __global__ __launch_bounds__(64) void k_blend(const uint2 *__restrict__ tile_ran
         uint32_t px[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            const float o0 = fmaf(Tk[k], u.bg[0], rk[k]), o1 = fmaf(Tk[k], u.bg[1], gk[k]);
-            const float o2 = fmaf(Tk[k], u.bg[2], bk[k]), o3 = fmaf(Tk[k], u.bg[3], ak[k]);
+            float b0 = u.bg[0], b1 = u.bg[1], b2 = u.bg[2], b3 = u.bg[3];
+            if (SCENE && u.has_scene_rgba && xb + k < u.x1) {      // destination = the opaque scene's colour at this pixel
+                const uint32_t c = scene_rgba[(size_t)r * u.W + xb + k];
+                b0 = (float)(c & 0xFF) / 255.0f; b1 = (float)((c >> 8) & 0xFF) / 255.0f;
+                b2 = (float)((c >> 16) & 0xFF) / 255.0f; b3 = (float)(c >> 24) / 255.0f;
+            }
+            const float o0 = fmaf(Tk[k], b0, rk[k]), o1 = fmaf(Tk[k], b1, gk[k]);
+            const float o2 = fmaf(Tk[k], b2, bk[k]), o3 = fmaf(Tk[k], b3, ak[k]);
             px[k] = (uint32_t)(fminf(fmaxf(o0, 0.0f), 1.0f) * 255.0f + 0.5f) |
                     ((uint32_t)(fminf(fmaxf(o1, 0.0f), 1.0f) * 255.0f + 0.5f) << 8) |
                     ((uint32_t)(fminf(fmaxf(o2, 0.0f), 1.0f) * 255.0f + 0.5f) << 16) |
@@ -516,7 +540,7 @@ int run_round(gs_ctx *ctx, const GsFrameUniforms &u, uint8_t *out, bool last_rou
     if (ROUND == 1 && g > small) g = small;
     const uint32_t pc = ROUND == 1 ? (uint32_t)(small * GS_CHUNK) : (uint32_t)ctx->pair_cap;      // grid hint for the radix kernels
     hipLaunchKernelGGL(k_project<ROUND>, dim3(g), dim3(GS_BLOCK), 0, st, ctx->sorted, ctx->splat, u, ctx->proj, ctx->rect,
-                       ctx->tile_count, ctx->spine, ctx->part_vis, ctx->unsat_mask, ctx->ctl);
+                       ctx->tile_count, ctx->spine, ctx->part_vis, ctx->unsat_mask, ctx->zwin, ctx->ctl);
     GS_HIP(hipGetLastError());
     if (ROUND == 0) GS_PROF_RECORD(ctx, 3);
     hipLaunchKernelGGL(k_pairs_check<ROUND>, dim3(1), dim3(GS_BLOCK), 0, st, ctx->ctl, (uint32_t)ctx->pair_cap, ctx->spine, ctx->part_vis, g,
@@ -543,12 +567,12 @@ int run_round(gs_ctx *ctx, const GsFrameUniforms &u, uint8_t *out, bool last_rou
     GS_HIP(hipGetLastError());
     if (ROUND == 0) GS_PROF_RECORD(ctx, 4);
     const uint32_t gb = ROUND == 1 ? (ntiles < 1024 ? ntiles : 1024) : ntiles;
-    if (u.flags & GS_RENDER_COUNT_FRAGS)
-        hipLaunchKernelGGL((k_blend<true, ROUND>), dim3(gb), dim3(64), 0, st, ctx->tile_range, fpairs, ctx->proj, u, out,
-                           ctx->state, ctx->unsat_mask, ctx->ctl);
-    else
-        hipLaunchKernelGGL((k_blend<false, ROUND>), dim3(gb), dim3(64), 0, st, ctx->tile_range, fpairs, ctx->proj, u, out,
-                           ctx->state, ctx->unsat_mask, ctx->ctl);
+    const bool scene = u.has_depth || u.has_scene_rgba;
+#define GS_LAUNCH_BLEND(C, S) hipLaunchKernelGGL((k_blend<C, ROUND, S>), dim3(gb), dim3(64), 0, st, ctx->tile_range, fpairs, ctx->proj, u, \
+                                                out, ctx->state, ctx->unsat_mask, ctx->zwin, ctx->scene_depth, ctx->scene_rgba, ctx->ctl)
+    if (u.flags & GS_RENDER_COUNT_FRAGS) { if (scene) GS_LAUNCH_BLEND(true, true); else GS_LAUNCH_BLEND(true, false); }
+    else { if (scene) GS_LAUNCH_BLEND(false, true); else GS_LAUNCH_BLEND(false, false); }
+#undef GS_LAUNCH_BLEND
     GS_HIP(hipGetLastError());
     return GS_OK;
 }
@@ -586,8 +610,12 @@ int gs_run_render(gs_ctx *ctx, const GsFrameUniforms &u, uint8_t *device_out)
         GS_HIP(hipMemsetAsync(ctx->tile_range, 0, sizeof(uint2) * ntiles, st));
         GsFrameUniforms ub = u; ub.near_count = 0xFFFFFFFFu;
         GS_PROF_RECORD(ctx, 3); GS_PROF_RECORD(ctx, 4);
-        hipLaunchKernelGGL((k_blend<false, 0>), dim3(ntiles), dim3(64), 0, st, ctx->tile_range, ctx->pair_a, ctx->proj, ub, out,
-                           ctx->state, ctx->unsat_mask, ctx->ctl);
+        if (ub.has_scene_rgba)
+            hipLaunchKernelGGL((k_blend<false, 0, true>), dim3(ntiles), dim3(64), 0, st, ctx->tile_range, ctx->pair_a, ctx->proj, ub, out,
+                               ctx->state, ctx->unsat_mask, ctx->zwin, ctx->scene_depth, ctx->scene_rgba, ctx->ctl);
+        else
+            hipLaunchKernelGGL((k_blend<false, 0, false>), dim3(ntiles), dim3(64), 0, st, ctx->tile_range, ctx->pair_a, ctx->proj, ub, out,
+                               ctx->state, ctx->unsat_mask, ctx->zwin, ctx->scene_depth, ctx->scene_rgba, ctx->ctl);
         GS_HIP(hipGetLastError());
         GS_PROF_RECORD(ctx, 5);
     }

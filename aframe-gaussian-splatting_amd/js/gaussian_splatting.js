@@ -139,6 +139,10 @@ class GaussianSplatting {
     return native.render(this.handle, p);
   }
 
+  // The opaque scene three.js draws before the transparent splat mesh: window-space depth (depthTest: true,
+  // depthWrite: false, index.js:179-180) and colour.  Float32Array / Uint8Array of width*height(*4), row 0 = top.
+  setScene(depth, rgba, width, height) { native.setScene(this.handle, depth || null, rgba || null, width || 0, height || 0); }
+
   // createWorker (index.js:488-599): same message protocol, GPU-backed.  `self` needs postMessage; onmessage is installed.
   createWorker(self) {
     const h = native.create(this.device);

@@ -282,6 +282,24 @@ static napi_value fn_render(napi_env env, napi_callback_info info)
     return ta;
 }
 
+/* setScene(h, depthFloat32Array | null, rgbaUint8Array | null, width, height): the opaque scene the splats are depth-tested
+ * against (depthTest: true, index.js:179) and blended over */
+static napi_value fn_set_scene(napi_env env, napi_callback_info info)
+{
+    napi_value argv[5];
+    if (!get_args(env, info, 5, argv, NULL)) return NULL;
+    gs_ctx *ctx = get_ctx(env, argv[0]); if (!ctx) return NULL;
+    void *d = NULL, *c = NULL; size_t dl = 0, cl = 0; int32_t w = 0, h = 0;
+    if (!is_nullish(env, argv[1]) && !get_bytes(env, argv[1], &d, &dl)) { napi_throw_type_error(env, NULL, "depth: expected a Float32Array"); return NULL; }
+    if (!is_nullish(env, argv[2]) && !get_bytes(env, argv[2], &c, &cl)) { napi_throw_type_error(env, NULL, "rgba: expected a Uint8Array"); return NULL; }
+    if (!is_nullish(env, argv[3])) NAPI_OK(napi_get_value_int32(env, argv[3], &w));
+    if (!is_nullish(env, argv[4])) NAPI_OK(napi_get_value_int32(env, argv[4], &h));
+    if ((d && dl < (size_t)w * h * 4) || (c && cl < (size_t)w * h * 4)) { napi_throw_range_error(env, NULL, "setScene: buffer smaller than width*height"); return NULL; }
+    int rc = gs_set_scene(ctx, (const float *)d, (const uint8_t *)c, w, h);
+    if (rc != GS_OK) return throw_gs(env, ctx, rc);
+    return NULL;
+}
+
 static napi_value fn_stats(napi_env env, napi_callback_info info)
 {
     napi_value argv[1], o, v;
@@ -380,7 +398,7 @@ static napi_value init(napi_env env, napi_value exports)
     static const struct { const char *name; napi_callback fn; } fns[] = {
         { "create", fn_create }, { "destroy", fn_destroy }, { "clear", fn_clear }, { "pushSplat", fn_push_splat },
         { "pushMatrices", fn_push_matrices }, { "loadPly", fn_load_ply }, { "plyToSplat", fn_ply_to_splat }, { "count", fn_count },
-        { "sort", fn_sort }, { "render", fn_render }, { "stats", fn_stats }, { "setOption", fn_set_option },
+        { "sort", fn_sort }, { "render", fn_render }, { "setScene", fn_set_scene }, { "stats", fn_stats }, { "setOption", fn_set_option },
         { "modelViewMatrix", fn_model_view }, { "projectionMatrix", fn_projection }, { "tickUniforms", fn_tick },
         { "scaledSize", fn_scaled_size },
     };

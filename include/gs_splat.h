@@ -121,6 +121,14 @@ GS_API int gs_render_device(gs_ctx *ctx, const gs_render_params *p, void *device
 /* XR: two eyes share one sort order from the head camera (index.js:441) -- two params, two images. */
 GS_API int gs_render_stereo(gs_ctx *ctx, const gs_render_params eyes[2], uint8_t *rgba_out[2], size_t stride);
 
+/* Scene compositing inputs (reference: the splat mesh is drawn in three.js' transparent pass with depthTest: true,
+ * depthWrite: false over the opaque scene, index.js:177-181): an optional window-space depth buffer of that scene
+ * (GL convention: 0 = near plane, 1 = far plane; a fragment survives iff its depth zndc*0.5+0.5 <= the buffer, LEQUAL)
+ * and an optional RGBA8 colour image that replaces the constant background.  Both fb_width x fb_height, tightly packed,
+ * row 0 = top, host memory (copied); NULL for either = not used; gs_set_scene(ctx, NULL, NULL, 0, 0) clears.
+ * Renders whose fb_width/fb_height differ from the scene's fail with GS_E_BADARG. */
+GS_API int gs_set_scene(gs_ctx *ctx, const float *depth, const uint8_t *rgba, int fb_width, int fb_height);
+
 /* Block until all work queued on the context's stream is done; collects the status and statistics of frames
  * rendered with GS_RENDER_ASYNC (GS_E_RETRY if one of them overflowed the pair buffers). */
 GS_API int gs_sync(gs_ctx *ctx);

@@ -351,14 +351,21 @@ GSO_API void gso_project(const float *center_scale, const uint32_t *cov_color, u
  * final rounding to RGBA8.  Output rows are top-down (row 0 = top of the
  * image); x0..x1 selects a column strip (multi-GPU tests).  `frags` counts the
  * reference-equivalent splat-fragments (|p|^2 <= 4, index.js:171-172). */
-GSO_API int gso_render(const float *center_scale, const uint32_t *cov_color, const uint32_t *sorted, size_t V,
-                       const float mv[16], const float P[16], float focal, int W, int H, int x0, int x1,
-                       const float bg[4], float *out_f32, uint8_t *out_u8, uint64_t *frags)
+GSO_API int gso_render_scene(const float *center_scale, const uint32_t *cov_color, const uint32_t *sorted, size_t V,
+                             const float mv[16], const float P[16], float focal, int W, int H, int x0, int x1,
+                             const float bg[4], const float *scene_depth /* W*H window depth, row 0 = top, or NULL */,
+                             const uint8_t *scene_rgba /* W*H*4, row 0 = top, or NULL */,
+                             float *out_f32, uint8_t *out_u8, uint64_t *frags)
 {
     const int SW = x1 - x0;
     float *fb = (float *)malloc(sizeof(float) * 4 * (size_t)SW * H);
     if (!fb) return -1;
-    for (size_t i = 0; i < (size_t)SW * H; i++) memcpy(fb + 4 * i, bg, 4 * sizeof(float));
+    for (int r = 0; r < H; r++)
+        for (int i = 0; i < SW; i++) {
+            float *d = fb + 4 * ((size_t)r * SW + i);
+            if (scene_rgba) for (int k = 0; k < 4; k++) d[k] = (float)scene_rgba[4 * ((size_t)r * W + x0 + i) + k] / 255.0f;
+            else memcpy(d, bg, 4 * sizeof(float));
+        }
     uint64_t nf = 0;
     for (size_t s = 0; s < V; s++) {
         gso_proj_t p;
@@ -370,9 +377,13 @@ GSO_API int gso_render(const float *center_scale, const uint32_t *cov_color, con
         int ix0 = lo < x0 ? x0 : (lo > x1 ? x1 : (int)lo), ix1 = hi > x1 - 1 ? x1 - 1 : (hi < x0 - 1 ? x0 - 1 : (int)hi);
         lo = floor((double)p.cy - hh); hi = ceil((double)p.cy + hh);
         int iy0 = lo < 0 ? 0 : (lo > H ? H : (int)lo), iy1 = hi > H - 1 ? H - 1 : (hi < -1 ? -1 : (int)hi);
+        /* depthTest: true, depthWrite: false (index.js:179-180): every fragment of the quad carries the same window
+         * depth zndc*0.5+0.5 and survives iff it is <= the opaque scene's depth (LEQUAL) */
+        const float zwin = p.zndc * 0.5f + 0.5f;
         for (int j = iy0; j <= iy1; j++) {
             const float dy = ((float)j + 0.5f) - p.cy;
             for (int i = ix0; i <= ix1; i++) {
+                if (scene_depth && !(zwin <= scene_depth[(size_t)(H - 1 - j) * W + i])) continue;
                 const float dx = ((float)i + 0.5f) - p.cx;
                 const float ppx = fmaf(dx, p.ax, dy * p.ay);
                 const float ppy = fmaf(dx, p.bx, dy * p.by);
@@ -396,6 +407,13 @@ GSO_API int gso_render(const float *center_scale, const uint32_t *cov_color, con
     if (frags) *frags = nf;
     free(fb);
     return 0;
+}
+
+GSO_API int gso_render(const float *center_scale, const uint32_t *cov_color, const uint32_t *sorted, size_t V,
+                       const float mv[16], const float P[16], float focal, int W, int H, int x0, int x1,
+                       const float bg[4], float *out_f32, uint8_t *out_u8, uint64_t *frags)
+{
+    return gso_render_scene(center_scale, cov_color, sorted, V, mv, P, focal, W, H, x0, x1, bg, NULL, NULL, out_f32, out_u8, frags);
 }
 
 /* ------------------------------------------------------------------ PLY -> .splat rows (index.js:600-745) */

@@ -48,6 +48,10 @@ def lib():
         L.gso_render.restype = C.c_int
         L.gso_render.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_float,
                                  C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.gso_render_scene.restype = C.c_int
+        L.gso_render_scene.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_float,
+                                       C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.c_void_p]
         L.gso_ply_to_splat.restype = C.c_int
         L.gso_ply_to_splat.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_size_t), C.c_char_p, C.c_size_t]
         _lib = L
@@ -123,8 +127,10 @@ def project(cs, cc, idx, mv, proj, focal_, vw, vh):
     return o
 
 
-def render(cs, cc, sorted_idx, mv, proj, focal_, W, H, x0=0, x1=None, bg=(0, 0, 0, 1), want_f32=True):
-    """-> (rgba8 [H,SW,4] top-down, f32 image or None, fragment count)"""
+def render(cs, cc, sorted_idx, mv, proj, focal_, W, H, x0=0, x1=None, bg=(0, 0, 0, 1), want_f32=True, scene_depth=None,
+           scene_rgba=None):
+    """-> (rgba8 [H,SW,4] top-down, f32 image or None, fragment count).  scene_depth [H,W] f32 window depth and
+    scene_rgba [H,W,4] u8 are the opaque scene the splats are depth-tested against / composited over."""
     x1 = W if x1 is None else x1
     cs = np.ascontiguousarray(cs, np.float32)
     cc = np.ascontiguousarray(cc, np.uint32)
@@ -136,8 +142,10 @@ def render(cs, cc, sorted_idx, mv, proj, focal_, W, H, x0=0, x1=None, bg=(0, 0, 
     u8 = np.zeros((H, sw, 4), np.uint8)
     f32 = np.zeros((H, sw, 4), np.float32) if want_f32 else None
     fr = C.c_uint64(0)
-    rc = lib().gso_render(_p(cs), _p(cc), _p(si), si.size, _p(mv), _p(proj), float(np.float32(focal_)), W, H, x0, x1,
-                          _p(bg), _p(f32), _p(u8), C.byref(fr))
+    sd = None if scene_depth is None else np.ascontiguousarray(scene_depth, np.float32)
+    sc = None if scene_rgba is None else np.ascontiguousarray(scene_rgba, np.uint8)
+    rc = lib().gso_render_scene(_p(cs), _p(cc), _p(si), si.size, _p(mv), _p(proj), float(np.float32(focal_)), W, H, x0, x1,
+                                _p(bg), _p(sd), _p(sc), _p(f32), _p(u8), C.byref(fr))
     if rc != 0:
         raise MemoryError("gso_render")
     return u8, f32, fr.value

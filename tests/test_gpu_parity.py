@@ -439,3 +439,46 @@ def test_c5_twenty_million_splats_4k():
         ref, _, _ = oracle.render(cs, cc, idx, mv, P, focal, 3840, 2160, x0=1900, x1=1964, want_f32=False)
         assert np.abs(full[:, 1900:1964].astype(int) - ref.astype(int)).max() <= PIXEL_TOL_LSB
         print("C5 stats:", st)
+
+
+def test_scene_depth_and_colour_compositing(ctx, scene_small):
+    """depthTest: true / depthWrite: false over an opaque scene (index.js:177-181): splat fragments behind the scene's
+    depth are rejected (LEQUAL), the rest is blended over the scene's colour.  Same fragments as the oracle, exactly."""
+    w, h = 400, 225
+    cam = synth.index_html_camera(w, h, 60.0, capi=capi)
+    ctx.clear(); ctx.push_splat(scene_small["rows"])
+    idx = ctx.sort(cam["view"])
+    yy, xx = np.mgrid[0:h, 0:w]
+    depth = np.full((h, w), 1.0, np.float32)
+    ball = (xx - 150) ** 2 + (yy - 100) ** 2 < 70 ** 2                       # an opaque "sphere" in the middle distance
+    depth[ball] = 0.9950 + 0.004 * ((xx[ball] - 150) ** 2 + (yy[ball] - 100) ** 2) / 70.0 ** 2
+    depth[:, 300:] = 0.0                                                    # a wall at the near plane: hides everything
+    rgba = np.zeros((h, w, 4), np.uint8)
+    rgba[..., 0] = (xx * 255 // w).astype(np.uint8); rgba[..., 2] = (yy * 255 // h).astype(np.uint8); rgba[..., 3] = 255
+    rgba[ball] = (239, 45, 94, 255)                                          # the demo spheres' colour (index.html:10-11)
+    mv, P, focal = _f32(cam)
+    want, _, frags = oracle.render(scene_small["cs"], scene_small["cc"], idx, mv, P, focal, w, h, scene_depth=depth, scene_rgba=rgba)
+    plain, _, frags_plain = oracle.render(scene_small["cs"], scene_small["cc"], idx, mv, P, focal, w, h)
+    assert frags < frags_plain
+    ctx.set_scene(depth, rgba)
+    try:
+        got = ctx.render(_params(cam))
+        assert np.abs(got.astype(int) - want.astype(int)).max() <= PIXEL_TOL_LSB
+        assert np.array_equal(got[:, 300:], rgba[:, 300:])                   # behind the wall: the scene untouched
+        ctx.render(_params(cam, flags=capi.RENDER_COUNT_FRAGS))
+        assert ctx.stats()["n_frags"] == frags
+        strips = [ctx.render(_params(cam, x0=a, x1=b)) for a, b in ((0, 208), (208, 400))]
+        assert np.array_equal(np.concatenate(strips, axis=1), got)
+        for pm in (1000, 50):                                               # both binning modes
+            ctx.set_option(capi.OPT_NEAR_PERMILLE, pm)
+            assert np.array_equal(ctx.render(_params(cam)), got)
+        ctx.set_option(capi.OPT_NEAR_PERMILLE, 0)
+        with pytest.raises(capi.GsError) as ei:                              # scene size must match the frame
+            ctx.render(_params(synth.index_html_camera(320, 180, 0.0, capi=capi)))
+        assert ei.value.code == capi.E_BADARG
+        ctx.set_scene(depth, None)                                           # depth only: constant background
+        want2, _, _ = oracle.render(scene_small["cs"], scene_small["cc"], idx, mv, P, focal, w, h, scene_depth=depth)
+        assert np.abs(ctx.render(_params(cam)).astype(int) - want2.astype(int)).max() <= PIXEL_TOL_LSB
+    finally:
+        ctx.set_scene(None, None)
+    assert np.abs(ctx.render(_params(cam)).astype(int) - plain.astype(int)).max() <= PIXEL_TOL_LSB

@@ -85,3 +85,21 @@ def test_camera_matches_reference(name):
     if "cutout" in c:
         assert np.array_equal(cut.view(np.uint32), c["cutout"].view(np.uint32))
     assert oracle.focal(pr, c["viewport"][1]) == c["focal"][0]
+
+
+def test_oracle_scene_depth_semantics():
+    """depthTest LEQUAL / depthWrite off (index.js:179-180) in the pixel oracle: a depth buffer at the far plane changes
+    nothing, one at the near plane rejects every fragment and leaves the scene colour."""
+    from conftest import pkg
+    synth = pkg("synth")
+    rows = synth.make_splat_rows(2000, seed=4)
+    cs, cc, mats = oracle.pack(rows)
+    cam = synth.index_html_camera(160, 90, 20.0)
+    idx = oracle.sort(mats, cam["view"])
+    mv, P = cam["gs_mv"].astype(np.float32), cam["gs_proj"].astype(np.float32)
+    base, _, n0 = oracle.render(cs, cc, idx, mv, P, cam["focal"], 160, 90)
+    far, _, n1 = oracle.render(cs, cc, idx, mv, P, cam["focal"], 160, 90, scene_depth=np.ones((90, 160), np.float32))
+    assert n0 == n1 > 0 and np.array_equal(base, far)
+    col = np.random.default_rng(1).integers(0, 256, (90, 160, 4)).astype(np.uint8)
+    near, _, n2 = oracle.render(cs, cc, idx, mv, P, cam["focal"], 160, 90, scene_depth=np.zeros((90, 160), np.float32), scene_rgba=col)
+    assert n2 == 0 and np.array_equal(near, col)
