@@ -507,6 +507,7 @@ GS_API int gs_set_option(gs_ctx *ctx, int option, int64_t value)
         ctx->near_fixed_permille = (int)value;
         if (value == 0) ctx->near_frac = 0.25f;
         return GS_OK;
+    case GS_OPT_RECORD_STAGED: ctx->dbg[1] = value ? 3 : 0; return GS_OK;
     case GS_OPT_TERMINATION:
         if (value < 2) FAIL(GS_E_BADARG, "termination 1/eps must be >= 2");
         ctx->t_eps = 1.0f / (float)value; return GS_OK;
@@ -543,7 +544,7 @@ GS_API int gs_download(gs_ctx *ctx, int which, void *out, size_t nbytes)
     case GS_BUF_SORTED: src = ctx->sorted; have = ctx->have_sort ? V * 4 : 0; break;
     case GS_BUF_PROJECTED: src = ctx->proj; have = ctx->have_sort ? V * 32 : 0; break;
     case GS_BUF_TILE_COUNT: src = ctx->tile_count; have = ctx->have_sort ? V * 4 : 0; break;
-    case 6: src = ctx->tile_range; have = ctx->tile_cap * 8; break;        // tile ranges (debugging)
+    case GS_BUF_TILE_STATS: src = ctx->tile_range; have = ctx->tile_cap * 8; break;
     default: FAIL(GS_E_BADARG, "unknown buffer %d", which);
     }
     if (nbytes > have) FAIL(GS_E_BADARG, "buffer %d holds %zu bytes, %zu requested", which, have, nbytes);

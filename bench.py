@@ -39,8 +39,13 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--splats", type=int, default=None, help="override N (default: train.splat-shaped 1,048,576)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--size", default=None, help="override the viewport, e.g. 3840x2160 (default 1920x1080)")
+    ap.add_argument("--cutout", action="store_true", help="cutout-demo.html pose with the cutoutEntity box (config C3)")
     args = ap.parse_args()
 
+    global W, H
+    if args.size:
+        W, H = (int(v) for v in args.size.lower().split("x"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -73,7 +78,8 @@ def main():
     # tile-aligned column strips
     x0, x1 = mg.strip_bounds(W, world, rank)
 
-    cams = [synth.index_html_camera(W, H, 360.0 * i / ORBIT_FRAMES, capi=capi) for i in range(ORBIT_FRAMES)]
+    pose = synth.cutout_demo_camera if args.cutout else synth.index_html_camera
+    cams = [pose(W, H, 360.0 * i / ORBIT_FRAMES, capi=capi) for i in range(ORBIT_FRAMES)]
     params = [capi.make_params(c["gs_mv"], c["gs_proj"], W, H, x0=x0, x1=x1, focal_=c["focal"]) for c in cams]
     strip = gathered = None
     if multi:
@@ -86,7 +92,7 @@ def main():
 
     def frame(i, flags=0):
         k = i % ORBIT_FRAMES
-        ctx.sort(cams[k]["view"], want_indices=False)
+        ctx.sort(cams[k]["view"], cams[k]["cutout"], want_indices=False)
         p = params[k]
         p.flags = flags
         if multi:
@@ -127,6 +133,23 @@ def main():
 
     # frames are enqueued back to back like the reference's render loop (GS_RENDER_ASYNC); gs_sync() at the end of
     # the region collects their status (an overflowing pair buffer would surface there as GS_E_RETRY)
+    # list entries the blend really stages before its tiles saturate (untimed measurement aid, sampled over 8 poses of the
+    # region, rank 0's strip): the byte count behind `roofline.achieved_touched`
+    staged_per_frame = None
+    if rank == 0:
+        ctx.set_option(capi.OPT_RECORD_STAGED, 1)
+        ctx.set_option(capi.OPT_NEAR_PERMILLE, 1000)
+        tot = []
+        ntl = ((x1 - x0 + 15) // 16) * ((H + 15) // 16)
+        for k in frames_used[:: max(1, len(frames_used) // 8)][:8]:
+            ctx.sort(cams[k]["view"], cams[k]["cutout"], want_indices=False)
+            params[k].flags = 0
+            ctx.render_device(params[k], strip.data_ptr() if multi else None)
+            tot.append(int(ctx.download(capi.BUF_TILE_STATS, ntl, np.uint32, 2)[:, 0].astype(np.int64).sum()))
+        staged_per_frame = float(np.mean(tot))
+        ctx.set_option(capi.OPT_RECORD_STAGED, 0)
+        ctx.set_option(capi.OPT_NEAR_PERMILLE, 0)
+
     # adaptation pre-roll (untimed, like the fragment counting above): one synchronous pass over the poses of the timed
     # region lets the library settle the share of splats it bins in its first, nearest-splats round for every pose
     retries = 0
@@ -174,6 +197,8 @@ def main():
         blend_bytes = (pairs / K) * 36.0 + 4.0 * sw * H
         blend_s = stage["ms_blend"] / K * 1e-3
         achieved = blend_bytes / blend_s / 1e9 if blend_s > 0 else 0.0
+        touched_bytes = staged_per_frame * 36.0 + 4.0 * sw * H
+        achieved_touched = touched_bytes / blend_s / 1e9 if blend_s > 0 else 0.0
         # whole-frame algorithmic bytes (SURVEY.md 8d formula)
         V, Vp, I = sorted_n / K, visible / K, pairs / K
         frame_bytes = (16 * n_splats + 4 * V) + (Vp * 36 + V * 4 + Vp * 32) + (I * 20) + (I * 36 + 4 * sw * H)
@@ -189,7 +214,8 @@ def main():
             "value": round(fps, 3), "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
             "ms_per_step": round(elapsed / K * 1e3, 4), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "train.splat-shaped synthetic, N=%d splats, %dx%d, 120-frame orbit (index.html:13 pose)" % (n_splats, W, H),
+            "config": {"workload": "train.splat-shaped synthetic, N=%d splats, %dx%d, 120-frame orbit (%s)" % (
+                           n_splats, W, H, "cutout-demo.html:22-24 pose + cutoutEntity box" if args.cutout else "index.html:13 pose"),
                        "parallelism": "column strips x%d, splat buffer replicated, RCCL gather" % world if world > 1 else "single GPU",
                        "strip_px": sw},
             "occlusion_binning": {"near_permille": s["near_permille"], "unsat_tiles_last_frame": s["unsat_tiles"],
@@ -205,10 +231,15 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "traffic_note": "HBM bytes/launch = 2*FETCH_SIZE + WRITE_SIZE from separate rocprofv3 --pmc passes "
                                          "(profiles/r01_pmc_hbm_traffic.md); early termination reads far less than the algorithmic 36*I",
-                         "bytes_per_launch": round(blend_bytes), "avg_launch_ms": round(blend_s * 1e3, 4)},
+                         "bytes_per_launch": round(blend_bytes), "avg_launch_ms": round(blend_s * 1e3, 4),
+                         "achieved_touched": round(achieved_touched, 2), "touched_bytes_per_launch": round(touched_bytes),
+                         "touched_note": "36 B x the list entries the kernel actually stages before its tiles saturate (early "
+                                         "termination) + the RGBA8 write; `achieved` uses the full algorithmic 36*I of the contract"},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(rows, cams[args.warmup % ORBIT_FRAMES], synth)
+        if args.size or args.cutout or args.splats:
+            out["metric"] = out["metric"].replace("@1920x1080", "@%dx%d" % (W, H)).replace("1M-splat", "%d-splat" % n_splats)
         print(json.dumps(out), flush=True)
     ctx.close()
     if multi:
@@ -225,15 +256,16 @@ def cpu_baseline(rows, cam, synth):
     rows4 = np.ascontiguousarray(mats[:, 12:16])
     ts = []
     for _ in range(5):
-        t = time.perf_counter(); idx = oracle.sort(rows4, cam["view"]); ts.append(time.perf_counter() - t)
+        t = time.perf_counter(); idx = oracle.sort(rows4, cam["view"], cam["cutout"]); ts.append(time.perf_counter() - t)
     t_sort = float(np.median(ts))
     t = time.perf_counter()
+    xa = (W // 2 - W // 16) // 16 * 16
     _, _, fr = oracle.render(cs, cc, idx, cam["gs_mv"].astype(np.float32), cam["gs_proj"].astype(np.float32), cam["focal"], W, H,
-                             x0=840, x1=1080, want_f32=False)
+                             x0=xa, x1=xa + W // 8, want_f32=False)
     t_strip = time.perf_counter() - t
     return {"value": round(1.0 / (t_sort + 8 * t_strip), 5), "unit": "frames/s", "cores": 1, "kind": "port",
-            "sample": "oracle/gs_oracle.c, 1 thread: median of 5 sorts of all %d splats (%.1f ms, %.1f Msplat/s) + one 240-px "
-                      "centre strip of one 1080p frame (%.2f s, %d frags) scaled x8" % (rows4.shape[0], t_sort * 1e3,
+            "sample": "oracle/gs_oracle.c, 1 thread: median of 5 sorts of all %d splats (%.1f ms, %.1f Msplat/s) + one 1/8-width "
+                      "centre strip of one frame (%.2f s, %d frags) scaled x8" % (rows4.shape[0], t_sort * 1e3,
                                                                                       rows4.shape[0] / t_sort / 1e6, t_strip, fr),
             "sort_msplat_per_s": round(rows4.shape[0] / t_sort / 1e6, 2), "host_cpus": os.cpu_count()}
 

@@ -179,6 +179,8 @@ typedef struct gs_stats {
 #define GS_OPT_TERMINATION 2    /* value = 1/eps for the transmittance early-out (default 4096)          */
 #define GS_OPT_NEAR_PERMILLE 3  /* occlusion-aware binning: 0 = adapt (default), 1..999 = bin that share of the nearest
                                    splats first and the rest only against unsaturated tiles, 1000 = single round      */
+#define GS_OPT_RECORD_STAGED 4  /* value != 0: each render overwrites the tile-range table with (list entries staged,
+                                   list length) per tile, readable with gs_download(GS_BUF_TILE_STATS) (measurement aid) */
 GS_API int gs_set_option(gs_ctx *ctx, int option, int64_t value);
 GS_API int gs_get_stats(gs_ctx *ctx, gs_stats *out);
 
@@ -189,6 +191,7 @@ GS_API int gs_get_stats(gs_ctx *ctx, gs_stats *out);
 #define GS_BUF_SORTED 3       /* V u32       last sort result                                           */
 #define GS_BUF_PROJECTED 4    /* V x 8 f32   projected records of the last render (sorted order)         */
 #define GS_BUF_TILE_COUNT 5   /* V u32       tiles touched per sorted splat in the last render            */
+#define GS_BUF_TILE_STATS 6   /* tiles x 2 u32  (entries staged, list length) after a GS_OPT_RECORD_STAGED render  */
 GS_API int gs_download(gs_ctx *ctx, int which, void *out, size_t nbytes);
 
 #ifdef __cplusplus
