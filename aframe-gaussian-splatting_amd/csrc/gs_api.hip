@@ -136,7 +136,7 @@ static int collect_status(gs_ctx *ctx, bool *overflowed)
     ctx->stats.acc_pairs = c->acc_pairs;
     // Adapt the share of splats binned in round 0.  An "event" = a frame whose round 0 left tiles unsaturated (round 1
     // re-binned for them): the share grows x1.5 and will never again shrink below 1.3 x the share that failed; without
-    // events it shrinks 2 % per collected frame.  After 16 clean frames round 1 is not even launched (11 empty kernels
+    // events it shrinks 10 % per collected frame until the first event, 2 % afterwards.  After 16 clean frames round 1 is not even launched (11 empty kernels
     // cost ~50 us): blend<0> raises round1_missed if that was wrong, and the frame is completed / re-rendered.
     if (ctx->near_fixed_permille <= 0 && ctx->stats.n_tiles) {
         const uint32_t events = c->unsat_events - ctx->seen_unsat_events;
@@ -150,7 +150,9 @@ static int collect_status(gs_ctx *ctx, bool *overflowed)
                 ctx->near_frac = nf; ctx->clean_frames = 0; ctx->skip_hold = 32;
             } else {
                 ctx->clean_frames += (uint32_t)(frames ? frames : 1);
-                float nf = ctx->near_frac * 0.98f; if (nf < ctx->near_floor) nf = ctx->near_floor; if (nf < 0.05f) nf = 0.05f;
+                // fast descent (x0.9) until a share has proved too small once, then a slow drift (x0.98) above the floor
+                float nf = ctx->near_frac * (ctx->near_floor > 0.0f ? 0.98f : 0.9f);
+                if (nf < ctx->near_floor) nf = ctx->near_floor; if (nf < 0.02f) nf = 0.02f;
                 if (nf < ctx->near_frac) ctx->near_frac = nf;
                 if (ctx->skip_hold) ctx->skip_hold--;
             }
