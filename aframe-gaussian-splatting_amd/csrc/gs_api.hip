@@ -198,7 +198,6 @@ GS_API int gs_create(int device, gs_ctx **out)
     if (!ctx) { snprintf(g_create_err, sizeof g_create_err, "out of host memory"); return GS_E_OOM; }
     memset(ctx, 0, sizeof *ctx);
     ctx->device = device; ctx->renderable = true; ctx->t_eps = 1.0f / 4096.0f; ctx->near_frac = 0.25f;
-    for (int i = 0; i < 4; i++) { char nm[16]; snprintf(nm, sizeof nm, "GS_DBG%d", i); const char *e = getenv(nm); ctx->dbg[i] = e ? atoi(e) : 0; }
 #define CREATE_HIP(call) do { hipError_t _e = (call); if (_e != hipSuccess) {                                              \
         snprintf(g_create_err, sizeof g_create_err, "%s failed: %s", #call, hipGetErrorString(_e)); gs_destroy(ctx);      \
         return GS_E_HIP; } } while (0)
@@ -348,7 +347,7 @@ static int fill_uniforms(gs_ctx *ctx, const gs_render_params *p, GsFrameUniforms
     u.focal = p->focal > 0 ? p->focal : (float)(((double)p->fb_height / 2.0) * fabs((double)p->projection[5]));
     u.tiles_x = (p->x1 - p->x0 + GS_TILE - 1) / GS_TILE; u.tiles_y = (p->fb_height + GS_TILE - 1) / GS_TILE;
     memcpy(u.bg, p->background, sizeof u.bg);
-    u.t_eps = ctx->t_eps; u.flags = p->flags; u.dbg0 = ctx->dbg[0]; u.dbg1 = ctx->dbg[1];
+    u.t_eps = ctx->t_eps; u.flags = p->flags; u.record_staged = ctx->record_staged ? 1u : 0u;
     u.mask_words = (uint32_t)(u.tiles_x + 31) / 32;
     // round 0 covers the nearest near_frac * N splats; counting / no-early-out renders need every fragment -> one round
     const float frac = ctx->near_fixed_permille > 0 ? ctx->near_fixed_permille / 1000.0f : ctx->near_frac;
@@ -509,7 +508,7 @@ GS_API int gs_set_option(gs_ctx *ctx, int option, int64_t value)
         ctx->near_fixed_permille = (int)value;
         if (value == 0) ctx->near_frac = 0.25f;
         return GS_OK;
-    case GS_OPT_RECORD_STAGED: ctx->dbg[1] = value ? 3 : 0; return GS_OK;
+    case GS_OPT_RECORD_STAGED: ctx->record_staged = value != 0; return GS_OK;
     case GS_OPT_TERMINATION:
         if (value < 2) FAIL(GS_E_BADARG, "termination 1/eps must be >= 2");
         ctx->t_eps = 1.0f / (float)value; return GS_OK;

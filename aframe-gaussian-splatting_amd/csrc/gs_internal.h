@@ -53,7 +53,7 @@ struct GsFrameUniforms {           // per-render constants, passed by value to k
     float bg[4];
     float t_eps;                   // early-out threshold on transmittance
     uint32_t flags;
-    int32_t dbg0, dbg1;            // experiment knobs (0 = default)
+    uint32_t record_staged;        // GS_OPT_RECORD_STAGED: blend overwrites the tile-range table with (staged, length)
     uint32_t near_count;           // round 0 bins the nearest near_count splats; 0xFFFFFFFF = single round (everything)
     uint32_t mask_words;           // 32-bit words per tile row of the unsaturated-tile mask
     uint32_t skip_round1;          // round 1 is not launched for this frame (optimistic; blend<0> raises round1_missed)
@@ -115,7 +115,7 @@ struct gs_ctx {
 
     // options / stats
     bool profile;
-    int dbg[4];                    // experiment knobs from env GS_DBG0..3 (0 = default behaviour)
+    bool record_staged;            // GS_OPT_RECORD_STAGED
     float t_eps;
     // profiling ring: GS_PROF_RING slots x GS_PROF_EVENTS events (sort begin/end, render begin, after project, after
     // binning, after blend of round 0, end of round 1)

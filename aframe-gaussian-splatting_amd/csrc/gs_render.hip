@@ -399,12 +399,12 @@ __global__ __launch_bounds__(64) void k_blend(const uint2 *__restrict__ tile_ran
         qmA.x = TA.x < t_eps ? -1.0f : qmA.x; qmA.y = TA.y < t_eps ? -1.0f : qmA.y;     // pixels that terminated in round 0
         qmB.x = TB.x < t_eps ? -1.0f : qmB.x; qmB.y = TB.y < t_eps ? -1.0f : qmB.y;
     }
-    uint32_t nfr = 0, dbg_steps = 0;
+    uint32_t nfr = 0, staged = 0;
     const uint2 range = tile_range[tile];
 
     for (uint32_t end = range.y; end > range.x;) {
         const uint32_t nb = min((uint32_t)GS_BLEND_BATCH, end - range.x);
-        dbg_steps += nb;
+        staged += nb;
 #pragma unroll
         for (int h = 0; h < GS_BLEND_BATCH / 64; h++) {            // nearest first: reverse the back-to-front list
             const uint32_t slot = h * 64 + lane;
@@ -520,7 +520,7 @@ __global__ __launch_bounds__(64) void k_blend(const uint2 *__restrict__ tile_ran
         for (int m = 32; m >= 1; m >>= 1) nfr += __shfl_xor(nfr, m, 64);
         if (lane == 0 && nfr) atomicAdd(&ctl->n_frags, (unsigned long long)nfr);
     }
-    if (u.dbg1 == 3 && lane == 0) const_cast<uint2 *>(tile_range)[tile] = make_uint2(dbg_steps, range.y - range.x);   // experiment: list entries staged vs list length
+    if (u.record_staged && lane == 0) const_cast<uint2 *>(tile_range)[tile] = make_uint2(staged, range.y - range.x);   // GS_OPT_RECORD_STAGED
     __syncthreads();                                               // s_rec is reused by the next tile of this wave
     }
 }

@@ -1,5 +1,6 @@
 #!/bin/bash
-# usage: tools/ab.sh "<env assignments>" ...   -- one profiled bench per variant, prints the per-kernel averages
+# usage: tools/ab.sh "<env assignments>" ...   -- one profiled bench per variant (e.g. different build flags or
+# environment), prints the per-kernel averages
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
 i=0

@@ -2,7 +2,6 @@
 front-to-back binning would pay."""
 import importlib, os, sys
 import numpy as np
-os.environ["GS_DBG1"] = "3"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 capi = importlib.import_module("aframe-gaussian-splatting_amd.capi"); synth = importlib.import_module("aframe-gaussian-splatting_amd.synth")
 rows = synth.make_splat_rows(synth.N_TRAIN)
