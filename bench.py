@@ -175,6 +175,10 @@ def main():
         if attempt == 3:
             raise RuntimeError("timed region kept asking for a re-render")
         retries += 1
+        if attempt >= 1:
+            # still not settled: pin the first-round share (twice the current one); with a pinned share the second
+            # binning round is always launched, so no frame can come back incomplete
+            ctx.set_option(capi.OPT_NEAR_PERMILLE, min(1000, 2 * max(ctx.stats()["near_permille"], 50)))
         for k in frames_used:                                # synchronous frames let the library re-adapt
             frame(k)
     s = ctx.stats()
