@@ -34,5 +34,19 @@ def gather_strips(strip_flat, width, height, dist, gathered=None, dst=0):
     return torch.cat([g[: height * w * 4].view(height, w, 4) for g, w in zip(gathered, widths) if w > 0], dim=1)
 
 
+def gather_strips_async(strip_flat, dist, gathered, dst=0):
+    """Start the gather of one frame's strips and return the work handle; the caller keeps rendering the next frame
+    into another strip buffer meanwhile (the collective runs on RCCL's own stream) and calls work.wait() before it
+    reuses `strip_flat` / reads `gathered`."""
+    return dist.gather(strip_flat, gathered if dist.get_rank() == dst else None, dst=dst, async_op=True)
+
+
+def assemble(gathered, width, height):
+    """Row-major H x W x 4 frame from the gathered strip buffers (on the gather root)."""
+    import torch
+    widths = strip_widths(width, len(gathered))
+    return torch.cat([g[: height * w * 4].view(height, w, 4) for g, w in zip(gathered, widths) if w > 0], dim=1)
+
+
 def strip_buffer_bytes(width, height, world):
     return height * max(strip_widths(width, world)) * 4

@@ -1,0 +1,14 @@
+#!/bin/bash
+# usage (GPU box, repo root): tools/gpu_pmc.sh <tag>  -- two separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE)
+TAG=${1:-pmc}
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+mkdir -p $R/gpurun_out
+cd /tmp && export TMPDIR=/tmp
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout 600 rocprofv3 --kernel-trace --pmc $c -d $R/gpurun_out/pmc_${TAG}_$c -o pmc -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $R/gpurun_out/pmc_${TAG}_$c.log 2>&1
+  echo "$c rc=$?"
+done
+cd $R
+python tools/pmc_summary.py gpurun_out/pmc_${TAG}_FETCH_SIZE/pmc_results.db gpurun_out/pmc_${TAG}_WRITE_SIZE/pmc_results.db gpurun_out/pmc_$TAG.md gpurun_out/pmc_$TAG.json
+rm -rf gpurun_out/pmc_${TAG}_FETCH_SIZE gpurun_out/pmc_${TAG}_WRITE_SIZE
+head -12 gpurun_out/pmc_$TAG.md
