@@ -347,7 +347,7 @@ static int fill_uniforms(gs_ctx *ctx, const gs_render_params *p, GsFrameUniforms
     u.focal = p->focal > 0 ? p->focal : (float)(((double)p->fb_height / 2.0) * fabs((double)p->projection[5]));
     u.tiles_x = (p->x1 - p->x0 + GS_TILE - 1) / GS_TILE; u.tiles_y = (p->fb_height + GS_TILE - 1) / GS_TILE;
     memcpy(u.bg, p->background, sizeof u.bg);
-    u.t_eps = ctx->t_eps; u.flags = p->flags; u.record_staged = ctx->record_staged ? 1u : 0u;
+    u.t_eps = ctx->t_eps; u.flags = p->flags; u.record_staged = ctx->record_staged;
     u.mask_words = (uint32_t)(u.tiles_x + 31) / 32;
     // round 0 covers the nearest near_frac * N splats; counting / no-early-out renders need every fragment -> one round
     const float frac = ctx->near_fixed_permille > 0 ? ctx->near_fixed_permille / 1000.0f : ctx->near_frac;
@@ -373,7 +373,7 @@ static int render_common(gs_ctx *ctx, const gs_render_params *p, void *device_rg
     if (!ctx->pair_cap) TRY(gs_ensure_pair_capacity(ctx, (size_t)1 << 22));
     const size_t mask_total = (size_t)u.tiles_y * u.mask_words;
     if (mask_total > ctx->mask_cap) { dev_free(ctx->unsat_mask); TRY(dev_alloc(ctx, &ctx->unsat_mask, mask_total)); ctx->mask_cap = mask_total; }
-    if (ntiles * 320 > ctx->state_cap) { dev_free(ctx->state); TRY(dev_alloc(ctx, &ctx->state, ntiles * 320)); ctx->state_cap = ntiles * 320; }
+    if (ntiles * 256 > ctx->state_cap) { dev_free(ctx->state); TRY(dev_alloc(ctx, &ctx->state, ntiles * 256)); ctx->state_cap = ntiles * 256; }
     const bool async = (u.flags & GS_RENDER_ASYNC) && !host_rgba && !(u.flags & GS_RENDER_COUNT_FRAGS);
     ctx->last_two_rounds = u.near_count != 0xFFFFFFFFu && ctx->n && ctx->have_sort;
     ctx->stats.n_tiles = ntiles; ctx->stats.blend_launches = 1;
@@ -508,7 +508,7 @@ GS_API int gs_set_option(gs_ctx *ctx, int option, int64_t value)
         ctx->near_fixed_permille = (int)value;
         if (value == 0) ctx->near_frac = 0.25f;
         return GS_OK;
-    case GS_OPT_RECORD_STAGED: ctx->record_staged = value != 0; return GS_OK;
+    case GS_OPT_RECORD_STAGED: ctx->record_staged = value == 2 ? 2u : (value != 0 ? 1u : 0u); return GS_OK;
     case GS_OPT_TERMINATION:
         if (value < 2) FAIL(GS_E_BADARG, "termination 1/eps must be >= 2");
         ctx->t_eps = 1.0f / (float)value; return GS_OK;

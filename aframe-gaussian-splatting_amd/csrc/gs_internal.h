@@ -98,7 +98,7 @@ struct gs_ctx {
     uint2 *pair_a, *pair_b; size_t pair_cap;   // (tile id, sorted position) records, ping-pong
     uint2 *tile_range; size_t tile_cap;     // per tile [start,end) into the sorted pair list
     uint8_t *fb; size_t fb_cap;             // RGBA8 strip
-    float4 *state; size_t state_cap;        // per tile 64 lanes x 5 float4: (T, r, g, b, a) of each lane's 4 pixels, round 0 -> 1
+    float4 *state; size_t state_cap;        // per tile 64 lanes x 4 float4: (T, r, g, b) of each lane's 4 pixels, round 0 -> 1
     uint32_t *unsat_mask; size_t mask_cap;  // one bit per tile (rows of mask_words words): left unsaturated by round 0
     float near_frac;                        // round 0 covers the nearest near_frac * N splats (adapted from unsat_round0)
     int near_fixed_permille;                // > 0: fixed by GS_OPT_NEAR_PERMILLE instead of adapted
@@ -115,7 +115,7 @@ struct gs_ctx {
 
     // options / stats
     bool profile;
-    bool record_staged;            // GS_OPT_RECORD_STAGED
+    uint32_t record_staged;        // GS_OPT_RECORD_STAGED (1 = entries staged, 2 = entries evaluated)
     float t_eps;
     // profiling ring: GS_PROF_RING slots x GS_PROF_EVENTS events (sort begin/end, render begin, after project, after
     // binning, after blend of round 0, end of round 1)

@@ -347,7 +347,7 @@ __global__ __launch_bounds__(GS_BLOCK) void k_tile_ranges(const uint2 *__restric
 // the list as soon as every pixel has T < t_eps (ballot), one rounding to RGBA8 at the end.
 // ROUND 0 starts from (T = 1, C = 0); a tile that is not saturated when its list ends saves its per-pixel state and
 // sets its bit in the tile mask (if a round 1 follows).  ROUND 1 runs only for masked tiles and resumes from the state.
-#define GS_BLEND_BATCH 128
+#define GS_BLEND_BATCH 64
 typedef float f2 __attribute__((ext_vector_type(2)));            // two pixels per packed-fp32 instruction (v_pk_*_f32)
 __device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
 
@@ -378,7 +378,7 @@ __global__ __launch_bounds__(64) void k_blend(const uint2 *__restrict__ tile_ran
     // 4 while the pixel is live (fragment kept iff q <= 4, index.js:172), -1 once it is outside / terminated
     f2 fxA = { (float)xb + 0.5f, (float)(xb + 1) + 0.5f }, fxB = { (float)(xb + 2) + 0.5f, (float)(xb + 3) + 0.5f };
     f2 TA = { 1.0f, 1.0f }, TB = { 1.0f, 1.0f };
-    f2 crA = { 0, 0 }, crB = { 0, 0 }, cgA = { 0, 0 }, cgB = { 0, 0 }, cbA = { 0, 0 }, cbB = { 0, 0 }, caA = { 0, 0 }, caB = { 0, 0 };
+    f2 crA = { 0, 0 }, crB = { 0, 0 }, cgA = { 0, 0 }, cgB = { 0, 0 }, cbA = { 0, 0 }, cbB = { 0, 0 };
     f2 qmA = { (row_in && xb < u.x1) ? 4.0f : -1.0f, (row_in && xb + 1 < u.x1) ? 4.0f : -1.0f };
     f2 qmB = { (row_in && xb + 2 < u.x1) ? 4.0f : -1.0f, (row_in && xb + 3 < u.x1) ? 4.0f : -1.0f };
     // opaque scene depth under each of the lane's 4 pixels (+inf = nothing in front of the far plane)
@@ -390,16 +390,16 @@ __global__ __launch_bounds__(64) void k_blend(const uint2 *__restrict__ tile_ran
         if (xb + 2 < u.x1) zb2 = zr[2];
         if (xb + 3 < u.x1) zb3 = zr[3];
     }
-    float4 *st = state + ((size_t)tile * 64 + lane) * 5;           // 5 x float4 per lane: T, r, g, b, a of its 4 pixels
+    float4 *st = state + ((size_t)tile * 64 + lane) * 4;           // 4 x float4 per lane: T, r, g, b of its 4 pixels
     if (ROUND == 1) {
-        const float4 t = st[0], c0 = st[1], c1 = st[2], c2 = st[3], c3 = st[4];
+        const float4 t = st[0], c0 = st[1], c1 = st[2], c2 = st[3];
         TA = (f2){ t.x, t.y }; TB = (f2){ t.z, t.w };
         crA = (f2){ c0.x, c0.y }; crB = (f2){ c0.z, c0.w }; cgA = (f2){ c1.x, c1.y }; cgB = (f2){ c1.z, c1.w };
-        cbA = (f2){ c2.x, c2.y }; cbB = (f2){ c2.z, c2.w }; caA = (f2){ c3.x, c3.y }; caB = (f2){ c3.z, c3.w };
+        cbA = (f2){ c2.x, c2.y }; cbB = (f2){ c2.z, c2.w };
         qmA.x = TA.x < t_eps ? -1.0f : qmA.x; qmA.y = TA.y < t_eps ? -1.0f : qmA.y;     // pixels that terminated in round 0
         qmB.x = TB.x < t_eps ? -1.0f : qmB.x; qmB.y = TB.y < t_eps ? -1.0f : qmB.y;
     }
-    uint32_t nfr = 0, staged = 0;
+    uint32_t nfr = 0, staged = 0, evaluated = 0;
     const uint2 range = tile_range[tile];
 
     for (uint32_t end = range.y; end > range.x;) {
@@ -426,7 +426,8 @@ __global__ __launch_bounds__(64) void k_blend(const uint2 *__restrict__ tile_ran
             // Two splats per step: their coverage tests are independent, so the second one's LDS read + ~13-instruction
             // dependent chain overlaps the first one's (the per-step latency, not issue bandwidth, bounds a tile that
             // runs alone in the kernel's tail).  Blending is still applied strictly in list order.
-            for (uint32_t s = 0; s < nb; s += 2) {
+            uint32_t s = 0;
+            for (; s < nb; s += 2) {
                 const float4 a0 = s_rec[2 * s], b0 = s_rec[2 * s + 1];
                 const float4 a1 = s_rec[2 * s + 2], b1 = s_rec[2 * s + 3];     // slot nb holds an inert record when nb is odd
                 const float dy0 = fy - a0.y, dy1 = fy - a1.y;
@@ -444,19 +445,20 @@ __global__ __launch_bounds__(64) void k_blend(const uint2 *__restrict__ tile_ran
                     bool p0 = qA.x <= qmA.x, p1 = qA.y <= qmA.y, p2 = qB.x <= qmB.x, p3 = qB.y <= qmB.y;               \
                     if (SCENE) { p0 = p0 && zz <= zb0; p1 = p1 && zz <= zb1; p2 = p2 && zz <= zb2; p3 = p3 && zz <= zb3; } \
                     if (p0 | p1 | p2 | p3) {                           /* discard test, index.js:172 */                \
-                        const float alpha = bb.w;                                                                      \
+                        const float alpha = bb.w, alpha255 = bb.w * (1.0f / 255.0f);                                   \
                         const uint32_t rgba = __float_as_uint(bb.z);                                                   \
-                        /* B = exp(A) * vColor.a (index.js:173); 0 for the pixels of this lane that the splat misses */ \
-                        const f2 BA = { p0 ? __expf(-qA.x) * alpha : 0.0f, p1 ? __expf(-qA.y) * alpha : 0.0f };        \
-                        const f2 BB = { p2 ? __expf(-qB.x) * alpha : 0.0f, p3 ? __expf(-qB.y) * alpha : 0.0f };        \
-                        const f2 wA = BA * TA, wB = BB * TB;                                                           \
-                        const f2 vA = wA * (1.0f / 255.0f), vB = wB * (1.0f / 255.0f);                                 \
+                        /* exp(A) (index.js:173); 0 for the pixels of this lane that the splat misses */               \
+                        const f2 EA = { p0 ? __expf(-qA.x) : 0.0f, p1 ? __expf(-qA.y) : 0.0f };                        \
+                        const f2 EB = { p2 ? __expf(-qB.x) : 0.0f, p3 ? __expf(-qB.y) : 0.0f };                        \
+                        /* fragment alpha B = exp(A)*vColor.a; its weight under what is in front: w = B*T.  T <- T - w \
+                           (= T*(1-B)), colour += rgb8 * (w/255) */                                                    \
+                        const f2 eA = EA * TA, eB = EB * TB;                                                           \
+                        const f2 vA = eA * alpha255, vB = eB * alpha255;                                               \
+                        TA = fma2((f2)(-alpha), eA, TA); TB = fma2((f2)(-alpha), eB, TB);                              \
                         const float c0 = (float)(rgba & 0xFF), c1 = (float)((rgba >> 8) & 0xFF), c2 = (float)((rgba >> 16) & 0xFF); \
                         crA = fma2((f2)(c0), vA, crA); crB = fma2((f2)(c0), vB, crB);                                  \
                         cgA = fma2((f2)(c1), vA, cgA); cgB = fma2((f2)(c1), vB, cgB);                                  \
                         cbA = fma2((f2)(c2), vA, cbA); cbB = fma2((f2)(c2), vB, cbB);                                  \
-                        caA += wA; caB += wB;                                                                          \
-                        TA *= (1.0f - BA); TB *= (1.0f - BB);                                                          \
                         if (COUNT) nfr += (uint32_t)p0 + (uint32_t)p1 + (uint32_t)p2 + (uint32_t)p3;                   \
                         /* a pixel stops taking fragments once its transmittance is below the threshold */           \
                         qmA.x = TA.x < t_eps ? -1.0f : qmA.x; qmA.y = TA.y < t_eps ? -1.0f : qmA.y;                    \
@@ -469,6 +471,7 @@ __global__ __launch_bounds__(64) void k_blend(const uint2 *__restrict__ tile_ran
 #undef GS_BLEND_APPLY
                 if (!(fmaxf(fmaxf(qmA.x, qmA.y), fmaxf(qmB.x, qmB.y)) > 0.0f)) break;
             }
+            if (u.record_staged == 2) evaluated += min(s + 2, nb);   // list entries this lane evaluated (measurement aid)
         }
         end -= nb;
         __syncthreads();                                           // s_rec is rewritten by the next batch
@@ -479,7 +482,7 @@ __global__ __launch_bounds__(64) void k_blend(const uint2 *__restrict__ tile_ran
         if (__any(fmaxf(fmaxf(qmA.x, qmA.y), fmaxf(qmB.x, qmB.y)) > 0.0f)) {
             st[0] = make_float4(TA.x, TA.y, TB.x, TB.y);
             st[1] = make_float4(crA.x, crA.y, crB.x, crB.y); st[2] = make_float4(cgA.x, cgA.y, cgB.x, cgB.y);
-            st[3] = make_float4(cbA.x, cbA.y, cbB.x, cbB.y); st[4] = make_float4(caA.x, caA.y, caB.x, caB.y);
+            st[3] = make_float4(cbA.x, cbA.y, cbB.x, cbB.y);
             if (lane == 0) {
                 atomicOr(&mask[ty * u.mask_words + (tx >> 5)], 1u << (tx & 31)); atomicAdd(&ctl->unsat_count, 1u);
                 if (u.skip_round1) ctl->round1_missed = 1;           // nobody will come for this tile unless the host notices
@@ -491,7 +494,7 @@ __global__ __launch_bounds__(64) void k_blend(const uint2 *__restrict__ tile_ran
         const int sw = u.x1 - u.x0;
         const int orow = (u.flags & GS_RENDER_FLIP_Y) ? (u.H - 1 - r) : r;
         const float Tk[4] = { TA.x, TA.y, TB.x, TB.y }, rk[4] = { crA.x, crA.y, crB.x, crB.y }, gk[4] = { cgA.x, cgA.y, cgB.x, cgB.y };
-        const float bk[4] = { cbA.x, cbA.y, cbB.x, cbB.y }, ak[4] = { caA.x, caA.y, caB.x, caB.y };
+        const float bk[4] = { cbA.x, cbA.y, cbB.x, cbB.y };
         uint32_t px[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
@@ -502,7 +505,8 @@ __global__ __launch_bounds__(64) void k_blend(const uint2 *__restrict__ tile_ran
                 b2 = (float)((c >> 16) & 0xFF) / 255.0f; b3 = (float)(c >> 24) / 255.0f;
             }
             const float o0 = fmaf(Tk[k], b0, rk[k]), o1 = fmaf(Tk[k], b1, gk[k]);
-            const float o2 = fmaf(Tk[k], b2, bk[k]), o3 = fmaf(Tk[k], b3, ak[k]);
+            // accumulated alpha = sum of the weights w = 1 - T (the weights telescope: T_k = T_{k-1} - w_k)
+            const float o2 = fmaf(Tk[k], b2, bk[k]), o3 = fmaf(Tk[k], b3, 1.0f - Tk[k]);
             px[k] = (uint32_t)(fminf(fmaxf(o0, 0.0f), 1.0f) * 255.0f + 0.5f) |
                     ((uint32_t)(fminf(fmaxf(o1, 0.0f), 1.0f) * 255.0f + 0.5f) << 8) |
                     ((uint32_t)(fminf(fmaxf(o2, 0.0f), 1.0f) * 255.0f + 0.5f) << 16) |
@@ -519,6 +523,11 @@ __global__ __launch_bounds__(64) void k_blend(const uint2 *__restrict__ tile_ran
 #pragma unroll
         for (int m = 32; m >= 1; m >>= 1) nfr += __shfl_xor(nfr, m, 64);
         if (lane == 0 && nfr) atomicAdd(&ctl->n_frags, (unsigned long long)nfr);
+    }
+    if (u.record_staged == 2) {                                    // entries the wave evaluated = its longest-lived lane's
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) evaluated = max(evaluated, (uint32_t)__shfl_xor(evaluated, m, 64));
+        staged = evaluated;
     }
     if (u.record_staged && lane == 0) const_cast<uint2 *>(tile_range)[tile] = make_uint2(staged, range.y - range.x);   // GS_OPT_RECORD_STAGED
     __syncthreads();                                               // s_rec is reused by the next tile of this wave

@@ -180,7 +180,8 @@ typedef struct gs_stats {
 #define GS_OPT_NEAR_PERMILLE 3  /* occlusion-aware binning: 0 = adapt (default), 1..999 = bin that share of the nearest
                                    splats first and the rest only against unsaturated tiles, 1000 = single round      */
 #define GS_OPT_RECORD_STAGED 4  /* value != 0: each render overwrites the tile-range table with (list entries staged,
-                                   list length) per tile, readable with gs_download(GS_BUF_TILE_STATS) (measurement aid) */
+                                   list length) per tile, readable with gs_download(GS_BUF_TILE_STATS) (measurement aid);
+                                   value 2 records the entries the tile evaluated before it saturated instead of staged */
 GS_API int gs_set_option(gs_ctx *ctx, int option, int64_t value);
 GS_API int gs_get_stats(gs_ctx *ctx, gs_stats *out);
 

@@ -6,7 +6,7 @@ capi = importlib.import_module("aframe-gaussian-splatting_amd.capi"); synth = im
 rows = synth.make_splat_rows(synth.N_TRAIN)
 with capi.Context(0) as ctx:
     ctx.push_splat(rows)
-    ctx.set_option(capi.OPT_RECORD_STAGED, 1); ctx.set_option(capi.OPT_NEAR_PERMILLE, 1000)
+    ctx.set_option(capi.OPT_RECORD_STAGED, int(os.environ.get("GS_RECORD", "1"))); ctx.set_option(capi.OPT_NEAR_PERMILLE, 1000)
     cam = synth.index_html_camera(1920, 1080, 0.0, capi=capi)
     ctx.sort(cam["view"])
     ctx.render(capi.make_params(cam["gs_mv"], cam["gs_proj"], 1920, 1080, focal_=cam["focal"]))
