@@ -208,6 +208,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    copy_peak = measured_copy_peak(ctx, capi) if rank == 0 else None
     total_frags = sum(frags[(args.warmup + i) % ORBIT_FRAMES] for i in range(args.steps))
     if rank == 0:
         K = args.steps
@@ -251,6 +252,7 @@ def main():
                           "frac_of_peak": round(frame_bytes * fps / 1e9 / HBM_PEAK_GBS, 5)},
             "roofline": {"kernel": "k_blend", "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                         "measured_copy_GBps": copy_peak,
                          "traffic_note": "HBM bytes/launch = 2*FETCH_SIZE + WRITE_SIZE from separate rocprofv3 --pmc passes "
                                          "(profiles/r01_pmc_hbm_traffic.md); early termination reads far less than the algorithmic 36*I",
                          "bytes_per_launch": round(blend_bytes), "avg_launch_ms": round(blend_s * 1e3, 4),
@@ -285,11 +287,77 @@ def cpu_baseline(rows, cam, synth):
     _, _, fr = oracle.render(cs, cc, idx, cam["gs_mv"].astype(np.float32), cam["gs_proj"].astype(np.float32), cam["focal"], W, H,
                              x0=xa, x1=xa + W // 8, want_f32=False)
     t_strip = time.perf_counter() - t
+    js = js_worker_sort(rows4, cam, idx, oracle)
     return {"value": round(1.0 / (t_sort + 8 * t_strip), 5), "unit": "frames/s", "cores": 1, "kind": "port",
             "sample": "oracle/gs_oracle.c, 1 thread: median of 5 sorts of all %d splats (%.1f ms, %.1f Msplat/s) + one 1/8-width "
                       "centre strip of one frame (%.2f s, %d frags) scaled x8" % (rows4.shape[0], t_sort * 1e3,
                                                                                       rows4.shape[0] / t_sort / 1e6, t_strip, fr),
-            "sort_msplat_per_s": round(rows4.shape[0] / t_sort / 1e6, 2), "host_cpus": os.cpu_count()}
+            "sort_msplat_per_s": round(rows4.shape[0] / t_sort / 1e6, 2), "host_cpus": os.cpu_count(), "cpu_model": cpu_model(),
+            "js_worker_sort": js}
+
+
+def measured_copy_peak(ctx, capi, nbytes=1 << 30, reps=5):
+    """Device-to-device copy rate of this GPU in the same run: GB/s of bytes MOVED (read + write) by
+    hipMemcpyDtoDAsync of a 1 GiB buffer, HIP events around `reps` copies.  The quoted HBM peak stays the 8 TB/s spec."""
+    import ctypes as C
+    try:
+        try:
+            hip = C.CDLL("libamdhip64.so")
+        except OSError:
+            hip = C.CDLL("/opt/rocm/lib/libamdhip64.so")
+        a, b, e0, e1 = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
+        if hip.hipMalloc(C.byref(a), C.c_size_t(nbytes)) or hip.hipMalloc(C.byref(b), C.c_size_t(nbytes)):
+            return None
+        hip.hipMemsetAsync(a, 1, C.c_size_t(nbytes), None); hip.hipMemsetAsync(b, 2, C.c_size_t(nbytes), None)
+        hip.hipEventCreate(C.byref(e0)); hip.hipEventCreate(C.byref(e1))
+        hip.hipMemcpyDtoDAsync(b, a, C.c_size_t(nbytes), None)
+        hip.hipEventRecord(e0, None)
+        for _ in range(reps):
+            hip.hipMemcpyDtoDAsync(b, a, C.c_size_t(nbytes), None)
+        hip.hipEventRecord(e1, None)
+        hip.hipEventSynchronize(e1)
+        ms = C.c_float(0)
+        hip.hipEventElapsedTime(C.byref(ms), e0, e1)
+        hip.hipEventDestroy(e0); hip.hipEventDestroy(e1); hip.hipFree(a); hip.hipFree(b)
+        return round(2.0 * nbytes * reps / (ms.value * 1e-3) / 1e9, 1) if ms.value > 0 else None
+    except Exception:
+        return None
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def js_worker_sort(rows4, cam, idx, oracle):
+    """The reference's sort runs in ONE JavaScript Worker: time oracle/worker_sort.js (a JS restatement of that worker
+    loop, pinned against the reference's golden vectors in tests/) under node on this host, same scene and pose, and check
+    its order against the C oracle's through a position-sensitive checksum.  None if node is not installed."""
+    import shutil
+    import subprocess
+    import tempfile
+    node = shutil.which("node")
+    if not node:
+        return None
+    with tempfile.TemporaryDirectory() as d:
+        rows4.astype("<f4").tofile(os.path.join(d, "rows.f32"))
+        un = [np.asarray(cam["view"], np.float32)] + ([np.asarray(cam["cutout"], np.float32)] if cam["cutout"] is not None else [])
+        np.concatenate(un).astype("<f4").tofile(os.path.join(d, "un.f32"))
+        try:
+            r = subprocess.run([node, os.path.join(ROOT, "oracle", "worker_sort.js"), "bench", os.path.join(d, "rows.f32"),
+                                os.path.join(d, "un.f32"), "5"], capture_output=True, text=True, timeout=300)
+            rep = json.loads(r.stdout.strip().splitlines()[-1])
+        except Exception as e:                                # the baseline is reported, never required
+            return {"error": str(e)[:200]}
+    ok = rep["kept"] == int(idx.size) and rep["order_sum"] == oracle.order_sum(idx)
+    return {"ms_per_sort": round(rep["ms_median"], 3), "msplat_per_s": round(rows4.shape[0] / rep["ms_median"] / 1e3, 2),
+            "cores": 1, "runtime": "node " + subprocess.run([node, "--version"], capture_output=True, text=True).stdout.strip(),
+            "matches_c_oracle": bool(ok), "sample": "median of 5 sorts of all %d splats, 64-byte worker rows" % rows4.shape[0]}
 
 
 if __name__ == "__main__":

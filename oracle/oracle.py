@@ -76,6 +76,13 @@ def sort(rows, view, cutout=None):
     return out[:v].copy()
 
 
+def order_sum(idx):
+    """Position-sensitive checksum of a sorted-index array: sum of value * (position + 1) mod 2^32 (oracle/worker_sort.js
+    prints the same figure for the JS restatement)."""
+    idx = np.asarray(idx, dtype=np.uint64)
+    return int((idx * np.arange(1, idx.size + 1, dtype=np.uint64) & np.uint64(0xFFFFFFFF)).sum() & np.uint64(0xFFFFFFFF))
+
+
 def pack(rows_bytes):
     rows = np.ascontiguousarray(np.frombuffer(bytes(rows_bytes), dtype=np.uint8))
     n = rows.size // 32

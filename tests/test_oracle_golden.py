@@ -18,6 +18,36 @@ def test_sort_matches_reference_worker(name):
     assert np.array_equal(got, c["sorted"])
 
 
+def test_js_worker_restatement_matches_reference_worker():
+    """oracle/worker_sort.js (the JS-worker CPU baseline bench.py times under node) against the same golden vectors."""
+    import json, os, shutil, subprocess
+    from conftest import GOLDEN, ROOT
+    node = shutil.which("node")
+    if not node:
+        pytest.skip("node not installed")
+    r = subprocess.run([node, os.path.join(ROOT, "oracle", "worker_sort.js"), "check", GOLDEN], capture_output=True, text=True, timeout=120)
+    rep = json.loads(r.stdout.strip().splitlines()[-1])
+    assert r.returncode == 0 and rep["failures"] == [] and rep["cases"] >= 12, (r.stdout, r.stderr)
+
+
+def test_js_worker_bench_mode_agrees_with_c_oracle(tmp_path):
+    import json, os, shutil, subprocess
+    from conftest import ROOT
+    node = shutil.which("node")
+    if not node:
+        pytest.skip("node not installed")
+    c = load_case("sort_n4096_cutout")
+    rows = c["rows4"].reshape(-1, 4)
+    rows.astype("<f4").tofile(tmp_path / "rows.f32")
+    np.concatenate([c["view"], c["cutout"]]).astype("<f4").tofile(tmp_path / "un.f32")
+    r = subprocess.run([node, os.path.join(ROOT, "oracle", "worker_sort.js"), "bench", str(tmp_path / "rows.f32"), str(tmp_path / "un.f32"), "2"],
+                       capture_output=True, text=True, timeout=120)
+    rep = json.loads(r.stdout.strip().splitlines()[-1])
+    want = oracle.sort(rows, c["view"], c["cutout"])
+    assert rep["n"] == rows.shape[0] and rep["kept"] == want.size
+    assert rep["order_sum"] == oracle.order_sum(want)
+
+
 def test_sort_full_matrix_stride():
     c = load_case("sort_n4096")
     rows = c["rows4"].reshape(-1, 4)
