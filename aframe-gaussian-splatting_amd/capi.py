@@ -18,7 +18,7 @@ BUF_CENTER_SCALE, BUF_COV_COLOR, BUF_SORT_ROWS, BUF_SORTED, BUF_PROJECTED, BUF_T
 
 EXPORTS = [
     "gs_create", "gs_destroy", "gs_last_error", "gs_version", "gs_clear", "gs_push_splat", "gs_push_matrices", "gs_load_ply",
-    "gs_ply_to_splat", "gs_count", "gs_sort", "gs_render", "gs_render_device", "gs_render_stereo", "gs_set_scene", "gs_sync",
+    "gs_ply_to_splat", "gs_ply_to_splat_gpu", "gs_count", "gs_sort", "gs_render", "gs_render_device", "gs_render_stereo", "gs_set_scene", "gs_sync",
     "gs_set_stream",
     "gs_model_view_matrix", "gs_projection_matrix", "gs_tick_uniforms", "gs_focal", "gs_scaled_size", "gs_set_option",
     "gs_get_stats", "gs_download",
@@ -76,6 +76,7 @@ def load(build_if_missing=True):
     L.gs_push_matrices.argtypes = [vp, vp, sz]
     L.gs_load_ply.argtypes = [vp, vp, sz]
     L.gs_ply_to_splat.argtypes = [vp, sz, vp, C.POINTER(sz), C.c_char_p, sz]
+    L.gs_ply_to_splat_gpu.argtypes = [vp, vp, sz, vp, C.POINTER(sz)]
     L.gs_count.argtypes = [vp]; L.gs_count.restype = sz
     L.gs_sort.argtypes = [vp, vp, vp, vp, u32p]
     L.gs_render.argtypes = [vp, C.POINTER(RenderParams), vp, sz]
@@ -203,6 +204,16 @@ class Context:
         if m.size % 16:
             raise ValueError("matrices must be a multiple of 16 floats")
         self._ck(self._L.gs_push_matrices(self._h, _p(m), m.size // 16))
+
+    def ply_to_splat(self, ply_bytes):
+        """processPlyBuffer on this context's GPU -> uint8[32 * n] (same bytes as the host converter)."""
+        buf = np.frombuffer(bytes(ply_bytes), np.uint8)
+        n = C.c_size_t(0)
+        self._ck(self._L.gs_ply_to_splat_gpu(self._h, _p(buf), buf.size, None, C.byref(n)))
+        out = np.zeros(n.value * 32, np.uint8)
+        if n.value:
+            self._ck(self._L.gs_ply_to_splat_gpu(self._h, _p(buf), buf.size, _p(out), C.byref(n)))
+        return out
 
     def load_ply(self, ply_bytes):
         buf = np.frombuffer(bytes(ply_bytes), np.uint8)

@@ -6,6 +6,7 @@
 #include <new>
 #include <vector>
 #include "gs_internal.h"
+#include "gs_ply.h"
 #include "gs_host_tables.h"
 
 static thread_local char g_create_err[512] = "";
@@ -35,6 +36,15 @@ static int ensure_scan_scratch(gs_ctx *ctx)
     if (ph > need_hist) need_hist = ph;
     if (need_hist > ctx->hist_cap) { dev_free(ctx->hist); TRY(dev_alloc(ctx, &ctx->hist, need_hist)); ctx->hist_cap = need_hist; }
     size_t need_spine = gs_div_up(need_hist, GS_CHUNK) + gs_div_up(ctx->cap, GS_BLOCK) + GS_RADIX_MAX_BINS + 16;   // project/emit chunks of 256
+    if (need_spine > ctx->spine_cap) { dev_free(ctx->spine); TRY(dev_alloc(ctx, &ctx->spine, need_spine)); ctx->spine_cap = need_spine; }
+    return GS_OK;
+}
+
+int gs_ensure_radix_scratch(gs_ctx *ctx, size_t items)
+{
+    const size_t need_hist = (size_t)GS_RADIX_MAX_BINS * (gs_div_up(items, GS_CHUNK) + 1);
+    if (need_hist > ctx->hist_cap) { dev_free(ctx->hist); TRY(dev_alloc(ctx, &ctx->hist, need_hist)); ctx->hist_cap = need_hist; }
+    const size_t need_spine = GS_RADIX_MAX_BINS + 16;
     if (need_spine > ctx->spine_cap) { dev_free(ctx->spine); TRY(dev_alloc(ctx, &ctx->spine, need_spine)); ctx->spine_cap = need_spine; }
     return GS_OK;
 }
@@ -258,6 +268,18 @@ GS_API int gs_clear(gs_ctx *ctx)
 
 GS_API size_t gs_count(const gs_ctx *ctx) { return ctx ? ctx->n : 0; }
 
+// pack `nrows` .splat rows that already sit in device memory behind the resident splats (capacity ensured by the caller)
+static int append_device_rows(gs_ctx *ctx, const uint4 *rows_dev, size_t nrows)
+{
+    int rc = gs_launch_pack(ctx, rows_dev, ctx->n, nrows);
+    const hipError_t e = hipStreamSynchronize(ctx->stream);
+    if (rc == GS_OK && e != hipSuccess) { snprintf(ctx->err, sizeof ctx->err, "pack failed: %s", hipGetErrorString(e)); rc = GS_E_HIP; }
+    if (rc != GS_OK) return rc;
+    ctx->n += nrows; ctx->renderable = true; ctx->have_sort = false;
+    ctx->stats.n_splats = ctx->n;
+    return GS_OK;
+}
+
 GS_API int gs_push_splat(gs_ctx *ctx, const void *rows, size_t nrows)
 {
     CHECK_CTX(ctx);
@@ -271,14 +293,10 @@ GS_API int gs_push_splat(gs_ctx *ctx, const void *rows, size_t nrows)
     hipError_t e = hipMemcpyAsync(stage, rows, nrows * 32, hipMemcpyHostToDevice, ctx->stream);
     int rc = GS_OK;
     if (e != hipSuccess) { snprintf(ctx->err, sizeof ctx->err, "upload failed: %s", hipGetErrorString(e)); rc = GS_E_HIP; }
-    if (rc == GS_OK) rc = gs_launch_pack(ctx, stage, ctx->n, nrows);
-    e = hipStreamSynchronize(ctx->stream);
-    if (rc == GS_OK && e != hipSuccess) { snprintf(ctx->err, sizeof ctx->err, "pack failed: %s", hipGetErrorString(e)); rc = GS_E_HIP; }
+    if (rc == GS_OK) rc = append_device_rows(ctx, stage, nrows);
+    else (void)hipStreamSynchronize(ctx->stream);
     dev_free(stage);
-    if (rc != GS_OK) return rc;
-    ctx->n += nrows; ctx->renderable = true; ctx->have_sort = false;
-    ctx->stats.n_splats = ctx->n;
-    return GS_OK;
+    return rc;
 }
 
 GS_API int gs_push_matrices(gs_ctx *ctx, const float *matrices, size_t nrows)
@@ -297,18 +315,64 @@ GS_API int gs_push_matrices(gs_ctx *ctx, const float *matrices, size_t nrows)
     return GS_OK;
 }
 
+// .ply -> .splat rows on the GPU (gs_ply.hip); rows_dev receives a device buffer of *nrows x 32 B that the caller frees.
+// A NaN importance (engine-defined order in the reference) is handed to the host converter so that there is ONE
+// definition of that case.
+static int ply_rows_to_device(gs_ctx *ctx, const void *bytes, size_t nbytes, uint4 **rows_dev, size_t *nrows)
+{
+    *rows_dev = nullptr; *nrows = 0;
+    gsm::PlyLayout L;
+    size_t n = 0, data_start = 0;
+    int rc = gs_ply_plan(bytes, nbytes, &L, &n, &data_start, ctx->err, sizeof ctx->err);
+    *nrows = n;
+    if (rc != GS_OK || !n) return rc;
+    GS_HIP(hipSetDevice(ctx->device));
+    uint4 *rows = nullptr;
+    TRY(dev_alloc(ctx, &rows, n * 2));
+    bool had_nan = false;
+    rc = gs_ply_rows_device(ctx, (const uint8_t *)bytes + data_start, L, n, rows, &had_nan);
+    if (rc == GS_OK && had_nan) {
+        std::vector<uint8_t> host;
+        try { host.resize(n * 32); } catch (...) { dev_free(rows); FAIL(GS_E_OOM, "out of host memory for %zu rows", n); }
+        rc = gs_ply_to_splat(bytes, nbytes, host.data(), &n, ctx->err, sizeof ctx->err);
+        if (rc == GS_OK && hipMemcpy(rows, host.data(), n * 32, hipMemcpyHostToDevice) != hipSuccess) {
+            snprintf(ctx->err, sizeof ctx->err, "upload failed"); rc = GS_E_HIP;
+        }
+    }
+    if (rc != GS_OK) { dev_free(rows); return rc; }
+    *rows_dev = rows;
+    return GS_OK;
+}
+
 GS_API int gs_load_ply(gs_ctx *ctx, const void *bytes, size_t nbytes)
 {
     CHECK_CTX(ctx);
     if (!bytes) FAIL(GS_E_BADARG, "gs_load_ply: bytes is NULL");
-    size_t n = 0;
-    int rc = gs_ply_to_splat(bytes, nbytes, nullptr, &n, ctx->err, sizeof ctx->err);
-    if (rc != GS_OK) return rc;
-    std::vector<uint8_t> rows;
-    try { rows.resize(n * 32); } catch (...) { FAIL(GS_E_OOM, "out of host memory for %zu rows", n); }
-    rc = gs_ply_to_splat(bytes, nbytes, rows.data(), &n, ctx->err, sizeof ctx->err);
-    if (rc != GS_OK) return rc;
-    return gs_push_splat(ctx, rows.data(), n);
+    if (!ctx->renderable && ctx->n) FAIL(GS_E_STATE, "gs_load_ply after gs_push_matrices: mixed ingest is not supported");
+    uint4 *rows = nullptr; size_t n = 0;
+    TRY(ply_rows_to_device(ctx, bytes, nbytes, &rows, &n));
+    if (!n) return GS_OK;
+    int rc = ensure_capacity(ctx, ctx->n + n);
+    if (rc == GS_OK) rc = append_device_rows(ctx, rows, n);         // the rows never leave HBM
+    dev_free(rows);
+    return rc;
+}
+
+GS_API int gs_ply_to_splat_gpu(gs_ctx *ctx, const void *bytes, size_t nbytes, void *out_rows, size_t *out_nrows)
+{
+    CHECK_CTX(ctx);
+    if (!bytes || !out_nrows) FAIL(GS_E_BADARG, "gs_ply_to_splat_gpu: NULL argument");
+    if (!out_rows) {                                             // size query: header + property checks only
+        gsm::PlyLayout L; size_t ds = 0;
+        return gs_ply_plan(bytes, nbytes, &L, out_nrows, &ds, ctx->err, sizeof ctx->err);
+    }
+    uint4 *rows = nullptr;
+    TRY(ply_rows_to_device(ctx, bytes, nbytes, &rows, out_nrows));
+    if (!*out_nrows) return GS_OK;
+    const hipError_t e = hipMemcpy(out_rows, rows, *out_nrows * 32, hipMemcpyDeviceToHost);
+    dev_free(rows);
+    if (e != hipSuccess) FAIL(GS_E_HIP, "download failed: %s", hipGetErrorString(e));
+    return GS_OK;
 }
 
 GS_API int gs_sort(gs_ctx *ctx, const float view[4], const float *cutout16, uint32_t *out_idx, uint32_t *out_n)

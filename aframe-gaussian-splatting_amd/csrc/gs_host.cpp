@@ -10,6 +10,7 @@
 #include <string>
 #include <vector>
 #include "../../include/gs_splat.h"
+#include "gs_ply.h"
 
 namespace {
 
@@ -60,7 +61,7 @@ void flip_y(double *e) { e[1] *= -1.0; e[4] *= -1.0; e[6] *= -1.0; e[9] *= -1.0;
 
 // ---------------------------------------------------------------- PLY
 
-enum PType { P_F64, P_I32, P_U32, P_F32, P_I16, P_U16, P_U8, P_I8 };
+typedef gsm::PlyType PType;
 const size_t kSize[] = { 8, 4, 4, 4, 2, 2, 1, 1 };
 
 struct Prop { std::string name; PType type; size_t offset; };
@@ -78,34 +79,10 @@ struct Header {
 
 PType parse_type(const std::string &t)       // TYPE_MAP, anything else reads as getInt8 (index.js:613-628)
 {
-    if (t == "double") return P_F64; if (t == "int") return P_I32; if (t == "uint") return P_U32; if (t == "float") return P_F32;
-    if (t == "short") return P_I16; if (t == "ushort") return P_U16; if (t == "uchar") return P_U8;
-    return P_I8;
-}
-
-double read_le(const uint8_t *p, PType t)
-{
-    switch (t) {
-    case P_F64: { double v; memcpy(&v, p, 8); return v; }
-    case P_I32: { int32_t v; memcpy(&v, p, 4); return v; }
-    case P_U32: { uint32_t v; memcpy(&v, p, 4); return v; }
-    case P_F32: { float v; memcpy(&v, p, 4); return v; }
-    case P_I16: { int16_t v; memcpy(&v, p, 2); return v; }
-    case P_U16: { uint16_t v; memcpy(&v, p, 2); return v; }
-    case P_U8: return *p;
-    default: return (int8_t)*p;
-    }
-}
-
-// Uint8ClampedArray element store: clamp to [0,255], round half to even, NaN -> 0
-uint8_t to_clamped_u8(double v)
-{
-    if (!(v > 0)) return 0;
-    if (v >= 255) return 255;
-    const double f = floor(v), d = v - f;
-    if (d > 0.5) return (uint8_t)(f + 1);
-    if (d < 0.5) return (uint8_t)f;
-    return (uint8_t)((((int)f) & 1) ? f + 1 : f);
+    if (t == "double") return gsm::PLY_F64; if (t == "int") return gsm::PLY_I32; if (t == "uint") return gsm::PLY_U32;
+    if (t == "float") return gsm::PLY_F32; if (t == "short") return gsm::PLY_I16; if (t == "ushort") return gsm::PLY_U16;
+    if (t == "uchar") return gsm::PLY_U8;
+    return gsm::PLY_I8;
 }
 
 int fail(char *err, size_t errlen, int code, const char *fmt, const char *arg = "")
@@ -196,80 +173,76 @@ GS_API void gs_scaled_size(int css_w, int css_h, double ratio, int *out_w, int *
     if (out_h) *out_h = css_h;
 }
 
-GS_API int gs_ply_to_splat(const void *bytes, size_t nbytes, void *out_rows, size_t *out_nrows, char *err, size_t errlen)
+// Header parse + resolution of every property processPlyBuffer reads, with the reference's error messages in the
+// reference's order (index.js:606-607 header, :643 "<prop> not found").  Shared by the host converter below and the
+// HIP converter (gs_ply.hip).
+int gs_ply_plan(const void *bytes, size_t nbytes, gsm::PlyLayout *layout, size_t *nrows, size_t *data_start, char *err, size_t errlen)
 {
-    if (!bytes || !out_nrows) return fail(err, errlen, GS_E_BADARG, "gs_ply_to_splat: NULL argument");
     const uint8_t *buf = (const uint8_t *)bytes;
     Header h;
     int rc = parse_header(buf, nbytes, h, err, errlen);
     if (rc != GS_OK) return rc;
     const size_t n = h.vertex_count;
-    const uint8_t *data = buf + h.data_start;
     if (n && h.row_bytes * n > nbytes - h.data_start)
         return fail(err, errlen, GS_E_PLY_DATA, "Offset is outside the bounds of the DataView");
-    auto at = [&](size_t row, const Prop *p) { return read_le(data + row * h.row_bytes + p->offset, p->type); };
-#define NEED(var, nm) const Prop *var = h.find(nm); if (!var) return fail(err, errlen, GS_E_PLY_PROP, "%s not found", nm)
+    gsm::PlyLayout L;
+    memset(&L, 0, sizeof L);
+    L.row_bytes = (uint32_t)h.row_bytes;
+    auto need = [&](int slot, const char *nm) -> bool {
+        const Prop *p = h.find(nm);
+        if (!p) { fail(err, errlen, GS_E_PLY_PROP, "%s not found", nm); return false; }
+        L.offset[slot] = (uint32_t)p->offset; L.type[slot] = (uint8_t)p->type;
+        return true;
+    };
+    L.has_scale = h.find("scale_0") != nullptr;
+    L.has_dc = h.find("f_dc_0") != nullptr;
+    L.has_opacity = h.find("opacity") != nullptr;
+    *nrows = n; *data_start = h.data_start; *layout = L;
+    // importance pass (index.js:656-664) touches scale_0..2 and opacity; it only runs when there are rows
+    if (L.has_scale && n) {
+        if (!need(gsm::PP_S0, "scale_0") || !need(gsm::PP_S1, "scale_1") || !need(gsm::PP_S2, "scale_2") || !need(gsm::PP_OPACITY, "opacity"))
+            return GS_E_PLY_PROP;
+    }
+    if (!n) return GS_OK;
+    // row pass (index.js:680-742)
+    if (L.has_scale) {
+        if (!need(gsm::PP_R0, "rot_0") || !need(gsm::PP_R1, "rot_1") || !need(gsm::PP_R2, "rot_2") || !need(gsm::PP_R3, "rot_3")) return GS_E_PLY_PROP;
+        if (!need(gsm::PP_S0, "scale_0") || !need(gsm::PP_S1, "scale_1") || !need(gsm::PP_S2, "scale_2")) return GS_E_PLY_PROP;
+    }
+    if (!need(gsm::PP_X, "x") || !need(gsm::PP_Y, "y") || !need(gsm::PP_Z, "z")) return GS_E_PLY_PROP;
+    if (L.has_dc) { if (!need(gsm::PP_C0, "f_dc_0") || !need(gsm::PP_C1, "f_dc_1") || !need(gsm::PP_C2, "f_dc_2")) return GS_E_PLY_PROP; }
+    else { if (!need(gsm::PP_C0, "red") || !need(gsm::PP_C1, "green") || !need(gsm::PP_C2, "blue")) return GS_E_PLY_PROP; }
+    if (L.has_opacity && !need(gsm::PP_OPACITY, "opacity")) return GS_E_PLY_PROP;
+    *layout = L;
+    return GS_OK;
+}
+
+GS_API int gs_ply_to_splat(const void *bytes, size_t nbytes, void *out_rows, size_t *out_nrows, char *err, size_t errlen)
+{
+    if (!bytes || !out_nrows) return fail(err, errlen, GS_E_BADARG, "gs_ply_to_splat: NULL argument");
+    gsm::PlyLayout L;
+    size_t n = 0, data_start = 0;
+    // the size query (out_rows == NULL) stops where the reference would have thrown so far: header and importance pass
+    int rc = gs_ply_plan(bytes, nbytes, &L, &n, &data_start, err, errlen);
+    *out_nrows = n;
+    if (rc != GS_OK) return rc;
+    if (!out_rows || !n) return GS_OK;
+    const uint8_t *data = (const uint8_t *)bytes + data_start;
 
     // importance = exp(s0)*exp(s1)*exp(s2) * sigmoid(opacity), stored f32; 0 when there is no scale_0 (index.js:653-664)
-    const Prop *scale0 = h.find("scale_0");
     std::vector<float> importance(n, 0.0f);
     std::vector<uint32_t> order(n);
     for (size_t i = 0; i < n; i++) order[i] = (uint32_t)i;
-    if (scale0 && n) {
-        NEED(scale1, "scale_1"); NEED(scale2, "scale_2"); NEED(opac, "opacity");
-        for (size_t i = 0; i < n; i++) {
-            const double size = exp(at(i, scale0)) * exp(at(i, scale1)) * exp(at(i, scale2));
-            const double opacity = 1 / (1 + exp(-at(i, opac)));
-            importance[i] = (float)(size * opacity);
-        }
-    }
+    if (L.has_scale)
+        for (size_t i = 0; i < n; i++) importance[i] = gsm::ply_importance(data + i * L.row_bytes, L);
     // sizeIndex.sort((b, a) => sizeList[a] - sizeList[b]): descending, stable (index.js:668)
     std::stable_sort(order.begin(), order.end(),
                      [&](uint32_t b, uint32_t a) { return (double)importance[a] - (double)importance[b] < 0; });
-    *out_nrows = n;
-    if (!out_rows || !n) return GS_OK;
-
-    const Prop *rot[4] = { nullptr, nullptr, nullptr, nullptr }, *sc[3] = { nullptr, nullptr, nullptr };
-    if (scale0) {
-        static const char *rn[4] = { "rot_0", "rot_1", "rot_2", "rot_3" }, *sn[3] = { "scale_0", "scale_1", "scale_2" };
-        for (int k = 0; k < 4; k++) { rot[k] = h.find(rn[k]); if (!rot[k]) return fail(err, errlen, GS_E_PLY_PROP, "%s not found", rn[k]); }
-        for (int k = 0; k < 3; k++) { sc[k] = h.find(sn[k]); if (!sc[k]) return fail(err, errlen, GS_E_PLY_PROP, "%s not found", sn[k]); }
-    }
-    NEED(px, "x"); NEED(py, "y"); NEED(pz, "z");
-    const Prop *dc[3] = { h.find("f_dc_0"), nullptr, nullptr }, *col[3] = { nullptr, nullptr, nullptr };
-    if (dc[0]) {
-        dc[1] = h.find("f_dc_1"); if (!dc[1]) return fail(err, errlen, GS_E_PLY_PROP, "%s not found", "f_dc_1");
-        dc[2] = h.find("f_dc_2"); if (!dc[2]) return fail(err, errlen, GS_E_PLY_PROP, "%s not found", "f_dc_2");
-    } else {
-        static const char *cn[3] = { "red", "green", "blue" };
-        for (int k = 0; k < 3; k++) { col[k] = h.find(cn[k]); if (!col[k]) return fail(err, errlen, GS_E_PLY_PROP, "%s not found", cn[k]); }
-    }
-    const Prop *opac = h.find("opacity");
-#undef NEED
-    uint8_t *out = (uint8_t *)out_rows;
+    uint32_t *out = (uint32_t *)out_rows;
     for (size_t j = 0; j < n; j++) {                                  // index.js:680-742
-        const size_t r = order[j];
-        uint8_t *o = out + 32 * j;
-        float f[6];
-        if (scale0) {
-            const double q0 = at(r, rot[0]), q1 = at(r, rot[1]), q2 = at(r, rot[2]), q3 = at(r, rot[3]);
-            const double qlen = sqrt(q0 * q0 + q1 * q1 + q2 * q2 + q3 * q3);
-            o[28] = to_clamped_u8((q0 / qlen) * 128 + 128); o[29] = to_clamped_u8((q1 / qlen) * 128 + 128);
-            o[30] = to_clamped_u8((q2 / qlen) * 128 + 128); o[31] = to_clamped_u8((q3 / qlen) * 128 + 128);
-            for (int k = 0; k < 3; k++) f[3 + k] = (float)exp(at(r, sc[k]));
-        } else {
-            f[3] = f[4] = f[5] = (float)0.01;
-            o[28] = 255; o[29] = o[30] = o[31] = 0;
-        }
-        f[0] = (float)at(r, px); f[1] = (float)at(r, py); f[2] = (float)at(r, pz);
-        memcpy(o, f, 24);
-        if (dc[0]) {
-            const double SH_C0 = 0.28209479177387814;
-            for (int k = 0; k < 3; k++) o[24 + k] = to_clamped_u8((0.5 + SH_C0 * at(r, dc[k])) * 255);
-        } else {
-            for (int k = 0; k < 3; k++) o[24 + k] = to_clamped_u8(at(r, col[k]));
-        }
-        o[27] = opac ? to_clamped_u8((1 / (1 + exp(-at(r, opac)))) * 255) : 255;
+        uint32_t w[8];
+        gsm::ply_row(data + (size_t)order[j] * L.row_bytes, L, w);
+        memcpy(out + 8 * j, w, 32);
     }
     return GS_OK;
 }

@@ -153,8 +153,13 @@ int gs_run_sort(gs_ctx *ctx, const float view[4], const float *cutout16);
 // ---- gs_render.hip
 int gs_run_render(gs_ctx *ctx, const GsFrameUniforms &u, uint8_t *device_out);
 int gs_run_round1(gs_ctx *ctx, const GsFrameUniforms &u, uint8_t *device_out);
+// ---- gs_ply.hip / gs_host.cpp
+namespace gsm { struct PlyLayout; }
+int gs_ply_rows_device(gs_ctx *ctx, const uint8_t *host_data, const gsm::PlyLayout &layout, size_t n, uint4 *rows_out, bool *had_nan);
+extern "C" int gs_ply_plan(const void *bytes, size_t nbytes, gsm::PlyLayout *layout, size_t *nrows, size_t *data_start, char *err, size_t errlen);
 // ---- gs_api.hip
 int gs_ensure_pair_capacity(gs_ctx *ctx, size_t pairs);
+int gs_ensure_radix_scratch(gs_ctx *ctx, size_t items);         // histogram / totals scratch for a radix sort of `items` records
 // event k (0..GS_PROF_EVENTS-1) of the current profiling slot, or nullptr when profiling is off
 hipEvent_t gs_prof_event(gs_ctx *ctx, int k);
 #define GS_PROF_RECORD(ctx, k) do { hipEvent_t _pev = gs_prof_event(ctx, k); if (_pev) GS_HIP(hipEventRecord(_pev, (ctx)->stream)); } while (0)

@@ -159,7 +159,8 @@ class GaussianSplatting {
     return self;
   }
 
-  processPlyBuffer(inputBuffer) { return native.plyToSplat(inputBuffer); }   // index.js:600-745
+  // processPlyBuffer (index.js:600-745): header on the host, importance order + row conversion on the GPU
+  processPlyBuffer(inputBuffer) { return native.plyToSplatGpu(this.handle, inputBuffer); }
 
   stats() { return native.stats(this.handle); }
 

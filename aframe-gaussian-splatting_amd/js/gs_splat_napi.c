@@ -188,6 +188,23 @@ static napi_value fn_ply_to_splat(napi_env env, napi_callback_info info)  /* pro
     return ab;
 }
 
+/* plyToSplatGpu(h, inputBuffer) -> ArrayBuffer: processPlyBuffer converted on the context's GPU (same bytes) */
+static napi_value fn_ply_to_splat_gpu(napi_env env, napi_callback_info info)
+{
+    napi_value argv[2];
+    if (!get_args(env, info, 2, argv, NULL)) return NULL;
+    gs_ctx *ctx = get_ctx(env, argv[0]); if (!ctx) return NULL;
+    void *data; size_t len;
+    if (!get_bytes(env, argv[1], &data, &len)) { napi_throw_type_error(env, NULL, "expected an ArrayBuffer or TypedArray"); return NULL; }
+    size_t n = 0;
+    int rc = gs_ply_to_splat_gpu(ctx, data, len, NULL, &n);
+    if (rc != GS_OK) return throw_gs(env, ctx, rc);
+    napi_value ab; void *out;
+    NAPI_OK(napi_create_arraybuffer(env, n * 32, &out, &ab));
+    if (n) { rc = gs_ply_to_splat_gpu(ctx, data, len, out, &n); if (rc != GS_OK) return throw_gs(env, ctx, rc); }
+    return ab;
+}
+
 static napi_value fn_count(napi_env env, napi_callback_info info)
 {
     napi_value argv[1], r;
@@ -397,7 +414,8 @@ static napi_value init(napi_env env, napi_value exports)
 {
     static const struct { const char *name; napi_callback fn; } fns[] = {
         { "create", fn_create }, { "destroy", fn_destroy }, { "clear", fn_clear }, { "pushSplat", fn_push_splat },
-        { "pushMatrices", fn_push_matrices }, { "loadPly", fn_load_ply }, { "plyToSplat", fn_ply_to_splat }, { "count", fn_count },
+        { "pushMatrices", fn_push_matrices }, { "loadPly", fn_load_ply }, { "plyToSplat", fn_ply_to_splat }, { "plyToSplatGpu", fn_ply_to_splat_gpu },
+        { "count", fn_count },
         { "sort", fn_sort }, { "render", fn_render }, { "setScene", fn_set_scene }, { "stats", fn_stats }, { "setOption", fn_set_option },
         { "modelViewMatrix", fn_model_view }, { "projectionMatrix", fn_projection }, { "tickUniforms", fn_tick },
         { "scaledSize", fn_scaled_size },

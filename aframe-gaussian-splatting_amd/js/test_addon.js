@@ -65,6 +65,14 @@ if (mode === 'cpu') {
 // ---- GPU: worker protocol against the reference worker's golden outputs
 const [scenePath, outPath, W, H, yaw] = process.argv.slice(4);
 const comp = new GaussianSplatting({ src: scenePath, pixelRatio: 1 }).init(null);
+for (const name of Object.keys(manifest).filter((k) => manifest[k].kind === 'ply')) {   // processPlyBuffer on the GPU
+  const c = loadCase(name);
+  const rows = new Uint8Array(comp.processPlyBuffer(c.ply.buffer.slice(c.ply.byteOffset, c.ply.byteOffset + c.ply.byteLength)));
+  ok(same(rows, c.rows), name + ' processPlyBuffer (GPU)');
+}
+try { comp.processPlyBuffer(Buffer.from('ply\nnope')); ok(false, 'bad header must throw'); } catch (e) {
+  ok(e.message === manifest.ply_errors.meta.no_end_header, 'PLY header message (GPU path): ' + e.message);
+}
 for (const name of Object.keys(manifest).filter((k) => manifest[k].kind === 'sort')) {
   const c = loadCase(name);
   let reply = null;

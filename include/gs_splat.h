@@ -71,8 +71,15 @@ GS_API int gs_push_splat(gs_ctx *ctx, const void *rows, size_t nrows);
 GS_API int gs_push_matrices(gs_ctx *ctx, const float *matrices, size_t nrows);
 
 /* processPlyBuffer(inputBuffer) (index.js:600-745) followed by pushDataBuffer: parse a binary
- * little-endian PLY, order rows by importance, convert to .splat rows, append. */
+ * little-endian PLY, order rows by importance, convert to .splat rows, append.  The header is parsed on
+ * the host; importance, the stable descending sort and the row conversion run on the GPU and the rows go
+ * from HBM straight into the pack kernel. */
 GS_API int gs_load_ply(gs_ctx *ctx, const void *bytes, size_t nbytes);
+
+/* processPlyBuffer alone, converted on the context's GPU: same bytes as gs_ply_to_splat (both evaluate the
+ * same f64 arithmetic, incl. the engine's Math.exp).  out_rows == NULL: size query (header and property
+ * checks only).  Errors are reported through gs_last_error(). */
+GS_API int gs_ply_to_splat_gpu(gs_ctx *ctx, const void *bytes, size_t nbytes, void *out_rows, size_t *out_nrows);
 
 /* processPlyBuffer alone (host side): PLY bytes -> .splat rows.  Call with out_rows == NULL to get
  * *out_nrows, then again with a buffer of 32 * *out_nrows bytes.  err (optional) receives the message

@@ -285,6 +285,34 @@ function cameraCase(name, cam, obj, cutout, vpW, vpH, proj, note) {
     'rotated camera + rotated/scaled entity + rotated cutout, asymmetric (XR-like) frustum');
 }
 
+// ---------------------------------------------------------------- Math.exp of the engine the reference runs on
+// processPlyBuffer's importance, scale and opacity all go through Math.exp (index.js:659-662, 700, 722): V8's
+// ieee754::exp (fdlibm e_exp.c), not a correctly-rounded exp.  These vectors pin the restatements (oracle gso_js_exp,
+// product gsm::js_exp) to what THIS engine returns, bit for bit.
+{
+  const r = rng(77); const xs = [];
+  const f32 = (v) => Math.fround(v);
+  for (const v of [0, -0, 1, -1, 0.5, -0.5, Infinity, -Infinity, NaN, 709.782712893384, 709.7827128933841, 710, -745.1332191019411,
+    -745.1332191019412, -746, -708.3964185322641, -720, 1e-10, -1e-10, 3.7252902984619140625e-9, 0.34657359027997264, 0.3465735902799727,
+    1.0397207708399179, 1.039720770839918, -0.34657359027997264, -1.0397207708399179, 88.72283905206835, -87.33654475055310898657, 700.5, -700.5]) xs.push(v);
+  for (let i = 0; i < 3000; i++) xs.push(f32(-4.2 + 0.9 * r.n()));              // ln-scale values as they sit in a PLY (f32)
+  for (let i = 0; i < 3000; i++) xs.push(-f32(0.5 + 2.5 * r.n()));              // -opacity
+  for (let i = 0; i < 1500; i++) xs.push(f32(60 * r.u() - 40));                  // wide f32 range
+  for (let i = 0; i < 600; i++) xs.push((r.u() - 0.5) * 1.5);                    // around the reduction thresholds, full f64 mantissas
+  for (let i = 0; i < 70; i++) xs.push(-700 - 50 * r.u());                       // gradual underflow
+  const x = new Float64Array(xs), y = new Float64Array(xs.length);
+  for (let i = 0; i < x.length; i++) y[i] = Math.exp(x[i]);
+  emit('math_exp', 'math', { x, exp: y }, { note: 'Math.exp under ' + process.version + ' (V8 ' + process.versions.v8 + ')' });
+}
+// a larger PLY so that the importance order is a real sort (4096 rows, compact 14-float layout)
+{
+  const r = rng(91);
+  const g = (i, nm) => { if (nm === 'opacity') return 0.5 + 2.5 * r.n(); if (nm.startsWith('scale_')) return -4.2 + 0.9 * r.n();
+    if (nm.startsWith('f_dc_')) return 1.2 * r.n(); if (nm.startsWith('rot_')) return r.n(); return 2.0 * r.n(); };
+  const props = ['x', 'y', 'z', 'f_dc_0', 'f_dc_1', 'f_dc_2', 'opacity', 'scale_0', 'scale_1', 'scale_2', 'rot_0', 'rot_1', 'rot_2', 'rot_3'].map((n) => ['float', n]);
+  plyCase('ply_n4096', props, 4096, g, 'compact 14-float layout, 4096 rows: importance order of a real-sized sort');
+}
+
 fs.writeFileSync(path.join(OUT, 'manifest.json'), JSON.stringify(manifest, null, 1));
 let bytes = 0; for (const f of fs.readdirSync(OUT)) bytes += fs.statSync(path.join(OUT, f)).size;
 console.log('wrote', Object.keys(manifest).length, 'cases,', bytes, 'bytes ->', OUT);

@@ -420,6 +420,65 @@ GSO_API int gso_render(const float *center_scale, const uint32_t *cov_color, con
 
 enum { T_F64, T_I32, T_U32, T_F32, T_I16, T_U16, T_U8, T_I8 };
 typedef struct { char name[64]; int type; size_t off; } prop_t;
+/* Math.exp as the reference's engine evaluates it.  THIRD-PARTY arithmetic, absent from /root/reference: V8
+ * (node 12.22.9 here, V8 7.8; any Chromium of the A-Frame 1.4 era) implements Math.exp with base::ieee754::exp, which
+ * is Sun's fdlibm 5.3 e_exp.c: argument reduction x = k*ln2 + r with a two-word ln2, the degree-5 minimax polynomial
+ * for r*(exp(r)+1)/(exp(r)-1), then scaling by 2^k; V8 adds one special case, exp(1) = E.  It is accurate to <1 ulp but NOT correctly rounded, so libm's
+ * exp() is not a substitute where bits matter.  Restated from the published algorithm; pinned bit for bit against
+ * tests/golden/math_exp.bin (8200 values produced by Math.exp under node in this container). */
+GSO_API double gso_js_exp(double x)
+{
+    static const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10,
+                        inv_ln2 = 1.44269504088896338700e+00,
+                        P1 = 1.66666666666666019037e-01, P2 = -2.77777777770155933842e-03, P3 = 6.61375632143793436117e-05,
+                        P4 = -1.65339022054652515390e-06, P5 = 4.13813679705723846039e-08;
+    uint64_t bits;
+    memcpy(&bits, &x, 8);
+    const int neg = (int)(bits >> 63);
+    const uint32_t hx = (uint32_t)(bits >> 32) & 0x7fffffffu;          /* high word of |x| */
+    double hi = 0.0, lo = 0.0;
+    int k = 0;
+    if (hx >= 0x40862E42u) {                                           /* |x| >= 709.78 */
+        if (hx >= 0x7ff00000u) {
+            if ((bits & 0x000fffffffffffffull) != 0) return x + x;     /* NaN */
+            return neg ? 0.0 : x;                                      /* exp(-inf) = 0, exp(+inf) = +inf */
+        }
+        if (x > 7.09782712893383973096e+02) return HUGE_VAL;           /* overflow */
+        if (x < -7.45133219101941108420e+02) return 0.0;               /* underflow */
+    }
+    if (hx > 0x3fd62e42u) {                                            /* |x| > 0.5 ln2 */
+        if (hx < 0x3FF0A2B2u) {                                        /* and |x| < 1.5 ln2 */
+            if (x == 1.0) return 2.718281828459045;                    /* V8 returns the constant E here (the formula is 1 ulp off) */
+            hi = neg ? x + ln2_hi : x - ln2_hi;
+            lo = neg ? -ln2_lo : ln2_lo;
+            k = neg ? -1 : 1;
+        } else {
+            k = (int)(inv_ln2 * x + (neg ? -0.5 : 0.5));
+            const double t = (double)k;
+            hi = x - t * ln2_hi;                                       /* t*ln2_hi is exact */
+            lo = t * ln2_lo;
+        }
+        x = hi - lo;
+    } else if (hx < 0x3e300000u) {                                     /* |x| < 2^-28 */
+        return 1.0 + x;
+    }
+    const double t = x * x;
+    const double c = x - t * (P1 + t * (P2 + t * (P3 + t * (P4 + t * P5))));
+    if (k == 0) return 1.0 - ((x * c) / (c - 2.0) - x);
+    double y = 1.0 - ((lo - (x * c) / (2.0 - c)) - hi);
+    /* y * 2^k */
+    uint64_t yb;
+    memcpy(&yb, &y, 8);
+    if (k >= -1021) {
+        yb += (uint64_t)(int64_t)k << 52;
+        memcpy(&y, &yb, 8);
+        return y;
+    }
+    yb += (uint64_t)(int64_t)(k + 1000) << 52;
+    memcpy(&y, &yb, 8);
+    return y * 9.33263618503218878990e-302;                            /* 2^-1000 */
+}
+
 static const int TSIZE[] = { 8, 4, 4, 4, 2, 2, 1, 1 };
 
 static double rd(const uint8_t *p, int type)
@@ -513,8 +572,8 @@ GSO_API int gso_ply_to_splat(const uint8_t *buf, size_t len, uint8_t *out, size_
         int s2 = FIND("scale_2"); if (s2 < 0) { snprintf(err, errlen, "scale_2 not found"); rc = -2; goto done; }
         int op = FIND("opacity"); if (op < 0) { snprintf(err, errlen, "opacity not found"); rc = -2; goto done; }
         for (size_t r = 0; r < n; r++) {
-            const double size = exp(AT(r, s0)) * exp(AT(r, s1)) * exp(AT(r, s2));
-            const double opacity = 1 / (1 + exp(-AT(r, op)));
+            const double size = gso_js_exp(AT(r, s0)) * gso_js_exp(AT(r, s1)) * gso_js_exp(AT(r, s2));
+            const double opacity = 1 / (1 + gso_js_exp(-AT(r, op)));
             imp[r].key = (float)(size * opacity);
         }
     }
@@ -547,7 +606,7 @@ GSO_API int gso_ply_to_splat(const uint8_t *buf, size_t len, uint8_t *out, size_
                 const double qlen = sqrt(q0 * q0 + q1 * q1 + q2 * q2 + q3 * q3);
                 o[28] = clamp_u8((q0 / qlen) * 128 + 128); o[29] = clamp_u8((q1 / qlen) * 128 + 128);
                 o[30] = clamp_u8((q2 / qlen) * 128 + 128); o[31] = clamp_u8((q3 / qlen) * 128 + 128);
-                f[3] = (float)exp(AT(r, s0)); f[4] = (float)exp(AT(r, s1)); f[5] = (float)exp(AT(r, s2));
+                f[3] = (float)gso_js_exp(AT(r, s0)); f[4] = (float)gso_js_exp(AT(r, s1)); f[5] = (float)gso_js_exp(AT(r, s2));
             } else {
                 f[3] = f[4] = f[5] = (float)0.01; o[28] = 255; o[29] = o[30] = o[31] = 0;
             }
@@ -558,7 +617,7 @@ GSO_API int gso_ply_to_splat(const uint8_t *buf, size_t len, uint8_t *out, size_
                 o[24] = clamp_u8((0.5 + SH_C0 * AT(r, dc0)) * 255); o[25] = clamp_u8((0.5 + SH_C0 * AT(r, dc1)) * 255);
                 o[26] = clamp_u8((0.5 + SH_C0 * AT(r, dc2)) * 255);
             } else { o[24] = clamp_u8(AT(r, cr)); o[25] = clamp_u8(AT(r, cg)); o[26] = clamp_u8(AT(r, cb)); }
-            o[27] = op >= 0 ? clamp_u8((1 / (1 + exp(-AT(r, op)))) * 255) : 255;
+            o[27] = op >= 0 ? clamp_u8((1 / (1 + gso_js_exp(-AT(r, op)))) * 255) : 255;
         }
     }
 done:

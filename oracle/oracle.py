@@ -52,6 +52,8 @@ def lib():
         L.gso_render_scene.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_float,
                                        C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_void_p, C.c_void_p]
+        L.gso_js_exp.restype = C.c_double
+        L.gso_js_exp.argtypes = [C.c_double]
         L.gso_ply_to_splat.restype = C.c_int
         L.gso_ply_to_splat.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_size_t), C.c_char_p, C.c_size_t]
         _lib = L
@@ -156,6 +158,13 @@ def render(cs, cc, sorted_idx, mv, proj, focal_, W, H, x0=0, x1=None, bg=(0, 0, 
     if rc != 0:
         raise MemoryError("gso_render")
     return u8, f32, fr.value
+
+
+def js_exp(x):
+    """Math.exp as V8 evaluates it (fdlibm e_exp.c), elementwise over a float64 array."""
+    x = np.ascontiguousarray(x, np.float64)
+    f = lib().gso_js_exp
+    return np.array([f(float(v)) for v in x.ravel()], np.float64).reshape(x.shape)
 
 
 class PlyError(Exception):

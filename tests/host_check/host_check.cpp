@@ -5,6 +5,7 @@
 #include <string.h>
 #include <vector>
 #include "gs_device_math.h"
+#include "gs_ply.h"
 #include "gs_host_tables.h"
 
 extern "C" {
@@ -89,4 +90,7 @@ float hc_frag_power(float dx, float dy, float ax, float ay, float bx, float by) 
 
 __attribute__((visibility("default")))
 int32_t hc_toint32(double d) { return gsm::js_toint32(d); }
+
+__attribute__((visibility("default")))
+void hc_js_exp(const double *x, size_t n, double *out) { for (size_t i = 0; i < n; i++) out[i] = gsm::js_exp(x[i]); }
 }

@@ -222,6 +222,46 @@ def test_load_ply_equals_push_of_converted_rows(ctx):
     assert ei.value.code == capi.E_PLY_HEADER and "Unable to read .ply file header" in ei.value.message
 
 
+@pytest.mark.parametrize("name", cases_of("ply"))
+def test_gpu_ply_converter_matches_reference_processPlyBuffer(ctx, name):
+    """processPlyBuffer on the GPU (importance keys, stable radix order, row conversion) == the reference's bytes."""
+    c = load_case(name)
+    assert np.array_equal(ctx.ply_to_splat(c["ply"]), c["rows"])
+
+
+def test_gpu_ply_converter_equals_host_converter_at_scale(ctx):
+    """300k INRIA-layout rows (a real multi-chunk radix sort, many near-equal importances): the HIP converter and the host
+    converter share their f64 arithmetic (gs_ply.h), so the bytes must be identical; the oracle agrees on a prefix."""
+    rows = synth.make_splat_rows(300_000, seed=synth.SEED_BASE + 11)
+    ply = synth.rows_to_inria_ply(rows)
+    got = ctx.ply_to_splat(ply)
+    assert np.array_equal(got, capi.ply_to_splat(ply))
+    small = synth.rows_to_inria_ply(np.asarray(rows).reshape(-1, 32)[:20_000])
+    assert np.array_equal(ctx.ply_to_splat(small), oracle.ply_to_splat(small))
+
+
+def test_gpu_ply_converter_errors_and_edge_cases(ctx, manifest):
+    e = manifest["ply_errors"]["meta"]
+    hdr = lambda props, nb, end=True: (b"ply\nformat binary_little_endian 1.0\nelement vertex 1\n" +
+                                       b"".join(b"property float %s\n" % p for p in props) + (b"end_header\n" if end else b"") + b"\0" * nb)
+    with pytest.raises(capi.GsError) as ei:
+        ctx.ply_to_splat(hdr([b"x"], 8, end=False))
+    assert ei.value.code == capi.E_PLY_HEADER and e["no_end_header"] in ei.value.message
+    with pytest.raises(capi.GsError) as ei:
+        ctx.ply_to_splat(hdr([b"x", b"y", b"z"], 12))
+    assert ei.value.code == capi.E_PLY_PROP and e["missing_red"] in ei.value.message
+    # zero vertices -> zero rows; NaN importance falls back to the host converter's definition
+    zero = b"ply\nformat binary_little_endian 1.0\nelement vertex 0\nproperty float x\nend_header\n"
+    assert ctx.ply_to_splat(zero).size == 0
+    rows = synth.make_splat_rows(64, seed=5)
+    ply = bytearray(synth.rows_to_inria_ply(rows))
+    start = bytes(ply).index(b"end_header\n") + 11
+    names = [l.split()[2] for l in bytes(ply[:start]).decode().split("\n") if l.startswith("property")]
+    off = 4 * names.index("scale_0")
+    ply[start + 3 * 4 * len(names) + off: start + 3 * 4 * len(names) + off + 4] = np.float32(np.nan).tobytes()
+    assert np.array_equal(ctx.ply_to_splat(bytes(ply)), capi.ply_to_splat(bytes(ply)))
+
+
 # ---------------------------------------------------------------- BASELINE.json sizes: properties + oracle
 
 @pytest.fixture(scope="module")

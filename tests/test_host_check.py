@@ -141,3 +141,15 @@ def test_exact_tile_rows_are_a_superset_of_pixel_coverage_and_tighter_than_the_r
                 assert lo <= tx_ <= hi, (i, ty_, tx_, lo, hi)
     assert checked > 1500
     assert tot_exact < 0.9 * tot_rect, (tot_exact, tot_rect)
+
+
+def test_product_js_exp_matches_the_engine(hc):
+    """gsm::js_exp (csrc/gs_ply.h, shared by the host and the HIP .ply converters) against Math.exp's own outputs."""
+    c = load_case("math_exp")
+    x = np.ascontiguousarray(c["x"])
+    out = np.zeros_like(x)
+    hc.hc_js_exp.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
+    hc.hc_js_exp.restype = None
+    hc.hc_js_exp(_p(x), x.size, _p(out))
+    both_nan = np.isnan(out) & np.isnan(c["exp"])
+    assert np.array_equal(out.view(np.uint64)[~both_nan], c["exp"].view(np.uint64)[~both_nan])

@@ -83,6 +83,16 @@ def test_ply_matches_reference_processPlyBuffer(name):
     assert np.array_equal(got, c["rows"])
 
 
+def test_js_exp_matches_the_engine_bit_for_bit():
+    """Math.exp is third-party arithmetic (V8's fdlibm port): the oracle's restatement must reproduce the 8200 values
+    node returned here, bit for bit -- libm's exp does not (it differs in the last bit for ~10 % of them)."""
+    c = load_case("math_exp")
+    got = oracle.js_exp(c["x"])
+    both_nan = np.isnan(got) & np.isnan(c["exp"])
+    assert c["x"].size >= 8000
+    assert np.array_equal(got.view(np.uint64)[~both_nan], c["exp"].view(np.uint64)[~both_nan])
+
+
 def _ply(props, nbytes, end=True):
     return (b"ply\nformat binary_little_endian 1.0\nelement vertex 1\n" +
             b"".join(b"property float %s\n" % n for n in props) + (b"end_header\n" if end else b"") + b"\0" * nbytes)
