@@ -98,20 +98,22 @@ class GaussianSplatting {
     this.loadedVertexCount += vertexCount;
   }
 
-  // tick (index.js:438-455) + the worker reply handler (index.js:201-207), single flight.
-  tick() {
+  // tick (index.js:438-455) + the worker reply handler (index.js:201-207), single flight.  The reference always sorts
+  // from this.camera (in XR: the head camera, one order for both eyes); passing an eye camera sorts for that eye alone
+  // (SURVEY.md 8f-3): comp.tick(eye); comp.render(eye, viewport).
+  tick(camera) {
     if (!this.sortReady) return;
     this.sortReady = false;
     try {
-      const u = this._tickUniforms();
+      const u = this._tickUniforms(camera);
       const indexes = native.sort(this.handle, u.view, u.cutout);
       this.sortedIndexes = indexes;
       this.instanceCount = indexes.length;
     } finally { this.sortReady = true; }
   }
 
-  _tickUniforms() {
-    return native.tickUniforms(elementsOf(this.camera.matrixWorld), elementsOf(this.object.matrixWorld),
+  _tickUniforms(camera) {
+    return native.tickUniforms(elementsOf((camera || this.camera).matrixWorld), elementsOf(this.object.matrixWorld),
       this.cutout ? elementsOf(this.cutout.matrixWorld) : undefined);
   }
 

@@ -522,3 +522,53 @@ def test_scene_depth_and_colour_compositing(ctx, scene_small):
     finally:
         ctx.set_scene(None, None)
     assert np.abs(ctx.render(_params(cam)).astype(int) - plain.astype(int)).max() <= PIXEL_TOL_LSB
+
+
+# ---------------------------------------------------------------- streaming ingest / several instances
+
+def test_progressive_pushes_render_partial_scenes_and_contexts_do_not_interfere(scene_small):
+    """The reference renders a partially loaded scene while chunks keep arriving (index.js:279-298) and allows several
+    component instances per page (cutout-demo.html:24-25): pushes between frames extend the resident data without
+    disturbing it, and two contexts on one GPU, driven alternately, give what each gives alone."""
+    rows = np.asarray(scene_small["rows"]).reshape(-1, 32)
+    cam = synth.index_html_camera(320, 180, 30.0, capi=capi)
+    mv, P, focal = _f32(cam)
+    cuts = [7000, 7001, 19000, rows.shape[0]]                 # ragged chunks, incl. a single-row push
+    other_rows = synth.make_splat_rows(12000, seed=4242)
+    cam_b = synth.index_html_camera(320, 180, 200.0, capi=capi)
+    with capi.Context(0) as alone:
+        alone.push_splat(other_rows)
+        alone.sort(cam_b["view"])
+        want_b = alone.render(_params(cam_b))
+    with capi.Context(0) as a, capi.Context(0) as b:
+        b.push_splat(other_rows)
+        prev = 0
+        for cut in cuts:
+            a.push_splat(rows[prev:cut]); prev = cut
+            assert a.count() == cut
+            idx = a.sort(cam["view"])
+            b.sort(cam_b["view"])                              # interleaved use of the second instance
+            img = a.render(_params(cam))
+            assert np.array_equal(b.render(_params(cam_b)), want_b)
+            cs, cc, mats = oracle.pack(rows[:cut])
+            assert np.array_equal(idx, oracle.sort(mats, cam["view"]))
+            ref, _, _ = oracle.render(cs, cc, idx, mv, P, focal, 320, 180, want_f32=False)
+            assert np.abs(img.astype(int) - ref.astype(int)).max() <= PIXEL_TOL_LSB
+        # the packed records of the first chunk are untouched by the later appends (capacity growth copies them)
+        first = a.download(capi.BUF_COV_COLOR, cuts[0], np.uint32, 4)
+        assert np.array_equal(first, oracle.pack(rows[:cuts[0]])[1])
+
+
+def test_xr_per_eye_sort_option(ctx, scene_small):
+    """the reference sorts once from the head camera for both eyes (index.js:441); sorting per eye is
+    plain API use (gs_sort with the eye's own view row, then gs_render) and each eye then matches the oracle drawn in its
+    own order."""
+    ctx.clear(); ctx.push_splat(scene_small["rows"])
+    l, r, head = synth.xr_eye_cameras(45.0, 0.25, capi=capi)
+    for eye in (l, r):
+        idx = ctx.sort(eye["view"])
+        assert np.array_equal(idx, oracle.sort(scene_small["mats"], eye["view"]))
+        img = ctx.render(_params(eye))
+        mv, P, focal = _f32(eye)
+        ref, _, _ = oracle.render(scene_small["cs"], scene_small["cc"], idx, mv, P, focal, eye["vw"], eye["vh"], want_f32=False)
+        assert np.abs(img.astype(int) - ref.astype(int)).max() <= PIXEL_TOL_LSB
