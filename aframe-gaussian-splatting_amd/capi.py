@@ -13,13 +13,13 @@ from . import build as _build
 GS_OK = 0
 E_BADARG, E_PLY_HEADER, E_PLY_PROP, E_HIP, E_OOM, E_NODEVICE, E_STATE, E_PLY_DATA, E_RETRY = -1, -2, -3, -4, -5, -6, -7, -8, -9
 RENDER_FLIP_Y, RENDER_COUNT_FRAGS, RENDER_NO_EARLY_OUT, RENDER_ASYNC = 1, 2, 4, 8
-OPT_PROFILE, OPT_TERMINATION, OPT_NEAR_PERMILLE, OPT_RECORD_STAGED = 1, 2, 3, 4
+OPT_PROFILE, OPT_TERMINATION, OPT_NEAR_PERMILLE, OPT_RECORD_STAGED, OPT_PIPELINE_DEPTH = 1, 2, 3, 4, 5
 BUF_CENTER_SCALE, BUF_COV_COLOR, BUF_SORT_ROWS, BUF_SORTED, BUF_PROJECTED, BUF_TILE_COUNT, BUF_TILE_STATS = 0, 1, 2, 3, 4, 5, 6
 
 EXPORTS = [
     "gs_create", "gs_destroy", "gs_last_error", "gs_version", "gs_clear", "gs_push_splat", "gs_push_matrices", "gs_load_ply",
     "gs_ply_to_splat", "gs_ply_to_splat_gpu", "gs_count", "gs_sort", "gs_render", "gs_render_device", "gs_render_stereo", "gs_set_scene", "gs_sync",
-    "gs_set_stream",
+    "gs_set_stream", "gs_frame_stream", "gs_wait_stream", "gs_stream_wait_frame",
     "gs_model_view_matrix", "gs_projection_matrix", "gs_tick_uniforms", "gs_focal", "gs_scaled_size", "gs_set_option",
     "gs_get_stats", "gs_download",
 ]
@@ -85,6 +85,9 @@ def load(build_if_missing=True):
     L.gs_set_scene.argtypes = [vp, vp, vp, i32, i32]
     L.gs_sync.argtypes = [vp]
     L.gs_set_stream.argtypes = [vp, vp]
+    L.gs_wait_stream.argtypes = [vp, vp]
+    L.gs_frame_stream.argtypes = [vp]; L.gs_frame_stream.restype = C.c_void_p
+    L.gs_stream_wait_frame.argtypes = [vp, vp]
     L.gs_model_view_matrix.argtypes = [vp, vp, vp]; L.gs_model_view_matrix.restype = None
     L.gs_projection_matrix.argtypes = [vp, vp]; L.gs_projection_matrix.restype = None
     L.gs_tick_uniforms.argtypes = [vp, vp, vp, vp, vp]; L.gs_tick_uniforms.restype = None
@@ -268,6 +271,18 @@ class Context:
 
     def set_stream(self, stream_ptr):
         self._ck(self._L.gs_set_stream(self._h, C.c_void_p(stream_ptr) if stream_ptr else None))
+
+    def frame_stream(self):
+        """hipStream_t (as an int) of the lane the current frame was enqueued on."""
+        return int(self._L.gs_frame_stream(self._h) or 0)
+
+    def wait_stream(self, stream_ptr):
+        """The next frame starts (on the GPU) only after everything queued on the given hipStream_t so far."""
+        self._ck(self._L.gs_wait_stream(self._h, C.c_void_p(stream_ptr)))
+
+    def stream_wait_frame(self, stream_ptr):
+        """The given hipStream_t waits (on the GPU) for the frame enqueued last."""
+        self._ck(self._L.gs_stream_wait_frame(self._h, C.c_void_p(stream_ptr)))
 
     def set_option(self, opt, value):
         self._ck(self._L.gs_set_option(self._h, int(opt), int(value)))

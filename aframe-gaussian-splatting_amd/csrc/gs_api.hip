@@ -31,11 +31,11 @@ template <typename T> static void dev_free(T *&p) { if (p) { (void)hipFree(p); p
 static int ensure_scan_scratch(gs_ctx *ctx)
 {
     // histogram table: bins x chunks for the larger of the two sorts; spine: one word per 2048 scanned words
-    size_t need_hist = (size_t)GS_RADIX_MAX_BINS * (gs_div_up(ctx->cap, GS_CHUNK) + 1);
+    size_t need_hist = (size_t)GS_RADIX_MAX_BINS * (gs_div_up(ctx->scratch_cap, GS_CHUNK) + 1);
     const size_t ph = (size_t)GS_RADIX_MAX_BINS * (gs_div_up(ctx->pair_cap, GS_CHUNK) + 1);
     if (ph > need_hist) need_hist = ph;
     if (need_hist > ctx->hist_cap) { dev_free(ctx->hist); TRY(dev_alloc(ctx, &ctx->hist, need_hist)); ctx->hist_cap = need_hist; }
-    size_t need_spine = gs_div_up(need_hist, GS_CHUNK) + gs_div_up(ctx->cap, GS_BLOCK) + GS_RADIX_MAX_BINS + 16;   // project/emit chunks of 256
+    size_t need_spine = gs_div_up(need_hist, GS_CHUNK) + gs_div_up(ctx->scratch_cap, GS_BLOCK) + GS_RADIX_MAX_BINS + 16;   // project/emit chunks of 256
     if (need_spine > ctx->spine_cap) { dev_free(ctx->spine); TRY(dev_alloc(ctx, &ctx->spine, need_spine)); ctx->spine_cap = need_spine; }
     return GS_OK;
 }
@@ -63,13 +63,40 @@ int gs_ensure_pair_capacity(gs_ctx *ctx, size_t pairs)
     return ensure_scan_scratch(ctx);
 }
 
-// grow the per-splat arrays to hold at least `want` splats, preserving the resident data
+// every lane idle (the resident arrays are about to change, or the caller wants the device quiet)
+static int drain_all(gs_ctx *ctx)
+{
+    gs_ctx *P = gs_root(ctx);
+    for (int i = 0; i < GS_MAX_LANES; i++)
+        if (P->lanes[i] && P->lanes[i]->stream) GS_HIP(hipStreamSynchronize(P->lanes[i]->stream));
+    return GS_OK;
+}
+
+// per-frame scratch of one lane (sort keys, projected records, pair lists, scan tables) for `cap` splats
+static int ensure_lane_scratch(gs_ctx *ctx, size_t cap)
+{
+    if (cap <= ctx->scratch_cap) return GS_OK;
+    GS_HIP(hipStreamSynchronize(ctx->stream));
+    dev_free(ctx->depth); dev_free(ctx->key_a); dev_free(ctx->kv_b); dev_free(ctx->val_a);
+    dev_free(ctx->proj); dev_free(ctx->rect); dev_free(ctx->tile_count); dev_free(ctx->zwin);
+    ctx->scratch_cap = 0; ctx->have_sort = false; ctx->sorted = nullptr;
+    TRY(dev_alloc(ctx, &ctx->depth, cap));
+    TRY(dev_alloc(ctx, &ctx->key_a, cap)); TRY(dev_alloc(ctx, &ctx->kv_b, cap)); TRY(dev_alloc(ctx, &ctx->val_a, cap));
+    TRY(dev_alloc(ctx, &ctx->proj, cap)); TRY(dev_alloc(ctx, &ctx->rect, cap));
+    TRY(dev_alloc(ctx, &ctx->tile_count, cap)); TRY(dev_alloc(ctx, &ctx->zwin, cap));
+    ctx->scratch_cap = cap;
+    TRY(gs_ensure_pair_capacity(ctx, cap * 8 > ((size_t)1 << 22) ? cap * 8 : (size_t)1 << 22));
+    return ensure_scan_scratch(ctx);
+}
+
+// grow the resident per-splat arrays (owner only) to hold at least `want` splats, preserving the data
 static int ensure_capacity(gs_ctx *ctx, size_t want)
 {
     if (want <= ctx->cap) return GS_OK;
     if (want > 0x7FFFFFF0ull) FAIL(GS_E_BADARG, "more than 2^31 splats");
     size_t cap = ctx->cap ? ctx->cap : (size_t)1 << 16;
     while (cap < want) cap *= 2;
+    TRY(drain_all(ctx));
     float4 *sr = nullptr; uint4 *sp = nullptr;
     TRY(dev_alloc(ctx, &sp, cap * 2)); TRY(dev_alloc(ctx, &sr, cap));
     if (ctx->n) {
@@ -79,16 +106,9 @@ static int ensure_capacity(gs_ctx *ctx, size_t want)
     }
     dev_free(ctx->splat); dev_free(ctx->sort_rows);
     ctx->splat = sp; ctx->sort_rows = sr;
-    dev_free(ctx->depth); dev_free(ctx->key_a); dev_free(ctx->kv_b); dev_free(ctx->val_a);
-    dev_free(ctx->proj); dev_free(ctx->rect); dev_free(ctx->tile_count); dev_free(ctx->zwin);
-    TRY(dev_alloc(ctx, &ctx->depth, cap));
-    TRY(dev_alloc(ctx, &ctx->key_a, cap)); TRY(dev_alloc(ctx, &ctx->kv_b, cap)); TRY(dev_alloc(ctx, &ctx->val_a, cap));
-    TRY(dev_alloc(ctx, &ctx->proj, cap)); TRY(dev_alloc(ctx, &ctx->rect, cap));
-    TRY(dev_alloc(ctx, &ctx->tile_count, cap)); TRY(dev_alloc(ctx, &ctx->zwin, cap));
     ctx->cap = cap;
-    ctx->have_sort = false; ctx->sorted = nullptr;
-    TRY(gs_ensure_pair_capacity(ctx, cap * 8 > ((size_t)1 << 22) ? cap * 8 : (size_t)1 << 22));
-    return ensure_scan_scratch(ctx);
+    for (int i = 0; i < GS_MAX_LANES; i++) if (ctx->lanes[i]) { ctx->lanes[i]->have_sort = false; ctx->lanes[i]->sorted = nullptr; }
+    return ensure_lane_scratch(ctx, cap);                       // lane 0 now; the other lanes when they are next used
 }
 
 
@@ -138,21 +158,22 @@ static int prof_advance(gs_ctx *ctx)
 }
 
 // after a stream sync: publish the counters of the last completed frame and react to pair-buffer overflow
-static int collect_status(gs_ctx *ctx, bool *overflowed)
+static int collect_status(gs_ctx *lane, bool *overflowed)
 {
-    const GsControl *c = ctx->ctl_host;
-    ctx->stats.n_sorted = c->n_kept; ctx->stats.n_visible = c->n_visible; ctx->stats.n_pairs = c->n_pairs_frame;
-    ctx->stats.acc_frames = c->acc_frames; ctx->stats.acc_sorted = c->acc_sorted; ctx->stats.acc_visible = c->acc_visible;
-    ctx->stats.acc_pairs = c->acc_pairs;
+    gs_ctx *ctx = gs_root(lane);                                // the adaptive share is one state for all lanes ...
+    const GsControl *c = lane->ctl_host;                        // ... fed by each lane's own counters
+    lane->stats.n_sorted = c->n_kept; lane->stats.n_visible = c->n_visible; lane->stats.n_pairs = c->n_pairs_frame;
+    lane->stats.acc_frames = c->acc_frames; lane->stats.acc_sorted = c->acc_sorted; lane->stats.acc_visible = c->acc_visible;
+    lane->stats.acc_pairs = c->acc_pairs;
     // Adapt the share of splats binned in round 0.  An "event" = a frame whose round 0 left tiles unsaturated (round 1
     // re-binned for them): the share grows x1.5 and will never again shrink below 1.3 x the share that failed; without
     // events it shrinks 10 % per collected frame until the first event, 2 % afterwards.  After 16 clean frames round 1 is not even launched (11 empty kernels
     // cost ~50 us): blend<0> raises round1_missed if that was wrong, and the frame is completed / re-rendered.
-    if (ctx->near_fixed_permille <= 0 && ctx->stats.n_tiles) {
-        const uint32_t events = c->unsat_events - ctx->seen_unsat_events;
-        const uint64_t frames = c->acc_frames >= ctx->seen_acc_frames ? c->acc_frames - ctx->seen_acc_frames : 1;
-        ctx->seen_unsat_events = c->unsat_events; ctx->seen_acc_frames = c->acc_frames;
-        if (ctx->last_two_rounds) {
+    if (ctx->near_fixed_permille <= 0 && lane->stats.n_tiles) {
+        const uint32_t events = c->unsat_events - lane->seen_unsat_events;
+        const uint64_t frames = c->acc_frames >= lane->seen_acc_frames ? c->acc_frames - lane->seen_acc_frames : 1;
+        lane->seen_unsat_events = c->unsat_events; lane->seen_acc_frames = c->acc_frames;
+        if (lane->last_two_rounds) {
             if (events || c->round1_missed) {
                 const float fl = ctx->near_frac * 1.3f > 1.0f ? 1.0f : ctx->near_frac * 1.3f;
                 if (fl > ctx->near_floor) ctx->near_floor = fl;
@@ -171,21 +192,129 @@ static int collect_status(gs_ctx *ctx, bool *overflowed)
             ctx->near_frac = 0.5f; ctx->near_floor = 0.0f; ctx->single_round_frames = 0; ctx->clean_frames = 0;
         }
     }
-    ctx->stats.unsat_tiles = ctx->last_two_rounds ? c->unsat_round0 : 0;
-    ctx->stats.near_permille = (uint32_t)(ctx->near_frac * 1000.0f + 0.5f);
+    lane->stats.unsat_tiles = lane->last_two_rounds ? c->unsat_round0 : 0;
+    lane->stats.near_permille = (uint32_t)(ctx->near_frac * 1000.0f + 0.5f);
     *overflowed = c->overflow_sticky != 0;
     if (*overflowed) {
         const size_t need = (size_t)c->max_total + c->max_total / 4 + 1;
-        GS_HIP(hipMemsetAsync(&ctx->ctl->overflow_sticky, 0, 2 * sizeof(uint32_t), ctx->stream));
-        GS_HIP(hipStreamSynchronize(ctx->stream));
-        TRY(gs_ensure_pair_capacity(ctx, need));
+        GS_HIP(hipMemsetAsync(&lane->ctl->overflow_sticky, 0, 2 * sizeof(uint32_t), lane->stream));
+        GS_HIP(hipStreamSynchronize(lane->stream));
+        if (gs_ensure_pair_capacity(lane, need) != GS_OK) { if (lane != ctx) memcpy(ctx->err, lane->err, sizeof ctx->err); return GS_E_OOM; }
     }
     return GS_OK;
 }
 
+// ---------------------------------------------------------------- lanes (frame pipelining)
+
+#define LANE_HIP(L, call) do { hipError_t _e = (call); if (_e != hipSuccess) {                                             \
+        snprintf(ctx->err, sizeof ctx->err, "%s failed: %s (%s:%d)", #call, hipGetErrorString(_e), __FILE__, __LINE__);    \
+        return (_e == hipErrorOutOfMemory) ? GS_E_OOM : GS_E_HIP; } } while (0)
+
+// stream, control block, per-workgroup partial slots, pinned mirror: what every lane owns besides its scratch
+static hipError_t init_frame_resources(gs_ctx *c)
+{
+    hipError_t e;
+#define IFR(call) do { e = (call); if (e != hipSuccess) return e; } while (0)
+    IFR(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    c->own_stream = true;
+    IFR(hipMalloc((void **)&c->ctl, sizeof(GsControl)));
+    IFR(hipMemset(c->ctl, 0, sizeof(GsControl)));
+    IFR(hipMalloc((void **)&c->part_min, GS_MAX_PART * sizeof(unsigned long long)));
+    IFR(hipMalloc((void **)&c->part_max, GS_MAX_PART * sizeof(unsigned long long)));
+    IFR(hipMalloc((void **)&c->part_cnt, GS_MAX_PART * sizeof(uint32_t)));
+    IFR(hipMalloc((void **)&c->part_valid, GS_MAX_PART * sizeof(uint32_t)));
+    IFR(hipMalloc((void **)&c->part_vis, GS_MAX_PART * sizeof(uint32_t)));
+    IFR(hipHostMalloc((void **)&c->ctl_host, sizeof(GsControl), hipHostMallocDefault));
+    memset(c->ctl_host, 0, sizeof(GsControl));
+    IFR(hipEventCreateWithFlags(&c->ev_frame, hipEventDisableTiming | hipEventReleaseToDevice));
+    IFR(hipEventCreateWithFlags(&c->ev_gate, hipEventDisableTiming | hipEventReleaseToDevice));
+#undef IFR
+    return hipSuccess;
+}
+
+static void free_frame_resources(gs_ctx *c)
+{
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    dev_free(c->depth); dev_free(c->key_a); dev_free(c->kv_b); dev_free(c->val_a);
+    dev_free(c->hist); dev_free(c->spine);
+    dev_free(c->proj); dev_free(c->rect); dev_free(c->tile_count); dev_free(c->zwin);
+    dev_free(c->pair_a); dev_free(c->pair_b);
+    dev_free(c->tile_range); dev_free(c->fb); dev_free(c->ctl); dev_free(c->state); dev_free(c->unsat_mask);
+    dev_free(c->part_min); dev_free(c->part_max); dev_free(c->part_cnt); dev_free(c->part_valid); dev_free(c->part_vis);
+    if (c->ctl_host) { (void)hipHostFree(c->ctl_host); c->ctl_host = nullptr; }
+    if (c->ring) { for (int i = 0; i < GS_PROF_RING * GS_PROF_EVENTS; i++) if (c->ring[i]) (void)hipEventDestroy(c->ring[i]); free(c->ring); c->ring = nullptr; }
+    free(c->ring_flags); c->ring_flags = nullptr;
+    if (c->ev_frame) (void)hipEventDestroy(c->ev_frame);
+    if (c->ev_gate) (void)hipEventDestroy(c->ev_gate);
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    c->stream = nullptr;
+}
+
+// switch the HIP-event profiling of one lane on/off (allocates its ring on first use, restarts its accumulators)
+static int set_profile(gs_ctx *ctx, bool on)
+{
+    GS_HIP(hipStreamSynchronize(ctx->stream));
+    TRY(prof_drain(ctx));
+    if (on && !ctx->ring) {
+        ctx->ring = (hipEvent_t *)calloc(GS_PROF_RING * GS_PROF_EVENTS, sizeof(hipEvent_t));
+        ctx->ring_flags = (uint8_t *)calloc(GS_PROF_RING, 1);
+        if (!ctx->ring || !ctx->ring_flags) FAIL(GS_E_OOM, "out of host memory");
+        for (int i = 0; i < GS_PROF_RING * GS_PROF_EVENTS; i++) GS_HIP(hipEventCreate(&ctx->ring[i]));
+    }
+    if (on && !ctx->profile) {                                   // (re)start accumulation
+        ctx->stats.prof_frames = 0;
+        ctx->stats.sum_ms_sort = ctx->stats.sum_ms_project = ctx->stats.sum_ms_bin = ctx->stats.sum_ms_blend = 0;
+        GS_HIP(hipMemsetAsync(&ctx->ctl->acc_frames, 0, sizeof(GsControl) - offsetof(GsControl, acc_frames), ctx->stream));
+        ctx->seen_acc_frames = 0;
+    }
+    ctx->profile = on;
+    return GS_OK;
+}
+
+// lane i of the owner `ctx`, created on first use, with the owner's current resident arrays / options and scratch for them
+static int get_lane(gs_ctx *ctx, int i, gs_ctx **out)
+{
+    gs_ctx *L = ctx->lanes[i];
+    if (!L) {
+        L = new (std::nothrow) gs_ctx();
+        if (!L) FAIL(GS_E_OOM, "out of host memory");
+        memset(L, 0, sizeof *L);
+        L->parent = ctx; L->device = ctx->device;
+        const hipError_t e = init_frame_resources(L);
+        if (e != hipSuccess) {
+            snprintf(ctx->err, sizeof ctx->err, "creating pipeline lane %d failed: %s", i, hipGetErrorString(e));
+            free_frame_resources(L); delete L;
+            return e == hipErrorOutOfMemory ? GS_E_OOM : GS_E_HIP;
+        }
+        ctx->lanes[i] = L;
+        if (ctx->profile && set_profile(L, true) != GS_OK) { memcpy(ctx->err, L->err, sizeof ctx->err); return GS_E_HIP; }
+    }
+    if (L != ctx) {
+        L->splat = ctx->splat; L->sort_rows = ctx->sort_rows; L->pow10tab = ctx->pow10tab;
+        L->n = ctx->n; L->cap = ctx->cap; L->renderable = ctx->renderable;
+        L->scene_depth = ctx->scene_depth; L->scene_rgba = ctx->scene_rgba; L->scene_w = ctx->scene_w; L->scene_h = ctx->scene_h;
+        L->record_staged = ctx->record_staged; L->t_eps = ctx->t_eps;
+        if (ensure_lane_scratch(L, ctx->cap) != GS_OK) { memcpy(ctx->err, L->err, sizeof ctx->err); return GS_E_OOM; }
+    }
+    *out = L;
+    return GS_OK;
+}
+
+// the lane a NEW frame goes to: the next one if the current frame was handed off asynchronously
+static int next_frame_lane(const gs_ctx *ctx)
+{
+    return (ctx->cur_async && !ctx->user_stream && ctx->pipe_depth > 1) ? (ctx->cur + 1) % ctx->pipe_depth : ctx->cur;
+}
+
+static int lane_rc(gs_ctx *ctx, gs_ctx *L, int rc)
+{
+    if (rc != GS_OK && L != ctx) memcpy(ctx->err, L->err, sizeof ctx->err);
+    return rc;
+}
+
 extern "C" {
 
-GS_API uint32_t gs_version(void) { return 0x000200; }
+GS_API uint32_t gs_version(void) { return 0x000300; }
 
 GS_API const char *gs_last_error(const gs_ctx *ctx) { return ctx ? ctx->err : g_create_err; }
 
@@ -208,21 +337,12 @@ GS_API int gs_create(int device, gs_ctx **out)
     if (!ctx) { snprintf(g_create_err, sizeof g_create_err, "out of host memory"); return GS_E_OOM; }
     memset(ctx, 0, sizeof *ctx);
     ctx->device = device; ctx->renderable = true; ctx->t_eps = 1.0f / 4096.0f; ctx->near_frac = 0.25f;
+    ctx->lanes[0] = ctx; ctx->pipe_depth = 3;
 #define CREATE_HIP(call) do { hipError_t _e = (call); if (_e != hipSuccess) {                                              \
         snprintf(g_create_err, sizeof g_create_err, "%s failed: %s", #call, hipGetErrorString(_e)); gs_destroy(ctx);      \
         return GS_E_HIP; } } while (0)
     CREATE_HIP(hipSetDevice(device));
-    CREATE_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
-    ctx->own_stream = true;
-    CREATE_HIP(hipMalloc((void **)&ctx->ctl, sizeof(GsControl)));
-    CREATE_HIP(hipMemset(ctx->ctl, 0, sizeof(GsControl)));
-    CREATE_HIP(hipMalloc((void **)&ctx->part_min, GS_MAX_PART * sizeof(unsigned long long)));
-    CREATE_HIP(hipMalloc((void **)&ctx->part_max, GS_MAX_PART * sizeof(unsigned long long)));
-    CREATE_HIP(hipMalloc((void **)&ctx->part_cnt, GS_MAX_PART * sizeof(uint32_t)));
-    CREATE_HIP(hipMalloc((void **)&ctx->part_valid, GS_MAX_PART * sizeof(uint32_t)));
-    CREATE_HIP(hipMalloc((void **)&ctx->part_vis, GS_MAX_PART * sizeof(uint32_t)));
-    CREATE_HIP(hipHostMalloc((void **)&ctx->ctl_host, sizeof(GsControl), hipHostMallocDefault));
-    memset(ctx->ctl_host, 0, sizeof(GsControl));
+    CREATE_HIP(init_frame_resources(ctx));
     {
         std::vector<double> tab(GS_POW10_ENTRIES);
         gs_build_pow10_table(tab.data());
@@ -238,19 +358,11 @@ GS_API int gs_destroy(gs_ctx *ctx)
 {
     if (!ctx) return GS_OK;
     (void)hipSetDevice(ctx->device);
-    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    for (int i = 1; i < GS_MAX_LANES; i++)
+        if (ctx->lanes[i]) { free_frame_resources(ctx->lanes[i]); delete ctx->lanes[i]; ctx->lanes[i] = nullptr; }
+    free_frame_resources(ctx);
     dev_free(ctx->splat); dev_free(ctx->sort_rows); dev_free(ctx->pow10tab);
-    dev_free(ctx->depth); dev_free(ctx->key_a); dev_free(ctx->kv_b); dev_free(ctx->val_a);
-    dev_free(ctx->hist); dev_free(ctx->spine);
-    dev_free(ctx->proj); dev_free(ctx->rect); dev_free(ctx->tile_count); dev_free(ctx->zwin);
     dev_free(ctx->scene_depth); dev_free(ctx->scene_rgba);
-    dev_free(ctx->pair_a); dev_free(ctx->pair_b);
-    dev_free(ctx->tile_range); dev_free(ctx->fb); dev_free(ctx->ctl); dev_free(ctx->state); dev_free(ctx->unsat_mask);
-    dev_free(ctx->part_min); dev_free(ctx->part_max); dev_free(ctx->part_cnt); dev_free(ctx->part_valid); dev_free(ctx->part_vis);
-    if (ctx->ctl_host) (void)hipHostFree(ctx->ctl_host);
-    if (ctx->ring) { for (int i = 0; i < GS_PROF_RING * GS_PROF_EVENTS; i++) if (ctx->ring[i]) (void)hipEventDestroy(ctx->ring[i]); free(ctx->ring); }
-    free(ctx->ring_flags);
-    if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return GS_OK;
 }
@@ -259,10 +371,16 @@ GS_API int gs_clear(gs_ctx *ctx)
 {
     CHECK_CTX(ctx);
     GS_HIP(hipSetDevice(ctx->device));
-    GS_HIP(hipStreamSynchronize(ctx->stream));
-    ctx->n = 0; ctx->renderable = true; ctx->have_sort = false; ctx->sorted = nullptr;
+    TRY(drain_all(ctx));
+    ctx->n = 0; ctx->renderable = true;
     ctx->near_frac = 0.25f; ctx->near_floor = 0.0f; ctx->clean_frames = 0; ctx->skip_hold = 0; ctx->single_round_frames = 0;
-    memset(&ctx->stats, 0, sizeof ctx->stats);
+    for (int i = 0; i < GS_MAX_LANES; i++) {
+        gs_ctx *L = ctx->lanes[i];
+        if (!L) continue;
+        L->have_sort = false; L->sorted = nullptr; L->n = 0;
+        memset(&L->stats, 0, sizeof L->stats);
+    }
+    ctx->cur = 0; ctx->cur_async = false;
     return GS_OK;
 }
 
@@ -275,7 +393,8 @@ static int append_device_rows(gs_ctx *ctx, const uint4 *rows_dev, size_t nrows)
     const hipError_t e = hipStreamSynchronize(ctx->stream);
     if (rc == GS_OK && e != hipSuccess) { snprintf(ctx->err, sizeof ctx->err, "pack failed: %s", hipGetErrorString(e)); rc = GS_E_HIP; }
     if (rc != GS_OK) return rc;
-    ctx->n += nrows; ctx->renderable = true; ctx->have_sort = false;
+    ctx->n += nrows; ctx->renderable = true;
+    for (int i = 0; i < GS_MAX_LANES; i++) if (ctx->lanes[i]) ctx->lanes[i]->have_sort = false;
     ctx->stats.n_splats = ctx->n;
     return GS_OK;
 }
@@ -287,6 +406,7 @@ GS_API int gs_push_splat(gs_ctx *ctx, const void *rows, size_t nrows)
     if (!rows) FAIL(GS_E_BADARG, "gs_push_splat: rows is NULL");
     if (!ctx->renderable && ctx->n) FAIL(GS_E_STATE, "gs_push_splat after gs_push_matrices: mixed ingest is not supported");
     GS_HIP(hipSetDevice(ctx->device));
+    TRY(drain_all(ctx));
     TRY(ensure_capacity(ctx, ctx->n + nrows));
     uint4 *stage = nullptr;
     TRY(dev_alloc(ctx, &stage, nrows * 2));
@@ -306,11 +426,13 @@ GS_API int gs_push_matrices(gs_ctx *ctx, const float *matrices, size_t nrows)
     if (!matrices) FAIL(GS_E_BADARG, "gs_push_matrices: matrices is NULL");
     if (ctx->renderable && ctx->n) FAIL(GS_E_STATE, "gs_push_matrices after gs_push_splat: mixed ingest is not supported");
     GS_HIP(hipSetDevice(ctx->device));
+    TRY(drain_all(ctx));
     TRY(ensure_capacity(ctx, ctx->n + nrows));
     // strided H2D copy: only elements 12..15 of every 16-float row are ever read (index.js:520-548)
     GS_HIP(hipMemcpy2DAsync(ctx->sort_rows + ctx->n, 16, matrices + 12, 64, 16, nrows, hipMemcpyHostToDevice, ctx->stream));
     GS_HIP(hipStreamSynchronize(ctx->stream));
-    ctx->n += nrows; ctx->renderable = false; ctx->have_sort = false;
+    ctx->n += nrows; ctx->renderable = false;
+    for (int i = 0; i < GS_MAX_LANES; i++) if (ctx->lanes[i]) ctx->lanes[i]->have_sort = false;
     ctx->stats.n_splats = ctx->n;
     return GS_OK;
 }
@@ -327,6 +449,7 @@ static int ply_rows_to_device(gs_ctx *ctx, const void *bytes, size_t nbytes, uin
     *nrows = n;
     if (rc != GS_OK || !n) return rc;
     GS_HIP(hipSetDevice(ctx->device));
+    TRY(drain_all(ctx));                                        // the converter borrows lane 0's stream and radix scratch
     uint4 *rows = nullptr;
     TRY(dev_alloc(ctx, &rows, n * 2));
     bool had_nan = false;
@@ -382,23 +505,28 @@ GS_API int gs_sort(gs_ctx *ctx, const float view[4], const float *cutout16, uint
     if (ctx->n == 0) {                                          // sort before any push (index.js:588-590)
         if (out_idx) out_idx[0] = 0;
         if (out_n) *out_n = 1;
-        ctx->have_sort = false; ctx->stats.n_sorted = 0;
+        ctx->lanes[ctx->cur]->have_sort = false; ctx->lanes[ctx->cur]->stats.n_sorted = 0;
         return GS_OK;
     }
     GS_HIP(hipSetDevice(ctx->device));
-    TRY(gs_run_sort(ctx, view, cutout16));
+    // a sort starts a frame: it goes to the next lane if the previous frame was handed off with GS_RENDER_ASYNC
+    gs_ctx *L = nullptr;
+    const int lane = next_frame_lane(ctx);
+    TRY(get_lane(ctx, lane, &L));
+    ctx->cur = lane; ctx->cur_async = false;
+    TRY(lane_rc(ctx, L, gs_run_sort(L, view, cutout16)));
     if (out_idx || out_n) {
-        GS_HIP(hipMemcpyAsync(ctx->ctl_host, ctx->ctl, sizeof(GsControl), hipMemcpyDeviceToHost, ctx->stream));
-        GS_HIP(hipStreamSynchronize(ctx->stream));
-        const uint32_t V = ctx->ctl_host->n_kept;
-        ctx->stats.n_sorted = V; ctx->sorted_n_host = V;
+        LANE_HIP(L, hipMemcpyAsync(L->ctl_host, L->ctl, sizeof(GsControl), hipMemcpyDeviceToHost, L->stream));
+        LANE_HIP(L, hipStreamSynchronize(L->stream));
+        const uint32_t V = L->ctl_host->n_kept;
+        L->stats.n_sorted = V; L->sorted_n_host = V;
         if (out_n) *out_n = V;
-        if (out_idx && V) GS_HIP(hipMemcpy(out_idx, ctx->sorted, (size_t)V * 4, hipMemcpyDeviceToHost));
+        if (out_idx && V) GS_HIP(hipMemcpy(out_idx, L->sorted, (size_t)V * 4, hipMemcpyDeviceToHost));
     }
     return GS_OK;
 }
 
-static int fill_uniforms(gs_ctx *ctx, const gs_render_params *p, GsFrameUniforms &u)
+static int fill_uniforms(gs_ctx *ctx /* owner: options, adaptive share, scene */, const gs_render_params *p, GsFrameUniforms &u)
 {
     if (!p) FAIL(GS_E_BADARG, "render params NULL");
     if (p->fb_width <= 0 || p->fb_height <= 0 || p->fb_width > 65535 * GS_TILE || p->fb_height > 65535 * GS_TILE)
@@ -424,12 +552,10 @@ static int fill_uniforms(gs_ctx *ctx, const gs_render_params *p, GsFrameUniforms
     return GS_OK;
 }
 
-static int render_common(gs_ctx *ctx, const gs_render_params *p, void *device_rgba, uint8_t *host_rgba, size_t stride)
+// one frame on lane `ctx` (the owner supplies options and the adaptive share through fill_uniforms)
+static int render_on_lane(gs_ctx *ctx, const GsFrameUniforms &u0, void *device_rgba, uint8_t *host_rgba, size_t stride)
 {
-    if (!ctx->renderable && ctx->n) FAIL(GS_E_STATE, "context was fed worker matrices only (gs_push_matrices): it can sort but not render");
-    GsFrameUniforms u;
-    TRY(fill_uniforms(ctx, p, u));
-    GS_HIP(hipSetDevice(ctx->device));
+    GsFrameUniforms u = u0;
     const size_t sw = (size_t)(u.x1 - u.x0), fb_bytes = sw * (size_t)u.H * 4;
     const size_t ntiles = (size_t)u.tiles_x * u.tiles_y;
     if (ntiles > ctx->tile_cap) { dev_free(ctx->tile_range); TRY(dev_alloc(ctx, &ctx->tile_range, ntiles)); ctx->tile_cap = ntiles; }
@@ -447,6 +573,7 @@ static int render_common(gs_ctx *ctx, const gs_render_params *p, void *device_rg
         TRY(gs_run_render(ctx, u, (uint8_t *)device_rgba));
         GS_HIP(hipMemcpyAsync(ctx->ctl_host, ctx->ctl, sizeof(GsControl), hipMemcpyDeviceToHost, ctx->stream));
         ctx->async_pending = true;
+        gs_root(ctx)->cur_async = true;
         return prof_advance(ctx);
     }
     for (int attempt = 0;; attempt++) {
@@ -478,6 +605,17 @@ static int render_common(gs_ctx *ctx, const gs_render_params *p, void *device_rg
     return GS_OK;
 }
 
+static int render_common(gs_ctx *ctx, const gs_render_params *p, void *device_rgba, uint8_t *host_rgba, size_t stride)
+{
+    if (!ctx->renderable && ctx->n) FAIL(GS_E_STATE, "context was fed worker matrices only (gs_push_matrices): it can sort but not render");
+    GsFrameUniforms u;
+    TRY(fill_uniforms(ctx, p, u));
+    GS_HIP(hipSetDevice(ctx->device));
+    gs_ctx *L = nullptr;
+    TRY(get_lane(ctx, ctx->cur, &L));                           // the frame's lane: where its gs_sort ran
+    return lane_rc(ctx, L, render_on_lane(L, u, device_rgba, host_rgba, stride));
+}
+
 GS_API int gs_render(gs_ctx *ctx, const gs_render_params *p, uint8_t *rgba_out, size_t stride)
 {
     CHECK_CTX(ctx);
@@ -503,7 +641,7 @@ GS_API int gs_set_scene(gs_ctx *ctx, const float *depth, const uint8_t *rgba, in
 {
     CHECK_CTX(ctx);
     GS_HIP(hipSetDevice(ctx->device));
-    GS_HIP(hipStreamSynchronize(ctx->stream));
+    TRY(drain_all(ctx));
     dev_free(ctx->scene_depth); dev_free(ctx->scene_rgba);
     ctx->scene_w = ctx->scene_h = 0;
     if (!depth && !rgba) return GS_OK;
@@ -519,19 +657,26 @@ GS_API int gs_sync(gs_ctx *ctx)
 {
     CHECK_CTX(ctx);
     GS_HIP(hipSetDevice(ctx->device));
-    GS_HIP(hipStreamSynchronize(ctx->stream));
-    TRY(prof_drain(ctx));
-    if (ctx->async_pending) {
-        ctx->async_pending = false;
-        const bool missed = ctx->ctl_host->round1_missed != 0;
-        if (missed) GS_HIP(hipMemsetAsync(&ctx->ctl->round1_missed, 0, sizeof(uint32_t), ctx->stream));
+    bool any_missed = false, any_over = false;
+    uint32_t want = 0;
+    for (int i = 0; i < GS_MAX_LANES; i++) {
+        gs_ctx *L = ctx->lanes[i];
+        if (!L) continue;
+        LANE_HIP(L, hipStreamSynchronize(L->stream));
+        TRY(lane_rc(ctx, L, prof_drain(L)));
+        if (!L->async_pending) continue;
+        L->async_pending = false;
+        const bool missed = L->ctl_host->round1_missed != 0;
+        if (missed) LANE_HIP(L, hipMemsetAsync(&L->ctl->round1_missed, 0, sizeof(uint32_t), L->stream));
         bool over = false;
-        TRY(collect_status(ctx, &over));
-        if (missed) FAIL(GS_E_RETRY, "an asynchronous frame skipped its second binning round but a tile had not saturated; "
-                                     "the share of splats binned first was raised - render the frames since the previous gs_sync() again");
-        if (over) FAIL(GS_E_RETRY, "an asynchronous frame needed %u pairs and overflowed the pair buffers; they were enlarged - "
-                                   "render the frames since the previous gs_sync() again", ctx->ctl_host->max_total);
+        TRY(collect_status(L, &over));
+        any_missed |= missed; any_over |= over;
+        if (over && L->ctl_host->max_total > want) want = L->ctl_host->max_total;
     }
+    if (any_missed) FAIL(GS_E_RETRY, "an asynchronous frame skipped its second binning round but a tile had not saturated; "
+                                     "the share of splats binned first was raised - render the frames since the previous gs_sync() again");
+    if (any_over) FAIL(GS_E_RETRY, "an asynchronous frame needed %u pairs and overflowed the pair buffers; they were enlarged - "
+                                   "render the frames since the previous gs_sync() again", want);
     return GS_OK;
 }
 
@@ -539,12 +684,38 @@ GS_API int gs_set_stream(gs_ctx *ctx, void *hip_stream)
 {
     CHECK_CTX(ctx);
     GS_HIP(hipSetDevice(ctx->device));
-    GS_HIP(hipStreamSynchronize(ctx->stream));
+    TRY(drain_all(ctx));
     if (ctx->own_stream) { (void)hipStreamDestroy(ctx->stream); ctx->own_stream = false; }
     if (hip_stream) ctx->stream = (hipStream_t)hip_stream;
     else { GS_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)); ctx->own_stream = true; }
+    // on a caller-owned stream every frame is ordered with the caller's own work on it: no lane rotation
+    ctx->user_stream = hip_stream != nullptr;
+    ctx->cur = 0; ctx->cur_async = false;
     return GS_OK;
 }
+
+GS_API int gs_wait_stream(gs_ctx *ctx, void *hip_stream)
+{
+    CHECK_CTX(ctx);
+    GS_HIP(hipSetDevice(ctx->device));
+    gs_ctx *L = nullptr;
+    TRY(get_lane(ctx, next_frame_lane(ctx), &L));               // the lane the next gs_sort() will use
+    GS_HIP(hipEventRecord(L->ev_gate, (hipStream_t)hip_stream));
+    GS_HIP(hipStreamWaitEvent(L->stream, L->ev_gate, 0));
+    return GS_OK;
+}
+
+GS_API int gs_stream_wait_frame(gs_ctx *ctx, void *hip_stream)
+{
+    CHECK_CTX(ctx);
+    GS_HIP(hipSetDevice(ctx->device));
+    gs_ctx *L = ctx->lanes[ctx->cur];
+    GS_HIP(hipEventRecord(L->ev_frame, L->stream));
+    GS_HIP(hipStreamWaitEvent((hipStream_t)hip_stream, L->ev_frame, 0));
+    return GS_OK;
+}
+
+GS_API void *gs_frame_stream(gs_ctx *ctx) { return ctx ? (void *)ctx->lanes[ctx->cur]->stream : nullptr; }
 
 GS_API int gs_set_option(gs_ctx *ctx, int option, int64_t value)
 {
@@ -552,20 +723,8 @@ GS_API int gs_set_option(gs_ctx *ctx, int option, int64_t value)
     switch (option) {
     case GS_OPT_PROFILE:
         GS_HIP(hipSetDevice(ctx->device));
-        GS_HIP(hipStreamSynchronize(ctx->stream));
-        TRY(prof_drain(ctx));
-        if (value && !ctx->ring) {
-            ctx->ring = (hipEvent_t *)calloc(GS_PROF_RING * GS_PROF_EVENTS, sizeof(hipEvent_t));
-            ctx->ring_flags = (uint8_t *)calloc(GS_PROF_RING, 1);
-            if (!ctx->ring || !ctx->ring_flags) FAIL(GS_E_OOM, "out of host memory");
-            for (int i = 0; i < GS_PROF_RING * GS_PROF_EVENTS; i++) GS_HIP(hipEventCreate(&ctx->ring[i]));
-        }
-        if (value && !ctx->profile) {                    // (re)start accumulation
-            ctx->stats.prof_frames = 0;
-            ctx->stats.sum_ms_sort = ctx->stats.sum_ms_project = ctx->stats.sum_ms_bin = ctx->stats.sum_ms_blend = 0;
-            GS_HIP(hipMemsetAsync(&ctx->ctl->acc_frames, 0, sizeof(GsControl) - offsetof(GsControl, acc_frames), ctx->stream));
-        }
-        ctx->profile = value != 0;
+        for (int i = 0; i < GS_MAX_LANES; i++)
+            if (ctx->lanes[i]) TRY(lane_rc(ctx, ctx->lanes[i], set_profile(ctx->lanes[i], value != 0)));
         return GS_OK;
     case GS_OPT_NEAR_PERMILLE:
         if (value < 0 || value > 1000) FAIL(GS_E_BADARG, "near permille must be 0 (adaptive) .. 1000 (single round)");
@@ -576,6 +735,13 @@ GS_API int gs_set_option(gs_ctx *ctx, int option, int64_t value)
     case GS_OPT_TERMINATION:
         if (value < 2) FAIL(GS_E_BADARG, "termination 1/eps must be >= 2");
         ctx->t_eps = 1.0f / (float)value; return GS_OK;
+    case GS_OPT_PIPELINE_DEPTH:
+        if (value < 1 || value > GS_MAX_LANES) FAIL(GS_E_BADARG, "pipeline depth must be 1..%d", GS_MAX_LANES);
+        GS_HIP(hipSetDevice(ctx->device));
+        TRY(drain_all(ctx));
+        ctx->pipe_depth = (int)value;
+        if (ctx->cur >= ctx->pipe_depth) { ctx->cur = 0; ctx->cur_async = false; }
+        return GS_OK;
     default: FAIL(GS_E_BADARG, "unknown option %d", option);
     }
 }
@@ -584,8 +750,22 @@ GS_API int gs_get_stats(gs_ctx *ctx, gs_stats *out)
 {
     CHECK_CTX(ctx);
     if (!out) FAIL(GS_E_BADARG, "gs_get_stats: out is NULL");
-    ctx->stats.n_splats = ctx->n;
-    *out = ctx->stats;
+    // per-frame figures: the current frame's lane; accumulators: summed over the lanes
+    gs_stats s = ctx->lanes[ctx->cur]->stats;
+    s.prof_frames = 0; s.sum_ms_sort = s.sum_ms_project = s.sum_ms_bin = s.sum_ms_blend = 0;
+    s.acc_frames = 0; s.acc_sorted = s.acc_visible = s.acc_pairs = 0;
+    for (int i = 0; i < GS_MAX_LANES; i++) {
+        const gs_ctx *L = ctx->lanes[i];
+        if (!L) continue;
+        s.prof_frames += L->stats.prof_frames;
+        s.sum_ms_sort += L->stats.sum_ms_sort; s.sum_ms_project += L->stats.sum_ms_project;
+        s.sum_ms_bin += L->stats.sum_ms_bin; s.sum_ms_blend += L->stats.sum_ms_blend;
+        s.acc_frames += L->stats.acc_frames; s.acc_sorted += L->stats.acc_sorted;
+        s.acc_visible += L->stats.acc_visible; s.acc_pairs += L->stats.acc_pairs;
+    }
+    s.n_splats = ctx->n;
+    s.near_permille = (uint32_t)(ctx->near_frac * 1000.0f + 0.5f);
+    *out = s;
     return GS_OK;
 }
 
@@ -594,9 +774,10 @@ GS_API int gs_download(gs_ctx *ctx, int which, void *out, size_t nbytes)
     CHECK_CTX(ctx);
     if (!out) FAIL(GS_E_BADARG, "gs_download: out is NULL");
     GS_HIP(hipSetDevice(ctx->device));
-    GS_HIP(hipStreamSynchronize(ctx->stream));
+    const gs_ctx *L = ctx->lanes[ctx->cur];                     // per-frame buffers: the current frame's lane
+    GS_HIP(hipStreamSynchronize(L->stream));
     const void *src = nullptr; size_t have = 0;
-    const size_t V = ctx->stats.n_sorted;
+    const size_t V = L->stats.n_sorted;
     if (which == GS_BUF_CENTER_SCALE || which == GS_BUF_COV_COLOR) {     // de-interleave the 32-byte splat records
         if (!ctx->renderable && ctx->n) FAIL(GS_E_STATE, "context holds worker rows only");
         if (nbytes > ctx->n * 16 || nbytes % 16) FAIL(GS_E_BADARG, "buffer %d holds %zu bytes, %zu requested", which, ctx->n * 16, nbytes);
@@ -606,10 +787,10 @@ GS_API int gs_download(gs_ctx *ctx, int which, void *out, size_t nbytes)
     }
     switch (which) {
     case GS_BUF_SORT_ROWS: src = ctx->sort_rows; have = ctx->n * 16; break;
-    case GS_BUF_SORTED: src = ctx->sorted; have = ctx->have_sort ? V * 4 : 0; break;
-    case GS_BUF_PROJECTED: src = ctx->proj; have = ctx->have_sort ? V * 32 : 0; break;
-    case GS_BUF_TILE_COUNT: src = ctx->tile_count; have = ctx->have_sort ? V * 4 : 0; break;
-    case GS_BUF_TILE_STATS: src = ctx->tile_range; have = ctx->tile_cap * 8; break;
+    case GS_BUF_SORTED: src = L->sorted; have = L->have_sort ? V * 4 : 0; break;
+    case GS_BUF_PROJECTED: src = L->proj; have = L->have_sort ? V * 32 : 0; break;
+    case GS_BUF_TILE_COUNT: src = L->tile_count; have = L->have_sort ? V * 4 : 0; break;
+    case GS_BUF_TILE_STATS: src = L->tile_range; have = L->tile_cap * 8; break;
     default: FAIL(GS_E_BADARG, "unknown buffer %d", which);
     }
     if (nbytes > have) FAIL(GS_E_BADARG, "buffer %d holds %zu bytes, %zu requested", which, have, nbytes);

@@ -16,6 +16,7 @@
 #define GS_PROF_EVENTS 7
 #define GS_MAX_PART 8192           // upper bound on the grid of any kernel that writes per-workgroup partials
 #define GS_CULLED_KEY 65536u       // depth-sort key of culled / dropped splats (sorts behind every bucket)
+#define GS_MAX_LANES 4             // frames in flight (GS_OPT_PIPELINE_DEPTH)
 
 // Device-resident control block: every data-dependent count lives here so that no stage needs a
 // host round trip; kernels read their problem size from it (grid-stride over chunks).
@@ -65,6 +66,19 @@ struct gs_ctx {
     hipStream_t stream;
     bool own_stream;
     char err[512];
+
+    // Frame pipelining.  A context owns up to GS_MAX_LANES "lanes": lane 0 is the context itself, the others are sibling
+    // gs_ctx records with their OWN stream, per-frame scratch, control block and profiling ring, whose resident arrays
+    // (splat, sort_rows, pow10tab, scene_*) alias the owner's.  Asynchronous frames rotate over the lanes, so the kernel
+    // chain of frame k+1 runs under the tail of frame k.
+    gs_ctx *parent;                // non-null for lanes 1..: the owning context
+    gs_ctx *lanes[GS_MAX_LANES];   // owner only; [0] = this
+    int pipe_depth;                // GS_OPT_PIPELINE_DEPTH (1 = no rotation)
+    int cur;                       // lane of the current frame (chosen by the last gs_sort)
+    bool cur_async;                // the current frame was rendered with GS_RENDER_ASYNC: the next gs_sort moves on
+    bool user_stream;              // gs_set_stream gave lane 0 a caller-owned stream: no rotation
+    size_t scratch_cap;            // splats the per-frame scratch of THIS lane is sized for
+    hipEvent_t ev_frame, ev_gate;  // gs_stream_wait_frame / gs_wait_stream
 
     // resident splat data (append-only; capacity doubles)
     size_t n, cap;
@@ -158,6 +172,7 @@ namespace gsm { struct PlyLayout; }
 int gs_ply_rows_device(gs_ctx *ctx, const uint8_t *host_data, const gsm::PlyLayout &layout, size_t n, uint4 *rows_out, bool *had_nan);
 extern "C" int gs_ply_plan(const void *bytes, size_t nbytes, gsm::PlyLayout *layout, size_t *nrows, size_t *data_start, char *err, size_t errlen);
 // ---- gs_api.hip
+static inline gs_ctx *gs_root(gs_ctx *c) { return c->parent ? c->parent : c; }
 int gs_ensure_pair_capacity(gs_ctx *ctx, size_t pairs);
 int gs_ensure_radix_scratch(gs_ctx *ctx, size_t items);         // histogram / totals scratch for a radix sort of `items` records
 // event k (0..GS_PROF_EVENTS-1) of the current profiling slot, or nullptr when profiling is off

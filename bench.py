@@ -62,10 +62,6 @@ def main():
         os.environ.setdefault("NCCL_DEBUG", "WARN")        # keep RCCL's version banner off stdout (ONE JSON line)
         os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        # a real (non-null) stream shared by torch, RCCL and the HIP library: the gather orders after the strip's
-        # kernels without any host round trip
-        stream = torch.cuda.Stream()
-        torch.cuda.set_stream(stream)
     capi = importlib.import_module(PKG + ".capi")
     synth = importlib.import_module(PKG + ".synth")
     mg = importlib.import_module(PKG + ".multigpu")
@@ -82,46 +78,42 @@ def main():
     cams = [pose(W, H, 360.0 * i / ORBIT_FRAMES, capi=capi) for i in range(ORBIT_FRAMES)]
     params = [capi.make_params(c["gs_mv"], c["gs_proj"], W, H, x0=x0, x1=x1, focal_=c["focal"]) for c in cams]
     strip = None
-    strips, gathereds, works = [], [], [None, None]
+    LANES = 3                                                # frames in flight (the library's default pipeline depth)
+    strips, gathereds, lane_streams = [], [], {}
     if multi:
-        # two strip buffers: the RCCL gather of frame k (on RCCL's own stream) overlaps the sort/render of frame k+1
-        for _ in range(2):
+        # One strip buffer per frame in flight.  The RCCL gather of a frame is queued on the SAME stream as the frame's
+        # kernels (gs_frame_stream: the library's pipeline lane, wrapped as a torch ExternalStream; c10d runs a blocking-
+        # style collective on the current stream), so it is ordered after the blend and before the frame that reuses the
+        # lane and the buffer -- no cross-stream event anywhere (each one stalls the pipeline for ~50 us here), and the
+        # gather of frame k overlaps the sort/render of frames k+1, k+2 on the other lanes.
+        for _ in range(LANES):
             strips.append(torch.zeros(mg.strip_buffer_bytes(W, H, world), dtype=torch.uint8, device="cuda"))   # tight H x sw x 4 rows
             gathereds.append([torch.zeros_like(strips[-1]) for _ in range(world)] if rank == 0 else None)
         strip = strips[0]
     last_frame = [None]
 
-    if multi:
-        assert stream.cuda_stream != 0
-        ctx.set_stream(stream.cuda_stream)
-
     def frame(i, flags=0):
         k = i % ORBIT_FRAMES
-        ctx.sort(cams[k]["view"], cams[k]["cutout"], want_indices=False)
         p = params[k]
         p.flags = flags
-        if multi:
-            b = i & 1
-            if works[b] is not None:                         # frame i-2 used this buffer: its gather must have landed
-                works[b].wait()
-                if rank == 0:
-                    last_frame[0] = mg.assemble(gathereds[b], W, H)     # row-major frame on the root
-            ctx.render_device(p, strips[b].data_ptr())
-            works[b] = mg.gather_strips_async(strips[b], dist, gathereds[b])
-            return None
-        ctx.render_device(p, None)
-        return None
+        ctx.sort(cams[k]["view"], cams[k]["cutout"], want_indices=False)
+        if not multi:
+            ctx.render_device(p, None)
+            return
+        b = i % LANES
+        ctx.render_device(p, strips[b].data_ptr())
+        sp = ctx.frame_stream()
+        if sp not in lane_streams:
+            lane_streams[sp] = torch.cuda.ExternalStream(sp)
+        with torch.cuda.stream(lane_streams[sp]):
+            dist.gather(strips[b], gathereds[b] if rank == 0 else None, dst=0)
+            if rank == 0:
+                last_frame[0] = mg.assemble(gathereds[b], W, H)     # row-major frame on the root
 
     def sync():
         """Drain the stream; True if the library asks for the frames since the last sync to be rendered again
         (GS_E_RETRY) -- agreed on by all ranks so that their control flow stays identical."""
         need = 0
-        for b in range(2):
-            if works[b] is not None:
-                works[b].wait()
-                if rank == 0:
-                    last_frame[0] = mg.assemble(gathereds[b], W, H)
-                works[b] = None
         try:
             ctx.sync()                                       # collects status/statistics of the asynchronous frames
         except capi.GsError as e:
@@ -154,6 +146,8 @@ def main():
     # region, rank 0's strip): the byte count behind `roofline.achieved_touched`
     staged_per_frame = None
     if rank == 0:
+        if multi:                                            # no gather may still be reading the strip buffers
+            torch.cuda.synchronize()
         ctx.set_option(capi.OPT_RECORD_STAGED, 1)
         ctx.set_option(capi.OPT_NEAR_PERMILLE, 1000)
         tot = []

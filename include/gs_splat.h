@@ -137,10 +137,23 @@ GS_API int gs_render_stereo(gs_ctx *ctx, const gs_render_params eyes[2], uint8_t
 GS_API int gs_set_scene(gs_ctx *ctx, const float *depth, const uint8_t *rgba, int fb_width, int fb_height);
 
 /* Block until all work queued on the context's stream is done; collects the status and statistics of frames
- * rendered with GS_RENDER_ASYNC (GS_E_RETRY if one of them overflowed the pair buffers). */
+ * rendered with GS_RENDER_ASYNC on any lane (GS_E_RETRY if one of them overflowed the pair buffers). */
 GS_API int gs_sync(gs_ctx *ctx);
-/* Run the context's kernels on a caller-owned hipStream_t (e.g. torch's current stream). NULL = own stream. */
+/* Run the context's kernels on a caller-owned hipStream_t (e.g. torch's current stream). NULL = own stream.
+ * On a caller-owned stream every frame is ordered with the caller's other work on it, so frames are not pipelined
+ * over lanes (GS_OPT_PIPELINE_DEPTH is ignored); use the two calls below to couple pipelined frames to other streams. */
 GS_API int gs_set_stream(gs_ctx *ctx, void *hip_stream);
+/* GPU-side ordering between pipelined frames and the caller's own streams (no host blocking):
+ * gs_wait_stream: the NEXT frame (next gs_sort + its renders) starts only after everything queued on hip_stream so
+ *                 far, e.g. a collective that still reads the buffer that frame will render into;
+ * gs_stream_wait_frame: hip_stream waits for the frame enqueued LAST (its gs_sort + renders so far), e.g. before a
+ *                 collective or copy on that stream consumes the frame's device_rgba. */
+/* The hipStream_t the current frame (last gs_sort + its renders) was enqueued on: work the caller queues on it -- a
+ * collective over the frame's device_rgba, a copy -- is ordered after the frame and before the frame that will reuse
+ * this lane, without any cross-stream event (those cost ~50 us of pipeline stall each on this platform). */
+GS_API void *gs_frame_stream(gs_ctx *ctx);
+GS_API int gs_wait_stream(gs_ctx *ctx, void *hip_stream);
+GS_API int gs_stream_wait_frame(gs_ctx *ctx, void *hip_stream);
 
 /* ---- uniforms / camera helpers (host side; reference: tick + camera matrices, index.js:438-487) ------ */
 
@@ -189,6 +202,11 @@ typedef struct gs_stats {
 #define GS_OPT_RECORD_STAGED 4  /* value != 0: each render overwrites the tile-range table with (list entries staged,
                                    list length) per tile, readable with gs_download(GS_BUF_TILE_STATS) (measurement aid);
                                    value 2 records the entries the tile evaluated before it saturated instead of staged */
+#define GS_OPT_PIPELINE_DEPTH 5 /* 1..4 (default 3): frames enqueued with GS_RENDER_ASYNC rotate over this many internal lanes
+                                   (own HIP stream + own per-frame scratch, resident splat data shared), so the kernel
+                                   chain of frame k+1 runs under the tail of frame k -- as the reference overlaps its
+                                   worker sort with drawing.  A gs_sort() begins a frame; it moves to the next lane when
+                                   the previous frame was handed off asynchronously.  1 = strictly one frame at a time   */
 GS_API int gs_set_option(gs_ctx *ctx, int option, int64_t value);
 GS_API int gs_get_stats(gs_ctx *ctx, gs_stats *out);
 

@@ -572,3 +572,57 @@ def test_xr_per_eye_sort_option(ctx, scene_small):
         mv, P, focal = _f32(eye)
         ref, _, _ = oracle.render(scene_small["cs"], scene_small["cc"], idx, mv, P, focal, eye["vw"], eye["vh"], want_f32=False)
         assert np.abs(img.astype(int) - ref.astype(int)).max() <= PIXEL_TOL_LSB
+
+
+# ---------------------------------------------------------------- frame pipelining (GS_OPT_PIPELINE_DEPTH)
+
+@pytest.mark.parametrize("depth", [1, 2, 3, 4])
+def test_pipelined_frames_on_lanes_equal_synchronous_frames(scene_small, depth):
+    """Asynchronous frames rotate over `depth` lanes (own stream + per-frame scratch, shared resident data) so that
+    consecutive frames overlap on the GPU.  Every frame must still be exactly the frame a synchronous render gives --
+    also after the resident data grew under the lanes' feet -- and the accumulated statistics must count every frame."""
+    import torch
+    rows = np.asarray(scene_small["rows"]).reshape(-1, 32)
+    w, h = 480, 270
+    cams = [synth.index_html_camera(w, h, 30.0 * i, capi=capi) for i in range(12)]
+
+    def pipelined(c):
+        bufs = [torch.zeros(w * h * 4, dtype=torch.uint8, device="cuda") for _ in cams]
+        streams = []
+        for attempt in range(4):
+            for cam, buf in zip(cams, bufs):
+                c.sort(cam["view"], want_indices=False)
+                c.render_device(_params(cam, flags=capi.RENDER_ASYNC), buf.data_ptr())
+                streams.append(c.frame_stream())
+            try:
+                c.sync()
+                break
+            except capi.GsError as e:                                      # adaptive share / pair capacity settled: again
+                assert e.code == capi.E_RETRY and attempt < 3
+                streams.clear()
+        torch.cuda.synchronize()
+        return [b.cpu().numpy().reshape(h, w, 4) for b in bufs], streams
+
+    with capi.Context(0) as c:
+        c.set_option(capi.OPT_PIPELINE_DEPTH, depth)
+        c.push_splat(rows[:20000])
+        want = []
+        for cam in cams:
+            c.sort(cam["view"]); want.append(c.render(_params(cam)))
+        c.set_option(capi.OPT_PROFILE, 1)
+        got, streams = pipelined(c)
+        s = c.stats()
+        assert s["acc_frames"] >= len(cams) and s["acc_frames"] == s["prof_frames"] and s["sum_ms_blend"] > 0
+        c.set_option(capi.OPT_PROFILE, 0)
+        for a, b in zip(got, want):
+            assert np.array_equal(a, b)
+        assert len(set(streams[:depth])) == depth                         # consecutive frames went to different lanes ...
+        assert streams[:len(cams) - depth] == streams[depth:len(cams)]      # ... in rotation
+        c.push_splat(rows[20000:])                                          # resident arrays and every lane's scratch regrow
+        want2 = []
+        for cam in cams:
+            c.sort(cam["view"]); want2.append(c.render(_params(cam)))
+        got2, _ = pipelined(c)
+        for a, b in zip(got2, want2):
+            assert np.array_equal(a, b)
+        assert not np.array_equal(want2[0], want[0])
