@@ -22,7 +22,9 @@ def strip_widths(width, world):
 def gather_strips(strip_flat, width, height, dist, gathered=None, dst=0):
     """Gather every rank's strip (a flat uint8 tensor holding tight H x w_r x 4 rows at its front, padded to the
     widest strip so all messages have one size) to `dst` and assemble the row-major H x W x 4 frame there.
-    Returns the frame on dst, None elsewhere."""
+    Returns the frame on dst, None elsewhere.  Both steps are queued on the CURRENT torch stream: bench.py makes that
+    the stream of the pipeline lane the frame was rendered on (Context.frame_stream), so the gather follows the frame's
+    blend and precedes the next frame on that lane with no cross-stream event."""
     import torch
     world, rank = dist.get_world_size(), dist.get_rank()
     if rank == dst and gathered is None:
@@ -31,20 +33,6 @@ def gather_strips(strip_flat, width, height, dist, gathered=None, dst=0):
     if rank != dst:
         return None
     widths = strip_widths(width, world)
-    return torch.cat([g[: height * w * 4].view(height, w, 4) for g, w in zip(gathered, widths) if w > 0], dim=1)
-
-
-def gather_strips_async(strip_flat, dist, gathered, dst=0):
-    """Start the gather of one frame's strips and return the work handle; the caller keeps rendering the next frame
-    into another strip buffer meanwhile (the collective runs on RCCL's own stream) and calls work.wait() before it
-    reuses `strip_flat` / reads `gathered`."""
-    return dist.gather(strip_flat, gathered if dist.get_rank() == dst else None, dst=dst, async_op=True)
-
-
-def assemble(gathered, width, height):
-    """Row-major H x W x 4 frame from the gathered strip buffers (on the gather root)."""
-    import torch
-    widths = strip_widths(width, len(gathered))
     return torch.cat([g[: height * w * 4].view(height, w, 4) for g, w in zip(gathered, widths) if w > 0], dim=1)
 
 

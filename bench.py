@@ -106,9 +106,7 @@ def main():
         if sp not in lane_streams:
             lane_streams[sp] = torch.cuda.ExternalStream(sp)
         with torch.cuda.stream(lane_streams[sp]):
-            dist.gather(strips[b], gathereds[b] if rank == 0 else None, dst=0)
-            if rank == 0:
-                last_frame[0] = mg.assemble(gathereds[b], W, H)     # row-major frame on the root
+            last_frame[0] = mg.gather_strips(strips[b], W, H, dist, gathereds[b])   # RCCL gather + row-major frame on rank 0
 
     def sync():
         """Drain the stream; True if the library asks for the frames since the last sync to be rendered again

@@ -34,7 +34,7 @@ def frame_ext(i, flags):
     with torch.cuda.stream(ext[sp]):
         T("stream_ctx", t); t = time.perf_counter()
         dist.gather(strips[b], gathereds[b], dst=0, group=groups[b]); T("collective", t); t = time.perf_counter()
-        if mode in ("ext", "ext3"): mg.assemble(gathereds[b], W, H)
+        if mode in ("ext", "ext3"): None
         T("assemble", t)
 def frame(i, flags):
     if mode.startswith("ext"): return frame_ext(i, flags)
@@ -43,7 +43,7 @@ def frame(i, flags):
     if works[b] is not None:
         with torch.cuda.stream(ts[b]):
             works[b].wait()
-            if mode == "gather": mg.assemble(gathereds[b], W, H)
+            if mode == "gather": None
         works[b] = None
     T("finish", t); t = time.perf_counter()
     ctx.wait_stream(ts[b].cuda_stream); T("wait_stream", t); t = time.perf_counter()
