@@ -343,8 +343,8 @@ __global__ __launch_bounds__(GS_BLOCK) void k_tile_ranges(const uint2 *__restric
 // and the kernel is LDS-bandwidth-bound (2 x ds_read_b128 = 8 LDS cycles per record per wave against ~20 VALU cycles);
 // four pixels per lane amortise each record read over 4x the arithmetic, and the row-shared terms dy*ay, dy*by are
 // computed once -- the expression tree per pixel is unchanged (frag_power), so coverage stays bit-identical.
-// Traversal is FRONT-to-back (the list is back-to-front) with a per-pixel transmittance accumulator; the wave leaves
-// the list as soon as every pixel has T < t_eps (ballot), one rounding to RGBA8 at the end.
+// Traversal is FRONT-to-back (the list is back-to-front) with a per-pixel transmittance accumulator; a lane leaves the
+// list once its four pixels all have T < t_eps, the wave when every lane has (ballot); one rounding to RGBA8 at the end.
 // ROUND 0 starts from (T = 1, C = 0); a tile that is not saturated when its list ends saves its per-pixel state and
 // sets its bit in the tile mask (if a round 1 follows).  ROUND 1 runs only for masked tiles and resumes from the state.
 #define GS_BLEND_BATCH 64
@@ -377,10 +377,12 @@ __global__ __launch_bounds__(64) void k_blend(const uint2 *__restrict__ tile_ran
     // per pixel pair: x centre, transmittance, premultiplied colour/alpha, and the coverage threshold qmax:
     // 4 while the pixel is live (fragment kept iff q <= 4, index.js:172), -1 once it is outside / terminated
     f2 fxA = { (float)xb + 0.5f, (float)(xb + 1) + 0.5f }, fxB = { (float)(xb + 2) + 0.5f, (float)(xb + 3) + 0.5f };
-    f2 TA = { 1.0f, 1.0f }, TB = { 1.0f, 1.0f };
+    // qm: coverage threshold, 4 inside the strip (fragment kept iff q <= 4, index.js:172), -1 for pixels outside it (never
+    // covered, never written; their T starts at 0 so that they do not keep the lane alive)
+    const f2 qmA = { (row_in && xb < u.x1) ? 4.0f : -1.0f, (row_in && xb + 1 < u.x1) ? 4.0f : -1.0f };
+    const f2 qmB = { (row_in && xb + 2 < u.x1) ? 4.0f : -1.0f, (row_in && xb + 3 < u.x1) ? 4.0f : -1.0f };
+    f2 TA = { qmA.x > 0.0f ? 1.0f : 0.0f, qmA.y > 0.0f ? 1.0f : 0.0f }, TB = { qmB.x > 0.0f ? 1.0f : 0.0f, qmB.y > 0.0f ? 1.0f : 0.0f };
     f2 crA = { 0, 0 }, crB = { 0, 0 }, cgA = { 0, 0 }, cgB = { 0, 0 }, cbA = { 0, 0 }, cbB = { 0, 0 };
-    f2 qmA = { (row_in && xb < u.x1) ? 4.0f : -1.0f, (row_in && xb + 1 < u.x1) ? 4.0f : -1.0f };
-    f2 qmB = { (row_in && xb + 2 < u.x1) ? 4.0f : -1.0f, (row_in && xb + 3 < u.x1) ? 4.0f : -1.0f };
     // opaque scene depth under each of the lane's 4 pixels (+inf = nothing in front of the far plane)
     float zb0 = 3.0e38f, zb1 = 3.0e38f, zb2 = 3.0e38f, zb3 = 3.0e38f;
     if (SCENE && u.has_depth && row_in) {
@@ -396,9 +398,12 @@ __global__ __launch_bounds__(64) void k_blend(const uint2 *__restrict__ tile_ran
         TA = (f2){ t.x, t.y }; TB = (f2){ t.z, t.w };
         crA = (f2){ c0.x, c0.y }; crB = (f2){ c0.z, c0.w }; cgA = (f2){ c1.x, c1.y }; cgB = (f2){ c1.z, c1.w };
         cbA = (f2){ c2.x, c2.y }; cbB = (f2){ c2.z, c2.w };
-        qmA.x = TA.x < t_eps ? -1.0f : qmA.x; qmA.y = TA.y < t_eps ? -1.0f : qmA.y;     // pixels that terminated in round 0
-        qmB.x = TB.x < t_eps ? -1.0f : qmB.x; qmB.y = TB.y < t_eps ? -1.0f : qmB.y;
     }
+    // A lane leaves the list when all four of its pixels are below the threshold (checked after every list entry, so the
+    // point of exit depends on the list alone -- not on batching or on the split into rounds); until then every pixel of
+    // the lane keeps blending: what a pixel below the threshold still receives is < t_eps in total.
+#define GS_LANE_LIVE() (fmaxf(fmaxf(TA.x, TA.y), fmaxf(TB.x, TB.y)) >= t_eps)
+    bool live = GS_LANE_LIVE();
     uint32_t nfr = 0, staged = 0, evaluated = 0;
     const uint2 range = tile_range[tile];
 
@@ -422,7 +427,7 @@ __global__ __launch_bounds__(64) void k_blend(const uint2 *__restrict__ tile_ran
             s_rec[2 * nb + 1] = make_float4(1.0f, 1.0f, 0.0f, 0.0f);
         }
         __syncthreads();
-        if (fmaxf(fmaxf(qmA.x, qmA.y), fmaxf(qmB.x, qmB.y)) > 0.0f) {
+        if (live) {
             // Two splats per step: their coverage tests are independent, so the second one's LDS read + ~13-instruction
             // dependent chain overlaps the first one's (the per-step latency, not issue bandwidth, bounds a tile that
             // runs alone in the kernel's tail).  Blending is still applied strictly in list order.
@@ -444,7 +449,7 @@ __global__ __launch_bounds__(64) void k_blend(const uint2 *__restrict__ tile_ran
                 {                                                                                                      \
                     bool p0 = qA.x <= qmA.x, p1 = qA.y <= qmA.y, p2 = qB.x <= qmB.x, p3 = qB.y <= qmB.y;               \
                     if (SCENE) { p0 = p0 && zz <= zb0; p1 = p1 && zz <= zb1; p2 = p2 && zz <= zb2; p3 = p3 && zz <= zb3; } \
-                    if (p0 | p1 | p2 | p3) {                           /* discard test, index.js:172 */                \
+                    if (live & (p0 | p1 | p2 | p3)) {                  /* discard test, index.js:172 */                \
                         const float alpha = bb.w, alpha255 = bb.w * (1.0f / 255.0f);                                   \
                         const uint32_t rgba = __float_as_uint(bb.z);                                                   \
                         /* exp(A) (index.js:173); 0 for the pixels of this lane that the splat misses */               \
@@ -460,26 +465,24 @@ __global__ __launch_bounds__(64) void k_blend(const uint2 *__restrict__ tile_ran
                         cgA = fma2((f2)(c1), vA, cgA); cgB = fma2((f2)(c1), vB, cgB);                                  \
                         cbA = fma2((f2)(c2), vA, cbA); cbB = fma2((f2)(c2), vB, cbB);                                  \
                         if (COUNT) nfr += (uint32_t)p0 + (uint32_t)p1 + (uint32_t)p2 + (uint32_t)p3;                   \
-                        /* a pixel stops taking fragments once its transmittance is below the threshold */           \
-                        qmA.x = TA.x < t_eps ? -1.0f : qmA.x; qmA.y = TA.y < t_eps ? -1.0f : qmA.y;                    \
-                        qmB.x = TB.x < t_eps ? -1.0f : qmB.x; qmB.y = TB.y < t_eps ? -1.0f : qmB.y;                    \
+                        live = GS_LANE_LIVE();                                                                         \
                     }                                                                                                  \
                 }
                 const float z0 = SCENE ? s_z[s] : 0.0f, z1 = SCENE ? s_z[s + 1] : 0.0f;
                 GS_BLEND_APPLY(qA0, qB0, b0, z0)
                 GS_BLEND_APPLY(qA1, qB1, b1, z1)
 #undef GS_BLEND_APPLY
-                if (!(fmaxf(fmaxf(qmA.x, qmA.y), fmaxf(qmB.x, qmB.y)) > 0.0f)) break;
+                if (!live) break;
             }
             if (u.record_staged == 2) evaluated += min(s + 2, nb);   // list entries this lane evaluated (measurement aid)
         }
         end -= nb;
         __syncthreads();                                           // s_rec is rewritten by the next batch
-        if (__all(!(fmaxf(fmaxf(qmA.x, qmA.y), fmaxf(qmB.x, qmB.y)) > 0.0f))) break;
+        if (__all(!live)) break;
     }
     if (ROUND == 0 && u.near_count < ctl->n_kept) {               // farther splats exist beyond this round
         // the nearer splats did not saturate this tile: keep the exact per-pixel state for round 1 and flag the tile
-        if (__any(fmaxf(fmaxf(qmA.x, qmA.y), fmaxf(qmB.x, qmB.y)) > 0.0f)) {
+        if (__any(live)) {
             st[0] = make_float4(TA.x, TA.y, TB.x, TB.y);
             st[1] = make_float4(crA.x, crA.y, crB.x, crB.y); st[2] = make_float4(cgA.x, cgA.y, cgB.x, cgB.y);
             st[3] = make_float4(cbA.x, cbA.y, cbB.x, cbB.y);
@@ -529,6 +532,7 @@ __global__ __launch_bounds__(64) void k_blend(const uint2 *__restrict__ tile_ran
         for (int m = 32; m >= 1; m >>= 1) evaluated = max(evaluated, (uint32_t)__shfl_xor(evaluated, m, 64));
         staged = evaluated;
     }
+#undef GS_LANE_LIVE
     if (u.record_staged && lane == 0) const_cast<uint2 *>(tile_range)[tile] = make_uint2(staged, range.y - range.x);   // GS_OPT_RECORD_STAGED
     __syncthreads();                                               // s_rec is reused by the next tile of this wave
     }

@@ -122,6 +122,8 @@ typedef struct gs_render_params {
 /* Draw the last gs_sort() order into a tightly described RGBA8 image in caller-owned host memory.
  * rgba_out: (x1-x0) x fb_height pixels, `stride` bytes per row (0 = tight), row 0 = top. */
 GS_API int gs_render(gs_ctx *ctx, const gs_render_params *p, uint8_t *rgba_out, size_t stride);
+/* Strips [x0,x1) whose x0 is a multiple of 4 (the multi-GPU partition uses multiples of 16) reproduce the corresponding
+ * columns of the full frame bit for bit; other strips within 1 LSB (early termination works on groups of 4 pixels). */
 /* Same, but the strip stays on the GPU: device_rgba is a device pointer (e.g. a torch tensor's
  * data_ptr, tight rows) or NULL to render into the context's own framebuffer only. */
 GS_API int gs_render_device(gs_ctx *ctx, const gs_render_params *p, void *device_rgba);

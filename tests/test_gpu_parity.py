@@ -164,9 +164,17 @@ def test_strips_tile_the_full_frame_exactly(ctx, scene_small):
     ctx.clear(); ctx.push_splat(scene_small["rows"])
     ctx.sort(cam["view"])
     full = ctx.render(_params(cam))
-    for bounds in ([0, 125, 250, 375, 500], [0, 7, 130, 499, 500]):        # aligned-ish and ragged strips
+    # strips that start on a 4-pixel boundary (the multi-GPU partition is tile-aligned: multiples of 16) reproduce the full
+    # frame bit for bit, ragged widths included: a lane's four pixels -- the unit of early termination -- are then the
+    # same four pixels as in the full frame
+    for bounds in ([0, 128, 256, 384, 500], [0, 16, 132, 496, 500], [0, 4, 500]):
         parts = [ctx.render(_params(cam, x0=a, x1=b)) for a, b in zip(bounds[:-1], bounds[1:])]
         assert np.array_equal(np.concatenate(parts, axis=1), full)
+    # any other strip groups the pixels differently: what a pixel still receives after it dropped below the
+    # termination threshold (< 1/4096 in total) may differ, the rounded image stays within the pixel tolerance
+    for bounds in ([0, 125, 250, 375, 500], [0, 7, 130, 499, 500]):
+        parts = [ctx.render(_params(cam, x0=a, x1=b)) for a, b in zip(bounds[:-1], bounds[1:])]
+        assert np.abs(np.concatenate(parts, axis=1).astype(int) - full.astype(int)).max() <= PIXEL_TOL_LSB
     mv, P, focal = _f32(cam)
     idx = ctx.sort(cam["view"])
     want, _, _ = oracle.render(scene_small["cs"], scene_small["cc"], idx, mv, P, focal, w, h, x0=130, x1=499)
