@@ -634,3 +634,88 @@ def test_pipelined_frames_on_lanes_equal_synchronous_frames(scene_small, depth):
         for a, b in zip(got2, want2):
             assert np.array_equal(a, b)
         assert not np.array_equal(want2[0], want[0])
+
+
+# ---------------------------------------------------------------- randomised / hostile inputs (bit-exact vs the oracle)
+
+def _hostile_floats(g, n):
+    """f32 values mixing ordinary magnitudes with the IEEE specials the JS arithmetic has defined answers for."""
+    v = g.normal(0.0, 3.0, n).astype(np.float32)
+    pick = g.random(n)
+    specials = np.array([np.nan, np.inf, -np.inf, 0.0, -0.0, 1e-45, -1e-45, 3.4e38, -3.4e38, 1e-30, 65504.0, 1e20], np.float32)
+    m = pick < 0.08
+    v[m] = specials[g.integers(0, specials.size, int(m.sum()))]
+    return v
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_sort_fuzz_specials_match_oracle(ctx, seed):
+    """Random sizes (incl. non-multiples of every chunk size), random view rows and cutout matrices, splat rows salted with
+    NaN / Inf / signed zeros / denormals / huge values: the index list must equal the oracle's bit for bit (the oracle is
+    pinned to the reference's worker on the golden vectors, incl. its NaN|0 and dropped-bucket behaviour)."""
+    g = np.random.Generator(np.random.PCG64(1000 + seed))
+    n = int(g.choice([1, 2, 63, 64, 65, 255, 257, 2047, 2049, 4097, 30011, 131071, 262145]))
+    rows4 = _hostile_floats(g, n * 4).reshape(n, 4)
+    rows4[:, 3] = np.abs(rows4[:, 3]) * 0.01 if seed % 3 else rows4[:, 3]       # mostly plausible sizes, sometimes anything
+    view = _hostile_floats(g, 4) if seed % 4 == 3 else g.normal(0.0, 1.0, 4).astype(np.float32)
+    cut = None
+    if seed % 2:
+        cut = g.normal(0.0, 0.4, 16).astype(np.float32)
+        if seed % 6 == 5:
+            cut[g.integers(0, 16)] = np.float32(np.nan)
+    ctx.clear(); ctx.push_matrices(_expand(rows4))
+    got = ctx.sort(view, cut)
+    want = oracle.sort(rows4, view, cut)
+    assert got.size == want.size and np.array_equal(got, want)
+
+
+def _same_f32(a, b):
+    """Bit-equal, except that a NaN matches any NaN: which NaN a JS engine stores into a Float32Array is implementation-
+    defined (ECMAScript NumericToRawBytes), so payload and sign of a NaN are not part of the reference's behaviour."""
+    a = np.asarray(a, np.float32); b = np.asarray(b, np.float32)
+    return a.shape == b.shape and bool(np.all((a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))))
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_pack_fuzz_random_bytes_match_oracle(ctx, seed):
+    """pushDataBuffer on rows of random BYTES (so positions / scales are arbitrary bit patterns: NaN, Inf, denormals) and on
+    rows with extreme but finite scales: both packed records and the worker row must equal the oracle's, bit for bit
+    (NaNs: as NaNs)."""
+    g = np.random.Generator(np.random.PCG64(2000 + seed))
+    n = int(g.choice([1, 77, 1000, 4099]))
+    rows = g.integers(0, 256, (n, 32), dtype=np.uint8)
+    if seed % 2:                                                              # finite, wide-range scales and positions
+        f = (g.normal(0.0, 1.0, (n, 6)) * 10.0 ** g.uniform(-8, 4, (n, 6))).astype("<f4")
+        rows[:, :24] = f.view(np.uint8).reshape(n, 24)
+    ctx.clear(); ctx.push_splat(rows)
+    cs, cc, mats = oracle.pack(rows)
+    assert _same_f32(ctx.download(capi.BUF_CENTER_SCALE, n, np.float32, 4), cs)
+    assert np.array_equal(ctx.download(capi.BUF_COV_COLOR, n, np.uint32, 4), cc)
+    assert _same_f32(ctx.download(capi.BUF_SORT_ROWS, n, np.float32, 4), mats[:, 12:16])
+    # and the sort of such a scene (NaN / Inf positions and sizes) is still the oracle's, bit for bit
+    view = g.normal(0.0, 1.0, 4).astype(np.float32)
+    assert np.array_equal(ctx.sort(view), oracle.sort(mats, view))
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_render_fuzz_random_scenes_match_oracle(ctx, seed):
+    """Random small scenes rendered from random orbit poses at odd resolutions: identical fragment counts, pixels within
+    the tolerance, for full frames and a 4-aligned strip."""
+    g = np.random.Generator(np.random.PCG64(3000 + seed))
+    n = int(g.choice([1, 50, 3000, 20000]))
+    rows = synth.make_splat_rows(n, seed=3100 + seed)
+    w, h = int(g.integers(17, 400)), int(g.integers(17, 300))
+    cam = synth.index_html_camera(w, h, float(g.uniform(0, 360)), capi=capi)
+    cs, cc, mats = oracle.pack(rows)
+    ctx.clear(); ctx.push_splat(rows)
+    idx = ctx.sort(cam["view"])
+    assert np.array_equal(idx, oracle.sort(mats, cam["view"]))
+    mv, P, focal = _f32(cam)
+    want, _, frags = oracle.render(cs, cc, idx, mv, P, focal, w, h, want_f32=False)
+    got = ctx.render(_params(cam))
+    assert np.abs(got.astype(int) - want.astype(int)).max() <= PIXEL_TOL_LSB
+    ctx.render(_params(cam, flags=capi.RENDER_COUNT_FRAGS))
+    assert ctx.stats()["n_frags"] == frags
+    x0 = 4 * int(g.integers(0, w // 8 + 1)); x1 = int(g.integers(x0 + 1, w + 1))
+    part = ctx.render(_params(cam, x0=x0, x1=x1))
+    assert np.array_equal(part, got[:, x0:x1])
