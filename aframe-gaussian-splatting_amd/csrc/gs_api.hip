@@ -568,10 +568,10 @@ static int render_on_lane(gs_ctx *ctx, const GsFrameUniforms &u0, void *device_r
     ctx->last_two_rounds = u.near_count != 0xFFFFFFFFu && ctx->n && ctx->have_sort;
     ctx->stats.n_tiles = ntiles; ctx->stats.blend_launches = 1;
     if (async) {
-        // pipelined frame: enqueue, stage the control block for gs_sync(), return.  An overflowing frame shows the
-        // background only and is reported (GS_E_RETRY) by the next gs_sync().
+        // pipelined frame: enqueue and return; gs_sync() reads the control block back (its flags and accumulators are
+        // cumulative, so one read-back per gs_sync() covers every frame since the last one -- a per-frame copy would be one
+        // more queue entry per frame).  An overflowing frame shows the background only and is reported (GS_E_RETRY) there.
         TRY(gs_run_render(ctx, u, (uint8_t *)device_rgba));
-        GS_HIP(hipMemcpyAsync(ctx->ctl_host, ctx->ctl, sizeof(GsControl), hipMemcpyDeviceToHost, ctx->stream));
         ctx->async_pending = true;
         gs_root(ctx)->cur_async = true;
         return prof_advance(ctx);
@@ -666,6 +666,7 @@ GS_API int gs_sync(gs_ctx *ctx)
         TRY(lane_rc(ctx, L, prof_drain(L)));
         if (!L->async_pending) continue;
         L->async_pending = false;
+        LANE_HIP(L, hipMemcpy(L->ctl_host, L->ctl, sizeof(GsControl), hipMemcpyDeviceToHost));
         const bool missed = L->ctl_host->round1_missed != 0;
         if (missed) LANE_HIP(L, hipMemsetAsync(&L->ctl->round1_missed, 0, sizeof(uint32_t), L->stream));
         bool over = false;
