@@ -719,3 +719,43 @@ def test_render_fuzz_random_scenes_match_oracle(ctx, seed):
     x0 = 4 * int(g.integers(0, w // 8 + 1)); x1 = int(g.integers(x0 + 1, w + 1))
     part = ctx.render(_params(cam, x0=x0, x1=x1))
     assert np.array_equal(part, got[:, x0:x1])
+
+
+def test_stream_coupling_calls_order_frames_with_caller_streams(scene_small):
+    """gs_frame_stream / gs_stream_wait_frame / gs_wait_stream: a copy queued on the frame's own lane stream, or on a side
+    stream that waits for the frame, sees the finished frame; a frame gated on a side stream starts after that stream's
+    work (a fill of its target buffer) -- all without host synchronisation in between."""
+    import torch
+    w, h = 320, 180
+    cams = [synth.index_html_camera(w, h, 40.0 * i, capi=capi) for i in range(6)]
+    with capi.Context(0) as c:
+        c.push_splat(scene_small["rows"])
+        want = []
+        for cam in cams:
+            c.sort(cam["view"]); want.append(c.render(_params(cam)))
+        for attempt in range(3):
+            bufs = [torch.zeros(w * h * 4, dtype=torch.uint8, device="cuda") for _ in cams]
+            outs = [torch.empty_like(b) for b in bufs]
+            side = torch.cuda.Stream()
+            for i, cam in enumerate(cams):
+                if i % 2 == 0:
+                    with torch.cuda.stream(side):
+                        bufs[i].fill_(77)                                   # must land BEFORE the frame overwrites the buffer
+                    c.wait_stream(side.cuda_stream)
+                c.sort(cam["view"], want_indices=False)
+                c.render_device(_params(cam, flags=capi.RENDER_ASYNC), bufs[i].data_ptr())
+                if i % 2 == 0:
+                    c.stream_wait_frame(side.cuda_stream)
+                    with torch.cuda.stream(side):
+                        outs[i].copy_(bufs[i])
+                else:
+                    with torch.cuda.stream(torch.cuda.ExternalStream(c.frame_stream())):
+                        outs[i].copy_(bufs[i])
+            try:
+                c.sync()
+                break
+            except capi.GsError as e:
+                assert e.code == capi.E_RETRY and attempt < 2
+        torch.cuda.synchronize()
+        for o, wnt in zip(outs, want):
+            assert np.array_equal(o.cpu().numpy().reshape(h, w, 4), wnt)
