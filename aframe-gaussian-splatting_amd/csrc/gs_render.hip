@@ -551,6 +551,8 @@ int run_round(gs_ctx *ctx, const GsFrameUniforms &u, uint8_t *out, bool last_rou
     uint32_t g = gs_div_up(Vmax, GS_BLOCK); if (g > GS_MAX_PART) g = GS_MAX_PART;
     const uint32_t small = 512;
     if (ROUND == 1 && g > small) g = small;
+    // round 0 of a two-round frame covers at most near_count splats: no point in launching workgroups for the rest
+    if (ROUND == 0 && u.near_count != 0xFFFFFFFFu) { const uint32_t gn = gs_div_up(u.near_count < Vmax ? u.near_count : Vmax, GS_BLOCK); if (gn < g) g = gn ? gn : 1; }
     const uint32_t pc = ROUND == 1 ? (uint32_t)(small * GS_CHUNK) : (uint32_t)ctx->pair_cap;      // grid hint for the radix kernels
     hipLaunchKernelGGL(k_project<ROUND>, dim3(g), dim3(GS_BLOCK), 0, st, ctx->sorted, ctx->splat, u, ctx->proj, ctx->rect,
                        ctx->tile_count, ctx->spine, ctx->part_vis, ctx->unsat_mask, ctx->zwin, ctx->ctl);
