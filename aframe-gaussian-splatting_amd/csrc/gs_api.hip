@@ -117,6 +117,7 @@ static int ensure_capacity(gs_ctx *ctx, size_t want)
 hipEvent_t gs_prof_event(gs_ctx *ctx, int k)
 {
     if (!ctx->profile || !ctx->ring) return nullptr;
+    if (ctx->profile_blend_only && k != 4 && k != 5) return nullptr;   // GS_OPT_PROFILE = 2: only the events around the blend
     const uint32_t slot = ctx->ring_head % GS_PROF_RING;
     ctx->ring_flags[slot] |= (uint8_t)(1u << k);
     return ctx->ring[slot * GS_PROF_EVENTS + k];
@@ -132,6 +133,12 @@ static int prof_drain(gs_ctx *ctx)
         ctx->ring_flags[slot] = 0;
         float ms;
         if ((f & 3) == 3) { GS_HIP(hipEventElapsedTime(&ms, e[0], e[1])); ctx->stats.ms_sort = ms; ctx->stats.sum_ms_sort += ms; }
+        if ((f & 0x7C) == 0x30) {                            // blend-only profiling
+            float d;
+            GS_HIP(hipEventElapsedTime(&d, e[4], e[5]));
+            ctx->stats.ms_blend = d; ctx->stats.sum_ms_blend += d;
+            ctx->stats.prof_frames++;
+        }
         if ((f & 0x7C) == 0x7C) {
             float a, b, d, r1;
             GS_HIP(hipEventElapsedTime(&a, e[2], e[3])); GS_HIP(hipEventElapsedTime(&b, e[3], e[4])); GS_HIP(hipEventElapsedTime(&d, e[4], e[5]));
@@ -251,7 +258,7 @@ static void free_frame_resources(gs_ctx *c)
 }
 
 // switch the HIP-event profiling of one lane on/off (allocates its ring on first use, restarts its accumulators)
-static int set_profile(gs_ctx *ctx, bool on)
+static int set_profile(gs_ctx *ctx, bool on, bool blend_only)
 {
     GS_HIP(hipStreamSynchronize(ctx->stream));
     TRY(prof_drain(ctx));
@@ -267,7 +274,7 @@ static int set_profile(gs_ctx *ctx, bool on)
         GS_HIP(hipMemsetAsync(&ctx->ctl->acc_frames, 0, sizeof(GsControl) - offsetof(GsControl, acc_frames), ctx->stream));
         ctx->seen_acc_frames = 0;
     }
-    ctx->profile = on;
+    ctx->profile = on; ctx->profile_blend_only = on && blend_only;
     return GS_OK;
 }
 
@@ -287,7 +294,7 @@ static int get_lane(gs_ctx *ctx, int i, gs_ctx **out)
             return e == hipErrorOutOfMemory ? GS_E_OOM : GS_E_HIP;
         }
         ctx->lanes[i] = L;
-        if (ctx->profile && set_profile(L, true) != GS_OK) { memcpy(ctx->err, L->err, sizeof ctx->err); return GS_E_HIP; }
+        if (ctx->profile && set_profile(L, true, ctx->profile_blend_only) != GS_OK) { memcpy(ctx->err, L->err, sizeof ctx->err); return GS_E_HIP; }
     }
     if (L != ctx) {
         L->splat = ctx->splat; L->sort_rows = ctx->sort_rows; L->pow10tab = ctx->pow10tab;
@@ -725,7 +732,7 @@ GS_API int gs_set_option(gs_ctx *ctx, int option, int64_t value)
     case GS_OPT_PROFILE:
         GS_HIP(hipSetDevice(ctx->device));
         for (int i = 0; i < GS_MAX_LANES; i++)
-            if (ctx->lanes[i]) TRY(lane_rc(ctx, ctx->lanes[i], set_profile(ctx->lanes[i], value != 0)));
+            if (ctx->lanes[i]) TRY(lane_rc(ctx, ctx->lanes[i], set_profile(ctx->lanes[i], value != 0, value == 2)));
         return GS_OK;
     case GS_OPT_NEAR_PERMILLE:
         if (value < 0 || value > 1000) FAIL(GS_E_BADARG, "near permille must be 0 (adaptive) .. 1000 (single round)");

@@ -129,6 +129,7 @@ struct gs_ctx {
 
     // options / stats
     bool profile;
+    bool profile_blend_only;       // GS_OPT_PROFILE = 2: HIP events around the blend kernel only (2 instead of 7 per frame)
     uint32_t record_staged;        // GS_OPT_RECORD_STAGED (1 = entries staged, 2 = entries evaluated)
     float t_eps;
     // profiling ring: GS_PROF_RING slots x GS_PROF_EVENTS events (sort begin/end, render begin, after project, after

@@ -172,7 +172,7 @@ def main():
     # library has adapted, the region is measured again from scratch.
     for attempt in range(4):
         ctx.set_option(capi.OPT_PROFILE, 0)
-        ctx.set_option(capi.OPT_PROFILE, 1)                  # HIP events around every stage, on the library's stream
+        ctx.set_option(capi.OPT_PROFILE, 2)                  # HIP events around the dominant kernel (blend), on its stream
         sync()
         t_start = time.perf_counter()
         for i in range(args.steps):
@@ -193,7 +193,18 @@ def main():
     s = ctx.stats()
     ctx.set_option(capi.OPT_PROFILE, 0)
     assert s["acc_frames"] == args.steps and s["prof_frames"] == args.steps, (s["acc_frames"], s["prof_frames"])
-    stage = {"ms_sort": s["sum_ms_sort"], "ms_project": s["sum_ms_project"], "ms_bin": s["sum_ms_bin"], "ms_blend": s["sum_ms_blend"]}
+    # per-stage breakdown: a second, UNTIMED pass over the same frames with events around every stage (7 per frame
+    # instead of 2; they cost ~4 % of the frame rate, so the timed region carries only the blend's)
+    ctx.set_option(capi.OPT_PROFILE, 1)
+    sync()
+    for i in range(args.steps):
+        frame(args.warmup + i, capi.RENDER_ASYNC)
+    sync()
+    s2 = ctx.stats()
+    ctx.set_option(capi.OPT_PROFILE, 0)
+    k2 = max(1, s2["prof_frames"])
+    stage = {"ms_sort": s2["sum_ms_sort"] * args.steps / k2, "ms_project": s2["sum_ms_project"] * args.steps / k2,
+             "ms_bin": s2["sum_ms_bin"] * args.steps / k2, "ms_blend": s["sum_ms_blend"]}
     pairs, visible, sorted_n = s["acc_pairs"], s["acc_visible"], s["acc_sorted"]
     if multi:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")

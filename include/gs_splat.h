@@ -197,7 +197,8 @@ typedef struct gs_stats {
     uint32_t near_permille;/* share of the splats binned in that first round (adapted, or GS_OPT_NEAR_PERMILLE)        */
 } gs_stats;
 
-#define GS_OPT_PROFILE 1        /* value != 0: bracket stages with HIP events on the context stream        */
+#define GS_OPT_PROFILE 1        /* 1: bracket every stage with HIP events on the frame's stream (7 per frame); 2: only
+                                   the blend kernel (2 per frame; sum_ms_blend / prof_frames); 0: off                  */
 #define GS_OPT_TERMINATION 2    /* value = 1/eps for the transmittance early-out (default 4096)          */
 #define GS_OPT_NEAR_PERMILLE 3  /* occlusion-aware binning: 0 = adapt (default), 1..999 = bin that share of the nearest
                                    splats first and the rest only against unsaturated tiles, 1000 = single round      */
