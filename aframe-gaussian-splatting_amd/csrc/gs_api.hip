@@ -300,7 +300,7 @@ static int get_lane(gs_ctx *ctx, int i, gs_ctx **out)
         L->splat = ctx->splat; L->sort_rows = ctx->sort_rows; L->pow10tab = ctx->pow10tab;
         L->n = ctx->n; L->cap = ctx->cap; L->renderable = ctx->renderable;
         L->scene_depth = ctx->scene_depth; L->scene_rgba = ctx->scene_rgba; L->scene_w = ctx->scene_w; L->scene_h = ctx->scene_h;
-        L->record_staged = ctx->record_staged; L->t_eps = ctx->t_eps;
+        L->record_staged = ctx->record_staged; L->t_eps = ctx->t_eps; L->wide_pairs = ctx->wide_pairs;
         if (ensure_lane_scratch(L, ctx->cap) != GS_OK) { memcpy(ctx->err, L->err, sizeof ctx->err); return GS_E_OOM; }
     }
     *out = L;
@@ -743,6 +743,7 @@ GS_API int gs_set_option(gs_ctx *ctx, int option, int64_t value)
     case GS_OPT_TERMINATION:
         if (value < 2) FAIL(GS_E_BADARG, "termination 1/eps must be >= 2");
         ctx->t_eps = 1.0f / (float)value; return GS_OK;
+    case GS_OPT_WIDE_PAIRS: ctx->wide_pairs = value != 0; return GS_OK;
     case GS_OPT_PIPELINE_DEPTH:
         if (value < 1 || value > GS_MAX_LANES) FAIL(GS_E_BADARG, "pipeline depth must be 1..%d", GS_MAX_LANES);
         GS_HIP(hipSetDevice(ctx->device));

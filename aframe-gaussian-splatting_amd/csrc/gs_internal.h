@@ -59,6 +59,7 @@ struct GsFrameUniforms {           // per-render constants, passed by value to k
     uint32_t mask_words;           // 32-bit words per tile row of the unsaturated-tile mask
     uint32_t skip_round1;          // round 1 is not launched for this frame (optimistic; blend<0> raises round1_missed)
     uint32_t has_depth, has_scene_rgba;   // scene compositing inputs present (gs_set_scene)
+    uint32_t pair_jbits;           // > 0: 4-byte pair records (tile << pair_jbits | sorted position - j_lo); 0: (tile, position) uint2
 };
 
 struct gs_ctx {
@@ -131,6 +132,7 @@ struct gs_ctx {
     bool profile;
     bool profile_blend_only;       // GS_OPT_PROFILE = 2: HIP events around the blend kernel only (2 instead of 7 per frame)
     uint32_t record_staged;        // GS_OPT_RECORD_STAGED (1 = entries staged, 2 = entries evaluated)
+    bool wide_pairs;               // GS_OPT_WIDE_PAIRS: always use 8-byte pair records
     float t_eps;
     // profiling ring: GS_PROF_RING slots x GS_PROF_EVENTS events (sort begin/end, render begin, after project, after
     // binning, after blend of round 0, end of round 1)
@@ -153,11 +155,15 @@ static inline uint32_t gs_div_up(uint64_t a, uint64_t b) { return (uint32_t)((a 
 
 // ---- gs_prims.hip
 // One stable LSD radix pass over n = *n_ptr items on digit (key >> shift) & (2^bits-1).
-// in:  packed (key,val) uint2 records, or a plain key array whose value is the element index.
-// out: packed (key,val) uint2 records, or the values alone (final pass).
+// record formats: GS_RADIX_KEYS    in: a plain key array whose value is the element index; out: the values alone (final pass)
+//                 GS_RADIX_PACKED  (key,val) uint2 records
+//                 GS_RADIX_KEYONLY 4-byte records that are their own payload (in and out)
 // have_hist: the caller's producer kernel already filled ctx->hist for this digit (skips the histogram launch).
 // zero_key:  value-only output stores 0 for items with this key (0xFFFFFFFF = never).
-int gs_launch_radix_pass(gs_ctx *ctx, const void *in, bool in_packed, void *out, bool out_packed, const uint32_t *n_ptr,
+#define GS_RADIX_KEYS 0
+#define GS_RADIX_PACKED 1
+#define GS_RADIX_KEYONLY 2
+int gs_launch_radix_pass(gs_ctx *ctx, const void *in, int in_fmt, void *out, int out_fmt, const uint32_t *n_ptr,
                          uint32_t max_n, int shift, int bits, bool have_hist = false, uint32_t zero_key = 0xFFFFFFFFu);
 // grid used by the radix kernels for max_n items (a producer that pre-fills the histogram must use the same chunking)
 uint32_t gs_radix_grid(uint32_t max_n);

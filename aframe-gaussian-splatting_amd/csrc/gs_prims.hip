@@ -88,11 +88,13 @@ __global__ __launch_bounds__(GS_BLOCK) void k_radix_rowscan(uint32_t *__restrict
 // wave-private LDS counter row, across waves via a 4-way prefix.  The chunk is then REORDERED IN LDS into digit
 // order and written out slot by slot, so consecutive lanes store consecutive addresses inside each digit run
 // (runs of ~2048/bins items) instead of 64 unrelated 8-byte stores per instruction.
-// IN_PACKED: input is (key,val) uint2 records, else a key array whose value is the element index.
-// OUT_PACKED: output is (key,val) uint2 records (one 8-byte store per item), else the value alone (last pass).
+// IN_FMT:  GS_RADIX_KEYS = a key array whose value is the element index, GS_RADIX_PACKED = (key,val) uint2 records,
+//          GS_RADIX_KEYONLY = 4-byte records that are their own payload (the digit is a bit field of the record).
+// OUT_FMT: GS_RADIX_KEYS = the value alone (last pass of an index sort), GS_RADIX_PACKED = (key,val) uint2 records (one
+//          8-byte store per item), GS_RADIX_KEYONLY = the 4-byte record.
 // zero_key: items whose key equals it store 0 as their value (value-only output): the depth sort uses this so that
 // culled splats (key 65536, which sort behind every bucket) leave zeros in the tail of the index list.
-template <bool IN_PACKED, bool OUT_PACKED>
+template <int IN_FMT, int OUT_FMT>
 __global__ __launch_bounds__(GS_BLOCK) void k_radix_scatter(const void *__restrict__ in, void *__restrict__ out,
                                                             const uint32_t *n_ptr, int shift, int bits, uint32_t zero_key,
                                                             const uint32_t *__restrict__ hist_scanned, const uint32_t *__restrict__ totals)
@@ -123,7 +125,7 @@ __global__ __launch_bounds__(GS_BLOCK) void k_radix_scatter(const void *__restri
         for (int r = 0; r < 8; r++) {
             const uint32_t i = c * GS_CHUNK + w * 512 + r * 64 + lane;
             const bool ok = i < n;
-            if (IN_PACKED) {
+            if (IN_FMT == GS_RADIX_PACKED) {
                 const uint2 kv = ok ? reinterpret_cast<const uint2 *>(in)[i] : make_uint2(0xFFFFFFFFu, 0u);
                 key[r] = kv.x; val[r] = kv.y;
             } else {
@@ -180,7 +182,8 @@ __global__ __launch_bounds__(GS_BLOCK) void k_radix_scatter(const void *__restri
             if (slot < items) {
                 const uint2 kv = s_kv[slot];
                 const uint32_t pos = s_gb[(kv.x >> shift) & mask] + slot;
-                if (OUT_PACKED) reinterpret_cast<uint2 *>(out)[pos] = kv;
+                if (OUT_FMT == GS_RADIX_PACKED) reinterpret_cast<uint2 *>(out)[pos] = kv;
+                else if (OUT_FMT == GS_RADIX_KEYONLY) reinterpret_cast<uint32_t *>(out)[pos] = kv.x;
                 else reinterpret_cast<uint32_t *>(out)[pos] = kv.x == zero_key ? 0u : kv.y;
             }
         }
@@ -200,7 +203,7 @@ uint32_t grid_for(uint32_t max_items)
 
 uint32_t gs_radix_grid(uint32_t max_n) { return grid_for(max_n); }
 
-int gs_launch_radix_pass(gs_ctx *ctx, const void *in, bool in_packed, void *out, bool out_packed, const uint32_t *n_ptr,
+int gs_launch_radix_pass(gs_ctx *ctx, const void *in, int in_fmt, void *out, int out_fmt, const uint32_t *n_ptr,
                          uint32_t max_n, int shift, int bits, bool have_hist, uint32_t zero_key)
 {
     const uint32_t g = grid_for(max_n);
@@ -208,13 +211,17 @@ int gs_launch_radix_pass(gs_ctx *ctx, const void *in, bool in_packed, void *out,
     const dim3 G(g), B(GS_BLOCK);
     hipStream_t st = ctx->stream;
     if (have_hist) { /* the producer of `in` already wrote hist[digit][chunk] */ }
-    else if (in_packed) hipLaunchKernelGGL(k_radix_hist<true>, G, B, 0, st, (const uint32_t *)in, n_ptr, shift, bits, ctx->hist);
+    else if (in_fmt == GS_RADIX_PACKED) hipLaunchKernelGGL(k_radix_hist<true>, G, B, 0, st, (const uint32_t *)in, n_ptr, shift, bits, ctx->hist);
     else hipLaunchKernelGGL(k_radix_hist<false>, G, B, 0, st, (const uint32_t *)in, n_ptr, shift, bits, ctx->hist);
     hipLaunchKernelGGL(k_radix_rowscan, dim3(1u << bits), B, 0, st, ctx->hist, n_ptr, totals);
-    if (in_packed && out_packed) hipLaunchKernelGGL((k_radix_scatter<true, true>), G, B, 0, st, in, out, n_ptr, shift, bits, zero_key, ctx->hist, totals);
-    else if (in_packed) hipLaunchKernelGGL((k_radix_scatter<true, false>), G, B, 0, st, in, out, n_ptr, shift, bits, zero_key, ctx->hist, totals);
-    else if (out_packed) hipLaunchKernelGGL((k_radix_scatter<false, true>), G, B, 0, st, in, out, n_ptr, shift, bits, zero_key, ctx->hist, totals);
-    else hipLaunchKernelGGL((k_radix_scatter<false, false>), G, B, 0, st, in, out, n_ptr, shift, bits, zero_key, ctx->hist, totals);
+#define GS_SCATTER(I, O) hipLaunchKernelGGL((k_radix_scatter<I, O>), G, B, 0, st, in, out, n_ptr, shift, bits, zero_key, ctx->hist, totals)
+    if (in_fmt == GS_RADIX_PACKED && out_fmt == GS_RADIX_PACKED) GS_SCATTER(GS_RADIX_PACKED, GS_RADIX_PACKED);
+    else if (in_fmt == GS_RADIX_PACKED && out_fmt == GS_RADIX_KEYS) GS_SCATTER(GS_RADIX_PACKED, GS_RADIX_KEYS);
+    else if (in_fmt == GS_RADIX_KEYS && out_fmt == GS_RADIX_PACKED) GS_SCATTER(GS_RADIX_KEYS, GS_RADIX_PACKED);
+    else if (in_fmt == GS_RADIX_KEYS && out_fmt == GS_RADIX_KEYS) GS_SCATTER(GS_RADIX_KEYS, GS_RADIX_KEYS);
+    else if (in_fmt == GS_RADIX_KEYONLY && out_fmt == GS_RADIX_KEYONLY) GS_SCATTER(GS_RADIX_KEYONLY, GS_RADIX_KEYONLY);
+    else { snprintf(ctx->err, sizeof ctx->err, "radix pass: unsupported record formats %d -> %d", in_fmt, out_fmt); return GS_E_BADARG; }
+#undef GS_SCATTER
     GS_HIP(hipGetLastError());
     return GS_OK;
 }

@@ -219,25 +219,34 @@ __global__ __launch_bounds__(GS_BLOCK) void k_pairs_check(GsControl *ctl, uint32
 // ones (thousands of tiles each) are queued in LDS and expanded by a whole wavefront, one lane per tile row.
 // ROUND 1 writes only the tiles whose bit is set in the unsaturated-tile mask.
 #define GS_EMIT_BIG 32u
-template <int ROUND>
-__device__ __forceinline__ uint32_t emit_run(uint2 *__restrict__ pairs, uint32_t o, uint32_t ty, uint32_t tiles_x, uint32_t t0, uint32_t n,
-                                             uint32_t j, const uint32_t *__restrict__ mask_row)
+// one pair record: 8 bytes (tile, sorted position) or, when tile bits + position bits fit (jbits > 0), 4 bytes
+// (tile << jbits | position - j_lo): half the traffic through emit, both radix passes, the range pass and the blend
+template <bool P32>
+__device__ __forceinline__ void put_pair(void *__restrict__ pairs, uint32_t o, uint32_t tile, uint32_t j, uint32_t jrel, uint32_t jbits)
+{
+    if (P32) reinterpret_cast<uint32_t *>(pairs)[o] = (tile << jbits) | jrel;
+    else reinterpret_cast<uint2 *>(pairs)[o] = make_uint2(tile, j);
+}
+
+template <int ROUND, bool P32>
+__device__ __forceinline__ uint32_t emit_run(void *__restrict__ pairs, uint32_t o, uint32_t ty, uint32_t tiles_x, uint32_t t0, uint32_t n,
+                                             uint32_t j, uint32_t jrel, uint32_t jbits, const uint32_t *__restrict__ mask_row)
 {
     if (ROUND == 0) {
-        for (uint32_t k = 0; k < n; k++) pairs[o++] = make_uint2(ty * tiles_x + t0 + k, j);
+        for (uint32_t k = 0; k < n; k++) put_pair<P32>(pairs, o++, ty * tiles_x + t0 + k, j, jrel, jbits);
     } else if (n) {
         for (uint32_t w = t0 >> 5; w <= ((t0 + n - 1) >> 5); w++) {
             uint32_t bits = mask_bits(mask_row, w, t0, n);
-            while (bits) { const uint32_t b = __ffs(bits) - 1; bits &= bits - 1; pairs[o++] = make_uint2(ty * tiles_x + w * 32 + b, j); }
+            while (bits) { const uint32_t b = __ffs(bits) - 1; bits &= bits - 1; put_pair<P32>(pairs, o++, ty * tiles_x + w * 32 + b, j, jrel, jbits); }
         }
     }
     return o;
 }
 
-template <int ROUND>
+template <int ROUND, bool P32>
 __global__ __launch_bounds__(GS_BLOCK) void k_emit(const gsm::Projected *__restrict__ proj, const uint2 *__restrict__ rect,
                                                    const uint32_t *__restrict__ tile_count, const uint32_t *__restrict__ spine,
-                                                   GsFrameUniforms u, uint2 *__restrict__ pairs, const uint32_t *__restrict__ mask,
+                                                   GsFrameUniforms u, void *__restrict__ pairs, const uint32_t *__restrict__ mask,
                                                    const GsControl *ctl)
 {
     __shared__ uint32_t s_big[GS_BLOCK], s_bigoff[GS_BLOCK];
@@ -274,7 +283,7 @@ __global__ __launch_bounds__(GS_BLOCK) void k_emit(const gsm::Projected *__restr
                 for (uint32_t ty = rc.x >> 16; ty <= (rc.y >> 16); ty++) {
                     uint32_t t0, n;
                     gsm::splat_tile_row(p, e, (int)ty, u.H, u.x0, u.x1, t0, n);
-                    o = emit_run<ROUND>(pairs, o, ty, tiles_x, t0, n, j, mask + ty * u.mask_words);
+                    o = emit_run<ROUND, P32>(pairs, o, ty, tiles_x, t0, n, j, j - j_lo, u.pair_jbits, mask + ty * u.mask_words);
                 }
             }
             __syncthreads();
@@ -297,7 +306,7 @@ __global__ __launch_bounds__(GS_BLOCK) void k_emit(const gsm::Projected *__restr
                         nm = (ROUND == 1 && n) ? mask_count(mask + ty * u.mask_words, t0, n) : n;
                     }
                     const uint32_t rinc = wave_incl_scan_u32(nm, lane);
-                    if (ty <= ty1) emit_run<ROUND>(pairs, base + rinc - nm, ty, tiles_x, t0, n, jb, mask + ty * u.mask_words);
+                    if (ty <= ty1) emit_run<ROUND, P32>(pairs, base + rinc - nm, ty, tiles_x, t0, n, jb, jb - j_lo, u.pair_jbits, mask + ty * u.mask_words);
                     base += __shfl(rinc, 63, 64);
                 }
             }
@@ -308,9 +317,12 @@ __global__ __launch_bounds__(GS_BLOCK) void k_emit(const gsm::Projected *__restr
 
 // [start,end) of every tile in the sorted pair list, written for ALL tiles (empty ones get an empty range at the
 // position where they would be), so no clearing pass is needed.
-__global__ __launch_bounds__(GS_BLOCK) void k_tile_ranges(const uint2 *__restrict__ pairs, uint2 *__restrict__ range, uint32_t ntiles,
-                                                          int round, const GsControl *ctl)
+__global__ __launch_bounds__(GS_BLOCK) void k_tile_ranges(const void *__restrict__ pairs, uint32_t jbits, uint2 *__restrict__ range,
+                                                          uint32_t ntiles, int round, const GsControl *ctl)
 {
+    const uint2 *p64 = reinterpret_cast<const uint2 *>(pairs);
+    const uint32_t *p32 = reinterpret_cast<const uint32_t *>(pairs);
+#define GS_PAIR_TILE(i) (jbits ? (p32[i] >> jbits) : p64[i].x)
     if (round == 1 && ctl->j_hi == 0) return;                      // nothing left for round 1: its blend returns too
     const uint32_t I = ctl->n_pairs;
     if (I == 0) {
@@ -318,12 +330,12 @@ __global__ __launch_bounds__(GS_BLOCK) void k_tile_ranges(const uint2 *__restric
         return;
     }
     for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < I; p += gridDim.x * blockDim.x) {
-        const uint32_t k = pairs[p].x;
+        const uint32_t k = GS_PAIR_TILE(p);
         if (p == 0) {
             for (uint32_t t = 0; t < k; t++) range[t] = make_uint2(0u, 0u);
             range[k].x = 0;
         } else {
-            const uint32_t kp = pairs[p - 1].x;
+            const uint32_t kp = GS_PAIR_TILE(p - 1);
             if (kp != k) {
                 range[kp].y = p;
                 for (uint32_t t = kp + 1; t < k; t++) range[t] = make_uint2(p, p);
@@ -336,6 +348,7 @@ __global__ __launch_bounds__(GS_BLOCK) void k_tile_ranges(const uint2 *__restric
         }
     }
 }
+#undef GS_PAIR_TILE
 
 // Fragment shader + blend for one 16x16 tile, ONE wavefront per tile, four horizontally adjacent pixels per lane
 // (lane l: image row l/4 of the tile, pixels 4*(l%4) .. +3).  The projected records of a batch are staged in LDS and
@@ -354,7 +367,7 @@ __device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementw
 // SCENE: the opaque scene's depth buffer (fragment kept iff its window depth <= the buffer: depthTest LEQUAL,
 // depthWrite off, index.js:179-180) and/or colour image (the destination the splats are blended over).
 template <bool COUNT, int ROUND, bool SCENE>
-__global__ __launch_bounds__(64) void k_blend(const uint2 *__restrict__ tile_range, const uint2 *__restrict__ pairs,
+__global__ __launch_bounds__(64) void k_blend(const uint2 *__restrict__ tile_range, const void *__restrict__ pairs,
                                               const gsm::Projected *__restrict__ proj, GsFrameUniforms u,
                                               uint8_t *__restrict__ out, float4 *__restrict__ state, uint32_t *__restrict__ mask,
                                               const float *__restrict__ zwin, const float *__restrict__ scene_depth,
@@ -365,6 +378,7 @@ __global__ __launch_bounds__(64) void k_blend(const uint2 *__restrict__ tile_ran
     const int lane = threadIdx.x;
     if (ROUND == 1 && ctl->j_hi == 0) return;                      // every tile saturated in round 0
     const uint32_t ntiles = (uint32_t)u.tiles_x * (uint32_t)u.tiles_y;
+    const uint32_t pair_j_lo = ctl->j_lo, pair_j_mask = (1u << u.pair_jbits) - 1u;   // 4-byte pair records carry position - j_lo
     for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {   // round 0: one tile per wave; round 1: small grid
     const uint32_t tx = tile % (uint32_t)u.tiles_x, ty = tile / (uint32_t)u.tiles_x;
     if (ROUND == 1 && !((mask[ty * u.mask_words + (tx >> 5)] >> (tx & 31)) & 1u)) continue;   // this tile is final already
@@ -414,7 +428,8 @@ __global__ __launch_bounds__(64) void k_blend(const uint2 *__restrict__ tile_ran
         for (int h = 0; h < GS_BLEND_BATCH / 64; h++) {            // nearest first: reverse the back-to-front list
             const uint32_t slot = h * 64 + lane;
             if (slot < nb) {
-                const uint32_t j = pairs[end - 1 - slot].y;
+                const uint32_t j = u.pair_jbits ? pair_j_lo + (reinterpret_cast<const uint32_t *>(pairs)[end - 1 - slot] & pair_j_mask)
+                                                : reinterpret_cast<const uint2 *>(pairs)[end - 1 - slot].y;
                 const float4 *src = reinterpret_cast<const float4 *>(proj + j);
                 s_rec[2 * slot] = src[0];
                 s_rec[2 * slot + 1] = src[1];
@@ -560,30 +575,40 @@ int run_round(gs_ctx *ctx, const GsFrameUniforms &u, uint8_t *out, bool last_rou
     if (ROUND == 0) GS_PROF_RECORD(ctx, 3);
     hipLaunchKernelGGL(k_pairs_check<ROUND>, dim3(1), dim3(GS_BLOCK), 0, st, ctx->ctl, (uint32_t)ctx->pair_cap, ctx->spine, ctx->part_vis, g,
                        u.near_count, last_round ? 1 : 0, ctx->unsat_mask, (uint32_t)u.tiles_y * u.mask_words);
-    hipLaunchKernelGGL(k_emit<ROUND>, dim3(g), dim3(GS_BLOCK), 0, st, ctx->proj, ctx->rect, ctx->tile_count, ctx->spine, u, ctx->pair_a,
-                       ctx->unsat_mask, ctx->ctl);
+    // pair record format: 4 bytes when the tile id and the round's position range fit in 32 bits together
+    const int tb = bits_for(ntiles);
+    const uint32_t jrange = ROUND == 0 ? (u.near_count != 0xFFFFFFFFu && u.near_count < Vmax ? u.near_count : Vmax) : Vmax;
+    const int jb = bits_for(jrange);
+    const bool p32 = !ctx->wide_pairs && tb + jb <= 32;
+    GsFrameUniforms v = u;
+    v.pair_jbits = p32 ? (uint32_t)jb : 0u;
+    if (p32) hipLaunchKernelGGL((k_emit<ROUND, true>), dim3(g), dim3(GS_BLOCK), 0, st, ctx->proj, ctx->rect, ctx->tile_count, ctx->spine, v,
+                                (void *)ctx->pair_a, ctx->unsat_mask, ctx->ctl);
+    else hipLaunchKernelGGL((k_emit<ROUND, false>), dim3(g), dim3(GS_BLOCK), 0, st, ctx->proj, ctx->rect, ctx->tile_count, ctx->spine, v,
+                            (void *)ctx->pair_a, ctx->unsat_mask, ctx->ctl);
     GS_HIP(hipGetLastError());
     int rc;
-    const int tb = bits_for(ntiles);
-    const uint2 *fpairs;
+    const int fmt = p32 ? GS_RADIX_KEYONLY : GS_RADIX_PACKED, sh = p32 ? jb : 0;
+    const void *fpairs;
     if (tb <= 9) {
-        rc = gs_launch_radix_pass(ctx, ctx->pair_a, true, ctx->pair_b, true, &ctx->ctl->n_pairs, pc, 0, tb);
+        rc = gs_launch_radix_pass(ctx, ctx->pair_a, fmt, ctx->pair_b, fmt, &ctx->ctl->n_pairs, pc, sh, tb);
         if (rc != GS_OK) return rc;
         fpairs = ctx->pair_b;
     } else {
         const int b1 = (tb + 1) / 2, b2 = tb - b1;
-        rc = gs_launch_radix_pass(ctx, ctx->pair_a, true, ctx->pair_b, true, &ctx->ctl->n_pairs, pc, 0, b1);
+        rc = gs_launch_radix_pass(ctx, ctx->pair_a, fmt, ctx->pair_b, fmt, &ctx->ctl->n_pairs, pc, sh, b1);
         if (rc != GS_OK) return rc;
-        rc = gs_launch_radix_pass(ctx, ctx->pair_b, true, ctx->pair_a, true, &ctx->ctl->n_pairs, pc, b1, b2);
+        rc = gs_launch_radix_pass(ctx, ctx->pair_b, fmt, ctx->pair_a, fmt, &ctx->ctl->n_pairs, pc, sh + b1, b2);
         if (rc != GS_OK) return rc;
         fpairs = ctx->pair_a;
     }
-    hipLaunchKernelGGL(k_tile_ranges, dim3(ROUND == 1 ? small : 2048), dim3(GS_BLOCK), 0, st, fpairs, ctx->tile_range, ntiles, ROUND, ctx->ctl);
+    hipLaunchKernelGGL(k_tile_ranges, dim3(ROUND == 1 ? small : 2048), dim3(GS_BLOCK), 0, st, fpairs, v.pair_jbits, ctx->tile_range, ntiles, ROUND,
+                       ctx->ctl);
     GS_HIP(hipGetLastError());
     if (ROUND == 0) GS_PROF_RECORD(ctx, 4);
     const uint32_t gb = ROUND == 1 ? (ntiles < 1024 ? ntiles : 1024) : ntiles;
     const bool scene = u.has_depth || u.has_scene_rgba;
-#define GS_LAUNCH_BLEND(C, S) hipLaunchKernelGGL((k_blend<C, ROUND, S>), dim3(gb), dim3(64), 0, st, ctx->tile_range, fpairs, ctx->proj, u, \
+#define GS_LAUNCH_BLEND(C, S) hipLaunchKernelGGL((k_blend<C, ROUND, S>), dim3(gb), dim3(64), 0, st, ctx->tile_range, fpairs, ctx->proj, v, \
                                                 out, ctx->state, ctx->unsat_mask, ctx->zwin, ctx->scene_depth, ctx->scene_rgba, ctx->ctl)
     if (u.flags & GS_RENDER_COUNT_FRAGS) { if (scene) GS_LAUNCH_BLEND(true, true); else GS_LAUNCH_BLEND(true, false); }
     else { if (scene) GS_LAUNCH_BLEND(false, true); else GS_LAUNCH_BLEND(false, false); }

@@ -133,11 +133,11 @@ int gs_run_sort(gs_ctx *ctx, const float view[4], const float *cutout16)
     hipLaunchKernelGGL(k_sort_bucket, dim3(g), dim3(GS_BLOCK), 0, ctx->stream, ctx->depth, n, ctx->key_a, ctx->part_min,
                        ctx->part_max, ctx->part_cnt, g, ctx->hist, ctx->ctl);
     GS_HIP(hipGetLastError());
-    int rc = gs_launch_radix_pass(ctx, ctx->key_a, false, ctx->kv_b, true, &ctx->ctl->n_total, n, 0, 8, /*have_hist=*/true);
+    int rc = gs_launch_radix_pass(ctx, ctx->key_a, GS_RADIX_KEYS, ctx->kv_b, GS_RADIX_PACKED, &ctx->ctl->n_total, n, 0, 8, /*have_hist=*/true);
     if (rc != GS_OK) return rc;
     // culled / dropped splats (key 65536) sort behind every bucket and store 0: the tail [V',V) of the result is 0 like
     // the reference's never-written Uint32Array slots
-    rc = gs_launch_radix_pass(ctx, ctx->kv_b, true, ctx->val_a, false, &ctx->ctl->n_total, n, 8, 9, false, GS_CULLED_KEY);
+    rc = gs_launch_radix_pass(ctx, ctx->kv_b, GS_RADIX_PACKED, ctx->val_a, GS_RADIX_KEYS, &ctx->ctl->n_total, n, 8, 9, false, GS_CULLED_KEY);
     if (rc != GS_OK) return rc;
     GS_PROF_RECORD(ctx, 1);
     ctx->sorted = ctx->val_a;

@@ -210,6 +210,8 @@ typedef struct gs_stats {
                                    chain of frame k+1 runs under the tail of frame k -- as the reference overlaps its
                                    worker sort with drawing.  A gs_sort() begins a frame; it moves to the next lane when
                                    the previous frame was handed off asynchronously.  1 = strictly one frame at a time   */
+#define GS_OPT_WIDE_PAIRS 6     /* value != 0: always bin with 8-byte (tile, position) records; default 0 = 4-byte records
+                                   whenever tile bits + position bits of the binning round fit in 32 (same images)      */
 GS_API int gs_set_option(gs_ctx *ctx, int option, int64_t value);
 GS_API int gs_get_stats(gs_ctx *ctx, gs_stats *out);
 

@@ -759,3 +759,24 @@ def test_stream_coupling_calls_order_frames_with_caller_streams(scene_small):
         torch.cuda.synchronize()
         for o, wnt in zip(outs, want):
             assert np.array_equal(o.cpu().numpy().reshape(h, w, 4), wnt)
+
+
+@pytest.mark.parametrize("w,h,n,permille", [(640, 360, 30000, 0), (1920, 1080, 300000, 0), (1920, 1080, 300000, 1000), (333, 211, 5000, 300)])
+def test_narrow_and_wide_pair_records_give_identical_frames(w, h, n, permille):
+    """The binning uses 4-byte (tile << b | position) records when they fit and 8-byte (tile, position) records otherwise:
+    the two formats must produce the same image, fragment count and pair count, for single- and two-round frames."""
+    rows = synth.make_splat_rows(n, seed=909)
+    cam = synth.index_html_camera(w, h, 123.0, capi=capi)
+    out = {}
+    for wide in (0, 1):
+        with capi.Context(0) as c:
+            c.set_option(capi.OPT_WIDE_PAIRS, wide)
+            c.set_option(capi.OPT_NEAR_PERMILLE, permille)
+            c.push_splat(rows)
+            c.sort(cam["view"])
+            img = c.render(_params(cam))
+            pairs = c.stats()["n_pairs"]
+            c.render(_params(cam, flags=capi.RENDER_COUNT_FRAGS))
+            out[wide] = (img, pairs, c.stats()["n_frags"])
+    assert np.array_equal(out[0][0], out[1][0]) and out[0][1] == out[1][1] and out[0][2] == out[1][2]
+    assert out[0][1] > 0
