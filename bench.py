@@ -42,6 +42,11 @@ def main():
     ap.add_argument("--size", default=None, help="override the viewport, e.g. 3840x2160 (default 1920x1080)")
     ap.add_argument("--cutout", action="store_true", help="cutout-demo.html pose with the cutoutEntity box (config C3)")
     args = ap.parse_args()
+    # stdout carries exactly ONE JSON line: whatever native libraries (RCCL's version banner, HIP warnings) write to file
+    # descriptor 1 during the run goes to stderr instead; the line is written to the real stdout at the end
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
 
     global W, H
     if args.size:
@@ -267,7 +272,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(rows, cams[args.warmup % ORBIT_FRAMES], synth)
         if args.size or args.cutout or args.splats:
             out["metric"] = out["metric"].replace("@1920x1080", "@%dx%d" % (W, H)).replace("1M-splat", "%d-splat" % n_splats)
-        print(json.dumps(out), flush=True)
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     ctx.close()
     if multi:
         dist.barrier()
