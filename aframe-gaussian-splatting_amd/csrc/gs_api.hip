@@ -3,7 +3,11 @@
 // library refuses to exist without a device (no CPU fallback).
 #include <stddef.h>
 #include <stdlib.h>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
 #include <new>
+#include <thread>
 #include <vector>
 #include "gs_internal.h"
 #include "gs_ply.h"
@@ -27,6 +31,9 @@ template <typename T> static int dev_alloc(gs_ctx *ctx, T **p, size_t count)
 }
 template <typename T> static void dev_free(T *&p) { if (p) { (void)hipFree(p); p = nullptr; } }
 #define TRY(x) do { int _rc = (x); if (_rc != GS_OK) return _rc; } while (0)
+
+static int lane_drain(gs_ctx *L);
+static void lane_stop_worker(gs_ctx *L);
 
 static int ensure_scan_scratch(gs_ctx *ctx)
 {
@@ -67,9 +74,15 @@ int gs_ensure_pair_capacity(gs_ctx *ctx, size_t pairs)
 static int drain_all(gs_ctx *ctx)
 {
     gs_ctx *P = gs_root(ctx);
-    for (int i = 0; i < GS_MAX_LANES; i++)
-        if (P->lanes[i] && P->lanes[i]->stream) GS_HIP(hipStreamSynchronize(P->lanes[i]->stream));
-    return GS_OK;
+    int first = GS_OK;
+    for (int i = 0; i < GS_MAX_LANES; i++) {
+        gs_ctx *L = P->lanes[i];
+        if (!L) continue;
+        const int rc = lane_drain(L);                              // a worker's failure surfaces at the next gs_sync()
+        if (rc != GS_OK && first == GS_OK) { first = rc; if (L != ctx) memcpy(ctx->err, L->err, sizeof ctx->err); }
+        if (L->stream) GS_HIP(hipStreamSynchronize(L->stream));
+    }
+    return first;
 }
 
 // per-frame scratch of one lane (sort keys, projected records, pair lists, scan tables) for `cap` splats
@@ -211,6 +224,85 @@ static int collect_status(gs_ctx *lane, bool *overflowed)
     return GS_OK;
 }
 
+// ---------------------------------------------------------------- enqueue threads
+// Enqueuing one frame costs the host ~100 us (18 kernel launches), about what the GPU needs for a frame once three of
+// them overlap -- so each lane gets a worker thread that does the launching: gs_sort() / gs_render_device(ASYNC) only
+// hand it the frame's uniforms, and the launches of the frames in flight proceed in parallel on the lanes' own streams.
+// Everything a worker touches is lane-local; the caller's thread touches a lane only after lane_drain().
+
+struct GsLaneCmd {
+    int type;                                                  // 0 = sort, 1 = asynchronous render
+    float view[4], cutout[16]; bool has_cutout;
+    GsFrameUniforms u; void *device_rgba;
+};
+
+struct GsLaneWorker {
+    std::thread th;
+    std::mutex m;
+    std::condition_variable cv_work, cv_idle;
+    std::deque<GsLaneCmd> q;
+    bool busy = false, stop = false;
+    int rc = GS_OK;                                            // first failure since the last drain (message in the lane's err)
+};
+
+static int render_async_on_lane(gs_ctx *ctx, const GsFrameUniforms &u, void *device_rgba);
+
+static void lane_worker_main(gs_ctx *L)
+{
+    GsLaneWorker *w = L->worker;
+    (void)hipSetDevice(L->device);
+    std::unique_lock<std::mutex> lk(w->m);
+    for (;;) {
+        w->cv_work.wait(lk, [&] { return w->stop || !w->q.empty(); });
+        if (w->q.empty()) break;                               // stop requested and nothing left to do
+        GsLaneCmd c = w->q.front(); w->q.pop_front();
+        w->busy = true;
+        lk.unlock();
+        int rc = GS_OK;
+        if (w->rc == GS_OK) rc = c.type == 0 ? gs_run_sort(L, c.view, c.has_cutout ? c.cutout : nullptr)
+                                             : render_async_on_lane(L, c.u, c.device_rgba);
+        lk.lock();
+        if (rc != GS_OK && w->rc == GS_OK) w->rc = rc;
+        w->busy = false;
+        if (w->q.empty()) w->cv_idle.notify_all();
+    }
+}
+
+// wait until the lane's worker has enqueued everything it was given; returns (and clears) its first failure
+static int lane_drain(gs_ctx *L)
+{
+    GsLaneWorker *w = L->worker;
+    if (!w) return GS_OK;
+    std::unique_lock<std::mutex> lk(w->m);
+    w->cv_idle.wait(lk, [&] { return w->q.empty() && !w->busy; });
+    const int rc = w->rc; w->rc = GS_OK;
+    return rc;
+}
+
+static int lane_push(gs_ctx *L, const GsLaneCmd &c)
+{
+    if (!L->worker) {
+        L->worker = new (std::nothrow) GsLaneWorker();
+        if (!L->worker) return GS_E_OOM;
+        L->worker->th = std::thread(lane_worker_main, L);
+    }
+    GsLaneWorker *w = L->worker;
+    { std::lock_guard<std::mutex> lk(w->m); w->q.push_back(c); }
+    w->cv_work.notify_one();
+    return GS_OK;
+}
+
+static void lane_stop_worker(gs_ctx *L)
+{
+    GsLaneWorker *w = L->worker;
+    if (!w) return;
+    { std::lock_guard<std::mutex> lk(w->m); w->stop = true; }
+    w->cv_work.notify_one();
+    if (w->th.joinable()) w->th.join();
+    delete w;
+    L->worker = nullptr;
+}
+
 // ---------------------------------------------------------------- lanes (frame pipelining)
 
 #define LANE_HIP(L, call) do { hipError_t _e = (call); if (_e != hipSuccess) {                                             \
@@ -241,6 +333,7 @@ static hipError_t init_frame_resources(gs_ctx *c)
 
 static void free_frame_resources(gs_ctx *c)
 {
+    lane_stop_worker(c);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     dev_free(c->depth); dev_free(c->key_a); dev_free(c->kv_b); dev_free(c->val_a);
     dev_free(c->hist); dev_free(c->spine);
@@ -260,6 +353,7 @@ static void free_frame_resources(gs_ctx *c)
 // switch the HIP-event profiling of one lane on/off (allocates its ring on first use, restarts its accumulators)
 static int set_profile(gs_ctx *ctx, bool on, bool blend_only)
 {
+    TRY(lane_drain(ctx));
     GS_HIP(hipStreamSynchronize(ctx->stream));
     TRY(prof_drain(ctx));
     if (on && !ctx->ring) {
@@ -296,6 +390,7 @@ static int get_lane(gs_ctx *ctx, int i, gs_ctx **out)
         ctx->lanes[i] = L;
         if (ctx->profile && set_profile(L, true, ctx->profile_blend_only) != GS_OK) { memcpy(ctx->err, L->err, sizeof ctx->err); return GS_E_HIP; }
     }
+    if (lane_drain(L) != GS_OK) { if (L != ctx) memcpy(ctx->err, L->err, sizeof ctx->err); return GS_E_HIP; }   // its worker is idle from here on
     if (L != ctx) {
         L->splat = ctx->splat; L->sort_rows = ctx->sort_rows; L->pow10tab = ctx->pow10tab;
         L->n = ctx->n; L->cap = ctx->cap; L->renderable = ctx->renderable;
@@ -305,6 +400,19 @@ static int get_lane(gs_ctx *ctx, int i, gs_ctx **out)
     }
     *out = L;
     return GS_OK;
+}
+
+// after drain_all(): give every lane the owner's current resident arrays, scene inputs and options
+static void refresh_lanes(gs_ctx *ctx)
+{
+    for (int i = 1; i < GS_MAX_LANES; i++) {
+        gs_ctx *L = ctx->lanes[i];
+        if (!L) continue;
+        L->splat = ctx->splat; L->sort_rows = ctx->sort_rows; L->pow10tab = ctx->pow10tab;
+        L->n = ctx->n; L->cap = ctx->cap; L->renderable = ctx->renderable;
+        L->scene_depth = ctx->scene_depth; L->scene_rgba = ctx->scene_rgba; L->scene_w = ctx->scene_w; L->scene_h = ctx->scene_h;
+        L->record_staged = ctx->record_staged; L->t_eps = ctx->t_eps; L->wide_pairs = ctx->wide_pairs;
+    }
 }
 
 // the lane a NEW frame goes to: the next one if the current frame was handed off asynchronously
@@ -344,7 +452,7 @@ GS_API int gs_create(int device, gs_ctx **out)
     if (!ctx) { snprintf(g_create_err, sizeof g_create_err, "out of host memory"); return GS_E_OOM; }
     memset(ctx, 0, sizeof *ctx);
     ctx->device = device; ctx->renderable = true; ctx->t_eps = 1.0f / 4096.0f; ctx->near_frac = 0.25f;
-    ctx->lanes[0] = ctx; ctx->pipe_depth = 3;
+    ctx->lanes[0] = ctx; ctx->pipe_depth = 3; ctx->enqueue_threads = true;
 #define CREATE_HIP(call) do { hipError_t _e = (call); if (_e != hipSuccess) {                                              \
         snprintf(g_create_err, sizeof g_create_err, "%s failed: %s", #call, hipGetErrorString(_e)); gs_destroy(ctx);      \
         return GS_E_HIP; } } while (0)
@@ -521,6 +629,17 @@ GS_API int gs_sort(gs_ctx *ctx, const float view[4], const float *cutout16, uint
     const int lane = next_frame_lane(ctx);
     TRY(get_lane(ctx, lane, &L));
     ctx->cur = lane; ctx->cur_async = false;
+    if (ctx->enqueue_threads && ctx->pipe_depth > 1 && !ctx->user_stream && !out_idx && !out_n) {
+        // nothing to hand back: the lane's worker thread does the launching (a failure surfaces at gs_sync())
+        GsLaneCmd c;
+        c.type = 0; memcpy(c.view, view, sizeof c.view);
+        c.has_cutout = cutout16 != nullptr;
+        if (cutout16) memcpy(c.cutout, cutout16, sizeof c.cutout);
+        c.device_rgba = nullptr;
+        L->have_sort = true;                                    // (set again by the worker; the render command follows it)
+        if (lane_push(L, c) != GS_OK) FAIL(GS_E_OOM, "out of host memory");
+        return GS_OK;
+    }
     TRY(lane_rc(ctx, L, gs_run_sort(L, view, cutout16)));
     if (out_idx || out_n) {
         LANE_HIP(L, hipMemcpyAsync(L->ctl_host, L->ctl, sizeof(GsControl), hipMemcpyDeviceToHost, L->stream));
@@ -559,30 +678,38 @@ static int fill_uniforms(gs_ctx *ctx /* owner: options, adaptive share, scene */
     return GS_OK;
 }
 
-// one frame on lane `ctx` (the owner supplies options and the adaptive share through fill_uniforms)
-static int render_on_lane(gs_ctx *ctx, const GsFrameUniforms &u0, void *device_rgba, uint8_t *host_rgba, size_t stride)
+// per-frame buffers of lane `ctx` for the viewport of `u`
+static int ensure_frame_buffers(gs_ctx *ctx, const GsFrameUniforms &u, bool need_fb)
 {
-    GsFrameUniforms u = u0;
     const size_t sw = (size_t)(u.x1 - u.x0), fb_bytes = sw * (size_t)u.H * 4;
     const size_t ntiles = (size_t)u.tiles_x * u.tiles_y;
     if (ntiles > ctx->tile_cap) { dev_free(ctx->tile_range); TRY(dev_alloc(ctx, &ctx->tile_range, ntiles)); ctx->tile_cap = ntiles; }
-    if (!device_rgba && fb_bytes > ctx->fb_cap) { dev_free(ctx->fb); TRY(dev_alloc(ctx, &ctx->fb, fb_bytes)); ctx->fb_cap = fb_bytes; }
+    if (need_fb && fb_bytes > ctx->fb_cap) { dev_free(ctx->fb); TRY(dev_alloc(ctx, &ctx->fb, fb_bytes)); ctx->fb_cap = fb_bytes; }
     if (!ctx->pair_cap) TRY(gs_ensure_pair_capacity(ctx, (size_t)1 << 22));
     const size_t mask_total = (size_t)u.tiles_y * u.mask_words;
     if (mask_total > ctx->mask_cap) { dev_free(ctx->unsat_mask); TRY(dev_alloc(ctx, &ctx->unsat_mask, mask_total)); ctx->mask_cap = mask_total; }
     if (ntiles * 256 > ctx->state_cap) { dev_free(ctx->state); TRY(dev_alloc(ctx, &ctx->state, ntiles * 256)); ctx->state_cap = ntiles * 256; }
-    const bool async = (u.flags & GS_RENDER_ASYNC) && !host_rgba && !(u.flags & GS_RENDER_COUNT_FRAGS);
     ctx->last_two_rounds = u.near_count != 0xFFFFFFFFu && ctx->n && ctx->have_sort;
     ctx->stats.n_tiles = ntiles; ctx->stats.blend_launches = 1;
-    if (async) {
-        // pipelined frame: enqueue and return; gs_sync() reads the control block back (its flags and accumulators are
-        // cumulative, so one read-back per gs_sync() covers every frame since the last one -- a per-frame copy would be one
-        // more queue entry per frame).  An overflowing frame shows the background only and is reported (GS_E_RETRY) there.
-        TRY(gs_run_render(ctx, u, (uint8_t *)device_rgba));
-        ctx->async_pending = true;
-        gs_root(ctx)->cur_async = true;
-        return prof_advance(ctx);
-    }
+    return GS_OK;
+}
+
+// pipelined frame on lane `ctx`: enqueue and return; gs_sync() reads the control block back (its flags and accumulators
+// are cumulative, so one read-back per gs_sync() covers every frame since the last one -- a per-frame copy would be one
+// more queue entry per frame).  An overflowing frame shows the background only and is reported (GS_E_RETRY) there.
+// Runs on the lane's worker thread when GS_OPT_ENQUEUE_THREADS is on.
+static int render_async_on_lane(gs_ctx *ctx, const GsFrameUniforms &u, void *device_rgba)
+{
+    TRY(ensure_frame_buffers(ctx, u, device_rgba == nullptr));
+    TRY(gs_run_render(ctx, u, (uint8_t *)device_rgba));
+    return prof_advance(ctx);
+}
+
+// synchronous frame on lane `ctx` (the owner supplies options and the adaptive share through fill_uniforms)
+static int render_sync_on_lane(gs_ctx *ctx, const GsFrameUniforms &u, void *device_rgba, uint8_t *host_rgba, size_t stride)
+{
+    const size_t sw = (size_t)(u.x1 - u.x0);
+    TRY(ensure_frame_buffers(ctx, u, device_rgba == nullptr));
     for (int attempt = 0;; attempt++) {
         TRY(gs_run_render(ctx, u, (uint8_t *)device_rgba));
         GS_HIP(hipMemcpyAsync(ctx->ctl_host, ctx->ctl, sizeof(GsControl), hipMemcpyDeviceToHost, ctx->stream));
@@ -618,9 +745,21 @@ static int render_common(gs_ctx *ctx, const gs_render_params *p, void *device_rg
     GsFrameUniforms u;
     TRY(fill_uniforms(ctx, p, u));
     GS_HIP(hipSetDevice(ctx->device));
-    gs_ctx *L = nullptr;
-    TRY(get_lane(ctx, ctx->cur, &L));                           // the frame's lane: where its gs_sort ran
-    return lane_rc(ctx, L, render_on_lane(L, u, device_rgba, host_rgba, stride));
+    gs_ctx *L = ctx->lanes[ctx->cur];                           // the frame's lane: where its gs_sort ran
+    const bool async = (u.flags & GS_RENDER_ASYNC) && !host_rgba && !(u.flags & GS_RENDER_COUNT_FRAGS);
+    if (async) {
+        L->async_pending = true; ctx->cur_async = true;
+        if (ctx->enqueue_threads && ctx->pipe_depth > 1 && !ctx->user_stream) {
+            GsLaneCmd c;
+            c.type = 1; c.has_cutout = false; c.u = u; c.device_rgba = device_rgba;
+            if (lane_push(L, c) != GS_OK) FAIL(GS_E_OOM, "out of host memory");
+            return GS_OK;
+        }
+        TRY(lane_rc(ctx, L, lane_drain(L)));
+        return lane_rc(ctx, L, render_async_on_lane(L, u, device_rgba));
+    }
+    TRY(lane_rc(ctx, L, lane_drain(L)));                         // whatever its worker still had to enqueue comes first
+    return lane_rc(ctx, L, render_sync_on_lane(L, u, device_rgba, host_rgba, stride));
 }
 
 GS_API int gs_render(gs_ctx *ctx, const gs_render_params *p, uint8_t *rgba_out, size_t stride)
@@ -651,12 +790,14 @@ GS_API int gs_set_scene(gs_ctx *ctx, const float *depth, const uint8_t *rgba, in
     TRY(drain_all(ctx));
     dev_free(ctx->scene_depth); dev_free(ctx->scene_rgba);
     ctx->scene_w = ctx->scene_h = 0;
+    refresh_lanes(ctx);
     if (!depth && !rgba) return GS_OK;
     if (fb_width <= 0 || fb_height <= 0) FAIL(GS_E_BADARG, "gs_set_scene: bad size %dx%d", fb_width, fb_height);
     const size_t px = (size_t)fb_width * fb_height;
     if (depth) { TRY(dev_alloc(ctx, &ctx->scene_depth, px)); GS_HIP(hipMemcpy(ctx->scene_depth, depth, px * 4, hipMemcpyHostToDevice)); }
     if (rgba) { TRY(dev_alloc(ctx, &ctx->scene_rgba, px)); GS_HIP(hipMemcpy(ctx->scene_rgba, rgba, px * 4, hipMemcpyHostToDevice)); }
     ctx->scene_w = fb_width; ctx->scene_h = fb_height;
+    refresh_lanes(ctx);
     return GS_OK;
 }
 
@@ -669,6 +810,7 @@ GS_API int gs_sync(gs_ctx *ctx)
     for (int i = 0; i < GS_MAX_LANES; i++) {
         gs_ctx *L = ctx->lanes[i];
         if (!L) continue;
+        TRY(lane_rc(ctx, L, lane_drain(L)));
         LANE_HIP(L, hipStreamSynchronize(L->stream));
         TRY(lane_rc(ctx, L, prof_drain(L)));
         if (!L->async_pending) continue;
@@ -718,12 +860,18 @@ GS_API int gs_stream_wait_frame(gs_ctx *ctx, void *hip_stream)
     CHECK_CTX(ctx);
     GS_HIP(hipSetDevice(ctx->device));
     gs_ctx *L = ctx->lanes[ctx->cur];
+    TRY(lane_rc(ctx, L, lane_drain(L)));
     GS_HIP(hipEventRecord(L->ev_frame, L->stream));
     GS_HIP(hipStreamWaitEvent((hipStream_t)hip_stream, L->ev_frame, 0));
     return GS_OK;
 }
 
-GS_API void *gs_frame_stream(gs_ctx *ctx) { return ctx ? (void *)ctx->lanes[ctx->cur]->stream : nullptr; }
+GS_API void *gs_frame_stream(gs_ctx *ctx)
+{
+    if (!ctx) return nullptr;
+    (void)lane_drain(ctx->lanes[ctx->cur]);                      // the frame's kernels are in the stream when this returns
+    return (void *)ctx->lanes[ctx->cur]->stream;
+}
 
 GS_API int gs_set_option(gs_ctx *ctx, int option, int64_t value)
 {
@@ -743,7 +891,16 @@ GS_API int gs_set_option(gs_ctx *ctx, int option, int64_t value)
     case GS_OPT_TERMINATION:
         if (value < 2) FAIL(GS_E_BADARG, "termination 1/eps must be >= 2");
         ctx->t_eps = 1.0f / (float)value; return GS_OK;
-    case GS_OPT_WIDE_PAIRS: ctx->wide_pairs = value != 0; return GS_OK;
+    case GS_OPT_WIDE_PAIRS:
+        GS_HIP(hipSetDevice(ctx->device));
+        TRY(drain_all(ctx));
+        ctx->wide_pairs = value != 0; refresh_lanes(ctx);
+        return GS_OK;
+    case GS_OPT_ENQUEUE_THREADS:
+        GS_HIP(hipSetDevice(ctx->device));
+        TRY(drain_all(ctx));
+        ctx->enqueue_threads = value != 0;
+        return GS_OK;
     case GS_OPT_PIPELINE_DEPTH:
         if (value < 1 || value > GS_MAX_LANES) FAIL(GS_E_BADARG, "pipeline depth must be 1..%d", GS_MAX_LANES);
         GS_HIP(hipSetDevice(ctx->device));
@@ -760,6 +917,7 @@ GS_API int gs_get_stats(gs_ctx *ctx, gs_stats *out)
     CHECK_CTX(ctx);
     if (!out) FAIL(GS_E_BADARG, "gs_get_stats: out is NULL");
     // per-frame figures: the current frame's lane; accumulators: summed over the lanes
+    for (int i = 0; i < GS_MAX_LANES; i++) if (ctx->lanes[i]) (void)lane_drain(ctx->lanes[i]);
     gs_stats s = ctx->lanes[ctx->cur]->stats;
     s.prof_frames = 0; s.sum_ms_sort = s.sum_ms_project = s.sum_ms_bin = s.sum_ms_blend = 0;
     s.acc_frames = 0; s.acc_sorted = s.acc_visible = s.acc_pairs = 0;
@@ -783,7 +941,8 @@ GS_API int gs_download(gs_ctx *ctx, int which, void *out, size_t nbytes)
     CHECK_CTX(ctx);
     if (!out) FAIL(GS_E_BADARG, "gs_download: out is NULL");
     GS_HIP(hipSetDevice(ctx->device));
-    const gs_ctx *L = ctx->lanes[ctx->cur];                     // per-frame buffers: the current frame's lane
+    gs_ctx *L = ctx->lanes[ctx->cur];                           // per-frame buffers: the current frame's lane
+    TRY(lane_rc(ctx, L, lane_drain(L)));
     GS_HIP(hipStreamSynchronize(L->stream));
     const void *src = nullptr; size_t have = 0;
     const size_t V = L->stats.n_sorted;

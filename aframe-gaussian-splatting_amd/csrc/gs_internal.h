@@ -62,6 +62,7 @@ struct GsFrameUniforms {           // per-render constants, passed by value to k
     uint32_t pair_jbits;           // > 0: 4-byte pair records (tile << pair_jbits | sorted position - j_lo); 0: (tile, position) uint2
 };
 
+struct GsLaneWorker;
 struct gs_ctx {
     int device;
     hipStream_t stream;
@@ -80,6 +81,8 @@ struct gs_ctx {
     bool user_stream;              // gs_set_stream gave lane 0 a caller-owned stream: no rotation
     size_t scratch_cap;            // splats the per-frame scratch of THIS lane is sized for
     hipEvent_t ev_frame, ev_gate;  // gs_stream_wait_frame / gs_wait_stream
+    struct GsLaneWorker *worker;   // enqueue thread of this lane (GS_OPT_ENQUEUE_THREADS), created on first use
+    bool enqueue_threads;          // owner: asynchronous frames are enqueued by the lanes' worker threads
 
     // resident splat data (append-only; capacity doubles)
     size_t n, cap;

@@ -75,6 +75,10 @@ def main():
     rows = synth.make_splat_rows(n_splats)
     ctx = capi.Context(local_rank)
     ctx.push_splat(rows)
+    if multi:
+        # the gather is queued on the frame's lane stream right after the frame, so this thread needs the frame's kernels
+        # enqueued when gs_render_device returns: no enqueue worker threads here
+        ctx.set_option(capi.OPT_ENQUEUE_THREADS, 0)
 
     # tile-aligned column strips
     x0, x1 = mg.strip_bounds(W, world, rank)

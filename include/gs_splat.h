@@ -212,6 +212,10 @@ typedef struct gs_stats {
                                    the previous frame was handed off asynchronously.  1 = strictly one frame at a time   */
 #define GS_OPT_WIDE_PAIRS 6     /* value != 0: always bin with 8-byte (tile, position) records; default 0 = 4-byte records
                                    whenever tile bits + position bits of the binning round fit in 32 (same images)      */
+#define GS_OPT_ENQUEUE_THREADS 7 /* default 1: gs_sort() (without an output array) and gs_render_device(GS_RENDER_ASYNC) hand the
+                                   frame to a worker thread of its pipeline lane, which does the ~18 kernel launches, so the
+                                   launches of the frames in flight run in parallel; failures surface at gs_sync().  0: the
+                                   calling thread launches everything itself                                            */
 GS_API int gs_set_option(gs_ctx *ctx, int option, int64_t value);
 GS_API int gs_get_stats(gs_ctx *ctx, gs_stats *out);
 

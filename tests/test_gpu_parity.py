@@ -780,3 +780,38 @@ def test_narrow_and_wide_pair_records_give_identical_frames(w, h, n, permille):
             out[wide] = (img, pairs, c.stats()["n_frags"])
     assert np.array_equal(out[0][0], out[1][0]) and out[0][1] == out[1][1] and out[0][2] == out[1][2]
     assert out[0][1] > 0
+
+
+def test_enqueue_threads_on_and_off_give_identical_frames_and_statistics(scene_small):
+    """GS_OPT_ENQUEUE_THREADS: the lanes' worker threads only change WHO launches the kernels of an asynchronous frame."""
+    import torch
+    w, h = 400, 225
+    cams = [synth.index_html_camera(w, h, 33.0 * i, capi=capi) for i in range(9)]
+    results = {}
+    for threads in (1, 0):
+        with capi.Context(0) as c:
+            c.set_option(capi.OPT_ENQUEUE_THREADS, threads)
+            c.push_splat(scene_small["rows"])
+            bufs = [torch.zeros(w * h * 4, dtype=torch.uint8, device="cuda") for _ in cams]
+            for attempt in range(4):
+                c.set_option(capi.OPT_PROFILE, 0); c.set_option(capi.OPT_PROFILE, 1)
+                for cam, buf in zip(cams, bufs):
+                    c.sort(cam["view"], want_indices=False)
+                    c.render_device(_params(cam, flags=capi.RENDER_ASYNC), buf.data_ptr())
+                try:
+                    c.sync()
+                    break
+                except capi.GsError as e:
+                    assert e.code == capi.E_RETRY and attempt < 3
+            torch.cuda.synchronize()
+            s = c.stats()
+            assert s["acc_frames"] == len(cams) == s["prof_frames"]
+            results[threads] = ([b.cpu().numpy() for b in bufs], s["acc_pairs"], s["acc_visible"], s["acc_sorted"])
+            # a synchronous frame right behind asynchronous ones (worker still busy) is ordered after them
+            c.sort(cams[0]["view"], want_indices=False)
+            c.render_device(_params(cams[0], flags=capi.RENDER_ASYNC), bufs[1].data_ptr())
+            c.sort(cams[0]["view"])
+            assert np.array_equal(c.render(_params(cams[0])).reshape(-1), results[threads][0][0])
+    for a, b in zip(results[0][0], results[1][0]):
+        assert np.array_equal(a, b)
+    assert results[0][2:] == results[1][2:]
