@@ -252,7 +252,9 @@ def main():
             "config": {"workload": "train.splat-shaped synthetic, N=%d splats, %dx%d, 120-frame orbit (%s)" % (
                            n_splats, W, H, "cutout-demo.html:22-24 pose + cutoutEntity box" if args.cutout else "index.html:13 pose"),
                        "parallelism": "column strips x%d, splat buffer replicated, RCCL gather" % world if world > 1 else "single GPU",
-                       "strip_px": sw},
+                       "strip_px": sw,
+                       "frames_in_flight": "3 (the library's pipeline lanes: every frame still runs its own full sort, projection, "
+                                           "binning and blend; consecutive frames overlap on the GPU)"},
             "occlusion_binning": {"near_permille": s["near_permille"], "unsat_tiles_last_frame": s["unsat_tiles"],
                                   "timed_region_retries": retries},
             "msplat_frags_per_s": round(total_frags / 1e6 / elapsed, 1),
