@@ -19,7 +19,7 @@ BUF_CENTER_SCALE, BUF_COV_COLOR, BUF_SORT_ROWS, BUF_SORTED, BUF_PROJECTED, BUF_T
 EXPORTS = [
     "gs_create", "gs_destroy", "gs_last_error", "gs_version", "gs_clear", "gs_push_splat", "gs_push_matrices", "gs_load_ply",
     "gs_ply_to_splat", "gs_ply_to_splat_gpu", "gs_count", "gs_sort", "gs_render", "gs_render_device", "gs_render_stereo", "gs_set_scene", "gs_sync",
-    "gs_set_stream", "gs_frame_stream", "gs_wait_stream", "gs_stream_wait_frame",
+    "gs_set_stream", "gs_frame_stream", "gs_frame_lane", "gs_lane_stream", "gs_wait_stream", "gs_stream_wait_frame",
     "gs_model_view_matrix", "gs_projection_matrix", "gs_tick_uniforms", "gs_focal", "gs_scaled_size", "gs_set_option",
     "gs_get_stats", "gs_download",
 ]
@@ -87,6 +87,8 @@ def load(build_if_missing=True):
     L.gs_set_stream.argtypes = [vp, vp]
     L.gs_wait_stream.argtypes = [vp, vp]
     L.gs_frame_stream.argtypes = [vp]; L.gs_frame_stream.restype = C.c_void_p
+    L.gs_frame_lane.argtypes = [vp]; L.gs_frame_lane.restype = C.c_int
+    L.gs_lane_stream.argtypes = [vp, C.c_int]; L.gs_lane_stream.restype = C.c_void_p
     L.gs_stream_wait_frame.argtypes = [vp, vp]
     L.gs_model_view_matrix.argtypes = [vp, vp, vp]; L.gs_model_view_matrix.restype = None
     L.gs_projection_matrix.argtypes = [vp, vp]; L.gs_projection_matrix.restype = None
@@ -275,6 +277,14 @@ class Context:
     def frame_stream(self):
         """hipStream_t (as an int) of the lane the current frame was enqueued on."""
         return int(self._L.gs_frame_stream(self._h) or 0)
+
+    def frame_lane(self):
+        """Index of the pipeline lane the current frame went to (no waiting)."""
+        return int(self._L.gs_frame_lane(self._h))
+
+    def lane_stream(self, lane):
+        """hipStream_t of a lane, once its worker thread has enqueued everything handed to it so far."""
+        return int(self._L.gs_lane_stream(self._h, int(lane)) or 0)
 
     def wait_stream(self, stream_ptr):
         """The next frame starts (on the GPU) only after everything queued on the given hipStream_t so far."""

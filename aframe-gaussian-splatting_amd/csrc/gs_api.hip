@@ -855,6 +855,15 @@ GS_API int gs_wait_stream(gs_ctx *ctx, void *hip_stream)
     return GS_OK;
 }
 
+GS_API int gs_frame_lane(gs_ctx *ctx) { return ctx ? ctx->cur : -1; }
+
+GS_API void *gs_lane_stream(gs_ctx *ctx, int lane)
+{
+    if (!ctx || lane < 0 || lane >= GS_MAX_LANES || !ctx->lanes[lane]) return nullptr;
+    (void)lane_drain(ctx->lanes[lane]);                          // everything handed to the lane so far is in its stream
+    return (void *)ctx->lanes[lane]->stream;
+}
+
 GS_API int gs_stream_wait_frame(gs_ctx *ctx, void *hip_stream)
 {
     CHECK_CTX(ctx);

@@ -75,10 +75,6 @@ def main():
     rows = synth.make_splat_rows(n_splats)
     ctx = capi.Context(local_rank)
     ctx.push_splat(rows)
-    if multi:
-        # the gather is queued on the frame's lane stream right after the frame, so this thread needs the frame's kernels
-        # enqueued when gs_render_device returns: no enqueue worker threads here
-        ctx.set_option(capi.OPT_ENQUEUE_THREADS, 0)
 
     # tile-aligned column strips
     x0, x1 = mg.strip_bounds(W, world, rank)
@@ -88,18 +84,30 @@ def main():
     params = [capi.make_params(c["gs_mv"], c["gs_proj"], W, H, x0=x0, x1=x1, focal_=c["focal"]) for c in cams]
     strip = None
     LANES = 3                                                # frames in flight (the library's default pipeline depth)
-    strips, gathereds, lane_streams = [], [], {}
+    LAG = 2                                                  # a frame's gather is queued after LAG more frames were handed over
+    strips, gathereds, lane_streams, owed = [], [], {}, []
     if multi:
         # One strip buffer per frame in flight.  The RCCL gather of a frame is queued on the SAME stream as the frame's
-        # kernels (gs_frame_stream: the library's pipeline lane, wrapped as a torch ExternalStream; c10d runs a blocking-
-        # style collective on the current stream), so it is ordered after the blend and before the frame that reuses the
-        # lane and the buffer -- no cross-stream event anywhere (each one stalls the pipeline for ~50 us here), and the
-        # gather of frame k overlaps the sort/render of frames k+1, k+2 on the other lanes.
+        # kernels (the library's pipeline lane, wrapped as a torch ExternalStream; c10d runs a blocking-style collective on
+        # the current stream), so it is ordered after the blend and before the frame that reuses the lane and the buffer --
+        # no cross-stream event anywhere (each one stalls the pipeline for ~50 us here), and the gather of frame k overlaps
+        # the sort/render of frames k+1, k+2 on the other lanes.  The lane's worker thread enqueues the frame; this thread
+        # queues the gather of frame k-LAG after handing over frame k, when that worker has long finished (LAG < LANES, so
+        # the gather still precedes the next frame of its lane).
         for _ in range(LANES):
             strips.append(torch.zeros(mg.strip_buffer_bytes(W, H, world), dtype=torch.uint8, device="cuda"))   # tight H x sw x 4 rows
             gathereds.append([torch.zeros_like(strips[-1]) for _ in range(world)] if rank == 0 else None)
         strip = strips[0]
     last_frame = [None]
+
+    def gather_owed(keep):
+        while len(owed) > keep:
+            lane, b = owed.pop(0)
+            sp = ctx.lane_stream(lane)
+            if sp not in lane_streams:
+                lane_streams[sp] = torch.cuda.ExternalStream(sp)
+            with torch.cuda.stream(lane_streams[sp]):
+                last_frame[0] = mg.gather_strips(strips[b], W, H, dist, gathereds[b])   # RCCL gather + row-major frame on rank 0
 
     def frame(i, flags=0):
         k = i % ORBIT_FRAMES
@@ -111,16 +119,15 @@ def main():
             return
         b = i % LANES
         ctx.render_device(p, strips[b].data_ptr())
-        sp = ctx.frame_stream()
-        if sp not in lane_streams:
-            lane_streams[sp] = torch.cuda.ExternalStream(sp)
-        with torch.cuda.stream(lane_streams[sp]):
-            last_frame[0] = mg.gather_strips(strips[b], W, H, dist, gathereds[b])   # RCCL gather + row-major frame on rank 0
+        owed.append((ctx.frame_lane(), b))
+        gather_owed(LAG if (flags & capi.RENDER_ASYNC) else 0)
 
     def sync():
         """Drain the stream; True if the library asks for the frames since the last sync to be rendered again
         (GS_E_RETRY) -- agreed on by all ranks so that their control flow stays identical."""
         need = 0
+        if multi:
+            gather_owed(0)
         try:
             ctx.sync()                                       # collects status/statistics of the asynchronous frames
         except capi.GsError as e:
@@ -154,6 +161,7 @@ def main():
     staged_per_frame = None
     if rank == 0:
         if multi:                                            # no gather may still be reading the strip buffers
+            gather_owed(0)
             torch.cuda.synchronize()
         ctx.set_option(capi.OPT_RECORD_STAGED, 1)
         ctx.set_option(capi.OPT_NEAR_PERMILLE, 1000)
@@ -220,6 +228,14 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # self-check of the N > 1 path: the frame assembled from the gathered strips of the LAST frame must equal, bit for bit,
+    # the full frame rank 0 renders alone for the same pose (the splat buffer is replicated, strips are tile-aligned)
+    frame_check = None
+    if multi and rank == 0 and last_frame[0] is not None:
+        k_last = (args.warmup + args.steps - 1) % ORBIT_FRAMES
+        ctx.sort(cams[k_last]["view"], cams[k_last]["cutout"], want_indices=False)
+        full = ctx.render(capi.make_params(cams[k_last]["gs_mv"], cams[k_last]["gs_proj"], W, H, focal_=cams[k_last]["focal"]))
+        frame_check = bool(np.array_equal(last_frame[0].cpu().numpy(), full))
     copy_peak = measured_copy_peak(ctx, capi) if rank == 0 else None
     total_frags = sum(frags[(args.warmup + i) % ORBIT_FRAMES] for i in range(args.steps))
     if rank == 0:
@@ -252,7 +268,7 @@ def main():
             "config": {"workload": "train.splat-shaped synthetic, N=%d splats, %dx%d, 120-frame orbit (%s)" % (
                            n_splats, W, H, "cutout-demo.html:22-24 pose + cutoutEntity box" if args.cutout else "index.html:13 pose"),
                        "parallelism": "column strips x%d, splat buffer replicated, RCCL gather" % world if world > 1 else "single GPU",
-                       "strip_px": sw,
+                       "strip_px": sw, "gathered_frame_equals_single_gpu_render": frame_check,
                        "frames_in_flight": "3 (the library's pipeline lanes: every frame still runs its own full sort, projection, "
                                            "binning and blend; consecutive frames overlap on the GPU)"},
             "occlusion_binning": {"near_permille": s["near_permille"], "unsat_tiles_last_frame": s["unsat_tiles"],

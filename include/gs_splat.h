@@ -154,6 +154,12 @@ GS_API int gs_set_stream(gs_ctx *ctx, void *hip_stream);
  * collective over the frame's device_rgba, a copy -- is ordered after the frame and before the frame that will reuse
  * this lane, without any cross-stream event (those cost ~50 us of pipeline stall each on this platform). */
 GS_API void *gs_frame_stream(gs_ctx *ctx);
+/* The same in two steps, for callers that want to keep enqueuing: gs_frame_lane() names the lane of the current frame
+ * (no waiting); gs_lane_stream() returns that lane's stream once its worker thread has enqueued everything handed to
+ * the lane so far.  Queuing the follow-up work of frame k only after frame k+1 (or k+2) has been handed over keeps the
+ * caller from waiting for the worker; it must still be queued before the lane is given its next frame. */
+GS_API int gs_frame_lane(gs_ctx *ctx);
+GS_API void *gs_lane_stream(gs_ctx *ctx, int lane);
 GS_API int gs_wait_stream(gs_ctx *ctx, void *hip_stream);
 GS_API int gs_stream_wait_frame(gs_ctx *ctx, void *hip_stream);
 
