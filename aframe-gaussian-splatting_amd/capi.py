@@ -65,7 +65,8 @@ def load(build_if_missing=True):
         if not build_if_missing:
             raise FileNotFoundError(_build.LIB + " not built; run __graft_entry__.build()")
         _build.build_lib()
-    L = C.CDLL(_build.LIB)
+    # GS_SPLAT_LIB: load another build of the same library (A/B measurements of kernel variants); never a different backend
+    L = C.CDLL(os.environ.get("GS_SPLAT_LIB") or _build.LIB)
     vp, sz, i32, u32p, f32 = C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_uint32), C.c_float
     L.gs_create.argtypes = [i32, C.POINTER(vp)]
     L.gs_destroy.argtypes = [vp]
