@@ -218,7 +218,9 @@ __global__ __launch_bounds__(GS_BLOCK) void k_pairs_check(GsControl *ctl, uint32
 // offset array ever goes to memory.  Splats touching few tiles are written by their own lane; the few screen-filling
 // ones (thousands of tiles each) are queued in LDS and expanded by a whole wavefront, one lane per tile row.
 // ROUND 1 writes only the tiles whose bit is set in the unsaturated-tile mask.
+#ifndef GS_EMIT_BIG
 #define GS_EMIT_BIG 32u
+#endif
 // one pair record: 8 bytes (tile, sorted position) or, when tile bits + position bits fit (jbits > 0), 4 bytes
 // (tile << jbits | position - j_lo): half the traffic through emit, both radix passes, the range pass and the blend
 template <bool P32>
@@ -360,7 +362,9 @@ __global__ __launch_bounds__(GS_BLOCK) void k_tile_ranges(const void *__restrict
 // list once its four pixels all have T < t_eps, the wave when every lane has (ballot); one rounding to RGBA8 at the end.
 // ROUND 0 starts from (T = 1, C = 0); a tile that is not saturated when its list ends saves its per-pixel state and
 // sets its bit in the tile mask (if a round 1 follows).  ROUND 1 runs only for masked tiles and resumes from the state.
+#ifndef GS_BLEND_BATCH
 #define GS_BLEND_BATCH 64
+#endif
 typedef float f2 __attribute__((ext_vector_type(2)));            // two pixels per packed-fp32 instruction (v_pk_*_f32)
 __device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
 
