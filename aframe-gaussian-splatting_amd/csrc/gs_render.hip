@@ -451,19 +451,27 @@ __global__ __launch_bounds__(64) void k_blend(const uint2 *__restrict__ tile_ran
             // dependent chain overlaps the first one's (the per-step latency, not issue bandwidth, bounds a tile that
             // runs alone in the kernel's tail).  Blending is still applied strictly in list order.
             uint32_t s = 0;
-            for (; s < nb; s += 2) {
+#ifndef GS_BLEND_SPLATS_PER_STEP
+#define GS_BLEND_SPLATS_PER_STEP 2
+#endif
+            for (; s < nb; s += GS_BLEND_SPLATS_PER_STEP) {
                 const float4 a0 = s_rec[2 * s], b0 = s_rec[2 * s + 1];
-                const float4 a1 = s_rec[2 * s + 2], b1 = s_rec[2 * s + 3];     // slot nb holds an inert record when nb is odd
-                const float dy0 = fy - a0.y, dy1 = fy - a1.y;
-                const float dyay0 = dy0 * a0.w, dyby0 = dy0 * b0.y, dyay1 = dy1 * a1.w, dyby1 = dy1 * b1.y;
+                const float dy0 = fy - a0.y;
+                const float dyay0 = dy0 * a0.w, dyby0 = dy0 * b0.y;
                 // |p|^2 of the interpolated vPosition, same expression tree per pixel as gsm::frag_power
-                const f2 dxA0 = fxA - a0.x, dxB0 = fxB - a0.x, dxA1 = fxA - a1.x, dxB1 = fxB - a1.x;
+                const f2 dxA0 = fxA - a0.x, dxB0 = fxB - a0.x;
                 const f2 pxA0 = fma2(dxA0, (f2)(a0.z), (f2)(dyay0)), pxB0 = fma2(dxB0, (f2)(a0.z), (f2)(dyay0));
                 const f2 pyA0 = fma2(dxA0, (f2)(b0.x), (f2)(dyby0)), pyB0 = fma2(dxB0, (f2)(b0.x), (f2)(dyby0));
+                const f2 qA0 = fma2(pxA0, pxA0, pyA0 * pyA0), qB0 = fma2(pxB0, pxB0, pyB0 * pyB0);   // -A, index.js:171
+#if GS_BLEND_SPLATS_PER_STEP == 2
+                const float4 a1 = s_rec[2 * s + 2], b1 = s_rec[2 * s + 3];     // slot nb holds an inert record when nb is odd
+                const float dy1 = fy - a1.y;
+                const float dyay1 = dy1 * a1.w, dyby1 = dy1 * b1.y;
+                const f2 dxA1 = fxA - a1.x, dxB1 = fxB - a1.x;
                 const f2 pxA1 = fma2(dxA1, (f2)(a1.z), (f2)(dyay1)), pxB1 = fma2(dxB1, (f2)(a1.z), (f2)(dyay1));
                 const f2 pyA1 = fma2(dxA1, (f2)(b1.x), (f2)(dyby1)), pyB1 = fma2(dxB1, (f2)(b1.x), (f2)(dyby1));
-                const f2 qA0 = fma2(pxA0, pxA0, pyA0 * pyA0), qB0 = fma2(pxB0, pxB0, pyB0 * pyB0);   // -A, index.js:171
                 const f2 qA1 = fma2(pxA1, pxA1, pyA1 * pyA1), qB1 = fma2(pxB1, pxB1, pyB1 * pyB1);
+#endif
 #define GS_BLEND_APPLY(qA, qB, bb, zz)                                                                                 \
                 {                                                                                                      \
                     bool p0 = qA.x <= qmA.x, p1 = qA.y <= qmA.y, p2 = qB.x <= qmB.x, p3 = qB.y <= qmB.y;               \
@@ -487,13 +495,16 @@ __global__ __launch_bounds__(64) void k_blend(const uint2 *__restrict__ tile_ran
                         live = GS_LANE_LIVE();                                                                         \
                     }                                                                                                  \
                 }
-                const float z0 = SCENE ? s_z[s] : 0.0f, z1 = SCENE ? s_z[s + 1] : 0.0f;
+                const float z0 = SCENE ? s_z[s] : 0.0f;
                 GS_BLEND_APPLY(qA0, qB0, b0, z0)
+#if GS_BLEND_SPLATS_PER_STEP == 2
+                const float z1 = SCENE ? s_z[s + 1] : 0.0f;
                 GS_BLEND_APPLY(qA1, qB1, b1, z1)
+#endif
 #undef GS_BLEND_APPLY
                 if (!live) break;
             }
-            if (u.record_staged == 2) evaluated += min(s + 2, nb);   // list entries this lane evaluated (measurement aid)
+            if (u.record_staged == 2) evaluated += min(s + GS_BLEND_SPLATS_PER_STEP, nb);   // list entries this lane evaluated (measurement aid)
         }
         end -= nb;
         __syncthreads();                                           // s_rec is rewritten by the next batch
