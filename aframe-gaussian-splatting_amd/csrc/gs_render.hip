@@ -251,8 +251,8 @@ __global__ __launch_bounds__(GS_BLOCK) void k_emit(const gsm::Projected *__restr
                                                    GsFrameUniforms u, void *__restrict__ pairs, const uint32_t *__restrict__ mask,
                                                    const GsControl *ctl)
 {
-    __shared__ uint32_t s_big[GS_BLOCK], s_bigoff[GS_BLOCK];
-    __shared__ uint32_t s_nbig, s_wave[4];
+    __shared__ uint32_t s_big[GS_BLOCK], s_bigoff[GS_BLOCK], s_mid[GS_BLOCK], s_midoff[GS_BLOCK];
+    __shared__ uint32_t s_nbig, s_nmid, s_wave[4];
     if (ctl->pair_overflow) return;
     const uint32_t j_lo = ctl->j_lo, j_hi = ctl->j_hi;               // set by k_pairs_check of this round
     const uint32_t nchunks = (j_hi - j_lo + GS_BLOCK - 1) / GS_BLOCK;
@@ -261,7 +261,7 @@ __global__ __launch_bounds__(GS_BLOCK) void k_emit(const gsm::Projected *__restr
     for (uint32_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
         uint32_t carry = spine[c];
         {
-            if (threadIdx.x == 0) s_nbig = 0;
+            if (threadIdx.x == 0) { s_nbig = 0; s_nmid = 0; }
             const uint32_t j = j_lo + c * GS_BLOCK + threadIdx.x;
             const uint32_t cnt = j < j_hi ? tile_count[j] : 0u;
             const uint32_t inc = wave_incl_scan_u32(cnt, lane);
@@ -273,8 +273,11 @@ __global__ __launch_bounds__(GS_BLOCK) void k_emit(const gsm::Projected *__restr
             uint32_t o = carry + wbase + inc - cnt;                  // this splat's first pair slot
             carry += total;
             if (cnt >= GS_EMIT_BIG) {
-                const uint32_t q = atomicAdd(&s_nbig, 1u);
-                s_big[q] = j; s_bigoff[q] = o;
+                // many tiles: expanded cooperatively, one lane per tile row -- by 16 lanes when the splat spans at most 16
+                // tile rows (four splats per wavefront pass), by a whole wavefront otherwise
+                const uint2 rc = rect[j];
+                if ((rc.y >> 16) - (rc.x >> 16) < 16u) { const uint32_t q = atomicAdd(&s_nmid, 1u); s_mid[q] = j; s_midoff[q] = o; }
+                else { const uint32_t q = atomicAdd(&s_nbig, 1u); s_big[q] = j; s_bigoff[q] = o; }
             } else if (cnt) {
                 const float4 *src = reinterpret_cast<const float4 *>(proj + j);
                 const float4 a = src[0], b = src[1];
@@ -289,6 +292,31 @@ __global__ __launch_bounds__(GS_BLOCK) void k_emit(const gsm::Projected *__restr
                 }
             }
             __syncthreads();
+            const uint32_t nmid = s_nmid;
+            for (uint32_t mi = (uint32_t)w * 4u + ((uint32_t)lane >> 4); mi < ((nmid + 15u) & ~15u); mi += 16u) {   // 16 lanes per splat
+                const bool have = mi < nmid;
+                const uint32_t jm = have ? s_mid[mi] : 0u;
+                uint32_t t0 = 0, n = 0, nm = 0, ty = 0;
+                bool row_ok = false;
+                if (have) {
+                    const float4 *src = reinterpret_cast<const float4 *>(proj + jm);
+                    const float4 a = src[0], b = src[1];
+                    gsm::Projected p; p.cx = a.x; p.cy = a.y; p.ax = a.z; p.ay = a.w; p.bx = b.x; p.by = b.y;
+                    gsm::EllipseRows e;
+                    gsm::ellipse_rows_setup(p, e);
+                    const uint2 rc = rect[jm];
+                    ty = (rc.x >> 16) + ((uint32_t)lane & 15u);
+                    row_ok = ty <= (rc.y >> 16);
+                    if (row_ok) {
+                        gsm::splat_tile_row(p, e, (int)ty, u.H, u.x0, u.x1, t0, n);
+                        nm = (ROUND == 1 && n) ? mask_count(mask + ty * u.mask_words, t0, n) : n;
+                    }
+                }
+                uint32_t rinc = nm;                                  // inclusive scan inside the 16-lane group
+#pragma unroll
+                for (int d = 1; d < 16; d <<= 1) { const uint32_t t = __shfl_up(rinc, d, 16); if ((lane & 15) >= d) rinc += t; }
+                if (row_ok) emit_run<ROUND, P32>(pairs, s_midoff[mi] + rinc - nm, ty, tiles_x, t0, n, jm, jm - j_lo, u.pair_jbits, mask + ty * u.mask_words);
+            }
             const uint32_t nbig = s_nbig;
             for (uint32_t bi = w; bi < nbig; bi += 4) {              // one wavefront per big splat
                 const uint32_t jb = s_big[bi];
