@@ -78,14 +78,14 @@ __global__ __launch_bounds__(GS_BLOCK) void k_project(const uint32_t *__restrict
 {
     __shared__ float s_rec[GS_BLOCK][6];
     __shared__ uint32_t s_rows[GS_BLOCK], s_j[GS_BLOCK];
-    __shared__ uint32_t s_nbig, s_vis, s_sum;
+    __shared__ uint32_t s_nbig, s_nmid, s_vis, s_sum;
     uint32_t j_lo, j_hi;
     round_range<ROUND>(ctl, u.near_count, j_lo, j_hi);
     const uint32_t nchunks = (j_hi - j_lo + GS_BLOCK - 1) / GS_BLOCK;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     if (threadIdx.x == 0) s_vis = 0;
     for (uint32_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
-        if (threadIdx.x == 0) { s_sum = 0; s_nbig = 0; }
+        if (threadIdx.x == 0) { s_sum = 0; s_nbig = 0; s_nmid = 0; }
         __syncthreads();
         const uint32_t j = j_lo + c * GS_BLOCK + threadIdx.x;
         uint32_t count = 0;
@@ -112,8 +112,10 @@ __global__ __launch_bounds__(GS_BLOCK) void k_project(const uint32_t *__restrict
                     dst[0] = make_float4(p.cx, p.cy, p.ax, p.ay);
                     dst[1] = make_float4(p.bx, p.by, __uint_as_float(p.rgba), p.alpha);
                     if (u.has_depth) zwin[j] = x.zndc * 0.5f + 0.5f;           // gl_FragCoord.z of every fragment of the quad
-                    if (ty1 - ty0 >= 16) {                                  // > 16 tile rows: count cooperatively
-                        const uint32_t q = atomicAdd(&s_nbig, 1u);
+                    if (ty1 - ty0 >= 2) {
+                        // three or more tile rows: counted cooperatively, one lane per row -- by 16-lane groups up to 16 rows
+                        // (queued from the front), by a whole wavefront beyond (queued from the back of the same arrays)
+                        const uint32_t q = (ty1 - ty0 >= 16) ? (GS_BLOCK - 1u - atomicAdd(&s_nbig, 1u)) : atomicAdd(&s_nmid, 1u);
                         s_rec[q][0] = p.cx; s_rec[q][1] = p.cy; s_rec[q][2] = p.ax; s_rec[q][3] = p.ay; s_rec[q][4] = p.bx; s_rec[q][5] = p.by;
                         s_rows[q] = ty0 | (ty1 << 16); s_j[q] = j;
                         queued = true;
@@ -134,8 +136,28 @@ __global__ __launch_bounds__(GS_BLOCK) void k_project(const uint32_t *__restrict
         }
         uint32_t vis = count ? 1u : 0u, sum = count;
         __syncthreads();
+        const uint32_t nmid = s_nmid;
+        for (uint32_t mi = (uint32_t)w * 4u + ((uint32_t)lane >> 4); mi < ((nmid + 15u) & ~15u); mi += 16u) {   // 16 lanes per splat
+            uint32_t n = 0;
+            if (mi < nmid) {
+                gsm::Projected p;
+                p.cx = s_rec[mi][0]; p.cy = s_rec[mi][1]; p.ax = s_rec[mi][2]; p.ay = s_rec[mi][3]; p.bx = s_rec[mi][4]; p.by = s_rec[mi][5];
+                gsm::EllipseRows e;
+                gsm::ellipse_rows_setup(p, e);
+                const uint32_t ty = (s_rows[mi] & 0xFFFF) + ((uint32_t)lane & 15u);
+                if (ty <= (s_rows[mi] >> 16)) {
+                    uint32_t a;
+                    gsm::splat_tile_row(p, e, (int)ty, u.H, u.x0, u.x1, a, n);
+                    if (ROUND == 1 && n) n = mask_count(mask + ty * u.mask_words, a, n);
+                }
+            }
+#pragma unroll
+            for (int m = 8; m >= 1; m >>= 1) n += __shfl_xor(n, m, 16);
+            if ((lane & 15) == 0 && mi < nmid) { tile_count[s_j[mi]] = n; sum += n; if (n) vis++; }
+        }
         const uint32_t nbig = s_nbig;
-        for (uint32_t bi = w; bi < nbig; bi += 4) {                   // one wavefront per queued splat
+        for (uint32_t bq = w; bq < nbig; bq += 4) {                   // one wavefront per queued splat of more than 16 tile rows
+            const uint32_t bi = GS_BLOCK - 1u - bq;
             gsm::Projected p;
             p.cx = s_rec[bi][0]; p.cy = s_rec[bi][1]; p.ax = s_rec[bi][2]; p.ay = s_rec[bi][3]; p.bx = s_rec[bi][4]; p.by = s_rec[bi][5];
             gsm::EllipseRows e;
