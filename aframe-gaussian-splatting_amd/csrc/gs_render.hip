@@ -15,7 +15,7 @@
 // Occlusion-aware binning in two rounds.  Front-to-back blending stops a pixel at T < eps, so whatever lies behind a
 // saturated tile is never read -- in the benchmark scene 81 % of the (tile, splat) records.  Round 0 therefore bins
 // and blends only the NEAREST `near_count` splats of the sorted order; tiles in which every pixel terminated are
-// final.  Tiles that did not saturate keep their exact fp32 per-pixel state (T, premultiplied RGBA) and set a bit in
+// final.  Tiles that did not saturate keep their exact fp32 per-pixel state (T, premultiplied RGB) and set a bit in
 // a tile mask; round 1 bins the remaining (farther) splats against the masked tiles only and continues those tiles
 // from the saved state.  The arithmetic per pixel is the same sequence of operations as a single pass, so the
 // result is bit-identical; only work that could not contribute is skipped.  When no tile is left unsaturated the
@@ -442,7 +442,7 @@ __global__ __launch_bounds__(64) void k_blend(const uint2 *__restrict__ tile_ran
     const float fy = (float)(u.H - 1 - r) + 0.5f;                  // pixel centre, GL window coordinates
     const bool no_early = COUNT || (u.flags & GS_RENDER_NO_EARLY_OUT);
     const float t_eps = no_early ? -1.0f : u.t_eps;                // T < t_eps never holds when early-out is off
-    // per pixel pair: x centre, transmittance, premultiplied colour/alpha, and the coverage threshold qmax:
+    // per pixel pair: x centre, transmittance, premultiplied colour (alpha is 1 - T), and the coverage threshold qmax:
     // 4 while the pixel is live (fragment kept iff q <= 4, index.js:172), -1 once it is outside / terminated
     f2 fxA = { (float)xb + 0.5f, (float)(xb + 1) + 0.5f }, fxB = { (float)(xb + 2) + 0.5f, (float)(xb + 3) + 0.5f };
     // qm: coverage threshold, 4 inside the strip (fragment kept iff q <= 4, index.js:172), -1 for pixels outside it (never
