@@ -442,8 +442,7 @@ __global__ __launch_bounds__(64) void k_blend(const uint2 *__restrict__ tile_ran
     const float fy = (float)(u.H - 1 - r) + 0.5f;                  // pixel centre, GL window coordinates
     const bool no_early = COUNT || (u.flags & GS_RENDER_NO_EARLY_OUT);
     const float t_eps = no_early ? -1.0f : u.t_eps;                // T < t_eps never holds when early-out is off
-    // per pixel pair: x centre, transmittance, premultiplied colour (alpha is 1 - T), and the coverage threshold qmax:
-    // 4 while the pixel is live (fragment kept iff q <= 4, index.js:172), -1 once it is outside / terminated
+    // per pixel pair: x centre, transmittance, premultiplied colour (alpha is 1 - T)
     f2 fxA = { (float)xb + 0.5f, (float)(xb + 1) + 0.5f }, fxB = { (float)(xb + 2) + 0.5f, (float)(xb + 3) + 0.5f };
     // qm: coverage threshold, 4 inside the strip (fragment kept iff q <= 4, index.js:172), -1 for pixels outside it (never
     // covered, never written; their T starts at 0 so that they do not keep the lane alive)
