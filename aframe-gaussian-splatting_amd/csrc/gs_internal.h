@@ -10,7 +10,11 @@
 // ---------------------------------------------------------------- geometry of the work decomposition
 #define GS_TILE 16                 // screen tile edge (pixels): 16x16 = one 256-thread workgroup
 #define GS_BLOCK 256               // threads per workgroup everywhere (4 wavefronts of 64)
-#define GS_CHUNK 2048              // items per workgroup pass in streaming kernels (8 per thread)
+#ifndef GS_CHUNK
+#define GS_CHUNK 2048              // items per workgroup pass in streaming kernels
+#endif
+#define GS_IPT (GS_CHUNK / GS_BLOCK) // items per thread and pass
+#define GS_SCAN_TILE 2048          // values per pass of the one-workgroup-per-row scan (8 per thread)
 #define GS_RADIX_MAX_BINS 512      // up to 9-bit digits (depth key = 17 bits = 8 + 9)
 #define GS_PROF_RING 256           // frames of HIP-event timings kept in flight
 #define GS_PROF_EVENTS 7

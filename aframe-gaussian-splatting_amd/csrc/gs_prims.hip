@@ -49,7 +49,7 @@ __global__ __launch_bounds__(GS_BLOCK) void k_radix_hist(const uint32_t *__restr
         for (uint32_t d = threadIdx.x; d < nbins; d += GS_BLOCK) s_hist[d] = 0;
         __syncthreads();
 #pragma unroll
-        for (int r = 0; r < 8; r++) {
+        for (int r = 0; r < GS_IPT; r++) {
             const uint32_t i = c * GS_CHUNK + r * GS_BLOCK + threadIdx.x;
             if (i < n) atomicAdd(&s_hist[(keys[PACKED ? 2 * (size_t)i : i] >> shift) & mask], 1u);
         }
@@ -68,7 +68,7 @@ __global__ __launch_bounds__(GS_BLOCK) void k_radix_rowscan(uint32_t *__restrict
     const uint32_t nchunks = (n + GS_CHUNK - 1) / GS_CHUNK;
     uint32_t *row = hist + (size_t)blockIdx.x * nchunks;
     uint32_t carry = 0;
-    for (uint32_t base = 0; base < nchunks; base += GS_CHUNK) {
+    for (uint32_t base = 0; base < nchunks; base += GS_SCAN_TILE) {
         const uint32_t i0 = base + threadIdx.x * 8;
         uint32_t v[8], sum = 0;
 #pragma unroll
@@ -82,7 +82,7 @@ __global__ __launch_bounds__(GS_BLOCK) void k_radix_rowscan(uint32_t *__restrict
     if (threadIdx.x == 0) totals[blockIdx.x] = carry;
 }
 
-// Stable scatter.  Item order inside a chunk: wave w owns items [w*512, w*512+512), processed in 8 rounds
+// Stable scatter.  Item order inside a chunk: wave w owns a quarter of the chunk (512 items at GS_CHUNK = 2048), processed in GS_IPT rounds
 // of 64 consecutive items (lane = item % 64), so "earlier" == (wave, round, lane) lexicographic.
 // Rank among equal digits: in-round via ballot match (one ballot per digit bit), across rounds via a
 // wave-private LDS counter row, across waves via a 4-way prefix.  The chunk is then REORDERED IN LDS into digit
@@ -120,10 +120,10 @@ __global__ __launch_bounds__(GS_BLOCK) void k_radix_scatter(const void *__restri
     for (uint32_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
         for (uint32_t i = threadIdx.x; i < 4 * GS_RADIX_MAX_BINS; i += GS_BLOCK) (&s_cnt[0][0])[i] = 0;
         __syncthreads();
-        uint32_t key[8], val[8], rank[8];
+        uint32_t key[GS_IPT], val[GS_IPT], rank[GS_IPT];
 #pragma unroll
-        for (int r = 0; r < 8; r++) {
-            const uint32_t i = c * GS_CHUNK + w * 512 + r * 64 + lane;
+        for (int r = 0; r < GS_IPT; r++) {
+            const uint32_t i = c * GS_CHUNK + w * (GS_CHUNK / 4) + r * 64 + lane;
             const bool ok = i < n;
             if (IN_FMT == GS_RADIX_PACKED) {
                 const uint2 kv = ok ? reinterpret_cast<const uint2 *>(in)[i] : make_uint2(0xFFFFFFFFu, 0u);
@@ -167,8 +167,8 @@ __global__ __launch_bounds__(GS_BLOCK) void k_radix_scatter(const void *__restri
         }
         __syncthreads();
 #pragma unroll
-        for (int r = 0; r < 8; r++) {
-            const uint32_t i = c * GS_CHUNK + w * 512 + r * 64 + lane;
+        for (int r = 0; r < GS_IPT; r++) {
+            const uint32_t i = c * GS_CHUNK + w * (GS_CHUNK / 4) + r * 64 + lane;
             if (i < n) {
                 const uint32_t d = (key[r] >> shift) & mask;
                 s_kv[s_cnt[w][d] + rank[r]] = make_uint2(key[r], val[r]);
@@ -177,7 +177,7 @@ __global__ __launch_bounds__(GS_BLOCK) void k_radix_scatter(const void *__restri
         __syncthreads();
         const uint32_t items = min((uint32_t)GS_CHUNK, n - c * GS_CHUNK);
 #pragma unroll
-        for (int r = 0; r < 8; r++) {
+        for (int r = 0; r < GS_IPT; r++) {
             const uint32_t slot = r * GS_BLOCK + threadIdx.x;
             if (slot < items) {
                 const uint2 kv = s_kv[slot];

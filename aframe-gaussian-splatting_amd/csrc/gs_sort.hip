@@ -35,7 +35,7 @@ __global__ __launch_bounds__(GS_BLOCK) void k_sort_depth(const float4 *__restric
     uint32_t cnt = 0;
     for (uint32_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
 #pragma unroll
-        for (int r = 0; r < 8; r++) {
+        for (int r = 0; r < GS_IPT; r++) {
             const uint32_t i = c * GS_CHUNK + r * GS_BLOCK + threadIdx.x;
             if (i < n) {
                 const float4 m = rows[i];
@@ -97,7 +97,7 @@ __global__ __launch_bounds__(GS_BLOCK) void k_sort_bucket(const float *__restric
         s_hist[threadIdx.x] = 0;
         __syncthreads();
 #pragma unroll
-        for (int r = 0; r < 8; r++) {
+        for (int r = 0; r < GS_IPT; r++) {
             const uint32_t i = c * GS_CHUNK + r * GS_BLOCK + threadIdx.x;
             if (i < n) {
                 const float d = depth[i];
