@@ -170,6 +170,7 @@ static inline uint32_t gs_div_up(uint64_t a, uint64_t b) { return (uint32_t)((a 
 #define GS_RADIX_KEYS 0
 #define GS_RADIX_PACKED 1
 #define GS_RADIX_KEYONLY 2
+#define GS_RADIX_SKIP 0xFFFFFFFFu   // GS_RADIX_KEYS input only: a record with this key is neither counted nor scattered (compaction)
 int gs_launch_radix_pass(gs_ctx *ctx, const void *in, int in_fmt, void *out, int out_fmt, const uint32_t *n_ptr,
                          uint32_t max_n, int shift, int bits, bool have_hist = false, uint32_t zero_key = 0xFFFFFFFFu);
 // grid used by the radix kernels for max_n items (a producer that pre-fills the histogram must use the same chunking)

@@ -124,7 +124,7 @@ __global__ __launch_bounds__(GS_BLOCK) void k_radix_scatter(const void *__restri
 #pragma unroll
         for (int r = 0; r < GS_IPT; r++) {
             const uint32_t i = c * GS_CHUNK + w * (GS_CHUNK / 4) + r * 64 + lane;
-            const bool ok = i < n;
+            bool ok = i < n;
             if (IN_FMT == GS_RADIX_PACKED) {
                 const uint2 kv = ok ? reinterpret_cast<const uint2 *>(in)[i] : make_uint2(0xFFFFFFFFu, 0u);
                 key[r] = kv.x; val[r] = kv.y;
@@ -133,6 +133,7 @@ __global__ __launch_bounds__(GS_BLOCK) void k_radix_scatter(const void *__restri
                 val[r] = i;
             }
             const uint32_t d = (key[r] >> shift) & mask;
+            if (IN_FMT == GS_RADIX_KEYS) ok = ok && key[r] != GS_RADIX_SKIP;   // compaction: skipped records take no slot
             unsigned long long peers = __ballot(ok);
             for (int b = 0; b < bits; b++) {
                 const bool bit = (d >> b) & 1u;
@@ -147,6 +148,7 @@ __global__ __launch_bounds__(GS_BLOCK) void k_radix_scatter(const void *__restri
             rank[r] = prev + before;
         }
         __syncthreads();
+        uint32_t chunk_items;                                        // records of this chunk that take a slot
         {   // digit totals of the chunk -> local digit starts (exclusive scan over digits, 2 per thread)
             const uint32_t d0 = threadIdx.x * 2;
             uint32_t t0 = 0, t1 = 0;
@@ -154,6 +156,7 @@ __global__ __launch_bounds__(GS_BLOCK) void k_radix_scatter(const void *__restri
             if (d0 + 1 < nbins) t1 = s_cnt[0][d0 + 1] + s_cnt[1][d0 + 1] + s_cnt[2][d0 + 1] + s_cnt[3][d0 + 1];
             uint32_t tot;
             const uint32_t ex = block_excl_scan(t0 + t1, s_wave, &tot);      // (two barriers inside)
+            chunk_items = tot;
 #pragma unroll
             for (int k = 0; k < 2; k++) {
                 const uint32_t d = d0 + k;
@@ -169,13 +172,13 @@ __global__ __launch_bounds__(GS_BLOCK) void k_radix_scatter(const void *__restri
 #pragma unroll
         for (int r = 0; r < GS_IPT; r++) {
             const uint32_t i = c * GS_CHUNK + w * (GS_CHUNK / 4) + r * 64 + lane;
-            if (i < n) {
+            if (i < n && (IN_FMT != GS_RADIX_KEYS || key[r] != GS_RADIX_SKIP)) {
                 const uint32_t d = (key[r] >> shift) & mask;
                 s_kv[s_cnt[w][d] + rank[r]] = make_uint2(key[r], val[r]);
             }
         }
         __syncthreads();
-        const uint32_t items = min((uint32_t)GS_CHUNK, n - c * GS_CHUNK);
+        const uint32_t items = chunk_items;
 #pragma unroll
         for (int r = 0; r < GS_IPT; r++) {
             const uint32_t slot = r * GS_BLOCK + threadIdx.x;

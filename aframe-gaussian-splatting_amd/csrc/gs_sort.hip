@@ -61,7 +61,7 @@ __global__ __launch_bounds__(GS_BLOCK) void k_sort_depth(const float4 *__restric
     if (threadIdx.x == 0) { part_min[blockIdx.x] = s_min; part_max[blockIdx.x] = s_max; part_cnt[blockIdx.x] = s_cnt; }
 }
 
-// pass 2 (index.js:558-561): 16-bit bucket of the stored depth; culled/dropped -> GS_CULLED_KEY.
+// pass 2 (index.js:558-561): 16-bit bucket of the stored depth; culled -> GS_RADIX_SKIP, dropped bucket -> GS_CULLED_KEY.
 // Every workgroup first folds pass 1's partials (<= 2048 slots, L2-resident) into the global min/max.
 __global__ __launch_bounds__(GS_BLOCK) void k_sort_bucket(const float *__restrict__ depth, uint32_t n, uint32_t *__restrict__ keys,
                                                           const unsigned long long *__restrict__ part_min,
@@ -100,14 +100,17 @@ __global__ __launch_bounds__(GS_BLOCK) void k_sort_bucket(const float *__restric
         for (int r = 0; r < GS_IPT; r++) {
             const uint32_t i = c * GS_CHUNK + r * GS_BLOCK + threadIdx.x;
             if (i < n) {
+                // culled splats leave the sort here: GS_RADIX_SKIP records are not counted and not scattered by pass A.
+                // Kept splats whose bucket falls outside the table (the reference drops their writes) carry GS_CULLED_KEY:
+                // they sort behind every bucket and store 0, the reference's never-written tail slots
                 const float d = depth[i];
-                uint32_t k = GS_CULLED_KEY;
+                uint32_t k = GS_RADIX_SKIP;
                 if (d != INFINITY) {
                     const int32_t b = gsm::sort_bucket(d, mn, inv);
-                    if (b >= 0) k = (uint32_t)b;
+                    k = b >= 0 ? (uint32_t)b : GS_CULLED_KEY;
+                    atomicAdd(&s_hist[k & 255u], 1u);
                 }
                 keys[i] = k;
-                atomicAdd(&s_hist[k & 255u], 1u);
             }
         }
         __syncthreads();
@@ -135,9 +138,9 @@ int gs_run_sort(gs_ctx *ctx, const float view[4], const float *cutout16)
     GS_HIP(hipGetLastError());
     int rc = gs_launch_radix_pass(ctx, ctx->key_a, GS_RADIX_KEYS, ctx->kv_b, GS_RADIX_PACKED, &ctx->ctl->n_total, n, 0, 8, /*have_hist=*/true);
     if (rc != GS_OK) return rc;
-    // culled / dropped splats (key 65536) sort behind every bucket and store 0: the tail [V',V) of the result is 0 like
-    // the reference's never-written Uint32Array slots
-    rc = gs_launch_radix_pass(ctx, ctx->kv_b, GS_RADIX_PACKED, ctx->val_a, GS_RADIX_KEYS, &ctx->ctl->n_total, n, 8, 9, false, GS_CULLED_KEY);
+    // pass A dropped the culled splats: V records are left.  Splats with a dropped bucket (key 65536) sort behind every
+    // bucket and store 0: the tail [V',V) of the result is 0 like the reference's never-written Uint32Array slots
+    rc = gs_launch_radix_pass(ctx, ctx->kv_b, GS_RADIX_PACKED, ctx->val_a, GS_RADIX_KEYS, &ctx->ctl->n_kept, n, 8, 9, false, GS_CULLED_KEY);
     if (rc != GS_OK) return rc;
     GS_PROF_RECORD(ctx, 1);
     ctx->sorted = ctx->val_a;
