@@ -323,6 +323,7 @@ static hipError_t init_frame_resources(gs_ctx *c)
     IFR(hipMalloc((void **)&c->part_cnt, GS_MAX_PART * sizeof(uint32_t)));
     IFR(hipMalloc((void **)&c->part_valid, GS_MAX_PART * sizeof(uint32_t)));
     IFR(hipMalloc((void **)&c->part_vis, GS_MAX_PART * sizeof(uint32_t)));
+    IFR(hipMalloc((void **)&c->huge_list, GS_HUGE_CAP * sizeof(uint32_t)));
     IFR(hipHostMalloc((void **)&c->ctl_host, sizeof(GsControl), hipHostMallocDefault));
     memset(c->ctl_host, 0, sizeof(GsControl));
     IFR(hipEventCreateWithFlags(&c->ev_frame, hipEventDisableTiming | hipEventReleaseToDevice));
@@ -340,7 +341,7 @@ static void free_frame_resources(gs_ctx *c)
     dev_free(c->proj); dev_free(c->rect); dev_free(c->tile_count); dev_free(c->zwin);
     dev_free(c->pair_a); dev_free(c->pair_b);
     dev_free(c->tile_range); dev_free(c->fb); dev_free(c->ctl); dev_free(c->state); dev_free(c->unsat_mask);
-    dev_free(c->part_min); dev_free(c->part_max); dev_free(c->part_cnt); dev_free(c->part_valid); dev_free(c->part_vis);
+    dev_free(c->part_min); dev_free(c->part_max); dev_free(c->part_cnt); dev_free(c->part_valid); dev_free(c->part_vis); dev_free(c->huge_list);
     if (c->ctl_host) { (void)hipHostFree(c->ctl_host); c->ctl_host = nullptr; }
     if (c->ring) { for (int i = 0; i < GS_PROF_RING * GS_PROF_EVENTS; i++) if (c->ring[i]) (void)hipEventDestroy(c->ring[i]); free(c->ring); c->ring = nullptr; }
     free(c->ring_flags); c->ring_flags = nullptr;

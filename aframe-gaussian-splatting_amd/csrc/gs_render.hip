@@ -74,8 +74,12 @@ __global__ __launch_bounds__(GS_BLOCK) void k_project(const uint32_t *__restrict
                                                       GsFrameUniforms u, gsm::Projected *__restrict__ proj, uint2 *__restrict__ rect,
                                                       uint32_t *__restrict__ tile_count, uint32_t *__restrict__ spine,
                                                       uint32_t *__restrict__ part_vis, const uint32_t *__restrict__ mask,
-                                                      float *__restrict__ zwin, const GsControl *ctl)
+                                                      float *__restrict__ zwin, GsControl *ctl, uint32_t *__restrict__ huge_list)
 {
+    // a splat that touches a huge number of tiles would make ONE wavefront of k_emit write them all (and the nearest,
+    // largest splats sit next to each other in the sorted order): list it, k_emit spreads it over the whole grid
+#define GS_NOTE_HUGE(jj, cnt, rows) do { if ((cnt) >= GS_HUGE_TILES && (rows) <= GS_HUGE_ROWS) {                          \
+        const uint32_t _q = atomicAdd(&ctl->n_huge, 1u); if (_q < GS_HUGE_CAP) huge_list[_q] = (jj); } } while (0)
     __shared__ float s_rec[GS_BLOCK][6];
     __shared__ uint32_t s_rows[GS_BLOCK], s_j[GS_BLOCK];
     __shared__ uint32_t s_nbig, s_nmid, s_vis, s_sum;
@@ -132,7 +136,7 @@ __global__ __launch_bounds__(GS_BLOCK) void k_project(const uint32_t *__restrict
                     }
                 }
             }
-            if (!queued) tile_count[j] = count;
+            if (!queued) { tile_count[j] = count; GS_NOTE_HUGE(j, count, 2u); }   // (at most 2 tile rows here: huge only on very wide strips)
         }
         uint32_t vis = count ? 1u : 0u, sum = count;
         __syncthreads();
@@ -153,7 +157,10 @@ __global__ __launch_bounds__(GS_BLOCK) void k_project(const uint32_t *__restrict
             }
 #pragma unroll
             for (int m = 8; m >= 1; m >>= 1) n += __shfl_xor(n, m, 16);
-            if ((lane & 15) == 0 && mi < nmid) { tile_count[s_j[mi]] = n; sum += n; if (n) vis++; }
+            if ((lane & 15) == 0 && mi < nmid) {
+                tile_count[s_j[mi]] = n; sum += n; if (n) vis++;
+                GS_NOTE_HUGE(s_j[mi], n, (s_rows[mi] >> 16) - (s_rows[mi] & 0xFFFF) + 1u);
+            }
         }
         const uint32_t nbig = s_nbig;
         for (uint32_t bq = w; bq < nbig; bq += 4) {                   // one wavefront per queued splat of more than 16 tile rows
@@ -172,7 +179,7 @@ __global__ __launch_bounds__(GS_BLOCK) void k_project(const uint32_t *__restrict
             }
 #pragma unroll
             for (int m = 32; m >= 1; m >>= 1) rsum += __shfl_xor(rsum, m, 64);
-            if (lane == 0) { tile_count[s_j[bi]] = rsum; sum += rsum; if (rsum) vis++; }
+            if (lane == 0) { tile_count[s_j[bi]] = rsum; sum += rsum; if (rsum) vis++; GS_NOTE_HUGE(s_j[bi], rsum, ty1 - ty0 + 1u); }
         }
 #pragma unroll
         for (int m = 32; m >= 1; m >>= 1) { vis += __shfl_xor(vis, m, 64); sum += __shfl_xor(sum, m, 64); }
@@ -182,6 +189,7 @@ __global__ __launch_bounds__(GS_BLOCK) void k_project(const uint32_t *__restrict
     }
     __syncthreads();
     if (threadIdx.x == 0) part_vis[blockIdx.x] = s_vis;
+#undef GS_NOTE_HUGE
 }
 
 // One workgroup: exclusive scan of the per-chunk totals (spine) -> chunk base offsets, I = grand total (refused and
@@ -223,6 +231,7 @@ __global__ __launch_bounds__(GS_BLOCK) void k_pairs_check(GsControl *ctl, uint32
         else { ctl->unsat_round0 = ctl->unsat_count; if (ctl->unsat_count) ctl->unsat_events += 1; }
         ctl->j_lo = j_lo; ctl->j_hi = j_hi;                          // for k_tile_ranges / k_blend of this round
         ctl->scan_total = total;
+        ctl->n_huge_round = ctl->n_huge; ctl->n_huge = 0;              // k_emit of this round expands them; the next k_project starts at 0
         ctl->want_frame += total;
         if (ctl->want_frame > ctl->max_total) ctl->max_total = ctl->want_frame;
         if (total > pair_cap) { ctl->pair_overflow = 1; ctl->overflow_sticky = 1; ctl->n_pairs = 0; }
@@ -271,15 +280,78 @@ template <int ROUND, bool P32>
 __global__ __launch_bounds__(GS_BLOCK) void k_emit(const gsm::Projected *__restrict__ proj, const uint2 *__restrict__ rect,
                                                    const uint32_t *__restrict__ tile_count, const uint32_t *__restrict__ spine,
                                                    GsFrameUniforms u, void *__restrict__ pairs, const uint32_t *__restrict__ mask,
-                                                   const GsControl *ctl)
+                                                   const GsControl *ctl, const uint32_t *__restrict__ huge_list)
 {
     __shared__ uint32_t s_big[GS_BLOCK], s_bigoff[GS_BLOCK], s_mid[GS_BLOCK], s_midoff[GS_BLOCK];
     __shared__ uint32_t s_nbig, s_nmid, s_wave[4];
+    __shared__ uint32_t s_hoff[GS_HUGE_ROWS + 1], s_ht0[GS_HUGE_ROWS], s_hbase;   // huge splat: row offsets / first tile of each row
     if (ctl->pair_overflow) return;
     const uint32_t j_lo = ctl->j_lo, j_hi = ctl->j_hi;               // set by k_pairs_check of this round
     const uint32_t nchunks = (j_hi - j_lo + GS_BLOCK - 1) / GS_BLOCK;
     const uint32_t tiles_x = (uint32_t)u.tiles_x;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    // Phase A: the huge splats of the round (listed by k_project), GS_HUGE_SLICES row slices each, spread over the whole
+    // grid.  Who writes a splat's pairs does not matter: its slot range is fixed by the offset scan.
+    const uint32_t nhuge = ctl->n_huge_round;
+    const bool defer = nhuge != 0 && nhuge <= GS_HUGE_CAP;
+    if (defer) for (uint32_t item = blockIdx.x; item < nhuge * GS_HUGE_SLICES; item += gridDim.x) {
+        const uint32_t jh = huge_list[item / GS_HUGE_SLICES], sl = item % GS_HUGE_SLICES;
+        const uint32_t hc = (jh - j_lo) / GS_BLOCK, ht = (jh - j_lo) % GS_BLOCK;
+        {   // the splat's first pair slot: its chunk's base + the in-chunk exclusive scan, recomputed here
+            const uint32_t jj = j_lo + hc * GS_BLOCK + threadIdx.x;
+            const uint32_t cnt = jj < j_hi ? tile_count[jj] : 0u;
+            const uint32_t inc = wave_incl_scan_u32(cnt, lane);
+            if (lane == 63) s_wave[w] = inc;
+            __syncthreads();
+            uint32_t wbase = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) if (k < w) wbase += s_wave[k];
+            if (threadIdx.x == ht) s_hbase = spine[hc] + wbase + inc - cnt;
+        }
+        const float4 *src = reinterpret_cast<const float4 *>(proj + jh);
+        const float4 a = src[0], b = src[1];
+        gsm::Projected p; p.cx = a.x; p.cy = a.y; p.ax = a.z; p.ay = a.w; p.bx = b.x; p.by = b.y;
+        gsm::EllipseRows e;
+        gsm::ellipse_rows_setup(p, e);
+        const uint2 rc = rect[jh];
+        const uint32_t ty0 = rc.x >> 16, rows = (rc.y >> 16) - ty0 + 1u;     // <= GS_HUGE_ROWS (k_project's listing rule)
+        uint32_t carry = 0;
+        for (uint32_t rb = 0; rb < rows; rb += GS_BLOCK) {               // per-row tile runs and their exclusive offsets
+            const uint32_t r = rb + threadIdx.x;
+            uint32_t t0 = 0, n = 0, nm = 0;
+            if (r < rows) {
+                gsm::splat_tile_row(p, e, (int)(ty0 + r), u.H, u.x0, u.x1, t0, n);
+                nm = (ROUND == 1 && n) ? mask_count(mask + (ty0 + r) * u.mask_words, t0, n) : n;
+            }
+            const uint32_t inc = wave_incl_scan_u32(nm, lane);
+            __syncthreads();                                          // (s_wave of the previous use has been read)
+            if (lane == 63) s_wave[w] = inc;
+            __syncthreads();
+            uint32_t wbase = 0, total = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) { const uint32_t t = s_wave[k]; if (k < w) wbase += t; total += t; }
+            if (r < rows) { s_hoff[r] = carry + wbase + inc - nm; s_ht0[r] = t0 | (n << 16); }
+            carry += total;
+        }
+        if (threadIdx.x == 0) s_hoff[rows] = carry;
+        __syncthreads();
+        const uint32_t r_lo = rows * sl / GS_HUGE_SLICES, r_hi = rows * (sl + 1u) / GS_HUGE_SLICES;
+        const uint32_t base = s_hbase, p_lo = s_hoff[r_lo], p_hi = s_hoff[r_hi];
+        if (ROUND == 0) {
+            // flattened: consecutive threads write consecutive pairs; the row of pair q by bisection of the row offsets
+            for (uint32_t q = p_lo + threadIdx.x; q < p_hi; q += GS_BLOCK) {
+                uint32_t lo = r_lo, hi = r_hi;                       // invariant: s_hoff[lo] <= q < s_hoff[hi]
+                while (hi - lo > 1u) { const uint32_t m = (lo + hi) >> 1; if (s_hoff[m] <= q) lo = m; else hi = m; }
+                const uint32_t t0 = s_ht0[lo] & 0xFFFFu;
+                put_pair<P32>(pairs, base + q, (ty0 + lo) * tiles_x + t0 + (q - s_hoff[lo]), jh, jh - j_lo, u.pair_jbits);
+            }
+        } else {
+            for (uint32_t r = r_lo + threadIdx.x; r < r_hi; r += GS_BLOCK)   // masked tiles: one thread per row
+                emit_run<ROUND, P32>(pairs, base + s_hoff[r], ty0 + r, tiles_x, s_ht0[r] & 0xFFFFu, s_ht0[r] >> 16, jh, jh - j_lo, u.pair_jbits,
+                                     mask + (ty0 + r) * u.mask_words);
+        }
+        __syncthreads();
+    }
     for (uint32_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
         uint32_t carry = spine[c];
         {
@@ -296,9 +368,10 @@ __global__ __launch_bounds__(GS_BLOCK) void k_emit(const gsm::Projected *__restr
             carry += total;
             if (cnt >= GS_EMIT_BIG) {
                 // many tiles: expanded cooperatively, one lane per tile row -- by 16 lanes when the splat spans at most 16
-                // tile rows (four splats per wavefront pass), by a whole wavefront otherwise
+                // tile rows (four splats per wavefront pass), by a whole wavefront otherwise; huge ones were done in phase A
                 const uint2 rc = rect[j];
-                if ((rc.y >> 16) - (rc.x >> 16) < 16u) { const uint32_t q = atomicAdd(&s_nmid, 1u); s_mid[q] = j; s_midoff[q] = o; }
+                if (defer && cnt >= GS_HUGE_TILES && (rc.y >> 16) - (rc.x >> 16) < GS_HUGE_ROWS) { /* phase A */ }
+                else if ((rc.y >> 16) - (rc.x >> 16) < 16u) { const uint32_t q = atomicAdd(&s_nmid, 1u); s_mid[q] = j; s_midoff[q] = o; }
                 else { const uint32_t q = atomicAdd(&s_nbig, 1u); s_big[q] = j; s_bigoff[q] = o; }
             } else if (cnt) {
                 const float4 *src = reinterpret_cast<const float4 *>(proj + j);
@@ -634,7 +707,7 @@ int run_round(gs_ctx *ctx, const GsFrameUniforms &u, uint8_t *out, bool last_rou
     if (ROUND == 0 && u.near_count != 0xFFFFFFFFu) { const uint32_t gn = gs_div_up(u.near_count < Vmax ? u.near_count : Vmax, GS_BLOCK); if (gn < g) g = gn ? gn : 1; }
     const uint32_t pc = ROUND == 1 ? (uint32_t)(small * GS_CHUNK) : (uint32_t)ctx->pair_cap;      // grid hint for the radix kernels
     hipLaunchKernelGGL(k_project<ROUND>, dim3(g), dim3(GS_BLOCK), 0, st, ctx->sorted, ctx->splat, u, ctx->proj, ctx->rect,
-                       ctx->tile_count, ctx->spine, ctx->part_vis, ctx->unsat_mask, ctx->zwin, ctx->ctl);
+                       ctx->tile_count, ctx->spine, ctx->part_vis, ctx->unsat_mask, ctx->zwin, ctx->ctl, ctx->huge_list);
     GS_HIP(hipGetLastError());
     if (ROUND == 0) GS_PROF_RECORD(ctx, 3);
     hipLaunchKernelGGL(k_pairs_check<ROUND>, dim3(1), dim3(GS_BLOCK), 0, st, ctx->ctl, (uint32_t)ctx->pair_cap, ctx->spine, ctx->part_vis, g,
@@ -647,9 +720,9 @@ int run_round(gs_ctx *ctx, const GsFrameUniforms &u, uint8_t *out, bool last_rou
     GsFrameUniforms v = u;
     v.pair_jbits = p32 ? (uint32_t)jb : 0u;
     if (p32) hipLaunchKernelGGL((k_emit<ROUND, true>), dim3(g), dim3(GS_BLOCK), 0, st, ctx->proj, ctx->rect, ctx->tile_count, ctx->spine, v,
-                                (void *)ctx->pair_a, ctx->unsat_mask, ctx->ctl);
+                                (void *)ctx->pair_a, ctx->unsat_mask, ctx->ctl, ctx->huge_list);
     else hipLaunchKernelGGL((k_emit<ROUND, false>), dim3(g), dim3(GS_BLOCK), 0, st, ctx->proj, ctx->rect, ctx->tile_count, ctx->spine, v,
-                            (void *)ctx->pair_a, ctx->unsat_mask, ctx->ctl);
+                            (void *)ctx->pair_a, ctx->unsat_mask, ctx->ctl, ctx->huge_list);
     GS_HIP(hipGetLastError());
     int rc;
     const int fmt = p32 ? GS_RADIX_KEYONLY : GS_RADIX_PACKED, sh = p32 ? jb : 0;

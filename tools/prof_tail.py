@@ -1,0 +1,19 @@
+#!/usr/bin/env python3
+"""Per-kernel averages over the LAST n dispatches of a rocprofv3 (rocpd sqlite) kernel trace -- i.e. the timed, pipelined
+frames of bench.py, without the synchronous counting / pre-roll frames.  usage: tools/prof_tail.py <results.db> [n]"""
+import re, sqlite3, sys
+db = sqlite3.connect(sys.argv[1])
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+tabs = [r[0] for r in db.execute("select name from sqlite_master where type in ('table','view')")]
+disp = sorted([t for t in tabs if "kernel_dispatch" in t], key=len)[0]
+sym = sorted([t for t in tabs if "kernel_symbol" in t], key=len)[0]
+rows = list(db.execute("select s.kernel_name, d.start, d.end from %s d join %s s on d.kernel_id = s.id order by d.start desc limit %d" % (disp, sym, n)))
+agg = {}
+for name, s, e in rows:
+    name = re.sub(r"\(anonymous namespace\)::", "", name); name = re.sub(r"^void ", "", name)
+    m = re.match(r"([\w:<>, ]+?)\(", name); name = (m.group(1) if m else name)[:44]
+    a = agg.setdefault(name, [0, 0.0]); a[0] += 1; a[1] += (e - s) / 1e3
+wall = (max(r[2] for r in rows) - min(r[1] for r in rows)) / 1e3
+print("last %d dispatches, wall %.1f us, kernel time %.1f us" % (len(rows), wall, sum(a[1] for a in agg.values())))
+for name, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+    print("  %-46s calls %5d  avg %9.2f us  share %5.1f %%" % (name, c, t / c, 100.0 * t / sum(a[1] for a in agg.values())))
