@@ -166,6 +166,18 @@ struct gs_ctx {
 
 static inline uint32_t gs_div_up(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
 
+// XCD-aware chunk order for the streaming kernels.  Workgroup i runs on XCD i % 8 and every XCD has its own L2, so with
+// chunk = workgroup index neighbouring chunks -- which write neighbouring segments of the same digit run, i.e. the two
+// halves of one 128-byte line -- sit in different L2s and each goes to HBM as a partial line.  Giving XCD k the k-th
+// contiguous eighth of the chunks lets those segments merge in one L2.  v = virtual workgroup index (grid a multiple of
+// 8, grid-strided); returns false for the padding slots of the last eighths.
+__device__ __forceinline__ bool gs_xcd_chunk(uint32_t v, uint32_t nchunks, uint32_t &chunk)
+{
+    const uint32_t per = (nchunks + 7u) >> 3;
+    chunk = (v & 7u) * per + (v >> 3);
+    return (v >> 3) < per && chunk < nchunks;
+}
+
 // ---- gs_prims.hip
 // One stable LSD radix pass over n = *n_ptr items on digit (key >> shift) & (2^bits-1).
 // record formats: GS_RADIX_KEYS    in: a plain key array whose value is the element index; out: the values alone (final pass)

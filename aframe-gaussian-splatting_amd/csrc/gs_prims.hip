@@ -45,7 +45,9 @@ __global__ __launch_bounds__(GS_BLOCK) void k_radix_hist(const uint32_t *__restr
     const uint32_t n = *n_ptr;
     const uint32_t nchunks = (n + GS_CHUNK - 1) / GS_CHUNK;
     const uint32_t nbins = 1u << bits, mask = nbins - 1;
-    for (uint32_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
+    for (uint32_t v = blockIdx.x; v < ((nchunks + 7u) & ~7u); v += gridDim.x) {
+        uint32_t c;
+        if (!gs_xcd_chunk(v, nchunks, c)) continue;
         for (uint32_t d = threadIdx.x; d < nbins; d += GS_BLOCK) s_hist[d] = 0;
         __syncthreads();
 #pragma unroll
@@ -109,7 +111,7 @@ __global__ __launch_bounds__(GS_BLOCK) void k_radix_scatter(const void *__restri
     const uint32_t nbins = 1u << bits, mask = nbins - 1;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const unsigned long long lt = (1ull << lane) - 1ull;
-    if (blockIdx.x >= nchunks) return;
+    if (blockIdx.x >= ((nchunks + 7u) & ~7u)) return;
     {   // exclusive scan of the <= 512 digit totals (2 per thread)
         const uint32_t d0 = threadIdx.x * 2;
         const uint32_t v0 = d0 < nbins ? totals[d0] : 0u, v1 = d0 + 1 < nbins ? totals[d0 + 1] : 0u;
@@ -117,7 +119,9 @@ __global__ __launch_bounds__(GS_BLOCK) void k_radix_scatter(const void *__restri
         const uint32_t ex = block_excl_scan(v0 + v1, s_wave, &tot);
         s_dbase[d0] = ex; s_dbase[d0 + 1] = ex + v0;
     }
-    for (uint32_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
+    for (uint32_t v = blockIdx.x; v < ((nchunks + 7u) & ~7u); v += gridDim.x) {
+        uint32_t c;
+        if (!gs_xcd_chunk(v, nchunks, c)) continue;
         for (uint32_t i = threadIdx.x; i < 4 * GS_RADIX_MAX_BINS; i += GS_BLOCK) (&s_cnt[0][0])[i] = 0;
         __syncthreads();
         uint32_t key[GS_IPT], val[GS_IPT], rank[GS_IPT];
@@ -199,7 +203,7 @@ uint32_t grid_for(uint32_t max_items)
     uint32_t g = gs_div_up(max_items, GS_CHUNK);
     if (g < 1) g = 1;
     if (g > 2048) g = 2048;
-    return g;
+    return (g + 7u) & ~7u;                                       // a multiple of 8: workgroup index mod 8 = XCD (gs_xcd_chunk)
 }
 
 }  // namespace

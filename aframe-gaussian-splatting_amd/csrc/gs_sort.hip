@@ -93,7 +93,9 @@ __global__ __launch_bounds__(GS_BLOCK) void k_sort_bucket(const float *__restric
     const double mn = gsm::ordered_to_f64(s_min), mx = gsm::ordered_to_f64(s_max);
     const double inv = 65535.0 / (mx - mn);                       // (256*256-1)/(maxDepth-minDepth)
     const uint32_t nchunks = (n + GS_CHUNK - 1) / GS_CHUNK;
-    for (uint32_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
+    for (uint32_t v = blockIdx.x; v < ((nchunks + 7u) & ~7u); v += gridDim.x) {
+        uint32_t c;
+        if (!gs_xcd_chunk(v, nchunks, c)) continue;                // XCD-aware chunk order (the histogram rows are shared lines)
         s_hist[threadIdx.x] = 0;
         __syncthreads();
 #pragma unroll
