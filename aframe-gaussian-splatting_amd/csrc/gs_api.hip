@@ -205,7 +205,8 @@ static int collect_status(gs_ctx *lane, bool *overflowed)
                 float nf = ctx->near_frac * (ctx->near_floor > 0.0f ? 0.98f : 0.9f);
                 if (nf < ctx->near_floor) nf = ctx->near_floor; if (nf < 0.02f) nf = 0.02f;
                 if (nf < ctx->near_frac) ctx->near_frac = nf;
-                if (ctx->skip_hold) ctx->skip_hold--;
+                const uint32_t fr = (uint32_t)(frames ? frames : 1);     // the hold is counted in frames, not in collections
+                ctx->skip_hold = ctx->skip_hold > fr ? ctx->skip_hold - fr : 0;
             }
             ctx->single_round_frames = 0;
         } else if (ctx->near_frac >= 1.0f && ++ctx->single_round_frames >= 64) {

@@ -179,8 +179,11 @@ def main():
     # adaptation pre-roll (untimed, like the fragment counting above): one synchronous pass over the poses of the timed
     # region lets the library settle the share of splats it bins in its first, nearest-splats round for every pose
     retries = 0
-    for k in frames_used:
-        frame(k)
+    preroll = 0
+    while preroll < 96:                                      # (short runs cycle through their poses until the share has settled)
+        for k in frames_used:
+            frame(k)
+            preroll += 1
     for i in range(args.warmup):
         frame(i, capi.RENDER_ASYNC)
     sync()
