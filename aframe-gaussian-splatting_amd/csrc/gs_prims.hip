@@ -96,15 +96,19 @@ __global__ __launch_bounds__(GS_BLOCK) void k_radix_rowscan(uint32_t *__restrict
 //          8-byte store per item), GS_RADIX_KEYONLY = the 4-byte record.
 // zero_key: items whose key equals it store 0 as their value (value-only output): the depth sort uses this so that
 // culled splats (key 65536, which sort behind every bucket) leave zeros in the tail of the index list.
-template <int IN_FMT, int OUT_FMT>
+// MAXB: bins the instantiation reserves LDS for (128 for the <= 7-bit digits of the pair sort, GS_RADIX_MAX_BINS otherwise);
+// together with 4-byte LDS slots for key-only records this takes a pair-sort workgroup from 28 KiB to 11 KiB of LDS.
+template <int IN_FMT, int OUT_FMT, int MAXB>
 __global__ __launch_bounds__(GS_BLOCK) void k_radix_scatter(const void *__restrict__ in, void *__restrict__ out,
                                                             const uint32_t *n_ptr, int shift, int bits, uint32_t zero_key,
                                                             const uint32_t *__restrict__ hist_scanned, const uint32_t *__restrict__ totals)
 {
-    __shared__ uint32_t s_cnt[4][GS_RADIX_MAX_BINS];            // 8 KiB  per-wave digit counts -> local slot bases
-    __shared__ uint32_t s_dbase[GS_RADIX_MAX_BINS];             // start of every digit's output run (whole array)
-    __shared__ uint32_t s_gb[GS_RADIX_MAX_BINS];                // global position of local slot 0 of each digit (minus slot)
-    __shared__ uint2 s_kv[GS_CHUNK];                            // 16 KiB chunk in digit order
+    constexpr bool KEYONLY = IN_FMT == GS_RADIX_KEYONLY && OUT_FMT == GS_RADIX_KEYONLY;
+    __shared__ uint32_t s_cnt[4][MAXB];                         // per-wave digit counts -> local slot bases
+    __shared__ uint32_t s_dbase[MAXB];                          // start of every digit's output run (whole array)
+    __shared__ uint32_t s_gb[MAXB];                             // global position of local slot 0 of each digit (minus slot)
+    __shared__ uint32_t s_k[GS_CHUNK];                          // the chunk in digit order: keys ...
+    __shared__ uint32_t s_v[KEYONLY ? 1 : GS_CHUNK];            // ... and values (not for key-only records)
     __shared__ uint32_t s_wave[4];
     const uint32_t n = *n_ptr;
     const uint32_t nchunks = (n + GS_CHUNK - 1) / GS_CHUNK;
@@ -117,12 +121,13 @@ __global__ __launch_bounds__(GS_BLOCK) void k_radix_scatter(const void *__restri
         const uint32_t v0 = d0 < nbins ? totals[d0] : 0u, v1 = d0 + 1 < nbins ? totals[d0 + 1] : 0u;
         uint32_t tot;
         const uint32_t ex = block_excl_scan(v0 + v1, s_wave, &tot);
-        s_dbase[d0] = ex; s_dbase[d0 + 1] = ex + v0;
+        if (d0 < nbins) s_dbase[d0] = ex;
+        if (d0 + 1 < nbins) s_dbase[d0 + 1] = ex + v0;
     }
     for (uint32_t v = blockIdx.x; v < ((nchunks + 7u) & ~7u); v += gridDim.x) {
         uint32_t c;
         if (!gs_xcd_chunk(v, nchunks, c)) continue;
-        for (uint32_t i = threadIdx.x; i < 4 * GS_RADIX_MAX_BINS; i += GS_BLOCK) (&s_cnt[0][0])[i] = 0;
+        for (uint32_t i = threadIdx.x; i < 4 * MAXB; i += GS_BLOCK) (&s_cnt[0][0])[i] = 0;
         __syncthreads();
         uint32_t key[GS_IPT], val[GS_IPT], rank[GS_IPT];
 #pragma unroll
@@ -178,7 +183,8 @@ __global__ __launch_bounds__(GS_BLOCK) void k_radix_scatter(const void *__restri
             const uint32_t i = c * GS_CHUNK + w * (GS_CHUNK / 4) + r * 64 + lane;
             if (i < n && (IN_FMT != GS_RADIX_KEYS || key[r] != GS_RADIX_SKIP)) {
                 const uint32_t d = (key[r] >> shift) & mask;
-                s_kv[s_cnt[w][d] + rank[r]] = make_uint2(key[r], val[r]);
+                s_k[s_cnt[w][d] + rank[r]] = key[r];
+                if (!KEYONLY) s_v[s_cnt[w][d] + rank[r]] = val[r];
             }
         }
         __syncthreads();
@@ -187,7 +193,7 @@ __global__ __launch_bounds__(GS_BLOCK) void k_radix_scatter(const void *__restri
         for (int r = 0; r < GS_IPT; r++) {
             const uint32_t slot = r * GS_BLOCK + threadIdx.x;
             if (slot < items) {
-                const uint2 kv = s_kv[slot];
+                const uint2 kv = make_uint2(s_k[slot], KEYONLY ? 0u : s_v[slot]);
                 const uint32_t pos = s_gb[(kv.x >> shift) & mask] + slot;
                 if (OUT_FMT == GS_RADIX_PACKED) reinterpret_cast<uint2 *>(out)[pos] = kv;
                 else if (OUT_FMT == GS_RADIX_KEYONLY) reinterpret_cast<uint32_t *>(out)[pos] = kv.x;
@@ -221,7 +227,8 @@ int gs_launch_radix_pass(gs_ctx *ctx, const void *in, int in_fmt, void *out, int
     else if (in_fmt == GS_RADIX_PACKED) hipLaunchKernelGGL(k_radix_hist<true>, G, B, 0, st, (const uint32_t *)in, n_ptr, shift, bits, ctx->hist);
     else hipLaunchKernelGGL(k_radix_hist<false>, G, B, 0, st, (const uint32_t *)in, n_ptr, shift, bits, ctx->hist);
     hipLaunchKernelGGL(k_radix_rowscan, dim3(1u << bits), B, 0, st, ctx->hist, n_ptr, totals);
-#define GS_SCATTER(I, O) hipLaunchKernelGGL((k_radix_scatter<I, O>), G, B, 0, st, in, out, n_ptr, shift, bits, zero_key, ctx->hist, totals)
+#define GS_SCATTER(I, O) do { if (bits <= 7) hipLaunchKernelGGL((k_radix_scatter<I, O, 128>), G, B, 0, st, in, out, n_ptr, shift, bits, zero_key, ctx->hist, totals); \
+                              else hipLaunchKernelGGL((k_radix_scatter<I, O, GS_RADIX_MAX_BINS>), G, B, 0, st, in, out, n_ptr, shift, bits, zero_key, ctx->hist, totals); } while (0)
     if (in_fmt == GS_RADIX_PACKED && out_fmt == GS_RADIX_PACKED) GS_SCATTER(GS_RADIX_PACKED, GS_RADIX_PACKED);
     else if (in_fmt == GS_RADIX_PACKED && out_fmt == GS_RADIX_KEYS) GS_SCATTER(GS_RADIX_PACKED, GS_RADIX_KEYS);
     else if (in_fmt == GS_RADIX_KEYS && out_fmt == GS_RADIX_PACKED) GS_SCATTER(GS_RADIX_KEYS, GS_RADIX_PACKED);
