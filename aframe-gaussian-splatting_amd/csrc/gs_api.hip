@@ -130,7 +130,8 @@ static int ensure_capacity(gs_ctx *ctx, size_t want)
 hipEvent_t gs_prof_event(gs_ctx *ctx, int k)
 {
     if (!ctx->profile || !ctx->ring) return nullptr;
-    if (ctx->profile_blend_only && k != 4 && k != 5) return nullptr;   // GS_OPT_PROFILE = 2: only the events around the blend
+    if (ctx->profile_blend_only && k != 4 && k != 5) return nullptr;   // GS_OPT_PROFILE = 2 / 3: only the events around the blend
+    if (ctx->profile_every > 1 && (ctx->profile_tick % ctx->profile_every) != 0) return nullptr;   // ... of every 4th frame
     const uint32_t slot = ctx->ring_head % GS_PROF_RING;
     ctx->ring_flags[slot] |= (uint8_t)(1u << k);
     return ctx->ring[slot * GS_PROF_EVENTS + k];
@@ -169,6 +170,7 @@ static int prof_drain(gs_ctx *ctx)
 static int prof_advance(gs_ctx *ctx)
 {
     if (!ctx->profile || !ctx->ring) return GS_OK;
+    ctx->profile_tick++;
     ctx->ring_head++; ctx->ring_pending++;
     if (ctx->ring_pending >= GS_PROF_RING - 1) {
         GS_HIP(hipStreamSynchronize(ctx->stream));
@@ -353,7 +355,7 @@ static void free_frame_resources(gs_ctx *c)
 }
 
 // switch the HIP-event profiling of one lane on/off (allocates its ring on first use, restarts its accumulators)
-static int set_profile(gs_ctx *ctx, bool on, bool blend_only)
+static int set_profile(gs_ctx *ctx, bool on, bool blend_only, uint32_t every = 1)
 {
     TRY(lane_drain(ctx));
     GS_HIP(hipStreamSynchronize(ctx->stream));
@@ -370,7 +372,7 @@ static int set_profile(gs_ctx *ctx, bool on, bool blend_only)
         GS_HIP(hipMemsetAsync(&ctx->ctl->acc_frames, 0, sizeof(GsControl) - offsetof(GsControl, acc_frames), ctx->stream));
         ctx->seen_acc_frames = 0;
     }
-    ctx->profile = on; ctx->profile_blend_only = on && blend_only;
+    ctx->profile = on; ctx->profile_blend_only = on && blend_only; ctx->profile_every = on ? every : 1; ctx->profile_tick = 0;
     return GS_OK;
 }
 
@@ -390,7 +392,7 @@ static int get_lane(gs_ctx *ctx, int i, gs_ctx **out)
             return e == hipErrorOutOfMemory ? GS_E_OOM : GS_E_HIP;
         }
         ctx->lanes[i] = L;
-        if (ctx->profile && set_profile(L, true, ctx->profile_blend_only) != GS_OK) { memcpy(ctx->err, L->err, sizeof ctx->err); return GS_E_HIP; }
+        if (ctx->profile && set_profile(L, true, ctx->profile_blend_only, ctx->profile_every) != GS_OK) { memcpy(ctx->err, L->err, sizeof ctx->err); return GS_E_HIP; }
     }
     if (lane_drain(L) != GS_OK) { if (L != ctx) memcpy(ctx->err, L->err, sizeof ctx->err); return GS_E_HIP; }   // its worker is idle from here on
     if (L != ctx) {
@@ -891,7 +893,7 @@ GS_API int gs_set_option(gs_ctx *ctx, int option, int64_t value)
     case GS_OPT_PROFILE:
         GS_HIP(hipSetDevice(ctx->device));
         for (int i = 0; i < GS_MAX_LANES; i++)
-            if (ctx->lanes[i]) TRY(lane_rc(ctx, ctx->lanes[i], set_profile(ctx->lanes[i], value != 0, value == 2)));
+            if (ctx->lanes[i]) TRY(lane_rc(ctx, ctx->lanes[i], set_profile(ctx->lanes[i], value != 0, value == 2 || value == 3, value == 3 ? 4u : 1u)));
         return GS_OK;
     case GS_OPT_NEAR_PERMILLE:
         if (value < 0 || value > 1000) FAIL(GS_E_BADARG, "near permille must be 0 (adaptive) .. 1000 (single round)");

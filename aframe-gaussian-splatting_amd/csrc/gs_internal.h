@@ -143,7 +143,9 @@ struct gs_ctx {
 
     // options / stats
     bool profile;
-    bool profile_blend_only;       // GS_OPT_PROFILE = 2: HIP events around the blend kernel only (2 instead of 7 per frame)
+    bool profile_blend_only;       // GS_OPT_PROFILE = 2 / 3: HIP events around the blend kernel only (2 instead of 7 per frame)
+    uint32_t profile_every;        // GS_OPT_PROFILE = 3: ... and only on every 4th frame of the lane (0 / 1 = every frame)
+    uint32_t profile_tick;
     uint32_t record_staged;        // GS_OPT_RECORD_STAGED (1 = entries staged, 2 = entries evaluated)
     bool wide_pairs;               // GS_OPT_WIDE_PAIRS: always use 8-byte pair records
     float t_eps;

@@ -192,7 +192,7 @@ def main():
     # library has adapted, the region is measured again from scratch.
     for attempt in range(4):
         ctx.set_option(capi.OPT_PROFILE, 0)
-        ctx.set_option(capi.OPT_PROFILE, 2)                  # HIP events around the dominant kernel (blend), on its stream
+        ctx.set_option(capi.OPT_PROFILE, 3)                  # HIP events around the dominant kernel (blend) on its stream, every 4th frame
         sync()
         t_start = time.perf_counter()
         for i in range(args.steps):
@@ -212,7 +212,8 @@ def main():
             frame(k)
     s = ctx.stats()
     ctx.set_option(capi.OPT_PROFILE, 0)
-    assert s["acc_frames"] == args.steps and s["prof_frames"] == args.steps, (s["acc_frames"], s["prof_frames"])
+    assert s["acc_frames"] == args.steps and s["prof_frames"] >= max(1, args.steps // 4 - 3), (s["acc_frames"], s["prof_frames"])
+    blend_frames = s["prof_frames"]                          # frames of the timed region whose blend was bracketed by HIP events
     # per-stage breakdown: a second, UNTIMED pass over the same frames with events around every stage (7 per frame
     # instead of 2; they cost ~4 % of the frame rate, so the timed region carries only the blend's)
     ctx.set_option(capi.OPT_PROFILE, 1)
@@ -224,7 +225,7 @@ def main():
     ctx.set_option(capi.OPT_PROFILE, 0)
     k2 = max(1, s2["prof_frames"])
     stage = {"ms_sort": s2["sum_ms_sort"] * args.steps / k2, "ms_project": s2["sum_ms_project"] * args.steps / k2,
-             "ms_bin": s2["sum_ms_bin"] * args.steps / k2, "ms_blend": s["sum_ms_blend"]}
+             "ms_bin": s2["sum_ms_bin"] * args.steps / k2, "ms_blend": s["sum_ms_blend"] * args.steps / blend_frames}
     pairs, visible, sorted_n = s["acc_pairs"], s["acc_visible"], s["acc_sorted"]
     if multi:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
@@ -289,6 +290,7 @@ def main():
                          "traffic_note": "HBM bytes/launch = 2*FETCH_SIZE + WRITE_SIZE from separate rocprofv3 --pmc passes "
                                          "(profiles/r01_pmc_hbm_traffic.md); early termination reads far less than the algorithmic 36*I",
                          "bytes_per_launch": round(blend_bytes), "avg_launch_ms": round(blend_s * 1e3, 4),
+                         "launches_timed": int(blend_frames),
                          "achieved_touched": round(achieved_touched, 2), "touched_bytes_per_launch": round(touched_bytes),
                          "touched_note": "36 B x the list entries the kernel actually stages before its tiles saturate (early "
                                          "termination) + the RGBA8 write; `achieved` uses the full algorithmic 36*I of the contract"},

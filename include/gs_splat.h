@@ -204,7 +204,8 @@ typedef struct gs_stats {
 } gs_stats;
 
 #define GS_OPT_PROFILE 1        /* 1: bracket every stage with HIP events on the frame's stream (7 per frame); 2: only
-                                   the blend kernel (2 per frame; sum_ms_blend / prof_frames); 0: off                  */
+                                   the blend kernel (2 per frame; sum_ms_blend / prof_frames); 3: like 2 but only on every
+                                   4th frame of a lane (an event pair costs ~5 % of the pipelined frame rate); 0: off */
 #define GS_OPT_TERMINATION 2    /* value = 1/eps for the transmittance early-out (default 4096)          */
 #define GS_OPT_NEAR_PERMILLE 3  /* occlusion-aware binning: 0 = adapt (default), 1..999 = bin that share of the nearest
                                    splats first and the rest only against unsaturated tiles, 1000 = single round      */
