@@ -500,7 +500,8 @@ __global__ __launch_bounds__(64) void k_blend(const uint2 *__restrict__ tile_ran
                                               const float *__restrict__ zwin, const float *__restrict__ scene_depth,
                                               const uint32_t *__restrict__ scene_rgba, GsControl *ctl)
 {
-    __shared__ float4 s_rec[2 * GS_BLEND_BATCH + 2];             // 4 KiB: one batch of projected records (+1 inert slot)
+    __shared__ float4 s_rec[2 * GS_BLEND_BATCH + 2];             // one batch of projected records (+1 inert slot)
+    __shared__ float4 s_col[GS_BLEND_BATCH + 1];                 // their colours, converted once per record: rgb8 * alpha / 255
     __shared__ float s_z[GS_BLEND_BATCH + 2];                    // their window depths (SCENE only)
     const int lane = threadIdx.x;
     if (ROUND == 1 && ctl->j_hi == 0) return;                      // every tile saturated in round 0
@@ -557,8 +558,13 @@ __global__ __launch_bounds__(64) void k_blend(const uint2 *__restrict__ tile_ran
                 const uint32_t j = u.pair_jbits ? pair_j_lo + (reinterpret_cast<const uint32_t *>(pairs)[end - 1 - slot] & pair_j_mask)
                                                 : reinterpret_cast<const uint2 *>(pairs)[end - 1 - slot].y;
                 const float4 *src = reinterpret_cast<const float4 *>(proj + j);
+                const float4 rb = src[1];
                 s_rec[2 * slot] = src[0];
-                s_rec[2 * slot + 1] = src[1];
+                s_rec[2 * slot + 1] = rb;
+                // what every lane would otherwise redo for every list entry: unpack the colour, fold alpha / 255 into it
+                const uint32_t rgba = __float_as_uint(rb.z);
+                const float a255 = rb.w * (1.0f / 255.0f);
+                s_col[slot] = make_float4((float)(rgba & 0xFF) * a255, (float)((rgba >> 8) & 0xFF) * a255, (float)((rgba >> 16) & 0xFF) * a255, 0.0f);
                 if (SCENE) s_z[slot] = u.has_depth ? zwin[j] : 0.0f;
             }
         }
@@ -566,6 +572,7 @@ __global__ __launch_bounds__(64) void k_blend(const uint2 *__restrict__ tile_ran
             if (SCENE) s_z[nb] = 0.0f;                               // pad an odd batch with a record no pixel can pass
             s_rec[2 * nb] = make_float4(-1.0e9f, -1.0e9f, 1.0f, 1.0f);   // centre far away, a = (1,1): q ~ 1e18 > 4
             s_rec[2 * nb + 1] = make_float4(1.0f, 1.0f, 0.0f, 0.0f);
+            s_col[nb] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         }
         __syncthreads();
         if (live) {
@@ -594,34 +601,33 @@ __global__ __launch_bounds__(64) void k_blend(const uint2 *__restrict__ tile_ran
                 const f2 pyA1 = fma2(dxA1, (f2)(b1.x), (f2)(dyby1)), pyB1 = fma2(dxB1, (f2)(b1.x), (f2)(dyby1));
                 const f2 qA1 = fma2(pxA1, pxA1, pyA1 * pyA1), qB1 = fma2(pxB1, pxB1, pyB1 * pyB1);
 #endif
-#define GS_BLEND_APPLY(qA, qB, bb, zz)                                                                                 \
+#define GS_BLEND_APPLY(qA, qB, bb, cc, zz)                                                                             \
                 {                                                                                                      \
                     bool p0 = qA.x <= qmA.x, p1 = qA.y <= qmA.y, p2 = qB.x <= qmB.x, p3 = qB.y <= qmB.y;               \
                     if (SCENE) { p0 = p0 && zz <= zb0; p1 = p1 && zz <= zb1; p2 = p2 && zz <= zb2; p3 = p3 && zz <= zb3; } \
                     if (live & (p0 | p1 | p2 | p3)) {                  /* discard test, index.js:172 */                \
-                        const float alpha = bb.w, alpha255 = bb.w * (1.0f / 255.0f);                                   \
-                        const uint32_t rgba = __float_as_uint(bb.z);                                                   \
+                        const float alpha = bb.w;                                                                      \
                         /* exp(A) (index.js:173); 0 for the pixels of this lane that the splat misses */               \
                         const f2 EA = { p0 ? __expf(-qA.x) : 0.0f, p1 ? __expf(-qA.y) : 0.0f };                        \
                         const f2 EB = { p2 ? __expf(-qB.x) : 0.0f, p3 ? __expf(-qB.y) : 0.0f };                        \
                         /* fragment alpha B = exp(A)*vColor.a; its weight under what is in front: w = B*T.  T <- T - w \
-                           (= T*(1-B)), colour += rgb8 * (w/255) */                                                    \
+                           (= T*(1-B)), colour += (rgb8 * alpha/255) * (exp(A)*T) with the bracket converted at staging */ \
                         const f2 eA = EA * TA, eB = EB * TB;                                                           \
-                        const f2 vA = eA * alpha255, vB = eB * alpha255;                                               \
                         TA = fma2((f2)(-alpha), eA, TA); TB = fma2((f2)(-alpha), eB, TB);                              \
-                        const float c0 = (float)(rgba & 0xFF), c1 = (float)((rgba >> 8) & 0xFF), c2 = (float)((rgba >> 16) & 0xFF); \
-                        crA = fma2((f2)(c0), vA, crA); crB = fma2((f2)(c0), vB, crB);                                  \
-                        cgA = fma2((f2)(c1), vA, cgA); cgB = fma2((f2)(c1), vB, cgB);                                  \
-                        cbA = fma2((f2)(c2), vA, cbA); cbB = fma2((f2)(c2), vB, cbB);                                  \
+                        crA = fma2((f2)(cc.x), eA, crA); crB = fma2((f2)(cc.x), eB, crB);                              \
+                        cgA = fma2((f2)(cc.y), eA, cgA); cgB = fma2((f2)(cc.y), eB, cgB);                              \
+                        cbA = fma2((f2)(cc.z), eA, cbA); cbB = fma2((f2)(cc.z), eB, cbB);                              \
                         if (COUNT) nfr += (uint32_t)p0 + (uint32_t)p1 + (uint32_t)p2 + (uint32_t)p3;                   \
                         live = GS_LANE_LIVE();                                                                         \
                     }                                                                                                  \
                 }
                 const float z0 = SCENE ? s_z[s] : 0.0f;
-                GS_BLEND_APPLY(qA0, qB0, b0, z0)
+                const float4 c0 = s_col[s];
+                GS_BLEND_APPLY(qA0, qB0, b0, c0, z0)
 #if GS_BLEND_SPLATS_PER_STEP == 2
                 const float z1 = SCENE ? s_z[s + 1] : 0.0f;
-                GS_BLEND_APPLY(qA1, qB1, b1, z1)
+                const float4 c1 = s_col[s + 1];
+                GS_BLEND_APPLY(qA1, qB1, b1, c1, z1)
 #endif
 #undef GS_BLEND_APPLY
                 if (!live) break;
