@@ -3,7 +3,7 @@
 // The kernels read their problem size from device memory (GsControl), so no stage of the frame
 // needs a host round trip.  They are HBM/L2-streaming kernels: 256-thread workgroups, 2048 items per
 // workgroup pass, 16-byte vector loads where the access pattern allows, LDS digit histograms, and
-// wavefront ballots for the stable in-wave rank (no MFMA: there is no contraction here).
+// LDS match words / wavefront ballots for the stable in-wave rank (no MFMA: there is no contraction here).
 #include "gs_internal.h"
 
 namespace {
@@ -105,6 +105,8 @@ __global__ __launch_bounds__(GS_BLOCK) void k_radix_scatter(const void *__restri
 {
     constexpr bool KEYONLY = IN_FMT == GS_RADIX_KEYONLY && OUT_FMT == GS_RADIX_KEYONLY;
     __shared__ uint32_t s_cnt[4][MAXB];                         // per-wave digit counts -> local slot bases
+    constexpr bool LDS_MATCH = MAXB <= 256;                     // (the 512-bin instantiation keeps the ballots: 16 KiB more LDS cost it more)
+    __shared__ unsigned long long s_match[4][LDS_MATCH ? MAXB : 1];   // per wave and digit: lanes holding that digit in the current round
     __shared__ uint32_t s_dbase[MAXB];                          // start of every digit's output run (whole array)
     __shared__ uint32_t s_gb[MAXB];                             // global position of local slot 0 of each digit (minus slot)
     __shared__ uint32_t s_k[GS_CHUNK];                          // the chunk in digit order: keys ...
@@ -127,7 +129,7 @@ __global__ __launch_bounds__(GS_BLOCK) void k_radix_scatter(const void *__restri
     for (uint32_t v = blockIdx.x; v < ((nchunks + 7u) & ~7u); v += gridDim.x) {
         uint32_t c;
         if (!gs_xcd_chunk(v, nchunks, c)) continue;
-        for (uint32_t i = threadIdx.x; i < 4 * MAXB; i += GS_BLOCK) (&s_cnt[0][0])[i] = 0;
+        for (uint32_t i = threadIdx.x; i < 4 * MAXB; i += GS_BLOCK) { (&s_cnt[0][0])[i] = 0; if (LDS_MATCH) (&s_match[0][0])[i] = 0ull; }
         __syncthreads();
         uint32_t key[GS_IPT], val[GS_IPT], rank[GS_IPT];
 #pragma unroll
@@ -143,16 +145,26 @@ __global__ __launch_bounds__(GS_BLOCK) void k_radix_scatter(const void *__restri
             }
             const uint32_t d = (key[r] >> shift) & mask;
             if (IN_FMT == GS_RADIX_KEYS) ok = ok && key[r] != GS_RADIX_SKIP;   // compaction: skipped records take no slot
-            unsigned long long peers = __ballot(ok);
-            for (int b = 0; b < bits; b++) {
-                const bool bit = (d >> b) & 1u;
-                const unsigned long long vb = __ballot(ok && bit);
-                peers &= bit ? vb : ~vb;
+            // match-any: which lanes of the wave hold the same digit this round.  Through LDS (<= 256 bins): every lane ORs
+            // its bit into the 64-bit word of its digit (one ds_or_b64 for the whole wave) and reads the word back -- two LDS
+            // operations instead of ~5 VALU instructions per digit bit (the scatter competes with the blend for VALU issue).
+            unsigned long long peers;
+            if (LDS_MATCH) {
+                if (ok) atomicOr(&s_match[w][d], 1ull << lane);
+                __builtin_amdgcn_wave_barrier();
+                peers = ok ? s_match[w][d] : 0ull;
+            } else {
+                peers = __ballot(ok);
+                for (int b = 0; b < bits; b++) {
+                    const bool bit = (d >> b) & 1u;
+                    const unsigned long long vb = __ballot(ok && bit);
+                    peers &= bit ? vb : ~vb;
+                }
             }
             const uint32_t before = __popcll(peers & lt), cnt = __popcll(peers);
             const uint32_t prev = ok ? s_cnt[w][d] : 0u;
-            __builtin_amdgcn_wave_barrier();                     // every peer has read before the leader bumps
-            if (ok && before == 0) s_cnt[w][d] = prev + cnt;
+            __builtin_amdgcn_wave_barrier();                     // every peer has read before the leader bumps / clears
+            if (ok && before == 0) { s_cnt[w][d] = prev + cnt; if (LDS_MATCH) s_match[w][d] = 0ull; }
             __builtin_amdgcn_wave_barrier();
             rank[r] = prev + before;
         }
@@ -228,6 +240,7 @@ int gs_launch_radix_pass(gs_ctx *ctx, const void *in, int in_fmt, void *out, int
     else hipLaunchKernelGGL(k_radix_hist<false>, G, B, 0, st, (const uint32_t *)in, n_ptr, shift, bits, ctx->hist);
     hipLaunchKernelGGL(k_radix_rowscan, dim3(1u << bits), B, 0, st, ctx->hist, n_ptr, totals);
 #define GS_SCATTER(I, O) do { if (bits <= 7) hipLaunchKernelGGL((k_radix_scatter<I, O, 128>), G, B, 0, st, in, out, n_ptr, shift, bits, zero_key, ctx->hist, totals); \
+                              else if (bits == 8) hipLaunchKernelGGL((k_radix_scatter<I, O, 256>), G, B, 0, st, in, out, n_ptr, shift, bits, zero_key, ctx->hist, totals); \
                               else hipLaunchKernelGGL((k_radix_scatter<I, O, GS_RADIX_MAX_BINS>), G, B, 0, st, in, out, n_ptr, shift, bits, zero_key, ctx->hist, totals); } while (0)
     if (in_fmt == GS_RADIX_PACKED && out_fmt == GS_RADIX_PACKED) GS_SCATTER(GS_RADIX_PACKED, GS_RADIX_PACKED);
     else if (in_fmt == GS_RADIX_PACKED && out_fmt == GS_RADIX_KEYS) GS_SCATTER(GS_RADIX_PACKED, GS_RADIX_KEYS);
