@@ -105,8 +105,8 @@ __global__ __launch_bounds__(GS_BLOCK) void k_radix_scatter(const void *__restri
 {
     constexpr bool KEYONLY = IN_FMT == GS_RADIX_KEYONLY && OUT_FMT == GS_RADIX_KEYONLY;
     __shared__ uint32_t s_cnt[4][MAXB];                         // per-wave digit counts -> local slot bases
-    constexpr bool LDS_MATCH = MAXB <= 256;                     // (the 512-bin instantiation keeps the ballots: 16 KiB more LDS cost it more)
-    __shared__ unsigned long long s_match[4][LDS_MATCH ? MAXB : 1];   // per wave and digit: lanes holding that digit in the current round
+    constexpr int MATCHB = MAXB <= 256 ? MAXB : 256;            // match words cover the low 8 digit bits; a 9th bit is refined by a ballot
+    __shared__ unsigned long long s_match[4][MATCHB];           // per wave and (low) digit: lanes holding it in the current round
     __shared__ uint32_t s_dbase[MAXB];                          // start of every digit's output run (whole array)
     __shared__ uint32_t s_gb[MAXB];                             // global position of local slot 0 of each digit (minus slot)
     __shared__ uint32_t s_k[GS_CHUNK];                          // the chunk in digit order: keys ...
@@ -129,7 +129,7 @@ __global__ __launch_bounds__(GS_BLOCK) void k_radix_scatter(const void *__restri
     for (uint32_t v = blockIdx.x; v < ((nchunks + 7u) & ~7u); v += gridDim.x) {
         uint32_t c;
         if (!gs_xcd_chunk(v, nchunks, c)) continue;
-        for (uint32_t i = threadIdx.x; i < 4 * MAXB; i += GS_BLOCK) { (&s_cnt[0][0])[i] = 0; if (LDS_MATCH) (&s_match[0][0])[i] = 0ull; }
+        for (uint32_t i = threadIdx.x; i < 4 * MAXB; i += GS_BLOCK) { (&s_cnt[0][0])[i] = 0; if (i < 4 * MATCHB) (&s_match[0][0])[i] = 0ull; }
         __syncthreads();
         uint32_t key[GS_IPT], val[GS_IPT], rank[GS_IPT];
 #pragma unroll
@@ -148,23 +148,19 @@ __global__ __launch_bounds__(GS_BLOCK) void k_radix_scatter(const void *__restri
             // match-any: which lanes of the wave hold the same digit this round.  Through LDS (<= 256 bins): every lane ORs
             // its bit into the 64-bit word of its digit (one ds_or_b64 for the whole wave) and reads the word back -- two LDS
             // operations instead of ~5 VALU instructions per digit bit (the scatter competes with the blend for VALU issue).
-            unsigned long long peers;
-            if (LDS_MATCH) {
-                if (ok) atomicOr(&s_match[w][d], 1ull << lane);
-                __builtin_amdgcn_wave_barrier();
-                peers = ok ? s_match[w][d] : 0ull;
-            } else {
-                peers = __ballot(ok);
-                for (int b = 0; b < bits; b++) {
-                    const bool bit = (d >> b) & 1u;
-                    const unsigned long long vb = __ballot(ok && bit);
-                    peers &= bit ? vb : ~vb;
-                }
+            const uint32_t dm = d & (uint32_t)(MATCHB - 1);
+            if (ok) atomicOr(&s_match[w][dm], 1ull << lane);
+            __builtin_amdgcn_wave_barrier();
+            unsigned long long peers = ok ? s_match[w][dm] : 0ull;
+            if (MAXB > MATCHB) {                                 // 9-bit digits: split the group by the top bit with one ballot
+                const bool top = (d >> 8) & 1u;
+                const unsigned long long vb = __ballot(ok && top);
+                peers &= top ? vb : ~vb;
             }
             const uint32_t before = __popcll(peers & lt), cnt = __popcll(peers);
             const uint32_t prev = ok ? s_cnt[w][d] : 0u;
             __builtin_amdgcn_wave_barrier();                     // every peer has read before the leader bumps / clears
-            if (ok && before == 0) { s_cnt[w][d] = prev + cnt; if (LDS_MATCH) s_match[w][d] = 0ull; }
+            if (ok && before == 0) { s_cnt[w][d] = prev + cnt; s_match[w][dm] = 0ull; }
             __builtin_amdgcn_wave_barrier();
             rank[r] = prev + before;
         }
