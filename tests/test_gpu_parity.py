@@ -815,3 +815,31 @@ def test_enqueue_threads_on_and_off_give_identical_frames_and_statistics(scene_s
     for a, b in zip(results[0][0], results[1][0]):
         assert np.array_equal(a, b)
     assert results[0][2:] == results[1][2:]
+
+
+def test_huge_splats_in_both_rounds_and_record_formats(scene_small):
+    """Splats touching thousands of tiles take the grid-wide slice path of k_emit (listed by k_project): with fat splats and
+    a tiny first-round share most of them are expanded in ROUND 1 (masked tiles, one thread per row), with a large share in
+    round 0 (flattened writes).  Every combination must give the single-round image, the oracle's fragment count included."""
+    rows = synth.make_splat_rows(6000, seed=31).reshape(-1, 32).copy()
+    rows[:, 12:24] = (rows[:, 12:24].copy().view("<f4") * np.float32(25.0)).view(np.uint8)     # enormous footprints
+    w, h = 1280, 720
+    cam = synth.index_html_camera(w, h, 77.0, capi=capi)
+    cs, cc, mats = oracle.pack(rows)
+    images = {}
+    for permille, wide in ((1000, 0), (2, 0), (2, 1), (500, 0), (500, 1)):
+        with capi.Context(0) as c:
+            c.set_option(capi.OPT_NEAR_PERMILLE, permille); c.set_option(capi.OPT_WIDE_PAIRS, wide)
+            c.push_splat(rows)
+            idx = c.sort(cam["view"])
+            images[(permille, wide)] = c.render(_params(cam))
+            if permille == 1000:
+                tc = c.download(capi.BUF_TILE_COUNT, idx.size, np.uint32, 1).reshape(-1)
+                assert (tc >= 1024).sum() >= 20                            # the scene really has huge splats
+                c.render(_params(cam, x0=600, x1=664, flags=capi.RENDER_COUNT_FRAGS))
+                mv, P, focal = _f32(cam)
+                _, _, frags = oracle.render(cs, cc, idx, mv, P, focal, w, h, x0=600, x1=664, want_f32=False)
+                assert c.stats()["n_frags"] == frags
+    ref = images[(1000, 0)]
+    for k, img in images.items():
+        assert np.array_equal(img, ref), k
