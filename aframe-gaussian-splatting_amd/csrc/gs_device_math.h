@@ -27,6 +27,8 @@ namespace gsm {
 // ECMAScript ToInt32, the `|0` at index.js:561.
 GS_HD int32_t js_toint32(double d)
 {
+    // in range: plain truncation (one conversion instruction); everything else (|d| >= 2^31, NaN, Inf) modular, below
+    if (d > -2147483649.0 && d < 2147483648.0) return (int32_t)d;
     union { double d; uint64_t u; } c; c.d = d;
     const int e = (int)((c.u >> 52) & 0x7FF);
     if (e == 0x7FF) return 0;                       // NaN, +-Inf -> 0
