@@ -35,8 +35,8 @@ W, H = 1920, 1080
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=120)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=480)
+    ap.add_argument("--warmup", type=int, default=24)
     ap.add_argument("--splats", type=int, default=None, help="override N (default: train.splat-shaped 1,048,576)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--size", default=None, help="override the viewport, e.g. 3840x2160 (default 1920x1080)")
