@@ -184,6 +184,9 @@ def main():
         for k in frames_used:
             frame(k)
             preroll += 1
+    for j in range(2 * LANES):                               # every pipeline lane allocated and warm, whatever W is
+        frame(frames_used[j % len(frames_used)], capi.RENDER_ASYNC)
+    sync()
     for i in range(args.warmup):
         frame(i, capi.RENDER_ASYNC)
     sync()
