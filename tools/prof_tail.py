@@ -8,8 +8,18 @@ tabs = [r[0] for r in db.execute("select name from sqlite_master where type in (
 disp = sorted([t for t in tabs if "kernel_dispatch" in t], key=len)[0]
 sym = sorted([t for t in tabs if "kernel_symbol" in t], key=len)[0]
 rows = list(db.execute("select s.kernel_name, d.start, d.end from %s d join %s s on d.kernel_id = s.id order by d.start desc limit %d" % (disp, sym, n)))
+def demangle(names):
+    import shutil, subprocess
+    tool = shutil.which("c++filt") or shutil.which("llvm-cxxfilt") or "/opt/rocm/lib/llvm/bin/llvm-cxxfilt"
+    try:
+        out = subprocess.run([tool], input="\n".join(names), capture_output=True, text=True, timeout=30).stdout.split("\n")
+        return dict(zip(names, out)) if len(out) >= len(names) else {}
+    except Exception:
+        return {}
+dm = demangle(sorted(set(r[0].replace(".kd", "") for r in rows)))
 agg = {}
 for name, s, e in rows:
+    name = dm.get(name.replace(".kd", ""), name)
     name = re.sub(r"\(anonymous namespace\)::", "", name); name = re.sub(r"^void ", "", name)
     m = re.match(r"([\w:<>, ]+?)\(", name); name = (m.group(1) if m else name)[:44]
     a = agg.setdefault(name, [0, 0.0]); a[0] += 1; a[1] += (e - s) / 1e3
