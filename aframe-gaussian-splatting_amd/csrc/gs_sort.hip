@@ -2,11 +2,11 @@
 //
 // Bit-exact contract: view depth, min/max and the bucket scale are IEEE f64 evaluated
 // left to right without FMA (library is built -ffp-contract=off); only the stored depth is rounded to
-// f32; the result is ordered by (bucket, original index).  Culled splats are carried through the two
-// stable radix passes with key 65536 (17-bit key = 8 + 9 bit digits) instead of being compacted first:
-// they sort behind every bucket, are not part of the first V' outputs, and store 0 as their value.  Splats whose bucket
-// falls outside [0,65535] (f32 rounding of the stored depth >> depth range) are dropped exactly like
-// the reference's out-of-bounds typed-array writes drop them: the tail [V',V) of the result is 0.
+// f32; the result is ordered by (bucket, original index).  The 17-bit key (16-bit bucket + one value for dropped
+// buckets) is sorted by two stable radix passes of 8 + 9 bits.  Culled splats leave in pass A (GS_RADIX_SKIP records are
+// neither counted nor scattered), so pass B runs over the V kept splats.  Kept splats whose bucket falls outside
+// [0,65535] (f32 rounding of the stored depth >> depth range) carry key 65536, sort behind every bucket and store 0 --
+// exactly like the reference's out-of-bounds typed-array writes leave 0 in the tail [V',V) of its result.
 #include "gs_internal.h"
 
 namespace {
