@@ -50,10 +50,16 @@ __global__ __launch_bounds__(GS_BLOCK) void k_radix_hist(const uint32_t *__restr
         if (!gs_xcd_chunk(v, nchunks, c)) continue;
         for (uint32_t d = threadIdx.x; d < nbins; d += GS_BLOCK) s_hist[d] = 0;
         __syncthreads();
+        uint32_t kk[GS_IPT];                                         // all loads first: their latencies overlap instead of adding up
 #pragma unroll
         for (int r = 0; r < GS_IPT; r++) {
             const uint32_t i = c * GS_CHUNK + r * GS_BLOCK + threadIdx.x;
-            if (i < n) atomicAdd(&s_hist[(keys[PACKED ? 2 * (size_t)i : i] >> shift) & mask], 1u);
+            kk[r] = i < n ? keys[PACKED ? 2 * (size_t)i : i] : 0u;
+        }
+#pragma unroll
+        for (int r = 0; r < GS_IPT; r++) {
+            const uint32_t i = c * GS_CHUNK + r * GS_BLOCK + threadIdx.x;
+            if (i < n) atomicAdd(&s_hist[(kk[r] >> shift) & mask], 1u);
         }
         __syncthreads();
         for (uint32_t d = threadIdx.x; d < nbins; d += GS_BLOCK) hist[d * nchunks + c] = s_hist[d];
@@ -133,9 +139,9 @@ __global__ __launch_bounds__(GS_BLOCK) void k_radix_scatter(const void *__restri
         __syncthreads();
         uint32_t key[GS_IPT], val[GS_IPT], rank[GS_IPT];
 #pragma unroll
-        for (int r = 0; r < GS_IPT; r++) {
+        for (int r = 0; r < GS_IPT; r++) {                            // all loads first: their latencies overlap
             const uint32_t i = c * GS_CHUNK + w * (GS_CHUNK / 4) + r * 64 + lane;
-            bool ok = i < n;
+            const bool ok = i < n;
             if (IN_FMT == GS_RADIX_PACKED) {
                 const uint2 kv = ok ? reinterpret_cast<const uint2 *>(in)[i] : make_uint2(0xFFFFFFFFu, 0u);
                 key[r] = kv.x; val[r] = kv.y;
@@ -143,6 +149,11 @@ __global__ __launch_bounds__(GS_BLOCK) void k_radix_scatter(const void *__restri
                 key[r] = ok ? reinterpret_cast<const uint32_t *>(in)[i] : 0xFFFFFFFFu;
                 val[r] = i;
             }
+        }
+#pragma unroll
+        for (int r = 0; r < GS_IPT; r++) {
+            const uint32_t i = c * GS_CHUNK + w * (GS_CHUNK / 4) + r * 64 + lane;
+            bool ok = i < n;
             const uint32_t d = (key[r] >> shift) & mask;
             if (IN_FMT == GS_RADIX_KEYS) ok = ok && key[r] != GS_RADIX_SKIP;   // compaction: skipped records take no slot
             // match-any: which lanes of the wave hold the same digit this round.  Through LDS (<= 256 bins): every lane ORs

@@ -34,11 +34,17 @@ __global__ __launch_bounds__(GS_BLOCK) void k_sort_depth(const float4 *__restric
     unsigned long long mn = ~0ull, mx = 0ull;
     uint32_t cnt = 0;
     for (uint32_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
+        float4 mm[GS_IPT];                                           // all loads first: their latencies overlap
+#pragma unroll
+        for (int r = 0; r < GS_IPT; r++) {
+            const uint32_t i = c * GS_CHUNK + r * GS_BLOCK + threadIdx.x;
+            mm[r] = i < n ? rows[i] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        }
 #pragma unroll
         for (int r = 0; r < GS_IPT; r++) {
             const uint32_t i = c * GS_CHUNK + r * GS_BLOCK + threadIdx.x;
             if (i < n) {
-                const float4 m = rows[i];
+                const float4 m = mm[r];
                 const double d = gsm::view_depth(u.view, m.x, m.y, m.z);
                 const bool inside = u.has_cutout ? gsm::in_cutout(u.cutout, m.x, m.y, m.z) : true;
                 const bool keep = gsm::sort_keep(d, m.w, inside);
@@ -98,6 +104,12 @@ __global__ __launch_bounds__(GS_BLOCK) void k_sort_bucket(const float *__restric
         if (!gs_xcd_chunk(v, nchunks, c)) continue;                // XCD-aware chunk order (the histogram rows are shared lines)
         s_hist[threadIdx.x] = 0;
         __syncthreads();
+        float dd[GS_IPT];                                            // all loads first: their latencies overlap
+#pragma unroll
+        for (int r = 0; r < GS_IPT; r++) {
+            const uint32_t i = c * GS_CHUNK + r * GS_BLOCK + threadIdx.x;
+            dd[r] = i < n ? depth[i] : INFINITY;
+        }
 #pragma unroll
         for (int r = 0; r < GS_IPT; r++) {
             const uint32_t i = c * GS_CHUNK + r * GS_BLOCK + threadIdx.x;
@@ -105,7 +117,7 @@ __global__ __launch_bounds__(GS_BLOCK) void k_sort_bucket(const float *__restric
                 // culled splats leave the sort here: GS_RADIX_SKIP records are not counted and not scattered by pass A.
                 // Kept splats whose bucket falls outside the table (the reference drops their writes) carry GS_CULLED_KEY:
                 // they sort behind every bucket and store 0, the reference's never-written tail slots
-                const float d = depth[i];
+                const float d = dd[r];
                 uint32_t k = GS_RADIX_SKIP;
                 if (d != INFINITY) {
                     const int32_t b = gsm::sort_bucket(d, mn, inv);
