@@ -282,7 +282,11 @@ __global__ __launch_bounds__(GS_BLOCK) void k_emit(const gsm::Projected *__restr
                                                    GsFrameUniforms u, void *__restrict__ pairs, const uint32_t *__restrict__ mask,
                                                    const GsControl *ctl, const uint32_t *__restrict__ huge_list)
 {
-    __shared__ uint32_t s_big[GS_BLOCK], s_bigoff[GS_BLOCK], s_mid[GS_BLOCK], s_midoff[GS_BLOCK];
+    // queues of the splats that are expanded cooperatively: 16-lane-group splats from the front, whole-wavefront splats
+    // from the back of the same arrays; their owner threads leave position, slot offset, projected record and row range
+    // here, so the expansion loops read LDS instead of paying a global round trip per splat
+    __shared__ uint32_t s_qj[GS_BLOCK], s_qoff[GS_BLOCK], s_qrows[GS_BLOCK];
+    __shared__ float s_qrec[GS_BLOCK][6];
     __shared__ uint32_t s_nbig, s_nmid, s_wave[4];
     __shared__ uint32_t s_hoff[GS_HUGE_ROWS + 1], s_ht0[GS_HUGE_ROWS], s_hbase;   // huge splat: row offsets / first tile of each row
     if (ctl->pair_overflow) return;
@@ -371,8 +375,13 @@ __global__ __launch_bounds__(GS_BLOCK) void k_emit(const gsm::Projected *__restr
                 // tile rows (four splats per wavefront pass), by a whole wavefront otherwise; huge ones were done in phase A
                 const uint2 rc = rect[j];
                 if (defer && cnt >= GS_HUGE_TILES && (rc.y >> 16) - (rc.x >> 16) < GS_HUGE_ROWS) { /* phase A */ }
-                else if ((rc.y >> 16) - (rc.x >> 16) < 16u) { const uint32_t q = atomicAdd(&s_nmid, 1u); s_mid[q] = j; s_midoff[q] = o; }
-                else { const uint32_t q = atomicAdd(&s_nbig, 1u); s_big[q] = j; s_bigoff[q] = o; }
+                else {
+                    const float4 *src = reinterpret_cast<const float4 *>(proj + j);
+                    const float4 a = src[0], b = src[1];
+                    const uint32_t q = ((rc.y >> 16) - (rc.x >> 16) < 16u) ? atomicAdd(&s_nmid, 1u) : GS_BLOCK - 1u - atomicAdd(&s_nbig, 1u);
+                    s_qj[q] = j; s_qoff[q] = o; s_qrows[q] = (rc.x >> 16) | (rc.y & 0xFFFF0000u);
+                    s_qrec[q][0] = a.x; s_qrec[q][1] = a.y; s_qrec[q][2] = a.z; s_qrec[q][3] = a.w; s_qrec[q][4] = b.x; s_qrec[q][5] = b.y;
+                }
             } else if (cnt) {
                 const float4 *src = reinterpret_cast<const float4 *>(proj + j);
                 const float4 a = src[0], b = src[1];
@@ -390,18 +399,16 @@ __global__ __launch_bounds__(GS_BLOCK) void k_emit(const gsm::Projected *__restr
             const uint32_t nmid = s_nmid;
             for (uint32_t mi = (uint32_t)w * 4u + ((uint32_t)lane >> 4); mi < ((nmid + 15u) & ~15u); mi += 16u) {   // 16 lanes per splat
                 const bool have = mi < nmid;
-                const uint32_t jm = have ? s_mid[mi] : 0u;
+                const uint32_t jm = have ? s_qj[mi] : 0u;
                 uint32_t t0 = 0, n = 0, nm = 0, ty = 0;
                 bool row_ok = false;
                 if (have) {
-                    const float4 *src = reinterpret_cast<const float4 *>(proj + jm);
-                    const float4 a = src[0], b = src[1];
-                    gsm::Projected p; p.cx = a.x; p.cy = a.y; p.ax = a.z; p.ay = a.w; p.bx = b.x; p.by = b.y;
+                    gsm::Projected p;
+                    p.cx = s_qrec[mi][0]; p.cy = s_qrec[mi][1]; p.ax = s_qrec[mi][2]; p.ay = s_qrec[mi][3]; p.bx = s_qrec[mi][4]; p.by = s_qrec[mi][5];
                     gsm::EllipseRows e;
                     gsm::ellipse_rows_setup(p, e);
-                    const uint2 rc = rect[jm];
-                    ty = (rc.x >> 16) + ((uint32_t)lane & 15u);
-                    row_ok = ty <= (rc.y >> 16);
+                    ty = (s_qrows[mi] & 0xFFFFu) + ((uint32_t)lane & 15u);
+                    row_ok = ty <= (s_qrows[mi] >> 16);
                     if (row_ok) {
                         gsm::splat_tile_row(p, e, (int)ty, u.H, u.x0, u.x1, t0, n);
                         nm = (ROUND == 1 && n) ? mask_count(mask + ty * u.mask_words, t0, n) : n;
@@ -410,19 +417,18 @@ __global__ __launch_bounds__(GS_BLOCK) void k_emit(const gsm::Projected *__restr
                 uint32_t rinc = nm;                                  // inclusive scan inside the 16-lane group
 #pragma unroll
                 for (int d = 1; d < 16; d <<= 1) { const uint32_t t = __shfl_up(rinc, d, 16); if ((lane & 15) >= d) rinc += t; }
-                if (row_ok) emit_run<ROUND, P32>(pairs, s_midoff[mi] + rinc - nm, ty, tiles_x, t0, n, jm, jm - j_lo, u.pair_jbits, mask + ty * u.mask_words);
+                if (row_ok) emit_run<ROUND, P32>(pairs, s_qoff[mi] + rinc - nm, ty, tiles_x, t0, n, jm, jm - j_lo, u.pair_jbits, mask + ty * u.mask_words);
             }
             const uint32_t nbig = s_nbig;
-            for (uint32_t bi = w; bi < nbig; bi += 4) {              // one wavefront per big splat
-                const uint32_t jb = s_big[bi];
-                const float4 *src = reinterpret_cast<const float4 *>(proj + jb);
-                const float4 a = src[0], b = src[1];
-                gsm::Projected p; p.cx = a.x; p.cy = a.y; p.ax = a.z; p.ay = a.w; p.bx = b.x; p.by = b.y;
+            for (uint32_t bq = w; bq < nbig; bq += 4) {              // one wavefront per big splat
+                const uint32_t bi = GS_BLOCK - 1u - bq;
+                const uint32_t jb = s_qj[bi];
+                gsm::Projected p;
+                p.cx = s_qrec[bi][0]; p.cy = s_qrec[bi][1]; p.ax = s_qrec[bi][2]; p.ay = s_qrec[bi][3]; p.bx = s_qrec[bi][4]; p.by = s_qrec[bi][5];
                 gsm::EllipseRows e;
                 gsm::ellipse_rows_setup(p, e);
-                const uint2 rc = rect[jb];
-                const uint32_t ty0 = rc.x >> 16, ty1 = rc.y >> 16;
-                uint32_t base = s_bigoff[bi];
+                const uint32_t ty0 = s_qrows[bi] & 0xFFFFu, ty1 = s_qrows[bi] >> 16;
+                uint32_t base = s_qoff[bi];
                 for (uint32_t tyb = ty0; tyb <= ty1; tyb += 64) {    // 64 tile rows per sweep
                     const uint32_t ty = tyb + lane;
                     uint32_t t0 = 0, n = 0, nm = 0;
