@@ -22,6 +22,16 @@
 
 namespace gsm {
 
+// ---------------------------------------------------------------- XCD-aware chunk order (see gs_internal.h)
+// virtual workgroup index v (grid a multiple of 8, grid-strided over [0, 8*ceil(nchunks/8))) -> chunk: XCD v % 8 takes the
+// (v % 8)-th contiguous eighth of the chunks.  Every chunk is produced exactly once; padding slots return false.
+GS_HD bool xcd_chunk(uint32_t v, uint32_t nchunks, uint32_t &chunk)
+{
+    const uint32_t per = (nchunks + 7u) >> 3;
+    chunk = (v & 7u) * per + (v >> 3);
+    return (v >> 3) < per && chunk < nchunks;
+}
+
 // ---------------------------------------------------------------- sort key (index.js:507-561)
 
 // ECMAScript ToInt32, the `|0` at index.js:561.

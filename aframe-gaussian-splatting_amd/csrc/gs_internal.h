@@ -173,12 +173,7 @@ static inline uint32_t gs_div_up(uint64_t a, uint64_t b) { return (uint32_t)((a 
 // halves of one 128-byte line -- sit in different L2s and each goes to HBM as a partial line.  Giving XCD k the k-th
 // contiguous eighth of the chunks lets those segments merge in one L2.  v = virtual workgroup index (grid a multiple of
 // 8, grid-strided); returns false for the padding slots of the last eighths.
-__device__ __forceinline__ bool gs_xcd_chunk(uint32_t v, uint32_t nchunks, uint32_t &chunk)
-{
-    const uint32_t per = (nchunks + 7u) >> 3;
-    chunk = (v & 7u) * per + (v >> 3);
-    return (v >> 3) < per && chunk < nchunks;
-}
+__device__ __forceinline__ bool gs_xcd_chunk(uint32_t v, uint32_t nchunks, uint32_t &chunk) { return gsm::xcd_chunk(v, nchunks, chunk); }
 
 // ---- gs_prims.hip
 // One stable LSD radix pass over n = *n_ptr items on digit (key >> shift) & (2^bits-1).

@@ -92,5 +92,8 @@ __attribute__((visibility("default")))
 int32_t hc_toint32(double d) { return gsm::js_toint32(d); }
 
 __attribute__((visibility("default")))
+int hc_xcd_chunk(uint32_t v, uint32_t nchunks, uint32_t *chunk) { return gsm::xcd_chunk(v, nchunks, *chunk) ? 1 : 0; }
+
+__attribute__((visibility("default")))
 void hc_js_exp(const double *x, size_t n, double *out) { for (size_t i = 0; i < n; i++) out[i] = gsm::js_exp(x[i]); }
 }

@@ -153,3 +153,19 @@ def test_product_js_exp_matches_the_engine(hc):
     hc.hc_js_exp(_p(x), x.size, _p(out))
     both_nan = np.isnan(out) & np.isnan(c["exp"])
     assert np.array_equal(out.view(np.uint64)[~both_nan], c["exp"].view(np.uint64)[~both_nan])
+
+
+def test_xcd_chunk_order_visits_every_chunk_once(hc):
+    """gsm::xcd_chunk (the radix kernels' chunk order): over the virtual indices [0, 8*ceil(n/8)) every chunk appears exactly
+    once, and the indices with the same v % 8 (one XCD) form one contiguous range of chunks."""
+    hc.hc_xcd_chunk.restype = C.c_int
+    hc.hc_xcd_chunk.argtypes = [C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]
+    for n in (1, 2, 7, 8, 9, 15, 16, 17, 63, 64, 65, 512, 937, 1000, 9766):
+        seen, by_xcd = [], {}
+        out = C.c_uint32(0)
+        for v in range(8 * ((n + 7) // 8)):
+            if hc.hc_xcd_chunk(v, n, C.byref(out)):
+                seen.append(out.value); by_xcd.setdefault(v % 8, []).append(out.value)
+        assert sorted(seen) == list(range(n)), n
+        for x, cs in by_xcd.items():
+            assert cs == list(range(cs[0], cs[0] + len(cs))), (n, x)
