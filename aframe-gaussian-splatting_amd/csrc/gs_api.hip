@@ -287,7 +287,12 @@ static int lane_push(gs_ctx *L, const GsLaneCmd &c)
     if (!L->worker) {
         L->worker = new (std::nothrow) GsLaneWorker();
         if (!L->worker) return GS_E_OOM;
-        L->worker->th = std::thread(lane_worker_main, L);
+        try { L->worker->th = std::thread(lane_worker_main, L); }
+        catch (...) {                                              // no exception crosses the C ABI
+            delete L->worker; L->worker = nullptr;
+            snprintf(L->err, sizeof L->err, "could not start the lane's enqueue thread");
+            return GS_E_OOM;
+        }
     }
     GsLaneWorker *w = L->worker;
     { std::lock_guard<std::mutex> lk(w->m); w->q.push_back(c); }
@@ -463,10 +468,10 @@ GS_API int gs_create(int device, gs_ctx **out)
     CREATE_HIP(hipSetDevice(device));
     CREATE_HIP(init_frame_resources(ctx));
     {
-        std::vector<double> tab(GS_POW10_ENTRIES);
-        gs_build_pow10_table(tab.data());
-        CREATE_HIP(hipMalloc((void **)&ctx->pow10tab, tab.size() * sizeof(double)));
-        CREATE_HIP(hipMemcpy(ctx->pow10tab, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice));
+        double tab[GS_POW10_ENTRIES];                           // a few KB: on the stack
+        gs_build_pow10_table(tab);
+        CREATE_HIP(hipMalloc((void **)&ctx->pow10tab, sizeof tab));
+        CREATE_HIP(hipMemcpy(ctx->pow10tab, tab, sizeof tab, hipMemcpyHostToDevice));
     }
 #undef CREATE_HIP
     *out = ctx;

@@ -176,7 +176,7 @@ GS_API void gs_scaled_size(int css_w, int css_h, double ratio, int *out_w, int *
 // Header parse + resolution of every property processPlyBuffer reads, with the reference's error messages in the
 // reference's order (index.js:606-607 header, :643 "<prop> not found").  Shared by the host converter below and the
 // HIP converter (gs_ply.hip).
-int gs_ply_plan(const void *bytes, size_t nbytes, gsm::PlyLayout *layout, size_t *nrows, size_t *data_start, char *err, size_t errlen)
+static int ply_plan(const void *bytes, size_t nbytes, gsm::PlyLayout *layout, size_t *nrows, size_t *data_start, char *err, size_t errlen)
 {
     const uint8_t *buf = (const uint8_t *)bytes;
     Header h;
@@ -217,7 +217,14 @@ int gs_ply_plan(const void *bytes, size_t nbytes, gsm::PlyLayout *layout, size_t
     return GS_OK;
 }
 
-GS_API int gs_ply_to_splat(const void *bytes, size_t nbytes, void *out_rows, size_t *out_nrows, char *err, size_t errlen)
+// no C++ exception crosses the C ABI: the header strings and the order arrays below are the only host allocations
+int gs_ply_plan(const void *bytes, size_t nbytes, gsm::PlyLayout *layout, size_t *nrows, size_t *data_start, char *err, size_t errlen)
+{
+    try { return ply_plan(bytes, nbytes, layout, nrows, data_start, err, errlen); }
+    catch (...) { return fail(err, errlen, GS_E_OOM, "out of host memory while reading the .ply header"); }
+}
+
+static int ply_to_splat(const void *bytes, size_t nbytes, void *out_rows, size_t *out_nrows, char *err, size_t errlen)
 {
     if (!bytes || !out_nrows) return fail(err, errlen, GS_E_BADARG, "gs_ply_to_splat: NULL argument");
     gsm::PlyLayout L;
@@ -245,6 +252,12 @@ GS_API int gs_ply_to_splat(const void *bytes, size_t nbytes, void *out_rows, siz
         memcpy(out + 8 * j, w, 32);
     }
     return GS_OK;
+}
+
+GS_API int gs_ply_to_splat(const void *bytes, size_t nbytes, void *out_rows, size_t *out_nrows, char *err, size_t errlen)
+{
+    try { return ply_to_splat(bytes, nbytes, out_rows, out_nrows, err, errlen); }
+    catch (...) { return fail(err, errlen, GS_E_OOM, "out of host memory while converting the .ply"); }
 }
 
 }  // extern "C"
