@@ -12,6 +12,8 @@ with capi.Context(0) as ctx:
     ctx.render(capi.make_params(cam["gs_mv"], cam["gs_proj"], 1920, 1080, focal_=cam["focal"]))
     t = ctx.download(capi.BUF_TILE_STATS, 8160, np.uint32, 2)
 steps, ln = t[:, 0].astype(np.int64), t[:, 1].astype(np.int64)
+if os.environ.get("GS_STATS_OUT"):
+    np.save(os.environ["GS_STATS_OUT"], t)
 print("tiles", len(ln), "pairs", ln.sum(), "staged", steps.sum(), "(%.1f%%)" % (100.0 * steps.sum() / ln.sum()))
 for q in (50, 90, 99, 99.9, 100):
     print("  p%-5s list len %6d   staged %6d" % (q, np.percentile(ln, q), np.percentile(steps, q)))
