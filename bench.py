@@ -75,6 +75,9 @@ def main():
     rows = synth.make_splat_rows(n_splats)
     ctx = capi.Context(local_rank)
     ctx.push_splat(rows)
+    depth = int(os.environ.get("GS_BENCH_DEPTH", "0"))       # experiment knob: frames in flight (library default 3)
+    if depth and not multi:
+        ctx.set_option(capi.OPT_PIPELINE_DEPTH, depth)
 
     # tile-aligned column strips
     x0, x1 = mg.strip_bounds(W, world, rank)
@@ -184,7 +187,7 @@ def main():
         for k in frames_used:
             frame(k)
             preroll += 1
-    for j in range(2 * LANES):                               # every pipeline lane allocated and warm, whatever W is
+    for j in range(2 * max(LANES, depth)):                   # every pipeline lane allocated and warm, whatever W is
         frame(frames_used[j % len(frames_used)], capi.RENDER_ASYNC)
     sync()
     for i in range(args.warmup):
