@@ -460,10 +460,15 @@ __global__ __launch_bounds__(GS_BLOCK) void k_tile_ranges(const void *__restrict
         for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < ntiles; t += gridDim.x * blockDim.x) range[t] = make_uint2(0u, 0u);
         return;
     }
+    // the empty tiles before the first and after the last listed tile (a cutout scene leaves thousands): by the whole grid
+    const uint32_t first = GS_PAIR_TILE(0), last = GS_PAIR_TILE(I - 1);
+    for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < ntiles; t += gridDim.x * blockDim.x) {
+        if (t < first) range[t] = make_uint2(0u, 0u);
+        else if (t > last) range[t] = make_uint2(I, I);
+    }
     for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < I; p += gridDim.x * blockDim.x) {
         const uint32_t k = GS_PAIR_TILE(p);
         if (p == 0) {
-            for (uint32_t t = 0; t < k; t++) range[t] = make_uint2(0u, 0u);
             range[k].x = 0;
         } else {
             const uint32_t kp = GS_PAIR_TILE(p - 1);
@@ -473,10 +478,7 @@ __global__ __launch_bounds__(GS_BLOCK) void k_tile_ranges(const void *__restrict
                 range[k].x = p;
             }
         }
-        if (p == I - 1) {
-            range[k].y = I;
-            for (uint32_t t = k + 1; t < ntiles; t++) range[t] = make_uint2(I, I);
-        }
+        if (p == I - 1) range[k].y = I;
     }
 }
 #undef GS_PAIR_TILE
