@@ -53,21 +53,34 @@ GS_HD int32_t js_toint32(double d)
     return (int32_t)lo;
 }
 
-// view-space depth of worker row (x,y,z,*)  (index.js:519-523): ((v0*x + v1*y) + v2*z) + v3 in f64
+// view-space depth of worker row (x,y,z,*)  (index.js:519-523): ((v0*x + v1*y) + v2*z) + v3 in f64.
+// The uniform arrives widened to f64 (exact): as kernel arguments the doubles sit in scalar registers, where the
+// float -> double conversions of 20 uniform values would otherwise occupy 40 vector registers per thread.
+GS_HD double view_depth(const double view[4], float x, float y, float z)
+{
+    return ((view[0] * (double)x + view[1] * (double)y) + view[2] * (double)z) + view[3];
+}
 GS_HD double view_depth(const float view[4], float x, float y, float z)
 {
-    return (((double)view[0] * (double)x + (double)view[1] * (double)y) + (double)view[2] * (double)z) + (double)view[3];
+    const double v[4] = { (double)view[0], (double)view[1], (double)view[2], (double)view[3] };
+    return view_depth(v, x, y, z);
 }
 
 // box cutout (index.js:492-500, 526-545); c = column-major object->unit-box matrix
-GS_HD bool in_cutout(const float *c, float xf, float yf, float zf)
+GS_HD bool in_cutout(const double *c, float xf, float yf, float zf)
 {
     const double x = xf, y = -(double)yf, z = zf;
-    const double w = 1.0 / ((((double)c[3] * x + (double)c[7] * y) + (double)c[11] * z) + (double)c[15]);
-    const double q0 = ((((double)c[0] * x + (double)c[4] * y) + (double)c[8] * z) + (double)c[12]) * w;
-    const double q1 = ((((double)c[1] * x + (double)c[5] * y) + (double)c[9] * z) + (double)c[13]) * w;
-    const double q2 = ((((double)c[2] * x + (double)c[6] * y) + (double)c[10] * z) + (double)c[14]) * w;
+    const double w = 1.0 / (((c[3] * x + c[7] * y) + c[11] * z) + c[15]);
+    const double q0 = (((c[0] * x + c[4] * y) + c[8] * z) + c[12]) * w;
+    const double q1 = (((c[1] * x + c[5] * y) + c[9] * z) + c[13]) * w;
+    const double q2 = (((c[2] * x + c[6] * y) + c[10] * z) + c[14]) * w;
     return !(q0 < -0.5 || q0 > 0.5 || q1 < -0.5 || q1 > 0.5 || q2 < -0.5 || q2 > 0.5);
+}
+GS_HD bool in_cutout(const float *c, float xf, float yf, float zf)
+{
+    double cd[16];
+    for (int i = 0; i < 16; i++) cd[i] = (double)c[i];
+    return in_cutout(cd, xf, yf, zf);
 }
 
 // keep test (index.js:548)

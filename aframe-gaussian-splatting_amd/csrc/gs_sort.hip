@@ -11,7 +11,14 @@
 
 namespace {
 
-struct SortUniforms { float view[4]; float cutout[16]; int has_cutout; };
+struct SortUniforms { double view[4]; double cutout[16]; int has_cutout; };   // widened on the host (exact): scalar registers
+// the depth kernel's chunking is its own (no histogram depends on it)
+#ifndef GS_DEPTH_IPT
+#define GS_DEPTH_IPT 4             // items per thread and pass: 52 vector registers, 8 waves per SIMD (8 items: 92, 5 waves)
+#endif
+#ifndef GS_DEPTH_GRID
+#define GS_DEPTH_GRID 2048u        // workgroups at most (one partial min/max/count slot each)
+#endif
 
 __device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v, int m)
 {
@@ -30,19 +37,20 @@ __global__ __launch_bounds__(GS_BLOCK) void k_sort_depth(const float4 *__restric
     __shared__ uint32_t s_cnt;
     if (threadIdx.x == 0) { s_min = ~0ull; s_max = 0ull; s_cnt = 0; }
     __syncthreads();
-    const uint32_t nchunks = (n + GS_CHUNK - 1) / GS_CHUNK;
+    constexpr uint32_t DCHUNK = GS_DEPTH_IPT * GS_BLOCK;         // this kernel's own chunking (no histogram depends on it)
+    const uint32_t nchunks = (n + DCHUNK - 1) / DCHUNK;
     unsigned long long mn = ~0ull, mx = 0ull;
     uint32_t cnt = 0;
     for (uint32_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
-        float4 mm[GS_IPT];                                           // all loads first: their latencies overlap
+        float4 mm[GS_DEPTH_IPT];                                     // all loads first: their latencies overlap
 #pragma unroll
-        for (int r = 0; r < GS_IPT; r++) {
-            const uint32_t i = c * GS_CHUNK + r * GS_BLOCK + threadIdx.x;
+        for (int r = 0; r < GS_DEPTH_IPT; r++) {
+            const uint32_t i = c * DCHUNK + r * GS_BLOCK + threadIdx.x;
             mm[r] = i < n ? rows[i] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         }
 #pragma unroll
-        for (int r = 0; r < GS_IPT; r++) {
-            const uint32_t i = c * GS_CHUNK + r * GS_BLOCK + threadIdx.x;
+        for (int r = 0; r < GS_DEPTH_IPT; r++) {
+            const uint32_t i = c * DCHUNK + r * GS_BLOCK + threadIdx.x;
             if (i < n) {
                 const float4 m = mm[r];
                 const double d = gsm::view_depth(u.view, m.x, m.y, m.z);
@@ -139,16 +147,19 @@ int gs_run_sort(gs_ctx *ctx, const float view[4], const float *cutout16)
 {
     const uint32_t n = (uint32_t)ctx->n;
     SortUniforms u;
-    memcpy(u.view, view, sizeof u.view);
+    for (int i = 0; i < 4; i++) u.view[i] = (double)view[i];
     u.has_cutout = cutout16 != nullptr;
-    if (cutout16) memcpy(u.cutout, cutout16, sizeof u.cutout); else memset(u.cutout, 0, sizeof u.cutout);
+    for (int i = 0; i < 16; i++) u.cutout[i] = cutout16 ? (double)cutout16[i] : 0.0;
 
     const uint32_t g = gs_radix_grid(n);                         // same chunking as the radix kernels (pre-filled histogram)
     GS_PROF_RECORD(ctx, 0);
-    hipLaunchKernelGGL(k_sort_depth, dim3(g), dim3(GS_BLOCK), 0, ctx->stream, ctx->sort_rows, n, u, ctx->depth, ctx->part_min,
+    uint32_t gd = gs_div_up(n, (uint32_t)(GS_DEPTH_IPT * GS_BLOCK));
+    if (gd < 1) gd = 1;
+    if (gd > GS_DEPTH_GRID) gd = GS_DEPTH_GRID;
+    hipLaunchKernelGGL(k_sort_depth, dim3(gd), dim3(GS_BLOCK), 0, ctx->stream, ctx->sort_rows, n, u, ctx->depth, ctx->part_min,
                        ctx->part_max, ctx->part_cnt);
     hipLaunchKernelGGL(k_sort_bucket, dim3(g), dim3(GS_BLOCK), 0, ctx->stream, ctx->depth, n, ctx->key_a, ctx->part_min,
-                       ctx->part_max, ctx->part_cnt, g, ctx->hist, ctx->ctl);
+                       ctx->part_max, ctx->part_cnt, gd, ctx->hist, ctx->ctl);
     GS_HIP(hipGetLastError());
     int rc = gs_launch_radix_pass(ctx, ctx->key_a, GS_RADIX_KEYS, ctx->kv_b, GS_RADIX_PACKED, &ctx->ctl->n_total, n, 0, 8, /*have_hist=*/true);
     if (rc != GS_OK) return rc;
