@@ -120,9 +120,9 @@ def main():
         if not multi:
             ctx.render_device(p, None)
             return
-        b = i % LANES
+        b = ctx.frame_lane()                                 # the strip buffer belongs to the lane: its stream orders gather and reuse
         ctx.render_device(p, strips[b].data_ptr())
-        owed.append((ctx.frame_lane(), b))
+        owed.append((b, b))
         gather_owed(LAG if (flags & capi.RENDER_ASYNC) else 0)
 
     def sync():
