@@ -14,9 +14,10 @@
 #include "gs_host_tables.h"
 
 static thread_local char g_create_err[512] = "";
+thread_local char *gs_tl_err = nullptr;
 
 #define CHECK_CTX(ctx) do { if (!(ctx)) return GS_E_BADARG; } while (0)
-#define FAIL(code, ...) do { snprintf(ctx->err, sizeof ctx->err, __VA_ARGS__); return (code); } while (0)
+#define FAIL(code, ...) do { snprintf(GS_ERRBUF(ctx), GS_ERRLEN, __VA_ARGS__); return (code); } while (0)
 
 template <typename T> static int dev_alloc(gs_ctx *ctx, T **p, size_t count)
 {
@@ -24,7 +25,7 @@ template <typename T> static int dev_alloc(gs_ctx *ctx, T **p, size_t count)
     if (!count) count = 1;
     hipError_t e = hipMalloc((void **)p, count * sizeof(T));
     if (e != hipSuccess) {
-        snprintf(ctx->err, sizeof ctx->err, "hipMalloc(%zu bytes) failed: %s", count * sizeof(T), hipGetErrorString(e));
+        snprintf(GS_ERRBUF(ctx), GS_ERRLEN, "hipMalloc(%zu bytes) failed: %s", count * sizeof(T), hipGetErrorString(e));
         return e == hipErrorOutOfMemory ? GS_E_OOM : GS_E_HIP;
     }
     return GS_OK;
@@ -245,7 +246,8 @@ struct GsLaneWorker {
     std::condition_variable cv_work, cv_idle;
     std::deque<GsLaneCmd> q;
     bool busy = false, stop = false;
-    int rc = GS_OK;                                            // first failure since the last drain (message in the lane's err)
+    int rc = GS_OK;                                            // first failure since the last drain ...
+    char err[GS_ERRLEN] = "";                                  // ... and its message: the worker never writes the lane's err itself
 };
 
 static int render_async_on_lane(gs_ctx *ctx, const GsFrameUniforms &u, void *device_rgba);
@@ -254,6 +256,8 @@ static void lane_worker_main(gs_ctx *L)
 {
     GsLaneWorker *w = L->worker;
     (void)hipSetDevice(L->device);
+    char scratch[GS_ERRLEN] = "";
+    gs_tl_err = scratch;                                       // GS_HIP / FAIL on this thread write here
     std::unique_lock<std::mutex> lk(w->m);
     for (;;) {
         w->cv_work.wait(lk, [&] { return w->stop || !w->q.empty(); });
@@ -265,7 +269,7 @@ static void lane_worker_main(gs_ctx *L)
         if (w->rc == GS_OK) rc = c.type == 0 ? gs_run_sort(L, c.view, c.has_cutout ? c.cutout : nullptr)
                                              : render_async_on_lane(L, c.u, c.device_rgba);
         lk.lock();
-        if (rc != GS_OK && w->rc == GS_OK) w->rc = rc;
+        if (rc != GS_OK && w->rc == GS_OK) { w->rc = rc; memcpy(w->err, scratch, sizeof w->err); }
         w->busy = false;
         if (w->q.empty()) w->cv_idle.notify_all();
     }
@@ -279,6 +283,7 @@ static int lane_drain(gs_ctx *L)
     std::unique_lock<std::mutex> lk(w->m);
     w->cv_idle.wait(lk, [&] { return w->q.empty() && !w->busy; });
     const int rc = w->rc; w->rc = GS_OK;
+    if (rc != GS_OK) memcpy(L->err, w->err, sizeof L->err);    // on the caller's thread, under the worker's mutex
     return rc;
 }
 
@@ -314,7 +319,7 @@ static void lane_stop_worker(gs_ctx *L)
 // ---------------------------------------------------------------- lanes (frame pipelining)
 
 #define LANE_HIP(L, call) do { hipError_t _e = (call); if (_e != hipSuccess) {                                             \
-        snprintf(ctx->err, sizeof ctx->err, "%s failed: %s (%s:%d)", #call, hipGetErrorString(_e), __FILE__, __LINE__);    \
+        snprintf(GS_ERRBUF(ctx), GS_ERRLEN, "%s failed: %s (%s:%d)", #call, hipGetErrorString(_e), __FILE__, __LINE__);    \
         return (_e == hipErrorOutOfMemory) ? GS_E_OOM : GS_E_HIP; } } while (0)
 
 // stream, control block, per-workgroup partial slots, pinned mirror: what every lane owns besides its scratch
@@ -392,7 +397,7 @@ static int get_lane(gs_ctx *ctx, int i, gs_ctx **out)
         L->parent = ctx; L->device = ctx->device;
         const hipError_t e = init_frame_resources(L);
         if (e != hipSuccess) {
-            snprintf(ctx->err, sizeof ctx->err, "creating pipeline lane %d failed: %s", i, hipGetErrorString(e));
+            snprintf(GS_ERRBUF(ctx), GS_ERRLEN, "creating pipeline lane %d failed: %s", i, hipGetErrorString(e));
             free_frame_resources(L); delete L;
             return e == hipErrorOutOfMemory ? GS_E_OOM : GS_E_HIP;
         }
@@ -515,7 +520,7 @@ static int append_device_rows(gs_ctx *ctx, const uint4 *rows_dev, size_t nrows)
 {
     int rc = gs_launch_pack(ctx, rows_dev, ctx->n, nrows);
     const hipError_t e = hipStreamSynchronize(ctx->stream);
-    if (rc == GS_OK && e != hipSuccess) { snprintf(ctx->err, sizeof ctx->err, "pack failed: %s", hipGetErrorString(e)); rc = GS_E_HIP; }
+    if (rc == GS_OK && e != hipSuccess) { snprintf(GS_ERRBUF(ctx), GS_ERRLEN, "pack failed: %s", hipGetErrorString(e)); rc = GS_E_HIP; }
     if (rc != GS_OK) return rc;
     ctx->n += nrows; ctx->renderable = true;
     for (int i = 0; i < GS_MAX_LANES; i++) if (ctx->lanes[i]) ctx->lanes[i]->have_sort = false;
@@ -536,7 +541,7 @@ GS_API int gs_push_splat(gs_ctx *ctx, const void *rows, size_t nrows)
     TRY(dev_alloc(ctx, &stage, nrows * 2));
     hipError_t e = hipMemcpyAsync(stage, rows, nrows * 32, hipMemcpyHostToDevice, ctx->stream);
     int rc = GS_OK;
-    if (e != hipSuccess) { snprintf(ctx->err, sizeof ctx->err, "upload failed: %s", hipGetErrorString(e)); rc = GS_E_HIP; }
+    if (e != hipSuccess) { snprintf(GS_ERRBUF(ctx), GS_ERRLEN, "upload failed: %s", hipGetErrorString(e)); rc = GS_E_HIP; }
     if (rc == GS_OK) rc = append_device_rows(ctx, stage, nrows);
     else (void)hipStreamSynchronize(ctx->stream);
     dev_free(stage);
@@ -583,7 +588,7 @@ static int ply_rows_to_device(gs_ctx *ctx, const void *bytes, size_t nbytes, uin
         try { host.resize(n * 32); } catch (...) { dev_free(rows); FAIL(GS_E_OOM, "out of host memory for %zu rows", n); }
         rc = gs_ply_to_splat(bytes, nbytes, host.data(), &n, ctx->err, sizeof ctx->err);
         if (rc == GS_OK && hipMemcpy(rows, host.data(), n * 32, hipMemcpyHostToDevice) != hipSuccess) {
-            snprintf(ctx->err, sizeof ctx->err, "upload failed"); rc = GS_E_HIP;
+            snprintf(GS_ERRBUF(ctx), GS_ERRLEN, "upload failed"); rc = GS_E_HIP;
         }
     }
     if (rc != GS_OK) { dev_free(rows); return rc; }
@@ -673,6 +678,10 @@ static int fill_uniforms(gs_ctx *ctx /* owner: options, adaptive share, scene */
     // focal = (viewport.w / 2) * |P[5]| in JS f64, uploaded as a float uniform (index.js:191-194)
     u.focal = p->focal > 0 ? p->focal : (float)(((double)p->fb_height / 2.0) * fabs((double)p->projection[5]));
     u.tiles_x = (p->x1 - p->x0 + GS_TILE - 1) / GS_TILE; u.tiles_y = (p->fb_height + GS_TILE - 1) / GS_TILE;
+    // the pair sort keys on the tile id in two digits of at most 9 bits (GS_RADIX_MAX_BINS): 2^18 tiles = 67 Mpixel per strip
+    if ((uint64_t)u.tiles_x * (uint64_t)u.tiles_y > (1ull << 18))
+        FAIL(GS_E_BADARG, "strip of %dx%d pixels has %llu tiles; at most 262144 (16x16-pixel tiles) are supported: render it in column strips",
+             p->x1 - p->x0, p->fb_height, (unsigned long long)u.tiles_x * (unsigned long long)u.tiles_y);
     memcpy(u.bg, p->background, sizeof u.bg);
     u.t_eps = ctx->t_eps; u.flags = p->flags; u.record_staged = ctx->record_staged;
     u.mask_words = (uint32_t)(u.tiles_x + 31) / 32;
@@ -832,6 +841,10 @@ GS_API int gs_sync(gs_ctx *ctx)
         any_missed |= missed; any_over |= over;
         if (over && L->ctl_host->max_total > want) want = L->ctl_host->max_total;
     }
+    if (any_over)                                                // one retry for all lanes: each gets room for the largest demand seen
+        for (int i = 0; i < GS_MAX_LANES; i++)
+            if (ctx->lanes[i] && ctx->lanes[i]->pair_cap)
+                TRY(lane_rc(ctx, ctx->lanes[i], gs_ensure_pair_capacity(ctx->lanes[i], (size_t)want + want / 4 + 1)));
     if (any_missed) FAIL(GS_E_RETRY, "an asynchronous frame skipped its second binning round but a tile had not saturated; "
                                      "the share of splats binned first was raised - render the frames since the previous gs_sync() again");
     if (any_over) FAIL(GS_E_RETRY, "an asynchronous frame needed %u pairs and overflowed the pair buffers; they were enlarged - "

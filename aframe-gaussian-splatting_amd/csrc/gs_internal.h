@@ -156,11 +156,18 @@ struct gs_ctx {
     gs_stats stats;
 };
 
+// Where a failure message goes.  A lane's enqueue thread (gs_api.hip) points gs_tl_err at ITS OWN buffer: lane 0 is the
+// owner context itself, and the caller's thread may be writing or reading ctx->err at the same moment; lane_drain()
+// copies the worker's message into the lane's err on the caller's thread.
+extern thread_local char *gs_tl_err;
+#define GS_ERRLEN 512
+#define GS_ERRBUF(ctx) (gs_tl_err ? gs_tl_err : (ctx)->err)
+
 #define GS_HIP(call)                                                                                     \
     do {                                                                                                 \
         hipError_t _e = (call);                                                                          \
         if (_e != hipSuccess) {                                                                          \
-            snprintf(ctx->err, sizeof ctx->err, "%s failed: %s (%s:%d)", #call, hipGetErrorString(_e),   \
+            snprintf(GS_ERRBUF(ctx), GS_ERRLEN, "%s failed: %s (%s:%d)", #call, hipGetErrorString(_e),   \
                      __FILE__, __LINE__);                                                                \
             return (_e == hipErrorOutOfMemory) ? GS_E_OOM : GS_E_HIP;                                    \
         }                                                                                                \

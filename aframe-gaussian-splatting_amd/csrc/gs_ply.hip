@@ -45,13 +45,13 @@ int gs_ply_rows_device(gs_ctx *ctx, const uint8_t *host_data, const gsm::PlyLayo
 {
     *had_nan = false;
     if (!n) return GS_OK;
-    if (n > 0x7FFFFFF0ull) { snprintf(ctx->err, sizeof ctx->err, "more than 2^31 PLY rows"); return GS_E_BADARG; }
+    if (n > 0x7FFFFFF0ull) { snprintf(GS_ERRBUF(ctx), GS_ERRLEN, "more than 2^31 PLY rows"); return GS_E_BADARG; }
     hipStream_t st = ctx->stream;
     uint8_t *data = nullptr; uint2 *kv_a = nullptr, *kv_b = nullptr; uint32_t *small = nullptr;
     const size_t raw = n * (size_t)L.row_bytes;
     int rc = GS_OK;
     auto cleanup = [&]() { (void)hipFree(data); (void)hipFree(kv_a); (void)hipFree(kv_b); (void)hipFree(small); };
-#define PLY_HIP(call) do { hipError_t _e = (call); if (_e != hipSuccess) { snprintf(ctx->err, sizeof ctx->err, "%s failed: %s", #call, hipGetErrorString(_e)); \
+#define PLY_HIP(call) do { hipError_t _e = (call); if (_e != hipSuccess) { snprintf(GS_ERRBUF(ctx), GS_ERRLEN, "%s failed: %s", #call, hipGetErrorString(_e)); \
                            cleanup(); return _e == hipErrorOutOfMemory ? GS_E_OOM : GS_E_HIP; } } while (0)
     PLY_HIP(hipMalloc(&data, raw + 8));
     PLY_HIP(hipMalloc(&small, 16));

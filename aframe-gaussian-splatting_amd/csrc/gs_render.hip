@@ -200,6 +200,7 @@ __global__ __launch_bounds__(GS_BLOCK) void k_pairs_check(GsControl *ctl, uint32
                                                           int last_round, uint32_t *__restrict__ mask, uint32_t mask_total_words)
 {
     __shared__ uint32_t s_vis, s_wave[4];
+    __shared__ unsigned long long s_total64[4];
     if (threadIdx.x == 0) s_vis = 0;
     __syncthreads();
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -217,13 +218,19 @@ __global__ __launch_bounds__(GS_BLOCK) void k_pairs_check(GsControl *ctl, uint32
     const uint32_t per = (nsp + GS_BLOCK - 1) / GS_BLOCK;
     const uint32_t lo = min(threadIdx.x * per, nsp), hi = min(lo + per, nsp);
     uint32_t s = 0;
-    for (uint32_t i = lo; i < hi; i++) s += spine[i];
+    unsigned long long s64 = 0;                                    // the demand itself in 64 bits: a sum past 2^32 must not wrap under pair_cap
+    for (uint32_t i = lo; i < hi; i++) { s += spine[i]; s64 += spine[i]; }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) s64 += ((unsigned long long)__shfl_xor((uint32_t)(s64 >> 32), m, 64) << 32) + __shfl_xor((uint32_t)s64, m, 64);
+    if (lane == 0) s_total64[w] = s64;
     const uint32_t inc = wave_incl_scan_u32(s, lane);
     if (lane == 63) s_wave[w] = inc;
     __syncthreads();
     uint32_t base = 0, total = 0;
 #pragma unroll
     for (int k = 0; k < 4; k++) { const uint32_t t = s_wave[k]; if (k < w) base += t; total += t; }
+    const unsigned long long total64 = s_total64[0] + s_total64[1] + s_total64[2] + s_total64[3];
+    if (total64 > 0xFFFFFFFFull) total = 0xFFFFFFFFu;              // saturate: larger than any pair_cap (<= 0xFFFF0000)
     uint32_t run = base + inc - s;
     for (uint32_t i = lo; i < hi; i++) { const uint32_t t = spine[i]; spine[i] = run; run += t; }
     if (threadIdx.x == 0) {
@@ -232,10 +239,13 @@ __global__ __launch_bounds__(GS_BLOCK) void k_pairs_check(GsControl *ctl, uint32
         ctl->j_lo = j_lo; ctl->j_hi = j_hi;                          // for k_tile_ranges / k_blend of this round
         ctl->scan_total = total;
         ctl->n_huge_round = ctl->n_huge; ctl->n_huge = 0;              // k_emit of this round expands them; the next k_project starts at 0
-        ctl->want_frame += total;
+        ctl->want_frame = (ctl->want_frame + total < total) ? 0xFFFFFFFFu : ctl->want_frame + total;   // (saturating)
         if (ctl->want_frame > ctl->max_total) ctl->max_total = ctl->want_frame;
+        // a round that does not fit, or that follows one of this frame that did not (k_emit wrote nothing then), bins nothing:
+        // the frame is re-rendered with larger buffers, and no kernel downstream may walk records that were never written
         if (total > pair_cap) { ctl->pair_overflow = 1; ctl->overflow_sticky = 1; ctl->n_pairs = 0; }
-        else { if (round == 0) ctl->pair_overflow = 0; ctl->n_pairs = total; }
+        else if (round == 0) { ctl->pair_overflow = 0; ctl->n_pairs = total; }
+        else ctl->n_pairs = ctl->pair_overflow ? 0u : total;
         ctl->n_visible += s_vis; ctl->n_pairs_frame += ctl->n_pairs;
         if (ROUND == 0 && near_count != 0xFFFFFFFFu) ctl->unsat_count = 0;   // counted by blend<0>, read by round 1
         if (last_round) {
@@ -704,7 +714,7 @@ __global__ __launch_bounds__(64) void k_blend(const uint2 *__restrict__ tile_ran
     }
 }
 
-int bits_for(uint32_t n) { int b = 1; while ((1u << b) < n) b++; return b; }
+int bits_for(uint32_t n) { int b = 1; while (b < 32 && (1u << b) < n) b++; return b; }
 
 // one round: project -> offsets -> emit -> stable sort by tile -> ranges -> blend.  Round 1 usually finds nothing to
 // do (every tile saturated), so it is launched on small grids: its kernels grid-stride when there is work.

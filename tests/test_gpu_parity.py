@@ -18,6 +18,28 @@ capi = pkg("capi")
 synth = pkg("synth")
 
 PIXEL_TOL_LSB = 1
+_REPORT = os.path.join(os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "gpurun_out",
+                       "pixel_parity.jsonl")
+
+
+def pix_check(tag, got, want, tol=PIXEL_TOL_LSB):
+    """per case the max-abs AND the 99.99th percentile of |RGBA8(HIP) - RGBA8(oracle)| over all channel
+    values are reported (stdout with -s, and one JSON line per case in gpurun_out/pixel_parity.jsonl, copied to profiles/),
+    and both are asserted against the tolerance."""
+    import json
+    d = np.abs(got.astype(np.int16) - want.astype(np.int16))
+    rep = {"case": tag, "shape": list(got.shape), "max_abs": int(d.max()) if d.size else 0,
+           "p9999": float(np.percentile(d, 99.99)) if d.size else 0.0, "nonzero_frac": float((d != 0).mean()) if d.size else 0.0}
+    print("pixel parity:", json.dumps(rep))
+    try:
+        os.makedirs(os.path.dirname(_REPORT), exist_ok=True)
+        with open(_REPORT, "a") as f:
+            f.write(json.dumps(rep) + "\n")
+    except OSError:
+        pass
+    assert rep["max_abs"] <= tol, "%s: max |dRGBA8| = %d" % (tag, rep["max_abs"])
+    assert rep["p9999"] <= tol
+    return rep
 
 
 @pytest.fixture(scope="module")
@@ -136,8 +158,7 @@ def test_pixels_match_oracle(ctx, scene_small, w, h, yaw):
     mv, P, focal = _f32(cam)
     want_u8, want_f32, want_frags = oracle.render(scene_small["cs"], scene_small["cc"], idx, mv, P, focal, w, h)
     got = ctx.render(_params(cam))
-    d = np.abs(got.astype(int) - want_u8.astype(int))
-    assert d.max() <= PIXEL_TOL_LSB, "max |dRGBA8| = %d" % d.max()
+    pix_check("small_%dx%d_yaw%g" % (w, h, yaw), got, want_u8)
     # without early termination the only difference is fp32 summation order
     got_all = ctx.render(_params(cam, flags=capi.RENDER_NO_EARLY_OUT))
     assert np.abs(got_all.astype(int) - want_u8.astype(int)).max() <= PIXEL_TOL_LSB
@@ -324,9 +345,27 @@ def test_render_1080p_strip_vs_oracle(ctx, scene_1m):
     mv, P, focal = _f32(cam)
     want, _, frags = oracle.render(cs, cc, idx, mv, P, focal, 1920, 1080, x0=880, x1=1040, want_f32=False)
     got = ctx.render(_params(cam, x0=880, x1=1040))
-    assert np.abs(got.astype(int) - want.astype(int)).max() <= PIXEL_TOL_LSB
+    pix_check("C2_1M_1920x1080_strip880-1040", got, want)
     ctx.render(_params(cam, x0=880, x1=1040, flags=capi.RENDER_COUNT_FRAGS))
     assert ctx.stats()["n_frags"] == frags
+
+
+def test_c1_train_1m_1280x720_strip_vs_oracle(ctx, scene_1m):
+    """C1: train.splat-shaped 1M splats at 1280x720 (BASELINE.json configs[0], the reference's own CPU-runnable case):
+    bit-exact sort, a 160-px column strip and its fragment count against the oracle, 5 strips == the full frame."""
+    cam = synth.index_html_camera(1280, 720, 100.0, capi=capi)
+    ctx.clear(); ctx.push_splat(scene_1m["rows"])
+    idx = ctx.sort(cam["view"])
+    assert np.array_equal(idx, oracle.sort(scene_1m["rows4"], cam["view"]))
+    cs, cc, _ = oracle.pack(scene_1m["rows"])
+    mv, P, focal = _f32(cam)
+    want, _, frags = oracle.render(cs, cc, idx, mv, P, focal, 1280, 720, x0=560, x1=720, want_f32=False)
+    full = ctx.render(_params(cam))
+    pix_check("C1_1M_1280x720_strip560-720", full[:, 560:720], want)
+    ctx.render(_params(cam, x0=560, x1=720, flags=capi.RENDER_COUNT_FRAGS))
+    assert ctx.stats()["n_frags"] == frags and frags > 1000000
+    parts = [ctx.render(_params(cam, x0=k * 256, x1=(k + 1) * 256)) for k in range(5)]
+    assert np.array_equal(np.concatenate(parts, axis=1), full)
 
 
 # ---------------------------------------------------------------- the larger BASELINE.json configurations
@@ -349,25 +388,40 @@ def test_c3_bicycle_6m_cutout_via_ply_loader(ctx):
     full = ctx.render(_params(cam))
     mv, P, focal = _f32(cam)
     ref, _, frags = oracle.render(cs, cc, idx, mv, P, focal, 1920, 1080, x0=900, x1=1060, want_f32=False)
-    assert np.abs(full[:, 900:1060].astype(int) - ref.astype(int)).max() <= PIXEL_TOL_LSB
+    pix_check("C3_ply1.5M_cutout_strip900-1060", full[:, 900:1060], ref)
     ctx.render(_params(cam, x0=900, x1=1060, flags=capi.RENDER_COUNT_FRAGS))
     assert ctx.stats()["n_frags"] == frags
 
 
 @pytest.mark.skipif(os.environ.get("GS_SKIP_SLOW") == "1", reason="large configs")
-def test_c3_six_million_sort_and_render_properties(ctx):
+def test_c3_six_million_cutout_strip_vs_oracle_and_properties(ctx):
+    """C3 at its full size: 6,291,456 splats, 1920x1080, cutoutEntity box.  Sort bit-exact (with and without the cutout);
+    the cutout frame's busiest 160-px column strip and its fragment count against the oracle; strips == full frame."""
     rows = synth.make_splat_rows(synth.N_BICYCLE, seed=synth.SEED_BASE + 3)
-    _, _, mats = oracle.pack(rows)
+    cs, cc, mats = oracle.pack(rows)
     ctx.clear(); ctx.push_splat(rows)
     cam = synth.cutout_demo_camera(1920, 1080, 75.0, capi=capi)
-    rows4 = np.ascontiguousarray(mats[:, 12:16])
-    assert np.array_equal(ctx.sort(cam["view"], cam["cutout"]), oracle.sort(rows4, cam["view"], cam["cutout"]))
+    rows4 = np.ascontiguousarray(mats[:, 12:16]); del mats
+    idx = ctx.sort(cam["view"], cam["cutout"])
+    assert np.array_equal(idx, oracle.sort(rows4, cam["view"], cam["cutout"]))
+    fullc = ctx.render(_params(cam))
+    assert ctx.stats()["n_pairs"] > 100000
+    cols = np.flatnonzero(fullc[:, :, :3].any(axis=(0, 2)))               # columns the cut-out scene reaches
+    assert cols.size > 160
+    xa = int(min(max(0, (cols[0] + cols[-1]) // 2 - 80) // 16 * 16, 1920 - 160))
+    mv, P, focal = _f32(cam)
+    ref, _, frags = oracle.render(cs, cc, idx, mv, P, focal, 1920, 1080, x0=xa, x1=xa + 160, want_f32=False)
+    pix_check("C3_6M_cutout_1920x1080_strip%d-%d" % (xa, xa + 160), fullc[:, xa:xa + 160], ref)
+    ctx.render(_params(cam, x0=xa, x1=xa + 160, flags=capi.RENDER_COUNT_FRAGS))
+    assert ctx.stats()["n_frags"] == frags and frags > 100000
+    partsc = [ctx.render(_params(cam, x0=k * 240, x1=(k + 1) * 240)) for k in range(8)]
+    assert np.array_equal(np.concatenate(partsc, axis=1), fullc)
     cam2 = synth.index_html_camera(1920, 1080, 75.0, capi=capi)
     assert np.array_equal(ctx.sort(cam2["view"]), oracle.sort(rows4, cam2["view"]))
     full = ctx.render(_params(cam2))
     parts = [ctx.render(_params(cam2, x0=k * 480, x1=(k + 1) * 480)) for k in range(4)]
     assert np.array_equal(np.concatenate(parts, axis=1), full)
-    assert ctx.stats()["n_pairs"] > 1000000
+    assert ctx.stats()["n_pairs"] > 100000                # (of the last strip; the share binned in round 0 adapts)
 
 
 @pytest.mark.skipif(os.environ.get("GS_SKIP_SLOW") == "1", reason="large configs")
@@ -383,13 +437,16 @@ def test_c4_xr_stereo_and_c5_4k_strip(ctx, scene_1m):
     cs, cc, _ = oracle.pack(scene_1m["rows"])
     mv, P, focal = _f32(l)
     ref, _, _ = oracle.render(cs, cc, idx, mv, P, focal, 1032, 1104, x0=500, x1=600, want_f32=False)
-    assert np.abs(o0[:, 500:600].astype(int) - ref.astype(int)).max() <= PIXEL_TOL_LSB
+    pix_check("C4_xr_left_eye_1032x1104_strip500-600", o0[:, 500:600], ref)
+    mv, P, focal = _f32(r)
+    ref, _, _ = oracle.render(cs, cc, idx, mv, P, focal, 1032, 1104, x0=432, x1=528, want_f32=False)
+    pix_check("C4_xr_right_eye_1032x1104_strip432-528", o1[:, 432:528], ref)
     cam = synth.index_html_camera(3840, 2160, 200.0, capi=capi)
     idx = ctx.sort(cam["view"])
     strip = ctx.render(_params(cam, x0=3 * 480, x1=4 * 480))
     mv, P, focal = _f32(cam)
     ref, _, _ = oracle.render(cs, cc, idx, mv, P, focal, 3840, 2160, x0=3 * 480, x1=3 * 480 + 96, want_f32=False)
-    assert np.abs(strip[:, :96].astype(int) - ref.astype(int)).max() <= PIXEL_TOL_LSB
+    pix_check("1M_3840x2160_strip1440-1536", strip[:, :96], ref)
     full = ctx.render(_params(cam))
     assert np.array_equal(full[:, 3 * 480:4 * 480], strip)
 
@@ -464,12 +521,12 @@ def test_two_round_occlusion_aware_binning_is_bit_identical(w, h, n, seed):
             assert np.array_equal(c2.render(_params(cam)), ref)
 
 
-@pytest.mark.skipif(os.environ.get("GS_RUN_20M") != "1", reason="C5-size smoke (20M splats, 3840x2160): set GS_RUN_20M=1")
 def test_c5_twenty_million_splats_4k():
     """C5: synthetic 20M gaussians at 3840x2160: bit-exact sort vs the oracle, 8 column strips == full frame,
-    a 64-px strip vs the oracle."""
+    a 64-px strip and its fragment count vs the oracle.  (About a minute: most of it is generating and packing the
+    20,971,520 input rows on the host.)"""
     n = synth.N_20M
-    rows = synth.make_splat_rows(n, seed=synth.SEED_BASE + 5, order_by_importance=False)
+    rows = synth.make_splat_rows_fast(n, seed=synth.SEED_BASE + 5)
     cs, cc, mats = oracle.pack(rows)
     rows4 = np.ascontiguousarray(mats[:, 12:16]); del mats
     cam = synth.index_html_camera(3840, 2160, 15.0, capi=capi)
@@ -484,8 +541,10 @@ def test_c5_twenty_million_splats_4k():
         parts = [c5.render(_params(cam, x0=k * 480, x1=(k + 1) * 480)) for k in range(8)]
         assert np.array_equal(np.concatenate(parts, axis=1), full)
         mv, P, focal = _f32(cam)
-        ref, _, _ = oracle.render(cs, cc, idx, mv, P, focal, 3840, 2160, x0=1900, x1=1964, want_f32=False)
-        assert np.abs(full[:, 1900:1964].astype(int) - ref.astype(int)).max() <= PIXEL_TOL_LSB
+        ref, _, frags = oracle.render(cs, cc, idx, mv, P, focal, 3840, 2160, x0=1900, x1=1964, want_f32=False)
+        pix_check("C5_20M_3840x2160_strip1900-1964", full[:, 1900:1964], ref)
+        c5.render(_params(cam, x0=1900, x1=1964, flags=capi.RENDER_COUNT_FRAGS))
+        assert c5.stats()["n_frags"] == frags
         print("C5 stats:", st)
 
 
