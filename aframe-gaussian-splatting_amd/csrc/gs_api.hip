@@ -36,26 +36,32 @@ template <typename T> static void dev_free(T *&p) { if (p) { (void)hipFree(p); p
 static int lane_drain(gs_ctx *L);
 static void lane_stop_worker(gs_ctx *L);
 
+static int ensure_radix_tables(gs_ctx *ctx, size_t items)
+{
+    // a histogram row per radix chunk (H) and per group of chunks (G); for long inputs the digit totals + one exclusive row
+    // per super-group
+    const size_t chunks = (gs_div_up(items, GS_CHUNK) + 8 + GS_RADIX_SUB - 1) / GS_RADIX_SUB * GS_RADIX_SUB;
+    const size_t groups = chunks / GS_RADIX_SUB + 8;
+    const size_t need_hist = (size_t)GS_RADIX_MAX_BINS * (chunks + groups);
+    if (chunks > ctx->hist_chunks || need_hist > ctx->hist_cap) {
+        dev_free(ctx->hist); ctx->hist_cap = 0; ctx->hist_chunks = 0;
+        TRY(dev_alloc(ctx, &ctx->hist, need_hist));
+        ctx->hist_cap = need_hist; ctx->hist_chunks = chunks;
+    }
+    const size_t need_aux = (size_t)GS_RADIX_MAX_BINS * (2 + gs_div_up(groups, GS_RADIX_SUPER));
+    if (need_aux > ctx->aux_cap) { dev_free(ctx->radix_aux); TRY(dev_alloc(ctx, &ctx->radix_aux, need_aux)); ctx->aux_cap = need_aux; }
+    return GS_OK;
+}
+
 static int ensure_scan_scratch(gs_ctx *ctx)
 {
-    // histogram table: bins x chunks for the larger of the two sorts; spine: one word per 2048 scanned words
-    size_t need_hist = (size_t)GS_RADIX_MAX_BINS * (gs_div_up(ctx->scratch_cap, GS_CHUNK) + 1);
-    const size_t ph = (size_t)GS_RADIX_MAX_BINS * (gs_div_up(ctx->pair_cap, GS_CHUNK) + 1);
-    if (ph > need_hist) need_hist = ph;
-    if (need_hist > ctx->hist_cap) { dev_free(ctx->hist); TRY(dev_alloc(ctx, &ctx->hist, need_hist)); ctx->hist_cap = need_hist; }
-    size_t need_spine = gs_div_up(need_hist, GS_CHUNK) + gs_div_up(ctx->scratch_cap, GS_BLOCK) + GS_RADIX_MAX_BINS + 16;   // project/emit chunks of 256
+    TRY(ensure_radix_tables(ctx, ctx->scratch_cap > ctx->pair_cap ? ctx->scratch_cap : ctx->pair_cap));   // the larger of the two sorts
+    const size_t need_spine = gs_div_up(ctx->scratch_cap, GS_BLOCK) + 16;   // project/emit chunks of 256 splats
     if (need_spine > ctx->spine_cap) { dev_free(ctx->spine); TRY(dev_alloc(ctx, &ctx->spine, need_spine)); ctx->spine_cap = need_spine; }
     return GS_OK;
 }
 
-int gs_ensure_radix_scratch(gs_ctx *ctx, size_t items)
-{
-    const size_t need_hist = (size_t)GS_RADIX_MAX_BINS * (gs_div_up(items, GS_CHUNK) + 1);
-    if (need_hist > ctx->hist_cap) { dev_free(ctx->hist); TRY(dev_alloc(ctx, &ctx->hist, need_hist)); ctx->hist_cap = need_hist; }
-    const size_t need_spine = GS_RADIX_MAX_BINS + 16;
-    if (need_spine > ctx->spine_cap) { dev_free(ctx->spine); TRY(dev_alloc(ctx, &ctx->spine, need_spine)); ctx->spine_cap = need_spine; }
-    return GS_OK;
-}
+int gs_ensure_radix_scratch(gs_ctx *ctx, size_t items) { return ensure_radix_tables(ctx, items); }
 
 int gs_ensure_pair_capacity(gs_ctx *ctx, size_t pairs)
 {
@@ -188,6 +194,10 @@ static int collect_status(gs_ctx *lane, bool *overflowed)
     lane->stats.n_sorted = c->n_kept; lane->stats.n_visible = c->n_visible; lane->stats.n_pairs = c->n_pairs_frame;
     lane->stats.acc_frames = c->acc_frames; lane->stats.acc_sorted = c->acc_sorted; lane->stats.acc_visible = c->acc_visible;
     lane->stats.acc_pairs = c->acc_pairs;
+    if (c->n_pairs_frame) {                                     // sizing hint for the next frames' pair sort (any lane's worker may read it)
+        const uint64_t h = (uint64_t)c->n_pairs_frame + c->n_pairs_frame / 4 + GS_CHUNK;
+        __atomic_store_n(&ctx->pair_hint, h > 0xFFFFFFFFull ? 0u : (uint32_t)h, __ATOMIC_RELAXED);
+    }
     // Adapt the share of splats binned in round 0.  An "event" = a frame whose round 0 left tiles unsaturated (round 1
     // re-binned for them): the share grows x1.5 and will never again shrink below 1.3 x the share that failed; without
     // events it shrinks 10 % per collected frame until the first event, 2 % afterwards.  After 16 clean frames round 1 is not even launched (11 empty kernels
@@ -350,7 +360,7 @@ static void free_frame_resources(gs_ctx *c)
     lane_stop_worker(c);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     dev_free(c->depth); dev_free(c->key_a); dev_free(c->kv_b); dev_free(c->val_a);
-    dev_free(c->hist); dev_free(c->spine);
+    dev_free(c->hist); dev_free(c->radix_aux); dev_free(c->spine);
     dev_free(c->proj); dev_free(c->rect); dev_free(c->tile_count); dev_free(c->zwin);
     dev_free(c->pair_a); dev_free(c->pair_b);
     dev_free(c->tile_range); dev_free(c->fb); dev_free(c->ctl); dev_free(c->state); dev_free(c->unsat_mask);
@@ -501,7 +511,7 @@ GS_API int gs_clear(gs_ctx *ctx)
     CHECK_CTX(ctx);
     GS_HIP(hipSetDevice(ctx->device));
     TRY(drain_all(ctx));
-    ctx->n = 0; ctx->renderable = true;
+    ctx->n = 0; ctx->renderable = true; ctx->pair_hint = 0;
     ctx->near_frac = 0.25f; ctx->near_floor = 0.0f; ctx->clean_frames = 0; ctx->skip_hold = 0; ctx->single_round_frames = 0;
     for (int i = 0; i < GS_MAX_LANES; i++) {
         gs_ctx *L = ctx->lanes[i];

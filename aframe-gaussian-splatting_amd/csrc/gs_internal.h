@@ -11,11 +11,17 @@
 #define GS_TILE 16                 // screen tile edge (pixels): 16x16 = one 256-thread workgroup
 #define GS_BLOCK 256               // threads per workgroup everywhere (4 wavefronts of 64)
 #ifndef GS_CHUNK
-#define GS_CHUNK 2048              // items per workgroup pass in streaming kernels
+#define GS_CHUNK 4096              // items per radix chunk = one histogram row (and per workgroup pass of the kernels that pre-fill rows)
 #endif
-#define GS_IPT (GS_CHUNK / GS_BLOCK) // items per thread and pass
-#define GS_SCAN_TILE 2048          // values per pass of the one-workgroup-per-row scan (8 per thread)
+#define GS_IPT (GS_CHUNK / GS_BLOCK) // items per thread and pass of a 256-thread producer kernel
+#define GS_RADIX_WAVES 8           // wavefronts per workgroup of the radix kernels (512 threads, 8 items per thread)
+#define GS_RADIX_THREADS (64 * GS_RADIX_WAVES)
 #define GS_RADIX_MAX_BINS 512      // up to 9-bit digits (depth key = 17 bits = 8 + 9)
+#define GS_RADIX_SUB 4             // chunks per histogram group: the rows are kept per chunk (H) and per group (G)
+#define GS_RADIX_SUPER 32          // G rows per super-group of the two-level offsets (long inputs)
+#ifndef GS_RADIX_BRUTE_ROWS
+#define GS_RADIX_BRUTE_ROWS 512    // up to this many G rows (8 M items) every scatter workgroup sums all of them itself
+#endif
 #define GS_PROF_RING 256           // frames of HIP-event timings kept in flight
 #define GS_PROF_EVENTS 7
 #define GS_MAX_PART 8192           // upper bound on the grid of any kernel that writes per-workgroup partials
@@ -113,8 +119,10 @@ struct gs_ctx {
     bool have_sort;
 
     // radix / scan scratch
-    uint32_t *hist;  size_t hist_cap;       // [bins][chunks]
-    uint32_t *spine; size_t spine_cap;      // per-scan-chunk sums
+    uint32_t *hist;  size_t hist_cap;       // digit-histogram rows: H[chunks][bins], then (gs_radix_group_rows) G[chunks / GS_RADIX_SUB][bins]
+    size_t hist_chunks;                     // chunks the H part is sized for
+    uint32_t *radix_aux; size_t aux_cap;    // long radix inputs: digit totals [GS_RADIX_MAX_BINS], then one exclusive row per super-group
+    uint32_t *spine; size_t spine_cap;      // per-256-splat totals of tiles touched (project -> emit)
 
     // render scratch
     gsm::Projected *proj;          // V records, sorted order
@@ -124,6 +132,7 @@ struct gs_ctx {
     float *zwin;                   // V window depth of each sorted splat (written only while a scene depth buffer is set)
     float *scene_depth; uint32_t *scene_rgba; int scene_w, scene_h;   // gs_set_scene
     uint2 *pair_a, *pair_b; size_t pair_cap;   // (tile id, sorted position) records, ping-pong
+    uint32_t pair_hint;                     // owner: pairs a frame is expected to bin (1.25 x the last collected frame's; 0 = unknown)
     uint2 *tile_range; size_t tile_cap;     // per tile [start,end) into the sorted pair list
     uint8_t *fb; size_t fb_cap;             // RGBA8 strip
     float4 *state; size_t state_cap;        // per tile 64 lanes x 4 float4: (T, r, g, b) of each lane's 4 pixels, round 0 -> 1
@@ -187,16 +196,19 @@ __device__ __forceinline__ bool gs_xcd_chunk(uint32_t v, uint32_t nchunks, uint3
 // record formats: GS_RADIX_KEYS    in: a plain key array whose value is the element index; out: the values alone (final pass)
 //                 GS_RADIX_PACKED  (key,val) uint2 records
 //                 GS_RADIX_KEYONLY 4-byte records that are their own payload (in and out)
-// have_hist: the caller's producer kernel already filled ctx->hist for this digit (skips the histogram launch).
+// max_n:     upper bound of *n_ptr (sizes the scratch); hint_n: the count to expect (0 = max_n) -- it picks the grid and
+//            between one- and two-level offsets, nothing that affects the result.
+// have_hist: the caller's producer kernel already filled ctx->hist[chunk][digit] for this digit (skips the histogram launch).
 // zero_key:  value-only output stores 0 for items with this key (0xFFFFFFFF = never).
 #define GS_RADIX_KEYS 0
 #define GS_RADIX_PACKED 1
 #define GS_RADIX_KEYONLY 2
 #define GS_RADIX_SKIP 0xFFFFFFFFu   // GS_RADIX_KEYS input only: a record with this key is neither counted nor scattered (compaction)
 int gs_launch_radix_pass(gs_ctx *ctx, const void *in, int in_fmt, void *out, int out_fmt, const uint32_t *n_ptr,
-                         uint32_t max_n, int shift, int bits, bool have_hist = false, uint32_t zero_key = 0xFFFFFFFFu);
+                         uint32_t max_n, uint32_t hint_n, int shift, int bits, bool have_hist = false, uint32_t zero_key = 0xFFFFFFFFu);
 // grid used by the radix kernels for max_n items (a producer that pre-fills the histogram must use the same chunking)
 uint32_t gs_radix_grid(uint32_t max_n);
+static inline uint32_t *gs_radix_group_rows(gs_ctx *ctx) { return ctx->hist + ctx->hist_chunks * GS_RADIX_MAX_BINS; }   // the G rows
 // ---- gs_pack.hip
 int gs_launch_pack(gs_ctx *ctx, const uint4 *rows_dev, size_t first, size_t nrows);
 // ---- gs_sort.hip

@@ -68,7 +68,7 @@ int gs_ply_rows_device(gs_ctx *ctx, const uint8_t *host_data, const gsm::PlyLayo
         if (rc != GS_OK) { cleanup(); return rc; }
         hipLaunchKernelGGL(k_ply_keys, dim3(g), dim3(GS_BLOCK), 0, st, data, L, n32, kv_a, small + 1);
         for (int pass = 0; pass < 4 && rc == GS_OK; pass++)
-            rc = gs_launch_radix_pass(ctx, (pass & 1) ? kv_b : kv_a, GS_RADIX_PACKED, (pass & 1) ? kv_a : kv_b, GS_RADIX_PACKED, small, n32, 8 * pass, 8);
+            rc = gs_launch_radix_pass(ctx, (pass & 1) ? kv_b : kv_a, GS_RADIX_PACKED, (pass & 1) ? kv_a : kv_b, GS_RADIX_PACKED, small, n32, n32, 8 * pass, 8);
         if (rc != GS_OK) { cleanup(); return rc; }
         order = kv_a;                                                // 4 passes: back in kv_a
     }

@@ -729,7 +729,10 @@ int run_round(gs_ctx *ctx, const GsFrameUniforms &u, uint8_t *out, bool last_rou
     if (ROUND == 1 && g > small) g = small;
     // round 0 of a two-round frame covers at most near_count splats: no point in launching workgroups for the rest
     if (ROUND == 0 && u.near_count != 0xFFFFFFFFu) { const uint32_t gn = gs_div_up(u.near_count < Vmax ? u.near_count : Vmax, GS_BLOCK); if (gn < g) g = gn ? gn : 1; }
-    const uint32_t pc = ROUND == 1 ? (uint32_t)(small * GS_CHUNK) : (uint32_t)ctx->pair_cap;      // grid hint for the radix kernels
+    const uint32_t pc = (uint32_t)ctx->pair_cap;
+    // what the pair sort should expect (grid, one- or two-level offsets): round 1 usually finds nothing; round 0 about what
+    // the last collected frames binned (0 = not known yet: the capacity)
+    const uint32_t ph = ROUND == 1 ? (uint32_t)(small * GS_CHUNK) : __atomic_load_n(&gs_root(ctx)->pair_hint, __ATOMIC_RELAXED);
     hipLaunchKernelGGL(k_project<ROUND>, dim3(g), dim3(GS_BLOCK), 0, st, ctx->sorted, ctx->splat, u, ctx->proj, ctx->rect,
                        ctx->tile_count, ctx->spine, ctx->part_vis, ctx->unsat_mask, ctx->zwin, ctx->ctl, ctx->huge_list);
     GS_HIP(hipGetLastError());
@@ -752,14 +755,14 @@ int run_round(gs_ctx *ctx, const GsFrameUniforms &u, uint8_t *out, bool last_rou
     const int fmt = p32 ? GS_RADIX_KEYONLY : GS_RADIX_PACKED, sh = p32 ? jb : 0;
     const void *fpairs;
     if (tb <= 9) {
-        rc = gs_launch_radix_pass(ctx, ctx->pair_a, fmt, ctx->pair_b, fmt, &ctx->ctl->n_pairs, pc, sh, tb);
+        rc = gs_launch_radix_pass(ctx, ctx->pair_a, fmt, ctx->pair_b, fmt, &ctx->ctl->n_pairs, pc, ph, sh, tb);
         if (rc != GS_OK) return rc;
         fpairs = ctx->pair_b;
     } else {
         const int b1 = (tb + 1) / 2, b2 = tb - b1;
-        rc = gs_launch_radix_pass(ctx, ctx->pair_a, fmt, ctx->pair_b, fmt, &ctx->ctl->n_pairs, pc, sh, b1);
+        rc = gs_launch_radix_pass(ctx, ctx->pair_a, fmt, ctx->pair_b, fmt, &ctx->ctl->n_pairs, pc, ph, sh, b1);
         if (rc != GS_OK) return rc;
-        rc = gs_launch_radix_pass(ctx, ctx->pair_b, fmt, ctx->pair_a, fmt, &ctx->ctl->n_pairs, pc, sh + b1, b2);
+        rc = gs_launch_radix_pass(ctx, ctx->pair_b, fmt, ctx->pair_a, fmt, &ctx->ctl->n_pairs, pc, ph, sh + b1, b2);
         if (rc != GS_OK) return rc;
         fpairs = ctx->pair_a;
     }

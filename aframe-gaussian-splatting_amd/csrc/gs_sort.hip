@@ -76,21 +76,24 @@ __global__ __launch_bounds__(GS_BLOCK) void k_sort_depth(const float4 *__restric
 }
 
 // pass 2 (index.js:558-561): 16-bit bucket of the stored depth; culled -> GS_RADIX_SKIP, dropped bucket -> GS_CULLED_KEY.
-// Every workgroup first folds pass 1's partials (<= 2048 slots, L2-resident) into the global min/max.
-__global__ __launch_bounds__(GS_BLOCK) void k_sort_bucket(const float *__restrict__ depth, uint32_t n, uint32_t *__restrict__ keys,
+// Every workgroup first folds pass 1's partials (<= 2048 slots, L2-resident) into the global min/max.  It also leaves radix
+// pass A's histogram rows (gs_prims.hip): one workgroup per group of GS_RADIX_SUB chunks writes a row per chunk (H) and one
+// for the group (G).
+__global__ __launch_bounds__(GS_RADIX_THREADS) void k_sort_bucket(const float *__restrict__ depth, uint32_t n, uint32_t *__restrict__ keys,
                                                           const unsigned long long *__restrict__ part_min,
                                                           const unsigned long long *__restrict__ part_max,
                                                           const uint32_t *__restrict__ part_cnt, uint32_t nparts,
-                                                          uint32_t *__restrict__ hist, GsControl *ctl)
+                                                          uint32_t *__restrict__ hrows, uint32_t *__restrict__ grows, GsControl *ctl)
 {
+    constexpr int NT = GS_RADIX_THREADS, IPT = GS_CHUNK / GS_RADIX_THREADS;
     __shared__ unsigned long long s_min, s_max;
     __shared__ uint32_t s_cnt;
-    __shared__ uint32_t s_hist[256];                              // low-digit histogram of this chunk = radix pass A's input
+    __shared__ uint32_t s_hist[256];                              // low-digit histogram of the current chunk = radix pass A's input
     if (threadIdx.x == 0) { s_min = ~0ull; s_max = 0ull; s_cnt = 0; }
     __syncthreads();
     {
         unsigned long long mn = ~0ull, mx = 0ull; uint32_t cnt = 0;
-        for (uint32_t i = threadIdx.x; i < nparts; i += GS_BLOCK) {
+        for (uint32_t i = threadIdx.x; i < nparts; i += NT) {
             const unsigned long long a = part_min[i], b = part_max[i];
             mn = a < mn ? a : mn; mx = b > mx ? b : mx; cnt += part_cnt[i];
         }
@@ -106,38 +109,47 @@ __global__ __launch_bounds__(GS_BLOCK) void k_sort_bucket(const float *__restric
     if (blockIdx.x == 0 && threadIdx.x == 0) { ctl->min_enc = s_min; ctl->max_enc = s_max; ctl->n_kept = s_cnt; ctl->n_total = n; }
     const double mn = gsm::ordered_to_f64(s_min), mx = gsm::ordered_to_f64(s_max);
     const double inv = 65535.0 / (mx - mn);                       // (256*256-1)/(maxDepth-minDepth)
-    const uint32_t nchunks = (n + GS_CHUNK - 1) / GS_CHUNK;
-    for (uint32_t v = blockIdx.x; v < ((nchunks + 7u) & ~7u); v += gridDim.x) {
-        uint32_t c;
-        if (!gs_xcd_chunk(v, nchunks, c)) continue;                // XCD-aware chunk order (the histogram rows are shared lines)
-        s_hist[threadIdx.x] = 0;
-        __syncthreads();
-        float dd[GS_IPT];                                            // all loads first: their latencies overlap
+    const uint32_t nchunks = (n + GS_CHUNK - 1) / GS_CHUNK, ngroups = (nchunks + GS_RADIX_SUB - 1) / GS_RADIX_SUB;
+    for (uint32_t v = blockIdx.x; v < ((ngroups + 7u) & ~7u); v += gridDim.x) {
+        uint32_t g;
+        if (!gs_xcd_chunk(v, ngroups, g)) continue;                // XCD-aware group order (neighbouring rows share lines)
+        if (threadIdx.x < 256) s_hist[threadIdx.x] = 0;
+        float dd[GS_RADIX_SUB][IPT];                                 // all loads first: their latencies overlap
 #pragma unroll
-        for (int r = 0; r < GS_IPT; r++) {
-            const uint32_t i = c * GS_CHUNK + r * GS_BLOCK + threadIdx.x;
-            dd[r] = i < n ? depth[i] : INFINITY;
-        }
+        for (int k = 0; k < GS_RADIX_SUB; k++)
 #pragma unroll
-        for (int r = 0; r < GS_IPT; r++) {
-            const uint32_t i = c * GS_CHUNK + r * GS_BLOCK + threadIdx.x;
-            if (i < n) {
-                // culled splats leave the sort here: GS_RADIX_SKIP records are not counted and not scattered by pass A.
-                // Kept splats whose bucket falls outside the table (the reference drops their writes) carry GS_CULLED_KEY:
-                // they sort behind every bucket and store 0, the reference's never-written tail slots
-                const float d = dd[r];
-                uint32_t k = GS_RADIX_SKIP;
-                if (d != INFINITY) {
-                    const int32_t b = gsm::sort_bucket(d, mn, inv);
-                    k = b >= 0 ? (uint32_t)b : GS_CULLED_KEY;
-                    atomicAdd(&s_hist[k & 255u], 1u);
-                }
-                keys[i] = k;
+            for (int r = 0; r < IPT; r++) {
+                const uint32_t i = (g * GS_RADIX_SUB + k) * GS_CHUNK + r * NT + threadIdx.x;
+                dd[k][r] = i < n ? depth[i] : INFINITY;
             }
+        uint32_t gsum = 0;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < GS_RADIX_SUB; k++) {
+            const uint32_t c = g * GS_RADIX_SUB + k;
+            if (c >= nchunks) break;
+#pragma unroll
+            for (int r = 0; r < IPT; r++) {
+                const uint32_t i = c * GS_CHUNK + r * NT + threadIdx.x;
+                if (i < n) {
+                    // culled splats leave the sort here: GS_RADIX_SKIP records are not counted and not scattered by pass A.
+                    // Kept splats whose bucket falls outside the table (the reference drops their writes) carry GS_CULLED_KEY:
+                    // they sort behind every bucket and store 0, the reference's never-written tail slots
+                    const float d = dd[k][r];
+                    uint32_t key = GS_RADIX_SKIP;
+                    if (d != INFINITY) {
+                        const int32_t b = gsm::sort_bucket(d, mn, inv);
+                        key = b >= 0 ? (uint32_t)b : GS_CULLED_KEY;
+                        atomicAdd(&s_hist[key & 255u], 1u);
+                    }
+                    keys[i] = key;
+                }
+            }
+            __syncthreads();
+            if (threadIdx.x < 256) { const uint32_t h = s_hist[threadIdx.x]; hrows[(size_t)c * 256u + threadIdx.x] = h; gsum += h; s_hist[threadIdx.x] = 0; }
+            __syncthreads();
         }
-        __syncthreads();
-        hist[threadIdx.x * nchunks + c] = s_hist[threadIdx.x];
-        __syncthreads();
+        if (threadIdx.x < 256) grows[(size_t)g * 256u + threadIdx.x] = gsum;
     }
 }
 
@@ -151,21 +163,21 @@ int gs_run_sort(gs_ctx *ctx, const float view[4], const float *cutout16)
     u.has_cutout = cutout16 != nullptr;
     for (int i = 0; i < 16; i++) u.cutout[i] = cutout16 ? (double)cutout16[i] : 0.0;
 
-    const uint32_t g = gs_radix_grid(n);                         // same chunking as the radix kernels (pre-filled histogram)
+    const uint32_t g = gs_radix_grid(gs_div_up(n, GS_RADIX_SUB)); // one workgroup per group of radix chunks (pre-filled histogram rows)
     GS_PROF_RECORD(ctx, 0);
     uint32_t gd = gs_div_up(n, (uint32_t)(GS_DEPTH_IPT * GS_BLOCK));
     if (gd < 1) gd = 1;
     if (gd > GS_DEPTH_GRID) gd = GS_DEPTH_GRID;
     hipLaunchKernelGGL(k_sort_depth, dim3(gd), dim3(GS_BLOCK), 0, ctx->stream, ctx->sort_rows, n, u, ctx->depth, ctx->part_min,
                        ctx->part_max, ctx->part_cnt);
-    hipLaunchKernelGGL(k_sort_bucket, dim3(g), dim3(GS_BLOCK), 0, ctx->stream, ctx->depth, n, ctx->key_a, ctx->part_min,
-                       ctx->part_max, ctx->part_cnt, gd, ctx->hist, ctx->ctl);
+    hipLaunchKernelGGL(k_sort_bucket, dim3(g), dim3(GS_RADIX_THREADS), 0, ctx->stream, ctx->depth, n, ctx->key_a, ctx->part_min,
+                       ctx->part_max, ctx->part_cnt, gd, ctx->hist, gs_radix_group_rows(ctx), ctx->ctl);
     GS_HIP(hipGetLastError());
-    int rc = gs_launch_radix_pass(ctx, ctx->key_a, GS_RADIX_KEYS, ctx->kv_b, GS_RADIX_PACKED, &ctx->ctl->n_total, n, 0, 8, /*have_hist=*/true);
+    int rc = gs_launch_radix_pass(ctx, ctx->key_a, GS_RADIX_KEYS, ctx->kv_b, GS_RADIX_PACKED, &ctx->ctl->n_total, n, n, 0, 8, /*have_hist=*/true);
     if (rc != GS_OK) return rc;
     // pass A dropped the culled splats: V records are left.  Splats with a dropped bucket (key 65536) sort behind every
     // bucket and store 0: the tail [V',V) of the result is 0 like the reference's never-written Uint32Array slots
-    rc = gs_launch_radix_pass(ctx, ctx->kv_b, GS_RADIX_PACKED, ctx->val_a, GS_RADIX_KEYS, &ctx->ctl->n_kept, n, 8, 9, false, GS_CULLED_KEY);
+    rc = gs_launch_radix_pass(ctx, ctx->kv_b, GS_RADIX_PACKED, ctx->val_a, GS_RADIX_KEYS, &ctx->ctl->n_kept, n, n, 8, 9, false, GS_CULLED_KEY);
     if (rc != GS_OK) return rc;
     GS_PROF_RECORD(ctx, 1);
     ctx->sorted = ctx->val_a;

@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""Development aid: frames/s of the frame loop for one configuration with the adaptive knobs PINNED, so two builds can be
+compared (bench.py lets the library adapt the share of splats binned first, which moves between runs).
+
+  tools/stage_bench.py [--splats N] [--size WxH] [--cutout] [--frames K] [--depths 1,3] [--near PERMILLE] [--sort-only]
+
+Prints one line per pipeline depth: frames/s, and the HIP-event stage times of a profiled pass.  Run under
+`rocprofv3 --kernel-trace --stats` + tools/prof_tail.py for per-kernel times (depth 1 = kernels alone on the GPU)."""
+import argparse, importlib, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+capi = importlib.import_module("aframe-gaussian-splatting_amd.capi"); synth = importlib.import_module("aframe-gaussian-splatting_amd.synth")
+ap = argparse.ArgumentParser()
+ap.add_argument("--splats", type=int, default=synth.N_TRAIN)
+ap.add_argument("--size", default="1920x1080")
+ap.add_argument("--cutout", action="store_true")
+ap.add_argument("--frames", type=int, default=240)
+ap.add_argument("--depths", default="1,3")
+ap.add_argument("--near", type=int, default=180, help="pinned share (permille) of the splats binned in the first round; 0 = adaptive")
+ap.add_argument("--sort-only", action="store_true")
+a = ap.parse_args()
+W, H = (int(v) for v in a.size.lower().split("x"))
+rows = synth.make_splat_rows_fast(a.splats) if a.splats >= (8 << 20) else synth.make_splat_rows(a.splats)
+pose = synth.cutout_demo_camera if a.cutout else synth.index_html_camera
+cams = [pose(W, H, 3.0 * i, capi=capi) for i in range(120)]
+params = [capi.make_params(c["gs_mv"], c["gs_proj"], W, H, focal_=c["focal"]) for c in cams]
+ctx = capi.Context(0)
+r = rows.reshape(-1, 32)
+for o in range(0, a.splats, 1 << 22):
+    ctx.push_splat(r[o:o + (1 << 22)])
+if a.near:
+    ctx.set_option(capi.OPT_NEAR_PERMILLE, a.near)
+
+
+def go(n):
+    t0 = time.perf_counter()
+    for i in range(n):
+        k = i % 120
+        ctx.sort(cams[k]["view"], cams[k]["cutout"], want_indices=False)
+        if not a.sort_only:
+            params[k].flags = capi.RENDER_ASYNC
+            ctx.render_device(params[k], None)
+    try:
+        ctx.sync()
+    except capi.GsError as e:
+        if e.code != capi.E_RETRY:
+            raise
+        return None
+    return time.perf_counter() - t0
+
+
+for k in range(0, 120, 4):                                   # buffers sized, share settled (if adaptive)
+    ctx.sort(cams[k]["view"], cams[k]["cutout"], want_indices=False)
+    if not a.sort_only:
+        params[k].flags = 0
+        ctx.render_device(params[k], None)
+for depth in (int(v) for v in a.depths.split(",")):
+    ctx.set_option(capi.OPT_PIPELINE_DEPTH, depth)
+    ctx.set_option(capi.OPT_PROFILE, 0)
+    go(24); go(24)
+    t = go(a.frames) or go(a.frames)
+    ctx.set_option(capi.OPT_PROFILE, 1)
+    go(24); go(min(a.frames, 120))
+    s = ctx.stats()
+    ctx.set_option(capi.OPT_PROFILE, 0)
+    k = max(1, s["prof_frames"])
+    print("N=%d %dx%d%s depth %d: %.0f frames/s (%.1f us/frame) | events: sort %.1f project %.1f bin %.1f blend %.1f us | V=%d Vp=%d I=%d near=%d" % (
+        a.splats, W, H, " cutout" if a.cutout else "", depth, a.frames / t, t / a.frames * 1e6, s["sum_ms_sort"] / k * 1e3,
+        s["sum_ms_project"] / k * 1e3, s["sum_ms_bin"] / k * 1e3, s["sum_ms_blend"] / k * 1e3, s["n_sorted"], s["n_visible"], s["n_pairs"],
+        s["near_permille"]), flush=True)
+ctx.close()
