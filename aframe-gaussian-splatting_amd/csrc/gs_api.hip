@@ -38,17 +38,10 @@ static void lane_stop_worker(gs_ctx *L);
 
 static int ensure_radix_tables(gs_ctx *ctx, size_t items)
 {
-    // a histogram row per radix chunk (H) and per group of chunks (G); for long inputs the digit totals + one exclusive row
-    // per super-group
-    const size_t chunks = (gs_div_up(items, GS_CHUNK) + 8 + GS_RADIX_SUB - 1) / GS_RADIX_SUB * GS_RADIX_SUB;
-    const size_t groups = chunks / GS_RADIX_SUB + 8;
-    const size_t need_hist = (size_t)GS_RADIX_MAX_BINS * (chunks + groups);
-    if (chunks > ctx->hist_chunks || need_hist > ctx->hist_cap) {
-        dev_free(ctx->hist); ctx->hist_cap = 0; ctx->hist_chunks = 0;
-        TRY(dev_alloc(ctx, &ctx->hist, need_hist));
-        ctx->hist_cap = need_hist; ctx->hist_chunks = chunks;
-    }
-    const size_t need_aux = (size_t)GS_RADIX_MAX_BINS * (2 + gs_div_up(groups, GS_RADIX_SUPER));
+    // a histogram row per radix chunk (sized for the short geometry's chunks) + the digit totals
+    const size_t need_hist = (size_t)GS_RADIX_MAX_BINS * (gs_div_up(items, GS_CHUNK_S) + 16);
+    if (need_hist > ctx->hist_cap) { dev_free(ctx->hist); ctx->hist_cap = 0; TRY(dev_alloc(ctx, &ctx->hist, need_hist)); ctx->hist_cap = need_hist; }
+    const size_t need_aux = (size_t)GS_RADIX_MAX_BINS * 2;
     if (need_aux > ctx->aux_cap) { dev_free(ctx->radix_aux); TRY(dev_alloc(ctx, &ctx->radix_aux, need_aux)); ctx->aux_cap = need_aux; }
     return GS_OK;
 }
@@ -68,7 +61,7 @@ int gs_ensure_pair_capacity(gs_ctx *ctx, size_t pairs)
     if (pairs <= ctx->pair_cap) return GS_OK;
     size_t cap = ctx->pair_cap ? ctx->pair_cap : (size_t)1 << 22;
     while (cap < pairs) cap += cap / 2 + 1;
-    cap = (cap + GS_CHUNK - 1) / GS_CHUNK * GS_CHUNK;
+    cap = (cap + GS_CHUNK_L - 1) / GS_CHUNK_L * GS_CHUNK_L;
     if (cap > 0xFFFF0000ull) FAIL(GS_E_OOM, "pair list of %zu entries exceeds the 32-bit index space", pairs);
     dev_free(ctx->pair_a); dev_free(ctx->pair_b);
     ctx->pair_cap = 0;
@@ -195,7 +188,7 @@ static int collect_status(gs_ctx *lane, bool *overflowed)
     lane->stats.acc_frames = c->acc_frames; lane->stats.acc_sorted = c->acc_sorted; lane->stats.acc_visible = c->acc_visible;
     lane->stats.acc_pairs = c->acc_pairs;
     if (c->n_pairs_frame) {                                     // sizing hint for the next frames' pair sort (any lane's worker may read it)
-        const uint64_t h = (uint64_t)c->n_pairs_frame + c->n_pairs_frame / 4 + GS_CHUNK;
+        const uint64_t h = (uint64_t)c->n_pairs_frame + c->n_pairs_frame / 4 + GS_CHUNK_L;
         __atomic_store_n(&ctx->pair_hint, h > 0xFFFFFFFFull ? 0u : (uint32_t)h, __ATOMIC_RELAXED);
     }
     // Adapt the share of splats binned in round 0.  An "event" = a frame whose round 0 left tiles unsaturated (round 1

@@ -10,18 +10,12 @@
 // ---------------------------------------------------------------- geometry of the work decomposition
 #define GS_TILE 16                 // screen tile edge (pixels): 16x16 = one 256-thread workgroup
 #define GS_BLOCK 256               // threads per workgroup everywhere (4 wavefronts of 64)
-#ifndef GS_CHUNK
-#define GS_CHUNK 4096              // items per radix chunk = one histogram row (and per workgroup pass of the kernels that pre-fill rows)
+#define GS_CHUNK_S 2048            // items per radix chunk = histogram row: short inputs (256-thread workgroups) ...
+#define GS_CHUNK_L 4096            // ... and long ones (512-thread workgroups); 8 items per thread in both
+#ifndef GS_RADIX_LARGE_N
+#define GS_RADIX_LARGE_N (3u << 20) // inputs expected to be longer than this take the long geometry
 #endif
-#define GS_IPT (GS_CHUNK / GS_BLOCK) // items per thread and pass of a 256-thread producer kernel
-#define GS_RADIX_WAVES 8           // wavefronts per workgroup of the radix kernels (512 threads, 8 items per thread)
-#define GS_RADIX_THREADS (64 * GS_RADIX_WAVES)
 #define GS_RADIX_MAX_BINS 512      // up to 9-bit digits (depth key = 17 bits = 8 + 9)
-#define GS_RADIX_SUB 4             // chunks per histogram group: the rows are kept per chunk (H) and per group (G)
-#define GS_RADIX_SUPER 32          // G rows per super-group of the two-level offsets (long inputs)
-#ifndef GS_RADIX_BRUTE_ROWS
-#define GS_RADIX_BRUTE_ROWS 512    // up to this many G rows (8 M items) every scatter workgroup sums all of them itself
-#endif
 #define GS_PROF_RING 256           // frames of HIP-event timings kept in flight
 #define GS_PROF_EVENTS 7
 #define GS_MAX_PART 8192           // upper bound on the grid of any kernel that writes per-workgroup partials
@@ -119,9 +113,8 @@ struct gs_ctx {
     bool have_sort;
 
     // radix / scan scratch
-    uint32_t *hist;  size_t hist_cap;       // digit-histogram rows: H[chunks][bins], then (gs_radix_group_rows) G[chunks / GS_RADIX_SUB][bins]
-    size_t hist_chunks;                     // chunks the H part is sized for
-    uint32_t *radix_aux; size_t aux_cap;    // long radix inputs: digit totals [GS_RADIX_MAX_BINS], then one exclusive row per super-group
+    uint32_t *hist;  size_t hist_cap;       // digit-histogram rows H[radix chunks][bins], scanned in place
+    uint32_t *radix_aux; size_t aux_cap;    // digit totals [GS_RADIX_MAX_BINS]
     uint32_t *spine; size_t spine_cap;      // per-256-splat totals of tiles touched (project -> emit)
 
     // render scratch
@@ -206,9 +199,12 @@ __device__ __forceinline__ bool gs_xcd_chunk(uint32_t v, uint32_t nchunks, uint3
 #define GS_RADIX_SKIP 0xFFFFFFFFu   // GS_RADIX_KEYS input only: a record with this key is neither counted nor scattered (compaction)
 int gs_launch_radix_pass(gs_ctx *ctx, const void *in, int in_fmt, void *out, int out_fmt, const uint32_t *n_ptr,
                          uint32_t max_n, uint32_t hint_n, int shift, int bits, bool have_hist = false, uint32_t zero_key = 0xFFFFFFFFu);
-// grid used by the radix kernels for max_n items (a producer that pre-fills the histogram must use the same chunking)
-uint32_t gs_radix_grid(uint32_t max_n);
-static inline uint32_t *gs_radix_group_rows(gs_ctx *ctx) { return ctx->hist + ctx->hist_chunks * GS_RADIX_MAX_BINS; }   // the G rows
+// grid used by the radix kernels for hint_n items (a producer that pre-fills the histogram rows uses the same chunking)
+uint32_t gs_radix_grid(uint32_t hint_n);
+// chunk length (GS_CHUNK_S / GS_CHUNK_L) a pass expecting hint_n items works with
+uint32_t gs_radix_chunk(uint32_t hint_n);
+// words per histogram row of a pass with nbins digits (rows are read 16 bytes at a time)
+static __host__ __device__ __forceinline__ uint32_t gs_radix_row_stride(uint32_t nbins) { return nbins < 4u ? 4u : nbins; }
 // ---- gs_pack.hip
 int gs_launch_pack(gs_ctx *ctx, const uint4 *rows_dev, size_t first, size_t nrows);
 // ---- gs_sort.hip

@@ -732,7 +732,7 @@ int run_round(gs_ctx *ctx, const GsFrameUniforms &u, uint8_t *out, bool last_rou
     const uint32_t pc = (uint32_t)ctx->pair_cap;
     // what the pair sort should expect (grid, one- or two-level offsets): round 1 usually finds nothing; round 0 about what
     // the last collected frames binned (0 = not known yet: the capacity)
-    const uint32_t ph = ROUND == 1 ? (uint32_t)(small * GS_CHUNK) : __atomic_load_n(&gs_root(ctx)->pair_hint, __ATOMIC_RELAXED);
+    const uint32_t ph = ROUND == 1 ? (uint32_t)(small * GS_CHUNK_S) : __atomic_load_n(&gs_root(ctx)->pair_hint, __ATOMIC_RELAXED);
     hipLaunchKernelGGL(k_project<ROUND>, dim3(g), dim3(GS_BLOCK), 0, st, ctx->sorted, ctx->splat, u, ctx->proj, ctx->rect,
                        ctx->tile_count, ctx->spine, ctx->part_vis, ctx->unsat_mask, ctx->zwin, ctx->ctl, ctx->huge_list);
     GS_HIP(hipGetLastError());

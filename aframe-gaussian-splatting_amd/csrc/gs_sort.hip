@@ -76,19 +76,19 @@ __global__ __launch_bounds__(GS_BLOCK) void k_sort_depth(const float4 *__restric
 }
 
 // pass 2 (index.js:558-561): 16-bit bucket of the stored depth; culled -> GS_RADIX_SKIP, dropped bucket -> GS_CULLED_KEY.
-// Every workgroup first folds pass 1's partials (<= 2048 slots, L2-resident) into the global min/max.  It also leaves radix
-// pass A's histogram rows (gs_prims.hip): one workgroup per group of GS_RADIX_SUB chunks writes a row per chunk (H) and one
-// for the group (G).
-__global__ __launch_bounds__(GS_RADIX_THREADS) void k_sort_bucket(const float *__restrict__ depth, uint32_t n, uint32_t *__restrict__ keys,
-                                                          const unsigned long long *__restrict__ part_min,
-                                                          const unsigned long long *__restrict__ part_max,
-                                                          const uint32_t *__restrict__ part_cnt, uint32_t nparts,
-                                                          uint32_t *__restrict__ hrows, uint32_t *__restrict__ grows, GsControl *ctl)
+// Every workgroup first folds pass 1's partials (<= 2048 slots, L2-resident) into the global min/max.  One workgroup per
+// radix chunk (geometry NW as in gs_prims.hip): it also leaves radix pass A's histogram row of the chunk.
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void k_sort_bucket(const float *__restrict__ depth, uint32_t n, uint32_t *__restrict__ keys,
+                                                         const unsigned long long *__restrict__ part_min,
+                                                         const unsigned long long *__restrict__ part_max,
+                                                         const uint32_t *__restrict__ part_cnt, uint32_t nparts,
+                                                         uint32_t *__restrict__ hist, GsControl *ctl)
 {
-    constexpr int NT = GS_RADIX_THREADS, IPT = GS_CHUNK / GS_RADIX_THREADS;
+    constexpr int NT = 64 * NW, IPT = 8, CH = NT * IPT;
     __shared__ unsigned long long s_min, s_max;
     __shared__ uint32_t s_cnt;
-    __shared__ uint32_t s_hist[256];                              // low-digit histogram of the current chunk = radix pass A's input
+    __shared__ uint32_t s_hist[256];                              // low-digit histogram of this chunk = radix pass A's input
     if (threadIdx.x == 0) { s_min = ~0ull; s_max = 0ull; s_cnt = 0; }
     __syncthreads();
     {
@@ -109,47 +109,38 @@ __global__ __launch_bounds__(GS_RADIX_THREADS) void k_sort_bucket(const float *_
     if (blockIdx.x == 0 && threadIdx.x == 0) { ctl->min_enc = s_min; ctl->max_enc = s_max; ctl->n_kept = s_cnt; ctl->n_total = n; }
     const double mn = gsm::ordered_to_f64(s_min), mx = gsm::ordered_to_f64(s_max);
     const double inv = 65535.0 / (mx - mn);                       // (256*256-1)/(maxDepth-minDepth)
-    const uint32_t nchunks = (n + GS_CHUNK - 1) / GS_CHUNK, ngroups = (nchunks + GS_RADIX_SUB - 1) / GS_RADIX_SUB;
-    for (uint32_t v = blockIdx.x; v < ((ngroups + 7u) & ~7u); v += gridDim.x) {
-        uint32_t g;
-        if (!gs_xcd_chunk(v, ngroups, g)) continue;                // XCD-aware group order (neighbouring rows share lines)
+    const uint32_t nchunks = (n + CH - 1) / CH;
+    for (uint32_t v = blockIdx.x; v < ((nchunks + 7u) & ~7u); v += gridDim.x) {
+        uint32_t c;
+        if (!gs_xcd_chunk(v, nchunks, c)) continue;                // XCD-aware chunk order (as the radix kernels)
         if (threadIdx.x < 256) s_hist[threadIdx.x] = 0;
-        float dd[GS_RADIX_SUB][IPT];                                 // all loads first: their latencies overlap
-#pragma unroll
-        for (int k = 0; k < GS_RADIX_SUB; k++)
-#pragma unroll
-            for (int r = 0; r < IPT; r++) {
-                const uint32_t i = (g * GS_RADIX_SUB + k) * GS_CHUNK + r * NT + threadIdx.x;
-                dd[k][r] = i < n ? depth[i] : INFINITY;
-            }
-        uint32_t gsum = 0;
         __syncthreads();
+        float dd[IPT];                                               // all loads first: their latencies overlap
 #pragma unroll
-        for (int k = 0; k < GS_RADIX_SUB; k++) {
-            const uint32_t c = g * GS_RADIX_SUB + k;
-            if (c >= nchunks) break;
-#pragma unroll
-            for (int r = 0; r < IPT; r++) {
-                const uint32_t i = c * GS_CHUNK + r * NT + threadIdx.x;
-                if (i < n) {
-                    // culled splats leave the sort here: GS_RADIX_SKIP records are not counted and not scattered by pass A.
-                    // Kept splats whose bucket falls outside the table (the reference drops their writes) carry GS_CULLED_KEY:
-                    // they sort behind every bucket and store 0, the reference's never-written tail slots
-                    const float d = dd[k][r];
-                    uint32_t key = GS_RADIX_SKIP;
-                    if (d != INFINITY) {
-                        const int32_t b = gsm::sort_bucket(d, mn, inv);
-                        key = b >= 0 ? (uint32_t)b : GS_CULLED_KEY;
-                        atomicAdd(&s_hist[key & 255u], 1u);
-                    }
-                    keys[i] = key;
-                }
-            }
-            __syncthreads();
-            if (threadIdx.x < 256) { const uint32_t h = s_hist[threadIdx.x]; hrows[(size_t)c * 256u + threadIdx.x] = h; gsum += h; s_hist[threadIdx.x] = 0; }
-            __syncthreads();
+        for (int r = 0; r < IPT; r++) {
+            const uint32_t i = c * CH + r * NT + threadIdx.x;
+            dd[r] = i < n ? depth[i] : INFINITY;
         }
-        if (threadIdx.x < 256) grows[(size_t)g * 256u + threadIdx.x] = gsum;
+#pragma unroll
+        for (int r = 0; r < IPT; r++) {
+            const uint32_t i = c * CH + r * NT + threadIdx.x;
+            if (i < n) {
+                // culled splats leave the sort here: GS_RADIX_SKIP records are not counted and not scattered by pass A.
+                // Kept splats whose bucket falls outside the table (the reference drops their writes) carry GS_CULLED_KEY:
+                // they sort behind every bucket and store 0, the reference's never-written tail slots
+                const float d = dd[r];
+                uint32_t k = GS_RADIX_SKIP;
+                if (d != INFINITY) {
+                    const int32_t b = gsm::sort_bucket(d, mn, inv);
+                    k = b >= 0 ? (uint32_t)b : GS_CULLED_KEY;
+                    atomicAdd(&s_hist[k & 255u], 1u);
+                }
+                keys[i] = k;
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < 256) hist[(size_t)c * 256u + threadIdx.x] = s_hist[threadIdx.x];   // row c of hist[chunk][digit]
+        __syncthreads();
     }
 }
 
@@ -163,15 +154,19 @@ int gs_run_sort(gs_ctx *ctx, const float view[4], const float *cutout16)
     u.has_cutout = cutout16 != nullptr;
     for (int i = 0; i < 16; i++) u.cutout[i] = cutout16 ? (double)cutout16[i] : 0.0;
 
-    const uint32_t g = gs_radix_grid(gs_div_up(n, GS_RADIX_SUB)); // one workgroup per group of radix chunks (pre-filled histogram rows)
+    const uint32_t g = gs_radix_grid(n);                         // same chunking as the radix kernels (pre-filled histogram rows)
     GS_PROF_RECORD(ctx, 0);
     uint32_t gd = gs_div_up(n, (uint32_t)(GS_DEPTH_IPT * GS_BLOCK));
     if (gd < 1) gd = 1;
     if (gd > GS_DEPTH_GRID) gd = GS_DEPTH_GRID;
     hipLaunchKernelGGL(k_sort_depth, dim3(gd), dim3(GS_BLOCK), 0, ctx->stream, ctx->sort_rows, n, u, ctx->depth, ctx->part_min,
                        ctx->part_max, ctx->part_cnt);
-    hipLaunchKernelGGL(k_sort_bucket, dim3(g), dim3(GS_RADIX_THREADS), 0, ctx->stream, ctx->depth, n, ctx->key_a, ctx->part_min,
-                       ctx->part_max, ctx->part_cnt, gd, ctx->hist, gs_radix_group_rows(ctx), ctx->ctl);
+    if (gs_radix_chunk(n) == GS_CHUNK_L)
+        hipLaunchKernelGGL(k_sort_bucket<8>, dim3(g), dim3(512), 0, ctx->stream, ctx->depth, n, ctx->key_a, ctx->part_min,
+                           ctx->part_max, ctx->part_cnt, gd, ctx->hist, ctx->ctl);
+    else
+        hipLaunchKernelGGL(k_sort_bucket<4>, dim3(g), dim3(256), 0, ctx->stream, ctx->depth, n, ctx->key_a, ctx->part_min,
+                           ctx->part_max, ctx->part_cnt, gd, ctx->hist, ctx->ctl);
     GS_HIP(hipGetLastError());
     int rc = gs_launch_radix_pass(ctx, ctx->key_a, GS_RADIX_KEYS, ctx->kv_b, GS_RADIX_PACKED, &ctx->ctl->n_total, n, n, 0, 8, /*have_hist=*/true);
     if (rc != GS_OK) return rc;

@@ -7,5 +7,5 @@ timeout 900 python tools/stage_bench.py "$@" 2>&1 | tee gpurun_out/stage_$TAG.tx
 cd /tmp && export TMPDIR=/tmp
 timeout 900 rocprofv3 --kernel-trace -d $R/gpurun_out/st_$TAG -o st -- python $R/tools/stage_bench.py "$@" --depths 1 --frames 60 > $R/gpurun_out/st_$TAG.log 2>&1
 cd $R
-python tools/prof_tail.py gpurun_out/st_$TAG/st_results.db ${TAIL:-1200} | tee -a gpurun_out/stage_$TAG.txt
+python tools/prof_tail.py gpurun_out/st_$TAG/st_results.db ${TAIL:-1200} ${TRACE:+--trace $TRACE} | tee -a gpurun_out/stage_$TAG.txt
 rm -rf gpurun_out/st_$TAG

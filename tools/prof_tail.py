@@ -27,3 +27,12 @@ wall = (max(r[2] for r in rows) - min(r[1] for r in rows)) / 1e3
 print("last %d dispatches, wall %.1f us, kernel time %.1f us" % (len(rows), wall, sum(a[1] for a in agg.values())))
 for name, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
     print("  %-46s calls %5d  avg %9.2f us  share %5.1f %%" % (name, c, t / c, 100.0 * t / sum(a[1] for a in agg.values())))
+if "--trace" in sys.argv:                                    # the last K dispatches in order: start offset, duration, gap to the previous end
+    k = int(sys.argv[sys.argv.index("--trace") + 1])
+    seq = sorted(rows[:k], key=lambda r: r[1])
+    t0, prev = seq[0][1], None
+    for name, s, e in seq:
+        nm = dm.get(name.replace(".kd", ""), name); nm = re.sub(r"\(anonymous namespace\)::", "", nm); nm = re.sub(r"^void ", "", nm)
+        m = re.match(r"([\w:<>, ]+?)\(", nm); nm = (m.group(1) if m else nm)[:40]
+        print("  +%8.1f us  %-40s %7.2f us   gap %6.2f" % ((s - t0) / 1e3, nm, (e - s) / 1e3, (s - prev) / 1e3 if prev else 0.0))
+        prev = e
