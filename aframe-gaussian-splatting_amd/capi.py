@@ -14,6 +14,8 @@ GS_OK = 0
 E_BADARG, E_PLY_HEADER, E_PLY_PROP, E_HIP, E_OOM, E_NODEVICE, E_STATE, E_PLY_DATA, E_RETRY = -1, -2, -3, -4, -5, -6, -7, -8, -9
 RENDER_FLIP_Y, RENDER_COUNT_FRAGS, RENDER_NO_EARLY_OUT, RENDER_ASYNC = 1, 2, 4, 8
 OPT_PROFILE, OPT_TERMINATION, OPT_NEAR_PERMILLE, OPT_RECORD_STAGED, OPT_PIPELINE_DEPTH, OPT_WIDE_PAIRS, OPT_ENQUEUE_THREADS = 1, 2, 3, 4, 5, 6, 7
+OPT_COMM_SELF_COPY = 8
+COMM_ID_BYTES = 128
 BUF_CENTER_SCALE, BUF_COV_COLOR, BUF_SORT_ROWS, BUF_SORTED, BUF_PROJECTED, BUF_TILE_COUNT, BUF_TILE_STATS = 0, 1, 2, 3, 4, 5, 6
 
 EXPORTS = [
@@ -22,7 +24,12 @@ EXPORTS = [
     "gs_set_stream", "gs_frame_stream", "gs_frame_lane", "gs_lane_stream", "gs_wait_stream", "gs_stream_wait_frame",
     "gs_model_view_matrix", "gs_projection_matrix", "gs_tick_uniforms", "gs_focal", "gs_scaled_size", "gs_set_option",
     "gs_get_stats", "gs_download",
+    "gs_comm_unique_id", "gs_comm_init", "gs_comm_destroy", "gs_partition", "gs_render_gathered", "gs_read_gathered",
 ]
+
+
+class Piece(C.Structure):
+    _fields_ = [("view", C.c_int32), ("x0", C.c_int32), ("x1", C.c_int32), ("owner", C.c_int32)]
 
 
 class RenderParams(C.Structure):
@@ -99,6 +106,12 @@ def load(build_if_missing=True):
     L.gs_set_option.argtypes = [vp, i32, C.c_int64]
     L.gs_get_stats.argtypes = [vp, C.POINTER(Stats)]
     L.gs_download.argtypes = [vp, i32, vp, sz]
+    L.gs_comm_unique_id.argtypes = [vp, vp]
+    L.gs_comm_init.argtypes = [vp, vp, i32, i32]
+    L.gs_comm_destroy.argtypes = [vp]
+    L.gs_partition.argtypes = [i32, C.POINTER(i32), i32, C.POINTER(Piece), i32]
+    L.gs_render_gathered.argtypes = [vp, C.POINTER(RenderParams), i32, i32, C.POINTER(vp), C.c_uint32]
+    L.gs_read_gathered.argtypes = [vp, i32, vp, sz]
     _lib = L
     return L
 
@@ -108,6 +121,18 @@ def _p(a):
 
 
 # ---- host helpers (no context needed) ------------------------------------------------------------------
+
+def partition(widths, world):
+    """gs_partition: [(view, x0, x1, owner rank)] for one view (column strips) or two (XR eyes), in gather order."""
+    widths = [int(w) for w in widths]
+    arr = (C.c_int * len(widths))(*widths)
+    out = (Piece * 128)()
+    n = load().gs_partition(len(widths), arr, int(world), out, 128)
+    if n < 0:
+        raise GsError(n, "gs_partition(%r, world=%d)" % (widths, world))
+    return [(out[i].view, out[i].x0, out[i].x1, out[i].owner) for i in range(n)]
+
+
 
 def model_view_matrix(cam_world, obj_world):
     a = np.ascontiguousarray(cam_world, np.float64); b = np.ascontiguousarray(obj_world, np.float64); o = np.zeros(16, np.float64)
@@ -294,6 +319,30 @@ class Context:
     def stream_wait_frame(self, stream_ptr):
         """The given hipStream_t waits (on the GPU) for the frame enqueued last."""
         self._ck(self._L.gs_stream_wait_frame(self._h, C.c_void_p(stream_ptr)))
+
+    # ---- several GPUs (one Context per GPU; see gs_splat.h) ----
+    def comm_unique_id(self):
+        buf = (C.c_uint8 * COMM_ID_BYTES)()
+        self._ck(self._L.gs_comm_unique_id(self._h, buf))
+        return bytes(buf)
+
+    def comm_init(self, uid, rank, world):
+        buf = (C.c_uint8 * COMM_ID_BYTES).from_buffer_copy(bytes(uid))
+        self._ck(self._L.gs_comm_init(self._h, buf, int(rank), int(world)))
+
+    def render_gathered(self, views, root=0, device_frames=None, flags=0):
+        """views: one RenderParams (column strips over the ranks) or two (XR eyes).  Asynchronous with RENDER_ASYNC."""
+        views = list(views) if isinstance(views, (list, tuple)) else [views]
+        arr = (RenderParams * len(views))(*views)
+        ptrs = None
+        if device_frames is not None:
+            ptrs = (C.c_void_p * len(views))(*[C.c_void_p(int(p)) if p else None for p in device_frames])
+        self._ck(self._L.gs_render_gathered(self._h, arr, len(views), int(root), ptrs, int(flags)))
+
+    def read_gathered(self, view, width, height):
+        out = np.empty((int(height), int(width), 4), np.uint8)
+        self._ck(self._L.gs_read_gathered(self._h, int(view), _p(out), 0))
+        return out
 
     def set_option(self, opt, value):
         self._ck(self._L.gs_set_option(self._h, int(opt), int(value)))

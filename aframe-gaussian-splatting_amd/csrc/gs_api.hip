@@ -5,6 +5,7 @@
 #include <stdlib.h>
 #include <condition_variable>
 #include <deque>
+#include <functional>
 #include <mutex>
 #include <new>
 #include <thread>
@@ -238,9 +239,10 @@ static int collect_status(gs_ctx *lane, bool *overflowed)
 // Everything a worker touches is lane-local; the caller's thread touches a lane only after lane_drain().
 
 struct GsLaneCmd {
-    int type;                                                  // 0 = sort, 1 = asynchronous render
+    int type;                                                  // 0 = sort, 1 = asynchronous render, 2 = call (gs_comm.hip: the frame's gather)
     float view[4], cutout[16]; bool has_cutout;
     GsFrameUniforms u; void *device_rgba;
+    std::function<int(gs_ctx *)> call;
 };
 
 struct GsLaneWorker {
@@ -269,8 +271,10 @@ static void lane_worker_main(gs_ctx *L)
         w->busy = true;
         lk.unlock();
         int rc = GS_OK;
-        if (w->rc == GS_OK) rc = c.type == 0 ? gs_run_sort(L, c.view, c.has_cutout ? c.cutout : nullptr)
-                                             : render_async_on_lane(L, c.u, c.device_rgba);
+        // (a call is run even after a failure: the gather of a frame must be issued on every rank, or the others wait for it)
+        if (c.type == 2) { const int r2 = c.call(L); if (w->rc == GS_OK) rc = r2; }
+        else if (w->rc == GS_OK) rc = c.type == 0 ? gs_run_sort(L, c.view, c.has_cutout ? c.cutout : nullptr)
+                                                  : render_async_on_lane(L, c.u, c.device_rgba);
         lk.lock();
         if (rc != GS_OK && w->rc == GS_OK) { w->rc = rc; memcpy(w->err, scratch, sizeof w->err); }
         w->busy = false;
@@ -356,6 +360,7 @@ static void free_frame_resources(gs_ctx *c)
     dev_free(c->hist); dev_free(c->radix_aux); dev_free(c->spine);
     dev_free(c->proj); dev_free(c->rect); dev_free(c->tile_count); dev_free(c->zwin);
     dev_free(c->pair_a); dev_free(c->pair_b);
+    gs_comm_free_lane(c);
     dev_free(c->tile_range); dev_free(c->fb); dev_free(c->ctl); dev_free(c->state); dev_free(c->unsat_mask);
     dev_free(c->part_min); dev_free(c->part_max); dev_free(c->part_cnt); dev_free(c->part_valid); dev_free(c->part_vis); dev_free(c->huge_list);
     if (c->ctl_host) { (void)hipHostFree(c->ctl_host); c->ctl_host = nullptr; }
@@ -490,6 +495,7 @@ GS_API int gs_destroy(gs_ctx *ctx)
 {
     if (!ctx) return GS_OK;
     (void)hipSetDevice(ctx->device);
+    (void)gs_comm_destroy(ctx);
     for (int i = 1; i < GS_MAX_LANES; i++)
         if (ctx->lanes[i]) { free_frame_resources(ctx->lanes[i]); delete ctx->lanes[i]; ctx->lanes[i] = nullptr; }
     free_frame_resources(ctx);
@@ -669,7 +675,7 @@ GS_API int gs_sort(gs_ctx *ctx, const float view[4], const float *cutout16, uint
     return GS_OK;
 }
 
-static int fill_uniforms(gs_ctx *ctx /* owner: options, adaptive share, scene */, const gs_render_params *p, GsFrameUniforms &u)
+int gs_fill_uniforms(gs_ctx *ctx /* owner: options, adaptive share, scene */, const gs_render_params *p, GsFrameUniforms &u)
 {
     if (!p) FAIL(GS_E_BADARG, "render params NULL");
     if (p->fb_width <= 0 || p->fb_height <= 0 || p->fb_width > 65535 * GS_TILE || p->fb_height > 65535 * GS_TILE)
@@ -760,11 +766,32 @@ static int render_sync_on_lane(gs_ctx *ctx, const GsFrameUniforms &u, void *devi
     return GS_OK;
 }
 
+// the frame's lane runs `call` after everything handed to it so far: on its worker thread for asynchronous frames (so the
+// caller keeps enqueuing), on the caller's thread otherwise.  The call's failure surfaces like a render's.
+int gs_lane_call(gs_ctx *ctx, bool async, std::function<int(gs_ctx *)> call)
+{
+    gs_ctx *L = ctx->lanes[ctx->cur];
+    if (async && ctx->enqueue_threads && ctx->pipe_depth > 1 && !ctx->user_stream) {
+        GsLaneCmd c;
+        c.type = 2; c.has_cutout = false; c.device_rgba = nullptr; c.call = std::move(call);
+        L->async_pending = true; ctx->cur_async = true;
+        if (lane_push(L, c) != GS_OK) FAIL(GS_E_OOM, "out of host memory");
+        return GS_OK;
+    }
+    TRY(lane_rc(ctx, L, lane_drain(L)));
+    return lane_rc(ctx, L, call(L));
+}
+
 static int render_common(gs_ctx *ctx, const gs_render_params *p, void *device_rgba, uint8_t *host_rgba, size_t stride)
 {
-    if (!ctx->renderable && ctx->n) FAIL(GS_E_STATE, "context was fed worker matrices only (gs_push_matrices): it can sort but not render");
     GsFrameUniforms u;
-    TRY(fill_uniforms(ctx, p, u));
+    TRY(gs_fill_uniforms(ctx, p, u));
+    return gs_render_uniforms(ctx, u, device_rgba, host_rgba, stride);
+}
+
+int gs_render_uniforms(gs_ctx *ctx, const GsFrameUniforms &u, void *device_rgba, uint8_t *host_rgba, size_t stride)
+{
+    if (!ctx->renderable && ctx->n) FAIL(GS_E_STATE, "context was fed worker matrices only (gs_push_matrices): it can sort but not render");
     GS_HIP(hipSetDevice(ctx->device));
     gs_ctx *L = ctx->lanes[ctx->cur];                           // the frame's lane: where its gs_sort ran
     const bool async = (u.flags & GS_RENDER_ASYNC) && !host_rgba && !(u.flags & GS_RENDER_COUNT_FRAGS);
@@ -935,6 +962,10 @@ GS_API int gs_set_option(gs_ctx *ctx, int option, int64_t value)
         TRY(drain_all(ctx));
         ctx->enqueue_threads = value != 0;
         return GS_OK;
+    case GS_OPT_COMM_SELF_COPY:
+        GS_HIP(hipSetDevice(ctx->device));
+        TRY(drain_all(ctx));
+        return gs_comm_set_self_copy(ctx, value != 0);
     case GS_OPT_PIPELINE_DEPTH:
         if (value < 1 || value > GS_MAX_LANES) FAIL(GS_E_BADARG, "pipeline depth must be 1..%d", GS_MAX_LANES);
         GS_HIP(hipSetDevice(ctx->device));

@@ -128,6 +128,11 @@ struct gs_ctx {
     uint32_t pair_hint;                     // owner: pairs a frame is expected to bin (1.25 x the last collected frame's; 0 = unknown)
     uint2 *tile_range; size_t tile_cap;     // per tile [start,end) into the sorted pair list
     uint8_t *fb; size_t fb_cap;             // RGBA8 strip
+    // multi-GPU frames (gs_comm.hip)
+    struct GsComm *comm;                    // owner: the communicator this context joined (gs_comm_init)
+    uint8_t *gstage; size_t gstage_cap;     // lane: the pieces of a gathered frame, tight rows each (its own; on the root everybody's)
+    uint8_t *gframe[2]; size_t gframe_cap[2];  // lane, root only: the assembled row-major image(s) of the last gathered frame
+    int gviews, gw[2], gh[2];               // ... and what they hold
     float4 *state; size_t state_cap;        // per tile 64 lanes x 4 float4: (T, r, g, b) of each lane's 4 pixels, round 0 -> 1
     uint32_t *unsat_mask; size_t mask_cap;  // one bit per tile (rows of mask_words words): left unsaturated by round 0
     float near_frac;                        // round 0 covers the nearest near_frac * N splats (adapted from unsat_round0)
@@ -218,6 +223,13 @@ int gs_ply_rows_device(gs_ctx *ctx, const uint8_t *host_data, const gsm::PlyLayo
 extern "C" int gs_ply_plan(const void *bytes, size_t nbytes, gsm::PlyLayout *layout, size_t *nrows, size_t *data_start, char *err, size_t errlen);
 // ---- gs_api.hip
 static inline gs_ctx *gs_root(gs_ctx *c) { return c->parent ? c->parent : c; }
+// (defined inside gs_api.hip's extern "C" block: C linkage, hidden visibility)
+extern "C" int gs_fill_uniforms(gs_ctx *ctx, const gs_render_params *p, GsFrameUniforms &u);
+// render the current frame's strip `u` on its lane (asynchronously if u.flags says so) into device_rgba / host_rgba
+extern "C" int gs_render_uniforms(gs_ctx *ctx, const GsFrameUniforms &u, void *device_rgba, uint8_t *host_rgba, size_t stride);
+// ---- gs_comm.hip
+void gs_comm_free_lane(gs_ctx *lane);
+int gs_comm_set_self_copy(gs_ctx *ctx, bool on);
 int gs_ensure_pair_capacity(gs_ctx *ctx, size_t pairs);
 int gs_ensure_radix_scratch(gs_ctx *ctx, size_t items);         // histogram / totals scratch for a radix sort of `items` records
 // event k (0..GS_PROF_EVENTS-1) of the current profiling slot, or nullptr when profiling is off

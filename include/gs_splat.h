@@ -163,6 +163,38 @@ GS_API void *gs_lane_stream(gs_ctx *ctx, int lane);
 GS_API int gs_wait_stream(gs_ctx *ctx, void *hip_stream);
 GS_API int gs_stream_wait_frame(gs_ctx *ctx, void *hip_stream);
 
+/* ---- several GPUs (no reference counterpart: the reference draws on one WebGL context) ------------------------------
+ * The viewport is split into tile-aligned column strips (or, for XR, the two eyes go to different GPUs), the splat buffer is
+ * replicated, every context sorts for the same view and renders its own pieces, and the pieces are gathered on one root
+ * over RCCL (xGMI).  One gs_ctx per GPU: one process per GPU (the launcher distributes the id: torch.distributed, MPI, a
+ * file) or several contexts in one process.  RCCL is loaded (dlopen "librccl.so.1") by gs_comm_init, not before: a
+ * single-GPU user never needs it.  Every rank must issue the same sequence of gs_sort / gs_render_*_gathered calls. */
+#define GS_COMM_ID_BYTES 128
+/* rank 0: create the id all ranks pass to gs_comm_init (ncclGetUniqueId) */
+GS_API int gs_comm_unique_id(gs_ctx *ctx, void *id_out);
+/* join the communicator as `rank` of `world` (ncclCommInitRank; collective: returns when every rank has called) */
+GS_API int gs_comm_init(gs_ctx *ctx, const void *id, int rank, int world);
+GS_API int gs_comm_destroy(gs_ctx *ctx);
+
+/* Who renders what: nviews images of widths[v] pixels over `world` ranks -> pieces (view, [x0,x1), owner rank), in the
+ * order they are gathered.  One view: tile-aligned column strips, as even as possible, the last strip takes the ragged
+ * edge.  Two views (XR eyes, index.js:13-15): world 1 renders both; otherwise the ranks are divided between the eyes (eye k ->
+ * rank k at world 2) and each eye is split in strips over its ranks.  Returns the number of pieces (<= max_pieces) or < 0. */
+typedef struct gs_piece { int32_t view, x0, x1, owner; } gs_piece;
+GS_API int gs_partition(int nviews, const int *widths, int world, gs_piece *out, int max_pieces);
+
+/* One frame over all ranks: each renders its pieces of the view(s) with the order of its last gs_sort() and sends them to
+ * `root`, where they are assembled into row-major RGBA8 images: device_frames[v] (device memory, fb_width x fb_height x 4
+ * tight) or, if NULL, buffers of the context readable with gs_read_gathered().  views[v].x0/x1 are ignored (the partition
+ * sets them).  flags: GS_RENDER_ASYNC enqueues and returns (completion and status at gs_sync()); GS_RENDER_FLIP_Y applies
+ * per view.  nviews = 2 is the XR frame: two eyes, ONE shared sort from the head camera (index.js:441). */
+GS_API int gs_render_gathered(gs_ctx *ctx, const gs_render_params *views, int nviews, int root, void *const *device_frames,
+                              uint32_t flags);
+/* root: copy view `view` of the last gathered frame (after gs_sync() for asynchronous frames) to host memory */
+GS_API int gs_read_gathered(gs_ctx *ctx, int view, uint8_t *rgba_out, size_t stride);
+#define GS_OPT_COMM_SELF_COPY 8 /* value != 0: the root sends its own pieces to itself through RCCL too instead of rendering them
+                                   in place (exercises send/recv on a single-GPU box; slower) */
+
 /* ---- uniforms / camera helpers (host side; reference: tick + camera matrices, index.js:438-487) ------ */
 
 /* getModelViewMatrix: camera.matrixWorld, object.matrixWorld (column-major f64) -> gsModelViewMatrix */

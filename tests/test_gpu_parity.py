@@ -902,3 +902,57 @@ def test_huge_splats_in_both_rounds_and_record_formats(scene_small):
     ref = images[(1000, 0)]
     for k, img in images.items():
         assert np.array_equal(img, ref), k
+
+
+# ---------------------------------------------------------------- several GPUs behind the C ABI (gs_comm.hip), world 1 here
+
+def test_gathered_frames_through_rccl_world1(scene_small):
+    """gs_render_gathered on a communicator of one rank: partition, staging, (optionally) RCCL send/recv of the root's own
+    pieces to itself, assembly -- the frame on the root equals gs_render's, mono and XR stereo, synchronous and pipelined
+    over the lanes.  (The N > 1 exchange itself needs N GPUs; the partition and assembly logic is also covered on CPU by
+    tests/test_multigpu_gloo.py.)"""
+    import ctypes
+    w, h = 640, 360
+    cams = [synth.index_html_camera(w, h, y, capi=capi) for y in (0.0, 120.0, 240.0, 300.0)]
+    l, r, head = synth.xr_eye_cameras(40.0, 0.25, capi=capi)
+    with capi.Context(0) as c:
+        c.push_splat(scene_small["rows"])
+        want = []
+        for cam in cams:
+            c.sort(cam["view"]); want.append(c.render(_params(cam)))
+        c.sort(head["view"]); wl, wr = c.render_stereo(_params(l), _params(r))
+        # 1. no communicator at all: plain assembly
+        c.sort(cams[0]["view"]); c.render_gathered(_params(cams[0]))
+        assert np.array_equal(c.read_gathered(0, w, h), want[0])
+        # 2. world-1 RCCL communicator, root's pieces rendered in place
+        c.comm_init(c.comm_unique_id(), 0, 1)
+        c.sort(cams[1]["view"]); c.render_gathered(_params(cams[1]))
+        assert np.array_equal(c.read_gathered(0, w, h), want[1])
+        # 3. ... and sent to itself through ncclSend / ncclRecv on the lane's stream
+        c.set_option(capi.OPT_COMM_SELF_COPY, 1)
+        c.sort(cams[2]["view"]); c.render_gathered(_params(cams[2]))
+        assert np.array_equal(c.read_gathered(0, w, h), want[2])
+        # XR: two eyes, one shared sort, two images
+        c.sort(head["view"]); c.render_gathered([_params(l), _params(r)])
+        assert np.array_equal(c.read_gathered(0, l["vw"], l["vh"]), wl) and np.array_equal(c.read_gathered(1, r["vw"], r["vh"]), wr)
+        # pipelined: frames enqueued back to back over the lanes, gathers issued in frame order by the lanes' workers; the
+        # caller's own device frames receive the images
+        hip = ctypes.CDLL("libamdhip64.so")
+        bufs = []
+        for _ in cams:
+            p = ctypes.c_void_p()
+            assert hip.hipMalloc(ctypes.byref(p), ctypes.c_size_t(w * h * 4)) == 0
+            bufs.append(p)
+        for rep in range(2):
+            for cam, b in zip(cams, bufs):
+                c.sort(cam["view"], want_indices=False)
+                c.render_gathered(_params(cam), device_frames=[b.value], flags=capi.RENDER_ASYNC)
+            c.sync()
+        for cam, b, wnt in zip(cams, bufs, want):
+            got = np.empty((h, w, 4), np.uint8)
+            assert hip.hipMemcpy(got.ctypes.data_as(ctypes.c_void_p), b, ctypes.c_size_t(w * h * 4), 2) == 0
+            assert np.array_equal(got, wnt)
+            hip.hipFree(b)
+        c.set_option(capi.OPT_COMM_SELF_COPY, 0)
+        c.sort(cams[3]["view"]); c.render_gathered(_params(cams[3], flags=capi.RENDER_FLIP_Y), flags=capi.RENDER_FLIP_Y)
+        assert np.array_equal(c.read_gathered(0, w, h), want[3][::-1])
