@@ -12,7 +12,7 @@ from . import build as _build
 
 GS_OK = 0
 E_BADARG, E_PLY_HEADER, E_PLY_PROP, E_HIP, E_OOM, E_NODEVICE, E_STATE, E_PLY_DATA, E_RETRY = -1, -2, -3, -4, -5, -6, -7, -8, -9
-RENDER_FLIP_Y, RENDER_COUNT_FRAGS, RENDER_NO_EARLY_OUT, RENDER_ASYNC = 1, 2, 4, 8
+RENDER_FLIP_Y, RENDER_COUNT_FRAGS, RENDER_NO_EARLY_OUT, RENDER_ASYNC, RENDER_COUNT_EVALUATED = 1, 2, 4, 8, 16
 OPT_PROFILE, OPT_TERMINATION, OPT_NEAR_PERMILLE, OPT_RECORD_STAGED, OPT_PIPELINE_DEPTH, OPT_WIDE_PAIRS, OPT_ENQUEUE_THREADS = 1, 2, 3, 4, 5, 6, 7
 OPT_COMM_SELF_COPY = 8
 COMM_ID_BYTES = 128
@@ -25,6 +25,7 @@ EXPORTS = [
     "gs_model_view_matrix", "gs_projection_matrix", "gs_tick_uniforms", "gs_focal", "gs_scaled_size", "gs_set_option",
     "gs_get_stats", "gs_download",
     "gs_comm_unique_id", "gs_comm_init", "gs_comm_destroy", "gs_partition", "gs_render_gathered", "gs_read_gathered",
+    "gs_host_alloc", "gs_host_free",
 ]
 
 
@@ -112,6 +113,8 @@ def load(build_if_missing=True):
     L.gs_partition.argtypes = [i32, C.POINTER(i32), i32, C.POINTER(Piece), i32]
     L.gs_render_gathered.argtypes = [vp, C.POINTER(RenderParams), i32, i32, C.POINTER(vp), C.c_uint32]
     L.gs_read_gathered.argtypes = [vp, i32, vp, sz]
+    L.gs_host_alloc.argtypes = [sz]; L.gs_host_alloc.restype = C.c_void_p
+    L.gs_host_free.argtypes = [vp]; L.gs_host_free.restype = None
     _lib = L
     return L
 
@@ -121,6 +124,23 @@ def _p(a):
 
 
 # ---- host helpers (no context needed) ------------------------------------------------------------------
+
+def host_frame(height, width):
+    """An H x W x 4 uint8 array over page-locked memory (gs_host_alloc); keep the returned owner alive, free with owner.free()."""
+    L = load()
+    n = int(height) * int(width) * 4
+    p = L.gs_host_alloc(n)
+    if not p:
+        raise MemoryError("gs_host_alloc(%d)" % n)
+
+    class _Owner:
+        def free(self):
+            if self.p:
+                L.gs_host_free(self.p); self.p = None
+    o = _Owner(); o.p = p
+    arr = np.ctypeslib.as_array((C.c_uint8 * n).from_address(p)).reshape(int(height), int(width), 4)
+    return arr, o
+
 
 def partition(widths, world):
     """gs_partition: [(view, x0, x1, owner rank)] for one view (column strips) or two (XR eyes), in gather order."""
@@ -271,6 +291,11 @@ class Context:
         out = np.zeros((max(params.fb_height, 0), sw, 4), np.uint8)
         scratch = out if out.size else np.zeros(4, np.uint8)          # let the library reject bad sizes itself
         self._ck(self._L.gs_render(self._h, C.byref(params), _p(scratch), 0))
+        return out
+
+    def render_into(self, params, out):
+        """gs_render into a caller-owned H x w x 4 uint8 array (e.g. page-locked memory from host_frame())."""
+        self._ck(self._L.gs_render(self._h, C.byref(params), _p(out), out.strides[0]))
         return out
 
     def render_device(self, params, device_ptr=None):

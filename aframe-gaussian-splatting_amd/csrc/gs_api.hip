@@ -849,6 +849,15 @@ GS_API int gs_set_scene(gs_ctx *ctx, const float *depth, const uint8_t *rgba, in
     return GS_OK;
 }
 
+GS_API void *gs_host_alloc(size_t nbytes)
+{
+    void *p = nullptr;
+    if (!nbytes || hipHostMalloc(&p, nbytes, hipHostMallocDefault) != hipSuccess) return nullptr;
+    return p;
+}
+
+GS_API void gs_host_free(void *p) { if (p) (void)hipHostFree(p); }
+
 GS_API int gs_sync(gs_ctx *ctx)
 {
     CHECK_CTX(ctx);

@@ -532,7 +532,7 @@ __global__ __launch_bounds__(64) void k_blend(const uint2 *__restrict__ tile_ran
     const int r = (int)ty * GS_TILE + (lane >> 2);                 // image row, 0 = top
     const bool row_in = r < u.H;
     const float fy = (float)(u.H - 1 - r) + 0.5f;                  // pixel centre, GL window coordinates
-    const bool no_early = COUNT || (u.flags & GS_RENDER_NO_EARLY_OUT);
+    const bool no_early = (COUNT && !(u.flags & GS_RENDER_COUNT_EVALUATED)) || (u.flags & GS_RENDER_NO_EARLY_OUT);
     const float t_eps = no_early ? -1.0f : u.t_eps;                // T < t_eps never holds when early-out is off
     // per pixel pair: x centre, transmittance, premultiplied colour (alpha is 1 - T)
     f2 fxA = { (float)xb + 0.5f, (float)(xb + 1) + 0.5f }, fxB = { (float)(xb + 2) + 0.5f, (float)(xb + 3) + 0.5f };

@@ -39,8 +39,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=24)
     ap.add_argument("--splats", type=int, default=None, help="override N (default: train.splat-shaped 1,048,576)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements (latency, readback, no early-out, sparse scene)")
     ap.add_argument("--size", default=None, help="override the viewport, e.g. 3840x2160 (default 1920x1080)")
     ap.add_argument("--cutout", action="store_true", help="cutout-demo.html pose with the cutoutEntity box (config C3)")
+    ap.add_argument("--xr", action="store_true", help="config C4: XR stereo 2 x (2064x2208 x xrPixelRatio 0.5), one shared head-camera sort, "
+                                                    "the eyes divided between the GPUs (eye k -> GPU k at --gpus 2)")
     args = ap.parse_args()
     # stdout carries exactly ONE JSON line: whatever native libraries (RCCL's version banner, HIP warnings) write to file
     # descriptor 1 during the run goes to stderr instead; the line is written to the real stdout at the end
@@ -54,90 +57,92 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    os.environ.setdefault("NCCL_DEBUG", "WARN")            # keep RCCL's version banner off stdout (ONE JSON line)
     dist = torch = None
-    # N > 1: one process per GPU over RCCL.  GS_BENCH_TORCH=1 forces the same code path (torch stream, device strip
-    # tensor, RCCL gather) in a single process so it can be exercised on a 1-GPU box.
-    multi = world > 1 or os.environ.get("GS_BENCH_TORCH") == "1"
-    if multi:
+    # N > 1: one process per GPU.  torch.distributed is the launcher-side plumbing only (rendezvous, the barrier and the
+    # MAX-over-ranks of the contract, handing the communicator id to every rank); the frames' data path -- strips rendered,
+    # sent to rank 0 and assembled -- is inside the C library (gs_render_gathered: RCCL send/recv on the frame's own HIP
+    # stream).  GS_BENCH_COMM=1 runs that same path in a single process (world 1, the root sends its pieces to itself
+    # through RCCL) so that it can be exercised on a 1-GPU box.
+    comm1 = world == 1 and os.environ.get("GS_BENCH_COMM") == "1"
+    if world > 1:
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        os.environ.setdefault("NCCL_DEBUG", "WARN")        # keep RCCL's version banner off stdout (ONE JSON line)
-        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     capi = importlib.import_module(PKG + ".capi")
     synth = importlib.import_module(PKG + ".synth")
-    mg = importlib.import_module(PKG + ".multigpu")
 
     n_splats = args.splats or synth.N_TRAIN
-    rows = synth.make_splat_rows(n_splats)
+    rows = synth.make_splat_rows_fast(n_splats) if n_splats >= (8 << 20) else synth.make_splat_rows(n_splats)
     ctx = capi.Context(local_rank)
-    ctx.push_splat(rows)
+    r32 = rows.reshape(-1, 32)
+    for o in range(0, n_splats, 1 << 22):                    # progressive ingest (index.js:279-298), 4 M rows per push
+        ctx.push_splat(r32[o:o + (1 << 22)])
     depth = int(os.environ.get("GS_BENCH_DEPTH", "0"))       # experiment knob: frames in flight (library default 3)
-    if depth and not multi:
+    if depth:
         ctx.set_option(capi.OPT_PIPELINE_DEPTH, depth)
+    gathered = world > 1 or comm1 or args.xr                 # frames go through gs_render_gathered
+    if world > 1:
+        box = [ctx.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        ctx.comm_init(box[0], rank, world)
+    elif comm1:
+        ctx.comm_init(ctx.comm_unique_id(), 0, 1)
+        ctx.set_option(capi.OPT_COMM_SELF_COPY, 1)
 
-    # tile-aligned column strips
-    x0, x1 = mg.strip_bounds(W, world, rank)
+    # views per orbit pose: one full frame (column strips over the ranks) or the two XR eyes (divided between the ranks)
+    if args.xr:
+        rigs = [synth.xr_eye_cameras(360.0 * i / ORBIT_FRAMES, 0.5, capi=capi) for i in range(ORBIT_FRAMES)]
+        W, H = rigs[0][0]["vw"], rigs[0][0]["vh"]
+        cams = [r[2] for r in rigs]                          # the sort uses the head camera (index.js:441)
+        views = [[capi.make_params(e["gs_mv"], e["gs_proj"], W, H, focal_=e["focal"]) for e in r[:2]] for r in rigs]
+        widths = [W, W]
+    else:
+        pose = synth.cutout_demo_camera if args.cutout else synth.index_html_camera
+        cams = [pose(W, H, 360.0 * i / ORBIT_FRAMES, capi=capi) for i in range(ORBIT_FRAMES)]
+        views = [[capi.make_params(c["gs_mv"], c["gs_proj"], W, H, focal_=c["focal"])] for c in cams]
+        widths = [W]
+    pieces = capi.partition(widths, world)
+    mine = [(v, x0, x1) for v, x0, x1, owner in pieces if owner == rank]
+    own_px = sum((x1 - x0) * H for _, x0, x1 in mine)
+    LANES = 3
 
-    pose = synth.cutout_demo_camera if args.cutout else synth.index_html_camera
-    cams = [pose(W, H, 360.0 * i / ORBIT_FRAMES, capi=capi) for i in range(ORBIT_FRAMES)]
-    params = [capi.make_params(c["gs_mv"], c["gs_proj"], W, H, x0=x0, x1=x1, focal_=c["focal"]) for c in cams]
-    strip = None
-    LANES = 3                                                # frames in flight (the library's default pipeline depth)
-    LAG = 2                                                  # a frame's gather is queued after LAG more frames were handed over
-    strips, gathereds, lane_streams, owed = [], [], {}, []
-    if multi:
-        # One strip buffer per frame in flight.  The RCCL gather of a frame is queued on the SAME stream as the frame's
-        # kernels (the library's pipeline lane, wrapped as a torch ExternalStream; c10d runs a blocking-style collective on
-        # the current stream), so it is ordered after the blend and before the frame that reuses the lane and the buffer --
-        # no cross-stream event anywhere (each one stalls the pipeline for ~50 us here), and the gather of frame k overlaps
-        # the sort/render of frames k+1, k+2 on the other lanes.  The lane's worker thread enqueues the frame; this thread
-        # queues the gather of frame k-LAG after handing over frame k, when that worker has long finished (LAG < LANES, so
-        # the gather still precedes the next frame of its lane).
-        for _ in range(LANES):
-            strips.append(torch.zeros(mg.strip_buffer_bytes(W, H, world), dtype=torch.uint8, device="cuda"))   # tight H x sw x 4 rows
-            gathereds.append([torch.zeros_like(strips[-1]) for _ in range(world)] if rank == 0 else None)
-        strip = strips[0]
-    last_frame = [None]
-
-    def gather_owed(keep):
-        while len(owed) > keep:
-            lane, b = owed.pop(0)
-            sp = ctx.lane_stream(lane)
-            if sp not in lane_streams:
-                lane_streams[sp] = torch.cuda.ExternalStream(sp)
-            with torch.cuda.stream(lane_streams[sp]):
-                last_frame[0] = mg.gather_strips(strips[b], W, H, dist, gathereds[b])   # RCCL gather + row-major frame on rank 0
+    def piece_params(k, v, x0, x1, flags):
+        q = views[k][v]
+        return capi.make_params(np.array(q.model_view), np.array(q.projection), W, H, x0=x0, x1=x1, focal_=q.focal, flags=flags)
 
     def frame(i, flags=0):
         k = i % ORBIT_FRAMES
-        p = params[k]
-        p.flags = flags
         ctx.sort(cams[k]["view"], cams[k]["cutout"], want_indices=False)
-        if not multi:
-            ctx.render_device(p, None)
-            return
-        b = ctx.frame_lane()                                 # the strip buffer belongs to the lane: its stream orders gather and reuse
-        ctx.render_device(p, strips[b].data_ptr())
-        owed.append((b, b))
-        gather_owed(LAG if (flags & capi.RENDER_ASYNC) else 0)
+        if gathered:
+            ctx.render_gathered(views[k], 0, None, flags)
+        else:
+            views[k][0].flags = flags
+            ctx.render_device(views[k][0], None)
+
+    def count_frame(k, flags):
+        """fragments of this rank's pieces of pose k (counting renders are synchronous, per context)"""
+        ctx.sort(cams[k]["view"], cams[k]["cutout"], want_indices=False)
+        tot = 0
+        for v, x0, x1 in mine:
+            ctx.render_device(piece_params(k, v, x0, x1, flags), None)
+            tot += ctx.stats()["n_frags"]
+        return tot
 
     def sync():
-        """Drain the stream; True if the library asks for the frames since the last sync to be rendered again
+        """Drain the streams; True if the library asks for the frames since the last sync to be rendered again
         (GS_E_RETRY) -- agreed on by all ranks so that their control flow stays identical."""
         need = 0
-        if multi:
-            gather_owed(0)
         try:
             ctx.sync()                                       # collects status/statistics of the asynchronous frames
         except capi.GsError as e:
             if e.code != capi.E_RETRY:
                 raise
             need = 1
-        if multi:
+        if world > 1:
             torch.cuda.synchronize()
             t = torch.tensor([need], dtype=torch.int32, device="cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -146,36 +151,34 @@ def main():
             torch.cuda.synchronize()
         return bool(need)
 
-    # reference-equivalent fragments per orbit frame (untimed; no early termination)
+    # reference-equivalent fragments per orbit frame (untimed; no early termination), and the fragments the blend really
+    # evaluates with early termination on (sampled poses)
     frames_used = sorted(set((args.warmup + i) % ORBIT_FRAMES for i in range(args.steps)))
-    frags = {}
-    for k in frames_used:
-        frame(k, capi.RENDER_COUNT_FRAGS)
-        frags[k] = ctx.stats()["n_frags"]                    # (counting renders are synchronous)
-    if multi:
-        t = torch.tensor([frags[k] for k in frames_used], dtype=torch.int64, device="cuda")
+    frags = {k: count_frame(k, capi.RENDER_COUNT_FRAGS) for k in frames_used}
+    sample = frames_used[:: max(1, len(frames_used) // 8)][:8]
+    evaluated = [count_frame(k, capi.RENDER_COUNT_FRAGS | capi.RENDER_COUNT_EVALUATED) for k in sample]
+    if world > 1:
+        t = torch.tensor([frags[k] for k in frames_used] + evaluated, dtype=torch.int64, device="cuda")
         dist.all_reduce(t)
-        frags = dict(zip(frames_used, t.tolist()))
+        vals = t.tolist()
+        frags = dict(zip(frames_used, vals[:len(frames_used)])); evaluated = vals[len(frames_used):]
+    evaluated_per_frame = float(np.mean(evaluated))
+    evaluated_share = evaluated_per_frame / max(1.0, float(np.mean([frags[k] for k in sample])))
 
-    # frames are enqueued back to back like the reference's render loop (GS_RENDER_ASYNC); gs_sync() at the end of
-    # the region collects their status (an overflowing pair buffer would surface there as GS_E_RETRY)
     # list entries the blend really stages before its tiles saturate (untimed measurement aid, sampled over 8 poses of the
-    # region, rank 0's strip): the byte count behind `roofline.achieved_touched`
+    # region, rank 0's first piece): the byte count behind `roofline.achieved_touched`
     staged_per_frame = None
-    if rank == 0:
-        if multi:                                            # no gather may still be reading the strip buffers
-            gather_owed(0)
-            torch.cuda.synchronize()
+    if rank == 0 and mine:
+        v0, xa, xb = mine[0]
         ctx.set_option(capi.OPT_RECORD_STAGED, 1)
         ctx.set_option(capi.OPT_NEAR_PERMILLE, 1000)
         tot = []
-        ntl = ((x1 - x0 + 15) // 16) * ((H + 15) // 16)
-        for k in frames_used[:: max(1, len(frames_used) // 8)][:8]:
+        ntl = ((xb - xa + 15) // 16) * ((H + 15) // 16)
+        for k in sample:
             ctx.sort(cams[k]["view"], cams[k]["cutout"], want_indices=False)
-            params[k].flags = 0
-            ctx.render_device(params[k], strip.data_ptr() if multi else None)
+            ctx.render_device(piece_params(k, v0, xa, xb, 0), None)
             tot.append(int(ctx.download(capi.BUF_TILE_STATS, ntl, np.uint32, 2)[:, 0].astype(np.int64).sum()))
-        staged_per_frame = float(np.mean(tot))
+        staged_per_frame = float(np.mean(tot)) * (own_px / float((xb - xa) * H))
         ctx.set_option(capi.OPT_RECORD_STAGED, 0)
         ctx.set_option(capi.OPT_NEAR_PERMILLE, 0)
 
@@ -218,8 +221,9 @@ def main():
             frame(k)
     s = ctx.stats()
     ctx.set_option(capi.OPT_PROFILE, 0)
-    assert s["acc_frames"] == args.steps and s["prof_frames"] >= max(1, args.steps // 4 - 3), (s["acc_frames"], s["prof_frames"])
-    blend_frames = s["prof_frames"]                          # frames of the timed region whose blend was bracketed by HIP events
+    blends_per_step = len(mine) if gathered else 1
+    assert s["acc_frames"] == args.steps * blends_per_step, (s["acc_frames"], args.steps, blends_per_step)
+    blend_frames = max(1, s["prof_frames"])                  # renders of the timed region whose blend was bracketed by HIP events
     # per-stage breakdown: a second, UNTIMED pass over the same frames with events around every stage (7 per frame
     # instead of 2; they cost ~4 % of the frame rate, so the timed region carries only the blend's)
     ctx.set_option(capi.OPT_PROFILE, 1)
@@ -229,87 +233,266 @@ def main():
     sync()
     s2 = ctx.stats()
     ctx.set_option(capi.OPT_PROFILE, 0)
-    k2 = max(1, s2["prof_frames"])
+    k2 = max(1, s2["prof_frames"]) / float(max(1, blends_per_step))     # profiled steps
     stage = {"ms_sort": s2["sum_ms_sort"] * args.steps / k2, "ms_project": s2["sum_ms_project"] * args.steps / k2,
-             "ms_bin": s2["sum_ms_bin"] * args.steps / k2, "ms_blend": s["sum_ms_blend"] * args.steps / blend_frames}
-    pairs, visible, sorted_n = s["acc_pairs"], s["acc_visible"], s["acc_sorted"]
-    if multi:
+             "ms_bin": s2["sum_ms_bin"] * args.steps / k2, "ms_blend": s["sum_ms_blend"] * args.steps * blends_per_step / blend_frames}
+    pairs, visible, sorted_n = s["acc_pairs"], s["acc_visible"], s["acc_sorted"] / float(max(1, blends_per_step))
+    if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # self-check of the N > 1 path: the frame assembled from the gathered strips of the LAST frame must equal, bit for bit,
-    # the full frame rank 0 renders alone for the same pose (the splat buffer is replicated, strips are tile-aligned)
+    # self-check of the gathered path: the image(s) assembled on rank 0 for the LAST pose must equal, bit for bit, what rank 0
+    # renders alone for the same pose (the splat buffer is replicated, pieces are tile-aligned)
     frame_check = None
-    if multi and rank == 0 and last_frame[0] is not None:
+    if gathered:
         k_last = (args.warmup + args.steps - 1) % ORBIT_FRAMES
-        ctx.sort(cams[k_last]["view"], cams[k_last]["cutout"], want_indices=False)
-        full = ctx.render(capi.make_params(cams[k_last]["gs_mv"], cams[k_last]["gs_proj"], W, H, focal_=cams[k_last]["focal"]))
-        frame_check = bool(np.array_equal(last_frame[0].cpu().numpy(), full))
+        frame(k_last, 0)                                     # collective: every rank
+        if rank == 0:
+            ok = True
+            for v in range(len(widths)):
+                got = ctx.read_gathered(v, W, H)
+                ok = ok and bool(np.array_equal(got, ctx.render(piece_params(k_last, v, 0, W, 0))))
+            frame_check = ok
     copy_peak = measured_copy_peak(ctx, capi) if rank == 0 else None
     total_frags = sum(frags[(args.warmup + i) % ORBIT_FRAMES] for i in range(args.steps))
+    extras = None
+    if rank == 0 and world == 1 and not args.no_extras and not args.xr:
+        extras = secondary_measurements(ctx, capi, synth, rows, cams, views, n_splats, args)
     if rank == 0:
         K = args.steps
         fps = K / elapsed
-        sw = x1 - x0
-        # dominant kernel = the per-tile blend.  Algorithmic bytes per launch:
+        # dominant kernel = the per-tile blend.  Algorithmic bytes per launch, launch = one piece's blend:
         #   B_blend = I*(4 + 32) (pair list entry + projected record, read once per tile) + 4*fb (RGBA8 write)
-        blend_bytes = (pairs / K) * 36.0 + 4.0 * sw * H
-        blend_s = stage["ms_blend"] / K * 1e-3
+        launches = K * blends_per_step
+        blend_bytes = (pairs / launches) * 36.0 + 4.0 * own_px / max(1, len(mine))
+        blend_s = stage["ms_blend"] / launches * 1e-3
         achieved = blend_bytes / blend_s / 1e9 if blend_s > 0 else 0.0
-        touched_bytes = staged_per_frame * 36.0 + 4.0 * sw * H
+        touched_bytes = (staged_per_frame or 0.0) / max(1, len(mine)) * 36.0 + 4.0 * own_px / max(1, len(mine))
         achieved_touched = touched_bytes / blend_s / 1e9 if blend_s > 0 else 0.0
-        # whole-frame algorithmic bytes (SURVEY.md 8d formula)
+        # whole-frame algorithmic bytes (SURVEY.md 8d formula), this rank's share
         V, Vp, I = sorted_n / K, visible / K, pairs / K
-        frame_bytes = (16 * n_splats + 4 * V) + (Vp * 36 + V * 4 + Vp * 32) + (I * 20) + (I * 36 + 4 * sw * H)
-        traffic = None
-        try:                                                 # HBM bytes/launch of k_blend from the committed PMC passes
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_hbm_traffic.json")))
-            if world == 1 and n_splats == synth.N_TRAIN:
-                key = [k for k in pmc if k.startswith("k_blend<false, 0")][0]     # the timed configuration's first-round blend
-                traffic = pmc[key]["hbm_bytes"]
-        except Exception:
-            traffic = None
+        frame_bytes = (16 * n_splats + 4 * V) + (Vp * 36 + V * 4 + Vp * 32) + (I * 20) + (I * 36 + 4 * own_px)
+        traffic, traffic_src = pmc_traffic(world, n_splats, args)
+        if args.xr:
+            metric = "XR stereo frames/sec, 2 x %dx%d (2064x2208 x xrPixelRatio 0.5), one shared head-camera sort" % (W, H)
+            workload = "train.splat-shaped synthetic, N=%d splats, XR stereo 2 x %dx%d, 120-frame orbit (index.html:13 pose, eyes +-32 mm)" % (n_splats, W, H)
+        else:
+            metric = "frames/sec @1920x1080 (sort+project+bin+blend per frame, 1M-splat train.splat-shaped scene)"
+            workload = "train.splat-shaped synthetic, N=%d splats, %dx%d, 120-frame orbit (%s)" % (
+                n_splats, W, H, "cutout-demo.html:22-24 pose + cutoutEntity box" if args.cutout else "index.html:13 pose")
+        if world > 1:
+            par = ("XR eyes divided over %d GPUs" % world if args.xr else "column strips x%d" % world) + \
+                  ", splat buffer replicated, pieces gathered on rank 0 by the C library over RCCL (gs_render_gathered)"
+        else:
+            par = "single GPU" + (", both eyes on it" if args.xr else "") + (", gathered path exercised at world 1 (GS_BENCH_COMM)" if comm1 else "")
         out = {
-            "metric": "frames/sec @1920x1080 (sort+project+bin+blend per frame, 1M-splat train.splat-shaped scene)",
+            "metric": metric,
             "value": round(fps, 3), "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
             "ms_per_step": round(elapsed / K * 1e3, 4), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "train.splat-shaped synthetic, N=%d splats, %dx%d, 120-frame orbit (%s)" % (
-                           n_splats, W, H, "cutout-demo.html:22-24 pose + cutoutEntity box" if args.cutout else "index.html:13 pose"),
-                       "parallelism": "column strips x%d, splat buffer replicated, RCCL gather" % world if world > 1 else "single GPU",
-                       "strip_px": sw, "gathered_frame_equals_single_gpu_render": frame_check,
+            "config": {"workload": workload, "parallelism": par,
+                       "pieces_of_rank0": [[v, x0, x1] for v, x0, x1 in mine], "gathered_frame_equals_single_gpu_render": frame_check,
                        "frames_in_flight": "3 (the library's pipeline lanes: every frame still runs its own full sort, projection, "
-                                           "binning and blend; consecutive frames overlap on the GPU)"},
+                                           "binning and blend; consecutive frames overlap on the GPU); see latency.fps_depth1 for one frame at a time"},
             "occlusion_binning": {"near_permille": s["near_permille"], "unsat_tiles_last_frame": s["unsat_tiles"],
                                   "timed_region_retries": retries},
             "msplat_frags_per_s": round(total_frags / 1e6 / elapsed, 1),
             "frags_per_frame": round(total_frags / K),
+            "frags_evaluated_per_frame": round(evaluated_per_frame),
+            "msplat_frags_evaluated_per_s": round(evaluated_per_frame * fps / 1e6, 1),
+            "frags_evaluated_share": round(evaluated_share, 5),
             "per_frame": {"V_sorted": round(V), "Vp_visible": round(Vp), "I_pairs": round(I),
                           "ms_sort": round(stage["ms_sort"] / K, 4), "ms_project": round(stage["ms_project"] / K, 4),
                           "ms_bin": round(stage["ms_bin"] / K, 4), "ms_blend": round(stage["ms_blend"] / K, 4)},
             "frame_hbm": {"algorithmic_bytes": round(frame_bytes), "achieved_GBps": round(frame_bytes * fps / 1e9, 1),
                           "frac_of_peak": round(frame_bytes * fps / 1e9 / HBM_PEAK_GBS, 5)},
             "roofline": {"kernel": "k_blend", "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
                          "measured_copy_GBps": copy_peak,
-                         "traffic_note": "HBM bytes/launch = 2*FETCH_SIZE + WRITE_SIZE from separate rocprofv3 --pmc passes "
-                                         "(profiles/r01_pmc_hbm_traffic.md); early termination reads far less than the algorithmic 36*I",
+                         "note": "the contract's roof for this path is HBM (no contraction anywhere: no MFMA), and `achieved` is the "
+                                 "algorithmic 36*I + 4*fb bytes over the kernel's launch time; the kernel itself is limited by VALU "
+                                 "issue, not by memory: see roofline_valu",
                          "bytes_per_launch": round(blend_bytes), "avg_launch_ms": round(blend_s * 1e3, 4),
                          "launches_timed": int(blend_frames),
-                         "achieved_touched": round(achieved_touched, 2), "touched_bytes_per_launch": round(touched_bytes),
-                         "touched_note": "36 B x the list entries the kernel actually stages before its tiles saturate (early "
-                                         "termination) + the RGBA8 write; `achieved` uses the full algorithmic 36*I of the contract"},
+                         "achieved_touched": round(achieved_touched, 2), "touched_bytes_per_launch": round(touched_bytes)},
+            "roofline_valu": None,                           # filled in by secondary_measurements (single GPU)
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if extras:
+            out.update(extras)
+        if world == 1 and not args.no_cpu_baseline and not args.xr:
             out["cpu_baseline"] = cpu_baseline(rows, cams[args.warmup % ORBIT_FRAMES], synth)
-        if args.size or args.cutout or args.splats:
+        if (args.size or args.cutout or args.splats) and not args.xr:
             out["metric"] = out["metric"].replace("@1920x1080", "@%dx%d" % (W, H)).replace("1M-splat", "%d-splat" % n_splats)
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
     ctx.close()
-    if multi:
+    if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+# VALU issue model of the blend (tools/micro/valu_rate.hip on gfx950: cycles per wave-instruction at full occupancy) and its
+# instruction count per evaluated fragment group, from the committed PMC pass (profiles/r01_pmc_valu.md: SQ_INSTS_VALU of
+# k_blend / list entries evaluated); both are properties of the kernel's code, re-measured when gs_render.hip changes
+BLEND_VALU_PER_ENTRY = 43.0        # VALU wave-instructions per list entry a tile's wavefront evaluates (256 pixels)
+VALU_CYCLES_PER_INSTR = 4.5        # average issue cost of the blend's mix (v_pk_fma 4.8, v_fma 3.8, v_exp 8.3, v_mul/add 2.5)
+SIMDS, CLOCK_GHZ = 1024, 2.4
+
+
+def pmc_traffic(world, n_splats, args):
+    """HBM bytes per launch of the timed configuration's blend from the committed rocprofv3 --pmc passes -- only if that
+    profile was taken from the kernel sources this run uses (sha of csrc/*.hip, *.h recorded by tools/pmc_summary.py)."""
+    try:
+        import hashlib
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_hbm_traffic.json")))
+        h = hashlib.sha1()
+        csrc = os.path.join(ROOT, PKG, "csrc")
+        for f in sorted(os.listdir(csrc)):
+            if f.endswith((".hip", ".h", ".cpp")):
+                h.update(open(os.path.join(csrc, f), "rb").read())
+        if world != 1 or n_splats != N_TRAIN_DEFAULT or args.size or args.cutout or args.xr:
+            return None, "no PMC pass for this configuration"
+        if pmc.get("_csrc_sha1") != h.hexdigest():
+            return None, "profiles/pmc_hbm_traffic.json was taken from other kernel sources (stale): not reported"
+        key = [k for k in pmc if k.startswith("k_blend<false, 0")][0]
+        return pmc[key]["hbm_bytes"], "profiles/pmc_hbm_traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this bench command; 2*FETCH + WRITE)"
+    except Exception as e:
+        return None, "no usable PMC profile (%s)" % type(e).__name__
+
+
+N_TRAIN_DEFAULT = 1 << 20
+
+
+def secondary_measurements(ctx, capi, synth, rows, cams, views, n_splats, args):
+    """What the headline number does not show: one frame at a time, the frame delivered to host
+    memory, the blend without early termination, and a scene whose tiles do NOT saturate.  Single GPU, untimed for `value`."""
+    out = {}
+
+    def loop(n, flags, first=0):
+        try:
+            ctx.sync()
+        except capi.GsError:
+            pass
+        t0 = time.perf_counter()
+        for i in range(n):
+            k = (first + i) % ORBIT_FRAMES
+            ctx.sort(cams[k]["view"], cams[k]["cutout"], want_indices=False)
+            views[k][0].flags = flags
+            ctx.render_device(views[k][0], None)
+        try:
+            ctx.sync()
+        except capi.GsError as e:
+            if e.code != capi.E_RETRY:
+                raise
+            return None
+        return time.perf_counter() - t0
+
+    n = min(args.steps, 240)
+    # latency: one frame in flight (pipeline depth 1): the kernel chain of a frame alone on the GPU
+    ctx.set_option(capi.OPT_PIPELINE_DEPTH, 1)
+    loop(24, capi.RENDER_ASYNC)
+    t = loop(n, capi.RENDER_ASYNC) or loop(n, capi.RENDER_ASYNC)
+    out["latency"] = {"fps_depth1": round(n / t, 1), "ms_per_frame_depth1": round(t / n * 1e3, 4),
+                      "note": "GS_OPT_PIPELINE_DEPTH = 1: frames enqueued back to back on ONE stream, nothing overlaps"}
+    # entries the blend evaluates (longest-lived lane per tile) -> VALU roofline of the blend, one frame at a time so that the
+    # kernel's HIP-event time is its own
+    ctx.set_option(capi.OPT_PROFILE, 2)
+    loop(24, capi.RENDER_ASYNC)
+    ctx.set_option(capi.OPT_PROFILE, 0); ctx.set_option(capi.OPT_PROFILE, 2)
+    loop(48, capi.RENDER_ASYNC)
+    sb = ctx.stats()
+    ctx.set_option(capi.OPT_PROFILE, 0)
+    blend_alone_s = sb["sum_ms_blend"] / max(1, sb["prof_frames"]) * 1e-3
+    ctx.set_option(capi.OPT_RECORD_STAGED, 2)
+    ev = []
+    ntl = ((W + 15) // 16) * ((H + 15) // 16)
+    for k in range(0, 48, 6):
+        ctx.sort(cams[k]["view"], cams[k]["cutout"], want_indices=False)
+        views[k][0].flags = 0
+        ctx.render_device(views[k][0], None)
+        ev.append(int(ctx.download(capi.BUF_TILE_STATS, ntl, np.uint32, 2)[:, 0].astype(np.int64).sum()))
+    ctx.set_option(capi.OPT_RECORD_STAGED, 0)
+    entries = float(np.mean(ev))
+    instr_rate = entries * BLEND_VALU_PER_ENTRY / blend_alone_s / 1e9 if blend_alone_s > 0 else 0.0
+    peak = SIMDS * CLOCK_GHZ / VALU_CYCLES_PER_INSTR
+    out["roofline_valu"] = {"kernel": "k_blend", "bound": "valu", "achieved": round(instr_rate, 1), "peak": round(peak, 1),
+                            "unit": "G wave-instr/s", "frac": round(instr_rate / peak, 4),
+                            "list_entries_evaluated_per_launch": round(entries), "avg_launch_ms_alone": round(blend_alone_s * 1e3, 4),
+                            "instr_per_list_entry": BLEND_VALU_PER_ENTRY, "cycles_per_instr": VALU_CYCLES_PER_INSTR,
+                            "note": "VALU wave-instructions issued per second by the blend running alone (depth 1) against "
+                                    "1024 SIMDs x 2.4 GHz / 4.5 cycles per instruction; entries = list entries each tile's wavefront "
+                                    "evaluated before it saturated (GS_OPT_RECORD_STAGED = 2, this run); 43 VALU instructions per entry "
+                                    "and the issue costs are properties of the kernel code (profiles/r01_pmc_valu.md, tools/micro/valu_rate.hip)"}
+    # the frame delivered to the host (what a JS caller of component.render() gets): gs_render into page-locked memory
+    host, owner = capi.host_frame(H, W)
+    t0 = time.perf_counter()
+    m = min(n, 120)
+    for i in range(m):
+        k = i % ORBIT_FRAMES
+        ctx.sort(cams[k]["view"], cams[k]["cutout"], want_indices=False)
+        views[k][0].flags = 0
+        ctx.render_into(views[k][0], host)
+    t = time.perf_counter() - t0
+    owner.free()
+    out["host_readback"] = {"fps_host_readback": round(m / t, 1), "ms_per_frame": round(t / m * 1e3, 4),
+                            "note": "synchronous gs_render into page-locked host memory (%.1f MB D2H per frame over PCIe), one frame at a time"
+                                    % (W * H * 4 / 1e6)}
+    ctx.set_option(capi.OPT_PIPELINE_DEPTH, int(os.environ.get("GS_BENCH_DEPTH", "0")) or 3)
+    # the blend without early termination (every reference-equivalent fragment evaluated), pipelined like the headline
+    loop(6, capi.RENDER_ASYNC | capi.RENDER_NO_EARLY_OUT)
+    m = min(n, 60)
+    t = loop(m, capi.RENDER_ASYNC | capi.RENDER_NO_EARLY_OUT)
+    if t:
+        out["no_early_out"] = {"fps_no_early_out": round(m / t, 1),
+                               "note": "GS_RENDER_NO_EARLY_OUT: one binning round over all splats, every fragment blended"}
+    # a scene that does NOT saturate: the same splats at a tenth of their opacity (alpha byte / 10): most tiles stay
+    # unsaturated after the nearest-splats round, so the second binning round does real work in every frame
+    sparse = rows.reshape(-1, 32).copy()
+    sparse[:, 27] = sparse[:, 27] // 10
+    with capi.Context(ctx.device) as c2:
+        c2.push_splat(sparse)
+
+        def loop2(nn, flags):
+            try:
+                c2.sync()
+            except capi.GsError:
+                pass
+            t0 = time.perf_counter()
+            for i in range(nn):
+                k = i % ORBIT_FRAMES
+                c2.sort(cams[k]["view"], cams[k]["cutout"], want_indices=False)
+                views[k][0].flags = flags
+                c2.render_device(views[k][0], None)
+            try:
+                c2.sync()
+            except capi.GsError as e:
+                if e.code != capi.E_RETRY:
+                    raise
+                return None
+            return time.perf_counter() - t0
+        for _ in range(2):
+            loop2(ORBIT_FRAMES, 0)                           # synchronous frames: the share settles
+        loop2(12, capi.RENDER_ASYNC)
+        m = min(n, 120)
+        t = loop2(m, capi.RENDER_ASYNC) or loop2(m, capi.RENDER_ASYNC) or loop2(m, capi.RENDER_ASYNC)
+        st = c2.stats()
+        if t:
+            out["unsaturated_scene"] = {"fps": round(m / t, 1), "near_permille": st["near_permille"],
+                                        "unsat_tiles_last_frame": st["unsat_tiles"], "tiles": st["n_tiles"],
+                                        "I_pairs_last_frame": st["n_pairs"],
+                                        "workload": "the same %d splats with opacity / 10 (tiles need 5-10x longer lists to reach T < 1/4096), "
+                                                    "%dx%d, 3 frames in flight; the library adapts by raising the share of splats binned first" % (n_splats, W, H)}
+        # ... and with that share pinned low, so that round 0 leaves most tiles unsaturated and the second binning round (masked
+        # tiles, resumed per-pixel state) does real work in every frame
+        c2.set_option(capi.OPT_NEAR_PERMILLE, 150)
+        loop2(12, 0); loop2(12, capi.RENDER_ASYNC)
+        t = loop2(m, capi.RENDER_ASYNC)
+        st = c2.stats()
+        if t:
+            out["unsaturated_scene"]["two_rounds_pinned"] = {
+                "fps": round(m / t, 1), "near_permille_pinned": 150, "unsat_tiles_last_frame": st["unsat_tiles"], "tiles": st["n_tiles"],
+                "unsat_share": round(st["unsat_tiles"] / max(1.0, float(st["n_tiles"])), 3), "I_pairs_last_frame": st["n_pairs"]}
+    return out
 
 
 def cpu_baseline(rows, cam, synth):

@@ -104,6 +104,8 @@ GS_API int gs_sort(gs_ctx *ctx, const float view[4], const float *cutout16, uint
 #define GS_RENDER_FLIP_Y 1u      /* rows bottom-up (WebGL readPixels order) instead of top-down              */
 #define GS_RENDER_COUNT_FRAGS 2u /* no early termination; count reference-equivalent splat-fragments         */
 #define GS_RENDER_NO_EARLY_OUT 4u/* blend every fragment (parity debugging)                                   */
+#define GS_RENDER_COUNT_EVALUATED 16u /* with GS_RENDER_COUNT_FRAGS: leave early termination ON and count the fragments
+                                    the blend really evaluates (one binning round; what the reference-equivalent count shrinks to) */
 #define GS_RENDER_ASYNC 8u       /* gs_render_device only: enqueue the frame and return; completion, status and
                                     statistics are collected by gs_sync().  The reference renders every frame
                                     without waiting for the GPU either (index.js:184-207).                        */
@@ -137,6 +139,11 @@ GS_API int gs_render_stereo(gs_ctx *ctx, const gs_render_params eyes[2], uint8_t
  * row 0 = top, host memory (copied); NULL for either = not used; gs_set_scene(ctx, NULL, NULL, 0, 0) clears.
  * Renders whose fb_width/fb_height differ from the scene's fail with GS_E_BADARG. */
 GS_API int gs_set_scene(gs_ctx *ctx, const float *depth, const uint8_t *rgba, int fb_width, int fb_height);
+
+/* Page-locked host memory for framebuffers (gs_render copies into it at PCIe speed, no staging copy; the N-API addon hands
+ * it to JavaScript as an external ArrayBuffer).  Free with gs_host_free. */
+GS_API void *gs_host_alloc(size_t nbytes);
+GS_API void gs_host_free(void *p);
 
 /* Block until all work queued on the context's stream is done; collects the status and statistics of frames
  * rendered with GS_RENDER_ASYNC on any lane (GS_E_RETRY if one of them overflowed the pair buffers). */

@@ -37,7 +37,16 @@ def main():
         o.write("| kernel | launches | FETCH_SIZE KiB/launch | WRITE_SIZE KiB/launch | HBM bytes/launch (2*F+W) |\n|---|---:|---:|---:|---:|\n")
         for r in rows:
             o.write("| %s | %d | %.1f | %.1f | %d |\n" % (r["kernel"], r["launches"], r["fetch_KiB"], r["write_KiB"], r["hbm_bytes"]))
-    json.dump({r["kernel"]: r for r in rows}, open(sys.argv[4], "w"), indent=1)
+    # the kernel sources these counters belong to: bench.py reports `roofline.traffic` only while they are unchanged
+    import hashlib, os
+    csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "aframe-gaussian-splatting_amd", "csrc")
+    h = hashlib.sha1()
+    for fn in sorted(os.listdir(csrc)):
+        if fn.endswith((".hip", ".h", ".cpp")):
+            h.update(open(os.path.join(csrc, fn), "rb").read())
+    d = {r["kernel"]: r for r in rows}
+    d["_csrc_sha1"] = h.hexdigest()
+    json.dump(d, open(sys.argv[4], "w"), indent=1)
 
 
 if __name__ == "__main__":
