@@ -15,6 +15,7 @@ E_BADARG, E_PLY_HEADER, E_PLY_PROP, E_HIP, E_OOM, E_NODEVICE, E_STATE, E_PLY_DAT
 RENDER_FLIP_Y, RENDER_COUNT_FRAGS, RENDER_NO_EARLY_OUT, RENDER_ASYNC, RENDER_COUNT_EVALUATED = 1, 2, 4, 8, 16
 OPT_PROFILE, OPT_TERMINATION, OPT_NEAR_PERMILLE, OPT_RECORD_STAGED, OPT_PIPELINE_DEPTH, OPT_WIDE_PAIRS, OPT_ENQUEUE_THREADS = 1, 2, 3, 4, 5, 6, 7
 OPT_COMM_SELF_COPY = 8
+OPT_BLEND_SPLIT = 9
 COMM_ID_BYTES = 128
 BUF_CENTER_SCALE, BUF_COV_COLOR, BUF_SORT_ROWS, BUF_SORTED, BUF_PROJECTED, BUF_TILE_COUNT, BUF_TILE_STATS = 0, 1, 2, 3, 4, 5, 6
 

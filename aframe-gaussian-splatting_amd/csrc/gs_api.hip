@@ -692,7 +692,7 @@ int gs_fill_uniforms(gs_ctx *ctx /* owner: options, adaptive share, scene */, co
         FAIL(GS_E_BADARG, "strip of %dx%d pixels has %llu tiles; at most 262144 (16x16-pixel tiles) are supported: render it in column strips",
              p->x1 - p->x0, p->fb_height, (unsigned long long)u.tiles_x * (unsigned long long)u.tiles_y);
     memcpy(u.bg, p->background, sizeof u.bg);
-    u.t_eps = ctx->t_eps; u.flags = p->flags; u.record_staged = ctx->record_staged;
+    u.t_eps = ctx->t_eps; u.flags = p->flags; u.record_staged = ctx->record_staged; u.split_min = ctx->blend_split_min;
     u.mask_words = (uint32_t)(u.tiles_x + 31) / 32;
     // round 0 covers the nearest near_frac * N splats; counting / no-early-out renders need every fragment -> one round
     const float frac = ctx->near_fixed_permille > 0 ? ctx->near_fixed_permille / 1000.0f : ctx->near_frac;
@@ -970,6 +970,10 @@ GS_API int gs_set_option(gs_ctx *ctx, int option, int64_t value)
         GS_HIP(hipSetDevice(ctx->device));
         TRY(drain_all(ctx));
         ctx->enqueue_threads = value != 0;
+        return GS_OK;
+    case GS_OPT_BLEND_SPLIT:
+        if (value < 0 || value > 0x7FFFFFFF) FAIL(GS_E_BADARG, "blend split: 0 (off) or the list length from which a tile is split");
+        ctx->blend_split_min = (uint32_t)value;
         return GS_OK;
     case GS_OPT_COMM_SELF_COPY:
         GS_HIP(hipSetDevice(ctx->device));

@@ -62,12 +62,14 @@ struct GsFrameUniforms {           // per-render constants, passed by value to k
     int32_t tiles_x, tiles_y;      // tile grid of the strip (origin at pixel x0, row 0 = top)
     float bg[4];
     float t_eps;                   // early-out threshold on transmittance
-    uint32_t flags;
+    uint32_t flags;                // GS_RENDER_* of the call | GS_FRAME_* (internal)
     uint32_t record_staged;        // GS_OPT_RECORD_STAGED: blend overwrites the tile-range table with (staged, length)
     uint32_t near_count;           // round 0 bins the nearest near_count splats; 0xFFFFFFFF = single round (everything)
     uint32_t mask_words;           // 32-bit words per tile row of the unsaturated-tile mask
     uint32_t skip_round1;          // round 1 is not launched for this frame (optimistic; blend<0> raises round1_missed)
     uint32_t has_depth, has_scene_rgba;   // scene compositing inputs present (gs_set_scene)
+    uint32_t split_min;            // GS_OPT_BLEND_SPLIT: tiles whose list has at least this many entries are blended by GS_SPLIT_WAVES
+                                   // wavefronts (k_blend<.., GS_SPLIT_WAVES>), the others by one; 0 = all by one
     uint32_t pair_jbits;           // > 0: 4-byte pair records (tile << pair_jbits | sorted position - j_lo); 0: (tile, position) uint2
 };
 
@@ -125,6 +127,7 @@ struct gs_ctx {
     float *zwin;                   // V window depth of each sorted splat (written only while a scene depth buffer is set)
     float *scene_depth; uint32_t *scene_rgba; int scene_w, scene_h;   // gs_set_scene
     uint2 *pair_a, *pair_b; size_t pair_cap;   // (tile id, sorted position) records, ping-pong
+    uint32_t blend_split_min;               // owner: GS_OPT_BLEND_SPLIT
     uint32_t pair_hint;                     // owner: pairs a frame is expected to bin (1.25 x the last collected frame's; 0 = unknown)
     uint2 *tile_range; size_t tile_cap;     // per tile [start,end) into the sorted pair list
     uint8_t *fb; size_t fb_cap;             // RGBA8 strip

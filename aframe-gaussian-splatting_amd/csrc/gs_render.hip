@@ -565,6 +565,7 @@ __global__ __launch_bounds__(64) void k_blend(const uint2 *__restrict__ tile_ran
     bool live = GS_LANE_LIVE();
     uint32_t nfr = 0, staged = 0, evaluated = 0;
     const uint2 range = tile_range[tile];
+    if (u.split_min && range.y - range.x >= u.split_min) continue;  // a long list: k_blend_px takes the tile (GS_OPT_BLEND_SPLIT)
 
     for (uint32_t end = range.y; end > range.x;) {
         const uint32_t nb = min((uint32_t)GS_BLEND_BATCH, end - range.x);
@@ -714,6 +715,175 @@ __global__ __launch_bounds__(64) void k_blend(const uint2 *__restrict__ tile_ran
     }
 }
 
+// GS_OPT_BLEND_SPLIT: the tiles with LONG lists, four wavefronts per tile, ONE pixel per lane (wave w: tile rows 4w .. 4w+3).
+// A frame in which few tiles carry long lists (a cut-out scene filling a tenth of the screen: 800 active tiles, lists of
+// 4000-6000 entries of which the busiest tile evaluates 1100 before it saturates) lasts as long as ONE wavefront's serial
+// walk of its list, at ~43 dependent VALU instructions per entry for its 4 pixels per lane, while most of the chip idles.
+// With a pixel per lane an entry costs ~14 instructions, the four bands of a tile walk the list concurrently on different
+// SIMDs, and each band stops as soon as ITS 64 pixels are saturated.  Same fragments, same per-pixel operation sequence; a
+// pixel now stops exactly when it falls below the threshold instead of when its lane's four pixels have (differences
+// < t_eps: within the 1 LSB tolerance, not bit-identical to k_blend's image).  Every wave stages its own batches, so the
+// projected records are read four times: affordable exactly when few tiles are active.
+// (Measured and dropped: splitting the LIST over 8 waves -- segments blended from fresh states and composed front to back.
+// A segment that starts at T = 1 never terminates early, so the tile's work grows from the ~300-1100 entries it really needs
+// to min(L, 2048): 188 -> 284 us on the 6 M cut-out frame.)
+#ifndef GS_PX_BATCH
+#define GS_PX_BATCH 128u           // list entries k_blend_px stages per batch (a multiple of 64: two dependent global loads per batch are the latency to hide)
+#endif
+#ifndef GS_PX_GROUP
+#define GS_PX_GROUP 4u             // list entries per step of k_blend_px (independent coverage tests and exp(): instruction-level parallelism)
+#endif
+template <int ROUND, bool SCENE>
+__global__ __launch_bounds__(256) void k_blend_px(const uint2 *__restrict__ tile_range, const void *__restrict__ pairs,
+                                                  const gsm::Projected *__restrict__ proj, GsFrameUniforms u,
+                                                  uint8_t *__restrict__ out, float4 *__restrict__ state, uint32_t *__restrict__ mask,
+                                                  const float *__restrict__ zwin, const float *__restrict__ scene_depth,
+                                                  const uint32_t *__restrict__ scene_rgba, GsControl *ctl)
+{
+    constexpr uint32_t PB = GS_PX_BATCH, PR = GS_PX_BATCH / 64u;   // records per batch / per lane
+    // a batch in LDS, per wave, laid out for two entries per packed-fp32 instruction: pair p = entries (2p, 2p+1) holds
+    // (cx0, cx1, cy0, cy1), (ax0, ax1, ay0, ay1), (bx0, bx1, by0, by1); colours (r, g, b) * alpha / 255 and alpha per entry
+    __shared__ float s_pair_all[4][3][PB / 2][4];
+    __shared__ float4 s_col_all[4][PB];
+    __shared__ float s_z_all[4][PB];
+    __shared__ uint32_t s_live[4];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    float (*s_pair)[PB / 2][4] = s_pair_all[w];
+    float4 *s_col = s_col_all[w];
+    float *s_z = s_z_all[w];
+    // a batch staged by the wave's lanes is read by all of them; the four waves run their own trip counts, so this is the
+    // completion of the wave's own LDS operations, not a workgroup barrier.  Only lgkmcnt: a fence would also wait for the
+    // global loads of the NEXT batch, which are in flight on purpose (that made every batch pay its two dependent loads)
+#define GS_WAVE_LDS_SYNC() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); } while (0)
+    if (ROUND == 1 && ctl->j_hi == 0) return;                      // every tile saturated in round 0
+    const uint32_t ntiles = (uint32_t)u.tiles_x * (uint32_t)u.tiles_y;
+    const uint32_t pair_j_lo = ctl->j_lo, pair_j_mask = (1u << u.pair_jbits) - 1u;
+    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const uint32_t tx = tile % (uint32_t)u.tiles_x, ty = tile / (uint32_t)u.tiles_x;
+        if (ROUND == 1 && !((mask[ty * u.mask_words + (tx >> 5)] >> (tx & 31)) & 1u)) continue;   // this tile is final already
+        const uint2 range = tile_range[tile];
+        if (range.y - range.x < u.split_min) continue;                // a short list: k_blend's tile
+        const int col = lane & 15, rr = w * 4 + (lane >> 4);           // pixel (col, rr) of the tile
+        const int px = u.x0 + (int)tx * GS_TILE + col;
+        const int r = (int)ty * GS_TILE + rr;                          // image row, 0 = top
+        const bool in = r < u.H && px < u.x1;
+        const float fx = (float)px + 0.5f, fy = (float)(u.H - 1 - r) + 0.5f;   // pixel centre, GL window coordinates
+        const float t_eps = (u.flags & GS_RENDER_NO_EARLY_OUT) ? -1.0f : u.t_eps;
+        const float qm = in ? 4.0f : -1.0f;                            // fragment kept iff q <= 4 (index.js:172); never outside the strip
+        float T = in ? 1.0f : 0.0f, cr = 0.0f, cg = 0.0f, cb = 0.0f;
+        float zb = 3.0e38f;
+        if (SCENE && u.has_depth && in) zb = scene_depth[(size_t)r * u.W + px];
+        // the per-pixel state of k_blend's layout: lane (rr * 4 + col / 4) holds 4 x float4 (T, r, g, b) of its 4 pixels
+        float *st = reinterpret_cast<float *>(state + ((size_t)tile * 64 + (uint32_t)(rr * 4 + col / 4)) * 4) + (col & 3);
+        if (ROUND == 1) { T = st[0]; cr = st[4]; cg = st[8]; cb = st[12]; }
+        bool live = T >= t_eps;
+        // the batch after the current one is fetched (pair -> projected record: two dependent global loads) while the current
+        // one is blended: a wave alone on its SIMD has nothing else to hide that latency behind
+        float4 n0[PR], n1[PR];
+        float nz[PR];
+#define GS_PX_FETCH(END, NB) do { _Pragma("unroll") for (uint32_t h = 0; h < PR; h++) { const uint32_t slot = h * 64u + (uint32_t)lane;          \
+            if (slot < (NB)) {                                                                                                               \
+            const uint32_t j = u.pair_jbits ? pair_j_lo + (reinterpret_cast<const uint32_t *>(pairs)[(END) - 1 - slot] & pair_j_mask)          \
+                                            : reinterpret_cast<const uint2 *>(pairs)[(END) - 1 - slot].y;                                    \
+            const float4 *src = reinterpret_cast<const float4 *>(proj + j);                                                                  \
+            n0[h] = src[0]; n1[h] = src[1];                                                                                                  \
+            if (SCENE) nz[h] = u.has_depth ? zwin[j] : 0.0f; } } } while (0)
+        GS_PX_FETCH(range.y, min(PB, range.y - range.x));              // nearest first: the list is back to front
+        for (uint32_t end = range.y; end > range.x;) {
+            const uint32_t nb = min(PB, end - range.x);
+            const uint32_t nbp = (nb + GS_PX_GROUP - 1u) & ~(GS_PX_GROUP - 1u);   // whole groups
+#pragma unroll
+            for (uint32_t h = 0; h < PR; h++) {
+                const uint32_t slot = h * 64u + (uint32_t)lane;
+                const uint32_t pi = slot >> 1, pk = slot & 1u;
+                if (slot < nb) {
+                    s_pair[0][pi][pk] = n0[h].x; s_pair[0][pi][2 + pk] = n0[h].y;      // centre
+                    s_pair[1][pi][pk] = n0[h].z; s_pair[1][pi][2 + pk] = n0[h].w;      // axis a
+                    s_pair[2][pi][pk] = n1[h].x; s_pair[2][pi][2 + pk] = n1[h].y;      // axis b
+                    // what every lane would otherwise redo for every list entry: unpack the colour, fold alpha / 255 into it
+                    const uint32_t rgba = __float_as_uint(n1[h].z);
+                    const float a255 = n1[h].w * (1.0f / 255.0f);
+                    s_col[slot] = make_float4((float)(rgba & 0xFF) * a255, (float)((rgba >> 8) & 0xFF) * a255, (float)((rgba >> 16) & 0xFF) * a255, n1[h].w);
+                    if (SCENE) s_z[slot] = nz[h];
+                } else if (slot < nbp) {                              // pad the batch to whole groups with records no pixel can pass
+                    if (SCENE) s_z[slot] = 0.0f;
+                    s_pair[0][pi][pk] = -1.0e9f; s_pair[0][pi][2 + pk] = -1.0e9f;       // centre far away, a = b = (1,1): q ~ 1e18 > 4
+                    s_pair[1][pi][pk] = 1.0f; s_pair[1][pi][2 + pk] = 1.0f;
+                    s_pair[2][pi][pk] = 1.0f; s_pair[2][pi][2 + pk] = 1.0f;
+                    s_col[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                }
+            }
+            if (end - nb > range.x) GS_PX_FETCH(end - nb, min(PB, end - nb - range.x));
+            GS_WAVE_LDS_SYNC();
+            if (live) {
+                // GS_PX_GROUP list entries per step.  Coverage and exp() of the group are independent of each other and of the pixel's
+                // state, so their LDS reads and ~10-instruction chains overlap; what is sequential per entry is only
+                // e = E * T; T -= alpha * e; C += c * e -- the same operations in the same order as k_blend applies them.
+                // A wave that runs alone on its SIMD (few active tiles) is bound by dependent-instruction latency, not issue.
+                for (uint32_t s4 = 0; s4 < nb; s4 += GS_PX_GROUP) {
+                    float E[GS_PX_GROUP];
+                    float4 cc[GS_PX_GROUP];
+#pragma unroll
+                    for (uint32_t k = 0; k < GS_PX_GROUP; k += 2) {
+                        const uint32_t pi = (s4 + k) >> 1;
+                        const float4 R0 = *reinterpret_cast<const float4 *>(s_pair[0][pi]), R1 = *reinterpret_cast<const float4 *>(s_pair[1][pi]);
+                        const float4 R2 = *reinterpret_cast<const float4 *>(s_pair[2][pi]);
+                        cc[k] = s_col[s4 + k]; cc[k + 1] = s_col[s4 + k + 1];
+                        // |p|^2 of the interpolated vPosition, same expression tree per pixel as gsm::frag_power / k_blend
+                        const f2 dx = (f2)(fx) - (f2){ R0.x, R0.y }, dy = (f2)(fy) - (f2){ R0.z, R0.w };
+                        const f2 pxv = fma2(dx, (f2){ R1.x, R1.y }, dy * (f2){ R1.z, R1.w });
+                        const f2 pyv = fma2(dx, (f2){ R2.x, R2.y }, dy * (f2){ R2.z, R2.w });
+                        const f2 q = fma2(pxv, pxv, pyv * pyv);
+                        bool p0 = q.x <= qm, p1 = q.y <= qm;           // discard test, index.js:172
+                        if (SCENE) { p0 = p0 && s_z[s4 + k] <= zb; p1 = p1 && s_z[s4 + k + 1] <= zb; }
+                        E[k] = p0 ? __expf(-q.x) : 0.0f;               // exp(A) (index.js:173); 0 where the splat misses the pixel
+                        E[k + 1] = p1 ? __expf(-q.y) : 0.0f;
+                    }
+#pragma unroll
+                    for (uint32_t k = 0; k < GS_PX_GROUP; k++) {
+                        const float e = E[k] * T;
+                        T = fmaf(-cc[k].w, e, T);
+                        cr = fmaf(cc[k].x, e, cr); cg = fmaf(cc[k].y, e, cg); cb = fmaf(cc[k].z, e, cb);
+                    }
+                    live = T >= t_eps;                                 // (checked per group: a few entries past the threshold, < t_eps in total)
+                    if (!live) break;
+                }
+            }
+            end -= nb;
+            GS_WAVE_LDS_SYNC();                                      // s_rec is rewritten by the next batch
+            if (__all(!live)) break;
+        }
+        const bool wave_live = __any(live);
+        if (lane == 0) s_live[w] = wave_live ? 1u : 0u;
+        __syncthreads();
+        const bool tile_live = (s_live[0] | s_live[1] | s_live[2] | s_live[3]) != 0u;
+        if (ROUND == 0 && u.near_count < ctl->n_kept && tile_live) {  // farther splats exist beyond this round and the tile wants them
+            st[0] = T; st[4] = cr; st[8] = cg; st[12] = cb;
+            if (threadIdx.x == 0) {
+                atomicOr(&mask[ty * u.mask_words + (tx >> 5)], 1u << (tx & 31)); atomicAdd(&ctl->unsat_count, 1u);
+                if (u.skip_round1) ctl->round1_missed = 1;
+            }
+        }
+        if (in) {
+            float b0 = u.bg[0], b1 = u.bg[1], b2 = u.bg[2], b3 = u.bg[3];
+            if (SCENE && u.has_scene_rgba) {
+                const uint32_t c = scene_rgba[(size_t)r * u.W + px];
+                b0 = (float)(c & 0xFF) / 255.0f; b1 = (float)((c >> 8) & 0xFF) / 255.0f;
+                b2 = (float)((c >> 16) & 0xFF) / 255.0f; b3 = (float)(c >> 24) / 255.0f;
+            }
+            const float o0 = fmaf(T, b0, cr), o1 = fmaf(T, b1, cg), o2 = fmaf(T, b2, cb), o3 = fmaf(T, b3, 1.0f - T);
+            const int sw = u.x1 - u.x0;
+            const int orow = (u.flags & GS_RENDER_FLIP_Y) ? (u.H - 1 - r) : r;
+            reinterpret_cast<uint32_t *>(out)[(size_t)orow * sw + (px - u.x0)] =
+                (uint32_t)(fminf(fmaxf(o0, 0.0f), 1.0f) * 255.0f + 0.5f) | ((uint32_t)(fminf(fmaxf(o1, 0.0f), 1.0f) * 255.0f + 0.5f) << 8) |
+                ((uint32_t)(fminf(fmaxf(o2, 0.0f), 1.0f) * 255.0f + 0.5f) << 16) | ((uint32_t)(fminf(fmaxf(o3, 0.0f), 1.0f) * 255.0f + 0.5f) << 24);
+        }
+        __syncthreads();                                             // s_live / the waves' LDS are reused by the next tile
+    }
+#undef GS_PX_FETCH
+#undef GS_WAVE_LDS_SYNC
+}
+
 int bits_for(uint32_t n) { int b = 1; while (b < 32 && (1u << b) < n) b++; return b; }
 
 // one round: project -> offsets -> emit -> stable sort by tile -> ranges -> blend.  Round 1 usually finds nothing to
@@ -772,6 +942,15 @@ int run_round(gs_ctx *ctx, const GsFrameUniforms &u, uint8_t *out, bool last_rou
     if (ROUND == 0) GS_PROF_RECORD(ctx, 4);
     const uint32_t gb = ROUND == 1 ? (ntiles < 1024 ? ntiles : 1024) : ntiles;
     const bool scene = u.has_depth || u.has_scene_rgba;
+    if ((u.flags & GS_RENDER_COUNT_FRAGS) || u.record_staged) v.split_min = 0;     // measurement renders: every tile by k_blend
+    if (v.split_min) {
+        // the tiles with long lists first (the long pole): workgroups stride over all tiles' ranges and take the long ones
+        const uint32_t gp = ntiles < 2048 ? ntiles : 2048;
+        if (scene) hipLaunchKernelGGL((k_blend_px<ROUND, true>), dim3(gp), dim3(256), 0, st, ctx->tile_range, fpairs, ctx->proj, v, out, ctx->state,
+                                      ctx->unsat_mask, ctx->zwin, ctx->scene_depth, ctx->scene_rgba, ctx->ctl);
+        else hipLaunchKernelGGL((k_blend_px<ROUND, false>), dim3(gp), dim3(256), 0, st, ctx->tile_range, fpairs, ctx->proj, v, out, ctx->state,
+                                ctx->unsat_mask, ctx->zwin, ctx->scene_depth, ctx->scene_rgba, ctx->ctl);
+    }
 #define GS_LAUNCH_BLEND(C, S) hipLaunchKernelGGL((k_blend<C, ROUND, S>), dim3(gb), dim3(64), 0, st, ctx->tile_range, fpairs, ctx->proj, v, \
                                                 out, ctx->state, ctx->unsat_mask, ctx->zwin, ctx->scene_depth, ctx->scene_rgba, ctx->ctl)
     if (u.flags & GS_RENDER_COUNT_FRAGS) { if (scene) GS_LAUNCH_BLEND(true, true); else GS_LAUNCH_BLEND(true, false); }

@@ -84,6 +84,11 @@ def main():
     depth = int(os.environ.get("GS_BENCH_DEPTH", "0"))       # experiment knob: frames in flight (library default 3)
     if depth:
         ctx.set_option(capi.OPT_PIPELINE_DEPTH, depth)
+    blend_split = int(os.environ.get("GS_BENCH_SPLIT", "1" if args.cutout else "0"))
+    if blend_split:
+        # the cut-out scene (C3) fills a tenth of the screen: ~600 active tiles with lists of thousands of entries.  Tiles with a
+        # list are blended by four wavefronts, one pixel per lane (GS_OPT_BLEND_SPLIT; images within the same 1 LSB tolerance)
+        ctx.set_option(capi.OPT_BLEND_SPLIT, blend_split)
     gathered = world > 1 or comm1 or args.xr                 # frames go through gs_render_gathered
     if world > 1:
         box = [ctx.comm_unique_id() if rank == 0 else None]
@@ -293,6 +298,7 @@ def main():
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": workload, "parallelism": par,
                        "pieces_of_rank0": [[v, x0, x1] for v, x0, x1 in mine], "gathered_frame_equals_single_gpu_render": frame_check,
+                       "blend_split_min_list": blend_split,
                        "frames_in_flight": "3 (the library's pipeline lanes: every frame still runs its own full sort, projection, "
                                            "binning and blend; consecutive frames overlap on the GPU); see latency.fps_depth1 for one frame at a time"},
             "occlusion_binning": {"near_permille": s["near_permille"], "unsat_tiles_last_frame": s["unsat_tiles"],

@@ -199,6 +199,14 @@ GS_API int gs_render_gathered(gs_ctx *ctx, const gs_render_params *views, int nv
                               uint32_t flags);
 /* root: copy view `view` of the last gathered frame (after gs_sync() for asynchronous frames) to host memory */
 GS_API int gs_read_gathered(gs_ctx *ctx, int view, uint8_t *rgba_out, size_t stride);
+#define GS_OPT_BLEND_SPLIT 9    /* 0 (default): one wavefront blends each tile, 4 pixels per lane.  L > 0: tiles whose list has at least
+                                   L entries (try 512) are blended by FOUR wavefronts, one pixel per lane -- for frames in which few
+                                   tiles carry long lists (a cut-out scene: the kernel otherwise lasts as long as ONE wavefront's
+                                   serial walk of the busiest tile's list).  Same fragments and per-pixel operations; a pixel of such
+                                   a tile stops exactly when it falls below the termination threshold instead of with its lane's
+                                   other three (within the 1 LSB tolerance), so images are bit-identical only between renders with
+                                   the same setting AND the same binning share: off by default.  The rule is per tile: strips
+                                   still equal the full frame bit for bit. */
 #define GS_OPT_COMM_SELF_COPY 8 /* value != 0: the root sends its own pieces to itself through RCCL too instead of rendering them
                                    in place (exercises send/recv on a single-GPU box; slower) */
 

@@ -956,3 +956,56 @@ def test_gathered_frames_through_rccl_world1(scene_small):
         c.set_option(capi.OPT_COMM_SELF_COPY, 0)
         c.sort(cams[3]["view"]); c.render_gathered(_params(cams[3], flags=capi.RENDER_FLIP_Y), flags=capi.RENDER_FLIP_Y)
         assert np.array_equal(c.read_gathered(0, w, h), want[3][::-1])
+
+
+def test_split_blend_several_wavefronts_per_tile(ctx, scene_small):
+    """GS_OPT_BLEND_SPLIT: tiles with long lists walked in segments by 8 wavefronts from fresh states and composed front to
+    back give the one-wavefront image within the pixel tolerance (same fragments, different fp32 summation order) -- whole
+    frames, both binning rounds (pinned share: round 1 resumes saved states), scene compositing, lists of several
+    2048-entry iterations -- and strips still equal the full frame bit for bit (the rule is per tile)."""
+    w, h = 640, 360
+    cam = synth.index_html_camera(w, h, 33.0, capi=capi)
+    mv, P, focal = _f32(cam)
+    with capi.Context(0) as c:
+        c.push_splat(scene_small["rows"])
+        idx = c.sort(cam["view"])
+        want, _, _ = oracle.render(scene_small["cs"], scene_small["cc"], idx, mv, P, focal, w, h, want_f32=False)
+        one = c.render(_params(cam))
+        for split in (1, 48, 300):                          # every tile with a list / the busier ones / the busiest
+            c.set_option(capi.OPT_BLEND_SPLIT, split)
+            for pm in (0, 1000, 100, 10):                   # adaptive, single round, shares that leave tiles for round 1
+                c.set_option(capi.OPT_NEAR_PERMILLE, pm)
+                got = c.render(_params(cam))
+                pix_check("split%d_blend_640x360_near%d" % (split, pm), got, want)
+                assert np.abs(got.astype(int) - one.astype(int)).max() <= PIXEL_TOL_LSB
+                parts = np.concatenate([c.render(_params(cam, x0=a, x1=b)) for a, b in ((0, 304), (304, w))], axis=1)
+                if pm:                                      # a fixed share: the same lists, the same kernel per tile -> bit-identical
+                    assert np.array_equal(parts, got)
+                else:                                       # the adaptive share moves between renders, and with it which tiles are "long"
+                    assert np.abs(parts.astype(int) - got.astype(int)).max() <= PIXEL_TOL_LSB
+            c.set_option(capi.OPT_NEAR_PERMILLE, 0)
+        # scene depth + colour under the split blend
+        yy, xx = np.mgrid[0:h, 0:w]
+        depth = (0.9990 + 0.0009 * ((xx // 40 + yy // 40) % 2)).astype(np.float32)
+        rgba = np.zeros((h, w, 4), np.uint8); rgba[..., 0] = (xx % 256).astype(np.uint8); rgba[..., 3] = 255
+        c.set_scene(depth, rgba)
+        ref, _, _ = oracle.render(scene_small["cs"], scene_small["cc"], idx, mv, P, focal, w, h, want_f32=False, scene_depth=depth, scene_rgba=rgba)
+        pix_check("split_blend_scene_640x360", c.render(_params(cam)), ref)
+        c.set_scene(None, None)
+    # long lists: a dense, faint cloud seen from outside -> thousands of entries per tile, several 2048-entry iterations
+    rows = synth.make_splat_rows(200000, seed=9).reshape(-1, 32).copy()
+    rows[:, 0:12] = (rows[:, 0:12].copy().view("<f4") * np.float32(0.08)).view(np.uint8)      # squeeze the positions
+    rows[:, 27] = np.maximum(rows[:, 27] // 24, 1)                                           # faint
+    cs, cc, mats = oracle.pack(rows)
+    cam = synth.index_html_camera(320, 180, 10.0, capi=capi)
+    mv, P, focal = _f32(cam)
+    with capi.Context(0) as c:
+        c.push_splat(rows)
+        idx = c.sort(cam["view"])
+        want, _, _ = oracle.render(cs, cc, idx, mv, P, focal, 320, 180, want_f32=False)
+        pix_check("long_lists_one_wave", c.render(_params(cam)), want)
+        assert c.stats()["n_pairs"] > 200000
+        c.set_option(capi.OPT_BLEND_SPLIT, 1024)
+        got = c.render(_params(cam))
+        pix_check("long_lists_split1024", got, want)
+        assert np.array_equal(c.render(_params(cam)), got)                                   # deterministic

@@ -4,7 +4,7 @@
 set -e
 R=$(cd "$(dirname "$0")/.." && pwd); C=$R/aframe-gaussian-splatting_amd/csrc; N=$1; shift
 T=$(mktemp -d)
-for f in gs_api gs_pack gs_prims gs_render gs_sort gs_ply; do
+for f in $(cd $C && ls *.hip | sed s/.hip//); do
   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fvisibility=hidden -fno-fast-math -Wno-unused-function "$@" -x hip -c $C/$f.hip -o $T/$f.o &
 done
 hipcc -O3 -std=c++17 -fPIC -ffp-contract=off -fvisibility=hidden -fno-fast-math -x hip -c $C/gs_host.cpp -o $T/gs_host.o &

@@ -17,6 +17,7 @@ ap.add_argument("--frames", type=int, default=240)
 ap.add_argument("--depths", default="1,3")
 ap.add_argument("--near", type=int, default=180, help="pinned share (permille) of the splats binned in the first round; 0 = adaptive")
 ap.add_argument("--sort-only", action="store_true")
+ap.add_argument("--split", type=int, default=0, help="GS_OPT_BLEND_SPLIT")
 a = ap.parse_args()
 W, H = (int(v) for v in a.size.lower().split("x"))
 rows = synth.make_splat_rows_fast(a.splats) if a.splats >= (8 << 20) else synth.make_splat_rows(a.splats)
@@ -27,6 +28,8 @@ ctx = capi.Context(0)
 r = rows.reshape(-1, 32)
 for o in range(0, a.splats, 1 << 22):
     ctx.push_splat(r[o:o + (1 << 22)])
+if a.split:
+    ctx.set_option(capi.OPT_BLEND_SPLIT, a.split)
 if a.near:
     ctx.set_option(capi.OPT_NEAR_PERMILLE, a.near)
 
