@@ -112,6 +112,18 @@ class GaussianSplatting {
     } finally { this.sortReady = true; }
   }
 
+  // The reference's rhythm: tick posts the sort and returns; the reply handler installs the new order and re-arms
+  // sortReady (index.js:201-207, 438-455).  Returns the promise of the order, or null while a sort is in flight.
+  tickAsync(camera) {
+    if (!this.sortReady) return null;
+    this.sortReady = false;
+    const u = this._tickUniforms(camera);
+    return native.sortAsync(this.handle, u.view, u.cutout).then((indexes) => {
+      this.sortedIndexes = indexes; this.instanceCount = indexes.length; this.sortReady = true;
+      return indexes;
+    }, (e) => { this.sortReady = true; throw e; });
+  }
+
   _tickUniforms(camera) {
     return native.tickUniforms(elementsOf((camera || this.camera).matrixWorld), elementsOf(this.object.matrixWorld),
       this.cutout ? elementsOf(this.cutout.matrixWorld) : undefined);
@@ -129,7 +141,21 @@ class GaussianSplatting {
 
   // The draw: onBeforeRender uniforms (index.js:184-195) + vertex/fragment/blend (index.js:77-181) -> RGBA8 pixels.
   // viewport = {width, height[, x0, x1]} in device pixels; returns Uint8Array, row 0 = top.
+  // The pixels land in page-locked memory owned by the component and reused frame after frame (one buffer per strip size):
+  // the returned Uint8Array is overwritten by the next render of the same size -- copy it to keep it.
   render(camera, viewport, options) {
+    const p = this._renderParams(camera, viewport, options);
+    return native.renderInto(this.handle, p, this._frame(p));
+  }
+
+  // The same draw off the JS thread (napi_async_work): resolves to the frame.  While it is in flight the component's
+  // other calls throw GS_BUSY (a context is single-caller, like the reference's single-flight worker).
+  renderAsync(camera, viewport, options) {
+    const p = this._renderParams(camera, viewport, options);
+    return native.renderAsync(this.handle, p, this._frame(p));
+  }
+
+  _renderParams(camera, viewport, options) {
     const proj = this.getProjectionMatrix(camera).elements;
     const p = Object.assign({
       modelView: this.getModelViewMatrix(camera).elements, projection: proj,
@@ -138,7 +164,14 @@ class GaussianSplatting {
     }, options || {});
     if (viewport.x0 !== undefined) p.x0 = viewport.x0;
     if (viewport.x1 !== undefined) p.x1 = viewport.x1;
-    return native.render(this.handle, p);
+    return p;
+  }
+
+  _frame(p) {
+    const w = (p.x1 !== undefined ? p.x1 : p.width) - (p.x0 || 0), key = w + 'x' + p.height;
+    if (!this._frames) this._frames = new Map();
+    if (!this._frames.has(key)) this._frames.set(key, native.allocFrame(w, p.height));
+    return this._frames.get(key);
   }
 
   // The opaque scene three.js draws before the transparent splat mesh: window-space depth (depthTest: true,
@@ -166,7 +199,8 @@ class GaussianSplatting {
 
   stats() { return native.stats(this.handle); }
 
-  remove() { native.destroy(this.handle); }          // the reference leaks its worker/textures; this does not
+  // the reference leaks its worker and textures; this frees the context (HBM, streams, threads) at once
+  remove() { native.destroy(this.handle); this._frames = null; }
 }
 
 // Optional: expose the same component name to an A-Frame-like registry.

@@ -28,7 +28,19 @@ static napi_value throw_gs(napi_env env, gs_ctx *ctx, int rc)
     return NULL;
 }
 
-static void ctx_finalize(napi_env env, void *data, void *hint) { (void)env; (void)hint; if (data) gs_destroy((gs_ctx *)data); }
+/* What a JS handle points to.  destroy() frees the context at once (HBM, streams, worker threads) and leaves the shell for
+ * the garbage collector; `busy` is set while an asynchronous call (sortAsync / renderAsync) owns the context: a gs_ctx is
+ * single-caller, like the reference's single-flight worker (sortReady, index.js:206, 220, 439-440). */
+typedef struct gs_handle { gs_ctx *ctx; int busy; } gs_handle;
+
+static void ctx_finalize(napi_env env, void *data, void *hint)
+{
+    (void)env; (void)hint;
+    gs_handle *h = (gs_handle *)data;
+    if (!h) return;
+    if (h->ctx) gs_destroy(h->ctx);
+    free(h);
+}
 
 /* argument helpers ------------------------------------------------------------------------------- */
 
@@ -41,7 +53,7 @@ static int get_args(napi_env env, napi_callback_info info, size_t want, napi_val
     return 1;
 }
 
-static gs_ctx *get_ctx(napi_env env, napi_value v)
+static gs_handle *get_handle(napi_env env, napi_value v)
 {
     void *p = NULL;
     napi_valuetype t;
@@ -49,7 +61,16 @@ static gs_ctx *get_ctx(napi_env env, napi_value v)
         napi_throw_type_error(env, NULL, "expected a context handle returned by create()");
         return NULL;
     }
-    return (gs_ctx *)p;
+    return (gs_handle *)p;
+}
+
+static gs_ctx *get_ctx(napi_env env, napi_value v)
+{
+    gs_handle *h = get_handle(env, v);
+    if (!h) return NULL;
+    if (!h->ctx) { napi_throw_error(env, "GS_DESTROYED", "the context has been destroyed"); return NULL; }
+    if (h->busy) { napi_throw_error(env, "GS_BUSY", "an asynchronous sort or render of this context is in flight"); return NULL; }
+    return h->ctx;
 }
 
 /* bytes of an ArrayBuffer / TypedArray / DataView / Buffer; returns 0 if v is none of those */
@@ -132,8 +153,11 @@ static napi_value fn_create(napi_env env, napi_callback_info info)      /* creat
     gs_ctx *ctx = NULL;
     int rc = gs_create(dev, &ctx);
     if (rc != GS_OK) return throw_gs(env, NULL, rc);
+    gs_handle *hd = (gs_handle *)calloc(1, sizeof *hd);
+    if (!hd) { gs_destroy(ctx); napi_throw_error(env, NULL, "out of memory"); return NULL; }
+    hd->ctx = ctx;
     napi_value h;
-    NAPI_OK(napi_create_external(env, ctx, ctx_finalize, NULL, &h));
+    if (napi_create_external(env, hd, ctx_finalize, NULL, &h) != napi_ok) { gs_destroy(ctx); free(hd); napi_throw_error(env, NULL, "napi_create_external"); return NULL; }
     return h;
 }
 
@@ -214,6 +238,28 @@ static napi_value fn_count(napi_env env, napi_callback_info info)
     return r;
 }
 
+/* `view` as tick posts it (view.buffer: an ArrayBuffer holding 4 floats, index.js:441-442, 453) or any array of 4 numbers; the raw
+ * bytes are taken only from an ArrayBuffer or a Float32Array -- a Float64Array view goes through the element-wise conversion */
+static int get_sort_args(napi_env env, napi_value vview, napi_value vcut, float view[4], float cut[16], const float **cutp)
+{
+    bool is_ab = false, is_ta = false;
+    void *vb = NULL; size_t vlen = 0;
+    int raw = 0;
+    if (napi_is_arraybuffer(env, vview, &is_ab) == napi_ok && is_ab) raw = napi_get_arraybuffer_info(env, vview, &vb, &vlen) == napi_ok && vlen >= 16;
+    else if (napi_is_typedarray(env, vview, &is_ta) == napi_ok && is_ta) {
+        napi_typedarray_type ty; size_t n; napi_value ab; size_t off;
+        raw = napi_get_typedarray_info(env, vview, &ty, &n, &vb, &ab, &off) == napi_ok && ty == napi_float32_array && n >= 4;
+    }
+    if (raw) memcpy(view, vb, 16);
+    else if (!get_floats(env, vview, view, 4)) { napi_throw_type_error(env, NULL, "view: expected 4 floats"); return 0; }
+    *cutp = NULL;
+    if (!is_nullish(env, vcut)) {
+        if (!get_floats(env, vcut, cut, 16)) { napi_throw_type_error(env, NULL, "cutout: expected 16 floats"); return 0; }
+        *cutp = cut;
+    }
+    return 1;
+}
+
 /* sort(h, view[4], cutout[16] | undefined, wantIndexes = true) -> Uint32Array (worker reply `sortedIndexes`) */
 static napi_value fn_sort(napi_env env, napi_callback_info info)
 {
@@ -221,14 +267,8 @@ static napi_value fn_sort(napi_env env, napi_callback_info info)
     if (!get_args(env, info, 4, argv, NULL)) return NULL;
     gs_ctx *ctx = get_ctx(env, argv[0]); if (!ctx) return NULL;
     float view[4], cut[16];
-    void *vb; size_t vlen;
-    if (get_bytes(env, argv[1], &vb, &vlen) && vlen >= 16) memcpy(view, vb, 16);   /* view.buffer as posted by tick */
-    else if (!get_floats(env, argv[1], view, 4)) { napi_throw_type_error(env, NULL, "view: expected 4 floats"); return NULL; }
     const float *cutp = NULL;
-    if (!is_nullish(env, argv[2])) {
-        if (!get_floats(env, argv[2], cut, 16)) { napi_throw_type_error(env, NULL, "cutout: expected 16 floats"); return NULL; }
-        cutp = cut;
-    }
+    if (!get_sort_args(env, argv[1], argv[2], view, cut, &cutp)) return NULL;
     bool want = true;
     if (!is_nullish(env, argv[3])) NAPI_OK(napi_get_value_bool(env, argv[3], &want));
     if (!want) {
@@ -297,6 +337,142 @@ static napi_value fn_render(napi_env env, napi_callback_info info)
     if (rc != GS_OK) return throw_gs(env, ctx, rc);
     NAPI_OK(napi_create_typedarray(env, napi_uint8_array, bytes, ab, 0, &ta));
     return ta;
+}
+
+/* page-locked framebuffers handed to JavaScript as external ArrayBuffers: gs_render copies into them at PCIe speed and the
+ * same memory is reused frame after frame (no per-call allocation, no extra copy) */
+static void frame_finalize(napi_env env, void *data, void *hint) { (void)env; (void)hint; gs_host_free(data); }
+
+/* allocFrame(width, height) -> Uint8Array(width * height * 4) over page-locked memory */
+static napi_value fn_alloc_frame(napi_env env, napi_callback_info info)
+{
+    napi_value argv[2]; int32_t w = 0, h = 0;
+    if (!get_args(env, info, 2, argv, NULL)) return NULL;
+    NAPI_OK(napi_get_value_int32(env, argv[0], &w)); NAPI_OK(napi_get_value_int32(env, argv[1], &h));
+    if (w <= 0 || h <= 0) { napi_throw_range_error(env, NULL, "allocFrame: bad size"); return NULL; }
+    const size_t bytes = (size_t)w * (size_t)h * 4;
+    void *p = gs_host_alloc(bytes);
+    if (!p) { napi_throw_error(env, NULL, "allocFrame: page-locked allocation failed"); return NULL; }
+    napi_value ab, ta;
+    if (napi_create_external_arraybuffer(env, p, bytes, frame_finalize, NULL, &ab) != napi_ok) { gs_host_free(p); napi_throw_error(env, NULL, "external arraybuffer"); return NULL; }
+    NAPI_OK(napi_create_typedarray(env, napi_uint8_array, bytes, ab, 0, &ta));
+    return ta;
+}
+
+/* renderInto(h, params, frameUint8Array) -> frame: the same draw as render(), into a caller-owned buffer (allocFrame) */
+static napi_value fn_render_into(napi_env env, napi_callback_info info)
+{
+    napi_value argv[3];
+    if (!get_args(env, info, 3, argv, NULL)) return NULL;
+    gs_ctx *ctx = get_ctx(env, argv[0]); if (!ctx) return NULL;
+    gs_render_params p;
+    if (!fill_params(env, argv[1], &p)) { napi_throw_type_error(env, NULL, "render: bad parameter object"); return NULL; }
+    if (p.x1 <= p.x0 || p.fb_height <= 0) { napi_throw_range_error(env, NULL, "render: empty strip"); return NULL; }
+    void *out; size_t len;
+    if (!get_bytes(env, argv[2], &out, &len) || len < (size_t)(p.x1 - p.x0) * (size_t)p.fb_height * 4) {
+        napi_throw_range_error(env, NULL, "renderInto: frame buffer missing or too small"); return NULL;
+    }
+    int rc = gs_render(ctx, &p, (uint8_t *)out, 0);
+    if (rc != GS_OK) return throw_gs(env, ctx, rc);
+    return argv[2];
+}
+
+/* ---- asynchronous calls (napi_async_work on the libuv pool): tick's fire-and-forget sort (index.js:438-455, reply handler
+ * 201-207) and the draw.  One in flight per context; the promise settles on the JS thread. ------------------------------ */
+typedef struct gs_async {
+    napi_async_work work; napi_deferred deferred; napi_ref keep;     /* keep: the handle (and the frame) stay alive meanwhile */
+    gs_handle *h; int kind;                                          /* 0 = sort, 1 = render */
+    float view[4], cut[16]; int has_cut;
+    uint32_t *idx; uint32_t n; size_t cap;
+    gs_render_params p; uint8_t *frame; napi_ref frame_ref;
+    int rc; char err[512];
+} gs_async;
+
+static void async_execute(napi_env env, void *data)
+{
+    (void)env;
+    gs_async *a = (gs_async *)data;
+    if (a->kind == 0) a->rc = gs_sort(a->h->ctx, a->view, a->has_cut ? a->cut : NULL, a->idx, &a->n);
+    else a->rc = gs_render(a->h->ctx, &a->p, a->frame, 0);
+    if (a->rc != GS_OK) { const char *m = gs_last_error(a->h->ctx); snprintf(a->err, sizeof a->err, "%s", (m && *m) ? m : "gs_splat call failed"); }
+}
+
+static void idx_finalize(napi_env env, void *data, void *hint) { (void)env; (void)hint; free(data); }
+
+static void async_complete(napi_env env, napi_status status, void *data)
+{
+    gs_async *a = (gs_async *)data;
+    napi_value result = NULL;
+    a->h->busy = 0;
+    if (status == napi_ok && a->rc == GS_OK) {
+        if (a->kind == 0) {                                       /* the worker's reply: {sortedIndexes}, moved not copied */
+            napi_value ab;
+            if (napi_create_external_arraybuffer(env, a->idx, (size_t)a->cap * 4, idx_finalize, NULL, &ab) == napi_ok) {
+                a->idx = NULL;
+                napi_create_typedarray(env, napi_uint32_array, a->n, ab, 0, &result);
+            }
+        } else napi_get_reference_value(env, a->frame_ref, &result);
+    }
+    if (result) napi_resolve_deferred(env, a->deferred, result);
+    else {
+        napi_value msg, err;
+        napi_create_string_utf8(env, a->rc != GS_OK ? a->err : "asynchronous call failed", NAPI_AUTO_LENGTH, &msg);
+        napi_create_error(env, NULL, msg, &err);
+        napi_reject_deferred(env, a->deferred, err);
+    }
+    if (a->keep) napi_delete_reference(env, a->keep);
+    if (a->frame_ref) napi_delete_reference(env, a->frame_ref);
+    napi_delete_async_work(env, a->work);
+    free(a->idx);
+    free(a);
+}
+
+static napi_value async_start(napi_env env, gs_async *a, napi_value handle, const char *name)
+{
+    napi_value promise, rname;
+    if (napi_create_promise(env, &a->deferred, &promise) != napi_ok || napi_create_reference(env, handle, 1, &a->keep) != napi_ok ||
+        napi_create_string_utf8(env, name, NAPI_AUTO_LENGTH, &rname) != napi_ok ||
+        napi_create_async_work(env, NULL, rname, async_execute, async_complete, a, &a->work) != napi_ok) {
+        free(a->idx); free(a); napi_throw_error(env, NULL, "could not start the asynchronous call"); return NULL;
+    }
+    a->h->busy = 1;
+    if (napi_queue_async_work(env, a->work) != napi_ok) { a->h->busy = 0; napi_throw_error(env, NULL, "could not queue the asynchronous call"); return NULL; }
+    return promise;
+}
+
+/* sortAsync(h, view, cutout | undefined) -> Promise<Uint32Array> */
+static napi_value fn_sort_async(napi_env env, napi_callback_info info)
+{
+    napi_value argv[3];
+    if (!get_args(env, info, 3, argv, NULL)) return NULL;
+    gs_ctx *ctx = get_ctx(env, argv[0]); if (!ctx) return NULL;
+    gs_async *a = (gs_async *)calloc(1, sizeof *a);
+    if (!a) { napi_throw_error(env, NULL, "out of memory"); return NULL; }
+    const float *cutp = NULL;
+    if (!get_sort_args(env, argv[1], argv[2], a->view, a->cut, &cutp)) { free(a); return NULL; }
+    a->has_cut = cutp != NULL; a->kind = 0; a->h = get_handle(env, argv[0]);
+    a->cap = gs_count(ctx); if (a->cap < 1) a->cap = 1;
+    a->idx = (uint32_t *)malloc(a->cap * 4);
+    if (!a->idx) { free(a); napi_throw_error(env, NULL, "out of memory"); return NULL; }
+    return async_start(env, a, argv[0], "gs_sort");
+}
+
+/* renderAsync(h, params, frameUint8Array) -> Promise<frame> */
+static napi_value fn_render_async(napi_env env, napi_callback_info info)
+{
+    napi_value argv[3];
+    if (!get_args(env, info, 3, argv, NULL)) return NULL;
+    gs_ctx *ctx = get_ctx(env, argv[0]); if (!ctx) return NULL;
+    gs_async *a = (gs_async *)calloc(1, sizeof *a);
+    if (!a) { napi_throw_error(env, NULL, "out of memory"); return NULL; }
+    if (!fill_params(env, argv[1], &a->p) || a->p.x1 <= a->p.x0 || a->p.fb_height <= 0) { free(a); napi_throw_type_error(env, NULL, "renderAsync: bad parameter object"); return NULL; }
+    void *out; size_t len;
+    if (!get_bytes(env, argv[2], &out, &len) || len < (size_t)(a->p.x1 - a->p.x0) * (size_t)a->p.fb_height * 4) {
+        free(a); napi_throw_range_error(env, NULL, "renderAsync: frame buffer missing or too small"); return NULL;
+    }
+    a->frame = (uint8_t *)out; a->kind = 1; a->h = get_handle(env, argv[0]);
+    if (napi_create_reference(env, argv[2], 1, &a->frame_ref) != napi_ok) { free(a); napi_throw_error(env, NULL, "reference"); return NULL; }
+    return async_start(env, a, argv[0], "gs_render");
 }
 
 /* setScene(h, depthFloat32Array | null, rgbaUint8Array | null, width, height): the opaque scene the splats are depth-tested
@@ -404,9 +580,10 @@ static napi_value fn_destroy(napi_env env, napi_callback_info info)      /* expl
 {
     napi_value argv[1];
     if (!get_args(env, info, 1, argv, NULL)) return NULL;
-    void *p = NULL; napi_valuetype t;
-    if (napi_typeof(env, argv[0], &t) == napi_ok && t == napi_external && napi_get_value_external(env, argv[0], &p) == napi_ok && p)
-        gs_clear((gs_ctx *)p);        /* drop the data now; the handle's finalizer frees the context */
+    gs_handle *h = get_handle(env, argv[0]);
+    if (!h) return NULL;
+    if (h->busy) { napi_throw_error(env, "GS_BUSY", "an asynchronous sort or render of this context is in flight"); return NULL; }
+    if (h->ctx) { gs_destroy(h->ctx); h->ctx = NULL; }     /* HBM, streams and threads go now; the shell goes with the JS handle */
     return NULL;
 }
 
@@ -416,7 +593,8 @@ static napi_value init(napi_env env, napi_value exports)
         { "create", fn_create }, { "destroy", fn_destroy }, { "clear", fn_clear }, { "pushSplat", fn_push_splat },
         { "pushMatrices", fn_push_matrices }, { "loadPly", fn_load_ply }, { "plyToSplat", fn_ply_to_splat }, { "plyToSplatGpu", fn_ply_to_splat_gpu },
         { "count", fn_count },
-        { "sort", fn_sort }, { "render", fn_render }, { "setScene", fn_set_scene }, { "stats", fn_stats }, { "setOption", fn_set_option },
+        { "sort", fn_sort }, { "sortAsync", fn_sort_async }, { "render", fn_render }, { "renderInto", fn_render_into },
+        { "renderAsync", fn_render_async }, { "allocFrame", fn_alloc_frame }, { "setScene", fn_set_scene }, { "stats", fn_stats }, { "setOption", fn_set_option },
         { "modelViewMatrix", fn_model_view }, { "projectionMatrix", fn_projection }, { "tickUniforms", fn_tick },
         { "scaledSize", fn_scaled_size },
     };

@@ -117,6 +117,30 @@ comp.loadData(camera, object, null, scenePath, 100003).then((n) => {
   fs.writeFileSync(outPath + '.idx', Buffer.from(comp.sortedIndexes.buffer, comp.sortedIndexes.byteOffset, comp.sortedIndexes.byteLength));
   const strip = comp.render(camera, { width: Number(W), height: Number(H), x0: 16, x1: 48 });
   ok(strip.length === 32 * H * 4, 'strip size');
-  comp.remove();
-  console.log('addon gpu checks ok:', checks);
+  ok(comp.render(camera, { width: Number(W), height: Number(H) }) === img, 'the frame buffer is reused (page-locked, no per-call allocation)');
+  // ---- the reference's rhythm: fire-and-forget sort, single flight (index.js:201-207, 438-455), draw off the JS thread
+  const keep = Uint32Array.from(comp.sortedIndexes), keepImg = Uint8Array.from(img);
+  const pending = comp.tickAsync();
+  ok(pending && typeof pending.then === 'function' && comp.sortReady === false, 'tickAsync posts the sort and returns');
+  ok(comp.tickAsync() === null, 'a second tick while the sort is in flight does nothing (sortReady)');
+  let busy = false;
+  try { comp.render(camera, { width: Number(W), height: Number(H) }); } catch (e) { busy = e.code === 'GS_BUSY'; }
+  ok(busy, 'the context refuses other calls while the asynchronous sort owns it');
+  return pending.then((idx) => {
+    ok(comp.sortReady === true && comp.instanceCount === idx.length && same(idx, keep), 'asynchronous order == synchronous order');
+    return comp.renderAsync(camera, { width: Number(W), height: Number(H) });
+  }).then((img2) => {
+    ok(same(img2, keepImg), 'asynchronous frame == synchronous frame');
+    // JS-visible rate: tick + render into the reused page-locked frame, synchronously, one frame at a time
+    const frames = 200;
+    const t0 = process.hrtime.bigint();
+    for (let i = 0; i < frames; i++) { comp.tick(); comp.render(camera, { width: Number(W), height: Number(H) }); }
+    const sec = Number(process.hrtime.bigint() - t0) / 1e9;
+    console.log('js-visible frames/s (tick + render into host memory, ' + W + 'x' + H + ', ' + n + ' splats): ' + (frames / sec).toFixed(1));
+    comp.remove();
+    let gone = false;
+    try { comp.tick(); } catch (e) { gone = e.code === 'GS_DESTROYED'; }
+    ok(gone, 'remove() destroys the context');
+    console.log('addon gpu checks ok:', checks);
+  });
 }).catch((e) => { console.error('FAIL:', e); process.exit(1); });

@@ -40,6 +40,15 @@ def test_addon_worker_protocol_and_render_gpu(tmp_path):
     r = subprocess.run([NODE, os.path.join(JS, "test_addon.js"), "gpu", GOLDEN, str(scene), str(out), str(w), str(h), str(yaw)],
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
+    assert "asynchronous" not in r.stderr
+    fps = [l for l in r.stdout.splitlines() if l.startswith("js-visible frames/s")]
+    assert fps, r.stdout
+    print(fps[0])                                            # the rate a JavaScript caller of tick() + render() sees (-s shows it)
+    try:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        open(os.path.join(ROOT, "gpurun_out", "js_visible_fps.txt"), "w").write(fps[0] + "\n")
+    except OSError:
+        pass
     img = np.frombuffer(out.read_bytes(), np.uint8).reshape(h, w, 4)
     idx = np.frombuffer((tmp_path / "frame.rgba.idx").read_bytes(), np.uint32)
     cam = synth.index_html_camera(w, h, yaw, capi=capi)
