@@ -26,7 +26,7 @@ EXPORTS = [
     "gs_model_view_matrix", "gs_projection_matrix", "gs_tick_uniforms", "gs_focal", "gs_scaled_size", "gs_set_option",
     "gs_get_stats", "gs_download",
     "gs_comm_unique_id", "gs_comm_init", "gs_comm_destroy", "gs_partition", "gs_render_gathered", "gs_read_gathered",
-    "gs_host_alloc", "gs_host_free",
+    "gs_host_alloc", "gs_host_free", "gs_sort_for", "gs_sort_gathered",
 ]
 
 
@@ -114,6 +114,8 @@ def load(build_if_missing=True):
     L.gs_partition.argtypes = [i32, C.POINTER(i32), i32, C.POINTER(Piece), i32]
     L.gs_render_gathered.argtypes = [vp, C.POINTER(RenderParams), i32, i32, C.POINTER(vp), C.c_uint32]
     L.gs_read_gathered.argtypes = [vp, i32, vp, sz]
+    L.gs_sort_for.argtypes = [vp, vp, vp, C.POINTER(RenderParams), vp, u32p]
+    L.gs_sort_gathered.argtypes = [vp, vp, vp, C.POINTER(RenderParams), i32]
     L.gs_host_alloc.argtypes = [sz]; L.gs_host_alloc.restype = C.c_void_p
     L.gs_host_free.argtypes = [vp]; L.gs_host_free.restype = None
     _lib = L
@@ -285,6 +287,26 @@ class Context:
         n = C.c_uint32(0)
         self._ck(self._L.gs_sort(self._h, _p(view), _p(cut), _p(out), C.byref(n)))
         return out[:n.value].copy()
+
+    def sort_for(self, view, cutout, strip_params, want_indices=True):
+        """gs_sort_for: the order of the splats that can reach strip_params' column strip (a sub-sequence of sort()'s result)."""
+        view = np.ascontiguousarray(view, np.float32)
+        cut = None if cutout is None else np.ascontiguousarray(cutout, np.float32)
+        if not want_indices:
+            self._ck(self._L.gs_sort_for(self._h, _p(view), _p(cut), C.byref(strip_params), None, None))
+            return None
+        out = np.zeros(max(self.count(), 1), np.uint32)
+        n = C.c_uint32(0)
+        self._ck(self._L.gs_sort_for(self._h, _p(view), _p(cut), C.byref(strip_params), _p(out), C.byref(n)))
+        return out[:n.value].copy()
+
+    def sort_gathered(self, view, cutout, views):
+        """the sort of a frame drawn with render_gathered(views): only this rank's strip when it owns exactly one"""
+        views = list(views) if isinstance(views, (list, tuple)) else [views]
+        arr = (RenderParams * len(views))(*views)
+        view = np.ascontiguousarray(view, np.float32)
+        cut = None if cutout is None else np.ascontiguousarray(cutout, np.float32)
+        self._ck(self._L.gs_sort_gathered(self._h, _p(view), _p(cut), arr, len(views)))
 
     # render
     def render(self, params, flip=False):

@@ -111,15 +111,16 @@ static int ensure_capacity(gs_ctx *ctx, size_t want)
     size_t cap = ctx->cap ? ctx->cap : (size_t)1 << 16;
     while (cap < want) cap *= 2;
     TRY(drain_all(ctx));
-    float4 *sr = nullptr; uint4 *sp = nullptr;
-    TRY(dev_alloc(ctx, &sp, cap * 2)); TRY(dev_alloc(ctx, &sr, cap));
+    float4 *sr = nullptr; uint4 *sp = nullptr; float *br = nullptr;
+    TRY(dev_alloc(ctx, &sp, cap * 2)); TRY(dev_alloc(ctx, &sr, cap)); TRY(dev_alloc(ctx, &br, cap));
     if (ctx->n) {
         GS_HIP(hipMemcpyAsync(sp, ctx->splat, ctx->n * 2 * sizeof(uint4), hipMemcpyDeviceToDevice, ctx->stream));
         GS_HIP(hipMemcpyAsync(sr, ctx->sort_rows, ctx->n * sizeof(float4), hipMemcpyDeviceToDevice, ctx->stream));
+        GS_HIP(hipMemcpyAsync(br, ctx->bound_r, ctx->n * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
         GS_HIP(hipStreamSynchronize(ctx->stream));
     }
-    dev_free(ctx->splat); dev_free(ctx->sort_rows);
-    ctx->splat = sp; ctx->sort_rows = sr;
+    dev_free(ctx->splat); dev_free(ctx->sort_rows); dev_free(ctx->bound_r);
+    ctx->splat = sp; ctx->sort_rows = sr; ctx->bound_r = br;
     ctx->cap = cap;
     for (int i = 0; i < GS_MAX_LANES; i++) if (ctx->lanes[i]) { ctx->lanes[i]->have_sort = false; ctx->lanes[i]->sorted = nullptr; }
     return ensure_lane_scratch(ctx, cap);                       // lane 0 now; the other lanes when they are next used
@@ -210,7 +211,7 @@ static int collect_status(gs_ctx *lane, bool *overflowed)
                 ctx->clean_frames += (uint32_t)(frames ? frames : 1);
                 // fast descent (x0.9) until a share has proved too small once, then a slow drift (x0.98) above the floor
                 float nf = ctx->near_frac * (ctx->near_floor > 0.0f ? 0.98f : 0.9f);
-                if (nf < ctx->near_floor) nf = ctx->near_floor; if (nf < 0.02f) nf = 0.02f;
+                if (nf < ctx->near_floor) nf = ctx->near_floor; if (nf < 0.001f) nf = 0.001f;
                 if (nf < ctx->near_frac) ctx->near_frac = nf;
                 const uint32_t fr = (uint32_t)(frames ? frames : 1);     // the hold is counted in frames, not in collections
                 ctx->skip_hold = ctx->skip_hold > fr ? ctx->skip_hold - fr : 0;
@@ -241,6 +242,7 @@ static int collect_status(gs_ctx *lane, bool *overflowed)
 struct GsLaneCmd {
     int type;                                                  // 0 = sort, 1 = asynchronous render, 2 = call (gs_comm.hip: the frame's gather)
     float view[4], cutout[16]; bool has_cutout;
+    bool has_strip; GsSortStrip strip;
     GsFrameUniforms u; void *device_rgba;
     std::function<int(gs_ctx *)> call;
 };
@@ -273,7 +275,7 @@ static void lane_worker_main(gs_ctx *L)
         int rc = GS_OK;
         // (a call is run even after a failure: the gather of a frame must be issued on every rank, or the others wait for it)
         if (c.type == 2) { const int r2 = c.call(L); if (w->rc == GS_OK) rc = r2; }
-        else if (w->rc == GS_OK) rc = c.type == 0 ? gs_run_sort(L, c.view, c.has_cutout ? c.cutout : nullptr)
+        else if (w->rc == GS_OK) rc = c.type == 0 ? gs_run_sort(L, c.view, c.has_cutout ? c.cutout : nullptr, c.has_strip ? &c.strip : nullptr)
                                                   : render_async_on_lane(L, c.u, c.device_rgba);
         lk.lock();
         if (rc != GS_OK && w->rc == GS_OK) { w->rc = rc; memcpy(w->err, scratch, sizeof w->err); }
@@ -414,7 +416,7 @@ static int get_lane(gs_ctx *ctx, int i, gs_ctx **out)
     }
     if (lane_drain(L) != GS_OK) { if (L != ctx) memcpy(ctx->err, L->err, sizeof ctx->err); return GS_E_HIP; }   // its worker is idle from here on
     if (L != ctx) {
-        L->splat = ctx->splat; L->sort_rows = ctx->sort_rows; L->pow10tab = ctx->pow10tab;
+        L->splat = ctx->splat; L->sort_rows = ctx->sort_rows; L->bound_r = ctx->bound_r; L->pow10tab = ctx->pow10tab;
         L->n = ctx->n; L->cap = ctx->cap; L->renderable = ctx->renderable;
         L->scene_depth = ctx->scene_depth; L->scene_rgba = ctx->scene_rgba; L->scene_w = ctx->scene_w; L->scene_h = ctx->scene_h;
         L->record_staged = ctx->record_staged; L->t_eps = ctx->t_eps; L->wide_pairs = ctx->wide_pairs;
@@ -430,7 +432,7 @@ static void refresh_lanes(gs_ctx *ctx)
     for (int i = 1; i < GS_MAX_LANES; i++) {
         gs_ctx *L = ctx->lanes[i];
         if (!L) continue;
-        L->splat = ctx->splat; L->sort_rows = ctx->sort_rows; L->pow10tab = ctx->pow10tab;
+        L->splat = ctx->splat; L->sort_rows = ctx->sort_rows; L->bound_r = ctx->bound_r; L->pow10tab = ctx->pow10tab;
         L->n = ctx->n; L->cap = ctx->cap; L->renderable = ctx->renderable;
         L->scene_depth = ctx->scene_depth; L->scene_rgba = ctx->scene_rgba; L->scene_w = ctx->scene_w; L->scene_h = ctx->scene_h;
         L->record_staged = ctx->record_staged; L->t_eps = ctx->t_eps; L->wide_pairs = ctx->wide_pairs;
@@ -499,7 +501,7 @@ GS_API int gs_destroy(gs_ctx *ctx)
     for (int i = 1; i < GS_MAX_LANES; i++)
         if (ctx->lanes[i]) { free_frame_resources(ctx->lanes[i]); delete ctx->lanes[i]; ctx->lanes[i] = nullptr; }
     free_frame_resources(ctx);
-    dev_free(ctx->splat); dev_free(ctx->sort_rows); dev_free(ctx->pow10tab);
+    dev_free(ctx->splat); dev_free(ctx->sort_rows); dev_free(ctx->bound_r); dev_free(ctx->pow10tab);
     dev_free(ctx->scene_depth); dev_free(ctx->scene_rgba);
     delete ctx;
     return GS_OK;
@@ -636,7 +638,31 @@ GS_API int gs_ply_to_splat_gpu(gs_ctx *ctx, const void *bytes, size_t nbytes, vo
     return GS_OK;
 }
 
+static int sort_common(gs_ctx *ctx, const float view[4], const float *cutout16, const GsSortStrip *strip, uint32_t *out_idx, uint32_t *out_n);
+
 GS_API int gs_sort(gs_ctx *ctx, const float view[4], const float *cutout16, uint32_t *out_idx, uint32_t *out_n)
+{
+    return sort_common(ctx, view, cutout16, nullptr, out_idx, out_n);
+}
+
+GS_API int gs_sort_for(gs_ctx *ctx, const float view[4], const float *cutout16, const gs_render_params *strip, uint32_t *out_idx, uint32_t *out_n)
+{
+    CHECK_CTX(ctx);
+    if (!strip) return sort_common(ctx, view, cutout16, nullptr, out_idx, out_n);
+    if (strip->fb_width <= 0 || strip->x0 < 0 || strip->x1 > strip->fb_width || strip->x0 >= strip->x1)
+        FAIL(GS_E_BADARG, "gs_sort_for: bad strip [%d,%d) for width %d", strip->x0, strip->x1, strip->fb_width);
+    GsSortStrip st;
+    memcpy(st.mv, strip->model_view, sizeof st.mv); memcpy(st.proj, strip->projection, sizeof st.proj);
+    st.focal = strip->focal > 0 ? strip->focal : (float)(((double)strip->fb_height / 2.0) * fabs((double)strip->projection[5]));
+    st.vw = (float)strip->fb_width; st.x0 = strip->x0; st.x1 = strip->x1;
+    // a perspective projection whose w does not depend on x or y (three.js PerspectiveCamera, WebXR eye frusta); anything else
+    // is sorted whole
+    const float *P = strip->projection;
+    const bool persp = P[3] == 0.0f && P[7] == 0.0f && P[15] == 0.0f && P[11] != 0.0f;
+    return sort_common(ctx, view, cutout16, persp ? &st : nullptr, out_idx, out_n);
+}
+
+static int sort_common(gs_ctx *ctx, const float view[4], const float *cutout16, const GsSortStrip *strip, uint32_t *out_idx, uint32_t *out_n)
 {
     CHECK_CTX(ctx);
     if (!view) FAIL(GS_E_BADARG, "gs_sort: view is NULL");
@@ -658,12 +684,14 @@ GS_API int gs_sort(gs_ctx *ctx, const float view[4], const float *cutout16, uint
         c.type = 0; memcpy(c.view, view, sizeof c.view);
         c.has_cutout = cutout16 != nullptr;
         if (cutout16) memcpy(c.cutout, cutout16, sizeof c.cutout);
+        c.has_strip = strip != nullptr;
+        if (strip) c.strip = *strip;
         c.device_rgba = nullptr;
         L->have_sort = true;                                    // (set again by the worker; the render command follows it)
         if (lane_push(L, c) != GS_OK) FAIL(GS_E_OOM, "out of host memory");
         return GS_OK;
     }
-    TRY(lane_rc(ctx, L, gs_run_sort(L, view, cutout16)));
+    TRY(lane_rc(ctx, L, gs_run_sort(L, view, cutout16, strip)));
     if (out_idx || out_n) {
         LANE_HIP(L, hipMemcpyAsync(L->ctl_host, L->ctl, sizeof(GsControl), hipMemcpyDeviceToHost, L->stream));
         LANE_HIP(L, hipStreamSynchronize(L->stream));
@@ -773,7 +801,7 @@ int gs_lane_call(gs_ctx *ctx, bool async, std::function<int(gs_ctx *)> call)
     gs_ctx *L = ctx->lanes[ctx->cur];
     if (async && ctx->enqueue_threads && ctx->pipe_depth > 1 && !ctx->user_stream) {
         GsLaneCmd c;
-        c.type = 2; c.has_cutout = false; c.device_rgba = nullptr; c.call = std::move(call);
+        c.type = 2; c.has_cutout = false; c.has_strip = false; c.device_rgba = nullptr; c.call = std::move(call);
         L->async_pending = true; ctx->cur_async = true;
         if (lane_push(L, c) != GS_OK) FAIL(GS_E_OOM, "out of host memory");
         return GS_OK;
@@ -799,7 +827,7 @@ int gs_render_uniforms(gs_ctx *ctx, const GsFrameUniforms &u, void *device_rgba,
         L->async_pending = true; ctx->cur_async = true;
         if (ctx->enqueue_threads && ctx->pipe_depth > 1 && !ctx->user_stream) {
             GsLaneCmd c;
-            c.type = 1; c.has_cutout = false; c.u = u; c.device_rgba = device_rgba;
+            c.type = 1; c.has_cutout = false; c.has_strip = false; c.u = u; c.device_rgba = device_rgba;
             if (lane_push(L, c) != GS_OK) FAIL(GS_E_OOM, "out of host memory");
             return GS_OK;
         }

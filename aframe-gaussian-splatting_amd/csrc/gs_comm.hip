@@ -300,6 +300,24 @@ GS_API int gs_render_gathered(gs_ctx *ctx, const gs_render_params *views, int nv
     return rc;
 }
 
+GS_API int gs_sort_gathered(gs_ctx *ctx, const float view[4], const float *cutout16, const gs_render_params *views, int nviews)
+{
+    if (!ctx || !views) return GS_E_BADARG;
+    if (nviews < 1 || nviews > 2) FAILC(GS_E_BADARG, "gs_sort_gathered: %d views (1 or 2)", nviews);
+    GsComm *c = ctx->comm;
+    const int world = c && c->comm ? c->world : 1, rank = c && c->comm ? c->rank : 0;
+    int widths[2] = { views[0].fb_width, nviews > 1 ? views[1].fb_width : 0 };
+    gs_piece pcs[128];
+    const int np = gs_partition(nviews, widths, world, pcs, 128);
+    if (np < 0) FAILC(GS_E_BADARG, "gs_sort_gathered: bad frame sizes or more than 128 pieces");
+    int mine = -1, count = 0;
+    for (int i = 0; i < np; i++) if (pcs[i].owner == rank) { mine = i; count++; }
+    if (count != 1) return gs_sort(ctx, view, cutout16, nullptr, nullptr);       // both eyes here, or nothing to draw: the whole order
+    gs_render_params p = views[pcs[mine].view];
+    p.x0 = pcs[mine].x0; p.x1 = pcs[mine].x1;
+    return gs_sort_for(ctx, view, cutout16, &p, nullptr, nullptr);
+}
+
 GS_API int gs_read_gathered(gs_ctx *ctx, int view, uint8_t *rgba_out, size_t stride)
 {
     if (!ctx || !rgba_out) return GS_E_BADARG;

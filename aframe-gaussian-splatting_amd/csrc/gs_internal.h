@@ -104,6 +104,8 @@ struct gs_ctx {
     //   [1] uint4  (6 x int16 Sigma, RGBA8)         covAndColorData     index.js:384-394
     uint4 *splat;                  // N x 2 x 16 B
     float4 *sort_rows;             // N x worker-row elements 12..15                 index.js:396-401
+    float *bound_r;                // N x upper bound of the splat's largest standard deviation in object space: sqrt(3 max|Sigma_ij|)
+                                   // (Gershgorin), +inf where unknown -- what gs_sort_for's strip test needs, 4 B per splat
     double *pow10tab;              // parseInt table (gs_host_tables.h)
 
     // sort scratch (sized by cap)
@@ -216,7 +218,9 @@ static __host__ __device__ __forceinline__ uint32_t gs_radix_row_stride(uint32_t
 // ---- gs_pack.hip
 int gs_launch_pack(gs_ctx *ctx, const uint4 *rows_dev, size_t first, size_t nrows);
 // ---- gs_sort.hip
-int gs_run_sort(gs_ctx *ctx, const float view[4], const float *cutout16);
+// strip: sort only the splats that can reach columns [x0, x1) of the frame these uniforms draw (gs_sort_for); nullptr = all
+struct GsSortStrip { float mv[16], proj[16]; float focal, vw; int32_t x0, x1; };
+int gs_run_sort(gs_ctx *ctx, const float view[4], const float *cutout16, const GsSortStrip *strip = nullptr);
 // ---- gs_render.hip
 int gs_run_render(gs_ctx *ctx, const GsFrameUniforms &u, uint8_t *device_out);
 int gs_run_round1(gs_ctx *ctx, const GsFrameUniforms &u, uint8_t *device_out);

@@ -7,7 +7,7 @@
 namespace {
 
 __global__ __launch_bounds__(GS_BLOCK) void k_pack(const uint4 *__restrict__ rows, uint32_t nrows, const double *__restrict__ pow10tab,
-                                                   uint4 *__restrict__ splat, float4 *__restrict__ sort_rows)
+                                                   uint4 *__restrict__ splat, float4 *__restrict__ sort_rows, float *__restrict__ bound_r)
 {
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nrows; i += gridDim.x * blockDim.x) {
         const uint4 a = rows[2 * i], b = rows[2 * i + 1];
@@ -17,6 +17,9 @@ __global__ __launch_bounds__(GS_BLOCK) void k_pack(const uint4 *__restrict__ row
         splat[2 * i] = make_uint4(__float_as_uint(o.cs[0]), __float_as_uint(o.cs[1]), __float_as_uint(o.cs[2]), __float_as_uint(o.cs[3]));
         splat[2 * i + 1] = make_uint4(o.cc[0], o.cc[1], o.cc[2], o.cc[3]);
         sort_rows[i] = make_float4(o.sort_row[0], o.sort_row[1], o.sort_row[2], o.sort_row[3]);
+        // largest eigenvalue of the dequantised covariance <= largest absolute row sum <= 3 max|Sigma_ij| = 3 * 32767 * cs[3]
+        const float mx = o.cs[3] * 32767.0f;
+        bound_r[i] = (mx == mx && mx < 3.0e37f) ? sqrtf(3.0f * mx) * 1.001f : INFINITY;
     }
 }
 
@@ -27,7 +30,7 @@ int gs_launch_pack(gs_ctx *ctx, const uint4 *rows_dev, size_t first, size_t nrow
     if (!nrows) return GS_OK;
     uint32_t g = gs_div_up(nrows, GS_BLOCK); if (g > 4096) g = 4096;
     hipLaunchKernelGGL(k_pack, dim3(g), dim3(GS_BLOCK), 0, ctx->stream, rows_dev, (uint32_t)nrows, ctx->pow10tab,
-                       ctx->splat + 2 * first, ctx->sort_rows + first);
+                       ctx->splat + 2 * first, ctx->sort_rows + first, ctx->bound_r + first);
     GS_HIP(hipGetLastError());
     return GS_OK;
 }

@@ -11,7 +11,12 @@
 
 namespace {
 
-struct SortUniforms { double view[4]; double cutout[16]; int has_cutout; };   // widened on the host (exact): scalar registers
+struct SortUniforms {                                            // widened on the host (exact): scalar registers
+    double view[4]; double cutout[16]; int has_cutout;
+    int has_strip;
+};
+// gs_sort_for: rows 0, 1 of gsModelViewMatrix, rows 0, 3 of gsProjectionMatrix, and the strip in pixels
+struct StripUniforms { float mvr0[4], mvr1[4], pr0[4], pr3[4]; float focal, norm_a, half_w, sx0, sx1; };
 // the depth kernel's chunking is its own (no histogram depends on it)
 #ifndef GS_DEPTH_IPT
 #define GS_DEPTH_IPT 4             // items per thread and pass: 52 vector registers, 8 waves per SIMD (8 items: 92, 5 waves)
@@ -29,7 +34,32 @@ __device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v,
 
 // pass 1 (index.js:517-555): depth, culls, f64 min/max of survivors.  16 B/splat in, 4 B/splat out.
 // Each workgroup leaves its (min, max, count) in a partial slot; no global atomics.
-__global__ __launch_bounds__(GS_BLOCK) void k_sort_depth(const float4 *__restrict__ rows, uint32_t n, SortUniforms u,
+// strip test of gs_sort_for: can a fragment of the splat fall on pixel columns [sx0, sx1]?  Fragments live where |p| <= 2
+// (index.js:171-172): an ellipse with semi-axes 2 v1, 2 v2 around the projected centre, whose half-width in x is
+// 2 sqrt(v1x^2 + v2x^2) <= 2 |v1| = 2 min(sqrt(2 lambda1), 1024) (index.js:139-149), and
+// lambda1 <= (|J|_2 |A|_2 sigma_max)^2 + 0.3 with J the shader's Jacobian at the splat's camera-space position
+// (index.js:127-135; J J^T = (f/z)^2 [[1 + rx^2, -rx ry], [-rx ry, 1 + ry^2]], largest eigenvalue (f/z)^2 (1 + rx^2 + ry^2)).
+// Conservative by construction, 1 % + 2 pixels of slack on top; NaN anywhere keeps the splat.
+// (fp32 with hardware rcp / sqrt: the test only has to err on the side of keeping, and 3 % + 3 pixels of slack dwarf the
+// rounding; in f64 -- divisions, a square root -- it cost more than the whole depth pass: 92 -> 158 us at 20 M splats.)
+__device__ __forceinline__ bool strip_may_touch(const StripUniforms &s, float x, float y, float z, float camz, float sigma)
+{
+    const float camx = fmaf(s.mvr0[2], z, fmaf(s.mvr0[1], y, s.mvr0[0] * x)) + s.mvr0[3];
+    const float camy = fmaf(s.mvr1[2], z, fmaf(s.mvr1[1], y, s.mvr1[0] * x)) + s.mvr1[3];
+    const float cw = fmaf(s.pr3[2], camz, fmaf(s.pr3[1], camy, s.pr3[0] * camx)) + s.pr3[3];
+    const float cx = fmaf(s.pr0[2], camz, fmaf(s.pr0[1], camy, s.pr0[0] * camx)) + s.pr0[3];
+    if (!(cw > 0.0f)) return true;
+    const float xpx = fmaf(cx, __builtin_amdgcn_rcpf(cw), 1.0f) * s.half_w;
+    const float iz = __builtin_amdgcn_rcpf(camz), rx = camx * iz, ry = camy * iz;
+    const float jn = fabsf(s.focal * iz) * __builtin_amdgcn_sqrtf(fmaf(rx, rx, fmaf(ry, ry, 1.0f)));
+    const float sd = jn * s.norm_a * sigma;
+    float ax = __builtin_amdgcn_sqrtf(2.0f * fmaf(sd, sd, 0.3f));
+    if (!(ax < 1024.0f)) ax = 1024.0f;
+    const float reach = fmaf(2.06f, ax, 3.0f);
+    return !(xpx + reach < s.sx0 || xpx - reach > s.sx1);
+}
+
+__global__ __launch_bounds__(GS_BLOCK) void k_sort_depth(const float4 *__restrict__ rows, const float *__restrict__ bound_r, uint32_t n, SortUniforms u, StripUniforms su,
                                                          float *__restrict__ depth_out, unsigned long long *__restrict__ part_min,
                                                          unsigned long long *__restrict__ part_max, uint32_t *__restrict__ part_cnt)
 {
@@ -43,10 +73,12 @@ __global__ __launch_bounds__(GS_BLOCK) void k_sort_depth(const float4 *__restric
     uint32_t cnt = 0;
     for (uint32_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
         float4 mm[GS_DEPTH_IPT];                                     // all loads first: their latencies overlap
+        float sg[GS_DEPTH_IPT];
 #pragma unroll
         for (int r = 0; r < GS_DEPTH_IPT; r++) {
             const uint32_t i = c * DCHUNK + r * GS_BLOCK + threadIdx.x;
             mm[r] = i < n ? rows[i] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            sg[r] = (u.has_strip && i < n) ? bound_r[i] : 0.0f;
         }
 #pragma unroll
         for (int r = 0; r < GS_DEPTH_IPT; r++) {
@@ -56,10 +88,14 @@ __global__ __launch_bounds__(GS_BLOCK) void k_sort_depth(const float4 *__restric
                 const double d = gsm::view_depth(u.view, m.x, m.y, m.z);
                 const bool inside = u.has_cutout ? gsm::in_cutout(u.cutout, m.x, m.y, m.z) : true;
                 const bool keep = gsm::sort_keep(d, m.w, inside);
-                depth_out[i] = keep ? (float)d : INFINITY;
+                // the bucket scale comes from EVERY splat the reference keeps (index.js:552-553), so a strip's order is the
+                // reference's order restricted to the strip's splats; only those are handed on
+                const bool mine = keep && (!u.has_strip || strip_may_touch(su, m.x, m.y, m.z, (float)d, sg[r]));
+                depth_out[i] = mine ? (float)d : INFINITY;
                 if (keep) {
                     const unsigned long long e = gsm::f64_to_ordered(d);
-                    mn = e < mn ? e : mn; mx = e > mx ? e : mx; cnt++;
+                    mn = e < mn ? e : mn; mx = e > mx ? e : mx;
+                    if (mine) cnt++;
                 }
             }
         }
@@ -70,7 +106,7 @@ __global__ __launch_bounds__(GS_BLOCK) void k_sort_depth(const float4 *__restric
         mn = omn < mn ? omn : mn; mx = omx > mx ? omx : mx;
         cnt += __shfl_xor(cnt, m, 64);
     }
-    if ((threadIdx.x & 63) == 0 && cnt) { atomicMin(&s_min, mn); atomicMax(&s_max, mx); atomicAdd(&s_cnt, cnt); }
+    if ((threadIdx.x & 63) == 0 && mx) { atomicMin(&s_min, mn); atomicMax(&s_max, mx); atomicAdd(&s_cnt, cnt); }   // (mx != 0: the wave kept something)
     __syncthreads();
     if (threadIdx.x == 0) { part_min[blockIdx.x] = s_min; part_max[blockIdx.x] = s_max; part_cnt[blockIdx.x] = s_cnt; }
 }
@@ -146,20 +182,50 @@ __global__ __launch_bounds__(64 * NW) void k_sort_bucket(const float *__restrict
 
 }  // namespace
 
-int gs_run_sort(gs_ctx *ctx, const float view[4], const float *cutout16)
+int gs_run_sort(gs_ctx *ctx, const float view[4], const float *cutout16, const GsSortStrip *strip)
 {
     const uint32_t n = (uint32_t)ctx->n;
     SortUniforms u;
     for (int i = 0; i < 4; i++) u.view[i] = (double)view[i];
     u.has_cutout = cutout16 != nullptr;
     for (int i = 0; i < 16; i++) u.cutout[i] = cutout16 ? (double)cutout16[i] : 0.0;
+    u.has_strip = 0;
+    StripUniforms su;
+    memset(&su, 0, sizeof su);
+    if (strip && ctx->renderable) {
+        const float *m = strip->mv, *p = strip->proj;
+        for (int k = 0; k < 4; k++) { su.mvr0[k] = m[4 * k]; su.mvr1[k] = m[4 * k + 1]; su.pr0[k] = p[4 * k]; su.pr3[k] = p[4 * k + 3]; }
+        // spectral norm of A = mat3(gsModelViewMatrix): power iteration on A^T A (symmetric 3x3), bracketed from above by the
+        // Frobenius norm; a rigid pose with uniform scale s gives s
+        double ata[3][3], fro = 0.0;
+        for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) {
+            ata[i][j] = 0.0;
+            for (int r = 0; r < 3; r++) ata[i][j] += (double)m[4 * i + r] * m[4 * j + r];
+        }
+        for (int i = 0; i < 3; i++) fro += ata[i][i];
+        double v[3] = { 1.0, 0.7, 0.4 }, lam = fro;
+        for (int it = 0; it < 64; it++) {
+            double w[3] = { 0, 0, 0 }, nn = 0.0;
+            for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) w[i] += ata[i][j] * v[j]; nn += w[i] * w[i]; }
+            nn = sqrt(nn);
+            if (!(nn > 0.0)) break;
+            for (int i = 0; i < 3; i++) v[i] = w[i] / nn;
+            lam = nn;
+        }
+        // (the iterate's Rayleigh quotient approaches the largest eigenvalue from below: 2 % on top, never above Frobenius)
+        double na = sqrt(lam) * 1.02;
+        if (!(na <= sqrt(fro) * 1.0001)) na = sqrt(fro) * 1.0001;
+        su.norm_a = (float)na * 1.0001f;
+        su.focal = strip->focal; su.half_w = 0.5f * strip->vw; su.sx0 = (float)strip->x0; su.sx1 = (float)strip->x1;
+        u.has_strip = (su.norm_a == su.norm_a && su.focal > 0.0f && strip->x1 > strip->x0) ? 1 : 0;
+    }
 
     const uint32_t g = gs_radix_grid(n);                         // same chunking as the radix kernels (pre-filled histogram rows)
     GS_PROF_RECORD(ctx, 0);
     uint32_t gd = gs_div_up(n, (uint32_t)(GS_DEPTH_IPT * GS_BLOCK));
     if (gd < 1) gd = 1;
     if (gd > GS_DEPTH_GRID) gd = GS_DEPTH_GRID;
-    hipLaunchKernelGGL(k_sort_depth, dim3(gd), dim3(GS_BLOCK), 0, ctx->stream, ctx->sort_rows, n, u, ctx->depth, ctx->part_min,
+    hipLaunchKernelGGL(k_sort_depth, dim3(gd), dim3(GS_BLOCK), 0, ctx->stream, ctx->sort_rows, ctx->bound_r, n, u, su, ctx->depth, ctx->part_min,
                        ctx->part_max, ctx->part_cnt);
     if (gs_radix_chunk(n) == GS_CHUNK_L)
         hipLaunchKernelGGL(k_sort_bucket<8>, dim3(g), dim3(512), 0, ctx->stream, ctx->depth, n, ctx->key_a, ctx->part_min,

@@ -121,10 +121,13 @@ def main():
 
     def frame(i, flags=0):
         k = i % ORBIT_FRAMES
-        ctx.sort(cams[k]["view"], cams[k]["cutout"], want_indices=False)
         if gathered:
+            # the sort of a gathered frame covers the splats that can reach this rank's strip (gs_sort_for): at N > 1 the
+            # sort, projection and binning shrink with the strip instead of being replicated on every GPU
+            ctx.sort_gathered(cams[k]["view"], cams[k]["cutout"], views[k])
             ctx.render_gathered(views[k], 0, None, flags)
         else:
+            ctx.sort(cams[k]["view"], cams[k]["cutout"], want_indices=False)
             views[k][0].flags = flags
             ctx.render_device(views[k][0], None)
 
@@ -255,9 +258,10 @@ def main():
         frame(k_last, 0)                                     # collective: every rank
         if rank == 0:
             ok = True
+            got = [ctx.read_gathered(v, W, H) for v in range(len(widths))]
+            ctx.sort(cams[k_last]["view"], cams[k_last]["cutout"], want_indices=False)     # the whole order for rank 0's own full frames
             for v in range(len(widths)):
-                got = ctx.read_gathered(v, W, H)
-                ok = ok and bool(np.array_equal(got, ctx.render(piece_params(k_last, v, 0, W, 0))))
+                ok = ok and bool(np.array_equal(got[v], ctx.render(piece_params(k_last, v, 0, W, 0))))
             frame_check = ok
     copy_peak = measured_copy_peak(ctx, capi) if rank == 0 else None
     total_frags = sum(frags[(args.warmup + i) % ORBIT_FRAMES] for i in range(args.steps))

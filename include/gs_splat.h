@@ -129,6 +129,17 @@ GS_API int gs_render(gs_ctx *ctx, const gs_render_params *p, uint8_t *rgba_out, 
 /* Same, but the strip stays on the GPU: device_rgba is a device pointer (e.g. a torch tensor's
  * data_ptr, tight rows) or NULL to render into the context's own framebuffer only. */
 GS_API int gs_render_device(gs_ctx *ctx, const gs_render_params *p, void *device_rgba);
+/* gs_sort for ONE column strip of a frame that is then drawn with exactly these parameters (strip->x0, x1; NULL = gs_sort):
+ * splats whose quad cannot reach the strip are left out by a conservative bound (4 min(sqrt(2 lambda1), 1024) + 2 pixels
+ * around the projected centre, lambda1 <= (|J| |A| sigma_max)^2 + 0.3, index.js:127-149), the others come in the reference's
+ * order -- the bucket scale still uses the depth range of EVERY splat the reference keeps (index.js:552-558).  The strip's
+ * pixels are bit-identical to those drawn from the full order; what shrinks is the sort (and everything downstream) on a GPU
+ * that owns one strip of eight.  out_idx / out_n: the strip's sub-sequence of the reference's Uint32Array.  Not for a sort
+ * that outlives its camera (the reference draws with the latest completed order, index.js:201-207): render with the pose
+ * it was sorted for. */
+GS_API int gs_sort_for(gs_ctx *ctx, const float view[4], const float *cutout16, const gs_render_params *strip,
+                       uint32_t *out_idx, uint32_t *out_n);
+
 /* XR: two eyes share one sort order from the head camera (index.js:441) -- two params, two images. */
 GS_API int gs_render_stereo(gs_ctx *ctx, const gs_render_params eyes[2], uint8_t *rgba_out[2], size_t stride);
 
@@ -197,6 +208,10 @@ GS_API int gs_partition(int nviews, const int *widths, int world, gs_piece *out,
  * per view.  nviews = 2 is the XR frame: two eyes, ONE shared sort from the head camera (index.js:441). */
 GS_API int gs_render_gathered(gs_ctx *ctx, const gs_render_params *views, int nviews, int root, void *const *device_frames,
                               uint32_t flags);
+/* The sort of a gathered frame: gs_sort_for the piece gs_partition gives this rank when it owns exactly one column strip of
+ * one view (the sort, projection and binning of an 8-GPU frame then shrink with the strip instead of being replicated), a plain
+ * gs_sort otherwise.  Call it with the views the following gs_render_gathered draws. */
+GS_API int gs_sort_gathered(gs_ctx *ctx, const float view[4], const float *cutout16, const gs_render_params *views, int nviews);
 /* root: copy view `view` of the last gathered frame (after gs_sync() for asynchronous frames) to host memory */
 GS_API int gs_read_gathered(gs_ctx *ctx, int view, uint8_t *rgba_out, size_t stride);
 #define GS_OPT_BLEND_SPLIT 9    /* 0 (default): one wavefront blends each tile, 4 pixels per lane.  L > 0: tiles whose list has at least

@@ -1009,3 +1009,43 @@ def test_split_blend_several_wavefronts_per_tile(ctx, scene_small):
         got = c.render(_params(cam))
         pix_check("long_lists_split1024", got, want)
         assert np.array_equal(c.render(_params(cam)), got)                                   # deterministic
+
+
+def test_sort_for_a_strip_is_a_subsequence_and_draws_the_same_pixels(ctx, scene_small):
+    """gs_sort_for (the multi-GPU sort): the order of the splats that can reach a column strip is the reference's order with the
+    others removed (same bucket scale: the depth range of ALL kept splats), the strip drawn from it is bit-identical to the
+    strip drawn from the full order, and a narrow strip keeps only a fraction of the splats -- mono frames, XR eye frusta
+    (asymmetric projection), the cut-out pose, big splats that reach far from their centre."""
+    def check(c, rows4, cam, strips, w, h, min_drop):
+        full = c.sort(cam["view"], cam["cutout"])
+        assert np.array_equal(full, oracle.sort(rows4, cam["view"], cam["cutout"]))
+        for x0, x1 in strips:
+            want = c.render(_params(cam, x0=x0, x1=x1))                  # (the last full sort is current)
+            sub = c.sort_for(cam["view"], cam["cutout"], _params(cam, x0=x0, x1=x1))
+            got = c.render(_params(cam, x0=x0, x1=x1))
+            assert np.array_equal(got, want), (x0, x1)
+            pos = np.full(int(full.max()) + 1 if full.size else 1, -1, np.int64); pos[full] = np.arange(full.size)
+            p = pos[sub]
+            assert np.all(p >= 0) and np.all(np.diff(p) > 0), "not a sub-sequence of the reference order"
+            if x1 - x0 <= w // 4:
+                assert sub.size <= full.size * min_drop, (sub.size, full.size)
+            c.sort(cam["view"], cam["cutout"], want_indices=False)       # back to the full order for the next strip's reference
+    w, h = 640, 360
+    rows4 = np.ascontiguousarray(scene_small["mats"][:, 12:16])
+    with capi.Context(0) as c:
+        c.push_splat(scene_small["rows"])
+        c.set_option(capi.OPT_NEAR_PERMILLE, 1000)                       # one binning round: the share does not depend on the sort's length
+        check(c, rows4, synth.index_html_camera(w, h, 20.0, capi=capi), [(0, 80), (80, 160), (272, 352), (560, 640), (0, 640)], w, h, 0.8)
+        check(c, rows4, synth.cutout_demo_camera(w, h, 75.0, capi=capi), [(160, 240), (320, 400)], w, h, 1.0)
+        l, r, head = synth.xr_eye_cameras(30.0, 0.25, capi=capi)
+        for eye in (l, r):
+            cam = dict(eye); cam["view"] = head["view"]; cam["cutout"] = None
+            check(c, rows4, cam, [(0, 128), (256, 384), (384, eye["vw"])], eye["vw"], eye["vh"], 0.9)
+    # fat splats (x6): quads reach hundreds of pixels from their centres
+    rows = scene_small["rows"].reshape(-1, 32).copy()
+    rows[:, 12:24] = (rows[:, 12:24].copy().view("<f4") * np.float32(6.0)).view(np.uint8)
+    _, _, mats = oracle.pack(rows)
+    with capi.Context(0) as c:
+        c.push_splat(rows)
+        c.set_option(capi.OPT_NEAR_PERMILLE, 1000)
+        check(c, np.ascontiguousarray(mats[:, 12:16]), synth.index_html_camera(w, h, 140.0, capi=capi), [(0, 80), (304, 384)], w, h, 1.0)

@@ -18,12 +18,18 @@ ap.add_argument("--depths", default="1,3")
 ap.add_argument("--near", type=int, default=180, help="pinned share (permille) of the splats binned in the first round; 0 = adaptive")
 ap.add_argument("--sort-only", action="store_true")
 ap.add_argument("--split", type=int, default=0, help="GS_OPT_BLEND_SPLIT")
+ap.add_argument("--strip", default=None, help="k/G: render only strip k of G tile-aligned column strips (what one of G GPUs does)")
+ap.add_argument("--sort-for", action="store_true", help="with --strip: gs_sort_for the strip instead of the full gs_sort")
 a = ap.parse_args()
 W, H = (int(v) for v in a.size.lower().split("x"))
 rows = synth.make_splat_rows_fast(a.splats) if a.splats >= (8 << 20) else synth.make_splat_rows(a.splats)
 pose = synth.cutout_demo_camera if a.cutout else synth.index_html_camera
 cams = [pose(W, H, 3.0 * i, capi=capi) for i in range(120)]
-params = [capi.make_params(c["gs_mv"], c["gs_proj"], W, H, focal_=c["focal"]) for c in cams]
+x0, x1 = 0, W
+if a.strip:
+    k_, g_ = (int(v) for v in a.strip.split("/"))
+    x0, x1 = [(p[1], p[2]) for p in capi.partition([W], g_) if p[3] == k_][0]
+params = [capi.make_params(c["gs_mv"], c["gs_proj"], W, H, x0=x0, x1=x1, focal_=c["focal"]) for c in cams]
 ctx = capi.Context(0)
 r = rows.reshape(-1, 32)
 for o in range(0, a.splats, 1 << 22):
@@ -38,7 +44,10 @@ def go(n):
     t0 = time.perf_counter()
     for i in range(n):
         k = i % 120
-        ctx.sort(cams[k]["view"], cams[k]["cutout"], want_indices=False)
+        if a.sort_for:
+            ctx.sort_for(cams[k]["view"], cams[k]["cutout"], params[k], want_indices=False)
+        else:
+            ctx.sort(cams[k]["view"], cams[k]["cutout"], want_indices=False)
         if not a.sort_only:
             params[k].flags = capi.RENDER_ASYNC
             ctx.render_device(params[k], None)
