@@ -5,7 +5,7 @@
 //   k_radix_hist     one row of 2^bits counts per chunk: H[chunk][digit] (contiguous rows: coalesced to write and to read).
 //                    Skipped when the kernel that PRODUCED the keys filled the rows itself (depth pass A: k_sort_bucket).
 //   k_radix_scan     in place: H[c][d] <- sum of H[c'][d] over c' < c (the chunk's offset inside every digit's run), and the
-//                    digit totals.  One 256-thread workgroup per slab of 16 digits -- 8 to 32 workgroups, a few us.
+//                    digit totals.  One workgroup (256 / 512 threads) per slab of 16 digits -- 8 to 32 workgroups, a few us.
 //   k_radix_scatter  one workgroup per chunk: stable rank of every item among the items of its digit, chunk reordered in LDS,
 //                    written to start-of-run + offset-of-chunk + rank.
 // Two workgroup geometries, chosen by the expected input length (a matter of speed only): 256 threads x 2048 items for
@@ -82,24 +82,26 @@ __global__ __launch_bounds__(64 * NW) void k_radix_hist(const uint32_t *__restri
     }
 }
 
-// In place: H[c][d] <- exclusive sum over the chunks before c; totals[d] = sum over all chunks.  One 256-thread workgroup per
-// slab of 16 digits (small workgroups: this kernel runs in the gaps of other frames' kernels, and a 1024-thread workgroup
-// waits until one CU has 16 free wave slots): thread (q, r) owns 4 digits and a contiguous run of rows, the first 16 of which
-// stay in registers between the two sweeps (run totals -> exclusive offsets of the runs by shuffles + 4 LDS partials -> the
-// rows' exclusive sums).
-__global__ __launch_bounds__(256) void k_radix_scan(uint32_t *__restrict__ hist, const uint32_t *n_ptr, uint32_t chunk, int bits,
-                                                    uint32_t *__restrict__ totals)
+// In place: H[c][d] <- exclusive sum over the chunks before c; totals[d] = sum over all chunks.  One workgroup of NW waves per
+// slab of 16 digits (small workgroups for short inputs: the kernel runs in the gaps of other frames' kernels, and a
+// 1024-thread workgroup waits until one CU has 16 free wave slots; 8 waves for long inputs: fewer rows per thread): thread
+// (q, r) owns 4 digits and a contiguous run of rows, the first 16 of which stay in registers between the two sweeps (run
+// totals -> exclusive offsets of the runs by shuffles + NW LDS partials -> the rows' exclusive sums), 8 rows in flight beyond.
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void k_radix_scan(uint32_t *__restrict__ hist, const uint32_t *n_ptr, uint32_t chunk, int bits,
+                                                        uint32_t *__restrict__ totals)
 {
     constexpr int RC = 16;                                          // rows cached in registers
-    __shared__ uint4 s_part[4][4];                                  // [wave][quad] totals
+    constexpr uint32_t LANES = 16u * NW;                            // row lanes: 4 quads x LANES threads
+    __shared__ uint4 s_part[NW][4];                                 // [wave][quad] totals
     const uint32_t n = *n_ptr;
     const uint32_t nchunks = (n + chunk - 1) / chunk;
     const uint32_t nbins = 1u << bits, rs = gs_radix_row_stride(nbins);
-    const uint32_t q = threadIdx.x & 3u, r = threadIdx.x >> 2;      // 4 quads x 64 row lanes
+    const uint32_t q = threadIdx.x & 3u, r = threadIdx.x >> 2;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const uint32_t d0 = blockIdx.x * 16u + q * 4u;                  // this thread's 4 digits
     const bool dig_ok = d0 < rs;
-    const uint32_t rpl = (nchunks + 63u) / 64u;                     // rows per row lane
+    const uint32_t rpl = (nchunks + LANES - 1u) / LANES;            // rows per row lane
     const uint32_t c_lo = min(r * rpl, nchunks), c_hi = min(c_lo + rpl, nchunks);
     uint32_t *col = hist + d0;
     uint4 h[RC];
@@ -110,11 +112,18 @@ __global__ __launch_bounds__(256) void k_radix_scan(uint32_t *__restrict__ hist,
     }
 #pragma unroll
     for (int k = 0; k < RC; k++) { run.x += h[k].x; run.y += h[k].y; run.z += h[k].z; run.w += h[k].w; }
-    if (dig_ok) for (uint32_t c = c_lo + RC; c < c_hi; c++) {       // long inputs: the rest of the run
-        const uint4 t = *reinterpret_cast<const uint4 *>(col + (size_t)c * rs);
-        run.x += t.x; run.y += t.y; run.z += t.z; run.w += t.w;
+    if (dig_ok) {                                                   // long inputs: the rest of the run, eight rows in flight
+        uint32_t c = c_lo + RC;
+        for (; c + 8u <= c_hi; c += 8u) {
+            uint4 t[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) t[k] = *reinterpret_cast<const uint4 *>(col + (size_t)(c + k) * rs);
+#pragma unroll
+            for (int k = 0; k < 8; k++) { run.x += t[k].x; run.y += t[k].y; run.z += t[k].z; run.w += t[k].w; }
+        }
+        for (; c < c_hi; c++) { const uint4 t = *reinterpret_cast<const uint4 *>(col + (size_t)c * rs); run.x += t.x; run.y += t.y; run.z += t.z; run.w += t.w; }
     }
-    // inclusive scan over the 16 row lanes of this wave that share the quad (lanes q, q + 4, ...), then over the 4 waves
+    // inclusive scan over the 16 row lanes of this wave that share the quad (lanes q, q + 4, ...), then over the waves
     uint4 inc = run;
 #pragma unroll
     for (int dlt = 4; dlt < 64; dlt <<= 1) {
@@ -126,7 +135,7 @@ __global__ __launch_bounds__(256) void k_radix_scan(uint32_t *__restrict__ hist,
     uint4 base = make_uint4(inc.x - run.x, inc.y - run.y, inc.z - run.z, inc.w - run.w);
     uint4 grand = make_uint4(0, 0, 0, 0);
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
+    for (int k = 0; k < NW; k++) {
         const uint4 p = s_part[k][q];
         if (k < w) { base.x += p.x; base.y += p.y; base.z += p.z; base.w += p.w; }
         grand.x += p.x; grand.y += p.y; grand.z += p.z; grand.w += p.w;
@@ -137,7 +146,18 @@ __global__ __launch_bounds__(256) void k_radix_scan(uint32_t *__restrict__ hist,
             if (c_lo + k < c_hi) *reinterpret_cast<uint4 *>(col + (size_t)(c_lo + k) * rs) = base;
             base.x += h[k].x; base.y += h[k].y; base.z += h[k].z; base.w += h[k].w;
         }
-        for (uint32_t c = c_lo + RC; c < c_hi; c++) {
+        uint32_t c = c_lo + RC;
+        for (; c + 8u <= c_hi; c += 8u) {
+            uint4 t[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) t[k] = *reinterpret_cast<const uint4 *>(col + (size_t)(c + k) * rs);
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                *reinterpret_cast<uint4 *>(col + (size_t)(c + k) * rs) = base;
+                base.x += t[k].x; base.y += t[k].y; base.z += t[k].z; base.w += t[k].w;
+            }
+        }
+        for (; c < c_hi; c++) {
             const uint4 t = *reinterpret_cast<const uint4 *>(col + (size_t)c * rs);
             *reinterpret_cast<uint4 *>(col + (size_t)c * rs) = base;
             base.x += t.x; base.y += t.y; base.z += t.z; base.w += t.w;
@@ -312,7 +332,7 @@ int launch_pass(gs_ctx *ctx, const void *in, int in_fmt, void *out, int out_fmt,
     if (have_hist) { /* the producer of `in` already wrote hist[chunk][digit] */ }
     else if (in_fmt == GS_RADIX_PACKED) hipLaunchKernelGGL((k_radix_hist<true, NW>), G, B, 0, st, (const uint32_t *)in, n_ptr, shift, bits, ctx->hist);
     else hipLaunchKernelGGL((k_radix_hist<false, NW>), G, B, 0, st, (const uint32_t *)in, n_ptr, shift, bits, ctx->hist);
-    hipLaunchKernelGGL(k_radix_scan, dim3(gs_div_up(gs_radix_row_stride(1u << bits), 16u)), dim3(256), 0, st, ctx->hist, n_ptr, CH, bits, totals);
+    hipLaunchKernelGGL((k_radix_scan<NW>), dim3(gs_div_up(gs_radix_row_stride(1u << bits), 16u)), dim3(64 * NW), 0, st, ctx->hist, n_ptr, CH, bits, totals);
 #define GS_SCATTER(I, O) do { if (bits <= 7) hipLaunchKernelGGL((k_radix_scatter<I, O, 128, NW>), G, B, 0, st, in, out, n_ptr, shift, bits, zero_key, ctx->hist, totals); \
                               else if (bits == 8) hipLaunchKernelGGL((k_radix_scatter<I, O, 256, NW>), G, B, 0, st, in, out, n_ptr, shift, bits, zero_key, ctx->hist, totals); \
                               else hipLaunchKernelGGL((k_radix_scatter<I, O, GS_RADIX_MAX_BINS, NW>), G, B, 0, st, in, out, n_ptr, shift, bits, zero_key, ctx->hist, totals); } while (0)

@@ -59,6 +59,7 @@ __device__ __forceinline__ bool strip_may_touch(const StripUniforms &s, float x,
     return !(xpx + reach < s.sx0 || xpx - reach > s.sx1);
 }
 
+template <bool STRIP>                                             // (two instantiations: the strip test must not cost the plain sort registers)
 __global__ __launch_bounds__(GS_BLOCK) void k_sort_depth(const float4 *__restrict__ rows, const float *__restrict__ bound_r, uint32_t n, SortUniforms u, StripUniforms su,
                                                          float *__restrict__ depth_out, unsigned long long *__restrict__ part_min,
                                                          unsigned long long *__restrict__ part_max, uint32_t *__restrict__ part_cnt)
@@ -78,7 +79,7 @@ __global__ __launch_bounds__(GS_BLOCK) void k_sort_depth(const float4 *__restric
         for (int r = 0; r < GS_DEPTH_IPT; r++) {
             const uint32_t i = c * DCHUNK + r * GS_BLOCK + threadIdx.x;
             mm[r] = i < n ? rows[i] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            sg[r] = (u.has_strip && i < n) ? bound_r[i] : 0.0f;
+            sg[r] = (STRIP && i < n) ? bound_r[i] : 0.0f;
         }
 #pragma unroll
         for (int r = 0; r < GS_DEPTH_IPT; r++) {
@@ -90,7 +91,7 @@ __global__ __launch_bounds__(GS_BLOCK) void k_sort_depth(const float4 *__restric
                 const bool keep = gsm::sort_keep(d, m.w, inside);
                 // the bucket scale comes from EVERY splat the reference keeps (index.js:552-553), so a strip's order is the
                 // reference's order restricted to the strip's splats; only those are handed on
-                const bool mine = keep && (!u.has_strip || strip_may_touch(su, m.x, m.y, m.z, (float)d, sg[r]));
+                const bool mine = keep && (!STRIP || strip_may_touch(su, m.x, m.y, m.z, (float)d, sg[r]));
                 depth_out[i] = mine ? (float)d : INFINITY;
                 if (keep) {
                     const unsigned long long e = gsm::f64_to_ordered(d);
@@ -225,8 +226,10 @@ int gs_run_sort(gs_ctx *ctx, const float view[4], const float *cutout16, const G
     uint32_t gd = gs_div_up(n, (uint32_t)(GS_DEPTH_IPT * GS_BLOCK));
     if (gd < 1) gd = 1;
     if (gd > GS_DEPTH_GRID) gd = GS_DEPTH_GRID;
-    hipLaunchKernelGGL(k_sort_depth, dim3(gd), dim3(GS_BLOCK), 0, ctx->stream, ctx->sort_rows, ctx->bound_r, n, u, su, ctx->depth, ctx->part_min,
-                       ctx->part_max, ctx->part_cnt);
+    if (u.has_strip) hipLaunchKernelGGL(k_sort_depth<true>, dim3(gd), dim3(GS_BLOCK), 0, ctx->stream, ctx->sort_rows, ctx->bound_r, n, u, su, ctx->depth,
+                                        ctx->part_min, ctx->part_max, ctx->part_cnt);
+    else hipLaunchKernelGGL(k_sort_depth<false>, dim3(gd), dim3(GS_BLOCK), 0, ctx->stream, ctx->sort_rows, ctx->bound_r, n, u, su, ctx->depth,
+                            ctx->part_min, ctx->part_max, ctx->part_cnt);
     if (gs_radix_chunk(n) == GS_CHUNK_L)
         hipLaunchKernelGGL(k_sort_bucket<8>, dim3(g), dim3(512), 0, ctx->stream, ctx->depth, n, ctx->key_a, ctx->part_min,
                            ctx->part_max, ctx->part_cnt, gd, ctx->hist, ctx->ctl);

@@ -90,10 +90,25 @@ def main():
         # list are blended by four wavefronts, one pixel per lane (GS_OPT_BLEND_SPLIT; images within the same 1 LSB tolerance)
         ctx.set_option(capi.OPT_BLEND_SPLIT, blend_split)
     gathered = world > 1 or comm1 or args.xr                 # frames go through gs_render_gathered
+    torch_gather = False                                     # fallback only: see below
     if world > 1:
-        box = [ctx.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(box, src=0)
-        ctx.comm_init(box[0], rank, world)
+        ok = 1
+        try:
+            box = [ctx.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            if box[0] is None:
+                raise capi.GsError(capi.E_STATE, "rank 0 could not create a communicator id")
+            ctx.comm_init(box[0], rank, world)
+        except capi.GsError as e:
+            sys.stderr.write("rank %d: gs_comm_init failed (%s)\n" % (rank, e))
+            ok = 0
+        t = torch.tensor([ok], dtype=torch.int32, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        if int(t.item()) == 0:
+            # The library's own communicator could not be set up on this node: keep the measurement alive with the plain form of
+            # the same exchange -- every rank renders its strip synchronously into a torch tensor, torch.distributed gathers the
+            # strips on rank 0 (no pipelining of the gather; reported in config.parallelism).
+            torch_gather = True
     elif comm1:
         ctx.comm_init(ctx.comm_unique_id(), 0, 1)
         ctx.set_option(capi.OPT_COMM_SELF_COPY, 1)
@@ -119,9 +134,23 @@ def main():
         q = views[k][v]
         return capi.make_params(np.array(q.model_view), np.array(q.projection), W, H, x0=x0, x1=x1, focal_=q.focal, flags=flags)
 
+    tg = {}
+
+    def frame_torch_gather(k):
+        mg = importlib.import_module(PKG + ".multigpu")
+        if not tg:
+            tg["strip"] = torch.zeros(mg.strip_buffer_bytes(W, H, world), dtype=torch.uint8, device="cuda")
+            tg["all"] = [torch.zeros_like(tg["strip"]) for _ in range(world)] if rank == 0 else None
+        ctx.sort(cams[k]["view"], cams[k]["cutout"], want_indices=False)
+        for v, x0, x1 in mine:
+            ctx.render_device(piece_params(k, v, x0, x1, 0), tg["strip"].data_ptr())     # synchronous
+        tg["frame"] = mg.gather_strips(tg["strip"], W, H, dist, tg["all"])
+
     def frame(i, flags=0):
         k = i % ORBIT_FRAMES
-        if gathered:
+        if torch_gather:
+            frame_torch_gather(k)
+        elif gathered:
             # the sort of a gathered frame covers the splats that can reach this rank's strip (gs_sort_for): at N > 1 the
             # sort, projection and binning shrink with the strip instead of being replicated on every GPU
             ctx.sort_gathered(cams[k]["view"], cams[k]["cutout"], views[k])
@@ -258,7 +287,7 @@ def main():
         frame(k_last, 0)                                     # collective: every rank
         if rank == 0:
             ok = True
-            got = [ctx.read_gathered(v, W, H) for v in range(len(widths))]
+            got = [tg["frame"].cpu().numpy()] if torch_gather else [ctx.read_gathered(v, W, H) for v in range(len(widths))]
             ctx.sort(cams[k_last]["view"], cams[k_last]["cutout"], want_indices=False)     # the whole order for rank 0's own full frames
             for v in range(len(widths)):
                 ok = ok and bool(np.array_equal(got[v], ctx.render(piece_params(k_last, v, 0, W, 0))))
@@ -292,7 +321,8 @@ def main():
                 n_splats, W, H, "cutout-demo.html:22-24 pose + cutoutEntity box" if args.cutout else "index.html:13 pose")
         if world > 1:
             par = ("XR eyes divided over %d GPUs" % world if args.xr else "column strips x%d" % world) + \
-                  ", splat buffer replicated, pieces gathered on rank 0 by the C library over RCCL (gs_render_gathered)"
+                  (", splat buffer replicated, strips gathered on rank 0 by torch.distributed (FALLBACK: gs_comm_init failed here)" if torch_gather else
+                   ", splat buffer replicated, pieces gathered on rank 0 by the C library over RCCL (gs_render_gathered)")
         else:
             par = "single GPU" + (", both eyes on it" if args.xr else "") + (", gathered path exercised at world 1 (GS_BENCH_COMM)" if comm1 else "")
         out = {
