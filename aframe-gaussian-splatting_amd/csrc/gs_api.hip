@@ -475,7 +475,7 @@ GS_API int gs_create(int device, gs_ctx **out)
     gs_ctx *ctx = new (std::nothrow) gs_ctx();
     if (!ctx) { snprintf(g_create_err, sizeof g_create_err, "out of host memory"); return GS_E_OOM; }
     memset(ctx, 0, sizeof *ctx);
-    ctx->device = device; ctx->renderable = true; ctx->t_eps = 1.0f / 4096.0f; ctx->near_frac = 0.25f;
+    ctx->device = device; ctx->renderable = true; ctx->t_eps = 1.0f / 1024.0f; ctx->near_frac = 0.25f;
     ctx->lanes[0] = ctx; ctx->pipe_depth = 3; ctx->enqueue_threads = true;
 #define CREATE_HIP(call) do { hipError_t _e = (call); if (_e != hipSuccess) {                                              \
         snprintf(g_create_err, sizeof g_create_err, "%s failed: %s", #call, hipGetErrorString(_e)); gs_destroy(ctx);      \
@@ -711,6 +711,8 @@ int gs_fill_uniforms(gs_ctx *ctx /* owner: options, adaptive share, scene */, co
     if (p->x0 < 0 || p->x1 > p->fb_width || p->x0 >= p->x1) FAIL(GS_E_BADARG, "bad strip [%d,%d) for width %d", p->x0, p->x1, p->fb_width);
     memcpy(u.mv, p->model_view, sizeof u.mv); memcpy(u.proj, p->projection, sizeof u.proj);
     u.W = p->fb_width; u.H = p->fb_height; u.x0 = p->x0; u.x1 = p->x1;
+    u.x1b = p->x0 + ((p->x1 - p->x0 + 3) & ~3);
+    if (u.x1b > p->fb_width) u.x1b = p->fb_width;
     u.vw = (float)p->fb_width; u.vh = (float)p->fb_height;
     // focal = (viewport.w / 2) * |P[5]| in JS f64, uploaded as a float uniform (index.js:191-194)
     u.focal = p->focal > 0 ? p->focal : (float)(((double)p->fb_height / 2.0) * fabs((double)p->projection[5]));

@@ -59,6 +59,7 @@ struct GsFrameUniforms {           // per-render constants, passed by value to k
     float focal, vw, vh;
     int32_t W, H;                  // full viewport
     int32_t x0, x1;                // strip
+    int32_t x1b;                   // x1 rounded up to a multiple of 4 pixels from x0, clipped to W: what is binned and blended (x1: written)
     int32_t tiles_x, tiles_y;      // tile grid of the strip (origin at pixel x0, row 0 = top)
     float bg[4];
     float t_eps;                   // early-out threshold on transmittance

@@ -104,7 +104,7 @@ __global__ __launch_bounds__(GS_BLOCK) void k_project(const uint32_t *__restrict
                 float xmin, xmax, ymin, ymax;
                 gsm::splat_pixel_bounds(p, x, xmin, xmax, ymin, ymax);
                 // clamp in float (bounds can be far outside the int range), then to the strip / screen
-                const float fx0 = fmaxf(xmin, (float)u.x0), fx1 = fminf(xmax, (float)(u.x1 - 1));
+                const float fx0 = fmaxf(xmin, (float)u.x0), fx1 = fminf(xmax, (float)(u.x1b - 1));
                 const float fy0 = fmaxf(ymin, 0.0f), fy1 = fminf(ymax, (float)(u.H - 1));
                 if (fx0 <= fx1 && fy0 <= fy1) {
                     const int ix0 = (int)fx0, ix1 = (int)fx1, jy0 = (int)fy0, jy1 = (int)fy1;
@@ -129,7 +129,7 @@ __global__ __launch_bounds__(GS_BLOCK) void k_project(const uint32_t *__restrict
                         gsm::ellipse_rows_setup(p, e);
                         for (uint32_t ty = ty0; ty <= ty1; ty++) {
                             uint32_t a, n;
-                            gsm::splat_tile_row(p, e, (int)ty, u.H, u.x0, u.x1, a, n);
+                            gsm::splat_tile_row(p, e, (int)ty, u.H, u.x0, u.x1b, a, n);
                             if (ROUND == 1 && n) n = mask_count(mask + ty * u.mask_words, a, n);
                             count += n;
                         }
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(GS_BLOCK) void k_project(const uint32_t *__restrict
                 const uint32_t ty = (s_rows[mi] & 0xFFFF) + ((uint32_t)lane & 15u);
                 if (ty <= (s_rows[mi] >> 16)) {
                     uint32_t a;
-                    gsm::splat_tile_row(p, e, (int)ty, u.H, u.x0, u.x1, a, n);
+                    gsm::splat_tile_row(p, e, (int)ty, u.H, u.x0, u.x1b, a, n);
                     if (ROUND == 1 && n) n = mask_count(mask + ty * u.mask_words, a, n);
                 }
             }
@@ -173,7 +173,7 @@ __global__ __launch_bounds__(GS_BLOCK) void k_project(const uint32_t *__restrict
             uint32_t rsum = 0;
             for (uint32_t ty = ty0 + lane; ty <= ty1; ty += 64) {
                 uint32_t a, n;
-                gsm::splat_tile_row(p, e, (int)ty, u.H, u.x0, u.x1, a, n);
+                gsm::splat_tile_row(p, e, (int)ty, u.H, u.x0, u.x1b, a, n);
                 if (ROUND == 1 && n) n = mask_count(mask + ty * u.mask_words, a, n);
                 rsum += n;
             }
@@ -334,7 +334,7 @@ __global__ __launch_bounds__(GS_BLOCK) void k_emit(const gsm::Projected *__restr
             const uint32_t r = rb + threadIdx.x;
             uint32_t t0 = 0, n = 0, nm = 0;
             if (r < rows) {
-                gsm::splat_tile_row(p, e, (int)(ty0 + r), u.H, u.x0, u.x1, t0, n);
+                gsm::splat_tile_row(p, e, (int)(ty0 + r), u.H, u.x0, u.x1b, t0, n);
                 nm = (ROUND == 1 && n) ? mask_count(mask + (ty0 + r) * u.mask_words, t0, n) : n;
             }
             const uint32_t inc = wave_incl_scan_u32(nm, lane);
@@ -401,7 +401,7 @@ __global__ __launch_bounds__(GS_BLOCK) void k_emit(const gsm::Projected *__restr
                 const uint2 rc = rect[j];
                 for (uint32_t ty = rc.x >> 16; ty <= (rc.y >> 16); ty++) {
                     uint32_t t0, n;
-                    gsm::splat_tile_row(p, e, (int)ty, u.H, u.x0, u.x1, t0, n);
+                    gsm::splat_tile_row(p, e, (int)ty, u.H, u.x0, u.x1b, t0, n);
                     o = emit_run<ROUND, P32>(pairs, o, ty, tiles_x, t0, n, j, j - j_lo, u.pair_jbits, mask + ty * u.mask_words);
                 }
             }
@@ -420,7 +420,7 @@ __global__ __launch_bounds__(GS_BLOCK) void k_emit(const gsm::Projected *__restr
                     ty = (s_qrows[mi] & 0xFFFFu) + ((uint32_t)lane & 15u);
                     row_ok = ty <= (s_qrows[mi] >> 16);
                     if (row_ok) {
-                        gsm::splat_tile_row(p, e, (int)ty, u.H, u.x0, u.x1, t0, n);
+                        gsm::splat_tile_row(p, e, (int)ty, u.H, u.x0, u.x1b, t0, n);
                         nm = (ROUND == 1 && n) ? mask_count(mask + ty * u.mask_words, t0, n) : n;
                     }
                 }
@@ -443,7 +443,7 @@ __global__ __launch_bounds__(GS_BLOCK) void k_emit(const gsm::Projected *__restr
                     const uint32_t ty = tyb + lane;
                     uint32_t t0 = 0, n = 0, nm = 0;
                     if (ty <= ty1) {
-                        gsm::splat_tile_row(p, e, (int)ty, u.H, u.x0, u.x1, t0, n);
+                        gsm::splat_tile_row(p, e, (int)ty, u.H, u.x0, u.x1b, t0, n);
                         nm = (ROUND == 1 && n) ? mask_count(mask + ty * u.mask_words, t0, n) : n;
                     }
                     const uint32_t rinc = wave_incl_scan_u32(nm, lane);
@@ -538,18 +538,20 @@ __global__ __launch_bounds__(64) void k_blend(const uint2 *__restrict__ tile_ran
     f2 fxA = { (float)xb + 0.5f, (float)(xb + 1) + 0.5f }, fxB = { (float)(xb + 2) + 0.5f, (float)(xb + 3) + 0.5f };
     // qm: coverage threshold, 4 inside the strip (fragment kept iff q <= 4, index.js:172), -1 for pixels outside it (never
     // covered, never written; their T starts at 0 so that they do not keep the lane alive)
-    const f2 qmA = { (row_in && xb < u.x1) ? 4.0f : -1.0f, (row_in && xb + 1 < u.x1) ? 4.0f : -1.0f };
-    const f2 qmB = { (row_in && xb + 2 < u.x1) ? 4.0f : -1.0f, (row_in && xb + 3 < u.x1) ? 4.0f : -1.0f };
+    // (x1b: the strip's right edge rounded up to the lane's group of 4 pixels, inside the frame: those pixels are blended --
+    // not written -- so that the lane leaves its list exactly where it does when the whole frame is drawn)
+    const f2 qmA = { (row_in && xb < u.x1b) ? 4.0f : -1.0f, (row_in && xb + 1 < u.x1b) ? 4.0f : -1.0f };
+    const f2 qmB = { (row_in && xb + 2 < u.x1b) ? 4.0f : -1.0f, (row_in && xb + 3 < u.x1b) ? 4.0f : -1.0f };
     f2 TA = { qmA.x > 0.0f ? 1.0f : 0.0f, qmA.y > 0.0f ? 1.0f : 0.0f }, TB = { qmB.x > 0.0f ? 1.0f : 0.0f, qmB.y > 0.0f ? 1.0f : 0.0f };
     f2 crA = { 0, 0 }, crB = { 0, 0 }, cgA = { 0, 0 }, cgB = { 0, 0 }, cbA = { 0, 0 }, cbB = { 0, 0 };
     // opaque scene depth under each of the lane's 4 pixels (+inf = nothing in front of the far plane)
     float zb0 = 3.0e38f, zb1 = 3.0e38f, zb2 = 3.0e38f, zb3 = 3.0e38f;
     if (SCENE && u.has_depth && row_in) {
         const float *zr = scene_depth + (size_t)r * u.W + xb;
-        if (xb < u.x1) zb0 = zr[0];
-        if (xb + 1 < u.x1) zb1 = zr[1];
-        if (xb + 2 < u.x1) zb2 = zr[2];
-        if (xb + 3 < u.x1) zb3 = zr[3];
+        if (xb < u.x1b) zb0 = zr[0];
+        if (xb + 1 < u.x1b) zb1 = zr[1];
+        if (xb + 2 < u.x1b) zb2 = zr[2];
+        if (xb + 3 < u.x1b) zb3 = zr[3];
     }
     float4 *st = state + ((size_t)tile * 64 + lane) * 4;           // 4 x float4 per lane: T, r, g, b of its 4 pixels
     if (ROUND == 1) {

@@ -124,8 +124,9 @@ typedef struct gs_render_params {
 /* Draw the last gs_sort() order into a tightly described RGBA8 image in caller-owned host memory.
  * rgba_out: (x1-x0) x fb_height pixels, `stride` bytes per row (0 = tight), row 0 = top. */
 GS_API int gs_render(gs_ctx *ctx, const gs_render_params *p, uint8_t *rgba_out, size_t stride);
-/* Strips [x0,x1) whose x0 is a multiple of 4 (the multi-GPU partition uses multiples of 16) reproduce the corresponding
- * columns of the full frame bit for bit; other strips within 1 LSB (early termination works on groups of 4 pixels). */
+/* Strips [x0,x1) whose x0 is a multiple of 4 (the multi-GPU partition uses multiples of 16), whatever x1, reproduce the
+ * corresponding columns of the full frame bit for bit; other strips within 1 LSB (early termination works on groups of 4
+ * pixels counted from x0). */
 /* Same, but the strip stays on the GPU: device_rgba is a device pointer (e.g. a torch tensor's
  * data_ptr, tight rows) or NULL to render into the context's own framebuffer only. */
 GS_API int gs_render_device(gs_ctx *ctx, const gs_render_params *p, void *device_rgba);
@@ -268,7 +269,9 @@ typedef struct gs_stats {
 #define GS_OPT_PROFILE 1        /* 1: bracket every stage with HIP events on the frame's stream (7 per frame); 2: only
                                    the blend kernel (2 per frame; sum_ms_blend / prof_frames); 3: like 2 but only on every
                                    4th frame of a lane (an event pair costs ~5 % of the pipelined frame rate); 0: off */
-#define GS_OPT_TERMINATION 2    /* value = 1/eps for the transmittance early-out (default 4096)          */
+#define GS_OPT_TERMINATION 2    /* value = 1/eps: a pixel stops blending once its transmittance T < eps (default 1024, SURVEY.md 8a row 9:
+                                   what lies behind then weighs < eps = 0.25 LSB of RGBA8 in total; the image stays within 1 LSB of the
+                                   back-to-front result for any eps < 1/256.  4096 was the round-1 default: 9 % fewer frames/s) */
 #define GS_OPT_NEAR_PERMILLE 3  /* occlusion-aware binning: 0 = adapt (default), 1..999 = bin that share of the nearest
                                    splats first and the rest only against unsaturated tiles, 1000 = single round      */
 #define GS_OPT_RECORD_STAGED 4  /* value != 0: each render overwrites the tile-range table with (list entries staged,

@@ -18,6 +18,7 @@ ap.add_argument("--depths", default="1,3")
 ap.add_argument("--near", type=int, default=180, help="pinned share (permille) of the splats binned in the first round; 0 = adaptive")
 ap.add_argument("--sort-only", action="store_true")
 ap.add_argument("--split", type=int, default=0, help="GS_OPT_BLEND_SPLIT")
+ap.add_argument("--term", type=int, default=0, help="GS_OPT_TERMINATION (1/eps)")
 ap.add_argument("--strip", default=None, help="k/G: render only strip k of G tile-aligned column strips (what one of G GPUs does)")
 ap.add_argument("--sort-for", action="store_true", help="with --strip: gs_sort_for the strip instead of the full gs_sort")
 a = ap.parse_args()
@@ -36,6 +37,8 @@ for o in range(0, a.splats, 1 << 22):
     ctx.push_splat(r[o:o + (1 << 22)])
 if a.split:
     ctx.set_option(capi.OPT_BLEND_SPLIT, a.split)
+if a.term:
+    ctx.set_option(capi.OPT_TERMINATION, a.term)
 if a.near:
     ctx.set_option(capi.OPT_NEAR_PERMILLE, a.near)
 
