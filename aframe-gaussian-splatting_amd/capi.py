@@ -26,7 +26,7 @@ EXPORTS = [
     "gs_model_view_matrix", "gs_projection_matrix", "gs_tick_uniforms", "gs_focal", "gs_scaled_size", "gs_set_option",
     "gs_get_stats", "gs_download",
     "gs_comm_unique_id", "gs_comm_init", "gs_comm_destroy", "gs_partition", "gs_render_gathered", "gs_read_gathered",
-    "gs_host_alloc", "gs_host_free", "gs_sort_for", "gs_sort_gathered",
+    "gs_host_alloc", "gs_host_free", "gs_sort_for", "gs_sort_gathered", "gs_gathered_size",
 ]
 
 
@@ -116,6 +116,7 @@ def load(build_if_missing=True):
     L.gs_read_gathered.argtypes = [vp, i32, vp, sz]
     L.gs_sort_for.argtypes = [vp, vp, vp, C.POINTER(RenderParams), vp, u32p]
     L.gs_sort_gathered.argtypes = [vp, vp, vp, C.POINTER(RenderParams), i32]
+    L.gs_gathered_size.argtypes = [vp, i32, C.POINTER(i32), C.POINTER(i32)]
     L.gs_host_alloc.argtypes = [sz]; L.gs_host_alloc.restype = C.c_void_p
     L.gs_host_free.argtypes = [vp]; L.gs_host_free.restype = None
     _lib = L

@@ -318,6 +318,17 @@ GS_API int gs_sort_gathered(gs_ctx *ctx, const float view[4], const float *cutou
     return gs_sort_for(ctx, view, cutout16, &p, nullptr, nullptr);
 }
 
+GS_API int gs_gathered_size(gs_ctx *ctx, int view, int *width, int *height)
+{
+    if (!ctx || !width || !height) return GS_E_BADARG;
+    int rc = gs_lane_call(ctx, false, [](gs_ctx *) { return GS_OK; });   // the lane's worker has enqueued (and recorded) the frame
+    if (rc != GS_OK) return rc;
+    gs_ctx *L = ctx->lanes[ctx->cur];
+    if (view < 0 || view >= L->gviews) FAILC(GS_E_STATE, "gs_gathered_size: no gathered frame for view %d on this context", view);
+    *width = L->gw[view]; *height = L->gh[view];
+    return GS_OK;
+}
+
 GS_API int gs_read_gathered(gs_ctx *ctx, int view, uint8_t *rgba_out, size_t stride)
 {
     if (!ctx || !rgba_out) return GS_E_BADARG;

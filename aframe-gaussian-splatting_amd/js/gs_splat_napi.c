@@ -475,6 +475,128 @@ static napi_value fn_render_async(napi_env env, napi_callback_info info)
     return async_start(env, a, argv[0], "gs_render");
 }
 
+/* ---- several GPUs: one node process (or worker) per GPU, each with its own context; see gs_splat.h ------------------- */
+
+/* partition([width0(, width1)], world) -> [{view, x0, x1, owner}, ...] */
+static napi_value fn_partition(napi_env env, napi_callback_info info)
+{
+    napi_value argv[2], arr;
+    if (!get_args(env, info, 2, argv, NULL)) return NULL;
+    uint32_t nv = 0; int32_t world = 1; int widths[2] = { 0, 0 };
+    NAPI_OK(napi_get_array_length(env, argv[0], &nv));
+    if (nv < 1 || nv > 2) { napi_throw_range_error(env, NULL, "partition: one or two views"); return NULL; }
+    for (uint32_t i = 0; i < nv; i++) { napi_value e; NAPI_OK(napi_get_element(env, argv[0], i, &e)); NAPI_OK(napi_get_value_int32(env, e, &widths[i])); }
+    NAPI_OK(napi_get_value_int32(env, argv[1], &world));
+    gs_piece pcs[128];
+    const int n = gs_partition((int)nv, widths, world, pcs, 128);
+    if (n < 0) { napi_throw_range_error(env, NULL, "partition: bad widths or world size"); return NULL; }
+    NAPI_OK(napi_create_array_with_length(env, (size_t)n, &arr));
+    for (int i = 0; i < n; i++) {
+        napi_value o, v;
+        NAPI_OK(napi_create_object(env, &o));
+        NAPI_OK(napi_create_int32(env, pcs[i].view, &v)); NAPI_OK(napi_set_named_property(env, o, "view", v));
+        NAPI_OK(napi_create_int32(env, pcs[i].x0, &v)); NAPI_OK(napi_set_named_property(env, o, "x0", v));
+        NAPI_OK(napi_create_int32(env, pcs[i].x1, &v)); NAPI_OK(napi_set_named_property(env, o, "x1", v));
+        NAPI_OK(napi_create_int32(env, pcs[i].owner, &v)); NAPI_OK(napi_set_named_property(env, o, "owner", v));
+        NAPI_OK(napi_set_element(env, arr, (uint32_t)i, o));
+    }
+    return arr;
+}
+
+/* commUniqueId(h) -> ArrayBuffer(128): rank 0 creates it, the launcher hands it to every rank (IPC message, file, ...) */
+static napi_value fn_comm_unique_id(napi_env env, napi_callback_info info)
+{
+    napi_value argv[1], ab; void *out;
+    if (!get_args(env, info, 1, argv, NULL)) return NULL;
+    gs_ctx *ctx = get_ctx(env, argv[0]); if (!ctx) return NULL;
+    NAPI_OK(napi_create_arraybuffer(env, GS_COMM_ID_BYTES, &out, &ab));
+    int rc = gs_comm_unique_id(ctx, out);
+    if (rc != GS_OK) return throw_gs(env, ctx, rc);
+    return ab;
+}
+
+/* commInit(h, id, rank, world): collective -- returns when every rank has called it */
+static napi_value fn_comm_init(napi_env env, napi_callback_info info)
+{
+    napi_value argv[4]; int32_t rank = 0, world = 1;
+    if (!get_args(env, info, 4, argv, NULL)) return NULL;
+    gs_ctx *ctx = get_ctx(env, argv[0]); if (!ctx) return NULL;
+    void *id; size_t len;
+    if (!get_bytes(env, argv[1], &id, &len) || len < GS_COMM_ID_BYTES) { napi_throw_type_error(env, NULL, "commInit: id must hold 128 bytes"); return NULL; }
+    NAPI_OK(napi_get_value_int32(env, argv[2], &rank)); NAPI_OK(napi_get_value_int32(env, argv[3], &world));
+    int rc = gs_comm_init(ctx, id, rank, world);
+    if (rc != GS_OK) return throw_gs(env, ctx, rc);
+    return NULL;
+}
+
+static int fill_views(napi_env env, napi_value arr, gs_render_params views[2], uint32_t *nv)
+{
+    bool is_arr = false;
+    if (napi_is_array(env, arr, &is_arr) != napi_ok) return 0;
+    if (!is_arr) { *nv = 1; return fill_params(env, arr, &views[0]); }
+    if (napi_get_array_length(env, arr, nv) != napi_ok || *nv < 1 || *nv > 2) return 0;
+    for (uint32_t i = 0; i < *nv; i++) { napi_value e; if (napi_get_element(env, arr, i, &e) != napi_ok || !fill_params(env, e, &views[i])) return 0; }
+    return 1;
+}
+
+/* sortGathered(h, view, cutout | undefined, views): the sort of the frame renderGathered(views) draws (this rank's strip) */
+static napi_value fn_sort_gathered(napi_env env, napi_callback_info info)
+{
+    napi_value argv[4];
+    if (!get_args(env, info, 4, argv, NULL)) return NULL;
+    gs_ctx *ctx = get_ctx(env, argv[0]); if (!ctx) return NULL;
+    float view[4], cut[16]; const float *cutp = NULL;
+    if (!get_sort_args(env, argv[1], argv[2], view, cut, &cutp)) return NULL;
+    gs_render_params views[2]; uint32_t nv = 0;
+    if (!fill_views(env, argv[3], views, &nv)) { napi_throw_type_error(env, NULL, "sortGathered: bad view parameters"); return NULL; }
+    int rc = gs_sort_gathered(ctx, view, cutp, views, (int)nv);
+    if (rc != GS_OK) return throw_gs(env, ctx, rc);
+    return NULL;
+}
+
+/* renderGathered(h, views, root = 0, flags = 0): every rank; the image(s) are assembled on the root (readGathered) */
+static napi_value fn_render_gathered(napi_env env, napi_callback_info info)
+{
+    napi_value argv[4]; int32_t root = 0; uint32_t flags = 0;
+    if (!get_args(env, info, 4, argv, NULL)) return NULL;
+    gs_ctx *ctx = get_ctx(env, argv[0]); if (!ctx) return NULL;
+    gs_render_params views[2]; uint32_t nv = 0;
+    if (!fill_views(env, argv[1], views, &nv)) { napi_throw_type_error(env, NULL, "renderGathered: bad view parameters"); return NULL; }
+    if (!is_nullish(env, argv[2])) NAPI_OK(napi_get_value_int32(env, argv[2], &root));
+    if (!is_nullish(env, argv[3])) NAPI_OK(napi_get_value_uint32(env, argv[3], &flags));
+    int rc = gs_render_gathered(ctx, views, (int)nv, root, NULL, flags);
+    if (rc != GS_OK) return throw_gs(env, ctx, rc);
+    return NULL;
+}
+
+/* readGathered(h, view, frameUint8Array) -> frame (root only; after sync() for asynchronous frames) */
+static napi_value fn_read_gathered(napi_env env, napi_callback_info info)
+{
+    napi_value argv[3]; int32_t view = 0;
+    if (!get_args(env, info, 3, argv, NULL)) return NULL;
+    gs_ctx *ctx = get_ctx(env, argv[0]); if (!ctx) return NULL;
+    NAPI_OK(napi_get_value_int32(env, argv[1], &view));
+    void *out; size_t len;
+    if (!get_bytes(env, argv[2], &out, &len)) { napi_throw_type_error(env, NULL, "readGathered: frame buffer missing"); return NULL; }
+    int w = 0, h = 0;
+    int rc = gs_gathered_size(ctx, view, &w, &h);
+    if (rc != GS_OK) return throw_gs(env, ctx, rc);
+    if (len < (size_t)w * (size_t)h * 4) { napi_throw_range_error(env, NULL, "readGathered: frame buffer too small"); return NULL; }
+    rc = gs_read_gathered(ctx, view, (uint8_t *)out, 0);
+    if (rc != GS_OK) return throw_gs(env, ctx, rc);
+    return argv[2];
+}
+
+static napi_value fn_sync(napi_env env, napi_callback_info info)
+{
+    napi_value argv[1];
+    if (!get_args(env, info, 1, argv, NULL)) return NULL;
+    gs_ctx *ctx = get_ctx(env, argv[0]); if (!ctx) return NULL;
+    int rc = gs_sync(ctx);
+    if (rc != GS_OK) return throw_gs(env, ctx, rc);
+    return NULL;
+}
+
 /* setScene(h, depthFloat32Array | null, rgbaUint8Array | null, width, height): the opaque scene the splats are depth-tested
  * against (depthTest: true, index.js:179) and blended over */
 static napi_value fn_set_scene(napi_env env, napi_callback_info info)
@@ -594,7 +716,9 @@ static napi_value init(napi_env env, napi_value exports)
         { "pushMatrices", fn_push_matrices }, { "loadPly", fn_load_ply }, { "plyToSplat", fn_ply_to_splat }, { "plyToSplatGpu", fn_ply_to_splat_gpu },
         { "count", fn_count },
         { "sort", fn_sort }, { "sortAsync", fn_sort_async }, { "render", fn_render }, { "renderInto", fn_render_into },
-        { "renderAsync", fn_render_async }, { "allocFrame", fn_alloc_frame }, { "setScene", fn_set_scene }, { "stats", fn_stats }, { "setOption", fn_set_option },
+        { "renderAsync", fn_render_async }, { "allocFrame", fn_alloc_frame }, { "sync", fn_sync },
+        { "partition", fn_partition }, { "commUniqueId", fn_comm_unique_id }, { "commInit", fn_comm_init },
+        { "sortGathered", fn_sort_gathered }, { "renderGathered", fn_render_gathered }, { "readGathered", fn_read_gathered }, { "setScene", fn_set_scene }, { "stats", fn_stats }, { "setOption", fn_set_option },
         { "modelViewMatrix", fn_model_view }, { "projectionMatrix", fn_projection }, { "tickUniforms", fn_tick },
         { "scaledSize", fn_scaled_size },
     };

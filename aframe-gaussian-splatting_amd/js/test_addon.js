@@ -137,6 +137,18 @@ comp.loadData(camera, object, null, scenePath, 100003).then((n) => {
     for (let i = 0; i < frames; i++) { comp.tick(); comp.render(camera, { width: Number(W), height: Number(H) }); }
     const sec = Number(process.hrtime.bigint() - t0) / 1e9;
     console.log('js-visible frames/s (tick + render into host memory, ' + W + 'x' + H + ', ' + n + ' splats): ' + (frames / sec).toFixed(1));
+    // several GPUs, from JavaScript: the partition, and a frame through the gathered path on a communicator of one rank
+    const parts = native.partition([1032, 1032], 2);
+    ok(parts.length === 2 && parts[0].view === 0 && parts[0].owner === 0 && parts[1].view === 1 && parts[1].owner === 1 &&
+       parts[1].x0 === 0 && parts[1].x1 === 1032, 'XR partition: eye k -> rank k');
+    ok(native.partition([1920], 8).every((q, i) => q.x0 === 240 * i && q.x1 === 240 * (i + 1) && q.owner === i), 'eight 240-pixel strips');
+    native.commInit(comp.handle, native.commUniqueId(comp.handle), 0, 1);
+    const p = comp._renderParams(camera, { width: Number(W), height: Number(H) });
+    const u = comp._tickUniforms();
+    native.sortGathered(comp.handle, u.view, u.cutout, p);
+    native.renderGathered(comp.handle, p, 0, 0);
+    const gathered = native.readGathered(comp.handle, 0, native.allocFrame(Number(W), Number(H)));
+    ok(same(gathered, keepImg), 'gathered frame (world 1) == render()');
     comp.remove();
     let gone = false;
     try { comp.tick(); } catch (e) { gone = e.code === 'GS_DESTROYED'; }

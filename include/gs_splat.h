@@ -215,6 +215,8 @@ GS_API int gs_render_gathered(gs_ctx *ctx, const gs_render_params *views, int nv
 GS_API int gs_sort_gathered(gs_ctx *ctx, const float view[4], const float *cutout16, const gs_render_params *views, int nviews);
 /* root: copy view `view` of the last gathered frame (after gs_sync() for asynchronous frames) to host memory */
 GS_API int gs_read_gathered(gs_ctx *ctx, int view, uint8_t *rgba_out, size_t stride);
+/* ... and its size in pixels (so that a binding can check the caller's buffer before the copy) */
+GS_API int gs_gathered_size(gs_ctx *ctx, int view, int *width, int *height);
 #define GS_OPT_BLEND_SPLIT 9    /* 0 (default): one wavefront blends each tile, 4 pixels per lane.  L > 0: tiles whose list has at least
                                    L entries (try 512) are blended by FOUR wavefronts, one pixel per lane -- for frames in which few
                                    tiles carry long lists (a cut-out scene: the kernel otherwise lasts as long as ONE wavefront's
