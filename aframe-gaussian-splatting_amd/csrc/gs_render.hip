@@ -728,7 +728,10 @@ __global__ __launch_bounds__(64) void k_blend(const uint2 *__restrict__ tile_ran
 // projected records are read four times: affordable exactly when few tiles are active.
 // (Measured and dropped: splitting the LIST over 8 waves -- segments blended from fresh states and composed front to back.
 // A segment that starts at T = 1 never terminates early, so the tile's work grows from the ~300-1100 entries it really needs
-// to min(L, 2048): 188 -> 284 us on the 6 M cut-out frame.)
+// to min(L, 2048): 188 -> 284 us on the 6 M cut-out frame.  The same speculation on top of THIS kernel -- segment-0 wave from
+// the band's true state, one to three more waves per band walking the following 256-entry segments from fresh states,
+// composed while the band is unsaturated -- changed nothing alone on the GPU (84 -> 80 us) and lost with frames overlapped
+// (8613 -> 8174 frames/s with 2 segments, 6658 with 4): the kernel is not bound by one tile's chain any more.)
 #ifndef GS_PX_BATCH
 #define GS_PX_BATCH 128u           // list entries k_blend_px stages per batch (a multiple of 64: two dependent global loads per batch are the latency to hide)
 #endif
