@@ -99,3 +99,14 @@ def test_synth_inria_ply_roundtrip_via_loader():
     assert np.array_equal(b[:, 24:27], rr[:, 24:27])                     # SH-DC -> RGB bytes exact
     assert np.max(np.abs(b[:, 27].astype(int) - rr[:, 27].astype(int))) <= 1
     assert np.allclose(b[:, 12:24].copy().view("<f4"), rr[:, 12:24].copy().view("<f4"), rtol=1e-6)
+
+
+def test_partition_is_host_side_and_validates():
+    """gs_partition needs no GPU: strips / XR eyes, and bad arguments are refused."""
+    assert capi.partition([1920], 8)[3] == (0, 720, 960, 3)
+    assert capi.partition([1032, 1032], 2) == [(0, 0, 1032, 0), (1, 0, 1032, 1)]
+    for bad in ([0], [100, 100, 100], []):
+        with pytest.raises(capi.GsError):
+            capi.partition(bad, 2)
+    with pytest.raises(capi.GsError):
+        capi.partition([100], 0)

@@ -1050,3 +1050,28 @@ def test_sort_for_a_strip_is_a_subsequence_and_draws_the_same_pixels(ctx, scene_
         c.push_splat(rows)
         c.set_option(capi.OPT_NEAR_PERMILLE, 1000)
         check(c, np.ascontiguousarray(mats[:, 12:16]), synth.index_html_camera(w, h, 140.0, capi=capi), [(0, 80), (304, 384)], w, h, 1.0)
+
+
+def test_new_entry_points_reject_bad_arguments(ctx, scene_small):
+    """Error behaviour of the round-2 entry points: negative status + a message, nothing rendered, the context stays usable."""
+    cam = synth.index_html_camera(320, 180, 0.0, capi=capi)
+    ctx.clear(); ctx.push_splat(scene_small["rows"])
+    ctx.sort(cam["view"])
+    good = ctx.render(_params(cam))
+    for bad in (lambda: ctx.render_gathered([_params(cam)] * 3),                       # three views
+                lambda: ctx.render_gathered(_params(cam), root=1),                     # root outside the (one-rank) world
+                lambda: ctx.render_gathered(_params(cam), flags=capi.RENDER_COUNT_FRAGS),
+                lambda: ctx.sort_for(cam["view"], None, _params(cam, x0=100, x1=50)),  # empty strip
+                lambda: ctx.sort_for(cam["view"], None, _params(cam, x0=0, x1=400)),   # beyond the frame
+                lambda: ctx.read_gathered(1, 320, 180),                                # no such view
+                lambda: ctx.set_option(capi.OPT_BLEND_SPLIT, -1),
+                lambda: ctx.comm_init(b"\0" * 128, 3, 2)):                              # rank outside the world
+        with pytest.raises(capi.GsError) as e:
+            bad()
+        assert e.value.code in (capi.E_BADARG, capi.E_STATE) and e.value.message
+    with pytest.raises(capi.GsError):
+        capi.partition([0], 2)
+    with pytest.raises(capi.GsError):
+        capi.partition([100, 100, 100], 2)
+    ctx.sort(cam["view"])
+    assert np.array_equal(ctx.render(_params(cam)), good)
