@@ -243,7 +243,7 @@ struct GsLaneCmd {
     int type;                                                  // 0 = sort, 1 = asynchronous render, 2 = call (gs_comm.hip: the frame's gather)
     float view[4], cutout[16]; bool has_cutout;
     bool has_strip; GsSortStrip strip;
-    GsFrameUniforms u; void *device_rgba;
+    GsFrameUniforms u; void *device_rgba; uint8_t *host_rgba; size_t stride;
     std::function<int(gs_ctx *)> call;
 };
 
@@ -257,7 +257,7 @@ struct GsLaneWorker {
     char err[GS_ERRLEN] = "";                                  // ... and its message: the worker never writes the lane's err itself
 };
 
-static int render_async_on_lane(gs_ctx *ctx, const GsFrameUniforms &u, void *device_rgba);
+static int render_async_on_lane(gs_ctx *ctx, const GsFrameUniforms &u, void *device_rgba, uint8_t *host_rgba, size_t stride);
 
 static void lane_worker_main(gs_ctx *L)
 {
@@ -276,7 +276,7 @@ static void lane_worker_main(gs_ctx *L)
         // (a call is run even after a failure: the gather of a frame must be issued on every rank, or the others wait for it)
         if (c.type == 2) { const int r2 = c.call(L); if (w->rc == GS_OK) rc = r2; }
         else if (w->rc == GS_OK) rc = c.type == 0 ? gs_run_sort(L, c.view, c.has_cutout ? c.cutout : nullptr, c.has_strip ? &c.strip : nullptr)
-                                                  : render_async_on_lane(L, c.u, c.device_rgba);
+                                                  : render_async_on_lane(L, c.u, c.device_rgba, c.host_rgba, c.stride);
         lk.lock();
         if (rc != GS_OK && w->rc == GS_OK) { w->rc = rc; memcpy(w->err, scratch, sizeof w->err); }
         w->busy = false;
@@ -686,7 +686,7 @@ static int sort_common(gs_ctx *ctx, const float view[4], const float *cutout16, 
         if (cutout16) memcpy(c.cutout, cutout16, sizeof c.cutout);
         c.has_strip = strip != nullptr;
         if (strip) c.strip = *strip;
-        c.device_rgba = nullptr;
+        c.device_rgba = nullptr; c.host_rgba = nullptr; c.stride = 0;
         L->have_sort = true;                                    // (set again by the worker; the render command follows it)
         if (lane_push(L, c) != GS_OK) FAIL(GS_E_OOM, "out of host memory");
         return GS_OK;
@@ -755,10 +755,17 @@ static int ensure_frame_buffers(gs_ctx *ctx, const GsFrameUniforms &u, bool need
 // are cumulative, so one read-back per gs_sync() covers every frame since the last one -- a per-frame copy would be one
 // more queue entry per frame).  An overflowing frame shows the background only and is reported (GS_E_RETRY) there.
 // Runs on the lane's worker thread when GS_OPT_ENQUEUE_THREADS is on.
-static int render_async_on_lane(gs_ctx *ctx, const GsFrameUniforms &u, void *device_rgba)
+static int render_async_on_lane(gs_ctx *ctx, const GsFrameUniforms &u, void *device_rgba, uint8_t *host_rgba, size_t stride)
 {
     TRY(ensure_frame_buffers(ctx, u, device_rgba == nullptr));
     TRY(gs_run_render(ctx, u, (uint8_t *)device_rgba));
+    if (host_rgba) {
+        // the frame follows its kernels on the lane's stream (page-locked destination: a real asynchronous copy that
+        // overlaps the next frames' kernels; pageable memory works too, through the runtime's staging)
+        const size_t sw = (size_t)(u.x1 - u.x0);
+        const uint8_t *src = device_rgba ? (const uint8_t *)device_rgba : ctx->fb;
+        GS_HIP(hipMemcpy2DAsync(host_rgba, stride ? stride : sw * 4, src, sw * 4, sw * 4, (size_t)u.H, hipMemcpyDeviceToHost, ctx->stream));
+    }
     return prof_advance(ctx);
 }
 
@@ -803,7 +810,7 @@ int gs_lane_call(gs_ctx *ctx, bool async, std::function<int(gs_ctx *)> call)
     gs_ctx *L = ctx->lanes[ctx->cur];
     if (async && ctx->enqueue_threads && ctx->pipe_depth > 1 && !ctx->user_stream) {
         GsLaneCmd c;
-        c.type = 2; c.has_cutout = false; c.has_strip = false; c.device_rgba = nullptr; c.call = std::move(call);
+        c.type = 2; c.has_cutout = false; c.has_strip = false; c.device_rgba = nullptr; c.host_rgba = nullptr; c.stride = 0; c.call = std::move(call);
         L->async_pending = true; ctx->cur_async = true;
         if (lane_push(L, c) != GS_OK) FAIL(GS_E_OOM, "out of host memory");
         return GS_OK;
@@ -824,17 +831,18 @@ int gs_render_uniforms(gs_ctx *ctx, const GsFrameUniforms &u, void *device_rgba,
     if (!ctx->renderable && ctx->n) FAIL(GS_E_STATE, "context was fed worker matrices only (gs_push_matrices): it can sort but not render");
     GS_HIP(hipSetDevice(ctx->device));
     gs_ctx *L = ctx->lanes[ctx->cur];                           // the frame's lane: where its gs_sort ran
-    const bool async = (u.flags & GS_RENDER_ASYNC) && !host_rgba && !(u.flags & GS_RENDER_COUNT_FRAGS);
+    const bool async = (u.flags & GS_RENDER_ASYNC) && !(u.flags & GS_RENDER_COUNT_FRAGS);
     if (async) {
+        if (host_rgba && stride && stride < (size_t)(u.x1 - u.x0) * 4) FAIL(GS_E_BADARG, "stride %zu smaller than a row (%zu bytes)", stride, (size_t)(u.x1 - u.x0) * 4);
         L->async_pending = true; ctx->cur_async = true;
         if (ctx->enqueue_threads && ctx->pipe_depth > 1 && !ctx->user_stream) {
             GsLaneCmd c;
-            c.type = 1; c.has_cutout = false; c.has_strip = false; c.u = u; c.device_rgba = device_rgba;
+            c.type = 1; c.has_cutout = false; c.has_strip = false; c.u = u; c.device_rgba = device_rgba; c.host_rgba = host_rgba; c.stride = stride;
             if (lane_push(L, c) != GS_OK) FAIL(GS_E_OOM, "out of host memory");
             return GS_OK;
         }
         TRY(lane_rc(ctx, L, lane_drain(L)));
-        return lane_rc(ctx, L, render_async_on_lane(L, u, device_rgba));
+        return lane_rc(ctx, L, render_async_on_lane(L, u, device_rgba, host_rgba, stride));
     }
     TRY(lane_rc(ctx, L, lane_drain(L)));                         // whatever its worker still had to enqueue comes first
     return lane_rc(ctx, L, render_sync_on_lane(L, u, device_rgba, host_rgba, stride));

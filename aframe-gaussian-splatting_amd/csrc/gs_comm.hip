@@ -26,6 +26,8 @@ typedef struct { char internal[128]; } ncclUniqueId;
 typedef int ncclResult_t;                                          // 0 = ncclSuccess
 enum { gsNcclUint8 = 1 };                                          // ncclUint8 / ncclChar share the element size
 
+#define GS_ASSEMBLE_MAX 16                                          // pieces per k_assemble launch
+
 struct GsComm {
     void *lib = nullptr;
     ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
@@ -68,9 +70,21 @@ static int load_rccl(gs_ctx *ctx, GsComm *c)
 
 namespace {
 
-// staging (pieces, tight rows of w pixels each) -> row-major image of W pixels per row; one thread per 16 bytes
-__global__ __launch_bounds__(256) void k_assemble(const uint8_t *__restrict__ piece, uint8_t *__restrict__ frame, int H, int w, int W, int x0)
+// staging (pieces, tight rows of w pixels each) -> row-major image(s) of W pixels per row; one thread per 16 bytes, all the
+// pieces of a frame in ONE launch (blockIdx.y = piece): at 8 ranks the root would otherwise queue 8 launches per frame
+struct AssemblePieces {
+    int n;
+    int x0[GS_ASSEMBLE_MAX], w[GS_ASSEMBLE_MAX], H[GS_ASSEMBLE_MAX], W[GS_ASSEMBLE_MAX];
+    uint32_t off256[GS_ASSEMBLE_MAX];                               // staging offset / 256
+    uint8_t *frame[GS_ASSEMBLE_MAX];
+};
+
+__global__ __launch_bounds__(256) void k_assemble(const uint8_t *__restrict__ stage, AssemblePieces a)
 {
+    const int pi = blockIdx.y;
+    const int H = a.H[pi], w = a.w[pi], W = a.W[pi], x0 = a.x0[pi];
+    const uint8_t *piece = stage + (size_t)a.off256[pi] * 256u;
+    uint8_t *frame = a.frame[pi];
     const uint32_t per_row = (uint32_t)(w + 3) / 4u;                // 4 pixels = 16 bytes per thread
     const uint32_t total = per_row * (uint32_t)H;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
@@ -164,13 +178,20 @@ int issue_gather(gs_ctx *L, const GatherJob &j)
         c->cv.notify_all();
     }
     if (rc != GS_OK || !is_root) return rc;
-    for (size_t i = 0; i < j.pieces.size(); i++) {
-        const gs_piece &p = j.pieces[i];
-        uint8_t *frame = j.out[p.view] ? j.out[p.view] : L->gframe[p.view];
-        const int w = p.x1 - p.x0;
-        const uint32_t work = (uint32_t)((w + 3) / 4) * (uint32_t)j.H[p.view];
-        uint32_t g = gs_div_up(work, 256); if (g > 2048) g = 2048;
-        hipLaunchKernelGGL(k_assemble, dim3(g), dim3(256), 0, L->stream, L->gstage + j.off[i], frame, j.H[p.view], w, j.W[p.view], p.x0);
+    for (size_t base = 0; base < j.pieces.size(); base += GS_ASSEMBLE_MAX) {
+        AssemblePieces a;
+        uint32_t most = 1;
+        a.n = (int)(j.pieces.size() - base < GS_ASSEMBLE_MAX ? j.pieces.size() - base : GS_ASSEMBLE_MAX);
+        for (int k = 0; k < a.n; k++) {
+            const gs_piece &p = j.pieces[base + k];
+            a.x0[k] = p.x0; a.w[k] = p.x1 - p.x0; a.H[k] = j.H[p.view]; a.W[k] = j.W[p.view];
+            a.off256[k] = (uint32_t)(j.off[base + k] / 256);
+            a.frame[k] = j.out[p.view] ? j.out[p.view] : L->gframe[p.view];
+            const uint32_t work = (uint32_t)((a.w[k] + 3) / 4) * (uint32_t)a.H[k];
+            if (work > most) most = work;
+        }
+        uint32_t g = gs_div_up(most, 256); if (g > 1024) g = 1024;
+        hipLaunchKernelGGL(k_assemble, dim3(g, a.n), dim3(256), 0, L->stream, L->gstage, a);
     }
     GS_HIP(hipGetLastError());
     L->gviews = j.nviews;

@@ -167,12 +167,28 @@ class GaussianSplatting {
     return p;
   }
 
-  _frame(p) {
-    const w = (p.x1 !== undefined ? p.x1 : p.width) - (p.x0 || 0), key = w + 'x' + p.height;
+  _frame(p, slot) {
+    const w = (p.x1 !== undefined ? p.x1 : p.width) - (p.x0 || 0), key = w + 'x' + p.height + (slot ? '#' + slot : '');
     if (!this._frames) this._frames = new Map();
     if (!this._frames.has(key)) this._frames.set(key, native.allocFrame(w, p.height));
     return this._frames.get(key);
   }
+
+  // Throughput mode -- what WebGL does behind the reference's back: the draw call returns at once and frames queue up on the
+  // GPU (index.js:184-207).  frameQueued = this frame's sort (the order stays on the GPU) + draw, enqueued on one of the
+  // library's pipeline lanes; the pixels follow their kernels into one of `QUEUE_DEPTH` page-locked frames, which is what is
+  // returned -- valid after sync().  sync() throws code GS-9 (GS_E_RETRY) if the frames since the previous sync() have to be
+  // queued again (a buffer grew).
+  frameQueued(camera, viewport, options) {
+    const u = this._tickUniforms(camera);
+    native.sort(this.handle, u.view, u.cutout, false);
+    const p = this._renderParams(camera, viewport, options);
+    p.flags = (p.flags || 0) | 8;                      // GS_RENDER_ASYNC
+    this._slot = ((this._slot || 0) % GaussianSplatting.QUEUE_DEPTH) + 1;
+    return native.renderInto(this.handle, p, this._frame(p, this._slot));
+  }
+
+  sync() { native.sync(this.handle); }
 
   // The opaque scene three.js draws before the transparent splat mesh: window-space depth (depthTest: true,
   // depthWrite: false, index.js:179-180) and colour.  Float32Array / Uint8Array of width*height(*4), row 0 = top.
@@ -202,6 +218,8 @@ class GaussianSplatting {
   // the reference leaks its worker and textures; this frees the context (HBM, streams, threads) at once
   remove() { native.destroy(this.handle); this._frames = null; }
 }
+
+GaussianSplatting.QUEUE_DEPTH = 3;                // frames in flight in throughput mode = GS_OPT_PIPELINE_DEPTH's default
 
 // Optional: expose the same component name to an A-Frame-like registry.
 function register(AFRAME) {

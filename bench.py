@@ -478,6 +478,43 @@ def secondary_measurements(ctx, capi, synth, rows, cams, views, n_splats, args):
                             "note": "synchronous gs_render into page-locked host memory (%.1f MB D2H per frame over PCIe), one frame at a time"
                                     % (W * H * 4 / 1e6)}
     ctx.set_option(capi.OPT_PIPELINE_DEPTH, int(os.environ.get("GS_BENCH_DEPTH", "0")) or 3)
+    # the same delivery with frames in flight: gs_render(GS_RENDER_ASYNC) copies each frame into its own page-locked buffer
+    # behind its kernels, on the frame's stream
+    NB = 6
+    bufs = [capi.host_frame(H, W) for _ in range(NB)]
+
+    def loop_host(nn):
+        try:
+            ctx.sync()
+        except capi.GsError:
+            pass
+        t0 = time.perf_counter()
+        for i in range(nn):
+            k = i % ORBIT_FRAMES
+            ctx.sort(cams[k]["view"], cams[k]["cutout"], want_indices=False)
+            views[k][0].flags = capi.RENDER_ASYNC
+            ctx.render_into(views[k][0], bufs[i % NB][0])
+            if i % NB == NB - 1:
+                try:
+                    ctx.sync()                               # the buffers are about to be reused
+                except capi.GsError as e:
+                    if e.code != capi.E_RETRY:
+                        raise
+        try:
+            ctx.sync()
+        except capi.GsError as e:
+            if e.code != capi.E_RETRY:
+                raise
+        return time.perf_counter() - t0
+
+    loop_host(12)
+    m = min(n, 120)
+    t = loop_host(m)
+    for _, o in bufs:
+        o.free()
+    out["host_readback"].update({"fps_host_readback_pipelined": round(m / t, 1),
+                                 "note_pipelined": "gs_render with GS_RENDER_ASYNC: frames queued on the three pipeline lanes, each copied into "
+                                                   "its own page-locked buffer on its lane's stream (six buffers, gs_sync every six frames)"})
     # the blend without early termination (every reference-equivalent fragment evaluated), pipelined like the headline
     loop(6, capi.RENDER_ASYNC | capi.RENDER_NO_EARLY_OUT)
     m = min(n, 60)

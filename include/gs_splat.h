@@ -106,9 +106,12 @@ GS_API int gs_sort(gs_ctx *ctx, const float view[4], const float *cutout16, uint
 #define GS_RENDER_NO_EARLY_OUT 4u/* blend every fragment (parity debugging)                                   */
 #define GS_RENDER_COUNT_EVALUATED 16u /* with GS_RENDER_COUNT_FRAGS: leave early termination ON and count the fragments
                                     the blend really evaluates (one binning round; what the reference-equivalent count shrinks to) */
-#define GS_RENDER_ASYNC 8u       /* gs_render_device only: enqueue the frame and return; completion, status and
-                                    statistics are collected by gs_sync().  The reference renders every frame
-                                    without waiting for the GPU either (index.js:184-207).                        */
+#define GS_RENDER_ASYNC 8u       /* enqueue the frame and return; completion, status and statistics are collected by
+                                    gs_sync().  The reference renders every frame without waiting for the GPU either
+                                    (index.js:184-207).  gs_render_device: the frame stays in HBM.  gs_render: the frame
+                                    is copied to rgba_out behind its kernels, on the frame's own stream -- rgba_out must
+                                    stay valid and unread until gs_sync(), one buffer per frame in flight, and should be
+                                    page-locked (gs_host_alloc) for the copy to overlap the following frames.           */
 
 typedef struct gs_render_params {
     float model_view[16]; /* gsModelViewMatrix, column-major (getModelViewMatrix, index.js:467-487)      */

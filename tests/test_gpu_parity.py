@@ -1075,3 +1075,49 @@ def test_new_entry_points_reject_bad_arguments(ctx, scene_small):
         capi.partition([100, 100, 100], 2)
     ctx.sort(cam["view"])
     assert np.array_equal(ctx.render(_params(cam)), good)
+
+
+@pytest.mark.gpu
+def test_asynchronous_host_frames_equal_synchronous_ones(scene_small):
+    """gs_render with GS_RENDER_ASYNC: the frame is copied to the caller's host memory behind its kernels on the frame's own
+    stream and is complete after gs_sync() -- page-locked buffers (gs_host_alloc), a strided one, and pageable memory."""
+    rows = np.asarray(scene_small["rows"]).reshape(-1, 32)
+    w, h = 480, 270
+    cams = [synth.index_html_camera(w, h, 40.0 * i, capi=capi) for i in range(6)]
+    with capi.Context(0) as c:
+        c.push_splat(rows)
+        want = []
+        for cam in cams:
+            c.sort(cam["view"]); want.append(c.render(_params(cam)))
+        pinned = [capi.host_frame(h, w) for _ in cams]
+        pageable = [np.full((h, w, 4), 7, np.uint8) for _ in cams]
+        wide = np.zeros((h, w + 16, 4), np.uint8)                          # rows of (w + 16) pixels: stride > a tight row
+        for dst in ([p[0] for p in pinned], pageable):
+            for attempt in range(4):
+                for cam, buf in zip(cams, dst):
+                    buf[...] = 7
+                    c.sort(cam["view"], want_indices=False)
+                    c.render_into(_params(cam, flags=capi.RENDER_ASYNC), buf)
+                try:
+                    c.sync()
+                    break
+                except capi.GsError as e:
+                    assert e.code == capi.E_RETRY and attempt < 3
+            for a, b in zip(dst, want):
+                assert np.array_equal(a, b)
+        c.sort(cams[2]["view"], want_indices=False)
+        c.render_into(_params(cams[2], flags=capi.RENDER_ASYNC), wide[:, :w])
+        c.sync()
+        assert np.array_equal(wide[:, :w], want[2]) and not wide[:, w:].any()
+        # a strip, and a stride smaller than a row is refused before anything is queued
+        c.sort(cams[1]["view"], want_indices=False)
+        strip = np.zeros((h, 64, 4), np.uint8)
+        c.render_into(_params(cams[1], x0=32, x1=96, flags=capi.RENDER_ASYNC), strip)
+        c.sync()
+        assert np.array_equal(strip, want[1][:, 32:96])
+        import ctypes
+        prm = _params(cams[1], flags=capi.RENDER_ASYNC)
+        assert c._L.gs_render(c._h, ctypes.byref(prm), strip.ctypes.data_as(ctypes.c_void_p), 16) == capi.E_BADARG
+        c.sync()
+        for _, o in pinned:
+            o.free()
