@@ -64,9 +64,10 @@ int gs_ensure_pair_capacity(gs_ctx *ctx, size_t pairs)
     while (cap < pairs) cap += cap / 2 + 1;
     cap = (cap + GS_CHUNK_L - 1) / GS_CHUNK_L * GS_CHUNK_L;
     if (cap > 0xFFFF0000ull) FAIL(GS_E_OOM, "pair list of %zu entries exceeds the 32-bit index space", pairs);
-    dev_free(ctx->pair_a); dev_free(ctx->pair_b);
+    dev_free(ctx->pair_a); dev_free(ctx->pair_b); dev_free(ctx->emit_extra);
     ctx->pair_cap = 0;
     TRY(dev_alloc(ctx, &ctx->pair_a, cap)); TRY(dev_alloc(ctx, &ctx->pair_b, cap));
+    TRY(dev_alloc(ctx, &ctx->emit_extra, cap / GS_EMIT_PAIRS + 2));
     ctx->pair_cap = cap;
     return ensure_scan_scratch(ctx);
 }
@@ -345,7 +346,6 @@ static hipError_t init_frame_resources(gs_ctx *c)
     IFR(hipMalloc((void **)&c->part_cnt, GS_MAX_PART * sizeof(uint32_t)));
     IFR(hipMalloc((void **)&c->part_valid, GS_MAX_PART * sizeof(uint32_t)));
     IFR(hipMalloc((void **)&c->part_vis, GS_MAX_PART * sizeof(uint32_t)));
-    IFR(hipMalloc((void **)&c->huge_list, GS_HUGE_CAP * sizeof(uint32_t)));
     IFR(hipHostMalloc((void **)&c->ctl_host, sizeof(GsControl), hipHostMallocDefault));
     memset(c->ctl_host, 0, sizeof(GsControl));
     IFR(hipEventCreateWithFlags(&c->ev_frame, hipEventDisableTiming | hipEventReleaseToDevice));
@@ -361,10 +361,10 @@ static void free_frame_resources(gs_ctx *c)
     dev_free(c->depth); dev_free(c->key_a); dev_free(c->kv_b); dev_free(c->val_a);
     dev_free(c->hist); dev_free(c->radix_aux); dev_free(c->spine);
     dev_free(c->proj); dev_free(c->rect); dev_free(c->tile_count); dev_free(c->zwin);
-    dev_free(c->pair_a); dev_free(c->pair_b);
+    dev_free(c->pair_a); dev_free(c->pair_b); dev_free(c->emit_extra);
     gs_comm_free_lane(c);
     dev_free(c->tile_range); dev_free(c->fb); dev_free(c->ctl); dev_free(c->state); dev_free(c->unsat_mask);
-    dev_free(c->part_min); dev_free(c->part_max); dev_free(c->part_cnt); dev_free(c->part_valid); dev_free(c->part_vis); dev_free(c->huge_list);
+    dev_free(c->part_min); dev_free(c->part_max); dev_free(c->part_cnt); dev_free(c->part_valid); dev_free(c->part_vis);
     if (c->ctl_host) { (void)hipHostFree(c->ctl_host); c->ctl_host = nullptr; }
     if (c->ring) { for (int i = 0; i < GS_PROF_RING * GS_PROF_EVENTS; i++) if (c->ring[i]) (void)hipEventDestroy(c->ring[i]); free(c->ring); c->ring = nullptr; }
     free(c->ring_flags); c->ring_flags = nullptr;

@@ -21,10 +21,12 @@
 #define GS_MAX_PART 8192           // upper bound on the grid of any kernel that writes per-workgroup partials
 #define GS_CULLED_KEY 65536u       // depth-sort key of culled / dropped splats (sorts behind every bucket)
 #define GS_MAX_LANES 4             // frames in flight (GS_OPT_PIPELINE_DEPTH)
-#define GS_HUGE_TILES 1024u        // a splat touching at least this many tiles is expanded by slices spread over the whole grid
-#define GS_HUGE_ROWS 1024u         // ... if it spans at most this many tile rows
-#define GS_HUGE_CAP 8192u          // capacity of the per-round list of such splats (beyond it nobody is deferred)
-#define GS_HUGE_SLICES 8u          // row slices per huge splat
+#ifndef GS_EMIT_PAIRS
+#define GS_EMIT_PAIRS 1024u        // pair slots written per k_emit work item (a slice of one chunk's pairs)
+#endif
+#ifndef GS_EMIT_RUNS
+#define GS_EMIT_RUNS 512u          // tile-row runs expanded per pass inside an item
+#endif
 
 // Device-resident control block: every data-dependent count lives here so that no stage needs a
 // host round trip; kernels read their problem size from it (grid-stride over chunks).
@@ -47,7 +49,7 @@ struct GsControl {
     uint32_t n_pairs_frame;        // I summed over the rounds of the frame
     uint32_t want_frame;           // pair demand of the frame so far (counts rounds that overflowed, too)
     uint32_t unsat_events;         // frames whose round 0 left tiles unsaturated (monotonic)
-    uint32_t n_huge, n_huge_round; // huge splats listed by k_project so far / of the round being emitted (moved by k_pairs_check)
+    uint32_t n_emit_extra, pad_emit; // k_emit work items beyond one per chunk (k_pairs_check -> k_emit of the same round)
     uint32_t round1_missed;        // sticky: round 1 was skipped optimistically but a tile needed it (host clears)
     uint32_t acc_frames;           // frames rendered since profiling was switched on
     unsigned long long acc_sorted, acc_visible, acc_pairs;   // sums of V, Vp, I over those frames
@@ -126,7 +128,7 @@ struct gs_ctx {
     gsm::Projected *proj;          // V records, sorted order
     uint2 *rect;                   // V x (tx0 | ty0<<16, tx1 | ty1<<16), strip-local tile coords
     uint32_t *tile_count;          // V
-    uint32_t *huge_list;           // GS_HUGE_CAP sorted positions of splats touching >= GS_HUGE_TILES tiles (per round)
+    uint2 *emit_extra;             // pair_cap / GS_EMIT_PAIRS + 2 (chunk, slice) items of the chunks with more than GS_EMIT_PAIRS pairs
     float *zwin;                   // V window depth of each sorted splat (written only while a scene depth buffer is set)
     float *scene_depth; uint32_t *scene_rgba; int scene_w, scene_h;   // gs_set_scene
     uint2 *pair_a, *pair_b; size_t pair_cap;   // (tile id, sorted position) records, ping-pong

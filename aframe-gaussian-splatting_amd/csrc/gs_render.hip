@@ -3,8 +3,8 @@
 //
 //   k_project      one thread per SORTED splat (not 6 like the instanced quad): gather one 32 B record,
 //                  Sigma' = (J W) Sigma (J W)^T, eigen axes, EXACT per-tile-row coverage count   [HBM gather]
-//   k_pairs_check  spine scan of tiles-touched -> chunk offsets, total I
-//   k_emit         (tile id, sorted position) records in splat order
+//   k_pairs_check  spine scan of tiles-touched -> chunk offsets, total I, the extra work items of heavy chunks
+//   k_emit         (tile id, sorted position) records in splat order, work handed out by pair slots
 //   radix x2       stable sort of the records by tile id only: the input is already in depth order, so each
 //                  tile's list inherits the reference's draw order with no depth key            [gs_prims]
 //   k_tile_ranges  [start,end) of every tile in the sorted list
@@ -74,12 +74,8 @@ __global__ __launch_bounds__(GS_BLOCK) void k_project(const uint32_t *__restrict
                                                       GsFrameUniforms u, gsm::Projected *__restrict__ proj, uint2 *__restrict__ rect,
                                                       uint32_t *__restrict__ tile_count, uint32_t *__restrict__ spine,
                                                       uint32_t *__restrict__ part_vis, const uint32_t *__restrict__ mask,
-                                                      float *__restrict__ zwin, GsControl *ctl, uint32_t *__restrict__ huge_list)
+                                                      float *__restrict__ zwin, GsControl *ctl)
 {
-    // a splat that touches a huge number of tiles would make ONE wavefront of k_emit write them all (and the nearest,
-    // largest splats sit next to each other in the sorted order): list it, k_emit spreads it over the whole grid
-#define GS_NOTE_HUGE(jj, cnt, rows) do { if ((cnt) >= GS_HUGE_TILES && (rows) <= GS_HUGE_ROWS) {                          \
-        const uint32_t _q = atomicAdd(&ctl->n_huge, 1u); if (_q < GS_HUGE_CAP) huge_list[_q] = (jj); } } while (0)
     __shared__ float s_rec[GS_BLOCK][6];
     __shared__ uint32_t s_rows[GS_BLOCK], s_j[GS_BLOCK];
     __shared__ uint32_t s_nbig, s_nmid, s_vis, s_sum;
@@ -136,7 +132,7 @@ __global__ __launch_bounds__(GS_BLOCK) void k_project(const uint32_t *__restrict
                     }
                 }
             }
-            if (!queued) { tile_count[j] = count; GS_NOTE_HUGE(j, count, 2u); }   // (at most 2 tile rows here: huge only on very wide strips)
+            if (!queued) tile_count[j] = count;
         }
         uint32_t vis = count ? 1u : 0u, sum = count;
         __syncthreads();
@@ -159,7 +155,6 @@ __global__ __launch_bounds__(GS_BLOCK) void k_project(const uint32_t *__restrict
             for (int m = 8; m >= 1; m >>= 1) n += __shfl_xor(n, m, 16);
             if ((lane & 15) == 0 && mi < nmid) {
                 tile_count[s_j[mi]] = n; sum += n; if (n) vis++;
-                GS_NOTE_HUGE(s_j[mi], n, (s_rows[mi] >> 16) - (s_rows[mi] & 0xFFFF) + 1u);
             }
         }
         const uint32_t nbig = s_nbig;
@@ -179,7 +174,7 @@ __global__ __launch_bounds__(GS_BLOCK) void k_project(const uint32_t *__restrict
             }
 #pragma unroll
             for (int m = 32; m >= 1; m >>= 1) rsum += __shfl_xor(rsum, m, 64);
-            if (lane == 0) { tile_count[s_j[bi]] = rsum; sum += rsum; if (rsum) vis++; GS_NOTE_HUGE(s_j[bi], rsum, ty1 - ty0 + 1u); }
+            if (lane == 0) { tile_count[s_j[bi]] = rsum; sum += rsum; if (rsum) vis++; }
         }
 #pragma unroll
         for (int m = 32; m >= 1; m >>= 1) { vis += __shfl_xor(vis, m, 64); sum += __shfl_xor(sum, m, 64); }
@@ -189,17 +184,21 @@ __global__ __launch_bounds__(GS_BLOCK) void k_project(const uint32_t *__restrict
     }
     __syncthreads();
     if (threadIdx.x == 0) part_vis[blockIdx.x] = s_vis;
-#undef GS_NOTE_HUGE
 }
 
 // One workgroup: exclusive scan of the per-chunk totals (spine) -> chunk base offsets, I = grand total (refused and
-// flagged if it does not fit the pair buffers), Vp from the partials, frame accumulators.
+// flagged if it does not fit the pair buffers), Vp from the partials, frame accumulators -- and k_emit's extra work items:
+// a chunk whose splats touch more than GS_EMIT_PAIRS tiles in total (the nearest, largest splats sit next to each other
+// in the sorted order) is written by several workgroups, GS_EMIT_PAIRS pair slots each; (chunk, slice) of every slice
+// after a chunk's first goes to `extra`.
+#define GS_SPINE_CACHED 8u
 template <int ROUND>
 __global__ __launch_bounds__(GS_BLOCK) void k_pairs_check(GsControl *ctl, uint32_t pair_cap, uint32_t *__restrict__ spine,
                                                           const uint32_t *__restrict__ part_vis, uint32_t nparts, uint32_t near_count,
-                                                          int last_round, uint32_t *__restrict__ mask, uint32_t mask_total_words)
+                                                          int last_round, uint32_t *__restrict__ mask, uint32_t mask_total_words,
+                                                          uint2 *__restrict__ extra)
 {
-    __shared__ uint32_t s_vis, s_wave[4];
+    __shared__ uint32_t s_vis, s_wave[4], s_wave_e[4];
     __shared__ unsigned long long s_total64[4];
     if (threadIdx.x == 0) s_vis = 0;
     __syncthreads();
@@ -219,26 +218,45 @@ __global__ __launch_bounds__(GS_BLOCK) void k_pairs_check(GsControl *ctl, uint32
     const uint32_t lo = min(threadIdx.x * per, nsp), hi = min(lo + per, nsp);
     uint32_t s = 0;
     unsigned long long s64 = 0;                                    // the demand itself in 64 bits: a sum past 2^32 must not wrap under pair_cap
-    for (uint32_t i = lo; i < hi; i++) { s += spine[i]; s64 += spine[i]; }
+    // (a thread's slice is read once, all loads in flight together, and kept in registers when it is short: the second
+    // pass would otherwise pay one memory round trip per element, serialised by its stores)
+    uint32_t tv[GS_SPINE_CACHED];
+    const bool cached = per <= GS_SPINE_CACHED;
+    uint32_t ne = 0;                                                // extra slices of this thread's chunks
+#define GS_EXTRA_OF(t) ((t) > GS_EMIT_PAIRS ? ((t) - 1u) / GS_EMIT_PAIRS : 0u)
+    if (cached) {
+#pragma unroll
+        for (uint32_t k = 0; k < GS_SPINE_CACHED; k++) { tv[k] = lo + k < hi ? spine[lo + k] : 0u; s += tv[k]; s64 += tv[k]; ne += GS_EXTRA_OF(tv[k]); }
+    } else for (uint32_t i = lo; i < hi; i++) { const uint32_t t = spine[i]; s += t; s64 += t; ne += GS_EXTRA_OF(t); }
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) s64 += ((unsigned long long)__shfl_xor((uint32_t)(s64 >> 32), m, 64) << 32) + __shfl_xor((uint32_t)s64, m, 64);
     if (lane == 0) s_total64[w] = s64;
-    const uint32_t inc = wave_incl_scan_u32(s, lane);
-    if (lane == 63) s_wave[w] = inc;
+    const uint32_t inc = wave_incl_scan_u32(s, lane), inc_e = wave_incl_scan_u32(ne, lane);
+    if (lane == 63) { s_wave[w] = inc; s_wave_e[w] = inc_e; }
     __syncthreads();
-    uint32_t base = 0, total = 0;
+    uint32_t base = 0, total = 0, base_e = 0, total_e = 0;
 #pragma unroll
-    for (int k = 0; k < 4; k++) { const uint32_t t = s_wave[k]; if (k < w) base += t; total += t; }
+    for (int k = 0; k < 4; k++) { const uint32_t t = s_wave[k], te = s_wave_e[k]; if (k < w) { base += t; base_e += te; } total += t; total_e += te; }
     const unsigned long long total64 = s_total64[0] + s_total64[1] + s_total64[2] + s_total64[3];
     if (total64 > 0xFFFFFFFFull) total = 0xFFFFFFFFu;              // saturate: larger than any pair_cap (<= 0xFFFF0000)
-    uint32_t run = base + inc - s;
-    for (uint32_t i = lo; i < hi; i++) { const uint32_t t = spine[i]; spine[i] = run; run += t; }
+    uint32_t run = base + inc - s, q = base_e + inc_e - ne;
+    const bool fits = total <= pair_cap;                            // (then at most pair_cap / GS_EMIT_PAIRS extra slices exist)
+#define GS_SPINE_STEP(i, t) do {                                                                                       \
+        spine[i] = run; run += (t);                                                                                    \
+        if (fits) for (uint32_t k2 = 0, n2 = GS_EXTRA_OF(t); k2 < n2; k2++) extra[q++] = make_uint2((i), k2 + 1u);     \
+        } while (0)
+    if (cached) {
+#pragma unroll
+        for (uint32_t k = 0; k < GS_SPINE_CACHED; k++) if (lo + k < hi) GS_SPINE_STEP(lo + k, tv[k]);
+    } else for (uint32_t i = lo; i < hi; i++) { const uint32_t t = spine[i]; GS_SPINE_STEP(i, t); }
+#undef GS_SPINE_STEP
+#undef GS_EXTRA_OF
     if (threadIdx.x == 0) {
+        ctl->n_emit_extra = fits ? total_e : 0u;
         if (ROUND == 0) { ctl->n_visible = 0; ctl->n_pairs_frame = 0; ctl->want_frame = 0; }
         else { ctl->unsat_round0 = ctl->unsat_count; if (ctl->unsat_count) ctl->unsat_events += 1; }
         ctl->j_lo = j_lo; ctl->j_hi = j_hi;                          // for k_tile_ranges / k_blend of this round
         ctl->scan_total = total;
-        ctl->n_huge_round = ctl->n_huge; ctl->n_huge = 0;              // k_emit of this round expands them; the next k_project starts at 0
         ctl->want_frame = (ctl->want_frame + total < total) ? 0xFFFFFFFFu : ctl->want_frame + total;   // (saturating)
         if (ctl->want_frame > ctl->max_total) ctl->max_total = ctl->want_frame;
         // a round that does not fit, or that follows one of this frame that did not (k_emit wrote nothing then), bins nothing:
@@ -254,14 +272,20 @@ __global__ __launch_bounds__(GS_BLOCK) void k_pairs_check(GsControl *ctl, uint32
     }
 }
 
-// (tile id, sorted position) records in splat order.  Each workgroup pass covers the same 256-splat chunk as
-// k_project; the pair offset of every splat is spine[chunk] + an in-workgroup exclusive scan of tile_count, so no
-// offset array ever goes to memory.  Splats touching few tiles are written by their own lane; the few screen-filling
-// ones (thousands of tiles each) are queued in LDS and expanded by a whole wavefront, one lane per tile row.
-// ROUND 1 writes only the tiles whose bit is set in the unsaturated-tile mask.
-#ifndef GS_EMIT_BIG
-#define GS_EMIT_BIG 32u
-#endif
+// (tile id, sorted position) records in splat order: pair slot = spine[chunk] + the in-chunk exclusive scan of tile_count
+// + the pair's index inside its splat (tile rows top to bottom, tiles left to right), so no offset array goes to memory.
+//
+// Work is handed out by PAIRS, not by splats: the tiles-per-splat distribution is extremely skewed (headline scene: 31 000
+// visible splats of the first round touch 1.7 M tiles, 10 % of them 60 % of that; a chunk of 256 consecutive splats holds
+// 580 pairs on average and 16 000 at the near end), and a splat-per-lane or splat-per-wavefront expansion leaves the
+// kernel waiting for the few workgroups that own the near chunks.  An item = GS_EMIT_PAIRS consecutive pair slots of one
+// chunk (the first slice of every chunk, plus k_pairs_check's `extra` slices of the heavy ones, taken first).  Per item:
+//   1. scan tile_count over the chunk; the splats whose slot range meets the slice are compacted into LDS;
+//   2. their tile-row runs (splat, row) -> (first tile, length), GS_EMIT_RUNS at a time, one run per thread slot, by bisection
+//      of the row-count scan; exclusive scan of the lengths;
+//   3. one thread per pair slot of the slice: the run by bisection of that scan, consecutive threads write consecutive
+//      slots.
+// ROUND 1 writes only the tiles whose bit is set in the unsaturated-tile mask (a run's length is then its popcount).
 // one pair record: 8 bytes (tile, sorted position) or, when tile bits + position bits fit (jbits > 0), 4 bytes
 // (tile << jbits | position - j_lo): half the traffic through emit, both radix passes, the range pass and the blend
 template <bool P32>
@@ -271,188 +295,154 @@ __device__ __forceinline__ void put_pair(void *__restrict__ pairs, uint32_t o, u
     else reinterpret_cast<uint2 *>(pairs)[o] = make_uint2(tile, j);
 }
 
-template <int ROUND, bool P32>
-__device__ __forceinline__ uint32_t emit_run(void *__restrict__ pairs, uint32_t o, uint32_t ty, uint32_t tiles_x, uint32_t t0, uint32_t n,
-                                             uint32_t j, uint32_t jrel, uint32_t jbits, const uint32_t *__restrict__ mask_row)
+// exclusive scan of one value per thread over the workgroup (256 threads), total returned in `total`
+__device__ __forceinline__ uint32_t block_exscan(uint32_t v, uint32_t *s_w, int lane, int w, uint32_t &total)
 {
-    if (ROUND == 0) {
-        for (uint32_t k = 0; k < n; k++) put_pair<P32>(pairs, o++, ty * tiles_x + t0 + k, j, jrel, jbits);
-    } else if (n) {
-        for (uint32_t w = t0 >> 5; w <= ((t0 + n - 1) >> 5); w++) {
-            uint32_t bits = mask_bits(mask_row, w, t0, n);
-            while (bits) { const uint32_t b = __ffs(bits) - 1; bits &= bits - 1; put_pair<P32>(pairs, o++, ty * tiles_x + w * 32 + b, j, jrel, jbits); }
-        }
+    const uint32_t inc = wave_incl_scan_u32(v, lane);
+    __syncthreads();                                                // (readers of the previous use are done)
+    if (lane == 63) s_w[w] = inc;
+    __syncthreads();
+    uint32_t base = 0;
+    total = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) { const uint32_t t = s_w[k]; if (k < w) base += t; total += t; }
+    return base + inc - v;
+}
+
+// tile column of the kth (0-based) unsaturated tile among [t0, t0 + n) of one tile row
+__device__ __forceinline__ uint32_t nth_masked_tile(const uint32_t *__restrict__ mask_row, uint32_t t0, uint32_t n, uint32_t kth)
+{
+    for (uint32_t w = t0 >> 5; w <= ((t0 + n - 1u) >> 5); w++) {
+        uint32_t bits = mask_bits(mask_row, w, t0, n);
+        const uint32_t c = (uint32_t)__popc(bits);
+        if (kth < c) { while (kth--) bits &= bits - 1u; return w * 32u + (uint32_t)__ffs(bits) - 1u; }
+        kth -= c;
     }
-    return o;
+    return t0;                                                      // (not reached: kth < the run's popcount)
 }
 
 template <int ROUND, bool P32>
 __global__ __launch_bounds__(GS_BLOCK) void k_emit(const gsm::Projected *__restrict__ proj, const uint2 *__restrict__ rect,
                                                    const uint32_t *__restrict__ tile_count, const uint32_t *__restrict__ spine,
-                                                   GsFrameUniforms u, void *__restrict__ pairs, const uint32_t *__restrict__ mask,
-                                                   const GsControl *ctl, const uint32_t *__restrict__ huge_list)
+                                                   const uint2 *__restrict__ extra, GsFrameUniforms u, void *__restrict__ pairs,
+                                                   const uint32_t *__restrict__ mask, const GsControl *ctl)
 {
-    // queues of the splats that are expanded cooperatively: 16-lane-group splats from the front, whole-wavefront splats
-    // from the back of the same arrays; their owner threads leave position, slot offset, projected record and row range
-    // here, so the expansion loops read LDS instead of paying a global round trip per splat
-    __shared__ uint32_t s_qj[GS_BLOCK], s_qoff[GS_BLOCK], s_qrows[GS_BLOCK];
-    __shared__ float s_qrec[GS_BLOCK][6];
-    __shared__ uint32_t s_nbig, s_nmid, s_wave[4];
-    __shared__ uint32_t s_hoff[GS_HUGE_ROWS + 1], s_ht0[GS_HUGE_ROWS], s_hbase;   // huge splat: row offsets / first tile of each row
+    __shared__ float s_rec[GS_BLOCK][6];                            // the slice's splats: projected record,
+    __shared__ uint32_t s_sp[GS_BLOCK], s_ty[GS_BLOCK];             // index in the chunk, first | last tile row,
+    __shared__ uint32_t s_rb[GS_BLOCK + 1];                         // exclusive scan of their tile-row counts
+    __shared__ uint32_t s_rt[GS_EMIT_RUNS], s_rx[GS_EMIT_RUNS];     // a batch of runs: first tile | splat << 24, exclusive scan of lengths
+    __shared__ uint32_t s_rn[ROUND == 1 ? GS_EMIT_RUNS : 1];        // ROUND 1: the run's unmasked length
+    __shared__ uint32_t s_w[4], s_first;
     if (ctl->pair_overflow) return;
     const uint32_t j_lo = ctl->j_lo, j_hi = ctl->j_hi;               // set by k_pairs_check of this round
-    const uint32_t nchunks = (j_hi - j_lo + GS_BLOCK - 1) / GS_BLOCK;
+    const uint32_t nchunks = (j_hi - j_lo + GS_BLOCK - 1) / GS_BLOCK, n_extra = ctl->n_emit_extra;
     const uint32_t tiles_x = (uint32_t)u.tiles_x;
+    const uint32_t tid = threadIdx.x;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    // Phase A: the huge splats of the round (listed by k_project), GS_HUGE_SLICES row slices each, spread over the whole
-    // grid.  Who writes a splat's pairs does not matter: its slot range is fixed by the offset scan.
-    const uint32_t nhuge = ctl->n_huge_round;
-    const bool defer = nhuge != 0 && nhuge <= GS_HUGE_CAP;
-    if (defer) for (uint32_t item = blockIdx.x; item < nhuge * GS_HUGE_SLICES; item += gridDim.x) {
-        const uint32_t jh = huge_list[item / GS_HUGE_SLICES], sl = item % GS_HUGE_SLICES;
-        const uint32_t hc = (jh - j_lo) / GS_BLOCK, ht = (jh - j_lo) % GS_BLOCK;
-        {   // the splat's first pair slot: its chunk's base + the in-chunk exclusive scan, recomputed here
-            const uint32_t jj = j_lo + hc * GS_BLOCK + threadIdx.x;
-            const uint32_t cnt = jj < j_hi ? tile_count[jj] : 0u;
-            const uint32_t inc = wave_incl_scan_u32(cnt, lane);
-            if (lane == 63) s_wave[w] = inc;
-            __syncthreads();
-            uint32_t wbase = 0;
-#pragma unroll
-            for (int k = 0; k < 4; k++) if (k < w) wbase += s_wave[k];
-            if (threadIdx.x == ht) s_hbase = spine[hc] + wbase + inc - cnt;
+    for (uint32_t item = blockIdx.x; item < n_extra + nchunks; item += gridDim.x) {
+        uint32_t c = item - n_extra, sub = 0;
+        if (item < n_extra) { const uint2 e = extra[item]; c = e.x; sub = e.y; }
+        const uint32_t base = spine[c];
+        const uint32_t j = j_lo + c * GS_BLOCK + tid;
+        // one memory round trip for everything the item may need: count, rectangle and record of every position of the
+        // chunk (the two latter are only meaningful -- and only used -- where the count is not zero)
+        uint32_t cnt = 0;
+        uint2 rc = make_uint2(0u, 0u);
+        float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb4 = ra;
+        if (j < j_hi) {
+            cnt = tile_count[j]; rc = rect[j];
+            const float4 *src = reinterpret_cast<const float4 *>(proj + j);
+            ra = src[0]; rb4 = src[1];
         }
-        const float4 *src = reinterpret_cast<const float4 *>(proj + jh);
-        const float4 a = src[0], b = src[1];
-        gsm::Projected p; p.cx = a.x; p.cy = a.y; p.ax = a.z; p.ay = a.w; p.bx = b.x; p.by = b.y;
-        gsm::EllipseRows e;
-        gsm::ellipse_rows_setup(p, e);
-        const uint2 rc = rect[jh];
-        const uint32_t ty0 = rc.x >> 16, rows = (rc.y >> 16) - ty0 + 1u;     // <= GS_HUGE_ROWS (k_project's listing rule)
-        uint32_t carry = 0;
-        for (uint32_t rb = 0; rb < rows; rb += GS_BLOCK) {               // per-row tile runs and their exclusive offsets
-            const uint32_t r = rb + threadIdx.x;
-            uint32_t t0 = 0, n = 0, nm = 0;
-            if (r < rows) {
-                gsm::splat_tile_row(p, e, (int)(ty0 + r), u.H, u.x0, u.x1b, t0, n);
-                nm = (ROUND == 1 && n) ? mask_count(mask + (ty0 + r) * u.mask_words, t0, n) : n;
-            }
-            const uint32_t inc = wave_incl_scan_u32(nm, lane);
-            __syncthreads();                                          // (s_wave of the previous use has been read)
-            if (lane == 63) s_wave[w] = inc;
-            __syncthreads();
-            uint32_t wbase = 0, total = 0;
-#pragma unroll
-            for (int k = 0; k < 4; k++) { const uint32_t t = s_wave[k]; if (k < w) wbase += t; total += t; }
-            if (r < rows) { s_hoff[r] = carry + wbase + inc - nm; s_ht0[r] = t0 | (n << 16); }
-            carry += total;
-        }
-        if (threadIdx.x == 0) s_hoff[rows] = carry;
-        __syncthreads();
-        const uint32_t r_lo = rows * sl / GS_HUGE_SLICES, r_hi = rows * (sl + 1u) / GS_HUGE_SLICES;
-        const uint32_t base = s_hbase, p_lo = s_hoff[r_lo], p_hi = s_hoff[r_hi];
-        if (ROUND == 0) {
-            // flattened: consecutive threads write consecutive pairs; the row of pair q by bisection of the row offsets
-            for (uint32_t q = p_lo + threadIdx.x; q < p_hi; q += GS_BLOCK) {
-                uint32_t lo = r_lo, hi = r_hi;                       // invariant: s_hoff[lo] <= q < s_hoff[hi]
-                while (hi - lo > 1u) { const uint32_t m = (lo + hi) >> 1; if (s_hoff[m] <= q) lo = m; else hi = m; }
-                const uint32_t t0 = s_ht0[lo] & 0xFFFFu;
-                put_pair<P32>(pairs, base + q, (ty0 + lo) * tiles_x + t0 + (q - s_hoff[lo]), jh, jh - j_lo, u.pair_jbits);
-            }
-        } else {
-            for (uint32_t r = r_lo + threadIdx.x; r < r_hi; r += GS_BLOCK)   // masked tiles: one thread per row
-                emit_run<ROUND, P32>(pairs, base + s_hoff[r], ty0 + r, tiles_x, s_ht0[r] & 0xFFFFu, s_ht0[r] >> 16, jh, jh - j_lo, u.pair_jbits,
-                                     mask + (ty0 + r) * u.mask_words);
+        uint32_t n_c;
+        const uint32_t ex = block_exscan(cnt, s_w, lane, w, n_c);
+        const uint32_t q0 = sub * GS_EMIT_PAIRS;
+        if (q0 >= n_c) continue;                                     // (uniform) a chunk without pairs
+        const uint32_t q1 = n_c - q0 > GS_EMIT_PAIRS ? q0 + GS_EMIT_PAIRS : n_c;
+        const bool needed = cnt != 0u && ex < q1 && ex + cnt > q0;
+        const uint32_t nr = needed ? (rc.y >> 16) - (rc.x >> 16) + 1u : 0u;
+        uint32_t K, R;
+        const uint32_t k = block_exscan(needed ? 1u : 0u, s_w, lane, w, K);
+        const uint32_t rb = block_exscan(nr, s_w, lane, w, R);
+        if (needed) {
+            s_rec[k][0] = ra.x; s_rec[k][1] = ra.y; s_rec[k][2] = ra.z; s_rec[k][3] = ra.w; s_rec[k][4] = rb4.x; s_rec[k][5] = rb4.y;
+            s_sp[k] = tid; s_ty[k] = (rc.x >> 16) | (rc.y & 0xFFFF0000u); s_rb[k] = rb;
+            if (k == 0) s_first = ex;
         }
         __syncthreads();
-    }
-    for (uint32_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
-        uint32_t carry = spine[c];
-        {
-            if (threadIdx.x == 0) { s_nbig = 0; s_nmid = 0; }
-            const uint32_t j = j_lo + c * GS_BLOCK + threadIdx.x;
-            const uint32_t cnt = j < j_hi ? tile_count[j] : 0u;
-            const uint32_t inc = wave_incl_scan_u32(cnt, lane);
-            if (lane == 63) s_wave[w] = inc;
-            __syncthreads();
-            uint32_t wbase = 0, total = 0;
+        const uint32_t o_first = s_first;                             // chunk-relative slot of the first compacted splat's first pair
+        const uint32_t ktop = K > 1u ? 1u << (31 - __clz((int)(K - 1u))) : 0u;   // first bisection step over K compacted splats
+        uint32_t xc = 0;                                              // pairs of the compacted splats before this batch of runs
+        for (uint32_t rb0 = 0; rb0 < R; rb0 += GS_EMIT_RUNS) {
+            // (the bisections of a thread's runs, and of its pairs below, are interleaved step by step: each step is one LDS
+            // round trip, and four independent ones in flight cost about as much as one)
+            constexpr uint32_t RPT = GS_EMIT_RUNS / GS_BLOCK;         // runs per thread and pass
+            uint32_t nm[RPT], kk[RPT], tsum = 0;
 #pragma unroll
-            for (int k = 0; k < 4; k++) { const uint32_t t = s_wave[k]; if (k < w) wbase += t; total += t; }
-            uint32_t o = carry + wbase + inc - cnt;                  // this splat's first pair slot
-            carry += total;
-            if (cnt >= GS_EMIT_BIG) {
-                // many tiles: expanded cooperatively, one lane per tile row -- by 16 lanes when the splat spans at most 16
-                // tile rows (four splats per wavefront pass), by a whole wavefront otherwise; huge ones were done in phase A
-                const uint2 rc = rect[j];
-                if (defer && cnt >= GS_HUGE_TILES && (rc.y >> 16) - (rc.x >> 16) < GS_HUGE_ROWS) { /* phase A */ }
-                else {
-                    const float4 *src = reinterpret_cast<const float4 *>(proj + j);
-                    const float4 a = src[0], b = src[1];
-                    const uint32_t q = ((rc.y >> 16) - (rc.x >> 16) < 16u) ? atomicAdd(&s_nmid, 1u) : GS_BLOCK - 1u - atomicAdd(&s_nbig, 1u);
-                    s_qj[q] = j; s_qoff[q] = o; s_qrows[q] = (rc.x >> 16) | (rc.y & 0xFFFF0000u);
-                    s_qrec[q][0] = a.x; s_qrec[q][1] = a.y; s_qrec[q][2] = a.z; s_qrec[q][3] = a.w; s_qrec[q][4] = b.x; s_qrec[q][5] = b.y;
-                }
-            } else if (cnt) {
-                const float4 *src = reinterpret_cast<const float4 *>(proj + j);
-                const float4 a = src[0], b = src[1];
-                gsm::Projected p; p.cx = a.x; p.cy = a.y; p.ax = a.z; p.ay = a.w; p.bx = b.x; p.by = b.y;
-                gsm::EllipseRows e;
-                gsm::ellipse_rows_setup(p, e);
-                const uint2 rc = rect[j];
-                for (uint32_t ty = rc.x >> 16; ty <= (rc.y >> 16); ty++) {
-                    uint32_t t0, n;
-                    gsm::splat_tile_row(p, e, (int)ty, u.H, u.x0, u.x1b, t0, n);
-                    o = emit_run<ROUND, P32>(pairs, o, ty, tiles_x, t0, n, j, j - j_lo, u.pair_jbits, mask + ty * u.mask_words);
+            for (uint32_t i = 0; i < RPT; i++) kk[i] = 0;             // the largest kk with s_rb[kk] <= r
+            for (uint32_t step = ktop; step; step >>= 1) {
+#pragma unroll
+                for (uint32_t i = 0; i < RPT; i++) {
+                    const uint32_t r = rb0 + tid * RPT + i, t = kk[i] + step;
+                    if (t < K && s_rb[t] <= r) kk[i] = t;
                 }
             }
-            __syncthreads();
-            const uint32_t nmid = s_nmid;
-            for (uint32_t mi = (uint32_t)w * 4u + ((uint32_t)lane >> 4); mi < ((nmid + 15u) & ~15u); mi += 16u) {   // 16 lanes per splat
-                const bool have = mi < nmid;
-                const uint32_t jm = have ? s_qj[mi] : 0u;
-                uint32_t t0 = 0, n = 0, nm = 0, ty = 0;
-                bool row_ok = false;
-                if (have) {
+#pragma unroll
+            for (uint32_t i = 0; i < RPT; i++) {
+                const uint32_t idx = tid * RPT + i, r = rb0 + idx, k1 = kk[i];
+                nm[i] = 0;
+                if (r < R) {
+                    const uint32_t row = (s_ty[k1] & 0xFFFFu) + (r - s_rb[k1]);
                     gsm::Projected p;
-                    p.cx = s_qrec[mi][0]; p.cy = s_qrec[mi][1]; p.ax = s_qrec[mi][2]; p.ay = s_qrec[mi][3]; p.bx = s_qrec[mi][4]; p.by = s_qrec[mi][5];
+                    p.cx = s_rec[k1][0]; p.cy = s_rec[k1][1]; p.ax = s_rec[k1][2]; p.ay = s_rec[k1][3]; p.bx = s_rec[k1][4]; p.by = s_rec[k1][5];
                     gsm::EllipseRows e;
                     gsm::ellipse_rows_setup(p, e);
-                    ty = (s_qrows[mi] & 0xFFFFu) + ((uint32_t)lane & 15u);
-                    row_ok = ty <= (s_qrows[mi] >> 16);
-                    if (row_ok) {
-                        gsm::splat_tile_row(p, e, (int)ty, u.H, u.x0, u.x1b, t0, n);
-                        nm = (ROUND == 1 && n) ? mask_count(mask + ty * u.mask_words, t0, n) : n;
-                    }
+                    uint32_t t0, n;
+                    gsm::splat_tile_row(p, e, (int)row, u.H, u.x0, u.x1b, t0, n);
+                    nm[i] = (ROUND == 1 && n) ? mask_count(mask + row * u.mask_words, t0, n) : n;
+                    s_rt[idx] = (row * tiles_x + t0) | (k1 << 24);
+                    if (ROUND == 1) s_rn[idx] = n;
                 }
-                uint32_t rinc = nm;                                  // inclusive scan inside the 16-lane group
+                tsum += nm[i];
+            }
+            uint32_t pb;
+            uint32_t x = block_exscan(tsum, s_w, lane, w, pb);
 #pragma unroll
-                for (int d = 1; d < 16; d <<= 1) { const uint32_t t = __shfl_up(rinc, d, 16); if ((lane & 15) >= d) rinc += t; }
-                if (row_ok) emit_run<ROUND, P32>(pairs, s_qoff[mi] + rinc - nm, ty, tiles_x, t0, n, jm, jm - j_lo, u.pair_jbits, mask + ty * u.mask_words);
-            }
-            const uint32_t nbig = s_nbig;
-            for (uint32_t bq = w; bq < nbig; bq += 4) {              // one wavefront per big splat
-                const uint32_t bi = GS_BLOCK - 1u - bq;
-                const uint32_t jb = s_qj[bi];
-                gsm::Projected p;
-                p.cx = s_qrec[bi][0]; p.cy = s_qrec[bi][1]; p.ax = s_qrec[bi][2]; p.ay = s_qrec[bi][3]; p.bx = s_qrec[bi][4]; p.by = s_qrec[bi][5];
-                gsm::EllipseRows e;
-                gsm::ellipse_rows_setup(p, e);
-                const uint32_t ty0 = s_qrows[bi] & 0xFFFFu, ty1 = s_qrows[bi] >> 16;
-                uint32_t base = s_qoff[bi];
-                for (uint32_t tyb = ty0; tyb <= ty1; tyb += 64) {    // 64 tile rows per sweep
-                    const uint32_t ty = tyb + lane;
-                    uint32_t t0 = 0, n = 0, nm = 0;
-                    if (ty <= ty1) {
-                        gsm::splat_tile_row(p, e, (int)ty, u.H, u.x0, u.x1b, t0, n);
-                        nm = (ROUND == 1 && n) ? mask_count(mask + ty * u.mask_words, t0, n) : n;
+            for (uint32_t i = 0; i < RPT; i++) { s_rx[tid * RPT + i] = x; x += nm[i]; }
+            __syncthreads();
+            // the batch's pairs 0 .. pb-1 sit at the chunk-relative slots s0 .. s0+pb-1; this item writes those inside [q0, q1)
+            const uint32_t s0 = o_first + xc;
+            const uint32_t p_lo = q0 > s0 ? q0 - s0 : 0u, p_hi = q1 > s0 ? (q1 - s0 < pb ? q1 - s0 : pb) : 0u;
+            const uint32_t nrun = R - rb0 < GS_EMIT_RUNS ? R - rb0 : GS_EMIT_RUNS;
+            const uint32_t rtop = 1u << (31 - __clz((int)nrun));      // (the slots past the batch's runs hold pb: never taken)
+            constexpr uint32_t PPT = 4;                               // pairs per thread and pass
+            for (uint32_t pp = p_lo + tid; pp < p_hi; pp += PPT * GS_BLOCK) {
+                uint32_t run[PPT];                                     // the largest run with s_rx[run] <= p (it has a positive length)
+#pragma unroll
+                for (uint32_t i = 0; i < PPT; i++) run[i] = 0;
+                for (uint32_t step = rtop; step; step >>= 1) {
+#pragma unroll
+                    for (uint32_t i = 0; i < PPT; i++) { const uint32_t t = run[i] + step; if (t < GS_EMIT_RUNS && s_rx[t] <= pp + i * GS_BLOCK) run[i] = t; }
+                }
+#pragma unroll
+                for (uint32_t i = 0; i < PPT; i++) {
+                    const uint32_t p = pp + i * GS_BLOCK;
+                    if (p >= p_hi) break;
+                    const uint32_t rt = s_rt[run[i]], k1 = rt >> 24, first = rt & 0xFFFFFFu, within = p - s_rx[run[i]];
+                    uint32_t tile = first + within;
+                    if (ROUND == 1) {
+                        const uint32_t row = first / tiles_x, t0 = first % tiles_x;
+                        tile = row * tiles_x + nth_masked_tile(mask + row * u.mask_words, t0, s_rn[run[i]], within);
                     }
-                    const uint32_t rinc = wave_incl_scan_u32(nm, lane);
-                    if (ty <= ty1) emit_run<ROUND, P32>(pairs, base + rinc - nm, ty, tiles_x, t0, n, jb, jb - j_lo, u.pair_jbits, mask + ty * u.mask_words);
-                    base += __shfl(rinc, 63, 64);
+                    const uint32_t jrel = c * GS_BLOCK + s_sp[k1];
+                    put_pair<P32>(pairs, base + s0 + p, tile, j_lo + jrel, jrel, u.pair_jbits);
                 }
             }
-            __syncthreads();
+            xc += pb;
+            if (s0 + pb >= q1) break;                                  // (uniform) the rest lies behind the slice
+            __syncthreads();                                          // the run tables are rewritten by the next batch
         }
+        __syncthreads();                                              // the splat tables are rewritten by the next item
     }
 }
 
@@ -909,11 +899,11 @@ int run_round(gs_ctx *ctx, const GsFrameUniforms &u, uint8_t *out, bool last_rou
     // the last collected frames binned (0 = not known yet: the capacity)
     const uint32_t ph = ROUND == 1 ? (uint32_t)(small * GS_CHUNK_S) : __atomic_load_n(&gs_root(ctx)->pair_hint, __ATOMIC_RELAXED);
     hipLaunchKernelGGL(k_project<ROUND>, dim3(g), dim3(GS_BLOCK), 0, st, ctx->sorted, ctx->splat, u, ctx->proj, ctx->rect,
-                       ctx->tile_count, ctx->spine, ctx->part_vis, ctx->unsat_mask, ctx->zwin, ctx->ctl, ctx->huge_list);
+                       ctx->tile_count, ctx->spine, ctx->part_vis, ctx->unsat_mask, ctx->zwin, ctx->ctl);
     GS_HIP(hipGetLastError());
     if (ROUND == 0) GS_PROF_RECORD(ctx, 3);
     hipLaunchKernelGGL(k_pairs_check<ROUND>, dim3(1), dim3(GS_BLOCK), 0, st, ctx->ctl, (uint32_t)ctx->pair_cap, ctx->spine, ctx->part_vis, g,
-                       u.near_count, last_round ? 1 : 0, ctx->unsat_mask, (uint32_t)u.tiles_y * u.mask_words);
+                       u.near_count, last_round ? 1 : 0, ctx->unsat_mask, (uint32_t)u.tiles_y * u.mask_words, ctx->emit_extra);
     // pair record format: 4 bytes when the tile id and the round's position range fit in 32 bits together
     const int tb = bits_for(ntiles);
     const uint32_t jrange = ROUND == 0 ? (u.near_count != 0xFFFFFFFFu && u.near_count < Vmax ? u.near_count : Vmax) : Vmax;
@@ -921,10 +911,12 @@ int run_round(gs_ctx *ctx, const GsFrameUniforms &u, uint8_t *out, bool last_rou
     const bool p32 = !ctx->wide_pairs && tb + jb <= 32;
     GsFrameUniforms v = u;
     v.pair_jbits = p32 ? (uint32_t)jb : 0u;
-    if (p32) hipLaunchKernelGGL((k_emit<ROUND, true>), dim3(g), dim3(GS_BLOCK), 0, st, ctx->proj, ctx->rect, ctx->tile_count, ctx->spine, v,
-                                (void *)ctx->pair_a, ctx->unsat_mask, ctx->ctl, ctx->huge_list);
-    else hipLaunchKernelGGL((k_emit<ROUND, false>), dim3(g), dim3(GS_BLOCK), 0, st, ctx->proj, ctx->rect, ctx->tile_count, ctx->spine, v,
-                            (void *)ctx->pair_a, ctx->unsat_mask, ctx->ctl, ctx->huge_list);
+    // (items = the round's chunks + the extra slices of the heavy ones: about I / GS_EMIT_PAIRS more)
+    uint32_t ge = g + (ROUND == 1 ? 0u : gs_div_up(ph ? ph : pc, GS_EMIT_PAIRS)); if (ge > GS_MAX_PART) ge = GS_MAX_PART;
+    if (p32) hipLaunchKernelGGL((k_emit<ROUND, true>), dim3(ge), dim3(GS_BLOCK), 0, st, ctx->proj, ctx->rect, ctx->tile_count, ctx->spine,
+                                ctx->emit_extra, v, (void *)ctx->pair_a, ctx->unsat_mask, ctx->ctl);
+    else hipLaunchKernelGGL((k_emit<ROUND, false>), dim3(ge), dim3(GS_BLOCK), 0, st, ctx->proj, ctx->rect, ctx->tile_count, ctx->spine,
+                            ctx->emit_extra, v, (void *)ctx->pair_a, ctx->unsat_mask, ctx->ctl);
     GS_HIP(hipGetLastError());
     int rc;
     const int fmt = p32 ? GS_RADIX_KEYONLY : GS_RADIX_PACKED, sh = p32 ? jb : 0;

@@ -877,9 +877,11 @@ def test_enqueue_threads_on_and_off_give_identical_frames_and_statistics(scene_s
 
 
 def test_huge_splats_in_both_rounds_and_record_formats(scene_small):
-    """Splats touching thousands of tiles take the grid-wide slice path of k_emit (listed by k_project): with fat splats and
-    a tiny first-round share most of them are expanded in ROUND 1 (masked tiles, one thread per row), with a large share in
-    round 0 (flattened writes).  Every combination must give the single-round image, the oracle's fragment count included."""
+    """k_emit hands its work out by pair slots: a chunk of 256 consecutive splats whose footprints add up to more than
+    GS_EMIT_PAIRS tiles is written by several workgroups (k_pairs_check's extra items), and a narrow strip makes chunks with
+    thousands of one-tile rows (several passes over the run table per item).  With fat splats and a tiny first-round share
+    most records are written in ROUND 1 (masked tiles: the kth unsaturated tile of a run), with a large share in round 0.
+    Every combination must give the single-round image, the oracle's fragment count included."""
     rows = synth.make_splat_rows(6000, seed=31).reshape(-1, 32).copy()
     rows[:, 12:24] = (rows[:, 12:24].copy().view("<f4") * np.float32(25.0)).view(np.uint8)     # enormous footprints
     w, h = 1280, 720
@@ -899,9 +901,11 @@ def test_huge_splats_in_both_rounds_and_record_formats(scene_small):
                 mv, P, focal = _f32(cam)
                 _, _, frags = oracle.render(cs, cc, idx, mv, P, focal, w, h, x0=600, x1=664, want_f32=False)
                 assert c.stats()["n_frags"] == frags
+            if wide == 0:
+                images[(permille, "strip")] = c.render(_params(cam, x0=608, x1=624))   # one tile column: rows x 1 tile per splat
     ref = images[(1000, 0)]
     for k, img in images.items():
-        assert np.array_equal(img, ref), k
+        assert np.array_equal(img, ref[:, 608:624] if k[1] == "strip" else ref), k
 
 
 # ---------------------------------------------------------------- several GPUs behind the C ABI (gs_comm.hip), world 1 here
