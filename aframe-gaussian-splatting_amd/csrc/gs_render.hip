@@ -496,6 +496,9 @@ __global__ __launch_bounds__(GS_BLOCK) void k_tile_ranges(const void *__restrict
 #ifndef GS_BLEND_BATCH
 #define GS_BLEND_BATCH 64
 #endif
+#ifndef GS_BLEND_PAD_WORDS
+#define GS_BLEND_PAD_WORDS 0
+#endif
 typedef float f2 __attribute__((ext_vector_type(2)));            // two pixels per packed-fp32 instruction (v_pk_*_f32)
 __device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
 
@@ -508,9 +511,14 @@ __global__ __launch_bounds__(64) void k_blend(const uint2 *__restrict__ tile_ran
                                               const float *__restrict__ zwin, const float *__restrict__ scene_depth,
                                               const uint32_t *__restrict__ scene_rgba, GsControl *ctl)
 {
-    __shared__ float4 s_rec[2 * GS_BLEND_BATCH + 2];             // one batch of projected records (+1 inert slot)
-    __shared__ float4 s_col[GS_BLEND_BATCH + 1];                 // their colours, converted once per record: rgb8 * alpha / 255
+    // one batch of list entries (+1 inert slot), 48 bytes each: the projected record's geometry (cx, cy, ax, ay | bx, by, -, -)
+    // and its colour converted once per record (rgb8 * alpha / 255, alpha) -- one LDS base address serves all three reads
+    __shared__ float4 s_ent[3 * (GS_BLEND_BATCH + 1)];
     __shared__ float s_z[GS_BLEND_BATCH + 2];                    // their window depths (SCENE only)
+#if GS_BLEND_PAD_WORDS
+    __shared__ uint32_t s_pad[GS_BLEND_PAD_WORDS];                 // occupancy cap: see GS_BLEND_PAD_WORDS
+    if (u.W < 0) s_pad[threadIdx.x] = 0u;                           // (never true; keeps the array allocated)
+#endif
     const int lane = threadIdx.x;
     if (ROUND == 1 && ctl->j_hi == 0) return;                      // every tile saturated in round 0
     const uint32_t ntiles = (uint32_t)u.tiles_x * (uint32_t)u.tiles_y;
@@ -570,20 +578,20 @@ __global__ __launch_bounds__(64) void k_blend(const uint2 *__restrict__ tile_ran
                                                 : reinterpret_cast<const uint2 *>(pairs)[end - 1 - slot].y;
                 const float4 *src = reinterpret_cast<const float4 *>(proj + j);
                 const float4 rb = src[1];
-                s_rec[2 * slot] = src[0];
-                s_rec[2 * slot + 1] = rb;
+                s_ent[3 * slot] = src[0];
+                s_ent[3 * slot + 1] = rb;
                 // what every lane would otherwise redo for every list entry: unpack the colour, fold alpha / 255 into it
                 const uint32_t rgba = __float_as_uint(rb.z);
                 const float a255 = rb.w * (1.0f / 255.0f);
-                s_col[slot] = make_float4((float)(rgba & 0xFF) * a255, (float)((rgba >> 8) & 0xFF) * a255, (float)((rgba >> 16) & 0xFF) * a255, 0.0f);
+                s_ent[3 * slot + 2] = make_float4((float)(rgba & 0xFF) * a255, (float)((rgba >> 8) & 0xFF) * a255, (float)((rgba >> 16) & 0xFF) * a255, rb.w);
                 if (SCENE) s_z[slot] = u.has_depth ? zwin[j] : 0.0f;
             }
         }
         if (lane == 0 && (nb & 1)) {
             if (SCENE) s_z[nb] = 0.0f;                               // pad an odd batch with a record no pixel can pass
-            s_rec[2 * nb] = make_float4(-1.0e9f, -1.0e9f, 1.0f, 1.0f);   // centre far away, a = (1,1): q ~ 1e18 > 4
-            s_rec[2 * nb + 1] = make_float4(1.0f, 1.0f, 0.0f, 0.0f);
-            s_col[nb] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            s_ent[3 * nb] = make_float4(-1.0e9f, -1.0e9f, 1.0f, 1.0f);   // centre far away, a = (1,1): q ~ 1e18 > 4
+            s_ent[3 * nb + 1] = make_float4(1.0f, 1.0f, 0.0f, 0.0f);
+            s_ent[3 * nb + 2] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         }
         __syncthreads();
         if (live) {
@@ -595,7 +603,7 @@ __global__ __launch_bounds__(64) void k_blend(const uint2 *__restrict__ tile_ran
 #define GS_BLEND_SPLATS_PER_STEP 2
 #endif
             for (; s < nb; s += GS_BLEND_SPLATS_PER_STEP) {
-                const float4 a0 = s_rec[2 * s], b0 = s_rec[2 * s + 1];
+                const float4 a0 = s_ent[3 * s]; const float2 b0 = *reinterpret_cast<const float2 *>(&s_ent[3 * s + 1]);
                 const float dy0 = fy - a0.y;
                 const float dyay0 = dy0 * a0.w, dyby0 = dy0 * b0.y;
                 // |p|^2 of the interpolated vPosition, same expression tree per pixel as gsm::frag_power
@@ -604,7 +612,7 @@ __global__ __launch_bounds__(64) void k_blend(const uint2 *__restrict__ tile_ran
                 const f2 pyA0 = fma2(dxA0, (f2)(b0.x), (f2)(dyby0)), pyB0 = fma2(dxB0, (f2)(b0.x), (f2)(dyby0));
                 const f2 qA0 = fma2(pxA0, pxA0, pyA0 * pyA0), qB0 = fma2(pxB0, pxB0, pyB0 * pyB0);   // -A, index.js:171
 #if GS_BLEND_SPLATS_PER_STEP == 2
-                const float4 a1 = s_rec[2 * s + 2], b1 = s_rec[2 * s + 3];     // slot nb holds an inert record when nb is odd
+                const float4 a1 = s_ent[3 * s + 3]; const float2 b1 = *reinterpret_cast<const float2 *>(&s_ent[3 * s + 4]);   // slot nb holds an inert record when nb is odd
                 const float dy1 = fy - a1.y;
                 const float dyay1 = dy1 * a1.w, dyby1 = dy1 * b1.y;
                 const f2 dxA1 = fxA - a1.x, dxB1 = fxB - a1.x;
@@ -612,15 +620,17 @@ __global__ __launch_bounds__(64) void k_blend(const uint2 *__restrict__ tile_ran
                 const f2 pyA1 = fma2(dxA1, (f2)(b1.x), (f2)(dyby1)), pyB1 = fma2(dxB1, (f2)(b1.x), (f2)(dyby1));
                 const f2 qA1 = fma2(pxA1, pxA1, pyA1 * pyA1), qB1 = fma2(pxB1, pxB1, pyB1 * pyB1);
 #endif
-#define GS_BLEND_APPLY(qA, qB, bb, cc, zz)                                                                             \
+#define GS_BLEND_APPLY(qA, qB, cc, zz)                                                                                 \
                 {                                                                                                      \
                     bool p0 = qA.x <= qmA.x, p1 = qA.y <= qmA.y, p2 = qB.x <= qmB.x, p3 = qB.y <= qmB.y;               \
                     if (SCENE) { p0 = p0 && zz <= zb0; p1 = p1 && zz <= zb1; p2 = p2 && zz <= zb2; p3 = p3 && zz <= zb3; } \
                     if (live & (p0 | p1 | p2 | p3)) {                  /* discard test, index.js:172 */                \
-                        const float alpha = bb.w;                                                                      \
+                        const float alpha = cc.w;                                                                      \
                         /* exp(A) (index.js:173); 0 for the pixels of this lane that the splat misses */               \
-                        const f2 EA = { p0 ? __expf(-qA.x) : 0.0f, p1 ? __expf(-qA.y) : 0.0f };                        \
-                        const f2 EB = { p2 ? __expf(-qB.x) : 0.0f, p3 ? __expf(-qB.y) : 0.0f };                        \
+                        /* (= __expf(-q): v_exp_f32 of q * -log2(e), the four multiplications as two packed ones) */   \
+                        const f2 tA = qA * (f2)(-1.44269502f), tB = qB * (f2)(-1.44269502f);                            \
+                        const f2 EA = { p0 ? __builtin_amdgcn_exp2f(tA.x) : 0.0f, p1 ? __builtin_amdgcn_exp2f(tA.y) : 0.0f }; \
+                        const f2 EB = { p2 ? __builtin_amdgcn_exp2f(tB.x) : 0.0f, p3 ? __builtin_amdgcn_exp2f(tB.y) : 0.0f }; \
                         /* fragment alpha B = exp(A)*vColor.a; its weight under what is in front: w = B*T.  T <- T - w \
                            (= T*(1-B)), colour += (rgb8 * alpha/255) * (exp(A)*T) with the bracket converted at staging */ \
                         const f2 eA = EA * TA, eB = EB * TB;                                                           \
@@ -633,12 +643,12 @@ __global__ __launch_bounds__(64) void k_blend(const uint2 *__restrict__ tile_ran
                     }                                                                                                  \
                 }
                 const float z0 = SCENE ? s_z[s] : 0.0f;
-                const float4 c0 = s_col[s];
-                GS_BLEND_APPLY(qA0, qB0, b0, c0, z0)
+                const float4 c0 = s_ent[3 * s + 2];
+                GS_BLEND_APPLY(qA0, qB0, c0, z0)
 #if GS_BLEND_SPLATS_PER_STEP == 2
                 const float z1 = SCENE ? s_z[s + 1] : 0.0f;
-                const float4 c1 = s_col[s + 1];
-                GS_BLEND_APPLY(qA1, qB1, b1, c1, z1)
+                const float4 c1 = s_ent[3 * s + 5];
+                GS_BLEND_APPLY(qA1, qB1, c1, z1)
 #endif
 #undef GS_BLEND_APPLY
                 if (!live) break;
@@ -646,7 +656,7 @@ __global__ __launch_bounds__(64) void k_blend(const uint2 *__restrict__ tile_ran
             if (u.record_staged == 2) evaluated += min(s + GS_BLEND_SPLATS_PER_STEP, nb);   // list entries this lane evaluated (measurement aid)
         }
         end -= nb;
-        __syncthreads();                                           // s_rec is rewritten by the next batch
+        __syncthreads();                                           // s_ent is rewritten by the next batch
         if (__all(!live)) break;
     }
     if (ROUND == 0 && u.near_count < ctl->n_kept) {               // farther splats exist beyond this round
@@ -703,7 +713,7 @@ __global__ __launch_bounds__(64) void k_blend(const uint2 *__restrict__ tile_ran
     }
 #undef GS_LANE_LIVE
     if (u.record_staged && lane == 0) const_cast<uint2 *>(tile_range)[tile] = make_uint2(staged, range.y - range.x);   // GS_OPT_RECORD_STAGED
-    __syncthreads();                                               // s_rec is reused by the next tile of this wave
+    __syncthreads();                                               // s_ent is reused by the next tile of this wave
     }
 }
 

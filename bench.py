@@ -374,7 +374,8 @@ def main():
 # VALU issue model of the blend (tools/micro/valu_rate.hip on gfx950: cycles per wave-instruction at full occupancy) and its
 # instruction count per evaluated fragment group, from the committed PMC pass (profiles/r01_pmc_valu.md: SQ_INSTS_VALU of
 # k_blend / list entries evaluated); both are properties of the kernel's code, re-measured when gs_render.hip changes
-BLEND_VALU_PER_ENTRY = 43.0        # VALU wave-instructions per list entry a tile's wavefront evaluates (256 pixels)
+BLEND_VALU_PER_ENTRY = 40.7        # VALU wave-instructions per list entry a tile's wavefront evaluates (256 pixels): the PMC figure of
+                                   # round 1 (43.0) x 87/92, the inner loop's VALU count after / before the round-2 changes (ISA listing)
 VALU_CYCLES_PER_INSTR = 4.5        # average issue cost of the blend's mix (v_pk_fma 4.8, v_fma 3.8, v_exp 8.3, v_mul/add 2.5)
 SIMDS, CLOCK_GHZ = 1024, 2.4
 
@@ -461,7 +462,7 @@ def secondary_measurements(ctx, capi, synth, rows, cams, views, n_splats, args):
                             "instr_per_list_entry": BLEND_VALU_PER_ENTRY, "cycles_per_instr": VALU_CYCLES_PER_INSTR,
                             "note": "VALU wave-instructions issued per second by the blend running alone (depth 1) against "
                                     "1024 SIMDs x 2.4 GHz / 4.5 cycles per instruction; entries = list entries each tile's wavefront "
-                                    "evaluated before it saturated (GS_OPT_RECORD_STAGED = 2, this run); 43 VALU instructions per entry "
+                                    "evaluated before it saturated (GS_OPT_RECORD_STAGED = 2, this run); VALU instructions per entry "
                                     "and the issue costs are properties of the kernel code (profiles/r01_pmc_valu.md, tools/micro/valu_rate.hip)"}
     # the frame delivered to the host (what a JS caller of component.render() gets): gs_render into page-locked memory
     host, owner = capi.host_frame(H, W)
