@@ -36,6 +36,7 @@ struct GsControl {
     unsigned long long n_frags;    // fragment counter (GS_RENDER_COUNT_FRAGS)
     uint32_t n_total;              // N at the time of the sort
     uint32_t n_kept;               // V : survivors of the sort culls  (= reference validCount)
+    uint32_t n_sorted, pad_sorted; // V': those of them with a bucket inside the table (compact depth-sort records: the rest is the zero tail)
     uint32_t n_valid;              // V': survivors whose bucket is in [0,65535]
     uint32_t n_visible;            // Vp: splats that pass the vertex-shader culls
     uint32_t n_pairs;              // I : (tile, splat) pairs
@@ -202,16 +203,24 @@ __device__ __forceinline__ bool gs_xcd_chunk(uint32_t v, uint32_t nchunks, uint3
 // record formats: GS_RADIX_KEYS    in: a plain key array whose value is the element index; out: the values alone (final pass)
 //                 GS_RADIX_PACKED  (key,val) uint2 records
 //                 GS_RADIX_KEYONLY 4-byte records that are their own payload (in and out)
+//                 GS_RADIX_KEYIDX  4-byte records `remaining key bits << idx_bits | element index`: out of a GS_RADIX_KEYS pass
+//                                  (key >> (shift + bits) goes on top of the index), in of the final pass (digit = record >> shift
+//                                  with shift = idx_bits, value = the low idx_bits bits) -- half the traffic of (key,val) records
 // max_n:     upper bound of *n_ptr (sizes the scratch); hint_n: the count to expect (0 = max_n) -- it picks the grid and
 //            between one- and two-level offsets, nothing that affects the result.
 // have_hist: the caller's producer kernel already filled ctx->hist[chunk][digit] for this digit (skips the histogram launch).
 // zero_key:  value-only output stores 0 for items with this key (0xFFFFFFFF = never).
+// idx_bits:  GS_RADIX_KEYIDX output: bits reserved for the element index.
+// count_out: GS_RADIX_KEYS input: where the pass leaves the number of records that took a slot (skipped ones do not).
+// fill_to:   GS_RADIX_KEYIDX -> GS_RADIX_KEYS: the output is zero-filled from *n_ptr up to *fill_to.
 #define GS_RADIX_KEYS 0
 #define GS_RADIX_PACKED 1
 #define GS_RADIX_KEYONLY 2
+#define GS_RADIX_KEYIDX 3
 #define GS_RADIX_SKIP 0xFFFFFFFFu   // GS_RADIX_KEYS input only: a record with this key is neither counted nor scattered (compaction)
 int gs_launch_radix_pass(gs_ctx *ctx, const void *in, int in_fmt, void *out, int out_fmt, const uint32_t *n_ptr,
-                         uint32_t max_n, uint32_t hint_n, int shift, int bits, bool have_hist = false, uint32_t zero_key = 0xFFFFFFFFu);
+                         uint32_t max_n, uint32_t hint_n, int shift, int bits, bool have_hist = false, uint32_t zero_key = 0xFFFFFFFFu,
+                         int idx_bits = 0, uint32_t *count_out = nullptr, const uint32_t *fill_to = nullptr);
 // grid used by the radix kernels for hint_n items (a producer that pre-fills the histogram rows uses the same chunking)
 uint32_t gs_radix_grid(uint32_t hint_n);
 // chunk length (GS_CHUNK_S / GS_CHUNK_L) a pass expecting hint_n items works with

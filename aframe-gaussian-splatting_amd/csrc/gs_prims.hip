@@ -174,8 +174,10 @@ __global__ __launch_bounds__(64 * NW) void k_radix_scan(uint32_t *__restrict__ h
 // instruction.
 // IN_FMT:  GS_RADIX_KEYS = a key array whose value is the element index, GS_RADIX_PACKED = (key,val) uint2 records,
 //          GS_RADIX_KEYONLY = 4-byte records that are their own payload (the digit is a bit field of the record).
+//          GS_RADIX_KEYIDX = 4-byte records `key bits << shift | index` (digit = record >> shift, value = the low bits).
 // OUT_FMT: GS_RADIX_KEYS = the value alone (last pass of an index sort), GS_RADIX_PACKED = (key,val) uint2 records (one
-//          8-byte store per item), GS_RADIX_KEYONLY = the 4-byte record.
+//          8-byte store per item), GS_RADIX_KEYONLY = the 4-byte record, GS_RADIX_KEYIDX = the key bits above this pass's
+//          digit on top of the element index (idx_bits wide).
 // zero_key: items whose key equals it store 0 as their value (value-only output): the depth sort uses this so that
 // splats with a dropped bucket (key 65536, which sort behind every bucket) leave zeros in the tail of the index list.
 // MAXB: bins the instantiation reserves LDS for (128 for the <= 7-bit digits of the pair sort; with 4-byte LDS slots for
@@ -183,10 +185,11 @@ __global__ __launch_bounds__(64 * NW) void k_radix_scan(uint32_t *__restrict__ h
 template <int IN_FMT, int OUT_FMT, int MAXB, int NW>
 __global__ __launch_bounds__(64 * NW) void k_radix_scatter(const void *__restrict__ in, void *__restrict__ out,
                                                            const uint32_t *n_ptr, int shift, int bits, uint32_t zero_key,
-                                                           const uint32_t *__restrict__ hist_scanned, const uint32_t *__restrict__ totals)
+                                                           const uint32_t *__restrict__ hist_scanned, const uint32_t *__restrict__ totals,
+                                                           int idx_bits, uint32_t *count_out, const uint32_t *fill_to)
 {
     constexpr int NT = 64 * NW, IPT = 8, CH = NT * IPT;
-    constexpr bool KEYONLY = IN_FMT == GS_RADIX_KEYONLY && OUT_FMT == GS_RADIX_KEYONLY;
+    constexpr bool KEYONLY = (IN_FMT == GS_RADIX_KEYONLY && OUT_FMT == GS_RADIX_KEYONLY) || IN_FMT == GS_RADIX_KEYIDX;
     __shared__ uint32_t s_cnt[NW][MAXB];                        // per-wave digit counts -> local slot bases
     constexpr int MATCHB = MAXB <= 256 ? MAXB : 256;            // match words cover the low 8 digit bits; a 9th bit is refined by a ballot
     __shared__ unsigned long long s_match[NW][MATCHB];          // per wave and (low) digit: lanes holding it in the current round
@@ -200,7 +203,11 @@ __global__ __launch_bounds__(64 * NW) void k_radix_scatter(const void *__restric
     const uint32_t nbins = 1u << bits, mask = nbins - 1, rs = gs_radix_row_stride(nbins);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const unsigned long long lt = (1ull << lane) - 1ull;
-    if (blockIdx.x >= ((nchunks + 7u) & ~7u)) return;
+    if (IN_FMT == GS_RADIX_KEYIDX && fill_to) {                  // the zero tail behind the sorted records (depth sort: dropped buckets)
+        const uint32_t upto = *fill_to;
+        for (uint32_t i = n + blockIdx.x * NT + threadIdx.x; i < upto; i += gridDim.x * NT) reinterpret_cast<uint32_t *>(out)[i] = 0u;
+    }
+    if (blockIdx.x >= ((nchunks + 7u) & ~7u) && !(count_out && blockIdx.x == 0)) return;
     {   // exclusive scan of the <= 512 digit totals (MAXB / NT per thread) -> run starts
         constexpr int DPT = (MAXB + NT - 1) / NT;
         uint32_t tv[DPT], sum = 0;
@@ -210,6 +217,7 @@ __global__ __launch_bounds__(64 * NW) void k_radix_scatter(const void *__restric
         uint32_t ex = block_excl_scan<NW>(sum, s_wave, &tot);
 #pragma unroll
         for (int k = 0; k < DPT; k++) { const uint32_t d = threadIdx.x * DPT + k; if (d < nbins) s_dbase[d] = ex; ex += tv[k]; }
+        if (count_out && blockIdx.x == 0 && threadIdx.x == 0) *count_out = tot;   // records that take a slot = the next pass's input
     }
     for (uint32_t v = blockIdx.x; v < ((nchunks + 7u) & ~7u); v += gridDim.x) {
         uint32_t c;
@@ -304,6 +312,8 @@ __global__ __launch_bounds__(64 * NW) void k_radix_scatter(const void *__restric
                 const uint32_t pos = s_gb[(kv.x >> shift) & mask] + slot;
                 if (OUT_FMT == GS_RADIX_PACKED) reinterpret_cast<uint2 *>(out)[pos] = kv;
                 else if (OUT_FMT == GS_RADIX_KEYONLY) reinterpret_cast<uint32_t *>(out)[pos] = kv.x;
+                else if (OUT_FMT == GS_RADIX_KEYIDX) reinterpret_cast<uint32_t *>(out)[pos] = ((kv.x >> (shift + bits)) << idx_bits) | kv.y;
+                else if (IN_FMT == GS_RADIX_KEYIDX) reinterpret_cast<uint32_t *>(out)[pos] = kv.x & ((1u << shift) - 1u);
                 else reinterpret_cast<uint32_t *>(out)[pos] = kv.x == zero_key ? 0u : kv.y;
             }
         }
@@ -322,7 +332,7 @@ uint32_t grid_for(uint32_t items, uint32_t chunk)
 
 template <int NW>
 int launch_pass(gs_ctx *ctx, const void *in, int in_fmt, void *out, int out_fmt, const uint32_t *n_ptr, uint32_t hint_n, int shift,
-                int bits, bool have_hist, uint32_t zero_key)
+                int bits, bool have_hist, uint32_t zero_key, int idx_bits, uint32_t *count_out, const uint32_t *fill_to)
 {
     constexpr uint32_t CH = 64 * NW * 8;
     const uint32_t g = grid_for(hint_n, CH);
@@ -333,14 +343,16 @@ int launch_pass(gs_ctx *ctx, const void *in, int in_fmt, void *out, int out_fmt,
     else if (in_fmt == GS_RADIX_PACKED) hipLaunchKernelGGL((k_radix_hist<true, NW>), G, B, 0, st, (const uint32_t *)in, n_ptr, shift, bits, ctx->hist);
     else hipLaunchKernelGGL((k_radix_hist<false, NW>), G, B, 0, st, (const uint32_t *)in, n_ptr, shift, bits, ctx->hist);
     hipLaunchKernelGGL((k_radix_scan<NW>), dim3(gs_div_up(gs_radix_row_stride(1u << bits), 16u)), dim3(64 * NW), 0, st, ctx->hist, n_ptr, CH, bits, totals);
-#define GS_SCATTER(I, O) do { if (bits <= 7) hipLaunchKernelGGL((k_radix_scatter<I, O, 128, NW>), G, B, 0, st, in, out, n_ptr, shift, bits, zero_key, ctx->hist, totals); \
-                              else if (bits == 8) hipLaunchKernelGGL((k_radix_scatter<I, O, 256, NW>), G, B, 0, st, in, out, n_ptr, shift, bits, zero_key, ctx->hist, totals); \
-                              else hipLaunchKernelGGL((k_radix_scatter<I, O, GS_RADIX_MAX_BINS, NW>), G, B, 0, st, in, out, n_ptr, shift, bits, zero_key, ctx->hist, totals); } while (0)
+#define GS_SCATTER(I, O) do { if (bits <= 7) hipLaunchKernelGGL((k_radix_scatter<I, O, 128, NW>), G, B, 0, st, in, out, n_ptr, shift, bits, zero_key, ctx->hist, totals, idx_bits, count_out, fill_to); \
+                              else if (bits == 8) hipLaunchKernelGGL((k_radix_scatter<I, O, 256, NW>), G, B, 0, st, in, out, n_ptr, shift, bits, zero_key, ctx->hist, totals, idx_bits, count_out, fill_to); \
+                              else hipLaunchKernelGGL((k_radix_scatter<I, O, GS_RADIX_MAX_BINS, NW>), G, B, 0, st, in, out, n_ptr, shift, bits, zero_key, ctx->hist, totals, idx_bits, count_out, fill_to); } while (0)
     if (in_fmt == GS_RADIX_PACKED && out_fmt == GS_RADIX_PACKED) GS_SCATTER(GS_RADIX_PACKED, GS_RADIX_PACKED);
     else if (in_fmt == GS_RADIX_PACKED && out_fmt == GS_RADIX_KEYS) GS_SCATTER(GS_RADIX_PACKED, GS_RADIX_KEYS);
     else if (in_fmt == GS_RADIX_KEYS && out_fmt == GS_RADIX_PACKED) GS_SCATTER(GS_RADIX_KEYS, GS_RADIX_PACKED);
     else if (in_fmt == GS_RADIX_KEYS && out_fmt == GS_RADIX_KEYS) GS_SCATTER(GS_RADIX_KEYS, GS_RADIX_KEYS);
     else if (in_fmt == GS_RADIX_KEYONLY && out_fmt == GS_RADIX_KEYONLY) GS_SCATTER(GS_RADIX_KEYONLY, GS_RADIX_KEYONLY);
+    else if (in_fmt == GS_RADIX_KEYS && out_fmt == GS_RADIX_KEYIDX) GS_SCATTER(GS_RADIX_KEYS, GS_RADIX_KEYIDX);
+    else if (in_fmt == GS_RADIX_KEYIDX && out_fmt == GS_RADIX_KEYS) GS_SCATTER(GS_RADIX_KEYIDX, GS_RADIX_KEYS);
     else { snprintf(GS_ERRBUF(ctx), GS_ERRLEN, "radix pass: unsupported record formats %d -> %d", in_fmt, out_fmt); return GS_E_BADARG; }
 #undef GS_SCATTER
     GS_HIP(hipGetLastError());
@@ -353,12 +365,13 @@ uint32_t gs_radix_chunk(uint32_t hint_n) { return hint_n > GS_RADIX_LARGE_N ? GS
 uint32_t gs_radix_grid(uint32_t hint_n) { return grid_for(hint_n, gs_radix_chunk(hint_n)); }
 
 int gs_launch_radix_pass(gs_ctx *ctx, const void *in, int in_fmt, void *out, int out_fmt, const uint32_t *n_ptr,
-                         uint32_t max_n, uint32_t hint_n, int shift, int bits, bool have_hist, uint32_t zero_key)
+                         uint32_t max_n, uint32_t hint_n, int shift, int bits, bool have_hist, uint32_t zero_key, int idx_bits,
+                         uint32_t *count_out, const uint32_t *fill_to)
 {
     if (bits < 1 || bits > 9) { snprintf(GS_ERRBUF(ctx), GS_ERRLEN, "radix pass: %d-bit digit (1..9 supported)", bits); return GS_E_BADARG; }
     if (hint_n > max_n || hint_n == 0) hint_n = max_n;
     // the geometry is a matter of speed only: both forms are exact for any *n_ptr <= max_n (a producer that pre-filled the
     // histogram rows used gs_radix_chunk(hint_n) as well)
-    return gs_radix_chunk(hint_n) == GS_CHUNK_L ? launch_pass<8>(ctx, in, in_fmt, out, out_fmt, n_ptr, hint_n, shift, bits, have_hist, zero_key)
-                                                : launch_pass<4>(ctx, in, in_fmt, out, out_fmt, n_ptr, hint_n, shift, bits, have_hist, zero_key);
+    return gs_radix_chunk(hint_n) == GS_CHUNK_L ? launch_pass<8>(ctx, in, in_fmt, out, out_fmt, n_ptr, hint_n, shift, bits, have_hist, zero_key, idx_bits, count_out, fill_to)
+                                                : launch_pass<4>(ctx, in, in_fmt, out, out_fmt, n_ptr, hint_n, shift, bits, have_hist, zero_key, idx_bits, count_out, fill_to);
 }

@@ -115,7 +115,11 @@ __global__ __launch_bounds__(GS_BLOCK) void k_sort_depth(const float4 *__restric
 // pass 2 (index.js:558-561): 16-bit bucket of the stored depth; culled -> GS_RADIX_SKIP, dropped bucket -> GS_CULLED_KEY.
 // Every workgroup first folds pass 1's partials (<= 2048 slots, L2-resident) into the global min/max.  One workgroup per
 // radix chunk (geometry NW as in gs_prims.hip): it also leaves radix pass A's histogram row of the chunk.
-template <int NW>
+// COMPACT (N <= 2^25): pass A sorts by the low 9 bucket bits and writes 4-byte records `bucket >> 9 << 25 | index`, pass B
+// by the 7 bits on top of the index: half the bytes of (key, index) records through three of the five streaming passes.
+// A 17th key bit has no room there, so kept splats with a dropped bucket leave the sort here as well; the final pass
+// zero-fills their slots [V', V) behind the sorted records (the reference's never-written tail).
+template <int NW, bool COMPACT>
 __global__ __launch_bounds__(64 * NW) void k_sort_bucket(const float *__restrict__ depth, uint32_t n, uint32_t *__restrict__ keys,
                                                          const unsigned long long *__restrict__ part_min,
                                                          const unsigned long long *__restrict__ part_max,
@@ -125,7 +129,8 @@ __global__ __launch_bounds__(64 * NW) void k_sort_bucket(const float *__restrict
     constexpr int NT = 64 * NW, IPT = 8, CH = NT * IPT;
     __shared__ unsigned long long s_min, s_max;
     __shared__ uint32_t s_cnt;
-    __shared__ uint32_t s_hist[256];                              // low-digit histogram of this chunk = radix pass A's input
+    constexpr uint32_t BINS = COMPACT ? 512u : 256u;
+    __shared__ uint32_t s_hist[BINS];                             // low-digit histogram of this chunk = radix pass A's input
     if (threadIdx.x == 0) { s_min = ~0ull; s_max = 0ull; s_cnt = 0; }
     __syncthreads();
     {
@@ -150,7 +155,7 @@ __global__ __launch_bounds__(64 * NW) void k_sort_bucket(const float *__restrict
     for (uint32_t v = blockIdx.x; v < ((nchunks + 7u) & ~7u); v += gridDim.x) {
         uint32_t c;
         if (!gs_xcd_chunk(v, nchunks, c)) continue;                // XCD-aware chunk order (as the radix kernels)
-        if (threadIdx.x < 256) s_hist[threadIdx.x] = 0;
+        for (uint32_t d = threadIdx.x; d < BINS; d += NT) s_hist[d] = 0;
         __syncthreads();
         float dd[IPT];                                               // all loads first: their latencies overlap
 #pragma unroll
@@ -169,14 +174,14 @@ __global__ __launch_bounds__(64 * NW) void k_sort_bucket(const float *__restrict
                 uint32_t k = GS_RADIX_SKIP;
                 if (d != INFINITY) {
                     const int32_t b = gsm::sort_bucket(d, mn, inv);
-                    k = b >= 0 ? (uint32_t)b : GS_CULLED_KEY;
-                    atomicAdd(&s_hist[k & 255u], 1u);
+                    if (COMPACT) { if (b >= 0) { k = (uint32_t)b; atomicAdd(&s_hist[k & 511u], 1u); } }
+                    else { k = b >= 0 ? (uint32_t)b : GS_CULLED_KEY; atomicAdd(&s_hist[k & 255u], 1u); }
                 }
                 keys[i] = k;
             }
         }
         __syncthreads();
-        if (threadIdx.x < 256) hist[(size_t)c * 256u + threadIdx.x] = s_hist[threadIdx.x];   // row c of hist[chunk][digit]
+        for (uint32_t d = threadIdx.x; d < BINS; d += NT) hist[(size_t)c * BINS + d] = s_hist[d];   // row c of hist[chunk][digit]
         __syncthreads();
     }
 }
@@ -230,19 +235,32 @@ int gs_run_sort(gs_ctx *ctx, const float view[4], const float *cutout16, const G
                                         ctx->part_min, ctx->part_max, ctx->part_cnt);
     else hipLaunchKernelGGL(k_sort_depth<false>, dim3(gd), dim3(GS_BLOCK), 0, ctx->stream, ctx->sort_rows, ctx->bound_r, n, u, su, ctx->depth,
                             ctx->part_min, ctx->part_max, ctx->part_cnt);
-    if (gs_radix_chunk(n) == GS_CHUNK_L)
-        hipLaunchKernelGGL(k_sort_bucket<8>, dim3(g), dim3(512), 0, ctx->stream, ctx->depth, n, ctx->key_a, ctx->part_min,
-                           ctx->part_max, ctx->part_cnt, gd, ctx->hist, ctx->ctl);
-    else
-        hipLaunchKernelGGL(k_sort_bucket<4>, dim3(g), dim3(256), 0, ctx->stream, ctx->depth, n, ctx->key_a, ctx->part_min,
-                           ctx->part_max, ctx->part_cnt, gd, ctx->hist, ctx->ctl);
+    // record format of the two passes: 4 bytes while the index fits in 25 bits (GS_OPT_WIDE_PAIRS forces the general form)
+    const bool compact = !ctx->wide_pairs && n <= (1u << 25);
+#define GS_LAUNCH_BUCKET(NW, C) hipLaunchKernelGGL((k_sort_bucket<NW, C>), dim3(g), dim3(64 * NW), 0, ctx->stream, ctx->depth, n, ctx->key_a, \
+                                                   ctx->part_min, ctx->part_max, ctx->part_cnt, gd, ctx->hist, ctx->ctl)
+    if (gs_radix_chunk(n) == GS_CHUNK_L) { if (compact) GS_LAUNCH_BUCKET(8, true); else GS_LAUNCH_BUCKET(8, false); }
+    else { if (compact) GS_LAUNCH_BUCKET(4, true); else GS_LAUNCH_BUCKET(4, false); }
+#undef GS_LAUNCH_BUCKET
     GS_HIP(hipGetLastError());
-    int rc = gs_launch_radix_pass(ctx, ctx->key_a, GS_RADIX_KEYS, ctx->kv_b, GS_RADIX_PACKED, &ctx->ctl->n_total, n, n, 0, 8, /*have_hist=*/true);
-    if (rc != GS_OK) return rc;
-    // pass A dropped the culled splats: V records are left.  Splats with a dropped bucket (key 65536) sort behind every
-    // bucket and store 0: the tail [V',V) of the result is 0 like the reference's never-written Uint32Array slots
-    rc = gs_launch_radix_pass(ctx, ctx->kv_b, GS_RADIX_PACKED, ctx->val_a, GS_RADIX_KEYS, &ctx->ctl->n_kept, n, n, 8, 9, false, GS_CULLED_KEY);
-    if (rc != GS_OK) return rc;
+    int rc;
+    if (compact) {
+        rc = gs_launch_radix_pass(ctx, ctx->key_a, GS_RADIX_KEYS, ctx->kv_b, GS_RADIX_KEYIDX, &ctx->ctl->n_total, n, n, 0, 9, /*have_hist=*/true,
+                                  0xFFFFFFFFu, 25, &ctx->ctl->n_sorted);
+        if (rc != GS_OK) return rc;
+        // V' records are left (culled splats and dropped buckets took no slot); slots [V', V) of the result are zero-filled:
+        // the reference's never-written Uint32Array tail
+        rc = gs_launch_radix_pass(ctx, ctx->kv_b, GS_RADIX_KEYIDX, ctx->val_a, GS_RADIX_KEYS, &ctx->ctl->n_sorted, n, n, 25, 7, false, 0xFFFFFFFFu, 0,
+                                  nullptr, &ctx->ctl->n_kept);
+        if (rc != GS_OK) return rc;
+    } else {
+        rc = gs_launch_radix_pass(ctx, ctx->key_a, GS_RADIX_KEYS, ctx->kv_b, GS_RADIX_PACKED, &ctx->ctl->n_total, n, n, 0, 8, /*have_hist=*/true);
+        if (rc != GS_OK) return rc;
+        // pass A dropped the culled splats: V records are left.  Splats with a dropped bucket (key 65536) sort behind every
+        // bucket and store 0: the tail [V',V) of the result is 0 like the reference's never-written Uint32Array slots
+        rc = gs_launch_radix_pass(ctx, ctx->kv_b, GS_RADIX_PACKED, ctx->val_a, GS_RADIX_KEYS, &ctx->ctl->n_kept, n, n, 8, 9, false, GS_CULLED_KEY);
+        if (rc != GS_OK) return rc;
+    }
     GS_PROF_RECORD(ctx, 1);
     ctx->sorted = ctx->val_a;
     ctx->have_sort = true;

@@ -70,6 +70,11 @@ def test_sort_matches_reference_worker_golden(ctx, name):
     got = ctx.sort(c["view"], c.get("cutout"))
     assert got.dtype == np.uint32 and got.size == c["sorted"].size
     assert np.array_equal(got, c["sorted"])
+    ctx.set_option(capi.OPT_WIDE_PAIRS, 1)                # the depth sort's general record format (N > 2^25)
+    try:
+        assert np.array_equal(ctx.sort(c["view"], c.get("cutout")), c["sorted"])
+    finally:
+        ctx.set_option(capi.OPT_WIDE_PAIRS, 0)
 
 
 def test_sort_before_push_answers_single_zero(ctx):
@@ -726,6 +731,14 @@ def test_sort_fuzz_specials_match_oracle(ctx, seed):
     got = ctx.sort(view, cut)
     want = oracle.sort(rows4, view, cut)
     assert got.size == want.size and np.array_equal(got, want)
+    # the general record format of the depth sort ((key, index) pairs, 8 + 9 bits: what N > 2^25 splats use) gives the same list
+    # as the compact one (`bucket >> 9 << 25 | index`, 9 + 7 bits, zero tail filled by the last pass)
+    ctx.set_option(capi.OPT_WIDE_PAIRS, 1)
+    try:
+        wide = ctx.sort(view, cut)
+    finally:
+        ctx.set_option(capi.OPT_WIDE_PAIRS, 0)
+    assert np.array_equal(wide, want)
 
 
 def _same_f32(a, b):
