@@ -198,7 +198,7 @@ __global__ __launch_bounds__(GS_BLOCK) void k_pairs_check(GsControl *ctl, uint32
                                                           int last_round, uint32_t *__restrict__ mask, uint32_t mask_total_words,
                                                           uint2 *__restrict__ extra)
 {
-    __shared__ uint32_t s_vis, s_wave[4], s_wave_e[4];
+    __shared__ uint32_t s_vis, s_wave[4], s_wave_e[4], s_tv[GS_SPINE_CACHED][GS_BLOCK], s_eb[GS_SPINE_CACHED][GS_BLOCK];
     __shared__ unsigned long long s_total64[4];
     if (threadIdx.x == 0) s_vis = 0;
     __syncthreads();
@@ -218,16 +218,20 @@ __global__ __launch_bounds__(GS_BLOCK) void k_pairs_check(GsControl *ctl, uint32
     const uint32_t lo = min(threadIdx.x * per, nsp), hi = min(lo + per, nsp);
     uint32_t s = 0;
     unsigned long long s64 = 0;                                    // the demand itself in 64 bits: a sum past 2^32 must not wrap under pair_cap
-    // (a thread's slice is read once, all loads in flight together, and kept in registers when it is short: the second
-    // pass would otherwise pay one memory round trip per element, serialised by its stores)
-    uint32_t tv[GS_SPINE_CACHED];
+    // A short slice is read once -- all its loads in flight together -- and parked in LDS: both sweeps then run as small rolled
+    // loops (this is ONE workgroup executing cold code once per frame: every instruction-cache line it touches is a memory
+    // round trip, and a sweep that re-reads global memory pays one more per element, serialised by its stores).
     const bool cached = per <= GS_SPINE_CACHED;
+    if (cached) {
+        uint32_t tv[GS_SPINE_CACHED];
+#pragma unroll
+        for (uint32_t k = 0; k < GS_SPINE_CACHED; k++) tv[k] = lo + k < hi ? spine[lo + k] : 0u;
+#pragma unroll
+        for (uint32_t k = 0; k < GS_SPINE_CACHED; k++) s_tv[k][threadIdx.x] = tv[k];
+    }
     uint32_t ne = 0;                                                // extra slices of this thread's chunks
 #define GS_EXTRA_OF(t) ((t) > GS_EMIT_PAIRS ? ((t) - 1u) / GS_EMIT_PAIRS : 0u)
-    if (cached) {
-#pragma unroll
-        for (uint32_t k = 0; k < GS_SPINE_CACHED; k++) { tv[k] = lo + k < hi ? spine[lo + k] : 0u; s += tv[k]; s64 += tv[k]; ne += GS_EXTRA_OF(tv[k]); }
-    } else for (uint32_t i = lo; i < hi; i++) { const uint32_t t = spine[i]; s += t; s64 += t; ne += GS_EXTRA_OF(t); }
+    for (uint32_t i = lo, k = 0; i < hi; i++, k++) { const uint32_t t = cached ? s_tv[k][threadIdx.x] : spine[i]; s += t; s64 += t; ne += GS_EXTRA_OF(t); }
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) s64 += ((unsigned long long)__shfl_xor((uint32_t)(s64 >> 32), m, 64) << 32) + __shfl_xor((uint32_t)s64, m, 64);
     if (lane == 0) s_total64[w] = s64;
@@ -241,15 +245,24 @@ __global__ __launch_bounds__(GS_BLOCK) void k_pairs_check(GsControl *ctl, uint32
     if (total64 > 0xFFFFFFFFull) total = 0xFFFFFFFFu;              // saturate: larger than any pair_cap (<= 0xFFFF0000)
     uint32_t run = base + inc - s, q = base_e + inc_e - ne;
     const bool fits = total <= pair_cap;                            // (then at most pair_cap / GS_EMIT_PAIRS extra slices exist)
-#define GS_SPINE_STEP(i, t) do {                                                                                       \
-        spine[i] = run; run += (t);                                                                                    \
-        if (fits) for (uint32_t k2 = 0, n2 = GS_EXTRA_OF(t); k2 < n2; k2++) extra[q++] = make_uint2((i), k2 + 1u);     \
-        } while (0)
-    if (cached) {
-#pragma unroll
-        for (uint32_t k = 0; k < GS_SPINE_CACHED; k++) if (lo + k < hi) GS_SPINE_STEP(lo + k, tv[k]);
-    } else for (uint32_t i = lo; i < hi; i++) { const uint32_t t = spine[i]; GS_SPINE_STEP(i, t); }
-#undef GS_SPINE_STEP
+    for (uint32_t i = lo, k = 0; i < hi; i++, k++) {
+        const uint32_t t = cached ? s_tv[k][threadIdx.x] : spine[i];
+        spine[i] = run; run += t;
+        const uint32_t n2 = fits ? GS_EXTRA_OF(t) : 0u;
+        if (cached) s_eb[k][threadIdx.x] = q;
+        else for (uint32_t k2 = 0; k2 < n2; k2++) extra[q + k2] = make_uint2(i, k2 + 1u);
+        q += n2;
+    }
+    if (cached && fits) {
+        // the extra slices are written with the chunks dealt out round-robin: the heavy chunks are neighbours (the nearest
+        // splats), i.e. all in the slices of a few threads, which would write hundreds of entries each
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < nsp; i += GS_BLOCK) {
+            const uint32_t owner = i / per, k = i % per;
+            const uint32_t n2 = GS_EXTRA_OF(s_tv[k][owner]), qb = s_eb[k][owner];
+            for (uint32_t k2 = 0; k2 < n2; k2++) extra[qb + k2] = make_uint2(i, k2 + 1u);
+        }
+    }
 #undef GS_EXTRA_OF
     if (threadIdx.x == 0) {
         ctl->n_emit_extra = fits ? total_e : 0u;
