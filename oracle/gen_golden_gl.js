@@ -1,0 +1,167 @@
+#!/usr/bin/env node
+// TEST INFRASTRUCTURE (oracle side). Not part of the product path.
+//
+// Pixel goldens from the reference's OWN shaders.  Runs the reference component (/root/reference/index.js, read by absolute
+// path, never copied) under node with recording stand-ins for the three.js objects it builds in initGL (index.js:26-221):
+// the ShaderMaterial's vertex / fragment shader text, blending and depth flags, the quad's vertex positions, the two data
+// textures that pushDataBuffer fills, the instanced index attribute that the worker's reply fills, and the uniforms that
+// material.onBeforeRender computes -- everything the WebGL draw consumes.  That draw is then executed by oracle/_ref/gl_ref
+// (oracle/gl_ref.c: Mesa llvmpipe through the DRI swrast interface, no X server needed) and its framebuffers are stored as
+// fixtures: tests/golden/gl_<case>.bin + manifest_gl.json.  A fixture holds DATA only (scene rows, camera, the reference's
+// sorted order and uniforms, pixels); the shader text goes to a scratch directory under oracle/_ref/ (git-ignored) and is
+// never stored in the repository.
+//
+// Runs only in the build container (needs /root/reference and Mesa's swrast_dri.so).  On the GPU box the committed fixtures
+// are used and this script is never executed.
+//
+//   python oracle/make_gl_scenes.py      # scene rows + cameras -> oracle/_ref/gl_scenes/ (same generator as the benchmark's)
+//   node oracle/gen_golden_gl.js         # regenerate tests/golden/gl_*.bin
+'use strict';
+const fs = require('fs');
+const path = require('path');
+const vm = require('vm');
+const { execFileSync } = require('child_process');
+const T = require('./three_standin.js');
+
+const REF = '/root/reference/index.js';
+const OUT = path.join(__dirname, '..', 'tests', 'golden');
+const SCRATCH = path.join(__dirname, '_ref');
+const GLREF = path.join(SCRATCH, 'gl_ref');
+const SCENES = path.join(SCRATCH, 'gl_scenes');
+if (!fs.existsSync(REF)) { console.error('reference not present; nothing to do'); process.exit(0); }
+if (!fs.existsSync(GLREF)) { console.error('oracle/_ref/gl_ref not built (python __graft_entry__.py)'); process.exit(1); }
+
+// ---------------------------------------------------------------- recording stand-ins for what initGL constructs
+class DataTexture { constructor(data, width, height, format, type) { Object.assign(this, { data, width, height, format, type, needsUpdate: false }); } }
+class BufferAttribute {
+  constructor(array, itemSize) { this.array = array; this.itemSize = itemSize; this.needsUpdate = false; }
+  setXYZ(i, x, y, z) { this.array[i * 3] = x; this.array[i * 3 + 1] = y; this.array[i * 3 + 2] = z; return this; }
+  set(values) { this.array.set(values); return this; }
+  setUsage() { return this; }
+}
+class InstancedBufferAttribute extends BufferAttribute {}
+class BufferGeometry {
+  constructor() { this.attributes = {}; }
+  setAttribute(name, attr) { this.attributes[name] = attr; return this; }
+  copy(g) { Object.assign(this.attributes, g.attributes); return this; }
+}
+class InstancedBufferGeometry extends BufferGeometry { constructor() { super(); this.instanceCount = Infinity; } }
+class ShaderMaterial { constructor(p) { Object.assign(this, p); } }
+class Mesh { constructor(geometry, material) { this.geometry = geometry; this.material = material; this.frustumCulled = true; } }
+const THREE = Object.assign({}, T, {
+  DataTexture, BufferAttribute, InstancedBufferAttribute, BufferGeometry, InstancedBufferGeometry, ShaderMaterial, Mesh,
+  RGBA: 'RGBA', FloatType: 'Float', RGBAIntegerFormat: 'RGBAInteger', UnsignedIntType: 'UnsignedInt', DynamicDrawUsage: 'Dynamic',
+  CustomBlending: 'CustomBlending', OneFactor: 'One',
+});
+
+let def;
+const quiet = { log() {}, error() {}, time() {}, timeEnd() {} };
+const ctx = {
+  AFRAME: { registerComponent: (n, d) => { def = d; } }, THREE, console: quiet, TextDecoder, Math, parseInt, Float32Array, Uint8Array,
+  Uint32Array, Int16Array, Int32Array, Uint8ClampedArray, DataView, ArrayBuffer, Proxy, Error, Promise, setTimeout, Infinity,
+};
+vm.createContext(ctx);
+vm.runInContext(fs.readFileSync(REF, 'utf8'), ctx, { filename: REF });
+
+// ---------------------------------------------------------------- fixture writer (same container format as gen_golden.js)
+const DT = new Map([[Float32Array, 'f4'], [Float64Array, 'f8'], [Uint32Array, 'u4'], [Uint8Array, 'u1']]);
+const manifest = {};
+function emit(name, arrays, meta) {
+  const chunks = []; let off = 0; const desc = {};
+  for (const k of Object.keys(arrays)) {
+    const a = arrays[k]; const dt = DT.get(a.constructor);
+    if (!dt) throw new Error('dtype? ' + k);
+    const b = Buffer.from(a.buffer, a.byteOffset, a.byteLength);
+    desc[k] = { dtype: dt, count: a.length, offset: off };
+    chunks.push(b); off += b.length;
+    const pad = (8 - (off % 8)) % 8; if (pad) { chunks.push(Buffer.alloc(pad)); off += pad; }
+  }
+  fs.writeFileSync(path.join(OUT, name + '.bin'), Buffer.concat(chunks));
+  manifest[name] = { kind: 'gl', arrays: desc, meta: meta || {} };
+}
+
+// ---------------------------------------------------------------- one case: the reference's own load -> sort -> draw-state path
+async function glCase(name, sc) {
+  const W = sc.width, H = sc.height, TEXW = 1024;              // gl.MAX_TEXTURE_SIZE as this "renderer" reports it (texture width, index.js:31-40)
+  const rows = fs.readFileSync(path.join(SCENES, sc.rows));
+  const n = rows.length / 32;
+  const M = (e) => { const m = new THREE.Matrix4(); m.elements = Array.from(e); return m; };
+  const gl = { MAX_TEXTURE_SIZE: 'MAX', TEXTURE_2D: 1, RGBA: 2, FLOAT: 3, RGBA_INTEGER: 4, UNSIGNED_INT: 5,
+    getParameter: () => TEXW, bindTexture() {}, texSubImage2D() {} };
+  let mesh = null;
+  const self = Object.create(def);
+  const workerSelf = { postMessage: (m) => { self.worker.onmessage({ data: m }); } };
+  def.createWorker(workerSelf);                                 // the reference's worker code, wired back to back
+  Object.assign(self, {
+    data: {}, loadedVertexCount: 0, rowLength: 32, sortReady: false,
+    camera: { matrixWorld: M(sc.cam_world), projectionMatrix: M(sc.proj) },
+    object: { matrixWorld: M(sc.obj_world), add: (m) => { mesh = m; }, frustumCulled: true },
+    renderer: { getContext: () => gl, properties: { get: () => ({ __webglTexture: {} }) },
+      getCurrentViewport: (v) => { v.x = 0; v.y = 0; v.z = W; v.w = H; return v; } },
+    worker: { postMessage: (m) => { workerSelf.onmessage({ data: m }); }, onmessage: null },
+  });
+  if (sc.cutout_world) self.cutout = { matrixWorld: M(sc.cutout_world) };
+  await self.initGL(n);                                          // index.js:26-221: textures, geometry, material, reply handler
+  const ab = rows.buffer.slice(rows.byteOffset, rows.byteOffset + rows.length);
+  self.pushDataBuffer(ab, n);                                    // index.js:328-437: fills both textures, pushes the worker rows
+  self.sortReady = true;
+  self.tick(0, 0);                                               // index.js:438-455 -> worker sort -> reply handler (index.js:201-207)
+  const mat = mesh.material, geo = mesh.geometry;
+  mat.onBeforeRender(self.renderer, null, self.camera, geo, mesh, null);   // index.js:184-195
+  const count = geo.instanceCount;
+  const u = mat.uniforms;
+  if (mat.blending !== 'CustomBlending' || mat.blendSrcAlpha !== 'One' || mat.blendSrc !== undefined || mat.blendDst !== undefined ||
+      mat.blendEquation !== undefined || mat.transparent !== true) throw new Error('material state differs from what gl_ref sets up');
+
+  // ---- the draw, on Mesa
+  const job = path.join(SCRATCH, 'gl_job_' + name);
+  fs.mkdirSync(job, { recursive: true });
+  fs.writeFileSync(path.join(job, 'vs.glsl'), mat.vertexShader);
+  fs.writeFileSync(path.join(job, 'fs.glsl'), mat.fragmentShader);
+  const f32 = (a) => Buffer.from(new Float32Array(a).buffer);
+  fs.writeFileSync(path.join(job, 'positions.bin'), f32(geo.attributes.position.array));
+  const idx = new Uint32Array(geo.attributes.splatIndex.array.buffer, 0, count);
+  fs.writeFileSync(path.join(job, 'index.bin'), Buffer.from(idx.buffer, idx.byteOffset, Math.max(4, count * 4)));
+  const cs = self.centerAndScaleTexture, cc = self.covAndColorTexture;
+  fs.writeFileSync(path.join(job, 'cs.bin'), Buffer.from(cs.data.buffer, cs.data.byteOffset, cs.data.byteLength));
+  fs.writeFileSync(path.join(job, 'cc.bin'), Buffer.from(cc.data.buffer, cc.data.byteOffset, cc.data.byteLength));
+  const fl = (a) => Array.from(new Float32Array(a)).map((v) => v.toPrecision(9)).join(' ');
+  fs.writeFileSync(path.join(job, 'job.txt'), [
+    'width ' + W, 'height ' + H, 'tex_width ' + cs.width, 'tex_height ' + cs.height, 'instances ' + count,
+    'depth_test ' + (mat.depthTest ? 1 : 0), 'depth_write ' + (mat.depthWrite ? 1 : 0),
+    'viewport ' + fl(u.viewport.value), 'focal ' + fl([u.focal.value]), 'clear 0 0 0 1',
+    'projection ' + fl(u.gsProjectionMatrix.value.elements), 'model_view ' + fl(u.gsModelViewMatrix.value.elements), ''].join('\n'));
+  for (const k of ['scene_depth', 'scene_rgba']) if (sc[k]) fs.copyFileSync(path.join(SCENES, sc[k]), path.join(job, k + '.bin'));
+  execFileSync(GLREF, [job], { stdio: 'inherit' });
+  const info = {};
+  for (const line of fs.readFileSync(path.join(job, 'out.txt'), 'utf8').split('\n')) { const k = line.indexOf(' '); if (k > 0) info[line.slice(0, k)] = line.slice(k + 1); }
+  const rgba8 = new Uint8Array(fs.readFileSync(path.join(job, 'out_rgba8.bin')));
+  const fb = fs.readFileSync(path.join(job, 'out_float.bin'));
+  const rgbaf = new Float32Array(fb.buffer, fb.byteOffset, fb.length / 4);
+  // the float framebuffer rounded ONCE to RGBA8 (clamp, * 255, + 0.5, truncate): what the reference's shading, raster and
+  // blend give without the per-fragment unorm8 rounding of an 8-bit colour buffer
+  const rgbaOnce = new Uint8Array(rgbaf.length);
+  for (let i = 0; i < rgbaf.length; i++) rgbaOnce[i] = Math.floor(Math.fround(Math.fround(Math.min(Math.max(rgbaf[i], 0), 1) * 255) + 0.5));
+  const sceneArrays = {};
+  if (sc.scene_depth) { const b = fs.readFileSync(path.join(SCENES, sc.scene_depth)); sceneArrays.scene_depth = Float32Array.from(new Float32Array(b.buffer, b.byteOffset, b.length / 4)); }
+  if (sc.scene_rgba) sceneArrays.scene_rgba = new Uint8Array(fs.readFileSync(path.join(SCENES, sc.scene_rgba)));
+  emit('gl_' + name, Object.assign({
+    rows: new Uint8Array(rows), cam_world: new Float64Array(sc.cam_world), obj_world: new Float64Array(sc.obj_world), proj: new Float64Array(sc.proj),
+    cutout_world: new Float64Array(sc.cutout_world || []), sorted: Uint32Array.from(idx),
+    gs_mv: new Float64Array(u.gsModelViewMatrix.value.elements), gs_proj: new Float64Array(u.gsProjectionMatrix.value.elements),
+    viewport: new Float64Array(u.viewport.value), focal: new Float64Array([u.focal.value]),
+    rgba8_fb: rgba8, rgba_float_fb_rounded: rgbaOnce,
+  }, sceneArrays), { n, width: W, height: H, instances: count, fragments: Number(info.fragments_float), fragments_rgba8_fb: Number(info.fragments_rgba8),
+    renderer: info.renderer, gl_version: info.version, has_cutout: !!sc.cutout_world, has_scene: !!(sc.scene_depth || sc.scene_rgba), note: sc.note });
+  console.log('gl_' + name + ':', n, 'splats,', count, 'instances,', info.fragments_float, 'fragments,', info.renderer);
+  for (const f of fs.readdirSync(job)) fs.unlinkSync(path.join(job, f));   // the scratch copy of the shader text does not outlive the run
+  fs.rmdirSync(job);
+}
+
+(async () => {
+  const scenes = JSON.parse(fs.readFileSync(path.join(SCENES, 'scenes.json'), 'utf8'));
+  for (const name of Object.keys(scenes)) await glCase(name, scenes[name]);
+  fs.writeFileSync(path.join(OUT, 'manifest_gl.json'), JSON.stringify(manifest, null, 1));
+  let bytes = 0; for (const f of fs.readdirSync(OUT)) if (f.startsWith('gl_')) bytes += fs.statSync(path.join(OUT, f)).size;
+  console.log('wrote', Object.keys(manifest).length, 'GL cases,', bytes, 'bytes ->', OUT);
+})().catch((e) => { console.error('FAILED:', e); process.exit(1); });

@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""TEST INFRASTRUCTURE (oracle side).  Scenes for oracle/gen_golden_gl.js: .splat rows from the benchmark's generator and
+the three.js-style camera inputs (camera / entity / cutout world matrices, projection matrix) of the demo poses, written to
+oracle/_ref/gl_scenes/ (scratch, git-ignored).  The uniforms are NOT computed here: the reference computes them itself."""
+import importlib, json, math, os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+synth = importlib.import_module("aframe-gaussian-splatting_amd.synth")
+OUT = os.path.join(ROOT, "oracle", "_ref", "gl_scenes"); os.makedirs(OUT, exist_ok=True)
+scenes = {}
+
+
+def scene(name, rows, w, h, cam, obj, proj, cutout=None, note="", depth=None, rgba=None):
+    fn = name + ".splat"
+    open(os.path.join(OUT, fn), "wb").write(np.ascontiguousarray(rows).tobytes())
+    scenes[name] = {"rows": fn, "width": w, "height": h, "cam_world": list(map(float, cam)), "obj_world": list(map(float, obj)),
+                    "proj": list(map(float, proj)), "cutout_world": (list(map(float, cutout)) if cutout is not None else None), "note": note}
+    if depth is not None:
+        open(os.path.join(OUT, name + ".depth"), "wb").write(np.ascontiguousarray(depth, "<f4").tobytes()); scenes[name]["scene_depth"] = name + ".depth"
+    if rgba is not None:
+        open(os.path.join(OUT, name + ".rgba"), "wb").write(np.ascontiguousarray(rgba, np.uint8).tobytes()); scenes[name]["scene_rgba"] = name + ".rgba"
+
+
+# index.html:13 pose, entity yaw 40 deg: the benchmark's scene generator at a size the software rasteriser finishes in seconds
+scene("index_yaw40", synth.make_splat_rows(4000, seed=401), 320, 180, synth.compose((0.0, 1.6, 0.0)), synth.compose((0.0, 1.5, -2.0), 40.0),
+      synth.perspective(80.0, 320 / 180), note="index.html:13 pose, entity yaw 40 deg, 4000 splats, 320x180")
+# cutout-demo.html:22-24 pose with the cutout box
+scene("cutout_demo", synth.make_splat_rows(8000, seed=402), 320, 180, synth.compose((5.132, 1.6, 7.237)), synth.compose((0.0, 0.8, -2.0), 15.0, (2.0, 2.0, 2.0)),
+      synth.perspective(80.0, 320 / 180), cutout=synth.compose((0.8145, 1.73322, -2.35981), 0.0, (4.17, 2.95, 3.89)),
+      note="cutout-demo.html:22-24 pose with its cutout box, 8000 splats, 320x180")
+# XR-like eye: asymmetric frustum, odd viewport (1032x1104 / 4)
+near, far = 0.005, 10000.0
+proj = synth.frustum(-math.tan(math.radians(54)) * near, math.tan(math.radians(40)) * near, math.tan(math.radians(44)) * near,
+                     -math.tan(math.radians(55)) * near, near, far)
+scene("xr_left_eye", synth.make_splat_rows(3000, seed=403), 258, 276, synth.compose((-0.032, 1.6, 0.0)), synth.compose((0.0, 1.5, -2.0), 200.0), proj,
+      note="left XR eye (asymmetric frustum, SURVEY 8d), 3000 splats, 258x276 (the sort uses this camera: one context per eye)")
+# the splats inside a three.js scene: an opaque surface drawn first (its window-space depth and colour are in the framebuffer
+# when the transparent splat mesh is drawn with depthTest on, depthWrite off: index.js:179-180)
+w, h = 256, 144
+yy, xx = np.mgrid[0:h, 0:w]
+dist = 2.2 + 3.5 * (xx / (w - 1.0)) + 0.8 * np.sin(yy / 17.0)             # metres in front of the camera, varies over the image
+zndc = (far + near) / (far - near) - 2.0 * far * near / ((far - near) * dist)
+depth = (0.5 * zndc + 0.5).astype(np.float32)
+depth[(xx // 32 + yy // 24) % 5 == 0] = 1.0                               # holes: nothing opaque there
+rgba = np.zeros((h, w, 4), np.uint8)
+rgba[..., 0] = (xx * 255 // (w - 1)).astype(np.uint8); rgba[..., 1] = (yy * 255 // (h - 1)).astype(np.uint8)
+rgba[..., 2] = (((xx // 16 + yy // 16) % 2) * 180 + 40).astype(np.uint8); rgba[..., 3] = 255
+scene("index_yaw130_scene", synth.make_splat_rows(4000, seed=404), w, h, synth.compose((0.0, 1.6, 0.0)), synth.compose((0.0, 1.5, -2.0), 130.0),
+      synth.perspective(80.0, w / h), depth=depth, rgba=rgba,
+      note="index.html pose, yaw 130 deg, drawn over an opaque scene (depth LEQUAL, no depth write; colour = destination), 4000 splats, 256x144")
+json.dump(scenes, open(os.path.join(OUT, "scenes.json"), "w"), indent=1)
+print("wrote", len(scenes), "scenes ->", OUT)

@@ -21,6 +21,18 @@ def build(force=False):
     return _SO
 
 
+def build_gl_ref():
+    """oracle/_ref/gl_ref: the harness that draws the reference's own shaders on Mesa (oracle/gl_ref.c).  Only where the
+    reference is present (the build container): its output -- tests/golden/gl_*.bin -- is what travels."""
+    src, out = os.path.join(_HERE, "gl_ref.c"), os.path.join(_HERE, "_ref", "gl_ref")
+    if not os.path.exists("/root/reference/index.js") or not os.path.exists("/usr/include/GL/internal/dri_interface.h"):
+        return None
+    if not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(src):
+        os.makedirs(os.path.dirname(out), exist_ok=True)
+        subprocess.check_call(["gcc", "-O2", "-Wall", "-o", out, src, "-ldl"])
+    return out
+
+
 class ProjT(C.Structure):
     _fields_ = [("visible", C.c_int32)] + [(n, C.c_float) for n in (
         "cx", "cy", "ax", "ay", "bx", "by", "v1x", "v1y", "v2x", "v2y", "zndc", "r", "g", "b", "alpha")]

@@ -1138,3 +1138,37 @@ def test_asynchronous_host_frames_equal_synchronous_ones(scene_small):
         c.sync()
         for _, o in pinned:
             o.free()
+
+
+# ---------------------------------------------------------------- the reference's own GLSL (drawn by Mesa) as the pixel golden
+
+import test_gl_pin as _glpin
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not _glpin.MAN, reason="GL goldens not generated")
+@pytest.mark.parametrize("name", sorted(_glpin.MAN))
+def test_hip_frames_match_reference_glsl_goldens(name):
+    """The HIP path against framebuffers that the reference's OWN vertex / fragment shaders, material state, textures,
+    sorted order and uniforms produced on Mesa llvmpipe (oracle/gen_golden_gl.js + oracle/gl_ref.c; see tests/test_gl_pin.py
+    for the two forms of the golden and the tolerances): the pin of SURVEY.md 8a rows 7-9 that does not go through the
+    build's own restatement."""
+    c = _glpin.load_gl(name)
+    w, h = c["meta"]["width"], c["meta"]["height"]
+    rows = c["rows"].reshape(-1, 32)
+    cut = c["cutout_world"] if c["cutout_world"].size else None
+    view, cutm = capi.tick_uniforms(c["cam_world"], c["obj_world"], cut)
+    sd, sr = _glpin.scene_of(c)
+    with capi.Context(0) as cx:
+        cx.push_splat(rows)
+        idx = cx.sort(view, cutm)
+        assert np.array_equal(idx, c["sorted"])                            # the order the reference's worker posted
+        if sd is not None or sr is not None:
+            cx.set_scene(sd, sr)
+        prm = capi.make_params(capi.model_view_matrix(c["cam_world"], c["obj_world"]), capi.projection_matrix(c["proj"]), w, h,
+                               focal_=capi.focal(c["gs_proj"], h))
+        img = cx.render(prm)
+        prm.flags = capi.RENDER_COUNT_FRAGS
+        cx.render(prm)
+        frags = cx.stats()["n_frags"]
+    _glpin.gl_compare(np.asarray(img).reshape(h, w, 4), frags, c, "HIP vs GLSL-on-Mesa: " + name)
