@@ -10,11 +10,14 @@
  *   sort / pack / ply / camera : PINNED -- checked bit-for-bit against golden
  *       vectors produced by executing the reference's own JavaScript under
  *       node (oracle/gen_golden.js -> tests/golden/, tests/test_oracle_golden.py).
- *   project / raster / blend   : PARITY UNPINNED -- the reference half is GLSL +
- *       fixed-function WebGL, which cannot run here (no GL) and for which the
- *       reference ships no tests or golden images.  This file restates
- *       index.js:77-181 in fp32 with a fixed operation order; it is the pixel
- *       oracle of last resort.
+ *   project / raster / blend   : PINNED against the reference's own GLSL as Mesa
+ *       llvmpipe executes it -- oracle/gen_golden_gl.js captures the shaders,
+ *       material state, textures, order and uniforms from the reference
+ *       component under node, oracle/gl_ref.c draws them (headless GL through
+ *       the DRI swrast interface), tests/test_gl_pin.py compares: equal
+ *       fragment counts, max 1 LSB against the float-framebuffer image.  This
+ *       file restates index.js:77-181 in fp32 with a fixed operation order; at
+ *       sizes a software rasteriser cannot draw it is the pixel oracle.
  *
  * Build: see oracle/Makefile (gcc -O2 -ffp-contract=off; no fast-math: the
  * sort contract needs un-fused IEEE f64).
