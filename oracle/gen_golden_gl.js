@@ -7,7 +7,7 @@
 // textures that pushDataBuffer fills, the instanced index attribute that the worker's reply fills, and the uniforms that
 // material.onBeforeRender computes -- everything the WebGL draw consumes.  That draw is then executed by oracle/_ref/gl_ref
 // (oracle/gl_ref.c: Mesa llvmpipe through the DRI swrast interface, no X server needed) and its framebuffers are stored as
-// fixtures: tests/golden/gl_<case>.bin + manifest_gl.json.  A fixture holds DATA only (scene rows, camera, the reference's
+// fixtures: tests/golden/gl_<case>.bin.gz + manifest_gl.json.  A fixture holds DATA only (scene rows, camera, the reference's
 // sorted order and uniforms, pixels); the shader text goes to a scratch directory under oracle/_ref/ (git-ignored) and is
 // never stored in the repository.
 //
@@ -15,12 +15,14 @@
 // are used and this script is never executed.
 //
 //   python oracle/make_gl_scenes.py      # scene rows + cameras -> oracle/_ref/gl_scenes/ (same generator as the benchmark's)
-//   node oracle/gen_golden_gl.js         # regenerate tests/golden/gl_*.bin
+//   node oracle/gen_golden_gl.js         # regenerate tests/golden/gl_*.bin.gz
 'use strict';
 const fs = require('fs');
 const path = require('path');
 const vm = require('vm');
 const { execFileSync } = require('child_process');
+const crypto = require('crypto');
+const zlib = require('zlib');
 const T = require('./three_standin.js');
 
 const REF = '/root/reference/index.js';
@@ -76,15 +78,17 @@ function emit(name, arrays, meta) {
     chunks.push(b); off += b.length;
     const pad = (8 - (off % 8)) % 8; if (pad) { chunks.push(Buffer.alloc(pad)); off += pad; }
   }
-  fs.writeFileSync(path.join(OUT, name + '.bin'), Buffer.concat(chunks));
+  fs.writeFileSync(path.join(OUT, name + '.bin.gz'), zlib.gzipSync(Buffer.concat(chunks), { level: 9 }));   // (images: 3-5x smaller)
   manifest[name] = { kind: 'gl', arrays: desc, meta: meta || {} };
 }
 
 // ---------------------------------------------------------------- one case: the reference's own load -> sort -> draw-state path
 async function glCase(name, sc) {
-  const W = sc.width, H = sc.height, TEXW = 1024;              // gl.MAX_TEXTURE_SIZE as this "renderer" reports it (texture width, index.js:31-40)
+  const W = sc.width, H = sc.height;
   const rows = fs.readFileSync(path.join(SCENES, sc.rows));
   const n = rows.length / 32;
+  // gl.MAX_TEXTURE_SIZE as this "renderer" reports it: the texture width, and its square the splat capacity (index.js:31-40)
+  const TEXW = n > (1 << 20) ? 4096 : 1024;
   const M = (e) => { const m = new THREE.Matrix4(); m.elements = Array.from(e); return m; };
   const gl = { MAX_TEXTURE_SIZE: 'MAX', TEXTURE_2D: 1, RGBA: 2, FLOAT: 3, RGBA_INTEGER: 4, UNSIGNED_INT: 5,
     getParameter: () => TEXW, bindTexture() {}, texSubImage2D() {} };
@@ -107,7 +111,9 @@ async function glCase(name, sc) {
   self.sortReady = true;
   self.tick(0, 0);                                               // index.js:438-455 -> worker sort -> reply handler (index.js:201-207)
   const mat = mesh.material, geo = mesh.geometry;
-  mat.onBeforeRender(self.renderer, null, self.camera, geo, mesh, null);   // index.js:184-195
+  // (XR: three.js draws each eye with the eye's camera, while tick sorted from this.camera, the head: index.js:441 vs 185-187)
+  const drawCamera = sc.eye_cam_world ? { matrixWorld: M(sc.eye_cam_world), projectionMatrix: M(sc.eye_proj) } : self.camera;
+  mat.onBeforeRender(self.renderer, null, drawCamera, geo, mesh, null);   // index.js:184-195
   const count = geo.instanceCount;
   const u = mat.uniforms;
   if (mat.blending !== 'CustomBlending' || mat.blendSrcAlpha !== 'One' || mat.blendSrc !== undefined || mat.blendDst !== undefined ||
@@ -129,7 +135,7 @@ async function glCase(name, sc) {
   fs.writeFileSync(path.join(job, 'job.txt'), [
     'width ' + W, 'height ' + H, 'tex_width ' + cs.width, 'tex_height ' + cs.height, 'instances ' + count,
     'depth_test ' + (mat.depthTest ? 1 : 0), 'depth_write ' + (mat.depthWrite ? 1 : 0),
-    'viewport ' + fl(u.viewport.value), 'focal ' + fl([u.focal.value]), 'clear 0 0 0 1',
+    'viewport ' + fl(u.viewport.value), 'focal ' + fl([u.focal.value]), 'clear 0 0 0 1', sc.strip ? 'strip ' + sc.strip[0] + ' ' + sc.strip[1] : '',
     'projection ' + fl(u.gsProjectionMatrix.value.elements), 'model_view ' + fl(u.gsModelViewMatrix.value.elements), ''].join('\n'));
   for (const k of ['scene_depth', 'scene_rgba']) if (sc[k]) fs.copyFileSync(path.join(SCENES, sc[k]), path.join(job, k + '.bin'));
   execFileSync(GLREF, [job], { stdio: 'inherit' });
@@ -145,14 +151,21 @@ async function glCase(name, sc) {
   const sceneArrays = {};
   if (sc.scene_depth) { const b = fs.readFileSync(path.join(SCENES, sc.scene_depth)); sceneArrays.scene_depth = Float32Array.from(new Float32Array(b.buffer, b.byteOffset, b.length / 4)); }
   if (sc.scene_rgba) sceneArrays.scene_rgba = new Uint8Array(fs.readFileSync(path.join(SCENES, sc.scene_rgba)));
+  // big scenes (the BASELINE sizes) are stored by recipe: the generator call that makes the rows + their SHA-1, the SHA-1 of the
+  // reference's sorted order, and a column strip of the frame (drawn with a scissor)
+  const sha1 = (b) => crypto.createHash('sha1').update(b).digest('hex');
+  const small = sc.store_rows !== false;
   emit('gl_' + name, Object.assign({
-    rows: new Uint8Array(rows), cam_world: new Float64Array(sc.cam_world), obj_world: new Float64Array(sc.obj_world), proj: new Float64Array(sc.proj),
-    cutout_world: new Float64Array(sc.cutout_world || []), sorted: Uint32Array.from(idx),
+    rows: small ? new Uint8Array(rows) : new Uint8Array(0), cam_world: new Float64Array(sc.cam_world), obj_world: new Float64Array(sc.obj_world),
+    proj: new Float64Array(sc.proj), cutout_world: new Float64Array(sc.cutout_world || []), sorted: small ? Uint32Array.from(idx) : new Uint32Array(0),
+    eye_cam_world: new Float64Array(sc.eye_cam_world || []), eye_proj: new Float64Array(sc.eye_proj || []),
     gs_mv: new Float64Array(u.gsModelViewMatrix.value.elements), gs_proj: new Float64Array(u.gsProjectionMatrix.value.elements),
     viewport: new Float64Array(u.viewport.value), focal: new Float64Array([u.focal.value]),
     rgba8_fb: rgba8, rgba_float_fb_rounded: rgbaOnce,
-  }, sceneArrays), { n, width: W, height: H, instances: count, fragments: Number(info.fragments_float), fragments_rgba8_fb: Number(info.fragments_rgba8),
-    renderer: info.renderer, gl_version: info.version, has_cutout: !!sc.cutout_world, has_scene: !!(sc.scene_depth || sc.scene_rgba), note: sc.note });
+  }, sceneArrays), { n, width: W, height: H, strip: sc.strip || [0, W], instances: count, fragments: Number(info.fragments_float),
+    fragments_rgba8_fb: Number(info.fragments_rgba8), renderer: info.renderer, gl_version: info.version, has_cutout: !!sc.cutout_world,
+    has_scene: !!(sc.scene_depth || sc.scene_rgba), rows_sha1: sha1(rows), sorted_sha1: sha1(Buffer.from(idx.buffer, idx.byteOffset, count * 4)),
+    rows_recipe: sc.rows_recipe || null, note: sc.note });
   console.log('gl_' + name + ':', n, 'splats,', count, 'instances,', info.fragments_float, 'fragments,', info.renderer);
   for (const f of fs.readdirSync(job)) fs.unlinkSync(path.join(job, f));   // the scratch copy of the shader text does not outlive the run
   fs.rmdirSync(job);
@@ -162,6 +175,9 @@ async function glCase(name, sc) {
   const scenes = JSON.parse(fs.readFileSync(path.join(SCENES, 'scenes.json'), 'utf8'));
   for (const name of Object.keys(scenes)) await glCase(name, scenes[name]);
   fs.writeFileSync(path.join(OUT, 'manifest_gl.json'), JSON.stringify(manifest, null, 1));
+  // the scratch scenes (up to 200 MB of rows) are not needed any more -- and oracle/_ref/ travels to the GPU box
+  for (const f of fs.readdirSync(SCENES)) fs.unlinkSync(path.join(SCENES, f));
+  fs.rmdirSync(SCENES);
   let bytes = 0; for (const f of fs.readdirSync(OUT)) if (f.startsWith('gl_')) bytes += fs.statSync(path.join(OUT, f)).size;
   console.log('wrote', Object.keys(manifest).length, 'GL cases,', bytes, 'bytes ->', OUT);
 })().catch((e) => { console.error('FAILED:', e); process.exit(1); });

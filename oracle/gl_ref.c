@@ -62,7 +62,7 @@ GLF(void, glDrawArraysInstanced, GLenum, GLint, GLsizei, GLsizei); GLF(void, glF
 GLF(void, glReadPixels, GLint, GLint, GLsizei, GLsizei, GLenum, GLenum, void *);
 GLF(void, glGenQueries, GLsizei, GLuint *); GLF(void, glBeginQuery, GLenum, GLuint); GLF(void, glEndQuery, GLenum);
 GLF(void, glGetQueryObjectui64v, GLuint, GLenum, GLuint64 *);
-GLF(void, glCullFace, GLenum); GLF(void, glFrontFace, GLenum);
+GLF(void, glCullFace, GLenum); GLF(void, glFrontFace, GLenum); GLF(void, glScissor, GLint, GLint, GLsizei, GLsizei);
 #define LOAD(name) do { *(void **)(&p_##name) = gpa(#name); if (!p_##name) { fprintf(stderr, "gl_ref: no %s\n", #name); return 2; } } while (0)
 
 static char *slurp(const char *dir, const char *name, size_t *len)
@@ -104,7 +104,7 @@ int main(int argc, char **argv)
     if (argc < 2) { fprintf(stderr, "usage: gl_ref <job dir>\n"); return 2; }
     const char *dir = argv[1];
     // ---- job description
-    int W = 0, H = 0, texw = 0, texh = 0, count = 0, depth_test = 1, depth_write = 0;
+    int W = 0, H = 0, texw = 0, texh = 0, count = 0, depth_test = 1, depth_write = 0, sx0 = 0, sx1 = 0;
     float viewport[2] = { 0, 0 }, focal = 0, proj[16], mv[16], clear[4] = { 0, 0, 0, 1 };
     {
         char *t = slurp(dir, "job.txt", NULL), *save = NULL;
@@ -117,6 +117,7 @@ int main(int argc, char **argv)
             else if (!strcmp(key, "instances")) count = atoi(v); else if (!strcmp(key, "depth_test")) depth_test = atoi(v);
             else if (!strcmp(key, "depth_write")) depth_write = atoi(v); else if (!strcmp(key, "focal")) focal = strtof(v, NULL);
             else if (!strcmp(key, "viewport")) sscanf(v, "%f %f", &viewport[0], &viewport[1]);
+            else if (!strcmp(key, "strip")) sscanf(v, "%d %d", &sx0, &sx1);
             else if (!strcmp(key, "clear")) sscanf(v, "%f %f %f %f", &clear[0], &clear[1], &clear[2], &clear[3]);
             else if (!strcmp(key, "projection") || !strcmp(key, "model_view")) {
                 float *m = key[0] == 'p' ? proj : mv; char *e = (char *)v;
@@ -126,6 +127,8 @@ int main(int argc, char **argv)
         free(t);
     }
     if (W <= 0 || H <= 0 || texw <= 0 || texh <= 0 || count < 0) { fprintf(stderr, "gl_ref: bad job\n"); return 2; }
+    if (sx1 <= sx0) { sx0 = 0; sx1 = W; }                           // `strip x0 x1`: only these pixel columns are drawn (scissor) and returned
+    if (sx0 < 0 || sx1 > W) { fprintf(stderr, "gl_ref: bad strip\n"); return 2; }
     g_w = W; g_h = H;
     size_t n_vs, n_fs, n_pos, n_idx, n_cs, n_cc;
     char *vs = slurp(dir, "vs.glsl", &n_vs), *fs = slurp(dir, "fs.glsl", &n_fs);
@@ -175,7 +178,7 @@ int main(int argc, char **argv)
     LOAD(glBindTexture); LOAD(glActiveTexture); LOAD(glTexParameteri); LOAD(glPixelStorei); LOAD(glTexImage2D); LOAD(glGenFramebuffers);
     LOAD(glBindFramebuffer); LOAD(glFramebufferTexture2D); LOAD(glCheckFramebufferStatus); LOAD(glViewport); LOAD(glClearColor); LOAD(glClearDepth);
     LOAD(glClear); LOAD(glEnable); LOAD(glDisable); LOAD(glDepthFunc); LOAD(glDepthMask); LOAD(glBlendEquation); LOAD(glBlendFuncSeparate);
-    LOAD(glDrawArraysInstanced); LOAD(glFinish); LOAD(glReadPixels); LOAD(glGenQueries); LOAD(glBeginQuery); LOAD(glEndQuery); LOAD(glGetQueryObjectui64v); LOAD(glCullFace); LOAD(glFrontFace);
+    LOAD(glDrawArraysInstanced); LOAD(glFinish); LOAD(glReadPixels); LOAD(glGenQueries); LOAD(glBeginQuery); LOAD(glEndQuery); LOAD(glGetQueryObjectui64v); LOAD(glCullFace); LOAD(glFrontFace); LOAD(glScissor);
     GLint maxtex = 0; p_glGetIntegerv(GL_MAX_TEXTURE_SIZE, &maxtex);
     if (texw > maxtex || texh > maxtex) { fprintf(stderr, "gl_ref: texture %dx%d exceeds %d\n", texw, texh, maxtex); return 2; }
 
@@ -247,6 +250,7 @@ int main(int argc, char **argv)
         p_glFramebufferTexture2D(GL_FRAMEBUFFER, GL_DEPTH_ATTACHMENT, GL_TEXTURE_2D, dep, 0);
         if (p_glCheckFramebufferStatus(GL_FRAMEBUFFER) != GL_FRAMEBUFFER_COMPLETE) { fprintf(stderr, "gl_ref: framebuffer incomplete\n"); return 3; }
         p_glViewport(0, 0, W, H);
+        if (sx0 != 0 || sx1 != W) { p_glEnable(GL_SCISSOR_TEST); p_glScissor(sx0, 0, sx1 - sx0, H); }
         p_glDepthMask(GL_TRUE); p_glClearColor(clear[0], clear[1], clear[2], clear[3]); p_glClearDepth(1.0);
         p_glClear((scene_rgba ? 0 : GL_COLOR_BUFFER_BIT) | (scene_depth ? 0 : GL_DEPTH_BUFFER_BIT));
         p_glDepthMask(depth_write ? GL_TRUE : GL_FALSE);
@@ -254,16 +258,17 @@ int main(int argc, char **argv)
         if (count) p_glDrawArraysInstanced(GL_TRIANGLES, 0, (GLsizei)(n_pos / 12), count);
         p_glEndQuery(GL_SAMPLES_PASSED); p_glFinish();
         GLuint64 r = 0; p_glGetQueryObjectui64v(q, GL_QUERY_RESULT, &r); passed[pass] = r;
-        const size_t px = (size_t)W * H;
+        const int SW = sx1 - sx0;
+        const size_t px = (size_t)SW * H;
         if (pass == 0) {
             uint8_t *buf = malloc(px * 4), *flip = malloc(px * 4);
-            p_glPixelStorei(GL_PACK_ALIGNMENT, 1); p_glReadPixels(0, 0, W, H, GL_RGBA, GL_UNSIGNED_BYTE, buf);
-            for (int y = 0; y < H; y++) memcpy(flip + (size_t)y * W * 4, buf + (size_t)(H - 1 - y) * W * 4, (size_t)W * 4);
+            p_glPixelStorei(GL_PACK_ALIGNMENT, 1); p_glReadPixels(sx0, 0, SW, H, GL_RGBA, GL_UNSIGNED_BYTE, buf);
+            for (int y = 0; y < H; y++) memcpy(flip + (size_t)y * SW * 4, buf + (size_t)(H - 1 - y) * SW * 4, (size_t)SW * 4);
             spill(dir, "out_rgba8.bin", flip, px * 4); free(buf); free(flip);
         } else {
             float *buf = malloc(px * 16), *flip = malloc(px * 16);
-            p_glReadPixels(0, 0, W, H, GL_RGBA, GL_FLOAT, buf);
-            for (int y = 0; y < H; y++) memcpy(flip + (size_t)y * W * 4, buf + (size_t)(H - 1 - y) * W * 4, (size_t)W * 16);
+            p_glReadPixels(sx0, 0, SW, H, GL_RGBA, GL_FLOAT, buf);
+            for (int y = 0; y < H; y++) memcpy(flip + (size_t)y * SW * 4, buf + (size_t)(H - 1 - y) * SW * 4, (size_t)SW * 16);
             spill(dir, "out_float.bin", flip, px * 16); free(buf); free(flip);
         }
         const GLenum e = p_glGetError();

@@ -10,11 +10,15 @@ OUT = os.path.join(ROOT, "oracle", "_ref", "gl_scenes"); os.makedirs(OUT, exist_
 scenes = {}
 
 
-def scene(name, rows, w, h, cam, obj, proj, cutout=None, note="", depth=None, rgba=None):
+def scene(name, rows, w, h, cam, obj, proj, cutout=None, note="", depth=None, rgba=None, strip=None, recipe=None, eye=None):
     fn = name + ".splat"
     open(os.path.join(OUT, fn), "wb").write(np.ascontiguousarray(rows).tobytes())
     scenes[name] = {"rows": fn, "width": w, "height": h, "cam_world": list(map(float, cam)), "obj_world": list(map(float, obj)),
                     "proj": list(map(float, proj)), "cutout_world": (list(map(float, cutout)) if cutout is not None else None), "note": note}
+    if eye is not None:
+        scenes[name].update({"eye_cam_world": list(map(float, eye[0])), "eye_proj": list(map(float, eye[1]))})
+    if strip is not None:
+        scenes[name].update({"strip": list(strip), "store_rows": False, "rows_recipe": recipe})
     if depth is not None:
         open(os.path.join(OUT, name + ".depth"), "wb").write(np.ascontiguousarray(depth, "<f4").tobytes()); scenes[name]["scene_depth"] = name + ".depth"
     if rgba is not None:
@@ -48,5 +52,29 @@ rgba[..., 2] = (((xx // 16 + yy // 16) % 2) * 180 + 40).astype(np.uint8); rgba[.
 scene("index_yaw130_scene", synth.make_splat_rows(4000, seed=404), w, h, synth.compose((0.0, 1.6, 0.0)), synth.compose((0.0, 1.5, -2.0), 130.0),
       synth.perspective(80.0, w / h), depth=depth, rgba=rgba,
       note="index.html pose, yaw 130 deg, drawn over an opaque scene (depth LEQUAL, no depth write; colour = destination), 4000 splats, 256x144")
+# BASELINE configs[1] itself: the benchmark's 1,048,576-splat scene at 1920x1080, orbit frame 7 (entity yaw 21 deg); the rows are
+# stored by recipe + SHA-1, the frame as a 64-pixel column strip
+if "--big" in sys.argv:
+    rows_1m = synth.make_splat_rows(synth.N_TRAIN)
+    rec_1m = {"fn": "make_splat_rows", "n": int(synth.N_TRAIN)}
+    scene("c2_1m_1080p_strip", rows_1m, 1920, 1080, synth.compose((0.0, 1.6, 0.0)), synth.compose((0.0, 1.5, -2.0), 21.0),
+          synth.perspective(80.0, 1920 / 1080), strip=(928, 992), recipe=rec_1m,
+          note="BASELINE configs[1]: the benchmark scene (1,048,576 splats) at 1920x1080, orbit frame 7, columns 928..991")
+    scene("c1_1m_720p_strip", rows_1m, 1280, 720, synth.compose((0.0, 1.6, 0.0)), synth.compose((0.0, 1.5, -2.0), 300.0),
+          synth.perspective(80.0, 1280 / 720), strip=(400, 464), recipe=rec_1m,
+          note="BASELINE configs[0]: the same scene at 1280x720, entity yaw 300 deg, columns 400..463")
+    # BASELINE configs[3]: XR, 2064x2208 x 0.5 per eye; ONE sort from the head camera (index.js:441), drawn with the right eye's camera
+    wx, hx = 1032, 1104
+    ro, lo = math.tan(math.radians(54)), math.tan(math.radians(40))
+    eye_proj = synth.frustum(-lo * near, ro * near, math.tan(math.radians(44)) * near, -math.tan(math.radians(55)) * near, near, far)
+    scene("c4_xr_right_eye_strip", rows_1m, wx, hx, synth.compose((0.0, 1.6, 0.0)), synth.compose((0.0, 1.5, -2.0), 10.0), synth.perspective(80.0, wx / hx),
+          strip=(480, 544), recipe=rec_1m, eye=(synth.compose((0.032, 1.6, 0.0)), eye_proj),
+          note="BASELINE configs[3]: right XR eye 1032x1104 (asymmetric frustum), order from the HEAD camera's sort, columns 480..543")
+    # BASELINE configs[2]: 6 M splats + the cutout-demo box at 1920x1080
+    scene("c3_6m_cutout_strip", synth.make_splat_rows(synth.N_BICYCLE, seed=synth.SEED_BASE + 3), 1920, 1080, synth.compose((5.132, 1.6, 7.237)),
+          synth.compose((0.0, 0.8, -2.0), 75.0, (2.0, 2.0, 2.0)), synth.perspective(80.0, 1920 / 1080),
+          cutout=synth.compose((0.8145, 1.73322, -2.35981), 0.0, (4.17, 2.95, 3.89)), strip=(640, 704),
+          recipe={"fn": "make_splat_rows", "n": int(synth.N_BICYCLE), "seed": int(synth.SEED_BASE + 3)},
+          note="BASELINE configs[2]: 6,291,456 splats + the cutout-demo.html box at 1920x1080, entity yaw 75 deg, columns 640..703")
 json.dump(scenes, open(os.path.join(OUT, "scenes.json"), "w"), indent=1)
 print("wrote", len(scenes), "scenes ->", OUT)

@@ -1155,20 +1155,24 @@ def test_hip_frames_match_reference_glsl_goldens(name):
     build's own restatement."""
     c = _glpin.load_gl(name)
     w, h = c["meta"]["width"], c["meta"]["height"]
-    rows = c["rows"].reshape(-1, 32)
+    x0, x1 = c["meta"]["strip"]
+    rows = _glpin.rows_of(c)
+    if rows is None:
+        pytest.skip("this numpy generates a different benchmark scene than the one the golden was drawn from")
     cut = c["cutout_world"] if c["cutout_world"].size else None
     view, cutm = capi.tick_uniforms(c["cam_world"], c["obj_world"], cut)
     sd, sr = _glpin.scene_of(c)
     with capi.Context(0) as cx:
         cx.push_splat(rows)
         idx = cx.sort(view, cutm)
-        assert np.array_equal(idx, c["sorted"])                            # the order the reference's worker posted
+        assert _glpin.same_order(idx, c)                                   # the order the reference's worker posted
         if sd is not None or sr is not None:
             cx.set_scene(sd, sr)
-        prm = capi.make_params(capi.model_view_matrix(c["cam_world"], c["obj_world"]), capi.projection_matrix(c["proj"]), w, h,
-                               focal_=capi.focal(c["gs_proj"], h))
+        dcam, dproj = _glpin.draw_camera(c)
+        prm = capi.make_params(capi.model_view_matrix(dcam, c["obj_world"]), capi.projection_matrix(dproj), w, h,
+                               x0=x0, x1=x1, focal_=capi.focal(c["gs_proj"], h))
         img = cx.render(prm)
         prm.flags = capi.RENDER_COUNT_FRAGS
         cx.render(prm)
         frags = cx.stats()["n_frags"]
-    _glpin.gl_compare(np.asarray(img).reshape(h, w, 4), frags, c, "HIP vs GLSL-on-Mesa: " + name)
+    _glpin.gl_compare(np.asarray(img).reshape(h, x1 - x0, 4), frags, c, "HIP vs GLSL-on-Mesa: " + name, early_termination=True)
