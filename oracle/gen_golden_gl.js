@@ -26,7 +26,7 @@ const zlib = require('zlib');
 const T = require('./three_standin.js');
 
 const REF = '/root/reference/index.js';
-const OUT = path.join(__dirname, '..', 'tests', 'golden');
+const OUT = process.env.GS_GL_OUT || path.join(__dirname, '..', 'tests', 'golden');   // (GS_GL_OUT / GS_GL_ONLY: side runs, e.g. timing a whole frame)
 const SCRATCH = path.join(__dirname, '_ref');
 const GLREF = path.join(SCRATCH, 'gl_ref');
 const SCENES = path.join(SCRATCH, 'gl_scenes');
@@ -166,14 +166,14 @@ async function glCase(name, sc) {
     fragments_rgba8_fb: Number(info.fragments_rgba8), renderer: info.renderer, gl_version: info.version, has_cutout: !!sc.cutout_world,
     has_scene: !!(sc.scene_depth || sc.scene_rgba), rows_sha1: sha1(rows), sorted_sha1: sha1(Buffer.from(idx.buffer, idx.byteOffset, count * 4)),
     rows_recipe: sc.rows_recipe || null, note: sc.note });
-  console.log('gl_' + name + ':', n, 'splats,', count, 'instances,', info.fragments_float, 'fragments,', info.renderer);
+  console.log('gl_' + name + ':', n, 'splats,', count, 'instances,', info.fragments_float, 'fragments,', info.renderer, '| draw', info.draw_seconds_rgba8, 's');
   for (const f of fs.readdirSync(job)) fs.unlinkSync(path.join(job, f));   // the scratch copy of the shader text does not outlive the run
   fs.rmdirSync(job);
 }
 
 (async () => {
   const scenes = JSON.parse(fs.readFileSync(path.join(SCENES, 'scenes.json'), 'utf8'));
-  for (const name of Object.keys(scenes)) await glCase(name, scenes[name]);
+  for (const name of Object.keys(scenes)) if (!process.env.GS_GL_ONLY || process.env.GS_GL_ONLY === name) await glCase(name, scenes[name]);
   fs.writeFileSync(path.join(OUT, 'manifest_gl.json'), JSON.stringify(manifest, null, 1));
   // the scratch scenes (up to 200 MB of rows) are not needed any more -- and oracle/_ref/ travels to the GPU box
   for (const f of fs.readdirSync(SCENES)) fs.unlinkSync(path.join(SCENES, f));

@@ -22,6 +22,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 #include <GL/gl.h>
 #include <GL/glext.h>
 #include <GL/internal/dri_interface.h>
@@ -221,6 +222,7 @@ int main(int argc, char **argv)
     p_glDepthMask(depth_write ? GL_TRUE : GL_FALSE);
     p_glEnable(GL_CULL_FACE); p_glCullFace(GL_BACK); p_glFrontFace(GL_CCW);                          // material.side = FrontSide (three.js default)
     uint64_t passed[2] = { 0, 0 };
+    double draw_s[2] = { 0, 0 };
     for (int pass = 0; pass < 2; pass++) {                        // 0: RGBA8 colour buffer, 1: RGBA32F colour buffer
         GLuint fbo, col, dep;
         p_glGenFramebuffers(1, &fbo); p_glBindFramebuffer(GL_FRAMEBUFFER, fbo);
@@ -254,9 +256,11 @@ int main(int argc, char **argv)
         p_glDepthMask(GL_TRUE); p_glClearColor(clear[0], clear[1], clear[2], clear[3]); p_glClearDepth(1.0);
         p_glClear((scene_rgba ? 0 : GL_COLOR_BUFFER_BIT) | (scene_depth ? 0 : GL_DEPTH_BUFFER_BIT));
         p_glDepthMask(depth_write ? GL_TRUE : GL_FALSE);
+        struct timespec t0, t1; p_glFinish(); clock_gettime(CLOCK_MONOTONIC, &t0);
         GLuint q; p_glGenQueries(1, &q); p_glBeginQuery(GL_SAMPLES_PASSED, q);
         if (count) p_glDrawArraysInstanced(GL_TRIANGLES, 0, (GLsizei)(n_pos / 12), count);
         p_glEndQuery(GL_SAMPLES_PASSED); p_glFinish();
+        clock_gettime(CLOCK_MONOTONIC, &t1); draw_s[pass] = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
         GLuint64 r = 0; p_glGetQueryObjectui64v(q, GL_QUERY_RESULT, &r); passed[pass] = r;
         const int SW = sx1 - sx0;
         const size_t px = (size_t)SW * H;
@@ -275,8 +279,9 @@ int main(int argc, char **argv)
         if (e != GL_NO_ERROR) { fprintf(stderr, "gl_ref: GL error 0x%x\n", e); return 3; }
     }
     char out[512];
-    snprintf(out, sizeof out, "fragments_rgba8 %llu\nfragments_float %llu\nrenderer %s\nversion %s\n", (unsigned long long)passed[0],
-             (unsigned long long)passed[1], (const char *)p_glGetString(GL_RENDERER), (const char *)p_glGetString(GL_VERSION));
+    snprintf(out, sizeof out, "fragments_rgba8 %llu\nfragments_float %llu\nrenderer %s\nversion %s\ndraw_seconds_rgba8 %.6f\ndraw_seconds_float %.6f\n",
+             (unsigned long long)passed[0], (unsigned long long)passed[1], (const char *)p_glGetString(GL_RENDERER), (const char *)p_glGetString(GL_VERSION),
+             draw_s[0], draw_s[1]);
     spill(dir, "out.txt", out, strlen(out));
     return 0;
 }
