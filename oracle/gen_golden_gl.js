@@ -161,7 +161,7 @@ async function glCase(name, sc) {
     eye_cam_world: new Float64Array(sc.eye_cam_world || []), eye_proj: new Float64Array(sc.eye_proj || []),
     gs_mv: new Float64Array(u.gsModelViewMatrix.value.elements), gs_proj: new Float64Array(u.gsProjectionMatrix.value.elements),
     viewport: new Float64Array(u.viewport.value), focal: new Float64Array([u.focal.value]),
-    rgba8_fb: rgba8, rgba_float_fb_rounded: rgbaOnce,
+    rgba8_fb: sc.store_rgba8 === false ? new Uint8Array(0) : rgba8, rgba_float_fb_rounded: rgbaOnce,
   }, sceneArrays), { n, width: W, height: H, strip: sc.strip || [0, W], instances: count, fragments: Number(info.fragments_float),
     fragments_rgba8_fb: Number(info.fragments_rgba8), renderer: info.renderer, gl_version: info.version, has_cutout: !!sc.cutout_world,
     has_scene: !!(sc.scene_depth || sc.scene_rgba), rows_sha1: sha1(rows), sorted_sha1: sha1(Buffer.from(idx.buffer, idx.byteOffset, count * 4)),

@@ -76,8 +76,11 @@ if "--big" in sys.argv:
           cutout=synth.compose((0.8145, 1.73322, -2.35981), 0.0, (4.17, 2.95, 3.89)), strip=(640, 704),
           recipe={"fn": "make_splat_rows", "n": int(synth.N_BICYCLE), "seed": int(synth.SEED_BASE + 3)},
           note="BASELINE configs[2]: 6,291,456 splats + the cutout-demo.html box at 1920x1080, entity yaw 75 deg, columns 640..703")
-if "--full-frame" in sys.argv:      # side run: the whole headline frame, to time the reference's GPU half on this host's cores
-    scene("c2_full_frame", synth.make_splat_rows(synth.N_TRAIN), 1920, 1080, synth.compose((0.0, 1.6, 0.0)), synth.compose((0.0, 1.5, -2.0), 21.0),
-          synth.perspective(80.0, 1920 / 1080), strip=(0, 1920), recipe={"fn": "make_splat_rows", "n": int(synth.N_TRAIN)}, note="timing only")
+if "--big" in sys.argv or "--full-frame" in sys.argv:
+    # the WHOLE headline frame (BASELINE configs[1], orbit frame 40: entity yaw 120 deg); only the float-buffer image is kept
+    scene("c2_1m_1080p_frame", synth.make_splat_rows(synth.N_TRAIN), 1920, 1080, synth.compose((0.0, 1.6, 0.0)), synth.compose((0.0, 1.5, -2.0), 120.0),
+          synth.perspective(80.0, 1920 / 1080), strip=(0, 1920), recipe={"fn": "make_splat_rows", "n": int(synth.N_TRAIN)},
+          note="BASELINE configs[1], the whole 1920x1080 frame, orbit frame 40 (also times the reference's GPU half on this host's cores)")
+    scenes["c2_1m_1080p_frame"]["store_rgba8"] = False
 json.dump(scenes, open(os.path.join(OUT, "scenes.json"), "w"), indent=1)
 print("wrote", len(scenes), "scenes ->", OUT)
