@@ -54,6 +54,16 @@ scene("index_yaw130_scene", synth.make_splat_rows(4000, seed=404), w, h, synth.c
       note="index.html pose, yaw 130 deg, drawn over an opaque scene (depth LEQUAL, no depth write; colour = destination), 4000 splats, 256x144")
 # BASELINE configs[1] itself: the benchmark's 1,048,576-splat scene at 1920x1080, orbit frame 7 (entity yaw 21 deg); the rows are
 # stored by recipe + SHA-1, the frame as a 64-pixel column strip
+# the dropped-bucket pathology (golden sort_oob_bucket): a cloud 1e-5 wide 500 m away -- the f32 rounding of the stored depths
+# exceeds their range, buckets fall outside the table, the reference's typed-array writes drop them and its index list ends in
+# zeros: splat 0 is drawn once more for every dropped splat (index.js:561-567, 201-207)
+g = np.random.Generator(np.random.PCG64(405))
+rows = synth.make_splat_rows(2048, seed=405).reshape(-1, 32).copy()
+pos = (np.array([0.4, 0.3, 500.0]) + 2e-6 * g.standard_normal((2048, 3))).astype("<f4")
+rows[:, 0:12] = pos.view(np.uint8).reshape(2048, 12)
+rows[:, 12:24] = (rows[:, 12:24].copy().view("<f4") * np.float32(60.0)).view(np.uint8)
+scene("oob_bucket", rows, 192, 108, synth.compose((0.0, 0.0, 0.0)), synth.compose((0.0, 0.0, 0.0), 1.0), synth.perspective(80.0, 192 / 108),
+      note="dropped-bucket pathology: 2048 splats within 1e-5 of (0.4, 0.3, 500) in file coordinates (the loader negates z); the index list ends in zeros and splat 0 is drawn again for each")
 if "--big" in sys.argv:
     rows_1m = synth.make_splat_rows(synth.N_TRAIN)
     rec_1m = {"fn": "make_splat_rows", "n": int(synth.N_TRAIN)}
