@@ -16,6 +16,7 @@ RENDER_FLIP_Y, RENDER_COUNT_FRAGS, RENDER_NO_EARLY_OUT, RENDER_ASYNC, RENDER_COU
 OPT_PROFILE, OPT_TERMINATION, OPT_NEAR_PERMILLE, OPT_RECORD_STAGED, OPT_PIPELINE_DEPTH, OPT_WIDE_PAIRS, OPT_ENQUEUE_THREADS = 1, 2, 3, 4, 5, 6, 7
 OPT_COMM_SELF_COPY = 8
 OPT_BLEND_SPLIT = 9
+OPT_FRAME_BATCH = 10
 COMM_ID_BYTES = 128
 BUF_CENTER_SCALE, BUF_COV_COLOR, BUF_SORT_ROWS, BUF_SORTED, BUF_PROJECTED, BUF_TILE_COUNT, BUF_TILE_STATS = 0, 1, 2, 3, 4, 5, 6
 

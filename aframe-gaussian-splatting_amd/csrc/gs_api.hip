@@ -241,6 +241,7 @@ static int collect_status(gs_ctx *lane, bool *overflowed)
 // Everything a worker touches is lane-local; the caller's thread touches a lane only after lane_drain().
 
 struct GsLaneCmd {
+    gs_ctx *target;                                            // the lane (or twin) the command is for
     int type;                                                  // 0 = sort, 1 = asynchronous render, 2 = call (gs_comm.hip: the frame's gather)
     float view[4], cutout[16]; bool has_cutout;
     bool has_strip; GsSortStrip strip;
@@ -254,11 +255,38 @@ struct GsLaneWorker {
     std::condition_variable cv_work, cv_idle;
     std::deque<GsLaneCmd> q;
     bool busy = false, stop = false;
+    uint64_t n_pairs = 0, n_single = 0;                        // frames sent out in pairs / alone (GS_DEBUG_PAIRS=1 prints them at shutdown)
     int rc = GS_OK;                                            // first failure since the last drain ...
     char err[GS_ERRLEN] = "";                                  // ... and its message: the worker never writes the lane's err itself
 };
 
 static int render_async_on_lane(gs_ctx *ctx, const GsFrameUniforms &u, void *device_rgba, uint8_t *host_rgba, size_t stride);
+
+static int ensure_frame_buffers(gs_ctx *ctx, const GsFrameUniforms &u, bool need_fb);
+static int prof_advance(gs_ctx *ctx);
+
+// GS_OPT_FRAME_BATCH: the frames of a lane and of its twin, when both are waiting, go out as ONE chain of launches
+static int run_frame_pair(gs_ctx *A, gs_ctx *B, const GsLaneCmd &s0, const GsLaneCmd &r0, const GsLaneCmd &s1, const GsLaneCmd &r1)
+{
+    gs_ctx *ctx = A;
+    gs_ctx *S[2] = { A, B };
+    const float *view[2] = { s0.view, s1.view };
+    const float *cut[2] = { s0.has_cutout ? s0.cutout : nullptr, s1.has_cutout ? s1.cutout : nullptr };
+    TRY(gs_run_sort2(S, view, cut));
+    const GsFrameUniforms U[2] = { r0.u, r1.u };
+    uint8_t *dev[2] = { (uint8_t *)r0.device_rgba, (uint8_t *)r1.device_rgba };
+    TRY(ensure_frame_buffers(A, U[0], dev[0] == nullptr));
+    TRY(ensure_frame_buffers(B, U[1], dev[1] == nullptr));
+    TRY(gs_run_render2(S, U, dev));
+    const GsLaneCmd *r[2] = { &r0, &r1 };
+    for (int k = 0; k < 2; k++) {
+        if (!r[k]->host_rgba) continue;
+        const size_t sw = (size_t)(U[k].x1 - U[k].x0);
+        const uint8_t *src = dev[k] ? dev[k] : S[k]->fb;
+        GS_HIP(hipMemcpy2DAsync(r[k]->host_rgba, r[k]->stride ? r[k]->stride : sw * 4, src, sw * 4, sw * 4, (size_t)U[k].H, hipMemcpyDeviceToHost, A->stream));
+    }
+    return prof_advance(A);                                     // (the pair's HIP events sit in the primary lane's ring)
+}
 
 static void lane_worker_main(gs_ctx *L)
 {
@@ -272,46 +300,65 @@ static void lane_worker_main(gs_ctx *L)
         if (w->q.empty()) break;                               // stop requested and nothing left to do
         GsLaneCmd c = w->q.front(); w->q.pop_front();
         w->busy = true;
-        lk.unlock();
         int rc = GS_OK;
+        gs_ctx *T = c.target;
+        bool paired = false;
+        GsLaneCmd r0, s1, r1;
+        if (c.type == 0 && T == L && L->twin && gs_root(L)->frame_batch == 2 && !c.has_strip && w->rc == GS_OK) {
+            // the sort of a frame on the primary lane: if its render and the twin's frame are queued behind it (the caller is
+            // normally several frames ahead of this thread; give it a moment if not), the two frames share their launches
+            w->cv_work.wait_for(lk, std::chrono::microseconds(200), [&] { return w->stop || w->q.size() >= 3; });
+            if (w->q.size() >= 3 && w->q[0].type == 1 && w->q[0].target == L && w->q[1].type == 0 && w->q[1].target == L->twin && !w->q[1].has_strip &&
+                w->q[2].type == 1 && w->q[2].target == L->twin && gs_frames_batchable(w->q[0].u, w->q[2].u) && L->n == L->twin->n) {
+                r0 = w->q[0]; s1 = w->q[1]; r1 = w->q[2];
+                w->q.pop_front(); w->q.pop_front(); w->q.pop_front();
+                paired = true;
+            }
+        }
+        lk.unlock();
         // (a call is run even after a failure: the gather of a frame must be issued on every rank, or the others wait for it)
-        if (c.type == 2) { const int r2 = c.call(L); if (w->rc == GS_OK) rc = r2; }
-        else if (w->rc == GS_OK) rc = c.type == 0 ? gs_run_sort(L, c.view, c.has_cutout ? c.cutout : nullptr, c.has_strip ? &c.strip : nullptr)
-                                                  : render_async_on_lane(L, c.u, c.device_rgba, c.host_rgba, c.stride);
+        if (paired) rc = run_frame_pair(L, L->twin, c, r0, s1, r1);
+        else if (c.type == 2) { const int r2 = c.call(T); if (w->rc == GS_OK) rc = r2; }
+        else if (w->rc == GS_OK) rc = c.type == 0 ? gs_run_sort(T, c.view, c.has_cutout ? c.cutout : nullptr, c.has_strip ? &c.strip : nullptr)
+                                                  : render_async_on_lane(T, c.u, c.device_rgba, c.host_rgba, c.stride);
         lk.lock();
         if (rc != GS_OK && w->rc == GS_OK) { w->rc = rc; memcpy(w->err, scratch, sizeof w->err); }
         w->busy = false;
-        if (w->q.empty()) w->cv_idle.notify_all();
+        if (paired) { L->inflight -= 2; L->twin->inflight -= 2; w->n_pairs += 2; } else { T->inflight -= 1; if (c.type == 1) w->n_single++; }
+        w->cv_idle.notify_all();
     }
 }
 
 // wait until the lane's worker has enqueued everything it was given; returns (and clears) its first failure
 static int lane_drain(gs_ctx *L)
 {
-    GsLaneWorker *w = L->worker;
+    GsLaneWorker *w = L->exec ? L->exec->worker : L->worker;
     if (!w) return GS_OK;
     std::unique_lock<std::mutex> lk(w->m);
-    w->cv_idle.wait(lk, [&] { return w->q.empty() && !w->busy; });
+    // everything handed over FOR THIS LANE has been executed (its twin's commands may still be queued: the two only share the thread)
+    w->cv_idle.wait(lk, [&] { return L->inflight == 0; });
     const int rc = w->rc; w->rc = GS_OK;
     if (rc != GS_OK) memcpy(L->err, w->err, sizeof L->err);    // on the caller's thread, under the worker's mutex
     return rc;
 }
 
-static int lane_push(gs_ctx *L, const GsLaneCmd &c)
+static int lane_push(gs_ctx *L, GsLaneCmd c)
 {
-    if (!L->worker) {
-        L->worker = new (std::nothrow) GsLaneWorker();
-        if (!L->worker) return GS_E_OOM;
-        try { L->worker->th = std::thread(lane_worker_main, L); }
+    gs_ctx *E = L->exec ? L->exec : L;
+    if (!E->worker) {
+        E->worker = new (std::nothrow) GsLaneWorker();
+        if (!E->worker) return GS_E_OOM;
+        try { E->worker->th = std::thread(lane_worker_main, E); }
         catch (...) {                                              // no exception crosses the C ABI
-            delete L->worker; L->worker = nullptr;
+            delete E->worker; E->worker = nullptr;
             snprintf(L->err, sizeof L->err, "could not start the lane's enqueue thread");
             return GS_E_OOM;
         }
     }
-    GsLaneWorker *w = L->worker;
-    { std::lock_guard<std::mutex> lk(w->m); w->q.push_back(c); }
-    w->cv_work.notify_one();
+    GsLaneWorker *w = E->worker;
+    c.target = L;
+    { std::lock_guard<std::mutex> lk(w->m); w->q.push_back(c); L->inflight++; }
+    w->cv_work.notify_all();
     return GS_OK;
 }
 
@@ -322,6 +369,7 @@ static void lane_stop_worker(gs_ctx *L)
     { std::lock_guard<std::mutex> lk(w->m); w->stop = true; }
     w->cv_work.notify_one();
     if (w->th.joinable()) w->th.join();
+    if (getenv("GS_DEBUG_PAIRS")) fprintf(stderr, "[gs] lane %p: %llu frames in pairs, %llu alone\n", (void *)L, (unsigned long long)w->n_pairs, (unsigned long long)w->n_single);
     delete w;
     L->worker = nullptr;
 }
@@ -333,12 +381,12 @@ static void lane_stop_worker(gs_ctx *L)
         return (_e == hipErrorOutOfMemory) ? GS_E_OOM : GS_E_HIP; } } while (0)
 
 // stream, control block, per-workgroup partial slots, pinned mirror: what every lane owns besides its scratch
-static hipError_t init_frame_resources(gs_ctx *c)
+static hipError_t init_frame_resources(gs_ctx *c, gs_ctx *primary = nullptr)
 {
     hipError_t e;
 #define IFR(call) do { e = (call); if (e != hipSuccess) return e; } while (0)
-    IFR(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    c->own_stream = true;
+    if (primary) { c->stream = primary->stream; c->own_stream = false; c->exec = primary; }   // a twin: frames on its primary's stream and thread
+    else { IFR(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; c->exec = c; }
     IFR(hipMalloc((void **)&c->ctl, sizeof(GsControl)));
     IFR(hipMemset(c->ctl, 0, sizeof(GsControl)));
     IFR(hipMalloc((void **)&c->part_min, GS_MAX_PART * sizeof(unsigned long long)));
@@ -356,7 +404,7 @@ static hipError_t init_frame_resources(gs_ctx *c)
 
 static void free_frame_resources(gs_ctx *c)
 {
-    lane_stop_worker(c);
+    if (c->exec == c || !c->exec) lane_stop_worker(c);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     dev_free(c->depth); dev_free(c->key_a); dev_free(c->kv_b); dev_free(c->val_a);
     dev_free(c->hist); dev_free(c->radix_aux); dev_free(c->spine);
@@ -401,17 +449,23 @@ static int get_lane(gs_ctx *ctx, int i, gs_ctx **out)
 {
     gs_ctx *L = ctx->lanes[i];
     if (!L) {
+        gs_ctx *primary = nullptr;
+        if (i >= GS_MAX_PRIMARY) TRY(get_lane(ctx, i - GS_MAX_PRIMARY, &primary));   // a twin: its primary lane first
         L = new (std::nothrow) gs_ctx();
         if (!L) FAIL(GS_E_OOM, "out of host memory");
         memset(L, 0, sizeof *L);
         L->parent = ctx; L->device = ctx->device;
-        const hipError_t e = init_frame_resources(L);
+        const hipError_t e = init_frame_resources(L, primary);
         if (e != hipSuccess) {
             snprintf(GS_ERRBUF(ctx), GS_ERRLEN, "creating pipeline lane %d failed: %s", i, hipGetErrorString(e));
             free_frame_resources(L); delete L;
             return e == hipErrorOutOfMemory ? GS_E_OOM : GS_E_HIP;
         }
         ctx->lanes[i] = L;
+        if (primary) {                                           // (the primary's enqueue thread reads `twin` under its mutex)
+            if (primary->worker) { std::lock_guard<std::mutex> lk(primary->worker->m); primary->twin = L; }
+            else primary->twin = L;
+        }
         if (ctx->profile && set_profile(L, true, ctx->profile_blend_only, ctx->profile_every) != GS_OK) { memcpy(ctx->err, L->err, sizeof ctx->err); return GS_E_HIP; }
     }
     if (lane_drain(L) != GS_OK) { if (L != ctx) memcpy(ctx->err, L->err, sizeof ctx->err); return GS_E_HIP; }   // its worker is idle from here on
@@ -440,9 +494,17 @@ static void refresh_lanes(gs_ctx *ctx)
 }
 
 // the lane a NEW frame goes to: the next one if the current frame was handed off asynchronously
-static int next_frame_lane(const gs_ctx *ctx)
+static int next_frame_lane(const gs_ctx *ctx, int *rot = nullptr)
 {
-    return (ctx->cur_async && !ctx->user_stream && ctx->pipe_depth > 1) ? (ctx->cur + 1) % ctx->pipe_depth : ctx->cur;
+    if (!(ctx->cur_async && !ctx->user_stream && ctx->pipe_depth > 1)) { if (rot) *rot = ctx->rot; return ctx->cur; }
+    if (ctx->frame_batch == 2 && ctx->enqueue_threads) {
+        // lane 0, its twin, lane 1, its twin, ...: the two frames of a pair sit behind each other in one enqueue thread's queue
+        const int r = (ctx->rot + 1) % (2 * ctx->pipe_depth);
+        if (rot) *rot = r;
+        return r / 2 + (r % 2) * GS_MAX_PRIMARY;
+    }
+    if (rot) *rot = 0;
+    return ctx->cur >= GS_MAX_PRIMARY ? 0 : (ctx->cur + 1) % ctx->pipe_depth;
 }
 
 static int lane_rc(gs_ctx *ctx, gs_ctx *L, int rc)
@@ -476,7 +538,7 @@ GS_API int gs_create(int device, gs_ctx **out)
     if (!ctx) { snprintf(g_create_err, sizeof g_create_err, "out of host memory"); return GS_E_OOM; }
     memset(ctx, 0, sizeof *ctx);
     ctx->device = device; ctx->renderable = true; ctx->t_eps = 1.0f / 1024.0f; ctx->near_frac = 0.25f;
-    ctx->lanes[0] = ctx; ctx->pipe_depth = 3; ctx->enqueue_threads = true;
+    ctx->lanes[0] = ctx; ctx->pipe_depth = 3; ctx->enqueue_threads = true; ctx->frame_batch = 1; ctx->exec = ctx;
 #define CREATE_HIP(call) do { hipError_t _e = (call); if (_e != hipSuccess) {                                              \
         snprintf(g_create_err, sizeof g_create_err, "%s failed: %s", #call, hipGetErrorString(_e)); gs_destroy(ctx);      \
         return GS_E_HIP; } } while (0)
@@ -498,7 +560,7 @@ GS_API int gs_destroy(gs_ctx *ctx)
     if (!ctx) return GS_OK;
     (void)hipSetDevice(ctx->device);
     (void)gs_comm_destroy(ctx);
-    for (int i = 1; i < GS_MAX_LANES; i++)
+    for (int i = GS_MAX_LANES - 1; i >= 1; i--)                  // twins before the lanes whose streams they borrow
         if (ctx->lanes[i]) { free_frame_resources(ctx->lanes[i]); delete ctx->lanes[i]; ctx->lanes[i] = nullptr; }
     free_frame_resources(ctx);
     dev_free(ctx->splat); dev_free(ctx->sort_rows); dev_free(ctx->bound_r); dev_free(ctx->pow10tab);
@@ -520,7 +582,7 @@ GS_API int gs_clear(gs_ctx *ctx)
         L->have_sort = false; L->sorted = nullptr; L->n = 0;
         memset(&L->stats, 0, sizeof L->stats);
     }
-    ctx->cur = 0; ctx->cur_async = false;
+    ctx->cur = 0; ctx->rot = 0; ctx->cur_async = false;
     return GS_OK;
 }
 
@@ -675,9 +737,10 @@ static int sort_common(gs_ctx *ctx, const float view[4], const float *cutout16, 
     GS_HIP(hipSetDevice(ctx->device));
     // a sort starts a frame: it goes to the next lane if the previous frame was handed off with GS_RENDER_ASYNC
     gs_ctx *L = nullptr;
-    const int lane = next_frame_lane(ctx);
+    int rot = 0;
+    const int lane = next_frame_lane(ctx, &rot);
     TRY(get_lane(ctx, lane, &L));
-    ctx->cur = lane; ctx->cur_async = false;
+    ctx->cur = lane; ctx->rot = rot; ctx->cur_async = false;
     if (ctx->enqueue_threads && ctx->pipe_depth > 1 && !ctx->user_stream && !out_idx && !out_n) {
         // nothing to hand back: the lane's worker thread does the launching (a failure surfaces at gs_sync())
         GsLaneCmd c;
@@ -939,7 +1002,7 @@ GS_API int gs_set_stream(gs_ctx *ctx, void *hip_stream)
     else { GS_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)); ctx->own_stream = true; }
     // on a caller-owned stream every frame is ordered with the caller's own work on it: no lane rotation
     ctx->user_stream = hip_stream != nullptr;
-    ctx->cur = 0; ctx->cur_async = false;
+    ctx->cur = 0; ctx->rot = 0; ctx->cur_async = false;
     return GS_OK;
 }
 
@@ -1018,11 +1081,18 @@ GS_API int gs_set_option(gs_ctx *ctx, int option, int64_t value)
         TRY(drain_all(ctx));
         return gs_comm_set_self_copy(ctx, value != 0);
     case GS_OPT_PIPELINE_DEPTH:
-        if (value < 1 || value > GS_MAX_LANES) FAIL(GS_E_BADARG, "pipeline depth must be 1..%d", GS_MAX_LANES);
+        if (value < 1 || value > GS_MAX_PRIMARY) FAIL(GS_E_BADARG, "pipeline depth must be 1..%d", GS_MAX_PRIMARY);
         GS_HIP(hipSetDevice(ctx->device));
         TRY(drain_all(ctx));
         ctx->pipe_depth = (int)value;
-        if (ctx->cur >= ctx->pipe_depth) { ctx->cur = 0; ctx->cur_async = false; }
+        ctx->cur = 0; ctx->rot = 0; ctx->cur_async = false;
+        return GS_OK;
+    case GS_OPT_FRAME_BATCH:
+        if (value != 1 && value != 2) FAIL(GS_E_BADARG, "frame batch must be 1 (off) or 2");
+        GS_HIP(hipSetDevice(ctx->device));
+        TRY(drain_all(ctx));
+        ctx->frame_batch = (int)value;
+        ctx->cur = 0; ctx->rot = 0; ctx->cur_async = false;
         return GS_OK;
     default: FAIL(GS_E_BADARG, "unknown option %d", option);
     }

@@ -20,7 +20,8 @@
 #define GS_PROF_EVENTS 7
 #define GS_MAX_PART 8192           // upper bound on the grid of any kernel that writes per-workgroup partials
 #define GS_CULLED_KEY 65536u       // depth-sort key of culled / dropped splats (sorts behind every bucket)
-#define GS_MAX_LANES 4             // frames in flight (GS_OPT_PIPELINE_DEPTH)
+#define GS_MAX_PRIMARY 4           // lanes with a stream and an enqueue thread of their own (GS_OPT_PIPELINE_DEPTH)
+#define GS_MAX_LANES 8             // ... + their twins (GS_OPT_FRAME_BATCH): lanes[GS_MAX_PRIMARY + i] shares stream and worker of lanes[i]
 #ifndef GS_EMIT_PAIRS
 #define GS_EMIT_PAIRS 1024u        // pair slots written per k_emit work item (a slice of one chunk's pairs)
 #endif
@@ -90,6 +91,11 @@ struct gs_ctx {
     // chain of frame k+1 runs under the tail of frame k.
     gs_ctx *parent;                // non-null for lanes 1..: the owning context
     gs_ctx *lanes[GS_MAX_LANES];   // owner only; [0] = this
+    gs_ctx *exec;                  // the lane whose stream and enqueue thread run this lane's frames: itself, or -- a twin -- its primary
+    gs_ctx *twin;                  // primary lanes: the twin, once created
+    int frame_batch;               // owner: GS_OPT_FRAME_BATCH (1 = off, 2 = consecutive asynchronous frames share their launches)
+    int rot;                       // owner: position in the rotation over (lane, twin) slots while batching
+    int inflight;                  // commands handed to the enqueue thread for THIS lane and not yet executed (under the worker's mutex)
     int pipe_depth;                // GS_OPT_PIPELINE_DEPTH (1 = no rotation)
     int cur;                       // lane of the current frame (chosen by the last gs_sort)
     bool cur_async;                // the current frame was rendered with GS_RENDER_ASYNC: the next gs_sort moves on
@@ -198,6 +204,28 @@ static inline uint32_t gs_div_up(uint64_t a, uint64_t b) { return (uint32_t)((a 
 // 8, grid-strided); returns false for the padding slots of the last eighths.
 __device__ __forceinline__ bool gs_xcd_chunk(uint32_t v, uint32_t nchunks, uint32_t &chunk) { return gsm::xcd_chunk(v, nchunks, chunk); }
 
+// ---- two frames per launch (GS_OPT_FRAME_BATCH)
+// A frame of 1 M splats is a chain of 18 short dependent kernels, most of them at the launch floor.  Two frames that take the
+// same path can share every launch: grid (x, 2), blockIdx.y = the frame, each with its OWN argument list -- its own scratch,
+// control block, uniforms, output.  The kernels' bodies are __device__ functions `k_xxx_body(args...)` (the plain kernels are
+// thin wrappers around them); k_twin calls a body with the argument pack blockIdx.y selects.
+template <class... A> struct GsPack;
+template <> struct GsPack<> {};
+template <class H, class... T> struct GsPack<H, T...> { H h; GsPack<T...> t; };
+static inline GsPack<> gs_pack_make() { return GsPack<>(); }
+template <class H, class... T> static inline GsPack<H, T...> gs_pack_make(H h, T... t) { GsPack<H, T...> p; p.h = h; p.t = gs_pack_make(t...); return p; }
+// F: a type with `template <class... A> static __device__ void call(const A &...)` that forwards to the body (host code may
+// not name a __device__ function, but it may name such a type): GS_BODY(F_name, k_xxx_body<...>)
+#define GS_BODY(Name, ...) struct Name { template <class... A> static __device__ __forceinline__ void call(const A &... a) { __VA_ARGS__(a...); } }
+template <class F, class... B> __device__ __forceinline__ void gs_pack_call(const GsPack<> &, const B &... b) { F::call(b...); }
+template <class F, class H, class... T, class... B> __device__ __forceinline__ void gs_pack_call(const GsPack<H, T...> &p, const B &... b) { gs_pack_call<F>(p.t, b..., p.h); }
+template <class F, int NT, class P> __global__ __launch_bounds__(NT) void k_twin(P p0, P p1) { if (blockIdx.y) gs_pack_call<F>(p1); else gs_pack_call<F>(p0); }
+// launch body F for two frames: gs_twin<F, threads>(grid_x, stream, pack0, pack1)
+template <class F, int NT, class P> static inline void gs_twin(uint32_t grid_x, hipStream_t st, const P &p0, const P &p1)
+{
+    hipLaunchKernelGGL((k_twin<F, NT, P>), dim3(grid_x, 2), dim3(NT), 0, st, p0, p1);
+}
+
 // ---- gs_prims.hip
 // One stable LSD radix pass over n = *n_ptr items on digit (key >> shift) & (2^bits-1).
 // record formats: GS_RADIX_KEYS    in: a plain key array whose value is the element index; out: the values alone (final pass)
@@ -221,6 +249,10 @@ __device__ __forceinline__ bool gs_xcd_chunk(uint32_t v, uint32_t nchunks, uint3
 int gs_launch_radix_pass(gs_ctx *ctx, const void *in, int in_fmt, void *out, int out_fmt, const uint32_t *n_ptr,
                          uint32_t max_n, uint32_t hint_n, int shift, int bits, bool have_hist = false, uint32_t zero_key = 0xFFFFFFFFu,
                          int idx_bits = 0, uint32_t *count_out = nullptr, const uint32_t *fill_to = nullptr);
+// the same pass over two frames' records, one launch per kernel (S[k]: histogram rows / totals of frame k)
+int gs_launch_radix_pass2(gs_ctx *const S[2], const void *const in[2], int in_fmt, void *const out[2], int out_fmt, const uint32_t *const n_ptr[2],
+                          uint32_t max_n, uint32_t hint_n, int shift, int bits, bool have_hist, uint32_t zero_key, int idx_bits,
+                          uint32_t *const count_out[2], const uint32_t *const fill_to[2]);
 // grid used by the radix kernels for hint_n items (a producer that pre-fills the histogram rows uses the same chunking)
 uint32_t gs_radix_grid(uint32_t hint_n);
 // chunk length (GS_CHUNK_S / GS_CHUNK_L) a pass expecting hint_n items works with
@@ -233,9 +265,13 @@ int gs_launch_pack(gs_ctx *ctx, const uint4 *rows_dev, size_t first, size_t nrow
 // strip: sort only the splats that can reach columns [x0, x1) of the frame these uniforms draw (gs_sort_for); nullptr = all
 struct GsSortStrip { float mv[16], proj[16]; float focal, vw; int32_t x0, x1; };
 int gs_run_sort(gs_ctx *ctx, const float view[4], const float *cutout16, const GsSortStrip *strip = nullptr);
+int gs_run_sort2(gs_ctx *const S[2], const float *const view[2], const float *const cutout16[2]);   // two frames per launch
 // ---- gs_render.hip
 int gs_run_render(gs_ctx *ctx, const GsFrameUniforms &u, uint8_t *device_out);
 int gs_run_round1(gs_ctx *ctx, const GsFrameUniforms &u, uint8_t *device_out);
+// two frames per launch (GS_OPT_FRAME_BATCH): whether two frames qualify, and the batched form of gs_run_render for those that do
+bool gs_frames_batchable(const GsFrameUniforms &a, const GsFrameUniforms &b);
+int gs_run_render2(gs_ctx *const S[2], const GsFrameUniforms U[2], uint8_t *const device_out[2]);
 // ---- gs_ply.hip / gs_host.cpp
 namespace gsm { struct PlyLayout; }
 int gs_ply_rows_device(gs_ctx *ctx, const uint8_t *host_data, const gsm::PlyLayout &layout, size_t n, uint4 *rows_out, bool *had_nan);

@@ -52,8 +52,8 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *s_wave
 
 // H[chunk][digit]: one contiguous row per chunk.  PACKED: keys are the .x of (key,val) uint2 records.
 template <bool PACKED, int NW>
-__global__ __launch_bounds__(64 * NW) void k_radix_hist(const uint32_t *__restrict__ keys, const uint32_t *n_ptr, int shift,
-                                                        int bits, uint32_t *__restrict__ hist)
+__device__ __forceinline__ void k_radix_hist_body(const uint32_t *__restrict__ keys, const uint32_t *n_ptr, int shift,
+                                                  int bits, uint32_t *__restrict__ hist)
 {
     constexpr int NT = 64 * NW, IPT = 8, CH = NT * IPT;
     __shared__ uint32_t s_hist[GS_RADIX_MAX_BINS];
@@ -82,14 +82,21 @@ __global__ __launch_bounds__(64 * NW) void k_radix_hist(const uint32_t *__restri
     }
 }
 
+template <bool PACKED, int NW>
+__global__ __launch_bounds__(64 * NW) void k_radix_hist(const uint32_t *__restrict__ keys, const uint32_t *n_ptr, int shift,
+                                                        int bits, uint32_t *__restrict__ hist)
+{
+    k_radix_hist_body<PACKED, NW>(keys, n_ptr, shift, bits, hist);
+}
+
 // In place: H[c][d] <- exclusive sum over the chunks before c; totals[d] = sum over all chunks.  One workgroup of NW waves per
 // slab of 16 digits (small workgroups for short inputs: the kernel runs in the gaps of other frames' kernels, and a
 // 1024-thread workgroup waits until one CU has 16 free wave slots; 8 waves for long inputs: fewer rows per thread): thread
 // (q, r) owns 4 digits and a contiguous run of rows, the first 16 of which stay in registers between the two sweeps (run
 // totals -> exclusive offsets of the runs by shuffles + NW LDS partials -> the rows' exclusive sums), 8 rows in flight beyond.
 template <int NW>
-__global__ __launch_bounds__(64 * NW) void k_radix_scan(uint32_t *__restrict__ hist, const uint32_t *n_ptr, uint32_t chunk, int bits,
-                                                        uint32_t *__restrict__ totals)
+__device__ __forceinline__ void k_radix_scan_body(uint32_t *__restrict__ hist, const uint32_t *n_ptr, uint32_t chunk, int bits,
+                                                  uint32_t *__restrict__ totals)
 {
     constexpr int RC = 16;                                          // rows cached in registers
     constexpr uint32_t LANES = 16u * NW;                            // row lanes: 4 quads x LANES threads
@@ -166,6 +173,13 @@ __global__ __launch_bounds__(64 * NW) void k_radix_scan(uint32_t *__restrict__ h
     }
 }
 
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void k_radix_scan(uint32_t *__restrict__ hist, const uint32_t *n_ptr, uint32_t chunk, int bits,
+                                                        uint32_t *__restrict__ totals)
+{
+    k_radix_scan_body<NW>(hist, n_ptr, chunk, bits, totals);
+}
+
 // Stable scatter, one workgroup per chunk.  Item order inside a chunk: wave w owns a 1/NW-th of the chunk, processed in IPT
 // rounds of 64 consecutive items (lane = item % 64), so "earlier" == (wave, round, lane) lexicographic.
 // Rank among equal digits: in-round via LDS match words (+ one ballot for a 9th digit bit), across rounds via a wave-private
@@ -183,10 +197,10 @@ __global__ __launch_bounds__(64 * NW) void k_radix_scan(uint32_t *__restrict__ h
 // MAXB: bins the instantiation reserves LDS for (128 for the <= 7-bit digits of the pair sort; with 4-byte LDS slots for
 // key-only records a pair-sort workgroup of the short geometry needs 11 KiB of LDS).
 template <int IN_FMT, int OUT_FMT, int MAXB, int NW>
-__global__ __launch_bounds__(64 * NW) void k_radix_scatter(const void *__restrict__ in, void *__restrict__ out,
-                                                           const uint32_t *n_ptr, int shift, int bits, uint32_t zero_key,
-                                                           const uint32_t *__restrict__ hist_scanned, const uint32_t *__restrict__ totals,
-                                                           int idx_bits, uint32_t *count_out, const uint32_t *fill_to)
+__device__ __forceinline__ void k_radix_scatter_body(const void *__restrict__ in, void *__restrict__ out,
+                                                     const uint32_t *n_ptr, int shift, int bits, uint32_t zero_key,
+                                                     const uint32_t *__restrict__ hist_scanned, const uint32_t *__restrict__ totals,
+                                                     int idx_bits, uint32_t *count_out, const uint32_t *fill_to)
 {
     constexpr int NT = 64 * NW, IPT = 8, CH = NT * IPT;
     constexpr bool KEYONLY = (IN_FMT == GS_RADIX_KEYONLY && OUT_FMT == GS_RADIX_KEYONLY) || IN_FMT == GS_RADIX_KEYIDX;
@@ -321,6 +335,15 @@ __global__ __launch_bounds__(64 * NW) void k_radix_scatter(const void *__restric
     }
 }
 
+template <int IN_FMT, int OUT_FMT, int MAXB, int NW>
+__global__ __launch_bounds__(64 * NW) void k_radix_scatter(const void *__restrict__ in, void *__restrict__ out,
+                                                           const uint32_t *n_ptr, int shift, int bits, uint32_t zero_key,
+                                                           const uint32_t *__restrict__ hist_scanned, const uint32_t *__restrict__ totals,
+                                                           int idx_bits, uint32_t *count_out, const uint32_t *fill_to)
+{
+    k_radix_scatter_body<IN_FMT, OUT_FMT, MAXB, NW>(in, out, n_ptr, shift, bits, zero_key, hist_scanned, totals, idx_bits, count_out, fill_to);
+}
+
 uint32_t grid_for(uint32_t items, uint32_t chunk)
 {
     uint32_t g = gs_div_up(items, chunk);
@@ -359,7 +382,61 @@ int launch_pass(gs_ctx *ctx, const void *in, int in_fmt, void *out, int out_fmt,
     return GS_OK;
 }
 
+template <bool PACKED, int NW> GS_BODY(F_hist, k_radix_hist_body<PACKED, NW>);
+template <int NW> GS_BODY(F_scan, k_radix_scan_body<NW>);
+template <int I, int O, int B, int NW> GS_BODY(F_scatter, k_radix_scatter_body<I, O, B, NW>);
+
+// the same pass for two frames in one launch per kernel (GS_OPT_FRAME_BATCH): S[k] supplies histogram rows and totals of frame k
+template <int NW>
+int launch_pass2(gs_ctx *const S[2], const void *const in[2], int in_fmt, void *const out[2], int out_fmt, const uint32_t *const n_ptr[2],
+                 uint32_t hint_n, int shift, int bits, bool have_hist, uint32_t zero_key, int idx_bits, uint32_t *const count_out[2],
+                 const uint32_t *const fill_to[2])
+{
+    constexpr uint32_t CH = 64 * NW * 8;
+    constexpr int NT = 64 * NW;
+    gs_ctx *ctx = S[0];
+    const uint32_t g = grid_for(hint_n, CH);
+    hipStream_t st = ctx->stream;
+    if (!have_hist) {
+        if (in_fmt == GS_RADIX_PACKED) { typedef F_hist<true, NW> F;
+            gs_twin<F, NT>(g, st, gs_pack_make((const uint32_t *)in[0], n_ptr[0], shift, bits, S[0]->hist), gs_pack_make((const uint32_t *)in[1], n_ptr[1], shift, bits, S[1]->hist)); }
+        else { typedef F_hist<false, NW> F;
+            gs_twin<F, NT>(g, st, gs_pack_make((const uint32_t *)in[0], n_ptr[0], shift, bits, S[0]->hist), gs_pack_make((const uint32_t *)in[1], n_ptr[1], shift, bits, S[1]->hist)); }
+    }
+    { typedef F_scan<NW> F;
+      gs_twin<F, NT>(gs_div_up(gs_radix_row_stride(1u << bits), 16u), st, gs_pack_make(S[0]->hist, n_ptr[0], CH, bits, S[0]->radix_aux),
+                        gs_pack_make(S[1]->hist, n_ptr[1], CH, bits, S[1]->radix_aux)); }
+#define GS_SCATTER2_B(I, O, B) do { typedef F_scatter<I, O, B, NW> F;                     \
+        gs_twin<F, NT>(g, st, gs_pack_make(in[0], out[0], n_ptr[0], shift, bits, zero_key, (const uint32_t *)S[0]->hist, (const uint32_t *)S[0]->radix_aux,  \
+                                              idx_bits, count_out[0], fill_to[0]),                                                                               \
+                          gs_pack_make(in[1], out[1], n_ptr[1], shift, bits, zero_key, (const uint32_t *)S[1]->hist, (const uint32_t *)S[1]->radix_aux,         \
+                                       idx_bits, count_out[1], fill_to[1])); } while (0)
+#define GS_SCATTER2(I, O) do { if (bits <= 7) GS_SCATTER2_B(I, O, 128); else if (bits == 8) GS_SCATTER2_B(I, O, 256); else GS_SCATTER2_B(I, O, GS_RADIX_MAX_BINS); } while (0)
+    if (in_fmt == GS_RADIX_KEYONLY && out_fmt == GS_RADIX_KEYONLY) GS_SCATTER2(GS_RADIX_KEYONLY, GS_RADIX_KEYONLY);
+    else if (in_fmt == GS_RADIX_PACKED && out_fmt == GS_RADIX_PACKED) GS_SCATTER2(GS_RADIX_PACKED, GS_RADIX_PACKED);
+    else if (in_fmt == GS_RADIX_KEYS && out_fmt == GS_RADIX_KEYIDX) GS_SCATTER2(GS_RADIX_KEYS, GS_RADIX_KEYIDX);
+    else if (in_fmt == GS_RADIX_KEYIDX && out_fmt == GS_RADIX_KEYS) GS_SCATTER2(GS_RADIX_KEYIDX, GS_RADIX_KEYS);
+    else if (in_fmt == GS_RADIX_KEYS && out_fmt == GS_RADIX_PACKED) GS_SCATTER2(GS_RADIX_KEYS, GS_RADIX_PACKED);
+    else if (in_fmt == GS_RADIX_PACKED && out_fmt == GS_RADIX_KEYS) GS_SCATTER2(GS_RADIX_PACKED, GS_RADIX_KEYS);
+    else { snprintf(GS_ERRBUF(ctx), GS_ERRLEN, "radix pass: unsupported record formats %d -> %d", in_fmt, out_fmt); return GS_E_BADARG; }
+#undef GS_SCATTER2
+#undef GS_SCATTER2_B
+    GS_HIP(hipGetLastError());
+    return GS_OK;
+}
+
 }  // namespace
+
+int gs_launch_radix_pass2(gs_ctx *const S[2], const void *const in[2], int in_fmt, void *const out[2], int out_fmt, const uint32_t *const n_ptr[2],
+                          uint32_t max_n, uint32_t hint_n, int shift, int bits, bool have_hist, uint32_t zero_key, int idx_bits,
+                          uint32_t *const count_out[2], const uint32_t *const fill_to[2])
+{
+    gs_ctx *ctx = S[0];
+    if (bits < 1 || bits > 9) { snprintf(GS_ERRBUF(ctx), GS_ERRLEN, "radix pass: %d-bit digit (1..9 supported)", bits); return GS_E_BADARG; }
+    if (hint_n > max_n || hint_n == 0) hint_n = max_n;
+    return gs_radix_chunk(hint_n) == GS_CHUNK_L ? launch_pass2<8>(S, in, in_fmt, out, out_fmt, n_ptr, hint_n, shift, bits, have_hist, zero_key, idx_bits, count_out, fill_to)
+                                                : launch_pass2<4>(S, in, in_fmt, out, out_fmt, n_ptr, hint_n, shift, bits, have_hist, zero_key, idx_bits, count_out, fill_to);
+}
 
 uint32_t gs_radix_chunk(uint32_t hint_n) { return hint_n > GS_RADIX_LARGE_N ? GS_CHUNK_L : GS_CHUNK_S; }
 uint32_t gs_radix_grid(uint32_t hint_n) { return grid_for(hint_n, gs_radix_chunk(hint_n)); }

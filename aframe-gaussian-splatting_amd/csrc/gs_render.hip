@@ -70,11 +70,11 @@ __device__ __forceinline__ void round_range(const GsControl *ctl, uint32_t near_
 // exact per-row tile counts are summed by a whole wavefront (one lane per tile row).  ROUND 1 counts only tiles whose
 // bit is set in the unsaturated-tile mask.
 template <int ROUND>
-__global__ __launch_bounds__(GS_BLOCK) void k_project(const uint32_t *__restrict__ sorted, const uint4 *__restrict__ splat,
-                                                      GsFrameUniforms u, gsm::Projected *__restrict__ proj, uint2 *__restrict__ rect,
-                                                      uint32_t *__restrict__ tile_count, uint32_t *__restrict__ spine,
-                                                      uint32_t *__restrict__ part_vis, const uint32_t *__restrict__ mask,
-                                                      float *__restrict__ zwin, GsControl *ctl)
+__device__ __forceinline__ void k_project_body(const uint32_t *__restrict__ sorted, const uint4 *__restrict__ splat,
+                                               const GsFrameUniforms &u, gsm::Projected *__restrict__ proj, uint2 *__restrict__ rect,
+                                               uint32_t *__restrict__ tile_count, uint32_t *__restrict__ spine,
+                                               uint32_t *__restrict__ part_vis, const uint32_t *__restrict__ mask,
+                                               float *__restrict__ zwin, GsControl *ctl)
 {
     __shared__ float s_rec[GS_BLOCK][6];
     __shared__ uint32_t s_rows[GS_BLOCK], s_j[GS_BLOCK];
@@ -186,6 +186,16 @@ __global__ __launch_bounds__(GS_BLOCK) void k_project(const uint32_t *__restrict
     if (threadIdx.x == 0) part_vis[blockIdx.x] = s_vis;
 }
 
+template <int ROUND>
+__global__ __launch_bounds__(GS_BLOCK) void k_project(const uint32_t *__restrict__ sorted, const uint4 *__restrict__ splat,
+                                                      GsFrameUniforms u, gsm::Projected *__restrict__ proj, uint2 *__restrict__ rect,
+                                                      uint32_t *__restrict__ tile_count, uint32_t *__restrict__ spine,
+                                                      uint32_t *__restrict__ part_vis, const uint32_t *__restrict__ mask,
+                                                      float *__restrict__ zwin, GsControl *ctl)
+{
+    k_project_body<ROUND>(sorted, splat, u, proj, rect, tile_count, spine, part_vis, mask, zwin, ctl);
+}
+
 // One workgroup: exclusive scan of the per-chunk totals (spine) -> chunk base offsets, I = grand total (refused and
 // flagged if it does not fit the pair buffers), Vp from the partials, frame accumulators -- and k_emit's extra work items:
 // a chunk whose splats touch more than GS_EMIT_PAIRS tiles in total (the nearest, largest splats sit next to each other
@@ -193,10 +203,10 @@ __global__ __launch_bounds__(GS_BLOCK) void k_project(const uint32_t *__restrict
 // after a chunk's first goes to `extra`.
 #define GS_SPINE_CACHED 8u
 template <int ROUND>
-__global__ __launch_bounds__(GS_BLOCK) void k_pairs_check(GsControl *ctl, uint32_t pair_cap, uint32_t *__restrict__ spine,
-                                                          const uint32_t *__restrict__ part_vis, uint32_t nparts, uint32_t near_count,
-                                                          int last_round, uint32_t *__restrict__ mask, uint32_t mask_total_words,
-                                                          uint2 *__restrict__ extra)
+__device__ __forceinline__ void k_pairs_check_body(GsControl *ctl, uint32_t pair_cap, uint32_t *__restrict__ spine,
+                                                   const uint32_t *__restrict__ part_vis, uint32_t nparts, uint32_t near_count,
+                                                   int last_round, uint32_t *__restrict__ mask, uint32_t mask_total_words,
+                                                   uint2 *__restrict__ extra)
 {
     __shared__ uint32_t s_vis, s_wave[4], s_wave_e[4], s_tv[GS_SPINE_CACHED][GS_BLOCK], s_eb[GS_SPINE_CACHED][GS_BLOCK];
     __shared__ unsigned long long s_total64[4];
@@ -285,6 +295,15 @@ __global__ __launch_bounds__(GS_BLOCK) void k_pairs_check(GsControl *ctl, uint32
     }
 }
 
+template <int ROUND>
+__global__ __launch_bounds__(GS_BLOCK) void k_pairs_check(GsControl *ctl, uint32_t pair_cap, uint32_t *__restrict__ spine,
+                                                          const uint32_t *__restrict__ part_vis, uint32_t nparts, uint32_t near_count,
+                                                          int last_round, uint32_t *__restrict__ mask, uint32_t mask_total_words,
+                                                          uint2 *__restrict__ extra)
+{
+    k_pairs_check_body<ROUND>(ctl, pair_cap, spine, part_vis, nparts, near_count, last_round, mask, mask_total_words, extra);
+}
+
 // (tile id, sorted position) records in splat order: pair slot = spine[chunk] + the in-chunk exclusive scan of tile_count
 // + the pair's index inside its splat (tile rows top to bottom, tiles left to right), so no offset array goes to memory.
 //
@@ -335,10 +354,10 @@ __device__ __forceinline__ uint32_t nth_masked_tile(const uint32_t *__restrict__
 }
 
 template <int ROUND, bool P32>
-__global__ __launch_bounds__(GS_BLOCK) void k_emit(const gsm::Projected *__restrict__ proj, const uint2 *__restrict__ rect,
-                                                   const uint32_t *__restrict__ tile_count, const uint32_t *__restrict__ spine,
-                                                   const uint2 *__restrict__ extra, GsFrameUniforms u, void *__restrict__ pairs,
-                                                   const uint32_t *__restrict__ mask, const GsControl *ctl)
+__device__ __forceinline__ void k_emit_body(const gsm::Projected *__restrict__ proj, const uint2 *__restrict__ rect,
+                                            const uint32_t *__restrict__ tile_count, const uint32_t *__restrict__ spine,
+                                            const uint2 *__restrict__ extra, const GsFrameUniforms &u, void *__restrict__ pairs,
+                                            const uint32_t *__restrict__ mask, const GsControl *ctl)
 {
     __shared__ float s_rec[GS_BLOCK][6];                            // the slice's splats: projected record,
     __shared__ uint32_t s_sp[GS_BLOCK], s_ty[GS_BLOCK];             // index in the chunk, first | last tile row,
@@ -459,10 +478,19 @@ __global__ __launch_bounds__(GS_BLOCK) void k_emit(const gsm::Projected *__restr
     }
 }
 
+template <int ROUND, bool P32>
+__global__ __launch_bounds__(GS_BLOCK) void k_emit(const gsm::Projected *__restrict__ proj, const uint2 *__restrict__ rect,
+                                                   const uint32_t *__restrict__ tile_count, const uint32_t *__restrict__ spine,
+                                                   const uint2 *__restrict__ extra, GsFrameUniforms u, void *__restrict__ pairs,
+                                                   const uint32_t *__restrict__ mask, const GsControl *ctl)
+{
+    k_emit_body<ROUND, P32>(proj, rect, tile_count, spine, extra, u, pairs, mask, ctl);
+}
+
 // [start,end) of every tile in the sorted pair list, written for ALL tiles (empty ones get an empty range at the
 // position where they would be), so no clearing pass is needed.
-__global__ __launch_bounds__(GS_BLOCK) void k_tile_ranges(const void *__restrict__ pairs, uint32_t jbits, uint2 *__restrict__ range,
-                                                          uint32_t ntiles, int round, const GsControl *ctl)
+__device__ __forceinline__ void k_tile_ranges_body(const void *__restrict__ pairs, uint32_t jbits, uint2 *__restrict__ range,
+                                                   uint32_t ntiles, int round, const GsControl *ctl)
 {
     const uint2 *p64 = reinterpret_cast<const uint2 *>(pairs);
     const uint32_t *p32 = reinterpret_cast<const uint32_t *>(pairs);
@@ -496,6 +524,12 @@ __global__ __launch_bounds__(GS_BLOCK) void k_tile_ranges(const void *__restrict
 }
 #undef GS_PAIR_TILE
 
+__global__ __launch_bounds__(GS_BLOCK) void k_tile_ranges(const void *__restrict__ pairs, uint32_t jbits, uint2 *__restrict__ range,
+                                                          uint32_t ntiles, int round, const GsControl *ctl)
+{
+    k_tile_ranges_body(pairs, jbits, range, ntiles, round, ctl);
+}
+
 // Fragment shader + blend for one 16x16 tile, ONE wavefront per tile, four horizontally adjacent pixels per lane
 // (lane l: image row l/4 of the tile, pixels 4*(l%4) .. +3).  The projected records of a batch are staged in LDS and
 // broadcast-read by the whole wave: with one pixel per lane the 4 waves of a 256-thread tile each re-read every record
@@ -518,11 +552,11 @@ __device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementw
 // SCENE: the opaque scene's depth buffer (fragment kept iff its window depth <= the buffer: depthTest LEQUAL,
 // depthWrite off, index.js:179-180) and/or colour image (the destination the splats are blended over).
 template <bool COUNT, int ROUND, bool SCENE>
-__global__ __launch_bounds__(64) void k_blend(const uint2 *__restrict__ tile_range, const void *__restrict__ pairs,
-                                              const gsm::Projected *__restrict__ proj, GsFrameUniforms u,
-                                              uint8_t *__restrict__ out, float4 *__restrict__ state, uint32_t *__restrict__ mask,
-                                              const float *__restrict__ zwin, const float *__restrict__ scene_depth,
-                                              const uint32_t *__restrict__ scene_rgba, GsControl *ctl)
+__device__ __forceinline__ void k_blend_body(const uint2 *__restrict__ tile_range, const void *__restrict__ pairs,
+                                             const gsm::Projected *__restrict__ proj, const GsFrameUniforms &u,
+                                             uint8_t *__restrict__ out, float4 *__restrict__ state, uint32_t *__restrict__ mask,
+                                             const float *__restrict__ zwin, const float *__restrict__ scene_depth,
+                                             const uint32_t *__restrict__ scene_rgba, GsControl *ctl)
 {
     // one batch of list entries (+1 inert slot), 48 bytes each: the projected record's geometry (cx, cy, ax, ay | bx, by, -, -)
     // and its colour converted once per record (rgb8 * alpha / 255, alpha) -- one LDS base address serves all three reads
@@ -730,6 +764,16 @@ __global__ __launch_bounds__(64) void k_blend(const uint2 *__restrict__ tile_ran
     }
 }
 
+template <bool COUNT, int ROUND, bool SCENE>
+__global__ __launch_bounds__(64) void k_blend(const uint2 *__restrict__ tile_range, const void *__restrict__ pairs,
+                                              const gsm::Projected *__restrict__ proj, GsFrameUniforms u,
+                                              uint8_t *__restrict__ out, float4 *__restrict__ state, uint32_t *__restrict__ mask,
+                                              const float *__restrict__ zwin, const float *__restrict__ scene_depth,
+                                              const uint32_t *__restrict__ scene_rgba, GsControl *ctl)
+{
+    k_blend_body<COUNT, ROUND, SCENE>(tile_range, pairs, proj, u, out, state, mask, zwin, scene_depth, scene_rgba, ctl);
+}
+
 // GS_OPT_BLEND_SPLIT: the tiles with LONG lists, four wavefronts per tile, ONE pixel per lane (wave w: tile rows 4w .. 4w+3).
 // A frame in which few tiles carry long lists (a cut-out scene filling a tenth of the screen: 800 active tiles, lists of
 // 4000-6000 entries of which the busiest tile evaluates 1100 before it saturates) lasts as long as ONE wavefront's serial
@@ -752,11 +796,11 @@ __global__ __launch_bounds__(64) void k_blend(const uint2 *__restrict__ tile_ran
 #define GS_PX_GROUP 4u             // list entries per step of k_blend_px (independent coverage tests and exp(): instruction-level parallelism)
 #endif
 template <int ROUND, bool SCENE>
-__global__ __launch_bounds__(256) void k_blend_px(const uint2 *__restrict__ tile_range, const void *__restrict__ pairs,
-                                                  const gsm::Projected *__restrict__ proj, GsFrameUniforms u,
-                                                  uint8_t *__restrict__ out, float4 *__restrict__ state, uint32_t *__restrict__ mask,
-                                                  const float *__restrict__ zwin, const float *__restrict__ scene_depth,
-                                                  const uint32_t *__restrict__ scene_rgba, GsControl *ctl)
+__device__ __forceinline__ void k_blend_px_body(const uint2 *__restrict__ tile_range, const void *__restrict__ pairs,
+                                                const gsm::Projected *__restrict__ proj, const GsFrameUniforms &u,
+                                                uint8_t *__restrict__ out, float4 *__restrict__ state, uint32_t *__restrict__ mask,
+                                                const float *__restrict__ zwin, const float *__restrict__ scene_depth,
+                                                const uint32_t *__restrict__ scene_rgba, GsControl *ctl)
 {
     constexpr uint32_t PB = GS_PX_BATCH, PR = GS_PX_BATCH / 64u;   // records per batch / per lane
     // a batch in LDS, per wave, laid out for two entries per packed-fp32 instruction: pair p = entries (2p, 2p+1) holds
@@ -902,6 +946,16 @@ __global__ __launch_bounds__(256) void k_blend_px(const uint2 *__restrict__ tile
 #undef GS_WAVE_LDS_SYNC
 }
 
+template <int ROUND, bool SCENE>
+__global__ __launch_bounds__(256) void k_blend_px(const uint2 *__restrict__ tile_range, const void *__restrict__ pairs,
+                                                  const gsm::Projected *__restrict__ proj, GsFrameUniforms u,
+                                                  uint8_t *__restrict__ out, float4 *__restrict__ state, uint32_t *__restrict__ mask,
+                                                  const float *__restrict__ zwin, const float *__restrict__ scene_depth,
+                                                  const uint32_t *__restrict__ scene_rgba, GsControl *ctl)
+{
+    k_blend_px_body<ROUND, SCENE>(tile_range, pairs, proj, u, out, state, mask, zwin, scene_depth, scene_rgba, ctl);
+}
+
 int bits_for(uint32_t n) { int b = 1; while (b < 32 && (1u << b) < n) b++; return b; }
 
 // one round: project -> offsets -> emit -> stable sort by tile -> ranges -> blend.  Round 1 usually finds nothing to
@@ -980,7 +1034,114 @@ int run_round(gs_ctx *ctx, const GsFrameUniforms &u, uint8_t *out, bool last_rou
     return GS_OK;
 }
 
+GS_BODY(F_project0, k_project_body<0>);
+GS_BODY(F_pairs_check0, k_pairs_check_body<0>);
+template <bool P32> GS_BODY(F_emit0, k_emit_body<0, P32>);
+GS_BODY(F_tile_ranges, k_tile_ranges_body);
+template <bool SCENE> GS_BODY(F_blend0, k_blend_body<false, 0, SCENE>);
+template <bool SCENE> GS_BODY(F_blend_px0, k_blend_px_body<0, SCENE>);
+
 }  // namespace
+
+// Two frames that take the same path, one launch per kernel (GS_OPT_FRAME_BATCH; grid (x, 2), blockIdx.y = the frame).  S[0], S[1]:
+// sibling lanes on ONE stream, each with its own scratch, control block and output.  Only the steady-state path exists in
+// this form: binning round 0 alone (a single round, or round 1 skipped optimistically), no counting / recording --
+// gs_frames_batchable() says whether two frames qualify; everything else takes the per-frame path.
+bool gs_frames_batchable(const GsFrameUniforms &a, const GsFrameUniforms &b)
+{
+    const bool one_round = a.near_count == 0xFFFFFFFFu || a.skip_round1;
+    return one_round && a.near_count == b.near_count && a.skip_round1 == b.skip_round1 && a.W == b.W && a.H == b.H && a.x0 == b.x0 && a.x1 == b.x1 &&
+           a.flags == b.flags && !(a.flags & (GS_RENDER_COUNT_FRAGS | GS_RENDER_COUNT_EVALUATED)) && !a.record_staged && !b.record_staged &&
+           a.split_min == b.split_min && a.has_depth == b.has_depth && a.has_scene_rgba == b.has_scene_rgba && a.t_eps == b.t_eps;
+}
+
+int gs_run_render2(gs_ctx *const S[2], const GsFrameUniforms U[2], uint8_t *const device_out[2])
+{
+    gs_ctx *ctx = S[0];
+    const GsFrameUniforms &u = U[0];
+    const uint32_t ntiles = (uint32_t)u.tiles_x * (uint32_t)u.tiles_y;
+    const uint32_t Vmax = (uint32_t)ctx->n;
+    hipStream_t st = ctx->stream;
+    uint8_t *out[2] = { device_out[0] ? device_out[0] : S[0]->fb, device_out[1] ? device_out[1] : S[1]->fb };
+    GS_PROF_RECORD(ctx, 2);
+    uint32_t g = gs_div_up(Vmax, GS_BLOCK); if (g > GS_MAX_PART) g = GS_MAX_PART;
+    if (u.near_count != 0xFFFFFFFFu) { const uint32_t gn = gs_div_up(u.near_count < Vmax ? u.near_count : Vmax, GS_BLOCK); if (gn < g) g = gn ? gn : 1; }
+    const uint32_t pc = (uint32_t)(S[0]->pair_cap < S[1]->pair_cap ? S[0]->pair_cap : S[1]->pair_cap);
+    const uint32_t ph = __atomic_load_n(&gs_root(ctx)->pair_hint, __ATOMIC_RELAXED);
+    const bool last_round = true;
+#define PK(k, ...) gs_pack_make(__VA_ARGS__)
+    gs_twin<F_project0, GS_BLOCK>(g, st,
+        gs_pack_make((const uint32_t *)S[0]->sorted, (const uint4 *)S[0]->splat, U[0], S[0]->proj, S[0]->rect, S[0]->tile_count, S[0]->spine, S[0]->part_vis,
+                     (const uint32_t *)S[0]->unsat_mask, S[0]->zwin, S[0]->ctl),
+        gs_pack_make((const uint32_t *)S[1]->sorted, (const uint4 *)S[1]->splat, U[1], S[1]->proj, S[1]->rect, S[1]->tile_count, S[1]->spine, S[1]->part_vis,
+                     (const uint32_t *)S[1]->unsat_mask, S[1]->zwin, S[1]->ctl));
+    GS_HIP(hipGetLastError());
+    GS_PROF_RECORD(ctx, 3);
+    gs_twin<F_pairs_check0, GS_BLOCK>(1, st,
+        gs_pack_make(S[0]->ctl, (uint32_t)S[0]->pair_cap, S[0]->spine, (const uint32_t *)S[0]->part_vis, g, U[0].near_count, last_round ? 1 : 0, S[0]->unsat_mask,
+                     (uint32_t)u.tiles_y * u.mask_words, S[0]->emit_extra),
+        gs_pack_make(S[1]->ctl, (uint32_t)S[1]->pair_cap, S[1]->spine, (const uint32_t *)S[1]->part_vis, g, U[1].near_count, last_round ? 1 : 0, S[1]->unsat_mask,
+                     (uint32_t)u.tiles_y * u.mask_words, S[1]->emit_extra));
+    const int tb = bits_for(ntiles);
+    const uint32_t jrange = (u.near_count != 0xFFFFFFFFu && u.near_count < Vmax) ? u.near_count : Vmax;
+    const int jb = bits_for(jrange);
+    const bool p32 = !ctx->wide_pairs && tb + jb <= 32;
+    GsFrameUniforms V[2] = { U[0], U[1] };
+    V[0].pair_jbits = V[1].pair_jbits = p32 ? (uint32_t)jb : 0u;
+    uint32_t ge = g + gs_div_up(ph ? ph : pc, GS_EMIT_PAIRS); if (ge > GS_MAX_PART) ge = GS_MAX_PART;
+#define GS_EMIT2(P) gs_twin<F_emit0<P>, GS_BLOCK>(ge, st,                                                                                              \
+        gs_pack_make((const gsm::Projected *)S[0]->proj, (const uint2 *)S[0]->rect, (const uint32_t *)S[0]->tile_count, (const uint32_t *)S[0]->spine,    \
+                     (const uint2 *)S[0]->emit_extra, V[0], (void *)S[0]->pair_a, (const uint32_t *)S[0]->unsat_mask, (const GsControl *)S[0]->ctl),      \
+        gs_pack_make((const gsm::Projected *)S[1]->proj, (const uint2 *)S[1]->rect, (const uint32_t *)S[1]->tile_count, (const uint32_t *)S[1]->spine,    \
+                     (const uint2 *)S[1]->emit_extra, V[1], (void *)S[1]->pair_a, (const uint32_t *)S[1]->unsat_mask, (const GsControl *)S[1]->ctl))
+    if (p32) GS_EMIT2(true); else GS_EMIT2(false);
+#undef GS_EMIT2
+    GS_HIP(hipGetLastError());
+    const int fmt = p32 ? GS_RADIX_KEYONLY : GS_RADIX_PACKED, sh = p32 ? jb : 0;
+    const void *in[2]; void *outp[2]; const uint32_t *np[2] = { &S[0]->ctl->n_pairs, &S[1]->ctl->n_pairs };
+    uint32_t *cnt[2] = { nullptr, nullptr }; const uint32_t *fill[2] = { nullptr, nullptr };
+    const void *fpairs[2];
+    int rc;
+    if (tb <= 9) {
+        for (int k = 0; k < 2; k++) { in[k] = S[k]->pair_a; outp[k] = S[k]->pair_b; }
+        rc = gs_launch_radix_pass2(S, in, fmt, outp, fmt, np, pc, ph, sh, tb, false, 0xFFFFFFFFu, 0, cnt, fill);
+        if (rc != GS_OK) return rc;
+        fpairs[0] = S[0]->pair_b; fpairs[1] = S[1]->pair_b;
+    } else {
+        const int b1 = (tb + 1) / 2, b2 = tb - b1;
+        for (int k = 0; k < 2; k++) { in[k] = S[k]->pair_a; outp[k] = S[k]->pair_b; }
+        rc = gs_launch_radix_pass2(S, in, fmt, outp, fmt, np, pc, ph, sh, b1, false, 0xFFFFFFFFu, 0, cnt, fill);
+        if (rc != GS_OK) return rc;
+        for (int k = 0; k < 2; k++) { in[k] = S[k]->pair_b; outp[k] = S[k]->pair_a; }
+        rc = gs_launch_radix_pass2(S, in, fmt, outp, fmt, np, pc, ph, sh + b1, b2, false, 0xFFFFFFFFu, 0, cnt, fill);
+        if (rc != GS_OK) return rc;
+        fpairs[0] = S[0]->pair_a; fpairs[1] = S[1]->pair_a;
+    }
+    gs_twin<F_tile_ranges, GS_BLOCK>(2048, st, gs_pack_make(fpairs[0], V[0].pair_jbits, S[0]->tile_range, ntiles, 0, (const GsControl *)S[0]->ctl),
+                                     gs_pack_make(fpairs[1], V[1].pair_jbits, S[1]->tile_range, ntiles, 0, (const GsControl *)S[1]->ctl));
+    GS_HIP(hipGetLastError());
+    GS_PROF_RECORD(ctx, 4);
+    V[0].split_min = V[1].split_min = u.split_min;
+#define GS_BLENDPX2(SC) gs_twin<F_blend_px0<SC>, 256>(ntiles < 2048 ? ntiles : 2048, st,                                                               \
+        gs_pack_make((const uint2 *)S[0]->tile_range, fpairs[0], (const gsm::Projected *)S[0]->proj, V[0], out[0], S[0]->state, S[0]->unsat_mask,         \
+                     (const float *)S[0]->zwin, (const float *)S[0]->scene_depth, (const uint32_t *)S[0]->scene_rgba, S[0]->ctl),                        \
+        gs_pack_make((const uint2 *)S[1]->tile_range, fpairs[1], (const gsm::Projected *)S[1]->proj, V[1], out[1], S[1]->state, S[1]->unsat_mask,         \
+                     (const float *)S[1]->zwin, (const float *)S[1]->scene_depth, (const uint32_t *)S[1]->scene_rgba, S[1]->ctl))
+    if (u.split_min) { if (u.has_depth || u.has_scene_rgba) GS_BLENDPX2(true); else GS_BLENDPX2(false); }   // the tiles with long lists first
+#undef GS_BLENDPX2
+#define GS_BLEND2(SC) gs_twin<F_blend0<SC>, 64>(ntiles, st,                                                                                             \
+        gs_pack_make((const uint2 *)S[0]->tile_range, fpairs[0], (const gsm::Projected *)S[0]->proj, V[0], out[0], S[0]->state, S[0]->unsat_mask,         \
+                     (const float *)S[0]->zwin, (const float *)S[0]->scene_depth, (const uint32_t *)S[0]->scene_rgba, S[0]->ctl),                        \
+        gs_pack_make((const uint2 *)S[1]->tile_range, fpairs[1], (const gsm::Projected *)S[1]->proj, V[1], out[1], S[1]->state, S[1]->unsat_mask,         \
+                     (const float *)S[1]->zwin, (const float *)S[1]->scene_depth, (const uint32_t *)S[1]->scene_rgba, S[1]->ctl))
+    if (u.has_depth || u.has_scene_rgba) GS_BLEND2(true); else GS_BLEND2(false);
+#undef GS_BLEND2
+#undef PK
+    GS_HIP(hipGetLastError());
+    GS_PROF_RECORD(ctx, 5);
+    GS_PROF_RECORD(ctx, 6);
+    return GS_OK;
+}
 
 // a skipped round 1 turned out to be needed: run it now (mask + state of the frame are still intact)
 int gs_run_round1(gs_ctx *ctx, const GsFrameUniforms &u, uint8_t *device_out)

@@ -60,9 +60,9 @@ __device__ __forceinline__ bool strip_may_touch(const StripUniforms &s, float x,
 }
 
 template <bool STRIP>                                             // (two instantiations: the strip test must not cost the plain sort registers)
-__global__ __launch_bounds__(GS_BLOCK) void k_sort_depth(const float4 *__restrict__ rows, const float *__restrict__ bound_r, uint32_t n, SortUniforms u, StripUniforms su,
-                                                         float *__restrict__ depth_out, unsigned long long *__restrict__ part_min,
-                                                         unsigned long long *__restrict__ part_max, uint32_t *__restrict__ part_cnt)
+__device__ __forceinline__ void k_sort_depth_body(const float4 *__restrict__ rows, const float *__restrict__ bound_r, uint32_t n, const SortUniforms &u, const StripUniforms &su,
+                                                  float *__restrict__ depth_out, unsigned long long *__restrict__ part_min,
+                                                  unsigned long long *__restrict__ part_max, uint32_t *__restrict__ part_cnt)
 {
     __shared__ unsigned long long s_min, s_max;
     __shared__ uint32_t s_cnt;
@@ -112,6 +112,14 @@ __global__ __launch_bounds__(GS_BLOCK) void k_sort_depth(const float4 *__restric
     if (threadIdx.x == 0) { part_min[blockIdx.x] = s_min; part_max[blockIdx.x] = s_max; part_cnt[blockIdx.x] = s_cnt; }
 }
 
+template <bool STRIP>
+__global__ __launch_bounds__(GS_BLOCK) void k_sort_depth(const float4 *__restrict__ rows, const float *__restrict__ bound_r, uint32_t n, SortUniforms u, StripUniforms su,
+                                                         float *__restrict__ depth_out, unsigned long long *__restrict__ part_min,
+                                                         unsigned long long *__restrict__ part_max, uint32_t *__restrict__ part_cnt)
+{
+    k_sort_depth_body<STRIP>(rows, bound_r, n, u, su, depth_out, part_min, part_max, part_cnt);
+}
+
 // pass 2 (index.js:558-561): 16-bit bucket of the stored depth; culled -> GS_RADIX_SKIP, dropped bucket -> GS_CULLED_KEY.
 // Every workgroup first folds pass 1's partials (<= 2048 slots, L2-resident) into the global min/max.  One workgroup per
 // radix chunk (geometry NW as in gs_prims.hip): it also leaves radix pass A's histogram row of the chunk.
@@ -120,11 +128,11 @@ __global__ __launch_bounds__(GS_BLOCK) void k_sort_depth(const float4 *__restric
 // A 17th key bit has no room there, so kept splats with a dropped bucket leave the sort here as well; the final pass
 // zero-fills their slots [V', V) behind the sorted records (the reference's never-written tail).
 template <int NW, bool COMPACT>
-__global__ __launch_bounds__(64 * NW) void k_sort_bucket(const float *__restrict__ depth, uint32_t n, uint32_t *__restrict__ keys,
-                                                         const unsigned long long *__restrict__ part_min,
-                                                         const unsigned long long *__restrict__ part_max,
-                                                         const uint32_t *__restrict__ part_cnt, uint32_t nparts,
-                                                         uint32_t *__restrict__ hist, GsControl *ctl)
+__device__ __forceinline__ void k_sort_bucket_body(const float *__restrict__ depth, uint32_t n, uint32_t *__restrict__ keys,
+                                                   const unsigned long long *__restrict__ part_min,
+                                                   const unsigned long long *__restrict__ part_max,
+                                                   const uint32_t *__restrict__ part_cnt, uint32_t nparts,
+                                                   uint32_t *__restrict__ hist, GsControl *ctl)
 {
     constexpr int NT = 64 * NW, IPT = 8, CH = NT * IPT;
     __shared__ unsigned long long s_min, s_max;
@@ -186,7 +194,75 @@ __global__ __launch_bounds__(64 * NW) void k_sort_bucket(const float *__restrict
     }
 }
 
+template <int NW, bool COMPACT>
+__global__ __launch_bounds__(64 * NW) void k_sort_bucket(const float *__restrict__ depth, uint32_t n, uint32_t *__restrict__ keys,
+                                                         const unsigned long long *__restrict__ part_min,
+                                                         const unsigned long long *__restrict__ part_max,
+                                                         const uint32_t *__restrict__ part_cnt, uint32_t nparts,
+                                                         uint32_t *__restrict__ hist, GsControl *ctl)
+{
+    k_sort_bucket_body<NW, COMPACT>(depth, n, keys, part_min, part_max, part_cnt, nparts, hist, ctl);
+}
+
+GS_BODY(F_sort_depth, k_sort_depth_body<false>);
+template <int NW, bool COMPACT> GS_BODY(F_sort_bucket, k_sort_bucket_body<NW, COMPACT>);
+
 }  // namespace
+
+// Two frames' sorts, one launch per kernel (GS_OPT_FRAME_BATCH): S[0] and S[1] are sibling lanes on ONE stream holding the same
+// resident data; each keeps its own depths, keys, tables, partial slots and control block.  No strip variant.
+int gs_run_sort2(gs_ctx *const S[2], const float *const view[2], const float *const cutout16[2])
+{
+    gs_ctx *ctx = S[0];
+    const uint32_t n = (uint32_t)ctx->n;
+    SortUniforms u[2];
+    StripUniforms su;
+    memset(&su, 0, sizeof su);
+    for (int k = 0; k < 2; k++) {
+        for (int i = 0; i < 4; i++) u[k].view[i] = (double)view[k][i];
+        u[k].has_cutout = cutout16[k] != nullptr;
+        for (int i = 0; i < 16; i++) u[k].cutout[i] = cutout16[k] ? (double)cutout16[k][i] : 0.0;
+        u[k].has_strip = 0;
+    }
+    const uint32_t g = gs_radix_grid(n);
+    hipStream_t st = ctx->stream;
+    GS_PROF_RECORD(ctx, 0);
+    uint32_t gd = gs_div_up(n, (uint32_t)(GS_DEPTH_IPT * GS_BLOCK));
+    if (gd < 1) gd = 1;
+    if (gd > GS_DEPTH_GRID) gd = GS_DEPTH_GRID;
+    gs_twin<F_sort_depth, GS_BLOCK>(gd, st, gs_pack_make((const float4 *)S[0]->sort_rows, (const float *)S[0]->bound_r, n, u[0], su, S[0]->depth, S[0]->part_min, S[0]->part_max, S[0]->part_cnt),
+                                    gs_pack_make((const float4 *)S[1]->sort_rows, (const float *)S[1]->bound_r, n, u[1], su, S[1]->depth, S[1]->part_min, S[1]->part_max, S[1]->part_cnt));
+    const bool compact = !ctx->wide_pairs && n <= (1u << 25);
+#define GS_BUCKET2(NW, C) gs_twin<F_sort_bucket<NW, C>, 64 * NW>(g, st,                                                                                    \
+        gs_pack_make((const float *)S[0]->depth, n, S[0]->key_a, (const unsigned long long *)S[0]->part_min, (const unsigned long long *)S[0]->part_max,     \
+                     (const uint32_t *)S[0]->part_cnt, gd, S[0]->hist, S[0]->ctl),                                                                            \
+        gs_pack_make((const float *)S[1]->depth, n, S[1]->key_a, (const unsigned long long *)S[1]->part_min, (const unsigned long long *)S[1]->part_max,     \
+                     (const uint32_t *)S[1]->part_cnt, gd, S[1]->hist, S[1]->ctl))
+    if (gs_radix_chunk(n) == GS_CHUNK_L) { if (compact) GS_BUCKET2(8, true); else GS_BUCKET2(8, false); }
+    else { if (compact) GS_BUCKET2(4, true); else GS_BUCKET2(4, false); }
+#undef GS_BUCKET2
+    GS_HIP(hipGetLastError());
+    const void *in[2]; void *out[2]; const uint32_t *np[2]; uint32_t *cnt[2]; const uint32_t *fill[2];
+    int rc;
+    if (compact) {
+        for (int k = 0; k < 2; k++) { in[k] = S[k]->key_a; out[k] = S[k]->kv_b; np[k] = &S[k]->ctl->n_total; cnt[k] = &S[k]->ctl->n_sorted; fill[k] = nullptr; }
+        rc = gs_launch_radix_pass2(S, in, GS_RADIX_KEYS, out, GS_RADIX_KEYIDX, np, n, n, 0, 9, true, 0xFFFFFFFFu, 25, cnt, fill);
+        if (rc != GS_OK) return rc;
+        for (int k = 0; k < 2; k++) { in[k] = S[k]->kv_b; out[k] = S[k]->val_a; np[k] = &S[k]->ctl->n_sorted; cnt[k] = nullptr; fill[k] = &S[k]->ctl->n_kept; }
+        rc = gs_launch_radix_pass2(S, in, GS_RADIX_KEYIDX, out, GS_RADIX_KEYS, np, n, n, 25, 7, false, 0xFFFFFFFFu, 0, cnt, fill);
+        if (rc != GS_OK) return rc;
+    } else {
+        for (int k = 0; k < 2; k++) { in[k] = S[k]->key_a; out[k] = S[k]->kv_b; np[k] = &S[k]->ctl->n_total; cnt[k] = nullptr; fill[k] = nullptr; }
+        rc = gs_launch_radix_pass2(S, in, GS_RADIX_KEYS, out, GS_RADIX_PACKED, np, n, n, 0, 8, true, 0xFFFFFFFFu, 0, cnt, fill);
+        if (rc != GS_OK) return rc;
+        for (int k = 0; k < 2; k++) { in[k] = S[k]->kv_b; out[k] = S[k]->val_a; np[k] = &S[k]->ctl->n_kept; }
+        rc = gs_launch_radix_pass2(S, in, GS_RADIX_PACKED, out, GS_RADIX_KEYS, np, n, n, 8, 9, false, GS_CULLED_KEY, 0, cnt, fill);
+        if (rc != GS_OK) return rc;
+    }
+    GS_PROF_RECORD(ctx, 1);
+    for (int k = 0; k < 2; k++) { S[k]->sorted = S[k]->val_a; S[k]->have_sort = true; }
+    return GS_OK;
+}
 
 int gs_run_sort(gs_ctx *ctx, const float view[4], const float *cutout16, const GsSortStrip *strip)
 {

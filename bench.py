@@ -90,6 +90,11 @@ def main():
         # list are blended by four wavefronts, one pixel per lane (GS_OPT_BLEND_SPLIT; images within the same 1 LSB tolerance)
         ctx.set_option(capi.OPT_BLEND_SPLIT, blend_split)
     gathered = world > 1 or comm1 or args.xr                 # frames go through gs_render_gathered
+    # two frames per launch (GS_OPT_FRAME_BATCH): consecutive asynchronous frames share every kernel launch (grid (x, 2), each frame on
+    # its own scratch); gathered frames (several GPUs, XR) go out one by one
+    frame_batch = 1 if gathered else int(os.environ.get("GS_BENCH_BATCH", "2"))
+    if frame_batch != 1:
+        ctx.set_option(capi.OPT_FRAME_BATCH, frame_batch)
     torch_gather = False                                     # fallback only: see below
     if world > 1:
         ok = 1
@@ -271,8 +276,10 @@ def main():
     s2 = ctx.stats()
     ctx.set_option(capi.OPT_PROFILE, 0)
     k2 = max(1, s2["prof_frames"]) / float(max(1, blends_per_step))     # profiled steps
-    stage = {"ms_sort": s2["sum_ms_sort"] * args.steps / k2, "ms_project": s2["sum_ms_project"] * args.steps / k2,
-             "ms_bin": s2["sum_ms_bin"] * args.steps / k2, "ms_blend": s["sum_ms_blend"] * args.steps * blends_per_step / blend_frames}
+    # (with two frames per launch the HIP events bracket a PAIR's kernels: a frame's share is half of the interval)
+    stage = {"ms_sort": s2["sum_ms_sort"] * args.steps / k2 / frame_batch, "ms_project": s2["sum_ms_project"] * args.steps / k2 / frame_batch,
+             "ms_bin": s2["sum_ms_bin"] * args.steps / k2 / frame_batch,
+             "ms_blend": s["sum_ms_blend"] * args.steps * blends_per_step / blend_frames / frame_batch}
     pairs, visible, sorted_n = s["acc_pairs"], s["acc_visible"], s["acc_sorted"] / float(max(1, blends_per_step))
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
@@ -333,8 +340,11 @@ def main():
             "config": {"workload": workload, "parallelism": par,
                        "pieces_of_rank0": [[v, x0, x1] for v, x0, x1 in mine], "gathered_frame_equals_single_gpu_render": frame_check,
                        "blend_split_min_list": blend_split,
-                       "frames_in_flight": "3 (the library's pipeline lanes: every frame still runs its own full sort, projection, "
-                                           "binning and blend; consecutive frames overlap on the GPU); see latency.fps_depth1 for one frame at a time"},
+                       "frames_in_flight": ("%d (the library's 3 pipeline lanes%s: every frame still runs its own full sort, projection, "
+                                            "binning and blend; consecutive frames overlap on the GPU); see latency.fps_depth1 for one frame at a time"
+                                            % (3 * frame_batch, " x 2 frames per launch, GS_OPT_FRAME_BATCH: the two frames of a pair share each "
+                                               "kernel launch, grid (x, 2), on separate scratch" if frame_batch == 2 else "")),
+                       "frames_per_launch": frame_batch},
             "occlusion_binning": {"near_permille": s["near_permille"], "unsat_tiles_last_frame": s["unsat_tiles"],
                                   "timed_region_retries": retries},
             "msplat_frags_per_s": round(total_frags / 1e6 / elapsed, 1),
@@ -353,7 +363,8 @@ def main():
                          "note": "the contract's roof for this path is HBM (no contraction anywhere: no MFMA), and `achieved` is the "
                                  "algorithmic 36*I + 4*fb bytes over the kernel's launch time; the kernel itself is limited by VALU "
                                  "issue, not by memory: see roofline_valu",
-                         "bytes_per_launch": round(blend_bytes), "avg_launch_ms": round(blend_s * 1e3, 4),
+                         "bytes_per_launch": round(blend_bytes * frame_batch), "avg_launch_ms": round(blend_s * frame_batch * 1e3, 4),
+                         "frames_per_launch": frame_batch,
                          "launches_timed": int(blend_frames),
                          "achieved_touched": round(achieved_touched, 2), "touched_bytes_per_launch": round(touched_bytes)},
             "roofline_valu": None,                           # filled in by secondary_measurements (single GPU)
@@ -481,7 +492,7 @@ def secondary_measurements(ctx, capi, synth, rows, cams, views, n_splats, args):
     ctx.set_option(capi.OPT_PIPELINE_DEPTH, int(os.environ.get("GS_BENCH_DEPTH", "0")) or 3)
     # the same delivery with frames in flight: gs_render(GS_RENDER_ASYNC) copies each frame into its own page-locked buffer
     # behind its kernels, on the frame's stream
-    NB = 6
+    NB = 12                                                  # (3 lanes x 2 frames per launch in flight, twice over)
     bufs = [capi.host_frame(H, W) for _ in range(NB)]
 
     def loop_host(nn):
@@ -515,7 +526,7 @@ def secondary_measurements(ctx, capi, synth, rows, cams, views, n_splats, args):
         o.free()
     out["host_readback"].update({"fps_host_readback_pipelined": round(m / t, 1),
                                  "note_pipelined": "gs_render with GS_RENDER_ASYNC: frames queued on the three pipeline lanes, each copied into "
-                                                   "its own page-locked buffer on its lane's stream (six buffers, gs_sync every six frames)"})
+                                                   "its own page-locked buffer on its lane's stream (twelve buffers, gs_sync every twelve frames)"})
     # the blend without early termination (every reference-equivalent fragment evaluated), pipelined like the headline
     loop(6, capi.RENDER_ASYNC | capi.RENDER_NO_EARLY_OUT)
     m = min(n, 60)

@@ -1176,3 +1176,80 @@ def test_hip_frames_match_reference_glsl_goldens(name):
         cx.render(prm)
         frags = cx.stats()["n_frags"]
     _glpin.gl_compare(np.asarray(img).reshape(h, x1 - x0, 4), frags, c, "HIP vs GLSL-on-Mesa: " + name, early_termination=True)
+
+
+@pytest.mark.gpu
+def test_paired_frames_share_their_launches_and_equal_plain_frames(scene_small):
+    """GS_OPT_FRAME_BATCH = 2: consecutive asynchronous frames go out in pairs, one launch per kernel for both (grid (x, 2)), on a
+    lane and its twin.  Every frame must be exactly the frame a synchronous render gives -- with an odd number of frames, with
+    frames of another size in between (those go out alone), into device and into host buffers -- and the accumulated statistics
+    must count every frame."""
+    import torch
+    rows = np.asarray(scene_small["rows"]).reshape(-1, 32)
+    w, h = 480, 270
+    cams = [synth.index_html_camera(w, h, 27.0 * i, capi=capi) for i in range(13)]
+    small = synth.index_html_camera(320, 180, 45.0, capi=capi)
+    with capi.Context(0) as c:
+        c.push_splat(rows)
+        want = []
+        for cam in cams:
+            c.sort(cam["view"]); want.append(c.render(_params(cam)))
+        c.sort(small["view"]); want_small = c.render(_params(small))
+        c.set_option(capi.OPT_FRAME_BATCH, 2)
+        c.set_option(capi.OPT_PROFILE, 1)
+        for attempt in range(4):
+            bufs = [torch.zeros(w * h * 4, dtype=torch.uint8, device="cuda") for _ in cams]
+            sbuf = torch.zeros(320 * 180 * 4, dtype=torch.uint8, device="cuda")
+            for i, (cam, buf) in enumerate(zip(cams, bufs)):
+                c.sort(cam["view"], want_indices=False)
+                c.render_device(_params(cam, flags=capi.RENDER_ASYNC), buf.data_ptr())
+                if i == 6:                                              # a frame of another size in the middle of the stream
+                    c.sort(small["view"], want_indices=False)
+                    c.render_device(_params(small, flags=capi.RENDER_ASYNC), sbuf.data_ptr())
+            try:
+                c.sync()
+                break
+            except capi.GsError as e:
+                assert e.code == capi.E_RETRY and attempt < 3
+        torch.cuda.synchronize()
+        for b, wnt in zip(bufs, want):
+            assert np.array_equal(b.cpu().numpy().reshape(h, w, 4), wnt)
+        assert np.array_equal(sbuf.cpu().numpy().reshape(180, 320, 4), want_small)
+        s = c.stats()
+        assert s["acc_frames"] >= len(cams) + 1
+        c.set_option(capi.OPT_PROFILE, 0)
+        # host frames, queued: pairs copy both frames behind their shared kernels
+        pinned = [capi.host_frame(h, w) for _ in cams]
+        for attempt in range(4):
+            for cam, (buf, _) in zip(cams, pinned):
+                buf[...] = 9
+                c.sort(cam["view"], want_indices=False)
+                c.render_into(_params(cam, flags=capi.RENDER_ASYNC), buf)
+            try:
+                c.sync()
+                break
+            except capi.GsError as e:
+                assert e.code == capi.E_RETRY and attempt < 3
+        for (buf, _), wnt in zip(pinned, want):
+            assert np.array_equal(buf, wnt)
+        for _, o in pinned:
+            o.free()
+        # synchronous calls still work while the option is on
+        c.sort(cams[3]["view"]); assert np.array_equal(c.render(_params(cams[3])), want[3])
+        # pairs with the split blend (GS_OPT_BLEND_SPLIT: k_blend_px takes the long lists of both frames in one launch)
+        c.set_option(capi.OPT_BLEND_SPLIT, 48)
+        c.set_option(capi.OPT_NEAR_PERMILLE, 1000)                              # single round: the split rule sees the same lists in both passes
+        want_split = []
+        for cam in cams[:6]:
+            c.sort(cam["view"]); want_split.append(c.render(_params(cam)))
+        bufs = [torch.zeros(w * h * 4, dtype=torch.uint8, device="cuda") for _ in cams[:6]]
+        for cam, buf in zip(cams[:6], bufs):
+            c.sort(cam["view"], want_indices=False)
+            c.render_device(_params(cam, flags=capi.RENDER_ASYNC), buf.data_ptr())
+        c.sync(); torch.cuda.synchronize()
+        for b, wnt in zip(bufs, want_split):
+            assert np.array_equal(b.cpu().numpy().reshape(h, w, 4), wnt)
+        c.set_option(capi.OPT_BLEND_SPLIT, 0); c.set_option(capi.OPT_NEAR_PERMILLE, 0)
+        # switching the option off returns to plain lanes
+        c.set_option(capi.OPT_FRAME_BATCH, 1)
+        c.sort(cams[5]["view"]); assert np.array_equal(c.render(_params(cams[5])), want[5])

@@ -19,6 +19,7 @@ ap.add_argument("--near", type=int, default=180, help="pinned share (permille) o
 ap.add_argument("--sort-only", action="store_true")
 ap.add_argument("--split", type=int, default=0, help="GS_OPT_BLEND_SPLIT")
 ap.add_argument("--term", type=int, default=0, help="GS_OPT_TERMINATION (1/eps)")
+ap.add_argument("--batch", type=int, default=1, help="GS_OPT_FRAME_BATCH")
 ap.add_argument("--strip", default=None, help="k/G: render only strip k of G tile-aligned column strips (what one of G GPUs does)")
 ap.add_argument("--sort-for", action="store_true", help="with --strip: gs_sort_for the strip instead of the full gs_sort")
 a = ap.parse_args()
@@ -41,6 +42,8 @@ if a.term:
     ctx.set_option(capi.OPT_TERMINATION, a.term)
 if a.near:
     ctx.set_option(capi.OPT_NEAR_PERMILLE, a.near)
+if a.batch != 1:
+    ctx.set_option(capi.OPT_FRAME_BATCH, a.batch)
 
 
 def go(n):
