@@ -176,10 +176,12 @@ class GaussianSplatting {
 
   // Throughput mode -- what WebGL does behind the reference's back: the draw call returns at once and frames queue up on the
   // GPU (index.js:184-207).  frameQueued = this frame's sort (the order stays on the GPU) + draw, enqueued on one of the
-  // library's pipeline lanes; the pixels follow their kernels into one of `QUEUE_DEPTH` page-locked frames, which is what is
+  // library's pipeline lanes (two frames per launch, GS_OPT_FRAME_BATCH); the pixels follow their kernels into one of
+  // `QUEUE_DEPTH` page-locked frames, which is what is
   // returned -- valid after sync().  sync() throws code GS-9 (GS_E_RETRY) if the frames since the previous sync() have to be
   // queued again (a buffer grew).
   frameQueued(camera, viewport, options) {
+    if (!this._paired) { native.setOption(this.handle, 10, 2); this._paired = true; }   // GS_OPT_FRAME_BATCH: consecutive queued frames share their launches
     const u = this._tickUniforms(camera);
     native.sort(this.handle, u.view, u.cutout, false);
     const p = this._renderParams(camera, viewport, options);
@@ -219,7 +221,7 @@ class GaussianSplatting {
   remove() { native.destroy(this.handle); this._frames = null; }
 }
 
-GaussianSplatting.QUEUE_DEPTH = 3;                // frames in flight in throughput mode = GS_OPT_PIPELINE_DEPTH's default
+GaussianSplatting.QUEUE_DEPTH = 6;                // frames in flight in throughput mode: GS_OPT_PIPELINE_DEPTH's default x 2 frames per launch
 
 // Optional: expose the same component name to an A-Frame-like registry.
 function register(AFRAME) {

@@ -406,7 +406,9 @@ def pmc_traffic(world, n_splats, args):
             return None, "no PMC pass for this configuration"
         if pmc.get("_csrc_sha1") != h.hexdigest():
             return None, "profiles/pmc_hbm_traffic.json was taken from other kernel sources (stale): not reported"
-        key = [k for k in pmc if k.startswith("k_blend<false, 0")][0]
+        # (the timed loop pairs frames: its blend launches are k_twin<F_blend0<...>> over two frames; the per-frame kernel otherwise)
+        keys = [k for k in pmc if "F_blend0<" in k] or [k for k in pmc if k.startswith("k_blend<false, 0")]
+        key = max(keys, key=lambda k: pmc[k].get("launches", 0))
         return pmc[key]["hbm_bytes"], "profiles/pmc_hbm_traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this bench command; 2*FETCH + WRITE)"
     except Exception as e:
         return None, "no usable PMC profile (%s)" % type(e).__name__
