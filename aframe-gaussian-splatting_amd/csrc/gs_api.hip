@@ -272,7 +272,8 @@ static int run_frame_pair(gs_ctx *A, gs_ctx *B, const GsLaneCmd &s0, const GsLan
     gs_ctx *S[2] = { A, B };
     const float *view[2] = { s0.view, s1.view };
     const float *cut[2] = { s0.has_cutout ? s0.cutout : nullptr, s1.has_cutout ? s1.cutout : nullptr };
-    TRY(gs_run_sort2(S, view, cut));
+    const GsSortStrip *strip[2] = { s0.has_strip ? &s0.strip : nullptr, s1.has_strip ? &s1.strip : nullptr };
+    TRY(gs_run_sort2(S, view, cut, strip));
     const GsFrameUniforms U[2] = { r0.u, r1.u };
     uint8_t *dev[2] = { (uint8_t *)r0.device_rgba, (uint8_t *)r1.device_rgba };
     TRY(ensure_frame_buffers(A, U[0], dev[0] == nullptr));
@@ -286,6 +287,24 @@ static int run_frame_pair(gs_ctx *A, gs_ctx *B, const GsLaneCmd &s0, const GsLan
         GS_HIP(hipMemcpy2DAsync(r[k]->host_rgba, r[k]->stride ? r[k]->stride : sw * 4, src, sw * 4, sw * 4, (size_t)U[k].H, hipMemcpyDeviceToHost, A->stream));
     }
     return prof_advance(A);                                     // (the pair's HIP events sit in the primary lane's ring)
+}
+
+// Is the frame whose sort `s0` was just popped (primary lane L) followed in the queue by its render [+ its gather call] and by
+// the twin's sort, render [+ gather call], all of a kind that may share launches?  n_take = commands to pop, calls = 1 if the
+// frames are gathered ones (gs_render_gathered: one piece each, the gather issued after the shared kernels, in frame order).
+static bool pair_waiting(const gs_ctx *L, const GsLaneCmd &s0, const std::deque<GsLaneCmd> &q, int *n_take, int *calls)
+{
+    const gs_ctx *T = L->twin;
+    if (q.size() < 3 || q[0].type != 1 || q[0].target != L) return false;
+    const int c = (q.size() >= 2 && q[1].type == 2 && q[1].target == L) ? 1 : 0;
+    const size_t need = 3 + 2 * (size_t)c;
+    if (q.size() < need) return false;
+    const GsLaneCmd &s1 = q[1 + c], &r1 = q[2 + c];
+    if (s1.type != 0 || s1.target != T || r1.type != 1 || r1.target != T || s1.has_strip != s0.has_strip) return false;
+    if (c && (q[3 + c].type != 2 || q[3 + c].target != T)) return false;
+    if (!gs_frames_batchable(q[0].u, r1.u) || L->n != T->n) return false;
+    *n_take = (int)need; *calls = c;
+    return true;
 }
 
 static void lane_worker_main(gs_ctx *L)
@@ -303,28 +322,33 @@ static void lane_worker_main(gs_ctx *L)
         int rc = GS_OK;
         gs_ctx *T = c.target;
         bool paired = false;
-        GsLaneCmd r0, s1, r1;
-        if (c.type == 0 && T == L && L->twin && gs_root(L)->frame_batch == 2 && !c.has_strip && w->rc == GS_OK) {
+        int n_take = 0, calls = 0;
+        GsLaneCmd pc[5];                                           // the rest of a pair: render 0 [call 0] sort 1 render 1 [call 1]
+        if (c.type == 0 && T == L && L->twin && gs_root(L)->frame_batch == 2 && w->rc == GS_OK) {
             // the sort of a frame on the primary lane: if its render and the twin's frame are queued behind it (the caller is
             // normally several frames ahead of this thread; give it a moment if not), the two frames share their launches
-            w->cv_work.wait_for(lk, std::chrono::microseconds(200), [&] { return w->stop || w->q.size() >= 3; });
-            if (w->q.size() >= 3 && w->q[0].type == 1 && w->q[0].target == L && w->q[1].type == 0 && w->q[1].target == L->twin && !w->q[1].has_strip &&
-                w->q[2].type == 1 && w->q[2].target == L->twin && gs_frames_batchable(w->q[0].u, w->q[2].u) && L->n == L->twin->n) {
-                r0 = w->q[0]; s1 = w->q[1]; r1 = w->q[2];
-                w->q.pop_front(); w->q.pop_front(); w->q.pop_front();
+            w->cv_work.wait_for(lk, std::chrono::microseconds(200), [&] { return w->stop || pair_waiting(L, c, w->q, &n_take, &calls) || w->q.size() >= 5; });
+            if (pair_waiting(L, c, w->q, &n_take, &calls)) {
+                for (int k = 0; k < n_take; k++) { pc[k] = w->q.front(); w->q.pop_front(); }
                 paired = true;
             }
         }
         lk.unlock();
         // (a call is run even after a failure: the gather of a frame must be issued on every rank, or the others wait for it)
-        if (paired) rc = run_frame_pair(L, L->twin, c, r0, s1, r1);
+        if (paired) {
+            rc = run_frame_pair(L, L->twin, c, pc[0], pc[1 + calls], pc[2 + calls]);
+            if (calls) {                                           // the two gathers, in frame order, behind the shared kernels
+                const int g0 = pc[1].call(L), g1 = pc[4].call(L->twin);
+                if (rc == GS_OK) rc = g0 != GS_OK ? g0 : g1;
+            }
+        }
         else if (c.type == 2) { const int r2 = c.call(T); if (w->rc == GS_OK) rc = r2; }
         else if (w->rc == GS_OK) rc = c.type == 0 ? gs_run_sort(T, c.view, c.has_cutout ? c.cutout : nullptr, c.has_strip ? &c.strip : nullptr)
                                                   : render_async_on_lane(T, c.u, c.device_rgba, c.host_rgba, c.stride);
         lk.lock();
         if (rc != GS_OK && w->rc == GS_OK) { w->rc = rc; memcpy(w->err, scratch, sizeof w->err); }
         w->busy = false;
-        if (paired) { L->inflight -= 2; L->twin->inflight -= 2; w->n_pairs += 2; } else { T->inflight -= 1; if (c.type == 1) w->n_single++; }
+        if (paired) { L->inflight -= 2 + calls; L->twin->inflight -= 2 + calls; w->n_pairs += 2; } else { T->inflight -= 1; if (c.type == 1) w->n_single++; }
         w->cv_idle.notify_all();
     }
 }

@@ -265,7 +265,7 @@ int gs_launch_pack(gs_ctx *ctx, const uint4 *rows_dev, size_t first, size_t nrow
 // strip: sort only the splats that can reach columns [x0, x1) of the frame these uniforms draw (gs_sort_for); nullptr = all
 struct GsSortStrip { float mv[16], proj[16]; float focal, vw; int32_t x0, x1; };
 int gs_run_sort(gs_ctx *ctx, const float view[4], const float *cutout16, const GsSortStrip *strip = nullptr);
-int gs_run_sort2(gs_ctx *const S[2], const float *const view[2], const float *const cutout16[2]);   // two frames per launch
+int gs_run_sort2(gs_ctx *const S[2], const float *const view[2], const float *const cutout16[2], const GsSortStrip *const strip[2]);   // two frames per launch
 // ---- gs_render.hip
 int gs_run_render(gs_ctx *ctx, const GsFrameUniforms &u, uint8_t *device_out);
 int gs_run_round1(gs_ctx *ctx, const GsFrameUniforms &u, uint8_t *device_out);

@@ -205,33 +205,35 @@ __global__ __launch_bounds__(64 * NW) void k_sort_bucket(const float *__restrict
 }
 
 GS_BODY(F_sort_depth, k_sort_depth_body<false>);
+GS_BODY(F_sort_depth_strip, k_sort_depth_body<true>);
 template <int NW, bool COMPACT> GS_BODY(F_sort_bucket, k_sort_bucket_body<NW, COMPACT>);
 
 }  // namespace
 
+static void fill_sort_uniforms(const gs_ctx *ctx, const float view[4], const float *cutout16, const GsSortStrip *strip, SortUniforms &u, StripUniforms &su);
+
 // Two frames' sorts, one launch per kernel (GS_OPT_FRAME_BATCH): S[0] and S[1] are sibling lanes on ONE stream holding the same
-// resident data; each keeps its own depths, keys, tables, partial slots and control block.  No strip variant.
-int gs_run_sort2(gs_ctx *const S[2], const float *const view[2], const float *const cutout16[2])
+// resident data; each keeps its own depths, keys, tables, partial slots and control block.  Strip sorts (gs_sort_for) pair with strip sorts.
+int gs_run_sort2(gs_ctx *const S[2], const float *const view[2], const float *const cutout16[2], const GsSortStrip *const strip[2])
 {
     gs_ctx *ctx = S[0];
     const uint32_t n = (uint32_t)ctx->n;
     SortUniforms u[2];
-    StripUniforms su;
-    memset(&su, 0, sizeof su);
-    for (int k = 0; k < 2; k++) {
-        for (int i = 0; i < 4; i++) u[k].view[i] = (double)view[k][i];
-        u[k].has_cutout = cutout16[k] != nullptr;
-        for (int i = 0; i < 16; i++) u[k].cutout[i] = cutout16[k] ? (double)cutout16[k][i] : 0.0;
-        u[k].has_strip = 0;
-    }
+    StripUniforms su[2];
+    for (int k = 0; k < 2; k++) fill_sort_uniforms(S[k], view[k], cutout16[k], strip ? strip[k] : nullptr, u[k], su[k]);
+    const bool strips = u[0].has_strip && u[1].has_strip;
+    if (!strips) u[0].has_strip = u[1].has_strip = 0;              // (a pair takes one path: both strip sorts, or both plain)
     const uint32_t g = gs_radix_grid(n);
     hipStream_t st = ctx->stream;
     GS_PROF_RECORD(ctx, 0);
     uint32_t gd = gs_div_up(n, (uint32_t)(GS_DEPTH_IPT * GS_BLOCK));
     if (gd < 1) gd = 1;
     if (gd > GS_DEPTH_GRID) gd = GS_DEPTH_GRID;
-    gs_twin<F_sort_depth, GS_BLOCK>(gd, st, gs_pack_make((const float4 *)S[0]->sort_rows, (const float *)S[0]->bound_r, n, u[0], su, S[0]->depth, S[0]->part_min, S[0]->part_max, S[0]->part_cnt),
-                                    gs_pack_make((const float4 *)S[1]->sort_rows, (const float *)S[1]->bound_r, n, u[1], su, S[1]->depth, S[1]->part_min, S[1]->part_max, S[1]->part_cnt));
+#define GS_DEPTH2(F) gs_twin<F, GS_BLOCK>(gd, st,                                                                                                     \
+        gs_pack_make((const float4 *)S[0]->sort_rows, (const float *)S[0]->bound_r, n, u[0], su[0], S[0]->depth, S[0]->part_min, S[0]->part_max, S[0]->part_cnt), \
+        gs_pack_make((const float4 *)S[1]->sort_rows, (const float *)S[1]->bound_r, n, u[1], su[1], S[1]->depth, S[1]->part_min, S[1]->part_max, S[1]->part_cnt))
+    if (strips) GS_DEPTH2(F_sort_depth_strip); else GS_DEPTH2(F_sort_depth);
+#undef GS_DEPTH2
     const bool compact = !ctx->wide_pairs && n <= (1u << 25);
 #define GS_BUCKET2(NW, C) gs_twin<F_sort_bucket<NW, C>, 64 * NW>(g, st,                                                                                    \
         gs_pack_make((const float *)S[0]->depth, n, S[0]->key_a, (const unsigned long long *)S[0]->part_min, (const unsigned long long *)S[0]->part_max,     \
@@ -264,15 +266,14 @@ int gs_run_sort2(gs_ctx *const S[2], const float *const view[2], const float *co
     return GS_OK;
 }
 
-int gs_run_sort(gs_ctx *ctx, const float view[4], const float *cutout16, const GsSortStrip *strip)
+// the uniforms of one sort: view row and cutout matrix widened to f64; for a strip sort (gs_sort_for) the rows of the frame's
+// matrices the reach test needs and an upper bound of ||mat3(modelView)||_2
+static void fill_sort_uniforms(const gs_ctx *ctx, const float view[4], const float *cutout16, const GsSortStrip *strip, SortUniforms &u, StripUniforms &su)
 {
-    const uint32_t n = (uint32_t)ctx->n;
-    SortUniforms u;
     for (int i = 0; i < 4; i++) u.view[i] = (double)view[i];
     u.has_cutout = cutout16 != nullptr;
     for (int i = 0; i < 16; i++) u.cutout[i] = cutout16 ? (double)cutout16[i] : 0.0;
     u.has_strip = 0;
-    StripUniforms su;
     memset(&su, 0, sizeof su);
     if (strip && ctx->renderable) {
         const float *m = strip->mv, *p = strip->proj;
@@ -301,6 +302,15 @@ int gs_run_sort(gs_ctx *ctx, const float view[4], const float *cutout16, const G
         su.focal = strip->focal; su.half_w = 0.5f * strip->vw; su.sx0 = (float)strip->x0; su.sx1 = (float)strip->x1;
         u.has_strip = (su.norm_a == su.norm_a && su.focal > 0.0f && strip->x1 > strip->x0) ? 1 : 0;
     }
+
+}
+
+int gs_run_sort(gs_ctx *ctx, const float view[4], const float *cutout16, const GsSortStrip *strip)
+{
+    const uint32_t n = (uint32_t)ctx->n;
+    SortUniforms u;
+    StripUniforms su;
+    fill_sort_uniforms(ctx, view, cutout16, strip, u, su);
 
     const uint32_t g = gs_radix_grid(n);                         // same chunking as the radix kernels (pre-filled histogram rows)
     GS_PROF_RECORD(ctx, 0);

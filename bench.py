@@ -90,11 +90,6 @@ def main():
         # list are blended by four wavefronts, one pixel per lane (GS_OPT_BLEND_SPLIT; images within the same 1 LSB tolerance)
         ctx.set_option(capi.OPT_BLEND_SPLIT, blend_split)
     gathered = world > 1 or comm1 or args.xr                 # frames go through gs_render_gathered
-    # two frames per launch (GS_OPT_FRAME_BATCH): consecutive asynchronous frames share every kernel launch (grid (x, 2), each frame on
-    # its own scratch); gathered frames (several GPUs, XR) go out one by one
-    frame_batch = 1 if gathered else int(os.environ.get("GS_BENCH_BATCH", "2"))
-    if frame_batch != 1:
-        ctx.set_option(capi.OPT_FRAME_BATCH, frame_batch)
     torch_gather = False                                     # fallback only: see below
     if world > 1:
         ok = 1
@@ -134,6 +129,14 @@ def main():
     mine = [(v, x0, x1) for v, x0, x1, owner in pieces if owner == rank]
     own_px = sum((x1 - x0) * H for _, x0, x1 in mine)
     LANES = 3
+    # two frames per launch (GS_OPT_FRAME_BATCH): consecutive asynchronous frames share every kernel launch (grid (x, 2), each frame on
+    # its own scratch).  Gathered frames pair too when a rank draws ONE piece per frame (column strips; an XR eye per GPU): the two
+    # gathers follow the shared kernels in frame order
+    frame_batch = int(os.environ.get("GS_BENCH_BATCH", "2"))
+    if gathered and len(mine) != 1:
+        frame_batch = 1                                      # (both XR eyes on one GPU: two renders per frame, frames go out one by one)
+    if frame_batch != 1:
+        ctx.set_option(capi.OPT_FRAME_BATCH, frame_batch)
 
     def piece_params(k, v, x0, x1, flags):
         q = views[k][v]

@@ -960,15 +960,30 @@ def test_gathered_frames_through_rccl_world1(scene_small):
             p = ctypes.c_void_p()
             assert hip.hipMalloc(ctypes.byref(p), ctypes.c_size_t(w * h * 4)) == 0
             bufs.append(p)
-        for rep in range(2):
-            for cam, b in zip(cams, bufs):
-                c.sort(cam["view"], want_indices=False)
-                c.render_gathered(_params(cam), device_frames=[b.value], flags=capi.RENDER_ASYNC)
-            c.sync()
-        for cam, b, wnt in zip(cams, bufs, want):
-            got = np.empty((h, w, 4), np.uint8)
-            assert hip.hipMemcpy(got.ctypes.data_as(ctypes.c_void_p), b, ctypes.c_size_t(w * h * 4), 2) == 0
-            assert np.array_equal(got, wnt)
+        for rep in range(4):
+            # reps 2, 3: GS_OPT_FRAME_BATCH -- gathered frames of one piece per rank are paired as well (shared kernels, then the
+            # two gathers in frame order); rep 3 with the strip sort of the multi-GPU loop (gs_sort_gathered)
+            c.set_option(capi.OPT_FRAME_BATCH, 2 if rep >= 2 else 1)
+            for attempt in range(4):
+                for b in bufs:
+                    assert hip.hipMemset(b, 0, ctypes.c_size_t(w * h * 4)) == 0
+                for cam, b in zip(cams + cams, bufs + bufs):
+                    if rep == 3:
+                        c.sort_gathered(cam["view"], None, _params(cam))
+                    else:
+                        c.sort(cam["view"], want_indices=False)
+                    c.render_gathered(_params(cam), device_frames=[b.value], flags=capi.RENDER_ASYNC)
+                try:
+                    c.sync()
+                    break
+                except capi.GsError as e:
+                    assert e.code == capi.E_RETRY and attempt < 3
+            for cam, b, wnt in zip(cams, bufs, want):
+                got = np.empty((h, w, 4), np.uint8)
+                assert hip.hipMemcpy(got.ctypes.data_as(ctypes.c_void_p), b, ctypes.c_size_t(w * h * 4), 2) == 0
+                assert np.array_equal(got, wnt), rep
+        c.set_option(capi.OPT_FRAME_BATCH, 1)
+        for b in bufs:
             hip.hipFree(b)
         c.set_option(capi.OPT_COMM_SELF_COPY, 0)
         c.sort(cams[3]["view"]); c.render_gathered(_params(cams[3], flags=capi.RENDER_FLIP_Y), flags=capi.RENDER_FLIP_Y)
