@@ -235,8 +235,9 @@ GS_API int gs_gathered_size(gs_ctx *ctx, int view, int *width, int *height);
                                    unpaired rendering), and 2 x GS_OPT_PIPELINE_DEPTH frames are in flight.  A frame of
                                    ~1 M splats is a chain of 18 short kernels at the launch floor: sharing them is worth
                                    ~20 % in frames/s.  Pairing happens in the lanes' enqueue threads when both frames are
-                                   queued (needs GS_OPT_ENQUEUE_THREADS); frames that differ in size, flags or path, strip
-                                   sorts and gathered frames go out alone.                                                  */
+                                   queued (needs GS_OPT_ENQUEUE_THREADS); gathered frames of one piece per rank pair as well
+                                   (their gathers follow the shared kernels in frame order); frames that differ in size,
+                                   flags or path go out alone.                                                              */
 #define GS_OPT_COMM_SELF_COPY 8 /* value != 0: the root sends its own pieces to itself through RCCL too instead of rendering them
                                    in place (exercises send/recv on a single-GPU box; slower) */
 

@@ -11,6 +11,7 @@ cams = [synth.index_html_camera(W, H, 15.0 * i, capi=capi) for i in range(24)]
 P = lambda cam, **kw: capi.make_params(cam["gs_mv"], cam["gs_proj"], W, H, focal_=cam["focal"], **kw)
 ref = capi.Context(0); ref.set_option(capi.OPT_PIPELINE_DEPTH, 1)
 c = capi.Context(0)
+c.set_option(capi.OPT_FRAME_BATCH, 2)                       # frames pair from the start; toggled at random below
 n = 20000
 c.push_splat(rows[:n]); ref.push_splat(rows[:n])
 t0 = time.time(); ops = 0; checked = 0
@@ -31,7 +32,8 @@ while time.time() - t0 < float(os.environ.get("STRESS_SECONDS", "20")):
         elif r < 0.90: c.stats()
         elif r < 0.93: c.set_option(capi.OPT_PIPELINE_DEPTH, int(g.integers(1, 5)))
         elif r < 0.95: c.set_option(capi.OPT_ENQUEUE_THREADS, int(g.integers(0, 2)))
-        elif r < 0.97: c.set_option(capi.OPT_PROFILE, int(g.integers(0, 3)))
+        elif r < 0.96: c.set_option(capi.OPT_PROFILE, int(g.integers(0, 3)))
+        elif r < 0.97: c.set_option(capi.OPT_FRAME_BATCH, int(g.integers(1, 3)))
         elif r < 0.985 and n < rows.shape[0]:
             m = min(rows.shape[0], n + int(g.integers(1, 9000)))
             c.push_splat(rows[n:m]); ref.push_splat(rows[n:m]); n = m
