@@ -34,7 +34,7 @@ template <typename T> static int dev_alloc(gs_ctx *ctx, T **p, size_t count)
 template <typename T> static void dev_free(T *&p) { if (p) { (void)hipFree(p); p = nullptr; } }
 #define TRY(x) do { int _rc = (x); if (_rc != GS_OK) return _rc; } while (0)
 
-static int lane_drain(gs_ctx *L);
+static int lane_drain(gs_ctx *L, bool flush = false);
 static void lane_stop_worker(gs_ctx *L);
 
 static int ensure_radix_tables(gs_ctx *ctx, size_t items)
@@ -80,7 +80,7 @@ static int drain_all(gs_ctx *ctx)
     for (int i = 0; i < GS_MAX_LANES; i++) {
         gs_ctx *L = P->lanes[i];
         if (!L) continue;
-        const int rc = lane_drain(L);                              // a worker's failure surfaces at the next gs_sync()
+        const int rc = lane_drain(L, true);                        // a worker's failure surfaces at the next gs_sync()
         if (rc != GS_OK && first == GS_OK) { first = rc; if (L != ctx) memcpy(ctx->err, L->err, sizeof ctx->err); }
         if (L->stream) GS_HIP(hipStreamSynchronize(L->stream));
     }
@@ -255,6 +255,7 @@ struct GsLaneWorker {
     std::condition_variable cv_work, cv_idle;
     std::deque<GsLaneCmd> q;
     bool busy = false, stop = false;
+    bool flush = false;                                        // a drain is waiting: do not hold a frame back for a partner
     uint64_t n_pairs = 0, n_single = 0;                        // frames sent out in pairs / alone (GS_DEBUG_PAIRS=1 prints them at shutdown)
     int rc = GS_OK;                                            // first failure since the last drain ...
     char err[GS_ERRLEN] = "";                                  // ... and its message: the worker never writes the lane's err itself
@@ -327,7 +328,7 @@ static void lane_worker_main(gs_ctx *L)
         if (c.type == 0 && T == L && L->twin && gs_root(L)->frame_batch == 2 && w->rc == GS_OK) {
             // the sort of a frame on the primary lane: if its render and the twin's frame are queued behind it (the caller is
             // normally several frames ahead of this thread; give it a moment if not), the two frames share their launches
-            w->cv_work.wait_for(lk, std::chrono::microseconds(200), [&] { return w->stop || pair_waiting(L, c, w->q, &n_take, &calls) || w->q.size() >= 5; });
+            w->cv_work.wait_for(lk, std::chrono::microseconds(200), [&] { return w->stop || w->flush || pair_waiting(L, c, w->q, &n_take, &calls) || w->q.size() >= 5; });
             if (pair_waiting(L, c, w->q, &n_take, &calls)) {
                 for (int k = 0; k < n_take; k++) { pc[k] = w->q.front(); w->q.pop_front(); }
                 paired = true;
@@ -348,17 +349,19 @@ static void lane_worker_main(gs_ctx *L)
         lk.lock();
         if (rc != GS_OK && w->rc == GS_OK) { w->rc = rc; memcpy(w->err, scratch, sizeof w->err); }
         w->busy = false;
+        if (w->q.empty()) w->flush = false;
         if (paired) { L->inflight -= 2 + calls; L->twin->inflight -= 2 + calls; w->n_pairs += 2; } else { T->inflight -= 1; if (c.type == 1) w->n_single++; }
         w->cv_idle.notify_all();
     }
 }
 
 // wait until the lane's worker has enqueued everything it was given; returns (and clears) its first failure
-static int lane_drain(gs_ctx *L)
+static int lane_drain(gs_ctx *L, bool flush)
 {
     GsLaneWorker *w = L->exec ? L->exec->worker : L->worker;
     if (!w) return GS_OK;
     std::unique_lock<std::mutex> lk(w->m);
+    if (flush && L->inflight) { w->flush = true; w->cv_work.notify_all(); }   // (gs_sync / drain_all: a frame waiting for its partner goes out now)
     // everything handed over FOR THIS LANE has been executed (its twin's commands may still be queued: the two only share the thread)
     w->cv_idle.wait(lk, [&] { return L->inflight == 0; });
     const int rc = w->rc; w->rc = GS_OK;
@@ -989,10 +992,13 @@ GS_API int gs_sync(gs_ctx *ctx)
     GS_HIP(hipSetDevice(ctx->device));
     bool any_missed = false, any_over = false;
     uint32_t want = 0;
+    // everything is about to be drained: the first frame after this goes to a twin's slot, i.e. out at once and alone (an idle GPU
+    // should not wait for a partner frame), the pairs start with the frame after it
+    if (ctx->frame_batch == 2) ctx->rot &= ~1;
     for (int i = 0; i < GS_MAX_LANES; i++) {
         gs_ctx *L = ctx->lanes[i];
         if (!L) continue;
-        TRY(lane_rc(ctx, L, lane_drain(L)));
+        TRY(lane_rc(ctx, L, lane_drain(L, true)));
         LANE_HIP(L, hipStreamSynchronize(L->stream));
         TRY(lane_rc(ctx, L, prof_drain(L)));
         if (!L->async_pending) continue;
