@@ -1097,6 +1097,8 @@ def test_new_entry_points_reject_bad_arguments(ctx, scene_small):
                 lambda: ctx.sort_for(cam["view"], None, _params(cam, x0=0, x1=400)),   # beyond the frame
                 lambda: ctx.read_gathered(1, 320, 180),                                # no such view
                 lambda: ctx.set_option(capi.OPT_BLEND_SPLIT, -1),
+                lambda: ctx.set_option(capi.OPT_FRAME_BATCH, 3),                     # 1 or 2
+                lambda: ctx.set_option(capi.OPT_PIPELINE_DEPTH, 5),                  # 1 .. 4
                 lambda: ctx.comm_init(b"\0" * 128, 3, 2)):                              # rank outside the world
         with pytest.raises(capi.GsError) as e:
             bad()
