@@ -120,6 +120,70 @@ __global__ __launch_bounds__(GS_BLOCK) void k_sort_depth(const float4 *__restric
     k_sort_depth_body<STRIP>(rows, bound_r, n, u, su, depth_out, part_min, part_max, part_cnt);
 }
 
+// The same pass for the two frames of a pair (GS_OPT_FRAME_BATCH) in ONE sweep over the splats: at 20 M splats the sort rows are
+// 320 MB of the 400 MB this pass streams per frame, and both frames read the same rows -- one read, two view rows / cutout
+// matrices, two depth arrays and two sets of partials (20 M @ 4K: 2464 -> 2606 frames/s; no difference at 1 M, where the rows
+// are cache-resident).  Per frame exactly the arithmetic of k_sort_depth.
+template <bool STRIP>
+__global__ __launch_bounds__(GS_BLOCK) void k_sort_depth_pair(const float4 *__restrict__ rows, const float *__restrict__ bound_r, uint32_t n,
+                                                              SortUniforms u0, SortUniforms u1, StripUniforms su0, StripUniforms su1,
+                                                              float *__restrict__ depth0, float *__restrict__ depth1,
+                                                              unsigned long long *__restrict__ pmin0, unsigned long long *__restrict__ pmax0, uint32_t *__restrict__ pcnt0,
+                                                              unsigned long long *__restrict__ pmin1, unsigned long long *__restrict__ pmax1, uint32_t *__restrict__ pcnt1)
+{
+    __shared__ unsigned long long s_min[2], s_max[2];
+    __shared__ uint32_t s_cnt[2];
+    if (threadIdx.x < 2) { s_min[threadIdx.x] = ~0ull; s_max[threadIdx.x] = 0ull; s_cnt[threadIdx.x] = 0; }
+    __syncthreads();
+    constexpr uint32_t DCHUNK = GS_DEPTH_IPT * GS_BLOCK;
+    const uint32_t nchunks = (n + DCHUNK - 1) / DCHUNK;
+    unsigned long long mn0 = ~0ull, mx0 = 0ull, mn1 = ~0ull, mx1 = 0ull;
+    uint32_t cnt0 = 0, cnt1 = 0;
+    for (uint32_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
+        float4 mm[GS_DEPTH_IPT];
+        float sg[GS_DEPTH_IPT];
+#pragma unroll
+        for (int r = 0; r < GS_DEPTH_IPT; r++) {
+            const uint32_t i = c * DCHUNK + r * GS_BLOCK + threadIdx.x;
+            mm[r] = i < n ? rows[i] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            sg[r] = (STRIP && i < n) ? bound_r[i] : 0.0f;
+        }
+#pragma unroll
+        for (int r = 0; r < GS_DEPTH_IPT; r++) {
+            const uint32_t i = c * DCHUNK + r * GS_BLOCK + threadIdx.x;
+            if (i < n) {
+                const float4 m = mm[r];
+#define GS_DEPTH_ONE(U, SU, OUT, MN, MX, CNT) do {                                                                      \
+                    const double d = gsm::view_depth(U.view, m.x, m.y, m.z);                                               \
+                    const bool inside = U.has_cutout ? gsm::in_cutout(U.cutout, m.x, m.y, m.z) : true;                     \
+                    const bool keep = gsm::sort_keep(d, m.w, inside);                                                      \
+                    const bool mine = keep && (!STRIP || strip_may_touch(SU, m.x, m.y, m.z, (float)d, sg[r]));            \
+                    OUT[i] = mine ? (float)d : INFINITY;                                                                   \
+                    if (keep) { const unsigned long long e = gsm::f64_to_ordered(d); MN = e < MN ? e : MN; MX = e > MX ? e : MX; if (mine) CNT++; } \
+                } while (0)
+                GS_DEPTH_ONE(u0, su0, depth0, mn0, mx0, cnt0);
+                GS_DEPTH_ONE(u1, su1, depth1, mn1, mx1, cnt1);
+#undef GS_DEPTH_ONE
+            }
+        }
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        const unsigned long long a0 = shfl_xor_u64(mn0, m), b0 = shfl_xor_u64(mx0, m), a1 = shfl_xor_u64(mn1, m), b1 = shfl_xor_u64(mx1, m);
+        mn0 = a0 < mn0 ? a0 : mn0; mx0 = b0 > mx0 ? b0 : mx0; mn1 = a1 < mn1 ? a1 : mn1; mx1 = b1 > mx1 ? b1 : mx1;
+        cnt0 += __shfl_xor(cnt0, m, 64); cnt1 += __shfl_xor(cnt1, m, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (mx0) { atomicMin(&s_min[0], mn0); atomicMax(&s_max[0], mx0); atomicAdd(&s_cnt[0], cnt0); }
+        if (mx1) { atomicMin(&s_min[1], mn1); atomicMax(&s_max[1], mx1); atomicAdd(&s_cnt[1], cnt1); }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        pmin0[blockIdx.x] = s_min[0]; pmax0[blockIdx.x] = s_max[0]; pcnt0[blockIdx.x] = s_cnt[0];
+        pmin1[blockIdx.x] = s_min[1]; pmax1[blockIdx.x] = s_max[1]; pcnt1[blockIdx.x] = s_cnt[1];
+    }
+}
+
 // pass 2 (index.js:558-561): 16-bit bucket of the stored depth; culled -> GS_RADIX_SKIP, dropped bucket -> GS_CULLED_KEY.
 // Every workgroup first folds pass 1's partials (<= 2048 slots, L2-resident) into the global min/max.  One workgroup per
 // radix chunk (geometry NW as in gs_prims.hip): it also leaves radix pass A's histogram row of the chunk.
@@ -204,8 +268,6 @@ __global__ __launch_bounds__(64 * NW) void k_sort_bucket(const float *__restrict
     k_sort_bucket_body<NW, COMPACT>(depth, n, keys, part_min, part_max, part_cnt, nparts, hist, ctl);
 }
 
-GS_BODY(F_sort_depth, k_sort_depth_body<false>);
-GS_BODY(F_sort_depth_strip, k_sort_depth_body<true>);
 template <int NW, bool COMPACT> GS_BODY(F_sort_bucket, k_sort_bucket_body<NW, COMPACT>);
 
 }  // namespace
@@ -229,11 +291,13 @@ int gs_run_sort2(gs_ctx *const S[2], const float *const view[2], const float *co
     uint32_t gd = gs_div_up(n, (uint32_t)(GS_DEPTH_IPT * GS_BLOCK));
     if (gd < 1) gd = 1;
     if (gd > GS_DEPTH_GRID) gd = GS_DEPTH_GRID;
-#define GS_DEPTH2(F) gs_twin<F, GS_BLOCK>(gd, st,                                                                                                     \
-        gs_pack_make((const float4 *)S[0]->sort_rows, (const float *)S[0]->bound_r, n, u[0], su[0], S[0]->depth, S[0]->part_min, S[0]->part_max, S[0]->part_cnt), \
-        gs_pack_make((const float4 *)S[1]->sort_rows, (const float *)S[1]->bound_r, n, u[1], su[1], S[1]->depth, S[1]->part_min, S[1]->part_max, S[1]->part_cnt))
-    if (strips) GS_DEPTH2(F_sort_depth_strip); else GS_DEPTH2(F_sort_depth);
-#undef GS_DEPTH2
+    // ONE sweep computes both frames' depths: the rows are read once (the lanes of a context alias the owner's resident arrays)
+    if (S[0]->sort_rows != S[1]->sort_rows) { snprintf(GS_ERRBUF(ctx), GS_ERRLEN, "paired sort: the two lanes hold different splat arrays"); return GS_E_STATE; }
+#define GS_DEPTHP(ST) hipLaunchKernelGGL((k_sort_depth_pair<ST>), dim3(gd), dim3(GS_BLOCK), 0, st, (const float4 *)S[0]->sort_rows, (const float *)S[0]->bound_r, n,  \
+                                         u[0], u[1], su[0], su[1], S[0]->depth, S[1]->depth, S[0]->part_min, S[0]->part_max, S[0]->part_cnt,                            \
+                                         S[1]->part_min, S[1]->part_max, S[1]->part_cnt)
+    if (strips) GS_DEPTHP(true); else GS_DEPTHP(false);
+#undef GS_DEPTHP
     const bool compact = !ctx->wide_pairs && n <= (1u << 25);
 #define GS_BUCKET2(NW, C) gs_twin<F_sort_bucket<NW, C>, 64 * NW>(g, st,                                                                                    \
         gs_pack_make((const float *)S[0]->depth, n, S[0]->key_a, (const unsigned long long *)S[0]->part_min, (const unsigned long long *)S[0]->part_max,     \
