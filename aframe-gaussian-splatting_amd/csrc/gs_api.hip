@@ -290,22 +290,54 @@ static int run_frame_pair(gs_ctx *A, gs_ctx *B, const GsLaneCmd &s0, const GsLan
     return prof_advance(A);                                     // (the pair's HIP events sit in the primary lane's ring)
 }
 
-// Is the frame whose sort `s0` was just popped (primary lane L) followed in the queue by its render [+ its gather call] and by
-// the twin's sort, render [+ gather call], all of a kind that may share launches?  n_take = commands to pop, calls = 1 if the
-// frames are gathered ones (gs_render_gathered: one piece each, the gather issued after the shared kernels, in frame order).
-static bool pair_waiting(const gs_ctx *L, const GsLaneCmd &s0, const std::deque<GsLaneCmd> &q, int *n_take, int *calls)
+// What follows the sort `s0` that was just popped (a frame on the primary lane L) in the queue?
+//   GS_Q_PAIR    its render [+ its gather call] and the twin's sort, render [+ gather call], of a kind that may share launches
+//                (n_take commands to pop; calls = 1: gathered frames of one piece each, the gathers issued after the shared
+//                kernels in frame order);
+//   GS_Q_STEREO  the renders of TWO views of this frame (both XR eyes drawn by this context), which may share launches;
+//   GS_Q_SINGLE  enough to know that neither will form;  GS_Q_WAIT  not enough yet.
+enum { GS_Q_WAIT, GS_Q_PAIR, GS_Q_STEREO, GS_Q_SINGLE };
+static int classify_queue(const gs_ctx *L, const GsLaneCmd &s0, const std::deque<GsLaneCmd> &q, int *n_take, int *calls)
 {
     const gs_ctx *T = L->twin;
-    if (q.size() < 3 || q[0].type != 1 || q[0].target != L) return false;
-    const int c = (q.size() >= 2 && q[1].type == 2 && q[1].target == L) ? 1 : 0;
+    if (q.empty()) return GS_Q_WAIT;
+    if (q[0].type != 1 || q[0].target != L) return GS_Q_SINGLE;
+    if (q.size() < 2) return GS_Q_WAIT;
+    if (q[1].type == 1) {                                          // a second view of the same frame
+        const bool ok = q[1].target == L && !s0.has_strip && !q[0].host_rgba && !q[1].host_rgba && gs_frames_batchable(q[0].u, q[1].u) && L->n == T->n;
+        return ok ? GS_Q_STEREO : GS_Q_SINGLE;
+    }
+    const int c = (q[1].type == 2 && q[1].target == L) ? 1 : 0;
     const size_t need = 3 + 2 * (size_t)c;
-    if (q.size() < need) return false;
-    const GsLaneCmd &s1 = q[1 + c], &r1 = q[2 + c];
-    if (s1.type != 0 || s1.target != T || r1.type != 1 || r1.target != T || s1.has_strip != s0.has_strip) return false;
-    if (c && (q[3 + c].type != 2 || q[3 + c].target != T)) return false;
-    if (!gs_frames_batchable(q[0].u, r1.u) || L->n != T->n) return false;
+    if (q.size() < (size_t)(2 + c)) return GS_Q_WAIT;
+    const GsLaneCmd &s1 = q[1 + c];
+    if (s1.type != 0 || s1.target != T || s1.has_strip != s0.has_strip) return GS_Q_SINGLE;
+    if (q.size() < (size_t)(3 + c)) return GS_Q_WAIT;
+    const GsLaneCmd &r1 = q[2 + c];
+    if (r1.type != 1 || r1.target != T || !gs_frames_batchable(q[0].u, r1.u) || L->n != T->n) return GS_Q_SINGLE;
+    if (c) {
+        if (q.size() < need) return GS_Q_WAIT;
+        if (q[3 + c].type != 2 || q[3 + c].target != T) return GS_Q_SINGLE;
+    }
     *n_take = (int)need; *calls = c;
-    return true;
+    return GS_Q_PAIR;
+}
+
+// one sort, then the two views in ONE chain of launches: the second view on the twin's scratch, from the lane's order
+static int run_two_views(gs_ctx *A, gs_ctx *B, const GsLaneCmd &s0, const GsLaneCmd &r0, const GsLaneCmd &r1)
+{
+    gs_ctx *ctx = A;
+    TRY(gs_run_sort(A, s0.view, s0.has_cutout ? s0.cutout : nullptr, nullptr));
+    // the twin's kernels read the order and its length through THEIR lane: point it at the lane's (counts: the head of the control block)
+    GS_HIP(hipMemcpyAsync(B->ctl, A->ctl, offsetof(GsControl, n_valid), hipMemcpyDeviceToDevice, A->stream));
+    B->sorted = A->sorted; B->have_sort = true;
+    gs_ctx *S[2] = { A, B };
+    const GsFrameUniforms U[2] = { r0.u, r1.u };
+    uint8_t *dev[2] = { (uint8_t *)r0.device_rgba, (uint8_t *)r1.device_rgba };
+    TRY(ensure_frame_buffers(A, U[0], dev[0] == nullptr));
+    TRY(ensure_frame_buffers(B, U[1], dev[1] == nullptr));
+    TRY(gs_run_render2(S, U, dev));
+    return prof_advance(A);
 }
 
 static void lane_worker_main(gs_ctx *L)
@@ -322,21 +354,26 @@ static void lane_worker_main(gs_ctx *L)
         w->busy = true;
         int rc = GS_OK;
         gs_ctx *T = c.target;
-        bool paired = false;
+        bool paired = false, stereo = false;
         int n_take = 0, calls = 0;
         GsLaneCmd pc[5];                                           // the rest of a pair: render 0 [call 0] sort 1 render 1 [call 1]
         if (c.type == 0 && T == L && L->twin && gs_root(L)->frame_batch == 2 && w->rc == GS_OK) {
             // the sort of a frame on the primary lane: if its render and the twin's frame are queued behind it (the caller is
             // normally several frames ahead of this thread; give it a moment if not), the two frames share their launches
-            w->cv_work.wait_for(lk, std::chrono::microseconds(200), [&] { return w->stop || w->flush || pair_waiting(L, c, w->q, &n_take, &calls) || w->q.size() >= 5; });
-            if (pair_waiting(L, c, w->q, &n_take, &calls)) {
+            int kind = GS_Q_WAIT;
+            w->cv_work.wait_for(lk, std::chrono::microseconds(200), [&] { kind = classify_queue(L, c, w->q, &n_take, &calls); return w->stop || w->flush || kind != GS_Q_WAIT; });
+            if (kind == GS_Q_PAIR) {
                 for (int k = 0; k < n_take; k++) { pc[k] = w->q.front(); w->q.pop_front(); }
                 paired = true;
+            } else if (kind == GS_Q_STEREO) {
+                pc[0] = w->q.front(); w->q.pop_front(); pc[1] = w->q.front(); w->q.pop_front();
+                stereo = true;
             }
         }
         lk.unlock();
         // (a call is run even after a failure: the gather of a frame must be issued on every rank, or the others wait for it)
-        if (paired) {
+        if (stereo) rc = run_two_views(L, L->twin, c, pc[0], pc[1]);
+        else if (paired) {
             rc = run_frame_pair(L, L->twin, c, pc[0], pc[1 + calls], pc[2 + calls]);
             if (calls) {                                           // the two gathers, in frame order, behind the shared kernels
                 const int g0 = pc[1].call(L), g1 = pc[4].call(L->twin);
@@ -350,7 +387,8 @@ static void lane_worker_main(gs_ctx *L)
         if (rc != GS_OK && w->rc == GS_OK) { w->rc = rc; memcpy(w->err, scratch, sizeof w->err); }
         w->busy = false;
         if (w->q.empty()) w->flush = false;
-        if (paired) { L->inflight -= 2 + calls; L->twin->inflight -= 2 + calls; w->n_pairs += 2; } else { T->inflight -= 1; if (c.type == 1) w->n_single++; }
+        if (stereo) { L->inflight -= 3; w->n_pairs += 2; }
+        else if (paired) { L->inflight -= 2 + calls; L->twin->inflight -= 2 + calls; w->n_pairs += 2; } else { T->inflight -= 1; if (c.type == 1) w->n_single++; }
         w->cv_idle.notify_all();
     }
 }
@@ -521,9 +559,15 @@ static void refresh_lanes(gs_ctx *ctx)
 }
 
 // the lane a NEW frame goes to: the next one if the current frame was handed off asynchronously
-static int next_frame_lane(const gs_ctx *ctx, int *rot = nullptr)
+static int next_frame_lane(const gs_ctx *ctx, int *rot = nullptr, bool solo = false)
 {
     if (!(ctx->cur_async && !ctx->user_stream && ctx->pipe_depth > 1)) { if (rot) *rot = ctx->rot; return ctx->cur; }
+    if (ctx->frame_batch == 2 && ctx->enqueue_threads && solo) {
+        // a frame of two views (XR eyes on one GPU): primary lanes only -- the twin's scratch is the second view's
+        const int lane = (ctx->cur % GS_MAX_PRIMARY + 1) % ctx->pipe_depth;
+        if (rot) *rot = 2 * lane;
+        return lane;
+    }
     if (ctx->frame_batch == 2 && ctx->enqueue_threads) {
         // lane 0, its twin, lane 1, its twin, ...: the two frames of a pair sit behind each other in one enqueue thread's queue
         const int r = (ctx->rot + 1) % (2 * ctx->pipe_depth);
@@ -727,12 +771,15 @@ GS_API int gs_ply_to_splat_gpu(gs_ctx *ctx, const void *bytes, size_t nbytes, vo
     return GS_OK;
 }
 
-static int sort_common(gs_ctx *ctx, const float view[4], const float *cutout16, const GsSortStrip *strip, uint32_t *out_idx, uint32_t *out_n);
+static int sort_common(gs_ctx *ctx, const float view[4], const float *cutout16, const GsSortStrip *strip, uint32_t *out_idx, uint32_t *out_n, bool solo = false);
 
 GS_API int gs_sort(gs_ctx *ctx, const float view[4], const float *cutout16, uint32_t *out_idx, uint32_t *out_n)
 {
     return sort_common(ctx, view, cutout16, nullptr, out_idx, out_n);
 }
+
+// the sort of a frame of two views drawn by this context (gs_sort_gathered): with GS_OPT_FRAME_BATCH the frame stays on a primary lane
+int gs_sort_two_views(gs_ctx *ctx, const float view[4], const float *cutout16) { return sort_common(ctx, view, cutout16, nullptr, nullptr, nullptr, true); }
 
 GS_API int gs_sort_for(gs_ctx *ctx, const float view[4], const float *cutout16, const gs_render_params *strip, uint32_t *out_idx, uint32_t *out_n)
 {
@@ -751,7 +798,7 @@ GS_API int gs_sort_for(gs_ctx *ctx, const float view[4], const float *cutout16, 
     return sort_common(ctx, view, cutout16, persp ? &st : nullptr, out_idx, out_n);
 }
 
-static int sort_common(gs_ctx *ctx, const float view[4], const float *cutout16, const GsSortStrip *strip, uint32_t *out_idx, uint32_t *out_n)
+static int sort_common(gs_ctx *ctx, const float view[4], const float *cutout16, const GsSortStrip *strip, uint32_t *out_idx, uint32_t *out_n, bool solo)
 {
     CHECK_CTX(ctx);
     if (!view) FAIL(GS_E_BADARG, "gs_sort: view is NULL");
@@ -765,8 +812,9 @@ static int sort_common(gs_ctx *ctx, const float view[4], const float *cutout16, 
     // a sort starts a frame: it goes to the next lane if the previous frame was handed off with GS_RENDER_ASYNC
     gs_ctx *L = nullptr;
     int rot = 0;
-    const int lane = next_frame_lane(ctx, &rot);
+    const int lane = next_frame_lane(ctx, &rot, solo);
     TRY(get_lane(ctx, lane, &L));
+    if (solo && ctx->frame_batch == 2 && lane < GS_MAX_PRIMARY) { gs_ctx *T = nullptr; TRY(get_lane(ctx, lane + GS_MAX_PRIMARY, &T)); }   // (the second view's scratch)
     ctx->cur = lane; ctx->rot = rot; ctx->cur_async = false;
     if (ctx->enqueue_threads && ctx->pipe_depth > 1 && !ctx->user_stream && !out_idx && !out_n) {
         // nothing to hand back: the lane's worker thread does the launching (a failure surfaces at gs_sync())

@@ -19,6 +19,7 @@
 #include "gs_internal.h"
 
 extern "C" int gs_lane_call(gs_ctx *ctx, bool async, std::function<int(gs_ctx *)> call);   // gs_api.hip
+extern "C" int gs_sort_two_views(gs_ctx *ctx, const float view[4], const float *cutout16);       // gs_api.hip
 
 // the slice of rccl.h this file needs (types only; the functions come from dlsym)
 typedef struct ncclComm *ncclComm_t;
@@ -333,7 +334,8 @@ GS_API int gs_sort_gathered(gs_ctx *ctx, const float view[4], const float *cutou
     if (np < 0) FAILC(GS_E_BADARG, "gs_sort_gathered: bad frame sizes or more than 128 pieces");
     int mine = -1, count = 0;
     for (int i = 0; i < np; i++) if (pcs[i].owner == rank) { mine = i; count++; }
-    if (count != 1) return gs_sort(ctx, view, cutout16, nullptr, nullptr);       // both eyes here, or nothing to draw: the whole order
+    if (count == 2) return gs_sort_two_views(ctx, view, cutout16);                // both eyes here: the whole order, once
+    if (count != 1) return gs_sort(ctx, view, cutout16, nullptr, nullptr);       // nothing to draw (or an unusual partition): the whole order
     gs_render_params p = views[pcs[mine].view];
     p.x0 = pcs[mine].x0; p.x1 = pcs[mine].x1;
     return gs_sort_for(ctx, view, cutout16, &p, nullptr, nullptr);

@@ -131,10 +131,10 @@ def main():
     LANES = 3
     # two frames per launch (GS_OPT_FRAME_BATCH): consecutive asynchronous frames share every kernel launch (grid (x, 2), each frame on
     # its own scratch).  Gathered frames pair too when a rank draws ONE piece per frame (column strips; an XR eye per GPU): the two
-    # gathers follow the shared kernels in frame order
+    # gathers follow the shared kernels in frame order; a rank that draws BOTH XR eyes pairs the two views of a frame instead
     frame_batch = int(os.environ.get("GS_BENCH_BATCH", "2"))
-    if gathered and len(mine) != 1:
-        frame_batch = 1                                      # (both XR eyes on one GPU: two renders per frame, frames go out one by one)
+    if gathered and len(mine) not in (1, 2):
+        frame_batch = 1                                      # (pairs: two frames of one piece each, or the two views of one frame)
     if frame_batch != 1:
         ctx.set_option(capi.OPT_FRAME_BATCH, frame_batch)
 

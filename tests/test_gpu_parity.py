@@ -982,6 +982,26 @@ def test_gathered_frames_through_rccl_world1(scene_small):
                 got = np.empty((h, w, 4), np.uint8)
                 assert hip.hipMemcpy(got.ctypes.data_as(ctypes.c_void_p), b, ctypes.c_size_t(w * h * 4), 2) == 0
                 assert np.array_equal(got, wnt), rep
+        # XR with GS_OPT_FRAME_BATCH: the two EYES of a frame share the launches (one sort, the second view on the twin's scratch)
+        eb = []
+        for e in (l, r):
+            p = ctypes.c_void_p()
+            assert hip.hipMalloc(ctypes.byref(p), ctypes.c_size_t(e["vw"] * e["vh"] * 4)) == 0
+            eb.append(p)
+        for attempt in range(4):
+            for _ in range(5):
+                c.sort_gathered(head["view"], None, [_params(l), _params(r)])
+                c.render_gathered([_params(l), _params(r)], device_frames=[eb[0].value, eb[1].value], flags=capi.RENDER_ASYNC)
+            try:
+                c.sync()
+                break
+            except capi.GsError as e:
+                assert e.code == capi.E_RETRY and attempt < 3
+        for e, b, wnt in zip((l, r), eb, (wl, wr)):
+            got = np.empty((e["vh"], e["vw"], 4), np.uint8)
+            assert hip.hipMemcpy(got.ctypes.data_as(ctypes.c_void_p), b, ctypes.c_size_t(got.nbytes), 2) == 0
+            assert np.array_equal(got, wnt)
+            hip.hipFree(b)
         c.set_option(capi.OPT_FRAME_BATCH, 1)
         for b in bufs:
             hip.hipFree(b)
