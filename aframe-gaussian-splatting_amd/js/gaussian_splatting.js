@@ -221,7 +221,8 @@ class GaussianSplatting {
   remove() { native.destroy(this.handle); this._frames = null; }
 }
 
-GaussianSplatting.QUEUE_DEPTH = 6;                // frames in flight in throughput mode: GS_OPT_PIPELINE_DEPTH's default x 2 frames per launch
+GaussianSplatting.QUEUE_DEPTH = 7;                // frames to queue between two sync() calls in throughput mode: the first goes out alone
+                                                   // at once, then GS_OPT_PIPELINE_DEPTH's default (3) pairs
 
 // Optional: expose the same component name to an A-Frame-like registry.
 function register(AFRAME) {
