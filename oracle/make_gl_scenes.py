@@ -73,6 +73,11 @@ if "--big" in sys.argv:
     scene("c1_1m_720p_strip", rows_1m, 1280, 720, synth.compose((0.0, 1.6, 0.0)), synth.compose((0.0, 1.5, -2.0), 300.0),
           synth.perspective(80.0, 1280 / 720), strip=(400, 464), recipe=rec_1m,
           note="BASELINE configs[0]: the same scene at 1280x720, entity yaw 300 deg, columns 400..463")
+    # BASELINE configs[4]'s frame size with the 1 M scene (its 20 M rows are beyond what node packs in reasonable time): 3840x2160 has
+    # 32 400 tiles -- 15 bits of tile id, so the binning takes its 8-byte pair records (GS_OPT_WIDE_PAIRS' path) -- one 64-pixel strip
+    scene("c5_size_4k_strip", rows_1m, 3840, 2160, synth.compose((0.0, 1.6, 0.0)), synth.compose((0.0, 1.5, -2.0), 222.0),
+          synth.perspective(80.0, 3840 / 2160), strip=(2112, 2176), recipe=rec_1m,
+          note="3840x2160 (BASELINE configs[4]'s size) with the 1 M scene, entity yaw 222 deg, columns 2112..2175")
     # BASELINE configs[3]: XR, 2064x2208 x 0.5 per eye; ONE sort from the head camera (index.js:441), drawn with the right eye's camera
     wx, hx = 1032, 1104
     ro, lo = math.tan(math.radians(54)), math.tan(math.radians(40))
