@@ -559,9 +559,12 @@ static void refresh_lanes(gs_ctx *ctx)
 }
 
 // the lane a NEW frame goes to: the next one if the current frame was handed off asynchronously
+// do asynchronous frames move on to another lane / twin?  (more than one lane, or one lane whose frames pair with its twin's)
+static inline bool gs_rotates(const gs_ctx *ctx) { return ctx->pipe_depth > 1 || (ctx->frame_batch == 2 && ctx->enqueue_threads); }
+
 static int next_frame_lane(const gs_ctx *ctx, int *rot = nullptr, bool solo = false)
 {
-    if (!(ctx->cur_async && !ctx->user_stream && ctx->pipe_depth > 1)) { if (rot) *rot = ctx->rot; return ctx->cur; }
+    if (!(ctx->cur_async && !ctx->user_stream && gs_rotates(ctx))) { if (rot) *rot = ctx->rot; return ctx->cur; }
     if (ctx->frame_batch == 2 && ctx->enqueue_threads && solo) {
         // a frame of two views (XR eyes on one GPU): primary lanes only -- the twin's scratch is the second view's
         const int lane = (ctx->cur % GS_MAX_PRIMARY + 1) % ctx->pipe_depth;
@@ -816,7 +819,7 @@ static int sort_common(gs_ctx *ctx, const float view[4], const float *cutout16, 
     TRY(get_lane(ctx, lane, &L));
     if (solo && ctx->frame_batch == 2 && lane < GS_MAX_PRIMARY) { gs_ctx *T = nullptr; TRY(get_lane(ctx, lane + GS_MAX_PRIMARY, &T)); }   // (the second view's scratch)
     ctx->cur = lane; ctx->rot = rot; ctx->cur_async = false;
-    if (ctx->enqueue_threads && ctx->pipe_depth > 1 && !ctx->user_stream && !out_idx && !out_n) {
+    if (ctx->enqueue_threads && gs_rotates(ctx) && !ctx->user_stream && !out_idx && !out_n) {
         // nothing to hand back: the lane's worker thread does the launching (a failure surfaces at gs_sync())
         GsLaneCmd c;
         c.type = 0; memcpy(c.view, view, sizeof c.view);
@@ -946,7 +949,7 @@ static int render_sync_on_lane(gs_ctx *ctx, const GsFrameUniforms &u, void *devi
 int gs_lane_call(gs_ctx *ctx, bool async, std::function<int(gs_ctx *)> call)
 {
     gs_ctx *L = ctx->lanes[ctx->cur];
-    if (async && ctx->enqueue_threads && ctx->pipe_depth > 1 && !ctx->user_stream) {
+    if (async && ctx->enqueue_threads && gs_rotates(ctx) && !ctx->user_stream) {
         GsLaneCmd c;
         c.type = 2; c.has_cutout = false; c.has_strip = false; c.device_rgba = nullptr; c.host_rgba = nullptr; c.stride = 0; c.call = std::move(call);
         L->async_pending = true; ctx->cur_async = true;
@@ -973,7 +976,7 @@ int gs_render_uniforms(gs_ctx *ctx, const GsFrameUniforms &u, void *device_rgba,
     if (async) {
         if (host_rgba && stride && stride < (size_t)(u.x1 - u.x0) * 4) FAIL(GS_E_BADARG, "stride %zu smaller than a row (%zu bytes)", stride, (size_t)(u.x1 - u.x0) * 4);
         L->async_pending = true; ctx->cur_async = true;
-        if (ctx->enqueue_threads && ctx->pipe_depth > 1 && !ctx->user_stream) {
+        if (ctx->enqueue_threads && gs_rotates(ctx) && !ctx->user_stream) {
             GsLaneCmd c;
             c.type = 1; c.has_cutout = false; c.has_strip = false; c.u = u; c.device_rgba = device_rgba; c.host_rgba = host_rgba; c.stride = stride;
             if (lane_push(L, c) != GS_OK) FAIL(GS_E_OOM, "out of host memory");

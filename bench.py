@@ -306,7 +306,7 @@ def main():
     total_frags = sum(frags[(args.warmup + i) % ORBIT_FRAMES] for i in range(args.steps))
     extras = None
     if rank == 0 and world == 1 and not args.no_extras and not args.xr:
-        extras = secondary_measurements(ctx, capi, synth, rows, cams, views, n_splats, args)
+        extras = secondary_measurements(ctx, capi, synth, rows, cams, views, n_splats, args, frame_batch)
     if rank == 0:
         K = args.steps
         fps = K / elapsed
@@ -420,7 +420,7 @@ def pmc_traffic(world, n_splats, args):
 N_TRAIN_DEFAULT = 1 << 20
 
 
-def secondary_measurements(ctx, capi, synth, rows, cams, views, n_splats, args):
+def secondary_measurements(ctx, capi, synth, rows, cams, views, n_splats, args, frame_batch=1):
     """What the headline number does not show: one frame at a time, the frame delivered to host
     memory, the blend without early termination, and a scene whose tiles do NOT saturate.  Single GPU, untimed for `value`."""
     out = {}
@@ -445,12 +445,20 @@ def secondary_measurements(ctx, capi, synth, rows, cams, views, n_splats, args):
         return time.perf_counter() - t0
 
     n = min(args.steps, 240)
-    # latency: one frame in flight (pipeline depth 1): the kernel chain of a frame alone on the GPU
+    # latency: one frame in flight (pipeline depth 1, frames not paired): the kernel chain of a frame alone on the GPU
+    ctx.set_option(capi.OPT_FRAME_BATCH, 1)
     ctx.set_option(capi.OPT_PIPELINE_DEPTH, 1)
     loop(24, capi.RENDER_ASYNC)
     t = loop(n, capi.RENDER_ASYNC) or loop(n, capi.RENDER_ASYNC)
     out["latency"] = {"fps_depth1": round(n / t, 1), "ms_per_frame_depth1": round(t / n * 1e3, 4),
                       "note": "GS_OPT_PIPELINE_DEPTH = 1: frames enqueued back to back on ONE stream, nothing overlaps"}
+    # the same single stream with two frames per launch (GS_OPT_FRAME_BATCH = 2 at depth 1): still nothing overlaps, but a chain of
+    # 18 launches draws two frames -- a throughput figure for one stream, NOT a frame's latency (that is ms_per_frame_depth1)
+    ctx.set_option(capi.OPT_FRAME_BATCH, 2)
+    loop(24, capi.RENDER_ASYNC)
+    t2 = loop(n, capi.RENDER_ASYNC) or loop(n, capi.RENDER_ASYNC)
+    ctx.set_option(capi.OPT_FRAME_BATCH, 1)
+    out["latency"].update({"fps_one_stream_paired": round(n / t2, 1), "ms_per_frame_one_stream_paired": round(t2 / n * 1e3, 4)})
     # entries the blend evaluates (longest-lived lane per tile) -> VALU roofline of the blend, one frame at a time so that the
     # kernel's HIP-event time is its own
     ctx.set_option(capi.OPT_PROFILE, 2)
@@ -495,6 +503,7 @@ def secondary_measurements(ctx, capi, synth, rows, cams, views, n_splats, args):
                             "note": "synchronous gs_render into page-locked host memory (%.1f MB D2H per frame over PCIe), one frame at a time"
                                     % (W * H * 4 / 1e6)}
     ctx.set_option(capi.OPT_PIPELINE_DEPTH, int(os.environ.get("GS_BENCH_DEPTH", "0")) or 3)
+    ctx.set_option(capi.OPT_FRAME_BATCH, frame_batch)           # (as in the timed loop)
     # the same delivery with frames in flight: gs_render(GS_RENDER_ASYNC) copies each frame into its own page-locked buffer
     # behind its kernels, on the frame's stream
     NB = 12                                                  # (3 lanes x 2 frames per launch in flight, twice over)

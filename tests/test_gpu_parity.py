@@ -1273,6 +1273,16 @@ def test_paired_frames_share_their_launches_and_equal_plain_frames(scene_small):
             o.free()
         # synchronous calls still work while the option is on
         c.sort(cams[3]["view"]); assert np.array_equal(c.render(_params(cams[3])), want[3])
+        # one lane: its frames pair with its twin's on the single stream
+        c.set_option(capi.OPT_PIPELINE_DEPTH, 1)
+        bufs = [torch.zeros(w * h * 4, dtype=torch.uint8, device="cuda") for _ in cams[:7]]
+        for cam, buf in zip(cams[:7], bufs):
+            c.sort(cam["view"], want_indices=False)
+            c.render_device(_params(cam, flags=capi.RENDER_ASYNC), buf.data_ptr())
+        c.sync(); torch.cuda.synchronize()
+        for b, wnt in zip(bufs, want[:7]):
+            assert np.array_equal(b.cpu().numpy().reshape(h, w, 4), wnt)
+        c.set_option(capi.OPT_PIPELINE_DEPTH, 3)
         # pairs with the split blend (GS_OPT_BLEND_SPLIT: k_blend_px takes the long lists of both frames in one launch)
         c.set_option(capi.OPT_BLEND_SPLIT, 48)
         c.set_option(capi.OPT_NEAR_PERMILLE, 1000)                              # single round: the split rule sees the same lists in both passes
