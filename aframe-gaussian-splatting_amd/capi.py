@@ -5,6 +5,7 @@ library is missing, or no GPU is usable, this raises.
 """
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 
@@ -75,6 +76,14 @@ def load(build_if_missing=True):
         if not build_if_missing:
             raise FileNotFoundError(_build.LIB + " not built; run __graft_entry__.build()")
         _build.build_lib()
+    # A process that also uses torch must load torch's HIP runtime first: the wheel ships its own libamdhip64 / libhsa-runtime64 under
+    # the same sonames as /opt/rocm's, the first one loaded serves both, and torch finds no GPU through the other one
+    # ("No HIP GPUs are available").  Only matters where torch is installed; the library itself does not need it.
+    if "torch" not in sys.modules and os.environ.get("GS_SPLAT_NO_TORCH_PRELOAD") is None:
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     # GS_SPLAT_LIB: load another build of the same library (A/B measurements of kernel variants); never a different backend
     L = C.CDLL(os.environ.get("GS_SPLAT_LIB") or _build.LIB)
     vp, sz, i32, u32p, f32 = C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_uint32), C.c_float

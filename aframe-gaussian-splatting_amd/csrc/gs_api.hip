@@ -387,7 +387,7 @@ static void lane_worker_main(gs_ctx *L)
         if (rc != GS_OK && w->rc == GS_OK) { w->rc = rc; memcpy(w->err, scratch, sizeof w->err); }
         w->busy = false;
         if (w->q.empty()) w->flush = false;
-        if (stereo) { L->inflight -= 3; w->n_pairs += 2; }
+        if (stereo) { L->inflight -= 3; w->n_pairs += 2; L->twin->async_pending = true; }   // (the second view's counters sit in the twin's control block)
         else if (paired) { L->inflight -= 2 + calls; L->twin->inflight -= 2 + calls; w->n_pairs += 2; } else { T->inflight -= 1; if (c.type == 1) w->n_single++; }
         w->cv_idle.notify_all();
     }

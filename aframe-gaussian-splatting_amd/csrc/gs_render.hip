@@ -1034,62 +1034,48 @@ int run_round(gs_ctx *ctx, const GsFrameUniforms &u, uint8_t *out, bool last_rou
     return GS_OK;
 }
 
-GS_BODY(F_project0, k_project_body<0>);
-GS_BODY(F_pairs_check0, k_pairs_check_body<0>);
-template <bool P32> GS_BODY(F_emit0, k_emit_body<0, P32>);
+template <int ROUND> GS_BODY(F_project, k_project_body<ROUND>);
+template <int ROUND> GS_BODY(F_pairs_check, k_pairs_check_body<ROUND>);
+template <int ROUND, bool P32> GS_BODY(F_emit, k_emit_body<ROUND, P32>);
 GS_BODY(F_tile_ranges, k_tile_ranges_body);
-template <bool SCENE> GS_BODY(F_blend0, k_blend_body<false, 0, SCENE>);
-template <bool SCENE> GS_BODY(F_blend_px0, k_blend_px_body<0, SCENE>);
+template <int ROUND, bool SCENE> GS_BODY(F_blend, k_blend_body<false, ROUND, SCENE>);
+template <int ROUND, bool SCENE> GS_BODY(F_blend_px, k_blend_px_body<ROUND, SCENE>);
 
-}  // namespace
-
-// Two frames that take the same path, one launch per kernel (GS_OPT_FRAME_BATCH; grid (x, 2), blockIdx.y = the frame).  S[0], S[1]:
-// sibling lanes on ONE stream, each with its own scratch, control block and output.  Only the steady-state path exists in
-// this form: binning round 0 alone (a single round, or round 1 skipped optimistically), no counting / recording --
-// gs_frames_batchable() says whether two frames qualify; everything else takes the per-frame path.
-bool gs_frames_batchable(const GsFrameUniforms &a, const GsFrameUniforms &b)
-{
-    const bool one_round = a.near_count == 0xFFFFFFFFu || a.skip_round1;
-    return one_round && a.near_count == b.near_count && a.skip_round1 == b.skip_round1 && a.W == b.W && a.H == b.H && a.x0 == b.x0 && a.x1 == b.x1 &&
-           a.flags == b.flags && !(a.flags & (GS_RENDER_COUNT_FRAGS | GS_RENDER_COUNT_EVALUATED)) && !a.record_staged && !b.record_staged &&
-           a.split_min == b.split_min && a.has_depth == b.has_depth && a.has_scene_rgba == b.has_scene_rgba && a.t_eps == b.t_eps;
-}
-
-int gs_run_render2(gs_ctx *const S[2], const GsFrameUniforms U[2], uint8_t *const device_out[2])
+// run_round() for two frames that take the same path: every kernel once, on a grid (x, 2) (blockIdx.y = the frame)
+template <int ROUND>
+int run_round2(gs_ctx *const S[2], const GsFrameUniforms U[2], uint8_t *const out[2], bool last_round)
 {
     gs_ctx *ctx = S[0];
     const GsFrameUniforms &u = U[0];
     const uint32_t ntiles = (uint32_t)u.tiles_x * (uint32_t)u.tiles_y;
     const uint32_t Vmax = (uint32_t)ctx->n;
     hipStream_t st = ctx->stream;
-    uint8_t *out[2] = { device_out[0] ? device_out[0] : S[0]->fb, device_out[1] ? device_out[1] : S[1]->fb };
-    GS_PROF_RECORD(ctx, 2);
     uint32_t g = gs_div_up(Vmax, GS_BLOCK); if (g > GS_MAX_PART) g = GS_MAX_PART;
-    if (u.near_count != 0xFFFFFFFFu) { const uint32_t gn = gs_div_up(u.near_count < Vmax ? u.near_count : Vmax, GS_BLOCK); if (gn < g) g = gn ? gn : 1; }
+    const uint32_t small = 512;
+    if (ROUND == 1 && g > small) g = small;
+    if (ROUND == 0 && u.near_count != 0xFFFFFFFFu) { const uint32_t gn = gs_div_up(u.near_count < Vmax ? u.near_count : Vmax, GS_BLOCK); if (gn < g) g = gn ? gn : 1; }
     const uint32_t pc = (uint32_t)(S[0]->pair_cap < S[1]->pair_cap ? S[0]->pair_cap : S[1]->pair_cap);
-    const uint32_t ph = __atomic_load_n(&gs_root(ctx)->pair_hint, __ATOMIC_RELAXED);
-    const bool last_round = true;
-#define PK(k, ...) gs_pack_make(__VA_ARGS__)
-    gs_twin<F_project0, GS_BLOCK>(g, st,
+    const uint32_t ph = ROUND == 1 ? (uint32_t)(small * GS_CHUNK_S) : __atomic_load_n(&gs_root(ctx)->pair_hint, __ATOMIC_RELAXED);
+    gs_twin<F_project<ROUND>, GS_BLOCK>(g, st,
         gs_pack_make((const uint32_t *)S[0]->sorted, (const uint4 *)S[0]->splat, U[0], S[0]->proj, S[0]->rect, S[0]->tile_count, S[0]->spine, S[0]->part_vis,
                      (const uint32_t *)S[0]->unsat_mask, S[0]->zwin, S[0]->ctl),
         gs_pack_make((const uint32_t *)S[1]->sorted, (const uint4 *)S[1]->splat, U[1], S[1]->proj, S[1]->rect, S[1]->tile_count, S[1]->spine, S[1]->part_vis,
                      (const uint32_t *)S[1]->unsat_mask, S[1]->zwin, S[1]->ctl));
     GS_HIP(hipGetLastError());
-    GS_PROF_RECORD(ctx, 3);
-    gs_twin<F_pairs_check0, GS_BLOCK>(1, st,
+    if (ROUND == 0) GS_PROF_RECORD(ctx, 3);
+    gs_twin<F_pairs_check<ROUND>, GS_BLOCK>(1, st,
         gs_pack_make(S[0]->ctl, (uint32_t)S[0]->pair_cap, S[0]->spine, (const uint32_t *)S[0]->part_vis, g, U[0].near_count, last_round ? 1 : 0, S[0]->unsat_mask,
                      (uint32_t)u.tiles_y * u.mask_words, S[0]->emit_extra),
         gs_pack_make(S[1]->ctl, (uint32_t)S[1]->pair_cap, S[1]->spine, (const uint32_t *)S[1]->part_vis, g, U[1].near_count, last_round ? 1 : 0, S[1]->unsat_mask,
                      (uint32_t)u.tiles_y * u.mask_words, S[1]->emit_extra));
     const int tb = bits_for(ntiles);
-    const uint32_t jrange = (u.near_count != 0xFFFFFFFFu && u.near_count < Vmax) ? u.near_count : Vmax;
+    const uint32_t jrange = ROUND == 0 ? (u.near_count != 0xFFFFFFFFu && u.near_count < Vmax ? u.near_count : Vmax) : Vmax;
     const int jb = bits_for(jrange);
     const bool p32 = !ctx->wide_pairs && tb + jb <= 32;
     GsFrameUniforms V[2] = { U[0], U[1] };
     V[0].pair_jbits = V[1].pair_jbits = p32 ? (uint32_t)jb : 0u;
-    uint32_t ge = g + gs_div_up(ph ? ph : pc, GS_EMIT_PAIRS); if (ge > GS_MAX_PART) ge = GS_MAX_PART;
-#define GS_EMIT2(P) gs_twin<F_emit0<P>, GS_BLOCK>(ge, st,                                                                                              \
+    uint32_t ge = g + (ROUND == 1 ? 0u : gs_div_up(ph ? ph : pc, GS_EMIT_PAIRS)); if (ge > GS_MAX_PART) ge = GS_MAX_PART;
+#define GS_EMIT2(P) gs_twin<F_emit<ROUND, P>, GS_BLOCK>(ge, st,                                                                                         \
         gs_pack_make((const gsm::Projected *)S[0]->proj, (const uint2 *)S[0]->rect, (const uint32_t *)S[0]->tile_count, (const uint32_t *)S[0]->spine,    \
                      (const uint2 *)S[0]->emit_extra, V[0], (void *)S[0]->pair_a, (const uint32_t *)S[0]->unsat_mask, (const GsControl *)S[0]->ctl),      \
         gs_pack_make((const gsm::Projected *)S[1]->proj, (const uint2 *)S[1]->rect, (const uint32_t *)S[1]->tile_count, (const uint32_t *)S[1]->spine,    \
@@ -1117,28 +1103,57 @@ int gs_run_render2(gs_ctx *const S[2], const GsFrameUniforms U[2], uint8_t *cons
         if (rc != GS_OK) return rc;
         fpairs[0] = S[0]->pair_a; fpairs[1] = S[1]->pair_a;
     }
-    gs_twin<F_tile_ranges, GS_BLOCK>(2048, st, gs_pack_make(fpairs[0], V[0].pair_jbits, S[0]->tile_range, ntiles, 0, (const GsControl *)S[0]->ctl),
-                                     gs_pack_make(fpairs[1], V[1].pair_jbits, S[1]->tile_range, ntiles, 0, (const GsControl *)S[1]->ctl));
+    gs_twin<F_tile_ranges, GS_BLOCK>(ROUND == 1 ? small : 2048, st,
+                                     gs_pack_make(fpairs[0], V[0].pair_jbits, S[0]->tile_range, ntiles, ROUND, (const GsControl *)S[0]->ctl),
+                                     gs_pack_make(fpairs[1], V[1].pair_jbits, S[1]->tile_range, ntiles, ROUND, (const GsControl *)S[1]->ctl));
     GS_HIP(hipGetLastError());
-    GS_PROF_RECORD(ctx, 4);
-    V[0].split_min = V[1].split_min = u.split_min;
-#define GS_BLENDPX2(SC) gs_twin<F_blend_px0<SC>, 256>(ntiles < 2048 ? ntiles : 2048, st,                                                               \
+    if (ROUND == 0) GS_PROF_RECORD(ctx, 4);
+    const uint32_t gb = ROUND == 1 ? (ntiles < 1024 ? ntiles : 1024) : ntiles;
+    const bool scene = u.has_depth || u.has_scene_rgba;
+#define GS_BLENDPX2(SC) gs_twin<F_blend_px<ROUND, SC>, 256>(ntiles < 2048 ? ntiles : 2048, st,                                                          \
         gs_pack_make((const uint2 *)S[0]->tile_range, fpairs[0], (const gsm::Projected *)S[0]->proj, V[0], out[0], S[0]->state, S[0]->unsat_mask,         \
                      (const float *)S[0]->zwin, (const float *)S[0]->scene_depth, (const uint32_t *)S[0]->scene_rgba, S[0]->ctl),                        \
         gs_pack_make((const uint2 *)S[1]->tile_range, fpairs[1], (const gsm::Projected *)S[1]->proj, V[1], out[1], S[1]->state, S[1]->unsat_mask,         \
                      (const float *)S[1]->zwin, (const float *)S[1]->scene_depth, (const uint32_t *)S[1]->scene_rgba, S[1]->ctl))
-    if (u.split_min) { if (u.has_depth || u.has_scene_rgba) GS_BLENDPX2(true); else GS_BLENDPX2(false); }   // the tiles with long lists first
+    if (u.split_min) { if (scene) GS_BLENDPX2(true); else GS_BLENDPX2(false); }   // the tiles with long lists first
 #undef GS_BLENDPX2
-#define GS_BLEND2(SC) gs_twin<F_blend0<SC>, 64>(ntiles, st,                                                                                             \
+#define GS_BLEND2(SC) gs_twin<F_blend<ROUND, SC>, 64>(gb, st,                                                                                           \
         gs_pack_make((const uint2 *)S[0]->tile_range, fpairs[0], (const gsm::Projected *)S[0]->proj, V[0], out[0], S[0]->state, S[0]->unsat_mask,         \
                      (const float *)S[0]->zwin, (const float *)S[0]->scene_depth, (const uint32_t *)S[0]->scene_rgba, S[0]->ctl),                        \
         gs_pack_make((const uint2 *)S[1]->tile_range, fpairs[1], (const gsm::Projected *)S[1]->proj, V[1], out[1], S[1]->state, S[1]->unsat_mask,         \
                      (const float *)S[1]->zwin, (const float *)S[1]->scene_depth, (const uint32_t *)S[1]->scene_rgba, S[1]->ctl))
-    if (u.has_depth || u.has_scene_rgba) GS_BLEND2(true); else GS_BLEND2(false);
+    if (scene) GS_BLEND2(true); else GS_BLEND2(false);
 #undef GS_BLEND2
-#undef PK
     GS_HIP(hipGetLastError());
+    return GS_OK;
+}
+
+}  // namespace
+
+// Two frames that take the same path, one launch per kernel (GS_OPT_FRAME_BATCH; grid (x, 2), blockIdx.y = the frame).  S[0], S[1]:
+// sibling lanes on ONE stream, each with its own scratch, control block and output.  Frames that count fragments or record
+// the staged depths take the per-frame path -- gs_frames_batchable() says whether two frames qualify.
+bool gs_frames_batchable(const GsFrameUniforms &a, const GsFrameUniforms &b)
+{
+    return a.near_count == b.near_count && a.skip_round1 == b.skip_round1 && a.W == b.W && a.H == b.H && a.x0 == b.x0 && a.x1 == b.x1 &&
+           a.flags == b.flags && !(a.flags & (GS_RENDER_COUNT_FRAGS | GS_RENDER_COUNT_EVALUATED)) && !a.record_staged && !b.record_staged &&
+           a.split_min == b.split_min && a.has_depth == b.has_depth && a.has_scene_rgba == b.has_scene_rgba && a.t_eps == b.t_eps;
+}
+
+int gs_run_render2(gs_ctx *const S[2], const GsFrameUniforms U[2], uint8_t *const device_out[2])
+{
+    gs_ctx *ctx = S[0];
+    const GsFrameUniforms &u = U[0];
+    uint8_t *out[2] = { device_out[0] ? device_out[0] : S[0]->fb, device_out[1] ? device_out[1] : S[1]->fb };
+    GS_PROF_RECORD(ctx, 2);
+    const bool two_rounds = u.near_count != 0xFFFFFFFFu;
+    int rc = run_round2<0>(S, U, out, !two_rounds || u.skip_round1);
+    if (rc != GS_OK) return rc;
     GS_PROF_RECORD(ctx, 5);
+    if (two_rounds && !u.skip_round1) {
+        rc = run_round2<1>(S, U, out, true);
+        if (rc != GS_OK) return rc;
+    }
     GS_PROF_RECORD(ctx, 6);
     return GS_OK;
 }

@@ -409,8 +409,8 @@ def pmc_traffic(world, n_splats, args):
             return None, "no PMC pass for this configuration"
         if pmc.get("_csrc_sha1") != h.hexdigest():
             return None, "profiles/pmc_hbm_traffic.json was taken from other kernel sources (stale): not reported"
-        # (the timed loop pairs frames: its blend launches are k_twin<F_blend0<...>> over two frames; the per-frame kernel otherwise)
-        keys = [k for k in pmc if "F_blend0<" in k] or [k for k in pmc if k.startswith("k_blend<false, 0")]
+        # (the timed loop pairs frames: its blend launches are k_twin<F_blend<0, ...>> over two frames; the per-frame kernel otherwise)
+        keys = [k for k in pmc if "F_blend<0" in k or "F_blend0<" in k] or [k for k in pmc if k.startswith("k_blend<false, 0")]
         key = max(keys, key=lambda k: pmc[k].get("launches", 0))
         return pmc[key]["hbm_bytes"], "profiles/pmc_hbm_traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this bench command; 2*FETCH + WRITE)"
     except Exception as e:
@@ -554,6 +554,7 @@ def secondary_measurements(ctx, capi, synth, rows, cams, views, n_splats, args, 
     sparse[:, 27] = sparse[:, 27] // 10
     with capi.Context(ctx.device) as c2:
         c2.push_splat(sparse)
+        c2.set_option(capi.OPT_FRAME_BATCH, frame_batch)           # (as the timed loop: two queued frames per launch)
 
         def loop2(nn, flags):
             try:

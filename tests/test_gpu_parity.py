@@ -1297,6 +1297,22 @@ def test_paired_frames_share_their_launches_and_equal_plain_frames(scene_small):
         for b, wnt in zip(bufs, want_split):
             assert np.array_equal(b.cpu().numpy().reshape(h, w, 4), wnt)
         c.set_option(capi.OPT_BLEND_SPLIT, 0); c.set_option(capi.OPT_NEAR_PERMILLE, 0)
+        # two binning rounds per frame (a pinned near share, small enough that round 1 has tiles to finish): both rounds' kernels
+        # are shared by the pair
+        for permille in (60, 400):
+            c.set_option(capi.OPT_NEAR_PERMILLE, permille)
+            want_two = []
+            for cam in cams[:7]:
+                c.sort(cam["view"]); want_two.append(c.render(_params(cam)))
+            bufs = [torch.zeros(w * h * 4, dtype=torch.uint8, device="cuda") for _ in cams[:7]]
+            for cam, buf in zip(cams[:7], bufs):
+                c.sort(cam["view"], want_indices=False)
+                c.render_device(_params(cam, flags=capi.RENDER_ASYNC), buf.data_ptr())
+            c.sync(); torch.cuda.synchronize()
+            for b, wnt, w1 in zip(bufs, want_two, want[:7]):
+                assert np.array_equal(b.cpu().numpy().reshape(h, w, 4), wnt)
+                assert np.abs(wnt.astype(np.int16) - w1.astype(np.int16)).max() <= 1     # (the share moves the early-out points only)
+        c.set_option(capi.OPT_NEAR_PERMILLE, 0)
         # switching the option off returns to plain lanes
         c.set_option(capi.OPT_FRAME_BATCH, 1)
         c.sort(cams[5]["view"]); assert np.array_equal(c.render(_params(cams[5])), want[5])
