@@ -18,6 +18,7 @@ OPT_PROFILE, OPT_TERMINATION, OPT_NEAR_PERMILLE, OPT_RECORD_STAGED, OPT_PIPELINE
 OPT_COMM_SELF_COPY = 8
 OPT_BLEND_SPLIT = 9
 OPT_FRAME_BATCH = 10
+OPT_SORT_NEAR = 11
 COMM_ID_BYTES = 128
 BUF_CENTER_SCALE, BUF_COV_COLOR, BUF_SORT_ROWS, BUF_SORTED, BUF_PROJECTED, BUF_TILE_COUNT, BUF_TILE_STATS = 0, 1, 2, 3, 4, 5, 6
 
@@ -47,7 +48,8 @@ class Stats(C.Structure):
                 ("ms_bin", C.c_float), ("ms_blend", C.c_float), ("ms_render", C.c_float), ("blend_launches", C.c_uint32),
                 ("prof_frames", C.c_uint32), ("sum_ms_sort", C.c_float), ("sum_ms_project", C.c_float), ("sum_ms_bin", C.c_float),
                 ("sum_ms_blend", C.c_float), ("acc_frames", C.c_uint64), ("acc_sorted", C.c_uint64), ("acc_visible", C.c_uint64),
-                ("acc_pairs", C.c_uint64), ("unsat_tiles", C.c_uint32), ("near_permille", C.c_uint32)]
+                ("acc_pairs", C.c_uint64), ("unsat_tiles", C.c_uint32), ("near_permille", C.c_uint32),
+                ("sort_records", C.c_uint32), ("reserved0", C.c_uint32)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

@@ -189,7 +189,8 @@ static int collect_status(gs_ctx *lane, bool *overflowed)
     const GsControl *c = lane->ctl_host;                        // ... fed by each lane's own counters
     lane->stats.n_sorted = c->n_kept; lane->stats.n_visible = c->n_visible; lane->stats.n_pairs = c->n_pairs_frame;
     lane->stats.acc_frames = c->acc_frames; lane->stats.acc_sorted = c->acc_sorted; lane->stats.acc_visible = c->acc_visible;
-    lane->stats.acc_pairs = c->acc_pairs;
+    lane->stats.acc_pairs = c->acc_pairs; lane->stats.sort_records = c->n_sorted;
+    ctx->last_kept = c->n_kept;
     if (c->n_pairs_frame) {                                     // sizing hint for the next frames' pair sort (any lane's worker may read it)
         const uint64_t h = (uint64_t)c->n_pairs_frame + c->n_pairs_frame / 4 + GS_CHUNK_L;
         __atomic_store_n(&ctx->pair_hint, h > 0xFFFFFFFFull ? 0u : (uint32_t)h, __ATOMIC_RELAXED);
@@ -244,7 +245,7 @@ struct GsLaneCmd {
     gs_ctx *target;                                            // the lane (or twin) the command is for
     int type;                                                  // 0 = sort, 1 = asynchronous render, 2 = call (gs_comm.hip: the frame's gather)
     float view[4], cutout[16]; bool has_cutout;
-    bool has_strip; GsSortStrip strip;
+    bool has_strip; GsSortStrip strip; uint32_t near_req;      // (sort: how much of the order the frame is expected to need; 0 = all)
     GsFrameUniforms u; void *device_rgba; uint8_t *host_rgba; size_t stride;
     std::function<int(gs_ctx *)> call;
 };
@@ -266,6 +267,33 @@ static int render_async_on_lane(gs_ctx *ctx, const GsFrameUniforms &u, void *dev
 static int ensure_frame_buffers(gs_ctx *ctx, const GsFrameUniforms &u, bool need_fb);
 static int prof_advance(gs_ctx *ctx);
 
+// Near-only sorts (GS_OPT_SORT_NEAR).  A frame whose single binning round covers the nearest near_count splats (round 1 skipped
+// optimistically, gs_fill_uniforms) reads nothing else of the order, so its sort lets only the splats go on that can be among
+// them (gs_sort.hip: an exact rule on the sort key; the positions it fills equal the whole order's).  The request is made when
+// the sort is issued, from the state the render's uniforms will be made from; a render that turns out to need more of the
+// order (another share, a counting render, round 1 after all, gs_download of the order) sorts again in full first.
+static uint32_t sort_near_request(const gs_ctx *ctx /* owner */)
+{
+    if (!ctx->sort_near_opt || !ctx->renderable) return 0;
+    if (ctx->sort_near_opt == 1 && ctx->n < ((size_t)1 << 22)) return 0;      // (short sorts are launch-bound: nothing to gain)
+    if (ctx->wide_pairs || ctx->n > ((size_t)1 << 25)) return 0;
+    if (ctx->near_fixed_permille > 0 || ctx->clean_frames < 16 || ctx->skip_hold || ctx->near_frac >= 1.0f) return 0;
+    const double nc = ceil((double)ctx->near_frac * (double)ctx->n);
+    // (a cutout or a strip that keeps little more than the frame reads anyway: the histogram and the threshold would buy nothing)
+    if (ctx->sort_near_opt == 1 && ctx->last_kept && nc * 2.0 > (double)ctx->last_kept) return 0;
+    return nc < 1 ? 1u : (uint32_t)nc;
+}
+static inline bool sort_covers(uint32_t near_req, const GsFrameUniforms &u)
+{
+    return near_req == 0 || (u.near_count != 0xFFFFFFFFu && u.skip_round1 && u.near_count <= near_req);
+}
+static int ensure_full_sort(gs_ctx *L)
+{
+    if (!L->have_sort || !L->sort_near_req) return GS_OK;
+    return gs_run_sort(L, L->sv_view, L->sv_has_cutout ? L->sv_cutout : nullptr, L->sv_has_strip ? &L->sv_strip : nullptr, 0);
+}
+static int ensure_sort_covers(gs_ctx *L, const GsFrameUniforms &u) { return sort_covers(L->sort_near_req, u) ? GS_OK : ensure_full_sort(L); }
+
 // GS_OPT_FRAME_BATCH: the frames of a lane and of its twin, when both are waiting, go out as ONE chain of launches
 static int run_frame_pair(gs_ctx *A, gs_ctx *B, const GsLaneCmd &s0, const GsLaneCmd &r0, const GsLaneCmd &s1, const GsLaneCmd &r1)
 {
@@ -274,8 +302,9 @@ static int run_frame_pair(gs_ctx *A, gs_ctx *B, const GsLaneCmd &s0, const GsLan
     const float *view[2] = { s0.view, s1.view };
     const float *cut[2] = { s0.has_cutout ? s0.cutout : nullptr, s1.has_cutout ? s1.cutout : nullptr };
     const GsSortStrip *strip[2] = { s0.has_strip ? &s0.strip : nullptr, s1.has_strip ? &s1.strip : nullptr };
-    TRY(gs_run_sort2(S, view, cut, strip));
     const GsFrameUniforms U[2] = { r0.u, r1.u };
+    const uint32_t near[2] = { sort_covers(s0.near_req, U[0]) ? s0.near_req : 0u, sort_covers(s1.near_req, U[1]) ? s1.near_req : 0u };
+    TRY(gs_run_sort2(S, view, cut, strip, near));
     uint8_t *dev[2] = { (uint8_t *)r0.device_rgba, (uint8_t *)r1.device_rgba };
     TRY(ensure_frame_buffers(A, U[0], dev[0] == nullptr));
     TRY(ensure_frame_buffers(B, U[1], dev[1] == nullptr));
@@ -327,10 +356,11 @@ static int classify_queue(const gs_ctx *L, const GsLaneCmd &s0, const std::deque
 static int run_two_views(gs_ctx *A, gs_ctx *B, const GsLaneCmd &s0, const GsLaneCmd &r0, const GsLaneCmd &r1)
 {
     gs_ctx *ctx = A;
-    TRY(gs_run_sort(A, s0.view, s0.has_cutout ? s0.cutout : nullptr, nullptr));
+    const uint32_t near = (sort_covers(s0.near_req, r0.u) && sort_covers(s0.near_req, r1.u)) ? s0.near_req : 0u;
+    TRY(gs_run_sort(A, s0.view, s0.has_cutout ? s0.cutout : nullptr, nullptr, near));
     // the twin's kernels read the order and its length through THEIR lane: point it at the lane's (counts: the head of the control block)
-    GS_HIP(hipMemcpyAsync(B->ctl, A->ctl, offsetof(GsControl, n_valid), hipMemcpyDeviceToDevice, A->stream));
-    B->sorted = A->sorted; B->have_sort = true;
+    GS_HIP(hipMemcpyAsync(B->ctl, A->ctl, offsetof(GsControl, n_visible), hipMemcpyDeviceToDevice, A->stream));
+    B->sorted = A->sorted; B->have_sort = true; B->sort_near_req = 0;   // (nothing of its own to sort again: the pair was checked above)
     gs_ctx *S[2] = { A, B };
     const GsFrameUniforms U[2] = { r0.u, r1.u };
     uint8_t *dev[2] = { (uint8_t *)r0.device_rgba, (uint8_t *)r1.device_rgba };
@@ -381,7 +411,7 @@ static void lane_worker_main(gs_ctx *L)
             }
         }
         else if (c.type == 2) { const int r2 = c.call(T); if (w->rc == GS_OK) rc = r2; }
-        else if (w->rc == GS_OK) rc = c.type == 0 ? gs_run_sort(T, c.view, c.has_cutout ? c.cutout : nullptr, c.has_strip ? &c.strip : nullptr)
+        else if (w->rc == GS_OK) rc = c.type == 0 ? gs_run_sort(T, c.view, c.has_cutout ? c.cutout : nullptr, c.has_strip ? &c.strip : nullptr, c.near_req)
                                                   : render_async_on_lane(T, c.u, c.device_rgba, c.host_rgba, c.stride);
         lk.lock();
         if (rc != GS_OK && w->rc == GS_OK) { w->rc = rc; memcpy(w->err, scratch, sizeof w->err); }
@@ -459,6 +489,9 @@ static hipError_t init_frame_resources(gs_ctx *c, gs_ctx *primary = nullptr)
     IFR(hipMalloc((void **)&c->part_cnt, GS_MAX_PART * sizeof(uint32_t)));
     IFR(hipMalloc((void **)&c->part_valid, GS_MAX_PART * sizeof(uint32_t)));
     IFR(hipMalloc((void **)&c->part_vis, GS_MAX_PART * sizeof(uint32_t)));
+    for (int k = 0; k < 2; k++) { IFR(hipMalloc((void **)&c->dhist[k], GS_DH_WORDS * sizeof(uint32_t))); IFR(hipMemset(c->dhist[k], 0, GS_DH_WORDS * sizeof(uint32_t))); }
+    c->dh_next = 0; c->dh_dirty = nullptr;
+    c->sort_near_req = 0;
     IFR(hipHostMalloc((void **)&c->ctl_host, sizeof(GsControl), hipHostMallocDefault));
     memset(c->ctl_host, 0, sizeof(GsControl));
     IFR(hipEventCreateWithFlags(&c->ev_frame, hipEventDisableTiming | hipEventReleaseToDevice));
@@ -477,7 +510,7 @@ static void free_frame_resources(gs_ctx *c)
     dev_free(c->pair_a); dev_free(c->pair_b); dev_free(c->emit_extra);
     gs_comm_free_lane(c);
     dev_free(c->tile_range); dev_free(c->fb); dev_free(c->ctl); dev_free(c->state); dev_free(c->unsat_mask);
-    dev_free(c->part_min); dev_free(c->part_max); dev_free(c->part_cnt); dev_free(c->part_valid); dev_free(c->part_vis);
+    dev_free(c->part_min); dev_free(c->part_max); dev_free(c->part_cnt); dev_free(c->part_valid); dev_free(c->part_vis); dev_free(c->dhist[0]); dev_free(c->dhist[1]);
     if (c->ctl_host) { (void)hipHostFree(c->ctl_host); c->ctl_host = nullptr; }
     if (c->ring) { for (int i = 0; i < GS_PROF_RING * GS_PROF_EVENTS; i++) if (c->ring[i]) (void)hipEventDestroy(c->ring[i]); free(c->ring); c->ring = nullptr; }
     free(c->ring_flags); c->ring_flags = nullptr;
@@ -612,7 +645,7 @@ GS_API int gs_create(int device, gs_ctx **out)
     if (!ctx) { snprintf(g_create_err, sizeof g_create_err, "out of host memory"); return GS_E_OOM; }
     memset(ctx, 0, sizeof *ctx);
     ctx->device = device; ctx->renderable = true; ctx->t_eps = 1.0f / 1024.0f; ctx->near_frac = 0.25f;
-    ctx->lanes[0] = ctx; ctx->pipe_depth = 3; ctx->enqueue_threads = true; ctx->frame_batch = 1; ctx->exec = ctx;
+    ctx->lanes[0] = ctx; ctx->pipe_depth = 3; ctx->enqueue_threads = true; ctx->frame_batch = 1; ctx->exec = ctx; ctx->sort_near_opt = 1;
 #define CREATE_HIP(call) do { hipError_t _e = (call); if (_e != hipSuccess) {                                              \
         snprintf(g_create_err, sizeof g_create_err, "%s failed: %s", #call, hipGetErrorString(_e)); gs_destroy(ctx);      \
         return GS_E_HIP; } } while (0)
@@ -649,7 +682,7 @@ GS_API int gs_clear(gs_ctx *ctx)
     GS_HIP(hipSetDevice(ctx->device));
     TRY(drain_all(ctx));
     ctx->n = 0; ctx->renderable = true; ctx->pair_hint = 0;
-    ctx->near_frac = 0.25f; ctx->near_floor = 0.0f; ctx->clean_frames = 0; ctx->skip_hold = 0; ctx->single_round_frames = 0;
+    ctx->near_frac = 0.25f; ctx->near_floor = 0.0f; ctx->clean_frames = 0; ctx->skip_hold = 0; ctx->single_round_frames = 0; ctx->last_kept = 0;
     for (int i = 0; i < GS_MAX_LANES; i++) {
         gs_ctx *L = ctx->lanes[i];
         if (!L) continue;
@@ -819,6 +852,7 @@ static int sort_common(gs_ctx *ctx, const float view[4], const float *cutout16, 
     TRY(get_lane(ctx, lane, &L));
     if (solo && ctx->frame_batch == 2 && lane < GS_MAX_PRIMARY) { gs_ctx *T = nullptr; TRY(get_lane(ctx, lane + GS_MAX_PRIMARY, &T)); }   // (the second view's scratch)
     ctx->cur = lane; ctx->rot = rot; ctx->cur_async = false;
+    const uint32_t near_req = (out_idx || out_n) ? 0u : sort_near_request(ctx);     // (the caller wants the order itself: all of it)
     if (ctx->enqueue_threads && gs_rotates(ctx) && !ctx->user_stream && !out_idx && !out_n) {
         // nothing to hand back: the lane's worker thread does the launching (a failure surfaces at gs_sync())
         GsLaneCmd c;
@@ -827,12 +861,13 @@ static int sort_common(gs_ctx *ctx, const float view[4], const float *cutout16, 
         if (cutout16) memcpy(c.cutout, cutout16, sizeof c.cutout);
         c.has_strip = strip != nullptr;
         if (strip) c.strip = *strip;
+        c.near_req = near_req;
         c.device_rgba = nullptr; c.host_rgba = nullptr; c.stride = 0;
         L->have_sort = true;                                    // (set again by the worker; the render command follows it)
         if (lane_push(L, c) != GS_OK) FAIL(GS_E_OOM, "out of host memory");
         return GS_OK;
     }
-    TRY(lane_rc(ctx, L, gs_run_sort(L, view, cutout16, strip)));
+    TRY(lane_rc(ctx, L, gs_run_sort(L, view, cutout16, strip, near_req)));
     if (out_idx || out_n) {
         LANE_HIP(L, hipMemcpyAsync(L->ctl_host, L->ctl, sizeof(GsControl), hipMemcpyDeviceToHost, L->stream));
         LANE_HIP(L, hipStreamSynchronize(L->stream));
@@ -899,6 +934,7 @@ static int ensure_frame_buffers(gs_ctx *ctx, const GsFrameUniforms &u, bool need
 static int render_async_on_lane(gs_ctx *ctx, const GsFrameUniforms &u, void *device_rgba, uint8_t *host_rgba, size_t stride)
 {
     TRY(ensure_frame_buffers(ctx, u, device_rgba == nullptr));
+    TRY(ensure_sort_covers(ctx, u));
     TRY(gs_run_render(ctx, u, (uint8_t *)device_rgba));
     if (host_rgba) {
         // the frame follows its kernels on the lane's stream (page-locked destination: a real asynchronous copy that
@@ -915,6 +951,7 @@ static int render_sync_on_lane(gs_ctx *ctx, const GsFrameUniforms &u, void *devi
 {
     const size_t sw = (size_t)(u.x1 - u.x0);
     TRY(ensure_frame_buffers(ctx, u, device_rgba == nullptr));
+    TRY(ensure_sort_covers(ctx, u));
     for (int attempt = 0;; attempt++) {
         TRY(gs_run_render(ctx, u, (uint8_t *)device_rgba));
         GS_HIP(hipMemcpyAsync(ctx->ctl_host, ctx->ctl, sizeof(GsControl), hipMemcpyDeviceToHost, ctx->stream));
@@ -923,6 +960,7 @@ static int render_sync_on_lane(gs_ctx *ctx, const GsFrameUniforms &u, void *devi
         if (ctx->ctl_host->round1_missed) {
             // round 1 was skipped but a tile did not saturate: its mask bit and per-pixel state are intact -- finish it now
             GS_HIP(hipMemsetAsync(&ctx->ctl->round1_missed, 0, sizeof(uint32_t), ctx->stream));
+            TRY(ensure_full_sort(ctx));                             // (round 1 reads the far part of the order)
             TRY(gs_run_round1(ctx, u, (uint8_t *)device_rgba));
             GS_HIP(hipMemcpyAsync(ctx->ctl_host, ctx->ctl, sizeof(GsControl), hipMemcpyDeviceToHost, ctx->stream));
             GS_HIP(hipStreamSynchronize(ctx->stream));
@@ -1056,6 +1094,13 @@ GS_API int gs_sync(gs_ctx *ctx)
         L->async_pending = false;
         LANE_HIP(L, hipMemcpy(L->ctl_host, L->ctl, sizeof(GsControl), hipMemcpyDeviceToHost));
         const bool missed = L->ctl_host->round1_missed != 0;
+        static const bool dbg_near = getenv("GS_DEBUG_NEAR") != nullptr;       // (what raised the share: printed per collected lane)
+        if (dbg_near && (L->ctl_host->round1_missed || L->ctl_host->unsat_events != L->seen_unsat_events)) {
+            const GsControl *c = L->ctl_host;
+            fprintf(stderr, "[gs] sync lane %d: missed %u unsat_events %u (seen %u) V %u P %u V' %u near_sorted %u req %u frames %u two_rounds %d near_frac %.4f clean %u hold %u\n", i, c->round1_missed,
+                    c->unsat_events, L->seen_unsat_events, c->n_kept, c->n_sorted, c->n_valid, c->near_sorted, L->sort_near_req, c->acc_frames, (int)L->last_two_rounds,
+                    ctx->near_frac, ctx->clean_frames, ctx->skip_hold);
+        }
         if (missed) LANE_HIP(L, hipMemsetAsync(&L->ctl->round1_missed, 0, sizeof(uint32_t), L->stream));
         bool over = false;
         TRY(collect_status(L, &over));
@@ -1175,6 +1220,12 @@ GS_API int gs_set_option(gs_ctx *ctx, int option, int64_t value)
         ctx->frame_batch = (int)value;
         ctx->cur = 0; ctx->rot = 0; ctx->cur_async = false;
         return GS_OK;
+    case GS_OPT_SORT_NEAR:
+        if (value > 2) FAIL(GS_E_BADARG, "near-only sorts: 0 (off), 1 (scenes of 4 M splats and more) or 2 (always)");
+        GS_HIP(hipSetDevice(ctx->device));
+        TRY(drain_all(ctx));
+        ctx->sort_near_opt = (int)value;
+        return GS_OK;
     default: FAIL(GS_E_BADARG, "unknown option %d", option);
     }
 }
@@ -1222,7 +1273,9 @@ GS_API int gs_download(gs_ctx *ctx, int which, void *out, size_t nbytes)
     }
     switch (which) {
     case GS_BUF_SORT_ROWS: src = ctx->sort_rows; have = ctx->n * 16; break;
-    case GS_BUF_SORTED: src = L->sorted; have = L->have_sort ? V * 4 : 0; break;
+    case GS_BUF_SORTED:
+        if (L->have_sort && L->sort_near_req) { TRY(lane_rc(ctx, L, ensure_full_sort(L))); GS_HIP(hipStreamSynchronize(L->stream)); }
+        src = L->sorted; have = L->have_sort ? V * 4 : 0; break;
     case GS_BUF_PROJECTED: src = L->proj; have = L->have_sort ? V * 32 : 0; break;
     case GS_BUF_TILE_COUNT: src = L->tile_count; have = L->have_sort ? V * 4 : 0; break;
     case GS_BUF_TILE_STATS: src = L->tile_range; have = L->tile_cap * 8; break;

@@ -29,6 +29,13 @@
 #define GS_EMIT_RUNS 512u          // tile-row runs expanded per pass inside an item
 #endif
 
+// strip: sort only the splats that can reach columns [x0, x1) of the frame these uniforms draw (gs_sort_for); nullptr = all
+struct GsSortStrip { float mv[16], proj[16]; float focal, vw; int32_t x0, x1; };
+#define GS_DEPTH_BINS 2048u        // depth histogram of a near-only sort: sign-less f32 bits >> 20 (exponent + 3 mantissa bits)
+#define GS_DH_COPIES 8u            // ... kept in this many copies (workgroup % copies)
+#define GS_DEPTH_COARSE (GS_DEPTH_BINS / 32u)   // ... with sums over 32 consecutive bins behind the copies
+#define GS_DH_WORDS (GS_DH_COPIES * (GS_DEPTH_BINS + GS_DEPTH_COARSE))
+
 // Device-resident control block: every data-dependent count lives here so that no stage needs a
 // host round trip; kernels read their problem size from it (grid-stride over chunks).
 struct GsControl {
@@ -37,8 +44,11 @@ struct GsControl {
     unsigned long long n_frags;    // fragment counter (GS_RENDER_COUNT_FRAGS)
     uint32_t n_total;              // N at the time of the sort
     uint32_t n_kept;               // V : survivors of the sort culls  (= reference validCount)
-    uint32_t n_sorted, pad_sorted; // V': those of them with a bucket inside the table (compact depth-sort records: the rest is the zero tail)
-    uint32_t n_valid;              // V': survivors whose bucket is in [0,65535]
+    uint32_t n_sorted;             // records that went through the depth sort: V' = those with a bucket inside the table (compact records: the rest is
+                                   // the zero tail), or only the nearest P of them (near-only sort)
+    uint32_t near_sorted;          // 1: `sorted` holds the order's last P valid positions [V' - P, V') only (gs_run_sort with near_req)
+    uint32_t n_valid;              // V' of the whole order, counted by a near-only sort (position of sorted[0] = n_valid - n_sorted)
+    uint32_t pad_near;
     uint32_t n_visible;            // Vp: splats that pass the vertex-shader culls
     uint32_t n_pairs;              // I : (tile, splat) pairs
     uint32_t pair_overflow;        // set when I exceeded the pair capacity (pairs clamped to 0)
@@ -125,6 +135,13 @@ struct gs_ctx {
     uint32_t *sorted;              // alias of the buffer holding the final order
     uint32_t sorted_n_host;        // V as last read back (only when the caller asked for it)
     bool have_sort;
+    // near-only sorts (GS_OPT_SORT_NEAR): histograms of the kept depths (GS_DH_COPIES x GS_DEPTH_BINS words; two buffers: a sort fills
+    // one and clears the one the previous sort filled), the request the last sort of this lane ran with (0 = whole order) and its arguments
+    uint32_t *dhist[2]; int dh_next; uint32_t *dh_dirty;
+    uint32_t sort_near_req;
+    float sv_view[4], sv_cutout[16]; bool sv_has_cutout, sv_has_strip; GsSortStrip sv_strip;
+    int sort_near_opt;             // owner: GS_OPT_SORT_NEAR
+    uint32_t last_kept;            // owner: V of the last collected frame (a near-only sort pays only where V is well above the share read)
 
     // radix / scan scratch
     uint32_t *hist;  size_t hist_cap;       // digit-histogram rows H[radix chunks][bins], scanned in place
@@ -262,10 +279,8 @@ static __host__ __device__ __forceinline__ uint32_t gs_radix_row_stride(uint32_t
 // ---- gs_pack.hip
 int gs_launch_pack(gs_ctx *ctx, const uint4 *rows_dev, size_t first, size_t nrows);
 // ---- gs_sort.hip
-// strip: sort only the splats that can reach columns [x0, x1) of the frame these uniforms draw (gs_sort_for); nullptr = all
-struct GsSortStrip { float mv[16], proj[16]; float focal, vw; int32_t x0, x1; };
-int gs_run_sort(gs_ctx *ctx, const float view[4], const float *cutout16, const GsSortStrip *strip = nullptr);
-int gs_run_sort2(gs_ctx *const S[2], const float *const view[2], const float *const cutout16[2], const GsSortStrip *const strip[2]);   // two frames per launch
+int gs_run_sort(gs_ctx *ctx, const float view[4], const float *cutout16, const GsSortStrip *strip = nullptr, uint32_t near_req = 0);
+int gs_run_sort2(gs_ctx *const S[2], const float *const view[2], const float *const cutout16[2], const GsSortStrip *const strip[2], const uint32_t near_req[2]);   // two frames per launch
 // ---- gs_render.hip
 int gs_run_render(gs_ctx *ctx, const GsFrameUniforms &u, uint8_t *device_out);
 int gs_run_round1(gs_ctx *ctx, const GsFrameUniforms &u, uint8_t *device_out);

@@ -81,6 +81,9 @@ __device__ __forceinline__ void k_project_body(const uint32_t *__restrict__ sort
     __shared__ uint32_t s_nbig, s_nmid, s_vis, s_sum;
     uint32_t j_lo, j_hi;
     round_range<ROUND>(ctl, u.near_count, j_lo, j_hi);
+    // a near-only sort holds positions [V' - P, V') of the order; the positions behind V' are the reference's zero tail
+    const bool near_sorted = ctl->near_sorted != 0u;
+    const uint32_t n_rec = ctl->n_sorted, j_base = near_sorted ? ctl->n_valid - n_rec : 0u;
     const uint32_t nchunks = (j_hi - j_lo + GS_BLOCK - 1) / GS_BLOCK;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     if (threadIdx.x == 0) s_vis = 0;
@@ -91,7 +94,7 @@ __device__ __forceinline__ void k_project_body(const uint32_t *__restrict__ sort
         uint32_t count = 0;
         bool queued = false;
         if (j < j_hi) {
-            const uint32_t idx = sorted[j];
+            const uint32_t idx = !near_sorted ? sorted[j] : (j - j_base < n_rec ? sorted[j - j_base] : 0u);
             const uint4 cs4 = splat[2 * (size_t)idx], cc4 = splat[2 * (size_t)idx + 1];   // one 32-byte record, one line
             const float cs[4] = { __uint_as_float(cs4.x), __uint_as_float(cs4.y), __uint_as_float(cs4.z), __uint_as_float(cs4.w) };
             const uint32_t cc[4] = { cc4.x, cc4.y, cc4.z, cc4.w };

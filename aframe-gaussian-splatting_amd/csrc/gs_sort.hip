@@ -32,6 +32,41 @@ __device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v,
     return ((unsigned long long)hi << 32) | lo;
 }
 
+// Near-only sorts (gs_run_sort with near_req): the pass also histograms the kept depths by the top 11 bits of the stored f32
+// |depth| (kept depths are negative, so the sign-less bit pattern grows with the distance: exponent + 3 mantissa bits, 12 %
+// steps); k_sort_bucket derives from it a bucket below which no splat can be among the nearest near_req.  Workgroups add
+// their LDS histogram to one of GS_DH_COPIES global copies (same-address atomics serialise at ~11 ns: 2048 workgroups on one
+// copy cost 22 us).  (Measured and dropped: the workgroup that finishes last reducing the copies to the threshold itself --
+// the release / acquire fences that takes across the 8 XCDs' L2s cost 70 us per sort.)
+// fill: this sort's histogram (nullptr: none wanted); zero: the one the lane's previous near-only sort filled, cleared here
+// (its reader finished long ago: stream order); zero_word: the control block's count of valid buckets, recounted by k_sort_bucket.
+struct DepthHist { uint32_t *fill, *zero, *zero_word; };
+__device__ __forceinline__ uint32_t depth_bin(float d) { return (__float_as_uint(d) & 0x7FFFFFFFu) >> 20; }
+__device__ __forceinline__ void depth_hist_begin(const DepthHist &dh, uint32_t *s_dh)
+{
+    if (dh.fill) for (uint32_t d = threadIdx.x; d < GS_DEPTH_BINS; d += GS_BLOCK) s_dh[d] = 0;
+    if (blockIdx.x == 0) {
+        if (dh.zero) for (uint32_t d = threadIdx.x; d < GS_DH_WORDS / 4u; d += GS_BLOCK) reinterpret_cast<uint4 *>(dh.zero)[d] = make_uint4(0, 0, 0, 0);
+        if (dh.zero_word && threadIdx.x == 0) *dh.zero_word = 0;
+    }
+}
+// (after a barrier that follows the last LDS atomic)  Two levels: the bins, and behind them sums over 32 consecutive bins each
+// (GS_DEPTH_COARSE = 64 words per copy), so that a reader finds the bin it wants with ~800 loads instead of all 16 K words
+__device__ __forceinline__ void depth_hist_end(const DepthHist &dh, const uint32_t *s_dh)
+{
+    if (!dh.fill) return;
+    const uint32_t cp = blockIdx.x % GS_DH_COPIES;
+    uint32_t *fine = dh.fill + cp * GS_DEPTH_BINS, *coarse = dh.fill + GS_DH_COPIES * GS_DEPTH_BINS + cp * GS_DEPTH_COARSE;
+    for (uint32_t d = threadIdx.x; d < GS_DEPTH_BINS; d += GS_BLOCK) {
+        const uint32_t v = s_dh[d];
+        if (v) atomicAdd(&fine[d], v);
+        uint32_t t = v;                                              // lanes 0..31 / 32..63 of a wave hold 32 consecutive bins
+#pragma unroll
+        for (int m = 16; m >= 1; m >>= 1) t += __shfl_xor(t, m, 64);
+        if ((threadIdx.x & 31u) == 0u && t) atomicAdd(&coarse[d >> 5], t);
+    }
+}
+
 // pass 1 (index.js:517-555): depth, culls, f64 min/max of survivors.  16 B/splat in, 4 B/splat out.
 // Each workgroup leaves its (min, max, count) in a partial slot; no global atomics.
 // strip test of gs_sort_for: can a fragment of the splat fall on pixel columns [sx0, sx1]?  Fragments live where |p| <= 2
@@ -62,11 +97,13 @@ __device__ __forceinline__ bool strip_may_touch(const StripUniforms &s, float x,
 template <bool STRIP>                                             // (two instantiations: the strip test must not cost the plain sort registers)
 __device__ __forceinline__ void k_sort_depth_body(const float4 *__restrict__ rows, const float *__restrict__ bound_r, uint32_t n, const SortUniforms &u, const StripUniforms &su,
                                                   float *__restrict__ depth_out, unsigned long long *__restrict__ part_min,
-                                                  unsigned long long *__restrict__ part_max, uint32_t *__restrict__ part_cnt)
+                                                  unsigned long long *__restrict__ part_max, uint32_t *__restrict__ part_cnt, DepthHist dh)
 {
     __shared__ unsigned long long s_min, s_max;
     __shared__ uint32_t s_cnt;
+    extern __shared__ uint32_t s_dh[];                           // GS_DEPTH_BINS words for a near-only sort, none otherwise (LDS the other frames' blends can use)
     if (threadIdx.x == 0) { s_min = ~0ull; s_max = 0ull; s_cnt = 0; }
+    depth_hist_begin(dh, s_dh);
     __syncthreads();
     constexpr uint32_t DCHUNK = GS_DEPTH_IPT * GS_BLOCK;         // this kernel's own chunking (no histogram depends on it)
     const uint32_t nchunks = (n + DCHUNK - 1) / DCHUNK;
@@ -93,6 +130,7 @@ __device__ __forceinline__ void k_sort_depth_body(const float4 *__restrict__ row
                 // reference's order restricted to the strip's splats; only those are handed on
                 const bool mine = keep && (!STRIP || strip_may_touch(su, m.x, m.y, m.z, (float)d, sg[r]));
                 depth_out[i] = mine ? (float)d : INFINITY;
+                if (mine && dh.fill) atomicAdd(&s_dh[depth_bin((float)d)], 1u);
                 if (keep) {
                     const unsigned long long e = gsm::f64_to_ordered(d);
                     mn = e < mn ? e : mn; mx = e > mx ? e : mx;
@@ -110,14 +148,15 @@ __device__ __forceinline__ void k_sort_depth_body(const float4 *__restrict__ row
     if ((threadIdx.x & 63) == 0 && mx) { atomicMin(&s_min, mn); atomicMax(&s_max, mx); atomicAdd(&s_cnt, cnt); }   // (mx != 0: the wave kept something)
     __syncthreads();
     if (threadIdx.x == 0) { part_min[blockIdx.x] = s_min; part_max[blockIdx.x] = s_max; part_cnt[blockIdx.x] = s_cnt; }
+    depth_hist_end(dh, s_dh);
 }
 
 template <bool STRIP>
 __global__ __launch_bounds__(GS_BLOCK) void k_sort_depth(const float4 *__restrict__ rows, const float *__restrict__ bound_r, uint32_t n, SortUniforms u, StripUniforms su,
                                                          float *__restrict__ depth_out, unsigned long long *__restrict__ part_min,
-                                                         unsigned long long *__restrict__ part_max, uint32_t *__restrict__ part_cnt)
+                                                         unsigned long long *__restrict__ part_max, uint32_t *__restrict__ part_cnt, DepthHist dh)
 {
-    k_sort_depth_body<STRIP>(rows, bound_r, n, u, su, depth_out, part_min, part_max, part_cnt);
+    k_sort_depth_body<STRIP>(rows, bound_r, n, u, su, depth_out, part_min, part_max, part_cnt, dh);
 }
 
 // The same pass for the two frames of a pair (GS_OPT_FRAME_BATCH) in ONE sweep over the splats: at 20 M splats the sort rows are
@@ -129,11 +168,15 @@ __global__ __launch_bounds__(GS_BLOCK) void k_sort_depth_pair(const float4 *__re
                                                               SortUniforms u0, SortUniforms u1, StripUniforms su0, StripUniforms su1,
                                                               float *__restrict__ depth0, float *__restrict__ depth1,
                                                               unsigned long long *__restrict__ pmin0, unsigned long long *__restrict__ pmax0, uint32_t *__restrict__ pcnt0,
-                                                              unsigned long long *__restrict__ pmin1, unsigned long long *__restrict__ pmax1, uint32_t *__restrict__ pcnt1)
+                                                              unsigned long long *__restrict__ pmin1, unsigned long long *__restrict__ pmax1, uint32_t *__restrict__ pcnt1,
+                                                              DepthHist dh0, DepthHist dh1)
 {
     __shared__ unsigned long long s_min[2], s_max[2];
     __shared__ uint32_t s_cnt[2];
+    extern __shared__ uint32_t s_dh0[];                          // 2 x GS_DEPTH_BINS words for near-only sorts, none otherwise
+    uint32_t *const s_dh1 = s_dh0 + GS_DEPTH_BINS;
     if (threadIdx.x < 2) { s_min[threadIdx.x] = ~0ull; s_max[threadIdx.x] = 0ull; s_cnt[threadIdx.x] = 0; }
+    depth_hist_begin(dh0, s_dh0); depth_hist_begin(dh1, s_dh1);
     __syncthreads();
     constexpr uint32_t DCHUNK = GS_DEPTH_IPT * GS_BLOCK;
     const uint32_t nchunks = (n + DCHUNK - 1) / DCHUNK;
@@ -153,16 +196,17 @@ __global__ __launch_bounds__(GS_BLOCK) void k_sort_depth_pair(const float4 *__re
             const uint32_t i = c * DCHUNK + r * GS_BLOCK + threadIdx.x;
             if (i < n) {
                 const float4 m = mm[r];
-#define GS_DEPTH_ONE(U, SU, OUT, MN, MX, CNT) do {                                                                      \
+#define GS_DEPTH_ONE(U, SU, OUT, MN, MX, CNT, DH, SDH) do {                                                             \
                     const double d = gsm::view_depth(U.view, m.x, m.y, m.z);                                               \
                     const bool inside = U.has_cutout ? gsm::in_cutout(U.cutout, m.x, m.y, m.z) : true;                     \
                     const bool keep = gsm::sort_keep(d, m.w, inside);                                                      \
                     const bool mine = keep && (!STRIP || strip_may_touch(SU, m.x, m.y, m.z, (float)d, sg[r]));            \
                     OUT[i] = mine ? (float)d : INFINITY;                                                                   \
+                    if (mine && DH.fill) atomicAdd(&SDH[depth_bin((float)d)], 1u);                                         \
                     if (keep) { const unsigned long long e = gsm::f64_to_ordered(d); MN = e < MN ? e : MN; MX = e > MX ? e : MX; if (mine) CNT++; } \
                 } while (0)
-                GS_DEPTH_ONE(u0, su0, depth0, mn0, mx0, cnt0);
-                GS_DEPTH_ONE(u1, su1, depth1, mn1, mx1, cnt1);
+                GS_DEPTH_ONE(u0, su0, depth0, mn0, mx0, cnt0, dh0, s_dh0);
+                GS_DEPTH_ONE(u1, su1, depth1, mn1, mx1, cnt1, dh1, s_dh1);
 #undef GS_DEPTH_ONE
             }
         }
@@ -182,6 +226,7 @@ __global__ __launch_bounds__(GS_BLOCK) void k_sort_depth_pair(const float4 *__re
         pmin0[blockIdx.x] = s_min[0]; pmax0[blockIdx.x] = s_max[0]; pcnt0[blockIdx.x] = s_cnt[0];
         pmin1[blockIdx.x] = s_min[1]; pmax1[blockIdx.x] = s_max[1]; pcnt1[blockIdx.x] = s_cnt[1];
     }
+    depth_hist_end(dh0, s_dh0); depth_hist_end(dh1, s_dh1);
 }
 
 // pass 2 (index.js:558-561): 16-bit bucket of the stored depth; culled -> GS_RADIX_SKIP, dropped bucket -> GS_CULLED_KEY.
@@ -191,19 +236,29 @@ __global__ __launch_bounds__(GS_BLOCK) void k_sort_depth_pair(const float4 *__re
 // by the 7 bits on top of the index: half the bytes of (key, index) records through three of the five streaming passes.
 // A 17th key bit has no room there, so kept splats with a dropped bucket leave the sort here as well; the final pass
 // zero-fills their slots [V', V) behind the sorted records (the reference's never-written tail).
-template <int NW, bool COMPACT>
+// NEAR (a near-only sort, COMPACT records): only the splats that can be among the nearest near_req of the order go on.
+// The depth histogram gives the first bin T with (kept splats in bins <= T) >= near_req; its far edge -e is a depth, b* = its
+// bucket, and a splat goes on iff its bucket >= b*: the bucket is monotonic in the stored depth, so every splat nearer than
+// the edge qualifies (at least near_req of them), and the rule is a threshold on the sort key itself -- the survivors are
+// exactly the last P valid positions of the whole order, in the same relative order.  The others leave like culled splats
+// (GS_RADIX_SKIP).  The kernel also counts V' (valid buckets among ALL kept splats): the survivors sit at positions
+// [V' - P, V') of the order (k_project subtracts V' - P).
+template <int NW, bool COMPACT, bool NEAR>
 __device__ __forceinline__ void k_sort_bucket_body(const float *__restrict__ depth, uint32_t n, uint32_t *__restrict__ keys,
                                                    const unsigned long long *__restrict__ part_min,
                                                    const unsigned long long *__restrict__ part_max,
                                                    const uint32_t *__restrict__ part_cnt, uint32_t nparts,
-                                                   uint32_t *__restrict__ hist, GsControl *ctl)
+                                                   uint32_t *__restrict__ hist, GsControl *ctl, const uint32_t *__restrict__ dhist, uint32_t near_req)
 {
+    static_assert(!NEAR || COMPACT, "near-only sorts use the compact records");
     constexpr int NT = 64 * NW, IPT = 8, CH = NT * IPT;
     __shared__ unsigned long long s_min, s_max;
     __shared__ uint32_t s_cnt;
     constexpr uint32_t BINS = COMPACT ? 512u : 256u;
     __shared__ uint32_t s_hist[BINS];                             // low-digit histogram of this chunk = radix pass A's input
-    if (threadIdx.x == 0) { s_min = ~0ull; s_max = 0ull; s_cnt = 0; }
+    __shared__ uint32_t s_nvalid;
+    __shared__ int32_t s_bcut;
+    if (threadIdx.x == 0) { s_min = ~0ull; s_max = 0ull; s_cnt = 0; s_nvalid = 0; s_bcut = 0; }
     __syncthreads();
     {
         unsigned long long mn = ~0ull, mx = 0ull; uint32_t cnt = 0;
@@ -220,9 +275,46 @@ __device__ __forceinline__ void k_sort_bucket_body(const float *__restrict__ dep
         if ((threadIdx.x & 63) == 0) { atomicMin(&s_min, mn); atomicMax(&s_max, mx); atomicAdd(&s_cnt, cnt); }
     }
     __syncthreads();
-    if (blockIdx.x == 0 && threadIdx.x == 0) { ctl->min_enc = s_min; ctl->max_enc = s_max; ctl->n_kept = s_cnt; ctl->n_total = n; }
+    if (blockIdx.x == 0 && threadIdx.x == 0) { ctl->min_enc = s_min; ctl->max_enc = s_max; ctl->n_kept = s_cnt; ctl->n_total = n; ctl->near_sorted = NEAR ? 1u : 0u; }
     const double mn = gsm::ordered_to_f64(s_min), mx = gsm::ordered_to_f64(s_max);
     const double inv = 65535.0 / (mx - mn);                       // (256*256-1)/(maxDepth-minDepth)
+    if (NEAR) {
+        // the first bin T with (kept splats in bins <= T) >= near_req, by the first wavefront: the 64 coarse sums (over the
+        // copies), a scan, then the 32 bins of the coarse bin where the count is reached
+        if (threadIdx.x < 64) {
+            const int l = threadIdx.x;
+            auto wave_scan = [&](uint32_t v) { for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(v, d, 64); if (l >= d) v += t; } return v; };
+            uint32_t cs = 0;
+#pragma unroll
+            for (uint32_t c = 0; c < GS_DH_COPIES; c++) cs += dhist[GS_DH_COPIES * GS_DEPTH_BINS + c * GS_DEPTH_COARSE + l];
+            const uint32_t cinc = wave_scan(cs);
+            const unsigned long long m = __ballot(cinc >= near_req);
+            uint32_t T = GS_DEPTH_BINS - 1u;                         // (fewer kept splats than near_req: all of them)
+            if (m) {
+                const int C = __ffsll((long long)m) - 1;
+                const uint32_t before = __shfl(cinc - cs, C, 64);    // kept splats nearer than coarse bin C
+                uint32_t fs = 0;
+                if (l < 32) {
+#pragma unroll
+                    for (uint32_t c = 0; c < GS_DH_COPIES; c++) fs += dhist[c * GS_DEPTH_BINS + (uint32_t)C * 32u + l];
+                }
+                const uint32_t finc = wave_scan(fs);
+                const unsigned long long m2 = __ballot(l < 32 && before + finc >= near_req);
+                T = (uint32_t)C * 32u + (m2 ? (uint32_t)(__ffsll((long long)m2) - 1) : 31u);
+            }
+            if (l == 0) {
+                int32_t bc = 0;
+                if (T < GS_DEPTH_BINS - 1u && inv > 0.0 && inv < 1.0e300) {   // (a degenerate depth range maps everything to bucket 0: keep all)
+                    const double x = ((double)(-__uint_as_float((T + 1u) << 20)) - mn) * inv;   // the far edge's place in the bucket table
+                    bc = !(x >= 0.0) ? 0 : (x >= 65535.0 ? 65535 : (int32_t)x);                // (NaN / before the table: everything valid)
+                }
+                s_bcut = bc;
+            }
+        }
+        __syncthreads();
+    }
+    const int32_t bcut = s_bcut;
+    uint32_t nvalid = 0;
     const uint32_t nchunks = (n + CH - 1) / CH;
     for (uint32_t v = blockIdx.x; v < ((nchunks + 7u) & ~7u); v += gridDim.x) {
         uint32_t c;
@@ -246,7 +338,8 @@ __device__ __forceinline__ void k_sort_bucket_body(const float *__restrict__ dep
                 uint32_t k = GS_RADIX_SKIP;
                 if (d != INFINITY) {
                     const int32_t b = gsm::sort_bucket(d, mn, inv);
-                    if (COMPACT) { if (b >= 0) { k = (uint32_t)b; atomicAdd(&s_hist[k & 511u], 1u); } }
+                    if (NEAR) { if (b >= 0) { nvalid++; if (b >= bcut) { k = (uint32_t)b; atomicAdd(&s_hist[k & 511u], 1u); } } }
+                    else if (COMPACT) { if (b >= 0) { k = (uint32_t)b; atomicAdd(&s_hist[k & 511u], 1u); } }
                     else { k = b >= 0 ? (uint32_t)b : GS_CULLED_KEY; atomicAdd(&s_hist[k & 255u], 1u); }
                 }
                 keys[i] = k;
@@ -256,33 +349,76 @@ __device__ __forceinline__ void k_sort_bucket_body(const float *__restrict__ dep
         for (uint32_t d = threadIdx.x; d < BINS; d += NT) hist[(size_t)c * BINS + d] = s_hist[d];   // row c of hist[chunk][digit]
         __syncthreads();
     }
+    if (NEAR) {                                                      // V' of the whole order: one global atomic per workgroup
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) nvalid += __shfl_xor(nvalid, m, 64);
+        if ((threadIdx.x & 63) == 0 && nvalid) atomicAdd(&s_nvalid, nvalid);
+        __syncthreads();
+        if (threadIdx.x == 0 && s_nvalid) atomicAdd(&ctl->n_valid, s_nvalid);
+    }
 }
 
-template <int NW, bool COMPACT>
+template <int NW, bool COMPACT, bool NEAR>
 __global__ __launch_bounds__(64 * NW) void k_sort_bucket(const float *__restrict__ depth, uint32_t n, uint32_t *__restrict__ keys,
                                                          const unsigned long long *__restrict__ part_min,
                                                          const unsigned long long *__restrict__ part_max,
                                                          const uint32_t *__restrict__ part_cnt, uint32_t nparts,
-                                                         uint32_t *__restrict__ hist, GsControl *ctl)
+                                                         uint32_t *__restrict__ hist, GsControl *ctl, const uint32_t *__restrict__ dhist, uint32_t near_req)
 {
-    k_sort_bucket_body<NW, COMPACT>(depth, n, keys, part_min, part_max, part_cnt, nparts, hist, ctl);
+    k_sort_bucket_body<NW, COMPACT, NEAR>(depth, n, keys, part_min, part_max, part_cnt, nparts, hist, ctl, dhist, near_req);
 }
 
-template <int NW, bool COMPACT> GS_BODY(F_sort_bucket, k_sort_bucket_body<NW, COMPACT>);
+template <int NW, bool COMPACT, bool NEAR> GS_BODY(F_sort_bucket, k_sort_bucket_body<NW, COMPACT, NEAR>);
 
 }  // namespace
 
 static void fill_sort_uniforms(const gs_ctx *ctx, const float view[4], const float *cutout16, const GsSortStrip *strip, SortUniforms &u, StripUniforms &su);
 
+// what the lane's order was made from and how much of it exists (the render re-sorts in full if it turns out to need more)
+static void remember_sort(gs_ctx *L, const float view[4], const float *cutout16, const GsSortStrip *strip, uint32_t near_req)
+{
+    memcpy(L->sv_view, view, sizeof L->sv_view);
+    L->sv_has_cutout = cutout16 != nullptr;
+    if (cutout16) memcpy(L->sv_cutout, cutout16, sizeof L->sv_cutout);
+    L->sv_has_strip = strip != nullptr;
+    if (strip) L->sv_strip = *strip;
+    L->sort_near_req = near_req;
+}
+
+// the depth-histogram buffers of this sort: fill the next one (near-only sorts), clear the one the previous near-only sort filled
+static DepthHist next_depth_hist(gs_ctx *L, bool near)
+{
+    DepthHist dh;
+    dh.zero = L->dh_dirty; L->dh_dirty = nullptr;
+    dh.fill = nullptr; dh.zero_word = nullptr;
+    if (near) {
+        dh.fill = L->dhist[L->dh_next]; L->dh_next ^= 1;
+        L->dh_dirty = dh.fill;
+        dh.zero_word = &L->ctl->n_valid;
+    }
+    return dh;
+}
+
+// records the second pass of a near-only sort should expect (its geometry and grid: a matter of speed only)
+static uint32_t near_hint(const gs_ctx *L, uint32_t n)
+{
+    const uint64_t h = (uint64_t)L->sort_near_req * 2u + 65536u;
+    return h < n ? (uint32_t)h : n;
+}
+
 // Two frames' sorts, one launch per kernel (GS_OPT_FRAME_BATCH): S[0] and S[1] are sibling lanes on ONE stream holding the same
 // resident data; each keeps its own depths, keys, tables, partial slots and control block.  Strip sorts (gs_sort_for) pair with strip sorts.
-int gs_run_sort2(gs_ctx *const S[2], const float *const view[2], const float *const cutout16[2], const GsSortStrip *const strip[2])
+int gs_run_sort2(gs_ctx *const S[2], const float *const view[2], const float *const cutout16[2], const GsSortStrip *const strip[2], const uint32_t near_req[2])
 {
     gs_ctx *ctx = S[0];
     const uint32_t n = (uint32_t)ctx->n;
     SortUniforms u[2];
     StripUniforms su[2];
     for (int k = 0; k < 2; k++) fill_sort_uniforms(S[k], view[k], cutout16[k], strip ? strip[k] : nullptr, u[k], su[k]);
+    const bool compact = !ctx->wide_pairs && n <= (1u << 25);
+    const bool near = compact && near_req && near_req[0] && near_req[1];   // (a pair takes one path)
+    DepthHist dh[2];
+    for (int k = 0; k < 2; k++) { remember_sort(S[k], view[k], cutout16[k], strip ? strip[k] : nullptr, near ? near_req[k] : 0u); dh[k] = next_depth_hist(S[k], near); }
     const bool strips = u[0].has_strip && u[1].has_strip;
     if (!strips) u[0].has_strip = u[1].has_strip = 0;              // (a pair takes one path: both strip sorts, or both plain)
     const uint32_t g = gs_radix_grid(n);
@@ -293,19 +429,18 @@ int gs_run_sort2(gs_ctx *const S[2], const float *const view[2], const float *co
     if (gd > GS_DEPTH_GRID) gd = GS_DEPTH_GRID;
     // ONE sweep computes both frames' depths: the rows are read once (the lanes of a context alias the owner's resident arrays)
     if (S[0]->sort_rows != S[1]->sort_rows) { snprintf(GS_ERRBUF(ctx), GS_ERRLEN, "paired sort: the two lanes hold different splat arrays"); return GS_E_STATE; }
-#define GS_DEPTHP(ST) hipLaunchKernelGGL((k_sort_depth_pair<ST>), dim3(gd), dim3(GS_BLOCK), 0, st, (const float4 *)S[0]->sort_rows, (const float *)S[0]->bound_r, n,  \
+#define GS_DEPTHP(ST) hipLaunchKernelGGL((k_sort_depth_pair<ST>), dim3(gd), dim3(GS_BLOCK), near ? 2u * GS_DEPTH_BINS * sizeof(uint32_t) : 0u, st, (const float4 *)S[0]->sort_rows, (const float *)S[0]->bound_r, n,  \
                                          u[0], u[1], su[0], su[1], S[0]->depth, S[1]->depth, S[0]->part_min, S[0]->part_max, S[0]->part_cnt,                            \
-                                         S[1]->part_min, S[1]->part_max, S[1]->part_cnt)
+                                         S[1]->part_min, S[1]->part_max, S[1]->part_cnt, dh[0], dh[1])
     if (strips) GS_DEPTHP(true); else GS_DEPTHP(false);
 #undef GS_DEPTHP
-    const bool compact = !ctx->wide_pairs && n <= (1u << 25);
-#define GS_BUCKET2(NW, C) gs_twin<F_sort_bucket<NW, C>, 64 * NW>(g, st,                                                                                    \
+#define GS_BUCKET2(NW, C, NR) gs_twin<F_sort_bucket<NW, C, NR>, 64 * NW>(g, st,                                                                            \
         gs_pack_make((const float *)S[0]->depth, n, S[0]->key_a, (const unsigned long long *)S[0]->part_min, (const unsigned long long *)S[0]->part_max,     \
-                     (const uint32_t *)S[0]->part_cnt, gd, S[0]->hist, S[0]->ctl),                                                                            \
+                     (const uint32_t *)S[0]->part_cnt, gd, S[0]->hist, S[0]->ctl, (const uint32_t *)dh[0].fill, S[0]->sort_near_req),                       \
         gs_pack_make((const float *)S[1]->depth, n, S[1]->key_a, (const unsigned long long *)S[1]->part_min, (const unsigned long long *)S[1]->part_max,     \
-                     (const uint32_t *)S[1]->part_cnt, gd, S[1]->hist, S[1]->ctl))
-    if (gs_radix_chunk(n) == GS_CHUNK_L) { if (compact) GS_BUCKET2(8, true); else GS_BUCKET2(8, false); }
-    else { if (compact) GS_BUCKET2(4, true); else GS_BUCKET2(4, false); }
+                     (const uint32_t *)S[1]->part_cnt, gd, S[1]->hist, S[1]->ctl, (const uint32_t *)dh[1].fill, S[1]->sort_near_req))
+    if (gs_radix_chunk(n) == GS_CHUNK_L) { if (near) GS_BUCKET2(8, true, true); else if (compact) GS_BUCKET2(8, true, false); else GS_BUCKET2(8, false, false); }
+    else { if (near) GS_BUCKET2(4, true, true); else if (compact) GS_BUCKET2(4, true, false); else GS_BUCKET2(4, false, false); }
 #undef GS_BUCKET2
     GS_HIP(hipGetLastError());
     const void *in[2]; void *out[2]; const uint32_t *np[2]; uint32_t *cnt[2]; const uint32_t *fill[2];
@@ -314,8 +449,9 @@ int gs_run_sort2(gs_ctx *const S[2], const float *const view[2], const float *co
         for (int k = 0; k < 2; k++) { in[k] = S[k]->key_a; out[k] = S[k]->kv_b; np[k] = &S[k]->ctl->n_total; cnt[k] = &S[k]->ctl->n_sorted; fill[k] = nullptr; }
         rc = gs_launch_radix_pass2(S, in, GS_RADIX_KEYS, out, GS_RADIX_KEYIDX, np, n, n, 0, 9, true, 0xFFFFFFFFu, 25, cnt, fill);
         if (rc != GS_OK) return rc;
-        for (int k = 0; k < 2; k++) { in[k] = S[k]->kv_b; out[k] = S[k]->val_a; np[k] = &S[k]->ctl->n_sorted; cnt[k] = nullptr; fill[k] = &S[k]->ctl->n_kept; }
-        rc = gs_launch_radix_pass2(S, in, GS_RADIX_KEYIDX, out, GS_RADIX_KEYS, np, n, n, 25, 7, false, 0xFFFFFFFFu, 0, cnt, fill);
+        // (a near-only sort leaves no zero tail: k_project supplies the zeros of the positions behind its records)
+        for (int k = 0; k < 2; k++) { in[k] = S[k]->kv_b; out[k] = S[k]->val_a; np[k] = &S[k]->ctl->n_sorted; cnt[k] = nullptr; fill[k] = near ? nullptr : &S[k]->ctl->n_kept; }
+        rc = gs_launch_radix_pass2(S, in, GS_RADIX_KEYIDX, out, GS_RADIX_KEYS, np, n, near ? near_hint(S[0], n) : n, 25, 7, false, 0xFFFFFFFFu, 0, cnt, fill);
         if (rc != GS_OK) return rc;
     } else {
         for (int k = 0; k < 2; k++) { in[k] = S[k]->key_a; out[k] = S[k]->kv_b; np[k] = &S[k]->ctl->n_total; cnt[k] = nullptr; fill[k] = nullptr; }
@@ -369,28 +505,32 @@ static void fill_sort_uniforms(const gs_ctx *ctx, const float view[4], const flo
 
 }
 
-int gs_run_sort(gs_ctx *ctx, const float view[4], const float *cutout16, const GsSortStrip *strip)
+int gs_run_sort(gs_ctx *ctx, const float view[4], const float *cutout16, const GsSortStrip *strip, uint32_t near_req)
 {
     const uint32_t n = (uint32_t)ctx->n;
     SortUniforms u;
     StripUniforms su;
     fill_sort_uniforms(ctx, view, cutout16, strip, u, su);
+    // record format of the two passes: 4 bytes while the index fits in 25 bits (GS_OPT_WIDE_PAIRS forces the general form)
+    const bool compact = !ctx->wide_pairs && n <= (1u << 25);
+    const bool near = compact && near_req;
+    remember_sort(ctx, view, cutout16, strip, near ? near_req : 0u);
+    const DepthHist dh = next_depth_hist(ctx, near);
 
     const uint32_t g = gs_radix_grid(n);                         // same chunking as the radix kernels (pre-filled histogram rows)
     GS_PROF_RECORD(ctx, 0);
     uint32_t gd = gs_div_up(n, (uint32_t)(GS_DEPTH_IPT * GS_BLOCK));
     if (gd < 1) gd = 1;
     if (gd > GS_DEPTH_GRID) gd = GS_DEPTH_GRID;
-    if (u.has_strip) hipLaunchKernelGGL(k_sort_depth<true>, dim3(gd), dim3(GS_BLOCK), 0, ctx->stream, ctx->sort_rows, ctx->bound_r, n, u, su, ctx->depth,
-                                        ctx->part_min, ctx->part_max, ctx->part_cnt);
-    else hipLaunchKernelGGL(k_sort_depth<false>, dim3(gd), dim3(GS_BLOCK), 0, ctx->stream, ctx->sort_rows, ctx->bound_r, n, u, su, ctx->depth,
-                            ctx->part_min, ctx->part_max, ctx->part_cnt);
-    // record format of the two passes: 4 bytes while the index fits in 25 bits (GS_OPT_WIDE_PAIRS forces the general form)
-    const bool compact = !ctx->wide_pairs && n <= (1u << 25);
-#define GS_LAUNCH_BUCKET(NW, C) hipLaunchKernelGGL((k_sort_bucket<NW, C>), dim3(g), dim3(64 * NW), 0, ctx->stream, ctx->depth, n, ctx->key_a, \
-                                                   ctx->part_min, ctx->part_max, ctx->part_cnt, gd, ctx->hist, ctx->ctl)
-    if (gs_radix_chunk(n) == GS_CHUNK_L) { if (compact) GS_LAUNCH_BUCKET(8, true); else GS_LAUNCH_BUCKET(8, false); }
-    else { if (compact) GS_LAUNCH_BUCKET(4, true); else GS_LAUNCH_BUCKET(4, false); }
+    const size_t dlds = near ? GS_DEPTH_BINS * sizeof(uint32_t) : 0u;
+    if (u.has_strip) hipLaunchKernelGGL(k_sort_depth<true>, dim3(gd), dim3(GS_BLOCK), dlds, ctx->stream, ctx->sort_rows, ctx->bound_r, n, u, su, ctx->depth,
+                                        ctx->part_min, ctx->part_max, ctx->part_cnt, dh);
+    else hipLaunchKernelGGL(k_sort_depth<false>, dim3(gd), dim3(GS_BLOCK), dlds, ctx->stream, ctx->sort_rows, ctx->bound_r, n, u, su, ctx->depth,
+                            ctx->part_min, ctx->part_max, ctx->part_cnt, dh);
+#define GS_LAUNCH_BUCKET(NW, C, NR) hipLaunchKernelGGL((k_sort_bucket<NW, C, NR>), dim3(g), dim3(64 * NW), 0, ctx->stream, ctx->depth, n, ctx->key_a, \
+                                                       ctx->part_min, ctx->part_max, ctx->part_cnt, gd, ctx->hist, ctx->ctl, (const uint32_t *)dh.fill, ctx->sort_near_req)
+    if (gs_radix_chunk(n) == GS_CHUNK_L) { if (near) GS_LAUNCH_BUCKET(8, true, true); else if (compact) GS_LAUNCH_BUCKET(8, true, false); else GS_LAUNCH_BUCKET(8, false, false); }
+    else { if (near) GS_LAUNCH_BUCKET(4, true, true); else if (compact) GS_LAUNCH_BUCKET(4, true, false); else GS_LAUNCH_BUCKET(4, false, false); }
 #undef GS_LAUNCH_BUCKET
     GS_HIP(hipGetLastError());
     int rc;
@@ -400,8 +540,9 @@ int gs_run_sort(gs_ctx *ctx, const float view[4], const float *cutout16, const G
         if (rc != GS_OK) return rc;
         // V' records are left (culled splats and dropped buckets took no slot); slots [V', V) of the result are zero-filled:
         // the reference's never-written Uint32Array tail
-        rc = gs_launch_radix_pass(ctx, ctx->kv_b, GS_RADIX_KEYIDX, ctx->val_a, GS_RADIX_KEYS, &ctx->ctl->n_sorted, n, n, 25, 7, false, 0xFFFFFFFFu, 0,
-                                  nullptr, &ctx->ctl->n_kept);
+        // (a near-only sort leaves no zero tail: k_project supplies the zeros of the positions behind its records)
+        rc = gs_launch_radix_pass(ctx, ctx->kv_b, GS_RADIX_KEYIDX, ctx->val_a, GS_RADIX_KEYS, &ctx->ctl->n_sorted, n, near ? near_hint(ctx, n) : n, 25, 7, false,
+                                  0xFFFFFFFFu, 0, nullptr, near ? nullptr : &ctx->ctl->n_kept);
         if (rc != GS_OK) return rc;
     } else {
         rc = gs_launch_radix_pass(ctx, ctx->key_a, GS_RADIX_KEYS, ctx->kv_b, GS_RADIX_PACKED, &ctx->ctl->n_total, n, n, 0, 8, /*have_hist=*/true);

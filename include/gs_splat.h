@@ -238,6 +238,14 @@ GS_API int gs_gathered_size(gs_ctx *ctx, int view, int *width, int *height);
                                    queued (needs GS_OPT_ENQUEUE_THREADS); gathered frames of one piece per rank pair as well
                                    (their gathers follow the shared kernels in frame order); frames that differ in size,
                                    flags or path go out alone.                                                              */
+#define GS_OPT_SORT_NEAR 11     /* near-only depth sorts.  A frame whose second binning round is skipped (the adaptive share has
+                                   been clean for 16 frames) reads only the nearest share of the order; its gs_sort then drops,
+                                   before the radix passes, every splat that cannot be among those -- an exact threshold on the
+                                   sort key from a histogram of the depths, so the positions the frame reads hold exactly what the
+                                   whole order holds there.  A render that needs more of the order after all (another share, a
+                                   counting render, round 1, gs_download of the order) sorts again in full by itself.  Sorts that
+                                   return the order (out_idx / out_n) are always complete.  0: off; 1 (default): for scenes of
+                                   4 M splats and more (below, the sort's passes are launch-bound); 2: always.               */
 #define GS_OPT_COMM_SELF_COPY 8 /* value != 0: the root sends its own pieces to itself through RCCL too instead of rendering them
                                    in place (exercises send/recv on a single-GPU box; slower) */
 
@@ -279,6 +287,9 @@ typedef struct gs_stats {
     uint64_t acc_pairs;   /* sum of I                                                                         */
     uint32_t unsat_tiles; /* tiles the nearest-splats round left unsaturated in the last collected frame             */
     uint32_t near_permille;/* share of the splats binned in that first round (adapted, or GS_OPT_NEAR_PERMILLE)        */
+    uint32_t sort_records;/* records the last collected frame's depth sort carried through its second pass: the kept
+                             splats with a valid bucket, or the nearest few of them (GS_OPT_SORT_NEAR)               */
+    uint32_t reserved0;
 } gs_stats;
 
 #define GS_OPT_PROFILE 1        /* 1: bracket every stage with HIP events on the frame's stream (7 per frame); 2: only

@@ -20,6 +20,7 @@ ap.add_argument("--sort-only", action="store_true")
 ap.add_argument("--split", type=int, default=0, help="GS_OPT_BLEND_SPLIT")
 ap.add_argument("--term", type=int, default=0, help="GS_OPT_TERMINATION (1/eps)")
 ap.add_argument("--batch", type=int, default=1, help="GS_OPT_FRAME_BATCH")
+ap.add_argument("--sort-near", type=int, default=None, help="GS_OPT_SORT_NEAR (0 off, 1 auto = the library's default, 2 always)")
 ap.add_argument("--strip", default=None, help="k/G: render only strip k of G tile-aligned column strips (what one of G GPUs does)")
 ap.add_argument("--sort-for", action="store_true", help="with --strip: gs_sort_for the strip instead of the full gs_sort")
 a = ap.parse_args()
@@ -44,6 +45,8 @@ if a.near:
     ctx.set_option(capi.OPT_NEAR_PERMILLE, a.near)
 if a.batch != 1:
     ctx.set_option(capi.OPT_FRAME_BATCH, a.batch)
+if a.sort_near is not None:
+    ctx.set_option(capi.OPT_SORT_NEAR, a.sort_near)
 
 
 def go(n):
@@ -81,8 +84,8 @@ for depth in (int(v) for v in a.depths.split(",")):
     s = ctx.stats()
     ctx.set_option(capi.OPT_PROFILE, 0)
     k = max(1, s["prof_frames"])
-    print("N=%d %dx%d%s depth %d: %.0f frames/s (%.1f us/frame) | events: sort %.1f project %.1f bin %.1f blend %.1f us | V=%d Vp=%d I=%d near=%d" % (
+    print("N=%d %dx%d%s depth %d: %.0f frames/s (%.1f us/frame) | events: sort %.1f project %.1f bin %.1f blend %.1f us | V=%d Vp=%d I=%d near=%d sortrec=%d" % (
         a.splats, W, H, " cutout" if a.cutout else "", depth, a.frames / t, t / a.frames * 1e6, s["sum_ms_sort"] / k * 1e3,
         s["sum_ms_project"] / k * 1e3, s["sum_ms_bin"] / k * 1e3, s["sum_ms_blend"] / k * 1e3, s["n_sorted"], s["n_visible"], s["n_pairs"],
-        s["near_permille"]), flush=True)
+        s["near_permille"], s["sort_records"]), flush=True)
 ctx.close()
