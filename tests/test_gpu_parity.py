@@ -746,6 +746,30 @@ def test_near_only_sorts_fill_the_positions_a_frame_reads_like_whole_sorts():
             assert s["sort_records"] * 1000 >= s["near_permille"] * s["n_sorted"] * 0.9, s   # ... and no shorter than the share read
             for a, b in zip(got, want):
                 assert np.array_equal(a, b)                                 # ... and the frames are the frames of whole sorts
+            # column strips, sorted with gs_sort_for (what one of several GPUs does): near-only as well, same pixels
+            if batch == 1:
+                strips = [(0, 320), (320, 640)]
+                for attempt in range(6):
+                    sb = []
+                    for k in range(6):
+                        for x0, x1 in strips:
+                            b = torch.zeros((x1 - x0) * h * 4, dtype=torch.uint8, device="cuda")
+                            sp = _params(cams[k], x0=x0, x1=x1, flags=capi.RENDER_ASYNC)
+                            c.sort_for(cams[k]["view"], None, sp, want_indices=False)
+                            c.render_device(sp, b.data_ptr())
+                            sb.append((k, x0, x1, b))
+                    try:
+                        c.sync()
+                        break
+                    except capi.GsError as e:
+                        assert e.code == capi.E_RETRY and attempt < 5
+                torch.cuda.synchronize()
+                s = c.stats()
+                assert 0 < s["sort_records"] <= s["n_sorted"], s
+                if s["near_permille"] * rows.shape[0] < 800 * s["n_sorted"]:   # the strip keeps more splats than the share read: a partial sort
+                    assert s["sort_records"] < s["n_sorted"], s
+                for k, x0, x1, b in sb:
+                    assert np.array_equal(b.cpu().numpy().reshape(h, x1 - x0, 4), want[k][:, x0:x1]), (k, x0, x1)
             # a synchronous frame on a near-only sort
             c.sort(cams[3]["view"], want_indices=False)
             assert np.array_equal(c.render(_params(cams[3])), want[3])
