@@ -5,15 +5,19 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 capi = importlib.import_module("aframe-gaussian-splatting_amd.capi"); synth = importlib.import_module("aframe-gaussian-splatting_amd.synth")
 g = np.random.Generator(np.random.PCG64(int(sys.argv[1]) if len(sys.argv) > 1 else 1))
-rows = synth.make_splat_rows(60000, seed=5).reshape(-1, 32)
+NEAR = os.environ.get("STRESS_NEAR") == "1"                # a dense scene + GS_OPT_SORT_NEAR = 2: near-only sorts and their fall-backs
+rows = (synth.make_splat_rows(synth.N_TRAIN) if NEAR else synth.make_splat_rows(60000, seed=5)).reshape(-1, 32)
 W, H = 640, 360
 cams = [synth.index_html_camera(W, H, 15.0 * i, capi=capi) for i in range(24)]
 P = lambda cam, **kw: capi.make_params(cam["gs_mv"], cam["gs_proj"], W, H, focal_=cam["focal"], **kw)
 ref = capi.Context(0); ref.set_option(capi.OPT_PIPELINE_DEPTH, 1)
 c = capi.Context(0)
 c.set_option(capi.OPT_FRAME_BATCH, 2)                       # frames pair from the start; toggled at random below
-n = 20000
+n = N0 = 700000 if NEAR else 20000
+if NEAR:
+    c.set_option(capi.OPT_SORT_NEAR, 2); ref.set_option(capi.OPT_SORT_NEAR, 0)
 c.push_splat(rows[:n]); ref.push_splat(rows[:n])
+near_sorts = 0
 t0 = time.time(); ops = 0; checked = 0
 while time.time() - t0 < float(os.environ.get("STRESS_SECONDS", "20")):
     r = g.random(); k = int(g.integers(0, len(cams))); ops += 1
@@ -25,6 +29,12 @@ while time.time() - t0 < float(os.environ.get("STRESS_SECONDS", "20")):
             ridx = ref.sort(cams[k]["view"]); rimg = ref.render(P(cams[k]))
             assert np.array_equal(idx, ridx) and np.array_equal(img, rimg), "mismatch at op %d" % ops
             checked += 1
+        elif r < 0.83:                                       # a synchronous frame on a sort that hands nothing back (possibly near-only)
+            c.sort(cams[k]["view"], None, want_indices=False); img = c.render(P(cams[k]))
+            st = c.stats(); near_sorts += 1 if 0 < st["sort_records"] < st["n_sorted"] else 0
+            ref.sort(cams[k]["view"], None, want_indices=False); rimg = ref.render(P(cams[k]))
+            assert np.array_equal(img, rimg), "mismatch (no indices) at op %d" % ops
+            checked += 1
         elif r < 0.86:
             try: c.sync()
             except capi.GsError as e:
@@ -34,15 +44,16 @@ while time.time() - t0 < float(os.environ.get("STRESS_SECONDS", "20")):
         elif r < 0.95: c.set_option(capi.OPT_ENQUEUE_THREADS, int(g.integers(0, 2)))
         elif r < 0.96: c.set_option(capi.OPT_PROFILE, int(g.integers(0, 3)))
         elif r < 0.97: c.set_option(capi.OPT_FRAME_BATCH, int(g.integers(1, 3)))
+        elif r < 0.972 and NEAR: c.set_option(capi.OPT_SORT_NEAR, int(g.integers(0, 3)) or 2)
         elif r < 0.985 and n < rows.shape[0]:
             m = min(rows.shape[0], n + int(g.integers(1, 9000)))
             c.push_splat(rows[n:m]); ref.push_splat(rows[n:m]); n = m
         elif r < 0.992: c.frame_stream()
         else:
-            c.clear(); ref.clear(); n = 20000; c.push_splat(rows[:n]); ref.push_splat(rows[:n])
+            c.clear(); ref.clear(); n = N0; c.push_splat(rows[:n]); ref.push_splat(rows[:n])
     except capi.GsError as e:
         if e.code != capi.E_RETRY: raise
 try: c.sync()
 except capi.GsError: pass
 c.close(); ref.close()
-print("stress ok: %d operations, %d checked frames, %d splats" % (ops, checked, n))
+print("stress ok: %d operations, %d checked frames (%d on near-only sorts), %d splats" % (ops, checked, near_sorts, n))
