@@ -19,6 +19,8 @@ OPT_COMM_SELF_COPY = 8
 OPT_BLEND_SPLIT = 9
 OPT_FRAME_BATCH = 10
 OPT_SORT_NEAR = 11
+OPT_COMM_TRANSPORT = 12
+TRANSPORT_RCCL, TRANSPORT_INPROC = 0, 1
 COMM_ID_BYTES = 128
 BUF_CENTER_SCALE, BUF_COV_COLOR, BUF_SORT_ROWS, BUF_SORTED, BUF_PROJECTED, BUF_TILE_COUNT, BUF_TILE_STATS = 0, 1, 2, 3, 4, 5, 6
 
@@ -382,7 +384,10 @@ class Context:
         self._ck(self._L.gs_stream_wait_frame(self._h, C.c_void_p(stream_ptr)))
 
     # ---- several GPUs (one Context per GPU; see gs_splat.h) ----
-    def comm_unique_id(self):
+    def comm_unique_id(self, transport=None):
+        """rank 0: the id every rank passes to comm_init.  transport: TRANSPORT_RCCL / TRANSPORT_INPROC (None = as set)."""
+        if transport is not None:
+            self.set_option(OPT_COMM_TRANSPORT, transport)
         buf = (C.c_uint8 * COMM_ID_BYTES)()
         self._ck(self._L.gs_comm_unique_id(self._h, buf))
         return bytes(buf)
@@ -400,8 +405,18 @@ class Context:
             ptrs = (C.c_void_p * len(views))(*[C.c_void_p(int(p)) if p else None for p in device_frames])
         self._ck(self._L.gs_render_gathered(self._h, arr, len(views), int(root), ptrs, int(flags)))
 
-    def read_gathered(self, view, width, height):
-        out = np.empty((int(height), int(width), 4), np.uint8)
+    def gathered_size(self, view):
+        w, h = C.c_int(0), C.c_int(0)
+        self._ck(self._L.gs_gathered_size(self._h, int(view), C.byref(w), C.byref(h)))
+        return w.value, h.value
+
+    def read_gathered(self, view, width=None, height=None):
+        """root: view `view` of the last gathered frame as H x W x 4 uint8 (the size is the library's; width / height, if
+        given, are checked against it)."""
+        w, h = self.gathered_size(view)
+        if (width is not None and int(width) != w) or (height is not None and int(height) != h):
+            raise ValueError("gathered frame %d is %dx%d, not %sx%s" % (view, w, h, width, height))
+        out = np.empty((h, w, 4), np.uint8)
         self._ck(self._L.gs_read_gathered(self._h, int(view), _p(out), 0))
         return out
 

@@ -398,6 +398,7 @@ static void lane_worker_main(gs_ctx *L)
             } else if (kind == GS_Q_STEREO) {
                 pc[0] = w->q.front(); w->q.pop_front(); pc[1] = w->q.front(); w->q.pop_front();
                 stereo = true;
+                L->twin->inflight++;                               // the second view runs on the twin's scratch: a drain of the twin waits for it
             }
         }
         lk.unlock();
@@ -417,7 +418,7 @@ static void lane_worker_main(gs_ctx *L)
         if (rc != GS_OK && w->rc == GS_OK) { w->rc = rc; memcpy(w->err, scratch, sizeof w->err); }
         w->busy = false;
         if (w->q.empty()) w->flush = false;
-        if (stereo) { L->inflight -= 3; w->n_pairs += 2; L->twin->async_pending = true; }   // (the second view's counters sit in the twin's control block)
+        if (stereo) { L->inflight -= 3; L->twin->inflight--; w->n_pairs += 2; L->twin->async_pending = true; }   // (the second view's counters sit in the twin's control block)
         else if (paired) { L->inflight -= 2 + calls; L->twin->inflight -= 2 + calls; w->n_pairs += 2; } else { T->inflight -= 1; if (c.type == 1) w->n_single++; }
         w->cv_idle.notify_all();
     }
@@ -984,18 +985,22 @@ static int render_sync_on_lane(gs_ctx *ctx, const GsFrameUniforms &u, void *devi
 
 // the frame's lane runs `call` after everything handed to it so far: on its worker thread for asynchronous frames (so the
 // caller keeps enqueuing), on the caller's thread otherwise.  The call's failure surfaces like a render's.
-int gs_lane_call(gs_ctx *ctx, bool async, std::function<int(gs_ctx *)> call)
+// always: the call runs even if something handed to the lane before it has failed, or the hand-over itself fails (the gather of
+// a frame, which the other ranks wait for); the earlier failure is what is returned.
+int gs_lane_call(gs_ctx *ctx, bool async, std::function<int(gs_ctx *)> call, bool always)
 {
     gs_ctx *L = ctx->lanes[ctx->cur];
     if (async && ctx->enqueue_threads && gs_rotates(ctx) && !ctx->user_stream) {
         GsLaneCmd c;
-        c.type = 2; c.has_cutout = false; c.has_strip = false; c.device_rgba = nullptr; c.host_rgba = nullptr; c.stride = 0; c.call = std::move(call);
+        c.type = 2; c.has_cutout = false; c.has_strip = false; c.device_rgba = nullptr; c.host_rgba = nullptr; c.stride = 0; c.call = call;
         L->async_pending = true; ctx->cur_async = true;
-        if (lane_push(L, c) != GS_OK) FAIL(GS_E_OOM, "out of host memory");
-        return GS_OK;
+        if (lane_push(L, c) == GS_OK) return GS_OK;
+        if (!always) FAIL(GS_E_OOM, "out of host memory");
     }
-    TRY(lane_rc(ctx, L, lane_drain(L)));
-    return lane_rc(ctx, L, call(L));
+    const int rc = lane_rc(ctx, L, lane_drain(L));
+    if (rc != GS_OK && !always) return rc;
+    const int rc2 = lane_rc(ctx, L, call(L));
+    return rc != GS_OK ? rc : rc2;
 }
 
 static int render_common(gs_ctx *ctx, const gs_render_params *p, void *device_rgba, uint8_t *host_rgba, size_t stride)
@@ -1206,6 +1211,9 @@ GS_API int gs_set_option(gs_ctx *ctx, int option, int64_t value)
         GS_HIP(hipSetDevice(ctx->device));
         TRY(drain_all(ctx));
         return gs_comm_set_self_copy(ctx, value != 0);
+    case GS_OPT_COMM_TRANSPORT:
+        if (value != 0 && value != 1) FAIL(GS_E_BADARG, "comm transport: 0 (RCCL) or 1 (in-process)");
+        return gs_comm_set_transport(ctx, (int)value);
     case GS_OPT_PIPELINE_DEPTH:
         if (value < 1 || value > GS_MAX_PRIMARY) FAIL(GS_E_BADARG, "pipeline depth must be 1..%d", GS_MAX_PRIMARY);
         GS_HIP(hipSetDevice(ctx->device));
@@ -1221,7 +1229,7 @@ GS_API int gs_set_option(gs_ctx *ctx, int option, int64_t value)
         ctx->cur = 0; ctx->rot = 0; ctx->cur_async = false;
         return GS_OK;
     case GS_OPT_SORT_NEAR:
-        if (value > 2) FAIL(GS_E_BADARG, "near-only sorts: 0 (off), 1 (scenes of 4 M splats and more) or 2 (always)");
+        if (value < 0 || value > 2) FAIL(GS_E_BADARG, "near-only sorts: 0 (off), 1 (scenes of 4 M splats and more) or 2 (always)");
         GS_HIP(hipSetDevice(ctx->device));
         TRY(drain_all(ctx));
         ctx->sort_near_opt = (int)value;

@@ -13,12 +13,18 @@
 // when the tickets before it have been issued.
 #include <dlfcn.h>
 #include <condition_variable>
+#include <atomic>
+#include <chrono>
+#include <deque>
 #include <functional>
+#include <map>
 #include <mutex>
+#include <string>
 #include <vector>
+#include <unistd.h>
 #include "gs_internal.h"
 
-extern "C" int gs_lane_call(gs_ctx *ctx, bool async, std::function<int(gs_ctx *)> call);   // gs_api.hip
+extern "C" int gs_lane_call(gs_ctx *ctx, bool async, std::function<int(gs_ctx *)> call, bool always = false);   // gs_api.hip
 extern "C" int gs_sort_two_views(gs_ctx *ctx, const float view[4], const float *cutout16);       // gs_api.hip
 
 // the slice of rccl.h this file needs (types only; the functions come from dlsym)
@@ -39,8 +45,10 @@ struct GsComm {
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
-    ncclComm_t comm = nullptr;
+    ncclComm_t comm = nullptr;                                     // RCCL's communicator, or -- in-process transport -- a GsLoopEndpoint
     int rank = 0, world = 1;
+    int transport = 0;                                             // GS_OPT_COMM_TRANSPORT: what gs_comm_unique_id makes an id for (0 RCCL, 1 in-process)
+    bool loop = false;                                             // the communicator joined is an in-process one
     bool self_copy = false;
     std::mutex m;                                                  // tickets: gathers are issued in frame order, one at a time
     std::condition_variable cv;
@@ -68,6 +76,209 @@ static int load_rccl(gs_ctx *ctx, GsComm *c)
 #define NCCL_OK(ctx, c, call) do { const ncclResult_t _r = (call); if (_r != 0) {                                        \
         snprintf(GS_ERRBUF(ctx), GS_ERRLEN, "%s failed: %s", #call, (c)->GetErrorString ? (c)->GetErrorString(_r) : "?"); \
         return GS_E_HIP; } } while (0)
+
+// ---------------------------------------------------------------- in-process transport (GS_OPT_COMM_TRANSPORT = 1)
+// Several contexts of ONE process -- on different GPUs (gs_create_multi: one host process drives the node) or on the same one
+// (the GPU test tier runs the whole multi-rank path, world 2 / 3 / 8, on a single device) -- exchange their pieces without
+// RCCL, behind the same five calls.  The semantics are ncclSend / ncclRecv's: messages between a pair of ranks match in
+// order; a send returns at once and its source buffer may be reused in stream order; a receive is complete in stream order.
+//   send   the piece is copied into a mailbox buffer on the sender's device on the sender's stream, an event recorded
+//          behind the copy, and the buffer posted to the (source, destination) queue of the hub;
+//   recv   (performed at GroupEnd, after the group's sends: a rank may send to itself) waits ON THE HOST until the matching
+//          send has been posted -- bounded: a peer that never sends fails the frame after GS_LOOP_TIMEOUT_S instead of hanging
+//          it --, makes its stream wait for the sender's event, pulls the buffer (a peer copy when the devices differ), records
+//          the buffer's release event and returns it to the pool; the next sender that takes it waits for that event.
+// A stream never waits for work that has not been submitted yet, so the hardware queues cannot deadlock whatever the number
+// of contexts sharing them.
+#define GS_LOOP_MAGIC "GSLOOPBK"
+#ifndef GS_LOOP_TIMEOUT_S
+#define GS_LOOP_TIMEOUT_S 60                                       // environment GS_COMM_TIMEOUT_S overrides (read when a communicator is opened)
+#endif
+
+namespace {
+
+struct GsLoopBuf {
+    void *p = nullptr; size_t cap = 0, bytes = 0; int dev = -1;
+    hipEvent_t ready = nullptr;                                    // sender's device: the copy into the buffer is done
+    hipEvent_t done = nullptr; int done_dev = -1; bool done_valid = false;   // receiver's device: the buffer has been read
+};
+
+struct GsLoopHub {
+    std::mutex m;
+    std::condition_variable cv;
+    int world = 0, refs = 0, timeout_s = GS_LOOP_TIMEOUT_S;
+    bool failed = false;                                           // a rank gave up: everybody waiting fails too
+    std::map<std::pair<int, int>, std::deque<GsLoopBuf *>> box;    // (source, destination) -> posted messages, in order
+    std::vector<GsLoopBuf *> pool;                                 // free buffers
+    std::string key;
+};
+
+struct GsLoopEndpoint { GsLoopHub *hub; int rank; int dev; };
+
+std::mutex g_loop_m;
+std::map<std::string, GsLoopHub *> g_loop_hubs;
+std::atomic<uint64_t> g_loop_serial{1};
+
+struct LoopRecv { void *buf; size_t bytes; int peer; GsLoopEndpoint *ep; hipStream_t st; };
+thread_local std::vector<LoopRecv> tl_loop_recvs;
+thread_local int tl_loop_group = 0;
+thread_local char tl_loop_err[160] = "";
+enum { LOOP_OK = 0, LOOP_ERR = 1 };
+
+int loop_fail(const char *what, hipError_t e = hipSuccess)
+{
+    if (e != hipSuccess) snprintf(tl_loop_err, sizeof tl_loop_err, "%s: %s", what, hipGetErrorString(e));
+    else snprintf(tl_loop_err, sizeof tl_loop_err, "%s", what);
+    return LOOP_ERR;
+}
+#define LOOP_HIP(call) do { const hipError_t _e = (call); if (_e != hipSuccess) return loop_fail(#call, _e); } while (0)
+
+void loop_free_buf(GsLoopBuf *b)
+{
+    int cur = 0; (void)hipGetDevice(&cur);
+    (void)hipSetDevice(b->dev);
+    if (b->p) (void)hipFree(b->p);
+    if (b->ready) (void)hipEventDestroy(b->ready);
+    if (b->done) { (void)hipSetDevice(b->done_dev); (void)hipEventDestroy(b->done); }
+    (void)hipSetDevice(cur);
+    delete b;
+}
+
+ncclResult_t loop_send(const void *src, size_t bytes, int, int peer, ncclComm_t comm, hipStream_t st)
+{
+    GsLoopEndpoint *ep = reinterpret_cast<GsLoopEndpoint *>(comm);
+    GsLoopHub *h = ep->hub;
+    if (peer < 0 || peer >= h->world) return loop_fail("send: peer out of range");
+    GsLoopBuf *b = nullptr;
+    {   // smallest free buffer of this device that is large enough
+        std::lock_guard<std::mutex> lk(h->m);
+        size_t best = (size_t)-1;
+        for (size_t i = 0; i < h->pool.size(); i++)
+            if (h->pool[i]->dev == ep->dev && h->pool[i]->cap >= bytes && (best == (size_t)-1 || h->pool[i]->cap < h->pool[best]->cap)) best = i;
+        if (best != (size_t)-1) { b = h->pool[best]; h->pool.erase(h->pool.begin() + (long)best); }
+    }
+    if (!b) {
+        b = new (std::nothrow) GsLoopBuf();
+        if (!b) return loop_fail("send: out of host memory");
+        b->dev = ep->dev; b->cap = (bytes + 0xFFFFF) & ~(size_t)0xFFFFF;
+        hipError_t e = hipMalloc(&b->p, b->cap);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&b->ready, hipEventDisableTiming);
+        if (e != hipSuccess) { loop_free_buf(b); return loop_fail("send: mailbox allocation", e); }
+    }
+    if (b->done_valid) { LOOP_HIP(hipStreamWaitEvent(st, b->done, 0)); b->done_valid = false; }   // its previous reader has finished
+    b->bytes = bytes;
+    if (bytes) LOOP_HIP(hipMemcpyAsync(b->p, src, bytes, hipMemcpyDeviceToDevice, st));
+    LOOP_HIP(hipEventRecord(b->ready, st));
+    { std::lock_guard<std::mutex> lk(h->m); h->box[std::make_pair(ep->rank, peer)].push_back(b); }
+    h->cv.notify_all();
+    return LOOP_OK;
+}
+
+int loop_recv_now(const LoopRecv &r)
+{
+    GsLoopHub *h = r.ep->hub;
+    GsLoopBuf *b = nullptr;
+    {
+        std::unique_lock<std::mutex> lk(h->m);
+        std::deque<GsLoopBuf *> &q = h->box[std::make_pair(r.peer, r.ep->rank)];
+        if (!h->cv.wait_for(lk, std::chrono::seconds(h->timeout_s), [&] { return h->failed || !q.empty(); })) {
+            h->failed = true; h->cv.notify_all();
+            snprintf(tl_loop_err, sizeof tl_loop_err, "recv: rank %d posted nothing for rank %d within %d s", r.peer, r.ep->rank, h->timeout_s);
+            return LOOP_ERR;
+        }
+        if (q.empty()) return loop_fail("recv: another rank of the in-process communicator failed");
+        b = q.front(); q.pop_front();
+    }
+    int rc = LOOP_OK;
+    if (b->bytes != r.bytes) { snprintf(tl_loop_err, sizeof tl_loop_err, "recv: rank %d sent %zu bytes, %zu expected", r.peer, b->bytes, r.bytes); rc = LOOP_ERR; }
+    hipError_t e = hipSuccess;
+    if (rc == LOOP_OK) e = hipStreamWaitEvent(r.st, b->ready, 0);
+    if (rc == LOOP_OK && e == hipSuccess && r.bytes) e = hipMemcpyAsync(r.buf, b->p, r.bytes, hipMemcpyDefault, r.st);
+    if (rc == LOOP_OK && e == hipSuccess) {
+        if (b->done && b->done_dev != r.ep->dev) { (void)hipEventDestroy(b->done); b->done = nullptr; }
+        if (!b->done) { e = hipEventCreateWithFlags(&b->done, hipEventDisableTiming); b->done_dev = r.ep->dev; }
+        if (e == hipSuccess) e = hipEventRecord(b->done, r.st);
+        if (e == hipSuccess) b->done_valid = true;
+    }
+    if (e != hipSuccess) rc = loop_fail("recv", e);
+    { std::lock_guard<std::mutex> lk(h->m); h->pool.push_back(b); if (rc != LOOP_OK) h->failed = true; }
+    if (rc != LOOP_OK) h->cv.notify_all();
+    return rc;
+}
+
+ncclResult_t loop_recv(void *dst, size_t bytes, int, int peer, ncclComm_t comm, hipStream_t st)
+{
+    GsLoopEndpoint *ep = reinterpret_cast<GsLoopEndpoint *>(comm);
+    if (peer < 0 || peer >= ep->hub->world) return loop_fail("recv: peer out of range");
+    const LoopRecv r = { dst, bytes, peer, ep, st };
+    if (tl_loop_group > 0) { tl_loop_recvs.push_back(r); return LOOP_OK; }
+    return loop_recv_now(r);
+}
+
+ncclResult_t loop_group_start() { tl_loop_group++; return LOOP_OK; }
+ncclResult_t loop_group_end()
+{
+    if (tl_loop_group > 0 && --tl_loop_group > 0) return LOOP_OK;
+    int rc = LOOP_OK;
+    for (size_t i = 0; i < tl_loop_recvs.size(); i++) if (rc == LOOP_OK) rc = loop_recv_now(tl_loop_recvs[i]);
+    tl_loop_recvs.clear();
+    return rc;
+}
+const char *loop_error_string(ncclResult_t) { return tl_loop_err; }
+
+ncclResult_t loop_comm_destroy(ncclComm_t comm)
+{
+    GsLoopEndpoint *ep = reinterpret_cast<GsLoopEndpoint *>(comm);
+    GsLoopHub *h = ep->hub;
+    bool last;
+    { std::lock_guard<std::mutex> g(g_loop_m); last = --h->refs == 0; if (last) g_loop_hubs.erase(h->key); }
+    if (last) {                                                    // (every rank has drained its streams: gs_comm_destroy syncs first)
+        for (auto &kv : h->box) for (GsLoopBuf *b : kv.second) loop_free_buf(b);
+        for (GsLoopBuf *b : h->pool) loop_free_buf(b);
+        delete h;
+    }
+    delete ep;
+    return LOOP_OK;
+}
+
+// join (or open) the hub an id names; never blocks: ranks may join in any order, from one thread or many
+int loop_join(gs_ctx *ctx, GsComm *c, const void *id, int rank, int world)
+{
+    const std::string key((const char *)id, GS_COMM_ID_BYTES);
+    GsLoopHub *h = nullptr;
+    {
+        std::lock_guard<std::mutex> g(g_loop_m);
+        auto it = g_loop_hubs.find(key);
+        if (it == g_loop_hubs.end()) {
+            h = new (std::nothrow) GsLoopHub();
+            if (!h) FAILC(GS_E_OOM, "out of host memory");
+            h->world = world; h->key = key;
+            const char *t = getenv("GS_COMM_TIMEOUT_S");
+            if (t && atoi(t) > 0) h->timeout_s = atoi(t);
+            g_loop_hubs[key] = h;
+        } else h = it->second;
+        if (h->world != world) FAILC(GS_E_BADARG, "gs_comm_init: this in-process communicator has %d ranks, not %d", h->world, world);
+        h->refs++;
+    }
+    GsLoopEndpoint *ep = new (std::nothrow) GsLoopEndpoint{ h, rank, ctx->device };
+    if (!ep) {
+        { std::lock_guard<std::mutex> g(g_loop_m); if (--h->refs == 0) { g_loop_hubs.erase(h->key); delete h; } }
+        FAILC(GS_E_OOM, "out of host memory");
+    }
+    // contexts on different GPUs pull each other's mailboxes directly where the platform allows (else the runtime stages the copy)
+    int ndev = 0; (void)hipGetDeviceCount(&ndev);
+    for (int d = 0; d < ndev; d++) if (d != ctx->device) {
+        int can = 0;
+        if (hipDeviceCanAccessPeer(&can, ctx->device, d) == hipSuccess && can) { const hipError_t e = hipDeviceEnablePeerAccess(d, 0); (void)e; (void)hipGetLastError(); }
+    }
+    c->Send = loop_send; c->Recv = loop_recv; c->GroupStart = loop_group_start; c->GroupEnd = loop_group_end;
+    c->GetErrorString = loop_error_string; c->CommDestroy = loop_comm_destroy;
+    c->comm = reinterpret_cast<ncclComm_t>(ep);
+    c->loop = true; c->rank = rank; c->world = world;
+    return GS_OK;
+}
+
+}  // namespace
 
 namespace {
 
@@ -147,23 +358,23 @@ int issue_gather(gs_ctx *L, const GatherJob &j)
     GsComm *c = P->comm;
     const bool is_root = c->rank == j.root;
     int rc = GS_OK;
-    {   // in ticket order, one group at a time
-        std::unique_lock<std::mutex> lk(c->m);
-        c->cv.wait(lk, [&] { return c->next_issue == j.ticket; });
+    {   // in ticket order, one group at a time (the ticket's holder works outside the mutex: the caller's thread takes the next
+        // frames' tickets meanwhile, and an in-process receive may wait for its sender here)
+        { std::unique_lock<std::mutex> lk(c->m); c->cv.wait(lk, [&] { return c->next_issue == j.ticket; }); }
         bool any = false;
         for (size_t i = 0; i < j.pieces.size(); i++) {
             const gs_piece &p = j.pieces[i];
             const bool mine = p.owner == c->rank;
             if ((mine && !is_root) || (is_root && (!mine || c->self_copy))) any = true;
         }
-        if (any) {
+        if (any && c->comm) {
             ncclResult_t r = c->GroupStart();
             for (size_t i = 0; r == 0 && i < j.pieces.size(); i++) {
                 const gs_piece &p = j.pieces[i];
                 const size_t bytes = (size_t)(p.x1 - p.x0) * j.H[p.view] * 4;
                 const bool mine = p.owner == c->rank;
-                // the root's own pieces are rendered where they are assembled from; with self_copy they travel through RCCL
-                // like everybody's (rendered into the second half of the staging buffer, received into the first)
+                // the root's own pieces are rendered where they are assembled from; with self_copy they travel through the
+                // transport like everybody's (rendered into the second half of the staging buffer, received into the first)
                 if (mine && (!is_root || c->self_copy))
                     r = c->Send(L->gstage + (is_root ? L->gstage_cap / 2 : 0) + j.off[i], bytes, gsNcclUint8, j.root, c->comm, L->stream);
                 if (r == 0 && is_root && (!mine || c->self_copy))
@@ -171,11 +382,11 @@ int issue_gather(gs_ctx *L, const GatherJob &j)
             }
             const ncclResult_t r2 = c->GroupEnd();
             if (r != 0 || r2 != 0) {
-                snprintf(GS_ERRBUF(ctx), GS_ERRLEN, "RCCL gather failed: %s", c->GetErrorString(r != 0 ? r : r2));
+                snprintf(GS_ERRBUF(ctx), GS_ERRLEN, "%s gather failed: %s", c->loop ? "in-process" : "RCCL", c->GetErrorString(r != 0 ? r : r2));
                 rc = GS_E_HIP;
             }
         }
-        c->next_issue++;
+        { std::lock_guard<std::mutex> lk(c->m); c->next_issue++; }
         c->cv.notify_all();
     }
     if (rc != GS_OK || !is_root) return rc;
@@ -231,6 +442,11 @@ GS_API int gs_comm_unique_id(gs_ctx *ctx, void *id_out)
 {
     if (!ctx || !id_out) return GS_E_BADARG;
     if (!ctx->comm) { ctx->comm = new (std::nothrow) GsComm(); if (!ctx->comm) FAILC(GS_E_OOM, "out of host memory"); }
+    if (ctx->comm->transport == 1) {                             // in-process: the id only has to be unique in this process
+        memset(id_out, 0, GS_COMM_ID_BYTES);
+        snprintf((char *)id_out, GS_COMM_ID_BYTES, GS_LOOP_MAGIC "%ld-%llu", (long)getpid(), (unsigned long long)g_loop_serial.fetch_add(1));
+        return GS_OK;
+    }
     int rc = load_rccl(ctx, ctx->comm);
     if (rc != GS_OK) return rc;
     GS_HIP(hipSetDevice(ctx->device));
@@ -247,6 +463,8 @@ GS_API int gs_comm_init(gs_ctx *ctx, const void *id, int rank, int world)
     if (!ctx->comm) { ctx->comm = new (std::nothrow) GsComm(); if (!ctx->comm) FAILC(GS_E_OOM, "out of host memory"); }
     GsComm *c = ctx->comm;
     if (c->comm) FAILC(GS_E_STATE, "gs_comm_init: the context already joined a communicator");
+    GS_HIP(hipSetDevice(ctx->device));
+    if (memcmp(id, GS_LOOP_MAGIC, sizeof(GS_LOOP_MAGIC) - 1) == 0) return loop_join(ctx, c, id, rank, world);
     int rc = load_rccl(ctx, c);
     if (rc != GS_OK) return rc;
     GS_HIP(hipSetDevice(ctx->device));
@@ -304,20 +522,24 @@ GS_API int gs_render_gathered(gs_ctx *ctx, const gs_render_params *views, int nv
         int rc = gs_lane_call(ctx, false, [&](gs_ctx *lane) { return ensure_gather_buffers(lane, j, stage_bytes, is_root); });
         if (rc != GS_OK) return rc;
     }
+    // The frame's ticket is taken before anything of it is enqueued, and from here on the gather IS issued whatever happens to
+    // this rank's own renders: the peers' receives (and the tickets behind this one) wait for it.
+    { std::lock_guard<std::mutex> lk(c->m); j.ticket = c->next_ticket++; }
+    int first = GS_OK;
+    char first_err[GS_ERRLEN] = "";
     // this rank's own pieces: ordinary strip renders into their staging slots
-    for (int i = 0; i < np; i++) {
+    for (int i = 0; i < np && first == GS_OK; i++) {
         if (pcs[i].owner != rank) continue;
         gs_render_params p = views[pcs[i].view];
         p.x0 = pcs[i].x0; p.x1 = pcs[i].x1;
         p.flags = (flags & ~(uint32_t)GS_RENDER_ASYNC) | (async ? GS_RENDER_ASYNC : 0u);
         GsFrameUniforms u;
-        int rc = gs_fill_uniforms(ctx, &p, u);
-        if (rc != GS_OK) return rc;
-        rc = gs_render_uniforms(ctx, u, L->gstage + (self ? L->gstage_cap / 2 : 0) + j.off[i], nullptr, 0);
-        if (rc != GS_OK) return rc;
+        first = gs_fill_uniforms(ctx, &p, u);
+        if (first == GS_OK) first = gs_render_uniforms(ctx, u, L->gstage + (self ? L->gstage_cap / 2 : 0) + j.off[i], nullptr, 0);
+        if (first != GS_OK) memcpy(first_err, ctx->err, sizeof first_err);
     }
-    { std::lock_guard<std::mutex> lk(c->m); j.ticket = c->next_ticket++; }
-    int rc = gs_lane_call(ctx, async, [j](gs_ctx *lane) { return issue_gather(lane, j); });
+    int rc = gs_lane_call(ctx, async && first == GS_OK, [j](gs_ctx *lane) { return issue_gather(lane, j); }, /*always=*/true);
+    if (first != GS_OK) { memcpy(ctx->err, first_err, sizeof ctx->err); return first; }
     if (rc == GS_OK && !async) GS_HIP(hipStreamSynchronize(L->stream));   // a synchronous call returns with the frame(s) complete on the root
     return rc;
 }
@@ -374,5 +596,12 @@ int gs_comm_set_self_copy(gs_ctx *ctx, bool on)
 {
     if (!ctx->comm) { ctx->comm = new (std::nothrow) GsComm(); if (!ctx->comm) return GS_E_OOM; }
     ctx->comm->self_copy = on;
+    return GS_OK;
+}
+
+int gs_comm_set_transport(gs_ctx *ctx, int transport)
+{
+    if (!ctx->comm) { ctx->comm = new (std::nothrow) GsComm(); if (!ctx->comm) return GS_E_OOM; }
+    ctx->comm->transport = transport;
     return GS_OK;
 }

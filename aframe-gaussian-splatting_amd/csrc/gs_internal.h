@@ -300,6 +300,7 @@ extern "C" int gs_render_uniforms(gs_ctx *ctx, const GsFrameUniforms &u, void *d
 // ---- gs_comm.hip
 void gs_comm_free_lane(gs_ctx *lane);
 int gs_comm_set_self_copy(gs_ctx *ctx, bool on);
+int gs_comm_set_transport(gs_ctx *ctx, int transport);
 int gs_ensure_pair_capacity(gs_ctx *ctx, size_t pairs);
 int gs_ensure_radix_scratch(gs_ctx *ctx, size_t items);         // histogram / totals scratch for a radix sort of `items` records
 // event k (0..GS_PROF_EVENTS-1) of the current profiling slot, or nullptr when profiling is off

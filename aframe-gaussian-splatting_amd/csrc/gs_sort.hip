@@ -15,8 +15,8 @@ struct SortUniforms {                                            // widened on t
     double view[4]; double cutout[16]; int has_cutout;
     int has_strip;
 };
-// gs_sort_for: rows 0, 1 of gsModelViewMatrix, rows 0, 3 of gsProjectionMatrix, and the strip in pixels
-struct StripUniforms { float mvr0[4], mvr1[4], pr0[4], pr3[4]; float focal, norm_a, half_w, sx0, sx1; };
+// gs_sort_for: rows 0, 1, 2 of gsModelViewMatrix, rows 0, 3 of gsProjectionMatrix, and the strip in pixels
+struct StripUniforms { float mvr0[4], mvr1[4], mvr2[4], pr0[4], pr3[4]; float focal, norm_a, half_w, sx0, sx1; };
 // the depth kernel's chunking is its own (no histogram depends on it)
 #ifndef GS_DEPTH_IPT
 #define GS_DEPTH_IPT 4             // items per thread and pass: 52 vector registers, 8 waves per SIMD (8 items: 92, 5 waves)
@@ -77,8 +77,11 @@ __device__ __forceinline__ void depth_hist_end(const DepthHist &dh, const uint32
 // Conservative by construction, 1 % + 2 pixels of slack on top; NaN anywhere keeps the splat.
 // (fp32 with hardware rcp / sqrt: the test only has to err on the side of keeping, and 3 % + 3 pixels of slack dwarf the
 // rounding; in f64 -- divisions, a square root -- it cost more than the whole depth pass: 92 -> 158 us at 20 M splats.)
-__device__ __forceinline__ bool strip_may_touch(const StripUniforms &s, float x, float y, float z, float camz, float sigma)
+// camz comes from the STRIP's own modelView row 2, not from the sort's view row: the two coincide for a mono frame, but an XR
+// eye is sorted with the head camera's view (index.js:441) and drawn with its own, possibly canted, matrix (index.js:185-187).
+__device__ __forceinline__ bool strip_may_touch(const StripUniforms &s, float x, float y, float z, float sigma)
 {
+    const float camz = fmaf(s.mvr2[2], z, fmaf(s.mvr2[1], y, s.mvr2[0] * x)) + s.mvr2[3];
     const float camx = fmaf(s.mvr0[2], z, fmaf(s.mvr0[1], y, s.mvr0[0] * x)) + s.mvr0[3];
     const float camy = fmaf(s.mvr1[2], z, fmaf(s.mvr1[1], y, s.mvr1[0] * x)) + s.mvr1[3];
     const float cw = fmaf(s.pr3[2], camz, fmaf(s.pr3[1], camy, s.pr3[0] * camx)) + s.pr3[3];
@@ -128,7 +131,7 @@ __device__ __forceinline__ void k_sort_depth_body(const float4 *__restrict__ row
                 const bool keep = gsm::sort_keep(d, m.w, inside);
                 // the bucket scale comes from EVERY splat the reference keeps (index.js:552-553), so a strip's order is the
                 // reference's order restricted to the strip's splats; only those are handed on
-                const bool mine = keep && (!STRIP || strip_may_touch(su, m.x, m.y, m.z, (float)d, sg[r]));
+                const bool mine = keep && (!STRIP || strip_may_touch(su, m.x, m.y, m.z, sg[r]));
                 depth_out[i] = mine ? (float)d : INFINITY;
                 if (mine && dh.fill) atomicAdd(&s_dh[depth_bin((float)d)], 1u);
                 if (keep) {
@@ -200,7 +203,7 @@ __global__ __launch_bounds__(GS_BLOCK) void k_sort_depth_pair(const float4 *__re
                     const double d = gsm::view_depth(U.view, m.x, m.y, m.z);                                               \
                     const bool inside = U.has_cutout ? gsm::in_cutout(U.cutout, m.x, m.y, m.z) : true;                     \
                     const bool keep = gsm::sort_keep(d, m.w, inside);                                                      \
-                    const bool mine = keep && (!STRIP || strip_may_touch(SU, m.x, m.y, m.z, (float)d, sg[r]));            \
+                    const bool mine = keep && (!STRIP || strip_may_touch(SU, m.x, m.y, m.z, sg[r]));            \
                     OUT[i] = mine ? (float)d : INFINITY;                                                                   \
                     if (mine && DH.fill) atomicAdd(&SDH[depth_bin((float)d)], 1u);                                         \
                     if (keep) { const unsigned long long e = gsm::f64_to_ordered(d); MN = e < MN ? e : MN; MX = e > MX ? e : MX; if (mine) CNT++; } \
@@ -477,7 +480,7 @@ static void fill_sort_uniforms(const gs_ctx *ctx, const float view[4], const flo
     memset(&su, 0, sizeof su);
     if (strip && ctx->renderable) {
         const float *m = strip->mv, *p = strip->proj;
-        for (int k = 0; k < 4; k++) { su.mvr0[k] = m[4 * k]; su.mvr1[k] = m[4 * k + 1]; su.pr0[k] = p[4 * k]; su.pr3[k] = p[4 * k + 3]; }
+        for (int k = 0; k < 4; k++) { su.mvr0[k] = m[4 * k]; su.mvr1[k] = m[4 * k + 1]; su.mvr2[k] = m[4 * k + 2]; su.pr0[k] = p[4 * k]; su.pr3[k] = p[4 * k + 3]; }
         // spectral norm of A = mat3(gsModelViewMatrix): power iteration on A^T A (symmetric 3x3), bracketed from above by the
         // Frobenius norm; a rigid pose with uniform scale s gives s
         double ata[3][3], fro = 0.0;

@@ -156,9 +156,10 @@ def cutout_demo_camera(vw=1920, vh=1080, yaw_deg=0.0, capi=None):
                     cutout_world=compose((0.8145, 1.73322, -2.35981), 0.0, (4.17, 2.95, 3.89)), capi=capi)
 
 
-def xr_eye_cameras(yaw_deg=0.0, xr_pixel_ratio=0.5, capi=None):
+def xr_eye_cameras(yaw_deg=0.0, xr_pixel_ratio=0.5, capi=None, cant_deg=0.0):
     """C4: two eyes +-0.032 m on x, asymmetric Quest-3-like frusta, 2064x2208 x xrPixelRatio each; the sort uses
-    the head camera (index.js:441) -- returned as the third element."""
+    the head camera (index.js:441) -- returned as the third element.  cant_deg: each eye turned outward about y by
+    that angle (canted displays: Index, Pimax), so an eye's view direction differs from the head camera's."""
     w, h = int(math.floor(2064 * xr_pixel_ratio)), int(math.floor(2208 * xr_pixel_ratio))
     near, far = 0.005, 10000.0
     obj = compose((0.0, 1.5, -2.0), yaw_deg)
@@ -167,6 +168,6 @@ def xr_eye_cameras(yaw_deg=0.0, xr_pixel_ratio=0.5, capi=None):
         # tan half-angles: outer 54 deg, inner 40 deg, up 44 deg, down 55 deg
         lo, ro = (math.tan(math.radians(54)), math.tan(math.radians(40))) if sx < 0 else (math.tan(math.radians(40)), math.tan(math.radians(54)))
         proj = frustum(-lo * near, ro * near, math.tan(math.radians(44)) * near, -math.tan(math.radians(55)) * near, near, far)
-        eyes.append(uniforms(compose((0.032 * sx, 1.6, 0.0)), obj, proj, w, h, capi=capi))
+        eyes.append(uniforms(compose((0.032 * sx, 1.6, 0.0), -sx * cant_deg), obj, proj, w, h, capi=capi))
     head = uniforms(compose((0.0, 1.6, 0.0)), obj, perspective(80.0, w / h), w, h, capi=capi)
     return eyes[0], eyes[1], head

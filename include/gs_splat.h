@@ -246,6 +246,12 @@ GS_API int gs_gathered_size(gs_ctx *ctx, int view, int *width, int *height);
                                    counting render, round 1, gs_download of the order) sorts again in full by itself.  Sorts that
                                    return the order (out_idx / out_n) are always complete.  0: off; 1 (default): for scenes of
                                    4 M splats and more (below, the sort's passes are launch-bound); 2: always.               */
+#define GS_OPT_COMM_TRANSPORT 12 /* what gs_comm_unique_id makes an id for.  0 (default): RCCL over xGMI, one process per GPU or several contexts
+                                   of one process.  1: the in-process transport -- contexts of ONE process (on different GPUs, or all on
+                                   the same one) exchange their pieces through mailbox buffers and peer copies on their own streams,
+                                   ncclSend / ncclRecv semantics, no RCCL; gs_comm_init with such an id never blocks, so one thread can
+                                   bring all ranks up (gs_create_multi does).  Set it on the context that creates the id; the other
+                                   ranks recognise the id.                                                                      */
 #define GS_OPT_COMM_SELF_COPY 8 /* value != 0: the root sends its own pieces to itself through RCCL too instead of rendering them
                                    in place (exercises send/recv on a single-GPU box; slower) */
 
