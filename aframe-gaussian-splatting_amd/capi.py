@@ -25,13 +25,16 @@ COMM_ID_BYTES = 128
 BUF_CENTER_SCALE, BUF_COV_COLOR, BUF_SORT_ROWS, BUF_SORTED, BUF_PROJECTED, BUF_TILE_COUNT, BUF_TILE_STATS = 0, 1, 2, 3, 4, 5, 6
 
 EXPORTS = [
-    "gs_create", "gs_destroy", "gs_last_error", "gs_version", "gs_clear", "gs_push_splat", "gs_push_matrices", "gs_load_ply",
+    "gs_create", "gs_destroy", "gs_last_error", "gs_version", "gs_device_count", "gs_clear", "gs_push_splat", "gs_push_matrices", "gs_load_ply",
     "gs_ply_to_splat", "gs_ply_to_splat_gpu", "gs_count", "gs_sort", "gs_render", "gs_render_device", "gs_render_stereo", "gs_set_scene", "gs_sync",
     "gs_set_stream", "gs_frame_stream", "gs_frame_lane", "gs_lane_stream", "gs_wait_stream", "gs_stream_wait_frame",
     "gs_model_view_matrix", "gs_projection_matrix", "gs_tick_uniforms", "gs_focal", "gs_scaled_size", "gs_set_option",
     "gs_get_stats", "gs_download",
     "gs_comm_unique_id", "gs_comm_init", "gs_comm_destroy", "gs_partition", "gs_render_gathered", "gs_read_gathered",
     "gs_host_alloc", "gs_host_free", "gs_sort_for", "gs_sort_gathered", "gs_gathered_size",
+    "gs_create_multi", "gs_multi_destroy", "gs_multi_last_error", "gs_multi_devices", "gs_multi_ctx", "gs_multi_clear",
+    "gs_multi_push_splat", "gs_multi_load_ply", "gs_multi_count", "gs_multi_set_option", "gs_multi_sort", "gs_multi_render",
+    "gs_multi_render_device", "gs_multi_read", "gs_multi_sync",
 ]
 
 
@@ -133,6 +136,21 @@ def load(build_if_missing=True):
     L.gs_gathered_size.argtypes = [vp, i32, C.POINTER(i32), C.POINTER(i32)]
     L.gs_host_alloc.argtypes = [sz]; L.gs_host_alloc.restype = C.c_void_p
     L.gs_host_free.argtypes = [vp]; L.gs_host_free.restype = None
+    L.gs_create_multi.argtypes = [C.POINTER(i32), i32, C.POINTER(vp)]
+    L.gs_multi_destroy.argtypes = [vp]
+    L.gs_multi_last_error.argtypes = [vp]; L.gs_multi_last_error.restype = C.c_char_p
+    L.gs_multi_devices.argtypes = [vp]
+    L.gs_multi_ctx.argtypes = [vp, i32]; L.gs_multi_ctx.restype = vp
+    L.gs_multi_clear.argtypes = [vp]
+    L.gs_multi_push_splat.argtypes = [vp, vp, sz]
+    L.gs_multi_load_ply.argtypes = [vp, vp, sz]
+    L.gs_multi_count.argtypes = [vp]; L.gs_multi_count.restype = sz
+    L.gs_multi_set_option.argtypes = [vp, i32, C.c_int64]
+    L.gs_multi_sort.argtypes = [vp, vp, vp, C.POINTER(RenderParams), i32]
+    L.gs_multi_render.argtypes = [vp, C.POINTER(RenderParams), i32, C.POINTER(vp), sz, C.c_uint32]
+    L.gs_multi_render_device.argtypes = [vp, C.POINTER(RenderParams), i32, C.POINTER(vp), C.c_uint32]
+    L.gs_multi_read.argtypes = [vp, i32, vp, sz]
+    L.gs_multi_sync.argtypes = [vp]
     _lib = L
     return L
 
@@ -158,6 +176,10 @@ def host_frame(height, width):
     o = _Owner(); o.p = p
     arr = np.ctypeslib.as_array((C.c_uint8 * n).from_address(p)).reshape(int(height), int(width), 4)
     return arr, o
+
+
+def device_count():
+    return int(load().gs_device_count())
 
 
 def partition(widths, world):
@@ -432,3 +454,96 @@ class Context:
         out = np.zeros((count, width), dtype)
         self._ck(self._L.gs_download(self._h, int(which), _p(out), out.nbytes))
         return out
+
+
+class Multi:
+    """gs_multi: one host process, several GPUs (or several "devices" on one GPU): the single-context calls over all of them."""
+
+    def __init__(self, devices):
+        self._L = load()
+        devs = [int(d) for d in devices]
+        arr = (C.c_int * len(devs))(*devs)
+        h = C.c_void_p()
+        rc = self._L.gs_create_multi(arr, len(devs), C.byref(h))
+        if rc != GS_OK:
+            raise GsError(rc, self._L.gs_multi_last_error(None).decode())
+        self._h = h
+        self.devices = devs
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.gs_multi_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _ck(self, rc):
+        if rc != GS_OK:
+            raise GsError(rc, self._L.gs_multi_last_error(self._h).decode())
+
+    def ctx_stats(self, i):
+        """gs_get_stats of the context on devices[i] (call sync() first)"""
+        s = Stats()
+        h = self._L.gs_multi_ctx(self._h, int(i))
+        rc = self._L.gs_get_stats(h, C.byref(s))
+        if rc != GS_OK:
+            raise GsError(rc, self._L.gs_last_error(h).decode())
+        return s.as_dict()
+
+    def clear(self):
+        self._ck(self._L.gs_multi_clear(self._h))
+
+    def push_splat(self, rows):
+        rows = np.ascontiguousarray(np.asarray(rows).view(np.uint8).reshape(-1))
+        if rows.size % 32:
+            raise ValueError("rows must be a multiple of 32 bytes")
+        self._ck(self._L.gs_multi_push_splat(self._h, _p(rows), rows.size // 32))
+
+    def load_ply(self, ply_bytes):
+        buf = np.frombuffer(bytes(ply_bytes), np.uint8)
+        self._ck(self._L.gs_multi_load_ply(self._h, _p(buf), buf.size))
+
+    def count(self):
+        return self._L.gs_multi_count(self._h)
+
+    def set_option(self, opt, value):
+        self._ck(self._L.gs_multi_set_option(self._h, int(opt), int(value)))
+
+    @staticmethod
+    def _views(views):
+        views = list(views) if isinstance(views, (list, tuple)) else [views]
+        return (RenderParams * len(views))(*views), len(views)
+
+    def sort(self, view, cutout, views):
+        arr, n = self._views(views)
+        view = np.ascontiguousarray(view, np.float32)
+        cut = None if cutout is None else np.ascontiguousarray(cutout, np.float32)
+        self._ck(self._L.gs_multi_sort(self._h, _p(view), _p(cut), arr, n))
+
+    def render(self, views, frames, flags=0):
+        """host-direct: frames = one H x W x 4 uint8 array per view (page-locked: host_frame()); strips are copied into them"""
+        arr, n = self._views(views)
+        frames = list(frames) if isinstance(frames, (list, tuple)) else [frames]
+        ptrs = (C.c_void_p * n)(*[f.ctypes.data for f in frames])
+        self._ck(self._L.gs_multi_render(self._h, arr, n, ptrs, frames[0].strides[0], int(flags)))
+
+    def render_device(self, views, device_frames=None, flags=0):
+        arr, n = self._views(views)
+        ptrs = None
+        if device_frames is not None:
+            ptrs = (C.c_void_p * n)(*[C.c_void_p(int(p)) if p else None for p in device_frames])
+        self._ck(self._L.gs_multi_render_device(self._h, arr, n, ptrs, int(flags)))
+
+    def read(self, view, width, height):
+        out = np.empty((int(height), int(width), 4), np.uint8)
+        self._ck(self._L.gs_multi_read(self._h, int(view), _p(out), 0))
+        return out
+
+    def sync(self):
+        self._ck(self._L.gs_multi_sync(self._h))

@@ -623,7 +623,13 @@ static int lane_rc(gs_ctx *ctx, gs_ctx *L, int rc)
 
 extern "C" {
 
-GS_API uint32_t gs_version(void) { return 0x000300; }
+GS_API uint32_t gs_version(void) { return 0x000400; }
+
+GS_API int gs_device_count(void)
+{
+    int n = 0;
+    return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
+}
 
 GS_API const char *gs_last_error(const gs_ctx *ctx) { return ctx ? ctx->err : g_create_err; }
 

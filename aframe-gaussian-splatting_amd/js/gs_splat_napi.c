@@ -699,6 +699,214 @@ static napi_value fn_scaled_size(napi_env env, napi_callback_info info)
     return arr;
 }
 
+/* ---- one Node.js process, several GPUs (gs_create_multi): the consumer `north_star` names is ONE JavaScript thread ----------
+ * createMulti([dev, ...]) -> handle;  multiPushSplat / multiLoadPly / multiClear / multiCount / multiSetOption;
+ * multiSort(h, view, cutout | null, views);  multiRender(h, views, frames, flags = 0): host-direct -- every GPU copies its
+ * strip straight into the caller's page-locked frame(s) (allocFrame);  multiRenderDevice(h, views, flags) + multiRead(h, view,
+ * frame): gathered on the first device;  multiSync(h);  multiDestroy(h). */
+typedef struct gs_mhandle { gs_multi *m; } gs_mhandle;
+
+static void multi_finalize(napi_env env, void *data, void *hint)
+{
+    (void)env; (void)hint;
+    gs_mhandle *h = (gs_mhandle *)data;
+    if (!h) return;
+    if (h->m) gs_multi_destroy(h->m);
+    free(h);
+}
+
+static napi_value throw_multi(napi_env env, gs_multi *m, int rc)
+{
+    char code[16];
+    const char *msg = gs_multi_last_error(m);
+    snprintf(code, sizeof code, "GS%d", rc);
+    napi_throw_error(env, code, (msg && *msg) ? msg : "gs_splat call failed");
+    return NULL;
+}
+
+static gs_mhandle *get_mhandle(napi_env env, napi_value v, int need_live)
+{
+    void *p = NULL;
+    napi_valuetype t;
+    if (napi_typeof(env, v, &t) != napi_ok || t != napi_external || napi_get_value_external(env, v, &p) != napi_ok || !p) {
+        napi_throw_type_error(env, NULL, "expected a handle returned by createMulti()");
+        return NULL;
+    }
+    if (need_live && !((gs_mhandle *)p)->m) { napi_throw_error(env, "GS_DESTROYED", "the multi-GPU context has been destroyed"); return NULL; }
+    return (gs_mhandle *)p;
+}
+
+static napi_value fn_create_multi(napi_env env, napi_callback_info info)
+{
+    napi_value argv[1];
+    if (!get_args(env, info, 1, argv, NULL)) return NULL;
+    uint32_t n = 0; bool is = false;
+    if (napi_is_array(env, argv[0], &is) != napi_ok || !is || napi_get_array_length(env, argv[0], &n) != napi_ok || n < 1 || n > 64) {
+        napi_throw_type_error(env, NULL, "createMulti: an array of 1..64 device ordinals"); return NULL;
+    }
+    int devs[64];
+    for (uint32_t i = 0; i < n; i++) {
+        napi_value e; int32_t d = 0;
+        if (napi_get_element(env, argv[0], i, &e) != napi_ok || napi_get_value_int32(env, e, &d) != napi_ok) { napi_throw_type_error(env, NULL, "createMulti: device ordinals are integers"); return NULL; }
+        devs[i] = d;
+    }
+    gs_multi *m = NULL;
+    int rc = gs_create_multi(devs, (int)n, &m);
+    if (rc != GS_OK) return throw_multi(env, NULL, rc);
+    gs_mhandle *hd = (gs_mhandle *)calloc(1, sizeof *hd);
+    if (!hd) { gs_multi_destroy(m); napi_throw_error(env, NULL, "out of memory"); return NULL; }
+    hd->m = m;
+    napi_value h;
+    if (napi_create_external(env, hd, multi_finalize, NULL, &h) != napi_ok) { gs_multi_destroy(m); free(hd); napi_throw_error(env, NULL, "napi_create_external"); return NULL; }
+    return h;
+}
+
+static napi_value fn_multi_destroy(napi_env env, napi_callback_info info)
+{
+    napi_value argv[1];
+    if (!get_args(env, info, 1, argv, NULL)) return NULL;
+    gs_mhandle *h = get_mhandle(env, argv[0], 0); if (!h) return NULL;
+    if (h->m) { gs_multi_destroy(h->m); h->m = NULL; }
+    return NULL;
+}
+
+static napi_value multi_push_common(napi_env env, napi_callback_info info, int ply)
+{
+    napi_value argv[3];
+    if (!get_args(env, info, 3, argv, NULL)) return NULL;
+    gs_mhandle *h = get_mhandle(env, argv[0], 1); if (!h) return NULL;
+    void *data; size_t len;
+    if (!get_bytes(env, argv[1], &data, &len)) { napi_throw_type_error(env, NULL, "expected an ArrayBuffer or TypedArray"); return NULL; }
+    size_t n = len / 32;
+    if (!ply && !is_nullish(env, argv[2])) {
+        int64_t want = 0;
+        NAPI_OK(napi_get_value_int64(env, argv[2], &want));
+        if (want < 0) want = 0;
+        if ((size_t)want < n) n = (size_t)want;
+    }
+    int rc = ply ? gs_multi_load_ply(h->m, data, len) : gs_multi_push_splat(h->m, data, n);
+    if (rc != GS_OK) return throw_multi(env, h->m, rc);
+    napi_value r;
+    NAPI_OK(napi_create_double(env, (double)gs_multi_count(h->m), &r));
+    return r;
+}
+static napi_value fn_multi_push_splat(napi_env env, napi_callback_info info) { return multi_push_common(env, info, 0); }
+static napi_value fn_multi_load_ply(napi_env env, napi_callback_info info) { return multi_push_common(env, info, 1); }
+
+static napi_value fn_multi_clear(napi_env env, napi_callback_info info)
+{
+    napi_value argv[1];
+    if (!get_args(env, info, 1, argv, NULL)) return NULL;
+    gs_mhandle *h = get_mhandle(env, argv[0], 1); if (!h) return NULL;
+    int rc = gs_multi_clear(h->m);
+    if (rc != GS_OK) return throw_multi(env, h->m, rc);
+    return NULL;
+}
+
+static napi_value fn_multi_count(napi_env env, napi_callback_info info)
+{
+    napi_value argv[1], r;
+    if (!get_args(env, info, 1, argv, NULL)) return NULL;
+    gs_mhandle *h = get_mhandle(env, argv[0], 1); if (!h) return NULL;
+    NAPI_OK(napi_create_double(env, (double)gs_multi_count(h->m), &r));
+    return r;
+}
+
+static napi_value fn_multi_set_option(napi_env env, napi_callback_info info)
+{
+    napi_value argv[3]; int32_t opt = 0; int64_t val = 0;
+    if (!get_args(env, info, 3, argv, NULL)) return NULL;
+    gs_mhandle *h = get_mhandle(env, argv[0], 1); if (!h) return NULL;
+    NAPI_OK(napi_get_value_int32(env, argv[1], &opt)); NAPI_OK(napi_get_value_int64(env, argv[2], &val));
+    int rc = gs_multi_set_option(h->m, opt, val);
+    if (rc != GS_OK) return throw_multi(env, h->m, rc);
+    return NULL;
+}
+
+static napi_value fn_multi_sort(napi_env env, napi_callback_info info)
+{
+    napi_value argv[4];
+    if (!get_args(env, info, 4, argv, NULL)) return NULL;
+    gs_mhandle *h = get_mhandle(env, argv[0], 1); if (!h) return NULL;
+    float view[4], cut[16]; const float *cutp = NULL;
+    if (!get_sort_args(env, argv[1], argv[2], view, cut, &cutp)) return NULL;
+    gs_render_params views[2]; uint32_t nv = 0;
+    if (!fill_views(env, argv[3], views, &nv)) { napi_throw_type_error(env, NULL, "multiSort: bad view parameters"); return NULL; }
+    int rc = gs_multi_sort(h->m, view, cutp, views, (int)nv);
+    if (rc != GS_OK) return throw_multi(env, h->m, rc);
+    return NULL;
+}
+
+/* multiRender(h, views, frames, flags = 0) -> frames.  frames: one Uint8Array (one view) or an array of them, fb_width x fb_height x 4 each */
+static napi_value fn_multi_render(napi_env env, napi_callback_info info)
+{
+    napi_value argv[4]; uint32_t flags = 0;
+    if (!get_args(env, info, 4, argv, NULL)) return NULL;
+    gs_mhandle *h = get_mhandle(env, argv[0], 1); if (!h) return NULL;
+    gs_render_params views[2]; uint32_t nv = 0;
+    if (!fill_views(env, argv[1], views, &nv)) { napi_throw_type_error(env, NULL, "multiRender: bad view parameters"); return NULL; }
+    if (!is_nullish(env, argv[3])) NAPI_OK(napi_get_value_uint32(env, argv[3], &flags));
+    uint8_t *frames[2] = { NULL, NULL };
+    bool is_arr = false;
+    napi_is_array(env, argv[2], &is_arr);
+    for (uint32_t v = 0; v < nv; v++) {
+        napi_value fv = argv[2];
+        if (is_arr && napi_get_element(env, argv[2], v, &fv) != napi_ok) { napi_throw_type_error(env, NULL, "multiRender: frames"); return NULL; }
+        void *out; size_t len;
+        if ((!is_arr && v > 0) || !get_bytes(env, fv, &out, &len) || len < (size_t)views[v].fb_width * (size_t)views[v].fb_height * 4) {
+            napi_throw_range_error(env, NULL, "multiRender: a frame buffer is missing or too small"); return NULL;
+        }
+        frames[v] = (uint8_t *)out;
+    }
+    int rc = gs_multi_render(h->m, views, (int)nv, frames, 0, flags);
+    if (rc != GS_OK) return throw_multi(env, h->m, rc);
+    return argv[2];
+}
+
+static napi_value fn_multi_render_device(napi_env env, napi_callback_info info)
+{
+    napi_value argv[3]; uint32_t flags = 0;
+    if (!get_args(env, info, 3, argv, NULL)) return NULL;
+    gs_mhandle *h = get_mhandle(env, argv[0], 1); if (!h) return NULL;
+    gs_render_params views[2]; uint32_t nv = 0;
+    if (!fill_views(env, argv[1], views, &nv)) { napi_throw_type_error(env, NULL, "multiRenderDevice: bad view parameters"); return NULL; }
+    if (!is_nullish(env, argv[2])) NAPI_OK(napi_get_value_uint32(env, argv[2], &flags));
+    int rc = gs_multi_render_device(h->m, views, (int)nv, NULL, flags);
+    if (rc != GS_OK) return throw_multi(env, h->m, rc);
+    return NULL;
+}
+
+/* multiRead(h, view, frameUint8Array) -> frame */
+static napi_value fn_multi_read(napi_env env, napi_callback_info info)
+{
+    napi_value argv[3]; int32_t view = 0;
+    if (!get_args(env, info, 3, argv, NULL)) return NULL;
+    gs_mhandle *h = get_mhandle(env, argv[0], 1); if (!h) return NULL;
+    NAPI_OK(napi_get_value_int32(env, argv[1], &view));
+    void *out; size_t len;
+    if (!get_bytes(env, argv[2], &out, &len)) { napi_throw_type_error(env, NULL, "multiRead: frame buffer missing"); return NULL; }
+    int rc = gs_multi_sync(h->m);
+    if (rc != GS_OK) return throw_multi(env, h->m, rc);
+    int w = 0, hh = 0;
+    gs_ctx *root = gs_multi_ctx(h->m, 0);
+    rc = gs_gathered_size(root, view, &w, &hh);
+    if (rc != GS_OK) return throw_gs(env, root, rc);
+    if (len < (size_t)w * (size_t)hh * 4) { napi_throw_range_error(env, NULL, "multiRead: frame buffer too small"); return NULL; }
+    rc = gs_multi_read(h->m, view, (uint8_t *)out, 0);
+    if (rc != GS_OK) return throw_multi(env, h->m, rc);
+    return argv[2];
+}
+
+static napi_value fn_multi_sync(napi_env env, napi_callback_info info)
+{
+    napi_value argv[1];
+    if (!get_args(env, info, 1, argv, NULL)) return NULL;
+    gs_mhandle *h = get_mhandle(env, argv[0], 1); if (!h) return NULL;
+    int rc = gs_multi_sync(h->m);
+    if (rc != GS_OK) return throw_multi(env, h->m, rc);
+    return NULL;
+}
+
 static napi_value fn_destroy(napi_env env, napi_callback_info info)      /* explicit teardown; GC finalizer is the fallback */
 {
     napi_value argv[1];
@@ -722,6 +930,10 @@ static napi_value init(napi_env env, napi_value exports)
         { "sortGathered", fn_sort_gathered }, { "renderGathered", fn_render_gathered }, { "readGathered", fn_read_gathered }, { "setScene", fn_set_scene }, { "stats", fn_stats }, { "setOption", fn_set_option },
         { "modelViewMatrix", fn_model_view }, { "projectionMatrix", fn_projection }, { "tickUniforms", fn_tick },
         { "scaledSize", fn_scaled_size },
+        { "createMulti", fn_create_multi }, { "multiDestroy", fn_multi_destroy }, { "multiPushSplat", fn_multi_push_splat },
+        { "multiLoadPly", fn_multi_load_ply }, { "multiClear", fn_multi_clear }, { "multiCount", fn_multi_count },
+        { "multiSetOption", fn_multi_set_option }, { "multiSort", fn_multi_sort }, { "multiRender", fn_multi_render },
+        { "multiRenderDevice", fn_multi_render_device }, { "multiRead", fn_multi_read }, { "multiSync", fn_multi_sync },
     };
     for (size_t i = 0; i < sizeof fns / sizeof fns[0]; i++) {
         napi_value f;

@@ -161,6 +161,29 @@ comp.loadData(camera, object, null, scenePath, 100003).then((n) => {
     native.renderGathered(comp.handle, p, 0, 0);
     const gathered = native.readGathered(comp.handle, 0, native.allocFrame(Number(W), Number(H)));
     ok(same(gathered, keepImg), 'gathered frame (world 1) == render()');
+    // ONE node process, several GPUs (here: two and three "devices" on the one GPU): createMulti owns the contexts, replicates the
+    // pushes, splits the frame in column strips; host-direct frames land in ONE page-locked buffer, device frames on the first GPU
+    const sceneBytes = fs.readFileSync(scenePath);
+    for (const devs of [[0, 0], [0, 0, 0]]) {
+      const mh = native.createMulti(devs);
+      ok(native.multiPushSplat(mh, sceneBytes.buffer.slice(sceneBytes.byteOffset, sceneBytes.byteOffset + sceneBytes.byteLength)) === n, 'multiPushSplat count');
+      native.multiSort(mh, u.view, u.cutout, p);
+      const mf = native.multiRender(mh, p, native.allocFrame(Number(W), Number(H)), 0);
+      ok(same(mf, keepImg), 'one process, ' + devs.length + ' devices: host-direct frame == render()');
+      const ring = [0, 1, 2, 3].map(() => native.allocFrame(Number(W), Number(H)));
+      for (let attempt = 0; attempt < 4; attempt++) {
+        for (const f of ring) { native.multiSort(mh, u.view, u.cutout, p); native.multiRender(mh, p, f, 8 /* GS_RENDER_ASYNC */); }
+        try { native.multiSync(mh); break; } catch (e) { if (e.code !== 'GS-9' || attempt === 3) throw e; }
+      }
+      ok(ring.every((f) => same(f, keepImg)), 'queued host-direct frames == render()');
+      native.multiSort(mh, u.view, u.cutout, p);
+      native.multiRenderDevice(mh, p, 0);
+      ok(same(native.multiRead(mh, 0, native.allocFrame(Number(W), Number(H))), keepImg), 'device frame gathered on the first device == render()');
+      native.multiDestroy(mh);
+      let dead = false;
+      try { native.multiSync(mh); } catch (e) { dead = e.code === 'GS_DESTROYED'; }
+      ok(dead, 'multiDestroy');
+    }
     comp.remove();
     let gone = false;
     try { comp.tick(); } catch (e) { gone = e.code === 'GS_DESTROYED'; }

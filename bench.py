@@ -44,7 +44,12 @@ def main():
     ap.add_argument("--cutout", action="store_true", help="cutout-demo.html pose with the cutoutEntity box (config C3)")
     ap.add_argument("--xr", action="store_true", help="config C4: XR stereo 2 x (2064x2208 x xrPixelRatio 0.5), one shared head-camera sort, "
                                                     "the eyes divided between the GPUs (eye k -> GPU k at --gpus 2)")
+    ap.add_argument("--single-process", action="store_true", help="ONE host process drives all --gpus devices (gs_create_multi; the Node.js "
+                                                                "consumer's form) instead of one process per GPU; device frames gathered on the first GPU")
+    ap.add_argument("--host-direct", action="store_true", help="with --single-process: every GPU copies its strip straight into one page-locked host frame")
     args = ap.parse_args()
+    if args.single_process:
+        return single_process_main(args)
     # stdout carries exactly ONE JSON line: whatever native libraries (RCCL's version banner, HIP warnings) write to file
     # descriptor 1 during the run goes to stderr instead; the line is written to the real stdout at the end
     sys.stdout.flush()
@@ -383,6 +388,109 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def single_process_main(args):
+    """python bench.py --gpus N --single-process [--host-direct]: the same frames from ONE host process (gs_create_multi).  Devices
+    0..N-1, wrapped onto the GPUs present (GS_BENCH_DEVICES=0,0,... overrides): on a one-GPU box N "devices" share the GPU, which
+    exercises the path but measures nothing about scaling.  `value` = frames/s of the whole job between two gs_multi_sync calls."""
+    global W, H
+    if args.size:
+        W, H = (int(v) for v in args.size.lower().split("x"))
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+    capi = importlib.import_module(PKG + ".capi")
+    synth = importlib.import_module(PKG + ".synth")
+    ndev = max(1, capi.device_count())
+    devs = [int(v) for v in os.environ["GS_BENCH_DEVICES"].split(",")] if os.environ.get("GS_BENCH_DEVICES") else [i % ndev for i in range(args.gpus)]
+    n_splats = args.splats or synth.N_TRAIN
+    rows = synth.make_splat_rows_fast(n_splats) if n_splats >= (8 << 20) else synth.make_splat_rows(n_splats)
+    pose = synth.cutout_demo_camera if args.cutout else synth.index_html_camera
+    if args.xr:
+        rigs = [synth.xr_eye_cameras(360.0 * i / ORBIT_FRAMES, 0.5, capi=capi) for i in range(ORBIT_FRAMES)]
+        W, H = rigs[0][0]["vw"], rigs[0][0]["vh"]
+        cams = [r[2] for r in rigs]
+        views = [[capi.make_params(e["gs_mv"], e["gs_proj"], W, H, focal_=e["focal"]) for e in r[:2]] for r in rigs]
+    else:
+        cams = [pose(W, H, 360.0 * i / ORBIT_FRAMES, capi=capi) for i in range(ORBIT_FRAMES)]
+        views = [[capi.make_params(c["gs_mv"], c["gs_proj"], W, H, focal_=c["focal"])] for c in cams]
+    nv = len(views[0])
+    NB = 12                                                  # frame buffers in rotation (a multiple of the 3 lanes x 2 frames per launch in flight)
+    ring = [[capi.host_frame(H, W) for _ in range(nv)] for _ in range(NB)] if args.host_direct else None
+    with capi.Multi(devs) as m:
+        r32 = rows.reshape(-1, 32)
+        for o in range(0, n_splats, 1 << 22):
+            m.push_splat(r32[o:o + (1 << 22)])
+        m.set_option(capi.OPT_FRAME_BATCH, int(os.environ.get("GS_BENCH_BATCH", "2")))
+
+        def frame(i, flags):
+            k = i % ORBIT_FRAMES
+            m.sort(cams[k]["view"], cams[k]["cutout"], views[k])
+            if ring:
+                m.render(views[k], [f[0] for f in ring[i % NB]], flags)
+            else:
+                m.render_device(views[k], None, flags)
+
+        def sync():
+            try:
+                m.sync()
+                return False
+            except capi.GsError as e:
+                if e.code != capi.E_RETRY:
+                    raise
+                return True
+
+        used = sorted(set((args.warmup + i) % ORBIT_FRAMES for i in range(args.steps)))
+        pre = 0
+        while pre < 96:                                      # untimed: the first-round share settles for every pose (as the per-process bench)
+            for k in used:
+                frame(k, 0); pre += 1
+        for i in range(max(args.warmup, NB)):
+            frame(i, capi.RENDER_ASYNC)
+        sync()
+        retries = 0
+        for attempt in range(4):
+            sync()
+            t0 = time.perf_counter()
+            for i in range(args.steps):
+                frame(args.warmup + i, capi.RENDER_ASYNC)
+            again = sync()
+            elapsed = time.perf_counter() - t0
+            if not again:
+                break
+            retries += 1
+            for k in used:
+                frame(k, 0)
+        # the last pose once more, synchronously, against one context's own full frame
+        k_last = (args.warmup + args.steps - 1) % ORBIT_FRAMES
+        frame(args.warmup + args.steps - 1, 0)
+        got = [ring[(args.warmup + args.steps - 1) % NB][v][0].copy() for v in range(nv)] if ring else [m.read(v, W, H) for v in range(nv)]
+        m.sync()
+        with capi.Context(devs[0]) as c:
+            for o in range(0, n_splats, 1 << 22):
+                c.push_splat(r32[o:o + (1 << 22)])
+            c.sort(cams[k_last]["view"], cams[k_last]["cutout"], want_indices=False)
+            ok = all(bool(np.array_equal(got[v], c.render(views[k_last][v]))) for v in range(nv))
+        s0 = m.ctx_stats(0)
+    fps = args.steps / elapsed
+    out = {"metric": "frames/sec @%dx%d (sort+project+bin+blend per frame, %d-splat train.splat-shaped scene)" % (W, H, n_splats),
+           "value": round(fps, 3), "unit": "frames/s", "n_gpus": len(devs), "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+           "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "train.splat-shaped synthetic, N=%d splats, %s%dx%d, 120-frame orbit" % (n_splats, "XR stereo 2 x " if args.xr else "", W, H),
+                      "parallelism": "ONE host process, devices %s (gs_create_multi: %s), splat buffer replicated, %s" % (
+                          devs, "XR eyes over the devices" if args.xr else "column strips",
+                          "every device copies its strip straight into one page-locked host frame (no collective)" if ring else
+                          "pieces gathered in HBM on the first device by the in-process transport (peer copies on the frames' streams)"),
+                      "distinct_gpus": len(set(devs)), "frame_equals_single_context_render": ok, "timed_region_retries": retries,
+                      "frames_in_flight": "3 lanes x 2 frames per launch per device"},
+           "host_frame_GBps": round(fps * W * H * 4 * nv / 1e9, 2) if ring else None,
+           "occlusion_binning": {"near_permille": s0["near_permille"]}}
+    os.write(real_stdout, (json.dumps(out) + "\n").encode())
+    for fr in (ring or []):
+        for _, o in fr:
+            o.free()
 
 
 # VALU issue model of the blend (tools/micro/valu_rate.hip on gfx950: cycles per wave-instruction at full occupancy) and its

@@ -53,6 +53,8 @@ GS_API int gs_destroy(gs_ctx *ctx);
 GS_API const char *gs_last_error(const gs_ctx *ctx);
 /* Library/ABI version, e.g. 0x000100 = 0.1.0 */
 GS_API uint32_t gs_version(void);
+/* HIP devices this process can use (0 = none: gs_create will fail) -- what a host would pass to gs_create_multi */
+GS_API int gs_device_count(void);
 
 /* ---- data ingest (reference: worker `clear`/`push`, pushDataBuffer, processPlyBuffer) --------------- */
 
@@ -220,6 +222,42 @@ GS_API int gs_sort_gathered(gs_ctx *ctx, const float view[4], const float *cutou
 GS_API int gs_read_gathered(gs_ctx *ctx, int view, uint8_t *rgba_out, size_t stride);
 /* ... and its size in pixels (so that a binding can check the caller's buffer before the copy) */
 GS_API int gs_gathered_size(gs_ctx *ctx, int view, int *width, int *height);
+/* ---- one host process, several GPUs (the reference is one JavaScript thread per page, index.js:1-23, with
+ * several component instances allowed, cutout-demo.html:24-25 -- a Node.js consumer cannot be one process per GPU) ----------
+ * A gs_multi owns one context per entry of `devices` (an ordinal may repeat: several "devices" on one GPU, which is how the
+ * single-GPU test tier runs it), keeps the splat buffer replicated on them and splits every frame as gs_partition says: column
+ * strips of one view, or the two XR eyes over the devices.  The calls have the single-context meaning and signatures; each
+ * context is fed by its own thread, so an asynchronous frame costs the caller the same whatever the number of GPUs.
+ * The communicator between the contexts is the in-process transport (GS_OPT_COMM_TRANSPORT = 1), set up by gs_create_multi. */
+typedef struct gs_multi gs_multi;
+GS_API int gs_create_multi(const int *devices, int ndev, gs_multi **out);
+GS_API int gs_multi_destroy(gs_multi *m);
+GS_API const char *gs_multi_last_error(const gs_multi *m);   /* m == NULL: the last gs_create_multi failure of the calling thread */
+GS_API int gs_multi_devices(const gs_multi *m);
+/* the context on devices[i] (statistics, downloads, per-context options); only between gs_multi_sync() and the next frame */
+GS_API gs_ctx *gs_multi_ctx(gs_multi *m, int i);
+GS_API int gs_multi_clear(gs_multi *m);                                              /* gs_clear on every device          */
+GS_API int gs_multi_push_splat(gs_multi *m, const void *rows, size_t nrows);         /* gs_push_splat, uploads in parallel */
+GS_API int gs_multi_load_ply(gs_multi *m, const void *bytes, size_t nbytes);
+GS_API size_t gs_multi_count(const gs_multi *m);
+GS_API int gs_multi_set_option(gs_multi *m, int option, int64_t value);              /* gs_set_option on every device     */
+/* tick + worker sort for the frame `views` describe (one view, or the two XR eyes with the head camera's view row, index.js:441):
+ * every device sorts what its own piece of the frame needs (gs_sort_gathered).  Asynchronous: failures surface at the next
+ * synchronous render or gs_multi_sync(). */
+GS_API int gs_multi_sort(gs_multi *m, const float view[4], const float *cutout16, const gs_render_params *views, int nviews);
+/* HOST-DIRECT frame: host_frames[v] is the caller's fb_width x fb_height RGBA8 image (`stride` bytes per row, 0 = tight; page-
+ * locked memory from gs_host_alloc lets the copies overlap the next frames); every device copies its strip straight into its
+ * columns behind its kernels -- no collective, no staging, no assembly.  Without GS_RENDER_ASYNC the call returns with the frame
+ * complete (and has drawn it again by itself if a device reported GS_E_RETRY); with it, completion and status come from
+ * gs_multi_sync(), one frame buffer per frame in flight. */
+GS_API int gs_multi_render(gs_multi *m, const gs_render_params *views, int nviews, uint8_t *const *host_frames, size_t stride, uint32_t flags);
+/* DEVICE frame: gathered on devices[0] through the in-process transport (peer copies on the frames' own streams) into
+ * device_frames[v] (memory of devices[0]) or, if NULL, into buffers read with gs_multi_read(). */
+GS_API int gs_multi_render_device(gs_multi *m, const gs_render_params *views, int nviews, void *const *device_frames, uint32_t flags);
+GS_API int gs_multi_read(gs_multi *m, int view, uint8_t *rgba_out, size_t stride);
+/* gs_sync on every device: GS_E_RETRY if any asynchronous frame since the last sync has to be drawn again */
+GS_API int gs_multi_sync(gs_multi *m);
+
 #define GS_OPT_BLEND_SPLIT 9    /* 0 (default): one wavefront blends each tile, 4 pixels per lane.  L > 0: tiles whose list has at least
                                    L entries (try 512) are blended by FOUR wavefronts, one pixel per lane -- for frames in which few
                                    tiles carry long lists (a cut-out scene: the kernel otherwise lasts as long as ONE wavefront's

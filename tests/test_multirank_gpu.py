@@ -296,3 +296,86 @@ def test_a_rank_that_never_sends_fails_the_frame_instead_of_hanging(rows_small, 
         assert ei.value.code == capi.E_HIP and "posted nothing" in ei.value.message
     finally:
         a.close(); b.close()
+
+
+# ---------------------------------------------------------------- one host process, several "devices" (gs_create_multi)
+
+@pytest.mark.parametrize("ndev", [1, 2, 3, 8])
+def test_multi_one_process_drives_all_devices(rows_small, ndev):
+    """gs_create_multi over `ndev` contexts on the one GPU, ONE caller thread: host-direct frames (every context copies its strip
+    into the caller's page-locked image), device frames gathered on devices[0] through the in-process transport, synchronous
+    and pipelined, mono and XR -- all bit-identical to one context's gs_render"""
+    w, h = 640, 360
+    cams = [synth.index_html_camera(w, h, y, capi=capi) for y in (0.0, 90.0, 180.0, 270.0)]
+    want = [f[0] for f in _single_frames(rows_small, cams, lambda cam: [_params(cam)])]
+    l, r, head = synth.xr_eye_cameras(40.0, 0.25, capi=capi)
+    with capi.Context(0) as c:
+        c.push_splat(rows_small)
+        c.sort(head["view"]); wl, wr = c.render_stereo(_params(l), _params(r))
+    frames = [capi.host_frame(h, w) for _ in cams]
+    with capi.Multi([0] * ndev) as m:
+        assert m.count() == 0
+        half = (rows_small.size // 64) * 32
+        m.push_splat(rows_small[:half]); m.push_splat(rows_small[half:])     # progressive ingest (index.js:279-298)
+        assert m.count() == rows_small.size // 32
+        # synchronous host-direct frames
+        for cam, (fr, _), wnt in zip(cams, frames, want):
+            fr[:] = 0
+            m.sort(cam["view"], None, _params(cam))
+            m.render(_params(cam), fr)
+            assert np.array_equal(fr, wnt)
+        # flipped rows
+        m.sort(cams[1]["view"], None, _params(cams[1]))
+        m.render(_params(cams[1], flags=capi.RENDER_FLIP_Y), frames[1][0], flags=capi.RENDER_FLIP_Y)
+        assert np.array_equal(frames[1][0], want[1][::-1])
+        # asynchronous host-direct frames: four in flight, paired on the lanes
+        m.set_option(capi.OPT_FRAME_BATCH, 2)
+        for attempt in range(6):
+            for fr, _ in frames:
+                fr[:] = 0
+            for rep in range(3):
+                for cam, (fr, _) in zip(cams, frames):
+                    m.sort(cam["view"], None, _params(cam))
+                    m.render(_params(cam), fr, flags=capi.RENDER_ASYNC)
+            try:
+                m.sync()
+                break
+            except capi.GsError as e:
+                assert e.code == capi.E_RETRY and attempt < 5
+        for (fr, _), wnt in zip(frames, want):
+            assert np.array_equal(fr, wnt)
+        # device frames, gathered on devices[0]
+        m.sort(cams[2]["view"], None, _params(cams[2]))
+        m.render_device(_params(cams[2]))
+        assert np.array_equal(m.read(0, w, h), want[2])
+        # XR: two eyes, the head camera's sort, eye k on device k from two devices on
+        el, er = capi.host_frame(l["vh"], l["vw"]), capi.host_frame(r["vh"], r["vw"])
+        m.sort(head["view"], None, [_params(l), _params(r)])
+        m.render([_params(l), _params(r)], [el[0], er[0]])
+        assert np.array_equal(el[0], wl) and np.array_equal(er[0], wr)
+        m.sort(head["view"], None, [_params(l), _params(r)])
+        m.render_device([_params(l), _params(r)])
+        assert np.array_equal(m.read(0, l["vw"], l["vh"]), wl) and np.array_equal(m.read(1, r["vw"], r["vh"]), wr)
+        m.sync()
+        st = [m.ctx_stats(i) for i in range(ndev)]
+        assert all(s["n_splats"] == rows_small.size // 32 for s in st)
+        el[1].free(); er[1].free()
+    for _, o in frames:
+        o.free()
+
+
+def test_multi_rejects_bad_arguments():
+    with pytest.raises(capi.GsError):
+        capi.Multi([])
+    with pytest.raises(capi.GsError):
+        capi.Multi([99])
+    cam = synth.index_html_camera(64, 64, 0.0, capi=capi)
+    with capi.Multi([0, 0]) as m:
+        fr = np.zeros((64, 64, 4), np.uint8)
+        with pytest.raises(capi.GsError):
+            m.render([_params(cam)] * 3, [fr] * 3)
+        with pytest.raises(capi.GsError):
+            m.render(_params(cam), fr, flags=capi.RENDER_COUNT_FRAGS)
+        m.sort(cam["view"], None, _params(cam))                 # nothing pushed: every context answers like the reference's empty worker
+        m.render(_params(cam), fr)
+        assert (fr[..., :3] == 0).all() and (fr[..., 3] == 255).all()
