@@ -20,6 +20,8 @@ OPT_BLEND_SPLIT = 9
 OPT_FRAME_BATCH = 10
 OPT_SORT_NEAR = 11
 OPT_COMM_TRANSPORT = 12
+OPT_AUTO_RETRY = 13
+OPT_HOST_WRITE = 14
 TRANSPORT_RCCL, TRANSPORT_INPROC = 0, 1
 COMM_ID_BYTES = 128
 BUF_CENTER_SCALE, BUF_COV_COLOR, BUF_SORT_ROWS, BUF_SORTED, BUF_PROJECTED, BUF_TILE_COUNT, BUF_TILE_STATS = 0, 1, 2, 3, 4, 5, 6
@@ -54,7 +56,7 @@ class Stats(C.Structure):
                 ("prof_frames", C.c_uint32), ("sum_ms_sort", C.c_float), ("sum_ms_project", C.c_float), ("sum_ms_bin", C.c_float),
                 ("sum_ms_blend", C.c_float), ("acc_frames", C.c_uint64), ("acc_sorted", C.c_uint64), ("acc_visible", C.c_uint64),
                 ("acc_pairs", C.c_uint64), ("unsat_tiles", C.c_uint32), ("near_permille", C.c_uint32),
-                ("sort_records", C.c_uint32), ("reserved0", C.c_uint32)]
+                ("sort_records", C.c_uint32), ("retried_frames", C.c_uint32)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

@@ -9,6 +9,7 @@
 #include <mutex>
 #include <new>
 #include <thread>
+#include <set>
 #include <vector>
 #include "gs_internal.h"
 #include "gs_ply.h"
@@ -33,6 +34,56 @@ template <typename T> static int dev_alloc(gs_ctx *ctx, T **p, size_t count)
 }
 template <typename T> static void dev_free(T *&p) { if (p) { (void)hipFree(p); p = nullptr; } }
 #define TRY(x) do { int _rc = (x); if (_rc != GS_OK) return _rc; } while (0)
+
+// ---- transparent re-rendering (GS_OPT_AUTO_RETRY).  An asynchronous frame can come back incomplete: it skipped its second
+// binning round and a tile had not saturated, or it outgrew the pair buffers.  The lane's control block says so at gs_sync() --
+// per lane, not per frame -- so every lane keeps a log of what it was asked since the last gs_sync(): the sort's arguments and
+// the renders that followed (uniforms, output pointers).  gs_sync() then draws the logged frames of a flagged lane (and of the
+// lane / twin that shares its stream) again, synchronously, both rounds, into the same buffers.  Written and read on the caller's
+// thread only.  Not decided here: gathered frames (the other ranks have to take part), frames sharing an output buffer with
+// another logged frame (drawing the older one again would overwrite the newer), data or scene changed meanwhile.
+struct GsFrameRec {
+    float view[4], cutout[16]; bool has_cutout, has_strip; GsSortStrip strip;
+    int nrender; bool undecidable;
+    struct { GsFrameUniforms u; void *dev; uint8_t *host; size_t stride; } r[2];
+};
+struct GsFrameLog { std::vector<GsFrameRec> recs; bool open = false; };
+#define GS_LOG_MAX 4096
+
+static GsFrameRec *log_open_rec(gs_ctx *L) { return (L->log && L->log->open && !L->log->recs.empty()) ? &L->log->recs.back() : nullptr; }
+static void log_sort(gs_ctx *L, const float view[4], const float *cutout16, const GsSortStrip *strip)
+{
+    if (!gs_root(L)->auto_retry) return;
+    if (!L->log) { L->log = new (std::nothrow) GsFrameLog(); if (!L->log) return; }
+    GsFrameLog *g = L->log;
+    if (g->open && !g->recs.empty() && g->recs.back().nrender == 0) g->recs.pop_back();   // a sort nothing was drawn from
+    if (g->recs.size() >= GS_LOG_MAX) { g->recs.back().undecidable = true; g->open = true; return; }   // (a caller that never syncs)
+    GsFrameRec r;
+    memcpy(r.view, view, sizeof r.view);
+    r.has_cutout = cutout16 != nullptr;
+    if (cutout16) memcpy(r.cutout, cutout16, sizeof r.cutout);
+    r.has_strip = strip != nullptr;
+    if (strip) r.strip = *strip;
+    r.nrender = 0; r.undecidable = false;
+    try { g->recs.push_back(r); g->open = true; } catch (...) { g->open = false; }
+}
+static void log_render(gs_ctx *L, const GsFrameUniforms &u, void *dev, uint8_t *host, size_t stride)
+{
+    GsFrameRec *r = log_open_rec(L);
+    if (!r) return;
+    if (r->nrender >= 2) { r->undecidable = true; return; }
+    r->r[r->nrender].u = u; r->r[r->nrender].dev = dev; r->r[r->nrender].host = host; r->r[r->nrender].stride = stride;
+    r->nrender++;
+}
+static void log_undecidable(gs_ctx *L) { GsFrameRec *r = log_open_rec(L); if (r) r->undecidable = true; }
+// after gs_sync: only the open frame stays (renders may still follow its sort), with nothing drawn
+static void log_reset(gs_ctx *L)
+{
+    if (!L->log) return;
+    GsFrameLog *g = L->log;
+    if (g->open && !g->recs.empty()) { GsFrameRec last = g->recs.back(); last.nrender = 0; last.undecidable = false; g->recs.clear(); g->recs.push_back(last); }
+    else g->recs.clear();
+}
 
 static int lane_drain(gs_ctx *L, bool flush = false);
 static void lane_stop_worker(gs_ctx *L);
@@ -77,6 +128,10 @@ static int drain_all(gs_ctx *ctx)
 {
     gs_ctx *P = gs_root(ctx);
     int first = GS_OK;
+    // what follows may change what the frames in the logs were drawn from (more splats, another scene image, other options):
+    // gs_sync() will not draw such frames again by itself
+    for (int i = 0; i < GS_MAX_LANES; i++)
+        if (P->lanes[i] && P->lanes[i]->log) for (const GsFrameRec &r : P->lanes[i]->log->recs) if (r.nrender) P->log_stale = true;
     for (int i = 0; i < GS_MAX_LANES; i++) {
         gs_ctx *L = P->lanes[i];
         if (!L) continue;
@@ -505,6 +560,7 @@ static void free_frame_resources(gs_ctx *c)
 {
     if (c->exec == c || !c->exec) lane_stop_worker(c);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    delete c->log; c->log = nullptr;
     dev_free(c->depth); dev_free(c->key_a); dev_free(c->kv_b); dev_free(c->val_a);
     dev_free(c->hist); dev_free(c->radix_aux); dev_free(c->spine);
     dev_free(c->proj); dev_free(c->rect); dev_free(c->tile_count); dev_free(c->zwin);
@@ -652,7 +708,7 @@ GS_API int gs_create(int device, gs_ctx **out)
     if (!ctx) { snprintf(g_create_err, sizeof g_create_err, "out of host memory"); return GS_E_OOM; }
     memset(ctx, 0, sizeof *ctx);
     ctx->device = device; ctx->renderable = true; ctx->t_eps = 1.0f / 1024.0f; ctx->near_frac = 0.25f;
-    ctx->lanes[0] = ctx; ctx->pipe_depth = 3; ctx->enqueue_threads = true; ctx->frame_batch = 1; ctx->exec = ctx; ctx->sort_near_opt = 1;
+    ctx->lanes[0] = ctx; ctx->pipe_depth = 3; ctx->enqueue_threads = true; ctx->frame_batch = 1; ctx->exec = ctx; ctx->sort_near_opt = 1; ctx->auto_retry = true;
 #define CREATE_HIP(call) do { hipError_t _e = (call); if (_e != hipSuccess) {                                              \
         snprintf(g_create_err, sizeof g_create_err, "%s failed: %s", #call, hipGetErrorString(_e)); gs_destroy(ctx);      \
         return GS_E_HIP; } } while (0)
@@ -849,6 +905,7 @@ static int sort_common(gs_ctx *ctx, const float view[4], const float *cutout16, 
         if (out_idx) out_idx[0] = 0;
         if (out_n) *out_n = 1;
         ctx->lanes[ctx->cur]->have_sort = false; ctx->lanes[ctx->cur]->stats.n_sorted = 0;
+        if (ctx->lanes[ctx->cur]->log) ctx->lanes[ctx->cur]->log->open = false;
         return GS_OK;
     }
     GS_HIP(hipSetDevice(ctx->device));
@@ -859,6 +916,7 @@ static int sort_common(gs_ctx *ctx, const float view[4], const float *cutout16, 
     TRY(get_lane(ctx, lane, &L));
     if (solo && ctx->frame_batch == 2 && lane < GS_MAX_PRIMARY) { gs_ctx *T = nullptr; TRY(get_lane(ctx, lane + GS_MAX_PRIMARY, &T)); }   // (the second view's scratch)
     ctx->cur = lane; ctx->rot = rot; ctx->cur_async = false;
+    log_sort(L, view, cutout16, strip);
     const uint32_t near_req = (out_idx || out_n) ? 0u : sort_near_request(ctx);     // (the caller wants the order itself: all of it)
     if (ctx->enqueue_threads && gs_rotates(ctx) && !ctx->user_stream && !out_idx && !out_n) {
         // nothing to hand back: the lane's worker thread does the launching (a failure surfaces at gs_sync())
@@ -894,6 +952,7 @@ int gs_fill_uniforms(gs_ctx *ctx /* owner: options, adaptive share, scene */, co
     if (p->x0 < 0 || p->x1 > p->fb_width || p->x0 >= p->x1) FAIL(GS_E_BADARG, "bad strip [%d,%d) for width %d", p->x0, p->x1, p->fb_width);
     memcpy(u.mv, p->model_view, sizeof u.mv); memcpy(u.proj, p->projection, sizeof u.proj);
     u.W = p->fb_width; u.H = p->fb_height; u.x0 = p->x0; u.x1 = p->x1;
+    u.out_pitch = p->x1 - p->x0;
     u.x1b = p->x0 + ((p->x1 - p->x0 + 3) & ~3);
     if (u.x1b > p->fb_width) u.x1b = p->fb_width;
     u.vw = (float)p->fb_width; u.vh = (float)p->fb_height;
@@ -984,7 +1043,10 @@ static int render_sync_on_lane(gs_ctx *ctx, const GsFrameUniforms &u, void *devi
         const uint8_t *src = device_rgba ? (const uint8_t *)device_rgba : ctx->fb;
         if (!stride) stride = sw * 4;
         if (stride < sw * 4) FAIL(GS_E_BADARG, "stride %zu smaller than a row (%zu bytes)", stride, sw * 4);
-        GS_HIP(hipMemcpy2D(host_rgba, stride, src, sw * 4, sw * 4, (size_t)u.H, hipMemcpyDeviceToHost));
+        // (a tight frame is ONE linear copy: the 2-D form goes through a slower path of the runtime even when pitch == width)
+        if (stride == sw * 4) GS_HIP(hipMemcpyAsync(host_rgba, src, sw * 4 * (size_t)u.H, hipMemcpyDeviceToHost, ctx->stream));
+        else GS_HIP(hipMemcpy2DAsync(host_rgba, stride, src, sw * 4, sw * 4, (size_t)u.H, hipMemcpyDeviceToHost, ctx->stream));
+        GS_HIP(hipStreamSynchronize(ctx->stream));
     }
     return GS_OK;
 }
@@ -996,6 +1058,7 @@ static int render_sync_on_lane(gs_ctx *ctx, const GsFrameUniforms &u, void *devi
 int gs_lane_call(gs_ctx *ctx, bool async, std::function<int(gs_ctx *)> call, bool always)
 {
     gs_ctx *L = ctx->lanes[ctx->cur];
+    if (always) log_undecidable(L);                                // (a frame's gather: every rank would have to draw it again)
     if (async && ctx->enqueue_threads && gs_rotates(ctx) && !ctx->user_stream) {
         GsLaneCmd c;
         c.type = 2; c.has_cutout = false; c.has_strip = false; c.device_rgba = nullptr; c.host_rgba = nullptr; c.stride = 0; c.call = call;
@@ -1016,15 +1079,41 @@ static int render_common(gs_ctx *ctx, const gs_render_params *p, void *device_rg
     return gs_render_uniforms(ctx, u, device_rgba, host_rgba, stride);
 }
 
-int gs_render_uniforms(gs_ctx *ctx, const GsFrameUniforms &u, void *device_rgba, uint8_t *host_rgba, size_t stride)
+// GS_OPT_HOST_WRITE: a page-locked host frame the GPU can address (gs_host_alloc, hipHostMalloc, a registered buffer) is written
+// by the blend kernel itself, 16 bytes per lane as its tile finishes -- the frame's way over PCIe then runs under the blending
+// of the other tiles instead of behind the last kernel, and there is no copy to wait for.  Returns the device-side address of
+// host_rgba, or nullptr when the frame has to be copied (pageable memory, odd alignment, option off).
+static void *host_frame_device_address(gs_ctx *ctx, const GsFrameUniforms &u, uint8_t *host_rgba, size_t stride, bool async)
+{
+    const int mode = ctx->host_write;
+    if (!host_rgba || mode == 0 || (mode == 2 && async)) return nullptr;
+    if (u.flags & GS_RENDER_COUNT_FRAGS) return nullptr;
+    if ((stride & 15) || ((uintptr_t)host_rgba & 15)) return nullptr;
+    hipPointerAttribute_t a;
+    memset(&a, 0, sizeof a);
+    if (hipPointerGetAttributes(&a, host_rgba) != hipSuccess) { (void)hipGetLastError(); return nullptr; }   // (pageable memory: not an error)
+    if (a.type != hipMemoryTypeHost || !a.devicePointer) return nullptr;
+    return a.devicePointer;
+}
+
+int gs_render_uniforms(gs_ctx *ctx, const GsFrameUniforms &u_in, void *device_rgba, uint8_t *host_rgba, size_t stride)
 {
     if (!ctx->renderable && ctx->n) FAIL(GS_E_STATE, "context was fed worker matrices only (gs_push_matrices): it can sort but not render");
     GS_HIP(hipSetDevice(ctx->device));
+    GsFrameUniforms u = u_in;
+    if (host_rgba && !device_rgba) {
+        const size_t row = (size_t)(u.x1 - u.x0) * 4, st = stride ? stride : row;
+        if (st < row) FAIL(GS_E_BADARG, "stride %zu smaller than a row (%zu bytes)", st, row);
+        if (void *d = host_frame_device_address(ctx, u, host_rgba, st, (u.flags & GS_RENDER_ASYNC) != 0)) {
+            device_rgba = d; host_rgba = nullptr; u.out_pitch = (int32_t)(st / 4);
+        }
+    }
     gs_ctx *L = ctx->lanes[ctx->cur];                           // the frame's lane: where its gs_sort ran
     const bool async = (u.flags & GS_RENDER_ASYNC) && !(u.flags & GS_RENDER_COUNT_FRAGS);
     if (async) {
         if (host_rgba && stride && stride < (size_t)(u.x1 - u.x0) * 4) FAIL(GS_E_BADARG, "stride %zu smaller than a row (%zu bytes)", stride, (size_t)(u.x1 - u.x0) * 4);
         L->async_pending = true; ctx->cur_async = true;
+        log_render(L, u, device_rgba, host_rgba, stride);
         if (ctx->enqueue_threads && gs_rotates(ctx) && !ctx->user_stream) {
             GsLaneCmd c;
             c.type = 1; c.has_cutout = false; c.has_strip = false; c.u = u; c.device_rgba = device_rgba; c.host_rgba = host_rgba; c.stride = stride;
@@ -1086,11 +1175,54 @@ GS_API void *gs_host_alloc(size_t nbytes)
 
 GS_API void gs_host_free(void *p) { if (p) (void)hipHostFree(p); }
 
+// gs_sync found incomplete asynchronous frames on the lanes of bad_unit[]: draw the frames logged for those lanes again, in the
+// order they were asked, synchronously (both binning rounds; a pair overflow grows the buffers and repeats inside
+// render_sync_on_lane).  Every lane is drained and idle.  GS_E_RETRY when the library cannot decide alone (see GsFrameRec).
+static int redraw_flagged_frames(gs_ctx *ctx, const bool bad_unit[GS_MAX_PRIMARY])
+{
+    // an output written by more than one logged frame (any lane): drawing one of them again could overwrite a newer image
+    std::set<const void *> outs;
+    for (int i = 0; i < GS_MAX_LANES; i++) {
+        gs_ctx *L = ctx->lanes[i];
+        if (!L || !L->log) continue;
+        for (const GsFrameRec &r : L->log->recs)
+            for (int k = 0; k < r.nrender; k++) {
+                const void *o = r.r[k].host ? (const void *)r.r[k].host : (r.r[k].dev ? (const void *)r.r[k].dev : (const void *)L);   // (the lane's own framebuffer)
+                if (o != (const void *)L && !outs.insert(o).second) return GS_E_RETRY;
+            }
+    }
+    for (int i = 0; i < GS_MAX_LANES; i++) {
+        gs_ctx *L = ctx->lanes[i];
+        if (!L || !L->log || !bad_unit[i % GS_MAX_PRIMARY]) continue;
+        for (const GsFrameRec &r : L->log->recs) if (r.nrender && r.undecidable) return GS_E_RETRY;
+    }
+    uint32_t redrawn = 0;
+    for (int i = 0; i < GS_MAX_LANES; i++) {
+        gs_ctx *L = ctx->lanes[i];
+        if (!L || !L->log || !bad_unit[i % GS_MAX_PRIMARY]) continue;
+        const std::vector<GsFrameRec> recs = L->log->recs;          // (render_sync_on_lane does not log, but keep the walk independent of it)
+        for (const GsFrameRec &r : recs) {
+            if (!r.nrender) continue;
+            TRY(lane_rc(ctx, L, gs_run_sort(L, r.view, r.has_cutout ? r.cutout : nullptr, r.has_strip ? &r.strip : nullptr, 0)));
+            for (int k = 0; k < r.nrender; k++) {
+                GsFrameUniforms u = r.r[k].u;
+                u.flags &= ~(uint32_t)GS_RENDER_ASYNC;
+                u.skip_round1 = 0;                                   // both rounds: complete by construction
+                TRY(lane_rc(ctx, L, render_sync_on_lane(L, u, r.r[k].dev, r.r[k].host, r.r[k].stride)));
+                redrawn++;
+            }
+        }
+    }
+    ctx->stats.retried_frames += redrawn;
+    return GS_OK;
+}
+
 GS_API int gs_sync(gs_ctx *ctx)
 {
     CHECK_CTX(ctx);
     GS_HIP(hipSetDevice(ctx->device));
     bool any_missed = false, any_over = false;
+    bool bad_unit[GS_MAX_PRIMARY] = { false, false, false, false };   // a lane or its twin (one stream, one worker) reported an incomplete frame
     uint32_t want = 0;
     // everything is about to be drained: the first frame after this goes to a twin's slot, i.e. out at once and alone (an idle GPU
     // should not wait for a partner frame), the pairs start with the frame after it
@@ -1116,17 +1248,27 @@ GS_API int gs_sync(gs_ctx *ctx)
         bool over = false;
         TRY(collect_status(L, &over));
         any_missed |= missed; any_over |= over;
+        if (missed || over) bad_unit[i % GS_MAX_PRIMARY] = true;
         if (over && L->ctl_host->max_total > want) want = L->ctl_host->max_total;
     }
     if (any_over)                                                // one retry for all lanes: each gets room for the largest demand seen
         for (int i = 0; i < GS_MAX_LANES; i++)
             if (ctx->lanes[i] && ctx->lanes[i]->pair_cap)
                 TRY(lane_rc(ctx, ctx->lanes[i], gs_ensure_pair_capacity(ctx->lanes[i], (size_t)want + want / 4 + 1)));
-    if (any_missed) FAIL(GS_E_RETRY, "an asynchronous frame skipped its second binning round but a tile had not saturated; "
+    const bool stale = ctx->log_stale;
+    ctx->log_stale = false;
+    int rc = GS_OK;
+    if (any_missed || any_over) {
+        rc = (ctx->auto_retry && !stale) ? redraw_flagged_frames(ctx, bad_unit) : GS_E_RETRY;
+        if (rc == GS_E_RETRY) {
+            if (any_missed) snprintf(ctx->err, sizeof ctx->err, "an asynchronous frame skipped its second binning round but a tile had not saturated; "
                                      "the share of splats binned first was raised - render the frames since the previous gs_sync() again");
-    if (any_over) FAIL(GS_E_RETRY, "an asynchronous frame needed %u pairs and overflowed the pair buffers; they were enlarged - "
-                                   "render the frames since the previous gs_sync() again", want);
-    return GS_OK;
+            else snprintf(ctx->err, sizeof ctx->err, "an asynchronous frame needed %u pairs and overflowed the pair buffers; they were enlarged - "
+                          "render the frames since the previous gs_sync() again", want);
+        }
+    }
+    for (int i = 0; i < GS_MAX_LANES; i++) if (ctx->lanes[i]) log_reset(ctx->lanes[i]);
+    return rc;
 }
 
 GS_API int gs_set_stream(gs_ctx *ctx, void *hip_stream)
@@ -1217,6 +1359,15 @@ GS_API int gs_set_option(gs_ctx *ctx, int option, int64_t value)
         GS_HIP(hipSetDevice(ctx->device));
         TRY(drain_all(ctx));
         return gs_comm_set_self_copy(ctx, value != 0);
+    case GS_OPT_HOST_WRITE:
+        if (value < 0 || value > 2) FAIL(GS_E_BADARG, "host write: 0 (copy engine), 1 (the blend writes page-locked frames itself) or 2 (synchronous frames only)");
+        ctx->host_write = (int)value;
+        return GS_OK;
+    case GS_OPT_AUTO_RETRY:
+        GS_HIP(hipSetDevice(ctx->device));
+        TRY(drain_all(ctx));
+        ctx->auto_retry = value != 0;
+        return GS_OK;
     case GS_OPT_COMM_TRANSPORT:
         if (value != 0 && value != 1) FAIL(GS_E_BADARG, "comm transport: 0 (RCCL) or 1 (in-process)");
         return gs_comm_set_transport(ctx, (int)value);
@@ -1263,6 +1414,7 @@ GS_API int gs_get_stats(gs_ctx *ctx, gs_stats *out)
         s.acc_visible += L->stats.acc_visible; s.acc_pairs += L->stats.acc_pairs;
     }
     s.n_splats = ctx->n;
+    s.retried_frames = ctx->stats.retried_frames;
     s.near_permille = (uint32_t)(ctx->near_frac * 1000.0f + 0.5f);
     *out = s;
     return GS_OK;

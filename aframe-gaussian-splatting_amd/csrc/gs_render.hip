@@ -723,7 +723,7 @@ __device__ __forceinline__ void k_blend_body(const uint2 *__restrict__ tile_rang
     }
     if (row_in && xb < u.x1) {
         // dst <- src.rgb*a + dst.rgb*(1-a), dst.a <- a + dst.a*(1-a), composed over the background
-        const int sw = u.x1 - u.x0;
+        const int sw = u.out_pitch;
         const int orow = (u.flags & GS_RENDER_FLIP_Y) ? (u.H - 1 - r) : r;
         const float Tk[4] = { TA.x, TA.y, TB.x, TB.y }, rk[4] = { crA.x, crA.y, crB.x, crB.y }, gk[4] = { cgA.x, cgA.y, cgB.x, cgB.y };
         const float bk[4] = { cbA.x, cbA.y, cbB.x, cbB.y };
@@ -937,7 +937,7 @@ __device__ __forceinline__ void k_blend_px_body(const uint2 *__restrict__ tile_r
                 b2 = (float)((c >> 16) & 0xFF) / 255.0f; b3 = (float)(c >> 24) / 255.0f;
             }
             const float o0 = fmaf(T, b0, cr), o1 = fmaf(T, b1, cg), o2 = fmaf(T, b2, cb), o3 = fmaf(T, b3, 1.0f - T);
-            const int sw = u.x1 - u.x0;
+            const int sw = u.out_pitch;
             const int orow = (u.flags & GS_RENDER_FLIP_Y) ? (u.H - 1 - r) : r;
             reinterpret_cast<uint32_t *>(out)[(size_t)orow * sw + (px - u.x0)] =
                 (uint32_t)(fminf(fmaxf(o0, 0.0f), 1.0f) * 255.0f + 0.5f) | ((uint32_t)(fminf(fmaxf(o1, 0.0f), 1.0f) * 255.0f + 0.5f) << 8) |

@@ -178,8 +178,9 @@ class GaussianSplatting {
   // GPU (index.js:184-207).  frameQueued = this frame's sort (the order stays on the GPU) + draw, enqueued on one of the
   // library's pipeline lanes (two frames per launch, GS_OPT_FRAME_BATCH); the pixels follow their kernels into one of
   // `QUEUE_DEPTH` page-locked frames, which is what is
-  // returned -- valid after sync().  sync() throws code GS-9 (GS_E_RETRY) if the frames since the previous sync() have to be
-  // queued again (a buffer grew).
+  // returned -- valid after sync().  A frame that comes back incomplete (a buffer had to grow, a skipped binning round was
+  // needed after all) is drawn again by sync() itself into the same frame (GS_OPT_AUTO_RETRY); sync() throws code GS-9
+  // (GS_E_RETRY) only if more than QUEUE_DEPTH frames were queued between two sync() calls (frames sharing a buffer).
   frameQueued(camera, viewport, options) {
     if (!this._paired) { native.setOption(this.handle, 10, 2); this._paired = true; }   // GS_OPT_FRAME_BATCH: consecutive queued frames share their launches
     const u = this._tickUniforms(camera);

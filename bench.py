@@ -272,7 +272,8 @@ def main():
     s = ctx.stats()
     ctx.set_option(capi.OPT_PROFILE, 0)
     blends_per_step = len(mine) if gathered else 1
-    assert s["acc_frames"] == args.steps * blends_per_step, (s["acc_frames"], args.steps, blends_per_step)
+    # (frames gs_sync() drew again by itself -- GS_OPT_AUTO_RETRY -- are inside the region's time and counted on top)
+    assert s["acc_frames"] >= args.steps * blends_per_step, (s["acc_frames"], args.steps, blends_per_step)
     blend_frames = max(1, s["prof_frames"])                  # renders of the timed region whose blend was bracketed by HIP events
     # per-stage breakdown: a second, UNTIMED pass over the same frames with events around every stage (7 per frame
     # instead of 2; they cost ~4 % of the frame rate, so the timed region carries only the blend's)
@@ -283,6 +284,19 @@ def main():
     sync()
     s2 = ctx.stats()
     ctx.set_option(capi.OPT_PROFILE, 0)
+    # what the region's fill and drain cost: the same loop over a region long enough to hide them (untimed for `value`)
+    steady_fps = None
+    if args.steps < 240:
+        sync()
+        ts = time.perf_counter()
+        for i in range(480):
+            frame(args.warmup + i, capi.RENDER_ASYNC)
+        if not sync():
+            steady_fps = 480 / (time.perf_counter() - ts)
+        if world > 1:
+            t = torch.tensor([steady_fps or 0.0], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            steady_fps = float(t.item()) or None
     k2 = max(1, s2["prof_frames"]) / float(max(1, blends_per_step))     # profiled steps
     # (with two frames per launch the HIP events bracket a PAIR's kernels: a frame's share is half of the interval)
     stage = {"ms_sort": s2["sum_ms_sort"] * args.steps / k2 / frame_batch, "ms_project": s2["sum_ms_project"] * args.steps / k2 / frame_batch,
@@ -352,7 +366,15 @@ def main():
                                             "binning and blend; consecutive frames overlap on the GPU); see latency.fps_depth1 for one frame at a time"
                                             % (3 * frame_batch, " x 2 frames per launch, GS_OPT_FRAME_BATCH: the two frames of a pair share each "
                                                "kernel launch, grid (x, 2), on separate scratch" if frame_batch == 2 else "")),
-                       "frames_per_launch": frame_batch},
+                       "frames_per_launch": frame_batch,
+                       "preroll_frames": preroll + 2 * max(LANES, depth) + args.warmup,
+                       "preroll_note": "untimed, before the region: %d synchronous frames cycling through the region's own poses (the library settles "
+                                       "the share of splats it bins first, and after 16 clean frames stops launching the second binning round), "
+                                       "%d asynchronous frames to allocate every lane, %d warm-up steps" % (preroll, 2 * max(LANES, depth), args.warmup),
+                       "region_ms": round(elapsed * 1e3, 3),
+                       "steady_state_fps": round(steady_fps, 1) if steady_fps else None,
+                       "fill_drain_share": round(max(0.0, 1.0 - fps / steady_fps), 4) if steady_fps else None,
+                       "frames_redrawn_by_sync": s.get("retried_frames", 0)},
             "occlusion_binning": {"near_permille": s["near_permille"], "unsat_tiles_last_frame": s["unsat_tiles"],
                                   "timed_region_retries": retries},
             "msplat_frags_per_s": round(total_frags / 1e6 / elapsed, 1),
@@ -596,25 +618,40 @@ def secondary_measurements(ctx, capi, synth, rows, cams, views, n_splats, args, 
                                     "1024 SIMDs x 2.4 GHz / 4.5 cycles per instruction; entries = list entries each tile's wavefront "
                                     "evaluated before it saturated (GS_OPT_RECORD_STAGED = 2, this run); VALU instructions per entry "
                                     "and the issue costs are properties of the kernel code (profiles/r01_pmc_valu.md, tools/micro/valu_rate.hip)"}
-    # the frame delivered to the host (what a JS caller of component.render() gets): gs_render into page-locked memory
+    # the frame delivered to the host (what a JS caller of component.render() gets): gs_render into page-locked memory.  Two ways
+    # there (GS_OPT_HOST_WRITE): the copy engine behind the frame's last kernel, or the blend kernel storing its tiles straight into
+    # the page-locked frame; the denominator is this box's own device-to-host rate (1 GiB, page-locked, same run)
+    pcie = measured_pcie_peak(capi)
+    fb_bytes = W * H * 4
     host, owner = capi.host_frame(H, W)
-    t0 = time.perf_counter()
     m = min(n, 120)
-    for i in range(m):
-        k = i % ORBIT_FRAMES
-        ctx.sort(cams[k]["view"], cams[k]["cutout"], want_indices=False)
-        views[k][0].flags = 0
-        ctx.render_into(views[k][0], host)
-    t = time.perf_counter() - t0
+
+    def loop_sync(mm):
+        t0 = time.perf_counter()
+        for i in range(mm):
+            k = i % ORBIT_FRAMES
+            ctx.sort(cams[k]["view"], cams[k]["cutout"], want_indices=False)
+            views[k][0].flags = 0
+            ctx.render_into(views[k][0], host)
+        return time.perf_counter() - t0
+
+    sync_ms = {}
+    for mode, tag in ((0, "copy_engine"), (1, "blend_writes_host")):
+        ctx.set_option(capi.OPT_HOST_WRITE, mode)
+        loop_sync(12)
+        sync_ms[tag] = loop_sync(m) / m * 1e3
+    ctx.set_option(capi.OPT_HOST_WRITE, 0)
     owner.free()
-    out["host_readback"] = {"fps_host_readback": round(m / t, 1), "ms_per_frame": round(t / m * 1e3, 4),
-                            "note": "synchronous gs_render into page-locked host memory (%.1f MB D2H per frame over PCIe), one frame at a time"
-                                    % (W * H * 4 / 1e6)}
+    best_sync = min(sync_ms, key=sync_ms.get)
+    out["host_readback"] = {"fps_host_readback": round(1e3 / sync_ms[best_sync], 1), "ms_per_frame": round(sync_ms[best_sync], 4),
+                            "ms_per_frame_by_path": {k: round(v, 4) for k, v in sync_ms.items()}, "path": best_sync,
+                            "pcie_d2h_peak_GBps": pcie,
+                            "note": "synchronous gs_render into page-locked host memory (%.1f MB per frame over PCIe), one frame at a time, sort included; "
+                                    "pcie_d2h_peak_GBps = a 1 GiB device-to-host copy into page-locked memory timed in this run" % (fb_bytes / 1e6)}
     ctx.set_option(capi.OPT_PIPELINE_DEPTH, int(os.environ.get("GS_BENCH_DEPTH", "0")) or 3)
     ctx.set_option(capi.OPT_FRAME_BATCH, frame_batch)           # (as in the timed loop)
-    # the same delivery with frames in flight: gs_render(GS_RENDER_ASYNC) copies each frame into its own page-locked buffer
-    # behind its kernels, on the frame's stream
-    NB = 12                                                  # (3 lanes x 2 frames per launch in flight, twice over)
+    # the same delivery with frames in flight: gs_render(GS_RENDER_ASYNC), each frame into its own page-locked buffer
+    NB = 24                                                  # (3 lanes x 2 frames per launch in flight, four times over: a sync drains the lanes)
     bufs = [capi.host_frame(H, W) for _ in range(NB)]
 
     def loop_host(nn):
@@ -641,14 +678,23 @@ def secondary_measurements(ctx, capi, synth, rows, cams, views, n_splats, args, 
                 raise
         return time.perf_counter() - t0
 
-    loop_host(12)
-    m = min(n, 120)
-    t = loop_host(m)
+    m = min(n, 240)
+    pipe = {}
+    for mode, tag in ((0, "copy_engine"), (1, "blend_writes_host")):
+        ctx.set_option(capi.OPT_HOST_WRITE, mode)
+        loop_host(24)
+        pipe[tag] = m / loop_host(m)
+    ctx.set_option(capi.OPT_HOST_WRITE, 0)
     for _, o in bufs:
         o.free()
-    out["host_readback"].update({"fps_host_readback_pipelined": round(m / t, 1),
-                                 "note_pipelined": "gs_render with GS_RENDER_ASYNC: frames queued on the three pipeline lanes, each copied into "
-                                                   "its own page-locked buffer on its lane's stream (twelve buffers, gs_sync every twelve frames)"})
+    best = max(pipe, key=pipe.get)
+    out["host_readback"].update({"fps_host_readback_pipelined": round(pipe[best], 1), "pipelined_path": best,
+                                 "fps_pipelined_by_path": {k: round(v, 1) for k, v in pipe.items()},
+                                 "pipelined_GBps": round(pipe[best] * fb_bytes / 1e9, 2),
+                                 "frac_of_pcie": round(pipe[best] * fb_bytes / 1e9 / pcie, 4) if pcie else None,
+                                 "note_pipelined": "gs_render with GS_RENDER_ASYNC: frames queued on the three pipeline lanes, each into its own "
+                                                   "page-locked buffer (24 buffers, gs_sync every 24 frames); frac_of_pcie = delivered bytes/s "
+                                                   "over pcie_d2h_peak_GBps"})
     # the blend without early termination (every reference-equivalent fragment evaluated), pipelined like the headline
     loop(6, capi.RENDER_ASYNC | capi.RENDER_NO_EARLY_OUT)
     m = min(n, 60)
@@ -768,6 +814,36 @@ def measured_copy_peak(ctx, capi, nbytes=1 << 30, reps=5):
         hip.hipEventElapsedTime(C.byref(ms), e0, e1)
         hip.hipEventDestroy(e0); hip.hipEventDestroy(e1); hip.hipFree(a); hip.hipFree(b)
         return round(2.0 * nbytes * reps / (ms.value * 1e-3) / 1e9, 1) if ms.value > 0 else None
+    except Exception:
+        return None
+
+
+def measured_pcie_peak(capi, nbytes=1 << 30, reps=3):
+    """Device-to-host copy rate of this box in the same run: GB/s of a 1 GiB hipMemcpyAsync from HBM into page-locked memory
+    (gs_host_alloc), HIP events around `reps` copies: the denominator of host_readback.frac_of_pcie."""
+    import ctypes as C
+    try:
+        try:
+            hip = C.CDLL("libamdhip64.so")
+        except OSError:
+            hip = C.CDLL("/opt/rocm/lib/libamdhip64.so")
+        L = capi.load()
+        host = L.gs_host_alloc(nbytes)
+        a, e0, e1 = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        if not host or hip.hipMalloc(C.byref(a), C.c_size_t(nbytes)):
+            return None
+        hip.hipMemsetAsync(a, 1, C.c_size_t(nbytes), None)
+        hip.hipEventCreate(C.byref(e0)); hip.hipEventCreate(C.byref(e1))
+        hip.hipMemcpyAsync(C.c_void_p(host), a, C.c_size_t(nbytes), 2, None)
+        hip.hipEventRecord(e0, None)
+        for _ in range(reps):
+            hip.hipMemcpyAsync(C.c_void_p(host), a, C.c_size_t(nbytes), 2, None)
+        hip.hipEventRecord(e1, None)
+        hip.hipEventSynchronize(e1)
+        ms = C.c_float(0)
+        hip.hipEventElapsedTime(C.byref(ms), e0, e1)
+        hip.hipEventDestroy(e0); hip.hipEventDestroy(e1); hip.hipFree(a); L.gs_host_free(C.c_void_p(host))
+        return round(nbytes * reps / (ms.value * 1e-3) / 1e9, 2) if ms.value > 0 else None
     except Exception:
         return None
 

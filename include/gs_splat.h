@@ -39,8 +39,11 @@ typedef enum gs_status {
     GS_E_NODEVICE = -6,    /* no usable gfx950 device                                                   */
     GS_E_STATE = -7,       /* call not valid in this state (e.g. render after matrices-only push)       */
     GS_E_PLY_DATA = -8,    /* vertex data shorter than the header promises (DataView RangeError in JS)  */
-    GS_E_RETRY = -9        /* gs_sync(): an asynchronous frame outgrew the pair buffers; they were enlarged,
-                              frames rendered since the previous gs_sync() must be rendered again            */
+    GS_E_RETRY = -9        /* gs_sync(): an asynchronous frame came back incomplete (it outgrew the pair buffers, or needed the
+                              binning round it had skipped) AND the library could not draw it again by itself: gathered frames
+                              (every rank has to take part), frames that share an output buffer, data pushed meanwhile, or
+                              GS_OPT_AUTO_RETRY = 0.  The frames since the previous gs_sync() must be rendered again.  Otherwise
+                              gs_sync() re-renders such frames into the same buffers before it returns.                  */
 } gs_status;
 
 /* ---- lifetime ----------------------------------------------------------------------------------- */
@@ -284,6 +287,14 @@ GS_API int gs_multi_sync(gs_multi *m);
                                    counting render, round 1, gs_download of the order) sorts again in full by itself.  Sorts that
                                    return the order (out_idx / out_n) are always complete.  0: off; 1 (default): for scenes of
                                    4 M splats and more (below, the sort's passes are launch-bound); 2: always.               */
+#define GS_OPT_HOST_WRITE 14    /* how gs_render's frame reaches a PAGE-LOCKED host buffer (gs_host_alloc).  0: copied by the copy engine behind
+                                   the frame's last kernel.  1: the blend kernel stores its tiles straight into the buffer (16 bytes per
+                                   lane as each tile finishes), so the transfer runs under the blending of the other tiles and nothing is
+                                   left to wait for.  2: that for synchronous frames only.  Pageable or oddly aligned buffers are always
+                                   copied.  Same pixels either way.                                                                  */
+#define GS_OPT_AUTO_RETRY 13    /* 1 (default): gs_sync() draws an asynchronous frame that came back incomplete again by itself -- same sort
+                                   arguments, same uniforms, same output buffers, both binning rounds -- before it returns; GS_E_RETRY is
+                                   left for the cases it cannot decide alone (see gs_status).  0: every such frame is reported.       */
 #define GS_OPT_COMM_TRANSPORT 12 /* what gs_comm_unique_id makes an id for.  0 (default): RCCL over xGMI, one process per GPU or several contexts
                                    of one process.  1: the in-process transport -- contexts of ONE process (on different GPUs, or all on
                                    the same one) exchange their pieces through mailbox buffers and peer copies on their own streams,
@@ -333,7 +344,7 @@ typedef struct gs_stats {
     uint32_t near_permille;/* share of the splats binned in that first round (adapted, or GS_OPT_NEAR_PERMILLE)        */
     uint32_t sort_records;/* records the last collected frame's depth sort carried through its second pass: the kept
                              splats with a valid bucket, or the nearest few of them (GS_OPT_SORT_NEAR)               */
-    uint32_t reserved0;
+    uint32_t retried_frames;/* asynchronous frames gs_sync() drew again by itself since the context was created (GS_OPT_AUTO_RETRY) */
 } gs_stats;
 
 #define GS_OPT_PROFILE 1        /* 1: bracket every stage with HIP events on the frame's stream (7 per frame); 2: only

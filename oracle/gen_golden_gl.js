@@ -67,7 +67,7 @@ vm.runInContext(fs.readFileSync(REF, 'utf8'), ctx, { filename: REF });
 
 // ---------------------------------------------------------------- fixture writer (same container format as gen_golden.js)
 const DT = new Map([[Float32Array, 'f4'], [Float64Array, 'f8'], [Uint32Array, 'u4'], [Uint8Array, 'u1']]);
-const manifest = {};
+const manifest = (process.env.GS_GL_MERGE && fs.existsSync(path.join(OUT, 'manifest_gl.json'))) ? JSON.parse(fs.readFileSync(path.join(OUT, 'manifest_gl.json'), 'utf8')) : {};   // GS_GL_MERGE: add / replace cases, keep the others
 function emit(name, arrays, meta) {
   const chunks = []; let off = 0; const desc = {};
   for (const k of Object.keys(arrays)) {
@@ -88,7 +88,7 @@ async function glCase(name, sc) {
   const rows = fs.readFileSync(path.join(SCENES, sc.rows));
   const n = rows.length / 32;
   // gl.MAX_TEXTURE_SIZE as this "renderer" reports it: the texture width, and its square the splat capacity (index.js:31-40)
-  const TEXW = n > (1 << 20) ? 4096 : 1024;
+  const TEXW = n > (1 << 24) ? 8192 : (n > (1 << 20) ? 4096 : 1024);
   const M = (e) => { const m = new THREE.Matrix4(); m.elements = Array.from(e); return m; };
   const gl = { MAX_TEXTURE_SIZE: 'MAX', TEXTURE_2D: 1, RGBA: 2, FLOAT: 3, RGBA_INTEGER: 4, UNSIGNED_INT: 5,
     getParameter: () => TEXW, bindTexture() {}, texSubImage2D() {} };
@@ -106,8 +106,13 @@ async function glCase(name, sc) {
   });
   if (sc.cutout_world) self.cutout = { matrixWorld: M(sc.cutout_world) };
   await self.initGL(n);                                          // index.js:26-221: textures, geometry, material, reply handler
-  const ab = rows.buffer.slice(rows.byteOffset, rows.byteOffset + rows.length);
-  self.pushDataBuffer(ab, n);                                    // index.js:328-437: fills both textures, pushes the worker rows
+  // index.js:328-437: fills both textures, pushes the worker rows -- in one call, or chunk by chunk like a progressive load
+  // (index.js:279-298); the worker appends each push to what it holds (index.js:576-586)
+  const chunk = sc.push_chunk || n;
+  for (let o = 0; o < n; o += chunk) {
+    const m = Math.min(chunk, n - o);
+    self.pushDataBuffer(rows.buffer.slice(rows.byteOffset + o * 32, rows.byteOffset + (o + m) * 32), m);
+  }
   self.sortReady = true;
   self.tick(0, 0);                                               // index.js:438-455 -> worker sort -> reply handler (index.js:201-207)
   const mat = mesh.material, geo = mesh.geometry;

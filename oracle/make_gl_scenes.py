@@ -97,5 +97,40 @@ if "--big" in sys.argv or "--full-frame" in sys.argv:
           synth.perspective(80.0, 1920 / 1080), strip=(0, 1920), recipe={"fn": "make_splat_rows", "n": int(synth.N_TRAIN)},
           note="BASELINE configs[1], the whole 1920x1080 frame, orbit frame 40 (also times the reference's GPU half on this host's cores)")
     scenes["c2_1m_1080p_frame"]["store_rgba8"] = False
+if "--big" in sys.argv or "--frames" in sys.argv:
+    # whole frames of the other single-GPU configurations (float-buffer image only): C1, and BOTH eyes of C4 -- one sort from the
+    # head camera (index.js:441), each eye drawn with its own camera
+    rows_1m = synth.make_splat_rows(synth.N_TRAIN)
+    rec_1m = {"fn": "make_splat_rows", "n": int(synth.N_TRAIN)}
+    scene("c1_1m_720p_frame", rows_1m, 1280, 720, synth.compose((0.0, 1.6, 0.0)), synth.compose((0.0, 1.5, -2.0), 63.0),
+          synth.perspective(80.0, 1280 / 720), strip=(0, 1280), recipe=rec_1m,
+          note="BASELINE configs[0], the whole 1280x720 frame, entity yaw 63 deg")
+    scenes["c1_1m_720p_frame"]["store_rgba8"] = False
+    wx, hx = 1032, 1104
+    for tag, sx in (("left", -1.0), ("right", 1.0)):
+        lo, ro = (math.tan(math.radians(54)), math.tan(math.radians(40))) if sx < 0 else (math.tan(math.radians(40)), math.tan(math.radians(54)))
+        eye_proj = synth.frustum(-lo * near, ro * near, math.tan(math.radians(44)) * near, -math.tan(math.radians(55)) * near, near, far)
+        nm = "c4_xr_%s_eye_frame" % tag
+        scene(nm, rows_1m, wx, hx, synth.compose((0.0, 1.6, 0.0)), synth.compose((0.0, 1.5, -2.0), 155.0), synth.perspective(80.0, wx / hx),
+              strip=(0, wx), recipe=rec_1m, eye=(synth.compose((0.032 * sx, 1.6, 0.0)), eye_proj),
+              note="BASELINE configs[3]: the whole %s XR eye 1032x1104, order from the HEAD camera's sort, entity yaw 155 deg" % tag)
+        scenes[nm]["store_rgba8"] = False
+if "--c5" in sys.argv:
+    # BASELINE configs[4]'s OWN scene: 20,971,520 splats at 3840x2160 -- more than 4096^2 vertices, so the "renderer" has to report
+    # MAX_TEXTURE_SIZE 8192 (index.js:30-36 would clamp at 16.7 M otherwise); pushed in chunks like a progressive load; one
+    # 64-pixel strip.  ~1.3 GB of worker rows in node, a few minutes.
+    n5 = 20 * (1 << 20)
+    scene("c5_20m_4k_strip", synth.make_splat_rows_fast(n5), 3840, 2160, synth.compose((0.0, 1.6, 0.0)), synth.compose((0.0, 1.5, -2.0), 33.0),
+          synth.perspective(80.0, 3840 / 2160), strip=(1888, 1952), recipe={"fn": "make_splat_rows_fast", "n": n5},
+          note="BASELINE configs[4]: 20,971,520 splats at 3840x2160, entity yaw 33 deg, columns 1888..1951 (MAX_TEXTURE_SIZE 8192)")
+    scenes["c5_20m_4k_strip"]["push_chunk"] = 1 << 22
+if "--only-new" in sys.argv:                                  # (side runs: GS_GL_MERGE=1 node oracle/gen_golden_gl.js keeps the other cases)
+    keep = [k for k in scenes if k.endswith("_frame") and not k.startswith("c2_") or k == "c5_20m_4k_strip"]
+    for k in list(scenes):
+        if k not in keep:
+            os.unlink(os.path.join(OUT, scenes[k]["rows"]))
+            for e in ("scene_depth", "scene_rgba"):
+                if e in scenes[k]: os.unlink(os.path.join(OUT, scenes[k][e]))
+            del scenes[k]
 json.dump(scenes, open(os.path.join(OUT, "scenes.json"), "w"), indent=1)
 print("wrote", len(scenes), "scenes ->", OUT)

@@ -11,11 +11,22 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "libgs_oracle.so")
+_SO = os.environ.get("GS_ORACLE_LIB") or os.path.join(_HERE, "libgs_oracle.so")   # (GS_ORACLE_LIB: the sanitizer build, tests only)
+
+
+def build_sanitized():
+    """oracle/libgs_oracle_san.so: gs_oracle.c under -fsanitize=address,undefined (loaded by a child process with libasan preloaded)"""
+    out = os.path.join(_HERE, "libgs_oracle_san.so")
+    src = os.path.join(_HERE, "gs_oracle.c")
+    if not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "libgs_oracle_san.so"])
+    return out
 
 
 def build(force=False):
     src = os.path.join(_HERE, "gs_oracle.c")
+    if os.environ.get("GS_ORACLE_LIB"):
+        return _SO
     if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
         subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
     return _SO

@@ -46,3 +46,17 @@ def cases_of(kind):
 @pytest.fixture(scope="session")
 def manifest():
     return load_manifest()
+
+
+_ROWS_CACHE = {}
+
+
+def cached_rows(fn, n, **kw):
+    """The benchmark's big synthetic scenes (1 M / 6 M / 20 M rows) are generated once per test process: several tests draw the same
+    one, and generating 20 M rows costs more than everything the GPU then does with them.  At most two scenes are kept."""
+    key = (fn, int(n), tuple(sorted(kw.items())))
+    if key not in _ROWS_CACHE:
+        while len(_ROWS_CACHE) >= 2:
+            _ROWS_CACHE.pop(next(iter(_ROWS_CACHE)))
+        _ROWS_CACHE[key] = getattr(pkg("synth"), fn)(int(n), **kw)
+    return _ROWS_CACHE[key]

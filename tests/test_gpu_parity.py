@@ -10,7 +10,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import cases_of, load_case, pkg
+from conftest import cached_rows, cases_of, load_case, pkg
 from oracle import oracle
 
 pytestmark = pytest.mark.gpu
@@ -458,7 +458,8 @@ def test_c4_xr_stereo_and_c5_4k_strip(ctx, scene_1m):
 
 def test_async_frames_match_synchronous_ones_and_report_overflow(scene_small):
     """GS_RENDER_ASYNC: frames enqueued back to back produce the same pixels as synchronous renders; statistics are
-    collected by gs_sync(); a frame that outgrows the pair buffers is reported as GS_E_RETRY and succeeds afterwards."""
+    collected by gs_sync(); a frame that outgrows the pair buffers is drawn again by gs_sync() itself (GS_OPT_AUTO_RETRY), or --
+    on request, or when two logged frames share an output buffer -- reported as GS_E_RETRY and succeeds afterwards."""
     import ctypes
     with capi.Context(0) as c2:
         c2.push_splat(scene_small["rows"])
@@ -475,26 +476,53 @@ def test_async_frames_match_synchronous_ones_and_report_overflow(scene_small):
         assert s["acc_frames"] == 3 and s["prof_frames"] == 3 and s["sum_ms_blend"] > 0 and s["acc_pairs"] > 0
         c2.set_option(capi.OPT_PROFILE, 0)
         assert np.array_equal(c2.render(_params(cams[2])), want[2])       # last async frame == synchronous frame
+    rows = synth.make_splat_rows(300000, seed=5)
+    rows = rows.reshape(-1, 32).copy()
+    rows[:, 12:24] = (rows[:, 12:24].copy().view("<f4") * np.float32(6.0)).view(np.uint8)   # fat splats: many tiles each
+    cam = synth.index_html_camera(1920, 1080, 0.0, capi=capi)
     with capi.Context(0) as c3:                                            # fresh context: small default pair capacity
-        rows = synth.make_splat_rows(300000, seed=5)
-        rows = rows.reshape(-1, 32).copy()
-        rows[:, 12:24] = (rows[:, 12:24].copy().view("<f4") * np.float32(6.0)).view(np.uint8)   # fat splats: many tiles each
         c3.push_splat(rows)
-        cam = synth.index_html_camera(1920, 1080, 0.0, capi=capi)
+        # no retry loop: a frame that outgrows the pair buffers is drawn again by gs_sync() itself, into the caller's buffer
+        host, owner = capi.host_frame(1080, 1920)
+        host[:] = 7
         c3.sort(cam["view"], want_indices=False)
-        c3.render_device(_params(cam, flags=capi.RENDER_ASYNC), None)
-        try:
-            c3.sync()
-            overflowed = False
-        except capi.GsError as e:
-            assert e.code == capi.E_RETRY
-            overflowed = True
-        c3.render_device(_params(cam, flags=capi.RENDER_ASYNC), None)
-        c3.sync()                                                          # enlarged to the frame's whole demand: no error now
+        c3.render_into(_params(cam, flags=capi.RENDER_ASYNC), host)
+        c3.sync()
+        s = c3.stats()
         a = c3.render(_params(cam))
-        assert c3.stats()["n_pairs"] > 0
+        assert np.array_equal(host, a)
+        assert s["n_pairs"] > 0
+        overflowed = c3.stats()["n_pairs"] > (1 << 22)
+        assert s["retried_frames"] == (1 if overflowed else 0), s
+        owner.free()
+    with capi.Context(0) as c4:                                            # GS_OPT_AUTO_RETRY = 0: the caller is told instead
+        c4.set_option(capi.OPT_AUTO_RETRY, 0)
+        c4.push_splat(rows)
+        c4.sort(cam["view"], want_indices=False)
+        c4.render_device(_params(cam, flags=capi.RENDER_ASYNC), None)
         if overflowed:
-            assert c3.stats()["n_pairs"] > (1 << 22)
+            with pytest.raises(capi.GsError) as ei:
+                c4.sync()
+            assert ei.value.code == capi.E_RETRY
+        else:
+            c4.sync()
+        c4.render_device(_params(cam, flags=capi.RENDER_ASYNC), None)
+        c4.sync()                                                          # enlarged to the frame's whole demand: no error now
+        assert np.array_equal(c4.render(_params(cam)), a)
+    with capi.Context(0) as c5:                                            # two logged frames into ONE buffer: not the library's call
+        c5.push_splat(rows)
+        buf, own = capi.host_frame(1080, 1920)
+        cam2 = synth.index_html_camera(1920, 1080, 90.0, capi=capi)
+        for cm in (cam, cam2):
+            c5.sort(cm["view"], want_indices=False)
+            c5.render_into(_params(cm, flags=capi.RENDER_ASYNC), buf)
+        if overflowed:
+            with pytest.raises(capi.GsError) as ei:
+                c5.sync()
+            assert ei.value.code == capi.E_RETRY
+        else:
+            c5.sync()
+        own.free()
 
 
 @pytest.mark.parametrize("w,h,n,seed", [(640, 360, 30000, 77), (1920, 1080, 400000, 12)])
@@ -531,7 +559,7 @@ def test_c5_twenty_million_splats_4k():
     a 64-px strip and its fragment count vs the oracle.  (About a minute: most of it is generating and packing the
     20,971,520 input rows on the host.)"""
     n = synth.N_20M
-    rows = synth.make_splat_rows_fast(n, seed=synth.SEED_BASE + 5)
+    rows = cached_rows("make_splat_rows_fast", n)                # (seed: the generator's default, SEED_BASE + 5)
     cs, cc, mats = oracle.pack(rows)
     rows4 = np.ascontiguousarray(mats[:, 12:16]); del mats
     cam = synth.index_html_camera(3840, 2160, 15.0, capi=capi)
@@ -551,6 +579,75 @@ def test_c5_twenty_million_splats_4k():
         c5.render(_params(cam, x0=1900, x1=1964, flags=capi.RENDER_COUNT_FRAGS))
         assert c5.stats()["n_frags"] == frags
         print("C5 stats:", st)
+        # Near-only sorts where they are the DEFAULT (GS_OPT_SORT_NEAR = 1: from 4 M splats; the long radix geometry, 512 threads x
+        # 4096 items): queued frames, alone and in pairs, and column strips sorted with gs_sort_for must equal the whole-sort frame
+        # bit for bit, their sorts must have been partial, and the strip must hold to the oracle like the whole-sort frame does
+        _near_only_frames_equal(c5, [cam, synth.index_html_camera(3840, 2160, 16.0, capi=capi)], [full, None], oracle_strip=(1900, 1964, ref))
+
+
+def _near_only_frames_equal(c, cams, want, oracle_strip=None, strips=((0, 480), (1440, 1920))):
+    """shared by the >= 4 M tests: queue frames until the share has settled (16 clean frames switch round 1 off and near-only
+    sorts on), then compare; want[k] None = take it from a whole-sort synchronous frame first"""
+    import torch
+    w, h = cams[0]["vw"], cams[0]["vh"]
+    c.set_option(capi.OPT_SORT_NEAR, 0)
+    for k, cam in enumerate(cams):
+        if want[k] is None:
+            c.sort(cam["view"], want_indices=False); want[k] = c.render(_params(cam))
+    c.set_option(capi.OPT_SORT_NEAR, 1)                                    # the default
+
+    def queued(views_of, reps):
+        """views_of(cam) -> (params, sort_for?) ; returns the device buffers of the last repetition"""
+        for attempt in range(8):
+            bufs = []
+            for rep in range(reps):
+                for k, cam in enumerate(cams):
+                    prm, strip_sort = views_of(cam)
+                    b = torch.zeros((prm.x1 - prm.x0) * h * 4, dtype=torch.uint8, device="cuda") if rep == reps - 1 else None
+                    if strip_sort:
+                        c.sort_for(cam["view"], None, prm, want_indices=False)
+                    else:
+                        c.sort(cam["view"], want_indices=False)
+                    c.render_device(prm, b.data_ptr() if b is not None else None)
+                    if b is not None:
+                        bufs.append((k, prm.x0, prm.x1, b))
+                if rep % 4 == 3:
+                    c.sync()
+            c.sync()
+            s = c.stats()
+            if s["sort_records"] < s["n_sorted"]:
+                break
+        torch.cuda.synchronize()
+        return bufs, s
+
+    for batch in (1, 2):
+        c.set_option(capi.OPT_FRAME_BATCH, batch)
+        bufs, s = queued(lambda cam: (_params(cam, flags=capi.RENDER_ASYNC), False), 16)
+        assert 0 < s["sort_records"] < s["n_sorted"], s                     # the sorts were partial
+        for k, x0, x1, b in bufs:
+            got = b.cpu().numpy().reshape(h, w, 4)
+            assert np.array_equal(got, want[k]), (batch, k)
+            if oracle_strip and k == 0:
+                pix_check("near-only queued frame (batch %d), strip vs oracle" % batch, got[:, oracle_strip[0]:oracle_strip[1]], oracle_strip[2])
+    c.set_option(capi.OPT_FRAME_BATCH, 1)
+    for x0, x1 in strips:                                                  # what one of several GPUs does
+        bufs, s = queued(lambda cam: (_params(cam, x0=x0, x1=x1, flags=capi.RENDER_ASYNC), True), 12)
+        print("near-only strip [%d,%d): sort records %d of %d kept" % (x0, x1, s["sort_records"], s["n_sorted"]))
+        for k, a, b_, b in bufs:
+            assert np.array_equal(b.cpu().numpy().reshape(h, x1 - x0, 4), want[k][:, x0:x1]), (k, x0, x1)
+
+
+@pytest.mark.skipif(os.environ.get("GS_SKIP_SLOW") == "1", reason="large configs")
+def test_near_only_sorts_by_default_six_million_splats():
+    """6,291,456 splats at 1920x1080 (no cutout: every splat in front of the camera is kept), GS_OPT_SORT_NEAR left at its
+    default: near-only sorts start by themselves once the share has settled"""
+    rows = synth.make_splat_rows(synth.N_BICYCLE, seed=synth.SEED_BASE + 3)
+    cams = [synth.index_html_camera(1920, 1080, y, capi=capi) for y in (50.0, 51.5, 53.0)]
+    with capi.Context(0) as c:
+        r = rows.reshape(-1, 32)
+        for a in range(0, r.shape[0], 1 << 22):
+            c.push_splat(r[a:a + (1 << 22)])
+        _near_only_frames_equal(c, cams, [None] * len(cams), strips=((0, 240), (960, 1200)))
 
 
 def test_scene_depth_and_colour_compositing(ctx, scene_small):
@@ -1266,6 +1363,54 @@ def test_asynchronous_host_frames_equal_synchronous_ones(scene_small):
         prm = _params(cams[1], flags=capi.RENDER_ASYNC)
         assert c._L.gs_render(c._h, ctypes.byref(prm), strip.ctypes.data_as(ctypes.c_void_p), 16) == capi.E_BADARG
         c.sync()
+        for _, o in pinned:
+            o.free()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", [1, 2])
+def test_blend_writes_page_locked_frames_directly(scene_small, mode):
+    """GS_OPT_HOST_WRITE: the blend kernel stores its tiles straight into a page-locked host frame (tight, strided as a column
+    strip of a wider frame, flipped, paired asynchronous frames) -- the same bytes as the copied frame; pageable memory is
+    still copied"""
+    w, h = 640, 360
+    cams = [synth.index_html_camera(w, h, y, capi=capi) for y in (0.0, 100.0, 200.0, 300.0)]
+    with capi.Context(0) as c:
+        c.push_splat(scene_small["rows"])
+        want = []
+        for cam in cams:
+            c.sort(cam["view"]); want.append(c.render(_params(cam)))
+        c.set_option(capi.OPT_HOST_WRITE, mode)
+        pinned = [capi.host_frame(h, w) for _ in cams]
+        for cam, (buf, _), wnt in zip(cams, pinned, want):                   # synchronous
+            buf[...] = 9
+            c.sort(cam["view"], want_indices=False)
+            c.render_into(_params(cam), buf)
+            assert np.array_equal(buf, wnt)
+        c.sort(cams[1]["view"], want_indices=False)
+        c.render_into(_params(cams[1], flags=capi.RENDER_FLIP_Y), pinned[1][0])
+        assert np.array_equal(pinned[1][0], want[1][::-1])
+        pageable = np.full((h, w, 4), 3, np.uint8)
+        c.render_into(_params(cams[1]), pageable)
+        assert np.array_equal(pageable, want[1])
+        # column strips of ONE wide page-locked frame, each written with the frame's row stride (what gs_multi_render does)
+        whole, own = capi.host_frame(h, w)
+        whole[...] = 5
+        c.sort(cams[2]["view"], want_indices=False)
+        for x0, x1 in ((0, 208), (208, 432), (432, 640)):
+            c.render_into(_params(cams[2], x0=x0, x1=x1), whole[:, x0:x1])
+        assert np.array_equal(whole, want[2])
+        own.free()
+        c.set_option(capi.OPT_FRAME_BATCH, 2)                              # asynchronous, paired
+        for (buf, _) in pinned:
+            buf[...] = 9
+        for rep in range(3):
+            for cam, (buf, _) in zip(cams, pinned):
+                c.sort(cam["view"], want_indices=False)
+                c.render_into(_params(cam, flags=capi.RENDER_ASYNC), buf)
+            c.sync()
+        for (buf, _), wnt in zip(pinned, want):
+            assert np.array_equal(buf, wnt)
         for _, o in pinned:
             o.free()
 

@@ -16,7 +16,7 @@ import threading
 import numpy as np
 import pytest
 
-from conftest import pkg
+from conftest import cached_rows, pkg
 
 pytestmark = pytest.mark.gpu
 capi = pkg("capi")
@@ -249,7 +249,7 @@ def test_c5_size_twenty_million_splats_4k_over_eight_ranks():
     """C5's size: 20 M splats @ 3840x2160 in eight column strips of 480 pixels (8-byte pair records, the long radix geometry,
     near-only strip sorts once the share has settled), gathered on rank 0 -- against one context's frame"""
     n = 20 * (1 << 20)
-    rows = synth.make_splat_rows_fast(n)
+    rows = cached_rows("make_splat_rows_fast", n)
     w, h = 3840, 2160
     cams = [synth.index_html_camera(w, h, y, capi=capi) for y in (33.0, 35.0)]
     want = [f[0] for f in _single_frames(rows, cams, lambda cam: [_params(cam)])]

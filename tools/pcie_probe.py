@@ -1,0 +1,115 @@
+#!/usr/bin/env python3
+"""Where does a frame's way to the host go?  (a synchronous 8.3 MB read-back cost 1.25 ms on the driver's box.)
+Prints the GPU's PCI address and NUMA node, the node page-locked memory lands on (hipHostMalloc vs mmap + mbind +
+hipHostRegister), the device-to-host copy rate of each for 1 GiB and for one 1920x1080 frame (8.3 MB), synchronous and
+asynchronous forms, tight and strided 2-D.  Measurement aid: python tools/pcie_probe.py > gpurun_out/pcie_probe.txt"""
+import ctypes as C
+import ctypes.util
+import os
+import time
+
+hip = C.CDLL("libamdhip64.so")
+libc = C.CDLL(ctypes.util.find_library("c"), use_errno=True)
+libc.mmap.restype = C.c_void_p
+libc.mmap.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_long]
+libc.syscall.restype = C.c_long
+SYS_mbind, SYS_move_pages = 237, 279
+FRAME = 1920 * 1080 * 4
+
+
+def ck(rc, what):
+    if rc != 0:
+        raise RuntimeError("%s -> %d" % (what, rc))
+
+
+def gpu_numa():
+    buf = C.create_string_buffer(64)
+    ck(hip.hipDeviceGetPCIBusId(buf, 64, 0), "hipDeviceGetPCIBusId")
+    bdf = buf.value.decode().lower()
+    node = None
+    for cand in (bdf, "0000:" + bdf if bdf.count(":") == 1 else bdf):
+        p = "/sys/bus/pci/devices/%s/numa_node" % cand
+        if os.path.exists(p):
+            node = int(open(p).read().strip()); break
+    return bdf, node
+
+
+def page_nodes(ptr, nbytes, samples=8):
+    """NUMA node of a few pages of [ptr, ptr + nbytes) (move_pages with nodes = NULL only queries)"""
+    n = samples
+    pages = (C.c_void_p * n)(*[ptr + (i * (nbytes // n) // 4096) * 4096 for i in range(n)])
+    status = (C.c_int * n)()
+    rc = libc.syscall(SYS_move_pages, 0, C.c_ulong(n), pages, None, status, 0)
+    return list(status) if rc == 0 else "move_pages errno %d" % C.get_errno()
+
+
+def d2h_rates(dev, host, tag):
+    e0, e1 = C.c_void_p(), C.c_void_p()
+    hip.hipEventCreate(C.byref(e0)); hip.hipEventCreate(C.byref(e1))
+    ms = C.c_float(0)
+    out = {}
+    for name, nbytes, reps in (("1GiB", 1 << 30, 3), ("frame8MB", FRAME, 50)):
+        hip.hipMemcpyAsync(C.c_void_p(host), dev, C.c_size_t(nbytes), 2, None); hip.hipDeviceSynchronize()
+        hip.hipEventRecord(e0, None)
+        for _ in range(reps):
+            hip.hipMemcpyAsync(C.c_void_p(host), dev, C.c_size_t(nbytes), 2, None)
+        hip.hipEventRecord(e1, None); hip.hipEventSynchronize(e1)
+        hip.hipEventElapsedTime(C.byref(ms), e0, e1)
+        out["async_" + name + "_GBps"] = round(nbytes * reps / (ms.value * 1e-3) / 1e9, 2)
+    # what a synchronous gs_render pays: one blocking copy of a frame, wall clock
+    for name, fn in (("hipMemcpy", lambda: hip.hipMemcpy(C.c_void_p(host), dev, C.c_size_t(FRAME), 2)),
+                     ("hipMemcpyAsync+sync", lambda: (hip.hipMemcpyAsync(C.c_void_p(host), dev, C.c_size_t(FRAME), 2, None), hip.hipStreamSynchronize(None))),
+                     ("hipMemcpy2D tight", lambda: hip.hipMemcpy2D(C.c_void_p(host), C.c_size_t(7680), dev, C.c_size_t(7680), C.c_size_t(7680), C.c_size_t(1080), 2)),
+                     ("hipMemcpy2DAsync strip 480px stride 7680", lambda: (hip.hipMemcpy2DAsync(C.c_void_p(host), C.c_size_t(7680), dev, C.c_size_t(1920), C.c_size_t(1920), C.c_size_t(1080), 2, None), hip.hipStreamSynchronize(None)))):
+        fn()
+        t0 = time.perf_counter()
+        for _ in range(50):
+            fn()
+        out["sync_ms_" + name] = round((time.perf_counter() - t0) / 50 * 1e3, 4)
+    print(tag, out)
+    hip.hipEventDestroy(e0); hip.hipEventDestroy(e1)
+
+
+def main():
+    ck(hip.hipSetDevice(0), "hipSetDevice")
+    bdf, node = gpu_numa()
+    nodes = sorted(d for d in os.listdir("/sys/devices/system/node") if d.startswith("node")) if os.path.isdir("/sys/devices/system/node") else []
+    print("gpu", bdf, "numa_node", node, "| host nodes", nodes, "| cpus", os.cpu_count(), "| this thread may run on", sorted(os.sched_getaffinity(0))[:4], "...")
+    dev = C.c_void_p()
+    ck(hip.hipMalloc(C.byref(dev), C.c_size_t(1 << 30)), "hipMalloc")
+    n = 1 << 30
+    # 1. hipHostMalloc
+    p = C.c_void_p()
+    ck(hip.hipHostMalloc(C.byref(p), C.c_size_t(n), 0), "hipHostMalloc")
+    C.memset(p, 1, n)
+    print("hipHostMalloc pages on nodes", page_nodes(p.value, n))
+    d2h_rates(dev, p.value, "hipHostMalloc:")
+    hip.hipHostFree(p)
+    # 2. pageable (what a caller without gs_host_alloc hands over)
+    q = libc.mmap(None, n, 3, 0x22, -1, 0)
+    C.memset(q, 1, n)
+    d2h_rates(dev, q, "pageable:")
+    # 3. mmap + mbind(gpu node) + hipHostRegister
+    for want in ([node] if node is not None and node >= 0 else []) + [None]:
+        r = libc.mmap(None, n, 3, 0x22, -1, 0)
+        if want is not None:
+            mask = (C.c_ulong * 16)()
+            mask[want // 64] = 1 << (want % 64)
+            rc = libc.syscall(SYS_mbind, C.c_void_p(r), C.c_ulong(n), 2, mask, C.c_ulong(1024), 0)        # MPOL_BIND
+            print("mbind ->", rc, "errno", C.get_errno() if rc else 0)
+        C.memset(r, 1, n)
+        rc = hip.hipHostRegister(C.c_void_p(r), C.c_size_t(n), 0)
+        print("registered (bound to node %s): rc %d, pages on nodes %s" % (want, rc, page_nodes(r, n)))
+        if rc == 0:
+            d2h_rates(dev, r, "mmap+register(node %s):" % want)
+            hip.hipHostUnregister(C.c_void_p(r))
+    # 4. a kernel-side view: does the device see hipHostMalloc memory directly?
+    attr = (C.c_byte * 128)()
+    p2 = C.c_void_p()
+    hip.hipHostMalloc(C.byref(p2), C.c_size_t(FRAME), 0)
+    dp = C.c_void_p()
+    print("hipHostGetDevicePointer rc", hip.hipHostGetDevicePointer(C.byref(dp), p2, 0), "same address:", dp.value == p2.value)
+
+
+if __name__ == "__main__":
+    main()
