@@ -21,11 +21,15 @@ ap.add_argument("--split", type=int, default=0, help="GS_OPT_BLEND_SPLIT")
 ap.add_argument("--term", type=int, default=0, help="GS_OPT_TERMINATION (1/eps)")
 ap.add_argument("--batch", type=int, default=1, help="GS_OPT_FRAME_BATCH")
 ap.add_argument("--sort-near", type=int, default=None, help="GS_OPT_SORT_NEAR (0 off, 1 auto = the library's default, 2 always)")
+ap.add_argument("--opacity-div", type=int, default=1, help="divide every splat's opacity byte by this (10: the scene whose tiles do not saturate)")
+ap.add_argument("--no-early-out", action="store_true", help="GS_RENDER_NO_EARLY_OUT: every fragment blended")
 ap.add_argument("--strip", default=None, help="k/G: render only strip k of G tile-aligned column strips (what one of G GPUs does)")
 ap.add_argument("--sort-for", action="store_true", help="with --strip: gs_sort_for the strip instead of the full gs_sort")
 a = ap.parse_args()
 W, H = (int(v) for v in a.size.lower().split("x"))
 rows = synth.make_splat_rows_fast(a.splats) if a.splats >= (8 << 20) else synth.make_splat_rows(a.splats)
+if a.opacity_div > 1:
+    rows = rows.reshape(-1, 32).copy(); rows[:, 27] = rows[:, 27] // a.opacity_div; rows = rows.reshape(-1)
 pose = synth.cutout_demo_camera if a.cutout else synth.index_html_camera
 cams = [pose(W, H, 3.0 * i, capi=capi) for i in range(120)]
 x0, x1 = 0, W
@@ -58,7 +62,7 @@ def go(n):
         else:
             ctx.sort(cams[k]["view"], cams[k]["cutout"], want_indices=False)
         if not a.sort_only:
-            params[k].flags = capi.RENDER_ASYNC
+            params[k].flags = capi.RENDER_ASYNC | (capi.RENDER_NO_EARLY_OUT if a.no_early_out else 0)
             ctx.render_device(params[k], None)
     try:
         ctx.sync()
