@@ -76,6 +76,14 @@ def library_path():
     return _build.LIB
 
 
+def _hip_runtime_mapped():
+    try:
+        with open("/proc/self/maps") as f:
+            return any("libamdhip64" in line for line in f)
+    except OSError:
+        return False
+
+
 def load(build_if_missing=True):
     """dlopen the HIP library (building it first if absent and a compiler is present)."""
     global _lib
@@ -85,13 +93,19 @@ def load(build_if_missing=True):
         if not build_if_missing:
             raise FileNotFoundError(_build.LIB + " not built; run __graft_entry__.build()")
         _build.build_lib()
-    # A process that also uses torch must load torch's HIP runtime first: the wheel ships its own libamdhip64 / libhsa-runtime64 under
-    # the same sonames as /opt/rocm's, the first one loaded serves both, and torch finds no GPU through the other one
-    # ("No HIP GPUs are available").  Only matters where torch is installed; the library itself does not need it.
-    if "torch" not in sys.modules and os.environ.get("GS_SPLAT_NO_TORCH_PRELOAD") is None:
+    # A process that also uses torch must have torch's HIP runtime loaded first: the wheel ships its own libamdhip64 /
+    # libhsa-runtime64 under the same sonames as /opt/rocm's, the first one loaded serves both, and torch finds no GPU through the
+    # other one ("No HIP GPUs are available").  Loading that ONE shared object is enough -- importing torch (1-2 s, hundreds of MB)
+    # is not a ctypes loader's business; nothing happens when no torch is installed, when a HIP runtime is already mapped, or with
+    # GS_SPLAT_NO_TORCH_PRELOAD set.
+    if "torch" not in sys.modules and os.environ.get("GS_SPLAT_NO_TORCH_PRELOAD") is None and not _hip_runtime_mapped():
         try:
-            import torch  # noqa: F401
-        except ImportError:
+            import importlib.util
+            spec = importlib.util.find_spec("torch")
+            cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so") if spec and spec.origin else None
+            if cand and os.path.exists(cand):
+                C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except (ImportError, OSError, ValueError):
             pass
     # GS_SPLAT_LIB: load another build of the same library (A/B measurements of kernel variants); never a different backend
     L = C.CDLL(os.environ.get("GS_SPLAT_LIB") or _build.LIB)

@@ -15,6 +15,19 @@ timeout 900 python bench.py --splats 6291456 --cutout --no-cpu-baseline --no-ext
 timeout 600 python bench.py --xr --no-cpu-baseline > $O/config_c4.json 2>/dev/null
 timeout 900 python bench.py --splats 20971520 --size 3840x2160 --steps 120 --no-cpu-baseline --no-extras > $O/config_c5.json 2>/dev/null
 GS_BENCH_COMM=1 timeout 600 python bench.py --no-cpu-baseline --no-extras > $O/bench_comm_world1.json 2>/dev/null
+# ONE host process driving several "devices" (gs_create_multi; on a one-GPU box they share the GPU: the path, not the scaling)
+for n in 1 2 8; do
+  timeout 300 python bench.py --gpus $n --single-process > $O/single_process_device_$n.json 2>/dev/null
+  timeout 300 python bench.py --gpus $n --single-process --host-direct > $O/single_process_host_$n.json 2>/dev/null
+done
+timeout 600 python bench.py --gpus 8 --single-process --splats 20971520 --size 3840x2160 --steps 120 > $O/single_process_device_8_c5.json 2>/dev/null
+for f in $O/single_process_*.json; do python -c "
+import json,sys
+try:
+    d=json.load(open('$f')); print('$f'.split('/')[-1], d['value'], d['config']['frame_equals_single_context_render'], d.get('host_frame_GBps'))
+except Exception as e: print('$f FAILED', e)"; done
+timeout 120 python tools/pcie_probe.py > $O/pcie_probe.txt 2>&1
+( cd tools/micro && hipcc --offload-arch=gfx950 -O3 -o graph_rate graph_rate.hip 2>/dev/null; timeout 120 ./graph_rate ) > $O/graph_rate.txt 2>&1
 for f in config_c1 config_c3 config_c4 config_c5 bench_comm_world1 bench_steps20; do python -c "
 import json,sys
 try:
