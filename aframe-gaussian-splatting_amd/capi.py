@@ -84,6 +84,21 @@ def _hip_runtime_mapped():
         return False
 
 
+def hip_runtime():
+    """ctypes handle of the HIP runtime THIS process has mapped (the one libgs_splat_hip.so talks to): for helpers that call
+    hipMalloc / hipMemcpy next to the library (tests, bench.py).  dlopen("libamdhip64.so") by NAME may pick another copy than
+    the one already loaded by path (torch's wheel and /opt/rocm both ship one), and memory from one is no use to the other."""
+    load()
+    try:
+        with open("/proc/self/maps") as f:
+            for line in f:
+                if "libamdhip64" in line and "/" in line:
+                    return C.CDLL(line[line.index("/"):].strip())
+    except OSError:
+        pass
+    return C.CDLL("libamdhip64.so")
+
+
 def load(build_if_missing=True):
     """dlopen the HIP library (building it first if absent and a compiler is present)."""
     global _lib

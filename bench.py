@@ -289,8 +289,8 @@ def main():
     if args.steps < 240:
         sync()
         ts = time.perf_counter()
-        for i in range(480):
-            frame(args.warmup + i, capi.RENDER_ASYNC)
+        for i in range(480):                                 # (the region's own poses, over and over: the share is settled for exactly those)
+            frame(args.warmup + (i % args.steps), capi.RENDER_ASYNC)
         if not sync():
             steady_fps = 480 / (time.perf_counter() - ts)
         if world > 1:
@@ -795,10 +795,7 @@ def measured_copy_peak(ctx, capi, nbytes=1 << 30, reps=5):
     hipMemcpyDtoDAsync of a 1 GiB buffer, HIP events around `reps` copies.  The quoted HBM peak stays the 8 TB/s spec."""
     import ctypes as C
     try:
-        try:
-            hip = C.CDLL("libamdhip64.so")
-        except OSError:
-            hip = C.CDLL("/opt/rocm/lib/libamdhip64.so")
+        hip = capi.hip_runtime()
         a, b, e0, e1 = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
         if hip.hipMalloc(C.byref(a), C.c_size_t(nbytes)) or hip.hipMalloc(C.byref(b), C.c_size_t(nbytes)):
             return None
@@ -823,10 +820,7 @@ def measured_pcie_peak(capi, nbytes=1 << 30, reps=3):
     (gs_host_alloc), HIP events around `reps` copies: the denominator of host_readback.frac_of_pcie."""
     import ctypes as C
     try:
-        try:
-            hip = C.CDLL("libamdhip64.so")
-        except OSError:
-            hip = C.CDLL("/opt/rocm/lib/libamdhip64.so")
+        hip = capi.hip_runtime()
         L = capi.load()
         host = L.gs_host_alloc(nbytes)
         a, e0, e1 = C.c_void_p(), C.c_void_p(), C.c_void_p()

@@ -1144,7 +1144,7 @@ def test_gathered_frames_through_rccl_world1(scene_small):
         assert np.array_equal(c.read_gathered(0, l["vw"], l["vh"]), wl) and np.array_equal(c.read_gathered(1, r["vw"], r["vh"]), wr)
         # pipelined: frames enqueued back to back over the lanes, gathers issued in frame order by the lanes' workers; the
         # caller's own device frames receive the images
-        hip = ctypes.CDLL("libamdhip64.so")
+        hip = capi.hip_runtime()
         bufs = []
         for _ in cams:
             p = ctypes.c_void_p()

@@ -95,7 +95,7 @@ class Ranks:
 
 class DevBuf:
     def __init__(self, nbytes):
-        self.hip = ctypes.CDLL("libamdhip64.so")
+        self.hip = capi.hip_runtime()
         self.p = ctypes.c_void_p()
         self.n = nbytes
         assert self.hip.hipMalloc(ctypes.byref(self.p), ctypes.c_size_t(nbytes)) == 0

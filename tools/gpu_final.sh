@@ -5,11 +5,15 @@
 TAG=${1:-rXX}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/final_$TAG; mkdir -p $O; cd $R
+# PART=profiles: only the bench lines, the kernel traces and the counter passes (no test tier, no other configurations)
+if [ "$PART" != "profiles" ]; then
 rm -f gpurun_out/pixel_parity.jsonl
 timeout 1200 python -m pytest tests -m gpu -q -s > $O/pytest.log 2>&1; echo "pytest rc=$?" | tee -a $O/pytest.log; grep -E "passed|failed" $O/pytest.log | tail -1
 cp gpurun_out/pixel_parity.jsonl $O/ 2>/dev/null; cp gpurun_out/js_visible_fps.txt $O/ 2>/dev/null
+fi
 timeout 900 python bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"; cut -c 1-240 $O/bench.json
 timeout 600 python bench.py --steps 20 --warmup 5 > $O/bench_steps20.json 2>/dev/null
+if [ "$PART" != "profiles" ]; then
 timeout 600 python bench.py --size 1280x720 --no-cpu-baseline --no-extras > $O/config_c1.json 2>/dev/null
 timeout 900 python bench.py --splats 6291456 --cutout --no-cpu-baseline --no-extras > $O/config_c3.json 2>/dev/null
 timeout 600 python bench.py --xr --no-cpu-baseline > $O/config_c4.json 2>/dev/null
@@ -20,12 +24,12 @@ for n in 1 2 8; do
   timeout 300 python bench.py --gpus $n --single-process > $O/single_process_device_$n.json 2>/dev/null
   timeout 300 python bench.py --gpus $n --single-process --host-direct > $O/single_process_host_$n.json 2>/dev/null
 done
-timeout 600 python bench.py --gpus 8 --single-process --splats 20971520 --size 3840x2160 --steps 120 > $O/single_process_device_8_c5.json 2>/dev/null
 for f in $O/single_process_*.json; do python -c "
 import json,sys
 try:
     d=json.load(open('$f')); print('$f'.split('/')[-1], d['value'], d['config']['frame_equals_single_context_render'], d.get('host_frame_GBps'))
 except Exception as e: print('$f FAILED', e)"; done
+fi
 timeout 120 python tools/pcie_probe.py > $O/pcie_probe.txt 2>&1
 ( cd tools/micro && hipcc --offload-arch=gfx950 -O3 -o graph_rate graph_rate.hip 2>/dev/null; timeout 120 ./graph_rate ) > $O/graph_rate.txt 2>&1
 for f in config_c1 config_c3 config_c4 config_c5 bench_comm_world1 bench_steps20; do python -c "

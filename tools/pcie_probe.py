@@ -8,7 +8,9 @@ import ctypes.util
 import os
 import time
 
-hip = C.CDLL("libamdhip64.so")
+import importlib, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+hip = importlib.import_module("aframe-gaussian-splatting_amd.capi").hip_runtime()
 libc = C.CDLL(ctypes.util.find_library("c"), use_errno=True)
 libc.mmap.restype = C.c_void_p
 libc.mmap.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_long]
