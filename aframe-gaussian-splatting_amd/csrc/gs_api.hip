@@ -944,6 +944,29 @@ static int sort_common(gs_ctx *ctx, const float view[4], const float *cutout16, 
     return GS_OK;
 }
 
+int gs_sort_by_call(gs_ctx *ctx, const float view[4], const float *cutout16, void *call_p)
+{
+    CHECK_CTX(ctx);
+    std::function<int(gs_ctx *)> &call = *static_cast<std::function<int(gs_ctx *)> *>(call_p);
+    GS_HIP(hipSetDevice(ctx->device));
+    gs_ctx *L = nullptr;
+    int rot = 0;
+    const int lane = next_frame_lane(ctx, &rot, false);
+    TRY(get_lane(ctx, lane, &L));
+    ctx->cur = lane; ctx->rot = rot; ctx->cur_async = false;
+    log_sort(L, view, cutout16, nullptr);
+    log_undecidable(L);                                            // (the other ranks are part of this frame's sort)
+    L->have_sort = true;
+    if (ctx->enqueue_threads && gs_rotates(ctx) && !ctx->user_stream) {
+        GsLaneCmd c;
+        c.type = 2; c.has_cutout = false; c.has_strip = false; c.device_rgba = nullptr; c.host_rgba = nullptr; c.stride = 0; c.call = call;
+        if (lane_push(L, c) == GS_OK) return GS_OK;                // (not a frame's end: the rotation is decided by its render)
+    }
+    const int rc = lane_rc(ctx, L, lane_drain(L));                 // run here, whatever came before: the other ranks wait for this exchange
+    const int rc2 = lane_rc(ctx, L, call(L));
+    return rc != GS_OK ? rc : rc2;
+}
+
 int gs_fill_uniforms(gs_ctx *ctx /* owner: options, adaptive share, scene */, const gs_render_params *p, GsFrameUniforms &u)
 {
     if (!p) FAIL(GS_E_BADARG, "render params NULL");
@@ -1359,6 +1382,12 @@ GS_API int gs_set_option(gs_ctx *ctx, int option, int64_t value)
         GS_HIP(hipSetDevice(ctx->device));
         TRY(drain_all(ctx));
         return gs_comm_set_self_copy(ctx, value != 0);
+    case GS_OPT_SORT_SHARE:
+        if (value < 0 || value > 1000) FAIL(GS_E_BADARG, "sort share: 0 (off) or the permille of the splats whose order the ranks exchange");
+        GS_HIP(hipSetDevice(ctx->device));
+        TRY(drain_all(ctx));
+        ctx->sort_share_permille = (int)value;
+        return GS_OK;
     case GS_OPT_HOST_WRITE:
         if (value < 0 || value > 2) FAIL(GS_E_BADARG, "host write: 0 (copy engine), 1 (the blend writes page-locked frames itself) or 2 (synchronous frames only)");
         ctx->host_write = (int)value;

@@ -53,6 +53,7 @@ struct GsComm {
     std::mutex m;                                                  // tickets: gathers are issued in frame order, one at a time
     std::condition_variable cv;
     uint64_t next_ticket = 0, next_issue = 0;
+    uint64_t share_seq = 0;                                        // frames sorted through GS_OPT_SORT_SHARE so far: frame f belongs to rank f mod world
 };
 
 #define FAILC(code, ...) do { snprintf(GS_ERRBUF(ctx), GS_ERRLEN, __VA_ARGS__); return (code); } while (0)
@@ -411,6 +412,60 @@ int issue_gather(gs_ctx *L, const GatherJob &j)
     return GS_OK;
 }
 
+// ---- GS_OPT_SORT_SHARE: the ranks take turns sorting.  The owner of a frame runs the ordinary near-only sort of the whole view
+// (gs_run_sort: the same kernels, hence the same order on whoever runs it) and sends two messages to every peer -- the head of its
+// control block (min / max, V, the record count P', V': what the projection needs to address the order) and the first `cap`
+// records of the order; a peer receives them where its own sort would have written them.  One send per peer, each over its own
+// xGMI link; the messages have a fixed size (the host does not know P'), and an order that does not fit is flagged, not truncated
+// silently.
+#define GS_SHARE_HEAD offsetof(GsControl, n_visible)
+
+__global__ void k_share_check(GsControl *ctl, uint32_t cap)
+{
+    if (ctl->n_sorted > cap) { ctl->n_sorted = cap; ctl->round1_missed = 1; }   // the frame is drawn from a truncated order: reported (GS_E_RETRY)
+}
+
+struct ShareJob {
+    float view[4], cutout[16]; bool has_cutout;
+    uint32_t near_req, cap; int owner; uint64_t ticket;
+};
+
+int issue_shared_sort(gs_ctx *L, const ShareJob &j)
+{
+    gs_ctx *ctx = L;
+    GsComm *c = gs_root(L)->comm;
+    const bool mine = c->rank == j.owner;
+    int rc = GS_OK;
+    if (mine) rc = gs_run_sort(L, j.view, j.has_cutout ? j.cutout : nullptr, nullptr, j.near_req);
+    else gs_remember_sort(L, j.view, j.has_cutout ? j.cutout : nullptr, nullptr, j.near_req);   // (what a fall-back to a whole local sort starts from)
+    { std::unique_lock<std::mutex> lk(c->m); c->cv.wait(lk, [&] { return c->next_issue == j.ticket; }); }
+    {   // whatever happened to the owner's sort, the exchange is issued: the peers wait for it
+        ncclResult_t r = c->GroupStart();
+        if (mine) {
+            for (int p = 0; r == 0 && p < c->world; p++) {
+                if (p == c->rank) continue;
+                r = c->Send(L->ctl, GS_SHARE_HEAD, gsNcclUint8, p, c->comm, L->stream);
+                if (r == 0) r = c->Send(L->val_a, (size_t)j.cap * 4, gsNcclUint8, p, c->comm, L->stream);
+            }
+        } else {
+            r = c->Recv(L->ctl, GS_SHARE_HEAD, gsNcclUint8, j.owner, c->comm, L->stream);
+            if (r == 0) r = c->Recv(L->val_a, (size_t)j.cap * 4, gsNcclUint8, j.owner, c->comm, L->stream);
+        }
+        const ncclResult_t r2 = c->GroupEnd();
+        if ((r != 0 || r2 != 0) && rc == GS_OK) {
+            snprintf(GS_ERRBUF(ctx), GS_ERRLEN, "%s exchange of the shared sort failed: %s", c->loop ? "in-process" : "RCCL", c->GetErrorString(r != 0 ? r : r2));
+            rc = GS_E_HIP;
+        }
+    }
+    { std::lock_guard<std::mutex> lk(c->m); c->next_issue++; }
+    c->cv.notify_all();
+    if (!mine) {
+        L->sorted = L->val_a; L->have_sort = true;
+        hipLaunchKernelGGL(k_share_check, dim3(1), dim3(1), 0, L->stream, L->ctl, j.cap);   // (the owner holds its whole order)
+    }
+    return rc;
+}
+
 }  // namespace
 
 void gs_comm_free_lane(gs_ctx *lane)
@@ -554,6 +609,23 @@ GS_API int gs_sort_gathered(gs_ctx *ctx, const float view[4], const float *cutou
     gs_piece pcs[128];
     const int np = gs_partition(nviews, widths, world, pcs, 128);
     if (np < 0) FAILC(GS_E_BADARG, "gs_sort_gathered: bad frame sizes or more than 128 pieces");
+    // GS_OPT_SORT_SHARE: the ranks take turns sorting (frame f: rank f mod world) and exchange the nearest part of the order
+    if (world > 1 && ctx->sort_share_permille > 0 && ctx->n > 0 && ctx->n <= ((size_t)1 << 25) && !ctx->wide_pairs && ctx->renderable) {
+        ShareJob j;
+        memcpy(j.view, view, sizeof j.view);
+        j.has_cutout = cutout16 != nullptr;
+        if (cutout16) memcpy(j.cutout, cutout16, sizeof j.cutout);
+        const double nr = ceil((double)ctx->sort_share_permille / 1000.0 * (double)ctx->n);
+        j.near_req = nr < 1 ? 1u : (uint32_t)nr;
+        // room for what the near-only rule lets through beyond near_req (the threshold is a whole depth-histogram bin and ties)
+        uint64_t cap = (uint64_t)j.near_req * 2u + 65536u;
+        if (cap > ctx->n) cap = ctx->n;
+        j.cap = (uint32_t)cap;
+        j.owner = (int)(c->share_seq++ % (uint64_t)world);
+        { std::lock_guard<std::mutex> lk(c->m); j.ticket = c->next_ticket++; }
+        std::function<int(gs_ctx *)> call = [j](gs_ctx *lane) { return issue_shared_sort(lane, j); };
+        return gs_sort_by_call(ctx, view, cutout16, &call);
+    }
     int mine = -1, count = 0;
     for (int i = 0; i < np; i++) if (pcs[i].owner == rank) { mine = i; count++; }
     if (count == 2) return gs_sort_two_views(ctx, view, cutout16);                // both eyes here: the whole order, once

@@ -198,6 +198,7 @@ struct gs_ctx {
     GsFrameLog *log;               // lane: the frames handed to it since the last gs_sync (caller's thread only)
     bool auto_retry;               // owner: GS_OPT_AUTO_RETRY
     int host_write;                // owner: GS_OPT_HOST_WRITE
+    int sort_share_permille;       // owner: GS_OPT_SORT_SHARE (0 = every rank sorts every frame)
     bool log_stale;                // owner: the resident data / scene changed under frames that are still in the logs
     gs_stats stats;
 };
@@ -287,6 +288,8 @@ static __host__ __device__ __forceinline__ uint32_t gs_radix_row_stride(uint32_t
 int gs_launch_pack(gs_ctx *ctx, const uint4 *rows_dev, size_t first, size_t nrows);
 // ---- gs_sort.hip
 int gs_run_sort(gs_ctx *ctx, const float view[4], const float *cutout16, const GsSortStrip *strip = nullptr, uint32_t near_req = 0);
+// what the lane's order was made from and how much of it exists (a render that needs more sorts again in full by itself)
+void gs_remember_sort(gs_ctx *L, const float view[4], const float *cutout16, const GsSortStrip *strip, uint32_t near_req);
 int gs_run_sort2(gs_ctx *const S[2], const float *const view[2], const float *const cutout16[2], const GsSortStrip *const strip[2], const uint32_t near_req[2]);   // two frames per launch
 // ---- gs_render.hip
 int gs_run_render(gs_ctx *ctx, const GsFrameUniforms &u, uint8_t *device_out);
@@ -308,6 +311,9 @@ extern "C" int gs_render_uniforms(gs_ctx *ctx, const GsFrameUniforms &u, void *d
 void gs_comm_free_lane(gs_ctx *lane);
 int gs_comm_set_self_copy(gs_ctx *ctx, bool on);
 int gs_comm_set_transport(gs_ctx *ctx, int transport);
+// begin a frame on its lane like gs_sort() does (lane rotation, frame log) and run `call` where the sort's kernels would be
+// enqueued: the frame's order comes from -- or goes to -- the other ranks (gs_comm.hip, GS_OPT_SORT_SHARE)
+extern "C" int gs_sort_by_call(gs_ctx *ctx, const float view[4], const float *cutout16, void *call /* std::function<int(gs_ctx *)> * */);
 int gs_ensure_pair_capacity(gs_ctx *ctx, size_t pairs);
 int gs_ensure_radix_scratch(gs_ctx *ctx, size_t items);         // histogram / totals scratch for a radix sort of `items` records
 // event k (0..GS_PROF_EVENTS-1) of the current profiling slot, or nullptr when profiling is off

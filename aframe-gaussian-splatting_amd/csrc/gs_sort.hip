@@ -378,7 +378,7 @@ template <int NW, bool COMPACT, bool NEAR> GS_BODY(F_sort_bucket, k_sort_bucket_
 static void fill_sort_uniforms(const gs_ctx *ctx, const float view[4], const float *cutout16, const GsSortStrip *strip, SortUniforms &u, StripUniforms &su);
 
 // what the lane's order was made from and how much of it exists (the render re-sorts in full if it turns out to need more)
-static void remember_sort(gs_ctx *L, const float view[4], const float *cutout16, const GsSortStrip *strip, uint32_t near_req)
+void gs_remember_sort(gs_ctx *L, const float view[4], const float *cutout16, const GsSortStrip *strip, uint32_t near_req)
 {
     memcpy(L->sv_view, view, sizeof L->sv_view);
     L->sv_has_cutout = cutout16 != nullptr;
@@ -421,7 +421,7 @@ int gs_run_sort2(gs_ctx *const S[2], const float *const view[2], const float *co
     const bool compact = !ctx->wide_pairs && n <= (1u << 25);
     const bool near = compact && near_req && near_req[0] && near_req[1];   // (a pair takes one path)
     DepthHist dh[2];
-    for (int k = 0; k < 2; k++) { remember_sort(S[k], view[k], cutout16[k], strip ? strip[k] : nullptr, near ? near_req[k] : 0u); dh[k] = next_depth_hist(S[k], near); }
+    for (int k = 0; k < 2; k++) { gs_remember_sort(S[k], view[k], cutout16[k], strip ? strip[k] : nullptr, near ? near_req[k] : 0u); dh[k] = next_depth_hist(S[k], near); }
     const bool strips = u[0].has_strip && u[1].has_strip;
     if (!strips) u[0].has_strip = u[1].has_strip = 0;              // (a pair takes one path: both strip sorts, or both plain)
     const uint32_t g = gs_radix_grid(n);
@@ -517,7 +517,7 @@ int gs_run_sort(gs_ctx *ctx, const float view[4], const float *cutout16, const G
     // record format of the two passes: 4 bytes while the index fits in 25 bits (GS_OPT_WIDE_PAIRS forces the general form)
     const bool compact = !ctx->wide_pairs && n <= (1u << 25);
     const bool near = compact && near_req;
-    remember_sort(ctx, view, cutout16, strip, near ? near_req : 0u);
+    gs_remember_sort(ctx, view, cutout16, strip, near ? near_req : 0u);
     const DepthHist dh = next_depth_hist(ctx, near);
 
     const uint32_t g = gs_radix_grid(n);                         // same chunking as the radix kernels (pre-filled histogram rows)

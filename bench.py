@@ -95,6 +95,12 @@ def main():
         # list are blended by four wavefronts, one pixel per lane (GS_OPT_BLEND_SPLIT; images within the same 1 LSB tolerance)
         ctx.set_option(capi.OPT_BLEND_SPLIT, blend_split)
     gathered = world > 1 or comm1 or args.xr                 # frames go through gs_render_gathered
+    # GS_OPT_SORT_SHARE: with several ranks and a scene whose depth sort dominates a strip's frame (20 M splats: 230 of 290 us),
+    # the ranks take turns sorting and exchange the nearest 3 % of the order (GS_BENCH_SORT_SHARE=<permille> overrides; 0 = off).
+    # At 1 M splats every kernel of the sort sits on the launch floor and the exchange only costs: off.
+    sort_share = int(os.environ.get("GS_BENCH_SORT_SHARE", "30" if (world > 1 and n_splats >= (8 << 20) and not args.xr) else "0"))
+    if sort_share and world > 1:
+        ctx.set_option(capi.OPT_SORT_SHARE, sort_share)
     torch_gather = False                                     # fallback only: see below
     if world > 1:
         ok = 1
@@ -361,7 +367,7 @@ def main():
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": workload, "parallelism": par,
                        "pieces_of_rank0": [[v, x0, x1] for v, x0, x1 in mine], "gathered_frame_equals_single_gpu_render": frame_check,
-                       "blend_split_min_list": blend_split,
+                       "blend_split_min_list": blend_split, "sort_share_permille": sort_share if world > 1 else 0,
                        "frames_in_flight": ("%d (the library's 3 pipeline lanes%s: every frame still runs its own full sort, projection, "
                                             "binning and blend; consecutive frames overlap on the GPU); see latency.fps_depth1 for one frame at a time"
                                             % (3 * frame_batch, " x 2 frames per launch, GS_OPT_FRAME_BATCH: the two frames of a pair share each "
@@ -444,7 +450,12 @@ def single_process_main(args):
         r32 = rows.reshape(-1, 32)
         for o in range(0, n_splats, 1 << 22):
             m.push_splat(r32[o:o + (1 << 22)])
+        if os.environ.get("GS_BENCH_DEPTH"):
+            m.set_option(capi.OPT_PIPELINE_DEPTH, int(os.environ["GS_BENCH_DEPTH"]))
         m.set_option(capi.OPT_FRAME_BATCH, int(os.environ.get("GS_BENCH_BATCH", "2")))
+        share = int(os.environ.get("GS_BENCH_SORT_SHARE", "0"))     # GS_OPT_SORT_SHARE (permille): the devices take turns sorting
+        if share:
+            m.set_option(capi.OPT_SORT_SHARE, share)
 
         def frame(i, flags):
             k = i % ORBIT_FRAMES
@@ -506,7 +517,8 @@ def single_process_main(args):
                           "every device copies its strip straight into one page-locked host frame (no collective)" if ring else
                           "pieces gathered in HBM on the first device by the in-process transport (peer copies on the frames' streams)"),
                       "distinct_gpus": len(set(devs)), "frame_equals_single_context_render": ok, "timed_region_retries": retries,
-                      "frames_in_flight": "3 lanes x 2 frames per launch per device"},
+                      "sort_share_permille": share,
+                      "frames_in_flight": "%s lanes x %s frames per launch per device" % (os.environ.get("GS_BENCH_DEPTH", "3"), os.environ.get("GS_BENCH_BATCH", "2"))},
            "host_frame_GBps": round(fps * W * H * 4 * nv / 1e9, 2) if ring else None,
            "occlusion_binning": {"near_permille": s0["near_permille"]}}
     os.write(real_stdout, (json.dumps(out) + "\n").encode())

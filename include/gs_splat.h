@@ -287,6 +287,16 @@ GS_API int gs_multi_sync(gs_multi *m);
                                    counting render, round 1, gs_download of the order) sorts again in full by itself.  Sorts that
                                    return the order (out_idx / out_n) are always complete.  0: off; 1 (default): for scenes of
                                    4 M splats and more (below, the sort's passes are launch-bound); 2: always.               */
+#define GS_OPT_SORT_SHARE 15    /* several ranks (gs_sort_gathered), value = permille P of the splats, 0 = off (default).  The depth sort is the
+                                   part of a frame that does not shrink with a rank's strip: every rank keys and sorts all N splats of every
+                                   frame (at 20 M splats 230 of a strip frame's 290 us).  With P > 0 the ranks take turns: frame f is
+                                   sorted by rank f mod world alone -- a near-only sort of the nearest P/1000 * N splats of the WHOLE view,
+                                   the same kernels, hence the same order -- which sends it (a few MB, one send per peer, each over its own
+                                   xGMI link) to the others; those receive it where their own sort would have run.  Every rank then draws
+                                   its pieces from that order exactly as after gs_sort(): same pixels.  A frame that needs more of the
+                                   order than was exchanged (its first binning round reads more than P/1000 * N splats, or did not skip
+                                   the second one) sorts again in full locally, as after any near-only sort.  Set the same value on every
+                                   rank, before the frames; needs N <= 2^25.                                                        */
 #define GS_OPT_HOST_WRITE 14    /* how gs_render's frame reaches a PAGE-LOCKED host buffer (gs_host_alloc).  0: copied by the copy engine behind
                                    the frame's last kernel.  1: the blend kernel stores its tiles straight into the buffer (16 bytes per
                                    lane as each tile finishes), so the transfer runs under the blending of the other tiles and nothing is

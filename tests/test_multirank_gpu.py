@@ -279,6 +279,74 @@ def test_c5_size_twenty_million_splats_4k_over_eight_ranks():
         R.close()
 
 
+def _shared_sort_frames(world, rows, w, h, yaws, permille, n_async, depth=3, batch=1, sync_every=6):
+    """GS_OPT_SORT_SHARE: frame f is sorted by rank f mod world alone and its order sent to the others; the assembled frames
+    must still equal one context's, whether a frame is covered by the exchanged part of the order or falls back to a local sort"""
+    cams = [synth.index_html_camera(w, h, y, capi=capi) for y in yaws]
+    want = [f[0] for f in _single_frames(rows, cams, lambda cam: [_params(cam)])]
+    R = Ranks(world, rows, depth=depth, batch=batch)
+    try:
+        bufs = [DevBuf(w * h * 4) for _ in cams]
+        got_sync, stats = {}, {}
+
+        def body(rank, c, R):
+            c.set_option(capi.OPT_SORT_SHARE, permille)
+            for k, cam in enumerate(cams[:2]):                         # synchronous frames (rank 0 owns the first, rank 1 the second)
+                c.sort_gathered(cam["view"], None, _params(cam))
+                c.render_gathered(_params(cam), root=0)
+                if rank == 0:
+                    got_sync[k] = c.read_gathered(0, w, h)
+                R.barrier.wait()
+            for attempt in range(8):
+                for i in range(n_async):
+                    k = i % len(cams)
+                    c.sort_gathered(cams[k]["view"], None, _params(cams[k]))
+                    c.render_gathered(_params(cams[k]), root=0, device_frames=[bufs[k].p.value] if rank == 0 else None, flags=capi.RENDER_ASYNC)
+                    if i % sync_every == sync_every - 1:
+                        if R.sync_all(rank, c):
+                            break
+                        st = c.stats()                                 # (was the last collected frame drawn from a partial order?)
+                        if 0 < st["sort_records"] < st["n_sorted"]:
+                            stats[rank] = stats.get(rank, 0) + 1
+                else:
+                    if not R.sync_all(rank, c):
+                        break
+                assert attempt < 7, "frames kept asking for a re-render"
+        R.run(body)
+        for k in (0, 1):
+            assert np.array_equal(got_sync[k], want[k]), (world, "sync", k)
+        for k, b in enumerate(bufs):
+            assert np.array_equal(b.read((h, w, 4)), want[k]), (world, permille, "async", k)
+            b.free()
+        return stats
+    finally:
+        R.close()
+
+
+@pytest.mark.parametrize("world,permille,batch", [(2, 1000, 1), (3, 400, 2), (8, 1000, 1)])
+def test_ranks_take_turns_sorting_small_scene(rows_small, world, permille, batch):
+    """the small scene never saturates its tiles (one binning round over everything): with 1000 permille the whole order is
+    exchanged and covers every frame; with 400 the exchanged part does not cover a frame and every rank sorts again locally"""
+    _shared_sort_frames(world, rows_small, 640, 360, (0.0, 75.0, 150.0, 225.0, 300.0), permille, n_async=18, batch=batch)
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_ranks_take_turns_sorting_c2(rows_1m, world):
+    """C2: once the share of splats binned first has settled (~16 %), the exchanged 30 % of the order covers every frame"""
+    st = _shared_sort_frames(world, rows_1m, 1920, 1080, (21.0, 22.0, 23.0), 300, n_async=72)
+    print("C2 shared sort, world %d: syncs whose last frame was drawn from the exchanged (partial) order, per rank:" % world, sorted(st.items()))
+    assert len(st) == world and all(v > 0 for v in st.values()), st              # every rank drew frames from the exchanged part alone
+
+
+def test_ranks_take_turns_sorting_c5_size():
+    """C5's size over eight ranks: 20 M splats @ 3840x2160, 3 % of the order exchanged (629 146 splats, 5.3 MB per peer)"""
+    n = 20 * (1 << 20)
+    rows = cached_rows("make_splat_rows_fast", n)
+    st = _shared_sort_frames(8, rows, 3840, 2160, (33.0, 35.0), 30, n_async=90, depth=1, sync_every=2)   # (the share shrinks 10 % per collected sync)
+    print("C5 shared sort, world 8: syncs whose last frame was drawn from the exchanged (partial) order, per rank:", sorted(st.items()))
+    assert len(st) == 8 and all(v > 0 for v in st.values()), st
+
+
 def test_a_rank_that_never_sends_fails_the_frame_instead_of_hanging(rows_small, monkeypatch):
     """in-process transport: a receive whose sender never shows up gives up (GS_COMM_TIMEOUT_S) and the frame fails with
     GS_E_HIP; the ticket sequence moves on, so the next frame -- with the peer present -- is complete again"""
