@@ -115,6 +115,14 @@ if "--big" in sys.argv or "--frames" in sys.argv:
               strip=(0, wx), recipe=rec_1m, eye=(synth.compose((0.032 * sx, 1.6, 0.0)), eye_proj),
               note="BASELINE configs[3]: the whole %s XR eye 1032x1104, order from the HEAD camera's sort, entity yaw 155 deg" % tag)
         scenes[nm]["store_rgba8"] = False
+if "--big" in sys.argv or "--c3frame" in sys.argv:
+    # the whole C3 frame: 6 M splats + the cutout-demo box (the reference's worker culls the rows itself), float-buffer image only
+    scene("c3_6m_cutout_frame", synth.make_splat_rows(synth.N_BICYCLE, seed=synth.SEED_BASE + 3), 1920, 1080, synth.compose((5.132, 1.6, 7.237)),
+          synth.compose((0.0, 0.8, -2.0), 200.0, (2.0, 2.0, 2.0)), synth.perspective(80.0, 1920 / 1080),
+          cutout=synth.compose((0.8145, 1.73322, -2.35981), 0.0, (4.17, 2.95, 3.89)), strip=(0, 1920),
+          recipe={"fn": "make_splat_rows", "n": int(synth.N_BICYCLE), "seed": int(synth.SEED_BASE + 3)},
+          note="BASELINE configs[2], the whole 1920x1080 frame: 6,291,456 splats + the cutout-demo.html box, entity yaw 200 deg")
+    scenes["c3_6m_cutout_frame"]["store_rgba8"] = False
 if "--c5" in sys.argv:
     # BASELINE configs[4]'s OWN scene: 20,971,520 splats at 3840x2160 -- more than 4096^2 vertices, so the "renderer" has to report
     # MAX_TEXTURE_SIZE 8192 (index.js:30-36 would clamp at 16.7 M otherwise); pushed in chunks like a progressive load; one
@@ -125,7 +133,7 @@ if "--c5" in sys.argv:
           note="BASELINE configs[4]: 20,971,520 splats at 3840x2160, entity yaw 33 deg, columns 1888..1951 (MAX_TEXTURE_SIZE 8192)")
     scenes["c5_20m_4k_strip"]["push_chunk"] = 1 << 22
 if "--only-new" in sys.argv:                                  # (side runs: GS_GL_MERGE=1 node oracle/gen_golden_gl.js keeps the other cases)
-    keep = [k for k in scenes if k.endswith("_frame") and not k.startswith("c2_") or k == "c5_20m_4k_strip"]
+    keep = [k for k in scenes if (k.endswith("_frame") and not k.startswith("c2_") and ("--c3frame" not in sys.argv or k.startswith("c3_"))) or k == "c5_20m_4k_strip"]
     for k in list(scenes):
         if k not in keep:
             os.unlink(os.path.join(OUT, scenes[k]["rows"]))
