@@ -229,6 +229,19 @@ static inline uint32_t gs_div_up(uint64_t a, uint64_t b) { return (uint32_t)((a 
 // 8, grid-strided); returns false for the padding slots of the last eighths.
 __device__ __forceinline__ bool gs_xcd_chunk(uint32_t v, uint32_t nchunks, uint32_t &chunk) { return gsm::xcd_chunk(v, nchunks, chunk); }
 
+// Wave priority of the chain kernels.  With several frames in flight the blend of one frame fills every SIMD with waves while
+// the short kernels of the other frames' chains (histograms, scans, scatters, projection, emit: each a link of a DEPENDENT chain)
+// wait for issue slots next to them.  s_setprio lets the SIMD's arbiter pick their instructions first; the blend, the only
+// kernel that is pure throughput, stays at priority 0.  (GS_CHAIN_PRIORITY = 0 builds without it.)
+#ifndef GS_CHAIN_PRIORITY
+#define GS_CHAIN_PRIORITY 0
+#endif
+#if GS_CHAIN_PRIORITY
+#define GS_CHAIN_PRIO() __builtin_amdgcn_s_setprio(GS_CHAIN_PRIORITY)
+#else
+#define GS_CHAIN_PRIO() ((void)0)
+#endif
+
 // ---- two frames per launch (GS_OPT_FRAME_BATCH)
 // A frame of 1 M splats is a chain of 18 short dependent kernels, most of them at the launch floor.  Two frames that take the
 // same path can share every launch: grid (x, 2), blockIdx.y = the frame, each with its OWN argument list -- its own scratch,

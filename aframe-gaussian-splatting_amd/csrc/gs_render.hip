@@ -76,6 +76,7 @@ __device__ __forceinline__ void k_project_body(const uint32_t *__restrict__ sort
                                                uint32_t *__restrict__ part_vis, const uint32_t *__restrict__ mask,
                                                float *__restrict__ zwin, GsControl *ctl)
 {
+    GS_CHAIN_PRIO();
     __shared__ float s_rec[GS_BLOCK][6];
     __shared__ uint32_t s_rows[GS_BLOCK], s_j[GS_BLOCK];
     __shared__ uint32_t s_nbig, s_nmid, s_vis, s_sum;
@@ -211,6 +212,7 @@ __device__ __forceinline__ void k_pairs_check_body(GsControl *ctl, uint32_t pair
                                                    int last_round, uint32_t *__restrict__ mask, uint32_t mask_total_words,
                                                    uint2 *__restrict__ extra)
 {
+    GS_CHAIN_PRIO();
     __shared__ uint32_t s_vis, s_wave[4], s_wave_e[4], s_tv[GS_SPINE_CACHED][GS_BLOCK], s_eb[GS_SPINE_CACHED][GS_BLOCK];
     __shared__ unsigned long long s_total64[4];
     if (threadIdx.x == 0) s_vis = 0;
@@ -362,6 +364,7 @@ __device__ __forceinline__ void k_emit_body(const gsm::Projected *__restrict__ p
                                             const uint2 *__restrict__ extra, const GsFrameUniforms &u, void *__restrict__ pairs,
                                             const uint32_t *__restrict__ mask, const GsControl *ctl)
 {
+    GS_CHAIN_PRIO();
     __shared__ float s_rec[GS_BLOCK][6];                            // the slice's splats: projected record,
     __shared__ uint32_t s_sp[GS_BLOCK], s_ty[GS_BLOCK];             // index in the chunk, first | last tile row,
     __shared__ uint32_t s_rb[GS_BLOCK + 1];                         // exclusive scan of their tile-row counts
@@ -495,6 +498,7 @@ __global__ __launch_bounds__(GS_BLOCK) void k_emit(const gsm::Projected *__restr
 __device__ __forceinline__ void k_tile_ranges_body(const void *__restrict__ pairs, uint32_t jbits, uint2 *__restrict__ range,
                                                    uint32_t ntiles, int round, const GsControl *ctl)
 {
+    GS_CHAIN_PRIO();
     const uint2 *p64 = reinterpret_cast<const uint2 *>(pairs);
     const uint32_t *p32 = reinterpret_cast<const uint32_t *>(pairs);
 #define GS_PAIR_TILE(i) (jbits ? (p32[i] >> jbits) : p64[i].x)

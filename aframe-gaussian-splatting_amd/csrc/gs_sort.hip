@@ -102,6 +102,7 @@ __device__ __forceinline__ void k_sort_depth_body(const float4 *__restrict__ row
                                                   float *__restrict__ depth_out, unsigned long long *__restrict__ part_min,
                                                   unsigned long long *__restrict__ part_max, uint32_t *__restrict__ part_cnt, DepthHist dh)
 {
+    GS_CHAIN_PRIO();
     __shared__ unsigned long long s_min, s_max;
     __shared__ uint32_t s_cnt;
     extern __shared__ uint32_t s_dh[];                           // GS_DEPTH_BINS words for a near-only sort, none otherwise (LDS the other frames' blends can use)
@@ -174,6 +175,7 @@ __global__ __launch_bounds__(GS_BLOCK) void k_sort_depth_pair(const float4 *__re
                                                               unsigned long long *__restrict__ pmin1, unsigned long long *__restrict__ pmax1, uint32_t *__restrict__ pcnt1,
                                                               DepthHist dh0, DepthHist dh1)
 {
+    GS_CHAIN_PRIO();
     __shared__ unsigned long long s_min[2], s_max[2];
     __shared__ uint32_t s_cnt[2];
     extern __shared__ uint32_t s_dh0[];                          // 2 x GS_DEPTH_BINS words for near-only sorts, none otherwise
@@ -253,6 +255,7 @@ __device__ __forceinline__ void k_sort_bucket_body(const float *__restrict__ dep
                                                    const uint32_t *__restrict__ part_cnt, uint32_t nparts,
                                                    uint32_t *__restrict__ hist, GsControl *ctl, const uint32_t *__restrict__ dhist, uint32_t near_req)
 {
+    GS_CHAIN_PRIO();
     static_assert(!NEAR || COMPACT, "near-only sorts use the compact records");
     constexpr int NT = 64 * NW, IPT = 8, CH = NT * IPT;
     __shared__ unsigned long long s_min, s_max;
