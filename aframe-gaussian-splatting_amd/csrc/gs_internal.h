@@ -23,7 +23,8 @@
 #define GS_MAX_PRIMARY 4           // lanes with a stream and an enqueue thread of their own (GS_OPT_PIPELINE_DEPTH)
 #define GS_MAX_LANES 8             // ... + their twins (GS_OPT_FRAME_BATCH): lanes[GS_MAX_PRIMARY + i] shares stream and worker of lanes[i]
 #ifndef GS_EMIT_PAIRS
-#define GS_EMIT_PAIRS 1024u        // pair slots written per k_emit work item (a slice of one chunk's pairs)
+#define GS_EMIT_PAIRS 2048u        // pair slots written per k_emit work item (a slice of one chunk's pairs).  Every slice re-reads its chunk's 256 x 44 B:
+                                   // 2048 instead of round 2's 1024 halves those re-reads (+2 % frames/s pipelined, -0.7 % for a frame alone; 4096: -4 % alone)
 #endif
 #ifndef GS_EMIT_RUNS
 #define GS_EMIT_RUNS 512u          // tile-row runs expanded per pass inside an item
