@@ -254,7 +254,11 @@ static int collect_status(gs_ctx *lane, bool *overflowed)
     // re-binned for them): the share grows x1.5 and will never again shrink below 1.3 x the share that failed; without
     // events it shrinks 10 % per collected frame until the first event, 2 % afterwards.  After 16 clean frames round 1 is not even launched (11 empty kernels
     // cost ~50 us): blend<0> raises round1_missed if that was wrong, and the frame is completed / re-rendered.
-    if (ctx->near_fixed_permille <= 0 && lane->stats.n_tiles) {
+    if (ctx->adapt_frozen) {
+        // gs_sync is drawing flagged frames again (redraw_flagged_frames) with the uniforms they were queued with: their share has
+        // been dealt with once already -- every one of them would count as a new failure and multiply the share by 1.5
+        lane->seen_unsat_events = c->unsat_events; lane->seen_acc_frames = c->acc_frames;
+    } else if (ctx->near_fixed_permille <= 0 && lane->stats.n_tiles) {
         const uint32_t events = c->unsat_events - lane->seen_unsat_events;
         const uint64_t frames = c->acc_frames >= lane->seen_acc_frames ? c->acc_frames - lane->seen_acc_frames : 1;
         lane->seen_unsat_events = c->unsat_events; lane->seen_acc_frames = c->acc_frames;
@@ -277,6 +281,12 @@ static int collect_status(gs_ctx *lane, bool *overflowed)
         } else if (ctx->near_frac >= 1.0f && ++ctx->single_round_frames >= 64) {
             ctx->near_frac = 0.5f; ctx->near_floor = 0.0f; ctx->single_round_frames = 0; ctx->clean_frames = 0;
         }
+    }
+    if (c->near_overflow) {
+        // a chunk of a near-only sort had more survivors than its stash holds (the frame was flagged and is drawn again from a
+        // whole sort): this context keeps to the whole-length passes from now on
+        ctx->near_stash_off = true;
+        GS_HIP(hipMemsetAsync(&lane->ctl->near_overflow, 0, sizeof(uint32_t), lane->stream));
     }
     lane->stats.unsat_tiles = lane->last_two_rounds ? c->unsat_round0 : 0;
     lane->stats.near_permille = (uint32_t)(ctx->near_frac * 1000.0f + 0.5f);
@@ -746,6 +756,7 @@ GS_API int gs_clear(gs_ctx *ctx)
     TRY(drain_all(ctx));
     ctx->n = 0; ctx->renderable = true; ctx->pair_hint = 0;
     ctx->near_frac = 0.25f; ctx->near_floor = 0.0f; ctx->clean_frames = 0; ctx->skip_hold = 0; ctx->single_round_frames = 0; ctx->last_kept = 0;
+    ctx->near_stash_off = false;
     for (int i = 0; i < GS_MAX_LANES; i++) {
         gs_ctx *L = ctx->lanes[i];
         if (!L) continue;
@@ -1220,6 +1231,8 @@ static int redraw_flagged_frames(gs_ctx *ctx, const bool bad_unit[GS_MAX_PRIMARY
         for (const GsFrameRec &r : L->log->recs) if (r.nrender && r.undecidable) return GS_E_RETRY;
     }
     uint32_t redrawn = 0;
+    struct Thaw { gs_ctx *c; ~Thaw() { c->adapt_frozen = false; } } thaw{ ctx };
+    ctx->adapt_frozen = true;
     for (int i = 0; i < GS_MAX_LANES; i++) {
         gs_ctx *L = ctx->lanes[i];
         if (!L || !L->log || !bad_unit[i % GS_MAX_PRIMARY]) continue;

@@ -36,6 +36,9 @@ struct GsSortStrip { float mv[16], proj[16]; float focal, vw; int32_t x0, x1; };
 #define GS_DH_COPIES 8u            // ... kept in this many copies (workgroup % copies)
 #define GS_DEPTH_COARSE (GS_DEPTH_BINS / 32u)   // ... with sums over 32 consecutive bins behind the copies
 #define GS_DH_WORDS (GS_DH_COPIES * (GS_DEPTH_BINS + GS_DEPTH_COARSE))
+#ifndef GS_NEAR_STASH
+#define GS_NEAR_STASH 512u         // survivors a 4096-item chunk of a near-only sort may stash (one eighth; the share asked for is <= 1/32)
+#endif
 
 // Device-resident control block: every data-dependent count lives here so that no stage needs a
 // host round trip; kernels read their problem size from it (grid-stride over chunks).
@@ -64,6 +67,8 @@ struct GsControl {
     uint32_t unsat_events;         // frames whose round 0 left tiles unsaturated (monotonic)
     uint32_t n_emit_extra, pad_emit; // k_emit work items beyond one per chunk (k_pairs_check -> k_emit of the same round)
     uint32_t round1_missed;        // sticky: round 1 was skipped optimistically but a tile needed it (host clears)
+    uint32_t near_overflow;        // sticky: a near-only sort's survivors did not fit a chunk's stash (host clears; the frame is also
+                                   // flagged round1_missed: it is drawn again from a whole sort)
     uint32_t acc_frames;           // frames rendered since profiling was switched on
     unsigned long long acc_sorted, acc_visible, acc_pairs;   // sums of V, Vp, I over those frames
 };
@@ -145,6 +150,7 @@ struct gs_ctx {
     uint32_t sort_near_req;
     float sv_view[4], sv_cutout[16]; bool sv_has_cutout, sv_has_strip; GsSortStrip sv_strip;
     int sort_near_opt;             // owner: GS_OPT_SORT_NEAR
+    bool near_stash_off;           // owner: a chunk's stash overflowed once: near-only sorts keep to the two whole-length passes
     uint32_t last_kept;            // owner: V of the last collected frame (a near-only sort pays only where V is well above the share read)
 
     // radix / scan scratch
@@ -200,6 +206,7 @@ struct gs_ctx {
     bool auto_retry;               // owner: GS_OPT_AUTO_RETRY
     int host_write;                // owner: GS_OPT_HOST_WRITE
     int sort_share_permille;       // owner: GS_OPT_SORT_SHARE (0 = every rank sorts every frame)
+    bool adapt_frozen;             // owner: gs_sync is drawing flagged frames again: their counters do not feed the adaptive share
     bool log_stale;                // owner: the resident data / scene changed under frames that are still in the logs
     gs_stats stats;
 };

@@ -379,6 +379,7 @@ int launch_pass(gs_ctx *ctx, const void *in, int in_fmt, void *out, int out_fmt,
     else if (in_fmt == GS_RADIX_KEYONLY && out_fmt == GS_RADIX_KEYONLY) GS_SCATTER(GS_RADIX_KEYONLY, GS_RADIX_KEYONLY);
     else if (in_fmt == GS_RADIX_KEYS && out_fmt == GS_RADIX_KEYIDX) GS_SCATTER(GS_RADIX_KEYS, GS_RADIX_KEYIDX);
     else if (in_fmt == GS_RADIX_KEYIDX && out_fmt == GS_RADIX_KEYS) GS_SCATTER(GS_RADIX_KEYIDX, GS_RADIX_KEYS);
+    else if (in_fmt == GS_RADIX_PACKED && out_fmt == GS_RADIX_KEYIDX) GS_SCATTER(GS_RADIX_PACKED, GS_RADIX_KEYIDX);
     else { snprintf(GS_ERRBUF(ctx), GS_ERRLEN, "radix pass: unsupported record formats %d -> %d", in_fmt, out_fmt); return GS_E_BADARG; }
 #undef GS_SCATTER
     GS_HIP(hipGetLastError());
@@ -421,6 +422,7 @@ int launch_pass2(gs_ctx *const S[2], const void *const in[2], int in_fmt, void *
     else if (in_fmt == GS_RADIX_KEYIDX && out_fmt == GS_RADIX_KEYS) GS_SCATTER2(GS_RADIX_KEYIDX, GS_RADIX_KEYS);
     else if (in_fmt == GS_RADIX_KEYS && out_fmt == GS_RADIX_PACKED) GS_SCATTER2(GS_RADIX_KEYS, GS_RADIX_PACKED);
     else if (in_fmt == GS_RADIX_PACKED && out_fmt == GS_RADIX_KEYS) GS_SCATTER2(GS_RADIX_PACKED, GS_RADIX_KEYS);
+    else if (in_fmt == GS_RADIX_PACKED && out_fmt == GS_RADIX_KEYIDX) GS_SCATTER2(GS_RADIX_PACKED, GS_RADIX_KEYIDX);
     else { snprintf(GS_ERRBUF(ctx), GS_ERRLEN, "radix pass: unsupported record formats %d -> %d", in_fmt, out_fmt); return GS_E_BADARG; }
 #undef GS_SCATTER2
 #undef GS_SCATTER2_B

@@ -374,6 +374,180 @@ __global__ __launch_bounds__(64 * NW) void k_sort_bucket(const float *__restrict
     k_sort_bucket_body<NW, COMPACT, NEAR>(depth, n, keys, part_min, part_max, part_cnt, nparts, hist, ctl, dhist, near_req);
 }
 
+// Near-only sorts of LONG inputs (round 3).  k_sort_bucket<.., NEAR> still wrote a key for every one of the N splats and pass A
+// still read, ranked and scanned all of them (20 M: 80 MB of keys, 5120 x 512 histogram rows) to move the 1.5 % that survive the
+// threshold.  Here the bucket pass hands the survivors on directly: every 4096-item chunk stashes its survivors -- (bucket, index)
+// records in INDEX order: items r * NT + t of a chunk are ranked by (r, t) through one ballot per row and a 64-entry scan of
+// the (row, wave) counts -- in a fixed slot of GS_NEAR_STASH records and leaves their count; k_near_gather turns the stashes into
+// one contiguous list (each workgroup sums the counts before its chunks itself: 20 KB of L2 reads at most, no scan launch), in
+// chunk order, i.e. in index order, and two stable passes over the P' records (9 + 7 bucket bits) give the order the
+// whole-length passes give.  A chunk with more survivors than its stash holds raises near_overflow + round1_missed: the frame
+// is drawn again from a whole sort and the context stops using the stash (gs_api.hip).
+template <int NW>
+__device__ __forceinline__ void k_near_stash_body(const float *__restrict__ depth, uint32_t n, const unsigned long long *__restrict__ part_min,
+                                                  const unsigned long long *__restrict__ part_max, const uint32_t *__restrict__ part_cnt, uint32_t nparts,
+                                                  uint2 *__restrict__ stash, uint32_t *__restrict__ cnt_out, GsControl *ctl,
+                                                  const uint32_t *__restrict__ dhist, uint32_t near_req)
+{
+    GS_CHAIN_PRIO();
+    constexpr int NT = 64 * NW, IPT = 8, CH = NT * IPT;
+    __shared__ unsigned long long s_min, s_max;
+    __shared__ uint32_t s_cnt, s_nvalid;
+    __shared__ int32_t s_bcut;
+    __shared__ uint32_t s_row[IPT * NW];                           // survivors per (row, wave) -> their first slot
+    if (threadIdx.x == 0) { s_min = ~0ull; s_max = 0ull; s_cnt = 0; s_nvalid = 0; s_bcut = 0; }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    {
+        unsigned long long mn = ~0ull, mx = 0ull; uint32_t cnt = 0;
+        for (uint32_t i = threadIdx.x; i < nparts; i += NT) {
+            const unsigned long long a = part_min[i], b = part_max[i];
+            mn = a < mn ? a : mn; mx = b > mx ? b : mx; cnt += part_cnt[i];
+        }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+            const unsigned long long omn = shfl_xor_u64(mn, m), omx = shfl_xor_u64(mx, m);
+            mn = omn < mn ? omn : mn; mx = omx > mx ? omx : mx;
+            cnt += __shfl_xor(cnt, m, 64);
+        }
+        if (lane == 0) { atomicMin(&s_min, mn); atomicMax(&s_max, mx); atomicAdd(&s_cnt, cnt); }
+    }
+    __syncthreads();
+    if (blockIdx.x == 0 && threadIdx.x == 0) { ctl->min_enc = s_min; ctl->max_enc = s_max; ctl->n_kept = s_cnt; ctl->n_total = n; ctl->near_sorted = 1u; }
+    const double mn = gsm::ordered_to_f64(s_min), mx = gsm::ordered_to_f64(s_max);
+    const double inv = 65535.0 / (mx - mn);
+    if (threadIdx.x < 64) {                                         // the threshold bucket: exactly k_sort_bucket<.., NEAR>'s rule
+        const int l = threadIdx.x;
+        auto wave_scan = [&](uint32_t v) { for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(v, d, 64); if (l >= d) v += t; } return v; };
+        uint32_t cs = 0;
+#pragma unroll
+        for (uint32_t c = 0; c < GS_DH_COPIES; c++) cs += dhist[GS_DH_COPIES * GS_DEPTH_BINS + c * GS_DEPTH_COARSE + l];
+        const uint32_t cinc = wave_scan(cs);
+        const unsigned long long m = __ballot(cinc >= near_req);
+        uint32_t T = GS_DEPTH_BINS - 1u;
+        if (m) {
+            const int C = __ffsll((long long)m) - 1;
+            const uint32_t before = __shfl(cinc - cs, C, 64);
+            uint32_t fs = 0;
+            if (l < 32) {
+#pragma unroll
+                for (uint32_t c = 0; c < GS_DH_COPIES; c++) fs += dhist[c * GS_DEPTH_BINS + (uint32_t)C * 32u + l];
+            }
+            const uint32_t finc = wave_scan(fs);
+            const unsigned long long m2 = __ballot(l < 32 && before + finc >= near_req);
+            T = (uint32_t)C * 32u + (m2 ? (uint32_t)(__ffsll((long long)m2) - 1) : 31u);
+        }
+        if (l == 0) {
+            int32_t bc = 0;
+            if (T < GS_DEPTH_BINS - 1u && inv > 0.0 && inv < 1.0e300) {
+                const double x = ((double)(-__uint_as_float((T + 1u) << 20)) - mn) * inv;
+                bc = !(x >= 0.0) ? 0 : (x >= 65535.0 ? 65535 : (int32_t)x);
+            }
+            s_bcut = bc;
+        }
+    }
+    __syncthreads();
+    const int32_t bcut = s_bcut;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    uint32_t nvalid = 0;
+    const uint32_t nchunks = (n + CH - 1) / CH;
+    for (uint32_t v = blockIdx.x; v < ((nchunks + 7u) & ~7u); v += gridDim.x) {
+        uint32_t c;
+        if (!gs_xcd_chunk(v, nchunks, c)) continue;
+        float dd[IPT];
+#pragma unroll
+        for (int r = 0; r < IPT; r++) {
+            const uint32_t i = c * CH + r * NT + threadIdx.x;
+            dd[r] = i < n ? depth[i] : INFINITY;
+        }
+        int32_t bk[IPT];
+        uint32_t before[IPT];
+#pragma unroll
+        for (int r = 0; r < IPT; r++) {
+            bk[r] = -1;
+            if (dd[r] != INFINITY) {
+                const int32_t b = gsm::sort_bucket(dd[r], mn, inv);
+                if (b >= 0) { nvalid++; if (b >= bcut) bk[r] = b; }
+            }
+            const unsigned long long bal = __ballot(bk[r] >= 0);
+            before[r] = (uint32_t)__popcll(bal & lt);
+            if (lane == 0) s_row[r * NW + w] = (uint32_t)__popcll(bal);
+        }
+        __syncthreads();
+        uint32_t total = 0;
+        if (threadIdx.x < 64) {                                     // exclusive scan of the IPT * NW (= 64 at NW = 8) counts, row-major = index order
+            uint32_t cv = threadIdx.x < IPT * NW ? s_row[threadIdx.x] : 0u, inc = cv;
+            for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(inc, d, 64); if (lane >= d) inc += t; }
+            if (threadIdx.x < IPT * NW) s_row[threadIdx.x] = inc - cv;
+            total = __shfl(inc, 63, 64);
+            if (threadIdx.x == 0) {
+                cnt_out[c] = total < GS_NEAR_STASH ? total : GS_NEAR_STASH;
+                if (total > GS_NEAR_STASH) { ctl->near_overflow = 1u; ctl->round1_missed = 1u; }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < IPT; r++) {
+            if (bk[r] >= 0) {
+                const uint32_t slot = s_row[r * NW + w] + before[r];
+                if (slot < GS_NEAR_STASH) stash[(size_t)c * GS_NEAR_STASH + slot] = make_uint2((uint32_t)bk[r], c * CH + r * NT + threadIdx.x);
+            }
+        }
+        __syncthreads();                                             // s_row is rewritten by the next chunk
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) nvalid += __shfl_xor(nvalid, m, 64);
+    if (lane == 0 && nvalid) atomicAdd(&s_nvalid, nvalid);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_nvalid) atomicAdd(&ctl->n_valid, s_nvalid);
+}
+
+// the stashes -> one list in chunk (= index) order; GS_GATHER_CHUNKS chunks per workgroup, which first sums the counts before them
+#define GS_GATHER_CHUNKS 8u
+__device__ __forceinline__ void k_near_gather_body(const uint2 *__restrict__ stash, const uint32_t *__restrict__ cnt, uint32_t n, uint32_t chunk,
+                                                   uint2 *__restrict__ out, GsControl *ctl)
+{
+    GS_CHAIN_PRIO();
+    __shared__ uint32_t s_w[4];
+    const uint32_t nchunks = (n + chunk - 1) / chunk;
+    const uint32_t ngroups = (nchunks + GS_GATHER_CHUNKS - 1) / GS_GATHER_CHUNKS;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (uint32_t g = blockIdx.x; g < ngroups; g += gridDim.x) {
+        const uint32_t c0 = g * GS_GATHER_CHUNKS;
+        uint32_t s = 0;
+        for (uint32_t i = threadIdx.x; i < c0; i += GS_BLOCK) s += cnt[i];
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
+        __syncthreads();
+        if (lane == 0) s_w[w] = s;
+        __syncthreads();
+        uint32_t base = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+        for (uint32_t c = c0; c < c0 + GS_GATHER_CHUNKS && c < nchunks; c++) {
+            const uint32_t k = cnt[c];
+            for (uint32_t t = threadIdx.x; t < k; t += GS_BLOCK) out[base + t] = stash[(size_t)c * GS_NEAR_STASH + t];
+            base += k;
+        }
+        if (g == ngroups - 1 && threadIdx.x == 0) ctl->n_sorted = base;    // P': what the two passes sort
+    }
+}
+
+template <int NW> GS_BODY(F_near_stash, k_near_stash_body<NW>);
+GS_BODY(F_near_gather, k_near_gather_body);
+
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void k_near_stash(const float *__restrict__ depth, uint32_t n, const unsigned long long *__restrict__ part_min,
+                                                        const unsigned long long *__restrict__ part_max, const uint32_t *__restrict__ part_cnt, uint32_t nparts,
+                                                        uint2 *__restrict__ stash, uint32_t *__restrict__ cnt_out, GsControl *ctl,
+                                                        const uint32_t *__restrict__ dhist, uint32_t near_req)
+{
+    k_near_stash_body<NW>(depth, n, part_min, part_max, part_cnt, nparts, stash, cnt_out, ctl, dhist, near_req);
+}
+__global__ __launch_bounds__(GS_BLOCK) void k_near_gather(const uint2 *__restrict__ stash, const uint32_t *__restrict__ cnt, uint32_t n, uint32_t chunk,
+                                                          uint2 *__restrict__ out, GsControl *ctl)
+{
+    k_near_gather_body(stash, cnt, n, chunk, out, ctl);
+}
+
 template <int NW, bool COMPACT, bool NEAR> GS_BODY(F_sort_bucket, k_sort_bucket_body<NW, COMPACT, NEAR>);
 
 }  // namespace
@@ -403,6 +577,19 @@ static DepthHist next_depth_hist(gs_ctx *L, bool near)
         dh.zero_word = &L->ctl->n_valid;
     }
     return dh;
+}
+
+// may this near-only sort hand its survivors on through the chunk stashes?  Long inputs only (the 4096-item geometry), a share of
+// at most 1/32 of the splats (a stash holds 1/8 of its chunk), and not after a stash has overflowed on this context
+static bool gs_near_stash_ok(const gs_ctx *L, uint32_t n, uint32_t near_req)
+{
+    return near_req && gs_radix_chunk(n) == GS_CHUNK_L && (uint64_t)near_req * 32u <= n && !gs_root(const_cast<gs_ctx *>(L))->near_stash_off &&
+           (size_t)(gs_div_up(n, GS_CHUNK_L) + 1u) * GS_NEAR_STASH <= L->scratch_cap / 2;
+}
+static uint32_t gs_near_gather_grid(uint32_t n)
+{
+    const uint32_t g = gs_div_up(gs_div_up(n, GS_CHUNK_L), 8u);
+    return g < 1 ? 1u : (g > 1024u ? 1024u : g);
 }
 
 // records the second pass of a near-only sort should expect (its geometry and grid: a matter of speed only)
@@ -440,6 +627,30 @@ int gs_run_sort2(gs_ctx *const S[2], const float *const view[2], const float *co
                                          S[1]->part_min, S[1]->part_max, S[1]->part_cnt, dh[0], dh[1])
     if (strips) GS_DEPTHP(true); else GS_DEPTHP(false);
 #undef GS_DEPTHP
+    // near-only sorts of long inputs hand their survivors on through per-chunk stashes instead of two whole-length passes (above)
+    const bool stash = near && gs_near_stash_ok(S[0], n, near_req[0]) && gs_near_stash_ok(S[1], n, near_req[1]);
+    if (stash) {
+        uint2 *list[2] = { S[0]->kv_b + S[0]->scratch_cap / 2, S[1]->kv_b + S[1]->scratch_cap / 2 };
+        gs_twin<F_near_stash<8>, 512>(g, st,
+            gs_pack_make((const float *)S[0]->depth, n, (const unsigned long long *)S[0]->part_min, (const unsigned long long *)S[0]->part_max, (const uint32_t *)S[0]->part_cnt, gd,
+                         S[0]->kv_b, S[0]->hist, S[0]->ctl, (const uint32_t *)dh[0].fill, S[0]->sort_near_req),
+            gs_pack_make((const float *)S[1]->depth, n, (const unsigned long long *)S[1]->part_min, (const unsigned long long *)S[1]->part_max, (const uint32_t *)S[1]->part_cnt, gd,
+                         S[1]->kv_b, S[1]->hist, S[1]->ctl, (const uint32_t *)dh[1].fill, S[1]->sort_near_req));
+        gs_twin<F_near_gather, GS_BLOCK>(gs_near_gather_grid(n), st,
+            gs_pack_make((const uint2 *)S[0]->kv_b, (const uint32_t *)S[0]->hist, n, (uint32_t)GS_CHUNK_L, list[0], S[0]->ctl),
+            gs_pack_make((const uint2 *)S[1]->kv_b, (const uint32_t *)S[1]->hist, n, (uint32_t)GS_CHUNK_L, list[1], S[1]->ctl));
+        GS_HIP(hipGetLastError());
+        const void *in2[2]; void *out2[2]; const uint32_t *np2[2]; uint32_t *cnt2[2] = { nullptr, nullptr }; const uint32_t *fill2[2] = { nullptr, nullptr };
+        for (int k = 0; k < 2; k++) { in2[k] = list[k]; out2[k] = S[k]->key_a; np2[k] = &S[k]->ctl->n_sorted; }
+        int rc2 = gs_launch_radix_pass2(S, in2, GS_RADIX_PACKED, out2, GS_RADIX_KEYIDX, np2, n, near_hint(S[0], n), 0, 9, false, 0xFFFFFFFFu, 25, cnt2, fill2);
+        if (rc2 != GS_OK) return rc2;
+        for (int k = 0; k < 2; k++) { in2[k] = S[k]->key_a; out2[k] = S[k]->val_a; }
+        rc2 = gs_launch_radix_pass2(S, in2, GS_RADIX_KEYIDX, out2, GS_RADIX_KEYS, np2, n, near_hint(S[0], n), 25, 7, false, 0xFFFFFFFFu, 0, cnt2, fill2);
+        if (rc2 != GS_OK) return rc2;
+        GS_PROF_RECORD(ctx, 1);
+        for (int k = 0; k < 2; k++) { S[k]->sorted = S[k]->val_a; S[k]->have_sort = true; }
+        return GS_OK;
+    }
 #define GS_BUCKET2(NW, C, NR) gs_twin<F_sort_bucket<NW, C, NR>, 64 * NW>(g, st,                                                                            \
         gs_pack_make((const float *)S[0]->depth, n, S[0]->key_a, (const unsigned long long *)S[0]->part_min, (const unsigned long long *)S[0]->part_max,     \
                      (const uint32_t *)S[0]->part_cnt, gd, S[0]->hist, S[0]->ctl, (const uint32_t *)dh[0].fill, S[0]->sort_near_req),                       \
@@ -533,6 +744,23 @@ int gs_run_sort(gs_ctx *ctx, const float view[4], const float *cutout16, const G
                                         ctx->part_min, ctx->part_max, ctx->part_cnt, dh);
     else hipLaunchKernelGGL(k_sort_depth<false>, dim3(gd), dim3(GS_BLOCK), dlds, ctx->stream, ctx->sort_rows, ctx->bound_r, n, u, su, ctx->depth,
                             ctx->part_min, ctx->part_max, ctx->part_cnt, dh);
+    if (near && gs_near_stash_ok(ctx, n, near_req)) {
+        // (survivors through per-chunk stashes: k_near_stash / k_near_gather above)
+        uint2 *list = ctx->kv_b + ctx->scratch_cap / 2;
+        hipLaunchKernelGGL((k_near_stash<8>), dim3(g), dim3(512), 0, ctx->stream, (const float *)ctx->depth, n, (const unsigned long long *)ctx->part_min,
+                           (const unsigned long long *)ctx->part_max, (const uint32_t *)ctx->part_cnt, gd, ctx->kv_b, ctx->hist, ctx->ctl, (const uint32_t *)dh.fill, ctx->sort_near_req);
+        hipLaunchKernelGGL(k_near_gather, dim3(gs_near_gather_grid(n)), dim3(GS_BLOCK), 0, ctx->stream, (const uint2 *)ctx->kv_b, (const uint32_t *)ctx->hist, n,
+                           (uint32_t)GS_CHUNK_L, list, ctx->ctl);
+        GS_HIP(hipGetLastError());
+        int rcs = gs_launch_radix_pass(ctx, list, GS_RADIX_PACKED, ctx->key_a, GS_RADIX_KEYIDX, &ctx->ctl->n_sorted, n, near_hint(ctx, n), 0, 9, false, 0xFFFFFFFFu, 25);
+        if (rcs != GS_OK) return rcs;
+        rcs = gs_launch_radix_pass(ctx, ctx->key_a, GS_RADIX_KEYIDX, ctx->val_a, GS_RADIX_KEYS, &ctx->ctl->n_sorted, n, near_hint(ctx, n), 25, 7, false, 0xFFFFFFFFu, 0, nullptr, nullptr);
+        if (rcs != GS_OK) return rcs;
+        GS_PROF_RECORD(ctx, 1);
+        ctx->sorted = ctx->val_a;
+        ctx->have_sort = true;
+        return GS_OK;
+    }
 #define GS_LAUNCH_BUCKET(NW, C, NR) hipLaunchKernelGGL((k_sort_bucket<NW, C, NR>), dim3(g), dim3(64 * NW), 0, ctx->stream, ctx->depth, n, ctx->key_a, \
                                                        ctx->part_min, ctx->part_max, ctx->part_cnt, gd, ctx->hist, ctx->ctl, (const uint32_t *)dh.fill, ctx->sort_near_req)
     if (gs_radix_chunk(n) == GS_CHUNK_L) { if (near) GS_LAUNCH_BUCKET(8, true, true); else if (compact) GS_LAUNCH_BUCKET(8, true, false); else GS_LAUNCH_BUCKET(8, false, false); }
