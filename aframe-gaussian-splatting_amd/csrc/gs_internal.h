@@ -67,6 +67,7 @@ struct GsControl {
     uint32_t unsat_events;         // frames whose round 0 left tiles unsaturated (monotonic)
     uint32_t n_emit_extra, pad_emit; // k_emit work items beyond one per chunk (k_pairs_check -> k_emit of the same round)
     uint32_t round1_missed;        // sticky: round 1 was skipped optimistically but a tile needed it (host clears)
+    uint32_t vis_total;            // visible splats of the current binning round (k_pairs_check)
     uint32_t near_overflow;        // sticky: a near-only sort's survivors did not fit a chunk's stash (host clears; the frame is also
                                    // flagged round1_missed: it is drawn again from a whole sort)
     uint32_t acc_frames;           // frames rendered since profiling was switched on
@@ -94,6 +95,9 @@ struct GsFrameUniforms {           // per-render constants, passed by value to k
     uint32_t split_min;            // GS_OPT_BLEND_SPLIT: tiles whose list has at least this many entries are blended by GS_SPLIT_WAVES
                                    // wavefronts (k_blend<.., GS_SPLIT_WAVES>), the others by one; 0 = all by one
     uint32_t pair_jbits;           // > 0: 4-byte pair records (tile << pair_jbits | sorted position - j_lo); 0: (tile, position) uint2
+    uint32_t pair_vcap;            // > 0 (with pair_jbits > 0): the low bits of a 4-byte record are not the sorted position but the splat's index
+                                   // among the VISIBLE splats of the round (< pair_vcap), whose projected records k_emit copies to `projc`
+                                   // in that order: a 4K frame has 15 tile bits and a round of 300 K positions 19, but a thousand visible splats 10
 };
 
 struct GsLaneWorker;
@@ -162,6 +166,9 @@ struct gs_ctx {
     gsm::Projected *proj;          // V records, sorted order
     uint2 *rect;                   // V x (tx0 | ty0<<16, tx1 | ty1<<16), strip-local tile coords
     uint32_t *tile_count;          // V
+    uint32_t *spine_vis;           // per 256-splat chunk: visible splats (project -> pairs_check: exclusive scan -> emit), sized like spine
+    gsm::Projected *projc; float *zwinc; size_t projc_cap;   // compact pair records: projected records / window depths of the visible splats, in order
+    uint32_t vis_hint;             // owner: visible splats a round is expected to have (the last collected frame's + 1/8 + 4096; 0 = unknown)
     uint2 *emit_extra;             // pair_cap / GS_EMIT_PAIRS + 2 (chunk, slice) items of the chunks with more than GS_EMIT_PAIRS pairs
     float *zwin;                   // V window depth of each sorted splat (written only while a scene depth buffer is set)
     float *scene_depth; uint32_t *scene_rgba; int scene_w, scene_h;   // gs_set_scene
@@ -196,7 +203,8 @@ struct gs_ctx {
     uint32_t profile_every;        // GS_OPT_PROFILE = 3: ... and only on every 4th frame of the lane (0 / 1 = every frame)
     uint32_t profile_tick;
     uint32_t record_staged;        // GS_OPT_RECORD_STAGED (1 = entries staged, 2 = entries evaluated)
-    bool wide_pairs;               // GS_OPT_WIDE_PAIRS: always use 8-byte pair records
+    bool wide_pairs;               // GS_OPT_WIDE_PAIRS = 1: always use 8-byte pair records
+    bool compact_pairs;            // GS_OPT_WIDE_PAIRS = 2: compact 4-byte records (visible-splat index) wherever they fit, also where the position form does
     float t_eps;
     // profiling ring: GS_PROF_RING slots x GS_PROF_EVENTS events (sort begin/end, render begin, after project, after
     // binning, after blend of round 0, end of round 1)

@@ -74,12 +74,12 @@ __device__ __forceinline__ void k_project_body(const uint32_t *__restrict__ sort
                                                const GsFrameUniforms &u, gsm::Projected *__restrict__ proj, uint2 *__restrict__ rect,
                                                uint32_t *__restrict__ tile_count, uint32_t *__restrict__ spine,
                                                uint32_t *__restrict__ part_vis, const uint32_t *__restrict__ mask,
-                                               float *__restrict__ zwin, GsControl *ctl)
+                                               float *__restrict__ zwin, GsControl *ctl, uint32_t *__restrict__ spine_vis)
 {
     GS_CHAIN_PRIO();
     __shared__ float s_rec[GS_BLOCK][6];
     __shared__ uint32_t s_rows[GS_BLOCK], s_j[GS_BLOCK];
-    __shared__ uint32_t s_nbig, s_nmid, s_vis, s_sum;
+    __shared__ uint32_t s_nbig, s_nmid, s_vis, s_sum, s_visc;
     uint32_t j_lo, j_hi;
     round_range<ROUND>(ctl, u.near_count, j_lo, j_hi);
     // a near-only sort holds positions [V' - P, V') of the order; the positions behind V' are the reference's zero tail
@@ -89,7 +89,7 @@ __device__ __forceinline__ void k_project_body(const uint32_t *__restrict__ sort
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     if (threadIdx.x == 0) s_vis = 0;
     for (uint32_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
-        if (threadIdx.x == 0) { s_sum = 0; s_nbig = 0; s_nmid = 0; }
+        if (threadIdx.x == 0) { s_sum = 0; s_nbig = 0; s_nmid = 0; s_visc = 0; }
         __syncthreads();
         const uint32_t j = j_lo + c * GS_BLOCK + threadIdx.x;
         uint32_t count = 0;
@@ -182,9 +182,9 @@ __device__ __forceinline__ void k_project_body(const uint32_t *__restrict__ sort
         }
 #pragma unroll
         for (int m = 32; m >= 1; m >>= 1) { vis += __shfl_xor(vis, m, 64); sum += __shfl_xor(sum, m, 64); }
-        if (lane == 0) { if (vis) atomicAdd(&s_vis, vis); if (sum) atomicAdd(&s_sum, sum); }
+        if (lane == 0) { if (vis) { atomicAdd(&s_vis, vis); atomicAdd(&s_visc, vis); } if (sum) atomicAdd(&s_sum, sum); }
         __syncthreads();
-        if (threadIdx.x == 0) spine[c] = s_sum;
+        if (threadIdx.x == 0) { spine[c] = s_sum; spine_vis[c] = s_visc; }
     }
     __syncthreads();
     if (threadIdx.x == 0) part_vis[blockIdx.x] = s_vis;
@@ -195,9 +195,9 @@ __global__ __launch_bounds__(GS_BLOCK) void k_project(const uint32_t *__restrict
                                                       GsFrameUniforms u, gsm::Projected *__restrict__ proj, uint2 *__restrict__ rect,
                                                       uint32_t *__restrict__ tile_count, uint32_t *__restrict__ spine,
                                                       uint32_t *__restrict__ part_vis, const uint32_t *__restrict__ mask,
-                                                      float *__restrict__ zwin, GsControl *ctl)
+                                                      float *__restrict__ zwin, GsControl *ctl, uint32_t *__restrict__ spine_vis)
 {
-    k_project_body<ROUND>(sorted, splat, u, proj, rect, tile_count, spine, part_vis, mask, zwin, ctl);
+    k_project_body<ROUND>(sorted, splat, u, proj, rect, tile_count, spine, part_vis, mask, zwin, ctl, spine_vis);
 }
 
 // One workgroup: exclusive scan of the per-chunk totals (spine) -> chunk base offsets, I = grand total (refused and
@@ -210,7 +210,7 @@ template <int ROUND>
 __device__ __forceinline__ void k_pairs_check_body(GsControl *ctl, uint32_t pair_cap, uint32_t *__restrict__ spine,
                                                    const uint32_t *__restrict__ part_vis, uint32_t nparts, uint32_t near_count,
                                                    int last_round, uint32_t *__restrict__ mask, uint32_t mask_total_words,
-                                                   uint2 *__restrict__ extra)
+                                                   uint2 *__restrict__ extra, uint32_t *__restrict__ spine_vis, uint32_t vcap)
 {
     GS_CHAIN_PRIO();
     __shared__ uint32_t s_vis, s_wave[4], s_wave_e[4], s_tv[GS_SPINE_CACHED][GS_BLOCK], s_eb[GS_SPINE_CACHED][GS_BLOCK];
@@ -279,7 +279,24 @@ __device__ __forceinline__ void k_pairs_check_body(GsControl *ctl, uint32_t pair
         }
     }
 #undef GS_EXTRA_OF
+    // compact pair records (vcap > 0): the chunks' visible counts -> the index of each chunk's first visible splat among the round's
+    uint32_t vis_total = 0;
+    if (vcap) {
+        uint32_t sv = 0;
+        for (uint32_t i = lo; i < hi; i++) sv += spine_vis[i];
+        const uint32_t incv = wave_incl_scan_u32(sv, lane);
+        __syncthreads();
+        if (lane == 63) s_wave[w] = incv;
+        __syncthreads();
+        uint32_t bv = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) { const uint32_t t = s_wave[k]; if (k < w) bv += t; vis_total += t; }
+        uint32_t runv = bv + incv - sv;
+        for (uint32_t i = lo; i < hi; i++) { const uint32_t t = spine_vis[i]; spine_vis[i] = runv; runv += t; }
+    }
     if (threadIdx.x == 0) {
+        ctl->vis_total = vis_total;
+        const bool vis_over = vcap && vis_total > vcap;            // more visible splats than the records can name: like a pair overflow (re-rendered)
         ctl->n_emit_extra = fits ? total_e : 0u;
         if (ROUND == 0) { ctl->n_visible = 0; ctl->n_pairs_frame = 0; ctl->want_frame = 0; }
         else { ctl->unsat_round0 = ctl->unsat_count; if (ctl->unsat_count) ctl->unsat_events += 1; }
@@ -289,7 +306,7 @@ __device__ __forceinline__ void k_pairs_check_body(GsControl *ctl, uint32_t pair
         if (ctl->want_frame > ctl->max_total) ctl->max_total = ctl->want_frame;
         // a round that does not fit, or that follows one of this frame that did not (k_emit wrote nothing then), bins nothing:
         // the frame is re-rendered with larger buffers, and no kernel downstream may walk records that were never written
-        if (total > pair_cap) { ctl->pair_overflow = 1; ctl->overflow_sticky = 1; ctl->n_pairs = 0; }
+        if (total > pair_cap || vis_over) { ctl->pair_overflow = 1; ctl->overflow_sticky = 1; ctl->n_pairs = 0; }
         else if (round == 0) { ctl->pair_overflow = 0; ctl->n_pairs = total; }
         else ctl->n_pairs = ctl->pair_overflow ? 0u : total;
         ctl->n_visible += s_vis; ctl->n_pairs_frame += ctl->n_pairs;
@@ -304,9 +321,9 @@ template <int ROUND>
 __global__ __launch_bounds__(GS_BLOCK) void k_pairs_check(GsControl *ctl, uint32_t pair_cap, uint32_t *__restrict__ spine,
                                                           const uint32_t *__restrict__ part_vis, uint32_t nparts, uint32_t near_count,
                                                           int last_round, uint32_t *__restrict__ mask, uint32_t mask_total_words,
-                                                          uint2 *__restrict__ extra)
+                                                          uint2 *__restrict__ extra, uint32_t *__restrict__ spine_vis, uint32_t vcap)
 {
-    k_pairs_check_body<ROUND>(ctl, pair_cap, spine, part_vis, nparts, near_count, last_round, mask, mask_total_words, extra);
+    k_pairs_check_body<ROUND>(ctl, pair_cap, spine, part_vis, nparts, near_count, last_round, mask, mask_total_words, extra, spine_vis, vcap);
 }
 
 // (tile id, sorted position) records in splat order: pair slot = spine[chunk] + the in-chunk exclusive scan of tile_count
@@ -362,11 +379,13 @@ template <int ROUND, bool P32>
 __device__ __forceinline__ void k_emit_body(const gsm::Projected *__restrict__ proj, const uint2 *__restrict__ rect,
                                             const uint32_t *__restrict__ tile_count, const uint32_t *__restrict__ spine,
                                             const uint2 *__restrict__ extra, const GsFrameUniforms &u, void *__restrict__ pairs,
-                                            const uint32_t *__restrict__ mask, const GsControl *ctl)
+                                            const uint32_t *__restrict__ mask, const GsControl *ctl,
+                                            const uint32_t *__restrict__ spine_vis, gsm::Projected *__restrict__ projc,
+                                            const float *__restrict__ zwin, float *__restrict__ zwinc)
 {
     GS_CHAIN_PRIO();
     __shared__ float s_rec[GS_BLOCK][6];                            // the slice's splats: projected record,
-    __shared__ uint32_t s_sp[GS_BLOCK], s_ty[GS_BLOCK];             // index in the chunk, first | last tile row,
+    __shared__ uint32_t s_sp[GS_BLOCK], s_ty[GS_BLOCK];             // index in the chunk (or among the round's visible splats), first | last tile row,
     __shared__ uint32_t s_rb[GS_BLOCK + 1];                         // exclusive scan of their tile-row counts
     __shared__ uint32_t s_rt[GS_EMIT_RUNS], s_rx[GS_EMIT_RUNS];     // a batch of runs: first tile | splat << 24, exclusive scan of lengths
     __shared__ uint32_t s_rn[ROUND == 1 ? GS_EMIT_RUNS : 1];        // ROUND 1: the run's unmasked length
@@ -396,6 +415,18 @@ __device__ __forceinline__ void k_emit_body(const gsm::Projected *__restrict__ p
         const uint32_t ex = block_exscan(cnt, s_w, lane, w, n_c);
         const uint32_t q0 = sub * GS_EMIT_PAIRS;
         if (q0 >= n_c) continue;                                     // (uniform) a chunk without pairs
+        // compact records (u.pair_vcap): a pair names its splat by the splat's index among the round's VISIBLE splats; the chunk's
+        // first slice also leaves the visible splats' projected records (and window depths) in that order for the blend
+        uint32_t vid = c * GS_BLOCK + tid;
+        if (ROUND == 0 && u.pair_vcap) {
+            uint32_t nv;
+            vid = spine_vis[c] + block_exscan(cnt ? 1u : 0u, s_w, lane, w, nv);
+            if (sub == 0 && cnt) {
+                float4 *dst = reinterpret_cast<float4 *>(projc + vid);
+                dst[0] = ra; dst[1] = rb4;
+                if (u.has_depth) zwinc[vid] = zwin[j];
+            }
+        }
         const uint32_t q1 = n_c - q0 > GS_EMIT_PAIRS ? q0 + GS_EMIT_PAIRS : n_c;
         const bool needed = cnt != 0u && ex < q1 && ex + cnt > q0;
         const uint32_t nr = needed ? (rc.y >> 16) - (rc.x >> 16) + 1u : 0u;
@@ -404,7 +435,7 @@ __device__ __forceinline__ void k_emit_body(const gsm::Projected *__restrict__ p
         const uint32_t rb = block_exscan(nr, s_w, lane, w, R);
         if (needed) {
             s_rec[k][0] = ra.x; s_rec[k][1] = ra.y; s_rec[k][2] = ra.z; s_rec[k][3] = ra.w; s_rec[k][4] = rb4.x; s_rec[k][5] = rb4.y;
-            s_sp[k] = tid; s_ty[k] = (rc.x >> 16) | (rc.y & 0xFFFF0000u); s_rb[k] = rb;
+            s_sp[k] = vid; s_ty[k] = (rc.x >> 16) | (rc.y & 0xFFFF0000u); s_rb[k] = rb;   // (vid: position in the round, or visible index)
             if (k == 0) s_first = ex;
         }
         __syncthreads();
@@ -472,7 +503,7 @@ __device__ __forceinline__ void k_emit_body(const gsm::Projected *__restrict__ p
                         const uint32_t row = first / tiles_x, t0 = first % tiles_x;
                         tile = row * tiles_x + nth_masked_tile(mask + row * u.mask_words, t0, s_rn[run[i]], within);
                     }
-                    const uint32_t jrel = c * GS_BLOCK + s_sp[k1];
+                    const uint32_t jrel = s_sp[k1];
                     put_pair<P32>(pairs, base + s0 + p, tile, j_lo + jrel, jrel, u.pair_jbits);
                 }
             }
@@ -488,9 +519,11 @@ template <int ROUND, bool P32>
 __global__ __launch_bounds__(GS_BLOCK) void k_emit(const gsm::Projected *__restrict__ proj, const uint2 *__restrict__ rect,
                                                    const uint32_t *__restrict__ tile_count, const uint32_t *__restrict__ spine,
                                                    const uint2 *__restrict__ extra, GsFrameUniforms u, void *__restrict__ pairs,
-                                                   const uint32_t *__restrict__ mask, const GsControl *ctl)
+                                                   const uint32_t *__restrict__ mask, const GsControl *ctl,
+                                                   const uint32_t *__restrict__ spine_vis, gsm::Projected *__restrict__ projc,
+                                                   const float *__restrict__ zwin, float *__restrict__ zwinc)
 {
-    k_emit_body<ROUND, P32>(proj, rect, tile_count, spine, extra, u, pairs, mask, ctl);
+    k_emit_body<ROUND, P32>(proj, rect, tile_count, spine, extra, u, pairs, mask, ctl, spine_vis, projc, zwin, zwinc);
 }
 
 // [start,end) of every tile in the sorted pair list, written for ALL tiles (empty ones get an empty range at the
@@ -576,7 +609,8 @@ __device__ __forceinline__ void k_blend_body(const uint2 *__restrict__ tile_rang
     const int lane = threadIdx.x;
     if (ROUND == 1 && ctl->j_hi == 0) return;                      // every tile saturated in round 0
     const uint32_t ntiles = (uint32_t)u.tiles_x * (uint32_t)u.tiles_y;
-    const uint32_t pair_j_lo = ctl->j_lo, pair_j_mask = (1u << u.pair_jbits) - 1u;   // 4-byte pair records carry position - j_lo
+    // 4-byte pair records carry position - j_lo, or (compact) the index among the visible splats: `proj` is then the compacted array
+    const uint32_t pair_j_lo = u.pair_vcap ? 0u : ctl->j_lo, pair_j_mask = (1u << u.pair_jbits) - 1u;
     for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {   // round 0: one tile per wave; round 1: small grid
     const uint32_t tx = tile % (uint32_t)u.tiles_x, ty = tile / (uint32_t)u.tiles_x;
     if (ROUND == 1 && !((mask[ty * u.mask_words + (tx >> 5)] >> (tx & 31)) & 1u)) continue;   // this tile is final already
@@ -826,7 +860,7 @@ __device__ __forceinline__ void k_blend_px_body(const uint2 *__restrict__ tile_r
 #define GS_WAVE_LDS_SYNC() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); } while (0)
     if (ROUND == 1 && ctl->j_hi == 0) return;                      // every tile saturated in round 0
     const uint32_t ntiles = (uint32_t)u.tiles_x * (uint32_t)u.tiles_y;
-    const uint32_t pair_j_lo = ctl->j_lo, pair_j_mask = (1u << u.pair_jbits) - 1u;
+    const uint32_t pair_j_lo = u.pair_vcap ? 0u : ctl->j_lo, pair_j_mask = (1u << u.pair_jbits) - 1u;
     for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const uint32_t tx = tile % (uint32_t)u.tiles_x, ty = tile / (uint32_t)u.tiles_x;
         if (ROUND == 1 && !((mask[ty * u.mask_words + (tx >> 5)] >> (tx & 31)) & 1u)) continue;   // this tile is final already
@@ -965,6 +999,34 @@ __global__ __launch_bounds__(256) void k_blend_px(const uint2 *__restrict__ tile
 
 int bits_for(uint32_t n) { int b = 1; while (b < 32 && (1u << b) < n) b++; return b; }
 
+// Compact pair records for a first binning round: bits of the visible-splat index, or 0 = not this time.  Used where the position
+// form does not fit 32 bits (or GS_OPT_WIDE_PAIRS = 2 asks for it), the number of visible splats is known from the frames
+// collected so far (vis_hint = the last + 1/8 + 4096), and tile bits + index bits fit.  A round with more visible
+// splats than that is re-rendered (k_pairs_check raises the pair-overflow flag) with the hint it then leaves.
+int gs_compact_bits(const gs_ctx *ctx, int tb, int jb)
+{
+    const gs_ctx *P = gs_root(const_cast<gs_ctx *>(ctx));
+    if (P->wide_pairs || (tb + jb <= 32 && !P->compact_pairs)) return 0;
+    const uint32_t hint = __atomic_load_n(&P->vis_hint, __ATOMIC_RELAXED);
+    if (!hint) return 0;
+    int vb = bits_for(hint);
+    if (vb < 10) vb = 10;
+    return (tb + vb <= 32 && vb <= 20 && vb < jb) ? vb : 0;
+}
+
+int gs_ensure_compact(gs_ctx *ctx, size_t vcap)
+{
+    if (vcap <= ctx->projc_cap) return GS_OK;
+    GS_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->projc) (void)hipFree(ctx->projc);
+    if (ctx->zwinc) (void)hipFree(ctx->zwinc);
+    ctx->projc = nullptr; ctx->zwinc = nullptr; ctx->projc_cap = 0;
+    GS_HIP(hipMalloc((void **)&ctx->projc, vcap * sizeof(gsm::Projected)));
+    GS_HIP(hipMalloc((void **)&ctx->zwinc, vcap * sizeof(float)));
+    ctx->projc_cap = vcap;
+    return GS_OK;
+}
+
 // one round: project -> offsets -> emit -> stable sort by tile -> ranges -> blend.  Round 1 usually finds nothing to
 // do (every tile saturated), so it is launched on small grids: its kernels grid-stride when there is work.
 template <int ROUND>
@@ -982,28 +1044,36 @@ int run_round(gs_ctx *ctx, const GsFrameUniforms &u, uint8_t *out, bool last_rou
     // what the pair sort should expect (grid, one- or two-level offsets): round 1 usually finds nothing; round 0 about what
     // the last collected frames binned (0 = not known yet: the capacity)
     const uint32_t ph = ROUND == 1 ? (uint32_t)(small * GS_CHUNK_S) : __atomic_load_n(&gs_root(ctx)->pair_hint, __ATOMIC_RELAXED);
-    hipLaunchKernelGGL(k_project<ROUND>, dim3(g), dim3(GS_BLOCK), 0, st, ctx->sorted, ctx->splat, u, ctx->proj, ctx->rect,
-                       ctx->tile_count, ctx->spine, ctx->part_vis, ctx->unsat_mask, ctx->zwin, ctx->ctl);
-    GS_HIP(hipGetLastError());
-    if (ROUND == 0) GS_PROF_RECORD(ctx, 3);
-    hipLaunchKernelGGL(k_pairs_check<ROUND>, dim3(1), dim3(GS_BLOCK), 0, st, ctx->ctl, (uint32_t)ctx->pair_cap, ctx->spine, ctx->part_vis, g,
-                       u.near_count, last_round ? 1 : 0, ctx->unsat_mask, (uint32_t)u.tiles_y * u.mask_words, ctx->emit_extra);
-    // pair record format: 4 bytes when the tile id and the round's position range fit in 32 bits together
+    // pair record format: 4 bytes when the tile id and the round's position range fit in 32 bits together -- or, where they do not
+    // (a 4K frame: 15 tile bits; a scene whose tiles do not saturate: 20 position bits), when the tile id and the index among the
+    // round's VISIBLE splats do (compact records: gs_compact_bits)
     const int tb = bits_for(ntiles);
     const uint32_t jrange = ROUND == 0 ? (u.near_count != 0xFFFFFFFFu && u.near_count < Vmax ? u.near_count : Vmax) : Vmax;
     const int jb = bits_for(jrange);
-    const bool p32 = !ctx->wide_pairs && tb + jb <= 32;
+    const int vb = ROUND == 0 ? gs_compact_bits(ctx, tb, jb) : 0;
+    const bool p32 = vb > 0 || (!ctx->wide_pairs && tb + jb <= 32);
     GsFrameUniforms v = u;
-    v.pair_jbits = p32 ? (uint32_t)jb : 0u;
+    v.pair_jbits = vb > 0 ? (uint32_t)vb : (p32 ? (uint32_t)jb : 0u);
+    v.pair_vcap = vb > 0 ? 1u << vb : 0u;
+    if (vb > 0) { const int rcc = gs_ensure_compact(ctx, (size_t)1 << vb); if (rcc != GS_OK) return rcc; }
+    hipLaunchKernelGGL(k_project<ROUND>, dim3(g), dim3(GS_BLOCK), 0, st, ctx->sorted, ctx->splat, u, ctx->proj, ctx->rect,
+                       ctx->tile_count, ctx->spine, ctx->part_vis, ctx->unsat_mask, ctx->zwin, ctx->ctl, ctx->spine_vis);
+    GS_HIP(hipGetLastError());
+    if (ROUND == 0) GS_PROF_RECORD(ctx, 3);
+    hipLaunchKernelGGL(k_pairs_check<ROUND>, dim3(1), dim3(GS_BLOCK), 0, st, ctx->ctl, (uint32_t)ctx->pair_cap, ctx->spine, ctx->part_vis, g,
+                       u.near_count, last_round ? 1 : 0, ctx->unsat_mask, (uint32_t)u.tiles_y * u.mask_words, ctx->emit_extra, ctx->spine_vis, v.pair_vcap);
     // (items = the round's chunks + the extra slices of the heavy ones: about I / GS_EMIT_PAIRS more)
     uint32_t ge = g + (ROUND == 1 ? 0u : gs_div_up(ph ? ph : pc, GS_EMIT_PAIRS)); if (ge > GS_MAX_PART) ge = GS_MAX_PART;
     if (p32) hipLaunchKernelGGL((k_emit<ROUND, true>), dim3(ge), dim3(GS_BLOCK), 0, st, ctx->proj, ctx->rect, ctx->tile_count, ctx->spine,
-                                ctx->emit_extra, v, (void *)ctx->pair_a, ctx->unsat_mask, ctx->ctl);
+                                ctx->emit_extra, v, (void *)ctx->pair_a, ctx->unsat_mask, ctx->ctl, ctx->spine_vis, ctx->projc, ctx->zwin, ctx->zwinc);
     else hipLaunchKernelGGL((k_emit<ROUND, false>), dim3(ge), dim3(GS_BLOCK), 0, st, ctx->proj, ctx->rect, ctx->tile_count, ctx->spine,
-                            ctx->emit_extra, v, (void *)ctx->pair_a, ctx->unsat_mask, ctx->ctl);
+                            ctx->emit_extra, v, (void *)ctx->pair_a, ctx->unsat_mask, ctx->ctl, ctx->spine_vis, ctx->projc, ctx->zwin, ctx->zwinc);
+    // (compact records: the blend reads the visible splats' records and window depths from the compacted arrays)
+    const gsm::Projected *bproj = v.pair_vcap ? ctx->projc : ctx->proj;
+    const float *bzwin = v.pair_vcap ? ctx->zwinc : ctx->zwin;
     GS_HIP(hipGetLastError());
     int rc;
-    const int fmt = p32 ? GS_RADIX_KEYONLY : GS_RADIX_PACKED, sh = p32 ? jb : 0;
+    const int fmt = p32 ? GS_RADIX_KEYONLY : GS_RADIX_PACKED, sh = p32 ? (int)v.pair_jbits : 0;   // (the tile id sits above the position / visible-index bits)
     const void *fpairs;
     if (tb <= 9) {
         rc = gs_launch_radix_pass(ctx, ctx->pair_a, fmt, ctx->pair_b, fmt, &ctx->ctl->n_pairs, pc, ph, sh, tb);
@@ -1027,13 +1097,13 @@ int run_round(gs_ctx *ctx, const GsFrameUniforms &u, uint8_t *out, bool last_rou
     if (v.split_min) {
         // the tiles with long lists first (the long pole): workgroups stride over all tiles' ranges and take the long ones
         const uint32_t gp = ntiles < 2048 ? ntiles : 2048;
-        if (scene) hipLaunchKernelGGL((k_blend_px<ROUND, true>), dim3(gp), dim3(256), 0, st, ctx->tile_range, fpairs, ctx->proj, v, out, ctx->state,
-                                      ctx->unsat_mask, ctx->zwin, ctx->scene_depth, ctx->scene_rgba, ctx->ctl);
-        else hipLaunchKernelGGL((k_blend_px<ROUND, false>), dim3(gp), dim3(256), 0, st, ctx->tile_range, fpairs, ctx->proj, v, out, ctx->state,
-                                ctx->unsat_mask, ctx->zwin, ctx->scene_depth, ctx->scene_rgba, ctx->ctl);
+        if (scene) hipLaunchKernelGGL((k_blend_px<ROUND, true>), dim3(gp), dim3(256), 0, st, ctx->tile_range, fpairs, bproj, v, out, ctx->state,
+                                      ctx->unsat_mask, bzwin, ctx->scene_depth, ctx->scene_rgba, ctx->ctl);
+        else hipLaunchKernelGGL((k_blend_px<ROUND, false>), dim3(gp), dim3(256), 0, st, ctx->tile_range, fpairs, bproj, v, out, ctx->state,
+                                ctx->unsat_mask, bzwin, ctx->scene_depth, ctx->scene_rgba, ctx->ctl);
     }
-#define GS_LAUNCH_BLEND(C, S) hipLaunchKernelGGL((k_blend<C, ROUND, S>), dim3(gb), dim3(64), 0, st, ctx->tile_range, fpairs, ctx->proj, v, \
-                                                out, ctx->state, ctx->unsat_mask, ctx->zwin, ctx->scene_depth, ctx->scene_rgba, ctx->ctl)
+#define GS_LAUNCH_BLEND(C, S) hipLaunchKernelGGL((k_blend<C, ROUND, S>), dim3(gb), dim3(64), 0, st, ctx->tile_range, fpairs, bproj, v, \
+                                                out, ctx->state, ctx->unsat_mask, bzwin, ctx->scene_depth, ctx->scene_rgba, ctx->ctl)
     if (u.flags & GS_RENDER_COUNT_FRAGS) { if (scene) GS_LAUNCH_BLEND(true, true); else GS_LAUNCH_BLEND(true, false); }
     else { if (scene) GS_LAUNCH_BLEND(false, true); else GS_LAUNCH_BLEND(false, false); }
 #undef GS_LAUNCH_BLEND
@@ -1063,34 +1133,39 @@ int run_round2(gs_ctx *const S[2], const GsFrameUniforms U[2], uint8_t *const ou
     if (ROUND == 0 && u.near_count != 0xFFFFFFFFu) { const uint32_t gn = gs_div_up(u.near_count < Vmax ? u.near_count : Vmax, GS_BLOCK); if (gn < g) g = gn ? gn : 1; }
     const uint32_t pc = (uint32_t)(S[0]->pair_cap < S[1]->pair_cap ? S[0]->pair_cap : S[1]->pair_cap);
     const uint32_t ph = ROUND == 1 ? (uint32_t)(small * GS_CHUNK_S) : __atomic_load_n(&gs_root(ctx)->pair_hint, __ATOMIC_RELAXED);
+    const int tb = bits_for(ntiles);
+    const uint32_t jrange = ROUND == 0 ? (u.near_count != 0xFFFFFFFFu && u.near_count < Vmax ? u.near_count : Vmax) : Vmax;
+    const int jb = bits_for(jrange);
+    const int vb = ROUND == 0 ? gs_compact_bits(ctx, tb, jb) : 0;
+    const bool p32 = vb > 0 || (!ctx->wide_pairs && tb + jb <= 32);
+    GsFrameUniforms V[2] = { U[0], U[1] };
+    V[0].pair_jbits = V[1].pair_jbits = vb > 0 ? (uint32_t)vb : (p32 ? (uint32_t)jb : 0u);
+    V[0].pair_vcap = V[1].pair_vcap = vb > 0 ? 1u << vb : 0u;
+    if (vb > 0) for (int k = 0; k < 2; k++) { const int rcc = gs_ensure_compact(S[k], (size_t)1 << vb); if (rcc != GS_OK) return rcc; }
     gs_twin<F_project<ROUND>, GS_BLOCK>(g, st,
         gs_pack_make((const uint32_t *)S[0]->sorted, (const uint4 *)S[0]->splat, U[0], S[0]->proj, S[0]->rect, S[0]->tile_count, S[0]->spine, S[0]->part_vis,
-                     (const uint32_t *)S[0]->unsat_mask, S[0]->zwin, S[0]->ctl),
+                     (const uint32_t *)S[0]->unsat_mask, S[0]->zwin, S[0]->ctl, S[0]->spine_vis),
         gs_pack_make((const uint32_t *)S[1]->sorted, (const uint4 *)S[1]->splat, U[1], S[1]->proj, S[1]->rect, S[1]->tile_count, S[1]->spine, S[1]->part_vis,
-                     (const uint32_t *)S[1]->unsat_mask, S[1]->zwin, S[1]->ctl));
+                     (const uint32_t *)S[1]->unsat_mask, S[1]->zwin, S[1]->ctl, S[1]->spine_vis));
     GS_HIP(hipGetLastError());
     if (ROUND == 0) GS_PROF_RECORD(ctx, 3);
     gs_twin<F_pairs_check<ROUND>, GS_BLOCK>(1, st,
         gs_pack_make(S[0]->ctl, (uint32_t)S[0]->pair_cap, S[0]->spine, (const uint32_t *)S[0]->part_vis, g, U[0].near_count, last_round ? 1 : 0, S[0]->unsat_mask,
-                     (uint32_t)u.tiles_y * u.mask_words, S[0]->emit_extra),
+                     (uint32_t)u.tiles_y * u.mask_words, S[0]->emit_extra, S[0]->spine_vis, V[0].pair_vcap),
         gs_pack_make(S[1]->ctl, (uint32_t)S[1]->pair_cap, S[1]->spine, (const uint32_t *)S[1]->part_vis, g, U[1].near_count, last_round ? 1 : 0, S[1]->unsat_mask,
-                     (uint32_t)u.tiles_y * u.mask_words, S[1]->emit_extra));
-    const int tb = bits_for(ntiles);
-    const uint32_t jrange = ROUND == 0 ? (u.near_count != 0xFFFFFFFFu && u.near_count < Vmax ? u.near_count : Vmax) : Vmax;
-    const int jb = bits_for(jrange);
-    const bool p32 = !ctx->wide_pairs && tb + jb <= 32;
-    GsFrameUniforms V[2] = { U[0], U[1] };
-    V[0].pair_jbits = V[1].pair_jbits = p32 ? (uint32_t)jb : 0u;
+                     (uint32_t)u.tiles_y * u.mask_words, S[1]->emit_extra, S[1]->spine_vis, V[1].pair_vcap));
     uint32_t ge = g + (ROUND == 1 ? 0u : gs_div_up(ph ? ph : pc, GS_EMIT_PAIRS)); if (ge > GS_MAX_PART) ge = GS_MAX_PART;
 #define GS_EMIT2(P) gs_twin<F_emit<ROUND, P>, GS_BLOCK>(ge, st,                                                                                         \
         gs_pack_make((const gsm::Projected *)S[0]->proj, (const uint2 *)S[0]->rect, (const uint32_t *)S[0]->tile_count, (const uint32_t *)S[0]->spine,    \
-                     (const uint2 *)S[0]->emit_extra, V[0], (void *)S[0]->pair_a, (const uint32_t *)S[0]->unsat_mask, (const GsControl *)S[0]->ctl),      \
+                     (const uint2 *)S[0]->emit_extra, V[0], (void *)S[0]->pair_a, (const uint32_t *)S[0]->unsat_mask, (const GsControl *)S[0]->ctl,       \
+                     (const uint32_t *)S[0]->spine_vis, S[0]->projc, (const float *)S[0]->zwin, S[0]->zwinc),                                            \
         gs_pack_make((const gsm::Projected *)S[1]->proj, (const uint2 *)S[1]->rect, (const uint32_t *)S[1]->tile_count, (const uint32_t *)S[1]->spine,    \
-                     (const uint2 *)S[1]->emit_extra, V[1], (void *)S[1]->pair_a, (const uint32_t *)S[1]->unsat_mask, (const GsControl *)S[1]->ctl))
+                     (const uint2 *)S[1]->emit_extra, V[1], (void *)S[1]->pair_a, (const uint32_t *)S[1]->unsat_mask, (const GsControl *)S[1]->ctl,       \
+                     (const uint32_t *)S[1]->spine_vis, S[1]->projc, (const float *)S[1]->zwin, S[1]->zwinc))
     if (p32) GS_EMIT2(true); else GS_EMIT2(false);
 #undef GS_EMIT2
     GS_HIP(hipGetLastError());
-    const int fmt = p32 ? GS_RADIX_KEYONLY : GS_RADIX_PACKED, sh = p32 ? jb : 0;
+    const int fmt = p32 ? GS_RADIX_KEYONLY : GS_RADIX_PACKED, sh = p32 ? (int)V[0].pair_jbits : 0;
     const void *in[2]; void *outp[2]; const uint32_t *np[2] = { &S[0]->ctl->n_pairs, &S[1]->ctl->n_pairs };
     uint32_t *cnt[2] = { nullptr, nullptr }; const uint32_t *fill[2] = { nullptr, nullptr };
     const void *fpairs[2];
@@ -1117,18 +1192,20 @@ int run_round2(gs_ctx *const S[2], const GsFrameUniforms U[2], uint8_t *const ou
     if (ROUND == 0) GS_PROF_RECORD(ctx, 4);
     const uint32_t gb = ROUND == 1 ? (ntiles < 1024 ? ntiles : 1024) : ntiles;
     const bool scene = u.has_depth || u.has_scene_rgba;
+    const gsm::Projected *bproj[2] = { vb > 0 ? S[0]->projc : S[0]->proj, vb > 0 ? S[1]->projc : S[1]->proj };
+    const float *bzwin[2] = { vb > 0 ? S[0]->zwinc : S[0]->zwin, vb > 0 ? S[1]->zwinc : S[1]->zwin };
 #define GS_BLENDPX2(SC) gs_twin<F_blend_px<ROUND, SC>, 256>(ntiles < 2048 ? ntiles : 2048, st,                                                          \
-        gs_pack_make((const uint2 *)S[0]->tile_range, fpairs[0], (const gsm::Projected *)S[0]->proj, V[0], out[0], S[0]->state, S[0]->unsat_mask,         \
-                     (const float *)S[0]->zwin, (const float *)S[0]->scene_depth, (const uint32_t *)S[0]->scene_rgba, S[0]->ctl),                        \
-        gs_pack_make((const uint2 *)S[1]->tile_range, fpairs[1], (const gsm::Projected *)S[1]->proj, V[1], out[1], S[1]->state, S[1]->unsat_mask,         \
-                     (const float *)S[1]->zwin, (const float *)S[1]->scene_depth, (const uint32_t *)S[1]->scene_rgba, S[1]->ctl))
+        gs_pack_make((const uint2 *)S[0]->tile_range, fpairs[0], bproj[0], V[0], out[0], S[0]->state, S[0]->unsat_mask,         \
+                     bzwin[0], (const float *)S[0]->scene_depth, (const uint32_t *)S[0]->scene_rgba, S[0]->ctl),                        \
+        gs_pack_make((const uint2 *)S[1]->tile_range, fpairs[1], bproj[1], V[1], out[1], S[1]->state, S[1]->unsat_mask,         \
+                     bzwin[1], (const float *)S[1]->scene_depth, (const uint32_t *)S[1]->scene_rgba, S[1]->ctl))
     if (u.split_min) { if (scene) GS_BLENDPX2(true); else GS_BLENDPX2(false); }   // the tiles with long lists first
 #undef GS_BLENDPX2
 #define GS_BLEND2(SC) gs_twin<F_blend<ROUND, SC>, 64>(gb, st,                                                                                           \
-        gs_pack_make((const uint2 *)S[0]->tile_range, fpairs[0], (const gsm::Projected *)S[0]->proj, V[0], out[0], S[0]->state, S[0]->unsat_mask,         \
-                     (const float *)S[0]->zwin, (const float *)S[0]->scene_depth, (const uint32_t *)S[0]->scene_rgba, S[0]->ctl),                        \
-        gs_pack_make((const uint2 *)S[1]->tile_range, fpairs[1], (const gsm::Projected *)S[1]->proj, V[1], out[1], S[1]->state, S[1]->unsat_mask,         \
-                     (const float *)S[1]->zwin, (const float *)S[1]->scene_depth, (const uint32_t *)S[1]->scene_rgba, S[1]->ctl))
+        gs_pack_make((const uint2 *)S[0]->tile_range, fpairs[0], bproj[0], V[0], out[0], S[0]->state, S[0]->unsat_mask,         \
+                     bzwin[0], (const float *)S[0]->scene_depth, (const uint32_t *)S[0]->scene_rgba, S[0]->ctl),                        \
+        gs_pack_make((const uint2 *)S[1]->tile_range, fpairs[1], bproj[1], V[1], out[1], S[1]->state, S[1]->unsat_mask,         \
+                     bzwin[1], (const float *)S[1]->scene_depth, (const uint32_t *)S[1]->scene_rgba, S[1]->ctl))
     if (scene) GS_BLEND2(true); else GS_BLEND2(false);
 #undef GS_BLEND2
     GS_HIP(hipGetLastError());

@@ -373,8 +373,11 @@ typedef struct gs_stats {
                                    chain of frame k+1 runs under the tail of frame k -- as the reference overlaps its
                                    worker sort with drawing.  A gs_sort() begins a frame; it moves to the next lane when
                                    the previous frame was handed off asynchronously.  1 = strictly one frame at a time   */
-#define GS_OPT_WIDE_PAIRS 6     /* value != 0: always bin with 8-byte (tile, position) records; default 0 = 4-byte records
-                                   whenever tile bits + position bits of the binning round fit in 32 (same images)      */
+#define GS_OPT_WIDE_PAIRS 6     /* record format of the binning (same images whatever the format).  0 (default): 4 bytes `tile << b | position`
+                                   whenever tile bits + position bits of the binning round fit in 32; where they do not (a 4K frame, a
+                                   scene whose tiles do not saturate) 4 bytes `tile << b | index among the round's visible splats` when
+                                   THAT fits -- the number of visible splats is known from the frames before --, else 8 bytes.  1: always
+                                   8-byte (tile, position) records.  2: the visible-index form wherever it fits.                 */
 #define GS_OPT_ENQUEUE_THREADS 7 /* default 1: gs_sort() (without an output array) and gs_render_device(GS_RENDER_ASYNC) hand the
                                    frame to a worker thread of its pipeline lane, which does the ~18 kernel launches, so the
                                    launches of the frames in flight run in parallel; failures surface at gs_sync().  0: the

@@ -1042,6 +1042,42 @@ def test_narrow_and_wide_pair_records_give_identical_frames(w, h, n, permille):
             out[wide] = (img, pairs, c.stats()["n_frags"])
     assert np.array_equal(out[0][0], out[1][0]) and out[0][1] == out[1][1] and out[0][2] == out[1][2]
     assert out[0][1] > 0
+    # the third form (round 3): 4-byte records naming a splat by its index among the round's VISIBLE splats, whose projected records
+    # k_emit lays out in that order -- what a 4K frame (15 tile bits) or an unsaturated scene (20 position bits) falls back on
+    # instead of 8-byte records.  GS_OPT_WIDE_PAIRS = 2 uses it wherever it fits; the first frame (no hint of the number of visible
+    # splats yet) is drawn with the other forms, the following ones compact: synchronous, queued alone and in pairs, over a scene.
+    with capi.Context(0) as c:
+        c.set_option(capi.OPT_WIDE_PAIRS, 2)
+        c.set_option(capi.OPT_NEAR_PERMILLE, permille)
+        c.push_splat(rows)
+        for rep in range(3):
+            c.sort(cam["view"], want_indices=False)
+            assert np.array_equal(c.render(_params(cam)), out[0][0]), rep
+            assert permille == 0 or c.stats()["n_pairs"] == out[0][1]          # (adaptive: the share moves from frame to frame)
+        c.render(_params(cam, flags=capi.RENDER_COUNT_FRAGS))
+        assert c.stats()["n_frags"] == out[0][2]
+        for batch in (1, 2):
+            c.set_option(capi.OPT_FRAME_BATCH, batch)
+            bufs = [capi.host_frame(h, w) for _ in range(4)]
+            for b, _ in bufs:
+                c.sort(cam["view"], want_indices=False)
+                c.render_into(_params(cam, flags=capi.RENDER_ASYNC), b)
+            c.sync()
+            for b, o in bufs:
+                assert np.array_equal(b, out[0][0]), batch
+                o.free()
+        depth = np.full((h, w), 0.9996, np.float32); depth[:, : w // 2] = 1.0
+        want_scene = None
+        for mode in (1, 2):
+            c.set_option(capi.OPT_WIDE_PAIRS, mode)
+            c.set_scene(depth, None)
+            c.sort(cam["view"], want_indices=False)
+            img = c.render(_params(cam))
+            img = c.render(_params(cam))
+            c.set_scene(None, None)
+            if want_scene is None:
+                want_scene = img
+            assert np.array_equal(img, want_scene), mode
 
 
 def test_enqueue_threads_on_and_off_give_identical_frames_and_statistics(scene_small):
