@@ -1061,9 +1061,24 @@ static int render_sync_on_lane(gs_ctx *ctx, const GsFrameUniforms &u, void *devi
     const size_t sw = (size_t)(u.x1 - u.x0);
     TRY(ensure_frame_buffers(ctx, u, device_rgba == nullptr));
     TRY(ensure_sort_covers(ctx, u));
+    if (host_rgba) {
+        if (!stride) stride = sw * 4;
+        if (stride < sw * 4) FAIL(GS_E_BADARG, "stride %zu smaller than a row (%zu bytes)", stride, sw * 4);
+    }
+    // the frame's way to the host is queued right behind its kernels, before the control block has told whether the frame is
+    // complete (one stream synchronisation per frame instead of two); the rare frame that is not is drawn and copied again
+    auto queue_copy = [&]() -> int {
+        if (!host_rgba) return GS_OK;
+        const uint8_t *src = device_rgba ? (const uint8_t *)device_rgba : ctx->fb;
+        // (a tight frame is ONE linear copy: the 2-D form goes through a slower path of the runtime even when pitch == width)
+        if (stride == sw * 4) GS_HIP(hipMemcpyAsync(host_rgba, src, sw * 4 * (size_t)u.H, hipMemcpyDeviceToHost, ctx->stream));
+        else GS_HIP(hipMemcpy2DAsync(host_rgba, stride, src, sw * 4, sw * 4, (size_t)u.H, hipMemcpyDeviceToHost, ctx->stream));
+        return GS_OK;
+    };
     for (int attempt = 0;; attempt++) {
         TRY(gs_run_render(ctx, u, (uint8_t *)device_rgba));
         GS_HIP(hipMemcpyAsync(ctx->ctl_host, ctx->ctl, sizeof(GsControl), hipMemcpyDeviceToHost, ctx->stream));
+        TRY(queue_copy());
         GS_HIP(hipStreamSynchronize(ctx->stream));
         if (ctx->profile && ctx->ring) { ctx->ring_head++; ctx->ring_pending++; TRY(prof_drain(ctx)); }
         if (ctx->ctl_host->round1_missed) {
@@ -1072,6 +1087,7 @@ static int render_sync_on_lane(gs_ctx *ctx, const GsFrameUniforms &u, void *devi
             TRY(ensure_full_sort(ctx));                             // (round 1 reads the far part of the order)
             TRY(gs_run_round1(ctx, u, (uint8_t *)device_rgba));
             GS_HIP(hipMemcpyAsync(ctx->ctl_host, ctx->ctl, sizeof(GsControl), hipMemcpyDeviceToHost, ctx->stream));
+            TRY(queue_copy());
             GS_HIP(hipStreamSynchronize(ctx->stream));
             ctx->ctl_host->round1_missed = 1;                      // seen by the adaptation below
         }
@@ -1082,15 +1098,6 @@ static int render_sync_on_lane(gs_ctx *ctx, const GsFrameUniforms &u, void *devi
     }
     ctx->async_pending = false;
     if (u.flags & GS_RENDER_COUNT_FRAGS) ctx->stats.n_frags = ctx->ctl_host->n_frags;
-    if (host_rgba) {
-        const uint8_t *src = device_rgba ? (const uint8_t *)device_rgba : ctx->fb;
-        if (!stride) stride = sw * 4;
-        if (stride < sw * 4) FAIL(GS_E_BADARG, "stride %zu smaller than a row (%zu bytes)", stride, sw * 4);
-        // (a tight frame is ONE linear copy: the 2-D form goes through a slower path of the runtime even when pitch == width)
-        if (stride == sw * 4) GS_HIP(hipMemcpyAsync(host_rgba, src, sw * 4 * (size_t)u.H, hipMemcpyDeviceToHost, ctx->stream));
-        else GS_HIP(hipMemcpy2DAsync(host_rgba, stride, src, sw * 4, sw * 4, (size_t)u.H, hipMemcpyDeviceToHost, ctx->stream));
-        GS_HIP(hipStreamSynchronize(ctx->stream));
-    }
     return GS_OK;
 }
 

@@ -663,7 +663,7 @@ def secondary_measurements(ctx, capi, synth, rows, cams, views, n_splats, args, 
     ctx.set_option(capi.OPT_PIPELINE_DEPTH, int(os.environ.get("GS_BENCH_DEPTH", "0")) or 3)
     ctx.set_option(capi.OPT_FRAME_BATCH, frame_batch)           # (as in the timed loop)
     # the same delivery with frames in flight: gs_render(GS_RENDER_ASYNC), each frame into its own page-locked buffer
-    NB = 24                                                  # (3 lanes x 2 frames per launch in flight, four times over: a sync drains the lanes)
+    NB = 48                                                  # (3 lanes x 2 frames per launch in flight, eight times over: a sync drains the lanes)
     bufs = [capi.host_frame(H, W) for _ in range(NB)]
 
     def loop_host(nn):
@@ -694,7 +694,7 @@ def secondary_measurements(ctx, capi, synth, rows, cams, views, n_splats, args, 
     pipe = {}
     for mode, tag in ((0, "copy_engine"), (1, "blend_writes_host")):
         ctx.set_option(capi.OPT_HOST_WRITE, mode)
-        loop_host(24)
+        loop_host(48)
         pipe[tag] = m / loop_host(m)
     ctx.set_option(capi.OPT_HOST_WRITE, 0)
     for _, o in bufs:
@@ -705,7 +705,7 @@ def secondary_measurements(ctx, capi, synth, rows, cams, views, n_splats, args, 
                                  "pipelined_GBps": round(pipe[best] * fb_bytes / 1e9, 2),
                                  "frac_of_pcie": round(pipe[best] * fb_bytes / 1e9 / pcie, 4) if pcie else None,
                                  "note_pipelined": "gs_render with GS_RENDER_ASYNC: frames queued on the three pipeline lanes, each into its own "
-                                                   "page-locked buffer (24 buffers, gs_sync every 24 frames); frac_of_pcie = delivered bytes/s "
+                                                   "page-locked buffer (48 buffers, gs_sync every 48 frames: a consumer that keeps frames queued); frac_of_pcie = delivered bytes/s "
                                                    "over pcie_d2h_peak_GBps"})
     # the blend without early termination (every reference-equivalent fragment evaluated), pipelined like the headline
     loop(6, capi.RENDER_ASYNC | capi.RENDER_NO_EARLY_OUT)
