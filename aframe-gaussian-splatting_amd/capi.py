@@ -25,7 +25,7 @@ OPT_HOST_WRITE = 14
 OPT_SORT_SHARE = 15
 TRANSPORT_RCCL, TRANSPORT_INPROC = 0, 1
 COMM_ID_BYTES = 128
-BUF_CENTER_SCALE, BUF_COV_COLOR, BUF_SORT_ROWS, BUF_SORTED, BUF_PROJECTED, BUF_TILE_COUNT, BUF_TILE_STATS = 0, 1, 2, 3, 4, 5, 6
+BUF_CENTER_SCALE, BUF_COV_COLOR, BUF_SORT_ROWS, BUF_SORTED, BUF_PROJECTED, BUF_TILE_COUNT, BUF_TILE_STATS, BUF_UNSAT_MASK = 0, 1, 2, 3, 4, 5, 6, 7
 
 EXPORTS = [
     "gs_create", "gs_destroy", "gs_last_error", "gs_version", "gs_device_count", "gs_clear", "gs_push_splat", "gs_push_matrices", "gs_load_ply",

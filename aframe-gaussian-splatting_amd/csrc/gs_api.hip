@@ -15,6 +15,9 @@
 #include "gs_ply.h"
 #include "gs_host_tables.h"
 
+#ifndef GS_NEAR_FLOOR_MULT
+#define GS_NEAR_FLOOR_MULT 1.2f     // the adaptive share never again shrinks below this x the share that failed (1.3: 5 % more pairs than needed, 1.15: redraws)
+#endif
 static thread_local char g_create_err[512] = "";
 thread_local char *gs_tl_err = nullptr;
 
@@ -259,7 +262,7 @@ static int collect_status(gs_ctx *lane, bool *overflowed)
         __atomic_store_n(&ctx->pair_hint, h > 0xFFFFFFFFull ? 0u : (uint32_t)h, __ATOMIC_RELAXED);
     }
     // Adapt the share of splats binned in round 0.  An "event" = a frame whose round 0 left tiles unsaturated (round 1
-    // re-binned for them): the share grows x1.5 and will never again shrink below 1.3 x the share that failed; without
+    // re-binned for them): the share grows x1.5 and will never again shrink below 1.2 x the share that failed; without
     // events it shrinks 10 % per collected frame until the first event, 2 % afterwards.  After 16 clean frames round 1 is not even launched (11 empty kernels
     // cost ~50 us): blend<0> raises round1_missed if that was wrong, and the frame is completed / re-rendered.
     if (ctx->adapt_frozen) {
@@ -272,7 +275,7 @@ static int collect_status(gs_ctx *lane, bool *overflowed)
         lane->seen_unsat_events = c->unsat_events; lane->seen_acc_frames = c->acc_frames;
         if (lane->last_two_rounds) {
             if (events || c->round1_missed) {
-                const float fl = ctx->near_frac * 1.3f > 1.0f ? 1.0f : ctx->near_frac * 1.3f;
+                const float fl = ctx->near_frac * GS_NEAR_FLOOR_MULT > 1.0f ? 1.0f : ctx->near_frac * GS_NEAR_FLOOR_MULT;
                 if (fl > ctx->near_floor) ctx->near_floor = fl;
                 float nf = ctx->near_frac * 1.5f; if (nf < ctx->near_floor) nf = ctx->near_floor; if (nf > 1.0f) nf = 1.0f;
                 ctx->near_frac = nf; ctx->clean_frames = 0; ctx->skip_hold = 32;
@@ -1504,6 +1507,7 @@ GS_API int gs_download(gs_ctx *ctx, int which, void *out, size_t nbytes)
     case GS_BUF_PROJECTED: src = L->proj; have = L->have_sort ? V * 32 : 0; break;
     case GS_BUF_TILE_COUNT: src = L->tile_count; have = L->have_sort ? V * 4 : 0; break;
     case GS_BUF_TILE_STATS: src = L->tile_range; have = L->tile_cap * 8; break;
+    case GS_BUF_UNSAT_MASK: src = L->unsat_mask; have = L->mask_cap * 4; break;
     default: FAIL(GS_E_BADARG, "unknown buffer %d", which);
     }
     if (nbytes > have) FAIL(GS_E_BADARG, "buffer %d holds %zu bytes, %zu requested", which, have, nbytes);

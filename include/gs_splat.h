@@ -393,6 +393,8 @@ GS_API int gs_get_stats(gs_ctx *ctx, gs_stats *out);
 #define GS_BUF_PROJECTED 4    /* V x 8 f32   projected records of the last render (sorted order)         */
 #define GS_BUF_TILE_COUNT 5   /* V u32       tiles touched per sorted splat in the last render            */
 #define GS_BUF_TILE_STATS 6   /* tiles x 2 u32  (entries staged, list length) after a GS_OPT_RECORD_STAGED render  */
+#define GS_BUF_UNSAT_MASK 7   /* tiles_y x ceil(tiles_x / 32) u32: one bit per tile the first binning round of the last render left
+                                 unsaturated (measurement aid)                                                         */
 GS_API int gs_download(gs_ctx *ctx, int which, void *out, size_t nbytes);
 
 #ifdef __cplusplus
