@@ -16,7 +16,7 @@
 #include "gs_host_tables.h"
 
 #ifndef GS_NEAR_FLOOR_MULT
-#define GS_NEAR_FLOOR_MULT 1.2f     // the adaptive share never again shrinks below this x the share that failed (1.3: 5 % more pairs than needed, 1.15: redraws)
+#define GS_NEAR_FLOOR_MULT 1.3f     // the adaptive share never again shrinks below this x the share that failed (1.2: 5 % faster on one orbit, redraws on another)
 #endif
 static thread_local char g_create_err[512] = "";
 thread_local char *gs_tl_err = nullptr;
@@ -262,7 +262,7 @@ static int collect_status(gs_ctx *lane, bool *overflowed)
         __atomic_store_n(&ctx->pair_hint, h > 0xFFFFFFFFull ? 0u : (uint32_t)h, __ATOMIC_RELAXED);
     }
     // Adapt the share of splats binned in round 0.  An "event" = a frame whose round 0 left tiles unsaturated (round 1
-    // re-binned for them): the share grows x1.5 and will never again shrink below 1.2 x the share that failed; without
+    // re-binned for them): the share grows x1.5 and will never again shrink below 1.3 x the share that failed; without
     // events it shrinks 10 % per collected frame until the first event, 2 % afterwards.  After 16 clean frames round 1 is not even launched (11 empty kernels
     // cost ~50 us): blend<0> raises round1_missed if that was wrong, and the frame is completed / re-rendered.
     if (ctx->adapt_frozen) {

@@ -187,7 +187,7 @@ struct gs_ctx {
     float near_frac;                        // round 0 covers the nearest near_frac * N splats (adapted from unsat_round0)
     int near_fixed_permille;                // > 0: fixed by GS_OPT_NEAR_PERMILLE instead of adapted
     bool last_two_rounds;                   // the last enqueued frame ran the two-round path (its unsat count is meaningful)
-    float near_floor;                       // never shrink the share below this (1.2 x the share that last proved too small)
+    float near_floor;                       // never shrink the share below this (1.3 x the share that last proved too small)
     uint32_t clean_frames, skip_hold;       // collected frames since the last unsaturated one / frames to keep round 1 on
     uint32_t seen_unsat_events; uint64_t seen_acc_frames;
     uint32_t single_round_frames;           // consecutive collected frames at near_frac == 1 (re-probe occlusion now and then)
