@@ -1282,15 +1282,24 @@ GS_API int gs_sync(gs_ctx *ctx)
     // everything is about to be drained: the first frame after this goes to a twin's slot, i.e. out at once and alone (an idle GPU
     // should not wait for a partner frame), the pairs start with the frame after it
     if (ctx->frame_batch == 2) ctx->rot &= ~1;
+    // The control blocks of the lanes with asynchronous frames follow the frames' kernels on the lanes' own streams, ALL of them before
+    // the first stream is waited for: six blocking copies one after the other (three lanes and their twins, 20-30 us each) were the
+    // last 150 us of every gs_sync() -- a tenth of a region of twenty frames (tools/prof_lanes.py).
+    for (int i = 0; i < GS_MAX_LANES; i++) {
+        gs_ctx *L = ctx->lanes[i];
+        if (L) TRY(lane_rc(ctx, L, lane_drain(L, true)));        // (every launch of every lane is in its stream)
+    }
+    for (int i = 0; i < GS_MAX_LANES; i++) {
+        gs_ctx *L = ctx->lanes[i];
+        if (L && L->async_pending) LANE_HIP(L, hipMemcpyAsync(L->ctl_host, L->ctl, sizeof(GsControl), hipMemcpyDeviceToHost, L->stream));
+    }
     for (int i = 0; i < GS_MAX_LANES; i++) {
         gs_ctx *L = ctx->lanes[i];
         if (!L) continue;
-        TRY(lane_rc(ctx, L, lane_drain(L, true)));
         LANE_HIP(L, hipStreamSynchronize(L->stream));
         TRY(lane_rc(ctx, L, prof_drain(L)));
         if (!L->async_pending) continue;
         L->async_pending = false;
-        LANE_HIP(L, hipMemcpy(L->ctl_host, L->ctl, sizeof(GsControl), hipMemcpyDeviceToHost));
         const bool missed = L->ctl_host->round1_missed != 0;
         static const bool dbg_near = getenv("GS_DEBUG_NEAR") != nullptr;       // (what raised the share: printed per collected lane)
         if (dbg_near && (L->ctl_host->round1_missed || L->ctl_host->unsat_events != L->seen_unsat_events)) {
