@@ -1231,7 +1231,13 @@ GS_API void gs_host_free(void *p) { if (p) (void)hipHostFree(p); }
 // gs_sync found incomplete asynchronous frames on the lanes of bad_unit[]: draw the frames logged for those lanes again, in the
 // order they were asked, synchronously (both binning rounds; a pair overflow grows the buffers and repeats inside
 // render_sync_on_lane).  Every lane is drained and idle.  GS_E_RETRY when the library cannot decide alone (see GsFrameRec).
+static int redraw_flagged_frames_impl(gs_ctx *ctx, const bool bad_unit[GS_MAX_PRIMARY]);
 static int redraw_flagged_frames(gs_ctx *ctx, const bool bad_unit[GS_MAX_PRIMARY])
+{
+    // (the walk copies the log and keeps a set of outputs: out of host memory there, the caller draws the frames again itself)
+    try { return redraw_flagged_frames_impl(ctx, bad_unit); } catch (...) { ctx->adapt_frozen = false; return GS_E_RETRY; }
+}
+static int redraw_flagged_frames_impl(gs_ctx *ctx, const bool bad_unit[GS_MAX_PRIMARY])
 {
     // an output written by more than one logged frame (any lane): drawing one of them again could overwrite a newer image
     std::set<const void *> outs;

@@ -66,13 +66,16 @@ static thread_local char g_multi_err[GS_ERRLEN] = "";
 
 namespace {
 
-void post(gs_multi *m, const std::function<int(gs_ctx *, int)> &fn)
+int post(gs_multi *m, const std::function<int(gs_ctx *, int)> &fn)
 {
-    for (Feeder *f : m->f) {
-        const int rank = f->rank;
-        { std::lock_guard<std::mutex> lk(f->m); f->q.push_back([fn, rank](gs_ctx *c) { return fn(c, rank); }); }
-        f->cv_work.notify_one();
-    }
+    try {                                                          // (no exception crosses the C ABI: a closure that cannot be queued is GS_E_OOM)
+        for (Feeder *f : m->f) {
+            const int rank = f->rank;
+            { std::lock_guard<std::mutex> lk(f->m); f->q.push_back([fn, rank](gs_ctx *c) { return fn(c, rank); }); }
+            f->cv_work.notify_one();
+        }
+    } catch (...) { snprintf(m->err, sizeof m->err, "out of host memory"); return GS_E_OOM; }
+    return GS_OK;
 }
 
 // wait until every feeder is idle; returns (and clears) the first failure, GS_E_RETRY only if nothing worse happened
@@ -88,7 +91,7 @@ int collect(gs_multi *m)
     return first;
 }
 
-int run_all(gs_multi *m, const std::function<int(gs_ctx *, int)> &fn) { post(m, fn); return collect(m); }
+int run_all(gs_multi *m, const std::function<int(gs_ctx *, int)> &fn) { const int rp = post(m, fn), rc = collect(m); return rp != GS_OK ? rp : rc; }
 
 int check_views(gs_multi *m, const gs_render_params *views, int nviews)
 {
@@ -196,18 +199,18 @@ GS_API int gs_multi_sort(gs_multi *m, const float view[4], const float *cutout16
     if (!m || !view) return GS_E_BADARG;
     int rc = check_views(m, views, nviews);
     if (rc != GS_OK) return rc;
-    memcpy(m->view, view, sizeof m->view);
+    // (a synchronous render that draws its frame again hands these very arrays back: memmove, self-assignment)
+    memmove(m->view, view, sizeof m->view);
     m->has_cutout = cutout16 != nullptr;
-    if (cutout16) memcpy(m->cutout, cutout16, sizeof m->cutout);
+    if (cutout16) memmove(m->cutout, cutout16, sizeof m->cutout);
     m->snviews = nviews;
-    for (int v = 0; v < nviews; v++) m->sviews[v] = views[v];
+    for (int v = 0; v < nviews; v++) if (&m->sviews[v] != &views[v]) m->sviews[v] = views[v];
     m->have_sort = true;
     struct A { float view[4], cutout[16]; bool has_cutout; gs_render_params views[2]; int nviews; } a;
     memcpy(a.view, m->view, sizeof a.view); memcpy(a.cutout, m->cutout, sizeof a.cutout); a.has_cutout = m->has_cutout;
     a.views[0] = views[0]; a.views[1] = views[nviews > 1 ? 1 : 0]; a.nviews = nviews;
     // (nothing is handed back: each context's own enqueue thread does the launching; failures surface at gs_multi_sync)
-    post(m, [a](gs_ctx *c, int) { return gs_sort_gathered(c, a.view, a.has_cutout ? a.cutout : nullptr, a.views, a.nviews); });
-    return GS_OK;
+    return post(m, [a](gs_ctx *c, int) { return gs_sort_gathered(c, a.view, a.has_cutout ? a.cutout : nullptr, a.views, a.nviews); });
 }
 
 static int render_once(gs_multi *m, const gs_render_params *views, int nviews, uint8_t *const *host_frames, size_t stride,
@@ -219,10 +222,9 @@ static int render_once(gs_multi *m, const gs_render_params *views, int nviews, u
     for (int v = 0; v < 2; v++) { a.host[v] = (host_frames && v < nviews) ? host_frames[v] : nullptr; a.dev[v] = (device_frames && v < nviews) ? device_frames[v] : nullptr; }
     a.has_dev = device_frames != nullptr;
     if (device) {
-        post(m, [a](gs_ctx *c, int rank) { return gs_render_gathered(c, a.views, a.nviews, 0, (rank == 0 && a.has_dev) ? a.dev : nullptr, a.flags); });
-        return GS_OK;
+        return post(m, [a](gs_ctx *c, int rank) { return gs_render_gathered(c, a.views, a.nviews, 0, (rank == 0 && a.has_dev) ? a.dev : nullptr, a.flags); });
     }
-    post(m, [a](gs_ctx *c, int rank) {
+    return post(m, [a](gs_ctx *c, int rank) {
         gs_piece mine[128]; int n = 0;
         int rc = pieces_of(rank, a.world, a.views, a.nviews, mine, &n);
         for (int i = 0; rc == GS_OK && i < n; i++) {
@@ -233,7 +235,6 @@ static int render_once(gs_multi *m, const gs_render_params *views, int nviews, u
         }
         return rc;
     });
-    return GS_OK;
 }
 
 static int render_multi(gs_multi *m, const gs_render_params *views, int nviews, uint8_t *const *host_frames, size_t stride,
@@ -260,7 +261,8 @@ static int render_multi(gs_multi *m, const gs_render_params *views, int nviews, 
         rc = run_all(m, [](gs_ctx *c, int) { return gs_sync(c); });
         if (rc != GS_E_RETRY) return rc;
         if (attempt >= 3 || !m->have_sort) return rc;
-        gs_multi_sort(m, m->view, m->has_cutout ? m->cutout : nullptr, m->sviews, m->snviews);
+        rc = gs_multi_sort(m, m->view, m->has_cutout ? m->cutout : nullptr, m->sviews, m->snviews);
+        if (rc != GS_OK) return rc;
         rc = render_once(m, views, nviews, host_frames, stride, device_frames, device, flags);
         if (rc != GS_OK) return rc;
     }
