@@ -1,0 +1,123 @@
+"""Test helper (CPU tier): runs bench.py's `main()` as ONE RANK of a torch.distributed job of world_size > 1 WITHOUT a GPU, so that
+the python the driver launches for its scaling runs -- rendezvous, the communicator id handed round, the barrier and the MAX over
+ranks of the contract, the agreement on retries, the self-check of the assembled frame, the ONE JSON line of rank 0 -- is executed
+before hardware does it.  Everything the GPU would do is replaced HERE, in the test's process, never in bench.py or the package:
+  * `capi.Context` by a stand-in that accepts the calls and reports made-up counters (frames of zeros);
+  * torch's CUDA entry points by no-ops / CPU tensors, the "nccl" process group by gloo.
+What comes out says nothing about performance (the test only looks at the line's shape and the control flow); the camera and
+partition code of the real library (host functions of libgs_splat_hip.so) runs as it is.
+usage: python -m torch.distributed.run --nproc-per-node N ... bench_world_driver.py <bench.py arguments>"""
+import importlib
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import torch                                                     # noqa: E402
+import torch.distributed as dist                                 # noqa: E402
+
+capi = importlib.import_module("aframe-gaussian-splatting_amd.capi")
+CALLS = {"sort": 0, "render": 0, "sort_gathered": 0, "render_gathered": 0, "sync": 0}
+
+
+class StandInContext:
+    """accepts what bench.py asks of a gs_ctx; counters grow as frames are 'drawn'"""
+
+    def __init__(self, device=0):
+        self.device = device
+        self.n = 0
+        self.opts = {}
+        self.frames = 0
+        self.prof = 0
+        self.world = 1
+        self.gathered = None
+
+    def push_splat(self, rows):
+        self.n += len(rows)
+
+    def set_option(self, opt, value):
+        self.opts[opt] = int(value)
+        if opt == capi.OPT_PROFILE and int(value) == 0:
+            self.frames_at_profile_off = self.frames
+
+    def comm_unique_id(self, transport=None):
+        return b"stand-in-communicator-id".ljust(128, b"\0")
+
+    def comm_init(self, uid, rank, world):
+        assert bytes(uid).startswith(b"stand-in-communicator-id"), "the id of rank 0 did not reach this rank"
+        if os.environ.get("BENCH_STANDIN_COMM_FAIL") == str(rank):   # (RCCL could not be brought up on this rank)
+            raise capi.GsError(capi.E_STATE, "stand-in: no communicator on this rank")
+        self.rank, self.world = rank, world
+
+    def sort(self, view, cutout=None, want_indices=True):
+        CALLS["sort"] += 1
+        return None if not want_indices else np.zeros(1, np.uint32)
+
+    def sort_gathered(self, view, cutout, views):
+        CALLS["sort_gathered"] += 1
+        self.gathered = views
+
+    def render_device(self, params, device_ptr=None):
+        CALLS["render"] += 1
+        self.frames += 1
+        self.prof += 1 if self.opts.get(capi.OPT_PROFILE) else 0
+
+    def render_gathered(self, views, root=0, device_frames=None, flags=0):
+        CALLS["render_gathered"] += 1
+        views = views if isinstance(views, (list, tuple)) else [views]
+        widths = [v.fb_width for v in views]
+        mine = [p for p in capi.partition(widths, self.world) if p[3] == self.rank]
+        self.frames += len(mine)
+        self.prof += len(mine) if self.opts.get(capi.OPT_PROFILE) else 0
+        self.last_views = views
+
+    def render(self, params):
+        return np.zeros((params.fb_height, params.x1 - params.x0, 4), np.uint8)
+
+    def read_gathered(self, view, width=None, height=None):
+        v = self.last_views[view]
+        return np.zeros((v.fb_height, v.fb_width, 4), np.uint8)
+
+    def sync(self):
+        CALLS["sync"] += 1
+        # BENCH_STANDIN_RETRY="<rank>:<nth sync>": that rank's nth gs_sync reports an incomplete asynchronous frame once
+        want = os.environ.get("BENCH_STANDIN_RETRY")
+        if want and [int(x) for x in want.split(":")] == [getattr(self, "rank", 0), CALLS["sync"]]:
+            raise capi.GsError(capi.E_RETRY, "stand-in: an asynchronous frame came back incomplete")
+
+    def stats(self):
+        f = max(1, self.frames)
+        return {"n_frags": 1000, "near_permille": 164, "unsat_tiles": 0, "acc_frames": self.frames, "prof_frames": max(1, self.prof), "sum_ms_sort": 0.04 * f,
+                "sum_ms_project": 0.01 * f, "sum_ms_bin": 0.06 * f, "sum_ms_blend": 0.05 * f, "acc_pairs": 1500000 * f, "acc_visible": 24000 * f,
+                "acc_sorted": 770000 * f, "retried_frames": 0, "n_pairs": 1500000}
+
+    def download(self, which, n, dtype, cols=1):
+        return np.zeros((n, cols), dtype)
+
+    def close(self):
+        pass
+
+
+def main():
+    capi.Context = StandInContext
+    capi.hip_runtime = lambda: (_ for _ in ()).throw(RuntimeError("no HIP runtime in the CPU tier"))
+    # torch: the calls bench.py makes with a GPU in mind, on CPU
+    torch.cuda.set_device = lambda *a, **k: None
+    torch.cuda.synchronize = lambda *a, **k: None
+    real_tensor = torch.tensor
+    torch.tensor = lambda *a, **k: real_tensor(*a, **{**k, "device": "cpu"}) if k.get("device") == "cuda" else real_tensor(*a, **k)
+    real_zeros = torch.zeros
+    torch.zeros = lambda *a, **k: real_zeros(*a, **{**k, "device": "cpu"}) if k.get("device") == "cuda" else real_zeros(*a, **k)
+    real_init = dist.init_process_group
+    dist.init_process_group = lambda backend=None, **k: real_init("gloo")
+    bench = importlib.import_module("bench")
+    bench.measured_copy_peak = lambda *a, **k: None
+    sys.argv = ["bench.py"] + sys.argv[1:]
+    bench.main()
+    sys.stderr.write("rank %s calls %r\n" % (os.environ.get("RANK"), CALLS))
+
+
+if __name__ == "__main__":
+    main()

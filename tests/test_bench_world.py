@@ -1,0 +1,61 @@
+"""CPU tier: the python the driver launches for its scaling runs (`python -m torch.distributed.run ... bench.py --gpus N`) executed
+with world_size 2 and 3 over gloo, the GPU replaced by a stand-in IN THE TEST'S PROCESS (tests/host_check/bench_world_driver.py;
+bench.py and the package are not touched): rendezvous, the communicator id handed from rank 0 to the others, barriers, the
+agreement of all ranks on a retry, the self-check of the assembled frame, exactly ONE JSON line from rank 0."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DRIVER = os.path.join(ROOT, "tests", "host_check", "bench_world_driver.py")
+
+
+def run(world, port, *args, env=None):
+    e = dict(os.environ)
+    e.update(env or {})
+    e.pop("GS_SPLAT_LIB", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), DRIVER, "--gpus", str(world)] + list(args)
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=e, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, "rank 0 prints ONE line, the other ranks nothing: %r" % lines
+    return json.loads(lines[0]), p.stderr
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_column_strips_over_ranks(world):
+    d, err = run(world, 29620 + world, "--steps", "6", "--warmup", "2")
+    assert d["n_gpus"] == world and d["steps"] == 6 and d["warmup"] == 2 and d["value"] > 0 and d["scaling"] == "strong"
+    assert d["config"]["parallelism"].startswith("column strips x%d" % world) and "RCCL" in d["config"]["parallelism"]
+    assert d["config"]["gathered_frame_equals_single_gpu_render"] is True
+    x = d["config"]["pieces_of_rank0"]
+    assert len(x) == 1 and x[0][0] == 0 and x[0][1] == 0 and x[0][2] % 16 == 0 and x[0][2] <= 1920 // world + 16
+    assert "roofline" in d and d["roofline"]["traffic"] is None            # (PMC passes exist for the one-GPU form only)
+    assert "cpu_baseline" not in d                                          # rank 0 at N = 1 only
+    for r in range(world):
+        assert "rank %d calls" % r in err                                   # every rank ran to the end
+
+
+def test_xr_eyes_over_two_ranks_and_a_retry_agreed_by_all():
+    # rank 1's 4th gs_sync (the one closing the timed region) reports an incomplete frame: BOTH ranks measure the region again
+    d, err = run(2, 29631, "--xr", "--steps", "4", "--warmup", "2", env={"BENCH_STANDIN_RETRY": "1:4"})
+    assert d["n_gpus"] == 2 and "XR" in d["metric"] and d["config"]["parallelism"].startswith("XR eyes divided over 2 GPUs")
+    assert d["occlusion_binning"]["timed_region_retries"] == 1
+    assert d["config"]["pieces_of_rank0"] == [[0, 0, 1032]]
+
+
+def test_sort_share_switched_on_for_long_scenes_only():
+    d, _ = run(2, 29632, "--steps", "4", "--warmup", "2", env={"GS_BENCH_SORT_SHARE": "30"})
+    assert d["config"]["sort_share_permille"] == 30
+    d, _ = run(2, 29633, "--steps", "4", "--warmup", "2")
+    assert d["config"]["sort_share_permille"] == 0
+
+
+def test_fallback_when_the_librarys_communicator_cannot_be_set_up():
+    # gs_comm_init fails on ONE rank: every rank switches to the plain exchange (strips gathered by torch.distributed), and says so
+    d, _ = run(2, 29634, "--steps", "4", "--warmup", "2", env={"BENCH_STANDIN_COMM_FAIL": "1"})
+    assert "FALLBACK" in d["config"]["parallelism"] and d["config"]["gathered_frame_equals_single_gpu_render"] is True and d["value"] > 0
