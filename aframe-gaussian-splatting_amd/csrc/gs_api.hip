@@ -585,7 +585,7 @@ static void free_frame_resources(gs_ctx *c)
     dev_free(c->depth); dev_free(c->key_a); dev_free(c->kv_b); dev_free(c->val_a);
     dev_free(c->hist); dev_free(c->radix_aux); dev_free(c->spine); dev_free(c->spine_vis); dev_free(c->projc); dev_free(c->zwinc);
     dev_free(c->proj); dev_free(c->rect); dev_free(c->tile_count); dev_free(c->zwin);
-    dev_free(c->pair_a); dev_free(c->pair_b); dev_free(c->emit_extra);
+    dev_free(c->pair_a); dev_free(c->pair_b); dev_free(c->emit_extra); dev_free(c->row_cnt); dev_free(c->row_tot);
     gs_comm_free_lane(c);
     dev_free(c->tile_range); dev_free(c->fb); dev_free(c->ctl); dev_free(c->state); dev_free(c->unsat_mask);
     dev_free(c->part_min); dev_free(c->part_max); dev_free(c->part_cnt); dev_free(c->part_valid); dev_free(c->part_vis); dev_free(c->dhist[0]); dev_free(c->dhist[1]);
@@ -998,7 +998,7 @@ int gs_fill_uniforms(gs_ctx *ctx /* owner: options, adaptive share, scene */, co
     memcpy(u.mv, p->model_view, sizeof u.mv); memcpy(u.proj, p->projection, sizeof u.proj);
     u.W = p->fb_width; u.H = p->fb_height; u.x0 = p->x0; u.x1 = p->x1;
     u.out_pitch = p->x1 - p->x0;
-    u.pair_jbits = 0; u.pair_vcap = 0;                           // (the record format is chosen per binning round: gs_render.hip)
+    u.pair_jbits = 0; u.pair_vcap = 0; u.rc_stride = 0;          // (the binning and its record format are chosen per round: gs_render.hip)
     u.x1b = p->x0 + ((p->x1 - p->x0 + 3) & ~3);
     if (u.x1b > p->fb_width) u.x1b = p->fb_width;
     u.vw = (float)p->fb_width; u.vh = (float)p->fb_height;
@@ -1416,6 +1416,12 @@ GS_API int gs_set_option(gs_ctx *ctx, int option, int64_t value)
         TRY(drain_all(ctx));
         if (value < 0 || value > 2) FAIL(GS_E_BADARG, "wide pairs: 0 (automatic), 1 (always 8-byte records) or 2 (compact 4-byte records wherever they fit)");
         ctx->wide_pairs = value == 1; ctx->compact_pairs = value == 2; refresh_lanes(ctx);
+        return GS_OK;
+    case GS_OPT_BINNING:
+        GS_HIP(hipSetDevice(ctx->device));
+        TRY(drain_all(ctx));
+        if (value < 0 || value > 1) FAIL(GS_E_BADARG, "binning: 0 (span lists wherever the strip fits) or 1 (pair records and two stable radix passes)");
+        ctx->bin_mode = (int)value;
         return GS_OK;
     case GS_OPT_ENQUEUE_THREADS:
         GS_HIP(hipSetDevice(ctx->device));

@@ -98,6 +98,8 @@ struct GsFrameUniforms {           // per-render constants, passed by value to k
     uint32_t pair_vcap;            // > 0 (with pair_jbits > 0): the low bits of a 4-byte record are not the sorted position but the splat's index
                                    // among the VISIBLE splats of the round (< pair_vcap), whose projected records k_emit copies to `projc`
                                    // in that order: a 4K frame has 15 tile bits and a round of 300 K positions 19, but a thousand visible splats 10
+    uint32_t rc_stride;            // span-list binning (GS_OPT_BINNING): chunks per tile row of the row-count table; 0 = pair records + radix passes.
+                                   // A tile's list entries are then the sorted positions themselves (pair_jbits = 32)
 };
 
 struct GsLaneWorker;
@@ -175,6 +177,9 @@ struct gs_ctx {
     uint2 *pair_a, *pair_b; size_t pair_cap;   // (tile id, sorted position) records, ping-pong
     uint32_t blend_split_min;               // owner: GS_OPT_BLEND_SPLIT
     uint32_t pair_hint;                     // owner: pairs a frame is expected to bin (1.25 x the last collected frame's; 0 = unknown)
+    uint32_t *row_cnt; size_t row_cnt_cap;  // span-list binning: [tile row][256-splat chunk] runs | tiles << 9 (k_project) -> runs before the chunk (k_row_scan)
+    uint2 *row_tot; size_t row_tot_cap;     // ... and per tile row (runs, tiles) of the round
+    int bin_mode;                           // owner: GS_OPT_BINNING
     uint2 *tile_range; size_t tile_cap;     // per tile [start,end) into the sorted pair list
     uint8_t *fb; size_t fb_cap;             // RGBA8 strip
     // multi-GPU frames (gs_comm.hip)

@@ -69,7 +69,10 @@ __device__ __forceinline__ void round_range(const GsControl *ctl, uint32_t near_
 // Splats whose bounding box spans more than 16 tile rows (few, but up to 68 rows each) are queued in LDS and their
 // exact per-row tile counts are summed by a whole wavefront (one lane per tile row).  ROUND 1 counts only tiles whose
 // bit is set in the unsaturated-tile mask.
-template <int ROUND>
+// RUNS (span-list binning, below): the chunk also leaves, per tile row, how many of its splats touch the row (runs) and how many
+// tiles they touch there, packed `runs | tiles << 9` (at most 256 runs of at most 256 tiles), in row_cnt[row][chunk]; `spine` is
+// not written.
+template <int ROUND, bool RUNS>
 __device__ __forceinline__ void k_project_body(const uint32_t *__restrict__ sorted, const uint4 *__restrict__ splat,
                                                const GsFrameUniforms &u, gsm::Projected *__restrict__ proj, uint2 *__restrict__ rect,
                                                uint32_t *__restrict__ tile_count, uint32_t *__restrict__ spine,
@@ -80,6 +83,8 @@ __device__ __forceinline__ void k_project_body(const uint32_t *__restrict__ sort
     __shared__ float s_rec[GS_BLOCK][6];
     __shared__ uint32_t s_rows[GS_BLOCK], s_j[GS_BLOCK];
     __shared__ uint32_t s_nbig, s_nmid, s_vis, s_sum, s_visc;
+    __shared__ uint32_t s_rc[RUNS ? GS_BLOCK : 1];                  // RUNS: the chunk's (runs | tiles << 9) per tile row
+    uint32_t *__restrict__ row_cnt = spine;                         // RUNS: the table takes the spine's argument slot
     uint32_t j_lo, j_hi;
     round_range<ROUND>(ctl, u.near_count, j_lo, j_hi);
     // a near-only sort holds positions [V' - P, V') of the order; the positions behind V' are the reference's zero tail
@@ -90,6 +95,7 @@ __device__ __forceinline__ void k_project_body(const uint32_t *__restrict__ sort
     if (threadIdx.x == 0) s_vis = 0;
     for (uint32_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
         if (threadIdx.x == 0) { s_sum = 0; s_nbig = 0; s_nmid = 0; s_visc = 0; }
+        if (RUNS) s_rc[threadIdx.x] = 0u;
         __syncthreads();
         const uint32_t j = j_lo + c * GS_BLOCK + threadIdx.x;
         uint32_t count = 0;
@@ -131,6 +137,7 @@ __device__ __forceinline__ void k_project_body(const uint32_t *__restrict__ sort
                             uint32_t a, n;
                             gsm::splat_tile_row(p, e, (int)ty, u.H, u.x0, u.x1b, a, n);
                             if (ROUND == 1 && n) n = mask_count(mask + ty * u.mask_words, a, n);
+                            if (RUNS && n) atomicAdd(&s_rc[ty], 1u | (n << 9));
                             count += n;
                         }
                     }
@@ -153,6 +160,7 @@ __device__ __forceinline__ void k_project_body(const uint32_t *__restrict__ sort
                     uint32_t a;
                     gsm::splat_tile_row(p, e, (int)ty, u.H, u.x0, u.x1b, a, n);
                     if (ROUND == 1 && n) n = mask_count(mask + ty * u.mask_words, a, n);
+                    if (RUNS && n) atomicAdd(&s_rc[ty], 1u | (n << 9));
                 }
             }
 #pragma unroll
@@ -174,6 +182,7 @@ __device__ __forceinline__ void k_project_body(const uint32_t *__restrict__ sort
                 uint32_t a, n;
                 gsm::splat_tile_row(p, e, (int)ty, u.H, u.x0, u.x1b, a, n);
                 if (ROUND == 1 && n) n = mask_count(mask + ty * u.mask_words, a, n);
+                if (RUNS && n) atomicAdd(&s_rc[ty], 1u | (n << 9));
                 rsum += n;
             }
 #pragma unroll
@@ -184,20 +193,21 @@ __device__ __forceinline__ void k_project_body(const uint32_t *__restrict__ sort
         for (int m = 32; m >= 1; m >>= 1) { vis += __shfl_xor(vis, m, 64); sum += __shfl_xor(sum, m, 64); }
         if (lane == 0) { if (vis) { atomicAdd(&s_vis, vis); atomicAdd(&s_visc, vis); } if (sum) atomicAdd(&s_sum, sum); }
         __syncthreads();
-        if (threadIdx.x == 0) { spine[c] = s_sum; spine_vis[c] = s_visc; }
+        if (RUNS) { if (threadIdx.x < (uint32_t)u.tiles_y) row_cnt[(size_t)threadIdx.x * u.rc_stride + c] = s_rc[threadIdx.x]; }
+        else if (threadIdx.x == 0) { spine[c] = s_sum; spine_vis[c] = s_visc; }
     }
     __syncthreads();
     if (threadIdx.x == 0) part_vis[blockIdx.x] = s_vis;
 }
 
-template <int ROUND>
+template <int ROUND, bool RUNS>
 __global__ __launch_bounds__(GS_BLOCK) void k_project(const uint32_t *__restrict__ sorted, const uint4 *__restrict__ splat,
                                                       GsFrameUniforms u, gsm::Projected *__restrict__ proj, uint2 *__restrict__ rect,
                                                       uint32_t *__restrict__ tile_count, uint32_t *__restrict__ spine,
                                                       uint32_t *__restrict__ part_vis, const uint32_t *__restrict__ mask,
                                                       float *__restrict__ zwin, GsControl *ctl, uint32_t *__restrict__ spine_vis)
 {
-    k_project_body<ROUND>(sorted, splat, u, proj, rect, tile_count, spine, part_vis, mask, zwin, ctl, spine_vis);
+    k_project_body<ROUND, RUNS>(sorted, splat, u, proj, rect, tile_count, spine, part_vis, mask, zwin, ctl, spine_vis);
 }
 
 // One workgroup: exclusive scan of the per-chunk totals (spine) -> chunk base offsets, I = grand total (refused and
@@ -570,6 +580,296 @@ __global__ __launch_bounds__(GS_BLOCK) void k_tile_ranges(const void *__restrict
     k_tile_ranges_body(pairs, jbits, range, ntiles, round, ctl);
 }
 
+// ================================================================= span-list binning (GS_OPT_BINNING; round 4)
+// What the fixed-function rasteriser did for the reference (index.js:52-66, 158-163), as a scan-line rasteriser does it: a splat
+// meets a tile row in ONE run of tiles (exact coverage, above), so a splat is first turned into its runs -- (first tile, length)
+// per tile row it touches -- and the runs of a tile row, kept in sorted-splat order, are then expanded into the row's per-tile
+// lists by one thread per tile COLUMN: thread x walks the row's runs in order and appends the splat to its list whenever the run
+// covers column x.  A column's appends happen in run order, i.e. in draw order: the lists come out stable without a single key
+// being sorted, and there are no (tile, splat) records before the lists themselves.  Against the pair records + two stable radix
+// passes of rounds 1-3 (hist / scan / scatter twice + emit + ranges = 8 launches, ~20 bytes of traffic per pair) a binning round
+// is 3 launches, and the work is per RUN (a tenth of the pairs in the headline scene), not per pair.
+//   k_project<.., RUNS>  also counts, per 256-splat chunk and tile row, the chunk's runs and tiles:        row_cnt[row][chunk]
+//   k_row_scan           one workgroup per tile row: row_cnt[row][.] <- runs before the chunk; (runs, tiles) of the row: row_tot
+//   k_emit_runs          per chunk: the runs again, each written to ITS ROW's segment of the run arrays at
+//                        start(row) + runs before the chunk + rank inside the chunk.  The rank -- how many earlier positions of
+//                        the chunk touch the same row -- comes from a 256-bit occupancy word per tile row that the chunk's
+//                        threads OR their bit into: order-free to build, a popcount to read
+//   k_lists              item = (tile row, segment of its runs): per-column counts of the runs BEFORE the segment and of ALL the
+//                        row's runs by difference arrays in LDS (+1 at the run's first column, -1 behind its last, prefix sum;
+//                        O(runs), each item recounts its row: a row holds a few thousand runs) -> the tiles' ranges and each
+//                        column's write cursor; then the walk.  Also the round's bookkeeping in the control block (what
+//                        k_pairs_check does for the pair records): block 0.
+// ROUND 1 counts, ranks and appends only tiles whose bit is set in the unsaturated-tile mask (a run stays one record; its
+// columns are filtered by the walk).  Tile lists hold the sorted positions themselves (pair_jbits = 32).
+#define GS_LIST_SEG 256u            // runs a k_lists item walks at least ...
+#define GS_LIST_SEGS 16u            // ... and a tile row is cut into at most this many items (long rows: longer walks, not more recounts)
+__device__ __forceinline__ uint32_t list_seg_len(uint32_t nr)
+{
+    const uint32_t s = (nr + GS_LIST_SEGS - 1u) / GS_LIST_SEGS;
+    return s <= GS_LIST_SEG ? GS_LIST_SEG : ((s + 63u) & ~63u);
+}
+
+// sum of one 64-bit value per thread over the workgroup
+__device__ __forceinline__ unsigned long long block_sum64(unsigned long long v, unsigned long long *s_p, int lane, int w)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += ((unsigned long long)__shfl_xor((uint32_t)(v >> 32), m, 64) << 32) + __shfl_xor((uint32_t)v, m, 64);
+    __syncthreads();
+    if (lane == 0) s_p[w] = v;
+    __syncthreads();
+    return s_p[0] + s_p[1] + s_p[2] + s_p[3];
+}
+
+template <int ROUND>
+__device__ __forceinline__ void k_row_scan_body(uint32_t *__restrict__ row_cnt, uint2 *__restrict__ row_tot, const GsControl *ctl,
+                                                uint32_t near_count, uint32_t rc_stride, uint32_t tiles_y, uint32_t *__restrict__ mask,
+                                                uint32_t mask_words)
+{
+    GS_CHAIN_PRIO();
+    __shared__ uint32_t s_w[4];
+    __shared__ unsigned long long s_p[4];
+    uint32_t j_lo, j_hi;
+    round_range<ROUND>(ctl, near_count, j_lo, j_hi);
+    const uint32_t nch = (j_hi - j_lo + GS_BLOCK - 1) / GS_BLOCK;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const uint32_t per = (nch + GS_BLOCK - 1) / GS_BLOCK;
+    const uint32_t lo = min(threadIdx.x * per, nch), hi = min(lo + per, nch);
+    for (uint32_t row = blockIdx.x; row < tiles_y; row += gridDim.x) {
+        if (ROUND == 0) for (uint32_t i = threadIdx.x; i < mask_words; i += GS_BLOCK) mask[row * mask_words + i] = 0u;   // read by blend<0> onwards
+        uint32_t *__restrict__ rc = row_cnt + (size_t)row * rc_stride;
+        uint32_t sr = 0;
+        unsigned long long sp = 0;
+        for (uint32_t c = lo; c < hi; c++) { const uint32_t v = rc[c]; sr += v & 0x1FFu; sp += v >> 9; }
+        uint32_t total;
+        uint32_t run = block_exscan(sr, s_w, lane, w, total);
+        const unsigned long long tp = block_sum64(sp, s_p, lane, w);
+        for (uint32_t c = lo; c < hi; c++) { const uint32_t v = rc[c]; rc[c] = run; run += v & 0x1FFu; }
+        if (threadIdx.x == 0) row_tot[row] = make_uint2(total, tp > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)tp);   // (saturated: larger than any pair_cap)
+    }
+}
+
+template <int ROUND>
+__global__ __launch_bounds__(GS_BLOCK) void k_row_scan(uint32_t *__restrict__ row_cnt, uint2 *__restrict__ row_tot, const GsControl *ctl,
+                                                       uint32_t near_count, uint32_t rc_stride, uint32_t tiles_y, uint32_t *__restrict__ mask,
+                                                       uint32_t mask_words)
+{
+    k_row_scan_body<ROUND>(row_cnt, row_tot, ctl, near_count, rc_stride, tiles_y, mask, mask_words);
+}
+
+// The runs of one chunk of 256 sorted positions, each to its tile row's segment (see above).  The traversal is k_project's:
+// splats of one or two tile rows by their own thread, of up to 16 rows by 16 lanes, beyond by a wavefront -- twice, once to build
+// the occupancy words and once to write.
+template <int ROUND>
+__device__ __forceinline__ void k_emit_runs_body(const gsm::Projected *__restrict__ proj, const uint2 *__restrict__ rect,
+                                                 const uint32_t *__restrict__ tile_count, const uint32_t *__restrict__ row_cnt,
+                                                 const uint2 *__restrict__ row_tot, const GsFrameUniforms &u,
+                                                 uint32_t *__restrict__ run_geom, uint32_t *__restrict__ run_ref,
+                                                 const uint32_t *__restrict__ mask, const GsControl *ctl, uint32_t pair_cap)
+{
+    GS_CHAIN_PRIO();
+    __shared__ float s_rec[GS_BLOCK][6];
+    __shared__ uint32_t s_rows[GS_BLOCK], s_t[GS_BLOCK];            // queued splats: first | last << 16 tile row, thread (= position in the chunk)
+    __shared__ unsigned long long s_m[GS_BLOCK][4];                 // per tile row: the chunk's positions with a run there
+    __shared__ uint32_t s_rowrun[GS_BLOCK], s_base[GS_BLOCK];
+    __shared__ uint32_t s_w[4], s_nbig, s_nmid;
+    __shared__ unsigned long long s_p[4];
+    const uint32_t tid = threadIdx.x;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const uint32_t tiles_y = (uint32_t)u.tiles_y;
+    {
+        const uint2 rt = tid < tiles_y ? row_tot[tid] : make_uint2(0u, 0u);
+        uint32_t tr;
+        s_rowrun[tid] = block_exscan(rt.x, s_w, lane, w, tr);      // first run of every tile row
+        const unsigned long long I = block_sum64(rt.y, s_p, lane, w);
+        // a round that does not fit the buffers (or follows one of this frame that did not) bins nothing: k_lists flags the frame
+        if (I > pair_cap || (ROUND == 1 && ctl->pair_overflow)) return;
+    }
+    uint32_t j_lo, j_hi;
+    round_range<ROUND>(ctl, u.near_count, j_lo, j_hi);
+    const uint32_t nchunks = (j_hi - j_lo + GS_BLOCK - 1) / GS_BLOCK;
+    for (uint32_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
+        s_m[tid][0] = 0ull; s_m[tid][1] = 0ull; s_m[tid][2] = 0ull; s_m[tid][3] = 0ull;
+        if (tid == 0) { s_nbig = 0; s_nmid = 0; }
+        if (tid < tiles_y) s_base[tid] = s_rowrun[tid] + row_cnt[(size_t)tid * u.rc_stride + c];
+        __syncthreads();
+        const uint32_t j = j_lo + c * GS_BLOCK + tid;
+        const uint32_t cnt = j < j_hi ? tile_count[j] : 0u;
+        bool own = false;
+        uint32_t ty0 = 0, ty1 = 0;
+        gsm::Projected p;
+        p.cx = p.cy = p.ax = p.ay = p.bx = p.by = 0.0f;
+        if (cnt) {
+            const uint2 rc = rect[j];
+            const float4 *src = reinterpret_cast<const float4 *>(proj + j);
+            const float4 ra = src[0]; const float2 rb = *reinterpret_cast<const float2 *>(src + 1);
+            p.cx = ra.x; p.cy = ra.y; p.ax = ra.z; p.ay = ra.w; p.bx = rb.x; p.by = rb.y;
+            ty0 = rc.x >> 16; ty1 = rc.y >> 16;
+            if (ty1 - ty0 >= 2) {
+                const uint32_t q = (ty1 - ty0 >= 16) ? (GS_BLOCK - 1u - atomicAdd(&s_nbig, 1u)) : atomicAdd(&s_nmid, 1u);
+                s_rec[q][0] = p.cx; s_rec[q][1] = p.cy; s_rec[q][2] = p.ax; s_rec[q][3] = p.ay; s_rec[q][4] = p.bx; s_rec[q][5] = p.by;
+                s_rows[q] = ty0 | (ty1 << 16); s_t[q] = tid;
+            } else own = true;
+        }
+        __syncthreads();
+        const uint32_t nmid = s_nmid, nbig = s_nbig;
+        // FN(position in the chunk, tile row, first tile, tiles) for every run of the chunk that has a tile to bin
+#define GS_RUN_ONE(PP, EE, T, TY, FN) do { uint32_t a_, n_;                                                                       \
+            gsm::splat_tile_row(PP, EE, (int)(TY), u.H, u.x0, u.x1b, a_, n_);                                                     \
+            if (n_ && (ROUND == 0 || mask_count(mask + (TY) * u.mask_words, a_, n_))) { FN((T), (TY), a_, n_); } } while (0)
+#define GS_RUN_PASS(FN) do {                                                                                                      \
+            if (own) { gsm::EllipseRows e; gsm::ellipse_rows_setup(p, e);                                                         \
+                for (uint32_t ty = ty0; ty <= ty1; ty++) GS_RUN_ONE(p, e, tid, ty, FN); }                                         \
+            for (uint32_t mi = (uint32_t)w * 4u + ((uint32_t)lane >> 4); mi < nmid; mi += 16u) {                                  \
+                gsm::Projected q;                                                                                                 \
+                q.cx = s_rec[mi][0]; q.cy = s_rec[mi][1]; q.ax = s_rec[mi][2]; q.ay = s_rec[mi][3]; q.bx = s_rec[mi][4]; q.by = s_rec[mi][5]; \
+                gsm::EllipseRows e; gsm::ellipse_rows_setup(q, e);                                                                \
+                const uint32_t ty = (s_rows[mi] & 0xFFFFu) + ((uint32_t)lane & 15u);                                              \
+                if (ty <= (s_rows[mi] >> 16)) GS_RUN_ONE(q, e, s_t[mi], ty, FN); }                                                \
+            for (uint32_t bq = (uint32_t)w; bq < nbig; bq += 4u) {                                                                \
+                const uint32_t bi = GS_BLOCK - 1u - bq;                                                                           \
+                gsm::Projected q;                                                                                                 \
+                q.cx = s_rec[bi][0]; q.cy = s_rec[bi][1]; q.ax = s_rec[bi][2]; q.ay = s_rec[bi][3]; q.bx = s_rec[bi][4]; q.by = s_rec[bi][5]; \
+                gsm::EllipseRows e; gsm::ellipse_rows_setup(q, e);                                                                \
+                for (uint32_t ty = (s_rows[bi] & 0xFFFFu) + (uint32_t)lane; ty <= (s_rows[bi] >> 16); ty += 64u) GS_RUN_ONE(q, e, s_t[bi], ty, FN); } \
+        } while (0)
+#define GS_RUN_MARK(T, TY, A, N) atomicOr(&s_m[TY][(T) >> 6], 1ull << ((T) & 63u))
+        GS_RUN_PASS(GS_RUN_MARK);
+        __syncthreads();
+#define GS_RUN_WRITE(T, TY, A, N) do { const uint32_t wq_ = (T) >> 6;                                                             \
+            uint32_t rank_ = (uint32_t)__popcll(s_m[TY][wq_] & ((1ull << ((T) & 63u)) - 1ull));                                   \
+            for (uint32_t k_ = 0; k_ < wq_; k_++) rank_ += (uint32_t)__popcll(s_m[TY][k_]);                                       \
+            const uint32_t slot_ = s_base[TY] + rank_;                                                                            \
+            run_geom[slot_] = (A) | ((N) << 16); run_ref[slot_] = j_lo + c * GS_BLOCK + (T); } while (0)
+        GS_RUN_PASS(GS_RUN_WRITE);
+#undef GS_RUN_WRITE
+#undef GS_RUN_MARK
+#undef GS_RUN_PASS
+#undef GS_RUN_ONE
+        __syncthreads();                                            // the tables are rewritten by the next chunk
+    }
+}
+
+template <int ROUND>
+__global__ __launch_bounds__(GS_BLOCK) void k_emit_runs(const gsm::Projected *__restrict__ proj, const uint2 *__restrict__ rect,
+                                                        const uint32_t *__restrict__ tile_count, const uint32_t *__restrict__ row_cnt,
+                                                        const uint2 *__restrict__ row_tot, GsFrameUniforms u,
+                                                        uint32_t *__restrict__ run_geom, uint32_t *__restrict__ run_ref,
+                                                        const uint32_t *__restrict__ mask, const GsControl *ctl, uint32_t pair_cap)
+{
+    k_emit_runs_body<ROUND>(proj, rect, tile_count, row_cnt, row_tot, u, run_geom, run_ref, mask, ctl, pair_cap);
+}
+
+// The tile lists of one segment of one tile row's runs (see above); block 0 also keeps the round's books.
+template <int ROUND>
+__device__ __forceinline__ void k_lists_body(const uint32_t *__restrict__ run_geom, const uint32_t *__restrict__ run_ref,
+                                             const uint2 *__restrict__ row_tot, uint32_t *__restrict__ lists, uint2 *__restrict__ tile_range,
+                                             const GsFrameUniforms &u, const uint32_t *__restrict__ mask, GsControl *ctl, uint32_t pair_cap,
+                                             const uint32_t *__restrict__ part_vis, uint32_t nparts, int last_round)
+{
+    GS_CHAIN_PRIO();
+    __shared__ uint32_t s_rrun[GS_BLOCK + 1], s_rpair[GS_BLOCK + 1], s_item[GS_BLOCK + 1];   // prefix sums over the tile rows: runs, tiles, items
+    __shared__ int s_dall[GS_BLOCK + 1], s_dbef[GS_BLOCK + 1];       // difference arrays over the tile columns: all runs of the row / those before the segment
+    __shared__ uint32_t s_g[GS_BLOCK], s_r[GS_BLOCK];               // a batch of the segment's runs: geometry, sorted position
+    __shared__ uint32_t s_w[4], s_vis;
+    __shared__ unsigned long long s_p[4];
+    const uint32_t tid = threadIdx.x;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const uint32_t tiles_x = (uint32_t)u.tiles_x, tiles_y = (uint32_t)u.tiles_y;
+    const uint2 rt = tid < tiles_y ? row_tot[tid] : make_uint2(0u, 0u);
+    uint32_t TR, TP, NI;
+    const uint32_t exr = block_exscan(rt.x, s_w, lane, w, TR);
+    const uint32_t exp_ = block_exscan(rt.y, s_w, lane, w, TP);      // (meaningful when the round fits: I <= pair_cap < 2^32)
+    const unsigned long long I = block_sum64(rt.y, s_p, lane, w);
+    const uint32_t nseg = tid < tiles_y ? max(1u, (rt.x + list_seg_len(rt.x) - 1u) / list_seg_len(rt.x)) : 0u;   // (every row has an item: its ranges are written)
+    const uint32_t exi = block_exscan(nseg, s_w, lane, w, NI);
+    if (tid == 0) { s_rrun[0] = 0; s_rpair[0] = 0; s_item[0] = 0; }
+    s_rrun[tid + 1] = exr + rt.x; s_rpair[tid + 1] = exp_ + rt.y; s_item[tid + 1] = exi + nseg;
+    const bool overflow = I > pair_cap || (ROUND == 1 && ctl->pair_overflow);
+    uint32_t j_lo, j_hi;
+    round_range<ROUND>(ctl, u.near_count, j_lo, j_hi);
+    if (blockIdx.x == 0) {
+        // the round's bookkeeping (k_pairs_check's, for the pair records)
+        if (tid == 0) s_vis = 0;
+        __syncthreads();
+        uint32_t v = 0;
+        if (j_hi > j_lo) for (uint32_t i = tid; i < nparts; i += GS_BLOCK) v += part_vis[i];
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+        if (lane == 0 && v) atomicAdd(&s_vis, v);
+        __syncthreads();
+        if (tid == 0) {
+            const uint32_t total = I > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)I;
+            ctl->vis_total = 0; ctl->n_emit_extra = 0;
+            if (ROUND == 0) { ctl->n_visible = 0; ctl->n_pairs_frame = 0; ctl->want_frame = 0; }
+            else { ctl->unsat_round0 = ctl->unsat_count; if (ctl->unsat_count) ctl->unsat_events += 1; }
+            ctl->j_lo = j_lo; ctl->j_hi = j_hi;                      // blend<1> returns at once when nothing was left for round 1
+            ctl->scan_total = total;
+            ctl->want_frame = (ctl->want_frame + total < total) ? 0xFFFFFFFFu : ctl->want_frame + total;   // (saturating)
+            if (ctl->want_frame > ctl->max_total) ctl->max_total = ctl->want_frame;
+            if (total > pair_cap) { ctl->pair_overflow = 1; ctl->overflow_sticky = 1; ctl->n_pairs = 0; }
+            else if (ROUND == 0) { ctl->pair_overflow = 0; ctl->n_pairs = total; }
+            else ctl->n_pairs = ctl->pair_overflow ? 0u : total;
+            ctl->n_visible += s_vis; ctl->n_pairs_frame += ctl->n_pairs;
+            if (ROUND == 0 && u.near_count != 0xFFFFFFFFu) ctl->unsat_count = 0;   // counted by blend<0>, read by round 1
+            if (last_round) {
+                ctl->acc_frames += 1; ctl->acc_sorted += ctl->n_kept; ctl->acc_visible += ctl->n_visible; ctl->acc_pairs += ctl->n_pairs_frame;
+            }
+        }
+    }
+    __syncthreads();
+    for (uint32_t item = blockIdx.x; item < NI; item += gridDim.x) {
+        uint32_t row = 0;                                            // the largest row with s_item[row] <= item
+#pragma unroll
+        for (uint32_t step = GS_BLOCK / 2; step; step >>= 1) { const uint32_t t = row + step; if (t < tiles_y && s_item[t] <= item) row = t; }
+        const uint32_t seg = item - s_item[row];
+        const uint32_t rb = s_rrun[row], nr = overflow ? 0u : s_rrun[row + 1] - rb, pb = s_rpair[row];
+        const uint32_t S = list_seg_len(nr), s0 = seg * S, s1 = min(nr, s0 + S);
+        s_dall[tid] = 0; s_dbef[tid] = 0;
+        if (tid == 0) { s_dall[GS_BLOCK] = 0; s_dbef[GS_BLOCK] = 0; }
+        __syncthreads();
+        for (uint32_t i = tid; i < nr; i += GS_BLOCK) {
+            const uint32_t g = run_geom[rb + i], t0 = g & 0xFFFFu, t1 = t0 + (g >> 16);
+            atomicAdd(&s_dall[t0], 1); atomicSub(&s_dall[t1], 1);
+            if (i < s0) { atomicAdd(&s_dbef[t0], 1); atomicSub(&s_dbef[t1], 1); }
+        }
+        __syncthreads();
+        // runs that cover this thread's column: all of the row / those before the segment
+        uint32_t ta, tb;
+        const uint32_t da = (uint32_t)s_dall[tid], db = (uint32_t)s_dbef[tid];
+        const uint32_t ca = block_exscan(da, s_w, lane, w, ta) + da, cb = block_exscan(db, s_w, lane, w, tb) + db;
+        const bool on = tid < tiles_x && (ROUND == 0 || ((mask[row * u.mask_words + (tid >> 5)] >> (tid & 31u)) & 1u));
+        const uint32_t cnt = on ? ca : 0u;
+        uint32_t tc;
+        const uint32_t first = pb + block_exscan(cnt, s_w, lane, w, tc);
+        if (seg == 0 && tid < tiles_x) tile_range[row * tiles_x + tid] = overflow ? make_uint2(0u, 0u) : make_uint2(first, first + cnt);
+        uint32_t off = first + cb;
+        for (uint32_t b0 = s0; b0 < s1; b0 += GS_BLOCK) {
+            const uint32_t i = b0 + tid;
+            if (i < s1) { s_g[tid] = run_geom[rb + i]; s_r[tid] = run_ref[rb + i]; }
+            __syncthreads();
+            const uint32_t nb = min((uint32_t)GS_BLOCK, s1 - b0);
+            if (on) {
+#pragma unroll 4
+                for (uint32_t k = 0; k < nb; k++) {
+                    const uint32_t g = s_g[k];
+                    if (tid - (g & 0xFFFFu) < (g >> 16)) { lists[off] = s_r[k]; off++; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+template <int ROUND>
+__global__ __launch_bounds__(GS_BLOCK) void k_lists(const uint32_t *__restrict__ run_geom, const uint32_t *__restrict__ run_ref,
+                                                    const uint2 *__restrict__ row_tot, uint32_t *__restrict__ lists, uint2 *__restrict__ tile_range,
+                                                    GsFrameUniforms u, const uint32_t *__restrict__ mask, GsControl *ctl, uint32_t pair_cap,
+                                                    const uint32_t *__restrict__ part_vis, uint32_t nparts, int last_round)
+{
+    k_lists_body<ROUND>(run_geom, run_ref, row_tot, lists, tile_range, u, mask, ctl, pair_cap, part_vis, nparts, last_round);
+}
+
 // Fragment shader + blend for one 16x16 tile, ONE wavefront per tile, four horizontally adjacent pixels per lane
 // (lane l: image row l/4 of the tile, pixels 4*(l%4) .. +3).  The projected records of a batch are staged in LDS and
 // broadcast-read by the whole wave: with one pixel per lane the 4 waves of a 256-thread tile each re-read every record
@@ -610,7 +910,8 @@ __device__ __forceinline__ void k_blend_body(const uint2 *__restrict__ tile_rang
     if (ROUND == 1 && ctl->j_hi == 0) return;                      // every tile saturated in round 0
     const uint32_t ntiles = (uint32_t)u.tiles_x * (uint32_t)u.tiles_y;
     // 4-byte pair records carry position - j_lo, or (compact) the index among the visible splats: `proj` is then the compacted array
-    const uint32_t pair_j_lo = u.pair_vcap ? 0u : ctl->j_lo, pair_j_mask = (1u << u.pair_jbits) - 1u;
+    // (span lists, pair_jbits = 32: the position itself)
+    const uint32_t pair_j_lo = (u.pair_vcap || u.pair_jbits >= 32u) ? 0u : ctl->j_lo, pair_j_mask = u.pair_jbits >= 32u ? 0xFFFFFFFFu : (1u << u.pair_jbits) - 1u;
     for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {   // round 0: one tile per wave; round 1: small grid
     const uint32_t tx = tile % (uint32_t)u.tiles_x, ty = tile / (uint32_t)u.tiles_x;
     if (ROUND == 1 && !((mask[ty * u.mask_words + (tx >> 5)] >> (tx & 31)) & 1u)) continue;   // this tile is final already
@@ -860,7 +1161,7 @@ __device__ __forceinline__ void k_blend_px_body(const uint2 *__restrict__ tile_r
 #define GS_WAVE_LDS_SYNC() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); } while (0)
     if (ROUND == 1 && ctl->j_hi == 0) return;                      // every tile saturated in round 0
     const uint32_t ntiles = (uint32_t)u.tiles_x * (uint32_t)u.tiles_y;
-    const uint32_t pair_j_lo = u.pair_vcap ? 0u : ctl->j_lo, pair_j_mask = (1u << u.pair_jbits) - 1u;
+    const uint32_t pair_j_lo = (u.pair_vcap || u.pair_jbits >= 32u) ? 0u : ctl->j_lo, pair_j_mask = u.pair_jbits >= 32u ? 0xFFFFFFFFu : (1u << u.pair_jbits) - 1u;
     for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const uint32_t tx = tile % (uint32_t)u.tiles_x, ty = tile / (uint32_t)u.tiles_x;
         if (ROUND == 1 && !((mask[ty * u.mask_words + (tx >> 5)] >> (tx & 31)) & 1u)) continue;   // this tile is final already
@@ -1027,6 +1328,90 @@ int gs_ensure_compact(gs_ctx *ctx, size_t vcap)
     return GS_OK;
 }
 
+// the blend of one round over the tile lists `fpairs` (records of the format v.pair_jbits / v.pair_vcap say)
+template <int ROUND>
+int launch_blend(gs_ctx *ctx, const GsFrameUniforms &u, GsFrameUniforms v, uint8_t *out, const void *fpairs, const gsm::Projected *bproj, const float *bzwin)
+{
+    const uint32_t ntiles = (uint32_t)u.tiles_x * (uint32_t)u.tiles_y;
+    hipStream_t st = ctx->stream;
+    const uint32_t gb = ROUND == 1 ? (ntiles < 1024 ? ntiles : 1024) : ntiles;
+    const bool scene = u.has_depth || u.has_scene_rgba;
+    if ((u.flags & GS_RENDER_COUNT_FRAGS) || u.record_staged) v.split_min = 0;     // measurement renders: every tile by k_blend
+    if (v.split_min) {
+        // the tiles with long lists first (the long pole): workgroups stride over all tiles' ranges and take the long ones
+        const uint32_t gp = ntiles < 2048 ? ntiles : 2048;
+        if (scene) hipLaunchKernelGGL((k_blend_px<ROUND, true>), dim3(gp), dim3(256), 0, st, ctx->tile_range, fpairs, bproj, v, out, ctx->state,
+                                      ctx->unsat_mask, bzwin, ctx->scene_depth, ctx->scene_rgba, ctx->ctl);
+        else hipLaunchKernelGGL((k_blend_px<ROUND, false>), dim3(gp), dim3(256), 0, st, ctx->tile_range, fpairs, bproj, v, out, ctx->state,
+                                ctx->unsat_mask, bzwin, ctx->scene_depth, ctx->scene_rgba, ctx->ctl);
+    }
+#define GS_LAUNCH_BLEND(C, S) hipLaunchKernelGGL((k_blend<C, ROUND, S>), dim3(gb), dim3(64), 0, st, ctx->tile_range, fpairs, bproj, v, \
+                                                out, ctx->state, ctx->unsat_mask, bzwin, ctx->scene_depth, ctx->scene_rgba, ctx->ctl)
+    if (u.flags & GS_RENDER_COUNT_FRAGS) { if (scene) GS_LAUNCH_BLEND(true, true); else GS_LAUNCH_BLEND(true, false); }
+    else { if (scene) GS_LAUNCH_BLEND(false, true); else GS_LAUNCH_BLEND(false, false); }
+#undef GS_LAUNCH_BLEND
+    GS_HIP(hipGetLastError());
+    return GS_OK;
+}
+
+// Span-list binning (GS_OPT_BINNING) for a round over at most `jrange` sorted positions: the chunk stride of its row-count table,
+// or 0 = pair records + radix passes.  The tile columns and rows of the strip must each fit one workgroup (frames up to 4096 x
+// 4096 pixels) and the table stay small (rows x chunks: 20 M positions at 4K would want 42 MB); a record format asked for by
+// name (GS_OPT_WIDE_PAIRS) means the records.
+#define GS_ROWCNT_MAX ((size_t)1 << 22)
+uint32_t span_list_stride(const gs_ctx *ctx, const GsFrameUniforms &u, uint32_t jrange)
+{
+    const gs_ctx *P = gs_root(const_cast<gs_ctx *>(ctx));
+    if (P->bin_mode == 1 || P->wide_pairs || P->compact_pairs) return 0;
+    if (u.tiles_x > GS_BLOCK || u.tiles_y > GS_BLOCK) return 0;
+    const uint32_t stride = gs_div_up(jrange, GS_BLOCK) + 1u;
+    if ((size_t)stride * (size_t)u.tiles_y > GS_ROWCNT_MAX) return 0;
+    return stride;
+}
+
+int gs_ensure_row_tables(gs_ctx *ctx, size_t entries)
+{
+    if (entries <= ctx->row_cnt_cap && ctx->row_tot) return GS_OK;
+    GS_HIP(hipStreamSynchronize(ctx->stream));
+    if (entries > ctx->row_cnt_cap) {
+        if (ctx->row_cnt) (void)hipFree(ctx->row_cnt);
+        ctx->row_cnt = nullptr; ctx->row_cnt_cap = 0;
+        const size_t cap = entries + entries / 4;
+        GS_HIP(hipMalloc((void **)&ctx->row_cnt, cap * sizeof(uint32_t)));
+        ctx->row_cnt_cap = cap;
+    }
+    if (!ctx->row_tot) { GS_HIP(hipMalloc((void **)&ctx->row_tot, GS_BLOCK * sizeof(uint2))); ctx->row_tot_cap = GS_BLOCK; }
+    return GS_OK;
+}
+
+// one round with span lists: project (+ row counts) -> row scan -> runs -> lists -> blend
+template <int ROUND>
+int run_round_spans(gs_ctx *ctx, const GsFrameUniforms &u, uint8_t *out, bool last_round, uint32_t g, uint32_t stride)
+{
+    hipStream_t st = ctx->stream;
+    const int rcc = gs_ensure_row_tables(ctx, (size_t)stride * (size_t)u.tiles_y);
+    if (rcc != GS_OK) return rcc;
+    GsFrameUniforms v = u;
+    v.rc_stride = stride; v.pair_jbits = 32u; v.pair_vcap = 0u;
+    // the pair buffers hold the runs (geometry and sorted position of each: there are never more runs than tiles) and the lists
+    uint32_t *run_geom = reinterpret_cast<uint32_t *>(ctx->pair_a), *run_ref = run_geom + ctx->pair_cap, *lists = reinterpret_cast<uint32_t *>(ctx->pair_b);
+    const uint32_t pc = (uint32_t)ctx->pair_cap;
+    hipLaunchKernelGGL((k_project<ROUND, true>), dim3(g), dim3(GS_BLOCK), 0, st, ctx->sorted, ctx->splat, v, ctx->proj, ctx->rect,
+                       ctx->tile_count, ctx->row_cnt, ctx->part_vis, ctx->unsat_mask, ctx->zwin, ctx->ctl, ctx->spine_vis);
+    GS_HIP(hipGetLastError());
+    if (ROUND == 0) GS_PROF_RECORD(ctx, 3);
+    hipLaunchKernelGGL(k_row_scan<ROUND>, dim3((uint32_t)u.tiles_y), dim3(GS_BLOCK), 0, st, ctx->row_cnt, ctx->row_tot, (const GsControl *)ctx->ctl, u.near_count,
+                       stride, (uint32_t)u.tiles_y, ctx->unsat_mask, u.mask_words);
+    hipLaunchKernelGGL(k_emit_runs<ROUND>, dim3(g), dim3(GS_BLOCK), 0, st, ctx->proj, ctx->rect, ctx->tile_count, ctx->row_cnt, ctx->row_tot, v,
+                       run_geom, run_ref, ctx->unsat_mask, (const GsControl *)ctx->ctl, pc);
+    uint32_t gl = (uint32_t)u.tiles_y * GS_LIST_SEGS; if (gl > (ROUND == 1 ? 512u : 2048u)) gl = ROUND == 1 ? 512u : 2048u;
+    hipLaunchKernelGGL(k_lists<ROUND>, dim3(gl), dim3(GS_BLOCK), 0, st, run_geom, run_ref, ctx->row_tot, lists, ctx->tile_range, v, ctx->unsat_mask,
+                       ctx->ctl, pc, ctx->part_vis, g, last_round ? 1 : 0);
+    GS_HIP(hipGetLastError());
+    if (ROUND == 0) GS_PROF_RECORD(ctx, 4);
+    return launch_blend<ROUND>(ctx, u, v, out, lists, ctx->proj, ctx->zwin);
+}
+
 // one round: project -> offsets -> emit -> stable sort by tile -> ranges -> blend.  Round 1 usually finds nothing to
 // do (every tile saturated), so it is launched on small grids: its kernels grid-stride when there is work.
 template <int ROUND>
@@ -1049,6 +1434,7 @@ int run_round(gs_ctx *ctx, const GsFrameUniforms &u, uint8_t *out, bool last_rou
     // round's VISIBLE splats do (compact records: gs_compact_bits)
     const int tb = bits_for(ntiles);
     const uint32_t jrange = ROUND == 0 ? (u.near_count != 0xFFFFFFFFu && u.near_count < Vmax ? u.near_count : Vmax) : Vmax;
+    if (const uint32_t stride = span_list_stride(ctx, u, jrange)) return run_round_spans<ROUND>(ctx, u, out, last_round, g, stride);
     const int jb = bits_for(jrange);
     const int vb = ROUND == 0 ? gs_compact_bits(ctx, tb, jb) : 0;
     const bool p32 = vb > 0 || (!ctx->wide_pairs && tb + jb <= 32);
@@ -1056,7 +1442,7 @@ int run_round(gs_ctx *ctx, const GsFrameUniforms &u, uint8_t *out, bool last_rou
     v.pair_jbits = vb > 0 ? (uint32_t)vb : (p32 ? (uint32_t)jb : 0u);
     v.pair_vcap = vb > 0 ? 1u << vb : 0u;
     if (vb > 0) { const int rcc = gs_ensure_compact(ctx, (size_t)1 << vb); if (rcc != GS_OK) return rcc; }
-    hipLaunchKernelGGL(k_project<ROUND>, dim3(g), dim3(GS_BLOCK), 0, st, ctx->sorted, ctx->splat, u, ctx->proj, ctx->rect,
+    hipLaunchKernelGGL((k_project<ROUND, false>), dim3(g), dim3(GS_BLOCK), 0, st, ctx->sorted, ctx->splat, u, ctx->proj, ctx->rect,
                        ctx->tile_count, ctx->spine, ctx->part_vis, ctx->unsat_mask, ctx->zwin, ctx->ctl, ctx->spine_vis);
     GS_HIP(hipGetLastError());
     if (ROUND == 0) GS_PROF_RECORD(ctx, 3);
@@ -1091,32 +1477,88 @@ int run_round(gs_ctx *ctx, const GsFrameUniforms &u, uint8_t *out, bool last_rou
                        ctx->ctl);
     GS_HIP(hipGetLastError());
     if (ROUND == 0) GS_PROF_RECORD(ctx, 4);
-    const uint32_t gb = ROUND == 1 ? (ntiles < 1024 ? ntiles : 1024) : ntiles;
-    const bool scene = u.has_depth || u.has_scene_rgba;
-    if ((u.flags & GS_RENDER_COUNT_FRAGS) || u.record_staged) v.split_min = 0;     // measurement renders: every tile by k_blend
-    if (v.split_min) {
-        // the tiles with long lists first (the long pole): workgroups stride over all tiles' ranges and take the long ones
-        const uint32_t gp = ntiles < 2048 ? ntiles : 2048;
-        if (scene) hipLaunchKernelGGL((k_blend_px<ROUND, true>), dim3(gp), dim3(256), 0, st, ctx->tile_range, fpairs, bproj, v, out, ctx->state,
-                                      ctx->unsat_mask, bzwin, ctx->scene_depth, ctx->scene_rgba, ctx->ctl);
-        else hipLaunchKernelGGL((k_blend_px<ROUND, false>), dim3(gp), dim3(256), 0, st, ctx->tile_range, fpairs, bproj, v, out, ctx->state,
-                                ctx->unsat_mask, bzwin, ctx->scene_depth, ctx->scene_rgba, ctx->ctl);
-    }
-#define GS_LAUNCH_BLEND(C, S) hipLaunchKernelGGL((k_blend<C, ROUND, S>), dim3(gb), dim3(64), 0, st, ctx->tile_range, fpairs, bproj, v, \
-                                                out, ctx->state, ctx->unsat_mask, bzwin, ctx->scene_depth, ctx->scene_rgba, ctx->ctl)
-    if (u.flags & GS_RENDER_COUNT_FRAGS) { if (scene) GS_LAUNCH_BLEND(true, true); else GS_LAUNCH_BLEND(true, false); }
-    else { if (scene) GS_LAUNCH_BLEND(false, true); else GS_LAUNCH_BLEND(false, false); }
-#undef GS_LAUNCH_BLEND
-    GS_HIP(hipGetLastError());
-    return GS_OK;
+    return launch_blend<ROUND>(ctx, u, v, out, fpairs, bproj, bzwin);
 }
 
-template <int ROUND> GS_BODY(F_project, k_project_body<ROUND>);
+template <int ROUND, bool RUNS> GS_BODY(F_project, k_project_body<ROUND, RUNS>);
+template <int ROUND> GS_BODY(F_row_scan, k_row_scan_body<ROUND>);
+template <int ROUND> GS_BODY(F_emit_runs, k_emit_runs_body<ROUND>);
+template <int ROUND> GS_BODY(F_lists, k_lists_body<ROUND>);
 template <int ROUND> GS_BODY(F_pairs_check, k_pairs_check_body<ROUND>);
 template <int ROUND, bool P32> GS_BODY(F_emit, k_emit_body<ROUND, P32>);
 GS_BODY(F_tile_ranges, k_tile_ranges_body);
 template <int ROUND, bool SCENE> GS_BODY(F_blend, k_blend_body<false, ROUND, SCENE>);
 template <int ROUND, bool SCENE> GS_BODY(F_blend_px, k_blend_px_body<ROUND, SCENE>);
+
+// the blend of one round for two frames (launch_blend's paired form)
+template <int ROUND>
+int launch_blend2(gs_ctx *const S[2], const GsFrameUniforms &u, const GsFrameUniforms V[2], uint8_t *const out[2], const void *const fpairs[2],
+                  const gsm::Projected *const bproj[2], const float *const bzwin[2])
+{
+    gs_ctx *ctx = S[0];
+    hipStream_t st = ctx->stream;
+    const uint32_t ntiles = (uint32_t)u.tiles_x * (uint32_t)u.tiles_y;
+    const uint32_t gb = ROUND == 1 ? (ntiles < 1024 ? ntiles : 1024) : ntiles;
+    const bool scene = u.has_depth || u.has_scene_rgba;
+#define GS_BLENDPX2(SC) gs_twin<F_blend_px<ROUND, SC>, 256>(ntiles < 2048 ? ntiles : 2048, st,                                                          \
+        gs_pack_make((const uint2 *)S[0]->tile_range, fpairs[0], bproj[0], V[0], out[0], S[0]->state, S[0]->unsat_mask,         \
+                     bzwin[0], (const float *)S[0]->scene_depth, (const uint32_t *)S[0]->scene_rgba, S[0]->ctl),                        \
+        gs_pack_make((const uint2 *)S[1]->tile_range, fpairs[1], bproj[1], V[1], out[1], S[1]->state, S[1]->unsat_mask,         \
+                     bzwin[1], (const float *)S[1]->scene_depth, (const uint32_t *)S[1]->scene_rgba, S[1]->ctl))
+    if (u.split_min) { if (scene) GS_BLENDPX2(true); else GS_BLENDPX2(false); }   // the tiles with long lists first
+#undef GS_BLENDPX2
+#define GS_BLEND2(SC) gs_twin<F_blend<ROUND, SC>, 64>(gb, st,                                                                                           \
+        gs_pack_make((const uint2 *)S[0]->tile_range, fpairs[0], bproj[0], V[0], out[0], S[0]->state, S[0]->unsat_mask,         \
+                     bzwin[0], (const float *)S[0]->scene_depth, (const uint32_t *)S[0]->scene_rgba, S[0]->ctl),                        \
+        gs_pack_make((const uint2 *)S[1]->tile_range, fpairs[1], bproj[1], V[1], out[1], S[1]->state, S[1]->unsat_mask,         \
+                     bzwin[1], (const float *)S[1]->scene_depth, (const uint32_t *)S[1]->scene_rgba, S[1]->ctl))
+    if (scene) GS_BLEND2(true); else GS_BLEND2(false);
+#undef GS_BLEND2
+    GS_HIP(hipGetLastError());
+    return GS_OK;
+}
+
+
+// run_round_spans() for two frames, one launch per kernel
+template <int ROUND>
+int run_round_spans2(gs_ctx *const S[2], const GsFrameUniforms U[2], uint8_t *const out[2], bool last_round, uint32_t g, uint32_t stride)
+{
+    gs_ctx *ctx = S[0];
+    const GsFrameUniforms &u = U[0];
+    hipStream_t st = ctx->stream;
+    for (int k = 0; k < 2; k++) { const int rcc = gs_ensure_row_tables(S[k], (size_t)stride * (size_t)u.tiles_y); if (rcc != GS_OK) return rcc; }
+    GsFrameUniforms V[2] = { U[0], U[1] };
+    for (int k = 0; k < 2; k++) { V[k].rc_stride = stride; V[k].pair_jbits = 32u; V[k].pair_vcap = 0u; }
+    uint32_t *geom[2], *ref[2], *lists[2];
+    for (int k = 0; k < 2; k++) { geom[k] = reinterpret_cast<uint32_t *>(S[k]->pair_a); ref[k] = geom[k] + S[k]->pair_cap; lists[k] = reinterpret_cast<uint32_t *>(S[k]->pair_b); }
+    gs_twin<F_project<ROUND, true>, GS_BLOCK>(g, st,
+        gs_pack_make((const uint32_t *)S[0]->sorted, (const uint4 *)S[0]->splat, V[0], S[0]->proj, S[0]->rect, S[0]->tile_count, S[0]->row_cnt, S[0]->part_vis,
+                     (const uint32_t *)S[0]->unsat_mask, S[0]->zwin, S[0]->ctl, S[0]->spine_vis),
+        gs_pack_make((const uint32_t *)S[1]->sorted, (const uint4 *)S[1]->splat, V[1], S[1]->proj, S[1]->rect, S[1]->tile_count, S[1]->row_cnt, S[1]->part_vis,
+                     (const uint32_t *)S[1]->unsat_mask, S[1]->zwin, S[1]->ctl, S[1]->spine_vis));
+    GS_HIP(hipGetLastError());
+    if (ROUND == 0) GS_PROF_RECORD(ctx, 3);
+    gs_twin<F_row_scan<ROUND>, GS_BLOCK>((uint32_t)u.tiles_y, st,
+        gs_pack_make(S[0]->row_cnt, S[0]->row_tot, (const GsControl *)S[0]->ctl, U[0].near_count, stride, (uint32_t)u.tiles_y, S[0]->unsat_mask, u.mask_words),
+        gs_pack_make(S[1]->row_cnt, S[1]->row_tot, (const GsControl *)S[1]->ctl, U[1].near_count, stride, (uint32_t)u.tiles_y, S[1]->unsat_mask, u.mask_words));
+    gs_twin<F_emit_runs<ROUND>, GS_BLOCK>(g, st,
+        gs_pack_make((const gsm::Projected *)S[0]->proj, (const uint2 *)S[0]->rect, (const uint32_t *)S[0]->tile_count, (const uint32_t *)S[0]->row_cnt,
+                     (const uint2 *)S[0]->row_tot, V[0], geom[0], ref[0], (const uint32_t *)S[0]->unsat_mask, (const GsControl *)S[0]->ctl, (uint32_t)S[0]->pair_cap),
+        gs_pack_make((const gsm::Projected *)S[1]->proj, (const uint2 *)S[1]->rect, (const uint32_t *)S[1]->tile_count, (const uint32_t *)S[1]->row_cnt,
+                     (const uint2 *)S[1]->row_tot, V[1], geom[1], ref[1], (const uint32_t *)S[1]->unsat_mask, (const GsControl *)S[1]->ctl, (uint32_t)S[1]->pair_cap));
+    uint32_t gl = (uint32_t)u.tiles_y * GS_LIST_SEGS; if (gl > (ROUND == 1 ? 512u : 2048u)) gl = ROUND == 1 ? 512u : 2048u;
+    gs_twin<F_lists<ROUND>, GS_BLOCK>(gl, st,
+        gs_pack_make((const uint32_t *)geom[0], (const uint32_t *)ref[0], (const uint2 *)S[0]->row_tot, lists[0], S[0]->tile_range, V[0], (const uint32_t *)S[0]->unsat_mask,
+                     S[0]->ctl, (uint32_t)S[0]->pair_cap, (const uint32_t *)S[0]->part_vis, g, last_round ? 1 : 0),
+        gs_pack_make((const uint32_t *)geom[1], (const uint32_t *)ref[1], (const uint2 *)S[1]->row_tot, lists[1], S[1]->tile_range, V[1], (const uint32_t *)S[1]->unsat_mask,
+                     S[1]->ctl, (uint32_t)S[1]->pair_cap, (const uint32_t *)S[1]->part_vis, g, last_round ? 1 : 0));
+    GS_HIP(hipGetLastError());
+    if (ROUND == 0) GS_PROF_RECORD(ctx, 4);
+    const void *fpairs[2] = { lists[0], lists[1] };
+    const gsm::Projected *bproj[2] = { S[0]->proj, S[1]->proj };
+    const float *bzwin[2] = { S[0]->zwin, S[1]->zwin };
+    return launch_blend2<ROUND>(S, u, V, out, fpairs, bproj, bzwin);
+}
 
 // run_round() for two frames that take the same path: every kernel once, on a grid (x, 2) (blockIdx.y = the frame)
 template <int ROUND>
@@ -1135,6 +1577,7 @@ int run_round2(gs_ctx *const S[2], const GsFrameUniforms U[2], uint8_t *const ou
     const uint32_t ph = ROUND == 1 ? (uint32_t)(small * GS_CHUNK_S) : __atomic_load_n(&gs_root(ctx)->pair_hint, __ATOMIC_RELAXED);
     const int tb = bits_for(ntiles);
     const uint32_t jrange = ROUND == 0 ? (u.near_count != 0xFFFFFFFFu && u.near_count < Vmax ? u.near_count : Vmax) : Vmax;
+    if (const uint32_t stride = span_list_stride(ctx, u, jrange)) return run_round_spans2<ROUND>(S, U, out, last_round, g, stride);
     const int jb = bits_for(jrange);
     const int vb = ROUND == 0 ? gs_compact_bits(ctx, tb, jb) : 0;
     const bool p32 = vb > 0 || (!ctx->wide_pairs && tb + jb <= 32);
@@ -1142,7 +1585,7 @@ int run_round2(gs_ctx *const S[2], const GsFrameUniforms U[2], uint8_t *const ou
     V[0].pair_jbits = V[1].pair_jbits = vb > 0 ? (uint32_t)vb : (p32 ? (uint32_t)jb : 0u);
     V[0].pair_vcap = V[1].pair_vcap = vb > 0 ? 1u << vb : 0u;
     if (vb > 0) for (int k = 0; k < 2; k++) { const int rcc = gs_ensure_compact(S[k], (size_t)1 << vb); if (rcc != GS_OK) return rcc; }
-    gs_twin<F_project<ROUND>, GS_BLOCK>(g, st,
+    gs_twin<F_project<ROUND, false>, GS_BLOCK>(g, st,
         gs_pack_make((const uint32_t *)S[0]->sorted, (const uint4 *)S[0]->splat, U[0], S[0]->proj, S[0]->rect, S[0]->tile_count, S[0]->spine, S[0]->part_vis,
                      (const uint32_t *)S[0]->unsat_mask, S[0]->zwin, S[0]->ctl, S[0]->spine_vis),
         gs_pack_make((const uint32_t *)S[1]->sorted, (const uint4 *)S[1]->splat, U[1], S[1]->proj, S[1]->rect, S[1]->tile_count, S[1]->spine, S[1]->part_vis,
@@ -1190,26 +1633,9 @@ int run_round2(gs_ctx *const S[2], const GsFrameUniforms U[2], uint8_t *const ou
                                      gs_pack_make(fpairs[1], V[1].pair_jbits, S[1]->tile_range, ntiles, ROUND, (const GsControl *)S[1]->ctl));
     GS_HIP(hipGetLastError());
     if (ROUND == 0) GS_PROF_RECORD(ctx, 4);
-    const uint32_t gb = ROUND == 1 ? (ntiles < 1024 ? ntiles : 1024) : ntiles;
-    const bool scene = u.has_depth || u.has_scene_rgba;
     const gsm::Projected *bproj[2] = { vb > 0 ? S[0]->projc : S[0]->proj, vb > 0 ? S[1]->projc : S[1]->proj };
     const float *bzwin[2] = { vb > 0 ? S[0]->zwinc : S[0]->zwin, vb > 0 ? S[1]->zwinc : S[1]->zwin };
-#define GS_BLENDPX2(SC) gs_twin<F_blend_px<ROUND, SC>, 256>(ntiles < 2048 ? ntiles : 2048, st,                                                          \
-        gs_pack_make((const uint2 *)S[0]->tile_range, fpairs[0], bproj[0], V[0], out[0], S[0]->state, S[0]->unsat_mask,         \
-                     bzwin[0], (const float *)S[0]->scene_depth, (const uint32_t *)S[0]->scene_rgba, S[0]->ctl),                        \
-        gs_pack_make((const uint2 *)S[1]->tile_range, fpairs[1], bproj[1], V[1], out[1], S[1]->state, S[1]->unsat_mask,         \
-                     bzwin[1], (const float *)S[1]->scene_depth, (const uint32_t *)S[1]->scene_rgba, S[1]->ctl))
-    if (u.split_min) { if (scene) GS_BLENDPX2(true); else GS_BLENDPX2(false); }   // the tiles with long lists first
-#undef GS_BLENDPX2
-#define GS_BLEND2(SC) gs_twin<F_blend<ROUND, SC>, 64>(gb, st,                                                                                           \
-        gs_pack_make((const uint2 *)S[0]->tile_range, fpairs[0], bproj[0], V[0], out[0], S[0]->state, S[0]->unsat_mask,         \
-                     bzwin[0], (const float *)S[0]->scene_depth, (const uint32_t *)S[0]->scene_rgba, S[0]->ctl),                        \
-        gs_pack_make((const uint2 *)S[1]->tile_range, fpairs[1], bproj[1], V[1], out[1], S[1]->state, S[1]->unsat_mask,         \
-                     bzwin[1], (const float *)S[1]->scene_depth, (const uint32_t *)S[1]->scene_rgba, S[1]->ctl))
-    if (scene) GS_BLEND2(true); else GS_BLEND2(false);
-#undef GS_BLEND2
-    GS_HIP(hipGetLastError());
-    return GS_OK;
+    return launch_blend2<ROUND>(S, u, V, out, fpairs, bproj, bzwin);
 }
 
 }  // namespace

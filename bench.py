@@ -86,6 +86,8 @@ def main():
     r32 = rows.reshape(-1, 32)
     for o in range(0, n_splats, 1 << 22):                    # progressive ingest (index.js:279-298), 4 M rows per push
         ctx.push_splat(r32[o:o + (1 << 22)])
+    if os.environ.get("GS_BENCH_BINNING"):                   # experiment knob: GS_OPT_BINNING (1 = pair records + radix passes, rounds 1-3)
+        ctx.set_option(capi.OPT_BINNING, int(os.environ["GS_BENCH_BINNING"]))
     depth = int(os.environ.get("GS_BENCH_DEPTH", "0"))       # experiment knob: frames in flight (library default 3)
     if depth:
         ctx.set_option(capi.OPT_PIPELINE_DEPTH, depth)

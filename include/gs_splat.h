@@ -378,6 +378,13 @@ typedef struct gs_stats {
                                    scene whose tiles do not saturate) 4 bytes `tile << b | index among the round's visible splats` when
                                    THAT fits -- the number of visible splats is known from the frames before --, else 8 bytes.  1: always
                                    8-byte (tile, position) records.  2: the visible-index form wherever it fits.                 */
+#define GS_OPT_BINNING 16       /* how a binning round turns visible splats into per-tile lists (same lists, same images).  0 (default): span
+                                   lists -- every splat becomes one run of tiles per tile row it touches, and the runs of a tile row, in
+                                   sorted order, are expanded into the row's tile lists by one thread per tile column: three launches per
+                                   round, work per run -- wherever a strip has at most 256 tile columns and rows (4096 x 4096 pixels) and
+                                   the round at most a few million sorted positions; elsewhere, and with 1: (tile, splat) pair records
+                                   sorted by two stable radix passes (rounds 1-3; eight launches per round).  GS_OPT_WIDE_PAIRS != 0 asks
+                                   for a record format and therefore for the records.                                            */
 #define GS_OPT_ENQUEUE_THREADS 7 /* default 1: gs_sort() (without an output array) and gs_render_device(GS_RENDER_ASYNC) hand the
                                    frame to a worker thread of its pipeline lane, which does the ~18 kernel launches, so the
                                    launches of the frames in flight run in parallel; failures surface at gs_sync().  0: the

@@ -1080,6 +1080,74 @@ def test_narrow_and_wide_pair_records_give_identical_frames(w, h, n, permille):
             assert np.array_equal(img, want_scene), mode
 
 
+@pytest.mark.parametrize("w,h,n,fat", [(640, 360, 30000, 1.0), (1920, 1080, 300000, 1.0), (333, 211, 5000, 1.0), (1280, 720, 6000, 25.0),
+                                       (3840, 2160, 200000, 3.0)])
+def test_span_lists_and_pair_records_give_identical_frames(w, h, n, fat):
+    """GS_OPT_BINNING (round 4): the tile lists built from per-tile-row runs by one thread per tile column (three launches) must be
+    the lists the pair records + two stable radix passes give -- same entries in the same order, hence the same image bit for bit,
+    the same pair / visible counts, fragment counts and per-tile list lengths: one round and two (tiny and large first-round
+    shares: most entries written against the unsaturated-tile mask), strips, scene depth, queued frames alone and in pairs."""
+    rows = synth.make_splat_rows(n, seed=4242).reshape(-1, 32).copy()
+    if fat != 1.0:
+        rows[:, 12:24] = (rows[:, 12:24].copy().view("<f4") * np.float32(fat)).view(np.uint8)
+    cam = synth.index_html_camera(w, h, 211.0, capi=capi)
+    tiles = ((w + 15) // 16) * ((h + 15) // 16)
+    x0 = (w // 3) & ~3
+    strips = [(0, w), (x0, min(w, x0 + 16)), (x0, min(w, x0 + 204))]
+    depth = np.full((h, w), 0.9996, np.float32); depth[:, : w // 2] = 1.0
+    out = {}
+    for mode in (1, 0):
+        with capi.Context(0) as c:
+            c.set_option(capi.OPT_BINNING, mode)
+            c.push_splat(rows)
+            res = []
+            for permille in (1000, 3, 400, 0):
+                c.set_option(capi.OPT_NEAR_PERMILLE, permille)
+                c.sort(cam["view"])
+                for a, b in strips:
+                    img = c.render(_params(cam, x0=a, x1=b))
+                    st = c.stats()
+                    res.append((permille, a, b, img, st["n_pairs"] if permille else None, st["n_visible"] if permille else None))
+                if permille == 1000:
+                    c.render(_params(cam, flags=capi.RENDER_COUNT_FRAGS))
+                    res.append(("frags", c.stats()["n_frags"]))
+                    c.set_option(capi.OPT_RECORD_STAGED, 1)
+                    c.render(_params(cam))
+                    res.append(("lists", c.download(capi.BUF_TILE_STATS, tiles, np.uint32, 2)[:, 1].copy()))
+                    c.set_option(capi.OPT_RECORD_STAGED, 0)
+                    c.set_scene(depth, None)
+                    c.sort(cam["view"])
+                    res.append(("scene", c.render(_params(cam))))
+                    c.set_scene(None, None)
+            c.set_option(capi.OPT_NEAR_PERMILLE, 250)
+            for batch in (1, 2):
+                c.set_option(capi.OPT_FRAME_BATCH, batch)
+                bufs = [capi.host_frame(h, w) for _ in range(5)]
+                for b, _ in bufs:
+                    c.sort(cam["view"], want_indices=False)
+                    c.render_into(_params(cam, flags=capi.RENDER_ASYNC), b)
+                c.sync()
+                for b, o in bufs:
+                    res.append(("queued", batch, b.copy()))
+                    o.free()
+            out[mode] = res
+    assert len(out[0]) == len(out[1])
+    for a, b in zip(out[0], out[1]):
+        assert len(a) == len(b)
+        for x, y in zip(a, b):
+            if isinstance(x, np.ndarray):
+                assert np.array_equal(x, y), a[:3]
+            else:
+                assert x == y, (a[:3], x, y)
+    full = [r for r in out[0] if r[0] == 1000 and r[1] == 0][0][3]
+    for r in out[0]:
+        if r[0] in (1000, 3, 400, 0):                              # every share and strip: the single-round full frame's columns
+            assert np.array_equal(r[3], full[:, r[1]:r[2]]), r[:3]
+        if r[0] == "queued":
+            assert np.array_equal(r[2], full)
+    assert [r for r in out[0] if r[0] == "lists"][0][1].sum() > 0
+
+
 def test_enqueue_threads_on_and_off_give_identical_frames_and_statistics(scene_small):
     """GS_OPT_ENQUEUE_THREADS: the lanes' worker threads only change WHO launches the kernels of an asynchronous frame."""
     import torch

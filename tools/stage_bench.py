@@ -25,6 +25,7 @@ ap.add_argument("--opacity-div", type=int, default=1, help="divide every splat's
 ap.add_argument("--no-early-out", action="store_true", help="GS_RENDER_NO_EARLY_OUT: every fragment blended")
 ap.add_argument("--strip", default=None, help="k/G: render only strip k of G tile-aligned column strips (what one of G GPUs does)")
 ap.add_argument("--sort-for", action="store_true", help="with --strip: gs_sort_for the strip instead of the full gs_sort")
+ap.add_argument("--binning", type=int, default=None, help="GS_OPT_BINNING (0 span lists, 1 pair records + radix passes)")
 a = ap.parse_args()
 W, H = (int(v) for v in a.size.lower().split("x"))
 rows = synth.make_splat_rows_fast(a.splats) if a.splats >= (8 << 20) else synth.make_splat_rows(a.splats)
@@ -41,6 +42,8 @@ ctx = capi.Context(0)
 r = rows.reshape(-1, 32)
 for o in range(0, a.splats, 1 << 22):
     ctx.push_splat(r[o:o + (1 << 22)])
+if a.binning is not None:
+    ctx.set_option(capi.OPT_BINNING, a.binning)
 if a.split:
     ctx.set_option(capi.OPT_BLEND_SPLIT, a.split)
 if a.term:
