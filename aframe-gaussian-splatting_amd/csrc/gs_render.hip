@@ -602,7 +602,9 @@ __global__ __launch_bounds__(GS_BLOCK) void k_tile_ranges(const void *__restrict
 //                        k_pairs_check does for the pair records): block 0.
 // ROUND 1 counts, ranks and appends only tiles whose bit is set in the unsaturated-tile mask (a run stays one record; its
 // columns are filtered by the walk).  Tile lists hold the sorted positions themselves (pair_jbits = 32).
+#ifndef GS_LIST_SEG
 #define GS_LIST_SEG 256u            // runs a k_lists item walks at least ...
+#endif
 #define GS_LIST_SEGS 16u            // ... and a tile row is cut into at most this many items (long rows: longer walks, not more recounts)
 __device__ __forceinline__ uint32_t list_seg_len(uint32_t nr)
 {
@@ -761,6 +763,25 @@ __global__ __launch_bounds__(GS_BLOCK) void k_emit_runs(const gsm::Projected *__
 }
 
 // The tile lists of one segment of one tile row's runs (see above); block 0 also keeps the round's books.
+// Per item: (1) the row's runs, all loads in flight, into ONE difference array of 64-bit words -- low half: every run, high half:
+// the runs before the segment (a prefix sum of such words is exact: the sums it passes through are counts, never negative) --
+// and one 64-bit scan over the columns gives both counts per column; (2) the segment in batches of 256 runs: every run ORs its
+// bit into the occupancy word of each column it covers (the words of a column are 256 bits: which runs of the batch cover it),
+// and the column's thread appends the batch's runs in bit order -- a column's thread takes as many steps as runs cover it, not
+// as many as the batch has.
+__device__ __forceinline__ unsigned long long wave_incl_scan_u64(unsigned long long v, int lane)
+{
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const unsigned long long t = ((unsigned long long)__shfl_up((uint32_t)(v >> 32), d, 64) << 32) | __shfl_up((uint32_t)v, d, 64);
+        if (lane >= d) v += t;
+    }
+    return v;
+}
+
+#ifndef GS_LIST_LOADS
+#define GS_LIST_LOADS 16u           // run records a thread of k_lists has in flight while it counts its row
+#endif
 template <int ROUND>
 __device__ __forceinline__ void k_lists_body(const uint32_t *__restrict__ run_geom, const uint32_t *__restrict__ run_ref,
                                              const uint2 *__restrict__ row_tot, uint32_t *__restrict__ lists, uint2 *__restrict__ tile_range,
@@ -769,8 +790,10 @@ __device__ __forceinline__ void k_lists_body(const uint32_t *__restrict__ run_ge
 {
     GS_CHAIN_PRIO();
     __shared__ uint32_t s_rrun[GS_BLOCK + 1], s_rpair[GS_BLOCK + 1], s_item[GS_BLOCK + 1];   // prefix sums over the tile rows: runs, tiles, items
-    __shared__ int s_dall[GS_BLOCK + 1], s_dbef[GS_BLOCK + 1];       // difference arrays over the tile columns: all runs of the row / those before the segment
-    __shared__ uint32_t s_g[GS_BLOCK], s_r[GS_BLOCK];               // a batch of the segment's runs: geometry, sorted position
+    __shared__ unsigned long long s_d[GS_BLOCK + 1];                // difference array over the tile columns: all runs | runs before the segment << 32
+    __shared__ __attribute__((aligned(16))) unsigned long long s_m[GS_BLOCK][4];                 // per tile column: the runs of the batch that cover it
+    __shared__ uint32_t s_r[GS_BLOCK];                              // the batch's sorted positions
+    __shared__ uint32_t s_off[GS_BLOCK], s_on[GS_BLOCK];            // per tile column: write cursor at the segment's start, column taken (ROUND 1: unsaturated)
     __shared__ uint32_t s_w[4], s_vis;
     __shared__ unsigned long long s_p[4];
     const uint32_t tid = threadIdx.x;
@@ -825,36 +848,92 @@ __device__ __forceinline__ void k_lists_body(const uint32_t *__restrict__ run_ge
         const uint32_t seg = item - s_item[row];
         const uint32_t rb = s_rrun[row], nr = overflow ? 0u : s_rrun[row + 1] - rb, pb = s_rpair[row];
         const uint32_t S = list_seg_len(nr), s0 = seg * S, s1 = min(nr, s0 + S);
-        s_dall[tid] = 0; s_dbef[tid] = 0;
-        if (tid == 0) { s_dall[GS_BLOCK] = 0; s_dbef[GS_BLOCK] = 0; }
+        s_d[tid] = 0ull;
+        if (tid == 0) s_d[GS_BLOCK] = 0ull;
         __syncthreads();
-        for (uint32_t i = tid; i < nr; i += GS_BLOCK) {
-            const uint32_t g = run_geom[rb + i], t0 = g & 0xFFFFu, t1 = t0 + (g >> 16);
-            atomicAdd(&s_dall[t0], 1); atomicSub(&s_dall[t1], 1);
-            if (i < s0) { atomicAdd(&s_dbef[t0], 1); atomicSub(&s_dbef[t1], 1); }
+        for (uint32_t i0 = 0; i0 < nr; i0 += GS_LIST_LOADS * GS_BLOCK) {
+            uint32_t g[GS_LIST_LOADS];
+#pragma unroll
+            for (uint32_t k = 0; k < GS_LIST_LOADS; k++) { const uint32_t i = i0 + k * GS_BLOCK + tid; g[k] = i < nr ? run_geom[rb + i] : 0u; }
+#pragma unroll
+            for (uint32_t k = 0; k < GS_LIST_LOADS; k++) {
+                const uint32_t i = i0 + k * GS_BLOCK + tid;
+                if (i < nr) {
+                    const uint32_t t0 = g[k] & 0xFFFFu, t1 = t0 + (g[k] >> 16);
+                    const unsigned long long one = i < s0 ? 0x100000001ull : 1ull;
+                    atomicAdd(&s_d[t0], one); atomicAdd(&s_d[t1], 0ull - one);
+                }
+            }
         }
         __syncthreads();
-        // runs that cover this thread's column: all of the row / those before the segment
-        uint32_t ta, tb;
-        const uint32_t da = (uint32_t)s_dall[tid], db = (uint32_t)s_dbef[tid];
-        const uint32_t ca = block_exscan(da, s_w, lane, w, ta) + da, cb = block_exscan(db, s_w, lane, w, tb) + db;
+        // runs that cover this thread's column: all of the row (low half) / those before the segment (high half)
+        const unsigned long long inc = wave_incl_scan_u64(s_d[tid], lane);
+        __syncthreads();
+        if (lane == 63) s_p[w] = inc;
+        __syncthreads();
+        unsigned long long cab = inc;
+#pragma unroll
+        for (int k = 0; k < 4; k++) if (k < w) cab += s_p[k];
+        const uint32_t ca = (uint32_t)cab, cb = (uint32_t)(cab >> 32);
         const bool on = tid < tiles_x && (ROUND == 0 || ((mask[row * u.mask_words + (tid >> 5)] >> (tid & 31u)) & 1u));
         const uint32_t cnt = on ? ca : 0u;
         uint32_t tc;
         const uint32_t first = pb + block_exscan(cnt, s_w, lane, w, tc);
         if (seg == 0 && tid < tiles_x) tile_range[row * tiles_x + tid] = overflow ? make_uint2(0u, 0u) : make_uint2(first, first + cnt);
-        uint32_t off = first + cb;
+        // A column's batch is walked by G threads (G = 2 while the strip has at most 128 tile columns: 1920 pixels), each taking a share
+        // of the batch's occupancy words, four runs per step: what bounds an item is the dependent chain bit -> position -> store of the
+        // busiest column (a batch of near, screen-wide splats covers every column 256 times).
+        const uint32_t G = tiles_x <= 128u ? 2u : 1u, col = G == 2u ? (tid & 127u) : tid, grp = G == 2u ? (tid >> 7) : 0u;
+        const uint32_t q_lo = grp * (4u / G), q_hi = q_lo + 4u / G;
+        s_off[tid] = first + cb;
+        s_on[tid] = on ? 1u : 0u;
+        uint32_t gn = 0, rn = 0;                                     // the next batch's records: in flight while this one is walked
+        if (s0 + tid < s1) { gn = run_geom[rb + s0 + tid]; rn = run_ref[rb + s0 + tid]; }
+        __syncthreads();
+        uint32_t off = s_off[col];
+        const bool mine = col < tiles_x && s_on[col] != 0u;
         for (uint32_t b0 = s0; b0 < s1; b0 += GS_BLOCK) {
-            const uint32_t i = b0 + tid;
-            if (i < s1) { s_g[tid] = run_geom[rb + i]; s_r[tid] = run_ref[rb + i]; }
+            const uint32_t g = gn;
+            s_r[tid] = rn;
+            s_m[tid][0] = 0ull; s_m[tid][1] = 0ull; s_m[tid][2] = 0ull; s_m[tid][3] = 0ull;
             __syncthreads();
-            const uint32_t nb = min((uint32_t)GS_BLOCK, s1 - b0);
-            if (on) {
-#pragma unroll 4
-                for (uint32_t k = 0; k < nb; k++) {
-                    const uint32_t g = s_g[k];
-                    if (tid - (g & 0xFFFFu) < (g >> 16)) { lists[off] = s_r[k]; off++; }
+            gn = 0;
+            if (b0 + GS_BLOCK + tid < s1) { gn = run_geom[rb + b0 + GS_BLOCK + tid]; rn = run_ref[rb + b0 + GS_BLOCK + tid]; }
+            {
+                // word w of every column belongs to wavefront w's 64 runs.  (Measured and dropped: a wavefront that holds long runs taking
+                // the columns one by one -- a ballot IS the column's word, no atomics on one address --: 21 -> 25 us alone on the headline
+                // frame, 72 -> 113 us where tiles do not saturate; the same-address atomics are not what an item waits for.)
+                const uint32_t t0 = g & 0xFFFFu, t1 = t0 + (g >> 16);   // (no run: t0 = t1 = 0)
+                const unsigned long long bit = 1ull << (tid & 63u);
+                for (uint32_t c = t0; c < t1; c++) atomicOr(&s_m[c][w], bit);
+            }
+            __syncthreads();
+            if (mine) {
+                const ulonglong2 m01 = *reinterpret_cast<const ulonglong2 *>(&s_m[col][0]), m23 = *reinterpret_cast<const ulonglong2 *>(&s_m[col][2]);
+                const unsigned long long mw[4] = { m01.x, m01.y, m23.x, m23.y };
+                uint32_t o = off;
+#pragma unroll
+                for (uint32_t q = 0; q < 4; q++) {
+                    unsigned long long bits = mw[q];
+                    const uint32_t nq = (uint32_t)__popcll(bits);
+                    if (q >= q_lo && q < q_hi) {
+                        for (uint32_t k = 0; k < nq; k += 4u) {
+                            uint32_t ix[4];
+#pragma unroll
+                            for (int e = 0; e < 4; e++) { ix[e] = bits ? (uint32_t)__ffsll((long long)bits) - 1u : 0u; bits &= bits - 1ull; }
+                            uint32_t rr[4];
+#pragma unroll
+                            for (int e = 0; e < 4; e++) rr[e] = s_r[q * 64u + ix[e]];
+                            const uint32_t left = nq - k;
+                            lists[o + k] = rr[0];
+                            if (left > 1u) lists[o + k + 1u] = rr[1];
+                            if (left > 2u) lists[o + k + 2u] = rr[2];
+                            if (left > 3u) lists[o + k + 3u] = rr[3];
+                        }
+                    }
+                    o += nq;
                 }
+                off = o;
             }
             __syncthreads();
         }
