@@ -966,10 +966,12 @@ static int sort_common(gs_ctx *ctx, const float view[4], const float *cutout16, 
     return GS_OK;
 }
 
-int gs_sort_by_call(gs_ctx *ctx, const float view[4], const float *cutout16, void *call_p)
+// Begin a frame whose sort is a call (gs_comm.hip: the order comes from -- or goes to -- the other ranks).  Two steps, so that the
+// caller can take what must stay in step across the ranks (its turn in the sort rota, the communicator ticket) only after
+// everything that can fail without the call having been queued -- here: lane selection and the lane's scratch -- has succeeded.
+int gs_sort_call_begin(gs_ctx *ctx, const float view[4], const float *cutout16)
 {
     CHECK_CTX(ctx);
-    std::function<int(gs_ctx *)> &call = *static_cast<std::function<int(gs_ctx *)> *>(call_p);
     GS_HIP(hipSetDevice(ctx->device));
     gs_ctx *L = nullptr;
     int rot = 0;
@@ -979,14 +981,30 @@ int gs_sort_by_call(gs_ctx *ctx, const float view[4], const float *cutout16, voi
     log_sort(L, view, cutout16, nullptr);
     log_undecidable(L);                                            // (the other ranks are part of this frame's sort)
     L->have_sort = true;
+    return GS_OK;
+}
+
+// ... and hand the call to the frame's lane: queued behind the lane's work, or run here.  The call is ALWAYS run.
+int gs_sort_call_issue(gs_ctx *ctx, void *call_p)
+{
+    std::function<int(gs_ctx *)> &call = *static_cast<std::function<int(gs_ctx *)> *>(call_p);
+    gs_ctx *L = ctx->lanes[ctx->cur];
     if (ctx->enqueue_threads && gs_rotates(ctx) && !ctx->user_stream) {
         GsLaneCmd c;
-        c.type = 2; c.has_cutout = false; c.has_strip = false; c.device_rgba = nullptr; c.host_rgba = nullptr; c.stride = 0; c.call = call;
-        if (lane_push(L, c) == GS_OK) return GS_OK;                // (not a frame's end: the rotation is decided by its render)
+        c.type = 2; c.has_cutout = false; c.has_strip = false; c.device_rgba = nullptr; c.host_rgba = nullptr; c.stride = 0;
+        bool queued = false;
+        try { c.call = call; queued = lane_push(L, c) == GS_OK; } catch (...) { queued = false; }
+        if (queued) return GS_OK;                                  // (not a frame's end: the rotation is decided by its render)
     }
     const int rc = lane_rc(ctx, L, lane_drain(L));                 // run here, whatever came before: the other ranks wait for this exchange
     const int rc2 = lane_rc(ctx, L, call(L));
     return rc != GS_OK ? rc : rc2;
+}
+
+int gs_sort_by_call(gs_ctx *ctx, const float view[4], const float *cutout16, void *call_p)
+{
+    TRY(gs_sort_call_begin(ctx, view, cutout16));
+    return gs_sort_call_issue(ctx, call_p);
 }
 
 int gs_fill_uniforms(gs_ctx *ctx /* owner: options, adaptive share, scene */, const gs_render_params *p, GsFrameUniforms &u)
@@ -1084,6 +1102,18 @@ static int render_sync_on_lane(gs_ctx *ctx, const GsFrameUniforms &u, void *devi
         TRY(queue_copy());
         GS_HIP(hipStreamSynchronize(ctx->stream));
         if (ctx->profile && ctx->ring) { ctx->ring_head++; ctx->ring_pending++; TRY(prof_drain(ctx)); }
+        if (ctx->ctl_host->order_incomplete) {
+            // the order this frame was drawn from was incomplete (a near-only sort whose survivors overflowed a chunk's stash, an
+            // exchanged order cut short): round 0 itself was blended from the wrong positions.  Sort in full, draw the whole frame again.
+            gs_ctx *P = gs_root(ctx);
+            GS_HIP(hipMemsetAsync(&ctx->ctl->order_incomplete, 0, sizeof(uint32_t), ctx->stream));
+            GS_HIP(hipMemsetAsync(&ctx->ctl->round1_missed, 0, sizeof(uint32_t), ctx->stream));
+            if (ctx->ctl_host->near_overflow) { P->near_stash_off = true; GS_HIP(hipMemsetAsync(&ctx->ctl->near_overflow, 0, sizeof(uint32_t), ctx->stream)); }
+            if (attempt >= 2) FAIL(GS_E_HIP, "the sorted order keeps coming back incomplete");
+            TRY(gs_run_sort(ctx, ctx->sv_view, ctx->sv_has_cutout ? ctx->sv_cutout : nullptr, ctx->sv_has_strip ? &ctx->sv_strip : nullptr, 0));
+            P->stats.retried_frames++;
+            continue;
+        }
         if (ctx->ctl_host->round1_missed) {
             // round 1 was skipped but a tile did not saturate: its mask bit and per-pixel state are intact -- finish it now
             GS_HIP(hipMemsetAsync(&ctx->ctl->round1_missed, 0, sizeof(uint32_t), ctx->stream));
@@ -1283,6 +1313,9 @@ GS_API int gs_sync(gs_ctx *ctx)
     CHECK_CTX(ctx);
     GS_HIP(hipSetDevice(ctx->device));
     bool any_missed = false, any_over = false;
+    // whatever way this call ends, the frames logged so far are not drawn again by a LATER gs_sync (their output buffers may be
+    // gone by then): a failure below leaves no records behind
+    struct LogGuard { gs_ctx *c; ~LogGuard() { for (int i = 0; i < GS_MAX_LANES; i++) if (c->lanes[i]) log_reset(c->lanes[i]); } } log_guard{ ctx };
     bool bad_unit[GS_MAX_PRIMARY] = { false, false, false, false };   // a lane or its twin (one stream, one worker) reported an incomplete frame
     uint32_t want = 0;
     // everything is about to be drained: the first frame after this goes to a twin's slot, i.e. out at once and alone (an idle GPU
@@ -1315,6 +1348,7 @@ GS_API int gs_sync(gs_ctx *ctx)
                     ctx->near_frac, ctx->clean_frames, ctx->skip_hold);
         }
         if (missed) LANE_HIP(L, hipMemsetAsync(&L->ctl->round1_missed, 0, sizeof(uint32_t), L->stream));
+        if (L->ctl_host->order_incomplete) LANE_HIP(L, hipMemsetAsync(&L->ctl->order_incomplete, 0, sizeof(uint32_t), L->stream));
         bool over = false;
         TRY(collect_status(L, &over));
         any_missed |= missed; any_over |= over;
@@ -1337,8 +1371,7 @@ GS_API int gs_sync(gs_ctx *ctx)
                           "render the frames since the previous gs_sync() again", want);
         }
     }
-    for (int i = 0; i < GS_MAX_LANES; i++) if (ctx->lanes[i]) log_reset(ctx->lanes[i]);
-    return rc;
+    return rc;                                                       // (log_guard resets the logs)
 }
 
 GS_API int gs_set_stream(gs_ctx *ctx, void *hip_stream)

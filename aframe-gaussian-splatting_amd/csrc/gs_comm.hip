@@ -422,7 +422,7 @@ int issue_gather(gs_ctx *L, const GatherJob &j)
 
 __global__ void k_share_check(GsControl *ctl, uint32_t cap)
 {
-    if (ctl->n_sorted > cap) { ctl->n_sorted = cap; ctl->round1_missed = 1; }   // the frame is drawn from a truncated order: reported (GS_E_RETRY)
+    if (ctl->n_sorted > cap) { ctl->n_sorted = cap; ctl->order_incomplete = 1; ctl->round1_missed = 1; }   // the frame is drawn from a truncated order: reported (GS_E_RETRY)
 }
 
 struct ShareJob {
@@ -621,10 +621,20 @@ GS_API int gs_sort_gathered(gs_ctx *ctx, const float view[4], const float *cutou
         uint64_t cap = (uint64_t)j.near_req * 2u + 65536u;
         if (cap > ctx->n) cap = ctx->n;
         j.cap = (uint32_t)cap;
+        // the frame's lane first (it can fail: scratch for a new lane), THEN the turn in the rota and the ticket: a rank that
+        // left here with them taken and nothing queued would be out of step with its peers for good
+        const int rb = gs_sort_call_begin(ctx, view, cutout16);
+        if (rb != GS_OK) return rb;
         j.owner = (int)(c->share_seq++ % (uint64_t)world);
         { std::lock_guard<std::mutex> lk(c->m); j.ticket = c->next_ticket++; }
-        std::function<int(gs_ctx *)> call = [j](gs_ctx *lane) { return issue_shared_sort(lane, j); };
-        return gs_sort_by_call(ctx, view, cutout16, &call);
+        std::function<int(gs_ctx *)> call;
+        try { call = [j](gs_ctx *lane) { return issue_shared_sort(lane, j); }; }
+        catch (...) {                                              // (the closure itself: run the exchange without one)
+            const int rd = gs_lane_call(ctx, false, [](gs_ctx *) { return GS_OK; }, false);
+            const int ri = issue_shared_sort(ctx->lanes[gs_frame_lane(ctx)], j);
+            return rd != GS_OK ? rd : ri;
+        }
+        return gs_sort_call_issue(ctx, &call);
     }
     int mine = -1, count = 0;
     for (int i = 0; i < np; i++) if (pcs[i].owner == rank) { mine = i; count++; }

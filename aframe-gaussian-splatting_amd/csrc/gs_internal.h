@@ -52,7 +52,9 @@ struct GsControl {
                                    // the zero tail), or only the nearest P of them (near-only sort)
     uint32_t near_sorted;          // 1: `sorted` holds the order's last P valid positions [V' - P, V') only (gs_run_sort with near_req)
     uint32_t n_valid;              // V' of the whole order, counted by a near-only sort (position of sorted[0] = n_valid - n_sorted)
-    uint32_t pad_near;
+    uint32_t order_incomplete;     // sticky: `sorted` does not hold everything it claims -- a near-only sort's chunk stash overflowed, an exchanged
+                                   // order was cut short (host clears).  The frames drawn from it are flagged round1_missed too (asynchronous frames:
+                                   // drawn again from a whole sort by gs_sync); a synchronous frame sorts in full and draws BOTH rounds again
     uint32_t n_visible;            // Vp: splats that pass the vertex-shader culls
     uint32_t n_pairs;              // I : (tile, splat) pairs
     uint32_t pair_overflow;        // set when I exceeded the pair capacity (pairs clamped to 0)
@@ -69,7 +71,7 @@ struct GsControl {
     uint32_t round1_missed;        // sticky: round 1 was skipped optimistically but a tile needed it (host clears)
     uint32_t vis_total;            // visible splats of the current binning round (k_pairs_check)
     uint32_t near_overflow;        // sticky: a near-only sort's survivors did not fit a chunk's stash (host clears; the frame is also
-                                   // flagged round1_missed: it is drawn again from a whole sort)
+                                   // flagged order_incomplete + round1_missed: it is drawn again from a whole sort)
     uint32_t acc_frames;           // frames rendered since profiling was switched on
     unsigned long long acc_sorted, acc_visible, acc_pairs;   // sums of V, Vp, I over those frames
 };
@@ -348,6 +350,9 @@ int gs_comm_set_transport(gs_ctx *ctx, int transport);
 // begin a frame on its lane like gs_sort() does (lane rotation, frame log) and run `call` where the sort's kernels would be
 // enqueued: the frame's order comes from -- or goes to -- the other ranks (gs_comm.hip, GS_OPT_SORT_SHARE)
 extern "C" int gs_sort_by_call(gs_ctx *ctx, const float view[4], const float *cutout16, void *call /* std::function<int(gs_ctx *)> * */);
+// the same in two steps: everything that can fail before the call is queued, then the hand-over (the call is always run)
+extern "C" int gs_sort_call_begin(gs_ctx *ctx, const float view[4], const float *cutout16);
+extern "C" int gs_sort_call_issue(gs_ctx *ctx, void *call /* std::function<int(gs_ctx *)> * */);
 int gs_ensure_pair_capacity(gs_ctx *ctx, size_t pairs);
 int gs_ensure_radix_scratch(gs_ctx *ctx, size_t items);         // histogram / totals scratch for a radix sort of `items` records
 // event k (0..GS_PROF_EVENTS-1) of the current profiling slot, or nullptr when profiling is off

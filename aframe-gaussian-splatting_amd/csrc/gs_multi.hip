@@ -60,6 +60,7 @@ struct gs_multi {
     // the last frame's arguments: a synchronous render that comes back with GS_E_RETRY is sorted and drawn again here
     float view[4] = { 0, 0, 0, 0 }, cutout[16]; bool has_cutout = false, have_sort = false;
     gs_render_params sviews[2]; int snviews = 0;
+    bool dead = false;                                             // a call reached only some of the devices (post): nothing more is accepted
 };
 
 static thread_local char g_multi_err[GS_ERRLEN] = "";
@@ -68,13 +69,28 @@ namespace {
 
 int post(gs_multi *m, const std::function<int(gs_ctx *, int)> &fn)
 {
+    // all or nothing: a collective (a gathered frame, a shared sort) queued on SOME feeders only would leave those ranks waiting
+    // the transport's whole timeout for peers that never take part.  The closures -- what can really run out of memory: they
+    // carry the call's arguments -- are all built before the first feeder sees anything; the hand-over then only moves them, and
+    // if even that fails the context is marked unusable instead of staying half-posted.
+    if (m->dead) { snprintf(m->err, sizeof m->err, "the multi-device context is unusable after a failed hand-over"); return GS_E_STATE; }
+    std::vector<std::function<int(gs_ctx *)>> cl;
     try {                                                          // (no exception crosses the C ABI: a closure that cannot be queued is GS_E_OOM)
-        for (Feeder *f : m->f) {
-            const int rank = f->rank;
-            { std::lock_guard<std::mutex> lk(f->m); f->q.push_back([fn, rank](gs_ctx *c) { return fn(c, rank); }); }
-            f->cv_work.notify_one();
-        }
+        cl.reserve(m->f.size());
+        for (Feeder *f : m->f) { const int rank = f->rank; cl.emplace_back([fn, rank](gs_ctx *c) { return fn(c, rank); }); }
     } catch (...) { snprintf(m->err, sizeof m->err, "out of host memory"); return GS_E_OOM; }
+    size_t k = 0;
+    for (Feeder *f : m->f) {
+        bool ok = true;
+        { std::lock_guard<std::mutex> lk(f->m); try { f->q.push_back(std::move(cl[k])); } catch (...) { ok = false; } }
+        if (!ok) {                                                  // (a queue node of a few hundred bytes could not be allocated)
+            m->dead = true;
+            snprintf(m->err, sizeof m->err, "out of host memory while a call was being handed to the devices: the multi-device context is unusable");
+            return GS_E_OOM;
+        }
+        f->cv_work.notify_one();
+        k++;
+    }
     return GS_OK;
 }
 

@@ -482,7 +482,7 @@ __device__ __forceinline__ void k_near_stash_body(const float *__restrict__ dept
             total = __shfl(inc, 63, 64);
             if (threadIdx.x == 0) {
                 cnt_out[c] = total < GS_NEAR_STASH ? total : GS_NEAR_STASH;
-                if (total > GS_NEAR_STASH) { ctl->near_overflow = 1u; ctl->round1_missed = 1u; }
+                if (total > GS_NEAR_STASH) { ctl->near_overflow = 1u; ctl->order_incomplete = 1u; ctl->round1_missed = 1u; }
             }
         }
         __syncthreads();

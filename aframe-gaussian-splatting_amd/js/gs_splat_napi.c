@@ -31,14 +31,38 @@ static napi_value throw_gs(napi_env env, gs_ctx *ctx, int rc)
 /* What a JS handle points to.  destroy() frees the context at once (HBM, streams, worker threads) and leaves the shell for
  * the garbage collector; `busy` is set while an asynchronous call (sortAsync / renderAsync) owns the context: a gs_ctx is
  * single-caller, like the reference's single-flight worker (sortReady, index.js:206, 220, 439-440). */
-typedef struct gs_handle { gs_ctx *ctx; int busy; } gs_handle;
+/* Frames queued with GS_RENDER_ASYNC are written by the GPU (a copy behind the frame's kernels) until the next sync: the
+ * handle holds a reference to each such frame until then, so that the garbage collector cannot finalize -- and, for
+ * allocFrame's page-locked memory, free -- a buffer a copy is still in flight to. */
+typedef struct gs_held { napi_ref *refs; size_t n, cap; } gs_held;
+static int held_add(napi_env env, gs_held *h, napi_value v)
+{
+    if (h->n == h->cap) {
+        const size_t cap = h->cap ? h->cap * 2 : 64;
+        napi_ref *r = (napi_ref *)realloc(h->refs, cap * sizeof *r);
+        if (!r) return 0;
+        h->refs = r; h->cap = cap;
+    }
+    if (napi_create_reference(env, v, 1, &h->refs[h->n]) != napi_ok) return 0;
+    h->n++;
+    return 1;
+}
+static void held_release(napi_env env, gs_held *h)               /* the GPU is done with them: after a sync, a clear, a destroy */
+{
+    for (size_t i = 0; i < h->n; i++) napi_delete_reference(env, h->refs[i]);
+    h->n = 0;
+}
+static void held_free(napi_env env, gs_held *h) { held_release(env, h); free(h->refs); h->refs = NULL; h->cap = 0; }
+
+typedef struct gs_handle { gs_ctx *ctx; int busy; gs_held held; } gs_handle;
 
 static void ctx_finalize(napi_env env, void *data, void *hint)
 {
-    (void)env; (void)hint;
+    (void)hint;
     gs_handle *h = (gs_handle *)data;
     if (!h) return;
-    if (h->ctx) gs_destroy(h->ctx);
+    if (h->ctx) gs_destroy(h->ctx);                              /* (drains the device first) */
+    held_free(env, &h->held);
     free(h);
 }
 
@@ -166,8 +190,9 @@ static napi_value fn_clear(napi_env env, napi_callback_info info)       /* worke
     napi_value argv[1];
     if (!get_args(env, info, 1, argv, NULL)) return NULL;
     gs_ctx *ctx = get_ctx(env, argv[0]); if (!ctx) return NULL;
-    int rc = gs_clear(ctx);
+    int rc = gs_clear(ctx);                                      /* (drains every lane) */
     if (rc != GS_OK) return throw_gs(env, ctx, rc);
+    held_release(env, &get_handle(env, argv[0])->held);
     return NULL;
 }
 
@@ -372,6 +397,7 @@ static napi_value fn_render_into(napi_env env, napi_callback_info info)
     if (!get_bytes(env, argv[2], &out, &len) || len < (size_t)(p.x1 - p.x0) * (size_t)p.fb_height * 4) {
         napi_throw_range_error(env, NULL, "renderInto: frame buffer missing or too small"); return NULL;
     }
+    if ((p.flags & GS_RENDER_ASYNC) && !held_add(env, &get_handle(env, argv[0])->held, argv[2])) { napi_throw_error(env, NULL, "out of memory"); return NULL; }
     int rc = gs_render(ctx, &p, (uint8_t *)out, 0);
     if (rc != GS_OK) return throw_gs(env, ctx, rc);
     return argv[2];
@@ -593,6 +619,7 @@ static napi_value fn_sync(napi_env env, napi_callback_info info)
     if (!get_args(env, info, 1, argv, NULL)) return NULL;
     gs_ctx *ctx = get_ctx(env, argv[0]); if (!ctx) return NULL;
     int rc = gs_sync(ctx);
+    held_release(env, &get_handle(env, argv[0])->held);           /* (every queued frame has reached its buffer, whatever the status) */
     if (rc != GS_OK) return throw_gs(env, ctx, rc);
     return NULL;
 }
@@ -704,14 +731,15 @@ static napi_value fn_scaled_size(napi_env env, napi_callback_info info)
  * multiSort(h, view, cutout | null, views);  multiRender(h, views, frames, flags = 0): host-direct -- every GPU copies its
  * strip straight into the caller's page-locked frame(s) (allocFrame);  multiRenderDevice(h, views, flags) + multiRead(h, view,
  * frame): gathered on the first device;  multiSync(h);  multiDestroy(h). */
-typedef struct gs_mhandle { gs_multi *m; } gs_mhandle;
+typedef struct gs_mhandle { gs_multi *m; gs_held held; } gs_mhandle;
 
 static void multi_finalize(napi_env env, void *data, void *hint)
 {
-    (void)env; (void)hint;
+    (void)hint;
     gs_mhandle *h = (gs_mhandle *)data;
     if (!h) return;
     if (h->m) gs_multi_destroy(h->m);
+    held_free(env, &h->held);
     free(h);
 }
 
@@ -767,6 +795,7 @@ static napi_value fn_multi_destroy(napi_env env, napi_callback_info info)
     if (!get_args(env, info, 1, argv, NULL)) return NULL;
     gs_mhandle *h = get_mhandle(env, argv[0], 0); if (!h) return NULL;
     if (h->m) { gs_multi_destroy(h->m); h->m = NULL; }
+    held_release(env, &h->held);
     return NULL;
 }
 
@@ -857,6 +886,7 @@ static napi_value fn_multi_render(napi_env env, napi_callback_info info)
             napi_throw_range_error(env, NULL, "multiRender: a frame buffer is missing or too small"); return NULL;
         }
         frames[v] = (uint8_t *)out;
+        if ((flags & GS_RENDER_ASYNC) && !held_add(env, &h->held, fv)) { napi_throw_error(env, NULL, "out of memory"); return NULL; }
     }
     int rc = gs_multi_render(h->m, views, (int)nv, frames, 0, flags);
     if (rc != GS_OK) return throw_multi(env, h->m, rc);
@@ -903,6 +933,7 @@ static napi_value fn_multi_sync(napi_env env, napi_callback_info info)
     if (!get_args(env, info, 1, argv, NULL)) return NULL;
     gs_mhandle *h = get_mhandle(env, argv[0], 1); if (!h) return NULL;
     int rc = gs_multi_sync(h->m);
+    held_release(env, &h->held);
     if (rc != GS_OK) return throw_multi(env, h->m, rc);
     return NULL;
 }
@@ -915,6 +946,7 @@ static napi_value fn_destroy(napi_env env, napi_callback_info info)      /* expl
     if (!h) return NULL;
     if (h->busy) { napi_throw_error(env, "GS_BUSY", "an asynchronous sort or render of this context is in flight"); return NULL; }
     if (h->ctx) { gs_destroy(h->ctx); h->ctx = NULL; }     /* HBM, streams and threads go now; the shell goes with the JS handle */
+    held_release(env, &h->held);
     return NULL;
 }
 

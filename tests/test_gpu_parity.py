@@ -650,6 +650,59 @@ def test_near_only_sorts_by_default_six_million_splats():
         _near_only_frames_equal(c, cams, [None] * len(cams), strips=((0, 240), (960, 1200)))
 
 
+@pytest.mark.skipif(os.environ.get("GS_SKIP_SLOW") == "1", reason="large configs")
+def test_synchronous_frame_on_an_overflowed_near_only_sort_is_drawn_again_in_full():
+    """a near-only sort of a long scene hands its survivors on through per-chunk stashes of 512 records; a chunk
+    of 4096 CONSECUTIVE splats that all sit right in front of the camera overflows its stash, and the order is then incomplete.
+    Asynchronous frames were always drawn again from a whole sort by gs_sync(); a SYNCHRONOUS frame only had its second binning
+    round run (the flag was read as 'round 1 was skipped') and returned a wrong image with GS_OK.  Now the order carries its own
+    flag: the frame sorts in full and draws both rounds again."""
+    n, w, h = 1 << 22, 1280, 720
+    rows = cached_rows("make_splat_rows", n, seed=synth.SEED_BASE + 11).reshape(-1, 32)
+    cam_a, cam_b = synth.index_html_camera(w, h, 10.0, capi=capi), synth.index_html_camera(w, h, 190.0, capi=capi)
+    with capi.Context(0) as c:
+        c.push_splat(rows)
+        order = c.sort(cam_b["view"])                                       # far -> near at pose B
+    near = order[-6000:]
+    keep = np.ones(n, bool); keep[near] = False
+    rows2 = np.concatenate([rows[np.sort(near)], rows[keep]])               # the 6000 nearest splats of pose B: one block of indices
+    with capi.Context(0) as c:
+        c.set_option(capi.OPT_SORT_NEAR, 0)
+        c.set_option(capi.OPT_TERMINATION, 4)                               # pixels stop at T < 1/4: tiles saturate within ~1 % of the order, so
+        c.push_splat(rows2)                                                 # that 4 M splats are enough for the stash path (share <= 1/32)
+        c.sort(cam_b["view"], want_indices=False)
+        want_b = c.render(_params(cam_b))
+    with capi.Context(0) as c:
+        c.set_option(capi.OPT_SORT_NEAR, 2)
+        c.set_option(capi.OPT_TERMINATION, 4)
+        c.push_splat(rows2)
+        for attempt in range(12):                                           # settle the share at pose A (the block is far away there)
+            for rep in range(8):
+                c.sort(cam_a["view"], want_indices=False)
+                c.render_device(_params(cam_a, flags=capi.RENDER_ASYNC))
+            c.sync()
+            s = c.stats()
+            if 0 < s["sort_records"] < s["n_sorted"] and s["near_permille"] <= 31:
+                break
+        assert 0 < s["sort_records"] < s["n_sorted"] and s["near_permille"] <= 31, s   # near-only sorts through the chunk stashes are on
+        before = s["retried_frames"]
+        c.sort(cam_b["view"], want_indices=False)                           # near-only: the block's chunk overflows its stash
+        got = c.render(_params(cam_b))                                      # synchronous
+        assert np.array_equal(got, want_b)
+        assert c.stats()["retried_frames"] > before                         # (it really was drawn again)
+        for rep in range(3):                                                # and the context goes on: queued and synchronous frames
+            c.sort(cam_b["view"], want_indices=False)
+            assert np.array_equal(c.render(_params(cam_b)), want_b)
+        bufs = [capi.host_frame(h, w) for _ in range(4)]
+        for b, _ in bufs:
+            c.sort(cam_b["view"], want_indices=False)
+            c.render_into(_params(cam_b, flags=capi.RENDER_ASYNC), b)
+        c.sync()
+        for b, o in bufs:
+            assert np.array_equal(b, want_b)
+            o.free()
+
+
 def test_scene_depth_and_colour_compositing(ctx, scene_small):
     """depthTest: true / depthWrite: false over an opaque scene (index.js:177-181): splat fragments behind the scene's
     depth are rejected (LEQUAL), the rest is blended over the scene's colour.  Same fragments as the oracle, exactly."""
