@@ -225,13 +225,51 @@ class GaussianSplatting {
 GaussianSplatting.QUEUE_DEPTH = 7;                // frames to queue between two sync() calls in throughput mode: the first goes out alone
                                                    // at once, then GS_OPT_PIPELINE_DEPTH's default (3) pairs
 
-// Optional: expose the same component name to an A-Frame-like registry.
+// The registered component (index.js:1-23): AFRAME.registerComponent("gaussian_splatting", ...) with the reference's life cycle.
+//   init    resolution properties (index.js:10-15); when the scene has loaded (index.js:17), loadData with the scene camera's
+//           three.js camera, the entity's object3D, the renderer and `src` (index.js:18), and cutoutEntity -> its object3D
+//           (index.js:19-21).  `this.ready` is the promise of that load.
+//   tick    the reference's tick posts the worker sort (index.js:438-455) and three.js then draws the mesh; here tick sorts
+//           and, if the host installed a frame sink, draws: `component.frameSink = (rgba, viewport) => ...` receives the
+//           RGBA framebuffer three.js would have drawn (page-locked, reused: copy it to keep it).  The drawing-buffer size is
+//           the renderer's (getDrawingBufferSize / domElement), i.e. what pixelRatio / xrPixelRatio made of the canvas.
+//   remove  frees the context.
+function sceneCamera(sceneEl) {                      // this.el.sceneEl.camera.el.components.camera.camera (index.js:18)
+  const c = sceneEl && sceneEl.camera;
+  return c && c.el && c.el.components && c.el.components.camera ? c.el.components.camera.camera : c;
+}
+function drawingBuffer(renderer) {
+  if (!renderer) return null;
+  if (renderer.getDrawingBufferSize) { const v = renderer.getDrawingBufferSize({ x: 0, y: 0, set(x, y) { this.x = x; this.y = y; return this; } });
+    const w = v.width !== undefined ? v.width : v.x, h = v.height !== undefined ? v.height : v.y; if (w > 0 && h > 0) return { width: w, height: h }; }
+  const el = renderer.domElement;
+  return el && el.width > 0 && el.height > 0 ? { width: el.width, height: el.height } : null;
+}
 function register(AFRAME) {
   AFRAME.registerComponent('gaussian_splatting', {
     schema,
-    init() { this.impl = new GaussianSplatting(this.data).init(this.el && this.el.sceneEl); },
-    tick() { if (this.impl.camera) this.impl.tick(); },
-    remove() { this.impl.remove(); },
+    init() {
+      const sceneEl = this.el && this.el.sceneEl;
+      this.impl = new GaussianSplatting(Object.assign({}, this.data, { cutoutEntity: null })).init(sceneEl);
+      this.ready = null;
+      const start = () => {
+        if (this.data.cutoutEntity) this.impl.cutout = this.data.cutoutEntity.object3D;          // index.js:19-21
+        this.ready = this.impl.loadData(sceneCamera(sceneEl), this.el.object3D, sceneEl.renderer, this.data.src);   // index.js:18
+        return this.ready;
+      };
+      if (!sceneEl) return;
+      if (sceneEl.hasLoaded) start(); else sceneEl.addEventListener('loaded', start);               // index.js:17
+    },
+    tick() {
+      const g = this.impl;
+      if (!g || !g.camera || !g.loadedVertexCount) return;
+      g.tick();                                                                                     // index.js:438-455
+      if (this.frameSink) {
+        const vp = this.viewport || drawingBuffer(g.renderer);
+        if (vp) this.frameSink(g.render(g.camera, vp), vp);
+      }
+    },
+    remove() { if (this.impl) this.impl.remove(); this.impl = null; },
   });
 }
 

@@ -148,6 +148,13 @@ def index_html_camera(vw=1920, vh=1080, yaw_deg=0.0, capi=None):
     return uniforms(compose((0.0, 1.6, 0.0)), compose((0.0, 1.5, -2.0), yaw_deg), perspective(80.0, vw / vh), vw, vh, capi=capi)
 
 
+def outside_cloud_camera(vw=1920, vh=1080, yaw_deg=0.0, capi=None, distance=7.5):
+    """The scene seen from OUTSIDE: the entity 3 sigma (7.5 units) in front of the A-Frame default camera instead of index.html's 2
+    (where the camera sits inside the sigma = 2.5 cloud and the nearest splats fill the screen): sky around the cloud, thin
+    coverage at its rim, many small splats per tile -- the regime between the saturated headline pose and the unsaturated scene."""
+    return uniforms(compose((0.0, 1.6, 0.0)), compose((0.0, 1.6, -float(distance)), yaw_deg), perspective(80.0, vw / vh), vw, vh, capi=capi)
+
+
 def cutout_demo_camera(vw=1920, vh=1080, yaw_deg=0.0, capi=None):
     """cutout-demo.html:22-24 pose: camera (5.132,1.6,7.237); entity scale 2 at (0,0.8,-2); cutout box
     scale (4.17,2.95,3.89) at (0.8145,1.73322,-2.35981)."""

@@ -118,10 +118,18 @@ def main():
         t = torch.tensor([ok], dtype=torch.int32, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
         if int(t.item()) == 0:
-            # The library's own communicator could not be set up on this node: keep the measurement alive with the plain form of
-            # the same exchange -- every rank renders its strip synchronously into a torch tensor, torch.distributed gathers the
-            # strips on rank 0 (no pipelining of the gather; reported in config.parallelism).
+            # The library's own communicator could not be set up on this node.  A line measured through torch.distributed would
+            # measure PyTorch, not gs_comm.hip: fail loudly -- unless GS_BENCH_TORCH_GATHER=1 asks for the plain form of the same
+            # exchange (every rank renders its strip synchronously into a torch tensor, torch.distributed gathers the strips on
+            # rank 0; no pipelining of the gather; labelled FALLBACK in config.parallelism)
+            if os.environ.get("GS_BENCH_TORCH_GATHER") != "1":
+                sys.stderr.write("rank %d: the library's RCCL communicator could not be set up (gs_comm_init) -- not measuring a torch.distributed "
+                                 "stand-in; set GS_BENCH_TORCH_GATHER=1 to run that fallback\n" % rank)
+                dist.destroy_process_group()
+                sys.exit(3)
             torch_gather = True
+        elif rank == 0:
+            first_contact_report(ctx, capi, world, pieces_hint=None)
     elif comm1:
         ctx.comm_init(ctx.comm_unique_id(), 0, 1)
         ctx.set_option(capi.OPT_COMM_SELF_COPY, 1)
@@ -261,6 +269,7 @@ def main():
         ctx.set_option(capi.OPT_PROFILE, 0)
         ctx.set_option(capi.OPT_PROFILE, 3)                  # HIP events around the dominant kernel (blend) on its stream, every 4th frame
         sync()
+        retried_before = ctx.stats().get("retried_frames", 0)
         t_start = time.perf_counter()
         for i in range(args.steps):
             frame(args.warmup + i, capi.RENDER_ASYNC)
@@ -281,7 +290,8 @@ def main():
     ctx.set_option(capi.OPT_PROFILE, 0)
     blends_per_step = len(mine) if gathered else 1
     # (frames gs_sync() drew again by itself -- GS_OPT_AUTO_RETRY -- are inside the region's time and counted on top)
-    assert s["acc_frames"] >= args.steps * blends_per_step, (s["acc_frames"], args.steps, blends_per_step)
+    assert s["acc_frames"] == (args.steps + s.get("retried_frames", 0) - retried_before) * blends_per_step or gathered, (
+        s["acc_frames"], args.steps, s.get("retried_frames", 0), retried_before, blends_per_step)
     blend_frames = max(1, s["prof_frames"])                  # renders of the timed region whose blend was bracketed by HIP events
     # per-stage breakdown: a second, UNTIMED pass over the same frames with events around every stage (7 per frame
     # instead of 2; they cost ~4 % of the frame rate, so the timed region carries only the blend's)
@@ -333,7 +343,7 @@ def main():
     total_frags = sum(frags[(args.warmup + i) % ORBIT_FRAMES] for i in range(args.steps))
     extras = None
     if rank == 0 and world == 1 and not args.no_extras and not args.xr:
-        extras = secondary_measurements(ctx, capi, synth, rows, cams, views, n_splats, args, frame_batch)
+        extras = secondary_measurements(ctx, capi, synth, rows, cams, views, n_splats, args, frame_batch, pmc_load(world, n_splats, args)[0])
     if rank == 0:
         K = args.steps
         fps = K / elapsed
@@ -348,7 +358,13 @@ def main():
         # whole-frame algorithmic bytes (SURVEY.md 8d formula), this rank's share
         V, Vp, I = sorted_n / K, visible / K, pairs / K
         frame_bytes = (16 * n_splats + 4 * V) + (Vp * 36 + V * 4 + Vp * 32) + (I * 20) + (I * 36 + 4 * own_px)
-        traffic, traffic_src = pmc_traffic(world, n_splats, args)
+        pmc_cfg, traffic_src = pmc_load(world, n_splats, args)
+        traffic = frame_traffic = None
+        if pmc_cfg:
+            row, fpl = pmc_blend_row(pmc_cfg)
+            if row:
+                traffic = round(row["hbm_bytes"] * frame_batch / fpl)      # per launch of THIS run (frame_batch frames)
+            frame_traffic = pmc_cfg.get("frame_hbm_bytes")
         if args.xr:
             metric = "XR stereo frames/sec, 2 x %dx%d (2064x2208 x xrPixelRatio 0.5), one shared head-camera sort" % (W, H)
             workload = "train.splat-shaped synthetic, N=%d splats, XR stereo 2 x %dx%d, 120-frame orbit (index.html:13 pose, eyes +-32 mm)" % (n_splats, W, H)
@@ -394,7 +410,12 @@ def main():
                           "ms_sort": round(stage["ms_sort"] / K, 4), "ms_project": round(stage["ms_project"] / K, 4),
                           "ms_bin": round(stage["ms_bin"] / K, 4), "ms_blend": round(stage["ms_blend"] / K, 4)},
             "frame_hbm": {"algorithmic_bytes": round(frame_bytes), "achieved_GBps": round(frame_bytes * fps / 1e9, 1),
-                          "frac_of_peak": round(frame_bytes * fps / 1e9 / HBM_PEAK_GBS, 5)},
+                          "frac_of_peak": round(frame_bytes * fps / 1e9 / HBM_PEAK_GBS, 5),
+                          "traffic": frame_traffic, "traffic_over_algorithmic": round(frame_traffic / frame_bytes, 3) if frame_traffic else None,
+                          "traffic_GBps": round(frame_traffic * fps / 1e9, 1) if frame_traffic else None,
+                          "note": "algorithmic_bytes = SURVEY.md 8(d): (16N + 4V) + (36Vp + 4V + 32Vp) + 20 I + (36 I + 4 fb) per frame, its "
+                                  "20 I priced for (tile, splat) records through a sort; `traffic` = counter bytes (2*FETCH_SIZE + WRITE_SIZE) of "
+                                  "EVERY kernel of the profiled pipelined loop per frame it drew (" + traffic_src + ")"},
             "roofline": {"kernel": "k_blend", "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
                          "measured_copy_GBps": copy_peak,
@@ -404,7 +425,8 @@ def main():
                          "bytes_per_launch": round(blend_bytes * frame_batch), "avg_launch_ms": round(blend_s * frame_batch * 1e3, 4),
                          "frames_per_launch": frame_batch,
                          "launches_timed": int(blend_frames),
-                         "achieved_touched": round(achieved_touched, 2), "touched_bytes_per_launch": round(touched_bytes)},
+                         "achieved_touched": round(achieved_touched, 2), "touched_bytes_per_launch": round(touched_bytes * frame_batch),
+                         "touched_bytes_per_frame": round(touched_bytes)},
             "roofline_valu": None,                           # filled in by secondary_measurements (single GPU)
         }
         if extras:
@@ -529,42 +551,62 @@ def single_process_main(args):
             o.free()
 
 
-# VALU issue model of the blend (tools/micro/valu_rate.hip on gfx950: cycles per wave-instruction at full occupancy) and its
-# instruction count per evaluated fragment group, from the committed PMC pass (profiles/r01_pmc_valu.md: SQ_INSTS_VALU of
-# k_blend / list entries evaluated); both are properties of the kernel's code, re-measured when gs_render.hip changes
-BLEND_VALU_PER_ENTRY = 40.7        # VALU wave-instructions per list entry a tile's wavefront evaluates (256 pixels): the PMC figure of
-                                   # round 1 (43.0) x 87/92, the inner loop's VALU count after / before the round-2 changes (ISA listing)
-VALU_CYCLES_PER_INSTR = 4.5        # average issue cost of the blend's mix (v_pk_fma 4.8, v_fma 3.8, v_exp 8.3, v_mul/add 2.5)
+# The VALU roofline of the blend comes from THIS round's counters (profiles/pmc_counters.json, written by tools/gpu_pmc.sh +
+# tools/pmc_summary.py and stamped with the SHA-1 of csrc/*): SQ_INSTS_VALU of the blend per launch / the list entries the same
+# profiled run's blend evaluates = VALU wave-instructions per list entry; SQ_ACTIVE_INST_VALU x 4 / SQ_INSTS_VALU = the SIMD cycles
+# one VALU wave-instruction of this kernel's mix occupies.  Two peaks are stated: the guide's (MI355X_MICROARCH.md latency table:
+# v_fma_f32 wave64 "2 cyc (SIMD-32)", the rate behind the 157.3 TF vector-fp32 datasheet figure) and the counters' own.
 SIMDS, CLOCK_GHZ = 1024, 2.4
+GUIDE_CYCLES_PER_VALU = 2.0
 
 
-def pmc_traffic(world, n_splats, args):
-    """HBM bytes per launch of the timed configuration's blend from the committed rocprofv3 --pmc passes -- only if that
-    profile was taken from the kernel sources this run uses (sha of csrc/*.hip, *.h recorded by tools/pmc_summary.py)."""
+def pmc_config_name(world, n_splats, args):
+    if world != 1 or args.xr:
+        return None
+    if n_splats == N_TRAIN_DEFAULT and not args.cutout:
+        return "c2" if not args.size else ("c1" if args.size.lower() == "1280x720" else None)
+    if n_splats == 6291456 and args.cutout and not args.size:
+        return "c3"
+    if n_splats == 20971520 and not args.cutout and (args.size or "").lower() == "3840x2160":
+        return "c5"
+    return None
+
+
+def pmc_load(world, n_splats, args):
+    """The committed rocprofv3 --pmc passes of this configuration -- only if they were taken from the kernel sources this run uses.
+    Returns (config dict or None, note)."""
     try:
         import hashlib
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_hbm_traffic.json")))
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_counters.json")))
         h = hashlib.sha1()
         csrc = os.path.join(ROOT, PKG, "csrc")
         for f in sorted(os.listdir(csrc)):
             if f.endswith((".hip", ".h", ".cpp")):
                 h.update(open(os.path.join(csrc, f), "rb").read())
-        if world != 1 or n_splats != N_TRAIN_DEFAULT or args.size or args.cutout or args.xr:
+        name = pmc_config_name(world, n_splats, args)
+        if name is None or name not in pmc.get("configs", {}):
             return None, "no PMC pass for this configuration"
         if pmc.get("_csrc_sha1") != h.hexdigest():
-            return None, "profiles/pmc_hbm_traffic.json was taken from other kernel sources (stale): not reported"
-        # (the timed loop pairs frames: its blend launches are k_twin<F_blend<0, ...>> over two frames; the per-frame kernel otherwise)
-        keys = [k for k in pmc if "F_blend<0" in k or "F_blend0<" in k] or [k for k in pmc if k.startswith("k_blend<false, 0")]
-        key = max(keys, key=lambda k: pmc[k].get("launches", 0))
-        return pmc[key]["hbm_bytes"], "profiles/pmc_hbm_traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this bench command; 2*FETCH + WRITE)"
+            return None, "profiles/pmc_counters.json was taken from other kernel sources (stale): not reported"
+        return pmc["configs"][name], "profiles/pmc_counters.json[%s] (separate rocprofv3 --pmc passes of tools/stage_bench.py --pmc-run, the pipelined loop of this configuration; 2*FETCH_SIZE + WRITE_SIZE)" % name
     except Exception as e:
         return None, "no usable PMC profile (%s)" % type(e).__name__
+
+
+def pmc_blend_row(cfg):
+    """the blend of the timed loop: k_twin<F_blend<0, ...>> over two frames (frames paired), the per-frame kernel otherwise"""
+    k = cfg["kernels"]
+    keys = [n for n in k if "F_blend<0" in n] or [n for n in k if n.startswith("k_blend<false, 0")]
+    if not keys:
+        return None, 1
+    key = max(keys, key=lambda n: k[n].get("launches", 0))
+    return k[key], (2 if "k_twin" in key else 1)
 
 
 N_TRAIN_DEFAULT = 1 << 20
 
 
-def secondary_measurements(ctx, capi, synth, rows, cams, views, n_splats, args, frame_batch=1):
+def secondary_measurements(ctx, capi, synth, rows, cams, views, n_splats, args, frame_batch=1, pmc_cfg=None):
     """What the headline number does not show: one frame at a time, the frame delivered to host
     memory, the blend without early termination, and a scene whose tiles do NOT saturate.  Single GPU, untimed for `value`."""
     out = {}
@@ -622,16 +664,35 @@ def secondary_measurements(ctx, capi, synth, rows, cams, views, n_splats, args, 
         ev.append(int(ctx.download(capi.BUF_TILE_STATS, ntl, np.uint32, 2)[:, 0].astype(np.int64).sum()))
     ctx.set_option(capi.OPT_RECORD_STAGED, 0)
     entries = float(np.mean(ev))
-    instr_rate = entries * BLEND_VALU_PER_ENTRY / blend_alone_s / 1e9 if blend_alone_s > 0 else 0.0
-    peak = SIMDS * CLOCK_GHZ / VALU_CYCLES_PER_INSTR
-    out["roofline_valu"] = {"kernel": "k_blend", "bound": "valu", "achieved": round(instr_rate, 1), "peak": round(peak, 1),
-                            "unit": "G wave-instr/s", "frac": round(instr_rate / peak, 4),
-                            "list_entries_evaluated_per_launch": round(entries), "avg_launch_ms_alone": round(blend_alone_s * 1e3, 4),
-                            "instr_per_list_entry": BLEND_VALU_PER_ENTRY, "cycles_per_instr": VALU_CYCLES_PER_INSTR,
-                            "note": "VALU wave-instructions issued per second by the blend running alone (depth 1) against "
-                                    "1024 SIMDs x 2.4 GHz / 4.5 cycles per instruction; entries = list entries each tile's wavefront "
-                                    "evaluated before it saturated (GS_OPT_RECORD_STAGED = 2, this run); VALU instructions per entry "
-                                    "and the issue costs are properties of the kernel code (profiles/r01_pmc_valu.md, tools/micro/valu_rate.hip)"}
+    rv = {"kernel": "k_blend", "bound": "valu", "unit": "G wave-instr/s", "list_entries_evaluated_per_frame": round(entries),
+          "avg_launch_ms_alone": round(blend_alone_s * 1e3, 4)}
+    row, fpl = pmc_blend_row(pmc_cfg) if pmc_cfg else (None, 1)
+    vv = (row or {}).get("valu")
+    pmc_entries = (pmc_cfg or {}).get("run_valu", {}).get("entries_evaluated_per_frame") or (pmc_cfg or {}).get("run", {}).get("entries_evaluated_per_frame")
+    if vv and pmc_entries and vv.get("SQ_INSTS_VALU"):
+        per_entry = vv["SQ_INSTS_VALU"] / (pmc_entries * fpl)                  # VALU wave-instructions per evaluated list entry (256 pixels)
+        cyc = 4.0 * vv["SQ_ACTIVE_INST_VALU"] / vv["SQ_INSTS_VALU"]            # SIMD cycles per VALU wave-instruction of this kernel's mix
+        instr_rate = entries * per_entry / blend_alone_s / 1e9 if blend_alone_s > 0 else 0.0
+        peak_guide, peak_ctr = SIMDS * CLOCK_GHZ / GUIDE_CYCLES_PER_VALU, SIMDS * CLOCK_GHZ / cyc
+        rv.update({"achieved": round(instr_rate, 1), "peak": round(peak_guide, 1), "frac": round(instr_rate / peak_guide, 4),
+                   "peak_at_counted_issue_cost": round(peak_ctr, 1), "frac_at_counted_issue_cost": round(instr_rate / peak_ctr, 4),
+                   "instr_per_list_entry": round(per_entry, 2), "cycles_per_instr_counted": round(cyc, 3), "cycles_per_instr_guide": GUIDE_CYCLES_PER_VALU,
+                   "pmc": {"SQ_INSTS_VALU_per_launch": vv["SQ_INSTS_VALU"], "SQ_ACTIVE_INST_VALU_quad_cycles_per_launch": vv["SQ_ACTIVE_INST_VALU"],
+                           "SQ_BUSY_CYCLES_per_launch": vv.get("SQ_BUSY_CYCLES"), "SQ_WAVES_per_launch": vv.get("SQ_WAVES"),
+                           "SQ_INSTS_LDS_per_launch": vv.get("SQ_INSTS_LDS"), "frames_per_launch": fpl,
+                           "list_entries_evaluated_per_frame_in_the_profiled_run": round(pmc_entries), "source": "profiles/pmc_counters.json"},
+                   "note": "VALU wave-instructions issued per second by the blend running alone (depth 1).  instr_per_list_entry and the issue "
+                           "cost are THIS build's counters: SQ_INSTS_VALU of the blend / list entries the same profiled loop's blend evaluates; "
+                           "4 x SQ_ACTIVE_INST_VALU (quad-cycles) / SQ_INSTS_VALU = SIMD cycles per VALU wave-instruction.  `peak` prices an "
+                           "instruction at the guide's 2 cycles per wave64 VALU (MI355X_MICROARCH.md: the rate of the 157.3 TF vector-fp32 "
+                           "datasheet figure, which counts both halves of a packed v_pk_fma_f32); the counters say that every kernel of this "
+                           "library spends 4.0-4.3 cycles per VALU wave-instruction (a wave64 instruction passes a 16-lane SIMD in 4 cycles; "
+                           "packed-fp32 and v_exp_f32 take longer), which is `peak_at_counted_issue_cost` -- the roof the kernel can actually reach "
+                           "without packing more work into an instruction"})
+    else:
+        rv.update({"achieved": None, "peak": round(SIMDS * CLOCK_GHZ / GUIDE_CYCLES_PER_VALU, 1), "frac": None,
+                   "note": "no VALU counter pass of these kernel sources in profiles/pmc_counters.json (tools/gpu_pmc.sh): not computed from constants"})
+    out["roofline_valu"] = rv
     # the frame delivered to the host (what a JS caller of component.render() gets): gs_render into page-locked memory.  Two ways
     # there (GS_OPT_HOST_WRITE): the copy engine behind the frame's last kernel, or the blend kernel storing its tiles straight into
     # the page-locked frame; the denominator is this box's own device-to-host rate (1 GiB, page-locked, same run)
@@ -764,7 +825,140 @@ def secondary_measurements(ctx, capi, synth, rows, cams, views, n_splats, args, 
             out["unsaturated_scene"]["two_rounds_pinned"] = {
                 "fps": round(m / t, 1), "near_permille_pinned": 150, "unsat_tiles_last_frame": st["unsat_tiles"], "tiles": st["n_tiles"],
                 "unsat_share": round(st["unsat_tiles"] / max(1.0, float(st["n_tiles"])), 3), "I_pairs_last_frame": st["n_pairs"]}
+    # ---- frames the library has NOT seen: the headline region is pre-rolled over its own poses, a moving camera is not
+    pose = synth.cutout_demo_camera if args.cutout else synth.index_html_camera
+
+    def params_of(cs):
+        return [capi.make_params(c["gs_mv"], c["gs_proj"], W, H, focal_=c["focal"]) for c in cs]
+
+    def lap(c, cs, ps, n, first=0, sync_every=24, flags=None):
+        """n queued frames over the poses cs, gs_sync every `sync_every` (a consumer that collects its frames); (seconds, retry requests)"""
+        asked = 0
+        try:
+            c.sync()
+        except capi.GsError:
+            pass
+        t0 = time.perf_counter()
+        for i in range(n):
+            k = (first + i) % len(cs)
+            c.sort(cs[k]["view"], cs[k]["cutout"], want_indices=False)
+            ps[k].flags = capi.RENDER_ASYNC if flags is None else flags
+            c.render_device(ps[k], None)
+            if i % sync_every == sync_every - 1 or i == n - 1:
+                try:
+                    c.sync()
+                except capi.GsError as e:
+                    if e.code != capi.E_RETRY:
+                        raise
+                    asked += 1
+        return time.perf_counter() - t0, asked
+
+    def stage_pass(c, cs, ps, n):
+        c.set_option(capi.OPT_PROFILE, 1)
+        lap(c, cs, ps, n, sync_every=48)
+        st = c.stats()
+        c.set_option(capi.OPT_PROFILE, 0)
+        k = max(1, st["prof_frames"]) * frame_batch
+        return {"ms_sort": round(st["sum_ms_sort"] / k, 4), "ms_project": round(st["sum_ms_project"] / k, 4), "ms_bin": round(st["sum_ms_bin"] / k, 4),
+                "ms_blend": round(st["sum_ms_blend"] / k, 4), "V_sorted": st["n_sorted"], "Vp_visible": st["n_visible"], "I_pairs": st["n_pairs"]}
+
+    with capi.Context(ctx.device) as c3:
+        r32 = rows.reshape(-1, 32)
+        for o in range(0, r32.shape[0], 1 << 22):
+            c3.push_splat(r32[o:o + (1 << 22)])
+        c3.set_option(capi.OPT_FRAME_BATCH, frame_batch)
+        if args.cutout:
+            c3.set_option(capi.OPT_BLEND_SPLIT, int(os.environ.get("GS_BENCH_SPLIT", "1")))
+        # (a) a FRESH context's first lap over 120 poses it has never drawn (half a step off the headline orbit's): the share of splats
+        # binned first starts at the library's default, the second binning round is still on, buffers grow; then the second lap
+        cold = [pose(W, H, 1.5 + 3.0 * i, capi=capi) for i in range(ORBIT_FRAMES)]
+        pc = params_of(cold)
+        t1, a1 = lap(c3, cold, pc, ORBIT_FRAMES)
+        s1 = c3.stats()
+        t2, a2 = lap(c3, cold, pc, ORBIT_FRAMES)
+        s2 = c3.stats()
+        out["cold_orbit"] = {"fps_first_lap": round(ORBIT_FRAMES / t1, 1), "fps_second_lap": round(ORBIT_FRAMES / t2, 1),
+                             "near_permille_after_first_lap": s1["near_permille"], "near_permille_after_second_lap": s2["near_permille"],
+                             "frames_redrawn_by_sync": [s1.get("retried_frames", 0), s2.get("retried_frames", 0) - s1.get("retried_frames", 0)],
+                             "sync_retry_requests": [a1, a2],
+                             "stages_second_lap": stage_pass(c3, cold, pc, ORBIT_FRAMES),
+                             "note": "a context created for this measurement, frames queued (3 lanes x %d per launch), gs_sync every 24 frames, "
+                                     "120 poses the library has not drawn before (yaw 1.5 + 3 i degrees), every frame a new pose; first lap includes "
+                                     "buffer growth, the adaptive share settling and every frame gs_sync drew again" % frame_batch}
+        # (b) the camera OUTSIDE the cloud, 3 sigma from its centre, looking in (sky around it, thin coverage at the rim)
+        outside = [synth.outside_cloud_camera(W, H, 3.0 * i, capi=capi) for i in range(ORBIT_FRAMES)]
+        po = params_of(outside)
+        lap(c3, outside, po, ORBIT_FRAMES)                       # the share settles for this regime
+        s3 = c3.stats()
+        t3, a3 = lap(c3, outside, po, 2 * ORBIT_FRAMES, sync_every=48)
+        s4 = c3.stats()
+        out["outside_cloud"] = {"fps": round(2 * ORBIT_FRAMES / t3, 1), "near_permille": s4["near_permille"], "unsat_tiles_last_frame": s4["unsat_tiles"],
+                                "tiles": s4["n_tiles"], "frames_redrawn_by_sync": s4.get("retried_frames", 0) - s3.get("retried_frames", 0),
+                                "sync_retry_requests": a3, "stages": stage_pass(c3, outside, po, ORBIT_FRAMES),
+                                "workload": "the same %d splats seen from outside: entity %.1f units (3 sigma) in front of the camera, %dx%d, 120-pose "
+                                            "orbit after one settling lap, frames queued, gs_sync every 48" % (n_splats, 7.5, W, H)}
+    # ---- the rate a JavaScript caller sees at this size (north_star: the framebuffer goes back to JavaScript): node + the addon + the shim
+    if n_splats <= (2 << 20):
+        out["js_visible"] = js_visible(rows, W, H)
     return out
+
+
+def js_visible(rows, w, h):
+    """aframe-gaussian-splatting_amd/js/bench_visible.js under node on this box: tick + render() one frame at a time, and frameQueued()
+    over a ring of 48 page-locked frames with sync() every 48 -- timed inside JavaScript.  None if node or the addon is missing."""
+    import shutil
+    import subprocess
+    import tempfile
+    node = shutil.which("node")
+    js = os.path.join(ROOT, PKG, "js")
+    if not node or not os.path.exists(os.path.join(js, "gs_splat_napi.node")):
+        return None
+    with tempfile.TemporaryDirectory() as d:
+        f = os.path.join(d, "scene.splat")
+        np.asarray(rows, np.uint8).tofile(f)
+        try:
+            r = subprocess.run([node, os.path.join(js, "bench_visible.js"), f, str(w), str(h), "240", "48"], capture_output=True, text=True, timeout=300)
+            rep = json.loads(r.stdout.strip().splitlines()[-1])
+        except Exception as e:
+            return {"error": (str(e) + " " + (r.stderr[-300:] if "r" in dir() else ""))[:400]}
+    rep["note"] = ("timed in JavaScript (process.hrtime), a new pose every frame: fps_sync = comp.tick() + comp.render() into the component's page-locked "
+                   "frame; fps_queued = comp.frameQueued() into a ring of 48 page-locked frames, comp.sync() every 48")
+    return rep
+
+
+def first_contact_report(ctx, capi, world, pieces_hint=None):
+    """Rank 0, before anything is timed at N > 1: what a failed scaling run is diagnosed from (stderr; stdout carries the ONE JSON line)."""
+    w = sys.stderr.write
+    ver = None
+    try:
+        import torch
+        ver = ".".join(str(v) for v in torch.cuda.nccl.version())
+    except Exception:
+        pass
+    w("[bench] first contact: world %d, RCCL (torch's copy; the library dlopens librccl.so.1) %s, HSA_ENABLE_IPC_MODE_LEGACY=%s\n" % (
+        world, ver, os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")))
+    try:
+        w("[bench] pieces of a mono %dx%d frame over %d ranks (view, x0, x1, owner): %s\n" % (W, H, world, capi.partition([W], world)))
+    except Exception as e:
+        w("[bench] partition failed: %r\n" % (e,))
+    try:
+        import ctypes as C
+        hip = capi.hip_runtime()
+        n = C.c_int(0)
+        hip.hipGetDeviceCount(C.byref(n))
+        rows = []
+        for a in range(n.value):
+            row = []
+            for b in range(n.value):
+                can = C.c_int(0)
+                if a != b:
+                    hip.hipDeviceCanAccessPeer(C.byref(can), C.c_int(a), C.c_int(b))
+                row.append("-" if a == b else str(can.value))
+            rows.append(" ".join(row))
+        w("[bench] %d visible devices; hipDeviceCanAccessPeer (row = device, column = peer):\n" % n.value + "\n".join("[bench]   " + r for r in rows) + "\n")
+    except Exception as e:                                        # a diagnostic, never a reason to fail
+        w("[bench] no peer-access matrix: %r\n" % (e,))
+    sys.stderr.flush()
 
 
 def cpu_baseline(rows, cam, synth):

@@ -4,7 +4,8 @@
 'use strict';
 const fs = require('fs');
 const path = require('path');
-const { GaussianSplatting, schema, native } = require('./gaussian_splatting.js');
+const PKG_JS = path.join(__dirname, '..', '..', 'aframe-gaussian-splatting_amd', 'js');
+const { GaussianSplatting, schema, native, register } = require(path.join(PKG_JS, 'gaussian_splatting.js'));
 
 const [mode, goldenDir] = process.argv.slice(2);
 const manifest = JSON.parse(fs.readFileSync(path.join(goldenDir, 'manifest.json'), 'utf8'));
@@ -99,13 +100,8 @@ for (const name of Object.keys(manifest).filter((k) => manifest[k].kind === 'sor
 }
 
 // ---- GPU: loadData (progressive chunks) -> tick -> render, written out for the Python side to compare
-const THREE = require(path.join(__dirname, '..', '..', 'oracle', 'three_standin.js'));
-function compose(p, yawDeg) {
-  const h = yawDeg * Math.PI / 360;
-  return new THREE.Matrix4().compose(new THREE.Vector3(p[0], p[1], p[2]), new THREE.Quaternion(0, Math.sin(h), 0, Math.cos(h)),
-    new THREE.Vector3(1, 1, 1));
-}
-const camera = { matrixWorld: compose([0, 1.6, 0], 0), projectionMatrix: new THREE.Matrix4().makePerspectiveFov(80, W / H, 0.005, 10000) };
+const { composeYaw: compose, perspective } = require('./mini_three.js');
+const camera = { matrixWorld: compose([0, 1.6, 0], 0), projectionMatrix: perspective(80, W / H, 0.005, 10000) };
 const object = { matrixWorld: compose([0, 1.5, -2], Number(yaw)) };
 comp.loadData(camera, object, null, scenePath, 100003).then((n) => {
   ok(n === Math.floor(fs.statSync(scenePath).size / 32), 'loadedVertexCount ' + n);
@@ -184,6 +180,36 @@ comp.loadData(camera, object, null, scenePath, 100003).then((n) => {
       try { native.multiSync(mh); } catch (e) { dead = e.code === 'GS_DESTROYED'; }
       ok(dead, 'multiDestroy');
     }
+    // ---- the REGISTERED component, driven the way A-Frame drives the reference's (index.js:8-23): registerComponent, init on an
+    // entity of a scene that has not loaded yet, the scene's 'loaded' event, then ticks; the host's frame sink gets the pixels
+    {
+      let def = null;
+      register({ registerComponent: (name, d) => { ok(name === 'gaussian_splatting', 'registered name'); def = d; } });
+      ok(def && def.schema === schema && ['init', 'tick', 'remove'].every((m) => typeof def[m] === 'function'), 'component definition');
+      const calls = [], listeners = {};
+      const renderer = { setPixelRatio: (r) => calls.push(['pr', r]), xr: { setFramebufferScaleFactor: (r) => calls.push(['xr', r]) },
+        getDrawingBufferSize: (v) => v.set(Number(W), Number(H)) };
+      const sceneEl = { renderer, hasLoaded: false, camera: { el: { components: { camera: { camera } } } },
+        addEventListener: (ev, fn) => { listeners[ev] = fn; } };
+      const inst = Object.create(def);
+      inst.data = { src: scenePath, cutoutEntity: null, pixelRatio: 1, xrPixelRatio: 0.5 };
+      inst.el = { sceneEl, object3D: object };
+      inst.init();
+      ok(calls.length === 2 && calls[0][0] === 'pr' && calls[0][1] === 1 && calls[1][0] === 'xr' && calls[1][1] === 0.5, 'init applies pixelRatio / xrPixelRatio (index.js:10-15)');
+      ok(typeof listeners.loaded === 'function' && inst.ready === null, 'init waits for the scene (index.js:17)');
+      inst.tick();                                                   // before the load: nothing to do, nothing thrown
+      const sunk = [];
+      inst.frameSink = (rgba, vp) => sunk.push([Uint8Array.from(rgba), vp]);
+      return listeners.loaded().then((count) => {
+        ok(count === n && inst.impl.camera === camera && inst.impl.object === object && inst.impl.renderer === renderer, 'loaded -> loadData(camera, object3D, renderer, src) (index.js:18)');
+        inst.tick();
+        ok(inst.impl.instanceCount === keep.length && same(inst.impl.sortedIndexes, keep), 'registered tick sorts (index.js:438)');
+        ok(sunk.length === 1 && sunk[0][1].width === Number(W) && same(sunk[0][0], keepImg), 'the frame sink receives the frame render() returns');
+        inst.remove();
+        ok(inst.impl === null, 'remove');
+      });
+    }
+  }).then(() => {
     comp.remove();
     let gone = false;
     try { comp.tick(); } catch (e) { gone = e.code === 'GS_DESTROYED'; }

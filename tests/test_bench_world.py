@@ -56,6 +56,22 @@ def test_sort_share_switched_on_for_long_scenes_only():
 
 
 def test_fallback_when_the_librarys_communicator_cannot_be_set_up():
-    # gs_comm_init fails on ONE rank: every rank switches to the plain exchange (strips gathered by torch.distributed), and says so
-    d, _ = run(2, 29634, "--steps", "4", "--warmup", "2", env={"BENCH_STANDIN_COMM_FAIL": "1"})
+    # gs_comm_init fails on ONE rank.  A scaling line measured through torch.distributed would measure PyTorch, not gs_comm.hip
+    # (VERDICT r3 #10): by default every rank gives up loudly and nothing is printed to stdout ...
+    e = dict(os.environ)
+    e.update({"BENCH_STANDIN_COMM_FAIL": "1"})
+    e.pop("GS_SPLAT_LIB", None); e.pop("GS_BENCH_TORCH_GATHER", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29633", DRIVER, "--gpus", "2", "--steps", "4", "--warmup", "2"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=e, cwd=ROOT)
+    assert p.returncode != 0 and not [l for l in p.stdout.splitlines() if l.strip().startswith("{")]
+    assert "could not be set up" in p.stderr and "GS_BENCH_TORCH_GATHER" in p.stderr
+    # ... and only GS_BENCH_TORCH_GATHER=1 runs the plain exchange (strips gathered by torch.distributed), labelled as such
+    d, _ = run(2, 29634, "--steps", "4", "--warmup", "2", env={"BENCH_STANDIN_COMM_FAIL": "1", "GS_BENCH_TORCH_GATHER": "1"})
     assert "FALLBACK" in d["config"]["parallelism"] and d["config"]["gathered_frame_equals_single_gpu_render"] is True and d["value"] > 0
+
+
+def test_first_contact_report_goes_to_stderr():
+    # rank 0 prints what a failed scaling run is diagnosed from before anything is timed: devices, peer-access matrix, the pieces
+    d, err = run(2, 29636, "--steps", "4", "--warmup", "2")
+    assert "[bench] first contact: world 2" in err and "pieces of a mono" in err

@@ -8,7 +8,7 @@ import pytest
 
 from conftest import GOLDEN, ROOT, pkg
 
-JS = os.path.join(ROOT, "aframe-gaussian-splatting_amd", "js")
+JS = os.path.join(ROOT, "tests", "js")                      # the node-side tests (the package's js/ holds the addon and the shim only)
 NODE = shutil.which("node")
 
 
@@ -58,3 +58,7 @@ def test_addon_worker_protocol_and_render_gpu(tmp_path):
         ctx.push_splat(rows); ctx.sort(cam["view"])
         want = ctx.render(capi.make_params(cam["gs_mv"], cam["gs_proj"], w, h, focal_=cam["focal"]))
     assert np.array_equal(img, want)
+    # ... and against the oracle itself (the node path's pixels were only HIP-vs-HIP)
+    cs, cc, _ = oracle.pack(rows)
+    ref, _, _ = oracle.render(cs, cc, idx, cam["gs_mv"].astype(np.float32), cam["gs_proj"].astype(np.float32), cam["focal"], w, h, want_f32=False)
+    assert int(np.abs(img.astype(int) - ref.astype(int)).max()) <= 1

@@ -1,16 +1,26 @@
 #!/bin/bash
-# usage (GPU box, repo root): tools/gpu_pmc.sh <tag>  -- two separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) over the
-# pipelined frame loop of the headline configuration (tools/stage_bench.py: adaptive share, 3 lanes x 2 frames per launch; its few
-# synchronous warm-up frames are < 10 % of the launches of a kernel)
+# usage (GPU box, repo root): [CONFIGS="c2 c1 c3 c5"] tools/gpu_pmc.sh <tag>  -- separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE and, for
+# c2, the VALU group) over the pipelined frame loop of each BASELINE configuration (tools/stage_bench.py --pmc-run: adaptive share, 3 lanes
+# x 2 frames per launch) -> gpurun_out/pmc_<tag>.md / .json (copied to profiles/ as r04_pmc_counters.md / pmc_counters.json)
 TAG=${1:-pmc}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-mkdir -p $R/gpurun_out
+D=$R/gpurun_out/pmc_$TAG; mkdir -p $D
 cd /tmp && export TMPDIR=/tmp
-for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 600 rocprofv3 --kernel-trace --pmc $c -d $R/gpurun_out/pmc_${TAG}_$c -o pmc -- python $R/tools/stage_bench.py --near 0 --depths 3 --frames 240 --batch 2 > $R/gpurun_out/pmc_${TAG}_$c.log 2>&1
-  echo "$c rc=$?"
+VALU="SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_LDS"
+for cfg in ${CONFIGS:-c2 c1 c3 c5}; do
+  case $cfg in
+    c2) A="--frames 240"; G="FETCH_SIZE WRITE_SIZE VALU";;
+    c1) A="--size 1280x720 --frames 240"; G="FETCH_SIZE WRITE_SIZE";;
+    c3) A="--splats 6291456 --cutout --split 1 --frames 120"; G="FETCH_SIZE WRITE_SIZE";;
+    c5) A="--splats 20971520 --size 3840x2160 --frames 96"; G="FETCH_SIZE WRITE_SIZE VALU";;
+  esac
+  for g in $G; do
+    if [ $g = VALU ]; then C="$VALU"; else C=$g; fi
+    timeout 900 rocprofv3 --kernel-trace --pmc $C -d $D/${cfg}_$g -o pmc -- python $R/tools/stage_bench.py --pmc-run --near 0 --depths 3 --batch 2 $A > $D/${cfg}_$g.log 2>&1
+    echo "$cfg $g rc=$? $(grep PMCRUN $D/${cfg}_$g.log | cut -c1-160)"
+  done
 done
 cd $R
-python tools/pmc_summary.py gpurun_out/pmc_${TAG}_FETCH_SIZE/pmc_results.db gpurun_out/pmc_${TAG}_WRITE_SIZE/pmc_results.db gpurun_out/pmc_$TAG.md gpurun_out/pmc_$TAG.json
-rm -rf gpurun_out/pmc_${TAG}_FETCH_SIZE gpurun_out/pmc_${TAG}_WRITE_SIZE
-head -12 gpurun_out/pmc_$TAG.md
+python tools/pmc_summary.py $D gpurun_out/pmc_$TAG.md gpurun_out/pmc_$TAG.json
+find $D -name "*.db" -delete
+head -30 gpurun_out/pmc_$TAG.md | cut -c1-220

@@ -26,6 +26,9 @@ ap.add_argument("--no-early-out", action="store_true", help="GS_RENDER_NO_EARLY_
 ap.add_argument("--strip", default=None, help="k/G: render only strip k of G tile-aligned column strips (what one of G GPUs does)")
 ap.add_argument("--sort-for", action="store_true", help="with --strip: gs_sort_for the strip instead of the full gs_sort")
 ap.add_argument("--binning", type=int, default=None, help="GS_OPT_BINNING (0 span lists, 1 pair records + radix passes)")
+ap.add_argument("--pmc-run", action="store_true", help="the run rocprofv3 --pmc passes profile (tools/gpu_pmc.sh): settle the share with synchronous frames, "
+                                                        "then ONLY queued frames of the orbit at the first depth; prints the frames queued and, untimed and "
+                                                        "synchronously afterwards, the list entries the blend evaluates per frame (GS_OPT_RECORD_STAGED = 2)")
 a = ap.parse_args()
 W, H = (int(v) for v in a.size.lower().split("x"))
 rows = synth.make_splat_rows_fast(a.splats) if a.splats >= (8 << 20) else synth.make_splat_rows(a.splats)
@@ -81,6 +84,25 @@ for k in range(0, 120, 4):                                   # buffers sized, sh
     if not a.sort_only:
         params[k].flags = 0
         ctx.render_device(params[k], None)
+if a.pmc_run:
+    import numpy as np
+    ctx.set_option(capi.OPT_PIPELINE_DEPTH, int(a.depths.split(",")[0]))
+    for rep in range(4):                                     # the second binning round is switched off after 16 clean frames
+        for k in range(0, 120, 3):
+            ctx.sort(cams[k]["view"], cams[k]["cutout"], want_indices=False); params[k].flags = 0; ctx.render_device(params[k], None)
+    go(24)
+    t = go(a.frames) or go(a.frames)
+    s = ctx.stats()
+    ctx.set_option(capi.OPT_RECORD_STAGED, 2)
+    ntl = ((x1 - x0 + 15) // 16) * ((H + 15) // 16)
+    ev = []
+    for k in range(0, 120, 5):
+        ctx.sort(cams[k]["view"], cams[k]["cutout"], want_indices=False); params[k].flags = 0; ctx.render_device(params[k], None)
+        ev.append(int(ctx.download(capi.BUF_TILE_STATS, ntl, np.uint32, 2)[:, 0].astype(np.int64).sum()))
+    print("PMCRUN frames_queued=%d frames_per_launch=%d fps=%.1f entries_evaluated_per_frame=%.1f pairs_last_frame=%d visible_last_frame=%d near_permille=%d" % (
+        24 + a.frames, a.batch, a.frames / t, float(np.mean(ev)), s["n_pairs"], s["n_visible"], s["near_permille"]), flush=True)
+    ctx.close()
+    sys.exit(0)
 for depth in (int(v) for v in a.depths.split(",")):
     ctx.set_option(capi.OPT_PIPELINE_DEPTH, depth)
     ctx.set_option(capi.OPT_PROFILE, 0)
