@@ -244,7 +244,17 @@ static int prof_advance(gs_ctx *ctx)
 }
 
 // after a stream sync: publish the counters of the last completed frame and react to pair-buffer overflow
-static int collect_status(gs_ctx *lane, bool *overflowed)
+// the share of splats binned first was too small for a frame drawn with `frac_used`: never again below 1.3 x that, now 1.5 x that
+static void share_raise(gs_ctx *ctx /* owner */, float frac_used)
+{
+    const float fl = frac_used * GS_NEAR_FLOOR_MULT > 1.0f ? 1.0f : frac_used * GS_NEAR_FLOOR_MULT;
+    if (fl > ctx->near_floor) ctx->near_floor = fl;
+    float nf = frac_used * 1.5f; if (nf < ctx->near_floor) nf = ctx->near_floor; if (nf > 1.0f) nf = 1.0f;
+    if (nf > ctx->near_frac) ctx->near_frac = nf;
+    ctx->clean_frames = 0; ctx->skip_hold = 32;
+}
+
+static int collect_status(gs_ctx *lane, bool *overflowed, bool *share_failed = nullptr)
 {
     gs_ctx *ctx = gs_root(lane);                                // the adaptive share is one state for all lanes ...
     const GsControl *c = lane->ctl_host;                        // ... fed by each lane's own counters
@@ -275,10 +285,10 @@ static int collect_status(gs_ctx *lane, bool *overflowed)
         lane->seen_unsat_events = c->unsat_events; lane->seen_acc_frames = c->acc_frames;
         if (lane->last_two_rounds) {
             if (events || c->round1_missed) {
-                const float fl = ctx->near_frac * GS_NEAR_FLOOR_MULT > 1.0f ? 1.0f : ctx->near_frac * GS_NEAR_FLOOR_MULT;
-                if (fl > ctx->near_floor) ctx->near_floor = fl;
-                float nf = ctx->near_frac * 1.5f; if (nf < ctx->near_floor) nf = ctx->near_floor; if (nf > 1.0f) nf = 1.0f;
-                ctx->near_frac = nf; ctx->clean_frames = 0; ctx->skip_hold = 32;
+                // the share proved too small: raised ONCE per collection by the caller (share_failed) -- the frames of all the lanes a
+                // gs_sync collects were drawn with the same share, and six lanes reporting the same failure used to multiply it by
+                // 1.5^6 and to leave the floor at 1.3 x 1.5^5 of the share that had really failed (a cold context ended up at 70 %)
+                if (share_failed) *share_failed = true;
             } else {
                 ctx->clean_frames += (uint32_t)(frames ? frames : 1);
                 // fast descent (x0.9) until a share has proved too small once, then a slow drift (x0.98) above the floor
@@ -348,12 +358,21 @@ static int prof_advance(gs_ctx *ctx);
 // them (gs_sort.hip: an exact rule on the sort key; the positions it fills equal the whole order's).  The request is made when
 // the sort is issued, from the state the render's uniforms will be made from; a render that turns out to need more of the
 // order (another share, a counting render, round 1 after all, gs_download of the order) sorts again in full first.
+// May a frame leave its second binning round out (and its sort be near-only)?  After 16 clean frames -- but not while the share is
+// still on its fast way DOWN from the default (no floor yet): that descent ends with a share that is too small, and with round 1
+// still launched the frame that finds it is completed by round 1 (an "event") instead of being flagged and drawn again with
+// everything queued behind it.  (A scene that never fails ends at the minimum share: skippable from there.)
+static inline bool round1_skippable(const gs_ctx *ctx /* owner */)
+{
+    return ctx->near_fixed_permille <= 0 && ctx->clean_frames >= 16 && !ctx->skip_hold && (ctx->near_floor > 0.0f || ctx->near_frac <= 0.0011f);
+}
+
 static uint32_t sort_near_request(const gs_ctx *ctx /* owner */)
 {
     if (!ctx->sort_near_opt || !ctx->renderable) return 0;
     if (ctx->sort_near_opt == 1 && ctx->n < ((size_t)1 << 22)) return 0;      // (short sorts are launch-bound: nothing to gain)
     if (ctx->wide_pairs || ctx->n > ((size_t)1 << 25)) return 0;
-    if (ctx->near_fixed_permille > 0 || ctx->clean_frames < 16 || ctx->skip_hold || ctx->near_frac >= 1.0f) return 0;
+    if (!round1_skippable(ctx) || ctx->near_frac >= 1.0f) return 0;
     const double nc = ceil((double)ctx->near_frac * (double)ctx->n);
     // (a cutout or a strip that keeps little more than the frame reads anyway: the histogram and the threshold would buy nothing)
     if (ctx->sort_near_opt == 1 && ctx->last_kept && nc * 2.0 > (double)ctx->last_kept) return 0;
@@ -1037,7 +1056,7 @@ int gs_fill_uniforms(gs_ctx *ctx /* owner: options, adaptive share, scene */, co
     u.has_depth = ctx->scene_depth != nullptr; u.has_scene_rgba = ctx->scene_rgba != nullptr;
     if ((u.has_depth || u.has_scene_rgba) && (ctx->scene_w != p->fb_width || ctx->scene_h != p->fb_height))
         FAIL(GS_E_BADARG, "scene inputs are %dx%d but the frame is %dx%d", ctx->scene_w, ctx->scene_h, p->fb_width, p->fb_height);
-    u.skip_round1 = (u.near_count != 0xFFFFFFFFu && ctx->near_fixed_permille <= 0 && ctx->clean_frames >= 16 && !ctx->skip_hold) ? 1u : 0u;
+    u.skip_round1 = (u.near_count != 0xFFFFFFFFu && round1_skippable(ctx)) ? 1u : 0u;
     return GS_OK;
 }
 
@@ -1124,8 +1143,10 @@ static int render_sync_on_lane(gs_ctx *ctx, const GsFrameUniforms &u, void *devi
             GS_HIP(hipStreamSynchronize(ctx->stream));
             ctx->ctl_host->round1_missed = 1;                      // seen by the adaptation below
         }
-        bool over = false;
-        TRY(collect_status(ctx, &over));
+        bool over = false, failed = false;
+        const float frac_used = gs_root(ctx)->near_frac;
+        TRY(collect_status(ctx, &over, &failed));
+        if (failed) share_raise(gs_root(ctx), frac_used);
         if (!over) break;
         if (attempt >= 2) FAIL(GS_E_OOM, "pair list keeps overflowing (%u pairs)", ctx->ctl_host->scan_total);
     }
@@ -1312,7 +1333,8 @@ GS_API int gs_sync(gs_ctx *ctx)
 {
     CHECK_CTX(ctx);
     GS_HIP(hipSetDevice(ctx->device));
-    bool any_missed = false, any_over = false;
+    bool any_missed = false, any_over = false, share_failed = false;
+    const float frac_used = ctx->near_frac;                       // what every frame queued since the last collection was drawn with
     // whatever way this call ends, the frames logged so far are not drawn again by a LATER gs_sync (their output buffers may be
     // gone by then): a failure below leaves no records behind
     struct LogGuard { gs_ctx *c; ~LogGuard() { for (int i = 0; i < GS_MAX_LANES; i++) if (c->lanes[i]) log_reset(c->lanes[i]); } } log_guard{ ctx };
@@ -1350,11 +1372,12 @@ GS_API int gs_sync(gs_ctx *ctx)
         if (missed) LANE_HIP(L, hipMemsetAsync(&L->ctl->round1_missed, 0, sizeof(uint32_t), L->stream));
         if (L->ctl_host->order_incomplete) LANE_HIP(L, hipMemsetAsync(&L->ctl->order_incomplete, 0, sizeof(uint32_t), L->stream));
         bool over = false;
-        TRY(collect_status(L, &over));
+        TRY(collect_status(L, &over, &share_failed));
         any_missed |= missed; any_over |= over;
         if (missed || over) bad_unit[i % GS_MAX_PRIMARY] = true;
         if (over && L->ctl_host->max_total > want) want = L->ctl_host->max_total;
     }
+    if (share_failed) share_raise(ctx, frac_used);               // (once, whatever the number of lanes that saw it)
     if (any_over)                                                // one retry for all lanes: each gets room for the largest demand seen
         for (int i = 0; i < GS_MAX_LANES; i++)
             if (ctx->lanes[i] && ctx->lanes[i]->pair_cap)
