@@ -496,6 +496,9 @@ static void lane_worker_main(gs_ctx *L)
                 L->twin->inflight++;                               // the second view runs on the twin's scratch: a drain of the twin waits for it
             }
         }
+        // (w->rc is the caller's to reset under the mutex -- lane_drain of the lane OR of its twin, which shares this thread -- so the
+        // launches below decide on a copy taken while the mutex is still held: ThreadSanitizer, round 4)
+        const int prior_rc = w->rc;
         lk.unlock();
         // (a call is run even after a failure: the gather of a frame must be issued on every rank, or the others wait for it)
         if (stereo) rc = run_two_views(L, L->twin, c, pc[0], pc[1]);
@@ -506,8 +509,8 @@ static void lane_worker_main(gs_ctx *L)
                 if (rc == GS_OK) rc = g0 != GS_OK ? g0 : g1;
             }
         }
-        else if (c.type == 2) { const int r2 = c.call(T); if (w->rc == GS_OK) rc = r2; }
-        else if (w->rc == GS_OK) rc = c.type == 0 ? gs_run_sort(T, c.view, c.has_cutout ? c.cutout : nullptr, c.has_strip ? &c.strip : nullptr, c.near_req)
+        else if (c.type == 2) { const int r2 = c.call(T); if (prior_rc == GS_OK) rc = r2; }
+        else if (prior_rc == GS_OK) rc = c.type == 0 ? gs_run_sort(T, c.view, c.has_cutout ? c.cutout : nullptr, c.has_strip ? &c.strip : nullptr, c.near_req)
                                                   : render_async_on_lane(T, c.u, c.device_rgba, c.host_rgba, c.stride);
         lk.lock();
         if (rc != GS_OK && w->rc == GS_OK) { w->rc = rc; memcpy(w->err, scratch, sizeof w->err); }

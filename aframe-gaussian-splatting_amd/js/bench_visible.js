@@ -1,7 +1,9 @@
 // node bench_visible.js <scene.splat> <width> <height> [frames = 240] [queueDepth = 48]
 // The frame rate a JavaScript caller of the component sees at a given size (bench.py's `js_visible`, north_star: "returns an RGBA
 // framebuffer to JavaScript"): a moving entity (a new pose every frame, index.js:438-455), every frame = sort + draw.
-//   sync    comp.tick(); comp.render(camera, viewport)            one frame at a time into the component's page-locked frame
+//   sync    comp.frame(camera, viewport)                          one frame at a time into the component's page-locked frame, the order
+//           stays on the GPU;  tick_render = comp.tick(); comp.render(...): the reference's shape -- tick hands the index list back
+//           to JavaScript (index.js:201-207), 3 MB per frame at 1 M splats
 //   queued  comp.frameQueued(camera, viewport) ... comp.sync()    frames queued on the pipeline lanes, each copied behind its
 //           kernels into one of `queueDepth` page-locked frames; sync() every queueDepth frames
 // Prints ONE JSON line.
@@ -28,6 +30,10 @@ comp.loadData(camera, object, null, scenePath).then((n) => {
   for (let i = 0; i < 120; i++) { pose(i); comp.tick(); comp.render(camera, vp); }              // buffers sized, share settled
   let t0 = process.hrtime.bigint(), sum = 0;
   for (let i = 0; i < frames; i++) { pose(i); comp.tick(); const img = comp.render(camera, vp); sum += img[(i * 4099) % img.length]; }
+  const tickSec = Number(process.hrtime.bigint() - t0) / 1e9;
+  for (let i = 0; i < 24; i++) { pose(i); comp.frame(camera, vp); }
+  t0 = process.hrtime.bigint();
+  for (let i = 0; i < frames; i++) { pose(i); const img = comp.frame(camera, vp); sum += img[(i * 4099) % img.length]; }
   const syncSec = Number(process.hrtime.bigint() - t0) / 1e9;
   let retries = 0;
   for (let i = 0; i < 2 * depth; i++) { pose(i); comp.frameQueued(camera, vp); if (i % depth === depth - 1) retries += trySync(); }
@@ -40,6 +46,7 @@ comp.loadData(camera, object, null, scenePath).then((n) => {
   const st = comp.stats();
   console.log(JSON.stringify({ splats: n, width: W, height: H, frames, queue_depth: depth, node: process.version,
     fps_sync: +(frames / syncSec).toFixed(1), ms_per_frame_sync: +(syncSec / frames * 1e3).toFixed(4),
+    fps_tick_render: +(frames / tickSec).toFixed(1), ms_per_frame_tick_render: +(tickSec / frames * 1e3).toFixed(4),
     fps_queued: +(frames / qSec).toFixed(1), queued_GBps: +(frames / qSec * W * H * 4 / 1e9).toFixed(2),
     sync_retries: retries, frames_redrawn_by_sync: st.retriedFrames !== undefined ? st.retriedFrames : (st.retried_frames || 0), checksum: sum }));
   comp.remove();

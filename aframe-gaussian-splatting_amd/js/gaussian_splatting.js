@@ -148,6 +148,16 @@ class GaussianSplatting {
     return native.renderInto(this.handle, p, this._frame(p));
   }
 
+  // One whole frame, synchronously, for a caller that wants pixels and not the index list: this frame's sort (the order stays on
+  // the GPU -- tick() hands sortedIndexes back to JavaScript like the reference's worker does, ~3 MB per tick at 1 M splats) and
+  // the draw.  Returns the frame like render().
+  frame(camera, viewport, options) {
+    const u = this._tickUniforms(camera);
+    native.sort(this.handle, u.view, u.cutout, false);
+    const p = this._renderParams(camera, viewport, options);
+    return native.renderInto(this.handle, p, this._frame(p));
+  }
+
   // The same draw off the JS thread (napi_async_work): resolves to the frame.  While it is in flight the component's
   // other calls throw GS_BUSY (a context is single-caller, like the reference's single-flight worker).
   renderAsync(camera, viewport, options) {

@@ -921,8 +921,9 @@ def js_visible(rows, w, h):
             rep = json.loads(r.stdout.strip().splitlines()[-1])
         except Exception as e:
             return {"error": (str(e) + " " + (r.stderr[-300:] if "r" in dir() else ""))[:400]}
-    rep["note"] = ("timed in JavaScript (process.hrtime), a new pose every frame: fps_sync = comp.tick() + comp.render() into the component's page-locked "
-                   "frame; fps_queued = comp.frameQueued() into a ring of 48 page-locked frames, comp.sync() every 48")
+    rep["note"] = ("timed in JavaScript (process.hrtime), a new pose every frame: fps_sync = comp.frame() -- sort (order kept on the GPU) + draw into the "
+                   "component's page-locked frame; fps_tick_render = comp.tick() + comp.render(), tick handing the index list back to JavaScript "
+                   "as the reference's worker does; fps_queued = comp.frameQueued() into a ring of 48 page-locked frames, comp.sync() every 48")
     return rep
 
 

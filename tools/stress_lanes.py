@@ -43,7 +43,8 @@ while time.time() - t0 < float(os.environ.get("STRESS_SECONDS", "20")):
         elif r < 0.93: c.set_option(capi.OPT_PIPELINE_DEPTH, int(g.integers(1, 5)))
         elif r < 0.95: c.set_option(capi.OPT_ENQUEUE_THREADS, int(g.integers(0, 2)))
         elif r < 0.96: c.set_option(capi.OPT_PROFILE, int(g.integers(0, 3)))
-        elif r < 0.97: c.set_option(capi.OPT_FRAME_BATCH, int(g.integers(1, 3)))
+        elif r < 0.966: c.set_option(capi.OPT_FRAME_BATCH, int(g.integers(1, 3)))
+        elif r < 0.97: c.set_option(capi.OPT_BINNING, int(g.integers(0, 2)))      # span lists <-> pair records (the reference context keeps the default)
         elif r < 0.972 and NEAR: c.set_option(capi.OPT_SORT_NEAR, int(g.integers(0, 3)) or 2)
         elif r < 0.985 and n < rows.shape[0]:
             m = min(rows.shape[0], n + int(g.integers(1, 9000)))
