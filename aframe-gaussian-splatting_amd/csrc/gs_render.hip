@@ -623,6 +623,40 @@ __device__ __forceinline__ unsigned long long block_sum64(unsigned long long v, 
     return s_p[0] + s_p[1] + s_p[2] + s_p[3];
 }
 
+// Prefix sums over the (at most 256) tile rows of a round's (runs, tiles) totals, by the workgroup's FIRST wavefront alone (four
+// rows per lane, one shuffle scan per column): first run / first tile of every row, and (ITEMS) the first k_lists item of every
+// row.  Every workgroup of k_emit_runs and k_lists needs them; as four workgroup-wide scans they were a quarter of k_lists'
+// instructions.  s_*[r] = sum over the rows before r, s_*[tiles_y .. 256] = the totals.  Returns the tiles of all rows (64 bits).
+template <bool ITEMS>
+__device__ __forceinline__ unsigned long long row_prefixes(const uint2 *__restrict__ row_tot, uint32_t tiles_y, uint32_t *s_rrun, uint32_t *s_rpair,
+                                                           uint32_t *s_item, unsigned long long *s_total)
+{
+    if (threadIdx.x < 64) {
+        const uint32_t l = threadIdx.x;
+        uint2 rt[4];
+#pragma unroll
+        for (uint32_t k = 0; k < 4; k++) rt[k] = 4u * l + k < tiles_y ? row_tot[4u * l + k] : make_uint2(0u, 0u);
+        uint32_t sr = 0, sp = 0, si = 0, ni[4];
+        unsigned long long sp64 = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < 4; k++) {
+            ni[k] = (ITEMS && 4u * l + k < tiles_y) ? max(1u, (rt[k].x + list_seg_len(rt[k].x) - 1u) / list_seg_len(rt[k].x)) : 0u;   // (every row has an item: its ranges are written)
+            sr += rt[k].x; sp += rt[k].y; sp64 += rt[k].y; si += ni[k];
+        }
+        uint32_t er = wave_incl_scan_u32(sr, (int)l) - sr, ep = wave_incl_scan_u32(sp, (int)l) - sp, ei = ITEMS ? wave_incl_scan_u32(si, (int)l) - si : 0u;
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) sp64 += ((unsigned long long)__shfl_xor((uint32_t)(sp64 >> 32), m, 64) << 32) + __shfl_xor((uint32_t)sp64, m, 64);
+#pragma unroll
+        for (uint32_t k = 0; k < 4; k++) {
+            s_rrun[4u * l + k] = er; s_rpair[4u * l + k] = ep; if (ITEMS) s_item[4u * l + k] = ei;
+            er += rt[k].x; ep += rt[k].y; ei += ni[k];
+        }
+        if (l == 63) { s_rrun[GS_BLOCK] = er; s_rpair[GS_BLOCK] = ep; if (ITEMS) s_item[GS_BLOCK] = ei; *s_total = sp64; }
+    }
+    __syncthreads();
+    return *s_total;
+}
+
 template <int ROUND>
 __device__ __forceinline__ void k_row_scan_body(uint32_t *__restrict__ row_cnt, uint2 *__restrict__ row_tot, const GsControl *ctl,
                                                 uint32_t near_count, uint32_t rc_stride, uint32_t tiles_y, uint32_t *__restrict__ mask,
@@ -673,17 +707,14 @@ __device__ __forceinline__ void k_emit_runs_body(const gsm::Projected *__restric
     __shared__ float s_rec[GS_BLOCK][6];
     __shared__ uint32_t s_rows[GS_BLOCK], s_t[GS_BLOCK];            // queued splats: first | last << 16 tile row, thread (= position in the chunk)
     __shared__ unsigned long long s_m[GS_BLOCK][4];                 // per tile row: the chunk's positions with a run there
-    __shared__ uint32_t s_rowrun[GS_BLOCK], s_base[GS_BLOCK];
-    __shared__ uint32_t s_w[4], s_nbig, s_nmid;
+    __shared__ uint32_t s_rowrun[GS_BLOCK + 1], s_rowpair[GS_BLOCK + 1], s_base[GS_BLOCK];
+    __shared__ uint32_t s_nbig, s_nmid;
     __shared__ unsigned long long s_p[4];
     const uint32_t tid = threadIdx.x;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const uint32_t tiles_y = (uint32_t)u.tiles_y;
     {
-        const uint2 rt = tid < tiles_y ? row_tot[tid] : make_uint2(0u, 0u);
-        uint32_t tr;
-        s_rowrun[tid] = block_exscan(rt.x, s_w, lane, w, tr);      // first run of every tile row
-        const unsigned long long I = block_sum64(rt.y, s_p, lane, w);
+        const unsigned long long I = row_prefixes<false>(row_tot, tiles_y, s_rowrun, s_rowpair, nullptr, s_p);   // first run of every tile row
         // a round that does not fit the buffers (or follows one of this frame that did not) bins nothing: k_lists flags the frame
         if (I > pair_cap || (ROUND == 1 && ctl->pair_overflow)) return;
     }
@@ -799,15 +830,9 @@ __device__ __forceinline__ void k_lists_body(const uint32_t *__restrict__ run_ge
     const uint32_t tid = threadIdx.x;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const uint32_t tiles_x = (uint32_t)u.tiles_x, tiles_y = (uint32_t)u.tiles_y;
-    const uint2 rt = tid < tiles_y ? row_tot[tid] : make_uint2(0u, 0u);
-    uint32_t TR, TP, NI;
-    const uint32_t exr = block_exscan(rt.x, s_w, lane, w, TR);
-    const uint32_t exp_ = block_exscan(rt.y, s_w, lane, w, TP);      // (meaningful when the round fits: I <= pair_cap < 2^32)
-    const unsigned long long I = block_sum64(rt.y, s_p, lane, w);
-    const uint32_t nseg = tid < tiles_y ? max(1u, (rt.x + list_seg_len(rt.x) - 1u) / list_seg_len(rt.x)) : 0u;   // (every row has an item: its ranges are written)
-    const uint32_t exi = block_exscan(nseg, s_w, lane, w, NI);
-    if (tid == 0) { s_rrun[0] = 0; s_rpair[0] = 0; s_item[0] = 0; }
-    s_rrun[tid + 1] = exr + rt.x; s_rpair[tid + 1] = exp_ + rt.y; s_item[tid + 1] = exi + nseg;
+    // s_rrun / s_rpair / s_item [r]: runs, tiles (meaningful when the round fits: I <= pair_cap < 2^32), items before tile row r
+    const unsigned long long I = row_prefixes<true>(row_tot, tiles_y, s_rrun, s_rpair, s_item, s_p);
+    const uint32_t NI = s_item[GS_BLOCK];
     const bool overflow = I > pair_cap || (ROUND == 1 && ctl->pair_overflow);
     uint32_t j_lo, j_hi;
     round_range<ROUND>(ctl, u.near_count, j_lo, j_hi);

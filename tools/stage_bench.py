@@ -25,6 +25,7 @@ ap.add_argument("--opacity-div", type=int, default=1, help="divide every splat's
 ap.add_argument("--no-early-out", action="store_true", help="GS_RENDER_NO_EARLY_OUT: every fragment blended")
 ap.add_argument("--strip", default=None, help="k/G: render only strip k of G tile-aligned column strips (what one of G GPUs does)")
 ap.add_argument("--sort-for", action="store_true", help="with --strip: gs_sort_for the strip instead of the full gs_sort")
+ap.add_argument("--outside", action="store_true", help="the camera OUTSIDE the cloud, 3 sigma from its centre (synth.outside_cloud_camera)")
 ap.add_argument("--binning", type=int, default=None, help="GS_OPT_BINNING (0 span lists, 1 pair records + radix passes)")
 ap.add_argument("--pmc-run", action="store_true", help="the run rocprofv3 --pmc passes profile (tools/gpu_pmc.sh): settle the share with synchronous frames, "
                                                         "then ONLY queued frames of the orbit at the first depth; prints the frames queued and, untimed and "
@@ -34,7 +35,7 @@ W, H = (int(v) for v in a.size.lower().split("x"))
 rows = synth.make_splat_rows_fast(a.splats) if a.splats >= (8 << 20) else synth.make_splat_rows(a.splats)
 if a.opacity_div > 1:
     rows = rows.reshape(-1, 32).copy(); rows[:, 27] = rows[:, 27] // a.opacity_div; rows = rows.reshape(-1)
-pose = synth.cutout_demo_camera if a.cutout else synth.index_html_camera
+pose = synth.cutout_demo_camera if a.cutout else (synth.outside_cloud_camera if a.outside else synth.index_html_camera)
 cams = [pose(W, H, 3.0 * i, capi=capi) for i in range(120)]
 x0, x1 = 0, W
 if a.strip:
