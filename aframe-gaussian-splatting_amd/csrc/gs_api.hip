@@ -267,6 +267,7 @@ static int collect_status(gs_ctx *lane, bool *overflowed, bool *share_failed = n
         const uint64_t vh = (uint64_t)c->n_visible + c->n_visible / 8u + 4096ull;
         __atomic_store_n(&ctx->vis_hint, vh > 0x7FFFFFFFull ? 0u : (uint32_t)vh, __ATOMIC_RELAXED);
     }
+    if (c->n_pairs_frame) __atomic_store_n(&ctx->run_hint, c->n_runs, __ATOMIC_RELAXED);
     if (c->n_pairs_frame) {                                     // sizing hint for the next frames' pair sort (any lane's worker may read it)
         const uint64_t h = (uint64_t)c->n_pairs_frame + c->n_pairs_frame / 4 + GS_CHUNK_L;
         __atomic_store_n(&ctx->pair_hint, h > 0xFFFFFFFFull ? 0u : (uint32_t)h, __ATOMIC_RELAXED);
@@ -607,7 +608,7 @@ static void free_frame_resources(gs_ctx *c)
     dev_free(c->depth); dev_free(c->key_a); dev_free(c->kv_b); dev_free(c->val_a);
     dev_free(c->hist); dev_free(c->radix_aux); dev_free(c->spine); dev_free(c->spine_vis); dev_free(c->projc); dev_free(c->zwinc);
     dev_free(c->proj); dev_free(c->rect); dev_free(c->tile_count); dev_free(c->zwin);
-    dev_free(c->pair_a); dev_free(c->pair_b); dev_free(c->emit_extra); dev_free(c->row_cnt); dev_free(c->row_tot);
+    dev_free(c->pair_a); dev_free(c->pair_b); dev_free(c->emit_extra); dev_free(c->row_cnt); dev_free(c->row_tot); dev_free(c->seg_diff);
     gs_comm_free_lane(c);
     dev_free(c->tile_range); dev_free(c->fb); dev_free(c->ctl); dev_free(c->state); dev_free(c->unsat_mask);
     dev_free(c->part_min); dev_free(c->part_max); dev_free(c->part_cnt); dev_free(c->part_valid); dev_free(c->part_vis); dev_free(c->dhist[0]); dev_free(c->dhist[1]);
@@ -787,7 +788,7 @@ GS_API int gs_clear(gs_ctx *ctx)
     CHECK_CTX(ctx);
     GS_HIP(hipSetDevice(ctx->device));
     TRY(drain_all(ctx));
-    ctx->n = 0; ctx->renderable = true; ctx->pair_hint = 0; ctx->vis_hint = 0;
+    ctx->n = 0; ctx->renderable = true; ctx->pair_hint = 0; ctx->vis_hint = 0; ctx->run_hint = 0;
     ctx->near_frac = 0.25f; ctx->near_floor = 0.0f; ctx->clean_frames = 0; ctx->skip_hold = 0; ctx->single_round_frames = 0; ctx->last_kept = 0;
     ctx->near_stash_off = false;
     for (int i = 0; i < GS_MAX_LANES; i++) {

@@ -67,7 +67,8 @@ struct GsControl {
     uint32_t n_pairs_frame;        // I summed over the rounds of the frame
     uint32_t want_frame;           // pair demand of the frame so far (counts rounds that overflowed, too)
     uint32_t unsat_events;         // frames whose round 0 left tiles unsaturated (monotonic)
-    uint32_t n_emit_extra, pad_emit; // k_emit work items beyond one per chunk (k_pairs_check -> k_emit of the same round)
+    uint32_t n_emit_extra;         // k_emit work items beyond one per chunk (k_pairs_check -> k_emit of the same round)
+    uint32_t n_runs;               // span-list binning: tile-row runs of the frame (k_lists; the host's hint for k_seg_count)
     uint32_t round1_missed;        // sticky: round 1 was skipped optimistically but a tile needed it (host clears)
     uint32_t vis_total;            // visible splats of the current binning round (k_pairs_check)
     uint32_t near_overflow;        // sticky: a near-only sort's survivors did not fit a chunk's stash (host clears; the frame is also
@@ -179,8 +180,10 @@ struct gs_ctx {
     uint2 *pair_a, *pair_b; size_t pair_cap;   // (tile id, sorted position) records, ping-pong
     uint32_t blend_split_min;               // owner: GS_OPT_BLEND_SPLIT
     uint32_t pair_hint;                     // owner: pairs a frame is expected to bin (1.25 x the last collected frame's; 0 = unknown)
+    uint32_t run_hint;                      // owner: tile-row runs of the last collected frame (span-list binning; 0 = unknown)
     uint32_t *row_cnt; size_t row_cnt_cap;  // span-list binning: [tile row][256-splat chunk] runs | tiles << 9 (k_project) -> runs before the chunk (k_row_scan)
     uint2 *row_tot; size_t row_tot_cap;     // ... and per tile row (runs, tiles) of the round
+    int *seg_diff;                          // ... and per k_lists item (tile row, segment of its runs) the segment's difference array over the tile columns
     int bin_mode;                           // owner: GS_OPT_BINNING
     uint2 *tile_range; size_t tile_cap;     // per tile [start,end) into the sorted pair list
     uint8_t *fb; size_t fb_cap;             // RGBA8 strip

@@ -588,22 +588,29 @@ __global__ __launch_bounds__(GS_BLOCK) void k_tile_ranges(const void *__restrict
 // covers column x.  A column's appends happen in run order, i.e. in draw order: the lists come out stable without a single key
 // being sorted, and there are no (tile, splat) records before the lists themselves.  Against the pair records + two stable radix
 // passes of rounds 1-3 (hist / scan / scatter twice + emit + ranges = 8 launches, ~20 bytes of traffic per pair) a binning round
-// is 3 launches, and the work is per RUN (a tenth of the pairs in the headline scene), not per pair.
+// is 4 launches, and the work is per RUN (a tenth of the pairs in the headline scene), not per pair.
 //   k_project<.., RUNS>  also counts, per 256-splat chunk and tile row, the chunk's runs and tiles:        row_cnt[row][chunk]
 //   k_row_scan           one workgroup per tile row: row_cnt[row][.] <- runs before the chunk; (runs, tiles) of the row: row_tot
 //   k_emit_runs          per chunk: the runs again, each written to ITS ROW's segment of the run arrays at
 //                        start(row) + runs before the chunk + rank inside the chunk.  The rank -- how many earlier positions of
 //                        the chunk touch the same row -- comes from a 256-bit occupancy word per tile row that the chunk's
 //                        threads OR their bit into: order-free to build, a popcount to read
-//   k_lists              item = (tile row, segment of its runs): per-column counts of the runs BEFORE the segment and of ALL the
-//                        row's runs by difference arrays in LDS (+1 at the run's first column, -1 behind its last, prefix sum;
-//                        O(runs), each item recounts its row: a row holds a few thousand runs) -> the tiles' ranges and each
-//                        column's write cursor; then the walk.  Also the round's bookkeeping in the control block (what
-//                        k_pairs_check does for the pair records): block 0.
+//   k_seg_count          item = (tile row, segment of its runs): the segment's difference array over the tile columns (+1 at a run's
+//                        first column, -1 behind its last), one row of ints per item
+//   k_lists              same items: per-column counts of the runs BEFORE the segment and of ALL the row's runs from the rows of
+//                        k_seg_count (added up, one prefix sum) -> the tiles' ranges and each column's write cursor; then the
+//                        walk.  Also the round's bookkeeping in the control block (what k_pairs_check does for the pair
+//                        records): block 0.
 // ROUND 1 counts, ranks and appends only tiles whose bit is set in the unsaturated-tile mask (a run stays one record; its
 // columns are filtered by the walk).  Tile lists hold the sorted positions themselves (pair_jbits = 32).
 #ifndef GS_LIST_SEG
 #define GS_LIST_SEG 256u            // runs a k_lists item walks at least ...
+#endif
+#ifndef GS_LIST_LOADS
+#define GS_LIST_LOADS 16u           // run records a thread of k_seg_count has in flight
+#endif
+#ifndef GS_SEGC_RUNS_PER_ROW
+#define GS_SEGC_RUNS_PER_ROW 4096u  // frames expected to hold more runs than this per tile row count their segments in a launch of their own (k_seg_count)
 #endif
 #define GS_LIST_SEGS 16u            // ... and a tile row is cut into at most this many items (long rows: longer walks, not more recounts)
 __device__ __forceinline__ uint32_t list_seg_len(uint32_t nr)
@@ -793,10 +800,61 @@ __global__ __launch_bounds__(GS_BLOCK) void k_emit_runs(const gsm::Projected *__
     k_emit_runs_body<ROUND>(proj, rect, tile_count, row_cnt, row_tot, u, run_geom, run_ref, mask, ctl, pair_cap);
 }
 
+// Per item of k_lists -- (tile row, segment of the row's runs) -- the difference array of the segment's runs over the tile columns
+// (+1 at a run's first column, -1 behind its last), written as one row of 256 ints.  k_lists then needs no pass over the row's
+// runs to know how many runs cover a column before its segment and in the whole row: it adds up the rows of the segments (at most
+// GS_LIST_SEGS loads per thread, all in flight) and scans once.  With every k_lists item counting its whole tile row itself the
+// work was rows x segments x runs: fine for the headline pose (3 000 runs per row), not for frames of many small splats (the 6 M
+// cut-out pose: 17 000 runs per row and 16 segments -- k_lists 55 us, more than the two radix passes it replaced).
+template <int ROUND>
+__device__ __forceinline__ void k_seg_count_body(const uint32_t *__restrict__ run_geom, const uint2 *__restrict__ row_tot, int *__restrict__ seg_diff,
+                                                 const GsFrameUniforms &u, const GsControl *ctl, uint32_t pair_cap)
+{
+    GS_CHAIN_PRIO();
+    __shared__ uint32_t s_rrun[GS_BLOCK + 1], s_rpair[GS_BLOCK + 1], s_item[GS_BLOCK + 1];
+    __shared__ int s_d[GS_BLOCK + 1];
+    __shared__ unsigned long long s_p[4];
+    const uint32_t tid = threadIdx.x, tiles_y = (uint32_t)u.tiles_y;
+    const unsigned long long I = row_prefixes<true>(row_tot, tiles_y, s_rrun, s_rpair, s_item, s_p);
+    if (I > pair_cap || (ROUND == 1 && ctl->pair_overflow)) return;  // (k_lists writes empty ranges and reads none of this)
+    const uint32_t NI = s_item[GS_BLOCK];
+    for (uint32_t item = blockIdx.x; item < NI; item += gridDim.x) {
+        uint32_t row = 0;
+#pragma unroll
+        for (uint32_t step = GS_BLOCK / 2; step; step >>= 1) { const uint32_t t = row + step; if (t < tiles_y && s_item[t] <= item) row = t; }
+        const uint32_t seg = item - s_item[row];
+        const uint32_t rb = s_rrun[row], nr = s_rrun[row + 1] - rb;
+        const uint32_t S = list_seg_len(nr), s0 = seg * S, s1 = min(nr, s0 + S);
+        s_d[tid] = 0;
+        if (tid == 0) s_d[GS_BLOCK] = 0;
+        __syncthreads();
+        for (uint32_t i0 = s0; i0 < s1; i0 += GS_LIST_LOADS * GS_BLOCK) {
+            uint32_t g[GS_LIST_LOADS];
+#pragma unroll
+            for (uint32_t k = 0; k < GS_LIST_LOADS; k++) { const uint32_t i = i0 + k * GS_BLOCK + tid; g[k] = i < s1 ? run_geom[rb + i] : 0u; }
+#pragma unroll
+            for (uint32_t k = 0; k < GS_LIST_LOADS; k++) {
+                const uint32_t i = i0 + k * GS_BLOCK + tid;
+                if (i < s1) { const uint32_t t0 = g[k] & 0xFFFFu; atomicAdd(&s_d[t0], 1); atomicSub(&s_d[t0 + (g[k] >> 16)], 1); }
+            }
+        }
+        __syncthreads();
+        seg_diff[(size_t)item * GS_BLOCK + tid] = s_d[tid];          // (a -1 at column 256 lies behind every column)
+        __syncthreads();
+    }
+}
+
+template <int ROUND>
+__global__ __launch_bounds__(GS_BLOCK) void k_seg_count(const uint32_t *__restrict__ run_geom, const uint2 *__restrict__ row_tot, int *__restrict__ seg_diff,
+                                                        GsFrameUniforms u, const GsControl *ctl, uint32_t pair_cap)
+{
+    k_seg_count_body<ROUND>(run_geom, row_tot, seg_diff, u, ctl, pair_cap);
+}
+
 // The tile lists of one segment of one tile row's runs (see above); block 0 also keeps the round's books.
-// Per item: (1) the row's runs, all loads in flight, into ONE difference array of 64-bit words -- low half: every run, high half:
-// the runs before the segment (a prefix sum of such words is exact: the sums it passes through are counts, never negative) --
-// and one 64-bit scan over the columns gives both counts per column; (2) the segment in batches of 256 runs: every run ORs its
+// Per item: (1) the difference arrays of the row's segments (k_seg_count) added up into ONE array of 64-bit words -- low half: every
+// segment, high half: the segments before this one -- and one 64-bit scan over the columns gives both counts per column (the sums
+// such a scan passes through are counts, never negative: exact); (2) the segment in batches of 256 runs: every run ORs its
 // bit into the occupancy word of each column it covers (the words of a column are 256 bits: which runs of the batch cover it),
 // and the column's thread appends the batch's runs in bit order -- a column's thread takes as many steps as runs cover it, not
 // as many as the batch has.
@@ -810,18 +868,15 @@ __device__ __forceinline__ unsigned long long wave_incl_scan_u64(unsigned long l
     return v;
 }
 
-#ifndef GS_LIST_LOADS
-#define GS_LIST_LOADS 16u           // run records a thread of k_lists has in flight while it counts its row
-#endif
-template <int ROUND>
+template <int ROUND, bool SEGC>
 __device__ __forceinline__ void k_lists_body(const uint32_t *__restrict__ run_geom, const uint32_t *__restrict__ run_ref,
-                                             const uint2 *__restrict__ row_tot, uint32_t *__restrict__ lists, uint2 *__restrict__ tile_range,
+                                             const uint2 *__restrict__ row_tot, const int *__restrict__ seg_diff, uint32_t *__restrict__ lists, uint2 *__restrict__ tile_range,
                                              const GsFrameUniforms &u, const uint32_t *__restrict__ mask, GsControl *ctl, uint32_t pair_cap,
                                              const uint32_t *__restrict__ part_vis, uint32_t nparts, int last_round)
 {
     GS_CHAIN_PRIO();
     __shared__ uint32_t s_rrun[GS_BLOCK + 1], s_rpair[GS_BLOCK + 1], s_item[GS_BLOCK + 1];   // prefix sums over the tile rows: runs, tiles, items
-    __shared__ unsigned long long s_d[GS_BLOCK + 1];                // difference array over the tile columns: all runs | runs before the segment << 32
+    __shared__ unsigned long long s_d[GS_BLOCK + 1];                // difference array over the tile columns: all runs of the row | runs before the segment << 32
     __shared__ __attribute__((aligned(16))) unsigned long long s_m[GS_BLOCK][4];                 // per tile column: the runs of the batch that cover it
     __shared__ uint32_t s_r[GS_BLOCK];                              // the batch's sorted positions
     __shared__ uint32_t s_off[GS_BLOCK], s_on[GS_BLOCK];            // per tile column: write cursor at the segment's start, column taken (ROUND 1: unsaturated)
@@ -849,6 +904,7 @@ __device__ __forceinline__ void k_lists_body(const uint32_t *__restrict__ run_ge
         if (tid == 0) {
             const uint32_t total = I > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)I;
             ctl->vis_total = 0; ctl->n_emit_extra = 0;
+            ctl->n_runs = (ROUND == 0 ? 0u : ctl->n_runs) + s_rrun[GS_BLOCK];   // runs of the frame (a hint for the next frames: k_seg_count or not)
             if (ROUND == 0) { ctl->n_visible = 0; ctl->n_pairs_frame = 0; ctl->want_frame = 0; }
             else { ctl->unsat_round0 = ctl->unsat_count; if (ctl->unsat_count) ctl->unsat_events += 1; }
             ctl->j_lo = j_lo; ctl->j_hi = j_hi;                      // blend<1> returns at once when nothing was left for round 1
@@ -873,20 +929,36 @@ __device__ __forceinline__ void k_lists_body(const uint32_t *__restrict__ run_ge
         const uint32_t seg = item - s_item[row];
         const uint32_t rb = s_rrun[row], nr = overflow ? 0u : s_rrun[row + 1] - rb, pb = s_rpair[row];
         const uint32_t S = list_seg_len(nr), s0 = seg * S, s1 = min(nr, s0 + S);
-        s_d[tid] = 0ull;
-        if (tid == 0) s_d[GS_BLOCK] = 0ull;
-        __syncthreads();
-        for (uint32_t i0 = 0; i0 < nr; i0 += GS_LIST_LOADS * GS_BLOCK) {
-            uint32_t g[GS_LIST_LOADS];
+        if (SEGC) {
+            // this column's difference-array entries of the row's segments (k_seg_count), all loads in flight: low half = every
+            // segment, high half = the segments before this one (a prefix sum of such words is exact: the sums it passes through
+            // are counts, never negative)
+            const uint32_t it0 = s_item[row], nsg = overflow ? 0u : s_item[row + 1] - it0;
+            int dd[GS_LIST_SEGS + 1];
 #pragma unroll
-            for (uint32_t k = 0; k < GS_LIST_LOADS; k++) { const uint32_t i = i0 + k * GS_BLOCK + tid; g[k] = i < nr ? run_geom[rb + i] : 0u; }
+            for (uint32_t k = 0; k <= GS_LIST_SEGS; k++) dd[k] = k < nsg ? seg_diff[(size_t)(it0 + k) * GS_BLOCK + tid] : 0;
+            long long da = 0, db = 0;
 #pragma unroll
-            for (uint32_t k = 0; k < GS_LIST_LOADS; k++) {
-                const uint32_t i = i0 + k * GS_BLOCK + tid;
-                if (i < nr) {
-                    const uint32_t t0 = g[k] & 0xFFFFu, t1 = t0 + (g[k] >> 16);
-                    const unsigned long long one = i < s0 ? 0x100000001ull : 1ull;
-                    atomicAdd(&s_d[t0], one); atomicAdd(&s_d[t1], 0ull - one);
+            for (uint32_t k = 0; k <= GS_LIST_SEGS; k++) { da += dd[k]; if (k < seg) db += dd[k]; }
+            s_d[tid] = (unsigned long long)da + ((unsigned long long)db << 32);
+        } else {
+            // the item counts its tile row itself: every run of the row into the difference array, all loads in flight (rows of a
+            // few thousand runs: cheaper than another launch)
+            s_d[tid] = 0ull;
+            if (tid == 0) s_d[GS_BLOCK] = 0ull;
+            __syncthreads();
+            for (uint32_t i0 = 0; i0 < nr; i0 += GS_LIST_LOADS * GS_BLOCK) {
+                uint32_t g[GS_LIST_LOADS];
+#pragma unroll
+                for (uint32_t k = 0; k < GS_LIST_LOADS; k++) { const uint32_t i = i0 + k * GS_BLOCK + tid; g[k] = i < nr ? run_geom[rb + i] : 0u; }
+#pragma unroll
+                for (uint32_t k = 0; k < GS_LIST_LOADS; k++) {
+                    const uint32_t i = i0 + k * GS_BLOCK + tid;
+                    if (i < nr) {
+                        const uint32_t t0 = g[k] & 0xFFFFu, t1 = t0 + (g[k] >> 16);
+                        const unsigned long long one = i < s0 ? 0x100000001ull : 1ull;
+                        atomicAdd(&s_d[t0], one); atomicAdd(&s_d[t1], 0ull - one);
+                    }
                 }
             }
         }
@@ -965,13 +1037,13 @@ __device__ __forceinline__ void k_lists_body(const uint32_t *__restrict__ run_ge
     }
 }
 
-template <int ROUND>
+template <int ROUND, bool SEGC>
 __global__ __launch_bounds__(GS_BLOCK) void k_lists(const uint32_t *__restrict__ run_geom, const uint32_t *__restrict__ run_ref,
-                                                    const uint2 *__restrict__ row_tot, uint32_t *__restrict__ lists, uint2 *__restrict__ tile_range,
+                                                    const uint2 *__restrict__ row_tot, const int *__restrict__ seg_diff, uint32_t *__restrict__ lists, uint2 *__restrict__ tile_range,
                                                     GsFrameUniforms u, const uint32_t *__restrict__ mask, GsControl *ctl, uint32_t pair_cap,
                                                     const uint32_t *__restrict__ part_vis, uint32_t nparts, int last_round)
 {
-    k_lists_body<ROUND>(run_geom, run_ref, row_tot, lists, tile_range, u, mask, ctl, pair_cap, part_vis, nparts, last_round);
+    k_lists_body<ROUND, SEGC>(run_geom, run_ref, row_tot, seg_diff, lists, tile_range, u, mask, ctl, pair_cap, part_vis, nparts, last_round);
 }
 
 // Fragment shader + blend for one 16x16 tile, ONE wavefront per tile, four horizontally adjacent pixels per lane
@@ -1475,7 +1547,7 @@ uint32_t span_list_stride(const gs_ctx *ctx, const GsFrameUniforms &u, uint32_t 
 
 int gs_ensure_row_tables(gs_ctx *ctx, size_t entries)
 {
-    if (entries <= ctx->row_cnt_cap && ctx->row_tot) return GS_OK;
+    if (entries <= ctx->row_cnt_cap && ctx->row_tot && ctx->seg_diff) return GS_OK;
     GS_HIP(hipStreamSynchronize(ctx->stream));
     if (entries > ctx->row_cnt_cap) {
         if (ctx->row_cnt) (void)hipFree(ctx->row_cnt);
@@ -1484,7 +1556,11 @@ int gs_ensure_row_tables(gs_ctx *ctx, size_t entries)
         GS_HIP(hipMalloc((void **)&ctx->row_cnt, cap * sizeof(uint32_t)));
         ctx->row_cnt_cap = cap;
     }
-    if (!ctx->row_tot) { GS_HIP(hipMalloc((void **)&ctx->row_tot, GS_BLOCK * sizeof(uint2))); ctx->row_tot_cap = GS_BLOCK; }
+    if (!ctx->row_tot) {
+        GS_HIP(hipMalloc((void **)&ctx->row_tot, GS_BLOCK * sizeof(uint2))); ctx->row_tot_cap = GS_BLOCK;
+        // (k_seg_count: a row of 256 ints per k_lists item; at most GS_LIST_SEGS items per tile row, at most 256 tile rows: 4.25 MB)
+        GS_HIP(hipMalloc((void **)&ctx->seg_diff, (size_t)GS_BLOCK * (GS_LIST_SEGS + 1u) * GS_BLOCK * sizeof(int)));
+    }
     return GS_OK;
 }
 
@@ -1509,8 +1585,18 @@ int run_round_spans(gs_ctx *ctx, const GsFrameUniforms &u, uint8_t *out, bool la
     hipLaunchKernelGGL(k_emit_runs<ROUND>, dim3(g), dim3(GS_BLOCK), 0, st, ctx->proj, ctx->rect, ctx->tile_count, ctx->row_cnt, ctx->row_tot, v,
                        run_geom, run_ref, ctx->unsat_mask, (const GsControl *)ctx->ctl, pc);
     uint32_t gl = (uint32_t)u.tiles_y * GS_LIST_SEGS; if (gl > (ROUND == 1 ? 512u : 2048u)) gl = ROUND == 1 ? 512u : 2048u;
-    hipLaunchKernelGGL(k_lists<ROUND>, dim3(gl), dim3(GS_BLOCK), 0, st, run_geom, run_ref, ctx->row_tot, lists, ctx->tile_range, v, ctx->unsat_mask,
-                       ctx->ctl, pc, ctx->part_vis, g, last_round ? 1 : 0);
+    // frames of many runs per tile row (many small splats: a cut-out scene, the cloud seen from outside, tiles that do not saturate)
+    // count their segments in a launch of their own; frames of few (the headline pose: 3 000 per row) let every k_lists item count its
+    // row itself -- one launch less.  Decided from the runs of the last collected frame: a matter of speed only, the lists are the same.
+    const bool segc = ROUND == 0 && __atomic_load_n(&gs_root(ctx)->run_hint, __ATOMIC_RELAXED) > GS_SEGC_RUNS_PER_ROW * (uint32_t)u.tiles_y;
+    if (segc) {
+        hipLaunchKernelGGL(k_seg_count<ROUND>, dim3(gl), dim3(GS_BLOCK), 0, st, (const uint32_t *)run_geom, (const uint2 *)ctx->row_tot, ctx->seg_diff, v,
+                           (const GsControl *)ctx->ctl, pc);
+        hipLaunchKernelGGL((k_lists<ROUND, true>), dim3(gl), dim3(GS_BLOCK), 0, st, run_geom, run_ref, ctx->row_tot, (const int *)ctx->seg_diff, lists, ctx->tile_range, v,
+                           ctx->unsat_mask, ctx->ctl, pc, ctx->part_vis, g, last_round ? 1 : 0);
+    } else
+        hipLaunchKernelGGL((k_lists<ROUND, false>), dim3(gl), dim3(GS_BLOCK), 0, st, run_geom, run_ref, ctx->row_tot, (const int *)ctx->seg_diff, lists, ctx->tile_range, v,
+                           ctx->unsat_mask, ctx->ctl, pc, ctx->part_vis, g, last_round ? 1 : 0);
     GS_HIP(hipGetLastError());
     if (ROUND == 0) GS_PROF_RECORD(ctx, 4);
     return launch_blend<ROUND>(ctx, u, v, out, lists, ctx->proj, ctx->zwin);
@@ -1587,7 +1673,8 @@ int run_round(gs_ctx *ctx, const GsFrameUniforms &u, uint8_t *out, bool last_rou
 template <int ROUND, bool RUNS> GS_BODY(F_project, k_project_body<ROUND, RUNS>);
 template <int ROUND> GS_BODY(F_row_scan, k_row_scan_body<ROUND>);
 template <int ROUND> GS_BODY(F_emit_runs, k_emit_runs_body<ROUND>);
-template <int ROUND> GS_BODY(F_lists, k_lists_body<ROUND>);
+template <int ROUND> GS_BODY(F_seg_count, k_seg_count_body<ROUND>);
+template <int ROUND, bool SEGC> GS_BODY(F_lists, k_lists_body<ROUND, SEGC>);
 template <int ROUND> GS_BODY(F_pairs_check, k_pairs_check_body<ROUND>);
 template <int ROUND, bool P32> GS_BODY(F_emit, k_emit_body<ROUND, P32>);
 GS_BODY(F_tile_ranges, k_tile_ranges_body);
@@ -1651,11 +1738,18 @@ int run_round_spans2(gs_ctx *const S[2], const GsFrameUniforms U[2], uint8_t *co
         gs_pack_make((const gsm::Projected *)S[1]->proj, (const uint2 *)S[1]->rect, (const uint32_t *)S[1]->tile_count, (const uint32_t *)S[1]->row_cnt,
                      (const uint2 *)S[1]->row_tot, V[1], geom[1], ref[1], (const uint32_t *)S[1]->unsat_mask, (const GsControl *)S[1]->ctl, (uint32_t)S[1]->pair_cap));
     uint32_t gl = (uint32_t)u.tiles_y * GS_LIST_SEGS; if (gl > (ROUND == 1 ? 512u : 2048u)) gl = ROUND == 1 ? 512u : 2048u;
-    gs_twin<F_lists<ROUND>, GS_BLOCK>(gl, st,
-        gs_pack_make((const uint32_t *)geom[0], (const uint32_t *)ref[0], (const uint2 *)S[0]->row_tot, lists[0], S[0]->tile_range, V[0], (const uint32_t *)S[0]->unsat_mask,
-                     S[0]->ctl, (uint32_t)S[0]->pair_cap, (const uint32_t *)S[0]->part_vis, g, last_round ? 1 : 0),
-        gs_pack_make((const uint32_t *)geom[1], (const uint32_t *)ref[1], (const uint2 *)S[1]->row_tot, lists[1], S[1]->tile_range, V[1], (const uint32_t *)S[1]->unsat_mask,
-                     S[1]->ctl, (uint32_t)S[1]->pair_cap, (const uint32_t *)S[1]->part_vis, g, last_round ? 1 : 0));
+    const bool segc = ROUND == 0 && __atomic_load_n(&gs_root(ctx)->run_hint, __ATOMIC_RELAXED) > GS_SEGC_RUNS_PER_ROW * (uint32_t)u.tiles_y;
+    if (segc)
+        gs_twin<F_seg_count<ROUND>, GS_BLOCK>(gl, st,
+            gs_pack_make((const uint32_t *)geom[0], (const uint2 *)S[0]->row_tot, S[0]->seg_diff, V[0], (const GsControl *)S[0]->ctl, (uint32_t)S[0]->pair_cap),
+            gs_pack_make((const uint32_t *)geom[1], (const uint2 *)S[1]->row_tot, S[1]->seg_diff, V[1], (const GsControl *)S[1]->ctl, (uint32_t)S[1]->pair_cap));
+#define GS_LISTS2(SC) gs_twin<F_lists<ROUND, SC>, GS_BLOCK>(gl, st,                                                                                              \
+        gs_pack_make((const uint32_t *)geom[0], (const uint32_t *)ref[0], (const uint2 *)S[0]->row_tot, (const int *)S[0]->seg_diff, lists[0], S[0]->tile_range, V[0], \
+                     (const uint32_t *)S[0]->unsat_mask, S[0]->ctl, (uint32_t)S[0]->pair_cap, (const uint32_t *)S[0]->part_vis, g, last_round ? 1 : 0),                \
+        gs_pack_make((const uint32_t *)geom[1], (const uint32_t *)ref[1], (const uint2 *)S[1]->row_tot, (const int *)S[1]->seg_diff, lists[1], S[1]->tile_range, V[1], \
+                     (const uint32_t *)S[1]->unsat_mask, S[1]->ctl, (uint32_t)S[1]->pair_cap, (const uint32_t *)S[1]->part_vis, g, last_round ? 1 : 0))
+    if (segc) GS_LISTS2(true); else GS_LISTS2(false);
+#undef GS_LISTS2
     GS_HIP(hipGetLastError());
     if (ROUND == 0) GS_PROF_RECORD(ctx, 4);
     const void *fpairs[2] = { lists[0], lists[1] };

@@ -252,7 +252,8 @@ def main():
     # region lets the library settle the share of splats it bins in its first, nearest-splats round for every pose
     retries = 0
     preroll = 0
-    while preroll < 96:                                      # (short runs cycle through their poses until the share has settled)
+    while preroll < max(96, 2 * len(frames_used)):           # (short runs cycle through their poses until the share has settled; long ones see every
+                                                             # pose twice: the share drifts down towards its floor between two visits of a pose)
         for k in frames_used:
             frame(k)
             preroll += 1
