@@ -416,7 +416,7 @@ def main():
                           "traffic_GBps": round(frame_traffic * fps / 1e9, 1) if frame_traffic else None,
                           "note": "algorithmic_bytes = SURVEY.md 8(d): (16N + 4V) + (36Vp + 4V + 32Vp) + 20 I + (36 I + 4 fb) per frame, its "
                                   "20 I priced for (tile, splat) records through a sort; `traffic` = counter bytes (2*FETCH_SIZE + WRITE_SIZE) of "
-                                  "EVERY kernel of the profiled pipelined loop per frame it drew (" + traffic_src + ")"},
+                                  "every paired launch of the profiled pipelined loop (k_twin / k_sort_depth_pair: two frames each) per frame (" + traffic_src + ")"},
             "roofline": {"kernel": "k_blend", "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
                          "measured_copy_GBps": copy_peak,

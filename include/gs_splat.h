@@ -199,7 +199,12 @@ GS_API int gs_stream_wait_frame(gs_ctx *ctx, void *hip_stream);
 #define GS_COMM_ID_BYTES 128
 /* rank 0: create the id all ranks pass to gs_comm_init (ncclGetUniqueId) */
 GS_API int gs_comm_unique_id(gs_ctx *ctx, void *id_out);
-/* join the communicator as `rank` of `world` (ncclCommInitRank; collective: returns when every rank has called) */
+/* join the communicator as `rank` of `world` (ncclCommInitRank; collective: returns when every rank has called).
+ * In-process transport (GS_OPT_COMM_TRANSPORT = 1): never blocks.  A receive of that transport waits ON THE HOST for its sender to
+ * post (GS_COMM_TIMEOUT_S, default 60 s), so ONE thread that drives several such ranks with SYNCHRONOUS gathered frames has to call
+ * the non-root ranks first and the root last (queued frames -- GS_RENDER_ASYNC -- and gs_create_multi, one thread per rank, have no
+ * such order).  A failed exchange is final, as with an aborted RCCL communicator: the rank that gave up has skipped an operation
+ * its peers performed; destroy the communicator on every rank and join a new one. */
 GS_API int gs_comm_init(gs_ctx *ctx, const void *id, int rank, int world);
 GS_API int gs_comm_destroy(gs_ctx *ctx);
 
