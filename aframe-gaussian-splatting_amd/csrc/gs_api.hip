@@ -310,6 +310,15 @@ static int collect_status(gs_ctx *lane, bool *overflowed, bool *share_failed = n
         ctx->near_stash_off = true;
         GS_HIP(hipMemsetAsync(&lane->ctl->near_overflow, 0, sizeof(uint32_t), lane->stream));
     }
+    if (c->near_sorted) ctx->near_spec = true;                   // a near-only sort has run: the threshold-bin hint exists (gs_near_spec_ok)
+    if (c->near_sorted == 2u) ctx->stats.spec_sorts++;
+    if (c->spec_fail) {
+        ctx->stats.spec_misses++;
+        // a near-only sort could not vouch for the candidates its depth pass had stashed (the frame was flagged and is drawn again
+        // from a whole sort).  1: the hint was behind -- it is exact now; 2: this scene does not suit the path
+        if (c->spec_fail == 2u) ctx->near_spec_off = true;
+        GS_HIP(hipMemsetAsync(&lane->ctl->spec_fail, 0, sizeof(uint32_t), lane->stream));
+    }
     lane->stats.unsat_tiles = lane->last_two_rounds ? c->unsat_round0 : 0;
     lane->stats.near_permille = (uint32_t)(ctx->near_frac * 1000.0f + 0.5f);
     *overflowed = c->overflow_sticky != 0;
@@ -753,6 +762,7 @@ GS_API int gs_create(int device, gs_ctx **out)
     memset(ctx, 0, sizeof *ctx);
     ctx->device = device; ctx->renderable = true; ctx->t_eps = 1.0f / 1024.0f; ctx->near_frac = 0.25f;
     ctx->lanes[0] = ctx; ctx->pipe_depth = 3; ctx->enqueue_threads = true; ctx->frame_batch = 1; ctx->exec = ctx; ctx->sort_near_opt = 1; ctx->auto_retry = true;
+    { const char *e = getenv("GS_SPEC_STASH"); ctx->near_spec_opt = !(e && e[0] == '0'); }   // (A/B: near-only sorts without the speculative stash)
 #define CREATE_HIP(call) do { hipError_t _e = (call); if (_e != hipSuccess) {                                              \
         snprintf(g_create_err, sizeof g_create_err, "%s failed: %s", #call, hipGetErrorString(_e)); gs_destroy(ctx);      \
         return GS_E_HIP; } } while (0)
@@ -790,7 +800,7 @@ GS_API int gs_clear(gs_ctx *ctx)
     TRY(drain_all(ctx));
     ctx->n = 0; ctx->renderable = true; ctx->pair_hint = 0; ctx->vis_hint = 0; ctx->run_hint = 0;
     ctx->near_frac = 0.25f; ctx->near_floor = 0.0f; ctx->clean_frames = 0; ctx->skip_hold = 0; ctx->single_round_frames = 0; ctx->last_kept = 0;
-    ctx->near_stash_off = false;
+    ctx->near_stash_off = false; ctx->near_spec = false; ctx->near_spec_off = false;
     for (int i = 0; i < GS_MAX_LANES; i++) {
         gs_ctx *L = ctx->lanes[i];
         if (!L) continue;
@@ -1132,6 +1142,7 @@ static int render_sync_on_lane(gs_ctx *ctx, const GsFrameUniforms &u, void *devi
             GS_HIP(hipMemsetAsync(&ctx->ctl->order_incomplete, 0, sizeof(uint32_t), ctx->stream));
             GS_HIP(hipMemsetAsync(&ctx->ctl->round1_missed, 0, sizeof(uint32_t), ctx->stream));
             if (ctx->ctl_host->near_overflow) { P->near_stash_off = true; GS_HIP(hipMemsetAsync(&ctx->ctl->near_overflow, 0, sizeof(uint32_t), ctx->stream)); }
+            if (ctx->ctl_host->spec_fail) { P->stats.spec_misses++; if (ctx->ctl_host->spec_fail == 2u) P->near_spec_off = true; GS_HIP(hipMemsetAsync(&ctx->ctl->spec_fail, 0, sizeof(uint32_t), ctx->stream)); }
             if (attempt >= 2) FAIL(GS_E_HIP, "the sorted order keeps coming back incomplete");
             TRY(gs_run_sort(ctx, ctx->sv_view, ctx->sv_has_cutout ? ctx->sv_cutout : nullptr, ctx->sv_has_strip ? &ctx->sv_strip : nullptr, 0));
             P->stats.retried_frames++;
@@ -1557,7 +1568,7 @@ GS_API int gs_get_stats(gs_ctx *ctx, gs_stats *out)
         s.acc_visible += L->stats.acc_visible; s.acc_pairs += L->stats.acc_pairs;
     }
     s.n_splats = ctx->n;
-    s.retried_frames = ctx->stats.retried_frames;
+    s.retried_frames = ctx->stats.retried_frames; s.spec_sorts = ctx->stats.spec_sorts; s.spec_misses = ctx->stats.spec_misses;
     s.near_permille = (uint32_t)(ctx->near_frac * 1000.0f + 0.5f);
     *out = s;
     return GS_OK;

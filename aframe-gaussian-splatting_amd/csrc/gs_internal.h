@@ -50,7 +50,7 @@ struct GsControl {
     uint32_t n_kept;               // V : survivors of the sort culls  (= reference validCount)
     uint32_t n_sorted;             // records that went through the depth sort: V' = those with a bucket inside the table (compact records: the rest is
                                    // the zero tail), or only the nearest P of them (near-only sort)
-    uint32_t near_sorted;          // 1: `sorted` holds the order's last P valid positions [V' - P, V') only (gs_run_sort with near_req)
+    uint32_t near_sorted;          // 1 / 2 (2: through the depth pass' own candidate stash): `sorted` holds the order's last P valid positions [V' - P, V') only (gs_run_sort with near_req)
     uint32_t n_valid;              // V' of the whole order, counted by a near-only sort (position of sorted[0] = n_valid - n_sorted)
     uint32_t order_incomplete;     // sticky: `sorted` does not hold everything it claims -- a near-only sort's chunk stash overflowed, an exchanged
                                    // order was cut short (host clears).  The frames drawn from it are flagged round1_missed too (asynchronous frames:
@@ -73,6 +73,10 @@ struct GsControl {
     uint32_t vis_total;            // visible splats of the current binning round (k_pairs_check)
     uint32_t near_overflow;        // sticky: a near-only sort's survivors did not fit a chunk's stash (host clears; the frame is also
                                    // flagged order_incomplete + round1_missed: it is drawn again from a whole sort)
+    uint32_t spec_fail;            // sticky: a near-only sort whose depth pass stashed the candidates itself (k_sort_depth<.., SPEC>) could not vouch for
+                                   // them -- 1: the threshold hint was behind (transient), 2: a stash overflowed / the depth range does not suit
+                                   // the path (the context stops using it); the frame is flagged order_incomplete + round1_missed (host clears)
+    uint32_t near_bin_hint;        // OWNER's block only: the threshold depth bin the context's last near-only sort found (any lane's kernels write it)
     uint32_t acc_frames;           // frames rendered since profiling was switched on
     unsigned long long acc_sorted, acc_visible, acc_pairs;   // sums of V, Vp, I over those frames
 };
@@ -160,6 +164,8 @@ struct gs_ctx {
     float sv_view[4], sv_cutout[16]; bool sv_has_cutout, sv_has_strip; GsSortStrip sv_strip;
     int sort_near_opt;             // owner: GS_OPT_SORT_NEAR
     bool near_stash_off;           // owner: a chunk's stash overflowed once: near-only sorts keep to the two whole-length passes
+    bool near_spec, near_spec_off; // owner: a near-only sort has been collected (the hint exists) / the speculative stash failed for good on this scene
+    int near_spec_opt;             // owner: 0 = never stash speculatively (GS_SPEC_STASH=0 in the environment: A/B)
     uint32_t last_kept;            // owner: V of the last collected frame (a near-only sort pays only where V is well above the share read)
 
     // radix / scan scratch

@@ -97,14 +97,68 @@ __device__ __forceinline__ bool strip_may_touch(const StripUniforms &s, float x,
     return !(xpx + reach < s.sx0 || xpx - reach > s.sx1);
 }
 
-template <bool STRIP>                                             // (two instantiations: the strip test must not cost the plain sort registers)
+// SPEC (near-only sorts of long inputs, round 4): the pass hands the candidates on itself.  A near-only sort keeps the splats whose
+// bucket reaches a threshold that is only known after the pass (it comes from this pass' depth histogram and min / max) -- so the
+// depths of all N splats were written (80 MB at 20 M) and read again by k_near_stash, which recomputed 20 M buckets in f64 to keep
+// 1.5 % of them.  But the threshold BIN moves slowly from frame to frame: with the bin the context's last near-only sort found
+// (*bin_hint) plus GS_SPEC_PAD the pass stashes every splat whose depth falls in those bins -- (stored f32 depth, index), in index
+// order, GS_SPEC_SLOT records per chunk of 1024 -- and writes no depth array at all; k_near_filter then applies the EXACT rule to
+// the candidates alone (same f32 depth, same min / max, same bucket arithmetic: the same records as before) after checking that
+// the candidates were a superset of what the exact threshold keeps.  If they were not (the camera jumped; a stash overflowed; the
+// depth range is so short that buckets could be dropped, which only a pass over every depth can count), the frame is flagged like
+// an overflowed stash: drawn again from a whole sort, and the hint is exact for the next frame.
+#ifndef GS_SPEC_SLOT
+#define GS_SPEC_SLOT 128u          // candidates a 1024-item chunk of the depth pass may stash (the share asked for is <= 1/32: 32 on average)
+#endif
+#ifndef GS_SPEC_PAD
+#define GS_SPEC_PAD 2u             // bins (12 % of depth each) beyond the last sort's threshold bin that are stashed too (one is needed when the bin
+                                   // has not moved: the threshold BUCKET lies inside the next bin; the second is the margin for a moving camera)
+#endif
+#define GS_SPEC_GROUP 32u          // chunks (of 1024 items) one k_near_filter workgroup compacts: 4096 stash slots
+// the stash step of one chunk: ranks by (row, wavefront, lane) = index order
+#define GS_SPEC_STASH_STEP(SP, FB, SROW, STASH, CNT, CTL, LIMREC) do {                                                                     \
+        uint32_t bef_[GS_DEPTH_IPT];                                                                                             \
+        _Pragma("unroll") for (int r = 0; r < GS_DEPTH_IPT; r++) {                                                                \
+            const unsigned long long bal_ = __ballot(SP[r]);                                                                     \
+            bef_[r] = (uint32_t)__popcll(bal_ & ((1ull << (threadIdx.x & 63)) - 1ull));                                           \
+            if ((threadIdx.x & 63) == 0) SROW[r * 4 + (threadIdx.x >> 6)] = (uint32_t)__popcll(bal_);                              \
+        }                                                                                                                        \
+        __syncthreads();                                                                                                         \
+        if (threadIdx.x < 64) {                                                                                                  \
+            const uint32_t cv_ = threadIdx.x < 4u * GS_DEPTH_IPT ? SROW[threadIdx.x] : 0u;                                        \
+            uint32_t inc_ = cv_;                                                                                                 \
+            for (int d_ = 1; d_ < 64; d_ <<= 1) { const uint32_t t_ = __shfl_up(inc_, d_, 64); if ((int)threadIdx.x >= d_) inc_ += t_; } \
+            if (threadIdx.x < 4u * GS_DEPTH_IPT) SROW[threadIdx.x] = inc_ - cv_;                                                  \
+            const uint32_t total_ = __shfl(inc_, 63, 64);                                                                        \
+            if (threadIdx.x == 0) {                                                                                              \
+                CNT[c] = (total_ < GS_SPEC_SLOT ? total_ : GS_SPEC_SLOT) | (LIMREC << 16);   /* the bins THIS chunk was stashed by: checked per chunk */ \
+                if (total_ > GS_SPEC_SLOT) CTL->spec_fail = 2u;                                                                   \
+            }                                                                                                                    \
+        }                                                                                                                        \
+        __syncthreads();                                                                                                         \
+        _Pragma("unroll") for (int r = 0; r < GS_DEPTH_IPT; r++) {                                                                \
+            if (SP[r]) {                                                                                                         \
+                const uint32_t slot_ = SROW[r * 4 + (threadIdx.x >> 6)] + bef_[r];                                                \
+                if (slot_ < GS_SPEC_SLOT) STASH[(size_t)c * GS_SPEC_SLOT + slot_] = make_uint2(FB[r], c * DCHUNK + r * GS_BLOCK + threadIdx.x); \
+            }                                                                                                                    \
+        }                                                                                                                        \
+        __syncthreads();                                                                                                         \
+    } while (0)
+
+template <bool STRIP, bool SPEC>                                  // (instantiations: the strip test / the stash must not cost the plain sort registers)
 __device__ __forceinline__ void k_sort_depth_body(const float4 *__restrict__ rows, const float *__restrict__ bound_r, uint32_t n, const SortUniforms &u, const StripUniforms &su,
                                                   float *__restrict__ depth_out, unsigned long long *__restrict__ part_min,
-                                                  unsigned long long *__restrict__ part_max, uint32_t *__restrict__ part_cnt, DepthHist dh)
+                                                  unsigned long long *__restrict__ part_max, uint32_t *__restrict__ part_cnt, DepthHist dh,
+                                                  uint2 *__restrict__ spec_stash, uint32_t *__restrict__ spec_cnt, const uint32_t *__restrict__ bin_hint, GsControl *ctl)
 {
     GS_CHAIN_PRIO();
     __shared__ unsigned long long s_min, s_max;
     __shared__ uint32_t s_cnt;
+    __shared__ uint32_t s_srow[SPEC ? 4 * GS_DEPTH_IPT : 1];
+    // the bins this workgroup stashes: up to the last sort's threshold bin + pad.  The hint is one word shared by the context's lanes
+    // and may change while this kernel runs: every chunk records the limit it was stashed by, and the filter checks chunk by chunk
+    const uint32_t hint_ = SPEC ? *bin_hint : 0u;
+    const uint32_t spec_lim = (SPEC && hint_ != 0xFFFFFFFFu) ? hint_ + GS_SPEC_PAD : 0u, spec_rec = (SPEC && hint_ != 0xFFFFFFFFu) ? spec_lim : 0xFFFFu;
     extern __shared__ uint32_t s_dh[];                           // GS_DEPTH_BINS words for a near-only sort, none otherwise (LDS the other frames' blends can use)
     if (threadIdx.x == 0) { s_min = ~0ull; s_max = 0ull; s_cnt = 0; }
     depth_hist_begin(dh, s_dh);
@@ -122,6 +176,10 @@ __device__ __forceinline__ void k_sort_depth_body(const float4 *__restrict__ row
             mm[r] = i < n ? rows[i] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             sg[r] = (STRIP && i < n) ? bound_r[i] : 0.0f;
         }
+        uint32_t fb[GS_DEPTH_IPT];
+        bool sp[GS_DEPTH_IPT];
+#pragma unroll
+        for (int r = 0; r < GS_DEPTH_IPT; r++) { fb[r] = 0u; sp[r] = false; }
 #pragma unroll
         for (int r = 0; r < GS_DEPTH_IPT; r++) {
             const uint32_t i = c * DCHUNK + r * GS_BLOCK + threadIdx.x;
@@ -133,8 +191,9 @@ __device__ __forceinline__ void k_sort_depth_body(const float4 *__restrict__ row
                 // the bucket scale comes from EVERY splat the reference keeps (index.js:552-553), so a strip's order is the
                 // reference's order restricted to the strip's splats; only those are handed on
                 const bool mine = keep && (!STRIP || strip_may_touch(su, m.x, m.y, m.z, sg[r]));
-                depth_out[i] = mine ? (float)d : INFINITY;
+                if (!SPEC) depth_out[i] = mine ? (float)d : INFINITY;
                 if (mine && dh.fill) atomicAdd(&s_dh[depth_bin((float)d)], 1u);
+                if (SPEC) { fb[r] = __float_as_uint((float)d); sp[r] = mine && depth_bin((float)d) <= spec_lim; }
                 if (keep) {
                     const unsigned long long e = gsm::f64_to_ordered(d);
                     mn = e < mn ? e : mn; mx = e > mx ? e : mx;
@@ -142,6 +201,7 @@ __device__ __forceinline__ void k_sort_depth_body(const float4 *__restrict__ row
                 }
             }
         }
+        if (SPEC) GS_SPEC_STASH_STEP(sp, fb, s_srow, spec_stash, spec_cnt, ctl, spec_rec);
     }
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) {                           // wavefront butterfly, then one LDS atomic per wave
@@ -155,29 +215,35 @@ __device__ __forceinline__ void k_sort_depth_body(const float4 *__restrict__ row
     depth_hist_end(dh, s_dh);
 }
 
-template <bool STRIP>
+template <bool STRIP, bool SPEC>
 __global__ __launch_bounds__(GS_BLOCK) void k_sort_depth(const float4 *__restrict__ rows, const float *__restrict__ bound_r, uint32_t n, SortUniforms u, StripUniforms su,
                                                          float *__restrict__ depth_out, unsigned long long *__restrict__ part_min,
-                                                         unsigned long long *__restrict__ part_max, uint32_t *__restrict__ part_cnt, DepthHist dh)
+                                                         unsigned long long *__restrict__ part_max, uint32_t *__restrict__ part_cnt, DepthHist dh,
+                                                         uint2 *__restrict__ spec_stash, uint32_t *__restrict__ spec_cnt, const uint32_t *__restrict__ bin_hint, GsControl *ctl)
 {
-    k_sort_depth_body<STRIP>(rows, bound_r, n, u, su, depth_out, part_min, part_max, part_cnt, dh);
+    k_sort_depth_body<STRIP, SPEC>(rows, bound_r, n, u, su, depth_out, part_min, part_max, part_cnt, dh, spec_stash, spec_cnt, bin_hint, ctl);
 }
 
 // The same pass for the two frames of a pair (GS_OPT_FRAME_BATCH) in ONE sweep over the splats: at 20 M splats the sort rows are
 // 320 MB of the 400 MB this pass streams per frame, and both frames read the same rows -- one read, two view rows / cutout
 // matrices, two depth arrays and two sets of partials (20 M @ 4K: 2464 -> 2606 frames/s; no difference at 1 M, where the rows
 // are cache-resident).  Per frame exactly the arithmetic of k_sort_depth.
-template <bool STRIP>
+struct SpecArgs { uint2 *stash; uint32_t *cnt; const uint32_t *bin_hint; GsControl *ctl; };
+template <bool STRIP, bool SPEC>
 __global__ __launch_bounds__(GS_BLOCK) void k_sort_depth_pair(const float4 *__restrict__ rows, const float *__restrict__ bound_r, uint32_t n,
                                                               SortUniforms u0, SortUniforms u1, StripUniforms su0, StripUniforms su1,
                                                               float *__restrict__ depth0, float *__restrict__ depth1,
                                                               unsigned long long *__restrict__ pmin0, unsigned long long *__restrict__ pmax0, uint32_t *__restrict__ pcnt0,
                                                               unsigned long long *__restrict__ pmin1, unsigned long long *__restrict__ pmax1, uint32_t *__restrict__ pcnt1,
-                                                              DepthHist dh0, DepthHist dh1)
+                                                              DepthHist dh0, DepthHist dh1, SpecArgs sa0, SpecArgs sa1)
 {
     GS_CHAIN_PRIO();
     __shared__ unsigned long long s_min[2], s_max[2];
     __shared__ uint32_t s_cnt[2];
+    __shared__ uint32_t s_srow0[SPEC ? 4 * GS_DEPTH_IPT : 1], s_srow1[SPEC ? 4 * GS_DEPTH_IPT : 1];
+    const uint32_t h0_ = SPEC ? *sa0.bin_hint : 0u, h1_ = SPEC ? *sa1.bin_hint : 0u;
+    const uint32_t lim0 = (SPEC && h0_ != 0xFFFFFFFFu) ? h0_ + GS_SPEC_PAD : 0u, rec0 = (SPEC && h0_ != 0xFFFFFFFFu) ? lim0 : 0xFFFFu;
+    const uint32_t lim1 = (SPEC && h1_ != 0xFFFFFFFFu) ? h1_ + GS_SPEC_PAD : 0u, rec1 = (SPEC && h1_ != 0xFFFFFFFFu) ? lim1 : 0xFFFFu;
     extern __shared__ uint32_t s_dh0[];                          // 2 x GS_DEPTH_BINS words for near-only sorts, none otherwise
     uint32_t *const s_dh1 = s_dh0 + GS_DEPTH_BINS;
     if (threadIdx.x < 2) { s_min[threadIdx.x] = ~0ull; s_max[threadIdx.x] = 0ull; s_cnt[threadIdx.x] = 0; }
@@ -196,24 +262,33 @@ __global__ __launch_bounds__(GS_BLOCK) void k_sort_depth_pair(const float4 *__re
             mm[r] = i < n ? rows[i] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             sg[r] = (STRIP && i < n) ? bound_r[i] : 0.0f;
         }
+        uint32_t fb0[GS_DEPTH_IPT], fb1[GS_DEPTH_IPT];
+        bool sp0[GS_DEPTH_IPT], sp1[GS_DEPTH_IPT];
+#pragma unroll
+        for (int r = 0; r < GS_DEPTH_IPT; r++) { fb0[r] = fb1[r] = 0u; sp0[r] = sp1[r] = false; }
 #pragma unroll
         for (int r = 0; r < GS_DEPTH_IPT; r++) {
             const uint32_t i = c * DCHUNK + r * GS_BLOCK + threadIdx.x;
             if (i < n) {
                 const float4 m = mm[r];
-#define GS_DEPTH_ONE(U, SU, OUT, MN, MX, CNT, DH, SDH) do {                                                             \
+#define GS_DEPTH_ONE(U, SU, OUT, MN, MX, CNT, DH, SDH, FB, SP, LIM) do {                                                \
                     const double d = gsm::view_depth(U.view, m.x, m.y, m.z);                                               \
                     const bool inside = U.has_cutout ? gsm::in_cutout(U.cutout, m.x, m.y, m.z) : true;                     \
                     const bool keep = gsm::sort_keep(d, m.w, inside);                                                      \
                     const bool mine = keep && (!STRIP || strip_may_touch(SU, m.x, m.y, m.z, sg[r]));            \
-                    OUT[i] = mine ? (float)d : INFINITY;                                                                   \
+                    if (!SPEC) OUT[i] = mine ? (float)d : INFINITY;                                                        \
                     if (mine && DH.fill) atomicAdd(&SDH[depth_bin((float)d)], 1u);                                         \
+                    if (SPEC) { FB[r] = __float_as_uint((float)d); SP[r] = mine && depth_bin((float)d) <= LIM; }           \
                     if (keep) { const unsigned long long e = gsm::f64_to_ordered(d); MN = e < MN ? e : MN; MX = e > MX ? e : MX; if (mine) CNT++; } \
                 } while (0)
-                GS_DEPTH_ONE(u0, su0, depth0, mn0, mx0, cnt0, dh0, s_dh0);
-                GS_DEPTH_ONE(u1, su1, depth1, mn1, mx1, cnt1, dh1, s_dh1);
+                GS_DEPTH_ONE(u0, su0, depth0, mn0, mx0, cnt0, dh0, s_dh0, fb0, sp0, lim0);
+                GS_DEPTH_ONE(u1, su1, depth1, mn1, mx1, cnt1, dh1, s_dh1, fb1, sp1, lim1);
 #undef GS_DEPTH_ONE
             }
+        }
+        if (SPEC) {
+            GS_SPEC_STASH_STEP(sp0, fb0, s_srow0, sa0.stash, sa0.cnt, sa0.ctl, rec0);
+            GS_SPEC_STASH_STEP(sp1, fb1, s_srow1, sa1.stash, sa1.cnt, sa1.ctl, rec1);
         }
     }
 #pragma unroll
@@ -253,7 +328,8 @@ __device__ __forceinline__ void k_sort_bucket_body(const float *__restrict__ dep
                                                    const unsigned long long *__restrict__ part_min,
                                                    const unsigned long long *__restrict__ part_max,
                                                    const uint32_t *__restrict__ part_cnt, uint32_t nparts,
-                                                   uint32_t *__restrict__ hist, GsControl *ctl, const uint32_t *__restrict__ dhist, uint32_t near_req)
+                                                   uint32_t *__restrict__ hist, GsControl *ctl, const uint32_t *__restrict__ dhist, uint32_t near_req,
+                                                   uint32_t *__restrict__ bin_hint)
 {
     GS_CHAIN_PRIO();
     static_assert(!NEAR || COMPACT, "near-only sorts use the compact records");
@@ -315,6 +391,7 @@ __device__ __forceinline__ void k_sort_bucket_body(const float *__restrict__ dep
                     bc = !(x >= 0.0) ? 0 : (x >= 65535.0 ? 65535 : (int32_t)x);                // (NaN / before the table: everything valid)
                 }
                 s_bcut = bc;
+                if (blockIdx.x == 0 && bin_hint) *bin_hint = T;      // (what the next frames' speculative stash goes by)
             }
         }
         __syncthreads();
@@ -369,9 +446,10 @@ __global__ __launch_bounds__(64 * NW) void k_sort_bucket(const float *__restrict
                                                          const unsigned long long *__restrict__ part_min,
                                                          const unsigned long long *__restrict__ part_max,
                                                          const uint32_t *__restrict__ part_cnt, uint32_t nparts,
-                                                         uint32_t *__restrict__ hist, GsControl *ctl, const uint32_t *__restrict__ dhist, uint32_t near_req)
+                                                         uint32_t *__restrict__ hist, GsControl *ctl, const uint32_t *__restrict__ dhist, uint32_t near_req,
+                                                         uint32_t *__restrict__ bin_hint)
 {
-    k_sort_bucket_body<NW, COMPACT, NEAR>(depth, n, keys, part_min, part_max, part_cnt, nparts, hist, ctl, dhist, near_req);
+    k_sort_bucket_body<NW, COMPACT, NEAR>(depth, n, keys, part_min, part_max, part_cnt, nparts, hist, ctl, dhist, near_req, bin_hint);
 }
 
 // Near-only sorts of LONG inputs (round 3).  k_sort_bucket<.., NEAR> still wrote a key for every one of the N splats and pass A
@@ -387,7 +465,7 @@ template <int NW>
 __device__ __forceinline__ void k_near_stash_body(const float *__restrict__ depth, uint32_t n, const unsigned long long *__restrict__ part_min,
                                                   const unsigned long long *__restrict__ part_max, const uint32_t *__restrict__ part_cnt, uint32_t nparts,
                                                   uint2 *__restrict__ stash, uint32_t *__restrict__ cnt_out, GsControl *ctl,
-                                                  const uint32_t *__restrict__ dhist, uint32_t near_req)
+                                                  const uint32_t *__restrict__ dhist, uint32_t near_req, uint32_t *__restrict__ bin_hint)
 {
     GS_CHAIN_PRIO();
     constexpr int NT = 64 * NW, IPT = 8, CH = NT * IPT;
@@ -444,6 +522,7 @@ __device__ __forceinline__ void k_near_stash_body(const float *__restrict__ dept
                 bc = !(x >= 0.0) ? 0 : (x >= 65535.0 ? 65535 : (int32_t)x);
             }
             s_bcut = bc;
+            if (blockIdx.x == 0 && bin_hint) *bin_hint = T;
         }
     }
     __syncthreads();
@@ -531,6 +610,184 @@ __device__ __forceinline__ void k_near_gather_body(const uint2 *__restrict__ sta
     }
 }
 
+// The exact rule applied to the candidates the depth pass stashed (k_sort_depth<.., SPEC>): fold the partials, find the threshold
+// bin and bucket exactly as k_near_stash does, CHECK that the candidates were a superset of what the rule keeps, and compact each
+// group of GS_SPEC_GROUP chunks' survivors -- (bucket, index), in index order -- into the group's buffer.
+//   superset: the first depth that was NOT stashed is the far edge of bin `lim` (= hint + pad); its bucket must lie below the
+//             threshold bucket (the bucket is monotonic in the stored depth), and the exact bin must not lie beyond lim;
+//   no dropped bucket anywhere: a kept splat's bucket leaves [0, 65535] only if rounding its depth to f32 moves it by a whole
+//             bucket -- impossible while one f32 ulp of the largest |depth| is narrower than a bucket; V' = V then (k_near_stash
+//             COUNTS V' over all depths, which this path never reads);
+//   no chunk's stash overflowed (raised by the depth pass).
+// A frame that fails is flagged like an overflowed stash (order_incomplete: drawn again from a whole sort); spec_fail says
+// why: 1 = the hint was behind (transient: it is exact now), 2 = this scene does not suit the path (the context stops using it).
+__device__ __forceinline__ void k_near_filter_body(const uint2 *__restrict__ stash, const uint32_t *__restrict__ cnt, uint32_t n,
+                                                   const unsigned long long *__restrict__ part_min, const unsigned long long *__restrict__ part_max,
+                                                   const uint32_t *__restrict__ part_cnt, uint32_t nparts, uint2 *__restrict__ group_out,
+                                                   uint32_t *__restrict__ gcnt, GsControl *ctl, const uint32_t *__restrict__ dhist, uint32_t near_req,
+                                                   uint32_t *__restrict__ bin_hint)
+{
+    GS_CHAIN_PRIO();
+    __shared__ unsigned long long s_min, s_max;
+    __shared__ uint32_t s_cnt, s_T, s_lmin, s_w[4];
+    __shared__ int32_t s_bcut;
+    if (threadIdx.x == 0) { s_min = ~0ull; s_max = 0ull; s_cnt = 0; s_bcut = 0; s_T = 0; }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    {
+        unsigned long long mn = ~0ull, mx = 0ull; uint32_t c = 0;
+        for (uint32_t i = threadIdx.x; i < nparts; i += GS_BLOCK) {
+            const unsigned long long a = part_min[i], b = part_max[i];
+            mn = a < mn ? a : mn; mx = b > mx ? b : mx; c += part_cnt[i];
+        }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+            const unsigned long long omn = shfl_xor_u64(mn, m), omx = shfl_xor_u64(mx, m);
+            mn = omn < mn ? omn : mn; mx = omx > mx ? omx : mx;
+            c += __shfl_xor(c, m, 64);
+        }
+        if (lane == 0) { atomicMin(&s_min, mn); atomicMax(&s_max, mx); atomicAdd(&s_cnt, c); }
+    }
+    __syncthreads();
+    const double mn = gsm::ordered_to_f64(s_min), mx = gsm::ordered_to_f64(s_max);
+    const double inv = 65535.0 / (mx - mn);
+    if (threadIdx.x < 64) {                                         // the threshold bin and bucket: exactly k_sort_bucket<.., NEAR>'s rule
+        const int l = threadIdx.x;
+        auto wave_scan = [&](uint32_t v) { for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(v, d, 64); if (l >= d) v += t; } return v; };
+        uint32_t cs = 0;
+#pragma unroll
+        for (uint32_t c = 0; c < GS_DH_COPIES; c++) cs += dhist[GS_DH_COPIES * GS_DEPTH_BINS + c * GS_DEPTH_COARSE + l];
+        const uint32_t cinc = wave_scan(cs);
+        const unsigned long long m = __ballot(cinc >= near_req);
+        uint32_t T = GS_DEPTH_BINS - 1u;
+        if (m) {
+            const int C = __ffsll((long long)m) - 1;
+            const uint32_t before = __shfl(cinc - cs, C, 64);
+            uint32_t fs = 0;
+            if (l < 32) {
+#pragma unroll
+                for (uint32_t c = 0; c < GS_DH_COPIES; c++) fs += dhist[c * GS_DEPTH_BINS + (uint32_t)C * 32u + l];
+            }
+            const uint32_t finc = wave_scan(fs);
+            const unsigned long long m2 = __ballot(l < 32 && before + finc >= near_req);
+            T = (uint32_t)C * 32u + (m2 ? (uint32_t)(__ffsll((long long)m2) - 1) : 31u);
+        }
+        if (l == 0) {
+            int32_t bc = 0;
+            if (T < GS_DEPTH_BINS - 1u && inv > 0.0 && inv < 1.0e300) {
+                const double x = ((double)(-__uint_as_float((T + 1u) << 20)) - mn) * inv;
+                bc = !(x >= 0.0) ? 0 : (x >= 65535.0 ? 65535 : (int32_t)x);
+            }
+            s_bcut = bc; s_T = T;
+        }
+    }
+    __syncthreads();
+    const int32_t bcut = s_bcut;
+    const uint32_t T = s_T;
+    // what cannot be decided chunk by chunk (every workgroup finds the same): the depth range, a stash that overflowed
+    uint32_t fail = 0;
+    {
+        const double big = fmax(fabs(mn), fabs(mx));
+        const uint32_t eb = (__float_as_uint((float)big) >> 23) & 0xFFu;
+        const double ulp = eb > 23u ? (double)__uint_as_float((eb - 23u) << 23) : 0.0;   // one f32 ulp of the largest |depth|
+        if (!(inv > 0.0 && inv < 1.0e300) || !(ulp * inv < 1.0) || ctl->spec_fail == 2u) fail = 2u;
+    }
+    // the smallest limit a chunk may have been stashed by: the exact bin, and far enough that the first depth NOT stashed (the far
+    // edge of that bin) has a bucket below the threshold's (a threshold bucket of 0 keeps every splat: never this path's case)
+    if (threadIdx.x == 0) {
+        uint32_t L = 0xFFFFu;
+        if (!s_cnt) L = 0u;
+        else if (bcut > 0 && !fail)
+            for (uint32_t c = T; c < T + 8u && c < GS_DEPTH_BINS - 1u; c++)
+                if (gsm::sort_bucket(-__uint_as_float((c + 1u) << 20), mn, inv) < bcut) { L = c; break; }
+        s_lmin = L;
+    }
+    __syncthreads();
+    const uint32_t lmin = s_lmin;
+    if (lmin == 0xFFFFu && !fail) fail = 2u;                         // (buckets coarser than depth bins, or everything kept: the whole-length passes do this scene)
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        ctl->min_enc = s_min; ctl->max_enc = s_max; ctl->n_kept = s_cnt; ctl->n_total = n; ctl->near_sorted = 2u;   // (2: by this path; read as "not 0" on the device)
+        ctl->n_valid = s_cnt;                                        // V' = V: no bucket can be dropped (checked above)
+        *bin_hint = T;
+        if (fail) { ctl->spec_fail = 2u; ctl->order_incomplete = 1u; ctl->round1_missed = 1u; }
+    }
+    const uint32_t nchunks = (n + GS_DEPTH_IPT * GS_BLOCK - 1) / (GS_DEPTH_IPT * GS_BLOCK);
+    const uint32_t ngroups = (nchunks + GS_SPEC_GROUP - 1) / GS_SPEC_GROUP;
+    constexpr uint32_t PER = GS_SPEC_GROUP * GS_SPEC_SLOT / GS_BLOCK;   // 16 consecutive stash slots per thread: index order
+    for (uint32_t g = blockIdx.x; g < ngroups; g += gridDim.x) {
+        const uint32_t slot0 = threadIdx.x * PER, c = g * GS_SPEC_GROUP + slot0 / GS_SPEC_SLOT, pos0 = slot0 % GS_SPEC_SLOT;
+        const uint32_t cw = (!fail && c < nchunks) ? cnt[c] : 0u, cc = cw & 0xFFFFu;
+        if (!fail && c < nchunks && pos0 == 0u && s_cnt && ((cw >> 16) < lmin || (cw >> 16) == 0xFFFFu)) {
+            // this chunk was stashed by a limit that does not cover what the exact rule keeps (the hint was behind, or absent): the
+            // frame is drawn again from a whole sort; the hint is exact for the next one
+            if (ctl->spec_fail != 2u) ctl->spec_fail = 1u;
+            ctl->order_incomplete = 1u; ctl->round1_missed = 1u;
+        }
+        uint2 rec[PER];
+#pragma unroll
+        for (uint32_t k = 0; k < PER; k++) rec[k] = pos0 + k < cc ? stash[(size_t)c * GS_SPEC_SLOT + pos0 + k] : make_uint2(0u, 0u);
+        uint32_t keep = 0, nk = 0;
+        int32_t bk[PER];
+#pragma unroll
+        for (uint32_t k = 0; k < PER; k++) {
+            bk[k] = -1;
+            if (pos0 + k < cc) { const int32_t b = gsm::sort_bucket(__uint_as_float(rec[k].x), mn, inv); if (b >= bcut) { bk[k] = b; keep |= 1u << k; nk++; } }
+        }
+        // exclusive scan of the threads' counts (threads hold consecutive slots: index order)
+        uint32_t inc = nk;
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(inc, d, 64); if (lane >= d) inc += t; }
+        __syncthreads();
+        if (lane == 63) s_w[w] = inc;
+        __syncthreads();
+        uint32_t base = inc - nk, total = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) { if (k < w) base += s_w[k]; total += s_w[k]; }
+        uint2 *out = group_out + (size_t)g * (GS_SPEC_GROUP * GS_SPEC_SLOT);
+#pragma unroll
+        for (uint32_t k = 0; k < PER; k++) if (keep & (1u << k)) out[base++] = make_uint2((uint32_t)bk[k], rec[k].y);
+        if (threadIdx.x == 0) gcnt[g] = total;
+    }
+}
+
+// the groups' survivors -> one list in group (= index) order; every workgroup first sums the counts of the groups before its own
+__device__ __forceinline__ void k_near_gather_groups_body(const uint2 *__restrict__ group_out, const uint32_t *__restrict__ gcnt, uint32_t n,
+                                                          uint2 *__restrict__ out, GsControl *ctl)
+{
+    GS_CHAIN_PRIO();
+    __shared__ uint32_t s_w[4];
+    const uint32_t nchunks = (n + GS_DEPTH_IPT * GS_BLOCK - 1) / (GS_DEPTH_IPT * GS_BLOCK);
+    const uint32_t ngroups = (nchunks + GS_SPEC_GROUP - 1) / GS_SPEC_GROUP;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (uint32_t g = blockIdx.x; g < ngroups; g += gridDim.x) {
+        uint32_t sv = 0;
+        for (uint32_t i = threadIdx.x; i < g; i += GS_BLOCK) sv += gcnt[i];
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) sv += __shfl_xor(sv, m, 64);
+        __syncthreads();
+        if (lane == 0) s_w[w] = sv;
+        __syncthreads();
+        const uint32_t base = s_w[0] + s_w[1] + s_w[2] + s_w[3], k = gcnt[g];
+        const uint2 *src = group_out + (size_t)g * (GS_SPEC_GROUP * GS_SPEC_SLOT);
+        for (uint32_t t = threadIdx.x; t < k; t += GS_BLOCK) out[base + t] = src[t];
+        if (g == ngroups - 1 && threadIdx.x == 0) ctl->n_sorted = base + k;   // P': what the two passes sort
+    }
+}
+GS_BODY(F_near_filter, k_near_filter_body);
+GS_BODY(F_near_gather_groups, k_near_gather_groups_body);
+__global__ __launch_bounds__(GS_BLOCK) void k_near_filter(const uint2 *__restrict__ stash, const uint32_t *__restrict__ cnt, uint32_t n,
+                                                          const unsigned long long *__restrict__ part_min, const unsigned long long *__restrict__ part_max,
+                                                          const uint32_t *__restrict__ part_cnt, uint32_t nparts, uint2 *__restrict__ group_out,
+                                                          uint32_t *__restrict__ gcnt, GsControl *ctl, const uint32_t *__restrict__ dhist, uint32_t near_req,
+                                                          uint32_t *__restrict__ bin_hint)
+{
+    k_near_filter_body(stash, cnt, n, part_min, part_max, part_cnt, nparts, group_out, gcnt, ctl, dhist, near_req, bin_hint);
+}
+__global__ __launch_bounds__(GS_BLOCK) void k_near_gather_groups(const uint2 *__restrict__ group_out, const uint32_t *__restrict__ gcnt, uint32_t n,
+                                                                 uint2 *__restrict__ out, GsControl *ctl)
+{
+    k_near_gather_groups_body(group_out, gcnt, n, out, ctl);
+}
+
 template <int NW> GS_BODY(F_near_stash, k_near_stash_body<NW>);
 GS_BODY(F_near_gather, k_near_gather_body);
 
@@ -538,9 +795,9 @@ template <int NW>
 __global__ __launch_bounds__(64 * NW) void k_near_stash(const float *__restrict__ depth, uint32_t n, const unsigned long long *__restrict__ part_min,
                                                         const unsigned long long *__restrict__ part_max, const uint32_t *__restrict__ part_cnt, uint32_t nparts,
                                                         uint2 *__restrict__ stash, uint32_t *__restrict__ cnt_out, GsControl *ctl,
-                                                        const uint32_t *__restrict__ dhist, uint32_t near_req)
+                                                        const uint32_t *__restrict__ dhist, uint32_t near_req, uint32_t *__restrict__ bin_hint)
 {
-    k_near_stash_body<NW>(depth, n, part_min, part_max, part_cnt, nparts, stash, cnt_out, ctl, dhist, near_req);
+    k_near_stash_body<NW>(depth, n, part_min, part_max, part_cnt, nparts, stash, cnt_out, ctl, dhist, near_req, bin_hint);
 }
 __global__ __launch_bounds__(GS_BLOCK) void k_near_gather(const uint2 *__restrict__ stash, const uint32_t *__restrict__ cnt, uint32_t n, uint32_t chunk,
                                                           uint2 *__restrict__ out, GsControl *ctl)
@@ -586,6 +843,16 @@ static bool gs_near_stash_ok(const gs_ctx *L, uint32_t n, uint32_t near_req)
     return near_req && gs_radix_chunk(n) == GS_CHUNK_L && (uint64_t)near_req * 32u <= n && !gs_root(const_cast<gs_ctx *>(L))->near_stash_off &&
            (size_t)(gs_div_up(n, GS_CHUNK_L) + 1u) * GS_NEAR_STASH <= L->scratch_cap / 2;
 }
+// ... and may its depth pass stash the candidates itself (k_sort_depth<.., SPEC>)?  Only once a near-only sort of this context has
+// been collected (the hint exists); never again after the path failed for good on this scene
+static bool gs_near_spec_ok(const gs_ctx *L, uint32_t n)
+{
+    const gs_ctx *P = gs_root(const_cast<gs_ctx *>(L));
+    return P->near_spec && !P->near_spec_off && P->near_spec_opt &&
+           (size_t)(gs_div_up(n, (uint32_t)(GS_DEPTH_IPT * GS_BLOCK)) + GS_SPEC_GROUP) * GS_SPEC_SLOT <= L->scratch_cap / 4 &&
+           (size_t)gs_div_up(n, (uint32_t)(GS_DEPTH_IPT * GS_BLOCK)) * 2u + 64u <= L->hist_cap;
+}
+static uint32_t gs_spec_groups(uint32_t n) { return gs_div_up(gs_div_up(n, (uint32_t)(GS_DEPTH_IPT * GS_BLOCK)), GS_SPEC_GROUP); }
 static uint32_t gs_near_gather_grid(uint32_t n)
 {
     const uint32_t g = gs_div_up(gs_div_up(n, GS_CHUNK_L), 8u);
@@ -622,23 +889,43 @@ int gs_run_sort2(gs_ctx *const S[2], const float *const view[2], const float *co
     if (gd > GS_DEPTH_GRID) gd = GS_DEPTH_GRID;
     // ONE sweep computes both frames' depths: the rows are read once (the lanes of a context alias the owner's resident arrays)
     if (S[0]->sort_rows != S[1]->sort_rows) { snprintf(GS_ERRBUF(ctx), GS_ERRLEN, "paired sort: the two lanes hold different splat arrays"); return GS_E_STATE; }
-#define GS_DEPTHP(ST) hipLaunchKernelGGL((k_sort_depth_pair<ST>), dim3(gd), dim3(GS_BLOCK), near ? 2u * GS_DEPTH_BINS * sizeof(uint32_t) : 0u, st, (const float4 *)S[0]->sort_rows, (const float *)S[0]->bound_r, n,  \
-                                         u[0], u[1], su[0], su[1], S[0]->depth, S[1]->depth, S[0]->part_min, S[0]->part_max, S[0]->part_cnt,                            \
-                                         S[1]->part_min, S[1]->part_max, S[1]->part_cnt, dh[0], dh[1])
-    if (strips) GS_DEPTHP(true); else GS_DEPTHP(false);
-#undef GS_DEPTHP
-    // near-only sorts of long inputs hand their survivors on through per-chunk stashes instead of two whole-length passes (above)
+    // near-only sorts of long inputs hand their survivors on through per-chunk stashes instead of two whole-length passes (above);
+    // with a threshold hint the depth pass stashes the candidates itself and writes no depths (SPEC)
     const bool stash = near && gs_near_stash_ok(S[0], n, near_req[0]) && gs_near_stash_ok(S[1], n, near_req[1]);
+    const bool spec = stash && gs_near_spec_ok(S[0], n) && gs_near_spec_ok(S[1], n);
+    uint32_t *const bin_hint = &gs_root(ctx)->ctl->near_bin_hint;
+    const uint32_t nch = gs_div_up(n, (uint32_t)(GS_DEPTH_IPT * GS_BLOCK));
+    SpecArgs sa[2];
+    for (int k = 0; k < 2; k++) { sa[k].stash = S[k]->kv_b; sa[k].cnt = S[k]->hist; sa[k].bin_hint = bin_hint; sa[k].ctl = S[k]->ctl; }
+#define GS_DEPTHP(ST, SP) hipLaunchKernelGGL((k_sort_depth_pair<ST, SP>), dim3(gd), dim3(GS_BLOCK), near ? 2u * GS_DEPTH_BINS * sizeof(uint32_t) : 0u, st, (const float4 *)S[0]->sort_rows, (const float *)S[0]->bound_r, n,  \
+                                         u[0], u[1], su[0], su[1], S[0]->depth, S[1]->depth, S[0]->part_min, S[0]->part_max, S[0]->part_cnt,                            \
+                                         S[1]->part_min, S[1]->part_max, S[1]->part_cnt, dh[0], dh[1], sa[0], sa[1])
+    if (spec) { if (strips) GS_DEPTHP(true, true); else GS_DEPTHP(false, true); }
+    else { if (strips) GS_DEPTHP(true, false); else GS_DEPTHP(false, false); }
+#undef GS_DEPTHP
     if (stash) {
         uint2 *list[2] = { S[0]->kv_b + S[0]->scratch_cap / 2, S[1]->kv_b + S[1]->scratch_cap / 2 };
+        if (spec) {
+            uint2 *grp[2] = { S[0]->kv_b + S[0]->scratch_cap / 4, S[1]->kv_b + S[1]->scratch_cap / 4 };
+            const uint32_t ng = gs_spec_groups(n);
+            gs_twin<F_near_filter, GS_BLOCK>(ng, st,
+                gs_pack_make((const uint2 *)S[0]->kv_b, (const uint32_t *)S[0]->hist, n, (const unsigned long long *)S[0]->part_min, (const unsigned long long *)S[0]->part_max,
+                             (const uint32_t *)S[0]->part_cnt, gd, grp[0], S[0]->hist + nch, S[0]->ctl, (const uint32_t *)dh[0].fill, S[0]->sort_near_req, bin_hint),
+                gs_pack_make((const uint2 *)S[1]->kv_b, (const uint32_t *)S[1]->hist, n, (const unsigned long long *)S[1]->part_min, (const unsigned long long *)S[1]->part_max,
+                             (const uint32_t *)S[1]->part_cnt, gd, grp[1], S[1]->hist + nch, S[1]->ctl, (const uint32_t *)dh[1].fill, S[1]->sort_near_req, bin_hint));
+            gs_twin<F_near_gather_groups, GS_BLOCK>(ng, st,
+                gs_pack_make((const uint2 *)grp[0], (const uint32_t *)(S[0]->hist + nch), n, list[0], S[0]->ctl),
+                gs_pack_make((const uint2 *)grp[1], (const uint32_t *)(S[1]->hist + nch), n, list[1], S[1]->ctl));
+        } else {
         gs_twin<F_near_stash<8>, 512>(g, st,
             gs_pack_make((const float *)S[0]->depth, n, (const unsigned long long *)S[0]->part_min, (const unsigned long long *)S[0]->part_max, (const uint32_t *)S[0]->part_cnt, gd,
-                         S[0]->kv_b, S[0]->hist, S[0]->ctl, (const uint32_t *)dh[0].fill, S[0]->sort_near_req),
+                         S[0]->kv_b, S[0]->hist, S[0]->ctl, (const uint32_t *)dh[0].fill, S[0]->sort_near_req, bin_hint),
             gs_pack_make((const float *)S[1]->depth, n, (const unsigned long long *)S[1]->part_min, (const unsigned long long *)S[1]->part_max, (const uint32_t *)S[1]->part_cnt, gd,
-                         S[1]->kv_b, S[1]->hist, S[1]->ctl, (const uint32_t *)dh[1].fill, S[1]->sort_near_req));
+                         S[1]->kv_b, S[1]->hist, S[1]->ctl, (const uint32_t *)dh[1].fill, S[1]->sort_near_req, bin_hint));
         gs_twin<F_near_gather, GS_BLOCK>(gs_near_gather_grid(n), st,
             gs_pack_make((const uint2 *)S[0]->kv_b, (const uint32_t *)S[0]->hist, n, (uint32_t)GS_CHUNK_L, list[0], S[0]->ctl),
             gs_pack_make((const uint2 *)S[1]->kv_b, (const uint32_t *)S[1]->hist, n, (uint32_t)GS_CHUNK_L, list[1], S[1]->ctl));
+        }
         GS_HIP(hipGetLastError());
         const void *in2[2]; void *out2[2]; const uint32_t *np2[2]; uint32_t *cnt2[2] = { nullptr, nullptr }; const uint32_t *fill2[2] = { nullptr, nullptr };
         for (int k = 0; k < 2; k++) { in2[k] = list[k]; out2[k] = S[k]->key_a; np2[k] = &S[k]->ctl->n_sorted; }
@@ -653,9 +940,9 @@ int gs_run_sort2(gs_ctx *const S[2], const float *const view[2], const float *co
     }
 #define GS_BUCKET2(NW, C, NR) gs_twin<F_sort_bucket<NW, C, NR>, 64 * NW>(g, st,                                                                            \
         gs_pack_make((const float *)S[0]->depth, n, S[0]->key_a, (const unsigned long long *)S[0]->part_min, (const unsigned long long *)S[0]->part_max,     \
-                     (const uint32_t *)S[0]->part_cnt, gd, S[0]->hist, S[0]->ctl, (const uint32_t *)dh[0].fill, S[0]->sort_near_req),                       \
+                     (const uint32_t *)S[0]->part_cnt, gd, S[0]->hist, S[0]->ctl, (const uint32_t *)dh[0].fill, S[0]->sort_near_req, bin_hint),             \
         gs_pack_make((const float *)S[1]->depth, n, S[1]->key_a, (const unsigned long long *)S[1]->part_min, (const unsigned long long *)S[1]->part_max,     \
-                     (const uint32_t *)S[1]->part_cnt, gd, S[1]->hist, S[1]->ctl, (const uint32_t *)dh[1].fill, S[1]->sort_near_req))
+                     (const uint32_t *)S[1]->part_cnt, gd, S[1]->hist, S[1]->ctl, (const uint32_t *)dh[1].fill, S[1]->sort_near_req, bin_hint))
     if (gs_radix_chunk(n) == GS_CHUNK_L) { if (near) GS_BUCKET2(8, true, true); else if (compact) GS_BUCKET2(8, true, false); else GS_BUCKET2(8, false, false); }
     else { if (near) GS_BUCKET2(4, true, true); else if (compact) GS_BUCKET2(4, true, false); else GS_BUCKET2(4, false, false); }
 #undef GS_BUCKET2
@@ -740,17 +1027,29 @@ int gs_run_sort(gs_ctx *ctx, const float view[4], const float *cutout16, const G
     if (gd < 1) gd = 1;
     if (gd > GS_DEPTH_GRID) gd = GS_DEPTH_GRID;
     const size_t dlds = near ? GS_DEPTH_BINS * sizeof(uint32_t) : 0u;
-    if (u.has_strip) hipLaunchKernelGGL(k_sort_depth<true>, dim3(gd), dim3(GS_BLOCK), dlds, ctx->stream, ctx->sort_rows, ctx->bound_r, n, u, su, ctx->depth,
-                                        ctx->part_min, ctx->part_max, ctx->part_cnt, dh);
-    else hipLaunchKernelGGL(k_sort_depth<false>, dim3(gd), dim3(GS_BLOCK), dlds, ctx->stream, ctx->sort_rows, ctx->bound_r, n, u, su, ctx->depth,
-                            ctx->part_min, ctx->part_max, ctx->part_cnt, dh);
-    if (near && gs_near_stash_ok(ctx, n, near_req)) {
-        // (survivors through per-chunk stashes: k_near_stash / k_near_gather above)
+    const bool stash = near && gs_near_stash_ok(ctx, n, near_req);
+    const bool spec = stash && gs_near_spec_ok(ctx, n);
+    uint32_t *const bin_hint = &gs_root(ctx)->ctl->near_bin_hint;
+#define GS_DEPTH1(ST, SP) hipLaunchKernelGGL((k_sort_depth<ST, SP>), dim3(gd), dim3(GS_BLOCK), dlds, ctx->stream, ctx->sort_rows, ctx->bound_r, n, u, su, ctx->depth, \
+                                             ctx->part_min, ctx->part_max, ctx->part_cnt, dh, ctx->kv_b, ctx->hist, (const uint32_t *)bin_hint, ctx->ctl)
+    if (spec) { if (u.has_strip) GS_DEPTH1(true, true); else GS_DEPTH1(false, true); }
+    else { if (u.has_strip) GS_DEPTH1(true, false); else GS_DEPTH1(false, false); }
+#undef GS_DEPTH1
+    if (stash) {
+        // (survivors through per-chunk stashes: k_near_stash / k_near_gather above; candidates stashed by the depth pass: k_near_filter)
         uint2 *list = ctx->kv_b + ctx->scratch_cap / 2;
+        if (spec) {
+            uint2 *grp = ctx->kv_b + ctx->scratch_cap / 4;
+            const uint32_t nch = gs_div_up(n, (uint32_t)(GS_DEPTH_IPT * GS_BLOCK)), ng = gs_spec_groups(n);
+            hipLaunchKernelGGL(k_near_filter, dim3(ng), dim3(GS_BLOCK), 0, ctx->stream, (const uint2 *)ctx->kv_b, (const uint32_t *)ctx->hist, n, (const unsigned long long *)ctx->part_min,
+                               (const unsigned long long *)ctx->part_max, (const uint32_t *)ctx->part_cnt, gd, grp, ctx->hist + nch, ctx->ctl, (const uint32_t *)dh.fill, ctx->sort_near_req, bin_hint);
+            hipLaunchKernelGGL(k_near_gather_groups, dim3(ng), dim3(GS_BLOCK), 0, ctx->stream, (const uint2 *)grp, (const uint32_t *)(ctx->hist + nch), n, list, ctx->ctl);
+        } else {
         hipLaunchKernelGGL((k_near_stash<8>), dim3(g), dim3(512), 0, ctx->stream, (const float *)ctx->depth, n, (const unsigned long long *)ctx->part_min,
-                           (const unsigned long long *)ctx->part_max, (const uint32_t *)ctx->part_cnt, gd, ctx->kv_b, ctx->hist, ctx->ctl, (const uint32_t *)dh.fill, ctx->sort_near_req);
+                           (const unsigned long long *)ctx->part_max, (const uint32_t *)ctx->part_cnt, gd, ctx->kv_b, ctx->hist, ctx->ctl, (const uint32_t *)dh.fill, ctx->sort_near_req, bin_hint);
         hipLaunchKernelGGL(k_near_gather, dim3(gs_near_gather_grid(n)), dim3(GS_BLOCK), 0, ctx->stream, (const uint2 *)ctx->kv_b, (const uint32_t *)ctx->hist, n,
                            (uint32_t)GS_CHUNK_L, list, ctx->ctl);
+        }
         GS_HIP(hipGetLastError());
         int rcs = gs_launch_radix_pass(ctx, list, GS_RADIX_PACKED, ctx->key_a, GS_RADIX_KEYIDX, &ctx->ctl->n_sorted, n, near_hint(ctx, n), 0, 9, false, 0xFFFFFFFFu, 25);
         if (rcs != GS_OK) return rcs;
@@ -762,7 +1061,7 @@ int gs_run_sort(gs_ctx *ctx, const float view[4], const float *cutout16, const G
         return GS_OK;
     }
 #define GS_LAUNCH_BUCKET(NW, C, NR) hipLaunchKernelGGL((k_sort_bucket<NW, C, NR>), dim3(g), dim3(64 * NW), 0, ctx->stream, ctx->depth, n, ctx->key_a, \
-                                                       ctx->part_min, ctx->part_max, ctx->part_cnt, gd, ctx->hist, ctx->ctl, (const uint32_t *)dh.fill, ctx->sort_near_req)
+                                                       ctx->part_min, ctx->part_max, ctx->part_cnt, gd, ctx->hist, ctx->ctl, (const uint32_t *)dh.fill, ctx->sort_near_req, bin_hint)
     if (gs_radix_chunk(n) == GS_CHUNK_L) { if (near) GS_LAUNCH_BUCKET(8, true, true); else if (compact) GS_LAUNCH_BUCKET(8, true, false); else GS_LAUNCH_BUCKET(8, false, false); }
     else { if (near) GS_LAUNCH_BUCKET(4, true, true); else if (compact) GS_LAUNCH_BUCKET(4, true, false); else GS_LAUNCH_BUCKET(4, false, false); }
 #undef GS_LAUNCH_BUCKET

@@ -399,7 +399,8 @@ def main():
                        "region_ms": round(elapsed * 1e3, 3),
                        "steady_state_fps": round(steady_fps, 1) if steady_fps else None,
                        "fill_drain_share": round(max(0.0, 1.0 - fps / steady_fps), 4) if steady_fps else None,
-                       "frames_redrawn_by_sync": s.get("retried_frames", 0)},
+                       "frames_redrawn_by_sync": s.get("retried_frames", 0),
+                       "near_only_sorts_from_the_depth_pass_stash": [s.get("spec_sorts", 0), s.get("spec_misses", 0)]},
             "occlusion_binning": {"near_permille": s["near_permille"], "unsat_tiles_last_frame": s["unsat_tiles"],
                                   "timed_region_retries": retries},
             "msplat_frags_per_s": round(total_frags / 1e6 / elapsed, 1),

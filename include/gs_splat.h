@@ -360,6 +360,9 @@ typedef struct gs_stats {
     uint32_t sort_records;/* records the last collected frame's depth sort carried through its second pass: the kept
                              splats with a valid bucket, or the nearest few of them (GS_OPT_SORT_NEAR)               */
     uint32_t retried_frames;/* asynchronous frames gs_sync() drew again by itself since the context was created (GS_OPT_AUTO_RETRY) */
+    uint32_t spec_sorts;  /* collected frames whose near-only sort took its candidates from the depth pass' own stash (no depth
+                             array written: a threshold hint from the previous frames decides what is stashed) ...              */
+    uint32_t spec_misses; /* ... and those of them whose candidates could not be vouched for (drawn again from a whole sort)    */
 } gs_stats;
 
 #define GS_OPT_PROFILE 1        /* 1: bracket every stage with HIP events on the frame's stream (7 per frame); 2: only

@@ -673,7 +673,8 @@ def _near_only_frames_equal(c, cams, want, oracle_strip=None, strips=((0, 480), 
     c.set_option(capi.OPT_FRAME_BATCH, 1)
     for x0, x1 in strips:                                                  # what one of several GPUs does
         bufs, s = queued(lambda cam: (_params(cam, x0=x0, x1=x1, flags=capi.RENDER_ASYNC), True), 12)
-        print("near-only strip [%d,%d): sort records %d of %d kept" % (x0, x1, s["sort_records"], s["n_sorted"]))
+        print("near-only strip [%d,%d): sort records %d of %d kept; %d sorts from the depth pass' own stash, %d missed" %
+              (x0, x1, s["sort_records"], s["n_sorted"], s["spec_sorts"], s["spec_misses"]))
         for k, a, b_, b in bufs:
             assert np.array_equal(b.cpu().numpy().reshape(h, x1 - x0, 4), want[k][:, x0:x1]), (k, x0, x1)
 
@@ -743,6 +744,73 @@ def test_synchronous_frame_on_an_overflowed_near_only_sort_is_drawn_again_in_ful
         for b, o in bufs:
             assert np.array_equal(b, want_b)
             o.free()
+
+
+def test_near_only_sorts_whose_depth_pass_stashes_the_candidates_give_the_same_frames():
+    """Round 4: once a near-only sort of the context has been collected, the depth pass of the next ones stashes the candidates itself
+    by the threshold bin the last sort found (+ 2 bins) and writes no depth array; k_near_filter applies the exact rule to the
+    candidates and vouches, chunk by chunk, that they were a superset of what it keeps.  The frames must be the frames of whole
+    sorts bit for bit: along an orbit (the hint follows), across a jump of the camera (the hint is behind: the frames are flagged and
+    drawn again), queued one by one and in pairs, and with the path switched off (GS_SPEC_STASH=0: the A/B of the bench)."""
+    import torch
+    n, w, h = 1 << 22, 1280, 720
+    rows = cached_rows("make_splat_rows", n, seed=synth.SEED_BASE + 11).reshape(-1, 32)
+    yaws = [10.0 + 3.0 * i for i in range(12)] + [190.0 + 3.0 * i for i in range(6)]
+    cams = [synth.index_html_camera(w, h, y, capi=capi) for y in yaws]
+    with capi.Context(0) as c:
+        c.set_option(capi.OPT_SORT_NEAR, 0)
+        c.set_option(capi.OPT_TERMINATION, 4)                               # (tiles saturate within ~1 % of the order: the share is <= 1/32 at 4 M)
+        c.push_splat(rows)
+        want = []
+        for cam in cams:
+            c.sort(cam["view"], want_indices=False); want.append(c.render(_params(cam)))
+
+    def run(spec_on, batch):
+        if not spec_on:
+            os.environ["GS_SPEC_STASH"] = "0"
+        try:
+            c = capi.Context(0)
+        finally:
+            os.environ.pop("GS_SPEC_STASH", None)
+        with c:
+            c.set_option(capi.OPT_SORT_NEAR, 2)
+            c.set_option(capi.OPT_TERMINATION, 4)
+            c.set_option(capi.OPT_FRAME_BATCH, batch)
+            c.push_splat(rows)
+            for attempt in range(60):                                       # the share settles on the first poses
+                for rep in range(2):
+                    for cam in cams[:4]:
+                        c.sort(cam["view"], want_indices=False)
+                        c.render_device(_params(cam, flags=capi.RENDER_ASYNC))
+                c.sync()
+                s = c.stats()
+                if 0 < s["sort_records"] < s["n_sorted"] and s["near_permille"] <= 31:
+                    break
+            assert 0 < s["sort_records"] < s["n_sorted"] and s["near_permille"] <= 31, s
+            bufs = [torch.zeros(w * h * 4, dtype=torch.uint8, device="cuda") for _ in cams]
+            for lap in range(2):                                            # (the second lap jumps back from 205 to 10 degrees)
+                for cam, b in zip(cams, bufs):
+                    c.sort(cam["view"], want_indices=False)
+                    c.render_device(_params(cam, flags=capi.RENDER_ASYNC), b.data_ptr())
+                c.sync()
+                torch.cuda.synchronize()
+                for k, b in enumerate(bufs):
+                    assert np.array_equal(b.cpu().numpy().reshape(h, w, 4), want[k]), (spec_on, batch, lap, k)
+            s = c.stats()
+            got_sync = []
+            for cam in (cams[3], cams[14], cams[4]):                        # synchronous frames: a near-only order, flagged or not
+                c.sort(cam["view"], want_indices=False); got_sync.append(c.render(_params(cam)))
+            assert np.array_equal(got_sync[0], want[3]) and np.array_equal(got_sync[1], want[14]) and np.array_equal(got_sync[2], want[4])
+            return s
+
+    for batch in (1, 2):
+        s = run(True, batch)
+        print("speculative stash, batch %d: %d sorts by it, %d missed, %d frames drawn again, share %d permille" %
+              (batch, s["spec_sorts"], s["spec_misses"], s["retried_frames"], s["near_permille"]))
+        assert s["spec_sorts"] > 0, s                                       # the path really ran ...
+        assert s["spec_misses"] < s["spec_sorts"], s                        # ... and vouched for most of its frames
+    s = run(False, 2)
+    assert s["spec_sorts"] == 0 and s["spec_misses"] == 0, s
 
 
 def test_scene_depth_and_colour_compositing(ctx, scene_small):

@@ -22,8 +22,8 @@ for name, s, e in rows:
     ev.append((s2, 1)); ev.append((e2, -1))
     short = re.sub(r"^.*?(F_\w+(?:<[^>]*>)?|k_(?!twin)\w+(?:<[^>]*>)?).*$", r"\1", name)[:40]
     per[short] = per.get(short, 0.0) + (e2 - s2)
-    if "blend" in short and "1," not in short:
-        blends += 1
+    if "blend" in short and "Li1E" not in short and "1," not in short:
+        blends += fpl if short.startswith("F_") else 1            # (a k_twin launch draws fpl frames)
 ev.sort()
 occ = {}
 cur, last = 0, a
@@ -32,7 +32,7 @@ for t, d in ev:
     cur += d; last = t
 occ[min(cur, 4)] = occ.get(min(cur, 4), 0.0) + (b - last)
 wall = b - a
-frames = max(1, blends * fpl)
+frames = max(1, blends)
 print("window %.1f ms, ~%d frames (%.1f us per frame)" % (wall / 1e6, frames, wall / 1e3 / frames))
 print("kernels in flight:", "  ".join("%s: %.1f %%" % (("%d" % k if k < 4 else "4+"), 100.0 * v / wall) for k, v in sorted(occ.items())))
 print("summed kernel time per frame: %.1f us" % (sum(per.values()) / 1e3 / frames))
@@ -70,3 +70,18 @@ if q:
         print("all-idle intervals: %d, total %.1f %% of the window; median %.1f us, p90 %.1f us, max %.1f us; intervals > 20 us: %d (%.1f %% of the window)" % (
             len(idle), 100.0 * tot / wall, idle[len(idle) // 2] / 1e3, idle[int(len(idle) * 0.9)] / 1e3, idle[-1] / 1e3,
             sum(1 for x in idle if x > 20000), 100.0 * sum(x for x in idle if x > 20000) / wall))
+
+# ---- which kernel boundaries carry a queue's idle time (same queue, consecutive dispatches)
+if q:
+    agg = {}
+    for qu, lst in byq.items():
+        for i in range(len(lst) - 1):
+            g = lst[i + 1][0] - lst[i][1]
+            if g <= 0:
+                continue
+            sh = lambda n: re.sub(r"^.*?(F_\w+|k_(?!twin)\w+).*$", r"\1", n)[:18]
+            k = sh(lst[i][2]) + " -> " + sh(lst[i + 1][2])
+            a_ = agg.setdefault(k, [0, 0.0]); a_[0] += 1; a_[1] += g
+    print("idle time of the queues by kernel boundary (sum over queues; share of window x queues):")
+    for k, (n_, t_) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:10]:
+        print("  %-40s %6d gaps  avg %6.1f us  %5.1f %%" % (k, n_, t_ / n_ / 1e3, 100.0 * t_ / (wall * max(1, len(byq)))))

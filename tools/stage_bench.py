@@ -107,7 +107,8 @@ if a.pmc_run:
 for depth in (int(v) for v in a.depths.split(",")):
     ctx.set_option(capi.OPT_PIPELINE_DEPTH, depth)
     ctx.set_option(capi.OPT_PROFILE, 0)
-    go(24); go(24)
+    for _ in range(6 if a.near == 0 else 2):                 # (adaptive share: a failure holds the second round on for 32 collected frames,
+        go(24)                                               # then 16 clean ones: the loop below should run in the settled state)
     t = go(a.frames) or go(a.frames)
     ctx.set_option(capi.OPT_PROFILE, 1)
     go(24); go(min(a.frames, 120))
