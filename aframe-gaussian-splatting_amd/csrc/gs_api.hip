@@ -276,9 +276,13 @@ static int collect_status(gs_ctx *lane, bool *overflowed, bool *share_failed = n
     // re-binned for them): the share grows x1.5 and will never again shrink below 1.3 x the share that failed; without
     // events it shrinks 10 % per collected frame until the first event, 2 % afterwards.  After 16 clean frames round 1 is not even launched (11 empty kernels
     // cost ~50 us): blend<0> raises round1_missed if that was wrong, and the frame is completed / re-rendered.
-    if (ctx->adapt_frozen) {
+    if (ctx->adapt_frozen || c->order_incomplete) {
         // gs_sync is drawing flagged frames again (redraw_flagged_frames) with the uniforms they were queued with: their share has
-        // been dealt with once already -- every one of them would count as a new failure and multiply the share by 1.5
+        // been dealt with once already -- every one of them would count as a new failure and multiply the share by 1.5.
+        // order_incomplete: the frames were drawn from an order that lacked splats (a stash overflowed, the speculative stash could
+        // not be vouched for): tiles that did not saturate say nothing about the SHARE -- the frames are drawn again from a whole
+        // sort either way.  (Counting them raised the share 23 -> 40 permille outside the cloud at 20 M, past the 1/32 the chunk
+        // stashes need: 3 718 -> 1 898 frames/s for good, after one overflow.)
         lane->seen_unsat_events = c->unsat_events; lane->seen_acc_frames = c->acc_frames;
     } else if (ctx->near_fixed_permille <= 0 && lane->stats.n_tiles) {
         const uint32_t events = c->unsat_events - lane->seen_unsat_events;
@@ -317,6 +321,8 @@ static int collect_status(gs_ctx *lane, bool *overflowed, bool *share_failed = n
         // a near-only sort could not vouch for the candidates its depth pass had stashed (the frame was flagged and is drawn again
         // from a whole sort).  1: the hint was behind -- it is exact now; 2: this scene does not suit the path
         if (c->spec_fail == 2u) ctx->near_spec_off = true;
+        // a camera that keeps outrunning the hint: every miss costs the redraw of the lane's logged frames
+        if (ctx->stats.spec_misses > 4u && ctx->stats.spec_misses * 8u > ctx->stats.spec_sorts) ctx->near_spec_off = true;
         GS_HIP(hipMemsetAsync(&lane->ctl->spec_fail, 0, sizeof(uint32_t), lane->stream));
     }
     lane->stats.unsat_tiles = lane->last_two_rounds ? c->unsat_round0 : 0;
