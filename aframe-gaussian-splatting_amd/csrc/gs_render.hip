@@ -1064,6 +1064,26 @@ __global__ __launch_bounds__(GS_BLOCK) void k_lists(const uint32_t *__restrict__
 #endif
 typedef float f2 __attribute__((ext_vector_type(2)));            // two pixels per packed-fp32 instruction (v_pk_*_f32)
 __device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+// fma2(a, (f2)(b.x), (f2)(c.x)) / fma2(a, (f2)(b.y), (f2)(c.y)): both halves of the result take the LOW / HIGH words of b and c
+__device__ __forceinline__ f2 fma2_lo12(f2 a, f2 b, f2 c)
+{
+    f2 r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ f2 fma2_hi12(f2 a, f2 b, f2 c)
+{
+    f2 r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,1]" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+// fma2((f2)(a.y), b, c): both halves of the result take the HIGH word of a (v_pk_fma_f32 op_sel:[1,0,0])
+__device__ __forceinline__ f2 fma2_hi0(f2 a, f2 b, f2 c)
+{
+    f2 r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0]" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
 
 // SCENE: the opaque scene's depth buffer (fragment kept iff its window depth <= the buffer: depthTest LEQUAL,
 // depthWrite off, index.js:179-180) and/or colour image (the destination the splats are blended over).
@@ -1142,19 +1162,23 @@ __device__ __forceinline__ void k_blend_body(const uint2 *__restrict__ tile_rang
                 const uint32_t j = u.pair_jbits ? pair_j_lo + (reinterpret_cast<const uint32_t *>(pairs)[end - 1 - slot] & pair_j_mask)
                                                 : reinterpret_cast<const uint2 *>(pairs)[end - 1 - slot].y;
                 const float4 *src = reinterpret_cast<const float4 *>(proj + j);
-                const float4 rb = src[1];
-                s_ent[3 * slot] = src[0];
-                s_ent[3 * slot + 1] = rb;
+                const float4 ra = src[0], rb = src[1];
+                // (cx, cy, ax, bx | ay, by, -, -): the two coefficients a row shares with dy sit in one register pair, so that
+                // dy * (ay, by) is one packed multiplication, and so do the two that multiply dx
+                s_ent[3 * slot] = make_float4(ra.x, ra.y, ra.z, rb.x);
+                s_ent[3 * slot + 1] = make_float4(ra.w, rb.y, 0.0f, 0.0f);
                 // what every lane would otherwise redo for every list entry: unpack the colour, fold alpha / 255 into it
                 const uint32_t rgba = __float_as_uint(rb.z);
                 const float a255 = rb.w * (1.0f / 255.0f);
-                s_ent[3 * slot + 2] = make_float4((float)(rgba & 0xFF) * a255, (float)((rgba >> 8) & 0xFF) * a255, (float)((rgba >> 16) & 0xFF) * a255, rb.w);
+                // (-alpha: T <- T - alpha * e is one packed fma with the record's word as it stands; with +alpha and a negate modifier the
+                // compiler copies the word to a register of its own first, one VALU instruction per list entry)
+                s_ent[3 * slot + 2] = make_float4(-rb.w, (float)(rgba & 0xFF) * a255, (float)((rgba >> 8) & 0xFF) * a255, (float)((rgba >> 16) & 0xFF) * a255);
                 if (SCENE) s_z[slot] = u.has_depth ? zwin[j] : 0.0f;
             }
         }
         if (lane == 0 && (nb & 1)) {
             if (SCENE) s_z[nb] = 0.0f;                               // pad an odd batch with a record no pixel can pass
-            s_ent[3 * nb] = make_float4(-1.0e9f, -1.0e9f, 1.0f, 1.0f);   // centre far away, a = (1,1): q ~ 1e18 > 4
+            s_ent[3 * nb] = make_float4(-1.0e9f, -1.0e9f, 1.0f, 1.0f);   // centre far away, a = b = (1,1): q ~ 1e18 > 4
             s_ent[3 * nb + 1] = make_float4(1.0f, 1.0f, 0.0f, 0.0f);
             s_ent[3 * nb + 2] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         }
@@ -1163,34 +1187,44 @@ __device__ __forceinline__ void k_blend_body(const uint2 *__restrict__ tile_rang
             // Two splats per step: their coverage tests are independent, so the second one's LDS read + ~13-instruction
             // dependent chain overlaps the first one's (the per-step latency, not issue bandwidth, bounds a tile that
             // runs alone in the kernel's tail).  Blending is still applied strictly in list order.
-            uint32_t s = 0;
 #ifndef GS_BLEND_SPLATS_PER_STEP
 #define GS_BLEND_SPLATS_PER_STEP 2
 #endif
-            for (; s < nb; s += GS_BLEND_SPLATS_PER_STEP) {
-                const float4 a0 = s_ent[3 * s]; const float2 b0 = *reinterpret_cast<const float2 *>(&s_ent[3 * s + 1]);
-                const float dy0 = fy - a0.y;
-                const float dyay0 = dy0 * a0.w, dyby0 = dy0 * b0.y;
-                // |p|^2 of the interpolated vPosition, same expression tree per pixel as gsm::frag_power
-                const f2 dxA0 = fxA - a0.x, dxB0 = fxB - a0.x;
-                const f2 pxA0 = fma2(dxA0, (f2)(a0.z), (f2)(dyay0)), pxB0 = fma2(dxB0, (f2)(a0.z), (f2)(dyay0));
-                const f2 pyA0 = fma2(dxA0, (f2)(b0.x), (f2)(dyby0)), pyB0 = fma2(dxB0, (f2)(b0.x), (f2)(dyby0));
-                const f2 qA0 = fma2(pxA0, pxA0, pyA0 * pyA0), qB0 = fma2(pxB0, pxB0, pyB0 * pyB0);   // -A, index.js:171
+            // the LDS address of the step's first entry, kept in a VECTOR register (the empty asm hides that it is uniform): left to
+            // itself the compiler keeps it in a scalar register and copies it to a vector register before each of the step's three
+            // groups of reads -- 1.5 VALU instructions per list entry of the ~44.5
+            uint32_t vo = 0;
+            asm volatile("" : "+v"(vo));
+            const uint32_t vend = nb * 48u;
+            for (; vo < vend; vo += 48u * GS_BLEND_SPLATS_PER_STEP) {
+                const char *eb = reinterpret_cast<const char *>(s_ent) + vo;
+#define GS_ENT4(k) (*reinterpret_cast<const float4 *>(eb + 16 * (k)))
+#define GS_ENT2(k) (*reinterpret_cast<const float2 *>(eb + 16 * (k)))
+                // |p|^2 of the interpolated vPosition, same expression tree per pixel as gsm::frag_power:
+                //   px = dx * ax + dy * ay, py = dx * bx + dy * by, q = px * px + py * py            (-A, index.js:171)
+#define GS_BLEND_Q(K, qA, qB)                                                                                          \
+                const float4 a_##K = GS_ENT4(3 * (K)); const f2 ab_##K = *reinterpret_cast<const f2 *>(eb + 48 * (K) + 16);  \
+                const f2 axbx_##K = { a_##K.z, a_##K.w };                                                               \
+                const f2 dyab_##K = (f2)(fy - a_##K.y) * ab_##K;     /* (dy * ay, dy * by) */                          \
+                const f2 dxA_##K = fxA - a_##K.x, dxB_##K = fxB - a_##K.x;                                              \
+                const f2 pxA_##K = fma2_lo12(dxA_##K, axbx_##K, dyab_##K), pxB_##K = fma2_lo12(dxB_##K, axbx_##K, dyab_##K); \
+                const f2 pyA_##K = fma2_hi12(dxA_##K, axbx_##K, dyab_##K), pyB_##K = fma2_hi12(dxB_##K, axbx_##K, dyab_##K); \
+                const f2 qA = fma2(pxA_##K, pxA_##K, pyA_##K * pyA_##K), qB = fma2(pxB_##K, pxB_##K, pyB_##K * pyB_##K);
+                GS_BLEND_Q(0, qA0, qB0)
 #if GS_BLEND_SPLATS_PER_STEP == 2
-                const float4 a1 = s_ent[3 * s + 3]; const float2 b1 = *reinterpret_cast<const float2 *>(&s_ent[3 * s + 4]);   // slot nb holds an inert record when nb is odd
-                const float dy1 = fy - a1.y;
-                const float dyay1 = dy1 * a1.w, dyby1 = dy1 * b1.y;
-                const f2 dxA1 = fxA - a1.x, dxB1 = fxB - a1.x;
-                const f2 pxA1 = fma2(dxA1, (f2)(a1.z), (f2)(dyay1)), pxB1 = fma2(dxB1, (f2)(a1.z), (f2)(dyay1));
-                const f2 pyA1 = fma2(dxA1, (f2)(b1.x), (f2)(dyby1)), pyB1 = fma2(dxB1, (f2)(b1.x), (f2)(dyby1));
-                const f2 qA1 = fma2(pxA1, pxA1, pyA1 * pyA1), qB1 = fma2(pxB1, pxB1, pyB1 * pyB1);
+                GS_BLEND_Q(1, qA1, qB1)                               // slot nb holds an inert record when nb is odd
 #endif
+#undef GS_BLEND_Q
 #define GS_BLEND_APPLY(qA, qB, cc, zz)                                                                                 \
                 {                                                                                                      \
                     bool p0 = qA.x <= qmA.x, p1 = qA.y <= qmA.y, p2 = qB.x <= qmB.x, p3 = qB.y <= qmB.y;               \
                     if (SCENE) { p0 = p0 && zz <= zb0; p1 = p1 && zz <= zb1; p2 = p2 && zz <= zb2; p3 = p3 && zz <= zb3; } \
                     if (live & (p0 | p1 | p2 | p3)) {                  /* discard test, index.js:172 */                \
-                        const float alpha = cc.w;                                                                      \
+                        /* the colour record as two 8-byte halves: the compiler splats .x / .y of a register pair through \
+                           op_sel but copies the fourth word of a 16-byte read to a register of its own first */      \
+                        const float2 cl_ = *reinterpret_cast<const float2 *>(eb + 16 * (cc));                          \
+                        const float2 ch_ = *reinterpret_cast<const float2 *>(eb + 16 * (cc) + 8);                      \
+                        const float nalpha = cl_.x;                  /* -alpha (staging) */                          \
                         /* exp(A) (index.js:173); 0 for the pixels of this lane that the splat misses */               \
                         /* (= __expf(-q): v_exp_f32 of q * -log2(e), the four multiplications as two packed ones) */   \
                         const f2 tA = qA * (f2)(-1.44269502f), tB = qB * (f2)(-1.44269502f);                            \
@@ -1199,26 +1233,30 @@ __device__ __forceinline__ void k_blend_body(const uint2 *__restrict__ tile_rang
                         /* fragment alpha B = exp(A)*vColor.a; its weight under what is in front: w = B*T.  T <- T - w \
                            (= T*(1-B)), colour += (rgb8 * alpha/255) * (exp(A)*T) with the bracket converted at staging */ \
                         const f2 eA = EA * TA, eB = EB * TB;                                                           \
-                        TA = fma2((f2)(-alpha), eA, TA); TB = fma2((f2)(-alpha), eB, TB);                              \
-                        crA = fma2((f2)(cc.x), eA, crA); crB = fma2((f2)(cc.x), eB, crB);                              \
-                        cgA = fma2((f2)(cc.y), eA, cgA); cgB = fma2((f2)(cc.y), eB, cgB);                              \
-                        cbA = fma2((f2)(cc.z), eA, cbA); cbB = fma2((f2)(cc.z), eB, cbB);                              \
+                        TA = fma2((f2)(nalpha), eA, TA); TB = fma2((f2)(nalpha), eB, TB);                              \
+                        crA = fma2((f2)(cl_.y), eA, crA); crB = fma2((f2)(cl_.y), eB, crB);                            \
+                        cgA = fma2((f2)(ch_.x), eA, cgA); cgB = fma2((f2)(ch_.x), eB, cgB);                            \
+                        /* (the compiler splats the high word of the FIRST pair through op_sel but copies the second    \
+                           pair's to a fresh register: the same packed fma, the selection written out) */              \
+                        const f2 chv_ = { ch_.x, ch_.y };                                                              \
+                        cbA = fma2_hi0(chv_, eA, cbA); cbB = fma2_hi0(chv_, eB, cbB);                                  \
                         if (COUNT) nfr += (uint32_t)p0 + (uint32_t)p1 + (uint32_t)p2 + (uint32_t)p3;                   \
                         live = GS_LANE_LIVE();                                                                         \
                     }                                                                                                  \
                 }
+                const uint32_t s = SCENE ? vo / 48u : 0u;               // (the entry's index: only the scene's depth test needs it)
                 const float z0 = SCENE ? s_z[s] : 0.0f;
-                const float4 c0 = s_ent[3 * s + 2];
-                GS_BLEND_APPLY(qA0, qB0, c0, z0)
+                GS_BLEND_APPLY(qA0, qB0, 2, z0)
 #if GS_BLEND_SPLATS_PER_STEP == 2
                 const float z1 = SCENE ? s_z[s + 1] : 0.0f;
-                const float4 c1 = s_ent[3 * s + 5];
-                GS_BLEND_APPLY(qA1, qB1, c1, z1)
+                GS_BLEND_APPLY(qA1, qB1, 5, z1)
 #endif
 #undef GS_BLEND_APPLY
+#undef GS_ENT4
+#undef GS_ENT2
                 if (!live) break;
             }
-            if (u.record_staged == 2) evaluated += min(s + GS_BLEND_SPLATS_PER_STEP, nb);   // list entries this lane evaluated (measurement aid)
+            if (u.record_staged == 2) evaluated += min(vo / 48u + GS_BLEND_SPLATS_PER_STEP, nb);   // list entries this lane evaluated (measurement aid)
         }
         end -= nb;
         __syncthreads();                                           // s_ent is rewritten by the next batch
@@ -1383,7 +1421,9 @@ __device__ __forceinline__ void k_blend_px_body(const uint2 *__restrict__ tile_r
                     // what every lane would otherwise redo for every list entry: unpack the colour, fold alpha / 255 into it
                     const uint32_t rgba = __float_as_uint(n1[h].z);
                     const float a255 = n1[h].w * (1.0f / 255.0f);
-                    s_col[slot] = make_float4((float)(rgba & 0xFF) * a255, (float)((rgba >> 8) & 0xFF) * a255, (float)((rgba >> 16) & 0xFF) * a255, n1[h].w);
+                    // (r, -alpha, g, b: the compiler pairs (cr, T) and (cg, cb) for packed fmas -- stored like this the record's words
+                    // are those pairs' multipliers as they stand; with (r, g, b, alpha) it spent a negation and two copies per entry)
+                    s_col[slot] = make_float4((float)(rgba & 0xFF) * a255, -n1[h].w, (float)((rgba >> 8) & 0xFF) * a255, (float)((rgba >> 16) & 0xFF) * a255);
                     if (SCENE) s_z[slot] = nz[h];
                 } else if (slot < nbp) {                              // pad the batch to whole groups with records no pixel can pass
                     if (SCENE) s_z[slot] = 0.0f;
@@ -1422,8 +1462,8 @@ __device__ __forceinline__ void k_blend_px_body(const uint2 *__restrict__ tile_r
 #pragma unroll
                     for (uint32_t k = 0; k < GS_PX_GROUP; k++) {
                         const float e = E[k] * T;
-                        T = fmaf(-cc[k].w, e, T);
-                        cr = fmaf(cc[k].x, e, cr); cg = fmaf(cc[k].y, e, cg); cb = fmaf(cc[k].z, e, cb);
+                        T = fmaf(cc[k].y, e, T);
+                        cr = fmaf(cc[k].x, e, cr); cg = fmaf(cc[k].z, e, cg); cb = fmaf(cc[k].w, e, cb);
                     }
                     live = T >= t_eps;                                 // (checked per group: a few entries past the threshold, < t_eps in total)
                     if (!live) break;
