@@ -254,7 +254,20 @@ static void share_raise(gs_ctx *ctx /* owner */, float frac_used)
     ctx->clean_frames = 0; ctx->skip_hold = 32;
 }
 
-static int collect_status(gs_ctx *lane, bool *overflowed, bool *share_failed = nullptr)
+// the speculative stash of near-only sorts failed: at once out of use for a while if the view does not suit it (kind 2), at the second
+// miss within a few collections if the threshold bin keeps outrunning the hint -- one miss is a camera jump, two in a row are a view
+// whose threshold is not smooth (the 20 M cloud seen from outside: the bin moves by up to three from one 3-degree pose to the next), and
+// every miss costs the redraw of the lanes' logged frames.  (A collected sort that took the path pays one unit of the 24 back.)
+static void gs_spec_back_off(gs_ctx *ctx /* owner */, bool unsuited)
+{
+    ctx->near_spec_miss_credit += 24u;
+    if (!unsuited && ctx->near_spec_miss_credit <= 32u) return;
+    ctx->near_spec_miss_credit = 0;
+    ctx->near_spec_backoff = ctx->near_spec_backoff ? (ctx->near_spec_backoff >= 32768u ? 65536u : ctx->near_spec_backoff * 2u) : 512u;
+    __atomic_store_n(&ctx->near_spec_hold, ctx->near_spec_backoff, __ATOMIC_RELAXED);
+}
+
+static int collect_status(gs_ctx *lane, bool *overflowed, bool *share_failed = nullptr, uint32_t *spec_failed = nullptr)
 {
     gs_ctx *ctx = gs_root(lane);                                // the adaptive share is one state for all lanes ...
     const GsControl *c = lane->ctl_host;                        // ... fed by each lane's own counters
@@ -311,18 +324,22 @@ static int collect_status(gs_ctx *lane, bool *overflowed, bool *share_failed = n
     if (c->near_overflow) {
         // a chunk of a near-only sort had more survivors than its stash holds (the frame was flagged and is drawn again from a
         // whole sort): this context keeps to the whole-length passes from now on
-        ctx->near_stash_off = true;
+        __atomic_store_n(&ctx->near_stash_off, true, __ATOMIC_RELAXED);   // (the lanes' enqueue threads read these flags while they launch sorts)
         GS_HIP(hipMemsetAsync(&lane->ctl->near_overflow, 0, sizeof(uint32_t), lane->stream));
     }
-    if (c->near_sorted) ctx->near_spec = true;                   // a near-only sort has run: the threshold-bin hint exists (gs_near_spec_ok)
-    if (c->near_sorted == 2u) ctx->stats.spec_sorts++;
+    if (c->near_sorted) {
+        __atomic_store_n(&ctx->near_spec, true, __ATOMIC_RELAXED);    // a near-only sort has run: the threshold-bin hint exists (gs_near_spec_ok)
+        const uint32_t h = __atomic_load_n(&ctx->near_spec_hold, __ATOMIC_RELAXED);
+        if (h) __atomic_store_n(&ctx->near_spec_hold, h - 1u, __ATOMIC_RELAXED);
+    }
+    if (c->near_sorted == 2u) { ctx->stats.spec_sorts++; if (ctx->near_spec_miss_credit) ctx->near_spec_miss_credit--; }
     if (c->spec_fail) {
-        ctx->stats.spec_misses++;
         // a near-only sort could not vouch for the candidates its depth pass had stashed (the frame was flagged and is drawn again
-        // from a whole sort).  1: the hint was behind -- it is exact now; 2: this scene does not suit the path
-        if (c->spec_fail == 2u) ctx->near_spec_off = true;
-        // a camera that keeps outrunning the hint: every miss costs the redraw of the lane's logged frames
-        if (ctx->stats.spec_misses > 4u && ctx->stats.spec_misses * 8u > ctx->stats.spec_sorts) ctx->near_spec_off = true;
+        // from a whole sort).  1: the hint was behind -- it is exact now; 2: a stash overflowed / the depth range does not suit the path
+        ctx->stats.spec_misses++;
+        // (the frames a gs_sync collects were sorted by ONE hint: the lanes that missed it together -- a camera jump -- are one event)
+        if (spec_failed) { if (c->spec_fail > *spec_failed) *spec_failed = c->spec_fail; }
+        else gs_spec_back_off(ctx, c->spec_fail == 2u);
         GS_HIP(hipMemsetAsync(&lane->ctl->spec_fail, 0, sizeof(uint32_t), lane->stream));
     }
     lane->stats.unsat_tiles = lane->last_two_rounds ? c->unsat_round0 : 0;
@@ -806,7 +823,7 @@ GS_API int gs_clear(gs_ctx *ctx)
     TRY(drain_all(ctx));
     ctx->n = 0; ctx->renderable = true; ctx->pair_hint = 0; ctx->vis_hint = 0; ctx->run_hint = 0;
     ctx->near_frac = 0.25f; ctx->near_floor = 0.0f; ctx->clean_frames = 0; ctx->skip_hold = 0; ctx->single_round_frames = 0; ctx->last_kept = 0;
-    ctx->near_stash_off = false; ctx->near_spec = false; ctx->near_spec_off = false;
+    ctx->near_stash_off = false; ctx->near_spec = false; ctx->near_spec_hold = 0; ctx->near_spec_backoff = 0; ctx->near_spec_miss_credit = 0;
     for (int i = 0; i < GS_MAX_LANES; i++) {
         gs_ctx *L = ctx->lanes[i];
         if (!L) continue;
@@ -1147,8 +1164,8 @@ static int render_sync_on_lane(gs_ctx *ctx, const GsFrameUniforms &u, void *devi
             gs_ctx *P = gs_root(ctx);
             GS_HIP(hipMemsetAsync(&ctx->ctl->order_incomplete, 0, sizeof(uint32_t), ctx->stream));
             GS_HIP(hipMemsetAsync(&ctx->ctl->round1_missed, 0, sizeof(uint32_t), ctx->stream));
-            if (ctx->ctl_host->near_overflow) { P->near_stash_off = true; GS_HIP(hipMemsetAsync(&ctx->ctl->near_overflow, 0, sizeof(uint32_t), ctx->stream)); }
-            if (ctx->ctl_host->spec_fail) { P->stats.spec_misses++; if (ctx->ctl_host->spec_fail == 2u) P->near_spec_off = true; GS_HIP(hipMemsetAsync(&ctx->ctl->spec_fail, 0, sizeof(uint32_t), ctx->stream)); }
+            if (ctx->ctl_host->near_overflow) { __atomic_store_n(&P->near_stash_off, true, __ATOMIC_RELAXED); GS_HIP(hipMemsetAsync(&ctx->ctl->near_overflow, 0, sizeof(uint32_t), ctx->stream)); }
+            if (ctx->ctl_host->spec_fail) { P->stats.spec_misses++; gs_spec_back_off(P, ctx->ctl_host->spec_fail == 2u); GS_HIP(hipMemsetAsync(&ctx->ctl->spec_fail, 0, sizeof(uint32_t), ctx->stream)); }
             if (attempt >= 2) FAIL(GS_E_HIP, "the sorted order keeps coming back incomplete");
             TRY(gs_run_sort(ctx, ctx->sv_view, ctx->sv_has_cutout ? ctx->sv_cutout : nullptr, ctx->sv_has_strip ? &ctx->sv_strip : nullptr, 0));
             P->stats.retried_frames++;
@@ -1355,6 +1372,7 @@ GS_API int gs_sync(gs_ctx *ctx)
     CHECK_CTX(ctx);
     GS_HIP(hipSetDevice(ctx->device));
     bool any_missed = false, any_over = false, share_failed = false;
+    uint32_t spec_failed = 0;
     const float frac_used = ctx->near_frac;                       // what every frame queued since the last collection was drawn with
     // whatever way this call ends, the frames logged so far are not drawn again by a LATER gs_sync (their output buffers may be
     // gone by then): a failure below leaves no records behind
@@ -1386,19 +1404,20 @@ GS_API int gs_sync(gs_ctx *ctx)
         static const bool dbg_near = getenv("GS_DEBUG_NEAR") != nullptr;       // (what raised the share: printed per collected lane)
         if (dbg_near && (L->ctl_host->round1_missed || L->ctl_host->unsat_events != L->seen_unsat_events)) {
             const GsControl *c = L->ctl_host;
-            fprintf(stderr, "[gs] sync lane %d: missed %u unsat_events %u (seen %u) V %u P %u V' %u near_sorted %u req %u frames %u two_rounds %d near_frac %.4f clean %u hold %u\n", i, c->round1_missed,
+            fprintf(stderr, "[gs] sync lane %d: order_incomplete %u spec_fail %u (T %u chunk limit %u) near_overflow %u missed %u unsat_events %u (seen %u) V %u P %u V' %u near_sorted %u req %u frames %u two_rounds %d near_frac %.4f clean %u hold %u\n", i, c->order_incomplete, c->spec_fail, c->spec_dbg >> 16, c->spec_dbg & 0xFFFFu, c->near_overflow, c->round1_missed,
                     c->unsat_events, L->seen_unsat_events, c->n_kept, c->n_sorted, c->n_valid, c->near_sorted, L->sort_near_req, c->acc_frames, (int)L->last_two_rounds,
                     ctx->near_frac, ctx->clean_frames, ctx->skip_hold);
         }
         if (missed) LANE_HIP(L, hipMemsetAsync(&L->ctl->round1_missed, 0, sizeof(uint32_t), L->stream));
         if (L->ctl_host->order_incomplete) LANE_HIP(L, hipMemsetAsync(&L->ctl->order_incomplete, 0, sizeof(uint32_t), L->stream));
         bool over = false;
-        TRY(collect_status(L, &over, &share_failed));
+        TRY(collect_status(L, &over, &share_failed, &spec_failed));
         any_missed |= missed; any_over |= over;
         if (missed || over) bad_unit[i % GS_MAX_PRIMARY] = true;
         if (over && L->ctl_host->max_total > want) want = L->ctl_host->max_total;
     }
     if (share_failed) share_raise(ctx, frac_used);               // (once, whatever the number of lanes that saw it)
+    if (spec_failed) gs_spec_back_off(ctx, spec_failed == 2u);
     if (any_over)                                                // one retry for all lanes: each gets room for the largest demand seen
         for (int i = 0; i < GS_MAX_LANES; i++)
             if (ctx->lanes[i] && ctx->lanes[i]->pair_cap)

@@ -76,6 +76,7 @@ struct GsControl {
     uint32_t spec_fail;            // sticky: a near-only sort whose depth pass stashed the candidates itself (k_sort_depth<.., SPEC>) could not vouch for
                                    // them -- 1: the threshold hint was behind (transient), 2: a stash overflowed / the depth range does not suit
                                    // the path (the context stops using it); the frame is flagged order_incomplete + round1_missed (host clears)
+    uint32_t spec_dbg;             // (GS_DEBUG_NEAR) exact threshold bin << 16 | the limit of a chunk that failed the check
     uint32_t near_bin_hint;        // OWNER's block only: the threshold depth bin the context's last near-only sort found (any lane's kernels write it)
     uint32_t acc_frames;           // frames rendered since profiling was switched on
     unsigned long long acc_sorted, acc_visible, acc_pairs;   // sums of V, Vp, I over those frames
@@ -164,7 +165,12 @@ struct gs_ctx {
     float sv_view[4], sv_cutout[16]; bool sv_has_cutout, sv_has_strip; GsSortStrip sv_strip;
     int sort_near_opt;             // owner: GS_OPT_SORT_NEAR
     bool near_stash_off;           // owner: a chunk's stash overflowed once: near-only sorts keep to the two whole-length passes
-    bool near_spec, near_spec_off; // owner: a near-only sort has been collected (the hint exists) / the speculative stash failed for good on this scene
+    bool near_spec;                // owner: a near-only sort has been collected (the threshold-bin hint exists)
+    uint32_t near_spec_hold;       // owner: collections of near-only frames (one per lane and gs_sync) still to come before the speculative stash is tried again (0 = in use).  A sort
+                                   // that overflowed its candidate stash or a run of misses sets it to near_spec_backoff, which doubles each time
+                                   // (512 ... 65536): a scene the path does not suit pays one redraw in ever more frames, a camera that only
+                                   // passed through such a view gets the path back
+    uint32_t near_spec_backoff, near_spec_miss_credit;
     int near_spec_opt;             // owner: 0 = never stash speculatively (GS_SPEC_STASH=0 in the environment: A/B)
     uint32_t last_kept;            // owner: V of the last collected frame (a near-only sort pays only where V is well above the share read)
 

@@ -722,6 +722,7 @@ __device__ __forceinline__ void k_near_filter_body(const uint2 *__restrict__ sta
             // frame is drawn again from a whole sort; the hint is exact for the next one
             if (ctl->spec_fail != 2u) ctl->spec_fail = 1u;
             ctl->order_incomplete = 1u; ctl->round1_missed = 1u;
+            ctl->spec_dbg = (T << 16) | (cw >> 16);
         }
         uint2 rec[PER];
 #pragma unroll
@@ -840,15 +841,15 @@ static DepthHist next_depth_hist(gs_ctx *L, bool near)
 // at most 1/32 of the splats (a stash holds 1/8 of its chunk), and not after a stash has overflowed on this context
 static bool gs_near_stash_ok(const gs_ctx *L, uint32_t n, uint32_t near_req)
 {
-    return near_req && gs_radix_chunk(n) == GS_CHUNK_L && (uint64_t)near_req * 32u <= n && !gs_root(const_cast<gs_ctx *>(L))->near_stash_off &&
+    return near_req && gs_radix_chunk(n) == GS_CHUNK_L && (uint64_t)near_req * 32u <= n && !__atomic_load_n(&gs_root(const_cast<gs_ctx *>(L))->near_stash_off, __ATOMIC_RELAXED) &&
            (size_t)(gs_div_up(n, GS_CHUNK_L) + 1u) * GS_NEAR_STASH <= L->scratch_cap / 2;
 }
 // ... and may its depth pass stash the candidates itself (k_sort_depth<.., SPEC>)?  Only once a near-only sort of this context has
-// been collected (the hint exists); never again after the path failed for good on this scene
+// been collected (the hint exists), and not while the path is held back after a failure (gs_spec_back_off)
 static bool gs_near_spec_ok(const gs_ctx *L, uint32_t n)
 {
     const gs_ctx *P = gs_root(const_cast<gs_ctx *>(L));
-    return P->near_spec && !P->near_spec_off && P->near_spec_opt &&
+    return __atomic_load_n(&P->near_spec, __ATOMIC_RELAXED) && !__atomic_load_n(&P->near_spec_hold, __ATOMIC_RELAXED) && P->near_spec_opt &&
            (size_t)(gs_div_up(n, (uint32_t)(GS_DEPTH_IPT * GS_BLOCK)) + GS_SPEC_GROUP) * GS_SPEC_SLOT <= L->scratch_cap / 4 &&
            (size_t)gs_div_up(n, (uint32_t)(GS_DEPTH_IPT * GS_BLOCK)) * 2u + 64u <= L->hist_cap;
 }

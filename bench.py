@@ -888,6 +888,7 @@ def secondary_measurements(ctx, capi, synth, rows, cams, views, n_splats, args, 
                              "near_permille_after_first_lap": s1["near_permille"], "near_permille_after_second_lap": s2["near_permille"],
                              "frames_redrawn_by_sync": [s1.get("retried_frames", 0), s2.get("retried_frames", 0) - s1.get("retried_frames", 0)],
                              "sync_retry_requests": [a1, a2],
+                             "near_only_sorts_from_the_depth_pass_stash": [s2.get("spec_sorts", 0), s2.get("spec_misses", 0)],
                              "stages_second_lap": stage_pass(c3, cold, pc, ORBIT_FRAMES),
                              "note": "a context created for this measurement, frames queued (3 lanes x %d per launch), gs_sync every 24 frames, "
                                      "120 poses the library has not drawn before (yaw 1.5 + 3 i degrees), every frame a new pose; first lap includes "
@@ -902,6 +903,9 @@ def secondary_measurements(ctx, capi, synth, rows, cams, views, n_splats, args, 
         out["outside_cloud"] = {"fps": round(2 * ORBIT_FRAMES / t3, 1), "near_permille": s4["near_permille"], "unsat_tiles_last_frame": s4["unsat_tiles"],
                                 "tiles": s4["n_tiles"], "frames_redrawn_by_sync": s4.get("retried_frames", 0) - s3.get("retried_frames", 0),
                                 "sync_retry_requests": a3, "stages": stage_pass(c3, outside, po, ORBIT_FRAMES),
+                                "near_only_sorts_from_the_depth_pass_stash": [s4.get("spec_sorts", 0) - s3.get("spec_sorts", 0),
+                                                                              s4.get("spec_misses", 0) - s3.get("spec_misses", 0)],
+                                "sort_records_last_frame": s4.get("sort_records", 0), "V_last_frame": s4.get("n_sorted", 0),
                                 "workload": "the same %d splats seen from outside: entity %.1f units (3 sigma) in front of the camera, %dx%d, 120-pose "
                                             "orbit after one settling lap, frames queued, gs_sync every 48" % (n_splats, 7.5, W, H)}
     # ---- the rate a JavaScript caller sees at this size (north_star: the framebuffer goes back to JavaScript): node + the addon + the shim
