@@ -33,6 +33,14 @@ def test_random_program_with_near_only_sorts():
     _run("stress_lanes.py", 43, env={"STRESS_NEAR": "1"})
 
 
+@pytest.mark.skipif(os.environ.get("GS_SKIP_SLOW") == "1", reason="large configs")
+def test_random_program_on_four_million_splats_with_the_speculative_stash():
+    """4 M splats along an orbit with jumps: near-only sorts through the chunk stashes and through the depth pass' own candidate stash
+    (round 4), their misses, redraws and the back-off, mixed with synchronous frames that are checked against a fresh context"""
+    tail = _run("stress_lanes.py", 44, seconds=12, env={"STRESS_BIG": "1"}, timeout=400)
+    assert "sorts from the depth pass' own stash" in tail
+
+
 @pytest.mark.parametrize("world,seed", [(2, 51), (3, 52)])
 def test_random_program_over_ranks_in_process_transport(world, seed):
     _run("stress_ranks.py", seed, world)
@@ -53,13 +61,18 @@ def _tsan_lib():
     return lib, rt
 
 
-@pytest.mark.parametrize("script,args", [("stress_lanes.py", (41,)), ("stress_ranks.py", (52, 3))])
-def test_host_threading_under_thread_sanitizer(script, args):
+@pytest.mark.parametrize("script,args,extra", [("stress_lanes.py", (41,), {}), ("stress_ranks.py", (52, 3), {}),
+                                               ("stress_lanes.py", (45,), {"STRESS_BIG": "1", "STRESS_SECONDS": "10"})])
+def test_host_threading_under_thread_sanitizer(script, args, extra):
+    if extra and os.environ.get("GS_SKIP_SLOW") == "1":
+        pytest.skip("large configs")
     lib, rt = _tsan_lib()
     if not rt or not os.path.exists(rt):
         pytest.skip("no ThreadSanitizer runtime next to hipcc")
     e = dict(os.environ)
-    e.update({"STRESS_SECONDS": "4", "GS_SPLAT_LIB": lib, "LD_PRELOAD": rt,
+    e.update({"STRESS_SECONDS": "4"})
+    e.update(extra)
+    e.update({"GS_SPLAT_LIB": lib, "LD_PRELOAD": rt,
               "TSAN_OPTIONS": "report_signal_unsafe=0 exitcode=66 history_size=4 suppressions=" + os.path.join(ROOT, "tests", "tsan.supp")})
     p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", script)] + [str(a) for a in args], capture_output=True, text=True, timeout=400, env=e, cwd=ROOT)
     out = p.stdout + p.stderr

@@ -6,21 +6,31 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.ins
 capi = importlib.import_module("aframe-gaussian-splatting_amd.capi"); synth = importlib.import_module("aframe-gaussian-splatting_amd.synth")
 g = np.random.Generator(np.random.PCG64(int(sys.argv[1]) if len(sys.argv) > 1 else 1))
 NEAR = os.environ.get("STRESS_NEAR") == "1"                # a dense scene + GS_OPT_SORT_NEAR = 2: near-only sorts and their fall-backs
-rows = (synth.make_splat_rows(synth.N_TRAIN) if NEAR else synth.make_splat_rows(60000, seed=5)).reshape(-1, 32)
-W, H = 640, 360
-cams = [synth.index_html_camera(W, H, 15.0 * i, capi=capi) for i in range(24)]
+BIG = os.environ.get("STRESS_BIG") == "1"                  # 4 M splats, pixels stopping at T < 1/4: near-only sorts through the chunk stashes and through the
+                                                           # depth pass' own candidate stash (the hint, its misses, the back-off), an orbit with jumps
+if BIG:
+    NEAR = True
+rows = (synth.make_splat_rows(1 << 22, seed=synth.SEED_BASE + 11) if BIG else synth.make_splat_rows(synth.N_TRAIN) if NEAR else synth.make_splat_rows(60000, seed=5)).reshape(-1, 32)
+W, H = (1280, 720) if BIG else (640, 360)
+cams = [synth.index_html_camera(W, H, 3.0 * i, capi=capi) for i in range(120)] if BIG else [synth.index_html_camera(W, H, 15.0 * i, capi=capi) for i in range(24)]
 P = lambda cam, **kw: capi.make_params(cam["gs_mv"], cam["gs_proj"], W, H, focal_=cam["focal"], **kw)
 ref = capi.Context(0); ref.set_option(capi.OPT_PIPELINE_DEPTH, 1)
 c = capi.Context(0)
 c.set_option(capi.OPT_FRAME_BATCH, 2)                       # frames pair from the start; toggled at random below
-n = N0 = 700000 if NEAR else 20000
+n = N0 = (1 << 22) if BIG else 700000 if NEAR else 20000
 if NEAR:
     c.set_option(capi.OPT_SORT_NEAR, 2); ref.set_option(capi.OPT_SORT_NEAR, 0)
+if BIG:
+    c.set_option(capi.OPT_TERMINATION, 4); ref.set_option(capi.OPT_TERMINATION, 4)
+kk = 0
 c.push_splat(rows[:n]); ref.push_splat(rows[:n])
 near_sorts = 0
 t0 = time.time(); ops = 0; checked = 0
 while time.time() - t0 < float(os.environ.get("STRESS_SECONDS", "20")):
     r = g.random(); k = int(g.integers(0, len(cams))); ops += 1
+    if BIG:                                                  # mostly the next pose of the orbit (the hint follows), a jump one time in twelve
+        kk = k if g.random() < 0.08 else (kk + 1) % len(cams); k = kk
+        if r >= 0.86: r = 0.0 if g.random() < 0.9 else r     # (fewer option changes: the share has to settle for near-only sorts to start)
     try:
         if r < 0.70:
             c.sort(cams[k]["view"], None, want_indices=False); c.render_device(P(cams[k], flags=capi.RENDER_ASYNC), None)
@@ -56,5 +66,7 @@ while time.time() - t0 < float(os.environ.get("STRESS_SECONDS", "20")):
         if e.code != capi.E_RETRY: raise
 try: c.sync()
 except capi.GsError: pass
+st = c.stats()
 c.close(); ref.close()
-print("stress ok: %d operations, %d checked frames (%d on near-only sorts), %d splats" % (ops, checked, near_sorts, n))
+print("stress ok: %d operations, %d checked frames (%d on near-only sorts), %d splats%s" % (
+    ops, checked, near_sorts, n, "; %d sorts from the depth pass' own stash, %d missed, %d frames drawn again" % (st["spec_sorts"], st["spec_misses"], st["retried_frames"]) if BIG else ""))
