@@ -76,6 +76,18 @@ GS_HD bool in_cutout(const double *c, float xf, float yf, float zf)
     const double q2 = (((c[2] * x + c[6] * y) + c[10] * z) + c[14]) * w;
     return !(q0 < -0.5 || q0 > 0.5 || q1 < -0.5 || q1 > 0.5 || q2 < -0.5 || q2 > 0.5);
 }
+// the same test for a matrix whose last row is (0, 0, 0, 1) -- checked by the caller --: for finite positions w is exactly 1
+// (0 * x is a zero, the sum of zeros and 1 is 1, 1 / 1 is 1) and q * 1 is q: the division and its three products are left out
+GS_HD bool in_cutout_affine(const double *c, float xf, float yf, float zf)
+{
+    const float fin = (xf - xf) + (yf - yf) + (zf - zf);           // 0 iff all three are finite (inf - inf, nan - nan: NaN)
+    if (!(fin == 0.0f)) return in_cutout(c, xf, yf, zf);
+    const double x = xf, y = -(double)yf, z = zf;
+    const double q0 = ((c[0] * x + c[4] * y) + c[8] * z) + c[12];
+    const double q1 = ((c[1] * x + c[5] * y) + c[9] * z) + c[13];
+    const double q2 = ((c[2] * x + c[6] * y) + c[10] * z) + c[14];
+    return !(q0 < -0.5 || q0 > 0.5 || q1 < -0.5 || q1 > 0.5 || q2 < -0.5 || q2 > 0.5);
+}
 GS_HD bool in_cutout(const float *c, float xf, float yf, float zf)
 {
     double cd[16];

@@ -12,7 +12,7 @@
 namespace {
 
 struct SortUniforms {                                            // widened on the host (exact): scalar registers
-    double view[4]; double cutout[16]; int has_cutout;
+    double view[4]; double cutout[16]; int has_cutout;          // has_cutout 2: the matrix is affine (last row 0 0 0 1): gsm::in_cutout_affine
     int has_strip;
 };
 // gs_sort_for: rows 0, 1, 2 of gsModelViewMatrix, rows 0, 3 of gsProjectionMatrix, and the strip in pixels
@@ -30,6 +30,13 @@ __device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v,
     uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
     lo = __shfl_xor(lo, m, 64); hi = __shfl_xor(hi, m, 64);
     return ((unsigned long long)hi << 32) | lo;
+}
+// min / max of two doubles that are not NaN, one instruction each (the builtins first canonicalise both operands: three more)
+__device__ __forceinline__ double min_f64(double a, double b) { double r; asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ double max_f64(double a, double b) { double r; asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ double shfl_xor_f64(double v, int m)
+{
+    return __longlong_as_double((long long)shfl_xor_u64((unsigned long long)__double_as_longlong(v), m));
 }
 
 // Near-only sorts (gs_run_sort with near_req): the pass also histograms the kept depths by the top 11 bits of the stored f32
@@ -165,7 +172,9 @@ __device__ __forceinline__ void k_sort_depth_body(const float4 *__restrict__ row
     __syncthreads();
     constexpr uint32_t DCHUNK = GS_DEPTH_IPT * GS_BLOCK;         // this kernel's own chunking (no histogram depends on it)
     const uint32_t nchunks = (n + DCHUNK - 1) / DCHUNK;
-    unsigned long long mn = ~0ull, mx = 0ull;
+    // min / max of the kept depths as doubles (kept depths are finite and negative: sort_keep), encoded once per wavefront at the end
+    // -- on the ordered-u64 encoding a splat cost two 64-bit compares and four selects
+    double mn = INFINITY, mx = -INFINITY;
     uint32_t cnt = 0;
     for (uint32_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
         float4 mm[GS_DEPTH_IPT];                                     // all loads first: their latencies overlap
@@ -173,8 +182,11 @@ __device__ __forceinline__ void k_sort_depth_body(const float4 *__restrict__ row
 #pragma unroll
         for (int r = 0; r < GS_DEPTH_IPT; r++) {
             const uint32_t i = c * DCHUNK + r * GS_BLOCK + threadIdx.x;
-            mm[r] = i < n ? rows[i] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            sg[r] = (STRIP && i < n) ? bound_r[i] : 0.0f;
+            // (unconditional, the index clamped: a conditional load put each item's wait and f64 conversions into its own branch, so the
+            // four loads of a thread went out one after the other; items beyond n are dropped below)
+            const uint32_t ic = i < n ? i : n - 1u;
+            mm[r] = rows[ic];
+            sg[r] = STRIP ? bound_r[ic] : 0.0f;
         }
         uint32_t fb[GS_DEPTH_IPT];
         bool sp[GS_DEPTH_IPT];
@@ -186,7 +198,7 @@ __device__ __forceinline__ void k_sort_depth_body(const float4 *__restrict__ row
             if (i < n) {
                 const float4 m = mm[r];
                 const double d = gsm::view_depth(u.view, m.x, m.y, m.z);
-                const bool inside = u.has_cutout ? gsm::in_cutout(u.cutout, m.x, m.y, m.z) : true;
+                const bool inside = u.has_cutout ? (u.has_cutout == 2 ? gsm::in_cutout_affine(u.cutout, m.x, m.y, m.z) : gsm::in_cutout(u.cutout, m.x, m.y, m.z)) : true;
                 const bool keep = gsm::sort_keep(d, m.w, inside);
                 // the bucket scale comes from EVERY splat the reference keeps (index.js:552-553), so a strip's order is the
                 // reference's order restricted to the strip's splats; only those are handed on
@@ -195,8 +207,7 @@ __device__ __forceinline__ void k_sort_depth_body(const float4 *__restrict__ row
                 if (mine && dh.fill) atomicAdd(&s_dh[depth_bin((float)d)], 1u);
                 if (SPEC) { fb[r] = __float_as_uint((float)d); sp[r] = mine && depth_bin((float)d) <= spec_lim; }
                 if (keep) {
-                    const unsigned long long e = gsm::f64_to_ordered(d);
-                    mn = e < mn ? e : mn; mx = e > mx ? e : mx;
+                    mn = min_f64(mn, d); mx = max_f64(mx, d);
                     if (mine) cnt++;
                 }
             }
@@ -205,11 +216,13 @@ __device__ __forceinline__ void k_sort_depth_body(const float4 *__restrict__ row
     }
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) {                           // wavefront butterfly, then one LDS atomic per wave
-        const unsigned long long omn = shfl_xor_u64(mn, m), omx = shfl_xor_u64(mx, m);
+        const double omn = shfl_xor_f64(mn, m), omx = shfl_xor_f64(mx, m);
         mn = omn < mn ? omn : mn; mx = omx > mx ? omx : mx;
         cnt += __shfl_xor(cnt, m, 64);
     }
-    if ((threadIdx.x & 63) == 0 && mx) { atomicMin(&s_min, mn); atomicMax(&s_max, mx); atomicAdd(&s_cnt, cnt); }   // (mx != 0: the wave kept something)
+    if ((threadIdx.x & 63) == 0 && mx > -INFINITY) {              // (the wave kept something)
+        atomicMin(&s_min, gsm::f64_to_ordered(mn)); atomicMax(&s_max, gsm::f64_to_ordered(mx)); atomicAdd(&s_cnt, cnt);
+    }
     __syncthreads();
     if (threadIdx.x == 0) { part_min[blockIdx.x] = s_min; part_max[blockIdx.x] = s_max; part_cnt[blockIdx.x] = s_cnt; }
     depth_hist_end(dh, s_dh);
@@ -251,7 +264,7 @@ __global__ __launch_bounds__(GS_BLOCK) void k_sort_depth_pair(const float4 *__re
     __syncthreads();
     constexpr uint32_t DCHUNK = GS_DEPTH_IPT * GS_BLOCK;
     const uint32_t nchunks = (n + DCHUNK - 1) / DCHUNK;
-    unsigned long long mn0 = ~0ull, mx0 = 0ull, mn1 = ~0ull, mx1 = 0ull;
+    double mn0 = INFINITY, mx0 = -INFINITY, mn1 = INFINITY, mx1 = -INFINITY;
     uint32_t cnt0 = 0, cnt1 = 0;
     for (uint32_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
         float4 mm[GS_DEPTH_IPT];
@@ -259,8 +272,11 @@ __global__ __launch_bounds__(GS_BLOCK) void k_sort_depth_pair(const float4 *__re
 #pragma unroll
         for (int r = 0; r < GS_DEPTH_IPT; r++) {
             const uint32_t i = c * DCHUNK + r * GS_BLOCK + threadIdx.x;
-            mm[r] = i < n ? rows[i] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            sg[r] = (STRIP && i < n) ? bound_r[i] : 0.0f;
+            // (unconditional, the index clamped: a conditional load put each item's wait and f64 conversions into its own branch, so the
+            // four loads of a thread went out one after the other; items beyond n are dropped below)
+            const uint32_t ic = i < n ? i : n - 1u;
+            mm[r] = rows[ic];
+            sg[r] = STRIP ? bound_r[ic] : 0.0f;
         }
         uint32_t fb0[GS_DEPTH_IPT], fb1[GS_DEPTH_IPT];
         bool sp0[GS_DEPTH_IPT], sp1[GS_DEPTH_IPT];
@@ -273,13 +289,13 @@ __global__ __launch_bounds__(GS_BLOCK) void k_sort_depth_pair(const float4 *__re
                 const float4 m = mm[r];
 #define GS_DEPTH_ONE(U, SU, OUT, MN, MX, CNT, DH, SDH, FB, SP, LIM) do {                                                \
                     const double d = gsm::view_depth(U.view, m.x, m.y, m.z);                                               \
-                    const bool inside = U.has_cutout ? gsm::in_cutout(U.cutout, m.x, m.y, m.z) : true;                     \
+                    const bool inside = U.has_cutout ? (U.has_cutout == 2 ? gsm::in_cutout_affine(U.cutout, m.x, m.y, m.z) : gsm::in_cutout(U.cutout, m.x, m.y, m.z)) : true; \
                     const bool keep = gsm::sort_keep(d, m.w, inside);                                                      \
                     const bool mine = keep && (!STRIP || strip_may_touch(SU, m.x, m.y, m.z, sg[r]));            \
                     if (!SPEC) OUT[i] = mine ? (float)d : INFINITY;                                                        \
                     if (mine && DH.fill) atomicAdd(&SDH[depth_bin((float)d)], 1u);                                         \
                     if (SPEC) { FB[r] = __float_as_uint((float)d); SP[r] = mine && depth_bin((float)d) <= LIM; }           \
-                    if (keep) { const unsigned long long e = gsm::f64_to_ordered(d); MN = e < MN ? e : MN; MX = e > MX ? e : MX; if (mine) CNT++; } \
+                    if (keep) { MN = min_f64(MN, d); MX = max_f64(MX, d); if (mine) CNT++; }                                 \
                 } while (0)
                 GS_DEPTH_ONE(u0, su0, depth0, mn0, mx0, cnt0, dh0, s_dh0, fb0, sp0, lim0);
                 GS_DEPTH_ONE(u1, su1, depth1, mn1, mx1, cnt1, dh1, s_dh1, fb1, sp1, lim1);
@@ -293,13 +309,13 @@ __global__ __launch_bounds__(GS_BLOCK) void k_sort_depth_pair(const float4 *__re
     }
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) {
-        const unsigned long long a0 = shfl_xor_u64(mn0, m), b0 = shfl_xor_u64(mx0, m), a1 = shfl_xor_u64(mn1, m), b1 = shfl_xor_u64(mx1, m);
+        const double a0 = shfl_xor_f64(mn0, m), b0 = shfl_xor_f64(mx0, m), a1 = shfl_xor_f64(mn1, m), b1 = shfl_xor_f64(mx1, m);
         mn0 = a0 < mn0 ? a0 : mn0; mx0 = b0 > mx0 ? b0 : mx0; mn1 = a1 < mn1 ? a1 : mn1; mx1 = b1 > mx1 ? b1 : mx1;
         cnt0 += __shfl_xor(cnt0, m, 64); cnt1 += __shfl_xor(cnt1, m, 64);
     }
     if ((threadIdx.x & 63) == 0) {
-        if (mx0) { atomicMin(&s_min[0], mn0); atomicMax(&s_max[0], mx0); atomicAdd(&s_cnt[0], cnt0); }
-        if (mx1) { atomicMin(&s_min[1], mn1); atomicMax(&s_max[1], mx1); atomicAdd(&s_cnt[1], cnt1); }
+        if (mx0 > -INFINITY) { atomicMin(&s_min[0], gsm::f64_to_ordered(mn0)); atomicMax(&s_max[0], gsm::f64_to_ordered(mx0)); atomicAdd(&s_cnt[0], cnt0); }
+        if (mx1 > -INFINITY) { atomicMin(&s_min[1], gsm::f64_to_ordered(mn1)); atomicMax(&s_max[1], gsm::f64_to_ordered(mx1)); atomicAdd(&s_cnt[1], cnt1); }
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -978,6 +994,9 @@ static void fill_sort_uniforms(const gs_ctx *ctx, const float view[4], const flo
     for (int i = 0; i < 4; i++) u.view[i] = (double)view[i];
     u.has_cutout = cutout16 != nullptr;
     for (int i = 0; i < 16; i++) u.cutout[i] = cutout16 ? (double)cutout16[i] : 0.0;
+    // an entity's inverse world matrix is affine: w = 1 / (0 x + 0 y + 0 z + 1) is exactly 1 for finite positions, the division and
+    // the three multiplications by it change nothing (in_cutout_affine takes the general path for a position that is not finite)
+    if (cutout16 && u.cutout[3] == 0.0 && u.cutout[7] == 0.0 && u.cutout[11] == 0.0 && u.cutout[15] == 1.0) u.has_cutout = 2;
     u.has_strip = 0;
     memset(&su, 0, sizeof su);
     if (strip && ctx->renderable) {
