@@ -94,6 +94,16 @@ int32_t hc_toint32(double d) { return gsm::js_toint32(d); }
 __attribute__((visibility("default")))
 int hc_xcd_chunk(uint32_t v, uint32_t nchunks, uint32_t *chunk) { return gsm::xcd_chunk(v, nchunks, *chunk) ? 1 : 0; }
 
+// positions (x, y, z) x n against an affine cut-out matrix: how many differ between the general test and the affine path
+__attribute__((visibility("default")))
+size_t hc_cutout_affine_mismatches(const float *pos3, size_t n, const double *c16)
+{
+    size_t bad = 0;
+    for (size_t i = 0; i < n; i++)
+        bad += gsm::in_cutout(c16, pos3[3 * i], pos3[3 * i + 1], pos3[3 * i + 2]) != gsm::in_cutout_affine(c16, pos3[3 * i], pos3[3 * i + 1], pos3[3 * i + 2]);
+    return bad;
+}
+
 __attribute__((visibility("default")))
 void hc_js_exp(const double *x, size_t n, double *out) { for (size_t i = 0; i < n; i++) out[i] = gsm::js_exp(x[i]); }
 }

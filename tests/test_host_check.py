@@ -64,6 +64,30 @@ def test_pack_matches_reference(hc, name):
     assert np.array_equal(sr.view(np.uint32), np.ascontiguousarray(ref_rows).view(np.uint32))
 
 
+def test_affine_cutout_path_equals_the_general_one(hc):
+    """round 4: a cut-out matrix whose last row is (0, 0, 0, 1) skips the perspective division (w is exactly 1 for finite
+    positions; a position that is not finite takes the general path).  Same answer for random boxes and positions incl. IEEE specials."""
+    hc.hc_cutout_affine_mismatches.restype = C.c_size_t
+    hc.hc_cutout_affine_mismatches.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
+    g = np.random.Generator(np.random.PCG64(20260927))
+    specials = np.array([0.0, -0.0, np.inf, -np.inf, np.nan, 1e-45, -1e-45, 3.4e38, -3.4e38, 0.5, -0.5, 1.0], np.float32)
+    for trial in range(40):
+        m = np.eye(4)
+        m[:3, :3] = g.normal(size=(3, 3)) * g.choice([0.05, 0.4, 1.0, 7.0])
+        m[:3, 3] = g.normal(size=3) * g.choice([0.0, 0.3, 3.0])
+        c16 = np.ascontiguousarray(m.T.reshape(-1), np.float64)        # column-major, last ROW (elements 3, 7, 11, 15) = 0 0 0 1
+        assert c16[3] == 0 and c16[7] == 0 and c16[11] == 0 and c16[15] == 1
+        pos = (g.normal(size=(20000, 3)) * g.choice([0.1, 1.0, 30.0])).astype(np.float32)
+        # positions on the faces of the box (|q| = 0.5 up to rounding): the boundary decides
+        inv = np.linalg.inv(m)
+        face = g.uniform(-0.5, 0.5, size=(4000, 3)); face[np.arange(4000), g.integers(0, 3, 4000)] = g.choice([-0.5, 0.5], 4000)
+        onface = (inv[:3, :3] @ face.T).T + inv[:3, 3]
+        onface[:, 1] *= -1.0                                           # (the test negates y: index.js:528)
+        sp = specials[g.integers(0, len(specials), size=(3000, 3))]
+        allpos = np.ascontiguousarray(np.concatenate([pos, onface.astype(np.float32), sp]), np.float32)
+        assert hc.hc_cutout_affine_mismatches(_p(allpos), allpos.shape[0], _p(c16)) == 0, trial
+
+
 def test_toint32(hc):
     for d, want in [(0.0, 0), (-0.9, 0), (65535.99, 65535), (-1.0, -1), (-393.7, -393), (2.0**31, -2**31), (2.0**32 + 5, 5),
                     (-(2.0**32) - 7, -7), (float("inf"), 0), (float("nan"), 0), (1e300, 0), (2.0**53 + 2, 2), (4294967295.0, -1)]:
