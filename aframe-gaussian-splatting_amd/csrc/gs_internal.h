@@ -7,6 +7,12 @@
 #include "../../include/gs_splat.h"
 #include "gs_device_math.h"
 
+// The kernels are written for gfx950 (CDNA4) and nothing else: wave64 ballots, packed-fp32 with op_sel, v_min_f64 / v_max_f64 and
+// s_waitcnt forms are written out as gfx9 inline assembly.  Another --offload-arch fails HERE, with a sentence, not in the assembler.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "libgs_splat_hip is written for gfx950 (MI355X) only: build with --offload-arch=gfx950"
+#endif
+
 // ---------------------------------------------------------------- geometry of the work decomposition
 #define GS_TILE 16                 // screen tile edge (pixels): 16x16 = one 256-thread workgroup
 #define GS_BLOCK 256               // threads per workgroup everywhere (4 wavefronts of 64)

@@ -1596,11 +1596,10 @@ int gs_ensure_row_tables(gs_ctx *ctx, size_t entries)
         GS_HIP(hipMalloc((void **)&ctx->row_cnt, cap * sizeof(uint32_t)));
         ctx->row_cnt_cap = cap;
     }
-    if (!ctx->row_tot) {
-        GS_HIP(hipMalloc((void **)&ctx->row_tot, GS_BLOCK * sizeof(uint2))); ctx->row_tot_cap = GS_BLOCK;
-        // (k_seg_count: a row of 256 ints per k_lists item; at most GS_LIST_SEGS items per tile row, at most 256 tile rows: 4.25 MB)
-        GS_HIP(hipMalloc((void **)&ctx->seg_diff, (size_t)GS_BLOCK * (GS_LIST_SEGS + 1u) * GS_BLOCK * sizeof(int)));
-    }
+    // (each table under its own check: a failed second allocation must not leave the first one vouching for both)
+    if (!ctx->row_tot) { GS_HIP(hipMalloc((void **)&ctx->row_tot, GS_BLOCK * sizeof(uint2))); ctx->row_tot_cap = GS_BLOCK; }
+    // (k_seg_count: a row of 256 ints per k_lists item; at most GS_LIST_SEGS items per tile row, at most 256 tile rows: 4.25 MB)
+    if (!ctx->seg_diff) GS_HIP(hipMalloc((void **)&ctx->seg_diff, (size_t)GS_BLOCK * (GS_LIST_SEGS + 1u) * GS_BLOCK * sizeof(int)));
     return GS_OK;
 }
 

@@ -619,7 +619,10 @@ static napi_value fn_sync(napi_env env, napi_callback_info info)
     if (!get_args(env, info, 1, argv, NULL)) return NULL;
     gs_ctx *ctx = get_ctx(env, argv[0]); if (!ctx) return NULL;
     int rc = gs_sync(ctx);
-    held_release(env, &get_handle(env, argv[0])->held);           /* (every queued frame has reached its buffer, whatever the status) */
+    /* GS_OK / GS_E_RETRY: every lane's stream has been waited for, every queued frame has reached its buffer.  Any other status may have
+     * left gs_sync early (a lane's failure is returned before the other lanes' streams are synchronised): a copy into one of the held
+     * buffers can still be in flight, so the references stay until the next sync that completes, a clear or the destroy (which drain) */
+    if (rc == GS_OK || rc == GS_E_RETRY) held_release(env, &get_handle(env, argv[0])->held);
     if (rc != GS_OK) return throw_gs(env, ctx, rc);
     return NULL;
 }
@@ -934,7 +937,7 @@ static napi_value fn_multi_sync(napi_env env, napi_callback_info info)
     if (!get_args(env, info, 1, argv, NULL)) return NULL;
     gs_mhandle *h = get_mhandle(env, argv[0], 1); if (!h) return NULL;
     int rc = gs_multi_sync(h->m);
-    held_release(env, &h->held);
+    if (rc == GS_OK || rc == GS_E_RETRY) held_release(env, &h->held);   /* (as fn_sync: kept while a copy may still be in flight) */
     if (rc != GS_OK) return throw_multi(env, h->m, rc);
     return NULL;
 }

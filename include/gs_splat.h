@@ -388,8 +388,9 @@ typedef struct gs_stats {
                                    8-byte (tile, position) records.  2: the visible-index form wherever it fits.                 */
 #define GS_OPT_BINNING 16       /* how a binning round turns visible splats into per-tile lists (same lists, same images).  0 (default): span
                                    lists -- every splat becomes one run of tiles per tile row it touches, and the runs of a tile row, in
-                                   sorted order, are expanded into the row's tile lists by one thread per tile column: three launches per
-                                   round, work per run -- wherever a strip has at most 256 tile columns and rows (4096 x 4096 pixels) and
+                                   sorted order, are expanded into the row's tile lists by one thread per tile column: four launches per
+                                   round (project, row scan, runs, lists; five with the segment counts of frames that hold many runs
+                                   per tile row), work per run -- wherever a strip has at most 256 tile columns and rows (4096 x 4096 pixels) and
                                    the round at most a few million sorted positions; elsewhere, and with 1: (tile, splat) pair records
                                    sorted by two stable radix passes (rounds 1-3; eight launches per round).  GS_OPT_WIDE_PAIRS != 0 asks
                                    for a record format and therefore for the records.                                            */
