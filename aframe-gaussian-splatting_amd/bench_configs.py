@@ -1,0 +1,154 @@
+"""The five BASELINE.json configurations as `bench.py` runs them -- ONE table, read by `bench.py` (what is measured) and by
+`tests/test_as_benched.py` (what is checked), so that the path a number is quoted on is the path a parity test has drawn.
+
+  C1  train.splat-shaped 1 M splats, 1280x720                  (BASELINE.json configs[0]; index.html:13 pose)
+  C2  the same scene, 1920x1080: the headline                  (configs[1])
+  C3  bicycle.ply-shaped 6 M splats, 1920x1080, cutoutEntity   (configs[2]; cutout-demo.html:22-24 pose and box)
+  C4  XR stereo 2 x (2064x2208 x xrPixelRatio 0.5)             (configs[3]; one shared head-camera sort, index.js:441)
+  C5  20 M splats, 3840x2160                                   (configs[4])
+
+Per configuration: the scene's recipe (generator + seed, SURVEY.md 8(d): seed = 0x5EED0000 + config -- C1 / C2 / C4 share the
+1 M scene, which is also what the GL goldens of tests/golden were drawn from), the viewport, the pose family, and the
+library options `bench.py` switches on for it.  Host-side plumbing only: nothing here is on the hot path.
+"""
+import os
+
+ORBIT_FRAMES = 120          # the benchmark orbit: entity yaw 360 i / 120 degrees
+LANES = 3                   # the library's default pipeline depth (GS_OPT_PIPELINE_DEPTH), what bench.py measures with
+PUSH_ROWS = 1 << 22         # progressive ingest (index.js:279-298): rows per gs_push_splat
+
+_SEED_BASE = 0x5EED0000
+
+# option names are resolved against capi (OPT_*) when they are applied: this module imports nothing of the product
+CONFIGS = {
+    "C1": {"splats": 1 << 20, "rows": ("make_splat_rows", {}), "size": (1280, 720), "pose": "index", "xr": False,
+           "options": {"OPT_FRAME_BATCH": 2}},
+    "C2": {"splats": 1 << 20, "rows": ("make_splat_rows", {}), "size": (1920, 1080), "pose": "index", "xr": False,
+           "options": {"OPT_FRAME_BATCH": 2}},
+    # the cut-out scene fills a tenth of the screen: ~600 active tiles with lists of thousands of entries.  Tiles with a list are
+    # blended by four wavefronts, one pixel per lane (GS_OPT_BLEND_SPLIT = 1: k_blend_px; images within the same 1 LSB tolerance)
+    "C3": {"splats": 6 * (1 << 20), "rows": ("make_splat_rows", {"seed": _SEED_BASE + 3}), "size": (1920, 1080), "pose": "cutout", "xr": False,
+           "options": {"OPT_FRAME_BATCH": 2, "OPT_BLEND_SPLIT": 1}},
+    # both eyes on one GPU: frames go through gs_sort_gathered / gs_render_gathered (world 1), the two views of a frame share launches
+    "C4": {"splats": 1 << 20, "rows": ("make_splat_rows", {}), "size": None, "pose": "xr", "xr": True,
+           "options": {"OPT_FRAME_BATCH": 2}},
+    # 20 M splats: near-only sorts (GS_OPT_SORT_NEAR's default from 4 M splats) through the depth pass' own candidate stash
+    "C5": {"splats": 20 * (1 << 20), "rows": ("make_splat_rows_fast", {}), "size": (3840, 2160), "pose": "index", "xr": False,
+           "options": {"OPT_FRAME_BATCH": 2}},
+}
+
+DESCRIPTION = {
+    "C1": "train.splat-shaped 1 M splats @1280x720 (configs[0])",
+    "C2": "train.splat-shaped 1 M splats @1920x1080 (configs[1], the headline)",
+    "C3": "bicycle.ply-shaped 6 M splats @1920x1080 + cutoutEntity box (configs[2])",
+    "C4": "XR stereo 2 x 1032x1104, one shared head-camera sort, both eyes on this GPU (configs[3])",
+    "C5": "20 M splats @3840x2160 on this one GPU (configs[4])",
+}
+
+
+def name_of(splats, size, cutout, xr):
+    """The table's name for what bench.py's flags describe, or None (a shape of the caller's own)."""
+    size = tuple(size) if size else None
+    for name, c in CONFIGS.items():
+        if bool(xr) != c["xr"]:
+            continue
+        if xr:
+            if splats in (None, c["splats"]) and not cutout:
+                return name
+            continue
+        if (splats or (1 << 20)) == c["splats"] and (size or (1920, 1080)) == c["size"] and bool(cutout) == (c["pose"] == "cutout"):
+            return name
+    return None
+
+
+def custom(splats, size, cutout, xr):
+    """A configuration of the caller's own shape (bench.py --splats / --size / --cutout), with the options its nearest table entry gets."""
+    return {"splats": splats or (1 << 20), "rows": ("make_splat_rows_fast" if (splats or 0) >= (8 << 20) else "make_splat_rows", {}),
+            "size": tuple(size) if size else (1920, 1080), "pose": "xr" if xr else ("cutout" if cutout else "index"), "xr": bool(xr),
+            "options": {"OPT_FRAME_BATCH": 2, **({"OPT_BLEND_SPLIT": 1} if cutout else {})}}
+
+
+def make_rows(cfg, synth, cache=None):
+    fn, kw = cfg["rows"]
+    if cache is not None:
+        return cache(fn, cfg["splats"], **kw)
+    return getattr(synth, fn)(cfg["splats"], **kw)
+
+
+def options_for(cfg, env=None, pieces_of_rank=1, gathered=False):
+    """{capi option name: value} bench.py sets for cfg.  The GS_BENCH_* environment knobs are experiment overrides (A/B runs);
+    a test passes env = {} and gets the table's own values."""
+    env = os.environ if env is None else env
+    o = dict(cfg["options"])
+    if env.get("GS_BENCH_BATCH"):
+        o["OPT_FRAME_BATCH"] = int(env["GS_BENCH_BATCH"])
+    if gathered and pieces_of_rank not in (1, 2):
+        o["OPT_FRAME_BATCH"] = 1                                  # (pairs: two frames of one piece each, or the two views of one frame)
+    if env.get("GS_BENCH_SPLIT") is not None and env.get("GS_BENCH_SPLIT") != "":
+        o["OPT_BLEND_SPLIT"] = int(env["GS_BENCH_SPLIT"])
+    if env.get("GS_BENCH_BINNING"):
+        o["OPT_BINNING"] = int(env["GS_BENCH_BINNING"])           # 1 = pair records + radix passes (rounds 1-3)
+    if env.get("GS_BENCH_DEPTH"):
+        o["OPT_PIPELINE_DEPTH"] = int(env["GS_BENCH_DEPTH"])      # frames in flight (library default 3)
+    if o.get("OPT_FRAME_BATCH") == 1:
+        o.pop("OPT_FRAME_BATCH")
+    if not o.get("OPT_BLEND_SPLIT"):
+        o.pop("OPT_BLEND_SPLIT", None)
+    return o
+
+
+def apply_options(ctx, capi, opts):
+    for k in sorted(opts):
+        ctx.set_option(getattr(capi, k), int(opts[k]))
+
+
+def push_rows(ctx, rows):
+    r32 = rows.reshape(-1, 32)
+    for o in range(0, r32.shape[0], PUSH_ROWS):
+        ctx.push_splat(r32[o:o + PUSH_ROWS])
+
+
+def poses(cfg, synth, capi, frames=None):
+    """The orbit of cfg: (cams, views, W, H).  cams[k]: the camera the SORT uses (the head camera for XR, index.js:441); views[k]:
+    the gs_render_params of the frame's view(s) -- one, or the two eyes."""
+    frames = range(ORBIT_FRAMES) if frames is None else frames
+    if cfg["xr"]:
+        rigs = {k: synth.xr_eye_cameras(360.0 * k / ORBIT_FRAMES, 0.5, capi=capi) for k in frames}
+        any_rig = next(iter(rigs.values()))
+        W, H = any_rig[0]["vw"], any_rig[0]["vh"]
+        cams = {k: r[2] for k, r in rigs.items()}
+        views = {k: [capi.make_params(e["gs_mv"], e["gs_proj"], W, H, focal_=e["focal"]) for e in r[:2]] for k, r in rigs.items()}
+    else:
+        W, H = cfg["size"]
+        pose = synth.cutout_demo_camera if cfg["pose"] == "cutout" else synth.index_html_camera
+        cams = {k: pose(W, H, 360.0 * k / ORBIT_FRAMES, capi=capi) for k in frames}
+        views = {k: [capi.make_params(c["gs_mv"], c["gs_proj"], W, H, focal_=c["focal"])] for k, c in cams.items()}
+    if isinstance(frames, range) and frames == range(ORBIT_FRAMES):
+        cams = [cams[k] for k in frames]
+        views = [views[k] for k in frames]
+    return cams, views, W, H
+
+
+def region_frames(warmup, steps):
+    """orbit frames of the timed region, in the order they are drawn, and the sorted set of them"""
+    seq = [(warmup + i) % ORBIT_FRAMES for i in range(steps)]
+    return seq, sorted(set(seq))
+
+
+def preroll(frame, sync, frames_used, warmup, async_flag, lanes=LANES, warmup_first=0):
+    """What bench.py does before its timed region (untimed): synchronous frames cycling through the region's own poses until at least
+    96 (and every pose twice) have been drawn -- the library settles the share of splats it bins first, and after 16 clean frames
+    stops launching the second binning round --, then 2 x lanes asynchronous frames so that every pipeline lane is allocated and
+    warm, a sync, the warm-up steps, a sync.  frame(k, flags) draws orbit frame k; returns the number of synchronous frames."""
+    n = 0
+    while n < max(96, 2 * len(frames_used)):
+        for k in frames_used:
+            frame(k, 0)
+            n += 1
+    for j in range(2 * lanes):
+        frame(frames_used[j % len(frames_used)], async_flag)
+    sync()
+    for i in range(warmup):
+        frame((warmup_first + i) % ORBIT_FRAMES, async_flag)
+    sync()
+    return n

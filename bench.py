@@ -48,7 +48,15 @@ def main():
     ap.add_argument("--single-process", action="store_true", help="ONE host process drives all --gpus devices (gs_create_multi; the Node.js "
                                                                 "consumer's form) instead of one process per GPU; device frames gathered on the first GPU")
     ap.add_argument("--host-direct", action="store_true", help="with --single-process: every GPU copies its strip straight into one page-locked host frame")
+    ap.add_argument("--config", choices=["C1", "C2", "C3", "C4", "C5"], default=None,
+                    help="a BASELINE.json configuration by name (aframe-gaussian-splatting_amd/bench_configs.py); default C2, or whatever --splats / --size / --cutout / --xr describe")
+    ap.add_argument("--no-configs", action="store_true", help="skip the other BASELINE configurations (`configs` in the line; single GPU, default run only)")
     args = ap.parse_args()
+    BC = importlib.import_module(PKG + ".bench_configs")
+    if args.config:                                          # the table's shape, spelled out for everything below that reads the flags
+        c = BC.CONFIGS[args.config]
+        args.splats = c["splats"]; args.cutout = c["pose"] == "cutout"; args.xr = c["xr"]
+        args.size = None if (c["size"] is None or c["size"] == (1920, 1080)) else "%dx%d" % c["size"]
     if args.single_process:
         return single_process_main(args)
     # stdout carries exactly ONE JSON line: whatever native libraries (RCCL's version banner, HIP warnings) write to file
@@ -81,22 +89,15 @@ def main():
     capi = importlib.import_module(PKG + ".capi")
     synth = importlib.import_module(PKG + ".synth")
 
-    n_splats = args.splats or synth.N_TRAIN
-    rows = synth.make_splat_rows_fast(n_splats) if n_splats >= (8 << 20) else synth.make_splat_rows(n_splats)
+    # the configuration: one table (bench_configs.py) says what scene, viewport, poses and LIBRARY OPTIONS each BASELINE.json
+    # configuration is measured with; tests/test_as_benched.py draws the same frames with the same option sets and checks them
+    cfg_name = BC.name_of(args.splats, [int(v) for v in args.size.lower().split("x")] if args.size else None, args.cutout, args.xr)
+    cfg = BC.CONFIGS[cfg_name] if cfg_name else BC.custom(args.splats, (W, H), args.cutout, args.xr)
+    n_splats = cfg["splats"]
+    rows = BC.make_rows(cfg, synth)
     ctx = capi.Context(local_rank)
-    r32 = rows.reshape(-1, 32)
-    for o in range(0, n_splats, 1 << 22):                    # progressive ingest (index.js:279-298), 4 M rows per push
-        ctx.push_splat(r32[o:o + (1 << 22)])
-    if os.environ.get("GS_BENCH_BINNING"):                   # experiment knob: GS_OPT_BINNING (1 = pair records + radix passes, rounds 1-3)
-        ctx.set_option(capi.OPT_BINNING, int(os.environ["GS_BENCH_BINNING"]))
+    BC.push_rows(ctx, rows)                                  # progressive ingest (index.js:279-298), 4 M rows per push
     depth = int(os.environ.get("GS_BENCH_DEPTH", "0"))       # experiment knob: frames in flight (library default 3)
-    if depth:
-        ctx.set_option(capi.OPT_PIPELINE_DEPTH, depth)
-    blend_split = int(os.environ.get("GS_BENCH_SPLIT", "1" if args.cutout else "0"))
-    if blend_split:
-        # the cut-out scene (C3) fills a tenth of the screen: ~600 active tiles with lists of thousands of entries.  Tiles with a
-        # list are blended by four wavefronts, one pixel per lane (GS_OPT_BLEND_SPLIT; images within the same 1 LSB tolerance)
-        ctx.set_option(capi.OPT_BLEND_SPLIT, blend_split)
     gathered = world > 1 or comm1 or args.xr                 # frames go through gs_render_gathered
     # GS_OPT_SORT_SHARE: with several ranks and a scene whose depth sort dominates a strip's frame (20 M splats: 230 of 290 us),
     # the ranks take turns sorting and exchange the nearest 3 % of the order (GS_BENCH_SORT_SHARE=<permille> overrides; 0 = off).
@@ -135,30 +136,22 @@ def main():
         ctx.comm_init(ctx.comm_unique_id(), 0, 1)
         ctx.set_option(capi.OPT_COMM_SELF_COPY, 1)
 
-    # views per orbit pose: one full frame (column strips over the ranks) or the two XR eyes (divided between the ranks)
-    if args.xr:
-        rigs = [synth.xr_eye_cameras(360.0 * i / ORBIT_FRAMES, 0.5, capi=capi) for i in range(ORBIT_FRAMES)]
-        W, H = rigs[0][0]["vw"], rigs[0][0]["vh"]
-        cams = [r[2] for r in rigs]                          # the sort uses the head camera (index.js:441)
-        views = [[capi.make_params(e["gs_mv"], e["gs_proj"], W, H, focal_=e["focal"]) for e in r[:2]] for r in rigs]
-        widths = [W, W]
-    else:
-        pose = synth.cutout_demo_camera if args.cutout else synth.index_html_camera
-        cams = [pose(W, H, 360.0 * i / ORBIT_FRAMES, capi=capi) for i in range(ORBIT_FRAMES)]
-        views = [[capi.make_params(c["gs_mv"], c["gs_proj"], W, H, focal_=c["focal"])] for c in cams]
-        widths = [W]
+    # views per orbit pose: one full frame (column strips over the ranks) or the two XR eyes (divided between the ranks); for XR
+    # the sort uses the head camera (index.js:441)
+    cams, views, W, H = BC.poses(cfg, synth, capi)
+    widths = [W] * len(views[0])
     pieces = capi.partition(widths, world)
     mine = [(v, x0, x1) for v, x0, x1, owner in pieces if owner == rank]
     own_px = sum((x1 - x0) * H for _, x0, x1 in mine)
-    LANES = 3
-    # two frames per launch (GS_OPT_FRAME_BATCH): consecutive asynchronous frames share every kernel launch (grid (x, 2), each frame on
-    # its own scratch).  Gathered frames pair too when a rank draws ONE piece per frame (column strips; an XR eye per GPU): the two
-    # gathers follow the shared kernels in frame order; a rank that draws BOTH XR eyes pairs the two views of a frame instead
-    frame_batch = int(os.environ.get("GS_BENCH_BATCH", "2"))
-    if gathered and len(mine) not in (1, 2):
-        frame_batch = 1                                      # (pairs: two frames of one piece each, or the two views of one frame)
-    if frame_batch != 1:
-        ctx.set_option(capi.OPT_FRAME_BATCH, frame_batch)
+    LANES = BC.LANES
+    # the configuration's library options (bench_configs.py; GS_BENCH_* = experiment overrides).  Two frames per launch
+    # (GS_OPT_FRAME_BATCH): consecutive asynchronous frames share every kernel launch (grid (x, 2), each frame on its own scratch).
+    # Gathered frames pair too when a rank draws ONE piece per frame (column strips; an XR eye per GPU): the two gathers follow the
+    # shared kernels in frame order; a rank that draws BOTH XR eyes pairs the two views of a frame instead
+    opts = BC.options_for(cfg, pieces_of_rank=len(mine), gathered=gathered)
+    BC.apply_options(ctx, capi, opts)
+    frame_batch = opts.get("OPT_FRAME_BATCH", 1)
+    blend_split = opts.get("OPT_BLEND_SPLIT", 0)
 
     def piece_params(k, v, x0, x1, flags):
         q = views[k][v]
@@ -252,18 +245,9 @@ def main():
     # adaptation pre-roll (untimed, like the fragment counting above): one synchronous pass over the poses of the timed
     # region lets the library settle the share of splats it bins in its first, nearest-splats round for every pose
     retries = 0
-    preroll = 0
-    while preroll < max(96, 2 * len(frames_used)):           # (short runs cycle through their poses until the share has settled; long ones see every
-                                                             # pose twice: the share drifts down towards its floor between two visits of a pose)
-        for k in frames_used:
-            frame(k)
-            preroll += 1
-    for j in range(2 * max(LANES, depth)):                   # every pipeline lane allocated and warm, whatever W is
-        frame(frames_used[j % len(frames_used)], capi.RENDER_ASYNC)
-    sync()
-    for i in range(args.warmup):
-        frame(i, capi.RENDER_ASYNC)
-    sync()
+    # (short runs cycle through their poses until the share has settled; long ones see every pose twice: the share drifts down towards
+    # its floor between two visits of a pose; then every pipeline lane allocated and warm, whatever W is; then the W warm-up steps)
+    preroll = BC.preroll(frame, sync, frames_used, args.warmup, capi.RENDER_ASYNC, lanes=max(LANES, depth))
     # ---- timed region: exactly K steps, barrier + synchronize on both sides.  A retry request from the closing sync
     # (an asynchronous frame outgrew a buffer or needed the skipped second binning round) invalidates the region: the
     # library has adapted, the region is measured again from scratch.
@@ -389,7 +373,7 @@ def main():
             "value": round(fps, 3), "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
             "ms_per_step": round(elapsed / K * 1e3, 4), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": workload, "parallelism": par,
+            "config": {"workload": workload, "name": cfg_name, "library_options": opts, "parallelism": par,
                        "pieces_of_rank0": [[v, x0, x1] for v, x0, x1 in mine], "gathered_frame_equals_single_gpu_render": frame_check,
                        "blend_split_min_list": blend_split, "sort_share_permille": sort_share if world > 1 else 0,
                        "frames_in_flight": ("%d (the library's 3 pipeline lanes%s: every frame still runs its own full sort, projection, "
@@ -463,8 +447,11 @@ def single_process_main(args):
     synth = importlib.import_module(PKG + ".synth")
     ndev = max(1, capi.device_count())
     devs = [int(v) for v in os.environ["GS_BENCH_DEVICES"].split(",")] if os.environ.get("GS_BENCH_DEVICES") else [i % ndev for i in range(args.gpus)]
-    n_splats = args.splats or synth.N_TRAIN
-    rows = synth.make_splat_rows_fast(n_splats) if n_splats >= (8 << 20) else synth.make_splat_rows(n_splats)
+    BC = importlib.import_module(PKG + ".bench_configs")
+    cfg_name = BC.name_of(args.splats, (W, H) if args.size else None, args.cutout, args.xr)
+    cfg = BC.CONFIGS[cfg_name] if cfg_name else BC.custom(args.splats, (W, H), args.cutout, args.xr)
+    n_splats = cfg["splats"]
+    rows = BC.make_rows(cfg, synth)                          # (the scene of the per-process bench: one table)
     pose = synth.cutout_demo_camera if args.cutout else synth.index_html_camera
     if args.xr:
         rigs = [synth.xr_eye_cameras(360.0 * i / ORBIT_FRAMES, 0.5, capi=capi) for i in range(ORBIT_FRAMES)]

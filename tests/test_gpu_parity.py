@@ -1471,10 +1471,13 @@ def test_gathered_frames_through_rccl_world1(scene_small):
 
 
 def test_split_blend_several_wavefronts_per_tile(ctx, scene_small):
-    """GS_OPT_BLEND_SPLIT: tiles with long lists walked in segments by 8 wavefronts from fresh states and composed front to
-    back give the one-wavefront image within the pixel tolerance (same fragments, different fp32 summation order) -- whole
-    frames, both binning rounds (pinned share: round 1 resumes saved states), scene compositing, lists of several
-    2048-entry iterations -- and strips still equal the full frame bit for bit (the rule is per tile)."""
+    """GS_OPT_BLEND_SPLIT (k_blend_px): tiles whose list has at least L entries are blended by FOUR wavefronts, one pixel per lane,
+    four entries per step -- the same fragments and per-pixel operations as the one-wavefront blend, but a pixel stops exactly when
+    it falls below the termination threshold instead of with its lane's other three.  The image stays within the pixel tolerance of
+    the oracle and of the one-wavefront image -- whole frames, both binning rounds (pinned share: round 1 resumes saved states),
+    scene compositing, lists of several batches -- and strips still equal the full frame bit for bit (the rule is per tile).
+    (The list split over 8 wavefronts from fresh states, which this docstring described until round 4, was measured and dropped:
+    DESIGN.md section 4.)  The BASELINE-sized run of this kernel is tests/test_as_benched.py::...[C3]."""
     w, h = 640, 360
     cam = synth.index_html_camera(w, h, 33.0, capi=capi)
     mv, P, focal = _f32(cam)
