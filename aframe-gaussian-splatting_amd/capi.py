@@ -58,7 +58,7 @@ class Stats(C.Structure):
                 ("prof_frames", C.c_uint32), ("sum_ms_sort", C.c_float), ("sum_ms_project", C.c_float), ("sum_ms_bin", C.c_float),
                 ("sum_ms_blend", C.c_float), ("acc_frames", C.c_uint64), ("acc_sorted", C.c_uint64), ("acc_visible", C.c_uint64),
                 ("acc_pairs", C.c_uint64), ("unsat_tiles", C.c_uint32), ("near_permille", C.c_uint32),
-                ("sort_records", C.c_uint32), ("retried_frames", C.c_uint32), ("spec_sorts", C.c_uint32), ("spec_misses", C.c_uint32)]
+                ("sort_records", C.c_uint32), ("retried_frames", C.c_uint32), ("spec_sorts", C.c_uint32), ("spec_misses", C.c_uint32), ("need_splats", C.c_uint32)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

@@ -96,6 +96,16 @@ static int ensure_radix_tables(gs_ctx *ctx, size_t items)
     // a histogram row per radix chunk (sized for the short geometry's chunks) + the digit totals
     const size_t need_hist = (size_t)GS_RADIX_MAX_BINS * (gs_div_up(items, GS_CHUNK_S) + 16);
     if (need_hist > ctx->hist_cap) { dev_free(ctx->hist); ctx->hist_cap = 0; TRY(dev_alloc(ctx, &ctx->hist, need_hist)); ctx->hist_cap = need_hist; }
+    // the MSD depth sort's group rows: 256 words per GS_MSD_GROUP chunks (of the short geometry), for at most GS_MSD_MAX_N splats
+    const size_t msd_items = items < GS_MSD_MAX_N ? items : (size_t)GS_MSD_MAX_N;
+    const size_t need_grp = (size_t)256 * (gs_div_up(gs_div_up(msd_items, GS_CHUNK_S), GS_MSD_GROUP) + 2);
+    // (+ k_seg_sort's work items behind them: 4 words of header and 4 per item, at most 256 segments + one block per 4096 records)
+    const size_t need_tab = 4 + 4 * ((size_t)512 + 256 + msd_items / 4096 + 16);   // (room for GS_SEG_GRID items at least: every workgroup reads ITS first item unconditionally)
+    if (need_grp > ctx->msd_grp_cap) {
+        dev_free(ctx->msd_grp); ctx->msd_grp_cap = 0; ctx->msd_tab = nullptr;
+        TRY(dev_alloc(ctx, &ctx->msd_grp, need_grp + need_tab));
+        ctx->msd_grp_cap = need_grp; ctx->msd_tab = ctx->msd_grp + need_grp;
+    }
     const size_t need_aux = (size_t)GS_RADIX_MAX_BINS * 2;
     if (need_aux > ctx->aux_cap) { dev_free(ctx->radix_aux); TRY(dev_alloc(ctx, &ctx->radix_aux, need_aux)); ctx->aux_cap = need_aux; }
     return GS_OK;
@@ -267,7 +277,29 @@ static void gs_spec_back_off(gs_ctx *ctx /* owner */, bool unsuited)
     __atomic_store_n(&ctx->near_spec_hold, ctx->near_spec_backoff, __ATOMIC_RELAXED);
 }
 
-static int collect_status(gs_ctx *lane, bool *overflowed, bool *share_failed = nullptr, uint32_t *spec_failed = nullptr)
+#ifndef GS_NEED_MARGIN
+#define GS_NEED_MARGIN 1.15         // the share binned first = what the collected frames' tiles needed x this (the walked share ended 1.17-1.3 x above the share that had failed)
+#endif
+// The share of splats binned first, from what the blends of the collected frames MEASURED (GsControl::need_near: per tile, how many of
+// the nearest splats it read before its pixels were saturated).  Rounds 1-4 walked the share: x 0.9 per collection from 25 % until a
+// share failed, x 1.5 then -- a fresh context needed dozens of collections (and one failure) to arrive, and a 20 M-splat scene drew
+// its first hundred frames with 5 M positions in the first round (`cold_orbit`: 63 frames/s).  One collection is enough now.
+static void share_from_need(gs_ctx *ctx /* owner */, uint32_t need)
+{
+    if (!need || ctx->near_fixed_permille > 0 || !ctx->n) return;
+    float target = 1.0f;                                         // 0xFFFFFFFF: a tile that no share saturates (sky): one round over everything
+    if (need != 0xFFFFFFFFu) {
+        target = (float)((double)need * GS_NEED_MARGIN / (double)ctx->n);
+        if (target > 0.85f) target = 1.0f;                       // (two rounds over nearly everything cost more than one)
+    }
+    if (target < ctx->near_floor) target = ctx->near_floor;      // never below 1.3 x a share that failed
+    if (target < 0.001f) target = 0.001f;
+    ctx->near_frac = target;
+    ctx->share_measured = true;
+    ctx->stats.need_splats = need;
+}
+
+static int collect_status(gs_ctx *lane, bool *overflowed, bool *share_failed = nullptr, uint32_t *spec_failed = nullptr, uint32_t *need_out = nullptr)
 {
     gs_ctx *ctx = gs_root(lane);                                // the adaptive share is one state for all lanes ...
     const GsControl *c = lane->ctl_host;                        // ... fed by each lane's own counters
@@ -289,6 +321,19 @@ static int collect_status(gs_ctx *lane, bool *overflowed, bool *share_failed = n
     // re-binned for them): the share grows x1.5 and will never again shrink below 1.3 x the share that failed; without
     // events it shrinks 10 % per collected frame until the first event, 2 % afterwards.  After 16 clean frames round 1 is not even launched (11 empty kernels
     // cost ~50 us): blend<0> raises round1_missed if that was wrong, and the frame is completed / re-rendered.
+    uint32_t need = 0;
+    for (uint32_t k = 0; k < GS_NEED_WORDS; k++) if (c->need_near[k] > need) need = c->need_near[k];
+    if (need) {
+        // The words are not cleared but SEEDED with 0.9 x the maximum: a tile issues its atomic only when it needs more than the word it
+        // read when it started, so after a clear every tile of the first frames would -- 8160 atomics on one cache line serialise at
+        // ~11 ns each: the first six frames after every gs_sync took twice as long.  Seeded, only the tiles within 10 % of the maximum
+        // speak up; a need that falls is followed 10 % per collection (the word is then an upper bound), one that rises at once.
+        // 0xFFFFFFFF (a tile nothing saturates) is kept, and dropped for one collection in sixteen: the scene may have changed.
+        uint32_t seed = need == 0xFFFFFFFFu ? ((++lane->need_probe & 15u) ? 0xFFFFFFFFu : 0u) : (uint32_t)((uint64_t)need * 9u / 10u);
+        GS_HIP(hipMemsetD32Async((hipDeviceptr_t)lane->ctl->need_near, (int)seed, GS_NEED_WORDS, lane->stream));
+    }
+    if (ctx->adapt_frozen || c->order_incomplete) need = 0;       // (frames drawn from a truncated order / drawn again: not this share's measurement)
+    if (need_out && need > *need_out) *need_out = need;
     if (ctx->adapt_frozen || c->order_incomplete) {
         // gs_sync is drawing flagged frames again (redraw_flagged_frames) with the uniforms they were queued with: their share has
         // been dealt with once already -- every one of them would count as a new failure and multiply the share by 1.5.
@@ -309,16 +354,19 @@ static int collect_status(gs_ctx *lane, bool *overflowed, bool *share_failed = n
                 if (share_failed) *share_failed = true;
             } else {
                 ctx->clean_frames += (uint32_t)(frames ? frames : 1);
-                // fast descent (x0.9) until a share has proved too small once, then a slow drift (x0.98) above the floor
-                float nf = ctx->near_frac * (ctx->near_floor > 0.0f ? 0.98f : 0.9f);
-                if (nf < ctx->near_floor) nf = ctx->near_floor; if (nf < 0.001f) nf = 0.001f;
-                if (nf < ctx->near_frac) ctx->near_frac = nf;
+                if (!need) {
+                    // no measurement (compact pair records name no positions): the walk of rounds 1-4 -- fast descent (x0.9) until a share
+                    // has proved too small once, then a slow drift (x0.98) above the floor
+                    float nf = ctx->near_frac * (ctx->near_floor > 0.0f ? 0.98f : 0.9f);
+                    if (nf < ctx->near_floor) nf = ctx->near_floor; if (nf < 0.001f) nf = 0.001f;
+                    if (nf < ctx->near_frac) ctx->near_frac = nf;
+                }
                 const uint32_t fr = (uint32_t)(frames ? frames : 1);     // the hold is counted in frames, not in collections
                 ctx->skip_hold = ctx->skip_hold > fr ? ctx->skip_hold - fr : 0;
             }
             ctx->single_round_frames = 0;
-        } else if (ctx->near_frac >= 1.0f && ++ctx->single_round_frames >= 64) {
-            ctx->near_frac = 0.5f; ctx->near_floor = 0.0f; ctx->single_round_frames = 0; ctx->clean_frames = 0;
+        } else if (!need && ctx->near_frac >= 1.0f && ++ctx->single_round_frames >= 64) {
+            ctx->near_frac = 0.5f; ctx->near_floor = 0.0f; ctx->single_round_frames = 0; ctx->clean_frames = 0;   // (unmeasured: re-probe occlusion now and then)
         }
     }
     if (c->near_overflow) {
@@ -397,13 +445,18 @@ static int prof_advance(gs_ctx *ctx);
 // everything queued behind it.  (A scene that never fails ends at the minimum share: skippable from there.)
 static inline bool round1_skippable(const gs_ctx *ctx /* owner */)
 {
-    return ctx->near_fixed_permille <= 0 && ctx->clean_frames >= 16 && !ctx->skip_hold && (ctx->near_floor > 0.0f || ctx->near_frac <= 0.0011f);
+    // (a MEASURED share -- share_from_need -- needs neither the failure that gives the walked share its floor nor sixteen frames of proof)
+    return ctx->near_fixed_permille <= 0 && ctx->clean_frames >= (ctx->share_measured ? 4u : 16u) && !ctx->skip_hold &&
+           (ctx->near_floor > 0.0f || ctx->near_frac <= 0.0011f || ctx->share_measured);
 }
 
 static uint32_t sort_near_request(const gs_ctx *ctx /* owner */)
 {
     if (!ctx->sort_near_opt || !ctx->renderable) return 0;
-    if (ctx->sort_near_opt == 1 && ctx->n < ((size_t)1 << 22)) return 0;      // (short sorts are launch-bound: nothing to gain)
+    // (short sorts are bound by their launches and dependent round trips, not by their records: measured again in round 5 with the
+    // four-launch MSD sort -- at 1 M splats the depth histogram and the threshold search cost the depth and bucket kernels 10 us, the
+    // two kernels behind them save 2 with a fifth of the records: 7 170 against 7 590 frames/s one frame at a time, the same pipelined)
+    if (ctx->sort_near_opt == 1 && ctx->n < ((size_t)1 << 22)) return 0;
     if (ctx->wide_pairs || ctx->n > ((size_t)1 << 25)) return 0;
     if (!round1_skippable(ctx) || ctx->near_frac >= 1.0f) return 0;
     const double nc = ceil((double)ctx->near_frac * (double)ctx->n);
@@ -638,7 +691,7 @@ static void free_frame_resources(gs_ctx *c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     delete c->log; c->log = nullptr;
     dev_free(c->depth); dev_free(c->key_a); dev_free(c->kv_b); dev_free(c->val_a);
-    dev_free(c->hist); dev_free(c->radix_aux); dev_free(c->spine); dev_free(c->spine_vis); dev_free(c->projc); dev_free(c->zwinc);
+    dev_free(c->hist); dev_free(c->radix_aux); dev_free(c->msd_grp); dev_free(c->spine); dev_free(c->spine_vis); dev_free(c->projc); dev_free(c->zwinc);
     dev_free(c->proj); dev_free(c->rect); dev_free(c->tile_count); dev_free(c->zwin);
     dev_free(c->pair_a); dev_free(c->pair_b); dev_free(c->emit_extra); dev_free(c->row_cnt); dev_free(c->row_tot); dev_free(c->seg_diff);
     gs_comm_free_lane(c);
@@ -668,7 +721,7 @@ static int set_profile(gs_ctx *ctx, bool on, bool blend_only, uint32_t every = 1
     if (on && !ctx->profile) {                                   // (re)start accumulation
         ctx->stats.prof_frames = 0;
         ctx->stats.sum_ms_sort = ctx->stats.sum_ms_project = ctx->stats.sum_ms_bin = ctx->stats.sum_ms_blend = 0;
-        GS_HIP(hipMemsetAsync(&ctx->ctl->acc_frames, 0, sizeof(GsControl) - offsetof(GsControl, acc_frames), ctx->stream));
+        GS_HIP(hipMemsetAsync(&ctx->ctl->acc_frames, 0, offsetof(GsControl, need_near) - offsetof(GsControl, acc_frames), ctx->stream));
         ctx->seen_acc_frames = 0;
     }
     ctx->profile = on; ctx->profile_blend_only = on && blend_only; ctx->profile_every = on ? every : 1; ctx->profile_tick = 0;
@@ -822,7 +875,7 @@ GS_API int gs_clear(gs_ctx *ctx)
     GS_HIP(hipSetDevice(ctx->device));
     TRY(drain_all(ctx));
     ctx->n = 0; ctx->renderable = true; ctx->pair_hint = 0; ctx->vis_hint = 0; ctx->run_hint = 0;
-    ctx->near_frac = 0.25f; ctx->near_floor = 0.0f; ctx->clean_frames = 0; ctx->skip_hold = 0; ctx->single_round_frames = 0; ctx->last_kept = 0;
+    ctx->near_frac = 0.25f; ctx->near_floor = 0.0f; ctx->clean_frames = 0; ctx->skip_hold = 0; ctx->single_round_frames = 0; ctx->last_kept = 0; ctx->share_measured = false;
     ctx->near_stash_off = false; ctx->near_spec = false; ctx->near_spec_hold = 0; ctx->near_spec_backoff = 0; ctx->near_spec_miss_credit = 0;
     for (int i = 0; i < GS_MAX_LANES; i++) {
         gs_ctx *L = ctx->lanes[i];
@@ -1182,9 +1235,11 @@ static int render_sync_on_lane(gs_ctx *ctx, const GsFrameUniforms &u, void *devi
             ctx->ctl_host->round1_missed = 1;                      // seen by the adaptation below
         }
         bool over = false, failed = false;
+        uint32_t need = 0;
         const float frac_used = gs_root(ctx)->near_frac;
-        TRY(collect_status(ctx, &over, &failed));
+        TRY(collect_status(ctx, &over, &failed, nullptr, &need));
         if (failed) share_raise(gs_root(ctx), frac_used);
+        else share_from_need(gs_root(ctx), need);
         if (!over) break;
         if (attempt >= 2) FAIL(GS_E_OOM, "pair list keeps overflowing (%u pairs)", ctx->ctl_host->scan_total);
     }
@@ -1251,7 +1306,12 @@ int gs_render_uniforms(gs_ctx *ctx, const GsFrameUniforms &u_in, void *device_rg
         }
     }
     gs_ctx *L = ctx->lanes[ctx->cur];                           // the frame's lane: where its gs_sort ran
-    const bool async = (u.flags & GS_RENDER_ASYNC) && !(u.flags & GS_RENDER_COUNT_FRAGS);
+    bool async = (u.flags & GS_RENDER_ASYNC) && !(u.flags & GS_RENDER_COUNT_FRAGS);
+    // A context that has not MEASURED its share yet (fresh, cleared, the share un-pinned) draws its first two-round frame synchronously
+    // even when asked to queue it: the frames queued behind it then use the share it measured instead of the 25 % every context starts
+    // with (at 20 M splats: 5 M positions in the first round of every frame until the first gs_sync).  The call returns with the frame
+    // complete; its status needs no gs_sync.
+    if (async && !ctx->share_measured && ctx->near_fixed_permille <= 0 && u.near_count != 0xFFFFFFFFu && ctx->n) { async = false; u.flags &= ~(uint32_t)GS_RENDER_ASYNC; }
     if (async) {
         if (host_rgba && stride && stride < (size_t)(u.x1 - u.x0) * 4) FAIL(GS_E_BADARG, "stride %zu smaller than a row (%zu bytes)", stride, (size_t)(u.x1 - u.x0) * 4);
         L->async_pending = true; ctx->cur_async = true;
@@ -1372,7 +1432,7 @@ GS_API int gs_sync(gs_ctx *ctx)
     CHECK_CTX(ctx);
     GS_HIP(hipSetDevice(ctx->device));
     bool any_missed = false, any_over = false, share_failed = false;
-    uint32_t spec_failed = 0;
+    uint32_t spec_failed = 0, need = 0;
     const float frac_used = ctx->near_frac;                       // what every frame queued since the last collection was drawn with
     // whatever way this call ends, the frames logged so far are not drawn again by a LATER gs_sync (their output buffers may be
     // gone by then): a failure below leaves no records behind
@@ -1411,12 +1471,13 @@ GS_API int gs_sync(gs_ctx *ctx)
         if (missed) LANE_HIP(L, hipMemsetAsync(&L->ctl->round1_missed, 0, sizeof(uint32_t), L->stream));
         if (L->ctl_host->order_incomplete) LANE_HIP(L, hipMemsetAsync(&L->ctl->order_incomplete, 0, sizeof(uint32_t), L->stream));
         bool over = false;
-        TRY(collect_status(L, &over, &share_failed, &spec_failed));
+        TRY(collect_status(L, &over, &share_failed, &spec_failed, &need));
         any_missed |= missed; any_over |= over;
         if (missed || over) bad_unit[i % GS_MAX_PRIMARY] = true;
         if (over && L->ctl_host->max_total > want) want = L->ctl_host->max_total;
     }
     if (share_failed) share_raise(ctx, frac_used);               // (once, whatever the number of lanes that saw it)
+    else share_from_need(ctx, need);                             // ... else what the collected frames' tiles needed (the maximum over the lanes)
     if (spec_failed) gs_spec_back_off(ctx, spec_failed == 2u);
     if (any_over)                                                // one retry for all lanes: each gets room for the largest demand seen
         for (int i = 0; i < GS_MAX_LANES; i++)
@@ -1501,7 +1562,7 @@ GS_API int gs_set_option(gs_ctx *ctx, int option, int64_t value)
     case GS_OPT_NEAR_PERMILLE:
         if (value < 0 || value > 1000) FAIL(GS_E_BADARG, "near permille must be 0 (adaptive) .. 1000 (single round)");
         ctx->near_fixed_permille = (int)value;
-        if (value == 0) ctx->near_frac = 0.25f;
+        if (value == 0) { ctx->near_frac = 0.25f; ctx->share_measured = false; }
         return GS_OK;
     case GS_OPT_RECORD_STAGED: ctx->record_staged = value == 2 ? 2u : (value != 0 ? 1u : 0u); return GS_OK;
     case GS_OPT_TERMINATION:
@@ -1593,7 +1654,7 @@ GS_API int gs_get_stats(gs_ctx *ctx, gs_stats *out)
         s.acc_visible += L->stats.acc_visible; s.acc_pairs += L->stats.acc_pairs;
     }
     s.n_splats = ctx->n;
-    s.retried_frames = ctx->stats.retried_frames; s.spec_sorts = ctx->stats.spec_sorts; s.spec_misses = ctx->stats.spec_misses;
+    s.retried_frames = ctx->stats.retried_frames; s.spec_sorts = ctx->stats.spec_sorts; s.spec_misses = ctx->stats.spec_misses; s.need_splats = ctx->stats.need_splats;
     s.near_permille = (uint32_t)(ctx->near_frac * 1000.0f + 0.5f);
     *out = s;
     return GS_OK;

@@ -22,6 +22,9 @@
 #define GS_RADIX_LARGE_N (3u << 20) // inputs expected to be longer than this take the long geometry
 #endif
 #define GS_RADIX_MAX_BINS 512      // up to 9-bit digits (depth key = 17 bits = 8 + 9)
+#define GS_NEED_WORDS 32u          // GsControl::need_near
+#define GS_MSD_GROUP 32u           // the MSD depth sort (gs_sort.hip): radix chunks per group row
+#define GS_MSD_MAX_N (1u << 24)    // ... takes sorts of at most this many splats (its records: low bucket byte << 24 | index)
 #define GS_PROF_RING 256           // frames of HIP-event timings kept in flight
 #define GS_PROF_EVENTS 7
 #define GS_MAX_PART 8192           // upper bound on the grid of any kernel that writes per-workgroup partials
@@ -84,8 +87,17 @@ struct GsControl {
                                    // the path (the context stops using it); the frame is flagged order_incomplete + round1_missed (host clears)
     uint32_t spec_dbg;             // (GS_DEBUG_NEAR) exact threshold bin << 16 | the limit of a chunk that failed the check
     uint32_t near_bin_hint;        // OWNER's block only: the threshold depth bin the context's last near-only sort found (any lane's kernels write it)
+    // What the share of splats binned first has to be (round 5: measured, not walked).  A tile's blend knows how far into its list it
+    // read before its 256 pixels were saturated; the sorted position of that entry says how many of the NEAREST splats had to be binned
+    // for the tile: V - position.  need_near[tile % GS_NEED_WORDS] = max over the tiles of the frames drawn since the host last cleared
+    // it (one fire-and-forget atomicMax per tile, spread over 32 words: a single word serialises at ~11 ns per tile); 0xFFFFFFFF: a tile
+    // was not saturated by the whole order (sky: no share helps it).  The host sets near_count from the maximum (gs_api.hip).
     uint32_t acc_frames;           // frames rendered since profiling was switched on
     unsigned long long acc_sorted, acc_visible, acc_pairs;   // sums of V, Vp, I over those frames
+    // (a cache line of its own: atomics drop the line from the XCDs' L2s, and the counts above are read by every kernel.  A tile's wave
+    // reads its word when it starts and issues the atomic only if its need is larger: a dozen atomics per frame instead of 8160 --
+    // 8160 atomics on ONE LINE serialise at ~11 ns each whatever the word: the blend went from 43 to 64 us)
+    alignas(128) uint32_t need_near[32];
 };
 
 struct GsFrameUniforms {           // per-render constants, passed by value to kernels
@@ -184,6 +196,8 @@ struct gs_ctx {
     uint32_t *hist;  size_t hist_cap;       // digit-histogram rows H[radix chunks][bins], scanned in place
     uint32_t *radix_aux; size_t aux_cap;    // digit totals [GS_RADIX_MAX_BINS]
     uint32_t *spine; size_t spine_cap;      // per-256-splat totals of tiles touched (project -> emit)
+    uint32_t *msd_grp; size_t msd_grp_cap;  // MSD depth sort: H[group of GS_MSD_GROUP radix chunks][bucket >> 8], words
+    uint32_t *msd_tab;                      // ... and k_seg_sort's work items (written by k_msd_scatter), behind the group rows in the same allocation
 
     // render scratch
     gsm::Projected *proj;          // V records, sorted order
@@ -216,6 +230,8 @@ struct gs_ctx {
     int near_fixed_permille;                // > 0: fixed by GS_OPT_NEAR_PERMILLE instead of adapted
     bool last_two_rounds;                   // the last enqueued frame ran the two-round path (its unsat count is meaningful)
     float near_floor;                       // never shrink the share below this (1.3 x the share that last proved too small)
+    bool share_measured;                    // owner: near_frac comes from a measurement (GsControl::need_near) -- share_from_need, gs_api.hip
+    uint32_t need_probe;                    // lane: collections that found "a tile nothing saturates" (every 16th re-probes)
     uint32_t clean_frames, skip_hold;       // collected frames since the last unsaturated one / frames to keep round 1 on
     uint32_t seen_unsat_events; uint64_t seen_acc_frames;
     uint32_t single_round_frames;           // consecutive collected frames at near_frac == 1 (re-probe occlusion now and then)
@@ -307,6 +323,14 @@ template <class F, int NT, class P> static inline void gs_twin(uint32_t grid_x, 
 {
     hipLaunchKernelGGL((k_twin<F, NT, P>), dim3(grid_x, 2), dim3(NT), 0, st, p0, p1);
 }
+// ... with a register budget: MINW = the waves per SIMD the kernel must leave room for (512 / MINW vector registers), for bodies whose
+// unrolled loops the compiler would otherwise give 180-250 registers -- workgroups that then wait for half a SIMD's register file to
+// drain while the other frames' blends hold it
+template <class F, int NT, int MINW, class P> __global__ __launch_bounds__(NT, MINW) void k_twin_w(P p0, P p1) { if (blockIdx.y) gs_pack_call<F>(p1); else gs_pack_call<F>(p0); }
+template <class F, int NT, int MINW, class P> static inline void gs_twin_w(uint32_t grid_x, hipStream_t st, const P &p0, const P &p1)
+{
+    hipLaunchKernelGGL((k_twin_w<F, NT, MINW, P>), dim3(grid_x, 2), dim3(NT), 0, st, p0, p1);
+}
 
 // ---- gs_prims.hip
 // One stable LSD radix pass over n = *n_ptr items on digit (key >> shift) & (2^bits-1).
@@ -335,6 +359,13 @@ int gs_launch_radix_pass(gs_ctx *ctx, const void *in, int in_fmt, void *out, int
 int gs_launch_radix_pass2(gs_ctx *const S[2], const void *const in[2], int in_fmt, void *const out[2], int out_fmt, const uint32_t *const n_ptr[2],
                           uint32_t max_n, uint32_t hint_n, int shift, int bits, bool have_hist, uint32_t zero_key, int idx_bits,
                           uint32_t *const count_out[2], const uint32_t *const fill_to[2]);
+// The last two launches of the MSD depth sort (gs_sort.hip: depth -> bucket + rows -> THIS): keys = ctx->key_a (16-bit bucket or
+// GS_RADIX_SKIP per splat), rows = ctx->hist H[chunk][bucket >> 8], group rows = ctx->msd_grp -> ctx->val_a (the index list, zero tail
+// [V', V) included), ctl->n_sorted = V'.  rec = ctx->kv_b used as 4-byte records between the two.
+// near: a near-only sort (no zero tail: k_project supplies the positions behind the records).
+int gs_launch_msd_sort(gs_ctx *ctx, uint32_t n, bool near);
+int gs_launch_msd_sort2(gs_ctx *const S[2], uint32_t n, bool near);
+bool gs_msd_enabled();             // (GS_SORT_MSD=0 in the environment: the two LSD passes everywhere)
 // grid used by the radix kernels for hint_n items (a producer that pre-fills the histogram rows uses the same chunking)
 uint32_t gs_radix_grid(uint32_t hint_n);
 // chunk length (GS_CHUNK_S / GS_CHUNK_L) a pass expecting hint_n items works with

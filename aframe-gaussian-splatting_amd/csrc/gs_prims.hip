@@ -347,6 +347,358 @@ __global__ __launch_bounds__(64 * NW) void k_radix_scatter(const void *__restric
     k_radix_scatter_body<IN_FMT, OUT_FMT, MAXB, NW>(in, out, n_ptr, shift, bits, zero_key, hist_scanned, totals, idx_bits, count_out, fill_to);
 }
 
+// ---------------------------------------------------------------- the MSD depth sort: its last two kernels (round 5)
+// The depth sort of a frame of <= 2^24 splats used to be seven launches (depth, bucket + histogram A, scan A, scatter A, histogram B,
+// scan B, scatter B), most of them at the launch floor at 1 M splats.  It is four now: depth, bucket, and these two.
+//   k_sort_bucket<.., MSD> (gs_sort.hip) writes the 16-bit bucket keys, the histogram rows of the HIGH bucket byte H[chunk][256] and,
+//     by one atomicAdd per digit a chunk holds, the rows G[group][256] of groups of GS_MSD_GROUP chunks.
+//   k_msd_scatter: one stable pass by the high byte WITHOUT a scan launch: a chunk's offset inside a digit's run is the sum of the
+//     group rows before its group and of the <= 31 chunk rows of its group before it (one digit per thread, ~50 independent 4-byte
+//     loads: ~12 MB of L2 reads per 1 M-splat sort, where every workgroup summing all rows before it would read 128 MB: measured and
+//     dropped in round 2), the digits' run starts are the column sums of the group rows.  Records out: low bucket byte << 24 | index.
+//   k_seg_sort: the array now consists of 256 segments (one per high byte), each in index order; ONE workgroup per segment sorts it by
+//     the low byte, stably, inside LDS: blocks of NT x IPT records, wave-private digit counters, match words for the in-round rank --
+//     the scatter's machinery with the offsets kept in LDS -- and writes the index list.  A segment longer than a block (depth
+//     distributions are peaked: the busiest 1/256 of the depth range holds 1 % of a Gaussian cloud) first counts its digits, then
+//     takes its blocks in order with a cursor per digit: any length is sorted correctly, a pathological one (all depths equal: one
+//     segment) just slowly.  The zero tail [V', V) of dropped buckets (index.js:561-567) is filled here.
+// The order is the reference's: ascending (bucket, original index) -- stable pass by the high byte, then stable by the low byte
+// inside a segment whose records are in index order.
+// Column dg of a table of 256-word rows summed over the rows [0, na) of table A and then [b0, b1) of table B -- BATCH loads in flight:
+// every load is unconditional (its row index clamped to a row that exists), what lies beyond the end contributes nothing.  A row read
+// costs an L2 miss (the group rows were written by device-scope atomics, which do not leave the line in the XCD's L2), so what matters
+// is the number of dependent round trips, not the loads.
+template <int BATCH>
+__device__ __forceinline__ uint32_t msd_column_sum(const uint32_t *__restrict__ A, uint32_t na, const uint32_t *__restrict__ Bt, uint32_t b0, uint32_t b1, uint32_t dg)
+{
+    const uint32_t total = na + (b1 - b0);
+    uint32_t sum = 0;
+    for (uint32_t v0 = 0; v0 < total; v0 += (uint32_t)BATCH) {
+        uint32_t t[BATCH];
+#pragma unroll
+        for (int k = 0; k < BATCH; k++) {
+            const uint32_t v = v0 + (uint32_t)k < total ? v0 + (uint32_t)k : v0;       // (v0 < total: a row that exists)
+            const uint32_t *row = v < na ? A + (size_t)v * 256u : Bt + (size_t)(b0 + (v - na)) * 256u;
+            t[k] = row[dg];
+        }
+#pragma unroll
+        for (int k = 0; k < BATCH; k++) sum += v0 + (uint32_t)k < total ? t[k] : 0u;
+    }
+    return sum;
+}
+
+// Stable rank of every item of a wavefront among the items of ITS digit, over IPT rounds of 64 consecutive items (the wave's items in
+// order: round, lane): rank = (items of the digit in earlier rounds) + (lanes of this round that hold the digit, below this one).
+// In-round: match-any through an LDS word per digit (every lane ORs its bit in, reads the word back).  Across rounds: the first lane
+// of every group adds the group's size to the wave's counter of the digit with a RETURNING LDS atomic -- LDS operations of one
+// wavefront execute in program order, so the values returned over the rounds are the running counts even though nothing waits for
+// them: they are collected at the end, one bpermute per round.  One LDS round trip per round (the word read back), where
+// k_radix_scatter's loop has two dependent ones (word and counter read, then the counter written before the next round may read it).
+// s_match: 256 words of THIS wave, zero on entry and on exit; s_cnt: 256 counters of this wave -- zero before the first call of a
+// block, the wave's digit counts afterwards (a second call continues the count: IPT = 32 as two calls of 16 keeps the registers of one).
+template <int IPT>
+__device__ __forceinline__ void wave_digit_ranks(const uint32_t *dig, const bool *ok, unsigned long long *s_match, uint32_t *s_cnt, uint32_t *rank, int lane)
+{
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    uint32_t prev[IPT], before[IPT];
+    int leader[IPT];
+#pragma unroll
+    for (int r = 0; r < IPT; r++) {
+        if (ok[r]) atomicOr(&s_match[dig[r]], 1ull << lane);
+        __builtin_amdgcn_wave_barrier();
+        const unsigned long long peers = ok[r] ? s_match[dig[r]] : 0ull;
+        before[r] = (uint32_t)__popcll(peers & lt);
+        leader[r] = peers ? __ffsll((long long)peers) - 1 : 0;
+        uint32_t pv = 0;
+        if (ok[r] && before[r] == 0u) { pv = atomicAdd(&s_cnt[dig[r]], (uint32_t)__popcll(peers)); s_match[dig[r]] = 0ull; }
+        __builtin_amdgcn_wave_barrier();
+        prev[r] = pv;
+    }
+#pragma unroll
+    for (int r = 0; r < IPT; r++) rank[r] = (uint32_t)__shfl((int)prev[r], leader[r], 64) + before[r];
+}
+
+#ifndef GS_SEG_B
+#define GS_SEG_B 4096u             // records per block of k_seg_sort (4 wavefronts x 16 rounds x 64)
+#endif
+#define GS_SEG_MAXBLK 8u           // a segment of more blocks is one work item: its blocks in turn, by one workgroup
+template <int NW>
+__device__ __forceinline__ void k_msd_scatter_body(const uint32_t *__restrict__ keys, uint32_t *__restrict__ rec, const uint32_t *n_ptr,
+                                                   const uint32_t *__restrict__ rows, const uint32_t *__restrict__ grp, uint32_t *count_out,
+                                                   uint32_t *__restrict__ seg_tab)
+{
+    GS_CHAIN_PRIO();
+    constexpr int NT = 64 * NW, IPT = 8, CH = NT * IPT, NB = 256, PB = 24;
+    __shared__ uint32_t s_cnt[NW][NB];
+    __shared__ unsigned long long s_match[NW][NB];
+    __shared__ uint32_t s_dbase[NB], s_gb[NB];
+    __shared__ uint32_t s_k[CH], s_v[CH];
+    __shared__ uint32_t s_wave[NW];
+    const uint32_t n = *n_ptr;
+    const uint32_t nchunks = (n + CH - 1) / CH, ngroups = (nchunks + GS_MSD_GROUP - 1u) / GS_MSD_GROUP;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const uint32_t dg = threadIdx.x < (uint32_t)NB ? threadIdx.x : 0u;   // this thread's digit (threads beyond 256 compute digit 0's sums and drop them)
+    const bool has_dg = threadIdx.x < (uint32_t)NB;
+    if (blockIdx.x >= ((nchunks + 7u) & ~7u) && !(count_out && blockIdx.x == 0)) return;
+    for (uint32_t i = threadIdx.x; i < NW * NB; i += NT) (&s_match[0][0])[i] = 0ull;   // (the ranking leaves them zero)
+    {   // digit totals = column sums of the group rows -> run starts
+        const uint32_t tot_d = has_dg ? msd_column_sum<16>(grp, ngroups, grp, 0u, 0u, dg) : 0u;
+        uint32_t tot;
+        const uint32_t ex = block_excl_scan<NW>(tot_d, s_wave, &tot);
+        if (has_dg) s_dbase[dg] = ex;
+        if (count_out && blockIdx.x == 0 && threadIdx.x == 0) *count_out = tot;   // the records that take a slot (V', or the survivors of a near-only sort)
+        if (blockIdx.x == 0) {
+            // k_seg_sort's work items (workgroup 0 writes them, every workgroup of that kernel reads its own): one per block of
+            // GS_SEG_B records of every non-empty segment -- the blocks of a segment are sorted by different workgroups --, but ONE item
+            // for a segment of more than GS_SEG_MAXBLK blocks (taken block after block by one workgroup: each block of a segment counts
+            // the whole segment first, which is quadratic in the length).  tab[0] = items, tab[1] = V'; items from tab + 4:
+            // (segment start, segment length, block, blocks | 0xFFFFFFFF = all of them in turn)
+            const uint32_t nbk = tot_d ? (tot_d + GS_SEG_B - 1u) / GS_SEG_B : 0u;
+            const uint32_t ni = nbk > GS_SEG_MAXBLK ? 1u : nbk;
+            uint32_t nitems;
+            const uint32_t ix = block_excl_scan<NW>(has_dg ? ni : 0u, s_wave, &nitems);
+            uint4 *items = reinterpret_cast<uint4 *>(seg_tab + 4);
+            if (has_dg) for (uint32_t j = 0; j < ni; j++) items[ix + j] = make_uint4(ex, tot_d, j, nbk > GS_SEG_MAXBLK ? 0xFFFFFFFFu : nbk);
+            if (threadIdx.x == 0) { seg_tab[0] = nitems; seg_tab[1] = tot; }
+        }
+    }
+    for (uint32_t v = blockIdx.x; v < ((nchunks + 7u) & ~7u); v += gridDim.x) {
+        uint32_t c;
+        if (!gs_xcd_chunk(v, nchunks, c)) continue;
+        for (uint32_t i = threadIdx.x; i < NW * NB; i += NT) (&s_cnt[0][0])[i] = 0;
+        __syncthreads();
+        uint32_t key[IPT], val[IPT], rank[IPT];
+#pragma unroll
+        for (int r = 0; r < IPT; r++) {                               // all loads first: their latencies overlap
+            const uint32_t i = c * CH + w * (CH / NW) + r * 64 + lane;
+            key[r] = i < n ? keys[i] : GS_RADIX_SKIP;
+            val[r] = i;
+        }
+        // This chunk's offset inside every digit's run = the rows of the groups before its own + the rows of the chunks of its group
+        // before it: <= 15 + 31 rows at 1 M splats.  The loads go out HERE, unconditional (row index clamped), and are summed behind
+        // the ranking: their round trip (an L2 miss each: the rows were written by another XCD) runs under it.
+        const uint32_t g0 = c / GS_MSD_GROUP, nrow = g0 + (c - g0 * GS_MSD_GROUP);
+        uint32_t pt[PB];
+#pragma unroll
+        for (int k = 0; k < PB; k++) {
+            const uint32_t vv = (uint32_t)k < nrow ? (uint32_t)k : 0u;
+            const uint32_t *row = (nrow == 0u || vv < g0) ? grp + (size_t)vv * 256u : rows + (size_t)(g0 * GS_MSD_GROUP + (vv - g0)) * 256u;
+            pt[k] = row[dg];
+        }
+        {
+            uint32_t dig[IPT]; bool ok[IPT];
+#pragma unroll
+            for (int r = 0; r < IPT; r++) { ok[r] = key[r] != GS_RADIX_SKIP; dig[r] = (key[r] >> 8) & 255u; }   // culled / dropped / not-near splats take no slot
+            wave_digit_ranks<IPT>(dig, ok, &s_match[w][0], &s_cnt[w][0], rank, lane);
+        }
+        uint32_t pre = 0;
+#pragma unroll
+        for (int k = 0; k < PB; k++) pre += (uint32_t)k < nrow ? pt[k] : 0u;
+        for (uint32_t v0 = PB; v0 < nrow; v0 += 16u) {                // (more than 24 rows: the later chunks of the later groups)
+            uint32_t t[16];
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                const uint32_t vv = v0 + (uint32_t)k < nrow ? v0 + (uint32_t)k : v0;
+                const uint32_t *row = vv < g0 ? grp + (size_t)vv * 256u : rows + (size_t)(g0 * GS_MSD_GROUP + (vv - g0)) * 256u;
+                t[k] = row[dg];
+            }
+#pragma unroll
+            for (int k = 0; k < 16; k++) pre += v0 + (uint32_t)k < nrow ? t[k] : 0u;
+        }
+        __syncthreads();
+        uint32_t chunk_items;
+        {   // digit totals of the chunk -> local digit starts; global position of every digit's local slot 0
+            uint32_t tv = 0;
+            if (has_dg) {
+#pragma unroll
+                for (int q = 0; q < NW; q++) tv += s_cnt[q][dg];
+            }
+            uint32_t tot;
+            const uint32_t ex = block_excl_scan<NW>(tv, s_wave, &tot);          // (two barriers inside)
+            chunk_items = tot;
+            if (has_dg) {
+                uint32_t run = ex;
+#pragma unroll
+                for (int q = 0; q < NW; q++) { const uint32_t cq = s_cnt[q][dg]; s_cnt[q][dg] = run; run += cq; }
+                s_gb[dg] = s_dbase[dg] + pre - ex;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < IPT; r++) {
+            if (key[r] != GS_RADIX_SKIP) {
+                const uint32_t d = (key[r] >> 8) & 255u;
+                s_k[s_cnt[w][d] + rank[r]] = key[r];
+                s_v[s_cnt[w][d] + rank[r]] = val[r];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < IPT; r++) {
+            const uint32_t slot = r * NT + threadIdx.x;
+            if (slot < chunk_items) {
+                const uint32_t k = s_k[slot];
+                rec[s_gb[(k >> 8) & 255u] + slot] = ((k & 255u) << 24) | s_v[slot];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// one block of a segment: R rounds per wavefront, NT x R records at most (the kernel picks the smallest R that holds the block's records:
+// a near-only sort's segments hold a few hundred, and every round is an LDS round trip whether it holds records or not)
+template <int NW, int R>
+__device__ __forceinline__ void seg_sort_block(const uint32_t *__restrict__ blk, uint32_t items, uint32_t *__restrict__ out, uint32_t (*s_cnt)[256],
+                                               unsigned long long (*s_match)[256], const uint32_t *s_dbase, uint32_t *s_cur, uint32_t *s_gb, uint32_t *s_k,
+                                               uint32_t *s_wave, uint32_t start, bool multi)
+{
+    constexpr int NT = 64 * NW, NB = 256;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const uint32_t dg = threadIdx.x < (uint32_t)NB ? threadIdx.x : 0u;
+    const bool has_dg = threadIdx.x < (uint32_t)NB;
+    for (uint32_t i = threadIdx.x; i < NW * NB; i += NT) (&s_cnt[0][0])[i] = 0;
+    __syncthreads();
+    uint32_t key[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        // item order inside a block: (wave, round, lane) = position = index order.  Unconditional and unclamped: all loads in flight,
+        // one base address + immediate offsets; what lies behind the block's end is other segments' records or unused scratch of the
+        // same allocation (rec holds 2 x capacity words) and is ignored below
+        key[r] = blk[w * (R * 64) + r * 64 + lane];
+    }
+    // (1) the waves' digit counts: fire-and-forget LDS atomics, nothing waits for them but the barrier
+#pragma unroll
+    for (int r = 0; r < R; r++)
+        if ((uint32_t)(w * (R * 64) + r * 64 + lane) < items) atomicAdd(&s_cnt[w][key[r] >> 24], 1u);
+    __syncthreads();
+    {   // (2) counts -> the local slot at which every wave's items of every digit begin; the digit's global position
+        uint32_t tv = 0;
+        if (has_dg) {
+#pragma unroll
+            for (int q = 0; q < NW; q++) tv += s_cnt[q][dg];
+        }
+        uint32_t tot;
+        const uint32_t ex = block_excl_scan<NW>(tv, s_wave, &tot);
+        if (has_dg) {
+            uint32_t run = ex;
+#pragma unroll
+            for (int q = 0; q < NW; q++) { const uint32_t cq = s_cnt[q][dg]; s_cnt[q][dg] = run; run += cq; }
+            // global position of local slot 0 of the digit: one block = the whole segment in digit order; several = the digit's
+            // run inside the segment + what the blocks before this one put there
+            s_gb[dg] = multi ? start + s_dbase[dg] + s_cur[dg] - ex : start;
+            if (multi) s_cur[dg] += tv;
+        }
+    }
+    __syncthreads();
+    // (3) stable ranks with the counters running on from those slots: the rank IS the item's local slot, it is placed at once and no
+    // rank outlives its eight rounds (all 32 ranks in registers at a time took 255 of them)
+#pragma unroll
+    for (int h = 0; h < R / 8; h++) {
+        uint32_t dig[8], slot[8]; bool ok[8];
+#pragma unroll
+        for (int r = 0; r < 8; r++) { ok[r] = (uint32_t)(w * (R * 64) + (h * 8 + r) * 64 + lane) < items; dig[r] = key[h * 8 + r] >> 24; }
+        wave_digit_ranks<8>(dig, ok, &s_match[w][0], &s_cnt[w][0], slot, lane);
+#pragma unroll
+        for (int r = 0; r < 8; r++) if (ok[r]) s_k[slot[r]] = key[h * 8 + r];
+    }
+    __syncthreads();
+#pragma unroll 8
+    for (int r = 0; r < R; r++) {                                     // (eight at a time: unrolled whole, the records, digit bases and addresses cost 100 registers)
+        const uint32_t slot = r * NT + threadIdx.x;
+        if (slot < items) { const uint32_t k = s_k[slot]; out[s_gb[k >> 24] + slot] = k & 0x00FFFFFFu; }
+    }
+    __syncthreads();
+}
+
+template <int NW, int IPT>
+__device__ __forceinline__ void k_seg_sort_body(const uint32_t *__restrict__ rec, uint32_t *__restrict__ out, const uint32_t *__restrict__ seg_tab, const uint32_t *fill_to)
+{
+    GS_CHAIN_PRIO();
+    constexpr int NT = 64 * NW, B = NT * IPT, NB = 256;
+    static_assert(NT >= NB && IPT == 16 && B == (int)GS_SEG_B, "one digit per thread; blocks of 8 / 16 rounds");
+    __shared__ uint32_t s_cnt[NW][NB];
+    __shared__ unsigned long long s_match[NW][NB];
+    __shared__ uint32_t s_dbase[NB], s_cur[NB], s_gb[NB];
+    __shared__ uint32_t s_k[B];
+    __shared__ uint32_t s_wave[NW];
+    const uint32_t dg = threadIdx.x < (uint32_t)NB ? threadIdx.x : 0u;
+    const bool has_dg = threadIdx.x < (uint32_t)NB;
+    const uint4 *items = reinterpret_cast<const uint4 *>(seg_tab + 4);
+    // (the header and the workgroup's first item in ONE round trip -- what this kernel reads was written by another XCD a moment ago,
+    // every dependent load is ~2 us: the table holds at least GS_SEG_GRID items' room, an item beyond the count is read and dropped)
+    const uint4 first_item = items[blockIdx.x];
+    const uint32_t nitems = seg_tab[0], total = seg_tab[1];
+    for (uint32_t i = threadIdx.x; i < NW * NB; i += NT) (&s_match[0][0])[i] = 0ull;   // (the ranking leaves them zero)
+    if (fill_to) {  // the zero tail behind the V' sorted records: splats whose bucket the reference drops (index.js:561-567 leave their slots 0)
+        const uint32_t upto = *fill_to;
+        for (uint32_t i = total + blockIdx.x * NT + threadIdx.x; i < upto; i += gridDim.x * NT) out[i] = 0u;
+    }
+    for (uint32_t v = blockIdx.x; v < nitems; v += gridDim.x) {
+        const uint4 it = v == blockIdx.x ? first_item : items[v];
+        const uint32_t start = it.x, len = it.y, blk = it.z, nblk = it.w;
+        const uint32_t *seg = rec + start;
+        __syncthreads();
+        if (nblk == 1u) {
+            if (len <= (uint32_t)NT * 8u) seg_sort_block<NW, 8>(seg, len, out, s_cnt, s_match, s_dbase, s_cur, s_gb, s_k, s_wave, start, false);
+            else seg_sort_block<NW, 16>(seg, len, out, s_cnt, s_match, s_dbase, s_cur, s_gb, s_k, s_wave, start, false);
+            continue;
+        }
+        // a segment of several blocks: its digit totals (the digits' run starts inside the segment) and what the blocks before THIS one
+        // hold of every digit (where this block's items of the digit go inside the run) -- counted here, by every block for itself
+        const bool all = nblk == 0xFFFFFFFFu;
+        const uint32_t before = all ? 0u : blk * (uint32_t)B;
+        if (has_dg) { s_cur[dg] = 0; s_dbase[dg] = 0; }
+        __syncthreads();
+        for (uint32_t i0 = 0; i0 < len; i0 += 16u * NT) {            // sixteen loads in flight per thread (unclamped: see seg_sort_block)
+            uint32_t t[16];
+#pragma unroll
+            for (int k = 0; k < 16; k++) t[k] = seg[i0 + (uint32_t)k * NT + threadIdx.x];
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                const uint32_t i = i0 + (uint32_t)k * NT + threadIdx.x;
+                if (i < len) { atomicAdd(&s_dbase[t[k] >> 24], 1u); if (i < before) atomicAdd(&s_cur[t[k] >> 24], 1u); }
+            }
+        }
+        __syncthreads();
+        const uint32_t tv = has_dg ? s_dbase[dg] : 0u;
+        uint32_t tt;
+        const uint32_t ex = block_excl_scan<NW>(tv, s_wave, &tt);
+        if (has_dg) s_dbase[dg] = ex;
+        __syncthreads();
+        if (!all) {
+            const uint32_t items_b = len - before < (uint32_t)B ? len - before : (uint32_t)B;
+            seg_sort_block<NW, 16>(seg + before, items_b, out, s_cnt, s_match, s_dbase, s_cur, s_gb, s_k, s_wave, start, true);
+        } else {
+            for (uint32_t b = 0; b * (uint32_t)B < len; b++) {
+                const uint32_t items_b = len - b * (uint32_t)B < (uint32_t)B ? len - b * (uint32_t)B : (uint32_t)B;
+                seg_sort_block<NW, 16>(seg + (size_t)b * B, items_b, out, s_cnt, s_match, s_dbase, s_cur, s_gb, s_k, s_wave, start, true);
+            }
+        }
+    }
+}
+
+template <int NW>
+__global__ __launch_bounds__(64 * NW, 4) void k_msd_scatter(const uint32_t *__restrict__ keys, uint32_t *__restrict__ rec, const uint32_t *n_ptr,
+                                                         const uint32_t *__restrict__ rows, const uint32_t *__restrict__ grp, uint32_t *count_out,
+                                                         uint32_t *__restrict__ seg_tab)
+{
+    k_msd_scatter_body<NW>(keys, rec, n_ptr, rows, grp, count_out, seg_tab);
+}
+template <int NW, int IPT>
+__global__ __launch_bounds__(64 * NW, 4) void k_seg_sort(const uint32_t *__restrict__ rec, uint32_t *__restrict__ out, const uint32_t *__restrict__ seg_tab, const uint32_t *fill_to)
+{
+    k_seg_sort_body<NW, IPT>(rec, out, seg_tab, fill_to);
+}
+template <int NW> GS_BODY(F_msd_scatter, k_msd_scatter_body<NW>);
+template <int NW, int IPT> GS_BODY(F_seg_sort, k_seg_sort_body<NW, IPT>);
+#define GS_SEG_GRID 512u           // k_seg_sort: workgroups (they stride over the work items: 256 segments + the extra blocks of the long ones)
+#ifndef GS_SEG_NW
+#define GS_SEG_NW 4                // k_seg_sort: wavefronts per workgroup ...
+#endif
+#ifndef GS_SEG_IPT
+#define GS_SEG_IPT 16              // ... and records per thread and block (4 x 64 x 16 = GS_SEG_B records per block)
+#endif
+
 uint32_t grid_for(uint32_t items, uint32_t chunk)
 {
     uint32_t g = gs_div_up(items, chunk);
@@ -441,6 +793,40 @@ int gs_launch_radix_pass2(gs_ctx *const S[2], const void *const in[2], int in_fm
     if (hint_n > max_n || hint_n == 0) hint_n = max_n;
     return gs_radix_chunk(hint_n) == GS_CHUNK_L ? launch_pass2<8>(S, in, in_fmt, out, out_fmt, n_ptr, hint_n, shift, bits, have_hist, zero_key, idx_bits, count_out, fill_to)
                                                 : launch_pass2<4>(S, in, in_fmt, out, out_fmt, n_ptr, hint_n, shift, bits, have_hist, zero_key, idx_bits, count_out, fill_to);
+}
+
+int gs_launch_msd_sort(gs_ctx *ctx, uint32_t n, bool near)
+{
+    const uint32_t chunk = gs_radix_chunk(n), g = grid_for(n, chunk);
+    hipStream_t st = ctx->stream;
+    uint32_t *rec = reinterpret_cast<uint32_t *>(ctx->kv_b);
+    if (chunk == GS_CHUNK_L) hipLaunchKernelGGL((k_msd_scatter<8>), dim3(g), dim3(512), 0, st, (const uint32_t *)ctx->key_a, rec, (const uint32_t *)&ctx->ctl->n_total,
+                                                (const uint32_t *)ctx->hist, (const uint32_t *)ctx->msd_grp, &ctx->ctl->n_sorted, ctx->msd_tab);
+    else hipLaunchKernelGGL((k_msd_scatter<4>), dim3(g), dim3(256), 0, st, (const uint32_t *)ctx->key_a, rec, (const uint32_t *)&ctx->ctl->n_total,
+                            (const uint32_t *)ctx->hist, (const uint32_t *)ctx->msd_grp, &ctx->ctl->n_sorted, ctx->msd_tab);
+    hipLaunchKernelGGL((k_seg_sort<GS_SEG_NW, GS_SEG_IPT>), dim3(GS_SEG_GRID), dim3(64 * GS_SEG_NW), 0, st, (const uint32_t *)rec, ctx->val_a, (const uint32_t *)ctx->msd_tab,
+                       near ? (const uint32_t *)nullptr : (const uint32_t *)&ctx->ctl->n_kept);
+    GS_HIP(hipGetLastError());
+    return GS_OK;
+}
+
+int gs_launch_msd_sort2(gs_ctx *const S[2], uint32_t n, bool near)
+{
+    gs_ctx *ctx = S[0];
+    const uint32_t chunk = gs_radix_chunk(n), g = grid_for(n, chunk);
+    hipStream_t st = ctx->stream;
+    uint32_t *rec[2] = { reinterpret_cast<uint32_t *>(S[0]->kv_b), reinterpret_cast<uint32_t *>(S[1]->kv_b) };
+#define GS_MSD_SC(NW) gs_twin_w<F_msd_scatter<NW>, 64 * NW, 4>(g, st,                                                                                      \
+        gs_pack_make((const uint32_t *)S[0]->key_a, rec[0], (const uint32_t *)&S[0]->ctl->n_total, (const uint32_t *)S[0]->hist, (const uint32_t *)S[0]->msd_grp, &S[0]->ctl->n_sorted, S[0]->msd_tab), \
+        gs_pack_make((const uint32_t *)S[1]->key_a, rec[1], (const uint32_t *)&S[1]->ctl->n_total, (const uint32_t *)S[1]->hist, (const uint32_t *)S[1]->msd_grp, &S[1]->ctl->n_sorted, S[1]->msd_tab))
+    if (chunk == GS_CHUNK_L) GS_MSD_SC(8); else GS_MSD_SC(4);
+#undef GS_MSD_SC
+    typedef F_seg_sort<GS_SEG_NW, GS_SEG_IPT> FS;
+    gs_twin_w<FS, 64 * GS_SEG_NW, 4>(GS_SEG_GRID, st,
+        gs_pack_make((const uint32_t *)rec[0], S[0]->val_a, (const uint32_t *)S[0]->msd_tab, near ? (const uint32_t *)nullptr : (const uint32_t *)&S[0]->ctl->n_kept),
+        gs_pack_make((const uint32_t *)rec[1], S[1]->val_a, (const uint32_t *)S[1]->msd_tab, near ? (const uint32_t *)nullptr : (const uint32_t *)&S[1]->ctl->n_kept));
+    GS_HIP(hipGetLastError());
+    return GS_OK;
 }
 
 uint32_t gs_radix_chunk(uint32_t hint_n) { return hint_n > GS_RADIX_LARGE_N ? GS_CHUNK_L : GS_CHUNK_S; }

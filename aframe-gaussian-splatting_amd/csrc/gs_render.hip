@@ -1151,10 +1151,14 @@ __device__ __forceinline__ void k_blend_body(const uint2 *__restrict__ tile_rang
     uint32_t nfr = 0, staged = 0, evaluated = 0;
     const uint2 range = tile_range[tile];
     if (u.split_min && range.y - range.x >= u.split_min) continue;  // a long list: k_blend_px takes the tile (GS_OPT_BLEND_SPLIT)
+    uint32_t j_mine = 0xFFFFFFFFu, nb_last = 0, e_l = 0;            // the sorted position this lane staged last / the size of the last batch / the last entry
+                                                                    // of that batch this lane evaluated (GsControl::need_near)
+    const uint32_t need_known = ctl->need_near[tile % GS_NEED_WORDS];   // (read now, compared at the end: a stale value only costs an atomic)
 
     for (uint32_t end = range.y; end > range.x;) {
         const uint32_t nb = min((uint32_t)GS_BLEND_BATCH, end - range.x);
         staged += nb;
+        nb_last = nb; e_l = 0;
 #pragma unroll
         for (int h = 0; h < GS_BLEND_BATCH / 64; h++) {            // nearest first: reverse the back-to-front list
             const uint32_t slot = h * 64 + lane;
@@ -1163,6 +1167,7 @@ __device__ __forceinline__ void k_blend_body(const uint2 *__restrict__ tile_rang
                                                 : reinterpret_cast<const uint2 *>(pairs)[end - 1 - slot].y;
                 const float4 *src = reinterpret_cast<const float4 *>(proj + j);
                 const float4 ra = src[0], rb = src[1];
+                if (GS_BLEND_BATCH == 64) j_mine = j;
                 // (cx, cy, ax, bx | ay, by, -, -): the two coefficients a row shares with dy sit in one register pair, so that
                 // dy * (ay, by) is one packed multiplication, and so do the two that multiply dx
                 s_ent[3 * slot] = make_float4(ra.x, ra.y, ra.z, rb.x);
@@ -1256,11 +1261,30 @@ __device__ __forceinline__ void k_blend_body(const uint2 *__restrict__ tile_rang
 #undef GS_ENT2
                 if (!live) break;
             }
+            e_l = min(vo / 48u + (GS_BLEND_SPLATS_PER_STEP - 1u), nb - 1u);   // (the step in which the lane left the list, or the batch's last entry)
             if (u.record_staged == 2) evaluated += min(vo / 48u + GS_BLEND_SPLATS_PER_STEP, nb);   // list entries this lane evaluated (measurement aid)
         }
         end -= nb;
         __syncthreads();                                           // s_ent is rewritten by the next batch
         if (__all(!live)) break;
+    }
+    if (!COUNT && GS_BLEND_BATCH == 64 && !(u.flags & GS_RENDER_NO_EARLY_OUT) && !u.pair_vcap) {   // (compact pair records name a splat by its index among the visible ones: no position)
+        // how many of the nearest splats this tile needed (GsControl::need_near): the sorted position of the entry at which its LAST
+        // lane left the list (lane k staged entry k of the batch: a tile's entries lie ~1000 sorted positions apart, "the batch" would
+        // be 40 % too much)
+        const bool sat = !__any(live);
+        const bool more = ROUND == 0 && u.near_count < ctl->n_kept;  // (not saturated, farther splats to come: round 1 speaks for the tile, or the frame is flagged)
+        if (sat || !more) {
+            uint32_t e_max = e_l;
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) e_max = max(e_max, (uint32_t)__shfl_xor((int)e_max, m, 64));
+            const uint32_t jf = nb_last ? (uint32_t)__shfl((int)j_mine, (int)e_max, 64) : 0xFFFFFFFFu;
+            if (lane == 0) {
+                const uint32_t V = ctl->n_kept;
+                const uint32_t need = !sat ? 0xFFFFFFFFu : (nb_last && jf < V ? V - jf : 0u);
+                if (need > need_known) atomicMax(&ctl->need_near[tile % GS_NEED_WORDS], need);
+            }
+        }
     }
     if (ROUND == 0 && u.near_count < ctl->n_kept) {               // farther splats exist beyond this round
         // the nearer splats did not saturate this tile: keep the exact per-pixel state for round 1 and flag the tile
@@ -1407,9 +1431,12 @@ __device__ __forceinline__ void k_blend_px_body(const uint2 *__restrict__ tile_r
             n0[h] = src[0]; n1[h] = src[1];                                                                                                  \
             if (SCENE) nz[h] = u.has_depth ? zwin[j] : 0.0f; } } } while (0)
         GS_PX_FETCH(range.y, min(PB, range.y - range.x));              // nearest first: the list is back to front
+        uint32_t end_w = range.y, e_l = 0;                              // this band's last batch was [.., end_w) of the list (nearest first); the last of its entries this lane evaluated
+        const uint32_t need_known = ctl->need_near[tile % GS_NEED_WORDS];
         for (uint32_t end = range.y; end > range.x;) {
             const uint32_t nb = min(PB, end - range.x);
             const uint32_t nbp = (nb + GS_PX_GROUP - 1u) & ~(GS_PX_GROUP - 1u);   // whole groups
+            end_w = end; e_l = 0;
 #pragma unroll
             for (uint32_t h = 0; h < PR; h++) {
                 const uint32_t slot = h * 64u + (uint32_t)lane;
@@ -1466,6 +1493,7 @@ __device__ __forceinline__ void k_blend_px_body(const uint2 *__restrict__ tile_r
                         cr = fmaf(cc[k].x, e, cr); cg = fmaf(cc[k].z, e, cg); cb = fmaf(cc[k].w, e, cb);
                     }
                     live = T >= t_eps;                                 // (checked per group: a few entries past the threshold, < t_eps in total)
+                    e_l = min(s4 + (GS_PX_GROUP - 1u), nb - 1u);
                     if (!live) break;
                 }
             }
@@ -1475,6 +1503,28 @@ __device__ __forceinline__ void k_blend_px_body(const uint2 *__restrict__ tile_r
         }
         const bool wave_live = __any(live);
         if (lane == 0) s_live[w] = wave_live ? 1u : 0u;
+        if (!(u.flags & GS_RENDER_NO_EARLY_OUT) && !u.pair_vcap) {
+            // GsControl::need_near, per band of the tile (as k_blend per tile): the list entry at which the band's last pixel stopped
+            const bool more = ROUND == 0 && u.near_count < ctl->n_kept;
+            if (!wave_live || !more) {
+                uint32_t e_max = e_l;
+#pragma unroll
+                for (int m = 32; m >= 1; m >>= 1) e_max = max(e_max, (uint32_t)__shfl_xor((int)e_max, m, 64));
+                if (lane == 0) {
+                    const uint32_t V = ctl->n_kept;
+                    uint32_t need = 0xFFFFFFFFu;
+                    if (!wave_live) {
+                        need = 0u;
+                        if (range.y > range.x && end_w > range.x + e_max) {
+                            const uint32_t li = end_w - 1u - e_max;      // (slot s of a batch = list entry end - 1 - s)
+                            const uint32_t jf = u.pair_jbits ? pair_j_lo + (reinterpret_cast<const uint32_t *>(pairs)[li] & pair_j_mask) : reinterpret_cast<const uint2 *>(pairs)[li].y;
+                            need = jf < V ? V - jf : 0u;
+                        }
+                    }
+                    if (need > need_known) atomicMax(&ctl->need_near[tile % GS_NEED_WORDS], need);
+                }
+            }
+        }
         __syncthreads();
         const bool tile_live = (s_live[0] | s_live[1] | s_live[2] | s_live[3]) != 0u;
         if (ROUND == 0 && u.near_count < ctl->n_kept && tile_live) {  // farther splats exist beyond this round and the tile wants them

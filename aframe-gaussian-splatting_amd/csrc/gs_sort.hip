@@ -47,7 +47,7 @@ __device__ __forceinline__ double shfl_xor_f64(double v, int m)
 // the release / acquire fences that takes across the 8 XCDs' L2s cost 70 us per sort.)
 // fill: this sort's histogram (nullptr: none wanted); zero: the one the lane's previous near-only sort filled, cleared here
 // (its reader finished long ago: stream order); zero_word: the control block's count of valid buckets, recounted by k_sort_bucket.
-struct DepthHist { uint32_t *fill, *zero, *zero_word; };
+struct DepthHist { uint32_t *fill, *zero, *zero_word; uint32_t *zero_grp; uint32_t zero_grp_words; };   // zero_grp: the MSD sort's group rows (below), cleared for k_sort_bucket<.., MSD>'s atomics
 __device__ __forceinline__ uint32_t depth_bin(float d) { return (__float_as_uint(d) & 0x7FFFFFFFu) >> 20; }
 __device__ __forceinline__ void depth_hist_begin(const DepthHist &dh, uint32_t *s_dh)
 {
@@ -55,6 +55,7 @@ __device__ __forceinline__ void depth_hist_begin(const DepthHist &dh, uint32_t *
     if (blockIdx.x == 0) {
         if (dh.zero) for (uint32_t d = threadIdx.x; d < GS_DH_WORDS / 4u; d += GS_BLOCK) reinterpret_cast<uint4 *>(dh.zero)[d] = make_uint4(0, 0, 0, 0);
         if (dh.zero_word && threadIdx.x == 0) *dh.zero_word = 0;
+        if (dh.zero_grp) for (uint32_t d = threadIdx.x; d < dh.zero_grp_words / 4u; d += GS_BLOCK) reinterpret_cast<uint4 *>(dh.zero_grp)[d] = make_uint4(0, 0, 0, 0);
     }
 }
 // (after a barrier that follows the last LDS atomic)  Two levels: the bins, and behind them sums over 32 consecutive bins each
@@ -339,20 +340,25 @@ __global__ __launch_bounds__(GS_BLOCK) void k_sort_depth_pair(const float4 *__re
 // exactly the last P valid positions of the whole order, in the same relative order.  The others leave like culled splats
 // (GS_RADIX_SKIP).  The kernel also counts V' (valid buckets among ALL kept splats): the survivors sit at positions
 // [V' - P, V') of the order (k_project subtracts V' - P).
-template <int NW, bool COMPACT, bool NEAR>
+// MSD (round 5, N <= 2^24: "the MSD sort" further down): the chunk's histogram row is that of the HIGH bucket byte -- H[chunk][bucket >> 8],
+// 256 words -- and the row is also added to the row of the chunk's GROUP of GS_MSD_GROUP chunks (one atomicAdd per digit the chunk
+// holds: 4096 distinct words at 1 M splats, each hit 32 times; cleared by the depth pass), so that k_msd_scatter finds the chunk's
+// offsets with ~50 row reads instead of a scan launch.  NEAR + MSD: a near-only sort through the same four launches.
+template <int NW, bool COMPACT, bool NEAR, bool MSD = false>
 __device__ __forceinline__ void k_sort_bucket_body(const float *__restrict__ depth, uint32_t n, uint32_t *__restrict__ keys,
                                                    const unsigned long long *__restrict__ part_min,
                                                    const unsigned long long *__restrict__ part_max,
                                                    const uint32_t *__restrict__ part_cnt, uint32_t nparts,
                                                    uint32_t *__restrict__ hist, GsControl *ctl, const uint32_t *__restrict__ dhist, uint32_t near_req,
-                                                   uint32_t *__restrict__ bin_hint)
+                                                   uint32_t *__restrict__ bin_hint, uint32_t *__restrict__ grp)
 {
     GS_CHAIN_PRIO();
     static_assert(!NEAR || COMPACT, "near-only sorts use the compact records");
+    static_assert(!MSD || COMPACT, "the MSD sort takes compact records");
     constexpr int NT = 64 * NW, IPT = 8, CH = NT * IPT;
     __shared__ unsigned long long s_min, s_max;
     __shared__ uint32_t s_cnt;
-    constexpr uint32_t BINS = COMPACT ? 512u : 256u;
+    constexpr uint32_t BINS = MSD ? 256u : (COMPACT ? 512u : 256u);
     __shared__ uint32_t s_hist[BINS];                             // low-digit histogram of this chunk = radix pass A's input
     __shared__ uint32_t s_nvalid;
     __shared__ int32_t s_bcut;
@@ -437,7 +443,8 @@ __device__ __forceinline__ void k_sort_bucket_body(const float *__restrict__ dep
                 uint32_t k = GS_RADIX_SKIP;
                 if (d != INFINITY) {
                     const int32_t b = gsm::sort_bucket(d, mn, inv);
-                    if (NEAR) { if (b >= 0) { nvalid++; if (b >= bcut) { k = (uint32_t)b; atomicAdd(&s_hist[k & 511u], 1u); } } }
+                    if (NEAR) { if (b >= 0) { nvalid++; if (b >= bcut) { k = (uint32_t)b; atomicAdd(&s_hist[MSD ? k >> 8 : k & 511u], 1u); } } }
+                    else if (MSD) { if (b >= 0) { k = (uint32_t)b; atomicAdd(&s_hist[k >> 8], 1u); } }
                     else if (COMPACT) { if (b >= 0) { k = (uint32_t)b; atomicAdd(&s_hist[k & 511u], 1u); } }
                     else { k = b >= 0 ? (uint32_t)b : GS_CULLED_KEY; atomicAdd(&s_hist[k & 255u], 1u); }
                 }
@@ -445,7 +452,11 @@ __device__ __forceinline__ void k_sort_bucket_body(const float *__restrict__ dep
             }
         }
         __syncthreads();
-        for (uint32_t d = threadIdx.x; d < BINS; d += NT) hist[(size_t)c * BINS + d] = s_hist[d];   // row c of hist[chunk][digit]
+        for (uint32_t d = threadIdx.x; d < BINS; d += NT) {
+            const uint32_t hv = s_hist[d];
+            hist[(size_t)c * BINS + d] = hv;                       // row c of hist[chunk][digit]
+            if (MSD && hv) atomicAdd(&grp[(size_t)(c / GS_MSD_GROUP) * BINS + d], hv);   // ... and into the row of the chunk's group
+        }
         __syncthreads();
     }
     if (NEAR) {                                                      // V' of the whole order: one global atomic per workgroup
@@ -457,15 +468,15 @@ __device__ __forceinline__ void k_sort_bucket_body(const float *__restrict__ dep
     }
 }
 
-template <int NW, bool COMPACT, bool NEAR>
+template <int NW, bool COMPACT, bool NEAR, bool MSD = false>
 __global__ __launch_bounds__(64 * NW) void k_sort_bucket(const float *__restrict__ depth, uint32_t n, uint32_t *__restrict__ keys,
                                                          const unsigned long long *__restrict__ part_min,
                                                          const unsigned long long *__restrict__ part_max,
                                                          const uint32_t *__restrict__ part_cnt, uint32_t nparts,
                                                          uint32_t *__restrict__ hist, GsControl *ctl, const uint32_t *__restrict__ dhist, uint32_t near_req,
-                                                         uint32_t *__restrict__ bin_hint)
+                                                         uint32_t *__restrict__ bin_hint, uint32_t *__restrict__ grp)
 {
-    k_sort_bucket_body<NW, COMPACT, NEAR>(depth, n, keys, part_min, part_max, part_cnt, nparts, hist, ctl, dhist, near_req, bin_hint);
+    k_sort_bucket_body<NW, COMPACT, NEAR, MSD>(depth, n, keys, part_min, part_max, part_cnt, nparts, hist, ctl, dhist, near_req, bin_hint, grp);
 }
 
 // Near-only sorts of LONG inputs (round 3).  k_sort_bucket<.., NEAR> still wrote a key for every one of the N splats and pass A
@@ -822,7 +833,7 @@ __global__ __launch_bounds__(GS_BLOCK) void k_near_gather(const uint2 *__restric
     k_near_gather_body(stash, cnt, n, chunk, out, ctl);
 }
 
-template <int NW, bool COMPACT, bool NEAR> GS_BODY(F_sort_bucket, k_sort_bucket_body<NW, COMPACT, NEAR>);
+template <int NW, bool COMPACT, bool NEAR, bool MSD = false> GS_BODY(F_sort_bucket, k_sort_bucket_body<NW, COMPACT, NEAR, MSD>);
 
 }  // namespace
 
@@ -844,13 +855,29 @@ static DepthHist next_depth_hist(gs_ctx *L, bool near)
 {
     DepthHist dh;
     dh.zero = L->dh_dirty; L->dh_dirty = nullptr;
-    dh.fill = nullptr; dh.zero_word = nullptr;
+    dh.fill = nullptr; dh.zero_word = nullptr; dh.zero_grp = nullptr; dh.zero_grp_words = 0;
     if (near) {
         dh.fill = L->dhist[L->dh_next]; L->dh_next ^= 1;
         L->dh_dirty = dh.fill;
         dh.zero_word = &L->ctl->n_valid;
     }
     return dh;
+}
+
+// The MSD sort (round 5; kernels and rationale in gs_prims.hip): whole sorts with compact records of at most 2^24 splats take four
+// launches -- depth, bucket (+ rows of the high bucket byte per chunk and per group of chunks), k_msd_scatter, k_seg_sort -- instead
+// of seven; so do near-only sorts that do not go through the chunk stashes (the bucket pass drops what lies behind the threshold, the
+// two kernels behind it see the survivors alone).  GS_SORT_MSD=0 in the environment keeps the two LSD passes (A/B runs; longer sorts use them anyway).
+bool gs_msd_enabled() { static const bool on = []() { const char *e = getenv("GS_SORT_MSD"); return !(e && e[0] == '0'); }(); return on; }
+static bool gs_msd_ok(const gs_ctx *L, uint32_t n, bool compact)
+{
+    return gs_msd_enabled() && compact && n <= GS_MSD_MAX_N && L->msd_grp &&
+           (size_t)256 * (gs_div_up(gs_div_up(n, gs_radix_chunk(n)), GS_MSD_GROUP) + 1u) <= L->msd_grp_cap;
+}
+static void gs_msd_arm(const gs_ctx *L, uint32_t n, DepthHist &dh)   // the depth pass clears the group rows the bucket pass adds to
+{
+    dh.zero_grp = L->msd_grp;
+    dh.zero_grp_words = 256u * gs_div_up(gs_div_up(n, gs_radix_chunk(n)), GS_MSD_GROUP);
 }
 
 // may this near-only sort hand its survivors on through the chunk stashes?  Long inputs only (the 4096-item geometry), a share of
@@ -896,6 +923,9 @@ int gs_run_sort2(gs_ctx *const S[2], const float *const view[2], const float *co
     const bool near = compact && near_req && near_req[0] && near_req[1];   // (a pair takes one path)
     DepthHist dh[2];
     for (int k = 0; k < 2; k++) { gs_remember_sort(S[k], view[k], cutout16[k], strip ? strip[k] : nullptr, near ? near_req[k] : 0u); dh[k] = next_depth_hist(S[k], near); }
+    const bool msd = gs_msd_ok(S[0], n, compact) && gs_msd_ok(S[1], n, compact) &&
+                     !(near && gs_near_stash_ok(S[0], n, near_req[0]) && gs_near_stash_ok(S[1], n, near_req[1]));   // (long near-only sorts keep their stashes)
+    if (msd) for (int k = 0; k < 2; k++) gs_msd_arm(S[k], n, dh[k]);
     const bool strips = u[0].has_strip && u[1].has_strip;
     if (!strips) u[0].has_strip = u[1].has_strip = 0;              // (a pair takes one path: both strip sorts, or both plain)
     const uint32_t g = gs_radix_grid(n);
@@ -955,11 +985,27 @@ int gs_run_sort2(gs_ctx *const S[2], const float *const view[2], const float *co
         for (int k = 0; k < 2; k++) { S[k]->sorted = S[k]->val_a; S[k]->have_sort = true; }
         return GS_OK;
     }
+    if (msd) {
+#define GS_BUCKETM(NW, NR) gs_twin<F_sort_bucket<NW, true, NR, true>, 64 * NW>(g, st,                                                                    \
+        gs_pack_make((const float *)S[0]->depth, n, S[0]->key_a, (const unsigned long long *)S[0]->part_min, (const unsigned long long *)S[0]->part_max,     \
+                     (const uint32_t *)S[0]->part_cnt, gd, S[0]->hist, S[0]->ctl, (const uint32_t *)dh[0].fill, S[0]->sort_near_req, bin_hint, S[0]->msd_grp), \
+        gs_pack_make((const float *)S[1]->depth, n, S[1]->key_a, (const unsigned long long *)S[1]->part_min, (const unsigned long long *)S[1]->part_max,     \
+                     (const uint32_t *)S[1]->part_cnt, gd, S[1]->hist, S[1]->ctl, (const uint32_t *)dh[1].fill, S[1]->sort_near_req, bin_hint, S[1]->msd_grp))
+        if (gs_radix_chunk(n) == GS_CHUNK_L) { if (near) GS_BUCKETM(8, true); else GS_BUCKETM(8, false); }
+        else { if (near) GS_BUCKETM(4, true); else GS_BUCKETM(4, false); }
+#undef GS_BUCKETM
+        GS_HIP(hipGetLastError());
+        const int rcm = gs_launch_msd_sort2(S, n, near);
+        if (rcm != GS_OK) return rcm;
+        GS_PROF_RECORD(ctx, 1);
+        for (int k = 0; k < 2; k++) { S[k]->sorted = S[k]->val_a; S[k]->have_sort = true; }
+        return GS_OK;
+    }
 #define GS_BUCKET2(NW, C, NR) gs_twin<F_sort_bucket<NW, C, NR>, 64 * NW>(g, st,                                                                            \
         gs_pack_make((const float *)S[0]->depth, n, S[0]->key_a, (const unsigned long long *)S[0]->part_min, (const unsigned long long *)S[0]->part_max,     \
-                     (const uint32_t *)S[0]->part_cnt, gd, S[0]->hist, S[0]->ctl, (const uint32_t *)dh[0].fill, S[0]->sort_near_req, bin_hint),             \
+                     (const uint32_t *)S[0]->part_cnt, gd, S[0]->hist, S[0]->ctl, (const uint32_t *)dh[0].fill, S[0]->sort_near_req, bin_hint, (uint32_t *)nullptr), \
         gs_pack_make((const float *)S[1]->depth, n, S[1]->key_a, (const unsigned long long *)S[1]->part_min, (const unsigned long long *)S[1]->part_max,     \
-                     (const uint32_t *)S[1]->part_cnt, gd, S[1]->hist, S[1]->ctl, (const uint32_t *)dh[1].fill, S[1]->sort_near_req, bin_hint))
+                     (const uint32_t *)S[1]->part_cnt, gd, S[1]->hist, S[1]->ctl, (const uint32_t *)dh[1].fill, S[1]->sort_near_req, bin_hint, (uint32_t *)nullptr))
     if (gs_radix_chunk(n) == GS_CHUNK_L) { if (near) GS_BUCKET2(8, true, true); else if (compact) GS_BUCKET2(8, true, false); else GS_BUCKET2(8, false, false); }
     else { if (near) GS_BUCKET2(4, true, true); else if (compact) GS_BUCKET2(4, true, false); else GS_BUCKET2(4, false, false); }
 #undef GS_BUCKET2
@@ -1039,7 +1085,9 @@ int gs_run_sort(gs_ctx *ctx, const float view[4], const float *cutout16, const G
     const bool compact = !ctx->wide_pairs && n <= (1u << 25);
     const bool near = compact && near_req;
     gs_remember_sort(ctx, view, cutout16, strip, near ? near_req : 0u);
-    const DepthHist dh = next_depth_hist(ctx, near);
+    DepthHist dh = next_depth_hist(ctx, near);
+    const bool msd = gs_msd_ok(ctx, n, compact) && !(near && gs_near_stash_ok(ctx, n, near_req));   // (long near-only sorts keep their stashes)
+    if (msd) gs_msd_arm(ctx, n, dh);
 
     const uint32_t g = gs_radix_grid(n);                         // same chunking as the radix kernels (pre-filled histogram rows)
     GS_PROF_RECORD(ctx, 0);
@@ -1080,8 +1128,24 @@ int gs_run_sort(gs_ctx *ctx, const float view[4], const float *cutout16, const G
         ctx->have_sort = true;
         return GS_OK;
     }
+    if (msd) {
+        // four launches: depth (above), bucket + rows of the high bucket byte, one stable scatter by that byte, one LDS sort per segment
+#define GS_LAUNCH_BUCKETM(NW, NR) hipLaunchKernelGGL((k_sort_bucket<NW, true, NR, true>), dim3(g), dim3(64 * NW), 0, ctx->stream, (const float *)ctx->depth, n, ctx->key_a,     \
+                                                     (const unsigned long long *)ctx->part_min, (const unsigned long long *)ctx->part_max, (const uint32_t *)ctx->part_cnt, gd, \
+                                                     ctx->hist, ctx->ctl, (const uint32_t *)dh.fill, ctx->sort_near_req, bin_hint, ctx->msd_grp)
+        if (gs_radix_chunk(n) == GS_CHUNK_L) { if (near) GS_LAUNCH_BUCKETM(8, true); else GS_LAUNCH_BUCKETM(8, false); }
+        else { if (near) GS_LAUNCH_BUCKETM(4, true); else GS_LAUNCH_BUCKETM(4, false); }
+#undef GS_LAUNCH_BUCKETM
+        GS_HIP(hipGetLastError());
+        const int rcm = gs_launch_msd_sort(ctx, n, near);
+        if (rcm != GS_OK) return rcm;
+        GS_PROF_RECORD(ctx, 1);
+        ctx->sorted = ctx->val_a;
+        ctx->have_sort = true;
+        return GS_OK;
+    }
 #define GS_LAUNCH_BUCKET(NW, C, NR) hipLaunchKernelGGL((k_sort_bucket<NW, C, NR>), dim3(g), dim3(64 * NW), 0, ctx->stream, ctx->depth, n, ctx->key_a, \
-                                                       ctx->part_min, ctx->part_max, ctx->part_cnt, gd, ctx->hist, ctx->ctl, (const uint32_t *)dh.fill, ctx->sort_near_req, bin_hint)
+                                                       ctx->part_min, ctx->part_max, ctx->part_cnt, gd, ctx->hist, ctx->ctl, (const uint32_t *)dh.fill, ctx->sort_near_req, bin_hint, (uint32_t *)nullptr)
     if (gs_radix_chunk(n) == GS_CHUNK_L) { if (near) GS_LAUNCH_BUCKET(8, true, true); else if (compact) GS_LAUNCH_BUCKET(8, true, false); else GS_LAUNCH_BUCKET(8, false, false); }
     else { if (near) GS_LAUNCH_BUCKET(4, true, true); else if (compact) GS_LAUNCH_BUCKET(4, true, false); else GS_LAUNCH_BUCKET(4, false, false); }
 #undef GS_LAUNCH_BUCKET

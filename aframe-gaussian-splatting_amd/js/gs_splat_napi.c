@@ -659,7 +659,7 @@ static napi_value fn_stats(napi_env env, napi_callback_info info)
     PUT("nFrags", s.n_frags); PUT("nTiles", s.n_tiles); PUT("msSort", s.ms_sort); PUT("msProject", s.ms_project);
     PUT("msBin", s.ms_bin); PUT("msBlend", s.ms_blend); PUT("msRender", s.ms_render);
     PUT("accFrames", s.acc_frames); PUT("unsatTiles", s.unsat_tiles); PUT("nearPermille", s.near_permille); PUT("sortRecords", s.sort_records);
-    PUT("retriedFrames", s.retried_frames); PUT("specSorts", s.spec_sorts); PUT("specMisses", s.spec_misses);
+    PUT("retriedFrames", s.retried_frames); PUT("specSorts", s.spec_sorts); PUT("specMisses", s.spec_misses); PUT("needSplats", s.need_splats);
 #undef PUT
     return o;
 }

@@ -422,6 +422,20 @@ def main():
         }
         if extras:
             out.update(extras)
+        # one roofline entry per stage of the headline frame ("per kernel and per frame"), counter bytes beside them
+        try:
+            out["rooflines"] = stage_rooflines(out["per_frame"], n_splats, V, Vp, I, own_px, pmc_cfg)
+        except Exception as e:                                        # noqa: BLE001 -- an extra never costs the line
+            out.setdefault("extras_failed", {})["rooflines"] = repr(e)[:200]
+        # the other BASELINE.json configurations, each in a context of its own, as the table draws them (C4 and C5 on this ONE GPU)
+        if world == 1 and cfg_name == "C2" and not args.no_configs and not args.no_extras:
+            out["configs"] = {}
+            cs, cw = min(K, 120), args.warmup
+            for other in ("C1", "C3", "C4", "C5"):
+                try:
+                    out["configs"][other] = measure_config(other, capi, synth, BC, cs, cw, ctx.device)
+                except Exception as e:                                    # noqa: BLE001
+                    out["configs"][other] = {"error": (type(e).__name__ + ": " + str(e))[:300]}
         if world == 1 and not args.no_cpu_baseline and not args.xr:
             out["cpu_baseline"] = cpu_baseline(rows, cams[args.warmup % ORBIT_FRAMES], synth)
         if (args.size or args.cutout or args.splats) and not args.xr:
@@ -625,280 +639,447 @@ def secondary_measurements(ctx, capi, synth, rows, cams, views, n_splats, args, 
         return time.perf_counter() - t0
 
     n = min(args.steps, 240)
-    # latency: one frame in flight (pipeline depth 1, frames not paired): the kernel chain of a frame alone on the GPU
-    ctx.set_option(capi.OPT_FRAME_BATCH, 1)
-    ctx.set_option(capi.OPT_PIPELINE_DEPTH, 1)
-    loop(24, capi.RENDER_ASYNC)
-    t = loop(n, capi.RENDER_ASYNC) or loop(n, capi.RENDER_ASYNC)
-    out["latency"] = {"fps_depth1": round(n / t, 1), "ms_per_frame_depth1": round(t / n * 1e3, 4),
-                      "note": "GS_OPT_PIPELINE_DEPTH = 1: frames enqueued back to back on ONE stream, nothing overlaps"}
-    # the same single stream with two frames per launch (GS_OPT_FRAME_BATCH = 2 at depth 1): still nothing overlaps, but a chain of
-    # 18 launches draws two frames -- a throughput figure for one stream, NOT a frame's latency (that is ms_per_frame_depth1)
-    ctx.set_option(capi.OPT_FRAME_BATCH, 2)
-    loop(24, capi.RENDER_ASYNC)
-    t2 = loop(n, capi.RENDER_ASYNC) or loop(n, capi.RENDER_ASYNC)
-    ctx.set_option(capi.OPT_FRAME_BATCH, 1)
-    out["latency"].update({"fps_one_stream_paired": round(n / t2, 1), "ms_per_frame_one_stream_paired": round(t2 / n * 1e3, 4)})
-    # entries the blend evaluates (longest-lived lane per tile) -> VALU roofline of the blend, one frame at a time so that the
-    # kernel's HIP-event time is its own
-    ctx.set_option(capi.OPT_PROFILE, 2)
-    loop(24, capi.RENDER_ASYNC)
-    ctx.set_option(capi.OPT_PROFILE, 0); ctx.set_option(capi.OPT_PROFILE, 2)
-    loop(48, capi.RENDER_ASYNC)
-    sb = ctx.stats()
-    ctx.set_option(capi.OPT_PROFILE, 0)
-    blend_alone_s = sb["sum_ms_blend"] / max(1, sb["prof_frames"]) * 1e-3
-    ctx.set_option(capi.OPT_RECORD_STAGED, 2)
-    ev = []
-    ntl = ((W + 15) // 16) * ((H + 15) // 16)
-    for k in range(0, 48, 6):
-        ctx.sort(cams[k]["view"], cams[k]["cutout"], want_indices=False)
-        views[k][0].flags = 0
-        ctx.render_device(views[k][0], None)
-        ev.append(int(ctx.download(capi.BUF_TILE_STATS, ntl, np.uint32, 2)[:, 0].astype(np.int64).sum()))
-    ctx.set_option(capi.OPT_RECORD_STAGED, 0)
-    entries = float(np.mean(ev))
-    rv = {"kernel": "k_blend", "bound": "valu", "unit": "G wave-instr/s", "list_entries_evaluated_per_frame": round(entries),
-          "avg_launch_ms_alone": round(blend_alone_s * 1e3, 4)}
-    row, fpl = pmc_blend_row(pmc_cfg) if pmc_cfg else (None, 1)
-    vv = (row or {}).get("valu")
-    pmc_entries = (pmc_cfg or {}).get("run_valu", {}).get("entries_evaluated_per_frame") or (pmc_cfg or {}).get("run", {}).get("entries_evaluated_per_frame")
-    if vv and pmc_entries and vv.get("SQ_INSTS_VALU"):
-        per_entry = vv["SQ_INSTS_VALU"] / (pmc_entries * fpl)                  # VALU wave-instructions per evaluated list entry (256 pixels)
-        cyc = 4.0 * vv["SQ_ACTIVE_INST_VALU"] / vv["SQ_INSTS_VALU"]            # SIMD cycles per VALU wave-instruction of this kernel's mix
-        instr_rate = entries * per_entry / blend_alone_s / 1e9 if blend_alone_s > 0 else 0.0
-        peak_guide, peak_ctr = SIMDS * CLOCK_GHZ / GUIDE_CYCLES_PER_VALU, SIMDS * CLOCK_GHZ / cyc
-        rv.update({"achieved": round(instr_rate, 1), "peak": round(peak_guide, 1), "frac": round(instr_rate / peak_guide, 4),
-                   "peak_at_counted_issue_cost": round(peak_ctr, 1), "frac_at_counted_issue_cost": round(instr_rate / peak_ctr, 4),
-                   "instr_per_list_entry": round(per_entry, 2), "cycles_per_instr_counted": round(cyc, 3), "cycles_per_instr_guide": GUIDE_CYCLES_PER_VALU,
-                   "pmc": {"SQ_INSTS_VALU_per_launch": vv["SQ_INSTS_VALU"], "SQ_ACTIVE_INST_VALU_quad_cycles_per_launch": vv["SQ_ACTIVE_INST_VALU"],
-                           "SQ_BUSY_CYCLES_per_launch": vv.get("SQ_BUSY_CYCLES"), "SQ_WAVES_per_launch": vv.get("SQ_WAVES"),
-                           "SQ_INSTS_LDS_per_launch": vv.get("SQ_INSTS_LDS"), "frames_per_launch": fpl,
-                           "list_entries_evaluated_per_frame_in_the_profiled_run": round(pmc_entries), "source": "profiles/pmc_counters.json"},
-                   "note": "VALU wave-instructions issued per second by the blend running alone (depth 1).  instr_per_list_entry and the issue "
-                           "cost are THIS build's counters: SQ_INSTS_VALU of the blend / list entries the same profiled loop's blend evaluates; "
-                           "4 x SQ_ACTIVE_INST_VALU (quad-cycles) / SQ_INSTS_VALU = SIMD cycles per VALU wave-instruction.  `peak` prices an "
-                           "instruction at the guide's 2 cycles per wave64 VALU (MI355X_MICROARCH.md: the rate of the 157.3 TF vector-fp32 "
-                           "datasheet figure, which counts both halves of a packed v_pk_fma_f32); the counters say that every kernel of this "
-                           "library spends 4.0-4.3 cycles per VALU wave-instruction (a wave64 instruction passes a 16-lane SIMD in 4 cycles; "
-                           "packed-fp32 and v_exp_f32 take longer), which is `peak_at_counted_issue_cost` -- the roof the kernel can actually reach "
-                           "without packing more work into an instruction"})
-    else:
-        rv.update({"achieved": None, "peak": round(SIMDS * CLOCK_GHZ / GUIDE_CYCLES_PER_VALU, 1), "frac": None,
-                   "note": "no VALU counter pass of these kernel sources in profiles/pmc_counters.json (tools/gpu_pmc.sh): not computed from constants"})
-    out["roofline_valu"] = rv
-    # the frame delivered to the host (what a JS caller of component.render() gets): gs_render into page-locked memory.  Two ways
-    # there (GS_OPT_HOST_WRITE): the copy engine behind the frame's last kernel, or the blend kernel storing its tiles straight into
-    # the page-locked frame; the denominator is this box's own device-to-host rate (1 GiB, page-locked, same run)
-    pcie = measured_pcie_peak(capi)
-    fb_bytes = W * H * 4
-    host, owner = capi.host_frame(H, W)
-    m = min(n, 120)
+    def guard(name, part):
+        """every extra in its own try/except: an exception in one of them must never cost the driver its line;
+        the options an extra switches are put back whatever happened"""
+        try:
+            part()
+        except Exception as e:                                   # noqa: BLE001 -- reported in the line, never raised
+            out.setdefault("extras_failed", {})[name] = (type(e).__name__ + ": " + str(e))[:300]
+            try:
+                ctx.sync()
+            except Exception:                                    # noqa: BLE001
+                pass
+        for opt, val in ((capi.OPT_PROFILE, 0), (capi.OPT_RECORD_STAGED, 0), (capi.OPT_HOST_WRITE, 0),
+                         (capi.OPT_PIPELINE_DEPTH, int(os.environ.get("GS_BENCH_DEPTH", "0")) or 3), (capi.OPT_FRAME_BATCH, frame_batch)):
+            try:
+                ctx.set_option(opt, val)
+            except Exception:                                    # noqa: BLE001
+                pass
 
-    def loop_sync(mm):
-        t0 = time.perf_counter()
-        for i in range(mm):
-            k = i % ORBIT_FRAMES
+    def part_latency():
+        # latency: one frame in flight (pipeline depth 1, frames not paired): the kernel chain of a frame alone on the GPU
+        ctx.set_option(capi.OPT_FRAME_BATCH, 1)
+        ctx.set_option(capi.OPT_PIPELINE_DEPTH, 1)
+        loop(24, capi.RENDER_ASYNC)
+        t = loop(n, capi.RENDER_ASYNC) or loop(n, capi.RENDER_ASYNC)
+        out["latency"] = {"fps_depth1": round(n / t, 1), "ms_per_frame_depth1": round(t / n * 1e3, 4),
+                          "note": "GS_OPT_PIPELINE_DEPTH = 1: frames enqueued back to back on ONE stream, nothing overlaps"}
+        # the same single stream with two frames per launch (GS_OPT_FRAME_BATCH = 2 at depth 1): still nothing overlaps, but a chain of
+        # 18 launches draws two frames -- a throughput figure for one stream, NOT a frame's latency (that is ms_per_frame_depth1)
+        ctx.set_option(capi.OPT_FRAME_BATCH, 2)
+        loop(24, capi.RENDER_ASYNC)
+        t2 = loop(n, capi.RENDER_ASYNC) or loop(n, capi.RENDER_ASYNC)
+        ctx.set_option(capi.OPT_FRAME_BATCH, 1)
+        out["latency"].update({"fps_one_stream_paired": round(n / t2, 1), "ms_per_frame_one_stream_paired": round(t2 / n * 1e3, 4)})
+    guard('latency', part_latency)
+
+    def part_roofline_valu():
+        # entries the blend evaluates (longest-lived lane per tile) -> VALU roofline of the blend, one frame at a time so that the
+        # kernel's HIP-event time is its own
+        ctx.set_option(capi.OPT_FRAME_BATCH, 1)
+        ctx.set_option(capi.OPT_PIPELINE_DEPTH, 1)
+        ctx.set_option(capi.OPT_PROFILE, 2)
+        loop(24, capi.RENDER_ASYNC)
+        ctx.set_option(capi.OPT_PROFILE, 0); ctx.set_option(capi.OPT_PROFILE, 2)
+        loop(48, capi.RENDER_ASYNC)
+        sb = ctx.stats()
+        ctx.set_option(capi.OPT_PROFILE, 0)
+        blend_alone_s = sb["sum_ms_blend"] / max(1, sb["prof_frames"]) * 1e-3
+        ctx.set_option(capi.OPT_RECORD_STAGED, 2)
+        ev = []
+        ntl = ((W + 15) // 16) * ((H + 15) // 16)
+        for k in range(0, 48, 6):
             ctx.sort(cams[k]["view"], cams[k]["cutout"], want_indices=False)
             views[k][0].flags = 0
-            ctx.render_into(views[k][0], host)
-        return time.perf_counter() - t0
+            ctx.render_device(views[k][0], None)
+            ev.append(int(ctx.download(capi.BUF_TILE_STATS, ntl, np.uint32, 2)[:, 0].astype(np.int64).sum()))
+        ctx.set_option(capi.OPT_RECORD_STAGED, 0)
+        entries = float(np.mean(ev))
+        rv = {"kernel": "k_blend", "bound": "valu", "unit": "G wave-instr/s", "list_entries_evaluated_per_frame": round(entries),
+              "avg_launch_ms_alone": round(blend_alone_s * 1e3, 4)}
+        row, fpl = pmc_blend_row(pmc_cfg) if pmc_cfg else (None, 1)
+        vv = (row or {}).get("valu")
+        pmc_entries = (pmc_cfg or {}).get("run_valu", {}).get("entries_evaluated_per_frame") or (pmc_cfg or {}).get("run", {}).get("entries_evaluated_per_frame")
+        if vv and pmc_entries and vv.get("SQ_INSTS_VALU"):
+            per_entry = vv["SQ_INSTS_VALU"] / (pmc_entries * fpl)                  # VALU wave-instructions per evaluated list entry (256 pixels)
+            cyc = 4.0 * vv["SQ_ACTIVE_INST_VALU"] / vv["SQ_INSTS_VALU"]            # SIMD cycles per VALU wave-instruction of this kernel's mix
+            instr_rate = entries * per_entry / blend_alone_s / 1e9 if blend_alone_s > 0 else 0.0
+            peak_guide, peak_ctr = SIMDS * CLOCK_GHZ / GUIDE_CYCLES_PER_VALU, SIMDS * CLOCK_GHZ / cyc
+            rv.update({"achieved": round(instr_rate, 1), "peak": round(peak_guide, 1), "frac": round(instr_rate / peak_guide, 4),
+                       "peak_at_counted_issue_cost": round(peak_ctr, 1), "frac_at_counted_issue_cost": round(instr_rate / peak_ctr, 4),
+                       "instr_per_list_entry": round(per_entry, 2), "cycles_per_instr_counted": round(cyc, 3), "cycles_per_instr_guide": GUIDE_CYCLES_PER_VALU,
+                       "pmc": {"SQ_INSTS_VALU_per_launch": vv["SQ_INSTS_VALU"], "SQ_ACTIVE_INST_VALU_quad_cycles_per_launch": vv["SQ_ACTIVE_INST_VALU"],
+                               "SQ_BUSY_CYCLES_per_launch": vv.get("SQ_BUSY_CYCLES"), "SQ_WAVES_per_launch": vv.get("SQ_WAVES"),
+                               "SQ_INSTS_LDS_per_launch": vv.get("SQ_INSTS_LDS"), "frames_per_launch": fpl,
+                               "list_entries_evaluated_per_frame_in_the_profiled_run": round(pmc_entries), "source": "profiles/pmc_counters.json"},
+                       "note": "VALU wave-instructions issued per second by the blend running alone (depth 1).  instr_per_list_entry and the issue "
+                               "cost are THIS build's counters: SQ_INSTS_VALU of the blend / list entries the same profiled loop's blend evaluates; "
+                               "4 x SQ_ACTIVE_INST_VALU (quad-cycles) / SQ_INSTS_VALU = SIMD cycles per VALU wave-instruction.  `peak` prices an "
+                               "instruction at the guide's 2 cycles per wave64 VALU (MI355X_MICROARCH.md: the rate of the 157.3 TF vector-fp32 "
+                               "datasheet figure, which counts both halves of a packed v_pk_fma_f32); the counters say that every kernel of this "
+                               "library spends 4.0-4.3 cycles per VALU wave-instruction (a wave64 instruction passes a 16-lane SIMD in 4 cycles; "
+                               "packed-fp32 and v_exp_f32 take longer), which is `peak_at_counted_issue_cost` -- the roof the kernel can actually reach "
+                               "without packing more work into an instruction"})
+        else:
+            rv.update({"achieved": None, "peak": round(SIMDS * CLOCK_GHZ / GUIDE_CYCLES_PER_VALU, 1), "frac": None,
+                       "note": "no VALU counter pass of these kernel sources in profiles/pmc_counters.json (tools/gpu_pmc.sh): not computed from constants"})
+        out["roofline_valu"] = rv
+    guard('roofline_valu', part_roofline_valu)
 
-    sync_ms = {}
-    for mode, tag in ((0, "copy_engine"), (1, "blend_writes_host")):
-        ctx.set_option(capi.OPT_HOST_WRITE, mode)
-        loop_sync(12)
-        sync_ms[tag] = loop_sync(m) / m * 1e3
-    ctx.set_option(capi.OPT_HOST_WRITE, 0)
-    owner.free()
-    best_sync = min(sync_ms, key=sync_ms.get)
-    out["host_readback"] = {"fps_host_readback": round(1e3 / sync_ms[best_sync], 1), "ms_per_frame": round(sync_ms[best_sync], 4),
-                            "ms_per_frame_by_path": {k: round(v, 4) for k, v in sync_ms.items()}, "path": best_sync,
-                            "pcie_d2h_peak_GBps": pcie,
-                            "note": "synchronous gs_render into page-locked host memory (%.1f MB per frame over PCIe), one frame at a time, sort included; "
-                                    "pcie_d2h_peak_GBps = a 1 GiB device-to-host copy into page-locked memory timed in this run" % (fb_bytes / 1e6)}
-    ctx.set_option(capi.OPT_PIPELINE_DEPTH, int(os.environ.get("GS_BENCH_DEPTH", "0")) or 3)
-    ctx.set_option(capi.OPT_FRAME_BATCH, frame_batch)           # (as in the timed loop)
-    # the same delivery with frames in flight: gs_render(GS_RENDER_ASYNC), each frame into its own page-locked buffer
-    NB = 48                                                  # (3 lanes x 2 frames per launch in flight, eight times over: a sync drains the lanes)
-    bufs = [capi.host_frame(H, W) for _ in range(NB)]
+    def part_host_readback():
+        # the frame delivered to the host (what a JS caller of component.render() gets): gs_render into page-locked memory.  Two ways
+        # there (GS_OPT_HOST_WRITE): the copy engine behind the frame's last kernel, or the blend kernel storing its tiles straight into
+        # the page-locked frame; the denominator is this box's own device-to-host rate (1 GiB, page-locked, same run)
+        ctx.set_option(capi.OPT_FRAME_BATCH, 1)                    # (the synchronous half: one frame at a time)
+        ctx.set_option(capi.OPT_PIPELINE_DEPTH, 1)
+        pcie = measured_pcie_peak(capi)
+        fb_bytes = W * H * 4
+        host, owner = capi.host_frame(H, W)
+        m = min(n, 120)
 
-    def loop_host(nn):
-        try:
-            ctx.sync()
-        except capi.GsError:
-            pass
-        t0 = time.perf_counter()
-        for i in range(nn):
-            k = i % ORBIT_FRAMES
-            ctx.sort(cams[k]["view"], cams[k]["cutout"], want_indices=False)
-            views[k][0].flags = capi.RENDER_ASYNC
-            ctx.render_into(views[k][0], bufs[i % NB][0])
-            if i % NB == NB - 1:
-                try:
-                    ctx.sync()                               # the buffers are about to be reused
-                except capi.GsError as e:
-                    if e.code != capi.E_RETRY:
-                        raise
-        try:
-            ctx.sync()
-        except capi.GsError as e:
-            if e.code != capi.E_RETRY:
-                raise
-        return time.perf_counter() - t0
+        def loop_sync(mm):
+            t0 = time.perf_counter()
+            for i in range(mm):
+                k = i % ORBIT_FRAMES
+                ctx.sort(cams[k]["view"], cams[k]["cutout"], want_indices=False)
+                views[k][0].flags = 0
+                ctx.render_into(views[k][0], host)
+            return time.perf_counter() - t0
 
-    m = min(n, 240)
-    pipe = {}
-    for mode, tag in ((0, "copy_engine"), (1, "blend_writes_host")):
-        ctx.set_option(capi.OPT_HOST_WRITE, mode)
-        loop_host(48)
-        pipe[tag] = m / loop_host(m)
-    ctx.set_option(capi.OPT_HOST_WRITE, 0)
-    for _, o in bufs:
-        o.free()
-    best = max(pipe, key=pipe.get)
-    out["host_readback"].update({"fps_host_readback_pipelined": round(pipe[best], 1), "pipelined_path": best,
-                                 "fps_pipelined_by_path": {k: round(v, 1) for k, v in pipe.items()},
-                                 "pipelined_GBps": round(pipe[best] * fb_bytes / 1e9, 2),
-                                 "frac_of_pcie": round(pipe[best] * fb_bytes / 1e9 / pcie, 4) if pcie else None,
-                                 "note_pipelined": "gs_render with GS_RENDER_ASYNC: frames queued on the three pipeline lanes, each into its own "
-                                                   "page-locked buffer (48 buffers, gs_sync every 48 frames: a consumer that keeps frames queued); frac_of_pcie = delivered bytes/s "
-                                                   "over pcie_d2h_peak_GBps"})
-    # the blend without early termination (every reference-equivalent fragment evaluated), pipelined like the headline
-    loop(6, capi.RENDER_ASYNC | capi.RENDER_NO_EARLY_OUT)
-    m = min(n, 60)
-    t = loop(m, capi.RENDER_ASYNC | capi.RENDER_NO_EARLY_OUT)
-    if t:
-        out["no_early_out"] = {"fps_no_early_out": round(m / t, 1),
-                               "note": "GS_RENDER_NO_EARLY_OUT: one binning round over all splats, every fragment blended"}
-    # a scene that does NOT saturate: the same splats at a tenth of their opacity (alpha byte / 10): most tiles stay
-    # unsaturated after the nearest-splats round, so the second binning round does real work in every frame
-    sparse = rows.reshape(-1, 32).copy()
-    sparse[:, 27] = sparse[:, 27] // 10
-    with capi.Context(ctx.device) as c2:
-        c2.push_splat(sparse)
-        c2.set_option(capi.OPT_FRAME_BATCH, frame_batch)           # (as the timed loop: two queued frames per launch)
+        sync_ms = {}
+        for mode, tag in ((0, "copy_engine"), (1, "blend_writes_host")):
+            ctx.set_option(capi.OPT_HOST_WRITE, mode)
+            loop_sync(12)
+            sync_ms[tag] = loop_sync(m) / m * 1e3
+        ctx.set_option(capi.OPT_HOST_WRITE, 0)
+        owner.free()
+        best_sync = min(sync_ms, key=sync_ms.get)
+        out["host_readback"] = {"fps_host_readback": round(1e3 / sync_ms[best_sync], 1), "ms_per_frame": round(sync_ms[best_sync], 4),
+                                "ms_per_frame_by_path": {k: round(v, 4) for k, v in sync_ms.items()}, "path": best_sync,
+                                "pcie_d2h_peak_GBps": pcie,
+                                "note": "synchronous gs_render into page-locked host memory (%.1f MB per frame over PCIe), one frame at a time, sort included; "
+                                        "pcie_d2h_peak_GBps = a 1 GiB device-to-host copy into page-locked memory timed in this run" % (fb_bytes / 1e6)}
+        ctx.set_option(capi.OPT_PIPELINE_DEPTH, int(os.environ.get("GS_BENCH_DEPTH", "0")) or 3)
+        ctx.set_option(capi.OPT_FRAME_BATCH, frame_batch)           # (as in the timed loop)
+        # the same delivery with frames in flight: gs_render(GS_RENDER_ASYNC), each frame into its own page-locked buffer
+        NB = 48                                                  # (3 lanes x 2 frames per launch in flight, eight times over: a sync drains the lanes)
+        bufs = [capi.host_frame(H, W) for _ in range(NB)]
 
-        def loop2(nn, flags):
+        def loop_host(nn):
             try:
-                c2.sync()
+                ctx.sync()
             except capi.GsError:
                 pass
             t0 = time.perf_counter()
             for i in range(nn):
                 k = i % ORBIT_FRAMES
-                c2.sort(cams[k]["view"], cams[k]["cutout"], want_indices=False)
-                views[k][0].flags = flags
-                c2.render_device(views[k][0], None)
+                ctx.sort(cams[k]["view"], cams[k]["cutout"], want_indices=False)
+                views[k][0].flags = capi.RENDER_ASYNC
+                ctx.render_into(views[k][0], bufs[i % NB][0])
+                if i % NB == NB - 1:
+                    try:
+                        ctx.sync()                               # the buffers are about to be reused
+                    except capi.GsError as e:
+                        if e.code != capi.E_RETRY:
+                            raise
             try:
-                c2.sync()
+                ctx.sync()
             except capi.GsError as e:
                 if e.code != capi.E_RETRY:
                     raise
-                return None
             return time.perf_counter() - t0
-        for _ in range(2):
-            loop2(ORBIT_FRAMES, 0)                           # synchronous frames: the share settles
-        loop2(12, capi.RENDER_ASYNC)
-        m = min(n, 120)
-        t = loop2(m, capi.RENDER_ASYNC) or loop2(m, capi.RENDER_ASYNC) or loop2(m, capi.RENDER_ASYNC)
-        st = c2.stats()
-        if t:
-            out["unsaturated_scene"] = {"fps": round(m / t, 1), "near_permille": st["near_permille"],
-                                        "unsat_tiles_last_frame": st["unsat_tiles"], "tiles": st["n_tiles"],
-                                        "I_pairs_last_frame": st["n_pairs"],
-                                        "workload": "the same %d splats with opacity / 10 (tiles need 5-10x longer lists to reach T < 1/4096), "
-                                                    "%dx%d, 3 frames in flight; the library adapts by raising the share of splats binned first" % (n_splats, W, H)}
-        # ... and with that share pinned low, so that round 0 leaves most tiles unsaturated and the second binning round (masked
-        # tiles, resumed per-pixel state) does real work in every frame
-        c2.set_option(capi.OPT_NEAR_PERMILLE, 150)
-        loop2(12, 0); loop2(12, capi.RENDER_ASYNC)
-        t = loop2(m, capi.RENDER_ASYNC)
-        st = c2.stats()
-        if t:
-            out["unsaturated_scene"]["two_rounds_pinned"] = {
-                "fps": round(m / t, 1), "near_permille_pinned": 150, "unsat_tiles_last_frame": st["unsat_tiles"], "tiles": st["n_tiles"],
-                "unsat_share": round(st["unsat_tiles"] / max(1.0, float(st["n_tiles"])), 3), "I_pairs_last_frame": st["n_pairs"]}
-    # ---- frames the library has NOT seen: the headline region is pre-rolled over its own poses, a moving camera is not
-    pose = synth.cutout_demo_camera if args.cutout else synth.index_html_camera
 
-    def params_of(cs):
-        return [capi.make_params(c["gs_mv"], c["gs_proj"], W, H, focal_=c["focal"]) for c in cs]
+        m = min(n, 240)
+        pipe = {}
+        for mode, tag in ((0, "copy_engine"), (1, "blend_writes_host")):
+            ctx.set_option(capi.OPT_HOST_WRITE, mode)
+            loop_host(48)
+            pipe[tag] = m / loop_host(m)
+        ctx.set_option(capi.OPT_HOST_WRITE, 0)
+        for _, o in bufs:
+            o.free()
+        best = max(pipe, key=pipe.get)
+        out["host_readback"].update({"fps_host_readback_pipelined": round(pipe[best], 1), "pipelined_path": best,
+                                     "fps_pipelined_by_path": {k: round(v, 1) for k, v in pipe.items()},
+                                     "pipelined_GBps": round(pipe[best] * fb_bytes / 1e9, 2),
+                                     "frac_of_pcie": round(pipe[best] * fb_bytes / 1e9 / pcie, 4) if pcie else None,
+                                     "note_pipelined": "gs_render with GS_RENDER_ASYNC: frames queued on the three pipeline lanes, each into its own "
+                                                       "page-locked buffer (48 buffers, gs_sync every 48 frames: a consumer that keeps frames queued); frac_of_pcie = delivered bytes/s "
+                                                       "over pcie_d2h_peak_GBps"})
+    guard('host_readback', part_host_readback)
 
-    def lap(c, cs, ps, n, first=0, sync_every=24, flags=None):
-        """n queued frames over the poses cs, gs_sync every `sync_every` (a consumer that collects its frames); (seconds, retry requests)"""
-        asked = 0
-        try:
-            c.sync()
-        except capi.GsError:
-            pass
-        t0 = time.perf_counter()
-        for i in range(n):
-            k = (first + i) % len(cs)
-            c.sort(cs[k]["view"], cs[k]["cutout"], want_indices=False)
-            ps[k].flags = capi.RENDER_ASYNC if flags is None else flags
-            c.render_device(ps[k], None)
-            if i % sync_every == sync_every - 1 or i == n - 1:
+    def part_no_early_out():
+        # the blend without early termination (every reference-equivalent fragment evaluated), pipelined like the headline
+        loop(6, capi.RENDER_ASYNC | capi.RENDER_NO_EARLY_OUT)
+        m = min(n, 60)
+        t = loop(m, capi.RENDER_ASYNC | capi.RENDER_NO_EARLY_OUT)
+        if t:
+            out["no_early_out"] = {"fps_no_early_out": round(m / t, 1),
+                                   "note": "GS_RENDER_NO_EARLY_OUT: one binning round over all splats, every fragment blended"}
+    guard('no_early_out', part_no_early_out)
+
+    def part_unsaturated_scene():
+        # a scene that does NOT saturate: the same splats at a tenth of their opacity (alpha byte / 10): most tiles stay
+        # unsaturated after the nearest-splats round, so the second binning round does real work in every frame
+        sparse = rows.reshape(-1, 32).copy()
+        sparse[:, 27] = sparse[:, 27] // 10
+        with capi.Context(ctx.device) as c2:
+            c2.push_splat(sparse)
+            c2.set_option(capi.OPT_FRAME_BATCH, frame_batch)           # (as the timed loop: two queued frames per launch)
+
+            def loop2(nn, flags):
                 try:
-                    c.sync()
+                    c2.sync()
+                except capi.GsError:
+                    pass
+                t0 = time.perf_counter()
+                for i in range(nn):
+                    k = i % ORBIT_FRAMES
+                    c2.sort(cams[k]["view"], cams[k]["cutout"], want_indices=False)
+                    views[k][0].flags = flags
+                    c2.render_device(views[k][0], None)
+                try:
+                    c2.sync()
                 except capi.GsError as e:
                     if e.code != capi.E_RETRY:
                         raise
-                    asked += 1
-        return time.perf_counter() - t0, asked
+                    return None
+                return time.perf_counter() - t0
+            for _ in range(2):
+                loop2(ORBIT_FRAMES, 0)                           # synchronous frames: the share settles
+            loop2(12, capi.RENDER_ASYNC)
+            m = min(n, 120)
+            t = loop2(m, capi.RENDER_ASYNC) or loop2(m, capi.RENDER_ASYNC) or loop2(m, capi.RENDER_ASYNC)
+            st = c2.stats()
+            if t:
+                out["unsaturated_scene"] = {"fps": round(m / t, 1), "near_permille": st["near_permille"],
+                                            "unsat_tiles_last_frame": st["unsat_tiles"], "tiles": st["n_tiles"],
+                                            "I_pairs_last_frame": st["n_pairs"],
+                                            "workload": "the same %d splats with opacity / 10 (tiles need 5-10x longer lists to reach T < 1/4096), "
+                                                        "%dx%d, 3 frames in flight; the library adapts by raising the share of splats binned first" % (n_splats, W, H)}
+            # ... and with that share pinned low, so that round 0 leaves most tiles unsaturated and the second binning round (masked
+            # tiles, resumed per-pixel state) does real work in every frame
+            c2.set_option(capi.OPT_NEAR_PERMILLE, 150)
+            loop2(12, 0); loop2(12, capi.RENDER_ASYNC)
+            t = loop2(m, capi.RENDER_ASYNC)
+            st = c2.stats()
+            if t:
+                out["unsaturated_scene"]["two_rounds_pinned"] = {
+                    "fps": round(m / t, 1), "near_permille_pinned": 150, "unsat_tiles_last_frame": st["unsat_tiles"], "tiles": st["n_tiles"],
+                    "unsat_share": round(st["unsat_tiles"] / max(1.0, float(st["n_tiles"])), 3), "I_pairs_last_frame": st["n_pairs"]}
+    guard('unsaturated_scene', part_unsaturated_scene)
 
-    def stage_pass(c, cs, ps, n):
-        c.set_option(capi.OPT_PROFILE, 1)
-        lap(c, cs, ps, n, sync_every=48)
-        st = c.stats()
-        c.set_option(capi.OPT_PROFILE, 0)
-        k = max(1, st["prof_frames"]) * frame_batch
-        return {"ms_sort": round(st["sum_ms_sort"] / k, 4), "ms_project": round(st["sum_ms_project"] / k, 4), "ms_bin": round(st["sum_ms_bin"] / k, 4),
-                "ms_blend": round(st["sum_ms_blend"] / k, 4), "V_sorted": st["n_sorted"], "Vp_visible": st["n_visible"], "I_pairs": st["n_pairs"]}
+    def part_cold_orbit_outside_cloud():
+        # ---- frames the library has NOT seen (VERDICT r3 #4): the headline region is pre-rolled over its own poses, a moving camera is not
+        pose = synth.cutout_demo_camera if args.cutout else synth.index_html_camera
 
-    with capi.Context(ctx.device) as c3:
-        r32 = rows.reshape(-1, 32)
-        for o in range(0, r32.shape[0], 1 << 22):
-            c3.push_splat(r32[o:o + (1 << 22)])
-        c3.set_option(capi.OPT_FRAME_BATCH, frame_batch)
-        if args.cutout:
-            c3.set_option(capi.OPT_BLEND_SPLIT, int(os.environ.get("GS_BENCH_SPLIT", "1")))
-        # (a) a FRESH context's first lap over 120 poses it has never drawn (half a step off the headline orbit's): the share of splats
-        # binned first starts at the library's default, the second binning round is still on, buffers grow; then the second lap
-        cold = [pose(W, H, 1.5 + 3.0 * i, capi=capi) for i in range(ORBIT_FRAMES)]
-        pc = params_of(cold)
-        t1, a1 = lap(c3, cold, pc, ORBIT_FRAMES)
-        s1 = c3.stats()
-        t2, a2 = lap(c3, cold, pc, ORBIT_FRAMES)
-        s2 = c3.stats()
-        out["cold_orbit"] = {"fps_first_lap": round(ORBIT_FRAMES / t1, 1), "fps_second_lap": round(ORBIT_FRAMES / t2, 1),
-                             "near_permille_after_first_lap": s1["near_permille"], "near_permille_after_second_lap": s2["near_permille"],
-                             "frames_redrawn_by_sync": [s1.get("retried_frames", 0), s2.get("retried_frames", 0) - s1.get("retried_frames", 0)],
-                             "sync_retry_requests": [a1, a2],
-                             "near_only_sorts_from_the_depth_pass_stash": [s2.get("spec_sorts", 0), s2.get("spec_misses", 0)],
-                             "stages_second_lap": stage_pass(c3, cold, pc, ORBIT_FRAMES),
-                             "note": "a context created for this measurement, frames queued (3 lanes x %d per launch), gs_sync every 24 frames, "
-                                     "120 poses the library has not drawn before (yaw 1.5 + 3 i degrees), every frame a new pose; first lap includes "
-                                     "buffer growth, the adaptive share settling and every frame gs_sync drew again" % frame_batch}
-        # (b) the camera OUTSIDE the cloud, 3 sigma from its centre, looking in (sky around it, thin coverage at the rim)
-        outside = [synth.outside_cloud_camera(W, H, 3.0 * i, capi=capi) for i in range(ORBIT_FRAMES)]
-        po = params_of(outside)
-        lap(c3, outside, po, ORBIT_FRAMES)                       # the share settles for this regime
-        s3 = c3.stats()
-        t3, a3 = lap(c3, outside, po, 2 * ORBIT_FRAMES, sync_every=48)
-        s4 = c3.stats()
-        out["outside_cloud"] = {"fps": round(2 * ORBIT_FRAMES / t3, 1), "near_permille": s4["near_permille"], "unsat_tiles_last_frame": s4["unsat_tiles"],
-                                "tiles": s4["n_tiles"], "frames_redrawn_by_sync": s4.get("retried_frames", 0) - s3.get("retried_frames", 0),
-                                "sync_retry_requests": a3, "stages": stage_pass(c3, outside, po, ORBIT_FRAMES),
-                                "near_only_sorts_from_the_depth_pass_stash": [s4.get("spec_sorts", 0) - s3.get("spec_sorts", 0),
-                                                                              s4.get("spec_misses", 0) - s3.get("spec_misses", 0)],
-                                "sort_records_last_frame": s4.get("sort_records", 0), "V_last_frame": s4.get("n_sorted", 0),
-                                "workload": "the same %d splats seen from outside: entity %.1f units (3 sigma) in front of the camera, %dx%d, 120-pose "
-                                            "orbit after one settling lap, frames queued, gs_sync every 48" % (n_splats, 7.5, W, H)}
-    # ---- the rate a JavaScript caller sees at this size (north_star: the framebuffer goes back to JavaScript): node + the addon + the shim
-    if n_splats <= (2 << 20):
-        out["js_visible"] = js_visible(rows, W, H)
+        def params_of(cs):
+            return [capi.make_params(c["gs_mv"], c["gs_proj"], W, H, focal_=c["focal"]) for c in cs]
+
+        def lap(c, cs, ps, n, first=0, sync_every=24, flags=None):
+            """n queued frames over the poses cs, gs_sync every `sync_every` (a consumer that collects its frames); (seconds, retry requests)"""
+            asked = 0
+            try:
+                c.sync()
+            except capi.GsError:
+                pass
+            t0 = time.perf_counter()
+            for i in range(n):
+                k = (first + i) % len(cs)
+                c.sort(cs[k]["view"], cs[k]["cutout"], want_indices=False)
+                ps[k].flags = capi.RENDER_ASYNC if flags is None else flags
+                c.render_device(ps[k], None)
+                if i % sync_every == sync_every - 1 or i == n - 1:
+                    try:
+                        c.sync()
+                    except capi.GsError as e:
+                        if e.code != capi.E_RETRY:
+                            raise
+                        asked += 1
+            return time.perf_counter() - t0, asked
+
+        def stage_pass(c, cs, ps, n):
+            c.set_option(capi.OPT_PROFILE, 1)
+            lap(c, cs, ps, n, sync_every=48)
+            st = c.stats()
+            c.set_option(capi.OPT_PROFILE, 0)
+            k = max(1, st["prof_frames"]) * frame_batch
+            return {"ms_sort": round(st["sum_ms_sort"] / k, 4), "ms_project": round(st["sum_ms_project"] / k, 4), "ms_bin": round(st["sum_ms_bin"] / k, 4),
+                    "ms_blend": round(st["sum_ms_blend"] / k, 4), "V_sorted": st["n_sorted"], "Vp_visible": st["n_visible"], "I_pairs": st["n_pairs"]}
+
+        with capi.Context(ctx.device) as c3:
+            r32 = rows.reshape(-1, 32)
+            for o in range(0, r32.shape[0], 1 << 22):
+                c3.push_splat(r32[o:o + (1 << 22)])
+            c3.set_option(capi.OPT_FRAME_BATCH, frame_batch)
+            if args.cutout:
+                c3.set_option(capi.OPT_BLEND_SPLIT, int(os.environ.get("GS_BENCH_SPLIT", "1")))
+            # (a) a FRESH context's first lap over 120 poses it has never drawn (half a step off the headline orbit's): the share of splats
+            # binned first starts at the library's default, the second binning round is still on, buffers grow; then the second lap
+            cold = [pose(W, H, 1.5 + 3.0 * i, capi=capi) for i in range(ORBIT_FRAMES)]
+            pc = params_of(cold)
+            t1, a1 = lap(c3, cold, pc, ORBIT_FRAMES)
+            s1 = c3.stats()
+            t2, a2 = lap(c3, cold, pc, ORBIT_FRAMES)
+            s2 = c3.stats()
+            out["cold_orbit"] = {"fps_first_lap": round(ORBIT_FRAMES / t1, 1), "fps_second_lap": round(ORBIT_FRAMES / t2, 1),
+                                 "near_permille_after_first_lap": s1["near_permille"], "near_permille_after_second_lap": s2["near_permille"],
+                                 "frames_redrawn_by_sync": [s1.get("retried_frames", 0), s2.get("retried_frames", 0) - s1.get("retried_frames", 0)],
+                                 "sync_retry_requests": [a1, a2],
+                                 "near_only_sorts_from_the_depth_pass_stash": [s2.get("spec_sorts", 0), s2.get("spec_misses", 0)],
+                                 "stages_second_lap": stage_pass(c3, cold, pc, ORBIT_FRAMES),
+                                 "note": "a context created for this measurement, frames queued (3 lanes x %d per launch), gs_sync every 24 frames, "
+                                         "120 poses the library has not drawn before (yaw 1.5 + 3 i degrees), every frame a new pose; first lap includes "
+                                         "buffer growth, the adaptive share settling and every frame gs_sync drew again" % frame_batch}
+            # (b) the camera OUTSIDE the cloud, 3 sigma from its centre, looking in (sky around it, thin coverage at the rim)
+            outside = [synth.outside_cloud_camera(W, H, 3.0 * i, capi=capi) for i in range(ORBIT_FRAMES)]
+            po = params_of(outside)
+            lap(c3, outside, po, ORBIT_FRAMES)                       # the share settles for this regime
+            s3 = c3.stats()
+            t3, a3 = lap(c3, outside, po, 2 * ORBIT_FRAMES, sync_every=48)
+            s4 = c3.stats()
+            out["outside_cloud"] = {"fps": round(2 * ORBIT_FRAMES / t3, 1), "near_permille": s4["near_permille"], "unsat_tiles_last_frame": s4["unsat_tiles"],
+                                    "tiles": s4["n_tiles"], "frames_redrawn_by_sync": s4.get("retried_frames", 0) - s3.get("retried_frames", 0),
+                                    "sync_retry_requests": a3, "stages": stage_pass(c3, outside, po, ORBIT_FRAMES),
+                                    "near_only_sorts_from_the_depth_pass_stash": [s4.get("spec_sorts", 0) - s3.get("spec_sorts", 0),
+                                                                                  s4.get("spec_misses", 0) - s3.get("spec_misses", 0)],
+                                    "sort_records_last_frame": s4.get("sort_records", 0), "V_last_frame": s4.get("n_sorted", 0),
+                                    "workload": "the same %d splats seen from outside: entity %.1f units (3 sigma) in front of the camera, %dx%d, 120-pose "
+                                                "orbit after one settling lap, frames queued, gs_sync every 48" % (n_splats, 7.5, W, H)}
+    guard('cold_orbit_outside_cloud', part_cold_orbit_outside_cloud)
+
+    def part_js_visible():
+        # ---- the rate a JavaScript caller sees at this size (north_star: the framebuffer goes back to JavaScript): node + the addon + the shim
+        if n_splats <= (2 << 20):
+            out["js_visible"] = js_visible(rows, W, H)
+    guard('js_visible', part_js_visible)
+
     return out
+
+
+# ---- per-stage rooflines and the other BASELINE configurations in the driver's line (VERDICT r4 "next" #5) -------------------------
+
+STAGE_KERNELS = {"sort": ("sort_depth", "sort_bucket", "F_scan", "F_hist", "F_scatter", "radix_", "near_", "msd_scatter", "seg_sort"),
+                 "project": ("project",), "bin": ("row_scan", "emit_runs", "seg_count", "lists", "pairs_check", "F_emit<", "k_emit<", "tile_ranges"),
+                 "blend": ("blend",)}
+
+
+def stage_bytes(N, V, Vp, I, fb_px):
+    """algorithmic bytes of each stage of one frame"""
+    return {"sort": 16.0 * N + 4.0 * V, "project": 36.0 * Vp + 4.0 * V + 32.0 * Vp, "bin": 20.0 * I, "blend": 36.0 * I + 4.0 * fb_px}
+
+
+def stage_traffic(pmc_cfg):
+    """counter bytes (2*FETCH_SIZE + WRITE_SIZE) per frame and stage of the profiled pipelined loop: its paired launches (two frames each),
+    grouped by kernel name; None without a counter pass of these sources"""
+    if not pmc_cfg:
+        return {}
+    k = pmc_cfg["kernels"]
+    paired = {n: r for n, r in k.items() if n.startswith("k_twin") or "_pair<" in n}
+    bl = [r["launches"] for n, r in paired.items() if "F_blend<0" in n]
+    if not bl:
+        return {}
+    frames = 2.0 * max(bl)
+    out = {}
+    for st, pats in STAGE_KERNELS.items():
+        tot = sum(r["hbm_bytes"] * r["launches"] for n, r in paired.items() if any(p in n for p in pats) and not (st != "blend" and "blend" in n))
+        out[st] = round(tot / frames)
+    return out
+
+
+def stage_rooflines(per_frame, N, V, Vp, I, fb_px, pmc_cfg=None):
+    """One entry per stage of a frame: bytes by SURVEY.md 8(d), microseconds from the HIP events on the library's streams (pipelined loop:
+    a stage's interval includes the time its kernels share the GPU with the other lanes' kernels), the fraction of the HBM peak, the
+    counter bytes where a counter pass of these kernel sources exists."""
+    B = stage_bytes(N, V, Vp, I, fb_px)
+    T = stage_traffic(pmc_cfg)
+    bound = {"sort": "hbm", "project": "hbm", "bin": "hbm", "blend": "valu"}
+    note = {"sort": "16 N + 4 V; at <= 4 M splats the chain is bound by its launch count and dependent latencies, not by bytes",
+            "project": "36 Vp + 4 V + 32 Vp; a gather of 32-byte records by sorted index (one 128-byte line each)",
+            "bin": "20 I, priced for (tile, splat) records through a sort; the span lists move less (frame_hbm.traffic)",
+            "blend": "36 I + 4 fb against the HBM peak as the contract asks; the kernel is bound by VALU issue (roofline_valu), "
+                     "and early termination leaves most of each list unread (roofline.traffic)"}
+    out = []
+    for st in ("sort", "project", "bin", "blend"):
+        ms = per_frame.get("ms_" + st) or 0.0
+        gbs = B[st] / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        out.append({"stage": st, "bound": bound[st], "algorithmic_bytes": round(B[st]), "us": round(ms * 1e3, 2), "achieved": round(gbs, 1),
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 5), "traffic": T.get(st), "note": note[st]})
+    return out
+
+
+def measure_config(name, capi, synth, BC, steps, warmup, device=0):
+    """One BASELINE configuration other than the headline's, measured like the headline (same table of options, same pre-roll, frames
+    queued between two syncs) in a context of its own: frames/s, the per-frame stage times and counts, the stage furthest up its roof."""
+    cfg = BC.CONFIGS[name]
+    rows = BC.make_rows(cfg, synth)
+    cams, views, w, h = BC.poses(cfg, synth, capi)
+    nv = len(views[0])
+    seq, used = BC.region_frames(warmup, steps)
+    with capi.Context(device) as ctx:
+        BC.push_rows(ctx, rows)
+        opts = BC.options_for(cfg, env={}, pieces_of_rank=nv, gathered=cfg["xr"])
+        BC.apply_options(ctx, capi, opts)
+        fb = opts.get("OPT_FRAME_BATCH", 1)
+
+        def frame(i, flags=0):
+            k = i % ORBIT_FRAMES
+            if cfg["xr"]:
+                ctx.sort_gathered(cams[k]["view"], cams[k]["cutout"], views[k])
+                ctx.render_gathered(views[k], 0, None, flags)
+            else:
+                ctx.sort(cams[k]["view"], cams[k]["cutout"], want_indices=False)
+                views[k][0].flags = flags
+                ctx.render_device(views[k][0], None)
+
+        def sync():
+            try:
+                ctx.sync()
+                return False
+            except capi.GsError as e:
+                if e.code != capi.E_RETRY:
+                    raise
+                return True
+
+        BC.preroll(frame, sync, used, warmup, capi.RENDER_ASYNC)
+        elapsed = None
+        for attempt in range(3):
+            sync()
+            gc.collect(); gc.disable()
+            t0 = time.perf_counter()
+            for i in range(steps):
+                frame(warmup + i, capi.RENDER_ASYNC)
+            again = sync()
+            dt = time.perf_counter() - t0
+            gc.enable()
+            if not again:
+                elapsed = dt
+                break
+            for k in used:
+                frame(k)
+        if elapsed is None:
+            return {"error": "the timed region kept asking for a re-render"}
+        ctx.set_option(capi.OPT_PROFILE, 1)
+        sync()
+        for i in range(steps):
+            frame(warmup + i, capi.RENDER_ASYNC)
+        sync()
+        s2 = ctx.stats()
+        ctx.set_option(capi.OPT_PROFILE, 0)
+        k2 = max(1, s2["prof_frames"]) * float(fb)                     # (with two frames per launch the events bracket a pair's kernels)
+        pf = {"V_sorted": s2["n_sorted"], "Vp_visible": s2["n_visible"], "I_pairs": s2["n_pairs"],
+              "ms_sort": round(s2["sum_ms_sort"] / k2, 4), "ms_project": round(s2["sum_ms_project"] / k2, 4),
+              "ms_bin": round(s2["sum_ms_bin"] / k2, 4), "ms_blend": round(s2["sum_ms_blend"] / k2, 4)}
+        rl = stage_rooflines(pf, cfg["splats"], pf["V_sorted"], pf["Vp_visible"], pf["I_pairs"], w * h)
+        dom = max(rl, key=lambda r: r["us"])
+        fps = steps / elapsed
+        return {"frames_per_s": round(fps, 1), "ms_per_step": round(elapsed / steps * 1e3, 4), "steps": steps, "warmup": warmup,
+                "workload": BC.DESCRIPTION[name], "size": [w, h], "views_per_frame": nv, "library_options": opts,
+                "near_permille": s2["near_permille"], "frames_redrawn_by_sync": s2.get("retried_frames", 0),
+                "per_frame": pf, "per_frame_note": "stage times per VIEW drawn (HIP events, pipelined loop)" if nv > 1 else "stage times per frame (HIP events, pipelined loop)",
+                "dominant_stage": {"stage": dom["stage"], "us": dom["us"], "bound": dom["bound"], "frac": dom["frac"]},
+                "rooflines": [{k: r[k] for k in ("stage", "bound", "algorithmic_bytes", "us", "achieved", "frac")} for r in rl]}
 
 
 def js_visible(rows, w, h):

@@ -363,6 +363,8 @@ typedef struct gs_stats {
     uint32_t spec_sorts;  /* collected frames whose near-only sort took its candidates from the depth pass' own stash (no depth
                              array written: a threshold hint from the previous frames decides what is stashed) ...              */
     uint32_t spec_misses; /* ... and those of them whose candidates could not be vouched for (drawn again from a whole sort)    */
+    uint32_t need_splats; /* how many of the NEAREST splats the last collected frames' tiles read before they were saturated (max over
+                             the tiles; 0xFFFFFFFF: a tile no share saturates): what near_permille is set from, x 1.3             */
 } gs_stats;
 
 #define GS_OPT_PROFILE 1        /* 1: bracket every stage with HIP events on the frame's stream (7 per frame); 2: only

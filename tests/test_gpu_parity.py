@@ -521,7 +521,11 @@ def test_async_frames_match_synchronous_ones_and_report_overflow(scene_small):
     rows = rows.reshape(-1, 32).copy()
     rows[:, 12:24] = (rows[:, 12:24].copy().view("<f4") * np.float32(6.0)).view(np.uint8)   # fat splats: many tiles each
     cam = synth.index_html_camera(1920, 1080, 0.0, capi=capi)
+    # (a context that has not measured its share yet draws its first two-round frame synchronously even when asked to queue it -- round 5,
+    # gs_render_uniforms --, and a synchronous frame grows the pair buffers by itself: the queued frames whose overflow is the subject
+    # here are therefore drawn with a pinned single round)
     with capi.Context(0) as c3:                                            # fresh context: small default pair capacity
+        c3.set_option(capi.OPT_NEAR_PERMILLE, 1000)
         c3.push_splat(rows)
         # no retry loop: a frame that outgrows the pair buffers is drawn again by gs_sync() itself, into the caller's buffer
         host, owner = capi.host_frame(1080, 1920)
@@ -538,6 +542,7 @@ def test_async_frames_match_synchronous_ones_and_report_overflow(scene_small):
         owner.free()
     with capi.Context(0) as c4:                                            # GS_OPT_AUTO_RETRY = 0: the caller is told instead
         c4.set_option(capi.OPT_AUTO_RETRY, 0)
+        c4.set_option(capi.OPT_NEAR_PERMILLE, 1000)
         c4.push_splat(rows)
         c4.sort(cam["view"], want_indices=False)
         c4.render_device(_params(cam, flags=capi.RENDER_ASYNC), None)
@@ -551,6 +556,7 @@ def test_async_frames_match_synchronous_ones_and_report_overflow(scene_small):
         c4.sync()                                                          # enlarged to the frame's whole demand: no error now
         assert np.array_equal(c4.render(_params(cam)), a)
     with capi.Context(0) as c5:                                            # two logged frames into ONE buffer: not the library's call
+        c5.set_option(capi.OPT_NEAR_PERMILLE, 1000)
         c5.push_splat(rows)
         buf, own = capi.host_frame(1080, 1920)
         cam2 = synth.index_html_camera(1920, 1080, 90.0, capi=capi)
