@@ -284,22 +284,55 @@ static void gs_spec_back_off(gs_ctx *ctx /* owner */, bool unsuited)
 // the nearest splats it read before its pixels were saturated).  Rounds 1-4 walked the share: x 0.9 per collection from 25 % until a
 // share failed, x 1.5 then -- a fresh context needed dozens of collections (and one failure) to arrive, and a 20 M-splat scene drew
 // its first hundred frames with 5 M positions in the first round (`cold_orbit`: 63 frames/s).  One collection is enough now.
-static void share_from_need(gs_ctx *ctx /* owner */, uint32_t need)
+static void share_from_need(gs_ctx *ctx /* owner */, uint32_t need, uint32_t frames)
 {
+    if (need) ctx->stats.need_splats = need;
     if (!need || ctx->near_fixed_permille > 0 || !ctx->n) return;
+    // what the share follows: the largest need of the recent past -- sixteen buckets of at least sixteen frames each (a collection of
+    // queued frames is a bucket; synchronous frames, a collection each, share one) -- so that a pose which needs less does not take
+    // away what another pose of the same orbit needs: bench.py's orbit is 120 poses whose needs lie between 80 and 125 permille, and a
+    // caller may queue hundreds of frames, all drawn with ONE share, before it collects.  Up at once, down when the window has moved on.
+    const int HN = (int)(sizeof ctx->need_hist / sizeof ctx->need_hist[0]);
+    if (ctx->need_hist_frames[ctx->need_hist_pos] >= 16u) {
+        ctx->need_hist_pos = (ctx->need_hist_pos + 1) % HN;
+        ctx->need_hist[ctx->need_hist_pos] = 0; ctx->need_hist_frames[ctx->need_hist_pos] = 0;
+    }
+    if (need > ctx->need_hist[ctx->need_hist_pos]) ctx->need_hist[ctx->need_hist_pos] = need;
+    ctx->need_hist_frames[ctx->need_hist_pos] += frames ? frames : 1u;
+    uint32_t m = 0;
+    for (int k = 0; k < HN; k++) if (ctx->need_hist[k] > m) m = ctx->need_hist[k];
     float target = 1.0f;                                         // 0xFFFFFFFF: a tile that no share saturates (sky): one round over everything
-    if (need != 0xFFFFFFFFu) {
-        target = (float)((double)need * GS_NEED_MARGIN / (double)ctx->n);
+    if (m != 0xFFFFFFFFu) {
+        // the margin on top follows what the camera does: 1.15 to begin with, a hundredth less with every collection that nothing missed
+        // (down to 1.04: a still or periodic camera needs none, and 10 % of share are 10 % of the binning and the blend's staging), a tenth
+        // more after a miss
+        if (ctx->need_margin < 1.04f) ctx->need_margin = (float)GS_NEED_MARGIN;
+        ctx->need_margin = ctx->need_margin - 0.01f < 1.04f ? 1.04f : ctx->need_margin - 0.01f;
+        target = (float)((double)m * (double)ctx->need_margin / (double)ctx->n);
         if (target > 0.85f) target = 1.0f;                       // (two rounds over nearly everything cost more than one)
     }
-    if (target < ctx->near_floor) target = ctx->near_floor;      // never below 1.3 x a share that failed
+    if (target < ctx->near_floor) target = ctx->near_floor;      // (a walked share's floor, where there is one)
     if (target < 0.001f) target = 0.001f;
     ctx->near_frac = target;
     ctx->share_measured = true;
-    ctx->stats.need_splats = need;
 }
 
-static int collect_status(gs_ctx *lane, bool *overflowed, bool *share_failed = nullptr, uint32_t *spec_failed = nullptr, uint32_t *need_out = nullptr)
+// a MISS under a measured share (round 1 skipped, a tile unsaturated; the frames are drawn again): the frames that missed needed more
+// than `frac_used`, how much more the frames drawn again will measure.  No floor -- the walk's "never again below 1.3 x the share that
+// failed" ratchets (1.3 x 92, then 1.3 x 120 = 156 permille over poses that need 80-115) where the measurement simply follows.
+static void share_missed(gs_ctx *ctx /* owner */, float frac_used)
+{
+    float nf = frac_used * 1.3f; if (nf > 1.0f) nf = 1.0f;
+    if (nf > ctx->near_frac) ctx->near_frac = nf;
+    if (ctx->need_margin < 1.04f) ctx->need_margin = (float)GS_NEED_MARGIN;
+    ctx->need_margin = ctx->need_margin + 0.1f > 1.3f ? 1.3f : ctx->need_margin + 0.1f;
+    const uint32_t as_need = (uint32_t)((double)nf * (double)ctx->n / (double)ctx->need_margin);   // (the window remembers it like a measurement)
+    if (as_need > ctx->need_hist[ctx->need_hist_pos]) ctx->need_hist[ctx->need_hist_pos] = as_need;
+    ctx->clean_frames = 0; ctx->skip_hold = 32;
+}
+
+static int collect_status(gs_ctx *lane, bool *overflowed, bool *share_failed = nullptr, uint32_t *spec_failed = nullptr, uint32_t *need_out = nullptr,
+                          uint32_t *frames_out = nullptr)
 {
     gs_ctx *ctx = gs_root(lane);                                // the adaptive share is one state for all lanes ...
     const GsControl *c = lane->ctl_host;                        // ... fed by each lane's own counters
@@ -328,11 +361,18 @@ static int collect_status(gs_ctx *lane, bool *overflowed, bool *share_failed = n
         // read when it started, so after a clear every tile of the first frames would -- 8160 atomics on one cache line serialise at
         // ~11 ns each: the first six frames after every gs_sync took twice as long.  Seeded, only the tiles within 10 % of the maximum
         // speak up; a need that falls is followed 10 % per collection (the word is then an upper bound), one that rises at once.
-        // 0xFFFFFFFF (a tile nothing saturates) is kept, and dropped for one collection in sixteen: the scene may have changed.
-        uint32_t seed = need == 0xFFFFFFFFu ? ((++lane->need_probe & 15u) ? 0xFFFFFFFFu : 0u) : (uint32_t)((uint64_t)need * 9u / 10u);
-        GS_HIP(hipMemsetD32Async((hipDeviceptr_t)lane->ctl->need_near, (int)seed, GS_NEED_WORDS, lane->stream));
+        // 0xFFFFFFFF (a tile nothing saturates) is kept, and dropped once in sixteen seedings: the scene may have changed.
+        // (... every fourth collection of the lane: the host follows the maximum of the last eight collections anyway, and a queue entry
+        // per lane and gs_sync is 60 us of a twenty-frame region)
+        if ((++lane->need_probe & 3u) == 0u) {
+            const uint32_t seed = need == 0xFFFFFFFFu ? ((lane->need_probe & 63u) ? 0xFFFFFFFFu : 0u) : (uint32_t)((uint64_t)need * 9u / 10u);
+            GS_HIP(hipMemsetD32Async((hipDeviceptr_t)lane->ctl->need_near, (int)seed, GS_NEED_WORDS, lane->stream));
+        }
     }
-    if (ctx->adapt_frozen || c->order_incomplete) need = 0;       // (frames drawn from a truncated order / drawn again: not this share's measurement)
+    // (frames drawn from a truncated order measure nothing.  Frames gs_sync draws AGAIN do -- both rounds, every tile's need recorded, the
+    // sky's 0xFFFFFFFF included -- and what they measure is what the frames that missed had needed: the share is right after ONE miss.
+    // Ignored like the rest of their counters, a camera that left the cloud took eight collections x 24 redrawn frames to get to 100 %)
+    if (c->order_incomplete) need = 0;
     if (need_out && need > *need_out) *need_out = need;
     if (ctx->adapt_frozen || c->order_incomplete) {
         // gs_sync is drawing flagged frames again (redraw_flagged_frames) with the uniforms they were queued with: their share has
@@ -346,8 +386,14 @@ static int collect_status(gs_ctx *lane, bool *overflowed, bool *share_failed = n
         const uint32_t events = c->unsat_events - lane->seen_unsat_events;
         const uint64_t frames = c->acc_frames >= lane->seen_acc_frames ? c->acc_frames - lane->seen_acc_frames : 1;
         lane->seen_unsat_events = c->unsat_events; lane->seen_acc_frames = c->acc_frames;
+        if (frames_out) *frames_out += (uint32_t)(frames ? frames : 1);
         if (lane->last_two_rounds) {
-            if (events || c->round1_missed) {
+            // An "event" -- round 0 left tiles unsaturated and round 1 finished them -- is a failure of a WALKED share; with the blend's
+            // measurement it is not: round 1 recorded what those tiles needed, and the share is set from that (share_from_need).  Counted as a
+            // failure it left a floor of 1.3 x a share that the measurement already covers (bench.py's region: need 111 K splats, the walk of
+            // the pre-roll's two-round frames ended at 1.3 x 120 = 156 permille where 1.15 x 106 = 122 do).  A MISS -- round 1 skipped and a
+            // tile unsaturated: the frame is drawn again -- is a failure either way.
+            if ((events && !(need && need != 0xFFFFFFFFu)) || c->round1_missed) {
                 // the share proved too small: raised ONCE per collection by the caller (share_failed) -- the frames of all the lanes a
                 // gs_sync collects were drawn with the same share, and six lanes reporting the same failure used to multiply it by
                 // 1.5^6 and to leave the floor at 1.3 x 1.5^5 of the share that had really failed (a cold context ended up at 70 %)
@@ -622,7 +668,7 @@ static int lane_drain(gs_ctx *L, bool flush)
     return rc;
 }
 
-static int lane_push(gs_ctx *L, GsLaneCmd c)
+static int ensure_worker(gs_ctx *L)
 {
     gs_ctx *E = L->exec ? L->exec : L;
     if (!E->worker) {
@@ -635,6 +681,13 @@ static int lane_push(gs_ctx *L, GsLaneCmd c)
             return GS_E_OOM;
         }
     }
+    return GS_OK;
+}
+
+static int lane_push(gs_ctx *L, GsLaneCmd c)
+{
+    gs_ctx *E = L->exec ? L->exec : L;
+    if (ensure_worker(L) != GS_OK) return GS_E_OOM;
     GsLaneWorker *w = E->worker;
     c.target = L;
     { std::lock_guard<std::mutex> lk(w->m); w->q.push_back(c); L->inflight++; }
@@ -764,6 +817,22 @@ static int get_lane(gs_ctx *ctx, int i, gs_ctx **out)
     return GS_OK;
 }
 
+// Every lane the options imply -- GS_OPT_PIPELINE_DEPTH lanes, their twins with GS_OPT_FRAME_BATCH = 2 -- created now, with scratch for the
+// resident splats and their enqueue threads: a caller that asks for pipelining on a loaded context pays for the lanes THERE (half a
+// millisecond each: a stream, a pinned control block, two dozen allocations, a thread) and not in its first six frames
+// (`cold_orbit`: 2.6 of the first lap's 11.5 ms).  Lanes of a context nobody asked to pipeline are still created on first use.
+static int prepare_lanes(gs_ctx *ctx)
+{
+    if (!ctx->n || ctx->user_stream || !ctx->renderable) return GS_OK;
+    for (int i = 0; i < ctx->pipe_depth; i++) {
+        gs_ctx *L = nullptr;
+        TRY(get_lane(ctx, i, &L));
+        if (ctx->enqueue_threads && ensure_worker(L) != GS_OK) FAIL(GS_E_OOM, "out of host memory");
+        if (ctx->frame_batch == 2 && ctx->enqueue_threads) TRY(get_lane(ctx, i + GS_MAX_PRIMARY, &L));
+    }
+    return GS_OK;
+}
+
 // after drain_all(): give every lane the owner's current resident arrays, scene inputs and options
 static void refresh_lanes(gs_ctx *ctx)
 {
@@ -875,7 +944,7 @@ GS_API int gs_clear(gs_ctx *ctx)
     GS_HIP(hipSetDevice(ctx->device));
     TRY(drain_all(ctx));
     ctx->n = 0; ctx->renderable = true; ctx->pair_hint = 0; ctx->vis_hint = 0; ctx->run_hint = 0;
-    ctx->near_frac = 0.25f; ctx->near_floor = 0.0f; ctx->clean_frames = 0; ctx->skip_hold = 0; ctx->single_round_frames = 0; ctx->last_kept = 0; ctx->share_measured = false;
+    ctx->near_frac = 0.25f; ctx->near_floor = 0.0f; ctx->clean_frames = 0; ctx->skip_hold = 0; ctx->single_round_frames = 0; ctx->last_kept = 0; ctx->share_measured = false; ctx->need_margin = 0.0f; memset(ctx->need_hist, 0, sizeof ctx->need_hist);
     ctx->near_stash_off = false; ctx->near_spec = false; ctx->near_spec_hold = 0; ctx->near_spec_backoff = 0; ctx->near_spec_miss_credit = 0;
     for (int i = 0; i < GS_MAX_LANES; i++) {
         gs_ctx *L = ctx->lanes[i];
@@ -1235,11 +1304,11 @@ static int render_sync_on_lane(gs_ctx *ctx, const GsFrameUniforms &u, void *devi
             ctx->ctl_host->round1_missed = 1;                      // seen by the adaptation below
         }
         bool over = false, failed = false;
-        uint32_t need = 0;
+        uint32_t need = 0, nfr = 0;
         const float frac_used = gs_root(ctx)->near_frac;
-        TRY(collect_status(ctx, &over, &failed, nullptr, &need));
-        if (failed) share_raise(gs_root(ctx), frac_used);
-        else share_from_need(gs_root(ctx), need);
+        TRY(collect_status(ctx, &over, &failed, nullptr, &need, &nfr));
+        if (failed) { if (gs_root(ctx)->share_measured) share_missed(gs_root(ctx), frac_used); else share_raise(gs_root(ctx), frac_used); }
+        else share_from_need(gs_root(ctx), need, nfr);
         if (!over) break;
         if (attempt >= 2) FAIL(GS_E_OOM, "pair list keeps overflowing (%u pairs)", ctx->ctl_host->scan_total);
     }
@@ -1311,7 +1380,18 @@ int gs_render_uniforms(gs_ctx *ctx, const GsFrameUniforms &u_in, void *device_rg
     // even when asked to queue it: the frames queued behind it then use the share it measured instead of the 25 % every context starts
     // with (at 20 M splats: 5 M positions in the first round of every frame until the first gs_sync).  The call returns with the frame
     // complete; its status needs no gs_sync.
-    if (async && !ctx->share_measured && ctx->near_fixed_permille <= 0 && u.near_count != 0xFFFFFFFFu && ctx->n) { async = false; u.flags &= ~(uint32_t)GS_RENDER_ASYNC; }
+    if (async && !ctx->share_measured && ctx->near_fixed_permille <= 0 && u.near_count != 0xFFFFFFFFu && ctx->n) {
+        async = false; u.flags &= ~(uint32_t)GS_RENDER_ASYNC;
+        // ... and the lanes that exist get their per-frame buffers for this frame's size now (tile ranges, per-pixel state, row tables:
+        // a dozen allocations each), while nothing is in flight, instead of one lane per frame over the next five
+        for (int i = 0; i < GS_MAX_LANES; i++) {
+            gs_ctx *Li = ctx->lanes[i];
+            if (!Li || Li == L || Li->scratch_cap < ctx->cap) continue;
+            if (lane_drain(Li) != GS_OK) continue;
+            (void)ensure_frame_buffers(Li, u, device_rgba == nullptr);
+            if (const size_t e = (u.tiles_x <= 256 && u.tiles_y <= 256 && !ctx->bin_mode) ? gs_row_tables_entries(ctx->n, (uint32_t)u.tiles_y) : 0) (void)gs_row_tables_ensure(Li, e);
+        }
+    }
     if (async) {
         if (host_rgba && stride && stride < (size_t)(u.x1 - u.x0) * 4) FAIL(GS_E_BADARG, "stride %zu smaller than a row (%zu bytes)", stride, (size_t)(u.x1 - u.x0) * 4);
         L->async_pending = true; ctx->cur_async = true;
@@ -1432,7 +1512,7 @@ GS_API int gs_sync(gs_ctx *ctx)
     CHECK_CTX(ctx);
     GS_HIP(hipSetDevice(ctx->device));
     bool any_missed = false, any_over = false, share_failed = false;
-    uint32_t spec_failed = 0, need = 0;
+    uint32_t spec_failed = 0, need = 0, nfr = 0;
     const float frac_used = ctx->near_frac;                       // what every frame queued since the last collection was drawn with
     // whatever way this call ends, the frames logged so far are not drawn again by a LATER gs_sync (their output buffers may be
     // gone by then): a failure below leaves no records behind
@@ -1471,13 +1551,13 @@ GS_API int gs_sync(gs_ctx *ctx)
         if (missed) LANE_HIP(L, hipMemsetAsync(&L->ctl->round1_missed, 0, sizeof(uint32_t), L->stream));
         if (L->ctl_host->order_incomplete) LANE_HIP(L, hipMemsetAsync(&L->ctl->order_incomplete, 0, sizeof(uint32_t), L->stream));
         bool over = false;
-        TRY(collect_status(L, &over, &share_failed, &spec_failed, &need));
+        TRY(collect_status(L, &over, &share_failed, &spec_failed, &need, &nfr));
         any_missed |= missed; any_over |= over;
         if (missed || over) bad_unit[i % GS_MAX_PRIMARY] = true;
         if (over && L->ctl_host->max_total > want) want = L->ctl_host->max_total;
     }
-    if (share_failed) share_raise(ctx, frac_used);               // (once, whatever the number of lanes that saw it)
-    else share_from_need(ctx, need);                             // ... else what the collected frames' tiles needed (the maximum over the lanes)
+    if (share_failed) { if (ctx->share_measured) share_missed(ctx, frac_used); else share_raise(ctx, frac_used); }   // (once, whatever the number of lanes that saw it)
+    else share_from_need(ctx, need, nfr);                        // ... else what the collected frames' tiles needed (the maximum over the lanes)
     if (spec_failed) gs_spec_back_off(ctx, spec_failed == 2u);
     if (any_over)                                                // one retry for all lanes: each gets room for the largest demand seen
         for (int i = 0; i < GS_MAX_LANES; i++)
@@ -1562,7 +1642,7 @@ GS_API int gs_set_option(gs_ctx *ctx, int option, int64_t value)
     case GS_OPT_NEAR_PERMILLE:
         if (value < 0 || value > 1000) FAIL(GS_E_BADARG, "near permille must be 0 (adaptive) .. 1000 (single round)");
         ctx->near_fixed_permille = (int)value;
-        if (value == 0) { ctx->near_frac = 0.25f; ctx->share_measured = false; }
+        if (value == 0) { ctx->near_frac = 0.25f; ctx->share_measured = false; ctx->need_margin = 0.0f; memset(ctx->need_hist, 0, sizeof ctx->need_hist); }
         return GS_OK;
     case GS_OPT_RECORD_STAGED: ctx->record_staged = value == 2 ? 2u : (value != 0 ? 1u : 0u); return GS_OK;
     case GS_OPT_TERMINATION:
@@ -1617,14 +1697,14 @@ GS_API int gs_set_option(gs_ctx *ctx, int option, int64_t value)
         TRY(drain_all(ctx));
         ctx->pipe_depth = (int)value;
         ctx->cur = 0; ctx->rot = 0; ctx->cur_async = false;
-        return GS_OK;
+        return prepare_lanes(ctx);
     case GS_OPT_FRAME_BATCH:
         if (value != 1 && value != 2) FAIL(GS_E_BADARG, "frame batch must be 1 (off) or 2");
         GS_HIP(hipSetDevice(ctx->device));
         TRY(drain_all(ctx));
         ctx->frame_batch = (int)value;
         ctx->cur = 0; ctx->rot = 0; ctx->cur_async = false;
-        return GS_OK;
+        return prepare_lanes(ctx);
     case GS_OPT_SORT_NEAR:
         if (value < 0 || value > 2) FAIL(GS_E_BADARG, "near-only sorts: 0 (off), 1 (scenes of 4 M splats and more) or 2 (always)");
         GS_HIP(hipSetDevice(ctx->device));

@@ -24,7 +24,10 @@
 #define GS_RADIX_MAX_BINS 512      // up to 9-bit digits (depth key = 17 bits = 8 + 9)
 #define GS_NEED_WORDS 32u          // GsControl::need_near
 #define GS_MSD_GROUP 32u           // the MSD depth sort (gs_sort.hip): radix chunks per group row
-#define GS_MSD_MAX_N (1u << 24)    // ... takes sorts of at most this many splats (its records: low bucket byte << 24 | index)
+#define GS_MSD_MAX_N (1u << 21)    // ... takes sorts of at most this many splats.  Its records (low bucket byte << 24 | index) would hold 2^24, but a chunk's
+                                   // offsets are summed from ~sqrt(chunks) x 2 rows by the scatter itself: 46 at 1 M splats (two round trips under the
+                                   // ranking), 79 at 6 M (five, in the open: C3's sort went from 129 to 175 us per frame); longer sorts keep the two LSD
+                                   // passes with their scan launches -- they are not launch-bound
 #define GS_PROF_RING 256           // frames of HIP-event timings kept in flight
 #define GS_PROF_EVENTS 7
 #define GS_MAX_PART 8192           // upper bound on the grid of any kernel that writes per-workgroup partials
@@ -232,6 +235,8 @@ struct gs_ctx {
     float near_floor;                       // never shrink the share below this (1.3 x the share that last proved too small)
     bool share_measured;                    // owner: near_frac comes from a measurement (GsControl::need_near) -- share_from_need, gs_api.hip
     uint32_t need_probe;                    // lane: collections that found "a tile nothing saturates" (every 16th re-probes)
+    float need_margin;                      // owner: the factor on top of the measured need (1.15 ... 1.04 while nothing misses, + 0.1 per miss)
+    uint32_t need_hist[16], need_hist_frames[16]; int need_hist_pos;   // owner: the needs of the last collections and the frames each covered (share_from_need)
     uint32_t clean_frames, skip_hold;       // collected frames since the last unsaturated one / frames to keep round 1 on
     uint32_t seen_unsat_events; uint64_t seen_acc_frames;
     uint32_t single_round_frames;           // consecutive collected frames at near_frac == 1 (re-probe occlusion now and then)
@@ -382,6 +387,10 @@ int gs_run_sort2(gs_ctx *const S[2], const float *const view[2], const float *co
 // ---- gs_render.hip
 int gs_run_render(gs_ctx *ctx, const GsFrameUniforms &u, uint8_t *device_out);
 int gs_run_round1(gs_ctx *ctx, const GsFrameUniforms &u, uint8_t *device_out);
+// span-list binning: the row tables of lane `ctx` for `entries` (tile rows x 256-splat chunks) words; and an upper bound of what a frame of
+// `tiles_y` tile rows over `n` sorted positions asks for (so that a context can size them before its first queued frames)
+int gs_row_tables_ensure(gs_ctx *ctx, size_t entries);
+size_t gs_row_tables_entries(size_t n, uint32_t tiles_y);
 // two frames per launch (GS_OPT_FRAME_BATCH): whether two frames qualify, and the batched form of gs_run_render for those that do
 bool gs_frames_batchable(const GsFrameUniforms &a, const GsFrameUniforms &b);
 int gs_run_render2(gs_ctx *const S[2], const GsFrameUniforms U[2], uint8_t *const device_out[2]);

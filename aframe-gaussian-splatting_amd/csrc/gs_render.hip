@@ -1635,6 +1635,12 @@ uint32_t span_list_stride(const gs_ctx *ctx, const GsFrameUniforms &u, uint32_t 
     return stride;
 }
 
+size_t gs_row_table_entries(size_t n, uint32_t tiles_y)
+{
+    const size_t e = (size_t)(gs_div_up(n, GS_BLOCK) + 1u) * (size_t)tiles_y;
+    return e > GS_ROWCNT_MAX ? 0 : e;                             // (beyond the table's limit such a round takes the pair records)
+}
+
 int gs_ensure_row_tables(gs_ctx *ctx, size_t entries)
 {
     if (entries <= ctx->row_cnt_cap && ctx->row_tot && ctx->seg_diff) return GS_OK;
@@ -1926,6 +1932,9 @@ int run_round2(gs_ctx *const S[2], const GsFrameUniforms U[2], uint8_t *const ou
 }
 
 }  // namespace
+
+int gs_row_tables_ensure(gs_ctx *ctx, size_t entries) { return gs_ensure_row_tables(ctx, entries); }
+size_t gs_row_tables_entries(size_t n, uint32_t tiles_y) { return gs_row_table_entries(n, tiles_y); }
 
 // Two frames that take the same path, one launch per kernel (GS_OPT_FRAME_BATCH; grid (x, 2), blockIdx.y = the frame).  S[0], S[1]:
 // sibling lanes on ONE stream, each with its own scratch, control block and output.  Frames that count fragments or record

