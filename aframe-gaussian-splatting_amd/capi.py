@@ -31,7 +31,7 @@ BUF_CENTER_SCALE, BUF_COV_COLOR, BUF_SORT_ROWS, BUF_SORTED, BUF_PROJECTED, BUF_T
 EXPORTS = [
     "gs_create", "gs_destroy", "gs_last_error", "gs_version", "gs_device_count", "gs_clear", "gs_push_splat", "gs_push_matrices", "gs_load_ply",
     "gs_ply_to_splat", "gs_ply_to_splat_gpu", "gs_count", "gs_sort", "gs_render", "gs_render_device", "gs_render_stereo", "gs_set_scene", "gs_sync",
-    "gs_set_stream", "gs_frame_stream", "gs_frame_lane", "gs_lane_stream", "gs_wait_stream", "gs_stream_wait_frame",
+    "gs_set_stream", "gs_frame_stream", "gs_frame_status_device", "gs_frame_lane", "gs_lane_stream", "gs_wait_stream", "gs_stream_wait_frame",
     "gs_model_view_matrix", "gs_projection_matrix", "gs_tick_uniforms", "gs_focal", "gs_scaled_size", "gs_set_option",
     "gs_get_stats", "gs_download",
     "gs_comm_unique_id", "gs_comm_init", "gs_comm_destroy", "gs_partition", "gs_render_gathered", "gs_read_gathered",
@@ -147,6 +147,7 @@ def load(build_if_missing=True):
     L.gs_set_stream.argtypes = [vp, vp]
     L.gs_wait_stream.argtypes = [vp, vp]
     L.gs_frame_stream.argtypes = [vp]; L.gs_frame_stream.restype = C.c_void_p
+    L.gs_frame_status_device.argtypes = [vp, C.POINTER(C.c_void_p)]; L.gs_frame_status_device.restype = C.c_int
     L.gs_frame_lane.argtypes = [vp]; L.gs_frame_lane.restype = C.c_int
     L.gs_lane_stream.argtypes = [vp, C.c_int]; L.gs_lane_stream.restype = C.c_void_p
     L.gs_stream_wait_frame.argtypes = [vp, vp]
@@ -421,6 +422,21 @@ class Context:
     def frame_stream(self):
         """hipStream_t (as an int) of the lane the current frame was enqueued on."""
         return int(self._L.gs_frame_stream(self._h) or 0)
+
+    def frame_status_device(self):
+        """device address (int) of the current frame's completion word: one uint32, 0 = complete, else drawn again at sync()"""
+        p = C.c_void_p()
+        self._ck(self._L.gs_frame_status_device(self._h, C.byref(p)))
+        return int(p.value or 0)
+
+    def frame_status(self):
+        """the completion word read back once the frame's stream is idle (a test's view of it: a GPU-side consumer reads the word itself)"""
+        addr, st = self.frame_status_device(), self.frame_stream()
+        hip = hip_runtime()
+        hip.hipStreamSynchronize(C.c_void_p(st))
+        v = C.c_uint32(0)
+        hip.hipMemcpy(C.byref(v), C.c_void_p(addr), C.c_size_t(4), 2)
+        return int(v.value)
 
     def frame_lane(self):
         """Index of the pipeline lane the current frame went to (no waiting)."""

@@ -877,7 +877,7 @@ static int lane_rc(gs_ctx *ctx, gs_ctx *L, int rc)
 
 extern "C" {
 
-GS_API uint32_t gs_version(void) { return 0x000400; }
+GS_API uint32_t gs_version(void) { return 0x000500; }
 
 GS_API int gs_device_count(void)
 {
@@ -1195,6 +1195,7 @@ int gs_fill_uniforms(gs_ctx *ctx /* owner: options, adaptive share, scene */, co
     u.W = p->fb_width; u.H = p->fb_height; u.x0 = p->x0; u.x1 = p->x1;
     u.out_pitch = p->x1 - p->x0;
     u.pair_jbits = 0; u.pair_vcap = 0; u.rc_stride = 0;          // (the binning and its record format are chosen per round: gs_render.hip)
+    u.status = nullptr;                                            // (the frame's lane supplies its own word: gs_render_uniforms)
     u.x1b = p->x0 + ((p->x1 - p->x0 + 3) & ~3);
     if (u.x1b > p->fb_width) u.x1b = p->fb_width;
     u.vw = (float)p->fb_width; u.vh = (float)p->fb_height;
@@ -1375,6 +1376,7 @@ int gs_render_uniforms(gs_ctx *ctx, const GsFrameUniforms &u_in, void *device_rg
         }
     }
     gs_ctx *L = ctx->lanes[ctx->cur];                           // the frame's lane: where its gs_sort ran
+    if (!u.status) u.status = &L->ctl->frame_status;             // the completion word of this frame (a gathered piece brings its own)
     bool async = (u.flags & GS_RENDER_ASYNC) && !(u.flags & GS_RENDER_COUNT_FRAGS);
     // A context that has not MEASURED its share yet (fresh, cleared, the share un-pinned) draws its first two-round frame synchronously
     // even when asked to queue it: the frames queued behind it then use the share it measured instead of the 25 % every context starts
@@ -1620,6 +1622,16 @@ GS_API int gs_stream_wait_frame(gs_ctx *ctx, void *hip_stream)
     TRY(lane_rc(ctx, L, lane_drain(L)));
     GS_HIP(hipEventRecord(L->ev_frame, L->stream));
     GS_HIP(hipStreamWaitEvent((hipStream_t)hip_stream, L->ev_frame, 0));
+    return GS_OK;
+}
+
+GS_API int gs_frame_status_device(gs_ctx *ctx, void **device_word)
+{
+    CHECK_CTX(ctx);
+    if (!device_word) FAIL(GS_E_BADARG, "gs_frame_status_device: device_word is NULL");
+    gs_ctx *L = ctx->lanes[ctx->cur];
+    TRY(lane_rc(ctx, L, lane_drain(L)));                         // (the frame's kernels are in the stream: the word is theirs from here on)
+    *device_word = (void *)&L->ctl->frame_status;
     return GS_OK;
 }
 

@@ -290,13 +290,25 @@ struct AssemblePieces {
     int x0[GS_ASSEMBLE_MAX], w[GS_ASSEMBLE_MAX], H[GS_ASSEMBLE_MAX], W[GS_ASSEMBLE_MAX];
     uint32_t off256[GS_ASSEMBLE_MAX];                               // staging offset / 256
     uint8_t *frame[GS_ASSEMBLE_MAX];
+    GsControl *ctl; int first;                                      // the root lane's control block; first launch of the frame's assembly
 };
 
+// Every piece travels with a trailer behind its pixels: the completion word of the render that drew it (GsFrameUniforms::status: 0 =
+// complete; an asynchronous piece that skipped its second binning round and had an unsaturated tile, or outgrew its pair buffers, is
+// not).  The root ORs the trailers into its lane's frame_status -- what gs_frame_status_device() names for a gathered frame -- and
+// raises its own sticky flag, so that ITS gs_sync() reports the frame (GS_E_RETRY) even when only a peer's piece was incomplete.
+#define GS_PIECE_TRAILER 16u
 __global__ __launch_bounds__(256) void k_assemble(const uint8_t *__restrict__ stage, AssemblePieces a)
 {
     const int pi = blockIdx.y;
     const int H = a.H[pi], w = a.w[pi], W = a.W[pi], x0 = a.x0[pi];
     const uint8_t *piece = stage + (size_t)a.off256[pi] * 256u;
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+        uint32_t v = 0;
+        for (int k = 0; k < a.n; k++) v |= *reinterpret_cast<const uint32_t *>(stage + (size_t)a.off256[k] * 256u + (size_t)a.w[k] * a.H[k] * 4u);
+        a.ctl->frame_status = a.first ? v : (a.ctl->frame_status | v);
+        if (v) a.ctl->round1_missed = 1;
+    }
     uint8_t *frame = a.frame[pi];
     const uint32_t per_row = (uint32_t)(w + 3) / 4u;                // 4 pixels = 16 bytes per thread
     const uint32_t total = per_row * (uint32_t)H;
@@ -372,7 +384,7 @@ int issue_gather(gs_ctx *L, const GatherJob &j)
             ncclResult_t r = c->GroupStart();
             for (size_t i = 0; r == 0 && i < j.pieces.size(); i++) {
                 const gs_piece &p = j.pieces[i];
-                const size_t bytes = (size_t)(p.x1 - p.x0) * j.H[p.view] * 4;
+                const size_t bytes = (size_t)(p.x1 - p.x0) * j.H[p.view] * 4 + GS_PIECE_TRAILER;   // (pixels + the piece's completion word)
                 const bool mine = p.owner == c->rank;
                 // the root's own pieces are rendered where they are assembled from; with self_copy they travel through the
                 // transport like everybody's (rendered into the second half of the staging buffer, received into the first)
@@ -393,6 +405,7 @@ int issue_gather(gs_ctx *L, const GatherJob &j)
     if (rc != GS_OK || !is_root) return rc;
     for (size_t base = 0; base < j.pieces.size(); base += GS_ASSEMBLE_MAX) {
         AssemblePieces a;
+        a.ctl = L->ctl; a.first = base == 0 ? 1 : 0;
         uint32_t most = 1;
         a.n = (int)(j.pieces.size() - base < GS_ASSEMBLE_MAX ? j.pieces.size() - base : GS_ASSEMBLE_MAX);
         for (int k = 0; k < a.n; k++) {
@@ -562,7 +575,7 @@ GS_API int gs_render_gathered(gs_ctx *ctx, const gs_render_params *views, int nv
     size_t off = 0;
     for (int i = 0; i < np; i++) {
         j.pieces.push_back(pcs[i]); j.off.push_back(off);
-        off += ((size_t)(pcs[i].x1 - pcs[i].x0) * j.H[pcs[i].view] * 4 + 255) & ~(size_t)255;
+        off += ((size_t)(pcs[i].x1 - pcs[i].x0) * j.H[pcs[i].view] * 4 + GS_PIECE_TRAILER + 255) & ~(size_t)255;
     }
     const bool is_root = rank == root;
     const bool self = is_root && c->self_copy && c->comm;
@@ -590,7 +603,9 @@ GS_API int gs_render_gathered(gs_ctx *ctx, const gs_render_params *views, int nv
         p.flags = (flags & ~(uint32_t)GS_RENDER_ASYNC) | (async ? GS_RENDER_ASYNC : 0u);
         GsFrameUniforms u;
         first = gs_fill_uniforms(ctx, &p, u);
-        if (first == GS_OK) first = gs_render_uniforms(ctx, u, L->gstage + (self ? L->gstage_cap / 2 : 0) + j.off[i], nullptr, 0);
+        uint8_t *slot = L->gstage + (self ? L->gstage_cap / 2 : 0) + j.off[i];
+        u.status = reinterpret_cast<uint32_t *>(slot + (size_t)(pcs[i].x1 - pcs[i].x0) * j.H[pcs[i].view] * 4);   // the piece's trailer
+        if (first == GS_OK) first = gs_render_uniforms(ctx, u, slot, nullptr, 0);
         if (first != GS_OK) memcpy(first_err, ctx->err, sizeof first_err);
     }
     int rc = gs_lane_call(ctx, async && first == GS_OK, [j](gs_ctx *lane) { return issue_gather(lane, j); }, /*always=*/true);

@@ -90,6 +90,8 @@ struct GsControl {
                                    // the path (the context stops using it); the frame is flagged order_incomplete + round1_missed (host clears)
     uint32_t spec_dbg;             // (GS_DEBUG_NEAR) exact threshold bin << 16 | the limit of a chunk that failed the check
     uint32_t near_bin_hint;        // OWNER's block only: the threshold depth bin the context's last near-only sort found (any lane's kernels write it)
+    uint32_t frame_status;         // the completion word of the lane's last frame (GsFrameUniforms::status points here unless the frame is a gathered piece;
+                                   // on the root of a gathered frame: the OR of all its pieces' words, written by k_assemble)
     // What the share of splats binned first has to be (round 5: measured, not walked).  A tile's blend knows how far into its list it
     // read before its 256 pixels were saturated; the sorted position of that entry says how many of the NEAREST splats had to be binned
     // for the tile: V - position.  need_near[tile % GS_NEED_WORDS] = max over the tiles of the frames drawn since the host last cleared
@@ -127,6 +129,10 @@ struct GsFrameUniforms {           // per-render constants, passed by value to k
     uint32_t pair_vcap;            // > 0 (with pair_jbits > 0): the low bits of a 4-byte record are not the sorted position but the splat's index
                                    // among the VISIBLE splats of the round (< pair_vcap), whose projected records k_emit copies to `projc`
                                    // in that order: a 4K frame has 15 tile bits and a round of 300 K positions 19, but a thousand visible splats 10
+    uint32_t *status;              // the frame's completion word (gs_frame_status_device): 0 = complete; bit 0: the second binning round was skipped and a
+                                   // tile was not saturated, bit 1: the pair buffers overflowed, bit 2: drawn from an incomplete order -- the frame is drawn
+                                   // again at gs_sync().  Written by the frame's own kernels (k_project<0> resets it, the blend raises the bits); the
+                                   // lane's control block by default, the trailer of the piece for a gathered frame (it travels with the piece)
     uint32_t rc_stride;            // span-list binning (GS_OPT_BINNING): chunks per tile row of the row-count table; 0 = pair records + radix passes.
                                    // A tile's list entries are then the sorted positions themselves (pair_jbits = 32)
 };

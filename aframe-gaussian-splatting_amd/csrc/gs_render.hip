@@ -93,6 +93,8 @@ __device__ __forceinline__ void k_project_body(const uint32_t *__restrict__ sort
     const uint32_t nchunks = (j_hi - j_lo + GS_BLOCK - 1) / GS_BLOCK;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     if (threadIdx.x == 0) s_vis = 0;
+    // the frame's completion word starts here (the first kernel of the frame's render; its sort may have left the order incomplete)
+    if (ROUND == 0 && blockIdx.x == 0 && threadIdx.x == 0 && u.status) *u.status = ctl->order_incomplete ? 4u : 0u;
     for (uint32_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
         if (threadIdx.x == 0) { s_sum = 0; s_nbig = 0; s_nmid = 0; s_visc = 0; }
         if (RUNS) s_rc[threadIdx.x] = 0u;
@@ -1103,6 +1105,8 @@ __device__ __forceinline__ void k_blend_body(const uint2 *__restrict__ tile_rang
     if (u.W < 0) s_pad[threadIdx.x] = 0u;                           // (never true; keeps the array allocated)
 #endif
     const int lane = threadIdx.x;
+    // (a round whose records did not fit bins nothing and this kernel draws the background: the completion word says so)
+    if (blockIdx.x == 0 && lane == 0 && u.status && ctl->pair_overflow) atomicOr(u.status, 2u);
     if (ROUND == 1 && ctl->j_hi == 0) return;                      // every tile saturated in round 0
     const uint32_t ntiles = (uint32_t)u.tiles_x * (uint32_t)u.tiles_y;
     // 4-byte pair records carry position - j_lo, or (compact) the index among the visible splats: `proj` is then the compacted array
@@ -1294,7 +1298,7 @@ __device__ __forceinline__ void k_blend_body(const uint2 *__restrict__ tile_rang
             st[3] = make_float4(cbA.x, cbA.y, cbB.x, cbB.y);
             if (lane == 0) {
                 atomicOr(&mask[ty * u.mask_words + (tx >> 5)], 1u << (tx & 31)); atomicAdd(&ctl->unsat_count, 1u);
-                if (u.skip_round1) ctl->round1_missed = 1;           // nobody will come for this tile unless the host notices
+                if (u.skip_round1) { ctl->round1_missed = 1; if (u.status) atomicOr(u.status, 1u); }   // nobody will come for this tile unless the host notices
             }
         }
     }
@@ -1531,7 +1535,7 @@ __device__ __forceinline__ void k_blend_px_body(const uint2 *__restrict__ tile_r
             st[0] = T; st[4] = cr; st[8] = cg; st[12] = cb;
             if (threadIdx.x == 0) {
                 atomicOr(&mask[ty * u.mask_words + (tx >> 5)], 1u << (tx & 31)); atomicAdd(&ctl->unsat_count, 1u);
-                if (u.skip_round1) ctl->round1_missed = 1;
+                if (u.skip_round1) { ctl->round1_missed = 1; if (u.status) atomicOr(u.status, 1u); }
             }
         }
         if (in) {

@@ -172,7 +172,8 @@ GS_API int gs_sync(gs_ctx *ctx);
  * On a caller-owned stream every frame is ordered with the caller's other work on it, so frames are not pipelined
  * over lanes (GS_OPT_PIPELINE_DEPTH is ignored); use the two calls below to couple pipelined frames to other streams. */
 GS_API int gs_set_stream(gs_ctx *ctx, void *hip_stream);
-/* GPU-side ordering between pipelined frames and the caller's own streams (no host blocking):
+/* GPU-side ordering between pipelined frames and the caller's own streams (no host blocking; what such a consumer reads may be an
+ * INCOMPLETE frame: test gs_frame_status_device()'s word, below):
  * gs_wait_stream: the NEXT frame (next gs_sort + its renders) starts only after everything queued on hip_stream so
  *                 far, e.g. a collective that still reads the buffer that frame will render into;
  * gs_stream_wait_frame: hip_stream waits for the frame enqueued LAST (its gs_sort + renders so far), e.g. before a
@@ -181,6 +182,20 @@ GS_API int gs_set_stream(gs_ctx *ctx, void *hip_stream);
  * collective over the frame's device_rgba, a copy -- is ordered after the frame and before the frame that will reuse
  * this lane, without any cross-stream event (those cost ~50 us of pipeline stall each on this platform). */
 GS_API void *gs_frame_stream(gs_ctx *ctx);
+/* ASYNCHRONOUS FRAMES ARE SPECULATIVE until gs_sync().  A frame queued with GS_RENDER_ASYNC may skip its second binning round (the
+ * share of splats binned first has been measured over the frames before) or bin into buffers sized from the frames before; if a tile
+ * then turns out not to be saturated, or the buffers to be too small, the frame is INCOMPLETE and gs_sync() draws it again (or asks
+ * for it: GS_E_RETRY).  The reference never draws from an incomplete order either (index.js:201-207: the draw uses the latest
+ * COMPLETED sort).  A consumer that reads the frame on the GPU before gs_sync() -- work queued on gs_frame_stream(), a stream coupled
+ * through gs_stream_wait_frame(), the library's own gather -- must therefore test the frame's completion word:
+ *   gs_frame_status_device(): *device_word = the device address of ONE uint32 of the current frame's lane, written by the frame's own
+ *   kernels: 0 = complete; non-zero = the frame will be drawn again at gs_sync() (bit 0: a tile was not saturated, bit 1: the pair
+ *   buffers overflowed, bit 2: the sorted order was incomplete).  Valid once the frame's kernels have run (in stream order behind
+ *   the frame) until the lane's NEXT frame begins (GS_OPT_PIPELINE_DEPTH x GS_OPT_FRAME_BATCH frames later); for a gathered frame,
+ *   on the root: the OR of the words of all its pieces (each piece travels with its own word, the root's gs_sync() reports the
+ *   frame even if only a peer's piece was incomplete).  Several renders of one frame on one context (gs_render_stereo): the word
+ *   describes the last of them. */
+GS_API int gs_frame_status_device(gs_ctx *ctx, void **device_word);
 /* The same in two steps, for callers that want to keep enqueuing: gs_frame_lane() names the lane of the current frame
  * (no waiting); gs_lane_stream() returns that lane's stream once its worker thread has enqueued everything handed to
  * the lane so far.  Queuing the follow-up work of frame k only after frame k+1 (or k+2) has been handed over keeps the

@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(L, name), name
     assert sorted(declared) == sorted(capi.EXPORTS)
-    assert L.gs_version() == 0x000400
+    assert L.gs_version() == 0x000500
 
 
 def test_no_cpu_fallback_without_gpu():

@@ -1833,3 +1833,62 @@ def test_paired_frames_share_their_launches_and_equal_plain_frames(scene_small):
         # switching the option off returns to plain lanes
         c.set_option(capi.OPT_FRAME_BATCH, 1)
         c.sort(cams[5]["view"]); assert np.array_equal(c.render(_params(cams[5])), want[5])
+
+
+@pytest.mark.gpu
+def test_completion_word_of_asynchronous_frames(scene_small):
+    """gs_frame_status_device (VERDICT r4 "next" #7): an asynchronous frame is speculative until gs_sync() -- it may have skipped its second
+    binning round, and then a tile that does not saturate makes it INCOMPLETE -- and a consumer that reads it on the GPU before gs_sync()
+    (a coupled stream, the library's own gather) must be able to tell.  The word of the frame's lane is 0 for a complete frame and
+    non-zero for one that gs_sync() will draw again; the reference never draws from an incomplete order either (index.js:201-207).
+    Forced miss: the share of splats binned first is measured inside the cloud (every tile saturates early, the second round is
+    switched off), then ONE frame is queued from outside the cloud, where the sky's tiles never saturate."""
+    rows = cached_rows("make_splat_rows", synth.N_TRAIN)                    # (the benchmark scene: inside it every tile saturates)
+    w, h = 640, 360
+    inside = [synth.index_html_camera(w, h, 3.0 * i, capi=capi) for i in range(12)]
+    outside = synth.outside_cloud_camera(w, h, 40.0, capi=capi)
+    with capi.Context(0) as c:
+        c.push_splat(rows)
+        for rep in range(6):                                               # synchronous frames: the share is measured, round 1 gets switched off
+            for cam in inside:
+                c.sort(cam["view"], want_indices=False); c.render_device(_params(cam), None)
+        assert c.frame_status() == 0                                       # a synchronous frame is complete when the call returns
+        # queued frames inside the cloud: complete, word 0 on every lane
+        for cam in inside[:6]:
+            c.sort(cam["view"], want_indices=False); c.render_device(_params(cam, flags=capi.RENDER_ASYNC), None)
+            assert c.frame_status() == 0
+        c.sync()
+        s0 = c.stats()
+        assert s0["near_permille"] < 900 and s0["retried_frames"] == 0
+        # one queued frame from outside: the sky does not saturate, the second round was skipped -> incomplete, and the word says so
+        c.sort(outside["view"], want_indices=False)
+        import torch
+        buf = torch.zeros(w * h * 4, dtype=torch.uint8, device="cuda")
+        c.render_device(_params(outside, flags=capi.RENDER_ASYNC), buf.data_ptr())
+        word = c.frame_status()
+        assert word & 1, word
+        c.sync()                                                           # ... and gs_sync() draws it again, complete, into the same buffer
+        torch.cuda.synchronize()
+        assert c.stats()["retried_frames"] == s0["retried_frames"] + 1
+        assert c.frame_status() == 0
+        c.sort(outside["view"]); want = c.render(_params(outside))
+        assert np.array_equal(buf.cpu().numpy().reshape(h, w, 4), want)
+    # a gathered frame (world 1, both XR eyes on this context): each piece carries its word, the root ORs them into its lane's
+    e0, e1, head = synth.xr_eye_cameras(20.0, 0.25, capi=capi)
+    W, H = e0["vw"], e0["vh"]
+    views = [capi.make_params(e["gs_mv"], e["gs_proj"], W, H, focal_=e["focal"]) for e in (e0, e1)]
+    with capi.Context(0) as c:
+        c.push_splat(rows)
+        for rep in range(48):
+            c.sort_gathered(head["view"], None, views); c.render_gathered(views, 0, None, 0)
+        c.sort_gathered(head["view"], None, views); c.render_gathered(views, 0, None, capi.RENDER_ASYNC)
+        assert c.frame_status() == 0
+        c.sync()
+        o0, o1, ohead = [synth.uniforms(synth.compose((0.032 * sx, 1.6, 0.0)), synth.compose((0.0, 1.6, -7.5), 40.0), synth.perspective(80.0, W / H), W, H, capi=capi)
+                         for sx in (-1.0, 1.0, 0.0)]
+        oviews = [capi.make_params(e["gs_mv"], e["gs_proj"], W, H, focal_=e["focal"]) for e in (o0, o1)]
+        c.sort_gathered(ohead["view"], None, oviews); c.render_gathered(oviews, 0, None, capi.RENDER_ASYNC)
+        assert c.frame_status() != 0                                       # the pieces were incomplete: the assembled frame says so ...
+        with pytest.raises(capi.GsError) as ei:                            # ... and the root's gs_sync() asks for it (gathered frames: every rank has to take part)
+            c.sync()
+        assert ei.value.code == capi.E_RETRY

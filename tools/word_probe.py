@@ -1,0 +1,28 @@
+import importlib, sys
+sys.path.insert(0, "/root/repo")
+capi = importlib.import_module("aframe-gaussian-splatting_amd.capi")
+synth = importlib.import_module("aframe-gaussian-splatting_amd.synth")
+rows = synth.make_splat_rows(synth.N_TRAIN)
+w, h = 640, 360
+P = lambda cam, **kw: capi.make_params(cam["gs_mv"], cam["gs_proj"], cam["vw"], cam["vh"], focal_=cam["focal"], **kw)
+inside = [synth.index_html_camera(w, h, 3.0 * i, capi=capi) for i in range(12)]
+outside = synth.outside_cloud_camera(w, h, 40.0, capi=capi)
+with capi.Context(0) as c:
+    c.push_splat(rows)
+    for rep in range(3):
+        for cam in inside:
+            c.sort(cam["view"], want_indices=False); c.render_device(P(cam), None)
+    print("after sync frames", {k: c.stats()[k] for k in ("near_permille", "need_splats", "unsat_tiles", "retried_frames")})
+    for cam in inside[:6]:
+        c.sort(cam["view"], want_indices=False); c.render_device(P(cam, flags=capi.RENDER_ASYNC), None)
+        print("word", c.frame_status(), "lane", c.frame_lane())
+    c.sync()
+    print("after async", {k: c.stats()[k] for k in ("near_permille", "need_splats", "unsat_tiles", "retried_frames")})
+    c.sort(outside["view"], want_indices=False)
+    c.render_device(P(outside, flags=capi.RENDER_ASYNC), None)
+    print("outside word", c.frame_status(), "lane", c.frame_lane())
+    try:
+        c.sync()
+    except Exception as e:
+        print("sync", e)
+    print("after outside", {k: c.stats()[k] for k in ("near_permille", "need_splats", "unsat_tiles", "retried_frames")})
