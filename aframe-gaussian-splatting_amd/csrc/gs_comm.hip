@@ -481,6 +481,17 @@ int issue_shared_sort(gs_ctx *L, const ShareJob &j)
 
 }  // namespace
 
+// The in-process transport's receives wait ON THE HOST for their sender to post (GS_COMM_TIMEOUT_S): a rank that is being torn down
+// while a feeder or enqueue thread of it -- or of a peer -- sits in such a wait must not make the teardown last a minute.  Cancelling
+// fails the hub (as a rank that timed out does): every waiting receive returns at once, the communicator is dead for all its ranks.
+void gs_comm_cancel(gs_ctx *ctx)
+{
+    if (!ctx || !ctx->comm || !ctx->comm->loop || !ctx->comm->comm) return;
+    GsLoopHub *h = reinterpret_cast<GsLoopEndpoint *>(ctx->comm->comm)->hub;
+    { std::lock_guard<std::mutex> lk(h->m); h->failed = true; }
+    h->cv.notify_all();
+}
+
 void gs_comm_free_lane(gs_ctx *lane)
 {
     if (lane->gstage) { (void)hipFree(lane->gstage); lane->gstage = nullptr; lane->gstage_cap = 0; }

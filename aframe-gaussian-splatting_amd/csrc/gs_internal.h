@@ -412,6 +412,7 @@ extern "C" int gs_fill_uniforms(gs_ctx *ctx, const gs_render_params *p, GsFrameU
 extern "C" int gs_render_uniforms(gs_ctx *ctx, const GsFrameUniforms &u, void *device_rgba, uint8_t *host_rgba, size_t stride);
 // ---- gs_comm.hip
 void gs_comm_free_lane(gs_ctx *lane);
+void gs_comm_cancel(gs_ctx *ctx);                                  // in-process transport: fail the hub so that every waiting receive returns at once (teardown)
 int gs_comm_set_self_copy(gs_ctx *ctx, bool on);
 int gs_comm_set_transport(gs_ctx *ctx, int transport);
 // begin a frame on its lane like gs_sort() does (lane rotation, frame log) and run `call` where the sort's kernels would be

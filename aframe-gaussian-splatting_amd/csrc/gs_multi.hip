@@ -165,6 +165,14 @@ GS_API int gs_create_multi(const int *devices, int ndev, gs_multi **out)
 GS_API int gs_multi_destroy(gs_multi *m)
 {
     if (!m) return GS_OK;
+    // a feeder that sits in a host-side receive of the in-process transport (its sender never posted: a device's frame failed, a
+    // caller that tears down mid-frame) is released now, not after GS_COMM_TIMEOUT_S: nothing of this communicator is wanted any more.
+    // Only when work is still queued: a quiet gs_multi keeps its hub intact until the endpoints go.
+    for (Feeder *f : m->f) {
+        bool busy;
+        { std::lock_guard<std::mutex> lk(f->m); busy = f->busy || !f->q.empty(); }
+        if (busy) { for (Feeder *g : m->f) gs_comm_cancel(g->ctx); break; }
+    }
     for (Feeder *f : m->f) {
         { std::lock_guard<std::mutex> lk(f->m); f->stop = true; }
         f->cv_work.notify_one();

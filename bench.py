@@ -106,7 +106,10 @@ def main():
     if sort_share and world > 1:
         ctx.set_option(capi.OPT_SORT_SHARE, sort_share)
     torch_gather = False                                     # fallback only: see below
+    path_tried = []                                          # the multi-GPU feature ladder: what was tried and why it was left (config.multi_gpu_path)
     if world > 1:
+        if rank == 0:
+            first_contact_report(ctx, capi, world, pieces_hint=None)   # BEFORE the first collective of the library: what a failed run is diagnosed from
         ok = 1
         try:
             box = [ctx.comm_unique_id() if rank == 0 else None]
@@ -120,18 +123,18 @@ def main():
         t = torch.tensor([ok], dtype=torch.int32, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
         if int(t.item()) == 0:
-            # The library's own communicator could not be set up on this node.  A line measured through torch.distributed would
-            # measure PyTorch, not gs_comm.hip: fail loudly -- unless GS_BENCH_TORCH_GATHER=1 asks for the plain form of the same
-            # exchange (every rank renders its strip synchronously into a torch tensor, torch.distributed gathers the strips on
-            # rank 0; no pipelining of the gather; labelled FALLBACK in config.parallelism)
-            if os.environ.get("GS_BENCH_TORCH_GATHER") != "1":
-                sys.stderr.write("rank %d: the library's RCCL communicator could not be set up (gs_comm_init) -- not measuring a torch.distributed "
-                                 "stand-in; set GS_BENCH_TORCH_GATHER=1 to run that fallback\n" % rank)
+            # The library's own communicator could not be set up on this node.  The run still yields a line (VERDICT r4 "next" #8: the first
+            # real multi-GPU run must, whatever breaks): the LAST rung of the ladder -- every rank renders its strip synchronously into a
+            # torch tensor, torch.distributed gathers the strips on rank 0, no pipelining of the gather -- labelled FALLBACK in
+            # config.parallelism and config.multi_gpu_path: it measures PyTorch's gather, not gs_comm.hip.  GS_BENCH_STRICT=1 refuses
+            # instead (exit 3), as round 4 did by default.
+            if os.environ.get("GS_BENCH_STRICT") == "1":
+                sys.stderr.write("rank %d: the library's RCCL communicator could not be set up (gs_comm_init) -- GS_BENCH_STRICT=1: not measuring a "
+                                 "torch.distributed stand-in\n" % rank)
                 dist.destroy_process_group()
                 sys.exit(3)
+            path_tried.append(["library gather (gs_comm_init)", "the communicator could not be set up on every rank"])
             torch_gather = True
-        elif rank == 0:
-            first_contact_report(ctx, capi, world, pieces_hint=None)
     elif comm1:
         ctx.comm_init(ctx.comm_unique_id(), 0, 1)
         ctx.set_option(capi.OPT_COMM_SELF_COPY, 1)
@@ -158,6 +161,7 @@ def main():
         return capi.make_params(np.array(q.model_view), np.array(q.projection), W, H, x0=x0, x1=x1, focal_=q.focal, flags=flags)
 
     tg = {}
+    ladder = {"replicated_sort": False}
 
     def frame_torch_gather(k):
         mg = importlib.import_module(PKG + ".multigpu")
@@ -176,7 +180,10 @@ def main():
         elif gathered:
             # the sort of a gathered frame covers the splats that can reach this rank's strip (gs_sort_for): at N > 1 the
             # sort, projection and binning shrink with the strip instead of being replicated on every GPU
-            ctx.sort_gathered(cams[k]["view"], cams[k]["cutout"], views[k])
+            if ladder["replicated_sort"]:
+                ctx.sort(cams[k]["view"], cams[k]["cutout"], want_indices=False)
+            else:
+                ctx.sort_gathered(cams[k]["view"], cams[k]["cutout"], views[k])
             ctx.render_gathered(views[k], 0, None, flags)
         else:
             ctx.sort(cams[k]["view"], cams[k]["cutout"], want_indices=False)
@@ -210,6 +217,68 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
         return bool(need)
+
+    def assembled_frame_ok(k_pose):
+        """collective: pose k drawn synchronously over all ranks; on rank 0: does the assembled image equal, bit for bit, what rank 0 renders
+        alone for the same pose (the splat buffer is replicated, pieces are tile-aligned)?  None on the other ranks."""
+        frame(k_pose, 0)
+        if rank != 0:
+            return None
+        got = [tg["frame"].cpu().numpy()] if torch_gather else [ctx.read_gathered(v, W, H) for v in range(len(widths))]
+        ctx.sort(cams[k_pose]["view"], cams[k_pose]["cutout"], want_indices=False)     # the whole order for rank 0's own full frames
+        ok = True
+        for v in range(len(widths)):
+            ok = ok and bool(np.array_equal(got[v], ctx.render(piece_params(k_pose, v, 0, W, 0))))
+        return ok
+
+    # ---- first contact with several GPUs: a ladder of features, each rung PROBED before anything is measured (a few queued frames, a
+    # sync, the self-check of one assembled frame; all ranks agree) -- pairs of gathered frames -> no pairs -> the sort replicated
+    # instead of per strip / shared -> strips gathered by torch.distributed -- so that the run yields a line whatever breaks, with the
+    # rung it ended on in config.multi_gpu_path.  (None of the library's multi-GPU code had run on more than one GPU when this was
+    # written: DESIGN.md section 7.)
+    if world > 1 and not torch_gather:
+        def probe():
+            ok = 1
+            why = ""
+            try:
+                for i in range(2 * LANES):
+                    frame(i, capi.RENDER_ASYNC)
+                sync()
+                good = assembled_frame_ok(0)
+                if rank == 0 and not good:
+                    ok, why = 0, "the assembled frame differs from rank 0's own render"
+            except capi.GsError as e:
+                ok, why = (-1 if e.code != capi.E_RETRY else 0), "gs error %d: %s" % (e.code, str(e)[:120])
+            t = torch.tensor([ok], dtype=torch.int32, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            return int(t.item()), why
+        rungs = [("gathered frames paired (GS_OPT_FRAME_BATCH = 2)" if frame_batch == 2 else "gathered frames, one per launch", None)]
+        if frame_batch == 2:
+            rungs.append(("gathered frames, one per launch", lambda: ctx.set_option(capi.OPT_FRAME_BATCH, 1)))
+        if sort_share:
+            rungs.append(("every rank sorts its own strip (GS_OPT_SORT_SHARE off)", lambda: ctx.set_option(capi.OPT_SORT_SHARE, 0)))
+        rungs.append(("the sort replicated on every rank (gs_sort instead of gs_sort_for)", lambda: ladder.__setitem__("replicated_sort", True)))
+        reached = None
+        for name_r, step in rungs:
+            if step:
+                step()
+            okp, why = probe()
+            if okp == 1:
+                reached = name_r
+                break
+            path_tried.append([name_r, why or "failed on another rank"])
+            if okp < 0:                                       # an error inside the communicator: nothing more to ask of it
+                break
+        if reached is None:
+            torch_gather = True
+        else:
+            path_tried.append([reached, "ok"])
+        if frame_batch == 2 and len(path_tried) > 1:
+            frame_batch = 1 if any(r[0].startswith("gathered frames paired") and r[1] != "ok" for r in path_tried) else frame_batch
+        if sort_share and any("GS_OPT_SORT_SHARE" in r[0] for r in path_tried):
+            sort_share = 0
+    if torch_gather:
+        path_tried.append(["strips rendered synchronously, gathered by torch.distributed (FALLBACK: measures PyTorch's gather)", "ok"])
 
     # reference-equivalent fragments per orbit frame (untimed; no early termination), and the fragments the blend really
     # evaluates with early termination on (sampled poses)
@@ -321,14 +390,7 @@ def main():
     frame_check = None
     if gathered:
         k_last = (args.warmup + args.steps - 1) % ORBIT_FRAMES
-        frame(k_last, 0)                                     # collective: every rank
-        if rank == 0:
-            ok = True
-            got = [tg["frame"].cpu().numpy()] if torch_gather else [ctx.read_gathered(v, W, H) for v in range(len(widths))]
-            ctx.sort(cams[k_last]["view"], cams[k_last]["cutout"], want_indices=False)     # the whole order for rank 0's own full frames
-            for v in range(len(widths)):
-                ok = ok and bool(np.array_equal(got[v], ctx.render(piece_params(k_last, v, 0, W, 0))))
-            frame_check = ok
+        frame_check = assembled_frame_ok(k_last)             # collective: every rank
     copy_peak = measured_copy_peak(ctx, capi) if rank == 0 else None
     total_frags = sum(frags[(args.warmup + i) % ORBIT_FRAMES] for i in range(args.steps))
     extras = None
@@ -374,6 +436,7 @@ def main():
             "ms_per_step": round(elapsed / K * 1e3, 4), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": workload, "name": cfg_name, "library_options": opts, "parallelism": par,
+                       "multi_gpu_path": path_tried if world > 1 else None,
                        "pieces_of_rank0": [[v, x0, x1] for v, x0, x1 in mine], "gathered_frame_equals_single_gpu_render": frame_check,
                        "blend_split_min_list": blend_split, "sort_share_permille": sort_share if world > 1 else 0,
                        "frames_in_flight": ("%d (the library's 3 pipeline lanes%s: every frame still runs its own full sort, projection, "

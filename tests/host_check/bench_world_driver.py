@@ -78,7 +78,10 @@ class StandInContext:
 
     def read_gathered(self, view, width=None, height=None):
         v = self.last_views[view]
-        return np.zeros((v.fb_height, v.fb_width, 4), np.uint8)
+        # BENCH_STANDIN_PAIRS_BAD=1: while gathered frames are paired (GS_OPT_FRAME_BATCH = 2) the assembled frame is WRONG -- what the
+        # probe of bench.py's feature ladder is there to notice
+        bad = os.environ.get("BENCH_STANDIN_PAIRS_BAD") == "1" and self.opts.get(capi.OPT_FRAME_BATCH) == 2
+        return np.full((v.fb_height, v.fb_width, 4), 1 if bad else 0, np.uint8)
 
     def sync(self):
         CALLS["sync"] += 1

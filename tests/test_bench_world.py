@@ -41,8 +41,8 @@ def test_column_strips_over_ranks(world):
 
 
 def test_xr_eyes_over_two_ranks_and_a_retry_agreed_by_all():
-    # rank 1's 4th gs_sync (the one closing the timed region) reports an incomplete frame: BOTH ranks measure the region again
-    d, err = run(2, 29631, "--xr", "--steps", "4", "--warmup", "2", env={"BENCH_STANDIN_RETRY": "1:4"})
+    # rank 1's 5th gs_sync (the one closing the timed region; the first is the feature ladder's probe) reports an incomplete frame: BOTH ranks measure the region again
+    d, err = run(2, 29631, "--xr", "--steps", "4", "--warmup", "2", env={"BENCH_STANDIN_RETRY": "1:5"})
     assert d["n_gpus"] == 2 and "XR" in d["metric"] and d["config"]["parallelism"].startswith("XR eyes divided over 2 GPUs")
     assert d["occlusion_binning"]["timed_region_retries"] == 1
     assert d["config"]["pieces_of_rank0"] == [[0, 0, 1032]]
@@ -56,19 +56,33 @@ def test_sort_share_switched_on_for_long_scenes_only():
 
 
 def test_fallback_when_the_librarys_communicator_cannot_be_set_up():
-    # gs_comm_init fails on ONE rank.  A scaling line measured through torch.distributed would measure PyTorch, not gs_comm.hip
-    # (VERDICT r3 #10): by default every rank gives up loudly and nothing is printed to stdout ...
+    # gs_comm_init fails on ONE rank.  The run still yields a line (VERDICT r4 "next" #8: the first real multi-GPU run must, whatever breaks):
+    # the last rung of the ladder -- strips gathered by torch.distributed -- labelled as the FALLBACK it is, with what was tried before it
+    d, _ = run(2, 29634, "--steps", "4", "--warmup", "2", env={"BENCH_STANDIN_COMM_FAIL": "1"})
+    assert "FALLBACK" in d["config"]["parallelism"] and d["config"]["gathered_frame_equals_single_gpu_render"] is True and d["value"] > 0
+    path = d["config"]["multi_gpu_path"]
+    assert path[0][0].startswith("library gather") and "could not be set up" in path[0][1] and "torch.distributed" in path[-1][0] and path[-1][1] == "ok"
+    # ... GS_BENCH_STRICT=1 refuses instead: a scaling line measured through torch.distributed measures PyTorch, not gs_comm.hip
     e = dict(os.environ)
-    e.update({"BENCH_STANDIN_COMM_FAIL": "1"})
-    e.pop("GS_SPLAT_LIB", None); e.pop("GS_BENCH_TORCH_GATHER", None)
+    e.update({"BENCH_STANDIN_COMM_FAIL": "1", "GS_BENCH_STRICT": "1"})
+    e.pop("GS_SPLAT_LIB", None)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", "29633", DRIVER, "--gpus", "2", "--steps", "4", "--warmup", "2"]
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=e, cwd=ROOT)
     assert p.returncode != 0 and not [l for l in p.stdout.splitlines() if l.strip().startswith("{")]
-    assert "could not be set up" in p.stderr and "GS_BENCH_TORCH_GATHER" in p.stderr
-    # ... and only GS_BENCH_TORCH_GATHER=1 runs the plain exchange (strips gathered by torch.distributed), labelled as such
-    d, _ = run(2, 29634, "--steps", "4", "--warmup", "2", env={"BENCH_STANDIN_COMM_FAIL": "1", "GS_BENCH_TORCH_GATHER": "1"})
-    assert "FALLBACK" in d["config"]["parallelism"] and d["config"]["gathered_frame_equals_single_gpu_render"] is True and d["value"] > 0
+    assert "could not be set up" in p.stderr and "GS_BENCH_STRICT" in p.stderr
+
+
+def test_feature_ladder_steps_down_when_a_probe_fails():
+    # paired gathered frames assemble a WRONG image on this "node" (stand-in): the probe notices before anything is measured, the pairs
+    # are switched off, the next rung's probe passes, and the line says which rung it was measured on
+    d, _ = run(2, 29637, "--steps", "4", "--warmup", "2", env={"BENCH_STANDIN_PAIRS_BAD": "1"})
+    path = d["config"]["multi_gpu_path"]
+    assert path[0][0].startswith("gathered frames paired") and "differs" in path[0][1]
+    assert path[-1] == ["gathered frames, one per launch", "ok"]
+    assert d["config"]["frames_per_launch"] == 1 and d["config"]["gathered_frame_equals_single_gpu_render"] is True
+    d, _ = run(2, 29638, "--steps", "4", "--warmup", "2")
+    assert d["config"]["multi_gpu_path"] == [["gathered frames paired (GS_OPT_FRAME_BATCH = 2)", "ok"]] and d["config"]["frames_per_launch"] == 2
 
 
 def test_first_contact_report_goes_to_stderr():
