@@ -21,7 +21,6 @@ OPT_FRAME_BATCH = 10
 OPT_SORT_NEAR = 11
 OPT_COMM_TRANSPORT = 12
 OPT_AUTO_RETRY = 13
-OPT_HOST_WRITE = 14
 OPT_SORT_SHARE = 15
 OPT_BINNING = 16
 TRANSPORT_RCCL, TRANSPORT_INPROC = 0, 1

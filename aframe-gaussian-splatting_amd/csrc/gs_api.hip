@@ -1346,23 +1346,6 @@ static int render_common(gs_ctx *ctx, const gs_render_params *p, void *device_rg
     return gs_render_uniforms(ctx, u, device_rgba, host_rgba, stride);
 }
 
-// GS_OPT_HOST_WRITE: a page-locked host frame the GPU can address (gs_host_alloc, hipHostMalloc, a registered buffer) is written
-// by the blend kernel itself, 16 bytes per lane as its tile finishes -- the frame's way over PCIe then runs under the blending
-// of the other tiles instead of behind the last kernel, and there is no copy to wait for.  Returns the device-side address of
-// host_rgba, or nullptr when the frame has to be copied (pageable memory, odd alignment, option off).
-static void *host_frame_device_address(gs_ctx *ctx, const GsFrameUniforms &u, uint8_t *host_rgba, size_t stride, bool async)
-{
-    const int mode = ctx->host_write;
-    if (!host_rgba || mode == 0 || (mode == 2 && async)) return nullptr;
-    if (u.flags & GS_RENDER_COUNT_FRAGS) return nullptr;
-    if ((stride & 15) || ((uintptr_t)host_rgba & 15)) return nullptr;
-    hipPointerAttribute_t a;
-    memset(&a, 0, sizeof a);
-    if (hipPointerGetAttributes(&a, host_rgba) != hipSuccess) { (void)hipGetLastError(); return nullptr; }   // (pageable memory: not an error)
-    if (a.type != hipMemoryTypeHost || !a.devicePointer) return nullptr;
-    return a.devicePointer;
-}
-
 int gs_render_uniforms(gs_ctx *ctx, const GsFrameUniforms &u_in, void *device_rgba, uint8_t *host_rgba, size_t stride)
 {
     if (!ctx->renderable && ctx->n) FAIL(GS_E_STATE, "context was fed worker matrices only (gs_push_matrices): it can sort but not render");
@@ -1371,9 +1354,6 @@ int gs_render_uniforms(gs_ctx *ctx, const GsFrameUniforms &u_in, void *device_rg
     if (host_rgba && !device_rgba) {
         const size_t row = (size_t)(u.x1 - u.x0) * 4, st = stride ? stride : row;
         if (st < row) FAIL(GS_E_BADARG, "stride %zu smaller than a row (%zu bytes)", st, row);
-        if (void *d = host_frame_device_address(ctx, u, host_rgba, st, (u.flags & GS_RENDER_ASYNC) != 0)) {
-            device_rgba = d; host_rgba = nullptr; u.out_pitch = (int32_t)(st / 4);
-        }
     }
     gs_ctx *L = ctx->lanes[ctx->cur];                           // the frame's lane: where its gs_sort ran
     if (!u.status) u.status = &L->ctl->frame_status;             // the completion word of this frame (a gathered piece brings its own)
@@ -1690,10 +1670,6 @@ GS_API int gs_set_option(gs_ctx *ctx, int option, int64_t value)
         GS_HIP(hipSetDevice(ctx->device));
         TRY(drain_all(ctx));
         ctx->sort_share_permille = (int)value;
-        return GS_OK;
-    case GS_OPT_HOST_WRITE:
-        if (value < 0 || value > 2) FAIL(GS_E_BADARG, "host write: 0 (copy engine), 1 (the blend writes page-locked frames itself) or 2 (synchronous frames only)");
-        ctx->host_write = (int)value;
         return GS_OK;
     case GS_OPT_AUTO_RETRY:
         GS_HIP(hipSetDevice(ctx->device));

@@ -111,8 +111,7 @@ struct GsFrameUniforms {           // per-render constants, passed by value to k
     float focal, vw, vh;
     int32_t W, H;                  // full viewport
     int32_t x0, x1;                // strip
-    int32_t out_pitch;             // pixels per row of the output image (x1 - x0 for a tight strip; the caller's row stride when the blend writes
-                                   // straight into a page-locked host frame, GS_OPT_HOST_WRITE)
+    int32_t out_pitch;             // pixels per row of the output image (x1 - x0: a tight strip)
     int32_t x1b;                   // x1 rounded up to a multiple of 4 pixels from x0, clipped to W: what is binned and blended (x1: written)
     int32_t tiles_x, tiles_y;      // tile grid of the strip (origin at pixel x0, row 0 = top)
     float bg[4];
@@ -267,7 +266,6 @@ struct gs_ctx {
     bool async_pending;            // frames were enqueued with GS_RENDER_ASYNC since the last gs_sync
     GsFrameLog *log;               // lane: the frames handed to it since the last gs_sync (caller's thread only)
     bool auto_retry;               // owner: GS_OPT_AUTO_RETRY
-    int host_write;                // owner: GS_OPT_HOST_WRITE
     int sort_share_permille;       // owner: GS_OPT_SORT_SHARE (0 = every rank sorts every frame)
     bool adapt_frozen;             // owner: gs_sync is drawing flagged frames again: their counters do not feed the adaptive share
     bool log_stale;                // owner: the resident data / scene changed under frames that are still in the logs

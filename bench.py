@@ -713,7 +713,7 @@ def secondary_measurements(ctx, capi, synth, rows, cams, views, n_splats, args, 
                 ctx.sync()
             except Exception:                                    # noqa: BLE001
                 pass
-        for opt, val in ((capi.OPT_PROFILE, 0), (capi.OPT_RECORD_STAGED, 0), (capi.OPT_HOST_WRITE, 0),
+        for opt, val in ((capi.OPT_PROFILE, 0), (capi.OPT_RECORD_STAGED, 0),
                          (capi.OPT_PIPELINE_DEPTH, int(os.environ.get("GS_BENCH_DEPTH", "0")) or 3), (capi.OPT_FRAME_BATCH, frame_batch)):
             try:
                 ctx.set_option(opt, val)
@@ -791,9 +791,9 @@ def secondary_measurements(ctx, capi, synth, rows, cams, views, n_splats, args, 
     guard('roofline_valu', part_roofline_valu)
 
     def part_host_readback():
-        # the frame delivered to the host (what a JS caller of component.render() gets): gs_render into page-locked memory.  Two ways
-        # there (GS_OPT_HOST_WRITE): the copy engine behind the frame's last kernel, or the blend kernel storing its tiles straight into
-        # the page-locked frame; the denominator is this box's own device-to-host rate (1 GiB, page-locked, same run)
+        # the frame delivered to the host (what a JS caller of component.render() gets): gs_render into page-locked memory, copied by the
+        # copy engine behind the frame's last kernel (the blend storing into the host frame itself was measured in rounds 3-4 and removed
+        # in round 5: no faster alone, slower with frames in flight); the denominator is this box's own device-to-host rate
         ctx.set_option(capi.OPT_FRAME_BATCH, 1)                    # (the synchronous half: one frame at a time)
         ctx.set_option(capi.OPT_PIPELINE_DEPTH, 1)
         pcie = measured_pcie_peak(capi)
@@ -811,11 +811,8 @@ def secondary_measurements(ctx, capi, synth, rows, cams, views, n_splats, args, 
             return time.perf_counter() - t0
 
         sync_ms = {}
-        for mode, tag in ((0, "copy_engine"), (1, "blend_writes_host")):
-            ctx.set_option(capi.OPT_HOST_WRITE, mode)
-            loop_sync(12)
-            sync_ms[tag] = loop_sync(m) / m * 1e3
-        ctx.set_option(capi.OPT_HOST_WRITE, 0)
+        loop_sync(12)
+        sync_ms["copy_engine"] = loop_sync(m) / m * 1e3
         owner.free()
         best_sync = min(sync_ms, key=sync_ms.get)
         out["host_readback"] = {"fps_host_readback": round(1e3 / sync_ms[best_sync], 1), "ms_per_frame": round(sync_ms[best_sync], 4),
@@ -855,11 +852,8 @@ def secondary_measurements(ctx, capi, synth, rows, cams, views, n_splats, args, 
 
         m = min(n, 240)
         pipe = {}
-        for mode, tag in ((0, "copy_engine"), (1, "blend_writes_host")):
-            ctx.set_option(capi.OPT_HOST_WRITE, mode)
-            loop_host(48)
-            pipe[tag] = m / loop_host(m)
-        ctx.set_option(capi.OPT_HOST_WRITE, 0)
+        loop_host(48)
+        pipe["copy_engine"] = m / loop_host(m)
         for _, o in bufs:
             o.free()
         best = max(pipe, key=pipe.get)

@@ -317,11 +317,8 @@ GS_API int gs_multi_sync(gs_multi *m);
                                    order than was exchanged (its first binning round reads more than P/1000 * N splats, or did not skip
                                    the second one) sorts again in full locally, as after any near-only sort.  Set the same value on every
                                    rank, before the frames; needs N <= 2^25.                                                        */
-#define GS_OPT_HOST_WRITE 14    /* how gs_render's frame reaches a PAGE-LOCKED host buffer (gs_host_alloc).  0: copied by the copy engine behind
-                                   the frame's last kernel.  1: the blend kernel stores its tiles straight into the buffer (16 bytes per
-                                   lane as each tile finishes), so the transfer runs under the blending of the other tiles and nothing is
-                                   left to wait for.  2: that for synchronous frames only.  Pageable or oddly aligned buffers are always
-                                   copied.  Same pixels either way.                                                                  */
+/* (option 14, GS_OPT_HOST_WRITE -- the blend kernel storing its tiles straight into a page-locked host frame -- was measured in rounds 3
+   and 4: no faster for a frame alone, 25 % slower with frames in flight; removed in round 5.  The copy engine delivers host frames.) */
 #define GS_OPT_AUTO_RETRY 13    /* 1 (default): gs_sync() draws an asynchronous frame that came back incomplete again by itself -- same sort
                                    arguments, same uniforms, same output buffers, both binning rounds -- before it returns; GS_E_RETRY is
                                    left for the cases it cannot decide alone (see gs_status).  0: every such frame is reported.       */

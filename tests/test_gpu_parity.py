@@ -1646,54 +1646,6 @@ def test_asynchronous_host_frames_equal_synchronous_ones(scene_small):
             o.free()
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize("mode", [1, 2])
-def test_blend_writes_page_locked_frames_directly(scene_small, mode):
-    """GS_OPT_HOST_WRITE: the blend kernel stores its tiles straight into a page-locked host frame (tight, strided as a column
-    strip of a wider frame, flipped, paired asynchronous frames) -- the same bytes as the copied frame; pageable memory is
-    still copied"""
-    w, h = 640, 360
-    cams = [synth.index_html_camera(w, h, y, capi=capi) for y in (0.0, 100.0, 200.0, 300.0)]
-    with capi.Context(0) as c:
-        c.push_splat(scene_small["rows"])
-        want = []
-        for cam in cams:
-            c.sort(cam["view"]); want.append(c.render(_params(cam)))
-        c.set_option(capi.OPT_HOST_WRITE, mode)
-        pinned = [capi.host_frame(h, w) for _ in cams]
-        for cam, (buf, _), wnt in zip(cams, pinned, want):                   # synchronous
-            buf[...] = 9
-            c.sort(cam["view"], want_indices=False)
-            c.render_into(_params(cam), buf)
-            assert np.array_equal(buf, wnt)
-        c.sort(cams[1]["view"], want_indices=False)
-        c.render_into(_params(cams[1], flags=capi.RENDER_FLIP_Y), pinned[1][0])
-        assert np.array_equal(pinned[1][0], want[1][::-1])
-        pageable = np.full((h, w, 4), 3, np.uint8)
-        c.render_into(_params(cams[1]), pageable)
-        assert np.array_equal(pageable, want[1])
-        # column strips of ONE wide page-locked frame, each written with the frame's row stride (what gs_multi_render does)
-        whole, own = capi.host_frame(h, w)
-        whole[...] = 5
-        c.sort(cams[2]["view"], want_indices=False)
-        for x0, x1 in ((0, 208), (208, 432), (432, 640)):
-            c.render_into(_params(cams[2], x0=x0, x1=x1), whole[:, x0:x1])
-        assert np.array_equal(whole, want[2])
-        own.free()
-        c.set_option(capi.OPT_FRAME_BATCH, 2)                              # asynchronous, paired
-        for (buf, _) in pinned:
-            buf[...] = 9
-        for rep in range(3):
-            for cam, (buf, _) in zip(cams, pinned):
-                c.sort(cam["view"], want_indices=False)
-                c.render_into(_params(cam, flags=capi.RENDER_ASYNC), buf)
-            c.sync()
-        for (buf, _), wnt in zip(pinned, want):
-            assert np.array_equal(buf, wnt)
-        for _, o in pinned:
-            o.free()
-
-
 # ---------------------------------------------------------------- the reference's own GLSL (drawn by Mesa) as the pixel golden
 
 import test_gl_pin as _glpin
