@@ -146,7 +146,8 @@ def load(build_if_missing=True):
     L.gs_set_stream.argtypes = [vp, vp]
     L.gs_wait_stream.argtypes = [vp, vp]
     L.gs_frame_stream.argtypes = [vp]; L.gs_frame_stream.restype = C.c_void_p
-    L.gs_frame_status_device.argtypes = [vp, C.POINTER(C.c_void_p)]; L.gs_frame_status_device.restype = C.c_int
+    if hasattr(L, "gs_frame_status_device"):                   # (an older build loaded through GS_SPLAT_LIB for an A/B run has none)
+        L.gs_frame_status_device.argtypes = [vp, C.POINTER(C.c_void_p)]; L.gs_frame_status_device.restype = C.c_int
     L.gs_frame_lane.argtypes = [vp]; L.gs_frame_lane.restype = C.c_int
     L.gs_lane_stream.argtypes = [vp, C.c_int]; L.gs_lane_stream.restype = C.c_void_p
     L.gs_stream_wait_frame.argtypes = [vp, vp]

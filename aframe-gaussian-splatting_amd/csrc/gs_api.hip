@@ -331,6 +331,25 @@ static void share_missed(gs_ctx *ctx /* owner */, float frac_used)
     ctx->clean_frames = 0; ctx->skip_hold = 32;
 }
 
+// Every lane's words are brought near what the collected frames measured: a lane whose words are far below it (a lane that has drawn
+// nothing yet -- its block is zero --, or nothing of this view) would have EVERY tile of its next frame issue its atomic: 8160 on one
+// line, ~90 us -- the first frame of five lanes after a run of synchronous frames, i.e. the fill of bench.py's twenty-frame region.
+static int seed_need_words(gs_ctx *ctx /* owner */, uint32_t need)
+{
+    if (!need) return GS_OK;
+    const uint32_t seed = need == 0xFFFFFFFFu ? need : (uint32_t)((uint64_t)need * 9u / 10u);
+    for (int i = 0; i < GS_MAX_LANES; i++) {
+        gs_ctx *L = ctx->lanes[i];
+        if (!L || !L->ctl) continue;
+        const uint32_t have = L->need_word_est;
+        const bool stale = need == 0xFFFFFFFFu ? have != 0xFFFFFFFFu : (have != 0xFFFFFFFFu && (uint64_t)have * 10u < (uint64_t)need * 8u);
+        if (!stale) continue;
+        L->need_seed_pending = seed ? seed : 1u;
+        L->need_word_est = seed;
+    }
+    return GS_OK;
+}
+
 static int collect_status(gs_ctx *lane, bool *overflowed, bool *share_failed = nullptr, uint32_t *spec_failed = nullptr, uint32_t *need_out = nullptr,
                           uint32_t *frames_out = nullptr)
 {
@@ -364,9 +383,11 @@ static int collect_status(gs_ctx *lane, bool *overflowed, bool *share_failed = n
         // 0xFFFFFFFF (a tile nothing saturates) is kept, and dropped once in sixteen seedings: the scene may have changed.
         // (... every fourth collection of the lane: the host follows the maximum of the last eight collections anyway, and a queue entry
         // per lane and gs_sync is 60 us of a twenty-frame region)
+        lane->need_word_est = need;                                // (what the lane's words hold now: their maximum)
         if ((++lane->need_probe & 3u) == 0u) {
             const uint32_t seed = need == 0xFFFFFFFFu ? ((lane->need_probe & 63u) ? 0xFFFFFFFFu : 0u) : (uint32_t)((uint64_t)need * 9u / 10u);
-            GS_HIP(hipMemsetD32Async((hipDeviceptr_t)lane->ctl->need_near, (int)seed, GS_NEED_WORDS, lane->stream));
+            lane->need_seed_pending = seed ? seed : 1u;            // (written by the lane's next frame itself: GsFrameUniforms::need_seed)
+            lane->need_word_est = seed;
         }
     }
     // (frames drawn from a truncated order measure nothing.  Frames gs_sync draws AGAIN do -- both rounds, every tile's need recorded, the
@@ -632,6 +653,8 @@ static void lane_worker_main(gs_ctx *L)
         // launches below decide on a copy taken while the mutex is still held: ThreadSanitizer, round 4)
         const int prior_rc = w->rc;
         lk.unlock();
+        static const bool dbg_slow = getenv("GS_DEBUG_WORKER") != nullptr;   // (diagnostic: commands that kept this thread longer than 60 us)
+        const auto dbg_t0 = std::chrono::steady_clock::now();
         // (a call is run even after a failure: the gather of a frame must be issued on every rank, or the others wait for it)
         if (stereo) rc = run_two_views(L, L->twin, c, pc[0], pc[1]);
         else if (paired) {
@@ -644,6 +667,10 @@ static void lane_worker_main(gs_ctx *L)
         else if (c.type == 2) { const int r2 = c.call(T); if (prior_rc == GS_OK) rc = r2; }
         else if (prior_rc == GS_OK) rc = c.type == 0 ? gs_run_sort(T, c.view, c.has_cutout ? c.cutout : nullptr, c.has_strip ? &c.strip : nullptr, c.near_req)
                                                   : render_async_on_lane(T, c.u, c.device_rgba, c.host_rgba, c.stride);
+        if (dbg_slow) {
+            const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - dbg_t0).count();
+            if (us > 60.0) fprintf(stderr, "[gs] worker %p: %s for lane %p took %.0f us\n", (void *)L, stereo ? "two views" : paired ? "a pair" : c.type == 0 ? "a sort" : c.type == 1 ? "a render" : "a call", (void *)T, us);
+        }
         lk.lock();
         if (rc != GS_OK && w->rc == GS_OK) { w->rc = rc; memcpy(w->err, scratch, sizeof w->err); }
         w->busy = false;
@@ -713,6 +740,20 @@ static void lane_stop_worker(gs_ctx *L)
         snprintf(GS_ERRBUF(ctx), GS_ERRLEN, "%s failed: %s (%s:%d)", #call, hipGetErrorString(_e), __FILE__, __LINE__);    \
         return (_e == hipErrorOutOfMemory) ? GS_E_OOM : GS_E_HIP; } } while (0)
 
+// The first dispatch of a hardware queue that asks for PRIVATE (scratch) memory -- or for more of it per lane than the queue has had
+// so far -- stops at the command processor until the runtime has allocated it: ~140 us, once per queue.  A few kernels here ask
+// for some (k_project<0, true>: 36 bytes of spill slots the compiler keeps although every SGPR spill went to VGPR lanes; the paired
+// k_seg_sort: 12), and which of the lanes' queues has met one of them before a caller starts timing is a matter of which frames
+// went out alone and which in pairs: round 5's twenty-frame region lost 80 us to one such stop on a queue the pre-roll had only
+// fed pairs (tools/prof_api.py: the launch call returned, the kernel started 140 us later).  So every lane's stream asks for more
+// than any kernel will, once, when the lane is made.
+__global__ void k_touch_private(uint32_t *out, uint32_t n)
+{
+    volatile uint32_t a[GS_TOUCH_PRIVATE_WORDS];                  // (volatile + a run-time index: stays in private memory)
+    for (uint32_t i = 0; i < GS_TOUCH_PRIVATE_WORDS; i++) a[i] = i * n;
+    out[0] = a[n % GS_TOUCH_PRIVATE_WORDS];
+}
+
 // stream, control block, per-workgroup partial slots, pinned mirror: what every lane owns besides its scratch
 static hipError_t init_frame_resources(gs_ctx *c, gs_ctx *primary = nullptr)
 {
@@ -734,6 +775,7 @@ static hipError_t init_frame_resources(gs_ctx *c, gs_ctx *primary = nullptr)
     memset(c->ctl_host, 0, sizeof(GsControl));
     IFR(hipEventCreateWithFlags(&c->ev_frame, hipEventDisableTiming | hipEventReleaseToDevice));
     IFR(hipEventCreateWithFlags(&c->ev_gate, hipEventDisableTiming | hipEventReleaseToDevice));
+    if (!primary) { k_touch_private<<<1, 64, 0, c->stream>>>(c->part_cnt, 1u); IFR(hipGetLastError()); }   // (the queue's private memory: above)
 #undef IFR
     return hipSuccess;
 }
@@ -1196,6 +1238,7 @@ int gs_fill_uniforms(gs_ctx *ctx /* owner: options, adaptive share, scene */, co
     u.out_pitch = p->x1 - p->x0;
     u.pair_jbits = 0; u.pair_vcap = 0; u.rc_stride = 0;          // (the binning and its record format are chosen per round: gs_render.hip)
     u.status = nullptr;                                            // (the frame's lane supplies its own word: gs_render_uniforms)
+    u.need_seed = 0;
     u.x1b = p->x0 + ((p->x1 - p->x0 + 3) & ~3);
     if (u.x1b > p->fb_width) u.x1b = p->fb_width;
     u.vw = (float)p->fb_width; u.vh = (float)p->fb_height;
@@ -1309,7 +1352,7 @@ static int render_sync_on_lane(gs_ctx *ctx, const GsFrameUniforms &u, void *devi
         const float frac_used = gs_root(ctx)->near_frac;
         TRY(collect_status(ctx, &over, &failed, nullptr, &need, &nfr));
         if (failed) { if (gs_root(ctx)->share_measured) share_missed(gs_root(ctx), frac_used); else share_raise(gs_root(ctx), frac_used); }
-        else share_from_need(gs_root(ctx), need, nfr);
+        else { share_from_need(gs_root(ctx), need, nfr); TRY(seed_need_words(gs_root(ctx), need)); }
         if (!over) break;
         if (attempt >= 2) FAIL(GS_E_OOM, "pair list keeps overflowing (%u pairs)", ctx->ctl_host->scan_total);
     }
@@ -1357,6 +1400,7 @@ int gs_render_uniforms(gs_ctx *ctx, const GsFrameUniforms &u_in, void *device_rg
     }
     gs_ctx *L = ctx->lanes[ctx->cur];                           // the frame's lane: where its gs_sort ran
     if (!u.status) u.status = &L->ctl->frame_status;             // the completion word of this frame (a gathered piece brings its own)
+    u.need_seed = L->need_seed_pending; L->need_seed_pending = 0;  // (a seed for the lane's need words travels with its next frame)
     bool async = (u.flags & GS_RENDER_ASYNC) && !(u.flags & GS_RENDER_COUNT_FRAGS);
     // A context that has not MEASURED its share yet (fresh, cleared, the share un-pinned) draws its first two-round frame synchronously
     // even when asked to queue it: the frames queued behind it then use the share it measured instead of the 25 % every context starts
@@ -1480,6 +1524,7 @@ static int redraw_flagged_frames_impl(gs_ctx *ctx, const bool bad_unit[GS_MAX_PR
                 GsFrameUniforms u = r.r[k].u;
                 u.flags &= ~(uint32_t)GS_RENDER_ASYNC;
                 u.skip_round1 = 0;                                   // both rounds: complete by construction
+                u.need_seed = 0;                                     // (the seed it carried has been written)
                 TRY(lane_rc(ctx, L, render_sync_on_lane(L, u, r.r[k].dev, r.r[k].host, r.r[k].stride)));
                 redrawn++;
             }
@@ -1539,7 +1584,7 @@ GS_API int gs_sync(gs_ctx *ctx)
         if (over && L->ctl_host->max_total > want) want = L->ctl_host->max_total;
     }
     if (share_failed) { if (ctx->share_measured) share_missed(ctx, frac_used); else share_raise(ctx, frac_used); }   // (once, whatever the number of lanes that saw it)
-    else share_from_need(ctx, need, nfr);                        // ... else what the collected frames' tiles needed (the maximum over the lanes)
+    else { share_from_need(ctx, need, nfr); TRY(seed_need_words(ctx, need)); }   // ... else what the collected frames' tiles needed (the maximum over the lanes)
     if (spec_failed) gs_spec_back_off(ctx, spec_failed == 2u);
     if (any_over)                                                // one retry for all lanes: each gets room for the largest demand seen
         for (int i = 0; i < GS_MAX_LANES; i++)

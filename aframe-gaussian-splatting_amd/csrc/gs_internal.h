@@ -22,6 +22,7 @@
 #define GS_RADIX_LARGE_N (3u << 20) // inputs expected to be longer than this take the long geometry
 #endif
 #define GS_RADIX_MAX_BINS 512      // up to 9-bit digits (depth key = 17 bits = 8 + 9)
+#define GS_TOUCH_PRIVATE_WORDS 16u   /* private dwords per lane a new lane's stream is made to allocate (gs_api.hip: k_touch_private) */
 #define GS_NEED_WORDS 32u          // GsControl::need_near
 #define GS_MSD_GROUP 32u           // the MSD depth sort (gs_sort.hip): radix chunks per group row
 #define GS_MSD_MAX_N (1u << 21)    // ... takes sorts of at most this many splats.  Its records (low bucket byte << 24 | index) would hold 2^24, but a chunk's
@@ -128,6 +129,8 @@ struct GsFrameUniforms {           // per-render constants, passed by value to k
     uint32_t pair_vcap;            // > 0 (with pair_jbits > 0): the low bits of a 4-byte record are not the sorted position but the splat's index
                                    // among the VISIBLE splats of the round (< pair_vcap), whose projected records k_emit copies to `projc`
                                    // in that order: a 4K frame has 15 tile bits and a round of 300 K positions 19, but a thousand visible splats 10
+    uint32_t need_seed;            // != 0: the frame's projection first sets the lane's need_near words to this (1: to zero) -- how the host seeds them
+                                   // after a collection: a hipMemsetD32Async per lane cost gs_sync() 20 us of host time each
     uint32_t *status;              // the frame's completion word (gs_frame_status_device): 0 = complete; bit 0: the second binning round was skipped and a
                                    // tile was not saturated, bit 1: the pair buffers overflowed, bit 2: drawn from an incomplete order -- the frame is drawn
                                    // again at gs_sync().  Written by the frame's own kernels (k_project<0> resets it, the blend raises the bits); the
@@ -239,7 +242,9 @@ struct gs_ctx {
     bool last_two_rounds;                   // the last enqueued frame ran the two-round path (its unsat count is meaningful)
     float near_floor;                       // never shrink the share below this (1.3 x the share that last proved too small)
     bool share_measured;                    // owner: near_frac comes from a measurement (GsControl::need_near) -- share_from_need, gs_api.hip
-    uint32_t need_probe;                    // lane: collections that found "a tile nothing saturates" (every 16th re-probes)
+    uint32_t need_probe;                    // lane: its collections with a measurement (every fourth re-seeds its words)
+    uint32_t need_word_est;                 // lane: what its need_near words hold at least (host-side estimate: seed_need_words)
+    uint32_t need_seed_pending;             // lane: the seed its next frame's projection writes into the words (GsFrameUniforms::need_seed; 0 = none)
     float need_margin;                      // owner: the factor on top of the measured need (1.15 ... 1.04 while nothing misses, + 0.1 per miss)
     uint32_t need_hist[16], need_hist_frames[16]; int need_hist_pos;   // owner: the needs of the last collections and the frames each covered (share_from_need)
     uint32_t clean_frames, skip_hold;       // collected frames since the last unsaturated one / frames to keep round 1 on

@@ -95,6 +95,7 @@ __device__ __forceinline__ void k_project_body(const uint32_t *__restrict__ sort
     if (threadIdx.x == 0) s_vis = 0;
     // the frame's completion word starts here (the first kernel of the frame's render; its sort may have left the order incomplete)
     if (ROUND == 0 && blockIdx.x == 0 && threadIdx.x == 0 && u.status) *u.status = ctl->order_incomplete ? 4u : 0u;
+    if (ROUND == 0 && blockIdx.x == 0 && u.need_seed && threadIdx.x < GS_NEED_WORDS) ctl->need_near[threadIdx.x] = u.need_seed == 1u ? 0u : u.need_seed;   // (the host's seed: gs_api.hip)
     for (uint32_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
         if (threadIdx.x == 0) { s_sum = 0; s_nbig = 0; s_nmid = 0; s_visc = 0; }
         if (RUNS) s_rc[threadIdx.x] = 0u;
@@ -1272,6 +1273,7 @@ __device__ __forceinline__ void k_blend_body(const uint2 *__restrict__ tile_rang
         __syncthreads();                                           // s_ent is rewritten by the next batch
         if (__all(!live)) break;
     }
+#ifndef GS_NO_NEED_RECORD        // (A/B builds: tools/build_variant.sh noneed -DGS_NO_NEED_RECORD)
     if (!COUNT && GS_BLEND_BATCH == 64 && !(u.flags & GS_RENDER_NO_EARLY_OUT) && !u.pair_vcap) {   // (compact pair records name a splat by its index among the visible ones: no position)
         // how many of the nearest splats this tile needed (GsControl::need_near): the sorted position of the entry at which its LAST
         // lane left the list (lane k staged entry k of the batch: a tile's entries lie ~1000 sorted positions apart, "the batch" would
@@ -1290,6 +1292,7 @@ __device__ __forceinline__ void k_blend_body(const uint2 *__restrict__ tile_rang
             }
         }
     }
+#endif
     if (ROUND == 0 && u.near_count < ctl->n_kept) {               // farther splats exist beyond this round
         // the nearer splats did not saturate this tile: keep the exact per-pixel state for round 1 and flag the tile
         if (__any(live)) {

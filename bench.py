@@ -331,9 +331,12 @@ def main():
         t_start = time.perf_counter()
         for i in range(args.steps):
             frame(args.warmup + i, capi.RENDER_ASYNC)
+        t_enq = time.perf_counter()
         again = sync()
         elapsed = time.perf_counter() - t_start
         gc.enable()
+        if os.environ.get("GS_BENCH_TIMING"):                    # diagnostic: how the region splits into enqueuing and the closing sync
+            sys.stderr.write("[bench] region: enqueue %.0f us + sync %.0f us\n" % ((t_enq - t_start) * 1e6, (elapsed - (t_enq - t_start)) * 1e6))
         if not again:
             break
         if attempt == 3:
