@@ -16,6 +16,7 @@ import os
 ORBIT_FRAMES = 120          # the benchmark orbit: entity yaw 360 i / 120 degrees
 LANES = 3                   # the library's default pipeline depth (GS_OPT_PIPELINE_DEPTH), what bench.py measures with
 PUSH_ROWS = 1 << 22         # progressive ingest (index.js:279-298): rows per gs_push_splat
+ASYNC_WARM = 6              # queued frames per lane before the warm-up steps (pre-roll, untimed): see preroll()
 
 _SEED_BASE = 0x5EED0000
 
@@ -136,16 +137,21 @@ def region_frames(warmup, steps):
 
 
 def preroll(frame, sync, frames_used, warmup, async_flag, lanes=LANES, warmup_first=0):
-    """What bench.py does before its timed region (untimed): synchronous frames cycling through the region's own poses until at least
-    96 (and every pose twice) have been drawn -- the library settles the share of splats it bins first, and after 16 clean frames
-    stops launching the second binning round --, then 2 x lanes asynchronous frames so that every pipeline lane is allocated and
-    warm, a sync, the warm-up steps, a sync.  frame(k, flags) draws orbit frame k; returns the number of synchronous frames."""
+    """What bench.py does before its timed region (untimed): ONE pass of synchronous frames over the region's own poses -- the library
+    sets the share of splats it bins first from what the blend measures (one frame is enough; the window keeps the largest need of
+    the poses it has seen) and after four clean frames stops launching the second binning round --, then ASYNC_WARM x lanes queued
+    frames in one batch so that every pipeline lane is allocated and its enqueue thread awake (the threads sleep while frames are
+    drawn synchronously, and a thread's first launches after a sleep take twice as long: 55 us per pair of frames against 27 --
+    GS_DEBUG_WORKER; with 2 x lanes frames the twenty-frame region came out 7 % slower), a sync, the warm-up steps, a sync.  frame(k, flags) draws orbit frame
+    k; returns the number of synchronous frames.  (Until round 4 the share was WALKED down 2 % per frame: 96 frames and every pose
+    twice.  GS_BENCH_PREROLL_FRAMES asks for at least that many again.)"""
     n = 0
-    while n < max(96, 2 * len(frames_used)):
+    at_least = int(os.environ.get("GS_BENCH_PREROLL_FRAMES", "0") or 0)
+    while n < max(at_least, len(frames_used)):
         for k in frames_used:
             frame(k, 0)
             n += 1
-    for j in range(2 * lanes):
+    for j in range(ASYNC_WARM * lanes):
         frame(frames_used[j % len(frames_used)], async_flag)
     sync()
     for i in range(warmup):

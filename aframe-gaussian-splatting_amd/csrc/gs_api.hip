@@ -311,6 +311,16 @@ static void share_from_need(gs_ctx *ctx /* owner */, uint32_t need, uint32_t fra
         target = (float)((double)m * (double)ctx->need_margin / (double)ctx->n);
         if (target > 0.85f) target = 1.0f;                       // (two rounds over nearly everything cost more than one)
     }
+    if (target >= 1.0f && ctx->last_kept) {
+        // One round over everything -- but "everything" is the V splats the sort KEEPS, and a cut-out or a strip may keep a few per cent
+        // of the N resident ones (the cut-out demo: 226 K of 6.3 M).  A share of 100 % sizes the round for N positions: grids, and row
+        // tables of N / 256 chunks per tile row that the row scan reads in full -- project 34 us instead of 24, binning 73 instead of 61.
+        // A share that covers V with a quarter to spare draws the same single round (nothing lies beyond it: no tile is flagged) on
+        // tables of that size; should V grow past it between two collections, the tiles that want more flag their frames like any
+        // other share that was too small.
+        const double cover = ((double)ctx->last_kept * 1.25 + 4096.0) / (double)ctx->n;
+        if (cover < 0.85) target = (float)cover;
+    }
     if (target < ctx->near_floor) target = ctx->near_floor;      // (a walked share's floor, where there is one)
     if (target < 0.001f) target = 0.001f;
     ctx->near_frac = target;
@@ -669,7 +679,7 @@ static void lane_worker_main(gs_ctx *L)
                                                   : render_async_on_lane(T, c.u, c.device_rgba, c.host_rgba, c.stride);
         if (dbg_slow) {
             const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - dbg_t0).count();
-            if (us > 60.0) fprintf(stderr, "[gs] worker %p: %s for lane %p took %.0f us\n", (void *)L, stereo ? "two views" : paired ? "a pair" : c.type == 0 ? "a sort" : c.type == 1 ? "a render" : "a call", (void *)T, us);
+            if (us > (getenv("GS_DEBUG_WORKER_US") ? atof(getenv("GS_DEBUG_WORKER_US")) : 60.0)) fprintf(stderr, "[gs] worker %p: %s for lane %p took %.0f us\n", (void *)L, stereo ? "two views" : paired ? "a pair" : c.type == 0 ? "a sort" : c.type == 1 ? "a render" : "a call", (void *)T, us);
         }
         lk.lock();
         if (rc != GS_OK && w->rc == GS_OK) { w->rc = rc; memcpy(w->err, scratch, sizeof w->err); }
@@ -775,7 +785,12 @@ static hipError_t init_frame_resources(gs_ctx *c, gs_ctx *primary = nullptr)
     memset(c->ctl_host, 0, sizeof(GsControl));
     IFR(hipEventCreateWithFlags(&c->ev_frame, hipEventDisableTiming | hipEventReleaseToDevice));
     IFR(hipEventCreateWithFlags(&c->ev_gate, hipEventDisableTiming | hipEventReleaseToDevice));
-    if (!primary) { k_touch_private<<<1, 64, 0, c->stream>>>(c->part_cnt, 1u); IFR(hipGetLastError()); }   // (the queue's private memory: above)
+    if (!primary) {                                               // (the queue's private memory: above)
+        const char *wq = getenv("GS_WARM_QUEUE");                  // (experiment: how many launches deep the new stream's queue is warmed)
+        const int nw = wq ? atoi(wq) : 1;
+        for (int k = 0; k < nw; k++) k_touch_private<<<1, 64, 0, c->stream>>>(c->part_cnt, 1u);
+        IFR(hipGetLastError());
+    }
 #undef IFR
     return hipSuccess;
 }

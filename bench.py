@@ -447,10 +447,10 @@ def main():
                                             % (3 * frame_batch, " x 2 frames per launch, GS_OPT_FRAME_BATCH: the two frames of a pair share each "
                                                "kernel launch, grid (x, 2), on separate scratch" if frame_batch == 2 else "")),
                        "frames_per_launch": frame_batch,
-                       "preroll_frames": preroll + 2 * max(LANES, depth) + args.warmup,
-                       "preroll_note": "untimed, before the region: %d synchronous frames cycling through the region's own poses (the library settles "
-                                       "the share of splats it bins first, and after 16 clean frames stops launching the second binning round), "
-                                       "%d asynchronous frames to allocate every lane, %d warm-up steps" % (preroll, 2 * max(LANES, depth), args.warmup),
+                       "preroll_frames": preroll + BC.ASYNC_WARM * max(LANES, depth) + args.warmup,
+                       "preroll_note": "untimed, before the region: %d synchronous frames, one pass over the region's own poses (the library sets the share "
+                                       "of splats it bins first from what the blend measures, and after 4 clean frames stops launching the second binning round), "
+                                       "%d queued frames in one batch (every lane allocated, its enqueue thread awake), %d warm-up steps" % (preroll, BC.ASYNC_WARM * max(LANES, depth), args.warmup),
                        "region_ms": round(elapsed * 1e3, 3),
                        "steady_state_fps": round(steady_fps, 1) if steady_fps else None,
                        "fill_drain_share": round(max(0.0, 1.0 - fps / steady_fps), 4) if steady_fps else None,

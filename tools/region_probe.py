@@ -32,6 +32,15 @@ with capi.Context(0) as c:
             c.download(capi.BUF_TILE_STATS, ((W + 15) // 16) * ((H + 15) // 16), np.uint32, 2)
         c.set_option(capi.OPT_RECORD_STAGED, 0); c.set_option(capi.OPT_NEAR_PERMILLE, 0)
     BC.preroll(frame, sync, used, 5, capi.RENDER_ASYNC)
+    def arg(name, d=0):
+        return int(sys.argv[sys.argv.index(name) + 1]) if name in sys.argv else d
+    for j in range(arg("--extra-async")):                      # what a longer pre-roll may have warmed: the queued path ...
+        frame(used[j % len(used)], capi.RENDER_ASYNC)
+    sync()
+    for j in range(arg("--extra-sync")):                       # ... the synchronous one (one pose) ...
+        frame(used[0], 0)
+    if arg("--sleep-ms"):                                      # ... or nothing but time
+        time.sleep(arg("--sleep-ms") / 1e3)
     out = []
     for rep in range(int(sys.argv[sys.argv.index("--reps") + 1]) if "--reps" in sys.argv else 10):
         if "--profile" in sys.argv:
@@ -51,8 +60,16 @@ with capi.Context(0) as c:
             c.stats()
         gc.collect(); gc.disable()
         t0 = time.perf_counter()
-        for i in range(20):
-            frame(5 + i, capi.RENDER_ASYNC)
+        if "--calls" in sys.argv:                               # every call of the enqueuing thread timed on its own
+            ts = [t0]
+            for i in range(20):
+                k = (5 + i) % 120
+                c.sort(cams[k]["view"], None, want_indices=False); ts.append(time.perf_counter())
+                views[k][0].flags = capi.RENDER_ASYNC; c.render_device(views[k][0], None); ts.append(time.perf_counter())
+            print("rep", rep, "calls us:", " ".join("%.0f" % ((b - a) * 1e6) for a, b in zip(ts, ts[1:])))
+        else:
+            for i in range(20):
+                frame(5 + i, capi.RENDER_ASYNC)
         t1 = time.perf_counter(); sync(); t2 = time.perf_counter(); gc.enable()
         out.append("%.0f+%.0f" % ((t1 - t0) * 1e6, (t2 - t1) * 1e6))
     s = c.stats()
