@@ -89,12 +89,16 @@ def options_for(cfg, env=None, pieces_of_rank=1, gathered=False):
         o["OPT_BLEND_SPLIT"] = int(env["GS_BENCH_SPLIT"])
     if env.get("GS_BENCH_BINNING"):
         o["OPT_BINNING"] = int(env["GS_BENCH_BINNING"])           # 1 = pair records + radix passes (rounds 1-3)
+    if env.get("GS_BENCH_SORT_NEAR"):
+        o["OPT_SORT_NEAR"] = int(env["GS_BENCH_SORT_NEAR"])       # 0 = whole sorts only (library default 1: near-only sorts where they pay)
     if env.get("GS_BENCH_DEPTH"):
         o["OPT_PIPELINE_DEPTH"] = int(env["GS_BENCH_DEPTH"])      # frames in flight (library default 3)
     if o.get("OPT_FRAME_BATCH") == 1:
         o.pop("OPT_FRAME_BATCH")
     if not o.get("OPT_BLEND_SPLIT"):
         o.pop("OPT_BLEND_SPLIT", None)
+    if env.get("GS_BENCH_SORT_NEAR") == "0":
+        o["OPT_SORT_NEAR"] = 0
     return o
 
 

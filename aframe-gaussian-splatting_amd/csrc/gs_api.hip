@@ -452,7 +452,7 @@ static int collect_status(gs_ctx *lane, bool *overflowed, bool *share_failed = n
         __atomic_store_n(&ctx->near_stash_off, true, __ATOMIC_RELAXED);   // (the lanes' enqueue threads read these flags while they launch sorts)
         GS_HIP(hipMemsetAsync(&lane->ctl->near_overflow, 0, sizeof(uint32_t), lane->stream));
     }
-    if (c->near_sorted) {
+    if (c->near_sorted == 1u || c->near_sorted == 2u) {          // (3: a tail sort -- no threshold, no hint)
         __atomic_store_n(&ctx->near_spec, true, __ATOMIC_RELAXED);    // a near-only sort has run: the threshold-bin hint exists (gs_near_spec_ok)
         const uint32_t h = __atomic_load_n(&ctx->near_spec_hold, __ATOMIC_RELAXED);
         if (h) __atomic_store_n(&ctx->near_spec_hold, h - 1u, __ATOMIC_RELAXED);
@@ -533,7 +533,10 @@ static uint32_t sort_near_request(const gs_ctx *ctx /* owner */)
     // (short sorts are bound by their launches and dependent round trips, not by their records: measured again in round 5 with the
     // four-launch MSD sort -- at 1 M splats the depth histogram and the threshold search cost the depth and bucket kernels 10 us, the
     // two kernels behind them save 2 with a fifth of the records: 7 170 against 7 590 frames/s one frame at a time, the same pipelined)
-    if (ctx->sort_near_opt == 1 && ctx->n < ((size_t)1 << 22)) return 0;
+    // ... so up to GS_MSD_MAX_N splats a near-only sort is a TAIL sort (gs_sort.hip): the four launches of the whole sort, of which the
+    // last two leave out the segments before the one the frame's first position lies in -- nothing is added in front
+    const bool tail = gs_msd_enabled() && ctx->n <= (size_t)GS_MSD_MAX_N && !ctx->wide_pairs;
+    if (ctx->sort_near_opt == 1 && ctx->n < ((size_t)1 << 22) && !tail) return 0;
     if (ctx->wide_pairs || ctx->n > ((size_t)1 << 25)) return 0;
     if (!round1_skippable(ctx) || ctx->near_frac >= 1.0f) return 0;
     const double nc = ceil((double)ctx->near_frac * (double)ctx->n);

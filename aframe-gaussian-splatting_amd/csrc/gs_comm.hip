@@ -449,7 +449,8 @@ int issue_shared_sort(gs_ctx *L, const ShareJob &j)
     GsComm *c = gs_root(L)->comm;
     const bool mine = c->rank == j.owner;
     int rc = GS_OK;
-    if (mine) rc = gs_run_sort(L, j.view, j.has_cutout ? j.cutout : nullptr, nullptr, j.near_req);
+    // (the peers receive j.cap records: a tail sort keeps a whole segment of the order more than asked for -- any number of records)
+    if (mine) { L->no_tail_sort = true; rc = gs_run_sort(L, j.view, j.has_cutout ? j.cutout : nullptr, nullptr, j.near_req); L->no_tail_sort = false; }
     else gs_remember_sort(L, j.view, j.has_cutout ? j.cutout : nullptr, nullptr, j.near_req);   // (what a fall-back to a whole local sort starts from)
     { std::unique_lock<std::mutex> lk(c->m); c->cv.wait(lk, [&] { return c->next_issue == j.ticket; }); }
     {   // whatever happened to the owner's sort, the exchange is issued: the peers wait for it

@@ -63,7 +63,7 @@ struct GsControl {
     uint32_t n_kept;               // V : survivors of the sort culls  (= reference validCount)
     uint32_t n_sorted;             // records that went through the depth sort: V' = those with a bucket inside the table (compact records: the rest is
                                    // the zero tail), or only the nearest P of them (near-only sort)
-    uint32_t near_sorted;          // 1 / 2 (2: through the depth pass' own candidate stash): `sorted` holds the order's last P valid positions [V' - P, V') only (gs_run_sort with near_req)
+    uint32_t near_sorted;          // 1 / 2 / 3 (2: through the depth pass' own candidate stash; 3: a tail sort, cut at a segment boundary by k_msd_scatter): `sorted` holds the order's last P valid positions [V' - P, V') only (gs_run_sort with near_req)
     uint32_t n_valid;              // V' of the whole order, counted by a near-only sort (position of sorted[0] = n_valid - n_sorted)
     uint32_t order_incomplete;     // sticky: `sorted` does not hold everything it claims -- a near-only sort's chunk stash overflowed, an exchanged
                                    // order was cut short (host clears).  The frames drawn from it are flagged round1_missed too (asynchronous frames:
@@ -191,6 +191,7 @@ struct gs_ctx {
     // one and clears the one the previous sort filled), the request the last sort of this lane ran with (0 = whole order) and its arguments
     uint32_t *dhist[2]; int dh_next; uint32_t *dh_dirty;
     uint32_t sort_near_req;
+    bool no_tail_sort;             // lane: this sort's near-only form must hold AT MOST ~2 x near_req records (the shared sort's exchange buffer): the histogram form, not a tail sort
     float sv_view[4], sv_cutout[16]; bool sv_has_cutout, sv_has_strip; GsSortStrip sv_strip;
     int sort_near_opt;             // owner: GS_OPT_SORT_NEAR
     bool near_stash_off;           // owner: a chunk's stash overflowed once: near-only sorts keep to the two whole-length passes
@@ -377,8 +378,8 @@ int gs_launch_radix_pass2(gs_ctx *const S[2], const void *const in[2], int in_fm
 // GS_RADIX_SKIP per splat), rows = ctx->hist H[chunk][bucket >> 8], group rows = ctx->msd_grp -> ctx->val_a (the index list, zero tail
 // [V', V) included), ctl->n_sorted = V'.  rec = ctx->kv_b used as 4-byte records between the two.
 // near: a near-only sort (no zero tail: k_project supplies the positions behind the records).
-int gs_launch_msd_sort(gs_ctx *ctx, uint32_t n, bool near);
-int gs_launch_msd_sort2(gs_ctx *const S[2], uint32_t n, bool near);
+int gs_launch_msd_sort(gs_ctx *ctx, uint32_t n, uint32_t tail_req);
+int gs_launch_msd_sort2(gs_ctx *const S[2], uint32_t n, const uint32_t tail_req[2]);
 bool gs_msd_enabled();             // (GS_SORT_MSD=0 in the environment: the two LSD passes everywhere)
 // grid used by the radix kernels for hint_n items (a producer that pre-fills the histogram rows uses the same chunking)
 uint32_t gs_radix_grid(uint32_t hint_n);

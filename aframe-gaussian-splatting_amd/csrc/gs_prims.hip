@@ -425,7 +425,7 @@ __device__ __forceinline__ void wave_digit_ranks(const uint32_t *dig, const bool
 template <int NW>
 __device__ __forceinline__ void k_msd_scatter_body(const uint32_t *__restrict__ keys, uint32_t *__restrict__ rec, const uint32_t *n_ptr,
                                                    const uint32_t *__restrict__ rows, const uint32_t *__restrict__ grp, uint32_t *count_out,
-                                                   uint32_t *__restrict__ seg_tab)
+                                                   uint32_t *__restrict__ seg_tab, uint32_t tail_req, GsControl *ctl)
 {
     GS_CHAIN_PRIO();
     constexpr int NT = 64 * NW, IPT = 8, CH = NT * IPT, NB = 256, PB = 24;
@@ -434,6 +434,7 @@ __device__ __forceinline__ void k_msd_scatter_body(const uint32_t *__restrict__ 
     __shared__ uint32_t s_dbase[NB], s_gb[NB];
     __shared__ uint32_t s_k[CH], s_v[CH];
     __shared__ uint32_t s_wave[NW];
+    __shared__ uint32_t s_cut, s_thr;
     const uint32_t n = *n_ptr;
     const uint32_t nchunks = (n + CH - 1) / CH, ngroups = (nchunks + GS_MSD_GROUP - 1u) / GS_MSD_GROUP;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -441,25 +442,41 @@ __device__ __forceinline__ void k_msd_scatter_body(const uint32_t *__restrict__ 
     const bool has_dg = threadIdx.x < (uint32_t)NB;
     if (blockIdx.x >= ((nchunks + 7u) & ~7u) && !(count_out && blockIdx.x == 0)) return;
     for (uint32_t i = threadIdx.x; i < NW * NB; i += NT) (&s_match[0][0])[i] = 0ull;   // (the ranking leaves them zero)
+    if (threadIdx.x == 0) { s_cut = 0u; s_thr = 0u; }
+    uint32_t thr = 0u;
     {   // digit totals = column sums of the group rows -> run starts
         const uint32_t tot_d = has_dg ? msd_column_sum<16>(grp, ngroups, grp, 0u, 0u, dg) : 0u;
         uint32_t tot;
-        const uint32_t ex = block_excl_scan<NW>(tot_d, s_wave, &tot);
+        uint32_t ex = block_excl_scan<NW>(tot_d, s_wave, &tot);
+        // A TAIL sort (tail_req != 0: the frame reads the last tail_req positions of the order at most -- the nearest splats, one binning
+        // round, gs_api.hip: sort_near_request): the order is cut at a SEGMENT boundary, the start of the segment that holds position
+        // V' - tail_req.  The segments before it are neither scattered nor sorted; the records behind the cut are stored from slot 0
+        // (k_project: near_sorted, j_base = n_valid - n_sorted).  The cut costs nothing: every workgroup has the digit totals in its hands
+        // here -- where the near-only sorts of long inputs build a depth histogram and search it for a threshold (10 us at 1 M splats).
+        if (tail_req && tail_req < tot) {
+            const uint32_t suffix = tot - ex;                              // records of this digit and the ones behind it
+            if (has_dg && suffix >= tail_req && suffix - tot_d < tail_req) { s_cut = ex; s_thr = dg; }   // (exactly one digit: its segment is not empty)
+            __syncthreads();
+        }
+        const uint32_t cut = s_cut;
+        thr = s_thr;
+        ex -= ex >= cut ? cut : ex;
         if (has_dg) s_dbase[dg] = ex;
-        if (count_out && blockIdx.x == 0 && threadIdx.x == 0) *count_out = tot;   // the records that take a slot (V', or the survivors of a near-only sort)
+        if (count_out && blockIdx.x == 0 && threadIdx.x == 0) *count_out = tot - cut;   // the records that take a slot (V', or what a tail sort keeps)
+        if (tail_req && blockIdx.x == 0 && threadIdx.x == 0) { ctl->near_sorted = 3u; ctl->n_valid = tot; }   // (3: a tail sort; read as "not 0" on the device)
         if (blockIdx.x == 0) {
             // k_seg_sort's work items (workgroup 0 writes them, every workgroup of that kernel reads its own): one per block of
             // GS_SEG_B records of every non-empty segment -- the blocks of a segment are sorted by different workgroups --, but ONE item
             // for a segment of more than GS_SEG_MAXBLK blocks (taken block after block by one workgroup: each block of a segment counts
             // the whole segment first, which is quadratic in the length).  tab[0] = items, tab[1] = V'; items from tab + 4:
             // (segment start, segment length, block, blocks | 0xFFFFFFFF = all of them in turn)
-            const uint32_t nbk = tot_d ? (tot_d + GS_SEG_B - 1u) / GS_SEG_B : 0u;
+            const uint32_t nbk = (tot_d && dg >= thr) ? (tot_d + GS_SEG_B - 1u) / GS_SEG_B : 0u;
             const uint32_t ni = nbk > GS_SEG_MAXBLK ? 1u : nbk;
             uint32_t nitems;
             const uint32_t ix = block_excl_scan<NW>(has_dg ? ni : 0u, s_wave, &nitems);
             uint4 *items = reinterpret_cast<uint4 *>(seg_tab + 4);
             if (has_dg) for (uint32_t j = 0; j < ni; j++) items[ix + j] = make_uint4(ex, tot_d, j, nbk > GS_SEG_MAXBLK ? 0xFFFFFFFFu : nbk);
-            if (threadIdx.x == 0) { seg_tab[0] = nitems; seg_tab[1] = tot; }
+            if (threadIdx.x == 0) { seg_tab[0] = nitems; seg_tab[1] = tot - cut; }
         }
     }
     for (uint32_t v = blockIdx.x; v < ((nchunks + 7u) & ~7u); v += gridDim.x) {
@@ -488,7 +505,11 @@ __device__ __forceinline__ void k_msd_scatter_body(const uint32_t *__restrict__ 
         {
             uint32_t dig[IPT]; bool ok[IPT];
 #pragma unroll
-            for (int r = 0; r < IPT; r++) { ok[r] = key[r] != GS_RADIX_SKIP; dig[r] = (key[r] >> 8) & 255u; }   // culled / dropped / not-near splats take no slot
+            for (int r = 0; r < IPT; r++) {                              // culled / dropped splats take no slot, nor do those before a tail sort's cut
+                dig[r] = (key[r] >> 8) & 255u;
+                if (dig[r] < thr) key[r] = GS_RADIX_SKIP;
+                ok[r] = key[r] != GS_RADIX_SKIP;
+            }
             wave_digit_ranks<IPT>(dig, ok, &s_match[w][0], &s_cnt[w][0], rank, lane);
         }
         uint32_t pre = 0;
@@ -680,9 +701,9 @@ __device__ __forceinline__ void k_seg_sort_body(const uint32_t *__restrict__ rec
 template <int NW>
 __global__ __launch_bounds__(64 * NW, 4) void k_msd_scatter(const uint32_t *__restrict__ keys, uint32_t *__restrict__ rec, const uint32_t *n_ptr,
                                                          const uint32_t *__restrict__ rows, const uint32_t *__restrict__ grp, uint32_t *count_out,
-                                                         uint32_t *__restrict__ seg_tab)
+                                                         uint32_t *__restrict__ seg_tab, uint32_t tail_req, GsControl *ctl)
 {
-    k_msd_scatter_body<NW>(keys, rec, n_ptr, rows, grp, count_out, seg_tab);
+    k_msd_scatter_body<NW>(keys, rec, n_ptr, rows, grp, count_out, seg_tab, tail_req, ctl);
 }
 template <int NW, int IPT>
 __global__ __launch_bounds__(64 * NW, 4) void k_seg_sort(const uint32_t *__restrict__ rec, uint32_t *__restrict__ out, const uint32_t *__restrict__ seg_tab, const uint32_t *fill_to)
@@ -795,36 +816,37 @@ int gs_launch_radix_pass2(gs_ctx *const S[2], const void *const in[2], int in_fm
                                                 : launch_pass2<4>(S, in, in_fmt, out, out_fmt, n_ptr, hint_n, shift, bits, have_hist, zero_key, idx_bits, count_out, fill_to);
 }
 
-int gs_launch_msd_sort(gs_ctx *ctx, uint32_t n, bool near)
+int gs_launch_msd_sort(gs_ctx *ctx, uint32_t n, uint32_t tail_req)
 {
+    const bool near = tail_req != 0u;
     const uint32_t chunk = gs_radix_chunk(n), g = grid_for(n, chunk);
     hipStream_t st = ctx->stream;
     uint32_t *rec = reinterpret_cast<uint32_t *>(ctx->kv_b);
     if (chunk == GS_CHUNK_L) hipLaunchKernelGGL((k_msd_scatter<8>), dim3(g), dim3(512), 0, st, (const uint32_t *)ctx->key_a, rec, (const uint32_t *)&ctx->ctl->n_total,
-                                                (const uint32_t *)ctx->hist, (const uint32_t *)ctx->msd_grp, &ctx->ctl->n_sorted, ctx->msd_tab);
+                                                (const uint32_t *)ctx->hist, (const uint32_t *)ctx->msd_grp, &ctx->ctl->n_sorted, ctx->msd_tab, tail_req, ctx->ctl);
     else hipLaunchKernelGGL((k_msd_scatter<4>), dim3(g), dim3(256), 0, st, (const uint32_t *)ctx->key_a, rec, (const uint32_t *)&ctx->ctl->n_total,
-                            (const uint32_t *)ctx->hist, (const uint32_t *)ctx->msd_grp, &ctx->ctl->n_sorted, ctx->msd_tab);
+                            (const uint32_t *)ctx->hist, (const uint32_t *)ctx->msd_grp, &ctx->ctl->n_sorted, ctx->msd_tab, tail_req, ctx->ctl);
     hipLaunchKernelGGL((k_seg_sort<GS_SEG_NW, GS_SEG_IPT>), dim3(GS_SEG_GRID), dim3(64 * GS_SEG_NW), 0, st, (const uint32_t *)rec, ctx->val_a, (const uint32_t *)ctx->msd_tab,
                        near ? (const uint32_t *)nullptr : (const uint32_t *)&ctx->ctl->n_kept);
     GS_HIP(hipGetLastError());
     return GS_OK;
 }
 
-int gs_launch_msd_sort2(gs_ctx *const S[2], uint32_t n, bool near)
+int gs_launch_msd_sort2(gs_ctx *const S[2], uint32_t n, const uint32_t tail_req[2])
 {
     gs_ctx *ctx = S[0];
     const uint32_t chunk = gs_radix_chunk(n), g = grid_for(n, chunk);
     hipStream_t st = ctx->stream;
     uint32_t *rec[2] = { reinterpret_cast<uint32_t *>(S[0]->kv_b), reinterpret_cast<uint32_t *>(S[1]->kv_b) };
 #define GS_MSD_SC(NW) gs_twin_w<F_msd_scatter<NW>, 64 * NW, 4>(g, st,                                                                                      \
-        gs_pack_make((const uint32_t *)S[0]->key_a, rec[0], (const uint32_t *)&S[0]->ctl->n_total, (const uint32_t *)S[0]->hist, (const uint32_t *)S[0]->msd_grp, &S[0]->ctl->n_sorted, S[0]->msd_tab), \
-        gs_pack_make((const uint32_t *)S[1]->key_a, rec[1], (const uint32_t *)&S[1]->ctl->n_total, (const uint32_t *)S[1]->hist, (const uint32_t *)S[1]->msd_grp, &S[1]->ctl->n_sorted, S[1]->msd_tab))
+        gs_pack_make((const uint32_t *)S[0]->key_a, rec[0], (const uint32_t *)&S[0]->ctl->n_total, (const uint32_t *)S[0]->hist, (const uint32_t *)S[0]->msd_grp, &S[0]->ctl->n_sorted, S[0]->msd_tab, tail_req[0], S[0]->ctl), \
+        gs_pack_make((const uint32_t *)S[1]->key_a, rec[1], (const uint32_t *)&S[1]->ctl->n_total, (const uint32_t *)S[1]->hist, (const uint32_t *)S[1]->msd_grp, &S[1]->ctl->n_sorted, S[1]->msd_tab, tail_req[1], S[1]->ctl))
     if (chunk == GS_CHUNK_L) GS_MSD_SC(8); else GS_MSD_SC(4);
 #undef GS_MSD_SC
     typedef F_seg_sort<GS_SEG_NW, GS_SEG_IPT> FS;
     gs_twin_w<FS, 64 * GS_SEG_NW, 4>(GS_SEG_GRID, st,
-        gs_pack_make((const uint32_t *)rec[0], S[0]->val_a, (const uint32_t *)S[0]->msd_tab, near ? (const uint32_t *)nullptr : (const uint32_t *)&S[0]->ctl->n_kept),
-        gs_pack_make((const uint32_t *)rec[1], S[1]->val_a, (const uint32_t *)S[1]->msd_tab, near ? (const uint32_t *)nullptr : (const uint32_t *)&S[1]->ctl->n_kept));
+        gs_pack_make((const uint32_t *)rec[0], S[0]->val_a, (const uint32_t *)S[0]->msd_tab, tail_req[0] ? (const uint32_t *)nullptr : (const uint32_t *)&S[0]->ctl->n_kept),
+        gs_pack_make((const uint32_t *)rec[1], S[1]->val_a, (const uint32_t *)S[1]->msd_tab, tail_req[1] ? (const uint32_t *)nullptr : (const uint32_t *)&S[1]->ctl->n_kept));
     GS_HIP(hipGetLastError());
     return GS_OK;
 }

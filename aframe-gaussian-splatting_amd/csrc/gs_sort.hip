@@ -864,10 +864,11 @@ static DepthHist next_depth_hist(gs_ctx *L, bool near)
     return dh;
 }
 
-// The MSD sort (round 5; kernels and rationale in gs_prims.hip): whole sorts with compact records of at most 2^24 splats take four
+// The MSD sort (round 5; kernels and rationale in gs_prims.hip): sorts with compact records of at most GS_MSD_MAX_N splats take four
 // launches -- depth, bucket (+ rows of the high bucket byte per chunk and per group of chunks), k_msd_scatter, k_seg_sort -- instead
-// of seven; so do near-only sorts that do not go through the chunk stashes (the bucket pass drops what lies behind the threshold, the
-// two kernels behind it see the survivors alone).  GS_SORT_MSD=0 in the environment keeps the two LSD passes (A/B runs; longer sorts use them anyway).
+// of seven.  A near-only sort on this path is a TAIL sort: the same four launches, k_msd_scatter drops the segments before the one
+// that holds position V' - near_req (it has the segment totals in its hands anyway) and k_seg_sort sorts the rest -- no depth
+// histogram, no threshold.  GS_SORT_MSD=0 in the environment keeps the two LSD passes (A/B runs; longer sorts use them anyway).
 bool gs_msd_enabled() { static const bool on = []() { const char *e = getenv("GS_SORT_MSD"); return !(e && e[0] == '0'); }(); return on; }
 static bool gs_msd_ok(const gs_ctx *L, uint32_t n, bool compact)
 {
@@ -920,11 +921,15 @@ int gs_run_sort2(gs_ctx *const S[2], const float *const view[2], const float *co
     StripUniforms su[2];
     for (int k = 0; k < 2; k++) fill_sort_uniforms(S[k], view[k], cutout16[k], strip ? strip[k] : nullptr, u[k], su[k]);
     const bool compact = !ctx->wide_pairs && n <= (1u << 25);
-    const bool near = compact && near_req && near_req[0] && near_req[1];   // (a pair takes one path)
-    DepthHist dh[2];
-    for (int k = 0; k < 2; k++) { gs_remember_sort(S[k], view[k], cutout16[k], strip ? strip[k] : nullptr, near ? near_req[k] : 0u); dh[k] = next_depth_hist(S[k], near); }
+    const bool near_both = compact && near_req && near_req[0] && near_req[1];   // (a pair takes one path)
     const bool msd = gs_msd_ok(S[0], n, compact) && gs_msd_ok(S[1], n, compact) &&
-                     !(near && gs_near_stash_ok(S[0], n, near_req[0]) && gs_near_stash_ok(S[1], n, near_req[1]));   // (long near-only sorts keep their stashes)
+                     !(near_both && gs_near_stash_ok(S[0], n, near_req[0]) && gs_near_stash_ok(S[1], n, near_req[1]));   // (long near-only sorts keep their stashes)
+    // a near-only sort on the MSD path is a TAIL sort (k_msd_scatter cuts the order at a segment boundary: no histogram, no threshold
+    // search -- each frame of the pair for itself); `near` below is the histogram form of the longer inputs
+    const uint32_t tail[2] = { msd && compact && near_req ? near_req[0] : 0u, msd && compact && near_req ? near_req[1] : 0u };
+    const bool near = near_both && !msd;
+    DepthHist dh[2];
+    for (int k = 0; k < 2; k++) { gs_remember_sort(S[k], view[k], cutout16[k], strip ? strip[k] : nullptr, near ? near_req[k] : tail[k]); dh[k] = next_depth_hist(S[k], near); }
     if (msd) for (int k = 0; k < 2; k++) gs_msd_arm(S[k], n, dh[k]);
     const bool strips = u[0].has_strip && u[1].has_strip;
     if (!strips) u[0].has_strip = u[1].has_strip = 0;              // (a pair takes one path: both strip sorts, or both plain)
@@ -986,16 +991,15 @@ int gs_run_sort2(gs_ctx *const S[2], const float *const view[2], const float *co
         return GS_OK;
     }
     if (msd) {
-#define GS_BUCKETM(NW, NR) gs_twin<F_sort_bucket<NW, true, NR, true>, 64 * NW>(g, st,                                                                    \
+#define GS_BUCKETM(NW) gs_twin<F_sort_bucket<NW, true, false, true>, 64 * NW>(g, st,                                                                    \
         gs_pack_make((const float *)S[0]->depth, n, S[0]->key_a, (const unsigned long long *)S[0]->part_min, (const unsigned long long *)S[0]->part_max,     \
                      (const uint32_t *)S[0]->part_cnt, gd, S[0]->hist, S[0]->ctl, (const uint32_t *)dh[0].fill, S[0]->sort_near_req, bin_hint, S[0]->msd_grp), \
         gs_pack_make((const float *)S[1]->depth, n, S[1]->key_a, (const unsigned long long *)S[1]->part_min, (const unsigned long long *)S[1]->part_max,     \
                      (const uint32_t *)S[1]->part_cnt, gd, S[1]->hist, S[1]->ctl, (const uint32_t *)dh[1].fill, S[1]->sort_near_req, bin_hint, S[1]->msd_grp))
-        if (gs_radix_chunk(n) == GS_CHUNK_L) { if (near) GS_BUCKETM(8, true); else GS_BUCKETM(8, false); }
-        else { if (near) GS_BUCKETM(4, true); else GS_BUCKETM(4, false); }
+        if (gs_radix_chunk(n) == GS_CHUNK_L) GS_BUCKETM(8); else GS_BUCKETM(4);
 #undef GS_BUCKETM
         GS_HIP(hipGetLastError());
-        const int rcm = gs_launch_msd_sort2(S, n, near);
+        const int rcm = gs_launch_msd_sort2(S, n, tail);
         if (rcm != GS_OK) return rcm;
         GS_PROF_RECORD(ctx, 1);
         for (int k = 0; k < 2; k++) { S[k]->sorted = S[k]->val_a; S[k]->have_sort = true; }
@@ -1083,10 +1087,11 @@ int gs_run_sort(gs_ctx *ctx, const float view[4], const float *cutout16, const G
     fill_sort_uniforms(ctx, view, cutout16, strip, u, su);
     // record format of the two passes: 4 bytes while the index fits in 25 bits (GS_OPT_WIDE_PAIRS forces the general form)
     const bool compact = !ctx->wide_pairs && n <= (1u << 25);
-    const bool near = compact && near_req;
-    gs_remember_sort(ctx, view, cutout16, strip, near ? near_req : 0u);
+    const bool msd = gs_msd_ok(ctx, n, compact) && !(compact && near_req && (gs_near_stash_ok(ctx, n, near_req) || ctx->no_tail_sort));   // (long near-only sorts keep their stashes)
+    const uint32_t tail = msd && compact ? near_req : 0u;          // (a near-only sort on the MSD path: k_msd_scatter cuts the order at a segment boundary)
+    const bool near = compact && near_req && !msd;               // (... on the longer inputs: depth histogram + threshold)
+    gs_remember_sort(ctx, view, cutout16, strip, near ? near_req : tail);
     DepthHist dh = next_depth_hist(ctx, near);
-    const bool msd = gs_msd_ok(ctx, n, compact) && !(near && gs_near_stash_ok(ctx, n, near_req));   // (long near-only sorts keep their stashes)
     if (msd) gs_msd_arm(ctx, n, dh);
 
     const uint32_t g = gs_radix_grid(n);                         // same chunking as the radix kernels (pre-filled histogram rows)
@@ -1130,14 +1135,13 @@ int gs_run_sort(gs_ctx *ctx, const float view[4], const float *cutout16, const G
     }
     if (msd) {
         // four launches: depth (above), bucket + rows of the high bucket byte, one stable scatter by that byte, one LDS sort per segment
-#define GS_LAUNCH_BUCKETM(NW, NR) hipLaunchKernelGGL((k_sort_bucket<NW, true, NR, true>), dim3(g), dim3(64 * NW), 0, ctx->stream, (const float *)ctx->depth, n, ctx->key_a,     \
+#define GS_LAUNCH_BUCKETM(NW) hipLaunchKernelGGL((k_sort_bucket<NW, true, false, true>), dim3(g), dim3(64 * NW), 0, ctx->stream, (const float *)ctx->depth, n, ctx->key_a,     \
                                                      (const unsigned long long *)ctx->part_min, (const unsigned long long *)ctx->part_max, (const uint32_t *)ctx->part_cnt, gd, \
                                                      ctx->hist, ctx->ctl, (const uint32_t *)dh.fill, ctx->sort_near_req, bin_hint, ctx->msd_grp)
-        if (gs_radix_chunk(n) == GS_CHUNK_L) { if (near) GS_LAUNCH_BUCKETM(8, true); else GS_LAUNCH_BUCKETM(8, false); }
-        else { if (near) GS_LAUNCH_BUCKETM(4, true); else GS_LAUNCH_BUCKETM(4, false); }
+        if (gs_radix_chunk(n) == GS_CHUNK_L) GS_LAUNCH_BUCKETM(8); else GS_LAUNCH_BUCKETM(4);
 #undef GS_LAUNCH_BUCKETM
         GS_HIP(hipGetLastError());
-        const int rcm = gs_launch_msd_sort(ctx, n, near);
+        const int rcm = gs_launch_msd_sort(ctx, n, tail);
         if (rcm != GS_OK) return rcm;
         GS_PROF_RECORD(ctx, 1);
         ctx->sorted = ctx->val_a;
