@@ -304,10 +304,13 @@ static void share_from_need(gs_ctx *ctx /* owner */, uint32_t need, uint32_t fra
     float target = 1.0f;                                         // 0xFFFFFFFF: a tile that no share saturates (sky): one round over everything
     if (m != 0xFFFFFFFFu) {
         // the margin on top follows what the camera does: 1.15 to begin with, a hundredth less with every collection that nothing missed
+        // -- with every eight frames of a collection of queued frames: a caller that collects every 24 frames was at 1.10 after a whole
+        // lap of 120 new poses without a miss, i.e. had binned 6 % more than it came to need for all of it --
         // (down to 1.04: a still or periodic camera needs none, and 10 % of share are 10 % of the binning and the blend's staging), a tenth
         // more after a miss
         if (ctx->need_margin < 1.04f) ctx->need_margin = (float)GS_NEED_MARGIN;
-        ctx->need_margin = ctx->need_margin - 0.01f < 1.04f ? 1.04f : ctx->need_margin - 0.01f;
+        const float less = 0.01f * (float)(frames > 8u ? frames / 8u : 1u);
+        ctx->need_margin = ctx->need_margin - less < 1.04f ? 1.04f : ctx->need_margin - less;
         target = (float)((double)m * (double)ctx->need_margin / (double)ctx->n);
         if (target > 0.85f) target = 1.0f;                       // (two rounds over nearly everything cost more than one)
     }
@@ -788,12 +791,8 @@ static hipError_t init_frame_resources(gs_ctx *c, gs_ctx *primary = nullptr)
     memset(c->ctl_host, 0, sizeof(GsControl));
     IFR(hipEventCreateWithFlags(&c->ev_frame, hipEventDisableTiming | hipEventReleaseToDevice));
     IFR(hipEventCreateWithFlags(&c->ev_gate, hipEventDisableTiming | hipEventReleaseToDevice));
-    if (!primary) {                                               // (the queue's private memory: above)
-        const char *wq = getenv("GS_WARM_QUEUE");                  // (experiment: how many launches deep the new stream's queue is warmed)
-        const int nw = wq ? atoi(wq) : 1;
-        for (int k = 0; k < nw; k++) k_touch_private<<<1, 64, 0, c->stream>>>(c->part_cnt, 1u);
-        IFR(hipGetLastError());
-    }
+    // (the queue's private memory: above.  One launch: 32 .. 512 of them -- a deeper warm-up of the new queue -- changed nothing)
+    if (!primary) { k_touch_private<<<1, 64, 0, c->stream>>>(c->part_cnt, 1u); IFR(hipGetLastError()); }
 #undef IFR
     return hipSuccess;
 }
@@ -1178,7 +1177,10 @@ static int sort_common(gs_ctx *ctx, const float view[4], const float *cutout16, 
     ctx->cur = lane; ctx->rot = rot; ctx->cur_async = false;
     log_sort(L, view, cutout16, strip);
     const uint32_t near_req = (out_idx || out_n) ? 0u : sort_near_request(ctx);     // (the caller wants the order itself: all of it)
-    if (ctx->enqueue_threads && gs_rotates(ctx) && !ctx->user_stream && !out_idx && !out_n) {
+    // (a context that has not measured its share yet draws its next frame synchronously -- gs_render_uniforms --: its sort on the caller's
+    // thread then, not on an enqueue thread that was created a moment ago and has to be woken first: 0.14 ms of that call's 0.7)
+    const bool cold = !ctx->share_measured && ctx->near_fixed_permille <= 0;   // (get_lane has drained the lane: nothing of it is waiting on its thread)
+    if (ctx->enqueue_threads && gs_rotates(ctx) && !ctx->user_stream && !out_idx && !out_n && !cold) {
         // nothing to hand back: the lane's worker thread does the launching (a failure surfaces at gs_sync())
         GsLaneCmd c;
         c.type = 0; memcpy(c.view, view, sizeof c.view);
@@ -1316,6 +1318,8 @@ static int render_async_on_lane(gs_ctx *ctx, const GsFrameUniforms &u, void *dev
     return prof_advance(ctx);
 }
 
+static bool gs_debug_cold() { static const bool on = getenv("GS_DEBUG_COLD") != nullptr; return on; }   // (diagnostic: what a synchronous frame's call spends where)
+
 // synchronous frame on lane `ctx` (the owner supplies options and the adaptive share through fill_uniforms)
 static int render_sync_on_lane(gs_ctx *ctx, const GsFrameUniforms &u, void *device_rgba, uint8_t *host_rgba, size_t stride)
 {
@@ -1427,7 +1431,10 @@ int gs_render_uniforms(gs_ctx *ctx, const GsFrameUniforms &u_in, void *device_rg
     if (async && !ctx->share_measured && ctx->near_fixed_permille <= 0 && u.near_count != 0xFFFFFFFFu && ctx->n) {
         async = false; u.flags &= ~(uint32_t)GS_RENDER_ASYNC;
         // ... and the lanes that exist get their per-frame buffers for this frame's size now (tile ranges, per-pixel state, row tables:
-        // a dozen allocations each), while nothing is in flight, instead of one lane per frame over the next five
+        // a dozen allocations each), while nothing is in flight, instead of one lane per frame over the next five.  (BEFORE the frame's
+        // kernels go out, not under them: allocations made while the device works take longer than the wait they would hide -- the
+        // call 0.93 ms instead of 0.66, tools/cold_probe.py)
+        const auto dbg_t0 = std::chrono::steady_clock::now();
         for (int i = 0; i < GS_MAX_LANES; i++) {
             gs_ctx *Li = ctx->lanes[i];
             if (!Li || Li == L || Li->scratch_cap < ctx->cap) continue;
@@ -1435,6 +1442,7 @@ int gs_render_uniforms(gs_ctx *ctx, const GsFrameUniforms &u_in, void *device_rg
             (void)ensure_frame_buffers(Li, u, device_rgba == nullptr);
             if (const size_t e = (u.tiles_x <= 256 && u.tiles_y <= 256 && !ctx->bin_mode) ? gs_row_tables_entries(ctx->n, (uint32_t)u.tiles_y) : 0) (void)gs_row_tables_ensure(Li, e);
         }
+        if (gs_debug_cold()) fprintf(stderr, "[gs] cold frame: the other lanes' buffers took %.0f us\n", std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - dbg_t0).count());
     }
     if (async) {
         if (host_rgba && stride && stride < (size_t)(u.x1 - u.x0) * 4) FAIL(GS_E_BADARG, "stride %zu smaller than a row (%zu bytes)", stride, (size_t)(u.x1 - u.x0) * 4);
@@ -1449,8 +1457,13 @@ int gs_render_uniforms(gs_ctx *ctx, const GsFrameUniforms &u_in, void *device_rg
         TRY(lane_rc(ctx, L, lane_drain(L)));
         return lane_rc(ctx, L, render_async_on_lane(L, u, device_rgba, host_rgba, stride));
     }
+    const auto dbg_t1 = std::chrono::steady_clock::now();
     TRY(lane_rc(ctx, L, lane_drain(L)));                         // whatever its worker still had to enqueue comes first
-    return lane_rc(ctx, L, render_sync_on_lane(L, u, device_rgba, host_rgba, stride));
+    const auto dbg_t2 = std::chrono::steady_clock::now();
+    const int rcs = lane_rc(ctx, L, render_sync_on_lane(L, u, device_rgba, host_rgba, stride));
+    if (gs_debug_cold()) fprintf(stderr, "[gs] synchronous frame: drain %.0f us, draw %.0f us\n", std::chrono::duration<double, std::micro>(dbg_t2 - dbg_t1).count(),
+                                         std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - dbg_t2).count());
+    return rcs;
 }
 
 GS_API int gs_render(gs_ctx *ctx, const gs_render_params *p, uint8_t *rgba_out, size_t stride)

@@ -299,14 +299,17 @@ GS_API int gs_multi_sync(gs_multi *m);
                                    queued (needs GS_OPT_ENQUEUE_THREADS); gathered frames of one piece per rank pair as well
                                    (their gathers follow the shared kernels in frame order); frames that differ in size,
                                    flags or path go out alone.                                                              */
-#define GS_OPT_SORT_NEAR 11     /* near-only depth sorts.  A frame whose second binning round is skipped (the adaptive share has
-                                   been clean for 16 frames) reads only the nearest share of the order; its gs_sort then drops,
-                                   before the radix passes, every splat that cannot be among those -- an exact threshold on the
-                                   sort key from a histogram of the depths, so the positions the frame reads hold exactly what the
-                                   whole order holds there.  A render that needs more of the order after all (another share, a
-                                   counting render, round 1, gs_download of the order) sorts again in full by itself.  Sorts that
-                                   return the order (out_idx / out_n) are always complete.  0: off; 1 (default): for scenes of
-                                   4 M splats and more (below, the sort's passes are launch-bound); 2: always.               */
+#define GS_OPT_SORT_NEAR 11     /* near-only depth sorts.  A frame whose second binning round is skipped (the share has been clean
+                                   for a few frames) reads only the nearest share of the order; its gs_sort then leaves out the
+                                   splats that cannot be among those, so that the positions the frame reads hold exactly what the
+                                   whole order holds there.  Up to 2 M splats (the four-launch sort): a TAIL sort -- the order is cut
+                                   at the boundary of the 256 depth segments the sort works in anyway, the segments before the cut
+                                   are neither scattered nor sorted.  Longer inputs: an exact threshold on the sort key from a
+                                   histogram of the depths, applied before the radix passes.  A render that needs more of the
+                                   order after all (another share, a counting render, round 1, gs_download of the order) sorts
+                                   again in full by itself.  Sorts that return the order (out_idx / out_n) are always complete.
+                                   0: off; 1 (default): tail sorts up to 2 M splats, the histogram form from 4 M (between the two
+                                   its extra work costs what it saves); 2: always.                                               */
 #define GS_OPT_SORT_SHARE 15    /* several ranks (gs_sort_gathered), value = permille P of the splats, 0 = off (default).  The depth sort is the
                                    part of a frame that does not shrink with a rank's strip: every rank keys and sorts all N splats of every
                                    frame (at 20 M splats 230 of a strip frame's 290 us).  With P > 0 the ranks take turns: frame f is
@@ -376,7 +379,8 @@ typedef struct gs_stats {
                              array written: a threshold hint from the previous frames decides what is stashed) ...              */
     uint32_t spec_misses; /* ... and those of them whose candidates could not be vouched for (drawn again from a whole sort)    */
     uint32_t need_splats; /* how many of the NEAREST splats the last collected frames' tiles read before they were saturated (max over
-                             the tiles; 0xFFFFFFFF: a tile no share saturates): what near_permille is set from, x 1.3             */
+                             the tiles; 0xFFFFFFFF: a tile no share saturates): what near_permille is set from, with a margin of
+                             15 % that shrinks to 4 % while no frame misses                                                        */
 } gs_stats;
 
 #define GS_OPT_PROFILE 1        /* 1: bracket every stage with HIP events on the frame's stream (7 per frame); 2: only

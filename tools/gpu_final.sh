@@ -13,30 +13,32 @@ cp gpurun_out/pixel_parity.jsonl gpurun_out/js_visible_fps.txt gpurun_out/ply_lo
 grep -E "^stress_|stress ok" $O/pytest.log > $O/stress_and_tsan.txt
 fi
 # counters first: the bench lines report them only from the sources they were taken from
-CONFIGS="${CONFIGS:-c2 c1 c3 c5}" tools/gpu_pmc.sh $TAG > $O/pmc.log 2>&1; tail -3 $O/pmc.log | cut -c1-160
+CONFIGS="${CONFIGS:-c2 c1 c3 c5 outside}" tools/gpu_pmc.sh $TAG > $O/pmc.log 2>&1; tail -3 $O/pmc.log | cut -c1-160
 cp gpurun_out/pmc_$TAG.md $O/pmc_counters.md; cp gpurun_out/pmc_$TAG.json $O/pmc_counters.json; cp gpurun_out/pmc_$TAG.json profiles/pmc_counters.json
-timeout 900 python bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"; cut -c 1-200 $O/bench.json
-for i in 1 2 3; do timeout 600 python bench.py --steps 20 --warmup 5 $([ $i != 1 ] && echo --no-cpu-baseline --no-extras) > $O/bench_steps20_$i.json 2>/dev/null; done
+# the driver's form first, exactly as the driver runs it (all configurations, all extras, the CPU baseline), then twice without the extras
+for i in 1 2 3; do timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 $([ $i != 1 ] && echo --no-cpu-baseline --no-extras --no-configs) > $O/bench_steps20_$i.json 2>$O/bench_steps20_$i.err; done
+timeout 900 python bench.py --no-configs > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"; cut -c 1-200 $O/bench.json
 if [ "$PART" != "profiles" ]; then
-timeout 600 python bench.py --size 1280x720 --no-cpu-baseline --no-extras > $O/config_c1.json 2>/dev/null
-timeout 900 python bench.py --splats 6291456 --cutout --no-cpu-baseline --no-extras > $O/config_c3.json 2>/dev/null
-timeout 600 python bench.py --xr --no-cpu-baseline > $O/config_c4.json 2>/dev/null
-timeout 1200 python bench.py --splats 20971520 --size 3840x2160 --steps 120 --no-cpu-baseline > $O/config_c5.json 2>/dev/null
-GS_BENCH_COMM=1 timeout 600 python bench.py --no-cpu-baseline --no-extras > $O/bench_comm_world1.json 2>/dev/null
-GS_BENCH_BINNING=1 timeout 600 python bench.py --no-cpu-baseline --no-extras > $O/bench_pair_records.json 2>/dev/null
-GS_BENCH_BINNING=1 timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras > $O/bench_pair_records_steps20.json 2>/dev/null
+timeout 600 python bench.py --config C1 --no-cpu-baseline --no-extras > $O/config_c1.json 2>/dev/null
+timeout 900 python bench.py --config C3 --no-cpu-baseline --no-extras > $O/config_c3.json 2>/dev/null
+timeout 600 python bench.py --config C4 --no-cpu-baseline > $O/config_c4.json 2>/dev/null
+timeout 1200 python bench.py --config C5 --steps 120 --no-cpu-baseline > $O/config_c5.json 2>/dev/null
+GS_BENCH_COMM=1 timeout 600 python bench.py --no-cpu-baseline --no-extras --no-configs > $O/bench_comm_world1.json 2>/dev/null
+GS_BENCH_BINNING=1 timeout 600 python bench.py --no-cpu-baseline --no-extras --no-configs > $O/bench_pair_records.json 2>/dev/null
+GS_BENCH_SORT_NEAR=0 timeout 600 python bench.py --no-cpu-baseline --no-extras --no-configs > $O/bench_whole_sorts.json 2>/dev/null
+GS_BENCH_SORT_NEAR=0 timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras --no-configs > $O/bench_whole_sorts_steps20.json 2>/dev/null
 for n in 1 2 8; do
   timeout 300 python bench.py --gpus $n --single-process > $O/single_process_device_$n.json 2>/dev/null
   timeout 300 python bench.py --gpus $n --single-process --host-direct > $O/single_process_host_$n.json 2>/dev/null
 done
 fi
-for f in bench bench_steps20_1 bench_steps20_2 bench_steps20_3 config_c1 config_c3 config_c4 config_c5 bench_comm_world1 bench_pair_records bench_pair_records_steps20; do python -c "
+for f in bench bench_steps20_1 bench_steps20_2 bench_steps20_3 config_c1 config_c3 config_c4 config_c5 bench_comm_world1 bench_pair_records bench_whole_sorts bench_whole_sorts_steps20; do python -c "
 import json,sys
 try:
     d=json.load(open('$O/$f.json')); print('$f', d['value'], d.get('latency',{}).get('fps_depth1'), (d.get('roofline') or {}).get('traffic'), (d.get('frame_hbm') or {}).get('traffic'))
 except Exception as e: print('$f FAILED', e)"; done
 cd /tmp && export TMPDIR=/tmp
-timeout 900 rocprofv3 --kernel-trace --stats -d $O/prof -o bench -- python $R/bench.py --steps 120 --warmup 5 --no-cpu-baseline --no-extras > $O/bench_prof.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats -d $O/prof -o bench -- python $R/bench.py --steps 120 --warmup 5 --no-cpu-baseline --no-extras --no-configs > $O/bench_prof.log 2>&1
 cd $R
 python tools/prof_summary.py $O/prof/bench_results.db > $O/kernel_stats.md 2>&1
 python tools/prof_tail.py $O/prof/bench_results.db 1440 > $O/timed_frames_c2.txt 2>&1

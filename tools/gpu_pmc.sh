@@ -1,17 +1,18 @@
 #!/bin/bash
-# usage (GPU box, repo root): [CONFIGS="c2 c1 c3 c5"] tools/gpu_pmc.sh <tag>  -- separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE and, for
+# usage (GPU box, repo root): [CONFIGS="c2 c1 c3 c5 outside"] tools/gpu_pmc.sh <tag>  -- separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE and, for
 # c2, the VALU group) over the pipelined frame loop of each BASELINE configuration (tools/stage_bench.py --pmc-run: adaptive share, 3 lanes
-# x 2 frames per launch) -> gpurun_out/pmc_<tag>.md / .json (copied to profiles/ as r04_pmc_counters.md / pmc_counters.json)
+# x 2 frames per launch; `outside`: the 1 M scene seen from outside the cloud, bench.py's outside_cloud) -> gpurun_out/pmc_<tag>.md / .json (copied to profiles/ as r05_pmc_counters.md / pmc_counters.json)
 TAG=${1:-pmc}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 D=$R/gpurun_out/pmc_$TAG; mkdir -p $D
 cd /tmp && export TMPDIR=/tmp
 VALU="SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_LDS"
-for cfg in ${CONFIGS:-c2 c1 c3 c5}; do
+for cfg in ${CONFIGS:-c2 c1 c3 c5 outside}; do
   case $cfg in
     c2) A="--frames 240"; G="FETCH_SIZE WRITE_SIZE VALU";;
     c1) A="--size 1280x720 --frames 240"; G="FETCH_SIZE WRITE_SIZE";;
-    c3) A="--splats 6291456 --cutout --split 1 --frames 120"; G="FETCH_SIZE WRITE_SIZE";;
+    c3) A="--splats 6291456 --seed 0x5EED0003 --cutout --split 1 --frames 120"; G="FETCH_SIZE WRITE_SIZE";;
+    outside) A="--outside --frames 240"; G="FETCH_SIZE WRITE_SIZE VALU";;
     c5) A="--splats 20971520 --size 3840x2160 --frames 96"; G="FETCH_SIZE WRITE_SIZE VALU";;
   esac
   for g in $G; do

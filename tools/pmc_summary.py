@@ -2,7 +2,7 @@
 """Summarise the rocprofv3 --pmc passes of tools/gpu_pmc.sh (separate runs per counter group, as MI355X_MICROARCH.md prescribes).
 
 usage: tools/pmc_summary.py <dir> <out.md> <out.json>
-  <dir>/<config>_<GROUP>/pmc_results.db + <dir>/<config>_<GROUP>.log for config in c1 c2 c3 c5 (whatever is there) and GROUP in
+  <dir>/<config>_<GROUP>/pmc_results.db + <dir>/<config>_<GROUP>.log for config in c1 c2 c3 c5 outside (whatever is there) and GROUP in
   FETCH_SIZE, WRITE_SIZE, VALU (= SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_LDS)
 
 FETCH_SIZE / WRITE_SIZE are in KiB per dispatch.  On gfx950 FETCH_SIZE reports exactly half of the bytes of a wide (16 B/lane)
@@ -54,7 +54,7 @@ def main():
     d, out_md, out_json = sys.argv[1:4]
     res = {"configs": {}}
     md = []
-    for cfg in ("c2", "c1", "c3", "c5"):
+    for cfg in ("c2", "c1", "c3", "c5", "outside"):
         f = load(os.path.join(d, cfg + "_FETCH_SIZE", "pmc_results.db")); w = load(os.path.join(d, cfg + "_WRITE_SIZE", "pmc_results.db"))
         v = load(os.path.join(d, cfg + "_VALU", "pmc_results.db"))
         if not f and not w and not v:

@@ -14,6 +14,7 @@ ap.add_argument("--splats", type=int, default=synth.N_TRAIN)
 ap.add_argument("--size", default="1920x1080")
 ap.add_argument("--cutout", action="store_true")
 ap.add_argument("--frames", type=int, default=240)
+ap.add_argument("--seed", default=None, help="seed of the synthetic scene (bench_configs: C3 = 0x5EED0003; default: the generator's own)")
 ap.add_argument("--depths", default="1,3")
 ap.add_argument("--near", type=int, default=180, help="pinned share (permille) of the splats binned in the first round; 0 = adaptive")
 ap.add_argument("--sort-only", action="store_true")
@@ -32,7 +33,7 @@ ap.add_argument("--pmc-run", action="store_true", help="the run rocprofv3 --pmc 
                                                         "synchronously afterwards, the list entries the blend evaluates per frame (GS_OPT_RECORD_STAGED = 2)")
 a = ap.parse_args()
 W, H = (int(v) for v in a.size.lower().split("x"))
-rows = synth.make_splat_rows_fast(a.splats) if a.splats >= (8 << 20) else synth.make_splat_rows(a.splats)
+rows = synth.make_splat_rows_fast(a.splats) if a.splats >= (8 << 20) else (synth.make_splat_rows(a.splats, seed=int(a.seed, 0)) if a.seed else synth.make_splat_rows(a.splats))
 if a.opacity_div > 1:
     rows = rows.reshape(-1, 32).copy(); rows[:, 27] = rows[:, 27] // a.opacity_div; rows = rows.reshape(-1)
 pose = synth.cutout_demo_camera if a.cutout else (synth.outside_cloud_camera if a.outside else synth.index_html_camera)
