@@ -108,8 +108,9 @@ if a.pmc_run:
 for depth in (int(v) for v in a.depths.split(",")):
     ctx.set_option(capi.OPT_PIPELINE_DEPTH, depth)
     ctx.set_option(capi.OPT_PROFILE, 0)
-    for _ in range(6 if a.near == 0 else 2):                 # (adaptive share: a failure holds the second round on for 32 collected frames,
-        go(24)                                               # then 16 clean ones: the loop below should run in the settled state)
+    for _ in range(3 if a.near == 0 else 2):                 # (adaptive share: the loop below should run in the settled state -- the share is what
+        go(120 if a.near == 0 else 24)                       # the poses SEEN needed: whole laps, or the first new pose of the timed loop misses and
+                                                             # gs_sync draws every frame queued since the last sync again, one by one)
     t = go(a.frames) or go(a.frames)
     ctx.set_option(capi.OPT_PROFILE, 1)
     go(24); go(min(a.frames, 120))
