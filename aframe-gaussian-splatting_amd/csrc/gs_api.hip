@@ -277,6 +277,9 @@ static void gs_spec_back_off(gs_ctx *ctx /* owner */, bool unsuited)
     __atomic_store_n(&ctx->near_spec_hold, ctx->near_spec_backoff, __ATOMIC_RELAXED);
 }
 
+#ifndef GS_NEED_MARGIN_MIN
+#define GS_NEED_MARGIN_MIN 1.04f    // what the margin on the measured share shrinks to while no frame misses (it starts at GS_NEED_MARGIN)
+#endif
 #ifndef GS_NEED_MARGIN
 #define GS_NEED_MARGIN 1.15         // the share binned first = what the collected frames' tiles needed x this (the walked share ended 1.17-1.3 x above the share that had failed)
 #endif
@@ -308,9 +311,9 @@ static void share_from_need(gs_ctx *ctx /* owner */, uint32_t need, uint32_t fra
         // lap of 120 new poses without a miss, i.e. had binned 6 % more than it came to need for all of it --
         // (down to 1.04: a still or periodic camera needs none, and 10 % of share are 10 % of the binning and the blend's staging), a tenth
         // more after a miss
-        if (ctx->need_margin < 1.04f) ctx->need_margin = (float)GS_NEED_MARGIN;
+        if (ctx->need_margin < GS_NEED_MARGIN_MIN) ctx->need_margin = (float)GS_NEED_MARGIN;
         const float less = 0.01f * (float)(frames > 8u ? frames / 8u : 1u);
-        ctx->need_margin = ctx->need_margin - less < 1.04f ? 1.04f : ctx->need_margin - less;
+        ctx->need_margin = ctx->need_margin - less < GS_NEED_MARGIN_MIN ? GS_NEED_MARGIN_MIN : ctx->need_margin - less;
         target = (float)((double)m * (double)ctx->need_margin / (double)ctx->n);
         if (target > 0.85f) target = 1.0f;                       // (two rounds over nearly everything cost more than one)
     }
@@ -337,7 +340,7 @@ static void share_missed(gs_ctx *ctx /* owner */, float frac_used)
 {
     float nf = frac_used * 1.3f; if (nf > 1.0f) nf = 1.0f;
     if (nf > ctx->near_frac) ctx->near_frac = nf;
-    if (ctx->need_margin < 1.04f) ctx->need_margin = (float)GS_NEED_MARGIN;
+    if (ctx->need_margin < GS_NEED_MARGIN_MIN) ctx->need_margin = (float)GS_NEED_MARGIN;
     ctx->need_margin = ctx->need_margin + 0.1f > 1.3f ? 1.3f : ctx->need_margin + 0.1f;
     const uint32_t as_need = (uint32_t)((double)nf * (double)ctx->n / (double)ctx->need_margin);   // (the window remembers it like a measurement)
     if (as_need > ctx->need_hist[ctx->need_hist_pos]) ctx->need_hist[ctx->need_hist_pos] = as_need;
@@ -1179,7 +1182,9 @@ static int sort_common(gs_ctx *ctx, const float view[4], const float *cutout16, 
     const uint32_t near_req = (out_idx || out_n) ? 0u : sort_near_request(ctx);     // (the caller wants the order itself: all of it)
     // (a context that has not measured its share yet draws its next frame synchronously -- gs_render_uniforms --: its sort on the caller's
     // thread then, not on an enqueue thread that was created a moment ago and has to be woken first: 0.14 ms of that call's 0.7)
-    const bool cold = !ctx->share_measured && ctx->near_fixed_permille <= 0;   // (get_lane has drained the lane: nothing of it is waiting on its thread)
+    // (... at most two sorts in a row: a context whose frames never measure -- counting renders, compact pair records -- keeps its threads)
+    const bool cold = !ctx->share_measured && ctx->near_fixed_permille <= 0 && ctx->cold_sorts < 2u;   // (get_lane has drained the lane: nothing of it is waiting on its thread)
+    if (cold) ctx->cold_sorts++; else if (ctx->share_measured) ctx->cold_sorts = 0;
     if (ctx->enqueue_threads && gs_rotates(ctx) && !ctx->user_stream && !out_idx && !out_n && !cold) {
         // nothing to hand back: the lane's worker thread does the launching (a failure surfaces at gs_sync())
         GsLaneCmd c;
@@ -1421,7 +1426,10 @@ int gs_render_uniforms(gs_ctx *ctx, const GsFrameUniforms &u_in, void *device_rg
         if (st < row) FAIL(GS_E_BADARG, "stride %zu smaller than a row (%zu bytes)", st, row);
     }
     gs_ctx *L = ctx->lanes[ctx->cur];                           // the frame's lane: where its gs_sort ran
-    if (!u.status) u.status = &L->ctl->frame_status;             // the completion word of this frame (a gathered piece brings its own)
+    // the completion word of this frame: the next word of the lane's ring (a gathered piece brings its own: the piece's trailer)
+    if (!L->async_pending) L->status_base = L->status_seq;       // (nothing of the lane waits for a collection: the frames to come count from here)
+    if (!u.status) { u.status = &L->ctl->status_ring[L->status_seq % GS_STATUS_RING]; L->status_seq++; }
+    L->status_cur = u.status;
     u.need_seed = L->need_seed_pending; L->need_seed_pending = 0;  // (a seed for the lane's need words travels with its next frame)
     bool async = (u.flags & GS_RENDER_ASYNC) && !(u.flags & GS_RENDER_COUNT_FRAGS);
     // A context that has not MEASURED its share yet (fresh, cleared, the share un-pinned) draws its first two-round frame synchronously
@@ -1548,8 +1556,18 @@ static int redraw_flagged_frames_impl(gs_ctx *ctx, const bool bad_unit[GS_MAX_PR
         gs_ctx *L = ctx->lanes[i];
         if (!L || !L->log || !bad_unit[i % GS_MAX_PRIMARY]) continue;
         const std::vector<GsFrameRec> recs = L->log->recs;          // (render_sync_on_lane does not log, but keep the walk independent of it)
+        // which of them: the frames whose completion word (read back with the control block) is not 0 -- as long as the lane's ring still
+        // holds the word of every render since the last collection; else, or for a render whose word is not in the ring, all of them
+        const bool words_valid = L->status_seq - L->status_base <= GS_STATUS_RING;
         for (const GsFrameRec &r : recs) {
             if (!r.nrender) continue;
+            bool complete = words_valid;
+            for (int k = 0; k < r.nrender && complete; k++) {
+                const uint32_t *w = r.r[k].u.status;
+                if (!w || w < L->ctl->status_ring || w >= L->ctl->status_ring + GS_STATUS_RING) complete = false;
+                else if (L->ctl_host->status_ring[w - L->ctl->status_ring] != 0u) complete = false;
+            }
+            if (complete) continue;
             TRY(lane_rc(ctx, L, gs_run_sort(L, r.view, r.has_cutout ? r.cutout : nullptr, r.has_strip ? &r.strip : nullptr, 0)));
             for (int k = 0; k < r.nrender; k++) {
                 GsFrameUniforms u = r.r[k].u;
@@ -1687,7 +1705,9 @@ GS_API int gs_frame_status_device(gs_ctx *ctx, void **device_word)
     if (!device_word) FAIL(GS_E_BADARG, "gs_frame_status_device: device_word is NULL");
     gs_ctx *L = ctx->lanes[ctx->cur];
     TRY(lane_rc(ctx, L, lane_drain(L)));                         // (the frame's kernels are in the stream: the word is theirs from here on)
-    *device_word = (void *)&L->ctl->frame_status;
+    // (the word the frame's last render was given; on the root of a gathered frame: where k_assemble ORs the pieces' words)
+    *device_word = (L->status_cur && L->status_cur >= L->ctl->status_ring && L->status_cur < L->ctl->status_ring + GS_STATUS_RING) ? (void *)L->status_cur
+                                                                                                                          : (void *)&L->ctl->frame_status;
     return GS_OK;
 }
 
@@ -1710,7 +1730,12 @@ GS_API int gs_set_option(gs_ctx *ctx, int option, int64_t value)
     case GS_OPT_NEAR_PERMILLE:
         if (value < 0 || value > 1000) FAIL(GS_E_BADARG, "near permille must be 0 (adaptive) .. 1000 (single round)");
         ctx->near_fixed_permille = (int)value;
-        if (value == 0) { ctx->near_frac = 0.25f; ctx->share_measured = false; ctx->need_margin = 0.0f; memset(ctx->need_hist, 0, sizeof ctx->need_hist); }
+        if (value == 0) {
+            // adapt from scratch: the default share, nothing measured -- on the device too (each lane's next frame clears its need words:
+            // a word that still says "a tile no share saturates" from frames long gone would keep the share at 100 % for 64 collections)
+            ctx->near_frac = 0.25f; ctx->share_measured = false; ctx->need_margin = 0.0f; ctx->cold_sorts = 0; memset(ctx->need_hist, 0, sizeof ctx->need_hist);
+            for (int i = 0; i < GS_MAX_LANES; i++) if (ctx->lanes[i]) { ctx->lanes[i]->need_seed_pending = 1u; ctx->lanes[i]->need_word_est = 0; }
+        }
         return GS_OK;
     case GS_OPT_RECORD_STAGED: ctx->record_staged = value == 2 ? 2u : (value != 0 ? 1u : 0u); return GS_OK;
     case GS_OPT_TERMINATION:

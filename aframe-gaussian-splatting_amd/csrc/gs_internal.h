@@ -23,6 +23,7 @@
 #endif
 #define GS_RADIX_MAX_BINS 512      // up to 9-bit digits (depth key = 17 bits = 8 + 9)
 #define GS_TOUCH_PRIVATE_WORDS 16u   /* private dwords per lane a new lane's stream is made to allocate (gs_api.hip: k_touch_private) */
+#define GS_STATUS_RING 64u             /* completion words per lane (GsControl::status_ring) */
 #define GS_NEED_WORDS 32u          // GsControl::need_near
 #define GS_MSD_GROUP 32u           // the MSD depth sort (gs_sort.hip): radix chunks per group row
 #define GS_MSD_MAX_N (1u << 21)    // ... takes sorts of at most this many splats.  Its records (low bucket byte << 24 | index) would hold 2^24, but a chunk's
@@ -104,6 +105,11 @@ struct GsControl {
     // reads its word when it starts and issues the atomic only if its need is larger: a dozen atomics per frame instead of 8160 --
     // 8160 atomics on ONE LINE serialise at ~11 ns each whatever the word: the blend went from 43 to 64 us)
     alignas(128) uint32_t need_near[32];
+    // The completion words of the lane's last GS_STATUS_RING renders (GsFrameUniforms::status points at one of them unless the frame is a
+    // gathered piece): render k of the lane since its last collection owns word k % GS_STATUS_RING.  gs_sync() reads them with the rest of
+    // the block and draws again exactly the logged frames whose word is not 0 -- while a lane has queued no more renders than the ring
+    // holds; beyond that every logged frame of a flagged lane is drawn again, as before round 5.
+    alignas(128) uint32_t status_ring[GS_STATUS_RING];
 };
 
 struct GsFrameUniforms {           // per-render constants, passed by value to kernels
@@ -192,6 +198,9 @@ struct gs_ctx {
     uint32_t *dhist[2]; int dh_next; uint32_t *dh_dirty;
     uint32_t sort_near_req;
     bool no_tail_sort;             // lane: this sort's near-only form must hold AT MOST ~2 x near_req records (the shared sort's exchange buffer): the histogram form, not a tail sort
+    uint32_t status_seq, status_base; // lane: renders handed to the lane so far (which word of the ring the next one gets) / its value when the first frame of the collection under way was queued
+    uint32_t *status_cur;          // lane: the word of the render handed over last (gs_frame_status_device)
+    uint32_t cold_sorts;           // owner: sorts run on the caller's thread because the share had not been measured yet (at most two in a row)
     float sv_view[4], sv_cutout[16]; bool sv_has_cutout, sv_has_strip; GsSortStrip sv_strip;
     int sort_near_opt;             // owner: GS_OPT_SORT_NEAR
     bool near_stash_off;           // owner: a chunk's stash overflowed once: near-only sorts keep to the two whole-length passes

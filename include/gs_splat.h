@@ -191,7 +191,8 @@ GS_API void *gs_frame_stream(gs_ctx *ctx);
  *   gs_frame_status_device(): *device_word = the device address of ONE uint32 of the current frame's lane, written by the frame's own
  *   kernels: 0 = complete; non-zero = the frame will be drawn again at gs_sync() (bit 0: a tile was not saturated, bit 1: the pair
  *   buffers overflowed, bit 2: the sorted order was incomplete).  Valid once the frame's kernels have run (in stream order behind
- *   the frame) until the lane's NEXT frame begins (GS_OPT_PIPELINE_DEPTH x GS_OPT_FRAME_BATCH frames later); for a gathered frame,
+ *   the frame) until the lane has been handed 64 more renders (every lane keeps a ring of 64 words: gs_sync() itself reads them and
+ *   draws again exactly the frames whose word is not 0); for a gathered frame,
  *   on the root: the OR of the words of all its pieces (each piece travels with its own word, the root's gs_sync() reports the
  *   frame even if only a peer's piece was incomplete).  Several renders of one frame on one context (gs_render_stereo): the word
  *   describes the last of them. */

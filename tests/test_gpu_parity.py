@@ -1825,6 +1825,32 @@ def test_completion_word_of_asynchronous_frames(scene_small):
         assert c.frame_status() == 0
         c.sort(outside["view"]); want = c.render(_params(outside))
         assert np.array_equal(buf.cpu().numpy().reshape(h, w, 4), want)
+        # ... EXACTLY the frames that missed: a batch of queued frames (alone and in pairs), one of them from outside -- every lane keeps
+        # the words of its last 64 renders, gs_sync() reads them and leaves the complete frames of a flagged lane alone
+        wants = []
+        for cam in inside:
+            c.sort(cam["view"]); wants.append(c.render(_params(cam)))
+        for batch in (1, 2):
+            c.set_option(capi.OPT_FRAME_BATCH, batch)
+            c.set_option(capi.OPT_NEAR_PERMILLE, 0)                        # (forget what the frames from outside needed: measure again inside)
+            for rep in range(8):                                           # (... round 1 goes off again)
+                for cam in inside:
+                    c.sort(cam["view"], want_indices=False); c.render_device(_params(cam), None)
+            st = c.stats()
+            assert st["near_permille"] < 900, st
+            bufs = [torch.zeros(w * h * 4, dtype=torch.uint8, device="cuda") for _ in range(13)]
+            seq = inside[:7] + [outside] + inside[7:]
+            for cam, b in zip(seq, bufs):
+                c.sort(cam["view"], want_indices=False); c.render_device(_params(cam, flags=capi.RENDER_ASYNC), b.data_ptr())
+            c.sync()
+            torch.cuda.synchronize()
+            drawn_again = c.stats()["retried_frames"] - st["retried_frames"]
+            assert 1 <= drawn_again <= 2, (batch, drawn_again)             # (the frame from outside; its partner of a pair only if that missed too)
+            got = [b.cpu().numpy().reshape(h, w, 4) for b in bufs]
+            assert np.array_equal(got[7], want)
+            for g, wv in zip(got[:7] + got[8:], wants):
+                assert np.array_equal(g, wv)
+        c.set_option(capi.OPT_FRAME_BATCH, 1)
     # a gathered frame (world 1, both XR eyes on this context): each piece carries its word, the root ORs them into its lane's
     e0, e1, head = synth.xr_eye_cameras(20.0, 0.25, capi=capi)
     W, H = e0["vw"], e0["vh"]
