@@ -1,0 +1,97 @@
+"""CPU tier: the table of configurations `bench.py` measures and `tests/test_as_benched.py` checks (aframe-gaussian-splatting_amd/
+bench_configs.py) against BASELINE.json's five configurations -- sizes, viewports, pose families -- and its own helpers (the flags of
+bench.py resolve to the table's entries; the option sets; the pre-roll's frame counts).  No GPU, no library calls: host logic only."""
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import pkg
+
+BC = pkg("bench_configs")
+synth = pkg("synth")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_the_table_is_baseline_json():
+    base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
+    texts = base["configs"]
+    assert len(texts) == 5 and sorted(BC.CONFIGS) == ["C1", "C2", "C3", "C4", "C5"]
+    want = {"C1": (1 << 20, (1280, 720)), "C2": (1 << 20, (1920, 1080)), "C3": (6 * (1 << 20), (1920, 1080)), "C5": (20 * (1 << 20), (3840, 2160))}
+    for (name, (n, size)), text in zip(sorted(want.items()), [texts[0], texts[1], texts[2], texts[4]]):
+        c = BC.CONFIGS[name]
+        assert c["splats"] == n and tuple(c["size"]) == size and not c["xr"]
+        m = re.search(r"(\d{3,4})\D(\d{3,4})", text.replace("×", "x"))       # the viewport BASELINE.json names for it
+        assert m and (int(m.group(1)), int(m.group(2))) == size, (name, text)
+        millions = re.search(r"~?(\d+)M", text)                                  # (configs[1] names the scene of configs[0]: "train.splat")
+        assert (millions and abs(int(millions.group(1)) * 1e6 - n) / n < 0.06) or (name == "C2" and "train.splat" in text), (name, text)
+    assert BC.CONFIGS["C3"]["pose"] == "cutout" and "cutoutEntity" in texts[2]
+    c4 = BC.CONFIGS["C4"]
+    assert c4["xr"] and c4["size"] is None and "xrPixelRatio=0.5" in texts[3] and "2064" in texts[3]
+    w, h = synth.xr_eye_cameras(0.0, 0.5)[0]["vw"], synth.xr_eye_cameras(0.0, 0.5)[0]["vh"]
+    assert (w, h) == (1032, 1104)                                                # 2064 x 2208 at xrPixelRatio 0.5
+    # the scene recipes: SURVEY.md 8(d) seeds; C1 / C2 / C4 share the scene the GL goldens were drawn from, C3 has its own
+    assert BC.CONFIGS["C1"]["rows"] == BC.CONFIGS["C2"]["rows"] == BC.CONFIGS["C4"]["rows"] == ("make_splat_rows", {})
+    assert BC.CONFIGS["C3"]["rows"] == ("make_splat_rows", {"seed": 0x5EED0003}) and BC.CONFIGS["C5"]["rows"][0] == "make_splat_rows_fast"
+
+
+def test_flags_resolve_to_the_table_and_options_are_what_is_documented():
+    assert BC.name_of(None, None, False, False) == "C2"
+    assert BC.name_of(1 << 20, [1280, 720], False, False) == "C1"
+    assert BC.name_of(6291456, None, True, False) == "C3"
+    assert BC.name_of(None, None, False, True) == "C4"
+    assert BC.name_of(20971520, [3840, 2160], False, False) == "C5"
+    assert BC.name_of(12345, None, False, False) is None and BC.name_of(6291456, None, False, False) is None
+    for name, c in BC.CONFIGS.items():
+        o = BC.options_for(c, env={}, pieces_of_rank=2 if c["xr"] else 1, gathered=c["xr"])
+        assert o.get("OPT_FRAME_BATCH") == 2, name                               # two frames per launch everywhere
+        assert (o.get("OPT_BLEND_SPLIT", 0) == 1) == (name == "C3"), name        # k_blend_px for the cut-out scene only
+        assert set(o) <= {"OPT_FRAME_BATCH", "OPT_BLEND_SPLIT"}, (name, o)       # nothing else is switched for a number that is quoted
+    # the experiment overrides are overrides: visible in the result, absent by default
+    c2 = BC.CONFIGS["C2"]
+    assert BC.options_for(c2, env={"GS_BENCH_SORT_NEAR": "0"})["OPT_SORT_NEAR"] == 0
+    assert "OPT_FRAME_BATCH" not in BC.options_for(c2, env={"GS_BENCH_BATCH": "1"})
+    assert BC.options_for(c2, env={"GS_BENCH_DEPTH": "2"})["OPT_PIPELINE_DEPTH"] == 2
+    assert BC.options_for(BC.CONFIGS["C3"], env={"GS_BENCH_SPLIT": "0"}).get("OPT_BLEND_SPLIT") is None
+    # a rank that draws three pieces of a gathered frame cannot pair
+    assert "OPT_FRAME_BATCH" not in BC.options_for(c2, env={}, pieces_of_rank=3, gathered=True)
+    cu = BC.custom(3 << 20, (800, 600), True, False)
+    assert cu["options"] == {"OPT_FRAME_BATCH": 2, "OPT_BLEND_SPLIT": 1} and cu["pose"] == "cutout" and cu["size"] == (800, 600)
+
+
+def test_region_and_preroll_are_what_bench_py_reports():
+    seq, used = BC.region_frames(5, 20)
+    assert seq == list(range(5, 25)) and used == seq
+    seq, used = BC.region_frames(24, 480)
+    assert len(seq) == 480 and used == list(range(120)) and seq[0] == 24 and seq[96] == 0
+    calls = []
+    n = BC.preroll(lambda k, flags=0: calls.append((k, flags)), lambda: calls.append("sync"), list(range(5, 25)), 5, 99)
+    assert n == 20                                                              # ONE pass of synchronous frames over the region's poses
+    sync_frames = [c for c in calls[:20]]
+    assert sync_frames == [(k, 0) for k in range(5, 25)]
+    rest = calls[20:]
+    assert rest[:BC.ASYNC_WARM * BC.LANES] == [((5 + j % 20), 99) for j in range(BC.ASYNC_WARM * BC.LANES)]   # one queued batch ...
+    assert rest[BC.ASYNC_WARM * BC.LANES] == "sync"
+    assert rest[BC.ASYNC_WARM * BC.LANES + 1:] == [(i, 99) for i in range(5)] + ["sync"]                       # ... the warm-up steps, a sync
+    os.environ["GS_BENCH_PREROLL_FRAMES"] = "96"
+    try:
+        calls.clear()
+        assert BC.preroll(lambda k, flags=0: calls.append(k), lambda: None, list(range(5, 25)), 0, 99) == 100   # whole passes until at least 96
+    finally:
+        del os.environ["GS_BENCH_PREROLL_FRAMES"]
+
+
+def test_pushes_are_progressive_and_rows_come_from_the_named_generator():
+    class Ctx:
+        def __init__(self): self.sizes = []
+        def push_splat(self, r): self.sizes.append(r.shape[0])
+    c = Ctx()
+    BC.push_rows(c, np.zeros((BC.PUSH_ROWS * 2 + 7) * 32, np.uint8))
+    assert c.sizes == [BC.PUSH_ROWS, BC.PUSH_ROWS, 7]                            # index.js:279-298: a scene arrives in chunks
+    seen = []
+    rows = BC.make_rows({"rows": ("make_splat_rows", {"seed": 7}), "splats": 64}, synth, cache=lambda fn, n, **kw: seen.append((fn, n, kw)) or "cached")
+    assert rows == "cached" and seen == [("make_splat_rows", 64, {"seed": 7})]
+    small = BC.make_rows({"rows": ("make_splat_rows", {"seed": 0x5EED0003}), "splats": 256}, synth)
+    assert np.asarray(small).size == 256 * 32 and np.array_equal(np.asarray(small), np.asarray(synth.make_splat_rows(256, seed=0x5EED0003)))
