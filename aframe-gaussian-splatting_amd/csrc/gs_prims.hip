@@ -425,7 +425,7 @@ __device__ __forceinline__ void wave_digit_ranks(const uint32_t *dig, const bool
 template <int NW>
 __device__ __forceinline__ void k_msd_scatter_body(const uint32_t *__restrict__ keys, uint32_t *__restrict__ rec, const uint32_t *n_ptr,
                                                    const uint32_t *__restrict__ rows, const uint32_t *__restrict__ grp, uint32_t *count_out,
-                                                   uint32_t *__restrict__ seg_tab, uint32_t tail_req, GsControl *ctl)
+                                                   uint32_t *__restrict__ seg_tab, uint32_t tail_req, GsControl *ctl, uint32_t n_host)
 {
     GS_CHAIN_PRIO();
     constexpr int NT = 64 * NW, IPT = 8, CH = NT * IPT, NB = 256, PB = 24;
@@ -435,12 +435,40 @@ __device__ __forceinline__ void k_msd_scatter_body(const uint32_t *__restrict__ 
     __shared__ uint32_t s_k[CH], s_v[CH];
     __shared__ uint32_t s_wave[NW];
     __shared__ uint32_t s_cut, s_thr;
-    const uint32_t n = *n_ptr;
+    // (the depth sort's record count is the host's N: one dependent load less in front of everything -- what this kernel waits for is
+    // round trips, and every one of them is ~2 us alone and more with two other kernels in flight)
+    const uint32_t n = n_host ? n_host : *n_ptr;
     const uint32_t nchunks = (n + CH - 1) / CH, ngroups = (nchunks + GS_MSD_GROUP - 1u) / GS_MSD_GROUP;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const uint32_t dg = threadIdx.x < (uint32_t)NB ? threadIdx.x : 0u;   // this thread's digit (threads beyond 256 compute digit 0's sums and drop them)
     const bool has_dg = threadIdx.x < (uint32_t)NB;
-    if (blockIdx.x >= ((nchunks + 7u) & ~7u) && !(count_out && blockIdx.x == 0)) return;
+    const uint32_t vend = (nchunks + 7u) & ~7u;
+    if (blockIdx.x >= vend && !(count_out && blockIdx.x == 0)) return;
+    // The loads of this workgroup's (first) chunk -- its keys, and the rows that give the chunk's offset inside every segment -- depend on
+    // nothing the kernel computes: they go out HERE, together with the group rows of the segment totals below, so that the kernel waits
+    // for ONE round trip where it waited for three (the record count, the totals, then keys + rows): 50.9 -> 42.7 us per pair of frames
+    // in the pipelined loop (tools/gpu_r5aa.sh; alone 10.0 -> 9.9: there the trips are short).  Unconditional, indices clamped: all in
+    // flight at once.
+    uint32_t key[IPT], pt[PB];
+    uint32_t c = 0;
+    auto load_chunk = [&](uint32_t cc) {
+#pragma unroll
+        for (int r = 0; r < IPT; r++) {
+            const uint32_t i = cc * CH + w * (CH / NW) + r * 64 + lane;
+            key[r] = keys[i < n ? i : n - 1u];                          // (n >= 1 here: there is a chunk; what lies behind n is masked below)
+        }
+        // This chunk's offset inside every digit's run = the rows of the groups before its own + the rows of the chunks of its group
+        // before it: <= 15 + 31 rows at 1 M splats (an L2 miss each: the rows were written by another XCD)
+        const uint32_t g0 = cc / GS_MSD_GROUP, nrow = g0 + (cc - g0 * GS_MSD_GROUP);
+#pragma unroll
+        for (int k = 0; k < PB; k++) {
+            const uint32_t vv = (uint32_t)k < nrow ? (uint32_t)k : 0u;
+            const uint32_t *row = (nrow == 0u || vv < g0) ? grp + (size_t)vv * 256u : rows + (size_t)(g0 * GS_MSD_GROUP + (vv - g0)) * 256u;
+            pt[k] = row[dg];
+        }
+    };
+    bool preloaded = blockIdx.x < vend && gs_xcd_chunk(blockIdx.x, nchunks, c);
+    if (preloaded) load_chunk(c);
     for (uint32_t i = threadIdx.x; i < NW * NB; i += NT) (&s_match[0][0])[i] = 0ull;   // (the ranking leaves them zero)
     if (threadIdx.x == 0) { s_cut = 0u; s_thr = 0u; }
     uint32_t thr = 0u;
@@ -479,33 +507,18 @@ __device__ __forceinline__ void k_msd_scatter_body(const uint32_t *__restrict__ 
             if (threadIdx.x == 0) { seg_tab[0] = nitems; seg_tab[1] = tot - cut; }
         }
     }
-    for (uint32_t v = blockIdx.x; v < ((nchunks + 7u) & ~7u); v += gridDim.x) {
-        uint32_t c;
-        if (!gs_xcd_chunk(v, nchunks, c)) continue;
+    for (uint32_t v = blockIdx.x; v < vend; v += gridDim.x) {
+        if (!preloaded) { if (!gs_xcd_chunk(v, nchunks, c)) continue; load_chunk(c); }   // (a grid smaller than the chunks: the later ones as they come)
+        preloaded = false;
         for (uint32_t i = threadIdx.x; i < NW * NB; i += NT) (&s_cnt[0][0])[i] = 0;
         __syncthreads();
-        uint32_t key[IPT], val[IPT], rank[IPT];
-#pragma unroll
-        for (int r = 0; r < IPT; r++) {                               // all loads first: their latencies overlap
-            const uint32_t i = c * CH + w * (CH / NW) + r * 64 + lane;
-            key[r] = i < n ? keys[i] : GS_RADIX_SKIP;
-            val[r] = i;
-        }
-        // This chunk's offset inside every digit's run = the rows of the groups before its own + the rows of the chunks of its group
-        // before it: <= 15 + 31 rows at 1 M splats.  The loads go out HERE, unconditional (row index clamped), and are summed behind
-        // the ranking: their round trip (an L2 miss each: the rows were written by another XCD) runs under it.
+        uint32_t rank[IPT];
         const uint32_t g0 = c / GS_MSD_GROUP, nrow = g0 + (c - g0 * GS_MSD_GROUP);
-        uint32_t pt[PB];
-#pragma unroll
-        for (int k = 0; k < PB; k++) {
-            const uint32_t vv = (uint32_t)k < nrow ? (uint32_t)k : 0u;
-            const uint32_t *row = (nrow == 0u || vv < g0) ? grp + (size_t)vv * 256u : rows + (size_t)(g0 * GS_MSD_GROUP + (vv - g0)) * 256u;
-            pt[k] = row[dg];
-        }
         {
             uint32_t dig[IPT]; bool ok[IPT];
 #pragma unroll
             for (int r = 0; r < IPT; r++) {                              // culled / dropped splats take no slot, nor do those before a tail sort's cut
+                if (c * CH + w * (CH / NW) + r * 64 + lane >= n) key[r] = GS_RADIX_SKIP;
                 dig[r] = (key[r] >> 8) & 255u;
                 if (dig[r] < thr) key[r] = GS_RADIX_SKIP;
                 ok[r] = key[r] != GS_RADIX_SKIP;
@@ -550,7 +563,7 @@ __device__ __forceinline__ void k_msd_scatter_body(const uint32_t *__restrict__ 
             if (key[r] != GS_RADIX_SKIP) {
                 const uint32_t d = (key[r] >> 8) & 255u;
                 s_k[s_cnt[w][d] + rank[r]] = key[r];
-                s_v[s_cnt[w][d] + rank[r]] = val[r];
+                s_v[s_cnt[w][d] + rank[r]] = c * CH + w * (CH / NW) + r * 64 + lane;
             }
         }
         __syncthreads();
@@ -701,9 +714,9 @@ __device__ __forceinline__ void k_seg_sort_body(const uint32_t *__restrict__ rec
 template <int NW>
 __global__ __launch_bounds__(64 * NW, 4) void k_msd_scatter(const uint32_t *__restrict__ keys, uint32_t *__restrict__ rec, const uint32_t *n_ptr,
                                                          const uint32_t *__restrict__ rows, const uint32_t *__restrict__ grp, uint32_t *count_out,
-                                                         uint32_t *__restrict__ seg_tab, uint32_t tail_req, GsControl *ctl)
+                                                         uint32_t *__restrict__ seg_tab, uint32_t tail_req, GsControl *ctl, uint32_t n_host)
 {
-    k_msd_scatter_body<NW>(keys, rec, n_ptr, rows, grp, count_out, seg_tab, tail_req, ctl);
+    k_msd_scatter_body<NW>(keys, rec, n_ptr, rows, grp, count_out, seg_tab, tail_req, ctl, n_host);
 }
 template <int NW, int IPT>
 __global__ __launch_bounds__(64 * NW, 4) void k_seg_sort(const uint32_t *__restrict__ rec, uint32_t *__restrict__ out, const uint32_t *__restrict__ seg_tab, const uint32_t *fill_to)
@@ -823,9 +836,9 @@ int gs_launch_msd_sort(gs_ctx *ctx, uint32_t n, uint32_t tail_req)
     hipStream_t st = ctx->stream;
     uint32_t *rec = reinterpret_cast<uint32_t *>(ctx->kv_b);
     if (chunk == GS_CHUNK_L) hipLaunchKernelGGL((k_msd_scatter<8>), dim3(g), dim3(512), 0, st, (const uint32_t *)ctx->key_a, rec, (const uint32_t *)&ctx->ctl->n_total,
-                                                (const uint32_t *)ctx->hist, (const uint32_t *)ctx->msd_grp, &ctx->ctl->n_sorted, ctx->msd_tab, tail_req, ctx->ctl);
+                                                (const uint32_t *)ctx->hist, (const uint32_t *)ctx->msd_grp, &ctx->ctl->n_sorted, ctx->msd_tab, tail_req, ctx->ctl, n);
     else hipLaunchKernelGGL((k_msd_scatter<4>), dim3(g), dim3(256), 0, st, (const uint32_t *)ctx->key_a, rec, (const uint32_t *)&ctx->ctl->n_total,
-                            (const uint32_t *)ctx->hist, (const uint32_t *)ctx->msd_grp, &ctx->ctl->n_sorted, ctx->msd_tab, tail_req, ctx->ctl);
+                            (const uint32_t *)ctx->hist, (const uint32_t *)ctx->msd_grp, &ctx->ctl->n_sorted, ctx->msd_tab, tail_req, ctx->ctl, n);
     hipLaunchKernelGGL((k_seg_sort<GS_SEG_NW, GS_SEG_IPT>), dim3(GS_SEG_GRID), dim3(64 * GS_SEG_NW), 0, st, (const uint32_t *)rec, ctx->val_a, (const uint32_t *)ctx->msd_tab,
                        near ? (const uint32_t *)nullptr : (const uint32_t *)&ctx->ctl->n_kept);
     GS_HIP(hipGetLastError());
@@ -839,8 +852,8 @@ int gs_launch_msd_sort2(gs_ctx *const S[2], uint32_t n, const uint32_t tail_req[
     hipStream_t st = ctx->stream;
     uint32_t *rec[2] = { reinterpret_cast<uint32_t *>(S[0]->kv_b), reinterpret_cast<uint32_t *>(S[1]->kv_b) };
 #define GS_MSD_SC(NW) gs_twin_w<F_msd_scatter<NW>, 64 * NW, 4>(g, st,                                                                                      \
-        gs_pack_make((const uint32_t *)S[0]->key_a, rec[0], (const uint32_t *)&S[0]->ctl->n_total, (const uint32_t *)S[0]->hist, (const uint32_t *)S[0]->msd_grp, &S[0]->ctl->n_sorted, S[0]->msd_tab, tail_req[0], S[0]->ctl), \
-        gs_pack_make((const uint32_t *)S[1]->key_a, rec[1], (const uint32_t *)&S[1]->ctl->n_total, (const uint32_t *)S[1]->hist, (const uint32_t *)S[1]->msd_grp, &S[1]->ctl->n_sorted, S[1]->msd_tab, tail_req[1], S[1]->ctl))
+        gs_pack_make((const uint32_t *)S[0]->key_a, rec[0], (const uint32_t *)&S[0]->ctl->n_total, (const uint32_t *)S[0]->hist, (const uint32_t *)S[0]->msd_grp, &S[0]->ctl->n_sorted, S[0]->msd_tab, tail_req[0], S[0]->ctl, n), \
+        gs_pack_make((const uint32_t *)S[1]->key_a, rec[1], (const uint32_t *)&S[1]->ctl->n_total, (const uint32_t *)S[1]->hist, (const uint32_t *)S[1]->msd_grp, &S[1]->ctl->n_sorted, S[1]->msd_tab, tail_req[1], S[1]->ctl, n))
     if (chunk == GS_CHUNK_L) GS_MSD_SC(8); else GS_MSD_SC(4);
 #undef GS_MSD_SC
     typedef F_seg_sort<GS_SEG_NW, GS_SEG_IPT> FS;

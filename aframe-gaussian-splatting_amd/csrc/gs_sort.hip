@@ -363,6 +363,21 @@ __device__ __forceinline__ void k_sort_bucket_body(const float *__restrict__ dep
     __shared__ uint32_t s_nvalid;
     __shared__ int32_t s_bcut;
     if (threadIdx.x == 0) { s_min = ~0ull; s_max = 0ull; s_cnt = 0; s_nvalid = 0; s_bcut = 0; }
+    // The depths of this workgroup's (first) chunk depend on nothing the kernel computes: they go out HERE, with the partials' loads below,
+    // not behind the fold of min / max and its two barriers -- one dependent round trip where there were two (round 5: what the short
+    // kernels of the sort wait for in the pipelined loop is round trips).  Unconditional, index clamped; what lies behind n is masked.
+    const uint32_t nchunks = (n + CH - 1) / CH, vend = (nchunks + 7u) & ~7u;
+    float dd[IPT];
+    uint32_t c = 0;
+    auto load_chunk = [&](uint32_t cc) {
+#pragma unroll
+        for (int r = 0; r < IPT; r++) {
+            const uint32_t i = cc * CH + r * NT + threadIdx.x;
+            dd[r] = depth[i < n ? i : n - 1u];                           // (n >= 1: there is a chunk)
+        }
+    };
+    bool preloaded = blockIdx.x < vend && gs_xcd_chunk(blockIdx.x, nchunks, c);
+    if (preloaded) load_chunk(c);
     __syncthreads();
     {
         unsigned long long mn = ~0ull, mx = 0ull; uint32_t cnt = 0;
@@ -420,18 +435,11 @@ __device__ __forceinline__ void k_sort_bucket_body(const float *__restrict__ dep
     }
     const int32_t bcut = s_bcut;
     uint32_t nvalid = 0;
-    const uint32_t nchunks = (n + CH - 1) / CH;
-    for (uint32_t v = blockIdx.x; v < ((nchunks + 7u) & ~7u); v += gridDim.x) {
-        uint32_t c;
-        if (!gs_xcd_chunk(v, nchunks, c)) continue;                // XCD-aware chunk order (as the radix kernels)
+    for (uint32_t v = blockIdx.x; v < vend; v += gridDim.x) {
+        if (!preloaded) { if (!gs_xcd_chunk(v, nchunks, c)) continue; load_chunk(c); }   // XCD-aware chunk order (as the radix kernels); all loads first
+        preloaded = false;
         for (uint32_t d = threadIdx.x; d < BINS; d += NT) s_hist[d] = 0;
         __syncthreads();
-        float dd[IPT];                                               // all loads first: their latencies overlap
-#pragma unroll
-        for (int r = 0; r < IPT; r++) {
-            const uint32_t i = c * CH + r * NT + threadIdx.x;
-            dd[r] = i < n ? depth[i] : INFINITY;
-        }
 #pragma unroll
         for (int r = 0; r < IPT; r++) {
             const uint32_t i = c * CH + r * NT + threadIdx.x;
