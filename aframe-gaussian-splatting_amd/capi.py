@@ -23,6 +23,7 @@ OPT_COMM_TRANSPORT = 12
 OPT_AUTO_RETRY = 13
 OPT_SORT_SHARE = 15
 OPT_BINNING = 16
+OPT_SUBTILE = 17
 TRANSPORT_RCCL, TRANSPORT_INPROC = 0, 1
 COMM_ID_BYTES = 128
 BUF_CENTER_SCALE, BUF_COV_COLOR, BUF_SORT_ROWS, BUF_SORTED, BUF_PROJECTED, BUF_TILE_COUNT, BUF_TILE_STATS, BUF_UNSAT_MASK = 0, 1, 2, 3, 4, 5, 6, 7

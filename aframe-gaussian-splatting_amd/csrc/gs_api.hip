@@ -375,6 +375,7 @@ static int collect_status(gs_ctx *lane, bool *overflowed, bool *share_failed = n
     lane->stats.acc_frames = c->acc_frames; lane->stats.acc_sorted = c->acc_sorted; lane->stats.acc_visible = c->acc_visible;
     lane->stats.acc_pairs = c->acc_pairs; lane->stats.sort_records = c->n_sorted;
     ctx->last_kept = c->n_kept;
+    if (c->n_pairs_frame) { ctx->last_pairs = c->n_pairs_frame; ctx->last_visible = c->n_visible; }
     {   // visible splats a round may expect (compact pair records: gs_compact_bits): the last collected frame's + an eighth + 4096
         // (a bit decides between 4- and 8-byte records: 437 K visible splats of the unsaturated scene need 19, twice as many 20)
         const uint64_t vh = (uint64_t)c->n_visible + c->n_visible / 8u + 4096ull;
@@ -968,7 +969,7 @@ GS_API int gs_create(int device, gs_ctx **out)
     if (!ctx) { snprintf(g_create_err, sizeof g_create_err, "out of host memory"); return GS_E_OOM; }
     memset(ctx, 0, sizeof *ctx);
     ctx->device = device; ctx->renderable = true; ctx->t_eps = 1.0f / 1024.0f; ctx->near_frac = 0.25f;
-    ctx->lanes[0] = ctx; ctx->pipe_depth = 3; ctx->enqueue_threads = true; ctx->frame_batch = 1; ctx->exec = ctx; ctx->sort_near_opt = 1; ctx->auto_retry = true;
+    ctx->lanes[0] = ctx; ctx->pipe_depth = 3; ctx->enqueue_threads = true; ctx->frame_batch = 1; ctx->exec = ctx; ctx->sort_near_opt = 1; ctx->auto_retry = true; ctx->subtile_opt = 1;
     { const char *e = getenv("GS_SPEC_STASH"); ctx->near_spec_opt = !(e && e[0] == '0'); }   // (A/B: near-only sorts without the speculative stash)
 #define CREATE_HIP(call) do { hipError_t _e = (call); if (_e != hipSuccess) {                                              \
         snprintf(g_create_err, sizeof g_create_err, "%s failed: %s", #call, hipGetErrorString(_e)); gs_destroy(ctx);      \
@@ -1005,7 +1006,7 @@ GS_API int gs_clear(gs_ctx *ctx)
     CHECK_CTX(ctx);
     GS_HIP(hipSetDevice(ctx->device));
     TRY(drain_all(ctx));
-    ctx->n = 0; ctx->renderable = true; ctx->pair_hint = 0; ctx->vis_hint = 0; ctx->run_hint = 0;
+    ctx->n = 0; ctx->renderable = true; ctx->pair_hint = 0; ctx->vis_hint = 0; ctx->run_hint = 0; ctx->last_pairs = 0; ctx->last_visible = 0;
     ctx->near_frac = 0.25f; ctx->near_floor = 0.0f; ctx->clean_frames = 0; ctx->skip_hold = 0; ctx->single_round_frames = 0; ctx->last_kept = 0; ctx->share_measured = false; ctx->need_margin = 0.0f; memset(ctx->need_hist, 0, sizeof ctx->need_hist);
     ctx->near_stash_off = false; ctx->near_spec = false; ctx->near_spec_hold = 0; ctx->near_spec_backoff = 0; ctx->near_spec_miss_credit = 0;
     for (int i = 0; i < GS_MAX_LANES; i++) {
@@ -1285,6 +1286,9 @@ int gs_fill_uniforms(gs_ctx *ctx /* owner: options, adaptive share, scene */, co
     if ((u.has_depth || u.has_scene_rgba) && (ctx->scene_w != p->fb_width || ctx->scene_h != p->fb_height))
         FAIL(GS_E_BADARG, "scene inputs are %dx%d but the frame is %dx%d", ctx->scene_w, ctx->scene_h, p->fb_width, p->fb_height);
     u.skip_round1 = (u.near_count != 0xFFFFFFFFu && round1_skippable(ctx)) ? 1u : 0u;
+    // sub-tile lists in the blend (GS_OPT_SUBTILE): where the last collected frame's visible splats touched few tiles each
+    static const double subtile_ratio = getenv("GS_SUBTILE_RATIO") ? atof(getenv("GS_SUBTILE_RATIO")) : 8.0;
+    u.subtile = ctx->subtile_opt == 2 ? 1u : (ctx->subtile_opt == 1 && ctx->last_visible && (double)ctx->last_pairs < subtile_ratio * (double)ctx->last_visible ? 1u : 0u);
     return GS_OK;
 }
 
@@ -1794,6 +1798,10 @@ GS_API int gs_set_option(gs_ctx *ctx, int option, int64_t value)
         ctx->frame_batch = (int)value;
         ctx->cur = 0; ctx->rot = 0; ctx->cur_async = false;
         return prepare_lanes(ctx);
+    case GS_OPT_SUBTILE:
+        if (value < 0 || value > 2) FAIL(GS_E_BADARG, "sub-tile lists: 0 (off), 1 (where splats are small) or 2 (always)");
+        ctx->subtile_opt = (int)value;
+        return GS_OK;
     case GS_OPT_SORT_NEAR:
         if (value < 0 || value > 2) FAIL(GS_E_BADARG, "near-only sorts: 0 (off), 1 (scenes of 4 M splats and more) or 2 (always)");
         GS_HIP(hipSetDevice(ctx->device));

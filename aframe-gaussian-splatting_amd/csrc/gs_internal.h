@@ -143,6 +143,8 @@ struct GsFrameUniforms {           // per-render constants, passed by value to k
                                    // lane's control block by default, the trailer of the piece for a gathered frame (it travels with the piece)
     uint32_t rc_stride;            // span-list binning (GS_OPT_BINNING): chunks per tile row of the row-count table; 0 = pair records + radix passes.
                                    // A tile's list entries are then the sorted positions themselves (pair_jbits = 32)
+    uint32_t subtile;              // GS_OPT_SUBTILE: k_blend splits a staged batch into the lists of the tile's sixteen 4x4-pixel blocks where that
+                                   // shortens the walk (gs_render.hip: same pixels either way)
 };
 
 struct GsLaneWorker;
@@ -238,6 +240,8 @@ struct gs_ctx {
     uint2 *row_tot; size_t row_tot_cap;     // ... and per tile row (runs, tiles) of the round
     int *seg_diff;                          // ... and per k_lists item (tile row, segment of its runs) the segment's difference array over the tile columns
     int bin_mode;                           // owner: GS_OPT_BINNING
+    int subtile_opt;                        // owner: GS_OPT_SUBTILE (0 off, 1 where the last collected frames' splats were small, 2 always)
+    uint32_t last_pairs, last_visible;      // owner: I and Vp of the last collected frame (what GS_OPT_SUBTILE = 1 decides on)
     uint2 *tile_range; size_t tile_cap;     // per tile [start,end) into the sorted pair list
     uint8_t *fb; size_t fb_cap;             // RGBA8 strip
     // multi-GPU frames (gs_comm.hip)

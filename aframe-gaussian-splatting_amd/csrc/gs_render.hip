@@ -1088,9 +1088,79 @@ __device__ __forceinline__ f2 fma2_hi0(f2 a, f2 b, f2 c)
     return r;
 }
 
+
+// ---- sub-tile lists (GS_OPT_SUBTILE; round 6).  One wavefront still owns a 16x16 tile, but a list entry that covers only a corner
+// of it -- the camera outside the cloud: the median splat is 13 pixels across, a tile's entry passes the coverage test in 19 % of
+// the tile's 256 pixels -- no longer costs all 64 lanes the entry's ~45 VALU instructions.  The tile is cut into sixteen 4x4-pixel
+// blocks, each the four pixels of four lanes (lane l draws row l/4, columns 4 (l%4) .. +3: block (l%4, l/16) = lanes 16 br + 4 k
+// + bc), and every staged batch of 64 entries is split into sixteen lists, one per block: the lane that stages entry s works out
+// from the entry's own record which blocks its |p| <= 2 ellipse can reach (the binning's exact band arithmetic, gsm::ellipse_band_
+// xrange, over the tile's four 4-row bands: a superset of the pixels that pass q <= 4, index.js:171-172), sixteen ballots turn the
+// lanes' masks into the blocks' lists, and the four lanes of a block walk THEIR list -- the wave takes as many steps as the
+// longest of the sixteen lists is long instead of one per entry.  An entry left out of a block's list would have failed the
+// coverage test in each of the block's pixels (e = 0: T and the colours unchanged), so every pixel still sees the same operations
+// in the same order: frames are bit-identical to the whole-tile walk's, fragment counts included.  A batch whose longest list is
+// nearly the batch (large splats: the headline pose) is walked whole, as before.
+#ifndef GS_SUBTILE_KEEP_NUM
+#define GS_SUBTILE_KEEP_NUM 13u     // a batch is split when its longest block list is at most 13/16 of it ...
+#endif
+#define GS_SUBTILE_STRIDE 68u       // bytes per block list: 64 entries + the inert pair behind them, banks 17 g + k / 4 apart
+#define GS_SUBTILE_INERT 64u        // the slot of the record no pixel passes
+#ifndef GS_SUBTILE_BANDS
+#define GS_SUBTILE_BANDS 4          // row bands per tile: 4 (4x4-pixel blocks, sixteen lists) or 2 (4 columns x 8 rows, eight lists)
+#endif
+#ifndef GS_SUBTILE_MASK
+#define GS_SUBTILE_MASK 0           // 0: the ellipse's exact x-interval per band; 1: its bounding box
+#endif
+#define GS_SUBTILE_GROUPS (4 * GS_SUBTILE_BANDS)
+#define GS_SUBTILE_ROWS (16 / GS_SUBTILE_BANDS)
+__device__ __forceinline__ uint32_t subtile_mask(const float4 ra, const float bx, const float by, const float tile_x0, const int r0, const int H)
+{
+    gsm::Projected p;
+    p.cx = ra.x; p.cy = ra.y; p.ax = ra.z; p.ay = ra.w; p.bx = bx; p.by = by;
+    gsm::EllipseRows e;
+    gsm::ellipse_rows_setup(p, e);
+    // half height of the ellipse, as ellipse_rows_setup's half width: 2 sqrt(A / D)
+    const float hh = 2.0f * gsm::fast_sqrt((0.25f * e.D4A) * gsm::fast_rcp(e.D));
+    if (!(hh >= 0.0f) || !(e.pad >= 0.0f)) return (1u << GS_SUBTILE_GROUPS) - 1u;   // (no such record leaves k_project; whole tile if one did)
+    uint32_t m = 0;
+#if GS_SUBTILE_MASK == 1
+    // bounding box: columns [cx - hw, cx + hw], rows [cy - hh, cy + hh] (GL y up), padded like the binning's intervals
+    const float hw = 2.0f * gsm::fast_sqrt((p.ay * p.ay + p.by * p.by) * gsm::fast_rcp(e.D));   // (as ellipse_rows_setup)
+    const float fi0 = fmaxf(ceilf(p.cx - hw - e.pad - 0.5f), tile_x0), fi1 = fminf(floorf(p.cx + hw + e.pad - 0.5f), tile_x0 + 15.0f);
+    // image row r has GL centre (H - 1 - r) + 0.5: rows r with |(H - 0.5 - r) - cy| <= hh + pad
+    const float fr0 = fmaxf(ceilf(((float)H - 0.5f) - p.cy - hh - e.pad), (float)r0), fr1 = fminf(floorf(((float)H - 0.5f) - p.cy + hh + e.pad), (float)r0 + 15.0f);
+    if (fi0 <= fi1 && fr0 <= fr1) {
+        const uint32_t c0 = (uint32_t)(fi0 - tile_x0) >> 2, c1 = (uint32_t)(fi1 - tile_x0) >> 2;
+        const uint32_t b0 = (uint32_t)(fr0 - (float)r0) / GS_SUBTILE_ROWS, b1 = (uint32_t)(fr1 - (float)r0) / GS_SUBTILE_ROWS;
+        const uint32_t cm = ((2u << c1) - 1u) & ~((1u << c0) - 1u);                   // columns c0 .. c1 of one band
+        const uint32_t rep = GS_SUBTILE_BANDS == 4 ? 0x1111u : 0x11u;                 // ... repeated in bands b0 .. b1
+        const uint32_t bm = ((16u << (4u * b1)) - 1u) & ~((1u << (4u * b0)) - 1u);
+        m = (cm * rep) & bm;
+    }
+#else
+#pragma unroll 1
+    for (int b = 0; b < GS_SUBTILE_BANDS; b++) {
+        // image rows r0 + ROWS b .. + ROWS - 1 (top-down); GL pixel-centre y of image row r is (H - 1 - r) + 0.5
+        const float ya = ((float)(H - 1 - (r0 + GS_SUBTILE_ROWS * b + GS_SUBTILE_ROWS - 1)) + 0.5f) - p.cy - e.pad, yb = ((float)(H - 1 - (r0 + GS_SUBTILE_ROWS * b)) + 0.5f) - p.cy + e.pad;
+        if (ya <= hh && yb >= -hh) {
+            float xmin, xmax;
+            gsm::ellipse_band_xrange(e, ya, yb, xmin, xmax);
+            const float fi0 = fmaxf(ceilf(p.cx + xmin - e.pad - 0.5f), tile_x0), fi1 = fminf(floorf(p.cx + xmax + e.pad - 0.5f), tile_x0 + 15.0f);
+            if (fi0 <= fi1) {
+                const uint32_t c0 = (uint32_t)(fi0 - tile_x0) >> 2, c1 = (uint32_t)(fi1 - tile_x0) >> 2;
+                m |= (((2u << c1) - 1u) & ~((1u << c0) - 1u)) << (4 * b);
+            }
+        }
+    }
+#endif
+    return m;
+}
+
 // SCENE: the opaque scene's depth buffer (fragment kept iff its window depth <= the buffer: depthTest LEQUAL,
 // depthWrite off, index.js:179-180) and/or colour image (the destination the splats are blended over).
-template <bool COUNT, int ROUND, bool SCENE>
+// SUB: with the sub-tile lists (GS_OPT_SUBTILE; a kernel of its own: the lists cost 20 vector registers, i.e. a wave per SIMD)
+template <bool COUNT, int ROUND, bool SCENE, bool SUB>
 __device__ __forceinline__ void k_blend_body(const uint2 *__restrict__ tile_range, const void *__restrict__ pairs,
                                              const gsm::Projected *__restrict__ proj, const GsFrameUniforms &u,
                                              uint8_t *__restrict__ out, float4 *__restrict__ state, uint32_t *__restrict__ mask,
@@ -1101,6 +1171,7 @@ __device__ __forceinline__ void k_blend_body(const uint2 *__restrict__ tile_rang
     // and its colour converted once per record (rgb8 * alpha / 255, alpha) -- one LDS base address serves all three reads
     __shared__ float4 s_ent[3 * (GS_BLEND_BATCH + 1)];
     __shared__ float s_z[GS_BLEND_BATCH + 2];                    // their window depths (SCENE only)
+    __shared__ __attribute__((aligned(16))) uint8_t s_list[SUB ? GS_SUBTILE_GROUPS * GS_SUBTILE_STRIDE : 16];   // GS_OPT_SUBTILE: per 4x4-pixel block, the batch's entries (slots) that can reach it
 #if GS_BLEND_PAD_WORDS
     __shared__ uint32_t s_pad[GS_BLEND_PAD_WORDS];                 // occupancy cap: see GS_BLEND_PAD_WORDS
     if (u.W < 0) s_pad[threadIdx.x] = 0u;                           // (never true; keeps the array allocated)
@@ -1109,6 +1180,12 @@ __device__ __forceinline__ void k_blend_body(const uint2 *__restrict__ tile_rang
     // (a round whose records did not fit bins nothing and this kernel draws the background: the completion word says so)
     if (blockIdx.x == 0 && lane == 0 && u.status && ctl->pair_overflow) atomicOr(u.status, 2u);
     if (ROUND == 1 && ctl->j_hi == 0) return;                      // every tile saturated in round 0
+    static_assert(GS_BLEND_BATCH == 64, "the sub-tile lists name a batch's entries by the lane that staged them");
+    if (SUB && lane == 0) {                                  // the record no pixel passes, behind every batch (staging never writes slot 64)
+        if (SCENE) s_z[GS_SUBTILE_INERT] = 0.0f;
+        s_ent[3 * GS_SUBTILE_INERT] = make_float4(-1.0e9f, -1.0e9f, 1.0f, 1.0f); s_ent[3 * GS_SUBTILE_INERT + 1] = make_float4(1.0f, 1.0f, 0.0f, 0.0f);
+        s_ent[3 * GS_SUBTILE_INERT + 2] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
     const uint32_t ntiles = (uint32_t)u.tiles_x * (uint32_t)u.tiles_y;
     // 4-byte pair records carry position - j_lo, or (compact) the index among the visible splats: `proj` is then the compacted array
     // (span lists, pair_jbits = 32: the position itself)
@@ -1164,6 +1241,7 @@ __device__ __forceinline__ void k_blend_body(const uint2 *__restrict__ tile_rang
         const uint32_t nb = min((uint32_t)GS_BLEND_BATCH, end - range.x);
         staged += nb;
         nb_last = nb; e_l = 0;
+        uint32_t m16 = 0;                                          // GS_OPT_SUBTILE: the 4x4-pixel blocks of the tile this lane's entry can reach
 #pragma unroll
         for (int h = 0; h < GS_BLEND_BATCH / 64; h++) {            // nearest first: reverse the back-to-front list
             const uint32_t slot = h * 64 + lane;
@@ -1173,6 +1251,7 @@ __device__ __forceinline__ void k_blend_body(const uint2 *__restrict__ tile_rang
                 const float4 *src = reinterpret_cast<const float4 *>(proj + j);
                 const float4 ra = src[0], rb = src[1];
                 if (GS_BLEND_BATCH == 64) j_mine = j;
+                if (SUB) m16 = subtile_mask(ra, rb.x, rb.y, (float)(u.x0 + (int)tx * GS_TILE), (int)ty * GS_TILE, u.H);
                 // (cx, cy, ax, bx | ay, by, -, -): the two coefficients a row shares with dy sit in one register pair, so that
                 // dy * (ay, by) is one packed multiplication, and so do the two that multiply dx
                 s_ent[3 * slot] = make_float4(ra.x, ra.y, ra.z, rb.x);
@@ -1193,56 +1272,58 @@ __device__ __forceinline__ void k_blend_body(const uint2 *__restrict__ tile_rang
             s_ent[3 * nb + 2] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         }
         __syncthreads();
-        if (live) {
-            // Two splats per step: their coverage tests are independent, so the second one's LDS read + ~13-instruction
-            // dependent chain overlaps the first one's (the per-step latency, not issue bandwidth, bounds a tile that
-            // runs alone in the kernel's tail).  Blending is still applied strictly in list order.
-#ifndef GS_BLEND_SPLATS_PER_STEP
-#define GS_BLEND_SPLATS_PER_STEP 2
-#endif
-            // the LDS address of the step's first entry, kept in a VECTOR register (the empty asm hides that it is uniform): left to
-            // itself the compiler keeps it in a scalar register and copies it to a vector register before each of the step's three
-            // groups of reads -- 1.5 VALU instructions per list entry of the ~44.5
-            uint32_t vo = 0;
-            asm volatile("" : "+v"(vo));
-            const uint32_t vend = nb * 48u;
-            for (; vo < vend; vo += 48u * GS_BLEND_SPLATS_PER_STEP) {
-                const char *eb = reinterpret_cast<const char *>(s_ent) + vo;
-#define GS_ENT4(k) (*reinterpret_cast<const float4 *>(eb + 16 * (k)))
-#define GS_ENT2(k) (*reinterpret_cast<const float2 *>(eb + 16 * (k)))
-                // |p|^2 of the interpolated vPosition, same expression tree per pixel as gsm::frag_power:
-                //   px = dx * ax + dy * ay, py = dx * bx + dy * by, q = px * px + py * py            (-A, index.js:171)
-#define GS_BLEND_Q(K, qA, qB)                                                                                          \
-                const float4 a_##K = GS_ENT4(3 * (K)); const f2 ab_##K = *reinterpret_cast<const f2 *>(eb + 48 * (K) + 16);  \
+        // ---- how the batch is walked: whole (every lane takes every entry), or split into the sixteen 4x4-pixel blocks' lists
+        uint32_t cnt_max = nb;
+        bool split = false;
+        if (SUB && nb >= 8u) {
+            // the lists: block g's k-th entry is the k-th set bit of its ballot; behind a list the inert slot, up to the longest list's
+            // (even) length.  Built before it is known whether the batch will be walked by them: the ballots are the count
+            uint32_t cm = 0;
+            uint32_t *lw = reinterpret_cast<uint32_t *>(s_list);
+            for (uint32_t i = (uint32_t)lane; i < GS_SUBTILE_GROUPS * GS_SUBTILE_STRIDE / 4u; i += 64u) lw[i] = GS_SUBTILE_INERT * 0x01010101u;
+#pragma unroll
+            for (int g = 0; g < GS_SUBTILE_GROUPS; g++) {
+                const unsigned long long bal = __ballot((m16 >> g) & 1u);
+                const uint32_t c = (uint32_t)__popcll(bal);
+                cm = c > cm ? c : cm;
+                const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+                if ((m16 >> g) & 1u) s_list[g * GS_SUBTILE_STRIDE + pos] = (uint8_t)lane;
+            }
+            split = cm * 16u <= nb * GS_SUBTILE_KEEP_NUM;            // (uniform: ballots and their counts are scalars)
+            if (split) {
+                cnt_max = cm;
+                __syncthreads();
+            }
+        }
+        // |p|^2 of the interpolated vPosition, same expression tree per pixel as gsm::frag_power:
+        //   px = dx * ax + dy * ay, py = dx * bx + dy * by, q = px * px + py * py            (-A, index.js:171)
+        // EB: the entry's 48 bytes in LDS -- (cx, cy, ax, bx | ay, by, -, - | -alpha, r, g, b premultiplied)
+#define GS_BLEND_Q(K, EB, qA, qB)                                                                                      \
+                const float4 a_##K = *reinterpret_cast<const float4 *>(EB); const f2 ab_##K = *reinterpret_cast<const f2 *>((EB) + 16); \
                 const f2 axbx_##K = { a_##K.z, a_##K.w };                                                               \
                 const f2 dyab_##K = (f2)(fy - a_##K.y) * ab_##K;     /* (dy * ay, dy * by) */                          \
                 const f2 dxA_##K = fxA - a_##K.x, dxB_##K = fxB - a_##K.x;                                              \
                 const f2 pxA_##K = fma2_lo12(dxA_##K, axbx_##K, dyab_##K), pxB_##K = fma2_lo12(dxB_##K, axbx_##K, dyab_##K); \
                 const f2 pyA_##K = fma2_hi12(dxA_##K, axbx_##K, dyab_##K), pyB_##K = fma2_hi12(dxB_##K, axbx_##K, dyab_##K); \
                 const f2 qA = fma2(pxA_##K, pxA_##K, pyA_##K * pyA_##K), qB = fma2(pxB_##K, pxB_##K, pyB_##K * pyB_##K);
-                GS_BLEND_Q(0, qA0, qB0)
-#if GS_BLEND_SPLATS_PER_STEP == 2
-                GS_BLEND_Q(1, qA1, qB1)                               // slot nb holds an inert record when nb is odd
-#endif
-#undef GS_BLEND_Q
-#define GS_BLEND_APPLY(qA, qB, cc, zz)                                                                                 \
+#define GS_BLEND_APPLY(qA, qB, EB, zz)                                                                                 \
                 {                                                                                                      \
                     bool p0 = qA.x <= qmA.x, p1 = qA.y <= qmA.y, p2 = qB.x <= qmB.x, p3 = qB.y <= qmB.y;               \
                     if (SCENE) { p0 = p0 && zz <= zb0; p1 = p1 && zz <= zb1; p2 = p2 && zz <= zb2; p3 = p3 && zz <= zb3; } \
                     if (live & (p0 | p1 | p2 | p3)) {                  /* discard test, index.js:172 */                \
                         /* the colour record as two 8-byte halves: the compiler splats .x / .y of a register pair through \
                            op_sel but copies the fourth word of a 16-byte read to a register of its own first */      \
-                        const float2 cl_ = *reinterpret_cast<const float2 *>(eb + 16 * (cc));                          \
-                        const float2 ch_ = *reinterpret_cast<const float2 *>(eb + 16 * (cc) + 8);                      \
+                        const float2 cl_ = *reinterpret_cast<const float2 *>((EB) + 32);                               \
+                        const float2 ch_ = *reinterpret_cast<const float2 *>((EB) + 40);                               \
                         const float nalpha = cl_.x;                  /* -alpha (staging) */                          \
                         /* exp(A) (index.js:173); 0 for the pixels of this lane that the splat misses */               \
                         /* (= __expf(-q): v_exp_f32 of q * -log2(e), the four multiplications as two packed ones) */   \
                         const f2 tA = qA * (f2)(-1.44269502f), tB = qB * (f2)(-1.44269502f);                            \
                         const f2 EA = { p0 ? __builtin_amdgcn_exp2f(tA.x) : 0.0f, p1 ? __builtin_amdgcn_exp2f(tA.y) : 0.0f }; \
-                        const f2 EB = { p2 ? __builtin_amdgcn_exp2f(tB.x) : 0.0f, p3 ? __builtin_amdgcn_exp2f(tB.y) : 0.0f }; \
+                        const f2 EB_ = { p2 ? __builtin_amdgcn_exp2f(tB.x) : 0.0f, p3 ? __builtin_amdgcn_exp2f(tB.y) : 0.0f }; \
                         /* fragment alpha B = exp(A)*vColor.a; its weight under what is in front: w = B*T.  T <- T - w \
                            (= T*(1-B)), colour += (rgb8 * alpha/255) * (exp(A)*T) with the bracket converted at staging */ \
-                        const f2 eA = EA * TA, eB = EB * TB;                                                           \
+                        const f2 eA = EA * TA, eB = EB_ * TB;                                                          \
                         TA = fma2((f2)(nalpha), eA, TA); TB = fma2((f2)(nalpha), eB, TB);                              \
                         crA = fma2((f2)(cl_.y), eA, crA); crB = fma2((f2)(cl_.y), eB, crB);                            \
                         cgA = fma2((f2)(ch_.x), eA, cgA); cgB = fma2((f2)(ch_.x), eB, cgB);                            \
@@ -1254,21 +1335,50 @@ __device__ __forceinline__ void k_blend_body(const uint2 *__restrict__ tile_rang
                         live = GS_LANE_LIVE();                                                                         \
                     }                                                                                                  \
                 }
+        if (SUB && live && split) {
+            // this lane's block list, two entries per step like the whole walk below (their coverage tests overlap); a lane whose
+            // list is shorter than the longest one finishes on the inert record
+            const uint8_t *lst = s_list + (((uint32_t)lane / (4u * GS_SUBTILE_ROWS)) * 4u + ((uint32_t)lane & 3u)) * GS_SUBTILE_STRIDE;
+            uint32_t k = 0, i_last = nb - 1u;
+            for (; k < cnt_max; k += 2u) {
+                const uint32_t pr = *reinterpret_cast<const uint16_t *>(lst + k);
+                const uint32_t i0 = pr & 0xFFu, i1 = pr >> 8;
+                const char *eb0 = reinterpret_cast<const char *>(s_ent) + i0 * 48u, *eb1 = reinterpret_cast<const char *>(s_ent) + i1 * 48u;
+                GS_BLEND_Q(0, eb0, qA0, qB0)
+                GS_BLEND_Q(1, eb1, qA1, qB1)
+                const float z0 = SCENE ? s_z[i0] : 0.0f, z1 = SCENE ? s_z[i1] : 0.0f;
+                GS_BLEND_APPLY(qA0, qB0, eb0, z0)
+                GS_BLEND_APPLY(qA1, qB1, eb1, z1)
+                if (!live) { i_last = min(i1 < GS_SUBTILE_INERT ? i1 : (i0 < GS_SUBTILE_INERT ? i0 : 0u), nb - 1u); break; }
+            }
+            e_l = i_last;                                            // (the entry at which the lane left the list, or the batch's last)
+            if (u.record_staged == 2) evaluated += min(k + 2u, cnt_max);
+        } else if (live) {
+            // Two splats per step: their coverage tests are independent, so the second one's LDS read + ~13-instruction
+            // dependent chain overlaps the first one's (the per-step latency, not issue bandwidth, bounds a tile that
+            // runs alone in the kernel's tail).  Blending is still applied strictly in list order.
+            // the LDS address of the step's first entry, kept in a VECTOR register (the empty asm hides that it is uniform): left to
+            // itself the compiler keeps it in a scalar register and copies it to a vector register before each of the step's three
+            // groups of reads -- 1.5 VALU instructions per list entry of the ~44.5
+            uint32_t vo = 0;
+            asm volatile("" : "+v"(vo));
+            const uint32_t vend = nb * 48u;
+            for (; vo < vend; vo += 48u * 2u) {
+                const char *eb = reinterpret_cast<const char *>(s_ent) + vo;
+                GS_BLEND_Q(0, eb, qA0, qB0)
+                GS_BLEND_Q(1, eb + 48, qA1, qB1)                      // slot nb holds an inert record when nb is odd
                 const uint32_t s = SCENE ? vo / 48u : 0u;               // (the entry's index: only the scene's depth test needs it)
                 const float z0 = SCENE ? s_z[s] : 0.0f;
-                GS_BLEND_APPLY(qA0, qB0, 2, z0)
-#if GS_BLEND_SPLATS_PER_STEP == 2
+                GS_BLEND_APPLY(qA0, qB0, eb, z0)
                 const float z1 = SCENE ? s_z[s + 1] : 0.0f;
-                GS_BLEND_APPLY(qA1, qB1, 5, z1)
-#endif
-#undef GS_BLEND_APPLY
-#undef GS_ENT4
-#undef GS_ENT2
+                GS_BLEND_APPLY(qA1, qB1, eb + 48, z1)
                 if (!live) break;
             }
-            e_l = min(vo / 48u + (GS_BLEND_SPLATS_PER_STEP - 1u), nb - 1u);   // (the step in which the lane left the list, or the batch's last entry)
-            if (u.record_staged == 2) evaluated += min(vo / 48u + GS_BLEND_SPLATS_PER_STEP, nb);   // list entries this lane evaluated (measurement aid)
+            e_l = min(vo / 48u + 1u, nb - 1u);                        // (the step in which the lane left the list, or the batch's last entry)
+            if (u.record_staged == 2) evaluated += min(vo / 48u + 2u, nb);   // list entries this lane evaluated (measurement aid)
         }
+#undef GS_BLEND_APPLY
+#undef GS_BLEND_Q
         end -= nb;
         __syncthreads();                                           // s_ent is rewritten by the next batch
         if (__all(!live)) break;
@@ -1351,14 +1461,14 @@ __device__ __forceinline__ void k_blend_body(const uint2 *__restrict__ tile_rang
     }
 }
 
-template <bool COUNT, int ROUND, bool SCENE>
+template <bool COUNT, int ROUND, bool SCENE, bool SUB = false>
 __global__ __launch_bounds__(64) void k_blend(const uint2 *__restrict__ tile_range, const void *__restrict__ pairs,
                                               const gsm::Projected *__restrict__ proj, GsFrameUniforms u,
                                               uint8_t *__restrict__ out, float4 *__restrict__ state, uint32_t *__restrict__ mask,
                                               const float *__restrict__ zwin, const float *__restrict__ scene_depth,
                                               const uint32_t *__restrict__ scene_rgba, GsControl *ctl)
 {
-    k_blend_body<COUNT, ROUND, SCENE>(tile_range, pairs, proj, u, out, state, mask, zwin, scene_depth, scene_rgba, ctl);
+    k_blend_body<COUNT, ROUND, SCENE, SUB>(tile_range, pairs, proj, u, out, state, mask, zwin, scene_depth, scene_rgba, ctl);
 }
 
 // GS_OPT_BLEND_SPLIT: the tiles with LONG lists, four wavefronts per tile, ONE pixel per lane (wave w: tile rows 4w .. 4w+3).
@@ -1618,11 +1728,13 @@ int launch_blend(gs_ctx *ctx, const GsFrameUniforms &u, GsFrameUniforms v, uint8
         else hipLaunchKernelGGL((k_blend_px<ROUND, false>), dim3(gp), dim3(256), 0, st, ctx->tile_range, fpairs, bproj, v, out, ctx->state,
                                 ctx->unsat_mask, bzwin, ctx->scene_depth, ctx->scene_rgba, ctx->ctl);
     }
-#define GS_LAUNCH_BLEND(C, S) hipLaunchKernelGGL((k_blend<C, ROUND, S>), dim3(gb), dim3(64), 0, st, ctx->tile_range, fpairs, bproj, v, \
+#define GS_LAUNCH_BLEND_(C, S, B) hipLaunchKernelGGL((k_blend<C, ROUND, S, B>), dim3(gb), dim3(64), 0, st, ctx->tile_range, fpairs, bproj, v, \
                                                 out, ctx->state, ctx->unsat_mask, bzwin, ctx->scene_depth, ctx->scene_rgba, ctx->ctl)
+#define GS_LAUNCH_BLEND(C, S) do { if (v.subtile) GS_LAUNCH_BLEND_(C, S, true); else GS_LAUNCH_BLEND_(C, S, false); } while (0)
     if (u.flags & GS_RENDER_COUNT_FRAGS) { if (scene) GS_LAUNCH_BLEND(true, true); else GS_LAUNCH_BLEND(true, false); }
     else { if (scene) GS_LAUNCH_BLEND(false, true); else GS_LAUNCH_BLEND(false, false); }
 #undef GS_LAUNCH_BLEND
+#undef GS_LAUNCH_BLEND_
     GS_HIP(hipGetLastError());
     return GS_OK;
 }
@@ -1780,7 +1892,7 @@ template <int ROUND, bool SEGC> GS_BODY(F_lists, k_lists_body<ROUND, SEGC>);
 template <int ROUND> GS_BODY(F_pairs_check, k_pairs_check_body<ROUND>);
 template <int ROUND, bool P32> GS_BODY(F_emit, k_emit_body<ROUND, P32>);
 GS_BODY(F_tile_ranges, k_tile_ranges_body);
-template <int ROUND, bool SCENE> GS_BODY(F_blend, k_blend_body<false, ROUND, SCENE>);
+template <int ROUND, bool SCENE, bool SUB> GS_BODY(F_blend, k_blend_body<false, ROUND, SCENE, SUB>);
 template <int ROUND, bool SCENE> GS_BODY(F_blend_px, k_blend_px_body<ROUND, SCENE>);
 
 // the blend of one round for two frames (launch_blend's paired form)
@@ -1800,13 +1912,15 @@ int launch_blend2(gs_ctx *const S[2], const GsFrameUniforms &u, const GsFrameUni
                      bzwin[1], (const float *)S[1]->scene_depth, (const uint32_t *)S[1]->scene_rgba, S[1]->ctl))
     if (u.split_min) { if (scene) GS_BLENDPX2(true); else GS_BLENDPX2(false); }   // the tiles with long lists first
 #undef GS_BLENDPX2
-#define GS_BLEND2(SC) gs_twin<F_blend<ROUND, SC>, 64>(gb, st,                                                                                           \
+#define GS_BLEND2_(SC, SB) gs_twin<F_blend<ROUND, SC, SB>, 64>(gb, st,                                                                                          \
         gs_pack_make((const uint2 *)S[0]->tile_range, fpairs[0], bproj[0], V[0], out[0], S[0]->state, S[0]->unsat_mask,         \
                      bzwin[0], (const float *)S[0]->scene_depth, (const uint32_t *)S[0]->scene_rgba, S[0]->ctl),                        \
         gs_pack_make((const uint2 *)S[1]->tile_range, fpairs[1], bproj[1], V[1], out[1], S[1]->state, S[1]->unsat_mask,         \
                      bzwin[1], (const float *)S[1]->scene_depth, (const uint32_t *)S[1]->scene_rgba, S[1]->ctl))
+#define GS_BLEND2(SC) do { if (V[0].subtile) GS_BLEND2_(SC, true); else GS_BLEND2_(SC, false); } while (0)
     if (scene) GS_BLEND2(true); else GS_BLEND2(false);
 #undef GS_BLEND2
+#undef GS_BLEND2_
     GS_HIP(hipGetLastError());
     return GS_OK;
 }
@@ -1950,7 +2064,7 @@ bool gs_frames_batchable(const GsFrameUniforms &a, const GsFrameUniforms &b)
 {
     return a.near_count == b.near_count && a.skip_round1 == b.skip_round1 && a.W == b.W && a.H == b.H && a.x0 == b.x0 && a.x1 == b.x1 &&
            a.flags == b.flags && !(a.flags & (GS_RENDER_COUNT_FRAGS | GS_RENDER_COUNT_EVALUATED)) && !a.record_staged && !b.record_staged &&
-           a.split_min == b.split_min && a.has_depth == b.has_depth && a.has_scene_rgba == b.has_scene_rgba && a.t_eps == b.t_eps;
+           a.split_min == b.split_min && a.subtile == b.subtile && a.has_depth == b.has_depth && a.has_scene_rgba == b.has_scene_rgba && a.t_eps == b.t_eps;
 }
 
 int gs_run_render2(gs_ctx *const S[2], const GsFrameUniforms U[2], uint8_t *const device_out[2])

@@ -413,6 +413,15 @@ typedef struct gs_stats {
                                    the round at most a few million sorted positions; elsewhere, and with 1: (tile, splat) pair records
                                    sorted by two stable radix passes (rounds 1-3; eight launches per round).  GS_OPT_WIDE_PAIRS != 0 asks
                                    for a record format and therefore for the records.                                            */
+#define GS_OPT_SUBTILE 17       /* how the blend walks a tile's list (same pixels, bit for bit, whatever the value).  The reference's rasteriser shades
+                                   only the fragments a quad covers (index.js:52-66, 166-176); a 16x16 tile's wavefront evaluates a list entry for
+                                   all 256 pixels.  With sub-tile lists the wavefront splits every batch of 64 entries into the lists of the
+                                   tile's sixteen 4x4-pixel blocks (which blocks an entry's ellipse can reach is worked out from its record when
+                                   it is staged) and takes as many steps as the longest of them -- worth it where splats are small against a
+                                   tile (the cloud seen from outside: a list entry covers a fifth of its tile).  0: never; 1 (default): in
+                                   frames that follow collected frames whose visible splats touched fewer than 8 tiles each on average
+                                   (GS_SUBTILE_RATIO in the environment overrides the 8); 2: always (a batch of large splats is still walked
+                                   whole: the decision is per batch).                                                              */
 #define GS_OPT_ENQUEUE_THREADS 7 /* default 1: gs_sort() (without an output array) and gs_render_device(GS_RENDER_ASYNC) hand the
                                    frame to a worker thread of its pipeline lane, which does the ~18 kernel launches, so the
                                    launches of the frames in flight run in parallel; failures surface at gs_sync().  0: the

@@ -55,6 +55,10 @@ def _tsan_lib():
     lib = os.path.join(ROOT, "aframe-gaussian-splatting_amd", "csrc", "libgs_variant_tsan.so")
     srcs = glob.glob(os.path.join(ROOT, "aframe-gaussian-splatting_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "aframe-gaussian-splatting_amd", "csrc", "*.h")) + \
         glob.glob(os.path.join(ROOT, "aframe-gaussian-splatting_amd", "csrc", "*.cpp")) + [os.path.join(ROOT, "include", "gs_splat.h")]
+    # (round 6: this pool's GPU boxes refuse sanitizer builds -- the script and its output are listed in .gpurunignore, so on a box they
+    # are absent and the test is skipped; where they are present -- a workstation with its own GPU -- it runs as in rounds 4-5)
+    if not os.path.exists(os.path.join(ROOT, "tools", "build_tsan.sh")):
+        pytest.skip("tools/build_tsan.sh is not shipped to this box (the GPU pool refuses sanitizer builds)")
     # the runtime first: without one the build cannot link, and the test is to be skipped, not to fail on the link error
     rt = subprocess.run([os.path.join(ROOT, "tools", "build_tsan.sh"), "--runtime"], capture_output=True, text=True).stdout.strip()
     if not rt or not os.path.exists(rt):

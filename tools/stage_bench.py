@@ -27,6 +27,8 @@ ap.add_argument("--no-early-out", action="store_true", help="GS_RENDER_NO_EARLY_
 ap.add_argument("--strip", default=None, help="k/G: render only strip k of G tile-aligned column strips (what one of G GPUs does)")
 ap.add_argument("--sort-for", action="store_true", help="with --strip: gs_sort_for the strip instead of the full gs_sort")
 ap.add_argument("--outside", action="store_true", help="the camera OUTSIDE the cloud, 3 sigma from its centre (synth.outside_cloud_camera)")
+ap.add_argument("--subtile", type=int, default=None, help="GS_OPT_SUBTILE (0 off, 1 auto = the library's default, 2 always)")
+ap.add_argument("--opt", action="append", default=[], help="NAME=VALUE: any capi.OPT_<NAME> (repeatable)")
 ap.add_argument("--binning", type=int, default=None, help="GS_OPT_BINNING (0 span lists, 1 pair records + radix passes)")
 ap.add_argument("--pmc-run", action="store_true", help="the run rocprofv3 --pmc passes profile (tools/gpu_pmc.sh): settle the share with synchronous frames, "
                                                         "then ONLY queued frames of the orbit at the first depth; prints the frames queued and, untimed and "
@@ -59,6 +61,10 @@ if a.batch != 1:
     ctx.set_option(capi.OPT_FRAME_BATCH, a.batch)
 if a.sort_near is not None:
     ctx.set_option(capi.OPT_SORT_NEAR, a.sort_near)
+if a.subtile is not None:
+    ctx.set_option(capi.OPT_SUBTILE, a.subtile)
+for kv in a.opt:
+    ctx.set_option(getattr(capi, "OPT_" + kv.split("=")[0].upper()), int(kv.split("=")[1]))
 
 
 def go(n):
