@@ -38,7 +38,23 @@ CONFIGS = {
            "options": {"OPT_FRAME_BATCH": 2}},
 }
 
+# Regimes of the headline scene that the headline pose does not show: measured, checked (tests/test_as_benched.py) and
+# reported like the configurations.  Same 1 M splats, same viewport, same options.
+#   R_outside  the camera OUTSIDE the cloud, 3 sigma from its centre, looking in (synth.outside_cloud_camera): 912 K visible splats of
+#              3.5 tiles each, sky around them; nothing like the 16 K screen-filling splats of the pose inside the cloud
+#   R_unsat    every opacity byte divided by ten at the headline pose: tiles need 5-10 x longer lists before T < 1/1024, most of the
+#              order is binned and blended
+REGIMES = {
+    "R_outside": {"splats": 1 << 20, "rows": ("make_splat_rows", {}), "size": (1920, 1080), "pose": "outside", "xr": False,
+                  "options": {"OPT_FRAME_BATCH": 2}},
+    "R_unsat": {"splats": 1 << 20, "rows": ("make_splat_rows", {}), "opacity_div": 10, "size": (1920, 1080), "pose": "index", "xr": False,
+                "options": {"OPT_FRAME_BATCH": 2}},
+}
+ALL = dict(CONFIGS, **REGIMES)
+
 DESCRIPTION = {
+    "R_outside": "the 1 M scene seen from outside the cloud (entity 7.5 units = 3 sigma in front of the camera) @1920x1080",
+    "R_unsat": "the 1 M scene with every opacity / 10 (tiles do not saturate) @1920x1080, headline pose",
     "C1": "train.splat-shaped 1 M splats @1280x720 (configs[0])",
     "C2": "train.splat-shaped 1 M splats @1920x1080 (configs[1], the headline)",
     "C3": "bicycle.ply-shaped 6 M splats @1920x1080 + cutoutEntity box (configs[2])",
@@ -71,9 +87,13 @@ def custom(splats, size, cutout, xr):
 
 def make_rows(cfg, synth, cache=None):
     fn, kw = cfg["rows"]
-    if cache is not None:
-        return cache(fn, cfg["splats"], **kw)
-    return getattr(synth, fn)(cfg["splats"], **kw)
+    rows = cache(fn, cfg["splats"], **kw) if cache is not None else getattr(synth, fn)(cfg["splats"], **kw)
+    if cfg.get("opacity_div", 1) > 1:                            # (a copy: the cache's scene is shared)
+        import numpy as np
+        r = np.asarray(rows).reshape(-1, 32).copy()
+        r[:, 27] = r[:, 27] // cfg["opacity_div"]
+        rows = r.reshape(-1)
+    return rows
 
 
 def options_for(cfg, env=None, pieces_of_rank=1, gathered=False):
@@ -125,7 +145,7 @@ def poses(cfg, synth, capi, frames=None):
         views = {k: [capi.make_params(e["gs_mv"], e["gs_proj"], W, H, focal_=e["focal"]) for e in r[:2]] for k, r in rigs.items()}
     else:
         W, H = cfg["size"]
-        pose = synth.cutout_demo_camera if cfg["pose"] == "cutout" else synth.index_html_camera
+        pose = {"cutout": synth.cutout_demo_camera, "outside": synth.outside_cloud_camera}.get(cfg["pose"], synth.index_html_camera)
         cams = {k: pose(W, H, 360.0 * k / ORBIT_FRAMES, capi=capi) for k in frames}
         views = {k: [capi.make_params(c["gs_mv"], c["gs_proj"], W, H, focal_=c["focal"])] for k, c in cams.items()}
     if isinstance(frames, range) and frames == range(ORBIT_FRAMES):
@@ -162,3 +182,46 @@ def preroll(frame, sync, frames_used, warmup, async_flag, lanes=LANES, warmup_fi
         frame((warmup_first + i) % ORBIT_FRAMES, async_flag)
     sync()
     return n
+
+
+# ---- what a frame of a timed region runs, in words (bench.py's `config.timed_work`; tests/test_bench_configs.py holds the sentences
+# to the option set and the statistics they are made from)
+SORT_MODES = {0: "whole", 1: "histogram", 2: "stash", 3: "tail"}      # gs_stats.sort_mode
+
+
+def sort_mode_name(opts, stats):
+    if opts.get("OPT_SORT_NEAR", 1) == 0:
+        return "whole"
+    return SORT_MODES.get(int(stats.get("sort_mode", 0)), "whole")
+
+
+def timed_work(opts, stats, lanes=LANES):
+    """{sort_mode, near_permille, frames_in_flight, text}: the reference sorts EVERY splat it keeps (index.js:507-570) and shades every
+    fragment (index.js:166-176); what the timed frames do instead -- with bit-identical pixels -- is said here, not implied."""
+    fb = int(opts.get("OPT_FRAME_BATCH", 1))
+    depth = int(opts.get("OPT_PIPELINE_DEPTH", lanes))
+    mode = sort_mode_name(opts, stats)
+    share = int(stats.get("near_permille", 1000))
+    parts = ["%d frames in flight (%d pipeline lanes%s)" % (depth * fb, depth, " x 2 frames per launch, GS_OPT_FRAME_BATCH: the two frames of a pair share each "
+                                                            "kernel launch, grid (x, 2), on separate scratch" if fb == 2 else "")]
+    parts.append("every frame runs its own depth pass over all N resident splats (key, culls, bucket: index.js:517-561)")
+    if mode == "whole":
+        parts.append("and sorts every kept splat (the reference's whole order)")
+    elif mode == "tail":
+        parts.append("and a TAIL sort: of the 256 depth segments only those the frame will read are scattered and sorted -- the positions it reads "
+                     "hold what the whole order holds there, the rest of the order is not produced (GS_OPT_SORT_NEAR)")
+    elif mode == "stash":
+        parts.append("and a near-only sort of the candidates its depth pass stashed (threshold bin from the frames before; a frame whose stash cannot "
+                     "be vouched for is drawn again from a whole sort) -- the positions it reads hold what the whole order holds there (GS_OPT_SORT_NEAR)")
+    else:
+        parts.append("and a near-only sort behind an exact threshold from a depth histogram -- the positions it reads hold what the whole order "
+                     "holds there (GS_OPT_SORT_NEAR)")
+    if share >= 1000:
+        parts.append("projects, bins and blends the whole order in one round")
+    else:
+        parts.append("projects, bins and blends the nearest %d permille of the order (the share the blends of the frames before measured, plus a "
+                     "margin); the second binning round over the rest is not launched once four collected frames needed none -- a tile that "
+                     "turns out unsaturated flags its frame, which gs_sync() draws again in full" % share)
+    if stats.get("subtile"):
+        parts.append("the blend walks sub-tile lists (GS_OPT_SUBTILE: sixteen 4x4-pixel blocks per tile)")
+    return {"sort_mode": mode, "near_permille": share, "frames_in_flight": depth * fb, "text": "; ".join(parts)}

@@ -35,7 +35,7 @@ EXPORTS = [
     "gs_model_view_matrix", "gs_projection_matrix", "gs_tick_uniforms", "gs_focal", "gs_scaled_size", "gs_set_option",
     "gs_get_stats", "gs_download",
     "gs_comm_unique_id", "gs_comm_init", "gs_comm_destroy", "gs_partition", "gs_render_gathered", "gs_read_gathered",
-    "gs_host_alloc", "gs_host_free", "gs_sort_for", "gs_sort_gathered", "gs_gathered_size",
+    "gs_host_alloc", "gs_host_free", "gs_sort_for", "gs_sort_gathered", "gs_gathered_size", "gs_sort_begin", "gs_sort_poll",
     "gs_create_multi", "gs_multi_destroy", "gs_multi_last_error", "gs_multi_devices", "gs_multi_ctx", "gs_multi_clear",
     "gs_multi_push_splat", "gs_multi_load_ply", "gs_multi_count", "gs_multi_set_option", "gs_multi_sort", "gs_multi_render",
     "gs_multi_render_device", "gs_multi_read", "gs_multi_sync",
@@ -58,7 +58,8 @@ class Stats(C.Structure):
                 ("prof_frames", C.c_uint32), ("sum_ms_sort", C.c_float), ("sum_ms_project", C.c_float), ("sum_ms_bin", C.c_float),
                 ("sum_ms_blend", C.c_float), ("acc_frames", C.c_uint64), ("acc_sorted", C.c_uint64), ("acc_visible", C.c_uint64),
                 ("acc_pairs", C.c_uint64), ("unsat_tiles", C.c_uint32), ("near_permille", C.c_uint32),
-                ("sort_records", C.c_uint32), ("retried_frames", C.c_uint32), ("spec_sorts", C.c_uint32), ("spec_misses", C.c_uint32), ("need_splats", C.c_uint32)]
+                ("sort_records", C.c_uint32), ("retried_frames", C.c_uint32), ("spec_sorts", C.c_uint32), ("spec_misses", C.c_uint32), ("need_splats", C.c_uint32),
+                ("sort_mode", C.c_uint32), ("subtile", C.c_uint32)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -139,6 +140,8 @@ def load(build_if_missing=True):
     L.gs_ply_to_splat_gpu.argtypes = [vp, vp, sz, vp, C.POINTER(sz)]
     L.gs_count.argtypes = [vp]; L.gs_count.restype = sz
     L.gs_sort.argtypes = [vp, vp, vp, vp, u32p]
+    L.gs_sort_begin.argtypes = [vp, vp, vp]
+    L.gs_sort_poll.argtypes = [vp, i32, vp, u32p, C.POINTER(C.c_int)]
     L.gs_render.argtypes = [vp, C.POINTER(RenderParams), vp, sz]
     L.gs_render_device.argtypes = [vp, C.POINTER(RenderParams), vp]
     L.gs_render_stereo.argtypes = [vp, C.POINTER(RenderParams), C.POINTER(vp), sz]
@@ -359,6 +362,22 @@ class Context:
         n = C.c_uint32(0)
         self._ck(self._L.gs_sort(self._h, _p(view), _p(cut), _p(out), C.byref(n)))
         return out[:n.value].copy()
+
+    def sort_begin(self, view, cutout=None):
+        """gs_sort_begin: post the sort and return (the reference's tick, index.js:438-455); draws keep using the last completed order"""
+        view = np.ascontiguousarray(view, np.float32)
+        cut = None if cutout is None else np.ascontiguousarray(cutout, np.float32)
+        self._ck(self._L.gs_sort_begin(self._h, _p(view), _p(cut)))
+
+    def sort_poll(self, wait=False, want_indices=True):
+        """gs_sort_poll: None while the sort begun with sort_begin() runs; else the new order (installed for the draws that follow), or
+        True with want_indices=False"""
+        out = np.zeros(max(self.count(), 1), np.uint32) if want_indices else None
+        n, done = C.c_uint32(0), C.c_int(0)
+        self._ck(self._L.gs_sort_poll(self._h, 1 if wait else 0, _p(out), C.byref(n), C.byref(done)))
+        if not done.value:
+            return None
+        return out[:n.value].copy() if want_indices else True
 
     def sort_for(self, view, cutout, strip_params, want_indices=True):
         """gs_sort_for: the order of the splats that can reach strip_params' column strip (a sub-sequence of sort()'s result)."""

@@ -374,6 +374,7 @@ static int collect_status(gs_ctx *lane, bool *overflowed, bool *share_failed = n
     lane->stats.n_sorted = c->n_kept; lane->stats.n_visible = c->n_visible; lane->stats.n_pairs = c->n_pairs_frame;
     lane->stats.acc_frames = c->acc_frames; lane->stats.acc_sorted = c->acc_sorted; lane->stats.acc_visible = c->acc_visible;
     lane->stats.acc_pairs = c->acc_pairs; lane->stats.sort_records = c->n_sorted;
+    lane->stats.sort_mode = c->near_sorted;
     ctx->last_kept = c->n_kept;
     if (c->n_pairs_frame) { ctx->last_pairs = c->n_pairs_frame; ctx->last_visible = c->n_visible; }
     {   // visible splats a round may expect (compact pair records: gs_compact_bits): the last collected frame's + an eighth + 4096
@@ -997,6 +998,7 @@ GS_API int gs_destroy(gs_ctx *ctx)
     free_frame_resources(ctx);
     dev_free(ctx->splat); dev_free(ctx->sort_rows); dev_free(ctx->bound_r); dev_free(ctx->pow10tab);
     dev_free(ctx->scene_depth); dev_free(ctx->scene_rgba);
+    if (ctx->ev_sort) (void)hipEventDestroy(ctx->ev_sort);
     delete ctx;
     return GS_OK;
 }
@@ -1015,7 +1017,7 @@ GS_API int gs_clear(gs_ctx *ctx)
         L->have_sort = false; L->sorted = nullptr; L->n = 0;
         memset(&L->stats, 0, sizeof L->stats);
     }
-    ctx->cur = 0; ctx->rot = 0; ctx->cur_async = false;
+    ctx->cur = 0; ctx->rot = 0; ctx->cur_async = false; ctx->pend_lane = 0;   // (a sort begun before the clear is dropped, like the worker's data: index.js:573-575)
     return GS_OK;
 }
 
@@ -1178,6 +1180,7 @@ static int sort_common(gs_ctx *ctx, const float view[4], const float *cutout16, 
     const int lane = next_frame_lane(ctx, &rot, solo);
     TRY(get_lane(ctx, lane, &L));
     if (solo && ctx->frame_batch == 2 && lane < GS_MAX_PRIMARY) { gs_ctx *T = nullptr; TRY(get_lane(ctx, lane + GS_MAX_PRIMARY, &T)); }   // (the second view's scratch)
+    if (ctx->pend_lane > 0 && lane == ctx->pend_lane - 1) FAIL(GS_E_STATE, "gs_sort: this frame's lane holds the sort begun with gs_sort_begin: collect it with gs_sort_poll first");
     ctx->cur = lane; ctx->rot = rot; ctx->cur_async = false;
     log_sort(L, view, cutout16, strip);
     const uint32_t near_req = (out_idx || out_n) ? 0u : sort_near_request(ctx);     // (the caller wants the order itself: all of it)
@@ -1209,6 +1212,70 @@ static int sort_common(gs_ctx *ctx, const float view[4], const float *cutout16, 
         if (out_n) *out_n = V;
         if (out_idx && V) GS_HIP(hipMemcpy(out_idx, L->sorted, (size_t)V * 4, hipMemcpyDeviceToHost));
     }
+    return GS_OK;
+}
+
+// ---- the reference's single-flight rhythm (include/gs_splat.h: gs_sort_begin / gs_sort_poll; index.js:201-207, 438-455)
+GS_API int gs_sort_begin(gs_ctx *ctx, const float view[4], const float *cutout16)
+{
+    CHECK_CTX(ctx);
+    if (!view) FAIL(GS_E_BADARG, "gs_sort_begin: view is NULL");
+    if (ctx->pend_lane) FAIL(GS_E_STATE, "gs_sort_begin: a sort is in flight (sortReady is false, index.js:439-440): collect it with gs_sort_poll");
+    if (ctx->n == 0) { ctx->pend_lane = -1; return GS_OK; }     // sort before any push: the reply will be [0] (index.js:588-590)
+    GS_HIP(hipSetDevice(ctx->device));
+    // the lane the sort runs on: a primary lane other than the one whose order the draws use (created on first use, whatever
+    // GS_OPT_PIPELINE_DEPTH says: the order in flight needs scratch of its own)
+    const int front = ctx->cur % GS_MAX_PRIMARY;
+    const int back = (front + 1) % (ctx->pipe_depth > 2 ? ctx->pipe_depth : 2);
+    gs_ctx *B = nullptr;
+    TRY(get_lane(ctx, back, &B));                                // (drained: nothing of it waits on its enqueue thread)
+    if (!ctx->ev_sort) GS_HIP(hipEventCreateWithFlags(&ctx->ev_sort, hipEventDisableTiming));
+    const int rc = lane_rc(ctx, B, gs_run_sort(B, view, cutout16, nullptr, 0));
+    B->have_sort = false;                                        // (not an order to draw from until it has been collected)
+    if (rc != GS_OK) return rc;
+    LANE_HIP(B, hipMemcpyAsync(B->ctl_host, B->ctl, sizeof(GsControl), hipMemcpyDeviceToHost, B->stream));
+    LANE_HIP(B, hipEventRecord(ctx->ev_sort, B->stream));
+    ctx->pend_lane = back + 1; ctx->pend_n = ctx->n;
+    return GS_OK;
+}
+
+GS_API int gs_sort_poll(gs_ctx *ctx, int wait, uint32_t *out_idx, uint32_t *out_n, int *done)
+{
+    CHECK_CTX(ctx);
+    if (!done) FAIL(GS_E_BADARG, "gs_sort_poll: done is NULL");
+    *done = 1;
+    if (out_n) *out_n = 0;
+    if (!ctx->pend_lane) return GS_OK;
+    if (ctx->pend_lane < 0) {                                    // begun before any push
+        ctx->pend_lane = 0;
+        if (ctx->n == 0) { if (out_idx) out_idx[0] = 0; if (out_n) *out_n = 1; return GS_OK; }
+        FAIL(GS_E_STATE, "gs_sort_poll: the sort was begun on an empty context and splats were pushed since: begin it again");
+    }
+    GS_HIP(hipSetDevice(ctx->device));
+    const int back = ctx->pend_lane - 1;
+    gs_ctx *B = ctx->lanes[back];
+    if (!wait) {
+        const hipError_t e = hipEventQuery(ctx->ev_sort);
+        if (e == hipErrorNotReady) { *done = 0; return GS_OK; }
+        if (e != hipSuccess) { ctx->pend_lane = 0; FAIL(GS_E_HIP, "hipEventQuery failed: %s", hipGetErrorString(e)); }
+    } else GS_HIP(hipEventSynchronize(ctx->ev_sort));
+    ctx->pend_lane = 0;
+    if (ctx->pend_n != ctx->n || B->n != ctx->n || !B->sorted) {
+        // the resident data changed under the sort (pushes drain every lane and drop the lanes' orders): over what is resident now
+        gs_ctx *L = nullptr;
+        TRY(get_lane(ctx, back, &L));
+        TRY(lane_rc(ctx, L, gs_run_sort(L, L->sv_view, L->sv_has_cutout ? L->sv_cutout : nullptr, nullptr, 0)));
+        LANE_HIP(L, hipMemcpyAsync(L->ctl_host, L->ctl, sizeof(GsControl), hipMemcpyDeviceToHost, L->stream));
+        LANE_HIP(L, hipStreamSynchronize(L->stream));
+        B = L;
+    }
+    const uint32_t V = B->ctl_host->n_kept;
+    B->have_sort = true; B->stats.n_sorted = V; B->sorted_n_host = V;
+    if (out_n) *out_n = V;
+    if (out_idx && V) GS_HIP(hipMemcpy(out_idx, B->sorted, (size_t)V * 4, hipMemcpyDeviceToHost));
+    // the new order is the one the draws use from here on (the reply handler, index.js:201-207)
+    ctx->cur = back; ctx->rot = 2 * back; ctx->cur_async = false;
+    log_sort(B, B->sv_view, B->sv_has_cutout ? B->sv_cutout : nullptr, nullptr);
     return GS_OK;
 }
 
@@ -1287,7 +1354,7 @@ int gs_fill_uniforms(gs_ctx *ctx /* owner: options, adaptive share, scene */, co
         FAIL(GS_E_BADARG, "scene inputs are %dx%d but the frame is %dx%d", ctx->scene_w, ctx->scene_h, p->fb_width, p->fb_height);
     u.skip_round1 = (u.near_count != 0xFFFFFFFFu && round1_skippable(ctx)) ? 1u : 0u;
     // sub-tile lists in the blend (GS_OPT_SUBTILE): where the last collected frame's visible splats touched few tiles each
-    static const double subtile_ratio = getenv("GS_SUBTILE_RATIO") ? atof(getenv("GS_SUBTILE_RATIO")) : 8.0;
+    static const double subtile_ratio = getenv("GS_SUBTILE_RATIO") ? atof(getenv("GS_SUBTILE_RATIO")) : 16.0;
     u.subtile = ctx->subtile_opt == 2 ? 1u : (ctx->subtile_opt == 1 && ctx->last_visible && (double)ctx->last_pairs < subtile_ratio * (double)ctx->last_visible ? 1u : 0u);
     return GS_OK;
 }
@@ -1434,6 +1501,7 @@ int gs_render_uniforms(gs_ctx *ctx, const GsFrameUniforms &u_in, void *device_rg
     if (!L->async_pending) L->status_base = L->status_seq;       // (nothing of the lane waits for a collection: the frames to come count from here)
     if (!u.status) { u.status = &L->ctl->status_ring[L->status_seq % GS_STATUS_RING]; L->status_seq++; }
     L->status_cur = u.status;
+    L->stats.subtile = u.subtile;
     u.need_seed = L->need_seed_pending; L->need_seed_pending = 0;  // (a seed for the lane's need words travels with its next frame)
     bool async = (u.flags & GS_RENDER_ASYNC) && !(u.flags & GS_RENDER_COUNT_FRAGS);
     // A context that has not MEASURED its share yet (fresh, cleared, the share un-pinned) draws its first two-round frame synchronously

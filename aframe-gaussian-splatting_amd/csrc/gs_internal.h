@@ -288,6 +288,10 @@ struct gs_ctx {
     int sort_share_permille;       // owner: GS_OPT_SORT_SHARE (0 = every rank sorts every frame)
     bool adapt_frozen;             // owner: gs_sync is drawing flagged frames again: their counters do not feed the adaptive share
     bool log_stale;                // owner: the resident data / scene changed under frames that are still in the logs
+    int pend_lane;                 // owner: lane + 1 of the sort begun with gs_sort_begin and not yet collected by gs_sort_poll (0 = none; -1: begun before
+                                   // any push: the reference's [0] reply is owed)
+    hipEvent_t ev_sort;            // owner: behind that sort's kernels and the copy of its control block
+    size_t pend_n;                 // owner: splats resident when it was begun
     gs_stats stats;
 };
 

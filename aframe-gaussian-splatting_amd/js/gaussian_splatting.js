@@ -112,16 +112,35 @@ class GaussianSplatting {
     } finally { this.sortReady = true; }
   }
 
-  // The reference's rhythm: tick posts the sort and returns; the reply handler installs the new order and re-arms
-  // sortReady (index.js:201-207, 438-455).  Returns the promise of the order, or null while a sort is in flight.
+  // The reference's rhythm: tick posts the sort and returns; the reply handler installs the new order and re-arms sortReady
+  // (index.js:201-207, 438-455) -- and every frame drawn meanwhile uses the last COMPLETED order.  Returns the promise of the order,
+  // or null while a sort is in flight.  render() / frame-less draws stay callable in between (they draw the old order); the new
+  // order is installed when the promise resolves.  No second thread: gs_sort_begin enqueues the sort on a pipeline lane of its own,
+  // the promise polls it (gs_sort_poll) from the event loop.
   tickAsync(camera) {
     if (!this.sortReady) return null;
     this.sortReady = false;
     const u = this._tickUniforms(camera);
-    return native.sortAsync(this.handle, u.view, u.cutout).then((indexes) => {
-      this.sortedIndexes = indexes; this.instanceCount = indexes.length; this.sortReady = true;
-      return indexes;
-    }, (e) => { this.sortReady = true; throw e; });
+    try { native.sortBegin(this.handle, u.view, u.cutout); } catch (e) { this.sortReady = true; throw e; }
+    return new Promise((resolve, reject) => {
+      const poll = () => {
+        if (this.sortReady) { resolve(this.sortedIndexes); return; }            // (collected meanwhile by tickFinish)
+        let indexes;
+        try { indexes = native.sortPoll(this.handle, false, true); } catch (e) { this.sortReady = true; reject(e); return; }
+        if (indexes === null) { setImmediate(poll); return; }
+        this.sortedIndexes = indexes; this.instanceCount = indexes.length; this.sortReady = true;
+        resolve(indexes);
+      };
+      setImmediate(poll);
+    });
+  }
+
+  // the same reply collected at once (blocks until the posted sort has run): what a caller without an event loop turn to spare does
+  tickFinish() {
+    if (this.sortReady) return this.sortedIndexes;
+    const indexes = native.sortPoll(this.handle, true, true);
+    this.sortedIndexes = indexes; this.instanceCount = indexes.length; this.sortReady = true;
+    return indexes;
   }
 
   _tickUniforms(camera) {

@@ -54,7 +54,13 @@ static void held_release(napi_env env, gs_held *h)               /* the GPU is d
 }
 static void held_free(napi_env env, gs_held *h) { held_release(env, h); free(h->refs); h->refs = NULL; h->cap = 0; }
 
-typedef struct gs_handle { gs_ctx *ctx; int busy; gs_held held; } gs_handle;
+/* The index list a sort hands back (the worker's reply {sortedIndexes}, index.js:587-596) lands in page-locked memory owned by the handle
+ * and wrapped ONCE in an external ArrayBuffer: a tick costs no allocation and no copy besides the device-to-host one (round 5: a
+ * malloc, the copy into a fresh ArrayBuffer and its zero fill were a third of tick() + render() at 1 M splats).  The Uint32Array a
+ * sort returns is therefore overwritten by the next sort of the same context -- the reference's consumer copies the reply into its
+ * instanced attribute at once (index.js:201-203).  The buffer grows with the scene; an outgrown one stays alive as long as JavaScript
+ * holds an array over it (its finalizer frees the page-locked memory). */
+typedef struct gs_handle { gs_ctx *ctx; int busy; gs_held held; uint32_t *idx; size_t idx_cap; napi_ref idx_ab; } gs_handle;
 
 static void ctx_finalize(napi_env env, void *data, void *hint)
 {
@@ -62,6 +68,7 @@ static void ctx_finalize(napi_env env, void *data, void *hint)
     gs_handle *h = (gs_handle *)data;
     if (!h) return;
     if (h->ctx) gs_destroy(h->ctx);                              /* (drains the device first) */
+    if (h->idx_ab) napi_delete_reference(env, h->idx_ab);         /* (the ArrayBuffer's finalizer frees the memory) */
     held_free(env, &h->held);
     free(h);
 }
@@ -285,6 +292,23 @@ static int get_sort_args(napi_env env, napi_value vview, napi_value vcut, float 
     return 1;
 }
 
+static void idx_host_finalize(napi_env env, void *data, void *hint) { (void)env; (void)hint; gs_host_free(data); }
+
+/* the handle's page-locked index buffer for the splats resident now, as its external ArrayBuffer */
+static int index_buffer(napi_env env, gs_handle *h, napi_value *ab)
+{
+    size_t cap = gs_count(h->ctx); if (cap < 1) cap = 1;
+    if (h->idx && h->idx_cap >= cap && h->idx_ab && napi_get_reference_value(env, h->idx_ab, ab) == napi_ok && *ab) return 1;
+    if (h->idx_ab) { napi_delete_reference(env, h->idx_ab); h->idx_ab = NULL; }    /* (outgrown: JavaScript's arrays keep it alive) */
+    cap += cap / 4;                                               /* (a scene that is still streaming in: not every push a new buffer) */
+    uint32_t *p = (uint32_t *)gs_host_alloc(cap * 4);
+    if (!p) { napi_throw_error(env, NULL, "page-locked allocation for the index list failed"); return 0; }
+    if (napi_create_external_arraybuffer(env, p, cap * 4, idx_host_finalize, NULL, ab) != napi_ok) { gs_host_free(p); napi_throw_error(env, NULL, "external arraybuffer"); return 0; }
+    if (napi_create_reference(env, *ab, 1, &h->idx_ab) != napi_ok) { h->idx_ab = NULL; napi_throw_error(env, NULL, "reference"); return 0; }
+    h->idx = p; h->idx_cap = cap;
+    return 1;
+}
+
 /* sort(h, view[4], cutout[16] | undefined, wantIndexes = true) -> Uint32Array (worker reply `sortedIndexes`) */
 static napi_value fn_sort(napi_env env, napi_callback_info info)
 {
@@ -301,15 +325,13 @@ static napi_value fn_sort(napi_env env, napi_callback_info info)
         if (rc != GS_OK) return throw_gs(env, ctx, rc);
         return NULL;
     }
-    size_t cap = gs_count(ctx); if (cap < 1) cap = 1;
-    uint32_t *tmp = (uint32_t *)malloc(cap * 4), n = 0;
-    if (!tmp) { napi_throw_error(env, NULL, "out of memory"); return NULL; }
-    int rc = gs_sort(ctx, view, cutp, tmp, &n);
-    if (rc != GS_OK) { free(tmp); return throw_gs(env, ctx, rc); }
-    napi_value ab, ta; void *out;
-    if (napi_create_arraybuffer(env, (size_t)n * 4, &out, &ab) != napi_ok) { free(tmp); napi_throw_error(env, NULL, "arraybuffer"); return NULL; }
-    memcpy(out, tmp, (size_t)n * 4);
-    free(tmp);
+    gs_handle *h = get_handle(env, argv[0]);
+    napi_value ab;
+    if (!index_buffer(env, h, &ab)) return NULL;
+    uint32_t n = 0;
+    int rc = gs_sort(ctx, view, cutp, h->idx, &n);
+    if (rc != GS_OK) return throw_gs(env, ctx, rc);
+    napi_value ta;
     NAPI_OK(napi_create_typedarray(env, napi_uint32_array, n, ab, 0, &ta));
     return ta;
 }
@@ -481,6 +503,42 @@ static napi_value fn_sort_async(napi_env env, napi_callback_info info)
     a->idx = (uint32_t *)malloc(a->cap * 4);
     if (!a->idx) { free(a); napi_throw_error(env, NULL, "out of memory"); return NULL; }
     return async_start(env, a, argv[0], "gs_sort");
+}
+
+/* The reference's rhythm without a second thread (gs_sort_begin / gs_sort_poll, index.js:201-207, 438-455): sortBegin posts the sort
+ * and returns; render() / renderInto() keep drawing from the last completed order; sortPoll(h, wait, wantIndexes) returns null while
+ * the sort runs, else installs the new order and returns it (Uint32Array; `true` if wantIndexes is false). */
+static napi_value fn_sort_begin(napi_env env, napi_callback_info info)
+{
+    napi_value argv[3];
+    if (!get_args(env, info, 3, argv, NULL)) return NULL;
+    gs_ctx *ctx = get_ctx(env, argv[0]); if (!ctx) return NULL;
+    float view[4], cut[16];
+    const float *cutp = NULL;
+    if (!get_sort_args(env, argv[1], argv[2], view, cut, &cutp)) return NULL;
+    const int rc = gs_sort_begin(ctx, view, cutp);
+    if (rc != GS_OK) return throw_gs(env, ctx, rc);
+    return NULL;
+}
+
+static napi_value fn_sort_poll(napi_env env, napi_callback_info info)
+{
+    napi_value argv[3];
+    if (!get_args(env, info, 3, argv, NULL)) return NULL;
+    gs_ctx *ctx = get_ctx(env, argv[0]); if (!ctx) return NULL;
+    bool wait = false, want = true;
+    if (!is_nullish(env, argv[1])) NAPI_OK(napi_get_value_bool(env, argv[1], &wait));
+    if (!is_nullish(env, argv[2])) NAPI_OK(napi_get_value_bool(env, argv[2], &want));
+    gs_handle *h = get_handle(env, argv[0]);
+    napi_value ab = NULL, res;
+    if (want && !index_buffer(env, h, &ab)) return NULL;
+    uint32_t n = 0; int done = 0;
+    const int rc = gs_sort_poll(ctx, wait ? 1 : 0, want ? h->idx : NULL, &n, &done);
+    if (rc != GS_OK) return throw_gs(env, ctx, rc);
+    if (!done) { NAPI_OK(napi_get_null(env, &res)); return res; }
+    if (!want) { NAPI_OK(napi_get_boolean(env, true, &res)); return res; }
+    NAPI_OK(napi_create_typedarray(env, napi_uint32_array, n, ab, 0, &res));
+    return res;
 }
 
 /* renderAsync(h, params, frameUint8Array) -> Promise<frame> */
@@ -659,7 +717,7 @@ static napi_value fn_stats(napi_env env, napi_callback_info info)
     PUT("nFrags", s.n_frags); PUT("nTiles", s.n_tiles); PUT("msSort", s.ms_sort); PUT("msProject", s.ms_project);
     PUT("msBin", s.ms_bin); PUT("msBlend", s.ms_blend); PUT("msRender", s.ms_render);
     PUT("accFrames", s.acc_frames); PUT("unsatTiles", s.unsat_tiles); PUT("nearPermille", s.near_permille); PUT("sortRecords", s.sort_records);
-    PUT("retriedFrames", s.retried_frames); PUT("specSorts", s.spec_sorts); PUT("specMisses", s.spec_misses); PUT("needSplats", s.need_splats);
+    PUT("retriedFrames", s.retried_frames); PUT("specSorts", s.spec_sorts); PUT("specMisses", s.spec_misses); PUT("needSplats", s.need_splats); PUT("sortMode", s.sort_mode); PUT("subtile", s.subtile);
 #undef PUT
     return o;
 }
@@ -960,7 +1018,7 @@ static napi_value init(napi_env env, napi_value exports)
         { "create", fn_create }, { "destroy", fn_destroy }, { "clear", fn_clear }, { "pushSplat", fn_push_splat },
         { "pushMatrices", fn_push_matrices }, { "loadPly", fn_load_ply }, { "plyToSplat", fn_ply_to_splat }, { "plyToSplatGpu", fn_ply_to_splat_gpu },
         { "count", fn_count },
-        { "sort", fn_sort }, { "sortAsync", fn_sort_async }, { "render", fn_render }, { "renderInto", fn_render_into },
+        { "sort", fn_sort }, { "sortAsync", fn_sort_async }, { "sortBegin", fn_sort_begin }, { "sortPoll", fn_sort_poll }, { "render", fn_render }, { "renderInto", fn_render_into },
         { "renderAsync", fn_render_async }, { "allocFrame", fn_alloc_frame }, { "sync", fn_sync },
         { "partition", fn_partition }, { "commUniqueId", fn_comm_unique_id }, { "commInit", fn_comm_init },
         { "sortGathered", fn_sort_gathered }, { "renderGathered", fn_render_gathered }, { "readGathered", fn_read_gathered }, { "setScene", fn_set_scene }, { "stats", fn_stats }, { "setOption", fn_set_option },

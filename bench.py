@@ -48,13 +48,14 @@ def main():
     ap.add_argument("--single-process", action="store_true", help="ONE host process drives all --gpus devices (gs_create_multi; the Node.js "
                                                                 "consumer's form) instead of one process per GPU; device frames gathered on the first GPU")
     ap.add_argument("--host-direct", action="store_true", help="with --single-process: every GPU copies its strip straight into one page-locked host frame")
-    ap.add_argument("--config", choices=["C1", "C2", "C3", "C4", "C5"], default=None,
-                    help="a BASELINE.json configuration by name (aframe-gaussian-splatting_amd/bench_configs.py); default C2, or whatever --splats / --size / --cutout / --xr describe")
+    ap.add_argument("--config", choices=["C1", "C2", "C3", "C4", "C5", "R_outside", "R_unsat"], default=None,
+                    help="a BASELINE.json configuration -- or a regime of the headline scene (R_outside: the camera outside the cloud, R_unsat: opacity / 10) -- "
+                         "by name (aframe-gaussian-splatting_amd/bench_configs.py); default C2, or whatever --splats / --size / --cutout / --xr describe")
     ap.add_argument("--no-configs", action="store_true", help="skip the other BASELINE configurations (`configs` in the line; single GPU, default run only)")
     args = ap.parse_args()
     BC = importlib.import_module(PKG + ".bench_configs")
     if args.config:                                          # the table's shape, spelled out for everything below that reads the flags
-        c = BC.CONFIGS[args.config]
+        c = BC.ALL[args.config]
         args.splats = c["splats"]; args.cutout = c["pose"] == "cutout"; args.xr = c["xr"]
         args.size = None if (c["size"] is None or c["size"] == (1920, 1080)) else "%dx%d" % c["size"]
     if args.single_process:
@@ -92,7 +93,9 @@ def main():
     # the configuration: one table (bench_configs.py) says what scene, viewport, poses and LIBRARY OPTIONS each BASELINE.json
     # configuration is measured with; tests/test_as_benched.py draws the same frames with the same option sets and checks them
     cfg_name = BC.name_of(args.splats, [int(v) for v in args.size.lower().split("x")] if args.size else None, args.cutout, args.xr)
-    cfg = BC.CONFIGS[cfg_name] if cfg_name else BC.custom(args.splats, (W, H), args.cutout, args.xr)
+    if args.config in BC.REGIMES:
+        cfg_name = args.config
+    cfg = BC.ALL[cfg_name] if cfg_name else BC.custom(args.splats, (W, H), args.cutout, args.xr)
     n_splats = cfg["splats"]
     rows = BC.make_rows(cfg, synth)
     ctx = capi.Context(local_rank)
@@ -377,6 +380,42 @@ def main():
             t = torch.tensor([steady_fps or 0.0], dtype=torch.float64, device="cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MIN)
             steady_fps = float(t.item()) or None
+    # the same region with whole sorts (GS_OPT_SORT_NEAR = 0: the reference's sort, index.js:507-570, for every frame), same process, same
+    # poses, untimed for `value`: what the tail / near-only sorts of the timed frames are worth
+    whole_sort_fps = same_protocol_fps = None
+    if opts.get("OPT_SORT_NEAR", 1) != 0 and not torch_gather:
+        def best_of_3():
+            for j in range(BC.ASYNC_WARM * LANES):
+                frame(args.warmup + (j % args.steps), capi.RENDER_ASYNC)
+            if sync():
+                return None
+            best = None
+            for _ in range(3):
+                gc.collect(); gc.disable()
+                tw = time.perf_counter()
+                for i in range(args.steps):
+                    frame(args.warmup + i, capi.RENDER_ASYNC)
+                ag = sync()
+                dt = time.perf_counter() - tw
+                gc.enable()
+                if not ag and (best is None or dt < best):
+                    best = dt
+            return args.steps / best if best else None
+        try:
+            ctx.set_option(capi.OPT_SORT_NEAR, 0)
+            whole_sort_fps = best_of_3()
+        finally:
+            ctx.set_option(capi.OPT_SORT_NEAR, opts.get("OPT_SORT_NEAR", 1))
+            sync()
+        # ... and the library's default again, by the same protocol (best of three regions right after each other: `value` is ONE region,
+        # and one region's spread is of the size of the difference)
+        for k in frames_used:
+            frame(k)
+        same_protocol_fps = best_of_3()
+        if world > 1:
+            t = torch.tensor([whole_sort_fps or 0.0, same_protocol_fps or 0.0], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            whole_sort_fps, same_protocol_fps = (float(v) or None for v in t.tolist())
     k2 = max(1, s2["prof_frames"]) / float(max(1, blends_per_step))     # profiled steps
     # (with two frames per launch the HIP events bracket a PAIR's kernels: a frame's share is half of the interval)
     stage = {"ms_sort": s2["sum_ms_sort"] * args.steps / k2 / frame_batch, "ms_project": s2["sum_ms_project"] * args.steps / k2 / frame_batch,
@@ -433,6 +472,7 @@ def main():
                    ", splat buffer replicated, pieces gathered on rank 0 by the C library over RCCL (gs_render_gathered)")
         else:
             par = "single GPU" + (", both eyes on it" if args.xr else "") + (", gathered path exercised at world 1 (GS_BENCH_COMM)" if comm1 else "")
+        work = BC.timed_work(dict(opts, OPT_PIPELINE_DEPTH=max(LANES, depth)), s)
         out = {
             "metric": metric,
             "value": round(fps, 3), "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
@@ -442,10 +482,8 @@ def main():
                        "multi_gpu_path": path_tried if world > 1 else None,
                        "pieces_of_rank0": [[v, x0, x1] for v, x0, x1 in mine], "gathered_frame_equals_single_gpu_render": frame_check,
                        "blend_split_min_list": blend_split, "sort_share_permille": sort_share if world > 1 else 0,
-                       "frames_in_flight": ("%d (the library's 3 pipeline lanes%s: every frame still runs its own full sort, projection, "
-                                            "binning and blend; consecutive frames overlap on the GPU); see latency.fps_depth1 for one frame at a time"
-                                            % (3 * frame_batch, " x 2 frames per launch, GS_OPT_FRAME_BATCH: the two frames of a pair share each "
-                                               "kernel launch, grid (x, 2), on separate scratch" if frame_batch == 2 else "")),
+                       "sort_mode": work["sort_mode"], "near_permille": work["near_permille"], "frames_in_flight": work["frames_in_flight"],
+                       "timed_work": work["text"] + "; see latency.fps_depth1 for one frame at a time",
                        "frames_per_launch": frame_batch,
                        "preroll_frames": preroll + BC.ASYNC_WARM * max(LANES, depth) + args.warmup,
                        "preroll_note": "untimed, before the region: %d synchronous frames, one pass over the region's own poses (the library sets the share "
@@ -456,6 +494,15 @@ def main():
                        "fill_drain_share": round(max(0.0, 1.0 - fps / steady_fps), 4) if steady_fps else None,
                        "frames_redrawn_by_sync": s.get("retried_frames", 0),
                        "near_only_sorts_from_the_depth_pass_stash": [s.get("spec_sorts", 0), s.get("spec_misses", 0)]},
+            # what was timed, at the top level (VERDICT r5 "next" #3): the sort's form, the share of the order a frame binned and blended,
+            # and the same region with whole sorts
+            "sort_mode": work["sort_mode"], "near_permille": work["near_permille"],
+            "whole_sort_fps": round(whole_sort_fps, 1) if whole_sort_fps else None,
+            "sort_mode_ab": {"whole_sorts_fps": round(whole_sort_fps, 1) if whole_sort_fps else None,
+                             "default_sorts_fps": round(same_protocol_fps, 1) if same_protocol_fps else None,
+                             "note": "the timed region again after `value` was taken, best of three regions each, same process and poses: with "
+                                     "GS_OPT_SORT_NEAR = 0 (every frame the reference's whole sort) and with the library's default (sort_mode)"},
+            "cold_orbit_fps_first_lap": None,                 # filled in from secondary_measurements (single GPU)
             "occlusion_binning": {"near_permille": s["near_permille"], "unsat_tiles_last_frame": s["unsat_tiles"],
                                   "timed_region_retries": retries},
             "msplat_frags_per_s": round(total_frags / 1e6 / elapsed, 1),
@@ -488,6 +535,7 @@ def main():
         }
         if extras:
             out.update(extras)
+            out["cold_orbit_fps_first_lap"] = (extras.get("cold_orbit") or {}).get("fps_first_lap")
         # one roofline entry per stage of the headline frame ("per kernel and per frame"), counter bytes beside them
         try:
             out["rooflines"] = stage_rooflines(out["per_frame"], n_splats, V, Vp, I, own_px, pmc_cfg)
@@ -502,6 +550,18 @@ def main():
                     out["configs"][other] = measure_config(other, capi, synth, BC, cs, cw, ctx.device)
                 except Exception as e:                                    # noqa: BLE001
                     out["configs"][other] = {"error": (type(e).__name__ + ": " + str(e))[:300]}
+            # ... and the regimes of the headline scene the headline pose does not show, measured the same way (bench_configs.REGIMES;
+            # drawn and checked as benched by tests/test_as_benched.py), with the blend's lane utilisation
+            out["regimes"] = {}
+            for other in sorted(BC.REGIMES):
+                try:
+                    out["regimes"][other] = measure_config(other, capi, synth, BC, cs, cw, ctx.device, utilisation=True)
+                except Exception as e:                                    # noqa: BLE001
+                    out["regimes"][other] = {"error": (type(e).__name__ + ": " + str(e))[:300]}
+            try:
+                out["lane_utilisation"] = lane_utilisation(ctx, capi, cams, views, W, H, sample)
+            except Exception as e:                                        # noqa: BLE001
+                out.setdefault("extras_failed", {})["lane_utilisation"] = repr(e)[:200]
         if world == 1 and not args.no_cpu_baseline and not args.xr:
             out["cpu_baseline"] = cpu_baseline(rows, cams[args.warmup % ORBIT_FRAMES], synth)
         if (args.size or args.cutout or args.splats) and not args.xr:
@@ -1069,10 +1129,52 @@ def stage_rooflines(per_frame, N, V, Vp, I, fb_px, pmc_cfg=None):
     return out
 
 
-def measure_config(name, capi, synth, BC, steps, warmup, device=0):
+def lane_utilisation(ctx, capi, cams, views, w, h, sample):
+    """fragments_passed / (list entries a tile's wavefront stepped through x 256 pixels), over the sample poses (VERDICT r5 "next" #1a): how
+    much of the blend's per-entry work lands on pixels the entry covers.  Measured untimed and synchronously with early termination on,
+    one binning round: fragments = GS_RENDER_COUNT_FRAGS | GS_RENDER_COUNT_EVALUATED, entries = GS_OPT_RECORD_STAGED = 2 (per tile: the
+    entries its longest-lived lane evaluated; with sub-tile lists: the steps' entries of its longest block list).  Both with the
+    sub-tile setting the timed frames ran with (GS_OPT_SUBTILE = 1: the library decides) and with the lists off."""
+    ntl = ((w + 15) // 16) * ((h + 15) // 16)
+    out = {}
+    try:
+        ctx.sync()
+    except capi.GsError:
+        pass
+    ctx.set_option(capi.OPT_NEAR_PERMILLE, 1000)
+    try:
+        for label, sub in (("as_benched", 1), ("whole_tile_walk", 0)):
+            ctx.set_option(capi.OPT_SUBTILE, sub)
+            fr, en, on = 0, 0, 0
+            for k in sample:
+                ctx.sort(cams[k]["view"], cams[k]["cutout"], want_indices=False)
+                p = views[k][0]
+                p.flags = 0
+                ctx.render_device(p, None)                        # (the frame GS_OPT_SUBTILE = 1 decides from)
+                p.flags = capi.RENDER_COUNT_FRAGS | capi.RENDER_COUNT_EVALUATED
+                ctx.render_device(p, None)
+                fr += ctx.stats()["n_frags"]
+                ctx.set_option(capi.OPT_RECORD_STAGED, 2)
+                p.flags = 0
+                ctx.render_device(p, None)
+                on += ctx.stats().get("subtile", 0)
+                en += int(ctx.download(capi.BUF_TILE_STATS, ntl, np.uint32, 2)[:, 0].astype(np.int64).sum())
+                ctx.set_option(capi.OPT_RECORD_STAGED, 0)
+            out[label] = {"fragments_passed_per_frame": round(fr / len(sample)), "entries_walked_per_frame": round(en / len(sample)),
+                          "lane_utilisation": round(fr / max(1.0, en * 256.0), 4), "subtile_lists": bool(on)}
+    finally:
+        ctx.set_option(capi.OPT_RECORD_STAGED, 0)
+        ctx.set_option(capi.OPT_SUBTILE, 1)
+        ctx.set_option(capi.OPT_NEAR_PERMILLE, 0)
+    out["note"] = ("fragments that pass the coverage test (index.js:171-172) with early termination on / (entries walked x 256 pixels); "
+                   "%d sample poses, one binning round, untimed" % len(sample))
+    return out
+
+
+def measure_config(name, capi, synth, BC, steps, warmup, device=0, utilisation=False):
     """One BASELINE configuration other than the headline's, measured like the headline (same table of options, same pre-roll, frames
     queued between two syncs) in a context of its own: frames/s, the per-frame stage times and counts, the stage furthest up its roof."""
-    cfg = BC.CONFIGS[name]
+    cfg = BC.ALL[name]
     rows = BC.make_rows(cfg, synth)
     cams, views, w, h = BC.poses(cfg, synth, capi)
     nv = len(views[0])
@@ -1134,9 +1236,14 @@ def measure_config(name, capi, synth, BC, steps, warmup, device=0):
         rl = stage_rooflines(pf, cfg["splats"], pf["V_sorted"], pf["Vp_visible"], pf["I_pairs"], w * h)
         dom = max(rl, key=lambda r: r["us"])
         fps = steps / elapsed
+        work = BC.timed_work(opts, s2)
+        util = None
+        if utilisation:
+            util = lane_utilisation(ctx, capi, cams, views, w, h, used[:: max(1, len(used) // 4)][:4])
         return {"frames_per_s": round(fps, 1), "ms_per_step": round(elapsed / steps * 1e3, 4), "steps": steps, "warmup": warmup,
                 "workload": BC.DESCRIPTION[name], "size": [w, h], "views_per_frame": nv, "library_options": opts,
-                "near_permille": s2["near_permille"], "frames_redrawn_by_sync": s2.get("retried_frames", 0),
+                "near_permille": s2["near_permille"], "sort_mode": work["sort_mode"], "subtile_lists": bool(s2.get("subtile")), "timed_work": work["text"],
+                "lane_utilisation": util, "frames_redrawn_by_sync": s2.get("retried_frames", 0),
                 "per_frame": pf, "per_frame_note": "stage times per VIEW drawn (HIP events, pipelined loop)" if nv > 1 else "stage times per frame (HIP events, pipelined loop)",
                 "dominant_stage": {"stage": dom["stage"], "us": dom["us"], "bound": dom["bound"], "frac": dom["frac"]},
                 "rooflines": [{k: r[k] for k in ("stage", "bound", "algorithmic_bytes", "us", "achieved", "frac")} for r in rl]}

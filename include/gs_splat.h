@@ -104,6 +104,20 @@ GS_API size_t gs_count(const gs_ctx *ctx);
  * so does this (out_n = 1, out_idx[0] = 0). */
 GS_API int gs_sort(gs_ctx *ctx, const float view[4], const float *cutout16, uint32_t *out_idx, uint32_t *out_n);
 
+/* The reference's single-flight rhythm (index.js:201-207, 438-455): tick() POSTS the sort to the worker and returns; every frame
+ * three.js draws until the worker's reply arrives uses the last COMPLETED order (the reply handler installs the new index list and
+ * re-arms sortReady).  One caller thread, no blocking:
+ *   gs_sort_begin  enqueues the whole sort for (view, cutout16) on a pipeline lane other than the one the current order lives on and
+ *                  returns at once.  GS_E_STATE while a begun sort has not been collected (the reference's `sortReady` guard,
+ *                  index.js:439-440).  gs_render* / gs_render_stereo keep drawing from the order of the last completed gs_sort /
+ *                  gs_sort_poll meanwhile (before the first one: nothing, as the reference's instanceCount starts at 0).
+ *   gs_sort_poll   *done = 0 if the sort is still running (wait == 0), else installs its order as the one gs_render* draws from,
+ *                  hands it back like gs_sort (out_idx optional, capacity >= max(gs_count(), 1); *out_n its length; begun before any
+ *                  push: [0], index.js:588-590) and sets *done = 1.  wait != 0 blocks until then.  Nothing begun: *done = 1, *out_n = 0.
+ * Splats pushed between the two calls: the sort is run again over what is resident when it is collected. */
+GS_API int gs_sort_begin(gs_ctx *ctx, const float view[4], const float *cutout16);
+GS_API int gs_sort_poll(gs_ctx *ctx, int wait, uint32_t *out_idx, uint32_t *out_n, int *done);
+
 /* ---- render (reference: vertex shader + rasteriser + fragment shader + blend, index.js:77-195) ------- */
 
 #define GS_RENDER_FLIP_Y 1u      /* rows bottom-up (WebGL readPixels order) instead of top-down              */
@@ -382,6 +396,10 @@ typedef struct gs_stats {
     uint32_t need_splats; /* how many of the NEAREST splats the last collected frames' tiles read before they were saturated (max over
                              the tiles; 0xFFFFFFFF: a tile no share saturates): what near_permille is set from, with a margin of
                              15 % that shrinks to 4 % while no frame misses                                                        */
+    uint32_t sort_mode;   /* how the last collected frame's depth sort ran: 0 = the whole order (the reference's, index.js:507-570); near-only
+                             forms (GS_OPT_SORT_NEAR): 1 = threshold from a depth histogram, 2 = candidates from the depth pass' own stash,
+                             3 = tail sort (the segments the frame does not read neither scattered nor sorted)                       */
+    uint32_t subtile;     /* 1 if the last frame's blend walked sub-tile lists (GS_OPT_SUBTILE)                                        */
 } gs_stats;
 
 #define GS_OPT_PROFILE 1        /* 1: bracket every stage with HIP events on the frame's stream (7 per frame); 2: only
@@ -419,8 +437,8 @@ typedef struct gs_stats {
                                    tile's sixteen 4x4-pixel blocks (which blocks an entry's ellipse can reach is worked out from its record when
                                    it is staged) and takes as many steps as the longest of them -- worth it where splats are small against a
                                    tile (the cloud seen from outside: a list entry covers a fifth of its tile).  0: never; 1 (default): in
-                                   frames that follow collected frames whose visible splats touched fewer than 8 tiles each on average
-                                   (GS_SUBTILE_RATIO in the environment overrides the 8); 2: always (a batch of large splats is still walked
+                                   frames that follow collected frames whose visible splats touched fewer than 16 tiles each on average
+                                   (GS_SUBTILE_RATIO in the environment overrides the 16); 2: always (a batch of large splats is still walked
                                    whole: the decision is per batch).                                                              */
 #define GS_OPT_ENQUEUE_THREADS 7 /* default 1: gs_sort() (without an output array) and gs_render_device(GS_RENDER_ASYNC) hand the
                                    frame to a worker thread of its pipeline lane, which does the ~18 kernel launches, so the

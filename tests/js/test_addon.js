@@ -114,17 +114,41 @@ comp.loadData(camera, object, null, scenePath, 100003).then((n) => {
   const strip = comp.render(camera, { width: Number(W), height: Number(H), x0: 16, x1: 48 });
   ok(strip.length === 32 * H * 4, 'strip size');
   ok(comp.render(camera, { width: Number(W), height: Number(H) }) === img, 'the frame buffer is reused (page-locked, no per-call allocation)');
-  // ---- the reference's rhythm: fire-and-forget sort, single flight (index.js:201-207, 438-455), draw off the JS thread
+  // ---- the reference's rhythm: fire-and-forget sort, single flight (index.js:201-207, 438-455): tick posts the sort, the frames drawn
+  // until its reply arrives use the last COMPLETED order, the reply installs the new one.  Pose A = the order held now; pose B = the
+  // entity turned by 70 degrees.
   const keep = Uint32Array.from(comp.sortedIndexes), keepImg = Uint8Array.from(img);
+  const vp = { width: Number(W), height: Number(H) };
+  const objectA = object, objectB = { matrixWorld: compose([0, 1.5, -2], Number(yaw) + 70) };
+  comp.object = objectB;
+  const staleWant = Uint8Array.from(comp.render(camera, vp));                  // pose B drawn with A's order: what the reference shows meanwhile
+  comp.tick();                                                                  // (synchronously: B's order ...)
+  const keepB = Uint32Array.from(comp.sortedIndexes), freshWant = Uint8Array.from(comp.render(camera, vp));   // ... and B's frame
+  ok(!same(keepB, keep) && !same(freshWant, staleWant), 'the two poses have different orders and the stale order shows');
+  comp.object = objectA; comp.tick(); comp.object = objectB;                   // back to: A's order installed, pose B to come
   const pending = comp.tickAsync();
   ok(pending && typeof pending.then === 'function' && comp.sortReady === false, 'tickAsync posts the sort and returns');
   ok(comp.tickAsync() === null, 'a second tick while the sort is in flight does nothing (sortReady)');
-  let busy = false;
-  try { comp.render(camera, { width: Number(W), height: Number(H) }); } catch (e) { busy = e.code === 'GS_BUSY'; }
-  ok(busy, 'the context refuses other calls while the asynchronous sort owns it');
+  let stale = null, threw = null;
+  try { stale = Uint8Array.from(comp.render(camera, vp)); } catch (e) { threw = e.code || String(e); }
+  ok(threw === null, 'render() while the sort is in flight does not throw (' + threw + ')');
+  ok(stale && same(stale, staleWant), 'render() while the sort is in flight draws with the last completed order (index.js:201-207)');
+  ok(same(comp.sortedIndexes, keep), 'sortedIndexes is still the completed order');
   return pending.then((idx) => {
-    ok(comp.sortReady === true && comp.instanceCount === idx.length && same(idx, keep), 'asynchronous order == synchronous order');
-    return comp.renderAsync(camera, { width: Number(W), height: Number(H) });
+    ok(comp.sortReady === true && comp.instanceCount === idx.length && same(idx, keepB), 'asynchronous order == synchronous order of the new pose');
+    ok(same(comp.render(camera, vp), freshWant), 'after the reply: render() draws the new order');
+    comp.object = objectA;
+    const p2 = comp.tickAsync();
+    ok(same(comp.tickFinish(), keep) && comp.sortReady === true, 'tickFinish() collects the posted sort at once');
+    return p2;
+  }).then(() => {
+    ok(same(comp.render(camera, vp), keepImg), 'pose A again, through the posted sort');
+    // the draw off the JS thread (napi_async_work) still owns the context while it runs: a context is single-caller
+    const pr = comp.renderAsync(camera, vp);
+    let busy = false;
+    try { comp.render(camera, vp); } catch (e) { busy = e.code === 'GS_BUSY'; }
+    ok(busy, 'the context refuses other calls while renderAsync owns it');
+    return pr;
   }).then((img2) => {
     ok(same(img2, keepImg), 'asynchronous frame == synchronous frame');
     // JS-visible rate: tick + render into the reused page-locked frame, synchronously, one frame at a time

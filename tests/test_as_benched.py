@@ -28,11 +28,11 @@ synth = pkg("synth")
 BC = pkg("bench_configs")
 
 WARMUP = 5                                                    # the driver's form: bench.py --steps 20 --warmup 5
-STEPS = {"C1": 20, "C2": 20, "C3": 12, "C4": 10, "C5": 8}     # poses of that region queued and checked (the big ones: its first poses)
+STEPS = {"C1": 20, "C2": 20, "C3": 12, "C4": 10, "C5": 8, "R_outside": 12, "R_unsat": 12}     # poses of that region queued and checked (the big ones: its first poses)
 GOLDENS = {"C1": ["gl_c1_1m_720p_strip", "gl_c1_1m_720p_frame"], "C2": ["gl_c2_1m_1080p_strip", "gl_c2_1m_1080p_frame"],
            "C3": ["gl_c3_6m_cutout_strip", "gl_c3_6m_cutout_frame"], "C4": [("gl_c4_xr_left_eye_frame", "gl_c4_xr_right_eye_frame")],
-           "C5": ["gl_c5_20m_4k_strip"]}
-BIT_EXACT = {"C1": True, "C2": True, "C3": False, "C4": True, "C5": True}
+           "C5": ["gl_c5_20m_4k_strip"], "R_outside": [], "R_unsat": []}
+BIT_EXACT = {"C1": True, "C2": True, "C3": False, "C4": True, "C5": True, "R_outside": True, "R_unsat": True}
 
 
 def _golden_pose(names, W, H):
@@ -54,12 +54,15 @@ def _golden_pose(names, W, H):
     return {"view": view, "cutout": cutm, "params": prm, "fixtures": fx, "names": names}
 
 
-@pytest.mark.parametrize("name", ["C1", "C2", "C3", "C4", "C5"])
+@pytest.mark.parametrize("name", ["C1", "C2", "C3", "C4", "C5", "R_outside", "R_unsat"])
 def test_every_baseline_configuration_as_bench_py_draws_it(name):
+    """(R_outside / R_unsat: the regimes of the headline scene bench.py reports next to the configurations -- the camera outside the cloud,
+    opacity / 10 -- bench_configs.REGIMES.  Their reference context walks whole tiles, GS_OPT_SUBTILE = 0: the sub-tile lists the library
+    switches on for small splats must not change a pixel; one strip of each is also held against the oracle.)"""
     if name in ("C3", "C5") and os.environ.get("GS_SKIP_SLOW") == "1":
         pytest.skip("large configs")
     import torch
-    cfg = BC.CONFIGS[name]
+    cfg = BC.ALL[name]
     rows = np.asarray(BC.make_rows(cfg, synth, cache=cached_rows))
     cams, views, W, H = BC.poses(cfg, synth, capi)
     nv = len(views[0])
@@ -131,6 +134,10 @@ def test_every_baseline_configuration_as_bench_py_draws_it(name):
 
         # (a) the same poses, one by one, from a context with default options
         BC.push_rows(ref, rows)
+        if name in BC.REGIMES:
+            ref.set_option(capi.OPT_SUBTILE, 0)
+            if name == "R_outside":
+                assert s1["subtile"] == 1, "outside the cloud the library is expected to switch the sub-tile lists on by itself"
         worst = 0
         for sp, fr in zip(specs, got):
             ref.sort(sp["view"], sp["cutout"], want_indices=False)
@@ -153,5 +160,17 @@ def test_every_baseline_configuration_as_bench_py_draws_it(name):
             for v, c in enumerate(gp["fixtures"]):
                 x0, x1 = c["meta"]["strip"]
                 _glpin.gl_compare(fr[v][:, x0:x1], None, c, "as benched (%s) vs GLSL-on-Mesa: %s" % (name, gp["names"][v]), early_termination=True)
+        # (c) the regimes have no GLSL golden: a 64-pixel strip of their first pose against the oracle (<= 1 LSB, index.js:166-181)
+        if name in BC.REGIMES:
+            from oracle import oracle
+            sp = specs[0]
+            cs, cc, mats = oracle.pack(rows)
+            idx = oracle.sort(np.ascontiguousarray(mats[:, 12:16]), sp["view"], sp["cutout"])
+            p0 = sp["params"][0]
+            xa = (W // 2) & ~15
+            want, _, _ = oracle.render(cs, cc, idx, np.array(p0.model_view, np.float32), np.array(p0.projection, np.float32), np.float32(p0.focal), W, H,
+                                       x0=xa, x1=xa + 64, want_f32=False)
+            d = int(np.abs(got[0][0][:, xa:xa + 64].astype(np.int16) - want.astype(np.int16)).max())
+            assert d <= 1, "%s: the queued frame is %d LSB from the oracle" % (name, d)
         print(name, "ok: %d queued frames %s the default path%s; %d GL golden pose(s)" % (
             len(specs), "bit-identical to" if BIT_EXACT[name] else "within %d LSB of" % worst, "", len(gold)))

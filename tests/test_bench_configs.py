@@ -95,3 +95,44 @@ def test_pushes_are_progressive_and_rows_come_from_the_named_generator():
     assert rows == "cached" and seen == [("make_splat_rows", 64, {"seed": 7})]
     small = BC.make_rows({"rows": ("make_splat_rows", {"seed": 0x5EED0003}), "splats": 256}, synth)
     assert np.asarray(small).size == 256 * 32 and np.array_equal(np.asarray(small), np.asarray(synth.make_splat_rows(256, seed=0x5EED0003)))
+
+
+def test_regimes_are_the_headline_scene_and_resolve_by_name():
+    """bench_configs.REGIMES (VERDICT r5 "next" #1b): the camera outside the cloud and the opacity / 10 scene -- the headline's splats,
+    viewport and options, another pose / another opacity byte; measured by bench.py like the configurations and drawn by
+    tests/test_as_benched.py."""
+    assert sorted(BC.REGIMES) == ["R_outside", "R_unsat"] and sorted(BC.ALL) == sorted(list(BC.CONFIGS) + list(BC.REGIMES))
+    c2 = BC.CONFIGS["C2"]
+    for name, r in BC.REGIMES.items():
+        assert r["splats"] == c2["splats"] and r["size"] == c2["size"] and r["options"] == c2["options"] and r["rows"] == c2["rows"], name
+        assert name in BC.DESCRIPTION
+    assert BC.REGIMES["R_outside"]["pose"] == "outside" and BC.REGIMES["R_unsat"].get("opacity_div") == 10
+    base = np.asarray(BC.make_rows({"rows": ("make_splat_rows", {}), "splats": 512}, synth)).reshape(-1, 32)
+    dim = np.asarray(BC.make_rows({"rows": ("make_splat_rows", {}), "splats": 512, "opacity_div": 10}, synth)).reshape(-1, 32)
+    assert np.array_equal(dim[:, :27], base[:, :27]) and np.array_equal(dim[:, 28:], base[:, 28:]) and np.array_equal(dim[:, 27], base[:, 27] // 10)
+    capi = pkg("capi")                                                           # (host-side helpers only: no device call)
+    cams, views, w, h = BC.poses(BC.REGIMES["R_outside"], synth, capi, frames=[0, 7])
+    want = synth.outside_cloud_camera(1920, 1080, 21.0, capi=capi)
+    assert (w, h) == (1920, 1080) and np.array_equal(cams[7]["view"], want["view"]) and np.allclose(np.array(views[7][0].model_view), want["gs_mv"].astype(np.float32))
+
+
+def test_timed_work_says_what_the_option_set_and_statistics_say():
+    """config.timed_work / sort_mode / near_permille of bench.py's line (VERDICT r5 "next" #3) are made HERE from the options applied and
+    the library's statistics: a frame that ran a tail sort over 129 permille of the order must not be described as a full sort."""
+    o2 = {"OPT_FRAME_BATCH": 2}
+    w = BC.timed_work(o2, {"sort_mode": 3, "near_permille": 129, "subtile": 0})
+    assert w["sort_mode"] == "tail" and w["near_permille"] == 129 and w["frames_in_flight"] == 6
+    assert "TAIL sort" in w["text"] and "nearest 129 permille" in w["text"] and "second binning round" in w["text"] and "sub-tile" not in w["text"]
+    assert "full sort" not in w["text"] and "whole order" in w["text"]                      # (only as what the positions read equal)
+    w = BC.timed_work(o2, {"sort_mode": 0, "near_permille": 1000, "subtile": 1})
+    assert w["sort_mode"] == "whole" and "sorts every kept splat" in w["text"] and "in one round" in w["text"] and "sub-tile lists" in w["text"]
+    w = BC.timed_work(dict(o2, OPT_SORT_NEAR=0), {"sort_mode": 3, "near_permille": 200})      # the A/B run: whatever the lane's last sort was
+    assert w["sort_mode"] == "whole"
+    w = BC.timed_work({"OPT_PIPELINE_DEPTH": 2}, {"sort_mode": 2, "near_permille": 23})
+    assert w["sort_mode"] == "stash" and w["frames_in_flight"] == 2 and "stashed" in w["text"] and "2 pipeline lanes)" in w["text"]
+    assert BC.timed_work({}, {"sort_mode": 1, "near_permille": 40})["sort_mode"] == "histogram"
+    # bench.py writes these at the top level of its line and does not carry the sentence VERDICT r5 objected to
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert "every frame still runs its own full sort" not in src and "every frame still runs its own full sort" not in open(os.path.join(ROOT, "README.md")).read()
+    for key in ('"sort_mode": work["sort_mode"]', '"whole_sort_fps"', '"cold_orbit_fps_first_lap"', '"near_permille": work["near_permille"]', "BC.timed_work("):
+        assert key in src, key

@@ -1870,3 +1870,67 @@ def test_completion_word_of_asynchronous_frames(scene_small):
         with pytest.raises(capi.GsError) as ei:                            # ... and the root's gs_sync() asks for it (gathered frames: every rank has to take part)
             c.sync()
         assert ei.value.code == capi.E_RETRY
+
+
+@pytest.mark.gpu
+def test_posted_sort_draws_with_the_last_completed_order_until_it_is_collected(scene_small):
+    """gs_sort_begin / gs_sort_poll (round 6): the reference's single-flight rhythm, index.js:201-207, 438-455 -- tick POSTS the sort, the
+    frames drawn until the worker's reply use the last completed order, the reply installs the new one.  Pose A's order drawn at pose
+    B is the 'stale' frame; it must be exactly what a context that never heard of pose B's sort draws."""
+    w, h = 640, 360
+    camA, camB = synth.index_html_camera(w, h, 20.0, capi=capi), synth.index_html_camera(w, h, 95.0, capi=capi)
+    rows = scene_small["rows"]
+    with capi.Context(0) as c:
+        # before any push: the reply is [0] (index.js:588-590), nothing to draw
+        c.sort_begin(camA["view"])
+        assert np.array_equal(c.sort_poll(wait=True), np.zeros(1, np.uint32))
+        assert c.sort_poll() is not None and c.sort_poll(wait=True).size == 0       # nothing begun: done, empty
+        c.push_splat(rows)
+        idxA = c.sort(camA["view"])
+        stale_want = c.render(_params(camB))
+        idxB = c.sort(camB["view"])
+        fresh_want = c.render(_params(camB))
+        assert not np.array_equal(idxA, idxB) and not np.array_equal(stale_want, fresh_want)
+        assert np.array_equal(idxB, oracle.sort(scene_small["mats"], camB["view"]))
+        c.sort(camA["view"], want_indices=False)
+        for rep in range(3):                                                        # (the lanes take turns as front and back)
+            c.sort_begin(camB["view"])
+            with pytest.raises(capi.GsError) as e:
+                c.sort_begin(camB["view"])                                          # sortReady is false (index.js:439-440)
+            assert e.value.code == capi.E_STATE
+            assert np.array_equal(c.render(_params(camB)), stale_want), "a draw while the sort is in flight uses the last completed order"
+            assert np.array_equal(c.render(_params(camB, x0=64, x1=128)), stale_want[:, 64:128])
+            got = None
+            for _ in range(100000):
+                got = c.sort_poll()
+                if got is not None:
+                    break
+            assert got is not None and np.array_equal(got, idxB)
+            assert np.array_equal(c.render(_params(camB)), fresh_want), "after the reply the new order is drawn"
+            c.sort_begin(camA["view"])
+            assert np.array_equal(c.sort_poll(wait=True), idxA)
+            assert np.array_equal(c.render(_params(camB)), stale_want)
+        # with a cutout, and without asking for the index list
+        camC = synth.cutout_demo_camera(w, h, 250.0, capi=capi)
+        c.sort_begin(camC["view"], camC["cutout"])
+        assert c.sort_poll(wait=True, want_indices=False) is True
+        want = c.render(_params(camC))
+        c.sort(camC["view"], camC["cutout"], want_indices=False)
+        assert np.array_equal(c.render(_params(camC)), want)
+        # splats pushed while the sort is in flight: the reply covers what is resident when it is collected
+        more = synth.make_splat_rows(5000, seed=5)
+        c.sort_begin(camA["view"])
+        c.push_splat(more)
+        got = c.sort_poll(wait=True)
+        cs2, cc2, mats2 = oracle.pack(np.concatenate([np.asarray(rows).reshape(-1), np.asarray(more).reshape(-1)]))
+        assert np.array_equal(got, oracle.sort(mats2, camA["view"]))
+        # queued (asynchronous) frames next to a posted sort
+        c.sort(camB["view"], want_indices=False)
+        want_b = c.render(_params(camB))
+        c.sort_begin(camA["view"])
+        buf = capi.host_frame(h, w)
+        c.render_into(_params(camB, flags=capi.RENDER_ASYNC), buf[0])
+        c.sync()
+        assert np.array_equal(buf[0], want_b)
+        assert c.sort_poll(wait=True, want_indices=False) is True
+        buf[1].free()

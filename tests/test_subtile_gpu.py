@@ -130,7 +130,7 @@ def test_subtile_lists_against_the_oracle(w, h, yaw):
 
 def test_subtile_lists_switch_themselves_on_where_splats_are_small():
     """GS_OPT_SUBTILE = 1 (the default): decided from the last collected frame's pairs per visible splat.  Outside the cloud (3-4 tiles
-    per splat) the walk shrinks after the first frame; at the headline pose (dozens of tiles per splat) it stays whole."""
+    per splat, the rule: fewer than 16) the walk shrinks after the first frame; at the headline pose (dozens of tiles per splat) it stays whole."""
     w, h = 1280, 720
     rows = synth.make_splat_rows(200000, seed=99)
     tiles = ((w + 15) // 16) * ((h + 15) // 16)
@@ -159,5 +159,5 @@ def test_subtile_lists_switch_themselves_on_where_splats_are_small():
         assert np.array_equal(ref[0][1], ref[2][1]) and np.array_equal(ref[0][1], ref[1][1])
         ratio = st["n_pairs"] / max(1, st["n_visible"])
         print("pose %s: %.1f tiles per visible splat; entries walked off %d, on %d, auto %d" % (pose.__name__, ratio, ref[0][0], ref[2][0], ref[1][0]))
-        assert (ratio < 8.0) == expect_on
+        assert (ratio < 16.0) == expect_on
         assert ref[1][0] == (ref[2][0] if expect_on else ref[0][0])
