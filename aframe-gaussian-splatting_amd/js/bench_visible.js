@@ -43,11 +43,28 @@ comp.loadData(camera, object, null, scenePath).then((n) => {
   for (let i = 0; i < frames; i++) { pose(i); const f = comp.frameQueued(camera, vp); if (i % depth === depth - 1) { retries += trySync(); sum += f[i % f.length]; } }
   retries += trySync();
   const qSec = Number(process.hrtime.bigint() - t0) / 1e9;
+  // the reference's own rhythm (index.js:201-207, 438-455): every animation frame posts a sort if none is in flight (tickAsync) and draws
+  // with the last completed order; the event loop gets a turn per frame (setImmediate), which is where the reply is collected
+  return (async () => {
+    let sorts = 0;
+    for (let i = 0; i < 24; i++) { pose(i); const p = comp.tickAsync(); if (p) p.then(() => {}); comp.render(camera, vp); await new Promise(setImmediate); }
+    comp.tickFinish();
+    t0 = process.hrtime.bigint();
+    for (let i = 0; i < frames; i++) {
+      pose(i);
+      const p = comp.tickAsync(); if (p) p.then(() => { sorts++; });
+      const img = comp.render(camera, vp); sum += img[(i * 4099) % img.length];
+      await new Promise(setImmediate);
+    }
+    comp.tickFinish();
+    const rhythmSec = Number(process.hrtime.bigint() - t0) / 1e9;
   const st = comp.stats();
   console.log(JSON.stringify({ splats: n, width: W, height: H, frames, queue_depth: depth, node: process.version,
     fps_sync: +(frames / syncSec).toFixed(1), ms_per_frame_sync: +(syncSec / frames * 1e3).toFixed(4),
     fps_tick_render: +(frames / tickSec).toFixed(1), ms_per_frame_tick_render: +(tickSec / frames * 1e3).toFixed(4),
     fps_queued: +(frames / qSec).toFixed(1), queued_GBps: +(frames / qSec * W * H * 4 / 1e9).toFixed(2),
+    fps_posted_sorts: +(frames / rhythmSec).toFixed(1), posted_sorts_completed: sorts,
     sync_retries: retries, frames_redrawn_by_sync: st.retriedFrames !== undefined ? st.retriedFrames : (st.retried_frames || 0), checksum: sum }));
   comp.remove();
+  })();
 }).catch((e) => { console.error('FAIL:', e && e.stack || e); process.exit(1); });

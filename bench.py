@@ -1269,7 +1269,9 @@ def js_visible(rows, w, h):
             return {"error": (str(e) + " " + (r.stderr[-300:] if "r" in dir() else ""))[:400]}
     rep["note"] = ("timed in JavaScript (process.hrtime), a new pose every frame: fps_sync = comp.frame() -- sort (order kept on the GPU) + draw into the "
                    "component's page-locked frame; fps_tick_render = comp.tick() + comp.render(), tick handing the index list back to JavaScript "
-                   "as the reference's worker does; fps_queued = comp.frameQueued() into a ring of 48 page-locked frames, comp.sync() every 48")
+                   "as the reference's worker does; fps_queued = comp.frameQueued() into a ring of 48 page-locked frames, comp.sync() every 48; "
+                   "fps_posted_sorts = the reference's own rhythm (index.js:201-207, 438-455): every frame comp.tickAsync() posts a sort if none is in "
+                   "flight and comp.render() draws with the last completed order, one event-loop turn per frame")
     return rep
 
 
