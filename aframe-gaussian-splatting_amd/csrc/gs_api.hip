@@ -301,7 +301,9 @@ static void share_from_need(gs_ctx *ctx /* owner */, uint32_t need, uint32_t fra
         ctx->need_hist[ctx->need_hist_pos] = 0; ctx->need_hist_frames[ctx->need_hist_pos] = 0;
     }
     if (need > ctx->need_hist[ctx->need_hist_pos]) ctx->need_hist[ctx->need_hist_pos] = need;
-    ctx->need_hist_frames[ctx->need_hist_pos] += frames ? frames : 1u;
+    // (frames gs_sync is drawing AGAIN -- adapt_frozen -- measure, but are no new evidence of a camera at rest: they neither age the window
+    // nor shrink the margin that their own miss has just raised)
+    if (!ctx->adapt_frozen) ctx->need_hist_frames[ctx->need_hist_pos] += frames ? frames : 1u;
     uint32_t m = 0;
     for (int k = 0; k < HN; k++) if (ctx->need_hist[k] > m) m = ctx->need_hist[k];
     float target = 1.0f;                                         // 0xFFFFFFFF: a tile that no share saturates (sky): one round over everything
@@ -312,7 +314,7 @@ static void share_from_need(gs_ctx *ctx /* owner */, uint32_t need, uint32_t fra
         // (down to 1.04: a still or periodic camera needs none, and 10 % of share are 10 % of the binning and the blend's staging), a tenth
         // more after a miss
         if (ctx->need_margin < GS_NEED_MARGIN_MIN) ctx->need_margin = (float)GS_NEED_MARGIN;
-        const float less = 0.01f * (float)(frames > 8u ? frames / 8u : 1u);
+        const float less = ctx->adapt_frozen ? 0.0f : 0.01f * (float)(frames > 8u ? frames / 8u : 1u);
         ctx->need_margin = ctx->need_margin - less < GS_NEED_MARGIN_MIN ? GS_NEED_MARGIN_MIN : ctx->need_margin - less;
         target = (float)((double)m * (double)ctx->need_margin / (double)ctx->n);
         if (target > 0.85f) target = 1.0f;                       // (two rounds over nearly everything cost more than one)
@@ -350,13 +352,16 @@ static void share_missed(gs_ctx *ctx /* owner */, float frac_used)
 // Every lane's words are brought near what the collected frames measured: a lane whose words are far below it (a lane that has drawn
 // nothing yet -- its block is zero --, or nothing of this view) would have EVERY tile of its next frame issue its atomic: 8160 on one
 // line, ~90 us -- the first frame of five lanes after a run of synchronous frames, i.e. the fill of bench.py's twenty-frame region.
-static int seed_need_words(gs_ctx *ctx /* owner */, uint32_t need)
+static int seed_need_words(gs_ctx *ctx /* owner */, uint32_t need, bool idle_only = false)
 {
     if (!need) return GS_OK;
     const uint32_t seed = need == 0xFFFFFFFFu ? need : (uint32_t)((uint64_t)need * 9u / 10u);
     for (int i = 0; i < GS_MAX_LANES; i++) {
         gs_ctx *L = ctx->lanes[i];
         if (!L || !L->ctl) continue;
+        // (from a synchronous frame: a lane with queued, uncollected frames keeps its words -- the seed its next projection would store is the
+        // host's ESTIMATE, and the larger maxima the frames in flight recorded would be lost before gs_sync reads them: ADVICE r5)
+        if (idle_only && L->async_pending) continue;
         const uint32_t have = L->need_word_est;
         const bool stale = need == 0xFFFFFFFFu ? have != 0xFFFFFFFFu : (have != 0xFFFFFFFFu && (uint64_t)have * 10u < (uint64_t)need * 8u);
         if (!stale) continue;
@@ -432,7 +437,9 @@ static int collect_status(gs_ctx *lane, bool *overflowed, bool *share_failed = n
             // failure it left a floor of 1.3 x a share that the measurement already covers (bench.py's region: need 111 K splats, the walk of
             // the pre-roll's two-round frames ended at 1.3 x 120 = 156 permille where 1.15 x 106 = 122 do).  A MISS -- round 1 skipped and a
             // tile unsaturated: the frame is drawn again -- is a failure either way.
-            if ((events && !(need && need != 0xFFFFFFFFu)) || c->round1_missed) {
+            // (need == 0xFFFFFFFF -- a tile no share saturates: sky -- is a measurement too: share_from_need goes to one round, or to the share that
+            // covers V, at once; counted as a failure it walked there x 1.3 per collection and came back with the margin at 1.3 and a hold: ADVICE r5)
+            if ((events && !need) || c->round1_missed) {
                 // the share proved too small: raised ONCE per collection by the caller (share_failed) -- the frames of all the lanes a
                 // gs_sync collects were drawn with the same share, and six lanes reporting the same failure used to multiply it by
                 // 1.5^6 and to leave the floor at 1.3 x 1.5^5 of the share that had really failed (a cold context ended up at 70 %)
@@ -1009,7 +1016,7 @@ GS_API int gs_clear(gs_ctx *ctx)
     GS_HIP(hipSetDevice(ctx->device));
     TRY(drain_all(ctx));
     ctx->n = 0; ctx->renderable = true; ctx->pair_hint = 0; ctx->vis_hint = 0; ctx->run_hint = 0; ctx->last_pairs = 0; ctx->last_visible = 0;
-    ctx->near_frac = 0.25f; ctx->near_floor = 0.0f; ctx->clean_frames = 0; ctx->skip_hold = 0; ctx->single_round_frames = 0; ctx->last_kept = 0; ctx->share_measured = false; ctx->need_margin = 0.0f; memset(ctx->need_hist, 0, sizeof ctx->need_hist);
+    ctx->near_frac = 0.25f; ctx->near_floor = 0.0f; ctx->clean_frames = 0; ctx->skip_hold = 0; ctx->single_round_frames = 0; ctx->last_kept = 0; ctx->share_measured = false; ctx->need_margin = 0.0f; ctx->cold_sorts = 0; ctx->cold_frames = 0; memset(ctx->need_hist, 0, sizeof ctx->need_hist);
     ctx->near_stash_off = false; ctx->near_spec = false; ctx->near_spec_hold = 0; ctx->near_spec_backoff = 0; ctx->near_spec_miss_credit = 0;
     for (int i = 0; i < GS_MAX_LANES; i++) {
         gs_ctx *L = ctx->lanes[i];
@@ -1188,7 +1195,7 @@ static int sort_common(gs_ctx *ctx, const float view[4], const float *cutout16, 
     // thread then, not on an enqueue thread that was created a moment ago and has to be woken first: 0.14 ms of that call's 0.7)
     // (... at most two sorts in a row: a context whose frames never measure -- counting renders, compact pair records -- keeps its threads)
     const bool cold = !ctx->share_measured && ctx->near_fixed_permille <= 0 && ctx->cold_sorts < 2u;   // (get_lane has drained the lane: nothing of it is waiting on its thread)
-    if (cold) ctx->cold_sorts++; else if (ctx->share_measured) ctx->cold_sorts = 0;
+    if (cold) ctx->cold_sorts++; else if (ctx->share_measured) { ctx->cold_sorts = 0; ctx->cold_frames = 0; }
     if (ctx->enqueue_threads && gs_rotates(ctx) && !ctx->user_stream && !out_idx && !out_n && !cold) {
         // nothing to hand back: the lane's worker thread does the launching (a failure surfaces at gs_sync())
         GsLaneCmd c;
@@ -1450,7 +1457,7 @@ static int render_sync_on_lane(gs_ctx *ctx, const GsFrameUniforms &u, void *devi
         const float frac_used = gs_root(ctx)->near_frac;
         TRY(collect_status(ctx, &over, &failed, nullptr, &need, &nfr));
         if (failed) { if (gs_root(ctx)->share_measured) share_missed(gs_root(ctx), frac_used); else share_raise(gs_root(ctx), frac_used); }
-        else { share_from_need(gs_root(ctx), need, nfr); TRY(seed_need_words(gs_root(ctx), need)); }
+        else { share_from_need(gs_root(ctx), need, nfr); TRY(seed_need_words(gs_root(ctx), need, true)); }
         if (!over) break;
         if (attempt >= 2) FAIL(GS_E_OOM, "pair list keeps overflowing (%u pairs)", ctx->ctl_host->scan_total);
     }
@@ -1508,8 +1515,12 @@ int gs_render_uniforms(gs_ctx *ctx, const GsFrameUniforms &u_in, void *device_rg
     // even when asked to queue it: the frames queued behind it then use the share it measured instead of the 25 % every context starts
     // with (at 20 M splats: 5 M positions in the first round of every frame until the first gs_sync).  The call returns with the frame
     // complete; its status needs no gs_sync.
-    if (async && !ctx->share_measured && ctx->near_fixed_permille <= 0 && u.near_count != 0xFFFFFFFFu && ctx->n) {
+    // (... at most two such frames in a row, like the cold sorts: a context whose blends never record a need -- compact pair records, a
+    // -DGS_NO_NEED_RECORD build, every tile saturated by round 0 of a walked share -- would otherwise draw EVERY queued frame synchronously,
+    // with a drain of every other lane each time: ADVICE r5)
+    if (async && !ctx->share_measured && ctx->near_fixed_permille <= 0 && u.near_count != 0xFFFFFFFFu && ctx->n && ctx->cold_frames < 2u) {
         async = false; u.flags &= ~(uint32_t)GS_RENDER_ASYNC;
+        ctx->cold_frames++;
         // ... and the lanes that exist get their per-frame buffers for this frame's size now (tile ranges, per-pixel state, row tables:
         // a dozen allocations each), while nothing is in flight, instead of one lane per frame over the next five.  (BEFORE the frame's
         // kernels go out, not under them: allocations made while the device works take longer than the wait they would hide -- the
@@ -1805,7 +1816,7 @@ GS_API int gs_set_option(gs_ctx *ctx, int option, int64_t value)
         if (value == 0) {
             // adapt from scratch: the default share, nothing measured -- on the device too (each lane's next frame clears its need words:
             // a word that still says "a tile no share saturates" from frames long gone would keep the share at 100 % for 64 collections)
-            ctx->near_frac = 0.25f; ctx->share_measured = false; ctx->need_margin = 0.0f; ctx->cold_sorts = 0; memset(ctx->need_hist, 0, sizeof ctx->need_hist);
+            ctx->near_frac = 0.25f; ctx->share_measured = false; ctx->need_margin = 0.0f; ctx->cold_sorts = 0; ctx->cold_frames = 0; memset(ctx->need_hist, 0, sizeof ctx->need_hist);
             for (int i = 0; i < GS_MAX_LANES; i++) if (ctx->lanes[i]) { ctx->lanes[i]->need_seed_pending = 1u; ctx->lanes[i]->need_word_est = 0; }
         }
         return GS_OK;

@@ -832,6 +832,8 @@ int gs_launch_radix_pass2(gs_ctx *const S[2], const void *const in[2], int in_fm
 int gs_launch_msd_sort(gs_ctx *ctx, uint32_t n, uint32_t tail_req)
 {
     const bool near = tail_req != 0u;
+    // k_seg_sort reads whole blocks: up to GS_SEG_B words past a segment's end, i.e. up to n + GS_SEG_B - 1 words into `rec` (= kv_b, 2 x scratch_cap words)
+    if ((size_t)ctx->scratch_cap * 2 < (size_t)n + GS_SEG_B) { snprintf(GS_ERRBUF(ctx), GS_ERRLEN, "msd sort: scratch of %zu splats is too small for %u records", ctx->scratch_cap, n); return GS_E_STATE; }
     const uint32_t chunk = gs_radix_chunk(n), g = grid_for(n, chunk);
     hipStream_t st = ctx->stream;
     uint32_t *rec = reinterpret_cast<uint32_t *>(ctx->kv_b);
@@ -848,6 +850,7 @@ int gs_launch_msd_sort(gs_ctx *ctx, uint32_t n, uint32_t tail_req)
 int gs_launch_msd_sort2(gs_ctx *const S[2], uint32_t n, const uint32_t tail_req[2])
 {
     gs_ctx *ctx = S[0];
+    for (int k = 0; k < 2; k++) if ((size_t)S[k]->scratch_cap * 2 < (size_t)n + GS_SEG_B) { snprintf(GS_ERRBUF(ctx), GS_ERRLEN, "msd sort: scratch of %zu splats is too small for %u records", S[k]->scratch_cap, n); return GS_E_STATE; }
     const uint32_t chunk = gs_radix_chunk(n), g = grid_for(n, chunk);
     hipStream_t st = ctx->stream;
     uint32_t *rec[2] = { reinterpret_cast<uint32_t *>(S[0]->kv_b), reinterpret_cast<uint32_t *>(S[1]->kv_b) };

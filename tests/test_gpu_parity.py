@@ -1950,3 +1950,31 @@ def test_posted_sort_draws_with_the_last_completed_order_until_it_is_collected(s
         assert np.array_equal(buf[0], want_b)
         assert c.sort_poll(wait=True, want_indices=False) is True
         buf[1].free()
+
+
+@pytest.mark.gpu
+def test_queued_frames_stay_queued_with_compact_pair_records(scene_small):
+    """a context that has not measured its share draws a queued frame synchronously (the frames behind it then use the measured
+    share) -- at most twice in a row, like the cold sorts: compact pair records (GS_OPT_WIDE_PAIRS = 2) name no sorted positions, their
+    blends record no need, and such a context must not end up drawing EVERY queued frame synchronously.  A frame that was queued moves
+    the next frame to another pipeline lane; one that was drawn synchronously does not."""
+    import torch
+    w, h = 640, 360
+    cams = [synth.index_html_camera(w, h, 3.0 * k, capi=capi) for k in range(12)]
+    with capi.Context(0) as c, capi.Context(0) as ref:
+        c.set_option(capi.OPT_WIDE_PAIRS, 2)
+        c.push_splat(scene_small["rows"]); ref.push_splat(scene_small["rows"])
+        for rnd in range(2):
+            lanes, bufs = [], []
+            for cam in cams:
+                b = torch.zeros(w * h * 4, dtype=torch.uint8, device="cuda")
+                c.sort(cam["view"], want_indices=False)
+                c.render_device(_params(cam, flags=capi.RENDER_ASYNC), b.data_ptr())
+                lanes.append(c.frame_lane()); bufs.append(b)
+            c.sync()
+            torch.cuda.synchronize()
+            assert len(set(lanes[2:])) > 1, lanes                     # after at most two cold frames the frames rotate over the lanes
+            for cam, b in zip(cams, bufs):
+                ref.sort(cam["view"], want_indices=False)
+                assert np.array_equal(b.cpu().numpy().reshape(h, w, 4), ref.render(_params(cam)))
+            c.set_option(capi.OPT_NEAR_PERMILLE, 0)                   # adapt from scratch: cold again, bounded again
