@@ -9,7 +9,7 @@
 #   stage <tag> [args]         tools/stage_bench.py un-profiled, then a depth-1 kernel trace of 60 frames summarised by tools/prof_tail.py
 #   trace <tag> [args]         rocprofv3 --kernel-trace --stats of `python <args>`; per-kernel table to gpurun_out/trace_<tag>.txt
 #   regimes <tag>              the three regimes (headline, outside the cloud, opacity / 10) x GS_OPT_SUBTILE 0 / 2: frames/s and stage times
-#   cumask <tag>               A/B of CU-masked lane streams (GS_LANE_CU_MASK), C2 driver form + stage times
+#   cumask <tag>               A/B of CU-masked lane streams (GS_LANE_CUS / GS_BLEND_CUS; library built with tools/experiments/cumask_streams.patch)
 #   variants <tag> [args]      tools/stage_bench.py [args] for the product and every csrc/libgs_variant_*.so
 #   pmcx <tag> "<ctrs>" <kernel> [args]   one --pmc pass over tools/stage_bench.py [args], per-kernel averages of the counters
 #   pmc <tag>                  tools/gpu_pmc.sh (counter passes) for the configurations bench.py reports traffic for
@@ -58,12 +58,18 @@ job_regimes() {
         done
     done
 }
-job_cumask() {
+job_cumask() {   # CU-masked lane streams: needs the library built with tools/experiments/cumask_streams.patch (measured in round 6 and dropped:
+                 # profiles/r06_ab_cumask.txt) -- per-lane ranges of every XCD's CUs, or a second masked stream for the blends
     local tag=${1:-$TAG}
-    for m in "" 6 5 4; do
-        echo "== GS_LANE_CU_MASK=$m" | tee -a gpurun_out/cumask_$tag.txt
-        GS_LANE_CU_MASK=$m timeout 600 python tools/stage_bench.py --near 0 --batch 2 --depths 3 --frames 480 2>&1 | grep -v amdgpu.ids | tee -a gpurun_out/cumask_$tag.txt
-        GS_LANE_CU_MASK=$m timeout 600 python tools/stage_bench.py --near 0 --batch 2 --outside --depths 3 --frames 240 2>&1 | grep -v amdgpu.ids | tee -a gpurun_out/cumask_$tag.txt
+    for v in "" "GS_LANE_CUS=8" "GS_LANE_CUS=11,11,10" "GS_LANE_CUS=16,16" "GS_BLEND_CUS=24" "GS_BLEND_CUS=20"; do
+        echo "== ${v:-no mask}" | tee -a gpurun_out/cumask_$tag.txt
+        env $v timeout 120 python tools/stage_bench.py --near 0 --batch 2 --depths 3 --frames 480 2>&1 | grep -v amdgpu.ids | tee -a gpurun_out/cumask_$tag.txt
+        env $v timeout 120 python tools/stage_bench.py --near 0 --batch 2 --outside --depths 3 --frames 240 2>&1 | grep -v amdgpu.ids | tee -a gpurun_out/cumask_$tag.txt
+    done
+    # the C2 driver form with the two best of them, and the per-queue timeline of one
+    for v in "" "GS_LANE_CUS=11,11,10" "GS_BLEND_CUS=24"; do
+        echo "== bench.py --steps 20 --warmup 5 :: ${v:-no mask}" | tee -a gpurun_out/cumask_$tag.txt
+        for i in 1 2 3; do env $v timeout 200 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('steps20', d['value'], 'steady', d['config'].get('steady_state_fps'))" | tee -a gpurun_out/cumask_$tag.txt; done
     done
 }
 job_variants() {   # every csrc/libgs_variant_*.so (tools/build_render_variant.sh) next to the product: stage_bench with the given args
