@@ -120,7 +120,7 @@ __device__ __forceinline__ void k_project_body(const uint32_t *__restrict__ sort
                     const int r0 = u.H - 1 - jy1, r1 = u.H - 1 - jy0;       // GL rows (y up) -> image rows (top-down)
                     const uint32_t tx0 = (uint32_t)(ix0 - u.x0) / GS_TILE, tx1 = (uint32_t)(ix1 - u.x0) / GS_TILE;
                     const uint32_t ty0 = (uint32_t)r0 / GS_TILE, ty1 = (uint32_t)r1 / GS_TILE;
-                    rect[j] = make_uint2(tx0 | (ty0 << 16), tx1 | (ty1 << 16));
+                    if (!RUNS || ty1 - ty0 >= 2) rect[j] = make_uint2(tx0 | (ty0 << 16), tx1 | (ty1 << 16));   // (RUNS, one or two tile rows: the runs themselves, below)
                     float4 *dst = reinterpret_cast<float4 *>(proj + j);
                     dst[0] = make_float4(p.cx, p.cy, p.ax, p.ay);
                     dst[1] = make_float4(p.bx, p.by, __uint_as_float(p.rgba), p.alpha);
@@ -136,13 +136,19 @@ __device__ __forceinline__ void k_project_body(const uint32_t *__restrict__ sort
                         // exact coverage: per tile row, the contiguous run of tiles the ellipse touches
                         gsm::EllipseRows e;
                         gsm::ellipse_rows_setup(p, e);
+                        uint32_t runs = 0, present = 0;                // RUNS: the (at most two) runs as k_emit_runs wants them
                         for (uint32_t ty = ty0; ty <= ty1; ty++) {
                             uint32_t a, n;
                             gsm::splat_tile_row(p, e, (int)ty, u.H, u.x0, u.x1b, a, n);
+                            if (RUNS && n) { runs |= (a | ((n - 1u) << 8)) << (16u * (ty - ty0)); present |= 1u << (ty - ty0); }
                             if (ROUND == 1 && n) n = mask_count(mask + ty * u.mask_words, a, n);
                             if (RUNS && n) atomicAdd(&s_rc[ty], 1u | (n << 9));
                             count += n;
                         }
+                        // (span lists: a splat of one or two tile rows hands its runs on -- first tile | tiles - 1 << 8 per row, strips of at most
+                        // 256 tile columns -- so that k_emit_runs neither reads its projected record nor repeats the band arithmetic twice: in a
+                        // frame of small splats that was 60 % of that kernel's instructions.  Bit 14 says so; tx0 of a queued splat is below 256)
+                        if (RUNS) rect[j] = make_uint2((ty0 << 16) | ((ty1 - ty0) << 15) | (1u << 14) | (present << 12), runs);
                     }
                 }
             }
@@ -742,17 +748,22 @@ __device__ __forceinline__ void k_emit_runs_body(const gsm::Projected *__restric
         uint32_t ty0 = 0, ty1 = 0;
         gsm::Projected p;
         p.cx = p.cy = p.ax = p.ay = p.bx = p.by = 0.0f;
+        uint32_t own_runs = 0, own_present = 0;                     // a splat of one or two tile rows: its runs as k_project left them
         if (cnt) {
             const uint2 rc = rect[j];
-            const float4 *src = reinterpret_cast<const float4 *>(proj + j);
-            const float4 ra = src[0]; const float2 rb = *reinterpret_cast<const float2 *>(src + 1);
-            p.cx = ra.x; p.cy = ra.y; p.ax = ra.z; p.ay = ra.w; p.bx = rb.x; p.by = rb.y;
-            ty0 = rc.x >> 16; ty1 = rc.y >> 16;
-            if (ty1 - ty0 >= 2) {
+            if (rc.x & (1u << 14)) {
+                own = true;
+                ty0 = rc.x >> 16; ty1 = ty0 + ((rc.x >> 15) & 1u);
+                own_runs = rc.y; own_present = (rc.x >> 12) & 3u;
+            } else {
+                const float4 *src = reinterpret_cast<const float4 *>(proj + j);
+                const float4 ra = src[0]; const float2 rb = *reinterpret_cast<const float2 *>(src + 1);
+                p.cx = ra.x; p.cy = ra.y; p.ax = ra.z; p.ay = ra.w; p.bx = rb.x; p.by = rb.y;
+                ty0 = rc.x >> 16; ty1 = rc.y >> 16;
                 const uint32_t q = (ty1 - ty0 >= 16) ? (GS_BLOCK - 1u - atomicAdd(&s_nbig, 1u)) : atomicAdd(&s_nmid, 1u);
                 s_rec[q][0] = p.cx; s_rec[q][1] = p.cy; s_rec[q][2] = p.ax; s_rec[q][3] = p.ay; s_rec[q][4] = p.bx; s_rec[q][5] = p.by;
                 s_rows[q] = ty0 | (ty1 << 16); s_t[q] = tid;
-            } else own = true;
+            }
         }
         __syncthreads();
         const uint32_t nmid = s_nmid, nbig = s_nbig;
@@ -761,8 +772,10 @@ __device__ __forceinline__ void k_emit_runs_body(const gsm::Projected *__restric
             gsm::splat_tile_row(PP, EE, (int)(TY), u.H, u.x0, u.x1b, a_, n_);                                                     \
             if (n_ && (ROUND == 0 || mask_count(mask + (TY) * u.mask_words, a_, n_))) { FN((T), (TY), a_, n_); } } while (0)
 #define GS_RUN_PASS(FN) do {                                                                                                      \
-            if (own) { gsm::EllipseRows e; gsm::ellipse_rows_setup(p, e);                                                         \
-                for (uint32_t ty = ty0; ty <= ty1; ty++) GS_RUN_ONE(p, e, tid, ty, FN); }                                         \
+            if (own) {                                                                                                            \
+                for (uint32_t ty = ty0; ty <= ty1; ty++) if ((own_present >> (ty - ty0)) & 1u) {                                  \
+                    const uint32_t r_ = own_runs >> (16u * (ty - ty0)), a_ = r_ & 0xFFu, n_ = ((r_ >> 8) & 0xFFu) + 1u;           \
+                    if (ROUND == 0 || mask_count(mask + ty * u.mask_words, a_, n_)) { FN(tid, ty, a_, n_); } } }                  \
             for (uint32_t mi = (uint32_t)w * 4u + ((uint32_t)lane >> 4); mi < nmid; mi += 16u) {                                  \
                 gsm::Projected q;                                                                                                 \
                 q.cx = s_rec[mi][0]; q.cy = s_rec[mi][1]; q.ax = s_rec[mi][2]; q.ay = s_rec[mi][3]; q.bx = s_rec[mi][4]; q.by = s_rec[mi][5]; \
