@@ -116,8 +116,8 @@ static int ensure_scan_scratch(gs_ctx *ctx)
     TRY(ensure_radix_tables(ctx, ctx->scratch_cap > ctx->pair_cap ? ctx->scratch_cap : ctx->pair_cap));   // the larger of the two sorts
     const size_t need_spine = gs_div_up(ctx->scratch_cap, GS_BLOCK) + 16;   // project/emit chunks of 256 splats
     if (need_spine > ctx->spine_cap) {
-        dev_free(ctx->spine); dev_free(ctx->spine_vis); ctx->spine_cap = 0;
-        TRY(dev_alloc(ctx, &ctx->spine, need_spine)); TRY(dev_alloc(ctx, &ctx->spine_vis, need_spine)); ctx->spine_cap = need_spine;
+        dev_free(ctx->spine); ctx->spine_cap = 0;
+        TRY(dev_alloc(ctx, &ctx->spine, need_spine)); ctx->spine_cap = need_spine;
     }
     return GS_OK;
 }
@@ -382,11 +382,6 @@ static int collect_status(gs_ctx *lane, bool *overflowed, bool *share_failed = n
     lane->stats.sort_mode = c->near_sorted;
     ctx->last_kept = c->n_kept;
     if (c->n_pairs_frame) { ctx->last_pairs = c->n_pairs_frame; ctx->last_visible = c->n_visible; }
-    {   // visible splats a round may expect (compact pair records: gs_compact_bits): the last collected frame's + an eighth + 4096
-        // (a bit decides between 4- and 8-byte records: 437 K visible splats of the unsaturated scene need 19, twice as many 20)
-        const uint64_t vh = (uint64_t)c->n_visible + c->n_visible / 8u + 4096ull;
-        __atomic_store_n(&ctx->vis_hint, vh > 0x7FFFFFFFull ? 0u : (uint32_t)vh, __ATOMIC_RELAXED);
-    }
     if (c->n_pairs_frame) __atomic_store_n(&ctx->run_hint, c->n_runs, __ATOMIC_RELAXED);
     if (c->n_pairs_frame) {                                     // sizing hint for the next frames' pair sort (any lane's worker may read it)
         const uint64_t h = (uint64_t)c->n_pairs_frame + c->n_pairs_frame / 4 + GS_CHUNK_L;
@@ -815,7 +810,7 @@ static void free_frame_resources(gs_ctx *c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     delete c->log; c->log = nullptr;
     dev_free(c->depth); dev_free(c->key_a); dev_free(c->kv_b); dev_free(c->val_a);
-    dev_free(c->hist); dev_free(c->radix_aux); dev_free(c->msd_grp); dev_free(c->spine); dev_free(c->spine_vis); dev_free(c->projc); dev_free(c->zwinc);
+    dev_free(c->hist); dev_free(c->radix_aux); dev_free(c->msd_grp); dev_free(c->spine);
     dev_free(c->proj); dev_free(c->rect); dev_free(c->tile_count); dev_free(c->zwin);
     dev_free(c->pair_a); dev_free(c->pair_b); dev_free(c->emit_extra); dev_free(c->row_cnt); dev_free(c->row_tot); dev_free(c->seg_diff);
     gs_comm_free_lane(c);
@@ -1015,7 +1010,7 @@ GS_API int gs_clear(gs_ctx *ctx)
     CHECK_CTX(ctx);
     GS_HIP(hipSetDevice(ctx->device));
     TRY(drain_all(ctx));
-    ctx->n = 0; ctx->renderable = true; ctx->pair_hint = 0; ctx->vis_hint = 0; ctx->run_hint = 0; ctx->last_pairs = 0; ctx->last_visible = 0;
+    ctx->n = 0; ctx->renderable = true; ctx->pair_hint = 0; ctx->run_hint = 0; ctx->last_pairs = 0; ctx->last_visible = 0;
     ctx->near_frac = 0.25f; ctx->near_floor = 0.0f; ctx->clean_frames = 0; ctx->skip_hold = 0; ctx->single_round_frames = 0; ctx->last_kept = 0; ctx->share_measured = false; ctx->need_margin = 0.0f; ctx->cold_sorts = 0; ctx->cold_frames = 0; memset(ctx->need_hist, 0, sizeof ctx->need_hist);
     ctx->near_stash_off = false; ctx->near_spec = false; ctx->near_spec_hold = 0; ctx->near_spec_backoff = 0; ctx->near_spec_miss_credit = 0;
     for (int i = 0; i < GS_MAX_LANES; i++) {
@@ -1336,7 +1331,7 @@ int gs_fill_uniforms(gs_ctx *ctx /* owner: options, adaptive share, scene */, co
     memcpy(u.mv, p->model_view, sizeof u.mv); memcpy(u.proj, p->projection, sizeof u.proj);
     u.W = p->fb_width; u.H = p->fb_height; u.x0 = p->x0; u.x1 = p->x1;
     u.out_pitch = p->x1 - p->x0;
-    u.pair_jbits = 0; u.pair_vcap = 0; u.rc_stride = 0;          // (the binning and its record format are chosen per round: gs_render.hip)
+    u.rc_stride = 0;                                               // (the binning is chosen per round: gs_render.hip)
     u.status = nullptr;                                            // (the frame's lane supplies its own word: gs_render_uniforms)
     u.need_seed = 0;
     u.x1b = p->x0 + ((p->x1 - p->x0 + 3) & ~3);
@@ -1827,8 +1822,8 @@ GS_API int gs_set_option(gs_ctx *ctx, int option, int64_t value)
     case GS_OPT_WIDE_PAIRS:
         GS_HIP(hipSetDevice(ctx->device));
         TRY(drain_all(ctx));
-        if (value < 0 || value > 2) FAIL(GS_E_BADARG, "wide pairs: 0 (automatic), 1 (always 8-byte records) or 2 (compact 4-byte records wherever they fit)");
-        ctx->wide_pairs = value == 1; ctx->compact_pairs = value == 2; refresh_lanes(ctx);
+        if (value < 0 || value > 1) FAIL(GS_E_BADARG, "wide records: 0 (automatic) or 1 (the depth sort's general 8-byte records whatever the number of splats)");
+        ctx->wide_pairs = value == 1; refresh_lanes(ctx);
         return GS_OK;
     case GS_OPT_BINNING:
         GS_HIP(hipSetDevice(ctx->device));

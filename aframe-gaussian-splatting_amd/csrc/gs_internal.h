@@ -131,10 +131,6 @@ struct GsFrameUniforms {           // per-render constants, passed by value to k
     uint32_t has_depth, has_scene_rgba;   // scene compositing inputs present (gs_set_scene)
     uint32_t split_min;            // GS_OPT_BLEND_SPLIT: tiles whose list has at least this many entries are blended by GS_SPLIT_WAVES
                                    // wavefronts (k_blend<.., GS_SPLIT_WAVES>), the others by one; 0 = all by one
-    uint32_t pair_jbits;           // > 0: 4-byte pair records (tile << pair_jbits | sorted position - j_lo); 0: (tile, position) uint2
-    uint32_t pair_vcap;            // > 0 (with pair_jbits > 0): the low bits of a 4-byte record are not the sorted position but the splat's index
-                                   // among the VISIBLE splats of the round (< pair_vcap), whose projected records k_emit copies to `projc`
-                                   // in that order: a 4K frame has 15 tile bits and a round of 300 K positions 19, but a thousand visible splats 10
     uint32_t need_seed;            // != 0: the frame's projection first sets the lane's need_near words to this (1: to zero) -- how the host seeds them
                                    // after a collection: a hipMemsetD32Async per lane cost gs_sync() 20 us of host time each
     uint32_t *status;              // the frame's completion word (gs_frame_status_device): 0 = complete; bit 0: the second binning round was skipped and a
@@ -142,7 +138,7 @@ struct GsFrameUniforms {           // per-render constants, passed by value to k
                                    // again at gs_sync().  Written by the frame's own kernels (k_project<0> resets it, the blend raises the bits); the
                                    // lane's control block by default, the trailer of the piece for a gathered frame (it travels with the piece)
     uint32_t rc_stride;            // span-list binning (GS_OPT_BINNING): chunks per tile row of the row-count table; 0 = pair records + radix passes.
-                                   // A tile's list entries are then the sorted positions themselves (pair_jbits = 32)
+                                   // A tile's list entries are then the sorted positions themselves, else (tile, position) records
     uint32_t subtile;              // GS_OPT_SUBTILE: k_blend splits a staged batch into the lists of the tile's sixteen 4x4-pixel blocks where that
                                    // shortens the walk (gs_render.hip: same pixels either way)
 };
@@ -228,9 +224,6 @@ struct gs_ctx {
     gsm::Projected *proj;          // V records, sorted order
     uint2 *rect;                   // V x (tx0 | ty0<<16, tx1 | ty1<<16), strip-local tile coords
     uint32_t *tile_count;          // V
-    uint32_t *spine_vis;           // per 256-splat chunk: visible splats (project -> pairs_check: exclusive scan -> emit), sized like spine
-    gsm::Projected *projc; float *zwinc; size_t projc_cap;   // compact pair records: projected records / window depths of the visible splats, in order
-    uint32_t vis_hint;             // owner: visible splats a round is expected to have (the last collected frame's + 1/8 + 4096; 0 = unknown)
     uint2 *emit_extra;             // pair_cap / GS_EMIT_PAIRS + 2 (chunk, slice) items of the chunks with more than GS_EMIT_PAIRS pairs
     float *zwin;                   // V window depth of each sorted splat (written only while a scene depth buffer is set)
     float *scene_depth; uint32_t *scene_rgba; int scene_w, scene_h;   // gs_set_scene
@@ -278,8 +271,7 @@ struct gs_ctx {
     uint32_t profile_every;        // GS_OPT_PROFILE = 3: ... and only on every 4th frame of the lane (0 / 1 = every frame)
     uint32_t profile_tick;
     uint32_t record_staged;        // GS_OPT_RECORD_STAGED (1 = entries staged, 2 = entries evaluated)
-    bool wide_pairs;               // GS_OPT_WIDE_PAIRS = 1: always use 8-byte pair records
-    bool compact_pairs;            // GS_OPT_WIDE_PAIRS = 2: compact 4-byte records (visible-splat index) wherever they fit, also where the position form does
+    bool wide_pairs;               // GS_OPT_WIDE_PAIRS = 1: the depth sort uses its general 8-byte (key, index) records whatever N (those of N > 2^25)
     float t_eps;
     // profiling ring: GS_PROF_RING slots x GS_PROF_EVENTS events (sort begin/end, render begin, after project, after
     // binning, after blend of round 0, end of round 1)

@@ -762,7 +762,6 @@ int launch_pass(gs_ctx *ctx, const void *in, int in_fmt, void *out, int out_fmt,
     else if (in_fmt == GS_RADIX_PACKED && out_fmt == GS_RADIX_KEYS) GS_SCATTER(GS_RADIX_PACKED, GS_RADIX_KEYS);
     else if (in_fmt == GS_RADIX_KEYS && out_fmt == GS_RADIX_PACKED) GS_SCATTER(GS_RADIX_KEYS, GS_RADIX_PACKED);
     else if (in_fmt == GS_RADIX_KEYS && out_fmt == GS_RADIX_KEYS) GS_SCATTER(GS_RADIX_KEYS, GS_RADIX_KEYS);
-    else if (in_fmt == GS_RADIX_KEYONLY && out_fmt == GS_RADIX_KEYONLY) GS_SCATTER(GS_RADIX_KEYONLY, GS_RADIX_KEYONLY);
     else if (in_fmt == GS_RADIX_KEYS && out_fmt == GS_RADIX_KEYIDX) GS_SCATTER(GS_RADIX_KEYS, GS_RADIX_KEYIDX);
     else if (in_fmt == GS_RADIX_KEYIDX && out_fmt == GS_RADIX_KEYS) GS_SCATTER(GS_RADIX_KEYIDX, GS_RADIX_KEYS);
     else if (in_fmt == GS_RADIX_PACKED && out_fmt == GS_RADIX_KEYIDX) GS_SCATTER(GS_RADIX_PACKED, GS_RADIX_KEYIDX);
@@ -802,8 +801,7 @@ int launch_pass2(gs_ctx *const S[2], const void *const in[2], int in_fmt, void *
                           gs_pack_make(in[1], out[1], n_ptr[1], shift, bits, zero_key, (const uint32_t *)S[1]->hist, (const uint32_t *)S[1]->radix_aux,         \
                                        idx_bits, count_out[1], fill_to[1])); } while (0)
 #define GS_SCATTER2(I, O) do { if (bits <= 7) GS_SCATTER2_B(I, O, 128); else if (bits == 8) GS_SCATTER2_B(I, O, 256); else GS_SCATTER2_B(I, O, GS_RADIX_MAX_BINS); } while (0)
-    if (in_fmt == GS_RADIX_KEYONLY && out_fmt == GS_RADIX_KEYONLY) GS_SCATTER2(GS_RADIX_KEYONLY, GS_RADIX_KEYONLY);
-    else if (in_fmt == GS_RADIX_PACKED && out_fmt == GS_RADIX_PACKED) GS_SCATTER2(GS_RADIX_PACKED, GS_RADIX_PACKED);
+    if (in_fmt == GS_RADIX_PACKED && out_fmt == GS_RADIX_PACKED) GS_SCATTER2(GS_RADIX_PACKED, GS_RADIX_PACKED);
     else if (in_fmt == GS_RADIX_KEYS && out_fmt == GS_RADIX_KEYIDX) GS_SCATTER2(GS_RADIX_KEYS, GS_RADIX_KEYIDX);
     else if (in_fmt == GS_RADIX_KEYIDX && out_fmt == GS_RADIX_KEYS) GS_SCATTER2(GS_RADIX_KEYIDX, GS_RADIX_KEYS);
     else if (in_fmt == GS_RADIX_KEYS && out_fmt == GS_RADIX_PACKED) GS_SCATTER2(GS_RADIX_KEYS, GS_RADIX_PACKED);

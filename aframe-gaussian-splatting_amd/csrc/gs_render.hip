@@ -77,12 +77,12 @@ __device__ __forceinline__ void k_project_body(const uint32_t *__restrict__ sort
                                                const GsFrameUniforms &u, gsm::Projected *__restrict__ proj, uint2 *__restrict__ rect,
                                                uint32_t *__restrict__ tile_count, uint32_t *__restrict__ spine,
                                                uint32_t *__restrict__ part_vis, const uint32_t *__restrict__ mask,
-                                               float *__restrict__ zwin, GsControl *ctl, uint32_t *__restrict__ spine_vis)
+                                               float *__restrict__ zwin, GsControl *ctl)
 {
     GS_CHAIN_PRIO();
     __shared__ float s_rec[GS_BLOCK][6];
     __shared__ uint32_t s_rows[GS_BLOCK], s_j[GS_BLOCK];
-    __shared__ uint32_t s_nbig, s_nmid, s_vis, s_sum, s_visc;
+    __shared__ uint32_t s_nbig, s_nmid, s_vis, s_sum;
     __shared__ uint32_t s_rc[RUNS ? GS_BLOCK : 1];                  // RUNS: the chunk's (runs | tiles << 9) per tile row
     uint32_t *__restrict__ row_cnt = spine;                         // RUNS: the table takes the spine's argument slot
     uint32_t j_lo, j_hi;
@@ -97,7 +97,7 @@ __device__ __forceinline__ void k_project_body(const uint32_t *__restrict__ sort
     if (ROUND == 0 && blockIdx.x == 0 && threadIdx.x == 0 && u.status) *u.status = ctl->order_incomplete ? 4u : 0u;
     if (ROUND == 0 && blockIdx.x == 0 && u.need_seed && threadIdx.x < GS_NEED_WORDS) ctl->need_near[threadIdx.x] = u.need_seed == 1u ? 0u : u.need_seed;   // (the host's seed: gs_api.hip)
     for (uint32_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
-        if (threadIdx.x == 0) { s_sum = 0; s_nbig = 0; s_nmid = 0; s_visc = 0; }
+        if (threadIdx.x == 0) { s_sum = 0; s_nbig = 0; s_nmid = 0; }
         if (RUNS) s_rc[threadIdx.x] = 0u;
         __syncthreads();
         const uint32_t j = j_lo + c * GS_BLOCK + threadIdx.x;
@@ -200,10 +200,10 @@ __device__ __forceinline__ void k_project_body(const uint32_t *__restrict__ sort
         }
 #pragma unroll
         for (int m = 32; m >= 1; m >>= 1) { vis += __shfl_xor(vis, m, 64); sum += __shfl_xor(sum, m, 64); }
-        if (lane == 0) { if (vis) { atomicAdd(&s_vis, vis); atomicAdd(&s_visc, vis); } if (sum) atomicAdd(&s_sum, sum); }
+        if (lane == 0) { if (vis) atomicAdd(&s_vis, vis); if (sum) atomicAdd(&s_sum, sum); }
         __syncthreads();
         if (RUNS) { if (threadIdx.x < (uint32_t)u.tiles_y) row_cnt[(size_t)threadIdx.x * u.rc_stride + c] = s_rc[threadIdx.x]; }
-        else if (threadIdx.x == 0) { spine[c] = s_sum; spine_vis[c] = s_visc; }
+        else if (threadIdx.x == 0) spine[c] = s_sum;
     }
     __syncthreads();
     if (threadIdx.x == 0) part_vis[blockIdx.x] = s_vis;
@@ -214,9 +214,9 @@ __global__ __launch_bounds__(GS_BLOCK) void k_project(const uint32_t *__restrict
                                                       GsFrameUniforms u, gsm::Projected *__restrict__ proj, uint2 *__restrict__ rect,
                                                       uint32_t *__restrict__ tile_count, uint32_t *__restrict__ spine,
                                                       uint32_t *__restrict__ part_vis, const uint32_t *__restrict__ mask,
-                                                      float *__restrict__ zwin, GsControl *ctl, uint32_t *__restrict__ spine_vis)
+                                                      float *__restrict__ zwin, GsControl *ctl)
 {
-    k_project_body<ROUND, RUNS>(sorted, splat, u, proj, rect, tile_count, spine, part_vis, mask, zwin, ctl, spine_vis);
+    k_project_body<ROUND, RUNS>(sorted, splat, u, proj, rect, tile_count, spine, part_vis, mask, zwin, ctl);
 }
 
 // One workgroup: exclusive scan of the per-chunk totals (spine) -> chunk base offsets, I = grand total (refused and
@@ -229,7 +229,7 @@ template <int ROUND>
 __device__ __forceinline__ void k_pairs_check_body(GsControl *ctl, uint32_t pair_cap, uint32_t *__restrict__ spine,
                                                    const uint32_t *__restrict__ part_vis, uint32_t nparts, uint32_t near_count,
                                                    int last_round, uint32_t *__restrict__ mask, uint32_t mask_total_words,
-                                                   uint2 *__restrict__ extra, uint32_t *__restrict__ spine_vis, uint32_t vcap)
+                                                   uint2 *__restrict__ extra)
 {
     GS_CHAIN_PRIO();
     __shared__ uint32_t s_vis, s_wave[4], s_wave_e[4], s_tv[GS_SPINE_CACHED][GS_BLOCK], s_eb[GS_SPINE_CACHED][GS_BLOCK];
@@ -298,24 +298,8 @@ __device__ __forceinline__ void k_pairs_check_body(GsControl *ctl, uint32_t pair
         }
     }
 #undef GS_EXTRA_OF
-    // compact pair records (vcap > 0): the chunks' visible counts -> the index of each chunk's first visible splat among the round's
-    uint32_t vis_total = 0;
-    if (vcap) {
-        uint32_t sv = 0;
-        for (uint32_t i = lo; i < hi; i++) sv += spine_vis[i];
-        const uint32_t incv = wave_incl_scan_u32(sv, lane);
-        __syncthreads();
-        if (lane == 63) s_wave[w] = incv;
-        __syncthreads();
-        uint32_t bv = 0;
-#pragma unroll
-        for (int k = 0; k < 4; k++) { const uint32_t t = s_wave[k]; if (k < w) bv += t; vis_total += t; }
-        uint32_t runv = bv + incv - sv;
-        for (uint32_t i = lo; i < hi; i++) { const uint32_t t = spine_vis[i]; spine_vis[i] = runv; runv += t; }
-    }
     if (threadIdx.x == 0) {
-        ctl->vis_total = vis_total;
-        const bool vis_over = vcap && vis_total > vcap;            // more visible splats than the records can name: like a pair overflow (re-rendered)
+        ctl->vis_total = 0;
         ctl->n_emit_extra = fits ? total_e : 0u;
         if (ROUND == 0) { ctl->n_visible = 0; ctl->n_pairs_frame = 0; ctl->want_frame = 0; }
         else { ctl->unsat_round0 = ctl->unsat_count; if (ctl->unsat_count) ctl->unsat_events += 1; }
@@ -325,7 +309,7 @@ __device__ __forceinline__ void k_pairs_check_body(GsControl *ctl, uint32_t pair
         if (ctl->want_frame > ctl->max_total) ctl->max_total = ctl->want_frame;
         // a round that does not fit, or that follows one of this frame that did not (k_emit wrote nothing then), bins nothing:
         // the frame is re-rendered with larger buffers, and no kernel downstream may walk records that were never written
-        if (total > pair_cap || vis_over) { ctl->pair_overflow = 1; ctl->overflow_sticky = 1; ctl->n_pairs = 0; }
+        if (total > pair_cap) { ctl->pair_overflow = 1; ctl->overflow_sticky = 1; ctl->n_pairs = 0; }
         else if (round == 0) { ctl->pair_overflow = 0; ctl->n_pairs = total; }
         else ctl->n_pairs = ctl->pair_overflow ? 0u : total;
         ctl->n_visible += s_vis; ctl->n_pairs_frame += ctl->n_pairs;
@@ -340,9 +324,9 @@ template <int ROUND>
 __global__ __launch_bounds__(GS_BLOCK) void k_pairs_check(GsControl *ctl, uint32_t pair_cap, uint32_t *__restrict__ spine,
                                                           const uint32_t *__restrict__ part_vis, uint32_t nparts, uint32_t near_count,
                                                           int last_round, uint32_t *__restrict__ mask, uint32_t mask_total_words,
-                                                          uint2 *__restrict__ extra, uint32_t *__restrict__ spine_vis, uint32_t vcap)
+                                                          uint2 *__restrict__ extra)
 {
-    k_pairs_check_body<ROUND>(ctl, pair_cap, spine, part_vis, nparts, near_count, last_round, mask, mask_total_words, extra, spine_vis, vcap);
+    k_pairs_check_body<ROUND>(ctl, pair_cap, spine, part_vis, nparts, near_count, last_round, mask, mask_total_words, extra);
 }
 
 // (tile id, sorted position) records in splat order: pair slot = spine[chunk] + the in-chunk exclusive scan of tile_count
@@ -359,15 +343,9 @@ __global__ __launch_bounds__(GS_BLOCK) void k_pairs_check(GsControl *ctl, uint32
 //   3. one thread per pair slot of the slice: the run by bisection of that scan, consecutive threads write consecutive
 //      slots.
 // ROUND 1 writes only the tiles whose bit is set in the unsaturated-tile mask (a run's length is then its popcount).
-// one pair record: 8 bytes (tile, sorted position) or, when tile bits + position bits fit (jbits > 0), 4 bytes
-// (tile << jbits | position - j_lo): half the traffic through emit, both radix passes, the range pass and the blend
-template <bool P32>
-__device__ __forceinline__ void put_pair(void *__restrict__ pairs, uint32_t o, uint32_t tile, uint32_t j, uint32_t jrel, uint32_t jbits)
-{
-    if (P32) reinterpret_cast<uint32_t *>(pairs)[o] = (tile << jbits) | jrel;
-    else reinterpret_cast<uint2 *>(pairs)[o] = make_uint2(tile, j);
-}
-
+// one pair record: 8 bytes (tile, sorted position).  (Rounds 2-5 also had two 4-byte forms -- tile | position, tile | index among the round's
+// visible splats -- for frames whose tile and position bits fit 32: since round 6 every frame a 4-byte record could serve is binned with span
+// lists, and the records are what is left for strips beyond 4096 pixels: docs/LAB_NOTES.md.)
 // exclusive scan of one value per thread over the workgroup (256 threads), total returned in `total`
 __device__ __forceinline__ uint32_t block_exscan(uint32_t v, uint32_t *s_w, int lane, int w, uint32_t &total)
 {
@@ -394,13 +372,11 @@ __device__ __forceinline__ uint32_t nth_masked_tile(const uint32_t *__restrict__
     return t0;                                                      // (not reached: kth < the run's popcount)
 }
 
-template <int ROUND, bool P32>
+template <int ROUND>
 __device__ __forceinline__ void k_emit_body(const gsm::Projected *__restrict__ proj, const uint2 *__restrict__ rect,
                                             const uint32_t *__restrict__ tile_count, const uint32_t *__restrict__ spine,
-                                            const uint2 *__restrict__ extra, const GsFrameUniforms &u, void *__restrict__ pairs,
-                                            const uint32_t *__restrict__ mask, const GsControl *ctl,
-                                            const uint32_t *__restrict__ spine_vis, gsm::Projected *__restrict__ projc,
-                                            const float *__restrict__ zwin, float *__restrict__ zwinc)
+                                            const uint2 *__restrict__ extra, const GsFrameUniforms &u, uint2 *__restrict__ pairs,
+                                            const uint32_t *__restrict__ mask, const GsControl *ctl)
 {
     GS_CHAIN_PRIO();
     __shared__ float s_rec[GS_BLOCK][6];                            // the slice's splats: projected record,
@@ -434,18 +410,7 @@ __device__ __forceinline__ void k_emit_body(const gsm::Projected *__restrict__ p
         const uint32_t ex = block_exscan(cnt, s_w, lane, w, n_c);
         const uint32_t q0 = sub * GS_EMIT_PAIRS;
         if (q0 >= n_c) continue;                                     // (uniform) a chunk without pairs
-        // compact records (u.pair_vcap): a pair names its splat by the splat's index among the round's VISIBLE splats; the chunk's
-        // first slice also leaves the visible splats' projected records (and window depths) in that order for the blend
-        uint32_t vid = c * GS_BLOCK + tid;
-        if (ROUND == 0 && u.pair_vcap) {
-            uint32_t nv;
-            vid = spine_vis[c] + block_exscan(cnt ? 1u : 0u, s_w, lane, w, nv);
-            if (sub == 0 && cnt) {
-                float4 *dst = reinterpret_cast<float4 *>(projc + vid);
-                dst[0] = ra; dst[1] = rb4;
-                if (u.has_depth) zwinc[vid] = zwin[j];
-            }
-        }
+        const uint32_t vid = c * GS_BLOCK + tid;                        // position in the round
         const uint32_t q1 = n_c - q0 > GS_EMIT_PAIRS ? q0 + GS_EMIT_PAIRS : n_c;
         const bool needed = cnt != 0u && ex < q1 && ex + cnt > q0;
         const uint32_t nr = needed ? (rc.y >> 16) - (rc.x >> 16) + 1u : 0u;
@@ -523,7 +488,7 @@ __device__ __forceinline__ void k_emit_body(const gsm::Projected *__restrict__ p
                         tile = row * tiles_x + nth_masked_tile(mask + row * u.mask_words, t0, s_rn[run[i]], within);
                     }
                     const uint32_t jrel = s_sp[k1];
-                    put_pair<P32>(pairs, base + s0 + p, tile, j_lo + jrel, jrel, u.pair_jbits);
+                    pairs[base + s0 + p] = make_uint2(tile, j_lo + jrel);
                 }
             }
             xc += pb;
@@ -534,26 +499,22 @@ __device__ __forceinline__ void k_emit_body(const gsm::Projected *__restrict__ p
     }
 }
 
-template <int ROUND, bool P32>
+template <int ROUND>
 __global__ __launch_bounds__(GS_BLOCK) void k_emit(const gsm::Projected *__restrict__ proj, const uint2 *__restrict__ rect,
                                                    const uint32_t *__restrict__ tile_count, const uint32_t *__restrict__ spine,
-                                                   const uint2 *__restrict__ extra, GsFrameUniforms u, void *__restrict__ pairs,
-                                                   const uint32_t *__restrict__ mask, const GsControl *ctl,
-                                                   const uint32_t *__restrict__ spine_vis, gsm::Projected *__restrict__ projc,
-                                                   const float *__restrict__ zwin, float *__restrict__ zwinc)
+                                                   const uint2 *__restrict__ extra, GsFrameUniforms u, uint2 *__restrict__ pairs,
+                                                   const uint32_t *__restrict__ mask, const GsControl *ctl)
 {
-    k_emit_body<ROUND, P32>(proj, rect, tile_count, spine, extra, u, pairs, mask, ctl, spine_vis, projc, zwin, zwinc);
+    k_emit_body<ROUND>(proj, rect, tile_count, spine, extra, u, pairs, mask, ctl);
 }
 
 // [start,end) of every tile in the sorted pair list, written for ALL tiles (empty ones get an empty range at the
 // position where they would be), so no clearing pass is needed.
-__device__ __forceinline__ void k_tile_ranges_body(const void *__restrict__ pairs, uint32_t jbits, uint2 *__restrict__ range,
+__device__ __forceinline__ void k_tile_ranges_body(const uint2 *__restrict__ p64, uint2 *__restrict__ range,
                                                    uint32_t ntiles, int round, const GsControl *ctl)
 {
     GS_CHAIN_PRIO();
-    const uint2 *p64 = reinterpret_cast<const uint2 *>(pairs);
-    const uint32_t *p32 = reinterpret_cast<const uint32_t *>(pairs);
-#define GS_PAIR_TILE(i) (jbits ? (p32[i] >> jbits) : p64[i].x)
+#define GS_PAIR_TILE(i) (p64[i].x)
     if (round == 1 && ctl->j_hi == 0) return;                      // nothing left for round 1: its blend returns too
     const uint32_t I = ctl->n_pairs;
     if (I == 0) {
@@ -583,10 +544,10 @@ __device__ __forceinline__ void k_tile_ranges_body(const void *__restrict__ pair
 }
 #undef GS_PAIR_TILE
 
-__global__ __launch_bounds__(GS_BLOCK) void k_tile_ranges(const void *__restrict__ pairs, uint32_t jbits, uint2 *__restrict__ range,
+__global__ __launch_bounds__(GS_BLOCK) void k_tile_ranges(const uint2 *__restrict__ pairs, uint2 *__restrict__ range,
                                                           uint32_t ntiles, int round, const GsControl *ctl)
 {
-    k_tile_ranges_body(pairs, jbits, range, ntiles, round, ctl);
+    k_tile_ranges_body(pairs, range, ntiles, round, ctl);
 }
 
 // ================================================================= span-list binning (GS_OPT_BINNING; round 4)
@@ -611,7 +572,7 @@ __global__ __launch_bounds__(GS_BLOCK) void k_tile_ranges(const void *__restrict
 //                        walk.  Also the round's bookkeeping in the control block (what k_pairs_check does for the pair
 //                        records): block 0.
 // ROUND 1 counts, ranks and appends only tiles whose bit is set in the unsaturated-tile mask (a run stays one record; its
-// columns are filtered by the walk).  Tile lists hold the sorted positions themselves (pair_jbits = 32).
+// columns are filtered by the walk).  Tile lists hold the sorted positions themselves (GsFrameUniforms::rc_stride != 0 says so).
 #ifndef GS_LIST_SEG
 #define GS_LIST_SEG 256u            // runs a k_lists item walks at least ...
 #endif
@@ -1200,9 +1161,7 @@ __device__ __forceinline__ void k_blend_body(const uint2 *__restrict__ tile_rang
         s_ent[3 * GS_SUBTILE_INERT + 2] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     }
     const uint32_t ntiles = (uint32_t)u.tiles_x * (uint32_t)u.tiles_y;
-    // 4-byte pair records carry position - j_lo, or (compact) the index among the visible splats: `proj` is then the compacted array
-    // (span lists, pair_jbits = 32: the position itself)
-    const uint32_t pair_j_lo = (u.pair_vcap || u.pair_jbits >= 32u) ? 0u : ctl->j_lo, pair_j_mask = u.pair_jbits >= 32u ? 0xFFFFFFFFu : (1u << u.pair_jbits) - 1u;
+    const bool span = u.rc_stride != 0u;                          // the lists hold sorted positions (span lists) / (tile, position) records
     for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {   // round 0: one tile per wave; round 1: small grid
     const uint32_t tx = tile % (uint32_t)u.tiles_x, ty = tile / (uint32_t)u.tiles_x;
     if (ROUND == 1 && !((mask[ty * u.mask_words + (tx >> 5)] >> (tx & 31)) & 1u)) continue;   // this tile is final already
@@ -1259,8 +1218,7 @@ __device__ __forceinline__ void k_blend_body(const uint2 *__restrict__ tile_rang
         for (int h = 0; h < GS_BLEND_BATCH / 64; h++) {            // nearest first: reverse the back-to-front list
             const uint32_t slot = h * 64 + lane;
             if (slot < nb) {
-                const uint32_t j = u.pair_jbits ? pair_j_lo + (reinterpret_cast<const uint32_t *>(pairs)[end - 1 - slot] & pair_j_mask)
-                                                : reinterpret_cast<const uint2 *>(pairs)[end - 1 - slot].y;
+                const uint32_t j = span ? reinterpret_cast<const uint32_t *>(pairs)[end - 1 - slot] : reinterpret_cast<const uint2 *>(pairs)[end - 1 - slot].y;
                 const float4 *src = reinterpret_cast<const float4 *>(proj + j);
                 const float4 ra = src[0], rb = src[1];
                 if (GS_BLEND_BATCH == 64) j_mine = j;
@@ -1397,7 +1355,7 @@ __device__ __forceinline__ void k_blend_body(const uint2 *__restrict__ tile_rang
         if (__all(!live)) break;
     }
 #ifndef GS_NO_NEED_RECORD        // (A/B builds: tools/build_variant.sh noneed -DGS_NO_NEED_RECORD)
-    if (!COUNT && GS_BLEND_BATCH == 64 && !(u.flags & GS_RENDER_NO_EARLY_OUT) && !u.pair_vcap) {   // (compact pair records name a splat by its index among the visible ones: no position)
+    if (!COUNT && GS_BLEND_BATCH == 64 && !(u.flags & GS_RENDER_NO_EARLY_OUT)) {
         // how many of the nearest splats this tile needed (GsControl::need_near): the sorted position of the entry at which its LAST
         // lane left the list (lane k staged entry k of the batch: a tile's entries lie ~1000 sorted positions apart, "the batch" would
         // be 40 % too much)
@@ -1529,7 +1487,7 @@ __device__ __forceinline__ void k_blend_px_body(const uint2 *__restrict__ tile_r
 #define GS_WAVE_LDS_SYNC() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); } while (0)
     if (ROUND == 1 && ctl->j_hi == 0) return;                      // every tile saturated in round 0
     const uint32_t ntiles = (uint32_t)u.tiles_x * (uint32_t)u.tiles_y;
-    const uint32_t pair_j_lo = (u.pair_vcap || u.pair_jbits >= 32u) ? 0u : ctl->j_lo, pair_j_mask = u.pair_jbits >= 32u ? 0xFFFFFFFFu : (1u << u.pair_jbits) - 1u;
+    const bool span = u.rc_stride != 0u;                          // the lists hold sorted positions (span lists) / (tile, position) records
     for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const uint32_t tx = tile % (uint32_t)u.tiles_x, ty = tile / (uint32_t)u.tiles_x;
         if (ROUND == 1 && !((mask[ty * u.mask_words + (tx >> 5)] >> (tx & 31)) & 1u)) continue;   // this tile is final already
@@ -1555,8 +1513,7 @@ __device__ __forceinline__ void k_blend_px_body(const uint2 *__restrict__ tile_r
         float nz[PR];
 #define GS_PX_FETCH(END, NB) do { _Pragma("unroll") for (uint32_t h = 0; h < PR; h++) { const uint32_t slot = h * 64u + (uint32_t)lane;          \
             if (slot < (NB)) {                                                                                                               \
-            const uint32_t j = u.pair_jbits ? pair_j_lo + (reinterpret_cast<const uint32_t *>(pairs)[(END) - 1 - slot] & pair_j_mask)          \
-                                            : reinterpret_cast<const uint2 *>(pairs)[(END) - 1 - slot].y;                                    \
+            const uint32_t j = span ? reinterpret_cast<const uint32_t *>(pairs)[(END) - 1 - slot] : reinterpret_cast<const uint2 *>(pairs)[(END) - 1 - slot].y; \
             const float4 *src = reinterpret_cast<const float4 *>(proj + j);                                                                  \
             n0[h] = src[0]; n1[h] = src[1];                                                                                                  \
             if (SCENE) nz[h] = u.has_depth ? zwin[j] : 0.0f; } } } while (0)
@@ -1633,7 +1590,7 @@ __device__ __forceinline__ void k_blend_px_body(const uint2 *__restrict__ tile_r
         }
         const bool wave_live = __any(live);
         if (lane == 0) s_live[w] = wave_live ? 1u : 0u;
-        if (!(u.flags & GS_RENDER_NO_EARLY_OUT) && !u.pair_vcap) {
+        if (!(u.flags & GS_RENDER_NO_EARLY_OUT)) {
             // GsControl::need_near, per band of the tile (as k_blend per tile): the list entry at which the band's last pixel stopped
             const bool more = ROUND == 0 && u.near_count < ctl->n_kept;
             if (!wave_live || !more) {
@@ -1647,7 +1604,7 @@ __device__ __forceinline__ void k_blend_px_body(const uint2 *__restrict__ tile_r
                         need = 0u;
                         if (range.y > range.x && end_w > range.x + e_max) {
                             const uint32_t li = end_w - 1u - e_max;      // (slot s of a batch = list entry end - 1 - s)
-                            const uint32_t jf = u.pair_jbits ? pair_j_lo + (reinterpret_cast<const uint32_t *>(pairs)[li] & pair_j_mask) : reinterpret_cast<const uint2 *>(pairs)[li].y;
+                            const uint32_t jf = span ? reinterpret_cast<const uint32_t *>(pairs)[li] : reinterpret_cast<const uint2 *>(pairs)[li].y;
                             need = jf < V ? V - jf : 0u;
                         }
                     }
@@ -1696,35 +1653,7 @@ __global__ __launch_bounds__(256) void k_blend_px(const uint2 *__restrict__ tile
 
 int bits_for(uint32_t n) { int b = 1; while (b < 32 && (1u << b) < n) b++; return b; }
 
-// Compact pair records for a first binning round: bits of the visible-splat index, or 0 = not this time.  Used where the position
-// form does not fit 32 bits (or GS_OPT_WIDE_PAIRS = 2 asks for it), the number of visible splats is known from the frames
-// collected so far (vis_hint = the last + 1/8 + 4096), and tile bits + index bits fit.  A round with more visible
-// splats than that is re-rendered (k_pairs_check raises the pair-overflow flag) with the hint it then leaves.
-int gs_compact_bits(const gs_ctx *ctx, int tb, int jb)
-{
-    const gs_ctx *P = gs_root(const_cast<gs_ctx *>(ctx));
-    if (P->wide_pairs || (tb + jb <= 32 && !P->compact_pairs)) return 0;
-    const uint32_t hint = __atomic_load_n(&P->vis_hint, __ATOMIC_RELAXED);
-    if (!hint) return 0;
-    int vb = bits_for(hint);
-    if (vb < 10) vb = 10;
-    return (tb + vb <= 32 && vb <= 20 && vb < jb) ? vb : 0;
-}
-
-int gs_ensure_compact(gs_ctx *ctx, size_t vcap)
-{
-    if (vcap <= ctx->projc_cap) return GS_OK;
-    GS_HIP(hipStreamSynchronize(ctx->stream));
-    if (ctx->projc) (void)hipFree(ctx->projc);
-    if (ctx->zwinc) (void)hipFree(ctx->zwinc);
-    ctx->projc = nullptr; ctx->zwinc = nullptr; ctx->projc_cap = 0;
-    GS_HIP(hipMalloc((void **)&ctx->projc, vcap * sizeof(gsm::Projected)));
-    GS_HIP(hipMalloc((void **)&ctx->zwinc, vcap * sizeof(float)));
-    ctx->projc_cap = vcap;
-    return GS_OK;
-}
-
-// the blend of one round over the tile lists `fpairs` (records of the format v.pair_jbits / v.pair_vcap say)
+// the blend of one round over the tile lists `fpairs` (sorted positions if v.rc_stride != 0, else (tile, position) records)
 template <int ROUND>
 int launch_blend(gs_ctx *ctx, const GsFrameUniforms &u, GsFrameUniforms v, uint8_t *out, const void *fpairs, const gsm::Projected *bproj, const float *bzwin)
 {
@@ -1756,11 +1685,11 @@ int launch_blend(gs_ctx *ctx, const GsFrameUniforms &u, GsFrameUniforms v, uint8
 // or 0 = pair records + radix passes.  The tile columns and rows of the strip must each fit one workgroup (frames up to 4096 x
 // 4096 pixels) and the table stay small (rows x chunks: 20 M positions at 4K would want 42 MB); a record format asked for by
 // name (GS_OPT_WIDE_PAIRS) means the records.
-#define GS_ROWCNT_MAX ((size_t)1 << 22)
+#define GS_ROWCNT_MAX ((size_t)1 << 25)
 uint32_t span_list_stride(const gs_ctx *ctx, const GsFrameUniforms &u, uint32_t jrange)
 {
     const gs_ctx *P = gs_root(const_cast<gs_ctx *>(ctx));
-    if (P->bin_mode == 1 || P->wide_pairs || P->compact_pairs) return 0;
+    if (P->bin_mode == 1) return 0;
     if (u.tiles_x > GS_BLOCK || u.tiles_y > GS_BLOCK) return 0;
     const uint32_t stride = gs_div_up(jrange, GS_BLOCK) + 1u;
     if ((size_t)stride * (size_t)u.tiles_y > GS_ROWCNT_MAX) return 0;
@@ -1799,12 +1728,12 @@ int run_round_spans(gs_ctx *ctx, const GsFrameUniforms &u, uint8_t *out, bool la
     const int rcc = gs_ensure_row_tables(ctx, (size_t)stride * (size_t)u.tiles_y);
     if (rcc != GS_OK) return rcc;
     GsFrameUniforms v = u;
-    v.rc_stride = stride; v.pair_jbits = 32u; v.pair_vcap = 0u;
+    v.rc_stride = stride;
     // the pair buffers hold the runs (geometry and sorted position of each: there are never more runs than tiles) and the lists
     uint32_t *run_geom = reinterpret_cast<uint32_t *>(ctx->pair_a), *run_ref = run_geom + ctx->pair_cap, *lists = reinterpret_cast<uint32_t *>(ctx->pair_b);
     const uint32_t pc = (uint32_t)ctx->pair_cap;
     hipLaunchKernelGGL((k_project<ROUND, true>), dim3(g), dim3(GS_BLOCK), 0, st, ctx->sorted, ctx->splat, v, ctx->proj, ctx->rect,
-                       ctx->tile_count, ctx->row_cnt, ctx->part_vis, ctx->unsat_mask, ctx->zwin, ctx->ctl, ctx->spine_vis);
+                       ctx->tile_count, ctx->row_cnt, ctx->part_vis, ctx->unsat_mask, ctx->zwin, ctx->ctl);
     GS_HIP(hipGetLastError());
     if (ROUND == 0) GS_PROF_RECORD(ctx, 3);
     hipLaunchKernelGGL(k_row_scan<ROUND>, dim3((uint32_t)u.tiles_y), dim3(GS_BLOCK), 0, st, ctx->row_cnt, ctx->row_tot, (const GsControl *)ctx->ctl, u.near_count,
@@ -1846,55 +1775,42 @@ int run_round(gs_ctx *ctx, const GsFrameUniforms &u, uint8_t *out, bool last_rou
     // what the pair sort should expect (grid, one- or two-level offsets): round 1 usually finds nothing; round 0 about what
     // the last collected frames binned (0 = not known yet: the capacity)
     const uint32_t ph = ROUND == 1 ? (uint32_t)(small * GS_CHUNK_S) : __atomic_load_n(&gs_root(ctx)->pair_hint, __ATOMIC_RELAXED);
-    // pair record format: 4 bytes when the tile id and the round's position range fit in 32 bits together -- or, where they do not
-    // (a 4K frame: 15 tile bits; a scene whose tiles do not saturate: 20 position bits), when the tile id and the index among the
-    // round's VISIBLE splats do (compact records: gs_compact_bits)
-    const int tb = bits_for(ntiles);
     const uint32_t jrange = ROUND == 0 ? (u.near_count != 0xFFFFFFFFu && u.near_count < Vmax ? u.near_count : Vmax) : Vmax;
     if (const uint32_t stride = span_list_stride(ctx, u, jrange)) return run_round_spans<ROUND>(ctx, u, out, last_round, g, stride);
-    const int jb = bits_for(jrange);
-    const int vb = ROUND == 0 ? gs_compact_bits(ctx, tb, jb) : 0;
-    const bool p32 = vb > 0 || (!ctx->wide_pairs && tb + jb <= 32);
+    // (tile, position) records through two stable radix passes on the tile id: strips beyond 4096 pixels (more than 256 tile columns or
+    // rows), or GS_OPT_BINNING = 1
+    const int tb = bits_for(ntiles);
     GsFrameUniforms v = u;
-    v.pair_jbits = vb > 0 ? (uint32_t)vb : (p32 ? (uint32_t)jb : 0u);
-    v.pair_vcap = vb > 0 ? 1u << vb : 0u;
-    if (vb > 0) { const int rcc = gs_ensure_compact(ctx, (size_t)1 << vb); if (rcc != GS_OK) return rcc; }
+    v.rc_stride = 0;
     hipLaunchKernelGGL((k_project<ROUND, false>), dim3(g), dim3(GS_BLOCK), 0, st, ctx->sorted, ctx->splat, u, ctx->proj, ctx->rect,
-                       ctx->tile_count, ctx->spine, ctx->part_vis, ctx->unsat_mask, ctx->zwin, ctx->ctl, ctx->spine_vis);
+                       ctx->tile_count, ctx->spine, ctx->part_vis, ctx->unsat_mask, ctx->zwin, ctx->ctl);
     GS_HIP(hipGetLastError());
     if (ROUND == 0) GS_PROF_RECORD(ctx, 3);
     hipLaunchKernelGGL(k_pairs_check<ROUND>, dim3(1), dim3(GS_BLOCK), 0, st, ctx->ctl, (uint32_t)ctx->pair_cap, ctx->spine, ctx->part_vis, g,
-                       u.near_count, last_round ? 1 : 0, ctx->unsat_mask, (uint32_t)u.tiles_y * u.mask_words, ctx->emit_extra, ctx->spine_vis, v.pair_vcap);
+                       u.near_count, last_round ? 1 : 0, ctx->unsat_mask, (uint32_t)u.tiles_y * u.mask_words, ctx->emit_extra);
     // (items = the round's chunks + the extra slices of the heavy ones: about I / GS_EMIT_PAIRS more)
     uint32_t ge = g + (ROUND == 1 ? 0u : gs_div_up(ph ? ph : pc, GS_EMIT_PAIRS)); if (ge > GS_MAX_PART) ge = GS_MAX_PART;
-    if (p32) hipLaunchKernelGGL((k_emit<ROUND, true>), dim3(ge), dim3(GS_BLOCK), 0, st, ctx->proj, ctx->rect, ctx->tile_count, ctx->spine,
-                                ctx->emit_extra, v, (void *)ctx->pair_a, ctx->unsat_mask, ctx->ctl, ctx->spine_vis, ctx->projc, ctx->zwin, ctx->zwinc);
-    else hipLaunchKernelGGL((k_emit<ROUND, false>), dim3(ge), dim3(GS_BLOCK), 0, st, ctx->proj, ctx->rect, ctx->tile_count, ctx->spine,
-                            ctx->emit_extra, v, (void *)ctx->pair_a, ctx->unsat_mask, ctx->ctl, ctx->spine_vis, ctx->projc, ctx->zwin, ctx->zwinc);
-    // (compact records: the blend reads the visible splats' records and window depths from the compacted arrays)
-    const gsm::Projected *bproj = v.pair_vcap ? ctx->projc : ctx->proj;
-    const float *bzwin = v.pair_vcap ? ctx->zwinc : ctx->zwin;
+    hipLaunchKernelGGL(k_emit<ROUND>, dim3(ge), dim3(GS_BLOCK), 0, st, ctx->proj, ctx->rect, ctx->tile_count, ctx->spine,
+                       ctx->emit_extra, v, ctx->pair_a, ctx->unsat_mask, ctx->ctl);
     GS_HIP(hipGetLastError());
     int rc;
-    const int fmt = p32 ? GS_RADIX_KEYONLY : GS_RADIX_PACKED, sh = p32 ? (int)v.pair_jbits : 0;   // (the tile id sits above the position / visible-index bits)
-    const void *fpairs;
+    const uint2 *fpairs;
     if (tb <= 9) {
-        rc = gs_launch_radix_pass(ctx, ctx->pair_a, fmt, ctx->pair_b, fmt, &ctx->ctl->n_pairs, pc, ph, sh, tb);
+        rc = gs_launch_radix_pass(ctx, ctx->pair_a, GS_RADIX_PACKED, ctx->pair_b, GS_RADIX_PACKED, &ctx->ctl->n_pairs, pc, ph, 0, tb);
         if (rc != GS_OK) return rc;
         fpairs = ctx->pair_b;
     } else {
         const int b1 = (tb + 1) / 2, b2 = tb - b1;
-        rc = gs_launch_radix_pass(ctx, ctx->pair_a, fmt, ctx->pair_b, fmt, &ctx->ctl->n_pairs, pc, ph, sh, b1);
+        rc = gs_launch_radix_pass(ctx, ctx->pair_a, GS_RADIX_PACKED, ctx->pair_b, GS_RADIX_PACKED, &ctx->ctl->n_pairs, pc, ph, 0, b1);
         if (rc != GS_OK) return rc;
-        rc = gs_launch_radix_pass(ctx, ctx->pair_b, fmt, ctx->pair_a, fmt, &ctx->ctl->n_pairs, pc, ph, sh + b1, b2);
+        rc = gs_launch_radix_pass(ctx, ctx->pair_b, GS_RADIX_PACKED, ctx->pair_a, GS_RADIX_PACKED, &ctx->ctl->n_pairs, pc, ph, b1, b2);
         if (rc != GS_OK) return rc;
         fpairs = ctx->pair_a;
     }
-    hipLaunchKernelGGL(k_tile_ranges, dim3(ROUND == 1 ? small : 2048), dim3(GS_BLOCK), 0, st, fpairs, v.pair_jbits, ctx->tile_range, ntiles, ROUND,
-                       ctx->ctl);
+    hipLaunchKernelGGL(k_tile_ranges, dim3(ROUND == 1 ? small : 2048), dim3(GS_BLOCK), 0, st, fpairs, ctx->tile_range, ntiles, ROUND, ctx->ctl);
     GS_HIP(hipGetLastError());
     if (ROUND == 0) GS_PROF_RECORD(ctx, 4);
-    return launch_blend<ROUND>(ctx, u, v, out, fpairs, bproj, bzwin);
+    return launch_blend<ROUND>(ctx, u, v, out, fpairs, ctx->proj, ctx->zwin);
 }
 
 template <int ROUND, bool RUNS> GS_BODY(F_project, k_project_body<ROUND, RUNS>);
@@ -1903,7 +1819,7 @@ template <int ROUND> GS_BODY(F_emit_runs, k_emit_runs_body<ROUND>);
 template <int ROUND> GS_BODY(F_seg_count, k_seg_count_body<ROUND>);
 template <int ROUND, bool SEGC> GS_BODY(F_lists, k_lists_body<ROUND, SEGC>);
 template <int ROUND> GS_BODY(F_pairs_check, k_pairs_check_body<ROUND>);
-template <int ROUND, bool P32> GS_BODY(F_emit, k_emit_body<ROUND, P32>);
+template <int ROUND> GS_BODY(F_emit, k_emit_body<ROUND>);
 GS_BODY(F_tile_ranges, k_tile_ranges_body);
 template <int ROUND, bool SCENE, bool SUB> GS_BODY(F_blend, k_blend_body<false, ROUND, SCENE, SUB>);
 template <int ROUND, bool SCENE> GS_BODY(F_blend_px, k_blend_px_body<ROUND, SCENE>);
@@ -1948,14 +1864,14 @@ int run_round_spans2(gs_ctx *const S[2], const GsFrameUniforms U[2], uint8_t *co
     hipStream_t st = ctx->stream;
     for (int k = 0; k < 2; k++) { const int rcc = gs_ensure_row_tables(S[k], (size_t)stride * (size_t)u.tiles_y); if (rcc != GS_OK) return rcc; }
     GsFrameUniforms V[2] = { U[0], U[1] };
-    for (int k = 0; k < 2; k++) { V[k].rc_stride = stride; V[k].pair_jbits = 32u; V[k].pair_vcap = 0u; }
+    for (int k = 0; k < 2; k++) V[k].rc_stride = stride;
     uint32_t *geom[2], *ref[2], *lists[2];
     for (int k = 0; k < 2; k++) { geom[k] = reinterpret_cast<uint32_t *>(S[k]->pair_a); ref[k] = geom[k] + S[k]->pair_cap; lists[k] = reinterpret_cast<uint32_t *>(S[k]->pair_b); }
     gs_twin<F_project<ROUND, true>, GS_BLOCK>(g, st,
         gs_pack_make((const uint32_t *)S[0]->sorted, (const uint4 *)S[0]->splat, V[0], S[0]->proj, S[0]->rect, S[0]->tile_count, S[0]->row_cnt, S[0]->part_vis,
-                     (const uint32_t *)S[0]->unsat_mask, S[0]->zwin, S[0]->ctl, S[0]->spine_vis),
+                     (const uint32_t *)S[0]->unsat_mask, S[0]->zwin, S[0]->ctl),
         gs_pack_make((const uint32_t *)S[1]->sorted, (const uint4 *)S[1]->splat, V[1], S[1]->proj, S[1]->rect, S[1]->tile_count, S[1]->row_cnt, S[1]->part_vis,
-                     (const uint32_t *)S[1]->unsat_mask, S[1]->zwin, S[1]->ctl, S[1]->spine_vis));
+                     (const uint32_t *)S[1]->unsat_mask, S[1]->zwin, S[1]->ctl));
     GS_HIP(hipGetLastError());
     if (ROUND == 0) GS_PROF_RECORD(ctx, 3);
     gs_twin<F_row_scan<ROUND>, GS_BLOCK>((uint32_t)u.tiles_y, st,
@@ -2002,66 +1918,57 @@ int run_round2(gs_ctx *const S[2], const GsFrameUniforms U[2], uint8_t *const ou
     if (ROUND == 0 && u.near_count != 0xFFFFFFFFu) { const uint32_t gn = gs_div_up(u.near_count < Vmax ? u.near_count : Vmax, GS_BLOCK); if (gn < g) g = gn ? gn : 1; }
     const uint32_t pc = (uint32_t)(S[0]->pair_cap < S[1]->pair_cap ? S[0]->pair_cap : S[1]->pair_cap);
     const uint32_t ph = ROUND == 1 ? (uint32_t)(small * GS_CHUNK_S) : __atomic_load_n(&gs_root(ctx)->pair_hint, __ATOMIC_RELAXED);
-    const int tb = bits_for(ntiles);
     const uint32_t jrange = ROUND == 0 ? (u.near_count != 0xFFFFFFFFu && u.near_count < Vmax ? u.near_count : Vmax) : Vmax;
     if (const uint32_t stride = span_list_stride(ctx, u, jrange)) return run_round_spans2<ROUND>(S, U, out, last_round, g, stride);
-    const int jb = bits_for(jrange);
-    const int vb = ROUND == 0 ? gs_compact_bits(ctx, tb, jb) : 0;
-    const bool p32 = vb > 0 || (!ctx->wide_pairs && tb + jb <= 32);
+    const int tb = bits_for(ntiles);
     GsFrameUniforms V[2] = { U[0], U[1] };
-    V[0].pair_jbits = V[1].pair_jbits = vb > 0 ? (uint32_t)vb : (p32 ? (uint32_t)jb : 0u);
-    V[0].pair_vcap = V[1].pair_vcap = vb > 0 ? 1u << vb : 0u;
-    if (vb > 0) for (int k = 0; k < 2; k++) { const int rcc = gs_ensure_compact(S[k], (size_t)1 << vb); if (rcc != GS_OK) return rcc; }
+    V[0].rc_stride = V[1].rc_stride = 0;
     gs_twin<F_project<ROUND, false>, GS_BLOCK>(g, st,
         gs_pack_make((const uint32_t *)S[0]->sorted, (const uint4 *)S[0]->splat, U[0], S[0]->proj, S[0]->rect, S[0]->tile_count, S[0]->spine, S[0]->part_vis,
-                     (const uint32_t *)S[0]->unsat_mask, S[0]->zwin, S[0]->ctl, S[0]->spine_vis),
+                     (const uint32_t *)S[0]->unsat_mask, S[0]->zwin, S[0]->ctl),
         gs_pack_make((const uint32_t *)S[1]->sorted, (const uint4 *)S[1]->splat, U[1], S[1]->proj, S[1]->rect, S[1]->tile_count, S[1]->spine, S[1]->part_vis,
-                     (const uint32_t *)S[1]->unsat_mask, S[1]->zwin, S[1]->ctl, S[1]->spine_vis));
+                     (const uint32_t *)S[1]->unsat_mask, S[1]->zwin, S[1]->ctl));
     GS_HIP(hipGetLastError());
     if (ROUND == 0) GS_PROF_RECORD(ctx, 3);
     gs_twin<F_pairs_check<ROUND>, GS_BLOCK>(1, st,
         gs_pack_make(S[0]->ctl, (uint32_t)S[0]->pair_cap, S[0]->spine, (const uint32_t *)S[0]->part_vis, g, U[0].near_count, last_round ? 1 : 0, S[0]->unsat_mask,
-                     (uint32_t)u.tiles_y * u.mask_words, S[0]->emit_extra, S[0]->spine_vis, V[0].pair_vcap),
+                     (uint32_t)u.tiles_y * u.mask_words, S[0]->emit_extra),
         gs_pack_make(S[1]->ctl, (uint32_t)S[1]->pair_cap, S[1]->spine, (const uint32_t *)S[1]->part_vis, g, U[1].near_count, last_round ? 1 : 0, S[1]->unsat_mask,
-                     (uint32_t)u.tiles_y * u.mask_words, S[1]->emit_extra, S[1]->spine_vis, V[1].pair_vcap));
+                     (uint32_t)u.tiles_y * u.mask_words, S[1]->emit_extra));
     uint32_t ge = g + (ROUND == 1 ? 0u : gs_div_up(ph ? ph : pc, GS_EMIT_PAIRS)); if (ge > GS_MAX_PART) ge = GS_MAX_PART;
-#define GS_EMIT2(P) gs_twin<F_emit<ROUND, P>, GS_BLOCK>(ge, st,                                                                                         \
-        gs_pack_make((const gsm::Projected *)S[0]->proj, (const uint2 *)S[0]->rect, (const uint32_t *)S[0]->tile_count, (const uint32_t *)S[0]->spine,    \
-                     (const uint2 *)S[0]->emit_extra, V[0], (void *)S[0]->pair_a, (const uint32_t *)S[0]->unsat_mask, (const GsControl *)S[0]->ctl,       \
-                     (const uint32_t *)S[0]->spine_vis, S[0]->projc, (const float *)S[0]->zwin, S[0]->zwinc),                                            \
-        gs_pack_make((const gsm::Projected *)S[1]->proj, (const uint2 *)S[1]->rect, (const uint32_t *)S[1]->tile_count, (const uint32_t *)S[1]->spine,    \
-                     (const uint2 *)S[1]->emit_extra, V[1], (void *)S[1]->pair_a, (const uint32_t *)S[1]->unsat_mask, (const GsControl *)S[1]->ctl,       \
-                     (const uint32_t *)S[1]->spine_vis, S[1]->projc, (const float *)S[1]->zwin, S[1]->zwinc))
-    if (p32) GS_EMIT2(true); else GS_EMIT2(false);
-#undef GS_EMIT2
+    gs_twin<F_emit<ROUND>, GS_BLOCK>(ge, st,
+        gs_pack_make((const gsm::Projected *)S[0]->proj, (const uint2 *)S[0]->rect, (const uint32_t *)S[0]->tile_count, (const uint32_t *)S[0]->spine,
+                     (const uint2 *)S[0]->emit_extra, V[0], S[0]->pair_a, (const uint32_t *)S[0]->unsat_mask, (const GsControl *)S[0]->ctl),
+        gs_pack_make((const gsm::Projected *)S[1]->proj, (const uint2 *)S[1]->rect, (const uint32_t *)S[1]->tile_count, (const uint32_t *)S[1]->spine,
+                     (const uint2 *)S[1]->emit_extra, V[1], S[1]->pair_a, (const uint32_t *)S[1]->unsat_mask, (const GsControl *)S[1]->ctl));
     GS_HIP(hipGetLastError());
-    const int fmt = p32 ? GS_RADIX_KEYONLY : GS_RADIX_PACKED, sh = p32 ? (int)V[0].pair_jbits : 0;
+    const int fmt = GS_RADIX_PACKED;
     const void *in[2]; void *outp[2]; const uint32_t *np[2] = { &S[0]->ctl->n_pairs, &S[1]->ctl->n_pairs };
     uint32_t *cnt[2] = { nullptr, nullptr }; const uint32_t *fill[2] = { nullptr, nullptr };
     const void *fpairs[2];
     int rc;
     if (tb <= 9) {
         for (int k = 0; k < 2; k++) { in[k] = S[k]->pair_a; outp[k] = S[k]->pair_b; }
-        rc = gs_launch_radix_pass2(S, in, fmt, outp, fmt, np, pc, ph, sh, tb, false, 0xFFFFFFFFu, 0, cnt, fill);
+        rc = gs_launch_radix_pass2(S, in, fmt, outp, fmt, np, pc, ph, 0, tb, false, 0xFFFFFFFFu, 0, cnt, fill);
         if (rc != GS_OK) return rc;
         fpairs[0] = S[0]->pair_b; fpairs[1] = S[1]->pair_b;
     } else {
         const int b1 = (tb + 1) / 2, b2 = tb - b1;
         for (int k = 0; k < 2; k++) { in[k] = S[k]->pair_a; outp[k] = S[k]->pair_b; }
-        rc = gs_launch_radix_pass2(S, in, fmt, outp, fmt, np, pc, ph, sh, b1, false, 0xFFFFFFFFu, 0, cnt, fill);
+        rc = gs_launch_radix_pass2(S, in, fmt, outp, fmt, np, pc, ph, 0, b1, false, 0xFFFFFFFFu, 0, cnt, fill);
         if (rc != GS_OK) return rc;
         for (int k = 0; k < 2; k++) { in[k] = S[k]->pair_b; outp[k] = S[k]->pair_a; }
-        rc = gs_launch_radix_pass2(S, in, fmt, outp, fmt, np, pc, ph, sh + b1, b2, false, 0xFFFFFFFFu, 0, cnt, fill);
+        rc = gs_launch_radix_pass2(S, in, fmt, outp, fmt, np, pc, ph, b1, b2, false, 0xFFFFFFFFu, 0, cnt, fill);
         if (rc != GS_OK) return rc;
         fpairs[0] = S[0]->pair_a; fpairs[1] = S[1]->pair_a;
     }
     gs_twin<F_tile_ranges, GS_BLOCK>(ROUND == 1 ? small : 2048, st,
-                                     gs_pack_make(fpairs[0], V[0].pair_jbits, S[0]->tile_range, ntiles, ROUND, (const GsControl *)S[0]->ctl),
-                                     gs_pack_make(fpairs[1], V[1].pair_jbits, S[1]->tile_range, ntiles, ROUND, (const GsControl *)S[1]->ctl));
+                                     gs_pack_make((const uint2 *)fpairs[0], S[0]->tile_range, ntiles, ROUND, (const GsControl *)S[0]->ctl),
+                                     gs_pack_make((const uint2 *)fpairs[1], S[1]->tile_range, ntiles, ROUND, (const GsControl *)S[1]->ctl));
     GS_HIP(hipGetLastError());
     if (ROUND == 0) GS_PROF_RECORD(ctx, 4);
-    const gsm::Projected *bproj[2] = { vb > 0 ? S[0]->projc : S[0]->proj, vb > 0 ? S[1]->projc : S[1]->proj };
-    const float *bzwin[2] = { vb > 0 ? S[0]->zwinc : S[0]->zwin, vb > 0 ? S[1]->zwinc : S[1]->zwin };
+    const gsm::Projected *bproj[2] = { S[0]->proj, S[1]->proj };
+    const float *bzwin[2] = { S[0]->zwin, S[1]->zwin };
     return launch_blend2<ROUND>(S, u, V, out, fpairs, bproj, bzwin);
 }
 

@@ -418,19 +418,17 @@ typedef struct gs_stats {
                                    chain of frame k+1 runs under the tail of frame k -- as the reference overlaps its
                                    worker sort with drawing.  A gs_sort() begins a frame; it moves to the next lane when
                                    the previous frame was handed off asynchronously.  1 = strictly one frame at a time   */
-#define GS_OPT_WIDE_PAIRS 6     /* record format of the binning (same images whatever the format).  0 (default): 4 bytes `tile << b | position`
-                                   whenever tile bits + position bits of the binning round fit in 32; where they do not (a 4K frame, a
-                                   scene whose tiles do not saturate) 4 bytes `tile << b | index among the round's visible splats` when
-                                   THAT fits -- the number of visible splats is known from the frames before --, else 8 bytes.  1: always
-                                   8-byte (tile, position) records.  2: the visible-index form wherever it fits.                 */
+#define GS_OPT_WIDE_PAIRS 6     /* 1: the depth sort carries its general 8-byte (key, index) records whatever the number of splats -- the format of
+                                   N > 2^25, where 4-byte records no longer hold bucket and index -- (same order; a test hook for that format on
+                                   small inputs).  0 (default): 4-byte records up to 2^25 splats.  (Rounds 2-5: also the binning's record
+                                   formats; since round 6 its (tile, position) records have ONE form, 8 bytes.)                     */
 #define GS_OPT_BINNING 16       /* how a binning round turns visible splats into per-tile lists (same lists, same images).  0 (default): span
                                    lists -- every splat becomes one run of tiles per tile row it touches, and the runs of a tile row, in
                                    sorted order, are expanded into the row's tile lists by one thread per tile column: four launches per
-                                   round (project, row scan, runs, lists; five with the segment counts of frames that hold many runs
-                                   per tile row), work per run -- wherever a strip has at most 256 tile columns and rows (4096 x 4096 pixels) and
-                                   the round at most a few million sorted positions; elsewhere, and with 1: (tile, splat) pair records
-                                   sorted by two stable radix passes (rounds 1-3; eight launches per round).  GS_OPT_WIDE_PAIRS != 0 asks
-                                   for a record format and therefore for the records.                                            */
+                                   round (project, row scan, runs, lists; five with the segment counts of frames that hold many runs per
+                                   tile row) -- wherever a strip has at most 256 tile columns and rows (4096 x 4096 pixels), i.e. for every
+                                   BASELINE configuration; beyond that, and with 1: (tile, splat) pair records sorted by two stable radix
+                                   passes (rounds 1-3; eight launches per round).                                                */
 #define GS_OPT_SUBTILE 17       /* how the blend walks a tile's list (same pixels, bit for bit, whatever the value).  The reference's rasteriser shades
                                    only the fragments a quad covers (index.js:52-66, 166-176); a 16x16 tile's wavefront evaluates a list entry for
                                    all 256 pixels.  With sub-tile lists the wavefront splits every batch of 64 entries into the lists of the

@@ -1212,9 +1212,10 @@ def test_stream_coupling_calls_order_frames_with_caller_streams(scene_small):
 
 
 @pytest.mark.parametrize("w,h,n,permille", [(640, 360, 30000, 0), (1920, 1080, 300000, 0), (1920, 1080, 300000, 1000), (333, 211, 5000, 300)])
-def test_narrow_and_wide_pair_records_give_identical_frames(w, h, n, permille):
-    """The binning uses 4-byte (tile << b | position) records when they fit and 8-byte (tile, position) records otherwise:
-    the two formats must produce the same image, fragment count and pair count, for single- and two-round frames."""
+def test_both_depth_sort_record_formats_give_identical_frames(w, h, n, permille):
+    """GS_OPT_WIDE_PAIRS = 1 makes the depth sort carry its general 8-byte (key, index) records (the format of N > 2^25) on a small input:
+    same order, hence the same image, fragment count and pair count, for single- and two-round frames.  (Rounds 2-5 also switched the
+    binning's record formats with it; since round 6 the (tile, position) records have one form -- tests: span lists against them, below.)"""
     rows = synth.make_splat_rows(n, seed=909)
     cam = synth.index_html_camera(w, h, 123.0, capi=capi)
     out = {}
@@ -1223,49 +1224,16 @@ def test_narrow_and_wide_pair_records_give_identical_frames(w, h, n, permille):
             c.set_option(capi.OPT_WIDE_PAIRS, wide)
             c.set_option(capi.OPT_NEAR_PERMILLE, permille)
             c.push_splat(rows)
-            c.sort(cam["view"])
+            idx = c.sort(cam["view"])
             img = c.render(_params(cam))
             pairs = c.stats()["n_pairs"]
             c.render(_params(cam, flags=capi.RENDER_COUNT_FRAGS))
-            out[wide] = (img, pairs, c.stats()["n_frags"])
-    assert np.array_equal(out[0][0], out[1][0]) and out[0][1] == out[1][1] and out[0][2] == out[1][2]
+            out[wide] = (img, pairs, c.stats()["n_frags"], idx)
+    assert np.array_equal(out[0][0], out[1][0]) and out[0][1] == out[1][1] and out[0][2] == out[1][2] and np.array_equal(out[0][3], out[1][3])
     assert out[0][1] > 0
-    # the third form (round 3): 4-byte records naming a splat by its index among the round's VISIBLE splats, whose projected records
-    # k_emit lays out in that order -- what a 4K frame (15 tile bits) or an unsaturated scene (20 position bits) falls back on
-    # instead of 8-byte records.  GS_OPT_WIDE_PAIRS = 2 uses it wherever it fits; the first frame (no hint of the number of visible
-    # splats yet) is drawn with the other forms, the following ones compact: synchronous, queued alone and in pairs, over a scene.
     with capi.Context(0) as c:
-        c.set_option(capi.OPT_WIDE_PAIRS, 2)
-        c.set_option(capi.OPT_NEAR_PERMILLE, permille)
-        c.push_splat(rows)
-        for rep in range(3):
-            c.sort(cam["view"], want_indices=False)
-            assert np.array_equal(c.render(_params(cam)), out[0][0]), rep
-            assert permille == 0 or c.stats()["n_pairs"] == out[0][1]          # (adaptive: the share moves from frame to frame)
-        c.render(_params(cam, flags=capi.RENDER_COUNT_FRAGS))
-        assert c.stats()["n_frags"] == out[0][2]
-        for batch in (1, 2):
-            c.set_option(capi.OPT_FRAME_BATCH, batch)
-            bufs = [capi.host_frame(h, w) for _ in range(4)]
-            for b, _ in bufs:
-                c.sort(cam["view"], want_indices=False)
-                c.render_into(_params(cam, flags=capi.RENDER_ASYNC), b)
-            c.sync()
-            for b, o in bufs:
-                assert np.array_equal(b, out[0][0]), batch
-                o.free()
-        depth = np.full((h, w), 0.9996, np.float32); depth[:, : w // 2] = 1.0
-        want_scene = None
-        for mode in (1, 2):
-            c.set_option(capi.OPT_WIDE_PAIRS, mode)
-            c.set_scene(depth, None)
-            c.sort(cam["view"], want_indices=False)
-            img = c.render(_params(cam))
-            img = c.render(_params(cam))
-            c.set_scene(None, None)
-            if want_scene is None:
-                want_scene = img
-            assert np.array_equal(img, want_scene), mode
+        with pytest.raises(capi.GsError):
+            c.set_option(capi.OPT_WIDE_PAIRS, 2)                     # (the compact 4-byte binning records of rounds 3-5 are gone)
 
 
 @pytest.mark.parametrize("w,h,n,fat", [(640, 360, 30000, 1.0), (1920, 1080, 300000, 1.0), (333, 211, 5000, 1.0), (1280, 720, 6000, 25.0),
@@ -1371,12 +1339,13 @@ def test_enqueue_threads_on_and_off_give_identical_frames_and_statistics(scene_s
     assert results[0][2:] == results[1][2:]
 
 
-def test_huge_splats_in_both_rounds_and_record_formats(scene_small):
+def test_huge_splats_in_both_rounds_and_both_binnings(scene_small):
     """k_emit hands its work out by pair slots: a chunk of 256 consecutive splats whose footprints add up to more than
     GS_EMIT_PAIRS tiles is written by several workgroups (k_pairs_check's extra items), and a narrow strip makes chunks with
     thousands of one-tile rows (several passes over the run table per item).  With fat splats and a tiny first-round share
     most records are written in ROUND 1 (masked tiles: the kth unsaturated tile of a run), with a large share in round 0.
-    Every combination must give the single-round image, the oracle's fragment count included."""
+    Every combination -- span lists and (GS_OPT_BINNING = 1) the pair records k_emit writes -- must give the single-round image, the oracle's
+    fragment count included."""
     rows = synth.make_splat_rows(6000, seed=31).reshape(-1, 32).copy()
     rows[:, 12:24] = (rows[:, 12:24].copy().view("<f4") * np.float32(25.0)).view(np.uint8)     # enormous footprints
     w, h = 1280, 720
@@ -1385,7 +1354,7 @@ def test_huge_splats_in_both_rounds_and_record_formats(scene_small):
     images = {}
     for permille, wide in ((1000, 0), (2, 0), (2, 1), (500, 0), (500, 1)):
         with capi.Context(0) as c:
-            c.set_option(capi.OPT_NEAR_PERMILLE, permille); c.set_option(capi.OPT_WIDE_PAIRS, wide)
+            c.set_option(capi.OPT_NEAR_PERMILLE, permille); c.set_option(capi.OPT_BINNING, wide)
             c.push_splat(rows)
             idx = c.sort(cam["view"])
             images[(permille, wide)] = c.render(_params(cam))
@@ -1950,31 +1919,3 @@ def test_posted_sort_draws_with_the_last_completed_order_until_it_is_collected(s
         assert np.array_equal(buf[0], want_b)
         assert c.sort_poll(wait=True, want_indices=False) is True
         buf[1].free()
-
-
-@pytest.mark.gpu
-def test_queued_frames_stay_queued_with_compact_pair_records(scene_small):
-    """a context that has not measured its share draws a queued frame synchronously (the frames behind it then use the measured
-    share) -- at most twice in a row, like the cold sorts: compact pair records (GS_OPT_WIDE_PAIRS = 2) name no sorted positions, their
-    blends record no need, and such a context must not end up drawing EVERY queued frame synchronously.  A frame that was queued moves
-    the next frame to another pipeline lane; one that was drawn synchronously does not."""
-    import torch
-    w, h = 640, 360
-    cams = [synth.index_html_camera(w, h, 3.0 * k, capi=capi) for k in range(12)]
-    with capi.Context(0) as c, capi.Context(0) as ref:
-        c.set_option(capi.OPT_WIDE_PAIRS, 2)
-        c.push_splat(scene_small["rows"]); ref.push_splat(scene_small["rows"])
-        for rnd in range(2):
-            lanes, bufs = [], []
-            for cam in cams:
-                b = torch.zeros(w * h * 4, dtype=torch.uint8, device="cuda")
-                c.sort(cam["view"], want_indices=False)
-                c.render_device(_params(cam, flags=capi.RENDER_ASYNC), b.data_ptr())
-                lanes.append(c.frame_lane()); bufs.append(b)
-            c.sync()
-            torch.cuda.synchronize()
-            assert len(set(lanes[2:])) > 1, lanes                     # after at most two cold frames the frames rotate over the lanes
-            for cam, b in zip(cams, bufs):
-                ref.sort(cam["view"], want_indices=False)
-                assert np.array_equal(b.cpu().numpy().reshape(h, w, 4), ref.render(_params(cam)))
-            c.set_option(capi.OPT_NEAR_PERMILLE, 0)                   # adapt from scratch: cold again, bounded again
