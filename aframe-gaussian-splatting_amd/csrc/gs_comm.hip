@@ -108,6 +108,8 @@ struct GsLoopHub {
     std::mutex m;
     std::condition_variable cv;
     int world = 0, refs = 0, timeout_s = GS_LOOP_TIMEOUT_S;
+    int jitter_us = 0;                                             // test hook (GS_COMM_TEST_JITTER_US): every post is held back by a pseudo-random time below this
+    std::atomic<uint32_t> jitter_seq{0};
     bool failed = false;                                           // a rank gave up: everybody waiting fails too
     std::map<std::pair<int, int>, std::deque<GsLoopBuf *>> box;    // (source, destination) -> posted messages, in order
     std::vector<GsLoopBuf *> pool;                                 // free buffers
@@ -170,6 +172,13 @@ ncclResult_t loop_send(const void *src, size_t bytes, int, int peer, ncclComm_t 
     b->bytes = bytes;
     if (bytes) LOOP_HIP(hipMemcpyAsync(b->p, src, bytes, hipMemcpyDeviceToDevice, st));
     LOOP_HIP(hipEventRecord(b->ready, st));
+    if (h->jitter_us > 0) {
+        // RCCL orders the messages of ONE pair of ranks and nothing else: the pieces of a frame may reach the root in any order across
+        // its peers, and a peer's piece of the next frame before another peer's piece of this one.  The test hook makes that happen here.
+        uint32_t x = (h->jitter_seq.fetch_add(1) + 1u) * 2654435761u ^ ((uint32_t)ep->rank * 40503u);
+        x ^= x >> 15; x *= 2246822519u; x ^= x >> 13;
+        usleep(x % (uint32_t)h->jitter_us);
+    }
     { std::lock_guard<std::mutex> lk(h->m); h->box[std::make_pair(ep->rank, peer)].push_back(b); }
     h->cv.notify_all();
     return LOOP_OK;
@@ -256,6 +265,8 @@ int loop_join(gs_ctx *ctx, GsComm *c, const void *id, int rank, int world)
             h->world = world; h->key = key;
             const char *t = getenv("GS_COMM_TIMEOUT_S");
             if (t && atoi(t) > 0) h->timeout_s = atoi(t);
+            const char *jt = getenv("GS_COMM_TEST_JITTER_US");
+            if (jt && atoi(jt) > 0) h->jitter_us = atoi(jt);
             g_loop_hubs[key] = h;
         } else h = it->second;
         if (h->world != world) FAILC(GS_E_BADARG, "gs_comm_init: this in-process communicator has %d ranks, not %d", h->world, world);

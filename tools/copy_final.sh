@@ -5,7 +5,7 @@ cp $F/bench.json $P/${T}_final_bench.json
 cp $F/bench_steps20_1.json $P/${T}_bench_steps20.json; cp $F/bench_steps20_2.json $P/${T}_bench_steps20_run2.json; cp $F/bench_steps20_3.json $P/${T}_bench_steps20_run3.json
 cp $F/bench_pair_records.json $P/${T}_bench_pair_records.json
 cp $F/bench_whole_sorts.json $P/${T}_bench_whole_sorts.json; cp $F/bench_whole_sorts_steps20.json $P/${T}_bench_whole_sorts_steps20.json
-for c in c1 c3 c4 c5; do cp $F/config_$c.json $P/${T}_config_$c.json; done
+for c in c1 c3 c4 c5 r_outside r_unsat; do cp $F/config_$c.json $P/${T}_config_$c.json; done
 cp $F/bench_comm_world1.json $P/${T}_bench_comm_world1.json
 for n in 1 2 8; do cp $F/single_process_device_$n.json $P/${T}_single_process_device_$n.json; cp $F/single_process_host_$n.json $P/${T}_single_process_host_$n.json; done
 cp $F/pmc_counters.md $P/${T}_pmc_counters.md; cp $F/pmc_counters.json $P/pmc_counters.json

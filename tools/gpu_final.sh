@@ -23,6 +23,8 @@ timeout 600 python bench.py --config C1 --no-cpu-baseline --no-extras > $O/confi
 timeout 900 python bench.py --config C3 --no-cpu-baseline --no-extras > $O/config_c3.json 2>/dev/null
 timeout 600 python bench.py --config C4 --no-cpu-baseline > $O/config_c4.json 2>/dev/null
 timeout 1200 python bench.py --config C5 --steps 120 --no-cpu-baseline > $O/config_c5.json 2>/dev/null
+timeout 600 python bench.py --config R_outside --no-cpu-baseline --no-extras > $O/config_r_outside.json 2>/dev/null
+timeout 600 python bench.py --config R_unsat --no-cpu-baseline --no-extras > $O/config_r_unsat.json 2>/dev/null
 GS_BENCH_COMM=1 timeout 600 python bench.py --no-cpu-baseline --no-extras --no-configs > $O/bench_comm_world1.json 2>/dev/null
 GS_BENCH_BINNING=1 timeout 600 python bench.py --no-cpu-baseline --no-extras --no-configs > $O/bench_pair_records.json 2>/dev/null
 GS_BENCH_SORT_NEAR=0 timeout 600 python bench.py --no-cpu-baseline --no-extras --no-configs > $O/bench_whole_sorts.json 2>/dev/null
@@ -32,7 +34,7 @@ for n in 1 2 8; do
   timeout 300 python bench.py --gpus $n --single-process --host-direct > $O/single_process_host_$n.json 2>/dev/null
 done
 fi
-for f in bench bench_steps20_1 bench_steps20_2 bench_steps20_3 config_c1 config_c3 config_c4 config_c5 bench_comm_world1 bench_pair_records bench_whole_sorts bench_whole_sorts_steps20; do python -c "
+for f in bench bench_steps20_1 bench_steps20_2 bench_steps20_3 config_c1 config_c3 config_c4 config_c5 config_r_outside config_r_unsat bench_comm_world1 bench_pair_records bench_whole_sorts bench_whole_sorts_steps20; do python -c "
 import json,sys
 try:
     d=json.load(open('$O/$f.json')); print('$f', d['value'], d.get('latency',{}).get('fps_depth1'), (d.get('roofline') or {}).get('traffic'), (d.get('frame_hbm') or {}).get('traffic'))
@@ -44,13 +46,13 @@ python tools/prof_summary.py $O/prof/bench_results.db > $O/kernel_stats.md 2>&1
 python tools/prof_tail.py $O/prof/bench_results.db 1440 > $O/timed_frames_c2.txt 2>&1
 rm -rf $O/prof
 ( cd /tmp && timeout 600 rocprofv3 --kernel-trace -d $O/pov -o b -- python $R/tools/stage_bench.py --depths 3 --frames 3000 --batch 2 --near 0 > $O/pov.log 2>&1 ); python tools/prof_overlap.py $O/pov/b_results.db 2 0.3 0.8 > $O/overlap_c2.txt 2>&1; rm -rf $O/pov
-TRACE=14 tools/gpu_stage.sh ${TAG}_c2 --near 0 --depths 1,3 > /dev/null 2>&1; cp gpurun_out/stage_${TAG}_c2.txt $O/stage_c2.txt
-TRACE=14 tools/gpu_stage.sh ${TAG}_c2_outside --near 0 --depths 1,3 --outside > /dev/null 2>&1; cp gpurun_out/stage_${TAG}_c2_outside.txt $O/stage_c2_outside_cloud.txt
-TRACE=14 tools/gpu_stage.sh ${TAG}_unsat --near 0 --depths 1,3 --opacity-div 10 --frames 120 > /dev/null 2>&1; cp gpurun_out/stage_${TAG}_unsat.txt $O/stage_unsaturated.txt
+tools/gpu.sh stage ${TAG}_c2 --near 0 --depths 1,3 > /dev/null 2>&1; cp gpurun_out/stage_${TAG}_c2.txt $O/stage_c2.txt
+tools/gpu.sh stage ${TAG}_c2_outside --near 0 --depths 1,3 --outside > /dev/null 2>&1; cp gpurun_out/stage_${TAG}_c2_outside.txt $O/stage_c2_outside_cloud.txt
+tools/gpu.sh stage ${TAG}_unsat --near 0 --depths 1,3 --opacity-div 10 --frames 120 > /dev/null 2>&1; cp gpurun_out/stage_${TAG}_unsat.txt $O/stage_unsaturated.txt
 if [ "$PART" != "profiles" ]; then
-TAIL=600 TRACE=15 tools/gpu_stage.sh ${TAG}_c3 --splats 6291456 --cutout --near 0 --depths 1,3 --frames 120 --split 1 > /dev/null 2>&1; cp gpurun_out/stage_${TAG}_c3.txt $O/stage_c3.txt
-TAIL=330 TRACE=14 tools/gpu_stage.sh ${TAG}_c5 --splats 20971520 --size 3840x2160 --frames 60 --depths 1,3 --near 0 > /dev/null 2>&1; cp gpurun_out/stage_${TAG}_c5.txt $O/stage_c5.txt
-TAIL=330 TRACE=14 tools/gpu_stage.sh ${TAG}_c5_outside --splats 20971520 --size 3840x2160 --frames 60 --depths 1,3 --near 0 --outside > /dev/null 2>&1; cp gpurun_out/stage_${TAG}_c5_outside.txt $O/stage_c5_outside_cloud.txt
+TAIL=600 tools/gpu.sh stage ${TAG}_c3 --splats 6291456 --cutout --near 0 --depths 1,3 --frames 120 --split 1 > /dev/null 2>&1; cp gpurun_out/stage_${TAG}_c3.txt $O/stage_c3.txt
+TAIL=330 tools/gpu.sh stage ${TAG}_c5 --splats 20971520 --size 3840x2160 --frames 60 --depths 1,3 --near 0 > /dev/null 2>&1; cp gpurun_out/stage_${TAG}_c5.txt $O/stage_c5.txt
+TAIL=330 tools/gpu.sh stage ${TAG}_c5_outside --splats 20971520 --size 3840x2160 --frames 60 --depths 1,3 --near 0 --outside > /dev/null 2>&1; cp gpurun_out/stage_${TAG}_c5_outside.txt $O/stage_c5_outside_cloud.txt
 fi
 timeout 120 python tools/pcie_probe.py > $O/pcie_probe.txt 2>&1
 ls $O
