@@ -17,6 +17,14 @@ ORBIT_FRAMES = 120          # the benchmark orbit: entity yaw 360 i / 120 degree
 LANES = 3                   # the library's default pipeline depth (GS_OPT_PIPELINE_DEPTH), what bench.py measures with
 PUSH_ROWS = 1 << 22         # progressive ingest (index.js:279-298): rows per gs_push_splat
 ASYNC_WARM = 6              # queued frames per lane before the warm-up steps (pre-roll, untimed): see preroll()
+FRUSTUM_SORT = True         # frames whose order stays on the GPU are sorted with gs_sort_for over the WHOLE frame (bench.py, tests/test_as_benched.py):
+                            # only the splats whose fragments can reach the viewport enter the order -- a sub-sequence of the reference's.
+                            # Up to 2 M splats (frustum_sort(cfg)): +5.6 % at the headline, +2.5 % at 720p; at 20 M the reach test makes the
+                            # depth pass -- the frame's longest kernel there -- a third slower (5 399 -> 3 634 frames/s): whole sorts
+
+
+def frustum_sort(cfg):
+    return bool(FRUSTUM_SORT and cfg["splats"] <= (2 << 20) and not cfg["xr"])
 
 _SEED_BASE = 0x5EED0000
 
@@ -195,7 +203,7 @@ def sort_mode_name(opts, stats):
     return SORT_MODES.get(int(stats.get("sort_mode", 0)), "whole")
 
 
-def timed_work(opts, stats, lanes=LANES):
+def timed_work(opts, stats, lanes=LANES, frustum=False):
     """{sort_mode, near_permille, frames_in_flight, text}: the reference sorts EVERY splat it keeps (index.js:507-570) and shades every
     fragment (index.js:166-176); what the timed frames do instead -- with bit-identical pixels -- is said here, not implied."""
     fb = int(opts.get("OPT_FRAME_BATCH", 1))
@@ -205,6 +213,10 @@ def timed_work(opts, stats, lanes=LANES):
     parts = ["%d frames in flight (%d pipeline lanes%s)" % (depth * fb, depth, " x 2 frames per launch, GS_OPT_FRAME_BATCH: the two frames of a pair share each "
                                                             "kernel launch, grid (x, 2), on separate scratch" if fb == 2 else "")]
     parts.append("every frame runs its own depth pass over all N resident splats (key, culls, bucket: index.js:517-561)")
+    if frustum:
+        parts.append("which hands on only the splats whose fragments can reach the viewport (gs_sort_for over the whole frame: a conservative bound on "
+                     "the quad's reach in x and y; the order is the reference's with the splats the frame cannot show left out, the bucket scale still that of "
+                     "every kept splat)")
     if mode == "whole":
         parts.append("and sorts every kept splat (the reference's whole order)")
     elif mode == "tail":
@@ -224,4 +236,5 @@ def timed_work(opts, stats, lanes=LANES):
                      "turns out unsaturated flags its frame, which gs_sync() draws again in full" % share)
     if stats.get("subtile"):
         parts.append("the blend walks sub-tile lists (GS_OPT_SUBTILE: sixteen 4x4-pixel blocks per tile)")
-    return {"sort_mode": mode, "near_permille": share, "frames_in_flight": depth * fb, "text": "; ".join(parts)}
+    return {"sort_mode": mode, "near_permille": share, "frames_in_flight": depth * fb, "text": "; ".join(parts),
+            "sort_call": "gs_sort_for(whole frame)" if frustum else "gs_sort"}

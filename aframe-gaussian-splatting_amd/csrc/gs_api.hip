@@ -330,7 +330,9 @@ static void share_from_need(gs_ctx *ctx /* owner */, uint32_t need, uint32_t fra
         if (cover < 0.85) target = (float)cover;
     }
     if (target < ctx->near_floor) target = ctx->near_floor;      // (a walked share's floor, where there is one)
-    if (target < 0.001f) target = 0.001f;
+    // (never fewer than 4096 positions: until round 6 never less than one permille -- 21 K positions of a 20 M scene, eight times what a
+    // frame sorted for its frustum needs there)
+    { const float fl = 4096.0f / (float)ctx->n; if (target < fl) target = fl > 1.0f ? 1.0f : fl; }
     ctx->near_frac = target;
     ctx->share_measured = true;
 }
@@ -1156,7 +1158,7 @@ GS_API int gs_sort_for(gs_ctx *ctx, const float view[4], const float *cutout16, 
     GsSortStrip st;
     memcpy(st.mv, strip->model_view, sizeof st.mv); memcpy(st.proj, strip->projection, sizeof st.proj);
     st.focal = strip->focal > 0 ? strip->focal : (float)(((double)strip->fb_height / 2.0) * fabs((double)strip->projection[5]));
-    st.vw = (float)strip->fb_width; st.x0 = strip->x0; st.x1 = strip->x1;
+    st.vw = (float)strip->fb_width; st.vh = (float)strip->fb_height; st.x0 = strip->x0; st.x1 = strip->x1;
     // a perspective projection whose w does not depend on x or y (three.js PerspectiveCamera, WebXR eye frusta); anything else
     // is sorted whole
     const float *P = strip->projection;

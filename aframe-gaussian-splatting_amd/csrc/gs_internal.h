@@ -45,7 +45,7 @@
 #endif
 
 // strip: sort only the splats that can reach columns [x0, x1) of the frame these uniforms draw (gs_sort_for); nullptr = all
-struct GsSortStrip { float mv[16], proj[16]; float focal, vw; int32_t x0, x1; };
+struct GsSortStrip { float mv[16], proj[16]; float focal, vw, vh; int32_t x0, x1; };   // (vh > 0: the rows [0, vh) are tested too)
 #define GS_DEPTH_BINS 2048u        // depth histogram of a near-only sort: sign-less f32 bits >> 20 (exponent + 3 mantissa bits)
 #define GS_DH_COPIES 8u            // ... kept in this many copies (workgroup % copies)
 #define GS_DEPTH_COARSE (GS_DEPTH_BINS / 32u)   // ... with sums over 32 consecutive bins behind the copies

@@ -16,7 +16,7 @@ struct SortUniforms {                                            // widened on t
     int has_strip;
 };
 // gs_sort_for: rows 0, 1, 2 of gsModelViewMatrix, rows 0, 3 of gsProjectionMatrix, and the strip in pixels
-struct StripUniforms { float mvr0[4], mvr1[4], mvr2[4], pr0[4], pr3[4]; float focal, norm_a, half_w, sx0, sx1; };
+struct StripUniforms { float mvr0[4], mvr1[4], mvr2[4], pr0[4], pr1[4], pr3[4]; float focal, norm_a, half_w, sx0, sx1, half_h, sy1; };   // (sy1 > 0: rows [0, sy1) tested too)
 // the depth kernel's chunking is its own (no histogram depends on it)
 #ifndef GS_DEPTH_IPT
 #define GS_DEPTH_IPT 4             // items per thread and pass: 52 vector registers, 8 waves per SIMD (8 items: 92, 5 waves)
@@ -102,7 +102,15 @@ __device__ __forceinline__ bool strip_may_touch(const StripUniforms &s, float x,
     float ax = __builtin_amdgcn_sqrtf(2.0f * fmaf(sd, sd, 0.3f));
     if (!(ax < 1024.0f)) ax = 1024.0f;
     const float reach = fmaf(2.06f, ax, 3.0f);
-    return !(xpx + reach < s.sx0 || xpx - reach > s.sx1);
+    if (xpx + reach < s.sx0 || xpx - reach > s.sx1) return false;
+    // the rows of the frame (round 6: a strip is as tall as its frame, and gs_sort_for over the WHOLE frame is a frustum cull): the same
+    // bound serves both axes -- 2 sqrt(v1y^2 + v2y^2) <= 2 |v1| too
+    if (s.sy1 > 0.0f) {
+        const float cy = fmaf(s.pr1[2], camz, fmaf(s.pr1[1], camy, s.pr1[0] * camx)) + s.pr1[3];
+        const float ypx = fmaf(cy, __builtin_amdgcn_rcpf(cw), 1.0f) * s.half_h;
+        if (ypx + reach < 0.0f || ypx - reach > s.sy1) return false;
+    }
+    return true;
 }
 
 // SPEC (near-only sorts of long inputs, round 4): the pass hands the candidates on itself.  A near-only sort keeps the splats whose
@@ -1059,7 +1067,7 @@ static void fill_sort_uniforms(const gs_ctx *ctx, const float view[4], const flo
     memset(&su, 0, sizeof su);
     if (strip && ctx->renderable) {
         const float *m = strip->mv, *p = strip->proj;
-        for (int k = 0; k < 4; k++) { su.mvr0[k] = m[4 * k]; su.mvr1[k] = m[4 * k + 1]; su.mvr2[k] = m[4 * k + 2]; su.pr0[k] = p[4 * k]; su.pr3[k] = p[4 * k + 3]; }
+        for (int k = 0; k < 4; k++) { su.mvr0[k] = m[4 * k]; su.mvr1[k] = m[4 * k + 1]; su.mvr2[k] = m[4 * k + 2]; su.pr0[k] = p[4 * k]; su.pr1[k] = p[4 * k + 1]; su.pr3[k] = p[4 * k + 3]; }
         // spectral norm of A = mat3(gsModelViewMatrix): power iteration on A^T A (symmetric 3x3), bracketed from above by the
         // Frobenius norm; a rigid pose with uniform scale s gives s
         double ata[3][3], fro = 0.0;
@@ -1082,6 +1090,7 @@ static void fill_sort_uniforms(const gs_ctx *ctx, const float view[4], const flo
         if (!(na <= sqrt(fro) * 1.0001)) na = sqrt(fro) * 1.0001;
         su.norm_a = (float)na * 1.0001f;
         su.focal = strip->focal; su.half_w = 0.5f * strip->vw; su.sx0 = (float)strip->x0; su.sx1 = (float)strip->x1;
+        su.half_h = 0.5f * strip->vh; su.sy1 = strip->vh > 0.0f ? strip->vh : 0.0f;
         u.has_strip = (su.norm_a == su.norm_a && su.focal > 0.0f && strip->x1 > strip->x0) ? 1 : 0;
     }
 

@@ -158,6 +158,9 @@ def main():
     BC.apply_options(ctx, capi, opts)
     frame_batch = opts.get("OPT_FRAME_BATCH", 1)
     blend_split = opts.get("OPT_BLEND_SPLIT", 0)
+    # the sort of a frame whose order stays on the GPU is gs_sort_for over the WHOLE frame (round 6): the depth pass hands on only the splats
+    # whose fragments can reach the viewport -- a sub-sequence of the reference's order, the same pixels (GS_BENCH_FRUSTUM_SORT=0: gs_sort)
+    frustum_sort = BC.frustum_sort(cfg) and os.environ.get("GS_BENCH_FRUSTUM_SORT", "1") != "0"
 
     def piece_params(k, v, x0, x1, flags):
         q = views[k][v]
@@ -189,7 +192,10 @@ def main():
                 ctx.sort_gathered(cams[k]["view"], cams[k]["cutout"], views[k])
             ctx.render_gathered(views[k], 0, None, flags)
         else:
-            ctx.sort(cams[k]["view"], cams[k]["cutout"], want_indices=False)
+            if frustum_sort:
+                ctx.sort_for(cams[k]["view"], cams[k]["cutout"], views[k][0], want_indices=False)
+            else:
+                ctx.sort(cams[k]["view"], cams[k]["cutout"], want_indices=False)
             views[k][0].flags = flags
             ctx.render_device(views[k][0], None)
 
@@ -472,7 +478,7 @@ def main():
                    ", splat buffer replicated, pieces gathered on rank 0 by the C library over RCCL (gs_render_gathered)")
         else:
             par = "single GPU" + (", both eyes on it" if args.xr else "") + (", gathered path exercised at world 1 (GS_BENCH_COMM)" if comm1 else "")
-        work = BC.timed_work(dict(opts, OPT_PIPELINE_DEPTH=max(LANES, depth)), s)
+        work = BC.timed_work(dict(opts, OPT_PIPELINE_DEPTH=max(LANES, depth)), s, frustum=frustum_sort and not gathered)
         out = {
             "metric": metric,
             "value": round(fps, 3), "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
@@ -483,6 +489,7 @@ def main():
                        "pieces_of_rank0": [[v, x0, x1] for v, x0, x1 in mine], "gathered_frame_equals_single_gpu_render": frame_check,
                        "blend_split_min_list": blend_split, "sort_share_permille": sort_share if world > 1 else 0,
                        "sort_mode": work["sort_mode"], "near_permille": work["near_permille"], "frames_in_flight": work["frames_in_flight"],
+                       "sort_call": work["sort_call"],
                        "timed_work": work["text"] + "; see latency.fps_depth1 for one frame at a time",
                        "frames_per_launch": frame_batch,
                        "preroll_frames": preroll + BC.ASYNC_WARM * max(LANES, depth) + args.warmup,
@@ -1191,7 +1198,10 @@ def measure_config(name, capi, synth, BC, steps, warmup, device=0, utilisation=F
                 ctx.sort_gathered(cams[k]["view"], cams[k]["cutout"], views[k])
                 ctx.render_gathered(views[k], 0, None, flags)
             else:
-                ctx.sort(cams[k]["view"], cams[k]["cutout"], want_indices=False)
+                if BC.frustum_sort(cfg):
+                    ctx.sort_for(cams[k]["view"], cams[k]["cutout"], views[k][0], want_indices=False)
+                else:
+                    ctx.sort(cams[k]["view"], cams[k]["cutout"], want_indices=False)
                 views[k][0].flags = flags
                 ctx.render_device(views[k][0], None)
 
@@ -1236,7 +1246,7 @@ def measure_config(name, capi, synth, BC, steps, warmup, device=0, utilisation=F
         rl = stage_rooflines(pf, cfg["splats"], pf["V_sorted"], pf["Vp_visible"], pf["I_pairs"], w * h)
         dom = max(rl, key=lambda r: r["us"])
         fps = steps / elapsed
-        work = BC.timed_work(opts, s2)
+        work = BC.timed_work(opts, s2, frustum=BC.frustum_sort(cfg))
         util = None
         if utilisation:
             util = lane_utilisation(ctx, capi, cams, views, w, h, used[:: max(1, len(used) // 4)][:4])

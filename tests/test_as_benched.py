@@ -93,8 +93,11 @@ def test_every_baseline_configuration_as_bench_py_draws_it(name):
                 ctx.sort_gathered(spec["view"], spec["cutout"], spec["params"])
                 ctx.render_gathered(spec["params"], 0, [b.data_ptr() for b in bufs] if bufs else None, flags)
             else:
-                ctx.sort(spec["view"], spec["cutout"], want_indices=False)
                 p = spec["params"][0]
+                if BC.frustum_sort(cfg):                            # (as bench.py: the sort of a frame whose order stays on the GPU)
+                    ctx.sort_for(spec["view"], spec["cutout"], p, want_indices=False)
+                else:
+                    ctx.sort(spec["view"], spec["cutout"], want_indices=False)
                 p.flags = flags
                 ctx.render_device(p, bufs[0].data_ptr() if bufs else None)
 

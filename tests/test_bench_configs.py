@@ -131,6 +131,9 @@ def test_timed_work_says_what_the_option_set_and_statistics_say():
     w = BC.timed_work({"OPT_PIPELINE_DEPTH": 2}, {"sort_mode": 2, "near_permille": 23})
     assert w["sort_mode"] == "stash" and w["frames_in_flight"] == 2 and "stashed" in w["text"] and "2 pipeline lanes)" in w["text"]
     assert BC.timed_work({}, {"sort_mode": 1, "near_permille": 40})["sort_mode"] == "histogram"
+    w = BC.timed_work(o2, {"sort_mode": 3, "near_permille": 30}, frustum=True)
+    assert w["sort_call"] == "gs_sort_for(whole frame)" and "reach the viewport" in w["text"] and BC.timed_work(o2, {})["sort_call"] == "gs_sort"
+    assert [n for n in sorted(BC.ALL) if BC.frustum_sort(BC.ALL[n])] == ["C1", "C2", "R_outside", "R_unsat"]     # (C3 / C5: the depth pass is the long pole; C4: two views, one order)
     # bench.py writes these at the top level of its line and does not carry the sentence VERDICT r5 objected to
     src = open(os.path.join(ROOT, "bench.py")).read()
     assert "every frame still runs its own full sort" not in src and "every frame still runs its own full sort" not in open(os.path.join(ROOT, "README.md")).read()

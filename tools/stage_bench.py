@@ -25,7 +25,7 @@ ap.add_argument("--sort-near", type=int, default=None, help="GS_OPT_SORT_NEAR (0
 ap.add_argument("--opacity-div", type=int, default=1, help="divide every splat's opacity byte by this (10: the scene whose tiles do not saturate)")
 ap.add_argument("--no-early-out", action="store_true", help="GS_RENDER_NO_EARLY_OUT: every fragment blended")
 ap.add_argument("--strip", default=None, help="k/G: render only strip k of G tile-aligned column strips (what one of G GPUs does)")
-ap.add_argument("--sort-for", action="store_true", help="with --strip: gs_sort_for the strip instead of the full gs_sort")
+ap.add_argument("--sort-for", action="store_true", help="gs_sort_for the strip (--strip) or the whole frame instead of the full gs_sort")
 ap.add_argument("--outside", action="store_true", help="the camera OUTSIDE the cloud, 3 sigma from its centre (synth.outside_cloud_camera)")
 ap.add_argument("--subtile", type=int, default=None, help="GS_OPT_SUBTILE (0 off, 1 auto = the library's default, 2 always)")
 ap.add_argument("--opt", action="append", default=[], help="NAME=VALUE: any capi.OPT_<NAME> (repeatable)")
@@ -88,7 +88,10 @@ def go(n):
 
 
 for k in range(0, 120, 4):                                   # buffers sized, share settled (if adaptive)
-    ctx.sort(cams[k]["view"], cams[k]["cutout"], want_indices=False)
+    if a.sort_for:
+        ctx.sort_for(cams[k]["view"], cams[k]["cutout"], params[k], want_indices=False)
+    else:
+        ctx.sort(cams[k]["view"], cams[k]["cutout"], want_indices=False)
     if not a.sort_only:
         params[k].flags = 0
         ctx.render_device(params[k], None)
