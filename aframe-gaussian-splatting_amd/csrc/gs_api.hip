@@ -1013,7 +1013,7 @@ GS_API int gs_clear(gs_ctx *ctx)
     GS_HIP(hipSetDevice(ctx->device));
     TRY(drain_all(ctx));
     ctx->n = 0; ctx->renderable = true; ctx->pair_hint = 0; ctx->run_hint = 0; ctx->last_pairs = 0; ctx->last_visible = 0;
-    ctx->near_frac = 0.25f; ctx->near_floor = 0.0f; ctx->clean_frames = 0; ctx->skip_hold = 0; ctx->single_round_frames = 0; ctx->last_kept = 0; ctx->share_measured = false; ctx->need_margin = 0.0f; ctx->cold_sorts = 0; ctx->cold_frames = 0; memset(ctx->need_hist, 0, sizeof ctx->need_hist);
+    ctx->near_frac = 0.25f; ctx->near_floor = 0.0f; ctx->clean_frames = 0; ctx->skip_hold = 0; ctx->single_round_frames = 0; ctx->last_kept = 0; ctx->share_measured = false; ctx->need_margin = 0.0f; ctx->cold_sorts = 0; ctx->cold_frames = 0; ctx->share_kind = 0; memset(ctx->need_hist, 0, sizeof ctx->need_hist);
     ctx->near_stash_off = false; ctx->near_spec = false; ctx->near_spec_hold = 0; ctx->near_spec_backoff = 0; ctx->near_spec_miss_credit = 0;
     for (int i = 0; i < GS_MAX_LANES; i++) {
         gs_ctx *L = ctx->lanes[i];
@@ -1187,6 +1187,21 @@ static int sort_common(gs_ctx *ctx, const float view[4], const float *cutout16, 
     if (ctx->pend_lane > 0 && lane == ctx->pend_lane - 1) FAIL(GS_E_STATE, "gs_sort: this frame's lane holds the sort begun with gs_sort_begin: collect it with gs_sort_poll first");
     ctx->cur = lane; ctx->rot = rot; ctx->cur_async = false;
     log_sort(L, view, cutout16, strip);
+    {   // The share of splats binned first is measured in POSITIONS of the order the frames are drawn from.  A strip's order (gs_sort_for: the
+        // splats that can reach the strip -- the whole frame: the frustum) is a sub-sequence of the whole one: "the nearest 30 000" of it reach
+        // five times as deep.  When the kind of order changes, what was measured on the other kind is dropped (round 6: bench.py's frames sorted
+        // for their frustum, then its one-frame-at-a-time extras with gs_sort, drew those with a share a fifth of what they needed and were
+        // drawn again by gs_sync until the share had crept up).
+        const uint32_t kind = strip ? 2u : 1u;                      // (strips of one frame differ less from each other than any of them from the whole order:
+                                                                    // a context that draws several strips in turn keeps one measurement, as before)
+        if (ctx->share_kind && ctx->share_kind != kind && ctx->near_fixed_permille <= 0) {
+            ctx->near_frac = 0.25f; ctx->near_floor = 0.0f; ctx->share_measured = false; ctx->need_margin = 0.0f; ctx->cold_sorts = 0; ctx->cold_frames = 0;
+            ctx->clean_frames = 0; ctx->skip_hold = 0;
+            memset(ctx->need_hist, 0, sizeof ctx->need_hist); memset(ctx->need_hist_frames, 0, sizeof ctx->need_hist_frames);
+            for (int i = 0; i < GS_MAX_LANES; i++) if (ctx->lanes[i]) { ctx->lanes[i]->need_seed_pending = 1u; ctx->lanes[i]->need_word_est = 0; }
+        }
+        ctx->share_kind = kind;
+    }
     const uint32_t near_req = (out_idx || out_n) ? 0u : sort_near_request(ctx);     // (the caller wants the order itself: all of it)
     // (a context that has not measured its share yet draws its next frame synchronously -- gs_render_uniforms --: its sort on the caller's
     // thread then, not on an enqueue thread that was created a moment ago and has to be woken first: 0.14 ms of that call's 0.7)

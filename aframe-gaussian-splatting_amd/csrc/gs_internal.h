@@ -199,6 +199,8 @@ struct gs_ctx {
     uint32_t status_seq, status_base; // lane: renders handed to the lane so far (which word of the ring the next one gets) / its value when the first frame of the collection under way was queued
     uint32_t *status_cur;          // lane: the word of the render handed over last (gs_frame_status_device)
     uint32_t cold_sorts;           // owner: sorts run on the caller's thread because the share had not been measured yet (at most two in a row)
+    uint32_t share_kind;           // owner: what kind of order the share was measured on -- 1: whole orders (gs_sort), 2: strips' orders (gs_sort_for);
+                                   // 0: nothing yet.  A sort of another kind starts the measurement afresh (positions of a strip's order are not positions of the whole)
     uint32_t cold_frames;          // owner: queued frames drawn synchronously for the same reason (at most two in a row: a context whose frames
                                    // never measure -- compact pair records, GS_NO_NEED_RECORD builds -- keeps its pipelining)
     float sv_view[4], sv_cutout[16]; bool sv_has_cutout, sv_has_strip; GsSortStrip sv_strip;

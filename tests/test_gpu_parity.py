@@ -1034,7 +1034,9 @@ def test_near_only_sorts_fill_the_positions_a_frame_reads_like_whole_sorts():
             # column strips, sorted with gs_sort_for (what one of several GPUs does): near-only as well, same pixels
             if batch == 1:
                 strips = [(0, 320), (320, 640)]
-                for attempt in range(6):
+                # (round 6: a strip's order is another KIND of order than the whole one -- its positions reach deeper --, so the share measured on
+                # whole orders above is dropped at the first gs_sort_for and measured again: the strips' sorts are whole until it has settled)
+                for attempt in range(10):
                     sb = []
                     for k in range(6):
                         for x0, x1 in strips:
@@ -1045,9 +1047,11 @@ def test_near_only_sorts_fill_the_positions_a_frame_reads_like_whole_sorts():
                             sb.append((k, x0, x1, b))
                     try:
                         c.sync()
-                        break
+                        st = c.stats()
+                        if attempt >= 1 and (st["sort_records"] < st["n_sorted"] or attempt >= 4):
+                            break
                     except capi.GsError as e:
-                        assert e.code == capi.E_RETRY and attempt < 5
+                        assert e.code == capi.E_RETRY and attempt < 9
                 torch.cuda.synchronize()
                 s = c.stats()
                 assert 0 < s["sort_records"] <= s["n_sorted"], s
