@@ -127,7 +127,7 @@ GS_HD double ordered_to_f64(uint64_t u)
 // JS parseInt(Number) for the value range the pack loop produces.  `pow10tab` holds, for E = 6..330 and
 // D = 1..9, the double nearest to D*10^-E at index (E-6)*9 + (D-1) (built on the host with strtod).
 // For 0 < |v| < 1e-6 the JS string is in exponent form and parseInt yields its leading digit, which is
-// the D of the largest table entry <= |v| (DESIGN.md "parseInt quirk").
+// the D of the largest table entry <= |v| (docs/LAB_NOTES.md "Sort bit-exactness notes").
 #define GS_POW10_EMIN 6
 #define GS_POW10_EMAX 330
 GS_HD int32_t js_parse_int(double v, const double *pow10tab)

@@ -22,7 +22,7 @@
 // kernels of round 1 find an empty range and return at once.
 //
 // The fixed-function rasteriser + ROP of the reference have no structural counterpart; parity is defined at
-// the pixel level against oracle/gs_oracle.c (DESIGN.md "Pixel parity").
+// the pixel level against oracle/gs_oracle.c (docs/LAB_NOTES.md "Pixel parity argument").
 #include "gs_internal.h"
 
 namespace {
