@@ -32,8 +32,23 @@ while time.time() - t0 < float(os.environ.get("STRESS_SECONDS", "20")):
         kk = k if g.random() < 0.08 else (kk + 1) % len(cams); k = kk
         if r >= 0.86: r = 0.0 if g.random() < 0.9 else r     # (fewer option changes: the share has to settle for near-only sorts to start)
     try:
-        if r < 0.70:
+        if r < 0.62:
             c.sort(cams[k]["view"], None, want_indices=False); c.render_device(P(cams[k], flags=capi.RENDER_ASYNC), None)
+        elif r < 0.68:                                       # (round 6) the frame sorted for its frustum: gs_sort_for over the whole frame, queued
+            c.sort_for(cams[k]["view"], None, P(cams[k]), want_indices=False); c.render_device(P(cams[k], flags=capi.RENDER_ASYNC), None)
+        elif r < 0.70:                                       # (round 6) a posted sort: draws meanwhile use the last completed order (index.js:201-207)
+            k0 = int(g.integers(0, len(cams)))
+            c.sort(cams[k0]["view"], None, want_indices=False)                   # the completed order: pose k0's
+            c.sort_begin(cams[k]["view"])
+            stale = c.render(P(cams[k]))
+            if g.random() < 0.5:
+                c.render_device(P(cams[k], flags=capi.RENDER_ASYNC), None)       # a queued frame next to the posted sort
+            got = c.sort_poll(wait=True)
+            fresh = c.render(P(cams[k]))
+            ref.sort(cams[k0]["view"], None, want_indices=False); rstale = ref.render(P(cams[k]))
+            ridx = ref.sort(cams[k]["view"]); rfresh = ref.render(P(cams[k]))
+            assert np.array_equal(got, ridx) and np.array_equal(stale, rstale) and np.array_equal(fresh, rfresh), "posted sort mismatch at op %d" % ops
+            checked += 1
         elif r < 0.80:
             idx = c.sort(cams[k]["view"]); img = c.render(P(cams[k]))
             ridx = ref.sort(cams[k]["view"]); rimg = ref.render(P(cams[k]))
@@ -54,7 +69,8 @@ while time.time() - t0 < float(os.environ.get("STRESS_SECONDS", "20")):
         elif r < 0.95: c.set_option(capi.OPT_ENQUEUE_THREADS, int(g.integers(0, 2)))
         elif r < 0.96: c.set_option(capi.OPT_PROFILE, int(g.integers(0, 3)))
         elif r < 0.966: c.set_option(capi.OPT_FRAME_BATCH, int(g.integers(1, 3)))
-        elif r < 0.97: c.set_option(capi.OPT_BINNING, int(g.integers(0, 2)))      # span lists <-> pair records (the reference context keeps the default)
+        elif r < 0.968: c.set_option(capi.OPT_BINNING, int(g.integers(0, 2)))     # span lists <-> pair records (the reference context keeps the default)
+        elif r < 0.97: c.set_option(capi.OPT_SUBTILE, int(g.integers(0, 3)))     # (round 6) sub-tile lists off / automatic / always: same pixels
         elif r < 0.972 and NEAR: c.set_option(capi.OPT_SORT_NEAR, int(g.integers(0, 3)) or 2)
         elif r < 0.985 and n < rows.shape[0]:
             m = min(rows.shape[0], n + int(g.integers(1, 9000)))
