@@ -701,9 +701,14 @@ SIMDS, CLOCK_GHZ = 1024, 2.4
 GUIDE_CYCLES_PER_VALU = 2.0
 
 
+PMC_NAMES = {"C1": "c1", "C2": "c2", "C3": "c3", "C5": "c5", "R_outside": "outside", "R_unsat": "unsat"}   # bench_configs name -> tools/gpu_pmc.sh's
+
+
 def pmc_config_name(world, n_splats, args):
     if world != 1 or args.xr:
         return None
+    if getattr(args, "config", None) in ("R_outside", "R_unsat"):
+        return PMC_NAMES[args.config]
     if n_splats == N_TRAIN_DEFAULT and not args.cutout:
         return "c2" if not args.size else ("c1" if args.size.lower() == "1280x720" else None)
     if n_splats == 6291456 and args.cutout and not args.size:
@@ -713,9 +718,9 @@ def pmc_config_name(world, n_splats, args):
     return None
 
 
-def pmc_load(world, n_splats, args):
+def pmc_load(world, n_splats, args, name=None):
     """The committed rocprofv3 --pmc passes of this configuration -- only if they were taken from the kernel sources this run uses.
-    Returns (config dict or None, note)."""
+    Returns (config dict or None, note).  name: tools/gpu_pmc.sh's name of the configuration (else derived from the flags)."""
     try:
         import hashlib
         pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_counters.json")))
@@ -724,7 +729,7 @@ def pmc_load(world, n_splats, args):
         for f in sorted(os.listdir(csrc)):
             if f.endswith((".hip", ".h", ".cpp")):
                 h.update(open(os.path.join(csrc, f), "rb").read())
-        name = pmc_config_name(world, n_splats, args)
+        name = name or pmc_config_name(world, n_splats, args)
         if name is None or name not in pmc.get("configs", {}):
             return None, "no PMC pass for this configuration"
         if pmc.get("_csrc_sha1") != h.hexdigest():
@@ -1243,7 +1248,8 @@ def measure_config(name, capi, synth, BC, steps, warmup, device=0, utilisation=F
         pf = {"V_sorted": s2["n_sorted"], "Vp_visible": s2["n_visible"], "I_pairs": s2["n_pairs"],
               "ms_sort": round(s2["sum_ms_sort"] / k2, 4), "ms_project": round(s2["sum_ms_project"] / k2, 4),
               "ms_bin": round(s2["sum_ms_bin"] / k2, 4), "ms_blend": round(s2["sum_ms_blend"] / k2, 4)}
-        rl = stage_rooflines(pf, cfg["splats"], pf["V_sorted"], pf["Vp_visible"], pf["I_pairs"], w * h)
+        pmc_cfg = pmc_load(1, cfg["splats"], None, name=PMC_NAMES.get(name))[0] if PMC_NAMES.get(name) else None
+        rl = stage_rooflines(pf, cfg["splats"], pf["V_sorted"], pf["Vp_visible"], pf["I_pairs"], w * h, pmc_cfg)
         dom = max(rl, key=lambda r: r["us"])
         fps = steps / elapsed
         work = BC.timed_work(opts, s2, frustum=BC.frustum_sort(cfg))
@@ -1256,7 +1262,7 @@ def measure_config(name, capi, synth, BC, steps, warmup, device=0, utilisation=F
                 "lane_utilisation": util, "frames_redrawn_by_sync": s2.get("retried_frames", 0),
                 "per_frame": pf, "per_frame_note": "stage times per VIEW drawn (HIP events, pipelined loop)" if nv > 1 else "stage times per frame (HIP events, pipelined loop)",
                 "dominant_stage": {"stage": dom["stage"], "us": dom["us"], "bound": dom["bound"], "frac": dom["frac"]},
-                "rooflines": [{k: r[k] for k in ("stage", "bound", "algorithmic_bytes", "us", "achieved", "frac")} for r in rl]}
+                "rooflines": [{k: r[k] for k in ("stage", "bound", "algorithmic_bytes", "us", "achieved", "frac", "traffic")} for r in rl]}
 
 
 def js_visible(rows, w, h):

@@ -54,7 +54,7 @@ def main():
     d, out_md, out_json = sys.argv[1:4]
     res = {"configs": {}}
     md = []
-    for cfg in ("c2", "c1", "c3", "c5", "outside"):
+    for cfg in ("c2", "c1", "c3", "c5", "outside", "unsat"):
         f = load(os.path.join(d, cfg + "_FETCH_SIZE", "pmc_results.db")); w = load(os.path.join(d, cfg + "_WRITE_SIZE", "pmc_results.db"))
         v = load(os.path.join(d, cfg + "_VALU", "pmc_results.db"))
         if not f and not w and not v:

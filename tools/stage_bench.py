@@ -67,14 +67,18 @@ for kv in a.opt:
     ctx.set_option(getattr(capi, "OPT_" + kv.split("=")[0].upper()), int(kv.split("=")[1]))
 
 
+def sort_k(k):
+    if a.sort_for:
+        ctx.sort_for(cams[k]["view"], cams[k]["cutout"], params[k], want_indices=False)
+    else:
+        ctx.sort(cams[k]["view"], cams[k]["cutout"], want_indices=False)
+
+
 def go(n):
     t0 = time.perf_counter()
     for i in range(n):
         k = i % 120
-        if a.sort_for:
-            ctx.sort_for(cams[k]["view"], cams[k]["cutout"], params[k], want_indices=False)
-        else:
-            ctx.sort(cams[k]["view"], cams[k]["cutout"], want_indices=False)
+        sort_k(k)
         if not a.sort_only:
             params[k].flags = capi.RENDER_ASYNC | (capi.RENDER_NO_EARLY_OUT if a.no_early_out else 0)
             ctx.render_device(params[k], None)
@@ -88,10 +92,7 @@ def go(n):
 
 
 for k in range(0, 120, 4):                                   # buffers sized, share settled (if adaptive)
-    if a.sort_for:
-        ctx.sort_for(cams[k]["view"], cams[k]["cutout"], params[k], want_indices=False)
-    else:
-        ctx.sort(cams[k]["view"], cams[k]["cutout"], want_indices=False)
+    sort_k(k)
     if not a.sort_only:
         params[k].flags = 0
         ctx.render_device(params[k], None)
@@ -100,7 +101,7 @@ if a.pmc_run:
     ctx.set_option(capi.OPT_PIPELINE_DEPTH, int(a.depths.split(",")[0]))
     for rep in range(4):                                     # the second binning round is switched off after 16 clean frames
         for k in range(0, 120, 3):
-            ctx.sort(cams[k]["view"], cams[k]["cutout"], want_indices=False); params[k].flags = 0; ctx.render_device(params[k], None)
+            sort_k(k); params[k].flags = 0; ctx.render_device(params[k], None)
     go(24)
     t = go(a.frames) or go(a.frames)
     s = ctx.stats()
@@ -108,7 +109,7 @@ if a.pmc_run:
     ntl = ((x1 - x0 + 15) // 16) * ((H + 15) // 16)
     ev = []
     for k in range(0, 120, 5):
-        ctx.sort(cams[k]["view"], cams[k]["cutout"], want_indices=False); params[k].flags = 0; ctx.render_device(params[k], None)
+        sort_k(k); params[k].flags = 0; ctx.render_device(params[k], None)
         ev.append(int(ctx.download(capi.BUF_TILE_STATS, ntl, np.uint32, 2)[:, 0].astype(np.int64).sum()))
     print("PMCRUN frames_queued=%d frames_per_launch=%d fps=%.1f entries_evaluated_per_frame=%.1f pairs_last_frame=%d visible_last_frame=%d near_permille=%d" % (
         24 + a.frames, a.batch, a.frames / t, float(np.mean(ev)), s["n_pairs"], s["n_visible"], s["near_permille"]), flush=True)
