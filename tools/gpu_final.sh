@@ -13,7 +13,7 @@ cp gpurun_out/pixel_parity.jsonl gpurun_out/js_visible_fps.txt gpurun_out/ply_lo
 grep -E "^stress_|stress ok" $O/pytest.log > $O/stress_and_tsan.txt
 fi
 # counters first: the bench lines report them only from the sources they were taken from
-CONFIGS="${CONFIGS:-c2 c1 c3 c5 outside}" tools/gpu_pmc.sh $TAG > $O/pmc.log 2>&1; tail -3 $O/pmc.log | cut -c1-160
+CONFIGS="${CONFIGS:-c2 c1 c3 c5 outside unsat}" tools/gpu_pmc.sh $TAG > $O/pmc.log 2>&1; tail -3 $O/pmc.log | cut -c1-160
 cp gpurun_out/pmc_$TAG.md $O/pmc_counters.md; cp gpurun_out/pmc_$TAG.json $O/pmc_counters.json; cp gpurun_out/pmc_$TAG.json profiles/pmc_counters.json
 # the driver's form first, exactly as the driver runs it (all configurations, all extras, the CPU baseline), then twice without the extras
 for i in 1 2 3; do timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 $([ $i != 1 ] && echo --no-cpu-baseline --no-extras --no-configs) > $O/bench_steps20_$i.json 2>$O/bench_steps20_$i.err; done
