@@ -1254,7 +1254,9 @@ GS_API int gs_sort_begin(gs_ctx *ctx, const float view[4], const float *cutout16
     if (rc != GS_OK) return rc;
     LANE_HIP(B, hipMemcpyAsync(B->ctl_host, B->ctl, sizeof(GsControl), hipMemcpyDeviceToHost, B->stream));
     LANE_HIP(B, hipEventRecord(ctx->ev_sort, B->stream));
-    ctx->pend_lane = back + 1; ctx->pend_n = ctx->n;
+    ctx->pend_lane = back + 1; ctx->pend_n = ctx->n; ctx->pend_gen = B->sort_gen;
+    memcpy(ctx->pend_view, view, sizeof ctx->pend_view); ctx->pend_has_cutout = cutout16 != nullptr;
+    if (cutout16) memcpy(ctx->pend_cutout, cutout16, sizeof ctx->pend_cutout);
     return GS_OK;
 }
 
@@ -1279,11 +1281,12 @@ GS_API int gs_sort_poll(gs_ctx *ctx, int wait, uint32_t *out_idx, uint32_t *out_
         if (e != hipSuccess) { ctx->pend_lane = 0; FAIL(GS_E_HIP, "hipEventQuery failed: %s", hipGetErrorString(e)); }
     } else GS_HIP(hipEventSynchronize(ctx->ev_sort));
     ctx->pend_lane = 0;
-    if (ctx->pend_n != ctx->n || B->n != ctx->n || !B->sorted) {
-        // the resident data changed under the sort (pushes drain every lane and drop the lanes' orders): over what is resident now
+    if (ctx->pend_n != ctx->n || B->n != ctx->n || !B->sorted || B->sort_gen != ctx->pend_gen) {
+        // the resident data changed under the sort (pushes drain every lane and drop the lanes' orders), or another sort has used the lane's
+        // scratch since (gs_sync drawing a flagged frame of this lane again): over what is resident now
         gs_ctx *L = nullptr;
         TRY(get_lane(ctx, back, &L));
-        TRY(lane_rc(ctx, L, gs_run_sort(L, L->sv_view, L->sv_has_cutout ? L->sv_cutout : nullptr, nullptr, 0)));
+        TRY(lane_rc(ctx, L, gs_run_sort(L, ctx->pend_view, ctx->pend_has_cutout ? ctx->pend_cutout : nullptr, nullptr, 0)));
         LANE_HIP(L, hipMemcpyAsync(L->ctl_host, L->ctl, sizeof(GsControl), hipMemcpyDeviceToHost, L->stream));
         LANE_HIP(L, hipStreamSynchronize(L->stream));
         B = L;

@@ -191,6 +191,7 @@ struct gs_ctx {
     uint32_t *sorted;              // alias of the buffer holding the final order
     uint32_t sorted_n_host;        // V as last read back (only when the caller asked for it)
     bool have_sort;
+    uint32_t sort_gen;             // lane: sorts run on this lane's scratch so far (gs_sort_poll: was the posted sort's result overwritten -- a redraw by gs_sync?)
     // near-only sorts (GS_OPT_SORT_NEAR): histograms of the kept depths (GS_DH_COPIES x GS_DEPTH_BINS words; two buffers: a sort fills
     // one and clears the one the previous sort filled), the request the last sort of this lane ran with (0 = whole order) and its arguments
     uint32_t *dhist[2]; int dh_next; uint32_t *dh_dirty;
@@ -288,6 +289,8 @@ struct gs_ctx {
                                    // any push: the reference's [0] reply is owed)
     hipEvent_t ev_sort;            // owner: behind that sort's kernels and the copy of its control block
     size_t pend_n;                 // owner: splats resident when it was begun
+    uint32_t pend_gen;             // owner: the lane's sort_gen right after it was enqueued
+    float pend_view[4], pend_cutout[16]; bool pend_has_cutout;   // owner: its arguments (a re-run does not trust the lane's saved ones)
     gs_stats stats;
 };
 

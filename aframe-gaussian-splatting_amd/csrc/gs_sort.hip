@@ -932,6 +932,7 @@ static uint32_t near_hint(const gs_ctx *L, uint32_t n)
 int gs_run_sort2(gs_ctx *const S[2], const float *const view[2], const float *const cutout16[2], const GsSortStrip *const strip[2], const uint32_t near_req[2])
 {
     gs_ctx *ctx = S[0];
+    S[0]->sort_gen++; S[1]->sort_gen++;
     const uint32_t n = (uint32_t)ctx->n;
     SortUniforms u[2];
     StripUniforms su[2];
@@ -1098,6 +1099,7 @@ static void fill_sort_uniforms(const gs_ctx *ctx, const float view[4], const flo
 
 int gs_run_sort(gs_ctx *ctx, const float view[4], const float *cutout16, const GsSortStrip *strip, uint32_t near_req)
 {
+    ctx->sort_gen++;
     const uint32_t n = (uint32_t)ctx->n;
     SortUniforms u;
     StripUniforms su;
