@@ -484,6 +484,11 @@ def main():
             "value": round(fps, 3), "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
             "ms_per_step": round(elapsed / K * 1e3, 4), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            # what "parity" means wherever a frame of this path is compared (tests/, smoke()): both bounds, always together
+            "parity": {"order": "bit-exact vs the reference worker (index.js:507-570)",
+                       "pixels_vs_fp32_oracle_and_float_buffer_GLSL": "<= 1 LSB (two pixels of sixteen golden frames at 2), fragment counts equal",
+                       "pixels_vs_the_RGBA8_buffer_the_reference_really_draws_into": "3-5 LSB, the oracle and this path alike (unorm8 rounding after every fragment, "
+                                                                                     "index.js:177-181 blending into an 8-bit target)"},
             "config": {"workload": workload, "name": cfg_name, "library_options": opts, "parallelism": par,
                        "multi_gpu_path": path_tried if world > 1 else None,
                        "pieces_of_rank0": [[v, x0, x1] for v, x0, x1 in mine], "gathered_frame_equals_single_gpu_render": frame_check,

@@ -5,6 +5,7 @@ the BASELINE.json configuration sizes.
 Bars: bit-exact for the sort index list, the packed records and the projected records; for pixels
 |RGBA8(HIP) - RGBA8(oracle)| <= 1 LSB (front-to-back fp32 + early termination at T < 1/1024 vs the oracle's
 back-to-front fp32 "over"; identical fragment sets by construction), fragment counts exactly equal."""
+import math
 import os
 
 import numpy as np
@@ -1560,6 +1561,53 @@ def test_sort_for_a_strip_is_a_subsequence_and_draws_the_same_pixels(ctx, scene_
         c.push_splat(rows)
         c.set_option(capi.OPT_NEAR_PERMILLE, 1000)
         check(c, np.ascontiguousarray(mats[:, 12:16]), synth.index_html_camera(w, h, 140.0, capi=capi), [(0, 80), (304, 384)], w, h, 1.0)
+
+
+def _tilted_camera(w, h, pitch_deg, roll_deg, yaw_deg, pos, fov=80.0):
+    """A camera world matrix with pitch and roll (the synth poses only yaw): R_y(yaw) R_x(pitch) R_z(roll) at `pos`, column-major."""
+    cy, sy = math.cos(math.radians(yaw_deg)), math.sin(math.radians(yaw_deg))
+    cx, sx = math.cos(math.radians(pitch_deg)), math.sin(math.radians(pitch_deg))
+    cz, sz = math.cos(math.radians(roll_deg)), math.sin(math.radians(roll_deg))
+    Ry = np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]]); Rx = np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]])
+    Rz = np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]])
+    M = np.eye(4); M[:3, :3] = Ry @ Rx @ Rz; M[:3, 3] = pos
+    return synth.uniforms(M.T.reshape(-1).copy(), synth.compose((0.0, 1.5, -2.0), 10.0), synth.perspective(fov, w / h), w, h, capi=capi)
+
+
+@pytest.mark.parametrize("pitch,roll,yaw,pos", [(35.0, 20.0, 0.0, (0.0, 1.6, 0.0)), (-50.0, -75.0, 160.0, (0.5, 3.0, -4.5)),
+                                                (80.0, 5.0, 0.0, (0.0, -2.0, -2.0)), (0.0, 90.0, 30.0, (3.0, 1.5, 1.0))])
+def test_frustum_sort_with_pitched_and_rolled_cameras(scene_small, pitch, roll, yaw, pos):
+    """gs_sort_for over the whole frame culls in x AND y (round 6): cameras that look up, down and sideways with a roll, where
+    the rows of the model-view matrix the two tests use are nothing like the yaw-only poses'.  The culled order is a subsequence
+    of the reference worker's (index.js:507-570), the frame drawn from it is bit-identical to the frame drawn from the whole
+    order and within 1 LSB of the oracle's with exactly its fragments; strips of the same pose likewise."""
+    w, h = 480, 270
+    cam = _tilted_camera(w, h, pitch, roll, yaw, pos)
+    rows4 = np.ascontiguousarray(scene_small["mats"][:, 12:16])
+    with capi.Context(0) as c:
+        c.push_splat(scene_small["rows"])
+        c.set_option(capi.OPT_NEAR_PERMILLE, 1000)
+        full = c.sort(cam["view"], None)
+        assert np.array_equal(full, oracle.sort(rows4, cam["view"], None))
+        want = c.render(_params(cam))
+        c.render(_params(cam, flags=capi.RENDER_COUNT_FRAGS)); frags_full = c.stats()["n_frags"]
+        mv, P, focal = _f32(cam)
+        ref, _, ref_frags = oracle.render(scene_small["cs"], scene_small["cc"], full, mv, P, focal, w, h, want_f32=False)
+        assert np.abs(want.astype(int) - ref.astype(int)).max() <= PIXEL_TOL_LSB and frags_full == ref_frags
+        pos_of = np.full(int(full.max()) + 1, -1, np.int64); pos_of[full] = np.arange(full.size)
+        kept = []
+        for x0, x1 in ((0, w), (0, 96), (192, 288), (400, w)):
+            sub = c.sort_for(cam["view"], None, _params(cam, x0=x0, x1=x1))
+            q = pos_of[sub]
+            assert np.all(q >= 0) and np.all(np.diff(q) > 0), "not a sub-sequence of the reference order"
+            got = c.render(_params(cam, x0=x0, x1=x1))
+            assert np.array_equal(got, want[:, x0:x1]), (x0, x1)
+            if (x0, x1) == (0, w):
+                c.render(_params(cam, flags=capi.RENDER_COUNT_FRAGS)); assert c.stats()["n_frags"] == ref_frags
+            kept.append(sub.size)
+        assert kept[0] < full.size, "the whole-frame cull dropped nothing at this pose"      # (every pose here leaves splats outside the frustum)
+        assert max(kept[1:]) <= kept[0]
+        print("tilted camera pitch %g roll %g: %d of %d splats kept for the frame, strips %s" % (pitch, roll, kept[0], full.size, kept[1:]))
 
 
 def test_new_entry_points_reject_bad_arguments(ctx, scene_small):
