@@ -444,7 +444,7 @@ static int collect_status(gs_ctx *lane, bool *overflowed, bool *share_failed = n
             } else {
                 ctx->clean_frames += (uint32_t)(frames ? frames : 1);
                 if (!need) {
-                    // no measurement (compact pair records name no positions): the walk of rounds 1-4 -- fast descent (x0.9) until a share
+                    // no measurement (counting renders, the pixel-split blend: no need word recorded): the walk of rounds 1-4 -- fast descent (x0.9) until a share
                     // has proved too small once, then a slow drift (x0.98) above the floor
                     float nf = ctx->near_frac * (ctx->near_floor > 0.0f ? 0.98f : 0.9f);
                     if (nf < ctx->near_floor) nf = ctx->near_floor; if (nf < 0.001f) nf = 0.001f;
@@ -1205,7 +1205,7 @@ static int sort_common(gs_ctx *ctx, const float view[4], const float *cutout16, 
     const uint32_t near_req = (out_idx || out_n) ? 0u : sort_near_request(ctx);     // (the caller wants the order itself: all of it)
     // (a context that has not measured its share yet draws its next frame synchronously -- gs_render_uniforms --: its sort on the caller's
     // thread then, not on an enqueue thread that was created a moment ago and has to be woken first: 0.14 ms of that call's 0.7)
-    // (... at most two sorts in a row: a context whose frames never measure -- counting renders, compact pair records -- keeps its threads)
+    // (... at most two sorts in a row: a context whose frames never measure -- counting renders -- keeps its threads)
     const bool cold = !ctx->share_measured && ctx->near_fixed_permille <= 0 && ctx->cold_sorts < 2u;   // (get_lane has drained the lane: nothing of it is waiting on its thread)
     if (cold) ctx->cold_sorts++; else if (ctx->share_measured) { ctx->cold_sorts = 0; ctx->cold_frames = 0; }
     if (ctx->enqueue_threads && gs_rotates(ctx) && !ctx->user_stream && !out_idx && !out_n && !cold) {
@@ -1530,8 +1530,8 @@ int gs_render_uniforms(gs_ctx *ctx, const GsFrameUniforms &u_in, void *device_rg
     // even when asked to queue it: the frames queued behind it then use the share it measured instead of the 25 % every context starts
     // with (at 20 M splats: 5 M positions in the first round of every frame until the first gs_sync).  The call returns with the frame
     // complete; its status needs no gs_sync.
-    // (... at most two such frames in a row, like the cold sorts: a context whose blends never record a need -- compact pair records, a
-    // -DGS_NO_NEED_RECORD build, every tile saturated by round 0 of a walked share -- would otherwise draw EVERY queued frame synchronously,
+    // (... at most two such frames in a row, like the cold sorts: a context whose blends never record a need -- counting renders, every tile
+    // saturated by round 0 of a walked share -- would otherwise draw EVERY queued frame synchronously,
     // with a drain of every other lane each time: ADVICE r5)
     if (async && !ctx->share_measured && ctx->near_fixed_permille <= 0 && u.near_count != 0xFFFFFFFFu && ctx->n && ctx->cold_frames < 2u) {
         async = false; u.flags &= ~(uint32_t)GS_RENDER_ASYNC;

@@ -203,7 +203,7 @@ struct gs_ctx {
     uint32_t share_kind;           // owner: what kind of order the share was measured on -- 1: whole orders (gs_sort), 2: strips' orders (gs_sort_for);
                                    // 0: nothing yet.  A sort of another kind starts the measurement afresh (positions of a strip's order are not positions of the whole)
     uint32_t cold_frames;          // owner: queued frames drawn synchronously for the same reason (at most two in a row: a context whose frames
-                                   // never measure -- compact pair records, GS_NO_NEED_RECORD builds -- keeps its pipelining)
+                                   // never measure -- counting renders -- keeps its pipelining)
     float sv_view[4], sv_cutout[16]; bool sv_has_cutout, sv_has_strip; GsSortStrip sv_strip;
     int sort_near_opt;             // owner: GS_OPT_SORT_NEAR
     bool near_stash_off;           // owner: a chunk's stash overflowed once: near-only sorts keep to the two whole-length passes
@@ -319,19 +319,6 @@ static inline uint32_t gs_div_up(uint64_t a, uint64_t b) { return (uint32_t)((a 
 // contiguous eighth of the chunks lets those segments merge in one L2.  v = virtual workgroup index (grid a multiple of
 // 8, grid-strided); returns false for the padding slots of the last eighths.
 __device__ __forceinline__ bool gs_xcd_chunk(uint32_t v, uint32_t nchunks, uint32_t &chunk) { return gsm::xcd_chunk(v, nchunks, chunk); }
-
-// Wave priority of the chain kernels.  With several frames in flight the blend of one frame fills every SIMD with waves while
-// the short kernels of the other frames' chains (histograms, scans, scatters, projection, emit: each a link of a DEPENDENT chain)
-// wait for issue slots next to them.  s_setprio lets the SIMD's arbiter pick their instructions first; the blend, the only
-// kernel that is pure throughput, stays at priority 0.  (GS_CHAIN_PRIORITY = 0 builds without it.)
-#ifndef GS_CHAIN_PRIORITY
-#define GS_CHAIN_PRIORITY 0
-#endif
-#if GS_CHAIN_PRIORITY
-#define GS_CHAIN_PRIO() __builtin_amdgcn_s_setprio(GS_CHAIN_PRIORITY)
-#else
-#define GS_CHAIN_PRIO() ((void)0)
-#endif
 
 // ---- two frames per launch (GS_OPT_FRAME_BATCH)
 // A frame of 1 M splats is a chain of 18 short dependent kernels, most of them at the launch floor.  Two frames that take the

@@ -55,7 +55,6 @@ template <bool PACKED, int NW>
 __device__ __forceinline__ void k_radix_hist_body(const uint32_t *__restrict__ keys, const uint32_t *n_ptr, int shift,
                                                   int bits, uint32_t *__restrict__ hist)
 {
-    GS_CHAIN_PRIO();
     constexpr int NT = 64 * NW, IPT = 8, CH = NT * IPT;
     __shared__ uint32_t s_hist[GS_RADIX_MAX_BINS];
     const uint32_t n = *n_ptr;
@@ -99,7 +98,6 @@ template <int NW>
 __device__ __forceinline__ void k_radix_scan_body(uint32_t *__restrict__ hist, const uint32_t *n_ptr, uint32_t chunk, int bits,
                                                   uint32_t *__restrict__ totals)
 {
-    GS_CHAIN_PRIO();
     constexpr int RC = 16;                                          // rows cached in registers
     constexpr uint32_t LANES = 16u * NW;                            // row lanes: 4 quads x LANES threads
     __shared__ uint4 s_part[NW][4];                                 // [wave][quad] totals
@@ -204,7 +202,6 @@ __device__ __forceinline__ void k_radix_scatter_body(const void *__restrict__ in
                                                      const uint32_t *__restrict__ hist_scanned, const uint32_t *__restrict__ totals,
                                                      int idx_bits, uint32_t *count_out, const uint32_t *fill_to)
 {
-    GS_CHAIN_PRIO();
     constexpr int NT = 64 * NW, IPT = 8, CH = NT * IPT;
     constexpr bool KEYONLY = (IN_FMT == GS_RADIX_KEYONLY && OUT_FMT == GS_RADIX_KEYONLY) || IN_FMT == GS_RADIX_KEYIDX;
     __shared__ uint32_t s_cnt[NW][MAXB];                        // per-wave digit counts -> local slot bases
@@ -427,7 +424,6 @@ __device__ __forceinline__ void k_msd_scatter_body(const uint32_t *__restrict__ 
                                                    const uint32_t *__restrict__ rows, const uint32_t *__restrict__ grp, uint32_t *count_out,
                                                    uint32_t *__restrict__ seg_tab, uint32_t tail_req, GsControl *ctl, uint32_t n_host)
 {
-    GS_CHAIN_PRIO();
     constexpr int NT = 64 * NW, IPT = 8, CH = NT * IPT, NB = 256, PB = 24;
     __shared__ uint32_t s_cnt[NW][NB];
     __shared__ unsigned long long s_match[NW][NB];
@@ -647,7 +643,6 @@ __device__ __forceinline__ void seg_sort_block(const uint32_t *__restrict__ blk,
 template <int NW, int IPT>
 __device__ __forceinline__ void k_seg_sort_body(const uint32_t *__restrict__ rec, uint32_t *__restrict__ out, const uint32_t *__restrict__ seg_tab, const uint32_t *fill_to)
 {
-    GS_CHAIN_PRIO();
     constexpr int NT = 64 * NW, B = NT * IPT, NB = 256;
     static_assert(NT >= NB && IPT == 16 && B == (int)GS_SEG_B, "one digit per thread; blocks of 8 / 16 rounds");
     __shared__ uint32_t s_cnt[NW][NB];

@@ -79,7 +79,6 @@ __device__ __forceinline__ void k_project_body(const uint32_t *__restrict__ sort
                                                uint32_t *__restrict__ part_vis, const uint32_t *__restrict__ mask,
                                                float *__restrict__ zwin, GsControl *ctl)
 {
-    GS_CHAIN_PRIO();
     __shared__ float s_rec[GS_BLOCK][6];
     __shared__ uint32_t s_rows[GS_BLOCK], s_j[GS_BLOCK];
     __shared__ uint32_t s_nbig, s_nmid, s_vis, s_sum;
@@ -231,7 +230,6 @@ __device__ __forceinline__ void k_pairs_check_body(GsControl *ctl, uint32_t pair
                                                    int last_round, uint32_t *__restrict__ mask, uint32_t mask_total_words,
                                                    uint2 *__restrict__ extra)
 {
-    GS_CHAIN_PRIO();
     __shared__ uint32_t s_vis, s_wave[4], s_wave_e[4], s_tv[GS_SPINE_CACHED][GS_BLOCK], s_eb[GS_SPINE_CACHED][GS_BLOCK];
     __shared__ unsigned long long s_total64[4];
     if (threadIdx.x == 0) s_vis = 0;
@@ -378,7 +376,6 @@ __device__ __forceinline__ void k_emit_body(const gsm::Projected *__restrict__ p
                                             const uint2 *__restrict__ extra, const GsFrameUniforms &u, uint2 *__restrict__ pairs,
                                             const uint32_t *__restrict__ mask, const GsControl *ctl)
 {
-    GS_CHAIN_PRIO();
     __shared__ float s_rec[GS_BLOCK][6];                            // the slice's splats: projected record,
     __shared__ uint32_t s_sp[GS_BLOCK], s_ty[GS_BLOCK];             // index in the chunk (or among the round's visible splats), first | last tile row,
     __shared__ uint32_t s_rb[GS_BLOCK + 1];                         // exclusive scan of their tile-row counts
@@ -513,7 +510,6 @@ __global__ __launch_bounds__(GS_BLOCK) void k_emit(const gsm::Projected *__restr
 __device__ __forceinline__ void k_tile_ranges_body(const uint2 *__restrict__ p64, uint2 *__restrict__ range,
                                                    uint32_t ntiles, int round, const GsControl *ctl)
 {
-    GS_CHAIN_PRIO();
 #define GS_PAIR_TILE(i) (p64[i].x)
     if (round == 1 && ctl->j_hi == 0) return;                      // nothing left for round 1: its blend returns too
     const uint32_t I = ctl->n_pairs;
@@ -639,7 +635,6 @@ __device__ __forceinline__ void k_row_scan_body(uint32_t *__restrict__ row_cnt, 
                                                 uint32_t near_count, uint32_t rc_stride, uint32_t tiles_y, uint32_t *__restrict__ mask,
                                                 uint32_t mask_words)
 {
-    GS_CHAIN_PRIO();
     __shared__ uint32_t s_w[4];
     __shared__ unsigned long long s_p[4];
     uint32_t j_lo, j_hi;
@@ -680,7 +675,6 @@ __device__ __forceinline__ void k_emit_runs_body(const gsm::Projected *__restric
                                                  uint32_t *__restrict__ run_geom, uint32_t *__restrict__ run_ref,
                                                  const uint32_t *__restrict__ mask, const GsControl *ctl, uint32_t pair_cap)
 {
-    GS_CHAIN_PRIO();
     __shared__ float s_rec[GS_BLOCK][6];
     __shared__ uint32_t s_rows[GS_BLOCK], s_t[GS_BLOCK];            // queued splats: first | last << 16 tile row, thread (= position in the chunk)
     __shared__ unsigned long long s_m[GS_BLOCK][4];                 // per tile row: the chunk's positions with a run there
@@ -787,7 +781,6 @@ template <int ROUND>
 __device__ __forceinline__ void k_seg_count_body(const uint32_t *__restrict__ run_geom, const uint2 *__restrict__ row_tot, int *__restrict__ seg_diff,
                                                  const GsFrameUniforms &u, const GsControl *ctl, uint32_t pair_cap)
 {
-    GS_CHAIN_PRIO();
     __shared__ uint32_t s_rrun[GS_BLOCK + 1], s_rpair[GS_BLOCK + 1], s_item[GS_BLOCK + 1];
     __shared__ int s_d[GS_BLOCK + 1];
     __shared__ unsigned long long s_p[4];
@@ -851,7 +844,6 @@ __device__ __forceinline__ void k_lists_body(const uint32_t *__restrict__ run_ge
                                              const GsFrameUniforms &u, const uint32_t *__restrict__ mask, GsControl *ctl, uint32_t pair_cap,
                                              const uint32_t *__restrict__ part_vis, uint32_t nparts, int last_round)
 {
-    GS_CHAIN_PRIO();
     __shared__ uint32_t s_rrun[GS_BLOCK + 1], s_rpair[GS_BLOCK + 1], s_item[GS_BLOCK + 1];   // prefix sums over the tile rows: runs, tiles, items
     __shared__ unsigned long long s_d[GS_BLOCK + 1];                // difference array over the tile columns: all runs of the row | runs before the segment << 32
     __shared__ __attribute__((aligned(16))) unsigned long long s_m[GS_BLOCK][4];                 // per tile column: the runs of the batch that cover it
@@ -1036,9 +1028,6 @@ __global__ __launch_bounds__(GS_BLOCK) void k_lists(const uint32_t *__restrict__
 #ifndef GS_BLEND_BATCH
 #define GS_BLEND_BATCH 64
 #endif
-#ifndef GS_BLEND_PAD_WORDS
-#define GS_BLEND_PAD_WORDS 0
-#endif
 typedef float f2 __attribute__((ext_vector_type(2)));            // two pixels per packed-fp32 instruction (v_pk_*_f32)
 __device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
 // fma2(a, (f2)(b.x), (f2)(c.x)) / fma2(a, (f2)(b.y), (f2)(c.y)): both halves of the result take the LOW / HIGH words of b and c
@@ -1080,12 +1069,7 @@ __device__ __forceinline__ f2 fma2_hi0(f2 a, f2 b, f2 c)
 #endif
 #define GS_SUBTILE_STRIDE 68u       // bytes per block list: 64 entries + the inert pair behind them, banks 17 g + k / 4 apart
 #define GS_SUBTILE_INERT 64u        // the slot of the record no pixel passes
-#ifndef GS_SUBTILE_BANDS
-#define GS_SUBTILE_BANDS 4          // row bands per tile: 4 (4x4-pixel blocks, sixteen lists) or 2 (4 columns x 8 rows, eight lists)
-#endif
-#ifndef GS_SUBTILE_MASK
-#define GS_SUBTILE_MASK 0           // 0: the ellipse's exact x-interval per band; 1: its bounding box
-#endif
+#define GS_SUBTILE_BANDS 4          // row bands per tile: 4x4-pixel blocks, sixteen lists (eight lists of 4 x 8 pixels: the same frames/s, docs/LAB_NOTES.md)
 #define GS_SUBTILE_GROUPS (4 * GS_SUBTILE_BANDS)
 #define GS_SUBTILE_ROWS (16 / GS_SUBTILE_BANDS)
 __device__ __forceinline__ uint32_t subtile_mask(const float4 ra, const float bx, const float by, const float tile_x0, const int r0, const int H)
@@ -1098,21 +1082,6 @@ __device__ __forceinline__ uint32_t subtile_mask(const float4 ra, const float bx
     const float hh = 2.0f * gsm::fast_sqrt((0.25f * e.D4A) * gsm::fast_rcp(e.D));
     if (!(hh >= 0.0f) || !(e.pad >= 0.0f)) return (1u << GS_SUBTILE_GROUPS) - 1u;   // (no such record leaves k_project; whole tile if one did)
     uint32_t m = 0;
-#if GS_SUBTILE_MASK == 1
-    // bounding box: columns [cx - hw, cx + hw], rows [cy - hh, cy + hh] (GL y up), padded like the binning's intervals
-    const float hw = 2.0f * gsm::fast_sqrt((p.ay * p.ay + p.by * p.by) * gsm::fast_rcp(e.D));   // (as ellipse_rows_setup)
-    const float fi0 = fmaxf(ceilf(p.cx - hw - e.pad - 0.5f), tile_x0), fi1 = fminf(floorf(p.cx + hw + e.pad - 0.5f), tile_x0 + 15.0f);
-    // image row r has GL centre (H - 1 - r) + 0.5: rows r with |(H - 0.5 - r) - cy| <= hh + pad
-    const float fr0 = fmaxf(ceilf(((float)H - 0.5f) - p.cy - hh - e.pad), (float)r0), fr1 = fminf(floorf(((float)H - 0.5f) - p.cy + hh + e.pad), (float)r0 + 15.0f);
-    if (fi0 <= fi1 && fr0 <= fr1) {
-        const uint32_t c0 = (uint32_t)(fi0 - tile_x0) >> 2, c1 = (uint32_t)(fi1 - tile_x0) >> 2;
-        const uint32_t b0 = (uint32_t)(fr0 - (float)r0) / GS_SUBTILE_ROWS, b1 = (uint32_t)(fr1 - (float)r0) / GS_SUBTILE_ROWS;
-        const uint32_t cm = ((2u << c1) - 1u) & ~((1u << c0) - 1u);                   // columns c0 .. c1 of one band
-        const uint32_t rep = GS_SUBTILE_BANDS == 4 ? 0x1111u : 0x11u;                 // ... repeated in bands b0 .. b1
-        const uint32_t bm = ((16u << (4u * b1)) - 1u) & ~((1u << (4u * b0)) - 1u);
-        m = (cm * rep) & bm;
-    }
-#else
 #pragma unroll 1
     for (int b = 0; b < GS_SUBTILE_BANDS; b++) {
         // image rows r0 + ROWS b .. + ROWS - 1 (top-down); GL pixel-centre y of image row r is (H - 1 - r) + 0.5
@@ -1127,7 +1096,6 @@ __device__ __forceinline__ uint32_t subtile_mask(const float4 ra, const float bx
             }
         }
     }
-#endif
     return m;
 }
 
@@ -1146,10 +1114,6 @@ __device__ __forceinline__ void k_blend_body(const uint2 *__restrict__ tile_rang
     __shared__ float4 s_ent[3 * (GS_BLEND_BATCH + 1)];
     __shared__ float s_z[GS_BLEND_BATCH + 2];                    // their window depths (SCENE only)
     __shared__ __attribute__((aligned(16))) uint8_t s_list[SUB ? GS_SUBTILE_GROUPS * GS_SUBTILE_STRIDE : 16];   // GS_OPT_SUBTILE: per 4x4-pixel block, the batch's entries (slots) that can reach it
-#if GS_BLEND_PAD_WORDS
-    __shared__ uint32_t s_pad[GS_BLEND_PAD_WORDS];                 // occupancy cap: see GS_BLEND_PAD_WORDS
-    if (u.W < 0) s_pad[threadIdx.x] = 0u;                           // (never true; keeps the array allocated)
-#endif
     const int lane = threadIdx.x;
     // (a round whose records did not fit bins nothing and this kernel draws the background: the completion word says so)
     if (blockIdx.x == 0 && lane == 0 && u.status && ctl->pair_overflow) atomicOr(u.status, 2u);
@@ -1354,7 +1318,6 @@ __device__ __forceinline__ void k_blend_body(const uint2 *__restrict__ tile_rang
         __syncthreads();                                           // s_ent is rewritten by the next batch
         if (__all(!live)) break;
     }
-#ifndef GS_NO_NEED_RECORD        // (A/B builds: tools/build_variant.sh noneed -DGS_NO_NEED_RECORD)
     if (!COUNT && GS_BLEND_BATCH == 64 && !(u.flags & GS_RENDER_NO_EARLY_OUT)) {
         // how many of the nearest splats this tile needed (GsControl::need_near): the sorted position of the entry at which its LAST
         // lane left the list (lane k staged entry k of the batch: a tile's entries lie ~1000 sorted positions apart, "the batch" would
@@ -1373,7 +1336,6 @@ __device__ __forceinline__ void k_blend_body(const uint2 *__restrict__ tile_rang
             }
         }
     }
-#endif
     if (ROUND == 0 && u.near_count < ctl->n_kept) {               // farther splats exist beyond this round
         // the nearer splats did not saturate this tile: keep the exact per-pixel state for round 1 and flag the tile
         if (__any(live)) {

@@ -167,7 +167,6 @@ __device__ __forceinline__ void k_sort_depth_body(const float4 *__restrict__ row
                                                   unsigned long long *__restrict__ part_max, uint32_t *__restrict__ part_cnt, DepthHist dh,
                                                   uint2 *__restrict__ spec_stash, uint32_t *__restrict__ spec_cnt, const uint32_t *__restrict__ bin_hint, GsControl *ctl)
 {
-    GS_CHAIN_PRIO();
     __shared__ unsigned long long s_min, s_max;
     __shared__ uint32_t s_cnt;
     __shared__ uint32_t s_srow[SPEC ? 4 * GS_DEPTH_IPT : 1];
@@ -259,7 +258,6 @@ __global__ __launch_bounds__(GS_BLOCK) void k_sort_depth_pair(const float4 *__re
                                                               unsigned long long *__restrict__ pmin1, unsigned long long *__restrict__ pmax1, uint32_t *__restrict__ pcnt1,
                                                               DepthHist dh0, DepthHist dh1, SpecArgs sa0, SpecArgs sa1)
 {
-    GS_CHAIN_PRIO();
     __shared__ unsigned long long s_min[2], s_max[2];
     __shared__ uint32_t s_cnt[2];
     __shared__ uint32_t s_srow0[SPEC ? 4 * GS_DEPTH_IPT : 1], s_srow1[SPEC ? 4 * GS_DEPTH_IPT : 1];
@@ -360,7 +358,6 @@ __device__ __forceinline__ void k_sort_bucket_body(const float *__restrict__ dep
                                                    uint32_t *__restrict__ hist, GsControl *ctl, const uint32_t *__restrict__ dhist, uint32_t near_req,
                                                    uint32_t *__restrict__ bin_hint, uint32_t *__restrict__ grp)
 {
-    GS_CHAIN_PRIO();
     static_assert(!NEAR || COMPACT, "near-only sorts use the compact records");
     static_assert(!MSD || COMPACT, "the MSD sort takes compact records");
     constexpr int NT = 64 * NW, IPT = 8, CH = NT * IPT;
@@ -510,7 +507,6 @@ __device__ __forceinline__ void k_near_stash_body(const float *__restrict__ dept
                                                   uint2 *__restrict__ stash, uint32_t *__restrict__ cnt_out, GsControl *ctl,
                                                   const uint32_t *__restrict__ dhist, uint32_t near_req, uint32_t *__restrict__ bin_hint)
 {
-    GS_CHAIN_PRIO();
     constexpr int NT = 64 * NW, IPT = 8, CH = NT * IPT;
     __shared__ unsigned long long s_min, s_max;
     __shared__ uint32_t s_cnt, s_nvalid;
@@ -629,7 +625,6 @@ __device__ __forceinline__ void k_near_stash_body(const float *__restrict__ dept
 __device__ __forceinline__ void k_near_gather_body(const uint2 *__restrict__ stash, const uint32_t *__restrict__ cnt, uint32_t n, uint32_t chunk,
                                                    uint2 *__restrict__ out, GsControl *ctl)
 {
-    GS_CHAIN_PRIO();
     __shared__ uint32_t s_w[4];
     const uint32_t nchunks = (n + chunk - 1) / chunk;
     const uint32_t ngroups = (nchunks + GS_GATHER_CHUNKS - 1) / GS_GATHER_CHUNKS;
@@ -670,7 +665,6 @@ __device__ __forceinline__ void k_near_filter_body(const uint2 *__restrict__ sta
                                                    uint32_t *__restrict__ gcnt, GsControl *ctl, const uint32_t *__restrict__ dhist, uint32_t near_req,
                                                    uint32_t *__restrict__ bin_hint)
 {
-    GS_CHAIN_PRIO();
     __shared__ unsigned long long s_min, s_max;
     __shared__ uint32_t s_cnt, s_T, s_lmin, s_w[4];
     __shared__ int32_t s_bcut;
@@ -797,7 +791,6 @@ __device__ __forceinline__ void k_near_filter_body(const uint2 *__restrict__ sta
 __device__ __forceinline__ void k_near_gather_groups_body(const uint2 *__restrict__ group_out, const uint32_t *__restrict__ gcnt, uint32_t n,
                                                           uint2 *__restrict__ out, GsControl *ctl)
 {
-    GS_CHAIN_PRIO();
     __shared__ uint32_t s_w[4];
     const uint32_t nchunks = (n + GS_DEPTH_IPT * GS_BLOCK - 1) / (GS_DEPTH_IPT * GS_BLOCK);
     const uint32_t ngroups = (nchunks + GS_SPEC_GROUP - 1) / GS_SPEC_GROUP;
