@@ -335,19 +335,25 @@ template <class H, class... T> static inline GsPack<H, T...> gs_pack_make(H h, T
 #define GS_BODY(Name, ...) struct Name { template <class... A> static __device__ __forceinline__ void call(const A &... a) { __VA_ARGS__(a...); } }
 template <class F, class... B> __device__ __forceinline__ void gs_pack_call(const GsPack<> &, const B &... b) { F::call(b...); }
 template <class F, class H, class... T, class... B> __device__ __forceinline__ void gs_pack_call(const GsPack<H, T...> &p, const B &... b) { gs_pack_call<F>(p.t, b..., p.h); }
-template <class F, int NT, class P> __global__ __launch_bounds__(NT) void k_twin(P p0, P p1) { if (blockIdx.y) gs_pack_call<F>(p1); else gs_pack_call<F>(p0); }
+// (the two packs as ONE array argument indexed by blockIdx.y: with `if (blockIdx.y) call(p1); else call(p0);` the compiler loads BOTH packs'
+// words into scalar registers ahead of the branch, and a body with large uniforms -- the depth pass' strip test, the projection -- then
+// parks scalars in lanes of a vector register: v_readlane was 23 % of the vector instructions of the paired depth pass)
+template <class P> struct GsTwinArgs { P p[2]; };
+template <class F, int NT, class P> __global__ __launch_bounds__(NT) void k_twin(GsTwinArgs<P> a) { gs_pack_call<F>(a.p[blockIdx.y]); }
 // launch body F for two frames: gs_twin<F, threads>(grid_x, stream, pack0, pack1)
 template <class F, int NT, class P> static inline void gs_twin(uint32_t grid_x, hipStream_t st, const P &p0, const P &p1)
 {
-    hipLaunchKernelGGL((k_twin<F, NT, P>), dim3(grid_x, 2), dim3(NT), 0, st, p0, p1);
+    GsTwinArgs<P> a; a.p[0] = p0; a.p[1] = p1;
+    hipLaunchKernelGGL((k_twin<F, NT, P>), dim3(grid_x, 2), dim3(NT), 0, st, a);
 }
 // ... with a register budget: MINW = the waves per SIMD the kernel must leave room for (512 / MINW vector registers), for bodies whose
 // unrolled loops the compiler would otherwise give 180-250 registers -- workgroups that then wait for half a SIMD's register file to
 // drain while the other frames' blends hold it
-template <class F, int NT, int MINW, class P> __global__ __launch_bounds__(NT, MINW) void k_twin_w(P p0, P p1) { if (blockIdx.y) gs_pack_call<F>(p1); else gs_pack_call<F>(p0); }
+template <class F, int NT, int MINW, class P> __global__ __launch_bounds__(NT, MINW) void k_twin_w(GsTwinArgs<P> a) { gs_pack_call<F>(a.p[blockIdx.y]); }
 template <class F, int NT, int MINW, class P> static inline void gs_twin_w(uint32_t grid_x, hipStream_t st, const P &p0, const P &p1)
 {
-    hipLaunchKernelGGL((k_twin_w<F, NT, MINW, P>), dim3(grid_x, 2), dim3(NT), 0, st, p0, p1);
+    GsTwinArgs<P> a; a.p[0] = p0; a.p[1] = p1;
+    hipLaunchKernelGGL((k_twin_w<F, NT, MINW, P>), dim3(grid_x, 2), dim3(NT), 0, st, a);
 }
 
 // ---- gs_prims.hip

@@ -250,6 +250,9 @@ __global__ __launch_bounds__(GS_BLOCK) void k_sort_depth(const float4 *__restric
 // matrices, two depth arrays and two sets of partials (20 M @ 4K: 2464 -> 2606 frames/s; no difference at 1 M, where the rows
 // are cache-resident).  Per frame exactly the arithmetic of k_sort_depth.
 struct SpecArgs { uint2 *stash; uint32_t *cnt; const uint32_t *bin_hint; GsControl *ctl; };
+#ifndef GS_DEPTH_PAIR_MIN_N
+#define GS_DEPTH_PAIR_MIN_N (1u << 22)   // paired sorts of fewer splats run k_sort_depth's body twice (gs_run_sort2)
+#endif
 template <bool STRIP, bool SPEC>
 __global__ __launch_bounds__(GS_BLOCK) void k_sort_depth_pair(const float4 *__restrict__ rows, const float *__restrict__ bound_r, uint32_t n,
                                                               SortUniforms u0, SortUniforms u1, StripUniforms su0, StripUniforms su1,
@@ -843,6 +846,7 @@ __global__ __launch_bounds__(GS_BLOCK) void k_near_gather(const uint2 *__restric
 }
 
 template <int NW, bool COMPACT, bool NEAR, bool MSD = false> GS_BODY(F_sort_bucket, k_sort_bucket_body<NW, COMPACT, NEAR, MSD>);
+template <bool STRIP, bool SPEC> GS_BODY(F_sort_depth, k_sort_depth_body<STRIP, SPEC>);
 
 }  // namespace
 
@@ -962,7 +966,20 @@ int gs_run_sort2(gs_ctx *const S[2], const float *const view[2], const float *co
 #define GS_DEPTHP(ST, SP) hipLaunchKernelGGL((k_sort_depth_pair<ST, SP>), dim3(gd), dim3(GS_BLOCK), near ? 2u * GS_DEPTH_BINS * sizeof(uint32_t) : 0u, st, (const float4 *)S[0]->sort_rows, (const float *)S[0]->bound_r, n,  \
                                          u[0], u[1], su[0], su[1], S[0]->depth, S[1]->depth, S[0]->part_min, S[0]->part_max, S[0]->part_cnt,                            \
                                          S[1]->part_min, S[1]->part_max, S[1]->part_cnt, dh[0], dh[1], sa[0], sa[1])
-    if (spec) { if (strips) GS_DEPTHP(true, true); else GS_DEPTHP(false, true); }
+    // ... where one sweep saves memory traffic: inputs the caches do not hold.  Below GS_DEPTH_PAIR_MIN_N splats the rows stay resident
+    // between the two frames' reads, and the one-sweep kernel pays for holding two frames' uniforms (two view rows, two cut-out matrices,
+    // two strips' 31 words each: more than the scalar registers hold -- the compiler parks them in lanes of a vector register, and 39 % of
+    // that kernel's vector instructions at 1 M splats were v_readlane): there the pair is k_sort_depth's body twice, blockIdx.y = the frame
+    if (!near && !spec && n < GS_DEPTH_PAIR_MIN_N) {
+#define GS_DEPTHT(ST) gs_twin<F_sort_depth<ST, false>, GS_BLOCK>(gd, st,                                                                                          \
+        gs_pack_make((const float4 *)S[0]->sort_rows, (const float *)S[0]->bound_r, n, u[0], su[0], S[0]->depth, S[0]->part_min, S[0]->part_max, S[0]->part_cnt, \
+                     dh[0], (uint2 *)nullptr, (uint32_t *)nullptr, (const uint32_t *)bin_hint, S[0]->ctl),                                                        \
+        gs_pack_make((const float4 *)S[1]->sort_rows, (const float *)S[1]->bound_r, n, u[1], su[1], S[1]->depth, S[1]->part_min, S[1]->part_max, S[1]->part_cnt, \
+                     dh[1], (uint2 *)nullptr, (uint32_t *)nullptr, (const uint32_t *)bin_hint, S[1]->ctl))
+        if (strips) GS_DEPTHT(true); else GS_DEPTHT(false);
+#undef GS_DEPTHT
+    }
+    else if (spec) { if (strips) GS_DEPTHP(true, true); else GS_DEPTHP(false, true); }
     else { if (strips) GS_DEPTHP(true, false); else GS_DEPTHP(false, false); }
 #undef GS_DEPTHP
     if (stash) {
