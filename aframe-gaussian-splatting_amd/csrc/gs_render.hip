@@ -1028,6 +1028,9 @@ __global__ __launch_bounds__(GS_BLOCK) void k_lists(const uint32_t *__restrict__
 #ifndef GS_BLEND_BATCH
 #define GS_BLEND_BATCH 64
 #endif
+#ifndef GS_BLEND_FACTOR
+#define GS_BLEND_FACTOR 1           // the coverage test of plain frames' whole-batch walk as a factor (GS_BLEND_APPLY_W)
+#endif
 typedef float f2 __attribute__((ext_vector_type(2)));            // two pixels per packed-fp32 instruction (v_pk_*_f32)
 __device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
 // fma2(a, (f2)(b.x), (f2)(c.x)) / fma2(a, (f2)(b.y), (f2)(c.y)): both halves of the result take the LOW / HIGH words of b and c
@@ -1041,6 +1044,13 @@ __device__ __forceinline__ f2 fma2_hi12(f2 a, f2 b, f2 c)
 {
     f2 r;
     asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,1]" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+// clamp(a * b + c) to [0, 1], both halves (v_pk_fma_f32 ... clamp)
+__device__ __forceinline__ f2 fma2_clamp(f2 a, f2 b, f2 c)
+{
+    f2 r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 clamp" : "=v"(r) : "v"(a), "v"(b), "v"(c));
     return r;
 }
 // fma2((f2)(a.y), b, c): both halves of the result take the HIGH word of a (v_pk_fma_f32 op_sel:[1,0,0])
@@ -1165,6 +1175,8 @@ __device__ __forceinline__ void k_blend_body(const uint2 *__restrict__ tile_rang
     // point of exit depends on the list alone -- not on batching or on the split into rounds); until then every pixel of
     // the lane keeps blending: what a pixel below the threshold still receives is < t_eps in total.
 #define GS_LANE_LIVE() (fmaxf(fmaxf(TA.x, TA.y), fmaxf(TB.x, TB.y)) >= t_eps)
+    f2 kbig = { 1.0e30f, 1.0e30f }, kone = { 1.0f, 1.0f };         // (GS_BLEND_APPLY_W; the empty asm keeps them in registers: as literals the
+    asm volatile("" : "+v"(kbig), "+v"(kone));                     // compiler builds each pair again in front of every use, 2 moves per entry)
     bool live = GS_LANE_LIVE();
     uint32_t nfr = 0, staged = 0, evaluated = 0;
     const uint2 range = tile_range[tile];
@@ -1270,6 +1282,29 @@ __device__ __forceinline__ void k_blend_body(const uint2 *__restrict__ tile_rang
                         live = GS_LANE_LIVE();                                                                         \
                     }                                                                                                  \
                 }
+        // The same step with the coverage test as a FACTOR instead of four compares and four selects (plain frames, both walks: no
+        // fragment count, no scene depth): w = clamp((qm - q) * 1e30 + 1) is exactly 1 where q <= qm and exactly 0 where q > qm (two
+        // floats that differ differ by 2^-22 at least near 4: times 1e30 that is +-2e23), and exp(A) * w is exp(A) or +0 -- the values the
+        // selects produce, so T and the colours see the same operations.  What goes is the skip of a step no lane's pixel passes
+        // (rare: lane utilisation 0.85 at the headline pose, and a step of the block lists serves sixteen blocks with sixteen entries), 2 of
+        // the 39 vector instructions per entry.
+#define GS_BLEND_APPLY_W(qA, qB, EB)                                                                                   \
+                if (live) {                                                                                            \
+                    const float2 cl_ = *reinterpret_cast<const float2 *>((EB) + 32);                                   \
+                    const float2 ch_ = *reinterpret_cast<const float2 *>((EB) + 40);                                   \
+                    const float nalpha = cl_.x;                                                                        \
+                    const f2 wA = fma2_clamp(qmA - qA, kbig, kone), wB = fma2_clamp(qmB - qB, kbig, kone);             \
+                    const f2 tA = qA * (f2)(-1.44269502f), tB = qB * (f2)(-1.44269502f);                                \
+                    const f2 EA = { __builtin_amdgcn_exp2f(tA.x), __builtin_amdgcn_exp2f(tA.y) };                      \
+                    const f2 EB_ = { __builtin_amdgcn_exp2f(tB.x), __builtin_amdgcn_exp2f(tB.y) };                     \
+                    const f2 eA = (EA * wA) * TA, eB = (EB_ * wB) * TB;                                                \
+                    TA = fma2((f2)(nalpha), eA, TA); TB = fma2((f2)(nalpha), eB, TB);                                  \
+                    crA = fma2((f2)(cl_.y), eA, crA); crB = fma2((f2)(cl_.y), eB, crB);                                \
+                    cgA = fma2((f2)(ch_.x), eA, cgA); cgB = fma2((f2)(ch_.x), eB, cgB);                                \
+                    const f2 chv_ = { ch_.x, ch_.y };                                                                  \
+                    cbA = fma2_hi0(chv_, eA, cbA); cbB = fma2_hi0(chv_, eB, cbB);                                      \
+                    live = GS_LANE_LIVE();                                                                             \
+                }
         if (SUB && live && split) {
             // this lane's block list, two entries per step like the whole walk below (their coverage tests overlap); a lane whose
             // list is shorter than the longest one finishes on the inert record
@@ -1281,9 +1316,14 @@ __device__ __forceinline__ void k_blend_body(const uint2 *__restrict__ tile_rang
                 const char *eb0 = reinterpret_cast<const char *>(s_ent) + i0 * 48u, *eb1 = reinterpret_cast<const char *>(s_ent) + i1 * 48u;
                 GS_BLEND_Q(0, eb0, qA0, qB0)
                 GS_BLEND_Q(1, eb1, qA1, qB1)
+                if (GS_BLEND_FACTOR && !COUNT && !SCENE) {
+                    GS_BLEND_APPLY_W(qA0, qB0, eb0)
+                    GS_BLEND_APPLY_W(qA1, qB1, eb1)
+                } else {
                 const float z0 = SCENE ? s_z[i0] : 0.0f, z1 = SCENE ? s_z[i1] : 0.0f;
                 GS_BLEND_APPLY(qA0, qB0, eb0, z0)
                 GS_BLEND_APPLY(qA1, qB1, eb1, z1)
+                }
                 if (!live) { i_last = min(i1 < GS_SUBTILE_INERT ? i1 : (i0 < GS_SUBTILE_INERT ? i0 : 0u), nb - 1u); break; }
             }
             e_l = i_last;                                            // (the entry at which the lane left the list, or the batch's last)
@@ -1304,14 +1344,20 @@ __device__ __forceinline__ void k_blend_body(const uint2 *__restrict__ tile_rang
                 GS_BLEND_Q(1, eb + 48, qA1, qB1)                      // slot nb holds an inert record when nb is odd
                 const uint32_t s = SCENE ? vo / 48u : 0u;               // (the entry's index: only the scene's depth test needs it)
                 const float z0 = SCENE ? s_z[s] : 0.0f;
+                if (GS_BLEND_FACTOR && !COUNT && !SCENE) {
+                    GS_BLEND_APPLY_W(qA0, qB0, eb)
+                    GS_BLEND_APPLY_W(qA1, qB1, eb + 48)
+                } else {
                 GS_BLEND_APPLY(qA0, qB0, eb, z0)
                 const float z1 = SCENE ? s_z[s + 1] : 0.0f;
                 GS_BLEND_APPLY(qA1, qB1, eb + 48, z1)
+                }
                 if (!live) break;
             }
             e_l = min(vo / 48u + 1u, nb - 1u);                        // (the step in which the lane left the list, or the batch's last entry)
             if (u.record_staged == 2) evaluated += min(vo / 48u + 2u, nb);   // list entries this lane evaluated (measurement aid)
         }
+#undef GS_BLEND_APPLY_W
 #undef GS_BLEND_APPLY
 #undef GS_BLEND_Q
         end -= nb;
