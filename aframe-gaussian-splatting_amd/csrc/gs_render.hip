@@ -1371,9 +1371,22 @@ __device__ __forceinline__ void k_blend_body(const uint2 *__restrict__ tile_rang
         const bool sat = !__any(live);
         const bool more = ROUND == 0 && u.near_count < ctl->n_kept;  // (not saturated, farther splats to come: round 1 speaks for the tile, or the frame is flagged)
         if (sat || !more) {
+            // the wave's maximum by data-parallel-primitive moves (no LDS round trips: as six ds_bpermute steps, each waiting for the one
+            // before, it was 39 vector instructions and ~700 cycles at the end of every tile): within quads, within rows of 16, then row 0 -> 1,
+            // 2 -> 3 and rows 0-1 -> 2-3; lane 63 holds the maximum
             uint32_t e_max = e_l;
-#pragma unroll
-            for (int m = 32; m >= 1; m >>= 1) e_max = max(e_max, (uint32_t)__shfl_xor((int)e_max, m, 64));
+            e_max = max(e_max, (uint32_t)__builtin_amdgcn_update_dpp((int)e_max, (int)e_max, 0xB1, 0xF, 0xF, false));    // quad_perm:[1,0,3,2]
+            e_max = max(e_max, (uint32_t)__builtin_amdgcn_update_dpp((int)e_max, (int)e_max, 0x4E, 0xF, 0xF, false));    // quad_perm:[2,3,0,1]
+            e_max = max(e_max, (uint32_t)__builtin_amdgcn_update_dpp((int)e_max, (int)e_max, 0x141, 0xF, 0xF, false));   // row_half_mirror
+            e_max = max(e_max, (uint32_t)__builtin_amdgcn_update_dpp((int)e_max, (int)e_max, 0x140, 0xF, 0xF, false));   // row_mirror
+            e_max = max(e_max, (uint32_t)__builtin_amdgcn_update_dpp((int)e_max, (int)e_max, 0x142, 0xA, 0xF, false));   // row_bcast:15 -> rows 1, 3
+            e_max = max(e_max, (uint32_t)__builtin_amdgcn_update_dpp((int)e_max, (int)e_max, 0x143, 0xC, 0xF, false));   // row_bcast:31 -> rows 2, 3
+            e_max = (uint32_t)__builtin_amdgcn_readlane((int)e_max, 63);
+#ifdef GS_DEBUG_DPP_MAX
+            { uint32_t chk = e_l;
+              for (int m = 32; m >= 1; m >>= 1) chk = max(chk, (uint32_t)__shfl_xor((int)chk, m, 64));
+              if (chk != e_max) __builtin_trap(); }
+#endif
             const uint32_t jf = nb_last ? (uint32_t)__shfl((int)j_mine, (int)e_max, 64) : 0xFFFFFFFFu;
             if (lane == 0) {
                 const uint32_t V = ctl->n_kept;
