@@ -1610,6 +1610,29 @@ def test_frustum_sort_with_pitched_and_rolled_cameras(scene_small, pitch, roll, 
         print("tilted camera pitch %g roll %g: %d of %d splats kept for the frame, strips %s" % (pitch, roll, kept[0], full.size, kept[1:]))
 
 
+def test_coverage_as_a_factor_draws_what_the_compares_and_selects_draw(scene_small):
+    """Plain frames apply the discard test `A < -4` (index.js:172) as a factor on exp(A) -- clamp((4 - q) * 1e30 + 1), exactly 0 or 1 --
+    where counting frames keep the four compares and selects (they need the predicates).  Same pixels, bit for bit: a counting render
+    (which runs without early termination) against a plain render without early termination, whole-tile walk and block lists, several
+    poses incl. fat splats whose boundaries cross many pixel centres."""
+    w, h = 640, 360
+    rows = scene_small["rows"].reshape(-1, 32)
+    fat = rows.copy(); fat[:, 12:24] = (fat[:, 12:24].copy().view("<f4") * np.float32(5.0)).view(np.uint8)
+    for data, poses in ((rows, ((synth.index_html_camera, 0.0), (synth.index_html_camera, 140.0), (synth.outside_cloud_camera, 30.0))),
+                        (fat, ((synth.index_html_camera, 75.0), (synth.outside_cloud_camera, 200.0)))):
+        with capi.Context(0) as c:
+            c.push_splat(data)
+            for sub in (0, 2):
+                c.set_option(capi.OPT_SUBTILE, sub)
+                for make, yaw in poses:
+                    cam = make(w, h, yaw, capi=capi)
+                    c.sort(cam["view"], None, want_indices=False)
+                    plain = c.render(_params(cam, flags=capi.RENDER_NO_EARLY_OUT))
+                    counted = c.render(_params(cam, flags=capi.RENDER_COUNT_FRAGS))
+                    assert c.stats()["n_frags"] > 100000
+                    assert np.array_equal(plain, counted), (sub, make.__name__, yaw, int(np.abs(plain.astype(int) - counted.astype(int)).max()))
+
+
 def test_new_entry_points_reject_bad_arguments(ctx, scene_small):
     """Error behaviour of the round-2 entry points: negative status + a message, nothing rendered, the context stays usable."""
     cam = synth.index_html_camera(320, 180, 0.0, capi=capi)
