@@ -27,6 +27,39 @@
 
 namespace {
 
+// Sums by data-parallel-primitive moves instead of __shfl_xor steps (each of those a ds_bpermute round trip plus its address arithmetic:
+// ~5 vector instructions where these take one or two).  row16_sum: every lane gets the sum over its row of 16 lanes (quads, then the two
+// mirrors); wave_sum: the wave's sum (rows 0 -> 1 and 2 -> 3, then rows 0-1 -> 2-3: lane 63 holds it).
+#define GS_DPP_ADD(V, CTRL, ROWS) (V) += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(V), (CTRL), (ROWS), 0xF, false)
+__device__ __forceinline__ uint32_t row16_sum(uint32_t v)
+{
+#ifdef GS_DEBUG_DPP_MAX
+    const uint32_t v0_ = v;
+#endif
+    GS_DPP_ADD(v, 0xB1, 0xF);      // quad_perm:[1,0,3,2]
+    GS_DPP_ADD(v, 0x4E, 0xF);      // quad_perm:[2,3,0,1]
+    GS_DPP_ADD(v, 0x141, 0xF);     // row_half_mirror
+    GS_DPP_ADD(v, 0x140, 0xF);     // row_mirror
+#ifdef GS_DEBUG_DPP_MAX
+    { uint32_t c = v0_; for (int m = 8; m >= 1; m >>= 1) c += __shfl_xor(c, m, 16); if (c != v) __builtin_trap(); }
+#endif
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v)
+{
+#ifdef GS_DEBUG_DPP_MAX
+    uint32_t c_ = v; for (int m = 32; m >= 1; m >>= 1) c_ += __shfl_xor(c_, m, 64);
+#endif
+    v = row16_sum(v);
+    GS_DPP_ADD(v, 0x142, 0xA);     // row_bcast:15 -> rows 1, 3
+    GS_DPP_ADD(v, 0x143, 0xC);     // row_bcast:31 -> rows 2, 3
+    v = (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+#ifdef GS_DEBUG_DPP_MAX
+    if (c_ != v) __builtin_trap();
+#endif
+    return v;
+}
+
 __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v, int lane)
 {
 #pragma unroll
@@ -171,8 +204,7 @@ __device__ __forceinline__ void k_project_body(const uint32_t *__restrict__ sort
                     if (RUNS && n) atomicAdd(&s_rc[ty], 1u | (n << 9));
                 }
             }
-#pragma unroll
-            for (int m = 8; m >= 1; m >>= 1) n += __shfl_xor(n, m, 16);
+            n = row16_sum(n);
             if ((lane & 15) == 0 && mi < nmid) {
                 tile_count[s_j[mi]] = n; sum += n; if (n) vis++;
             }
@@ -193,12 +225,10 @@ __device__ __forceinline__ void k_project_body(const uint32_t *__restrict__ sort
                 if (RUNS && n) atomicAdd(&s_rc[ty], 1u | (n << 9));
                 rsum += n;
             }
-#pragma unroll
-            for (int m = 32; m >= 1; m >>= 1) rsum += __shfl_xor(rsum, m, 64);
+            rsum = wave_sum(rsum);
             if (lane == 0) { tile_count[s_j[bi]] = rsum; sum += rsum; if (rsum) vis++; }
         }
-#pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) { vis += __shfl_xor(vis, m, 64); sum += __shfl_xor(sum, m, 64); }
+        vis = wave_sum(vis); sum = wave_sum(sum);
         if (lane == 0) { if (vis) atomicAdd(&s_vis, vis); if (sum) atomicAdd(&s_sum, sum); }
         __syncthreads();
         if (RUNS) { if (threadIdx.x < (uint32_t)u.tiles_y) row_cnt[(size_t)threadIdx.x * u.rc_stride + c] = s_rc[threadIdx.x]; }
